@@ -1,0 +1,188 @@
+/*
+ * mdgrad_hip.h -- C ABI of libmdgrad_hip.so: the MI355X (gfx950) hot path of the
+ * differentiable-MD inner loop (force evaluation + integrator + adjoint + RDF + SchNet
+ * message passing), hand-written HIP.  This header is the drop-in boundary: plain
+ * pointers and sizes, no torch types.  All pointers are DEVICE pointers (HIP, fp32 /
+ * int32 unless stated) except where marked `host`; `stream` is a hipStream_t passed as
+ * void*.  Every entry point enqueues on `stream` and returns without synchronising;
+ * the return value is 0 on success or a negative MDG_E* code (mdg_last_error() gives
+ * the message).  Functions are stateless and re-entrant.
+ *
+ * The reference (torchmd/mdgrad, pure Python on PyTorch) has no FFI; each entry point
+ * below names the reference op chain (file:line under /root/reference) it replaces.
+ * INTEGRATION.md shows the ctypes binding the reference-side maintainer would add.
+ */
+#ifndef MDGRAD_HIP_H
+#define MDGRAD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDG_OK            0
+#define MDG_EINVAL       -1   /* bad argument (size / null / unsupported combination) */
+#define MDG_ELAUNCH      -2   /* HIP launch error                                     */
+#define MDG_ECAPACITY    -3   /* (reported through device flags, see nbr builders)    */
+
+#define MDG_MAX_TERMS     4
+#define MDG_MAX_THETA     3   /* per term */
+#define MDG_MAX_CHAINS    16
+
+/* pair functional forms -- torchmd/potentials.py */
+#define MDG_PAIR_LJ       0   /* 4 eps[(s/r)^p - c (s/r)^q]; theta=(sigma,eps). LennardJones :317-327,
+                                 LJFamily :61-73, LennardJones69 :329-339, ExcludedVolume :341-352 (c=0) */
+#define MDG_PAIR_MORSE    1   /* ModifiedMorse :75-93; constants a, phi; no parameters */
+#define MDG_PAIR_BUCK     2   /* Buck :354-365; theta=(A,B,C) */
+#define MDG_PAIR_YUKAWA   3   /* eps exp(-kappa r)/r; theta=(eps,kappa); NOT in the reference */
+
+typedef struct MdgPairTerm {
+    int32_t kind;          /* MDG_PAIR_*                                                    */
+    int32_t p, q;          /* LJ-family integer powers (q ignored when c == 0)              */
+    float   c;             /* LJ-family attractive coefficient (1 = LJ, 0 = ExcludedVolume) */
+    float   a, phi;        /* ModifiedMorse constants                                       */
+    float   cutoff;        /* pair kept iff 0 < d^2 < cutoff^2 (topology.py:67)             */
+    int32_t theta_off;     /* first parameter of this term inside theta[]                   */
+    int32_t n_theta;
+    int32_t reserved;
+    const uint8_t* mask;   /* optional [N,N] 0/1 selection (index_tuple / ex_pairs,
+                              topology.py:15-27,37-53); NULL = all pairs                    */
+} MdgPairTerm;
+
+typedef struct MdgTerms {
+    int32_t n_terms;
+    int32_t n_theta_total;
+    MdgPairTerm t[MDG_MAX_TERMS];
+} MdgTerms;
+
+/* periodic cell: row vectors h[3][3] and its inverse (host side computes the inverse the
+ * way the reference does, `cell.inverse()`, topology.py:59) */
+typedef struct MdgCell {
+    float h[9];
+    float inv[9];
+    int32_t diag;          /* 1 when h is diagonal (fast path) */
+} MdgCell;
+
+const char* mdg_last_error(void);
+int mdg_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  neighbour list   (replaces generate_nbr_list, torchmd/topology.py:30-73)
+ *
+ * Output is a padded per-atom ("ELL") FULL list sorted by neighbour index: row i holds
+ * cnt[i] <= max_nbr entries col[i*max_nbr + k] (ascending j, both directions present)
+ * and shift[...] = (ox+1) + 3(oy+1) + 9(oz+1), the image flags of the reference's
+ * `offsets` for the ordered pair (i,j) (d = x_i - x_j - o.cell).  The reference's
+ * half list `nbr_list[P,2]` (i<j, lexicographic) and `offsets[P,3]` are the entries with
+ * j > i in row order -- see mdg_nbr_half_from_ell.  *overflow is set to max over rows of
+ * the needed count when some row needs more than max_nbr entries (caller re-allocates).
+ *
+ * mdg_nbr_build_dense: all-pairs minimum image, any (triclinic) cell, O(N^2).
+ * mdg_nbr_build_cell : cell list (bin -> sort -> 27-stencil), orthorhombic cells with
+ *                      at least 3 bins per side; identical output.
+ * `scratch` for the cell build: int32[ 2*N + 2*ncell_max + 8 ] (see mdg_nbr_cell_scratch).
+ */
+int mdg_nbr_build_dense(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
+                        float cutoff, const uint8_t* mask,
+                        int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
+                        int32_t* overflow, void* stream);
+int64_t mdg_nbr_cell_scratch(int n_atoms, const MdgCell* cell /*host*/, float cutoff);
+int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
+                       float cutoff, const uint8_t* mask,
+                       int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
+                       int32_t* overflow, int32_t* scratch, void* stream);
+/* half list in the reference's order: row_base = exclusive scan of per-row (j>i) counts.
+ * nbr int64[P,2], offsets f32[P,3]; P must be the value returned in *n_pairs by
+ * mdg_nbr_half_count (device int32).  edge_id (optional, int32[N*max_nbr]) receives for
+ * every ELL slot the index of its undirected pair in the half list. */
+int mdg_nbr_half_count(const int32_t* col, const int32_t* cnt, int n_atoms, int max_nbr,
+                       int32_t* row_base /*[N+1]*/, void* stream);
+int mdg_nbr_half_fill(const int32_t* col, const int32_t* shift, const int32_t* cnt,
+                      const int32_t* row_base, int n_atoms, int max_nbr,
+                      int64_t* nbr, float* offsets, int32_t* edge_id, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2-K4  pair energy / gradient / Hessian-vector product over an ELL list
+ * (replaces compute_dis + pair form + .sum() and both autograd passes through them:
+ *  torchmd/topology.py:5-12, torchmd/interface.py:298-299, torchmd/md.py:227-228,
+ *  torchmd/sovlers.py:229-233)
+ *
+ *   energy[0]      = sum_pairs phi(r)                    (if energy != NULL)
+ *   grad[N,3]      = dU/dx                               (if grad   != NULL)  (F = -grad)
+ *   gtheta[K]      = dU/dtheta                           (if gtheta != NULL, with grad)
+ *   hw[N,3]        = H w                                 (if w != NULL)
+ *   gtheta_w[K]    = d(w . dU/dx)/dtheta                 (if w != NULL)
+ * One term per call (each term owns its list).  partial: f32 scratch of
+ * mdg_pair_partial_size(n_atoms) floats.  Deterministic (no float atomics).
+ */
+int64_t mdg_pair_partial_size(int n_atoms);
+int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
+                      const int32_t* col, const int32_t* shift, const int32_t* cnt, int max_nbr,
+                      const MdgPairTerm* term /*host*/, const float* theta,
+                      const float* w,
+                      float* energy, float* grad, float* gtheta,
+                      float* hw, float* gtheta_w,
+                      float* partial, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5-K7  fused trajectories for small systems (one workgroup per replica, state in LDS,
+ * all-pairs minimum image re-evaluated at every force call = the reference's
+ * topology_update_freq=1 semantics).
+ *
+ * forward  (replaces odeint(NH_verlet|verlet): torchmd/sovlers.py:106-127 / 21-40,
+ *           torchmd/tinydiffeq.py:56-76, RHS torchmd/md.py:210-240 / 133-150)
+ *   ensemble: 0 = NoseHooverChain, 1 = NVE (dv/dt = F, no 1/m: md.py:145-148)
+ *   v0,q0 [R,N,3], pv0 [R,C]; t [T] time grid (dt_k = t[k+1]-t[k] in fp32 like the
+ *   reference); outputs v_t,q_t [R,T,N,3], pv_t [R,T,C] (frame 0 = inputs).
+ *   The force at q_k is evaluated once and reused by the next step (bit-compatible with
+ *   the reference's two calls).
+ * adjoint  (replaces OdeintAdjointMethod.backward: torchmd/sovlers.py:211-293 with the
+ *           backward branches :129-164 / :42-101)
+ *   g_* are dL/d(frames) (any may be NULL = zeros); outputs adj_v0,adj_q0 [R,N,3],
+ *   adj_pv0 [R,C], adj_theta [R,K] (sum over R on the caller's side).
+ * nonfinite (optional int32[R]): set to 1 for replicas whose state became non-finite.
+ */
+typedef struct MdgTrajParams {
+    int32_t n_rep, n_atoms, n_frames, n_chains;
+    int32_t ensemble;
+    int32_t block;                 /* 0 = choose */
+    float   T;                     /* NHC target temperature (energy units) */
+    float   n_dof;                 /* N * dim  (md.py:187) */
+    float   Q[MDG_MAX_CHAINS];     /* md.py:191-193 */
+} MdgTrajParams;
+
+int mdg_traj_fwd_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                       const MdgTerms* terms /*host*/, const float* theta,
+                       const float* mass, const float* t_grid,
+                       const float* v0, const float* q0, const float* pv0,
+                       float* v_t, float* q_t, float* pv_t, int32_t* nonfinite, void* stream);
+int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                       const MdgTerms* terms /*host*/, const float* theta,
+                       const float* mass, const float* t_grid,
+                       const float* v_t, const float* q_t, const float* pv_t,
+                       const float* g_v, const float* g_q, const float* g_pv,
+                       float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K8  soft-histogram RDF  (replaces rdf.forward and its autograd backward:
+ *     torchmd/observable.py:62-76 with GaussianSmearing nff/nn/layers.py:14-31)
+ *   xyz [F,N,3]; pairs i<j with 0 < d < cutoff (min image) over all frames;
+ *   raw[k] = sum exp(coeff (d - mu_k)^2), mu_k = mu0 + k*dmu, k < nbins.
+ *   fwd writes raw[nbins] (normalisation / volume factors are cheap host-side torch ops).
+ *   bwd: given g_raw[nbins] = dL/draw, writes g_xyz [F,N,3].
+ *   partial: f32 scratch of mdg_rdf_partial_size(...) floats.
+ */
+int64_t mdg_rdf_partial_size(int n_frames, int n_atoms, int nbins);
+int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
+                float cutoff, const uint8_t* mask, const float* mu /*[nbins]*/, float coeff,
+                int nbins, float* raw, float* partial, void* stream);
+int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
+                float cutoff, const uint8_t* mask, const float* mu, float coeff, int nbins,
+                const float* g_raw, float* g_xyz, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDGRAD_HIP_H */

@@ -1,0 +1,61 @@
+"""Builds libmdgrad_hip.so in-tree with hipcc for gfx950 (no CMake, no torch extension
+machinery: the library has a plain C ABI and does not link against torch)."""
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libmdgrad_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(src, dst, deps):
+    if not os.path.exists(dst):
+        return True
+    m = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > m for p in [src] + deps)
+
+
+def _compile(src):
+    obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
+    deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    if _newer(src, obj, deps):
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+        return obj, True, r.stderr
+    return obj, False, ""
+
+
+def build_library(verbose=True):
+    os.makedirs(OBJDIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    if not srcs:
+        raise RuntimeError("no HIP sources under %s" % CSRC)
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        res = list(ex.map(_compile, srcs))
+    objs = [o for o, _, _ in res]
+    rebuilt = any(c for _, c, _ in res)
+    if verbose:
+        for (o, c, err) in res:
+            if c and err.strip():
+                print(err, file=sys.stderr)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("libmdgrad_hip.so: %s (%d sources, %s)" % (LIB, len(srcs), "rebuilt" if rebuilt else "up to date"))
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library()

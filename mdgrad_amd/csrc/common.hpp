@@ -1,0 +1,206 @@
+// Shared device code for libmdgrad_hip (gfx950 / CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mdgrad_hip.h"
+
+#define MDG_WAVE 64
+
+void mdg_set_error(const char* fmt, ...);
+
+#define MDG_CHECK_ARG(cond, ...)                                                       \
+    do { if (!(cond)) { mdg_set_error(__VA_ARGS__); return MDG_EINVAL; } } while (0)
+
+#define MDG_CHECK_LAUNCH(name)                                                         \
+    do { hipError_t e_ = hipGetLastError();                                            \
+         if (e_ != hipSuccess) { mdg_set_error("%s: %s", name, hipGetErrorString(e_)); \
+                                 return MDG_ELAUNCH; } } while (0)
+
+// ----------------------------------------------------------------------------- cell
+// Minimum image exactly as topology.py:59-64: s = D . inv ; o = -(s > .5) + (s < -.5) ;
+// D += o . h   (D = x_j - x_i).  Returns the packed image code (ox+1)+3(oy+1)+9(oz+1).
+template <bool DIAG>
+__device__ __forceinline__ int min_image(const MdgCell& c, float& dx, float& dy, float& dz) {
+    float sx, sy, sz;
+    if (DIAG) {
+        sx = dx * c.inv[0]; sy = dy * c.inv[4]; sz = dz * c.inv[8];
+    } else {
+        sx = fmaf(dz, c.inv[6], fmaf(dy, c.inv[3], dx * c.inv[0]));
+        sy = fmaf(dz, c.inv[7], fmaf(dy, c.inv[4], dx * c.inv[1]));
+        sz = fmaf(dz, c.inv[8], fmaf(dy, c.inv[5], dx * c.inv[2]));
+    }
+    const float ox = (sx < -0.5f ? 1.f : 0.f) - (sx > 0.5f ? 1.f : 0.f);
+    const float oy = (sy < -0.5f ? 1.f : 0.f) - (sy > 0.5f ? 1.f : 0.f);
+    const float oz = (sz < -0.5f ? 1.f : 0.f) - (sz > 0.5f ? 1.f : 0.f);
+    if (DIAG) {
+        dx = fmaf(ox, c.h[0], dx); dy = fmaf(oy, c.h[4], dy); dz = fmaf(oz, c.h[8], dz);
+    } else {
+        dx += fmaf(oz, c.h[6], fmaf(oy, c.h[3], ox * c.h[0]));
+        dy += fmaf(oz, c.h[7], fmaf(oy, c.h[4], ox * c.h[1]));
+        dz += fmaf(oz, c.h[8], fmaf(oy, c.h[5], ox * c.h[2]));
+    }
+    return (int)(ox + 1.f) + 3 * (int)(oy + 1.f) + 9 * (int)(oz + 1.f);
+}
+
+// d = x_i - x_j - o.h for a stored image code (compute_dis, topology.py:9-10)
+__device__ __forceinline__ void apply_shift(const MdgCell& c, int code, float& dx, float& dy,
+                                            float& dz) {
+    const float ox = (float)(code % 3 - 1), oy = (float)((code / 3) % 3 - 1),
+                oz = (float)(code / 9 - 1);
+    dx -= fmaf(oz, c.h[6], fmaf(oy, c.h[3], ox * c.h[0]));
+    dy -= fmaf(oz, c.h[7], fmaf(oy, c.h[4], ox * c.h[1]));
+    dz -= fmaf(oz, c.h[8], fmaf(oy, c.h[5], ox * c.h[2]));
+}
+
+// squared norm with the reference's association ((x^2 + y^2) + z^2), un-contracted, so the
+// cutoff test selects the same pairs as torch's pow(2).sum(-1)
+__device__ __forceinline__ float norm2_ref(float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
+// ----------------------------------------------------------------------------- pair forms
+__device__ __forceinline__ float ipow(float x, int n) {
+    float r = 1.f;
+    while (n > 0) { if (n & 1) r *= x; x *= x; n >>= 1; }
+    return r;
+}
+
+// LEVEL 0: u            1: + du, du_dtheta           2: + d2u, ddu_dtheta
+struct PairOut {
+    float u, du, d2u;
+    float du_dth[MDG_MAX_THETA];
+    float ddu_dth[MDG_MAX_THETA];
+};
+
+// KIND >= 0 fixes the functional form at compile time (single-term specialisations);
+// KIND < 0 dispatches on t.kind at run time.
+template <int LEVEL, int KIND = -1>
+__device__ __forceinline__ void pair_eval(const MdgPairTerm& t, const float* __restrict__ th,
+                                          float r, PairOut& o) {
+    const float ir = 1.0f / r;
+    switch (KIND >= 0 ? KIND : t.kind) {
+    case MDG_PAIR_LJ: {
+        const float sig = th[0], eps = th[1];
+        const float s = sig * ir;
+        float sp, sq;
+        if (t.p == 12 && t.q == 6) { const float s2 = s * s; sq = s2 * s2 * s2; sp = sq * sq; }
+        else { sp = ipow(s, t.p); sq = ipow(s, t.q); }
+        sq *= t.c;
+        const float fp = (float)t.p, fq = (float)t.q;
+        o.u = 4.f * eps * (sp - sq);
+        if (LEVEL >= 1) {
+            const float m1 = -fp * sp + fq * sq;
+            o.du = 4.f * eps * m1 * ir;
+            o.du_dth[0] = 4.f * eps * (-m1) / sig;
+            o.du_dth[1] = 4.f * (sp - sq);
+            if (LEVEL >= 2) {
+                o.d2u = 4.f * eps * (fp * (fp + 1.f) * sp - fq * (fq + 1.f) * sq) * ir * ir;
+                o.ddu_dth[0] = 4.f * eps * (-fp * fp * sp + fq * fq * sq) * ir / sig;
+                o.ddu_dth[1] = 4.f * m1 * ir;
+            }
+        }
+    } break;
+    case MDG_PAIR_MORSE: {
+        const float a = t.a, ph = t.phi;
+        const float A = ph >= 0.f ? 0.f : (expf(2.f * a / ph) - 2.f * expf(a / ph));
+        const float rp = powf(r, ph);
+        const float x = a * (1.f - rp) / ph;
+        const float e1 = expf(x), e2 = e1 * e1;
+        const float inv = 1.f / (1.f + A);
+        o.u = (e2 - 2.f * e1 - A) * inv;
+        if (LEVEL >= 1) {
+            const float ux = (2.f * e2 - 2.f * e1) * inv;
+            const float xr = -a * rp * ir;
+            o.du = ux * xr;
+            if (LEVEL >= 2) {
+                const float uxx = (4.f * e2 - 2.f * e1) * inv;
+                const float xrr = -a * (ph - 1.f) * rp * ir * ir;
+                o.d2u = uxx * xr * xr + ux * xrr;
+            }
+        }
+    } break;
+    case MDG_PAIR_BUCK: {
+        const float A = th[0], B = th[1], C = th[2];
+        const float e = expf(-B * r);
+        const float ir2 = ir * ir, ir6 = ir2 * ir2 * ir2;
+        o.u = A * e - C * ir6;
+        if (LEVEL >= 1) {
+            o.du = -A * B * e + 6.f * C * ir6 * ir;
+            o.du_dth[0] = e; o.du_dth[1] = -A * r * e; o.du_dth[2] = -ir6;
+            if (LEVEL >= 2) {
+                o.d2u = A * B * B * e - 42.f * C * ir6 * ir2;
+                o.ddu_dth[0] = -B * e; o.ddu_dth[1] = A * e * (B * r - 1.f);
+                o.ddu_dth[2] = 6.f * ir6 * ir;
+            }
+        }
+    } break;
+    default: {  // MDG_PAIR_YUKAWA
+        const float eps = th[0], kap = th[1];
+        const float e = expf(-kap * r);
+        o.u = eps * e * ir;
+        if (LEVEL >= 1) {
+            const float kr1 = kap * r + 1.f;
+            o.du = -eps * e * kr1 * ir * ir;
+            o.du_dth[0] = e * ir; o.du_dth[1] = -eps * e;
+            if (LEVEL >= 2) {
+                o.d2u = eps * e * (kap * kap * r * r + 2.f * kap * r + 2.f) * ir * ir * ir;
+                o.ddu_dth[0] = -e * kr1 * ir * ir; o.ddu_dth[1] = eps * e * kap;
+            }
+        }
+    } break;
+    }
+}
+
+// ----------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum across a contiguous power-of-two lane group of width W (W <= 64)
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// run-time width variant (w is wave-uniform)
+__device__ __forceinline__ float group_sum_rt(float v, int w) {
+    for (int o = w >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Block-wide sum, result broadcast to every thread.  `red` = LDS scratch of >= 17 floats.
+// Deterministic (fixed tree).  Contains two barriers.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();                       // protect `red` from the previous use
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < nw; ++k) s += red[k];
+    return s;
+}
+
+// Block-wide sum of NV values at once (one barrier pair).  `red` >= (#waves * NV) floats.
+template <int NV>
+__device__ __forceinline__ void block_sum_n(float (&v)[NV], float* red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) red[wid * NV + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        float s = 0.f;
+        for (int w = 0; w < nw; ++w) s += red[w * NV + k];
+        v[k] = s;
+    }
+}

@@ -1,0 +1,318 @@
+// K1: neighbour list builders (replace generate_nbr_list, torchmd/topology.py:30-73).
+//
+// Output layout (see include/mdgrad_hip.h): padded per-atom FULL list, rows sorted by
+// neighbour index -- the layout the per-atom gather kernels want (no scatter, no atomics);
+// the reference's lexicographic half list is the (j > i) subsequence of every row.
+//
+//   dense : one wave per row scans all j in index order; ordered compaction with
+//           ballot/popcount keeps rows sorted.  Any cell (triclinic ok).
+//   cell  : bin atoms (wrapped fractional coordinates) -> counting sort -> one wave per
+//           atom walks the 27-bin stencil, then rank-sorts its row in LDS.  The pair test is
+//           the SAME arithmetic as the dense path (reference minimum image + un-contracted
+//           d^2), so both produce identical lists.
+#include <stdarg.h>
+#include <string.h>
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+void mdg_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* mdg_last_error(void) { return g_err; }
+extern "C" int mdg_version(void) { return 100; }
+
+namespace {
+
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+    return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// pair test shared by both builders: returns image code, or -1 when (i,j) is not a neighbour
+template <bool DIAG>
+__device__ __forceinline__ int pair_test(const MdgCell& c, const float* __restrict__ pos, int i, int j,
+                                         float xi, float yi, float zi, float rc2,
+                                         const uint8_t* __restrict__ mask, int N) {
+    float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+    const int code = min_image<DIAG>(c, dx, dy, dz);
+    const float d2 = norm2_ref(dx, dy, dz);
+    bool ok = (d2 < rc2) && (d2 != 0.f);
+    if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
+    return ok ? code : -1;
+}
+
+template <bool DIAG>
+__global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, MdgCell cell, float rc2,
+                                 const uint8_t* __restrict__ mask, int32_t* __restrict__ col,
+                                 int32_t* __restrict__ shift, int32_t* __restrict__ cnt, int max_nbr,
+                                 int32_t* __restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    int base = 0;
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        const int j = j0 + lane;
+        int code = -1;
+        if (j < N && j != i) code = pair_test<DIAG>(cell, pos, i, j, xi, yi, zi, rc2, mask, N);
+        const unsigned long long b = __ballot(code >= 0);
+        if (code >= 0) {
+            const int k = base + __popcll(b & lanemask_lt());
+            if (k < max_nbr) { col[(size_t)i * max_nbr + k] = j; shift[(size_t)i * max_nbr + k] = code; }
+        }
+        base += __popcll(b);
+    }
+    if (lane == 0) {
+        cnt[i] = base < max_nbr ? base : max_nbr;
+        if (base > max_nbr) atomicMax(overflow, base);
+    }
+}
+
+// ---------------------------------------------------------------------------- cell list
+struct Bins { int nb[3]; int ncell; };
+
+__host__ __device__ inline Bins make_bins(const MdgCell& c, float cutoff) {
+    Bins b;
+    for (int d = 0; d < 3; ++d) {
+        int n = (int)floorf(c.h[4 * d] / cutoff);
+        b.nb[d] = n < 1 ? 1 : n;
+    }
+    b.ncell = b.nb[0] * b.nb[1] * b.nb[2];
+    return b;
+}
+
+__device__ __forceinline__ int bin_coord(float x, float inv, int nb) {
+    float fr = x * inv;
+    fr -= floorf(fr);
+    int b = (int)(fr * (float)nb);
+    return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
+}
+
+__global__ void bin_count_kernel(const float* __restrict__ pos, int N, MdgCell cell, Bins bins,
+                                 int32_t* __restrict__ atom_bin, int32_t* __restrict__ bin_cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int bx = bin_coord(pos[3 * i], cell.inv[0], bins.nb[0]);
+    const int by = bin_coord(pos[3 * i + 1], cell.inv[4], bins.nb[1]);
+    const int bz = bin_coord(pos[3 * i + 2], cell.inv[8], bins.nb[2]);
+    const int b = (bx * bins.nb[1] + by) * bins.nb[2] + bz;
+    atom_bin[i] = b;
+    atomicAdd(&bin_cnt[b], 1);
+}
+
+// single-block exclusive scan: out[k] = sum_{l<k} in[l], out[n] = total; also copies to cursor
+__global__ void scan_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out,
+                            int32_t* __restrict__ cursor) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int k = base + threadIdx.x;
+        const int v = k < n ? in[k] : 0;
+        int x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+        if (lane == 63) wsum[wid] = x;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int carry = carry_s;
+        const int excl = carry + woff + x - v;
+        if (k < n) { out[k] = excl; if (cursor) cursor[k] = excl; }
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + x;
+        __syncthreads();
+        (void)nw;
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
+__global__ void bin_fill_kernel(const int32_t* __restrict__ atom_bin, int N, int32_t* __restrict__ cursor,
+                                int32_t* __restrict__ sorted_atoms) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const int slot = atomicAdd(&cursor[atom_bin[i]], 1);
+    sorted_atoms[slot] = i;
+}
+
+constexpr int ROW_CAP = 512;   // LDS row buffer per wave (entries)
+
+__global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, MdgCell cell, Bins bins, float rc2,
+                                const uint8_t* __restrict__ mask, const int32_t* __restrict__ atom_bin,
+                                const int32_t* __restrict__ bin_start, const int32_t* __restrict__ sorted_atoms,
+                                int32_t* __restrict__ col, int32_t* __restrict__ shift,
+                                int32_t* __restrict__ cnt, int max_nbr, int32_t* __restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int32_t* bj = sm + wid * 2 * ROW_CAP;
+    int32_t* bc = bj + ROW_CAP;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wid;
+    if (i >= N) return;
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    const int b = atom_bin[i];
+    const int bz = b % bins.nb[2], by = (b / bins.nb[2]) % bins.nb[1], bx = b / (bins.nb[2] * bins.nb[1]);
+    int base = 0;
+    for (int s = 0; s < 27; ++s) {
+        const int cx = (bx + s / 9 - 1 + bins.nb[0]) % bins.nb[0];
+        const int cy = (by + (s / 3) % 3 - 1 + bins.nb[1]) % bins.nb[1];
+        const int cz = (bz + s % 3 - 1 + bins.nb[2]) % bins.nb[2];
+        const int c = (cx * bins.nb[1] + cy) * bins.nb[2] + cz;
+        const int a0 = bin_start[c], a1 = bin_start[c + 1];
+        for (int a = a0; a < a1; a += 64) {
+            const int idx = a + lane;
+            int code = -1, j = -1;
+            if (idx < a1) {
+                j = sorted_atoms[idx];
+                if (j != i) code = pair_test<true>(cell, pos, i, j, xi, yi, zi, rc2, mask, N);
+            }
+            const unsigned long long bal = __ballot(code >= 0);
+            if (code >= 0) {
+                const int k = base + __popcll(bal & lanemask_lt());
+                if (k < ROW_CAP) { bj[k] = j; bc[k] = code; }
+            }
+            base += __popcll(bal);
+        }
+    }
+    const int n = base < ROW_CAP ? base : ROW_CAP;
+    // rank sort by neighbour index (entries are distinct)
+    for (int k = lane; k < n; k += 64) {
+        const int jk = bj[k];
+        int rank = 0;
+        for (int l = 0; l < n; ++l) rank += bj[l] < jk;
+        if (rank < max_nbr) { col[(size_t)i * max_nbr + rank] = jk; shift[(size_t)i * max_nbr + rank] = bc[k]; }
+    }
+    if (lane == 0) {
+        cnt[i] = base < max_nbr ? base : max_nbr;
+        if (base > max_nbr) atomicMax(overflow, base);
+    }
+}
+
+// ---------------------------------------------------------------------------- half list
+__device__ __forceinline__ int first_greater(const int32_t* __restrict__ row, int n, int key) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (row[mid] > key) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+
+__global__ void half_count_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ cnt, int N,
+                                  int max_nbr, int32_t* __restrict__ row_half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    row_half[i] = cnt[i] - first_greater(col + (size_t)i * max_nbr, cnt[i], i);
+}
+
+__global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ shift,
+                                 const int32_t* __restrict__ cnt, const int32_t* __restrict__ row_base,
+                                 int N, int max_nbr, int64_t* __restrict__ nbr, float* __restrict__ offsets,
+                                 int32_t* __restrict__ edge_id) {
+    const int i = blockIdx.x;
+    const int32_t* row = col + (size_t)i * max_nbr;
+    const int n = cnt[i];
+    const int fg = first_greater(row, n, i);
+    const int base = row_base[i];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const int j = row[k];
+        if (k >= fg) {
+            const int e = base + (k - fg);
+            if (nbr) { nbr[2 * (size_t)e] = i; nbr[2 * (size_t)e + 1] = j; }
+            if (offsets) {
+                const int code = shift[(size_t)i * max_nbr + k];
+                offsets[3 * (size_t)e] = (float)(code % 3 - 1);
+                offsets[3 * (size_t)e + 1] = (float)((code / 3) % 3 - 1);
+                offsets[3 * (size_t)e + 2] = (float)(code / 9 - 1);
+            }
+            if (edge_id) edge_id[(size_t)i * max_nbr + k] = e;
+        } else if (edge_id) {
+            // reverse slot: locate i inside row j
+            const int32_t* rj = col + (size_t)j * max_nbr;
+            const int nj = cnt[j];
+            const int fgj = first_greater(rj, nj, j);
+            const int pos_i = first_greater(rj, nj, i - 1);        // index of i in row j
+            edge_id[(size_t)i * max_nbr + k] = row_base[j] + (pos_i - fgj);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdg_nbr_build_dense(const float* pos, int n_atoms, const MdgCell* cell, float cutoff,
+                                   const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
+                                   int max_nbr, int32_t* overflow, void* stream) {
+    MDG_CHECK_ARG(pos && cell && col && shift && cnt && overflow, "nbr_build_dense: null buffer");
+    MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0 && cutoff > 0.f, "nbr_build_dense: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const int wpb = 4;
+    dim3 grid((n_atoms + wpb - 1) / wpb), block(64 * wpb);
+    const float rc2 = cutoff * cutoff;
+    if (cell->diag)
+        hipLaunchKernelGGL(nbr_dense_kernel<true>, grid, block, 0, st, pos, n_atoms, *cell, rc2, mask, col,
+                           shift, cnt, max_nbr, overflow);
+    else
+        hipLaunchKernelGGL(nbr_dense_kernel<false>, grid, block, 0, st, pos, n_atoms, *cell, rc2, mask, col,
+                           shift, cnt, max_nbr, overflow);
+    MDG_CHECK_LAUNCH("nbr_dense_kernel");
+    return MDG_OK;
+}
+
+extern "C" int64_t mdg_nbr_cell_scratch(int n_atoms, const MdgCell* cell, float cutoff) {
+    if (!cell || n_atoms <= 0 || cutoff <= 0.f) return -1;
+    const Bins b = make_bins(*cell, cutoff);
+    return 2 * (int64_t)n_atoms + 3 * (int64_t)(b.ncell + 1) + 8;
+}
+
+extern "C" int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* cell, float cutoff,
+                                  const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
+                                  int max_nbr, int32_t* overflow, int32_t* scratch, void* stream) {
+    MDG_CHECK_ARG(pos && cell && col && shift && cnt && overflow && scratch, "nbr_build_cell: null buffer");
+    MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0 && cutoff > 0.f, "nbr_build_cell: bad sizes");
+    MDG_CHECK_ARG(cell->diag, "nbr_build_cell: orthorhombic cells only (use mdg_nbr_build_dense)");
+    const Bins bins = make_bins(*cell, cutoff);
+    MDG_CHECK_ARG(bins.nb[0] >= 3 && bins.nb[1] >= 3 && bins.nb[2] >= 3,
+                  "nbr_build_cell: box shorter than 3 cutoffs (use mdg_nbr_build_dense)");
+    MDG_CHECK_ARG(max_nbr <= ROW_CAP, "nbr_build_cell: max_nbr > %d", ROW_CAP);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* atom_bin = scratch;
+    int32_t* sorted_atoms = atom_bin + n_atoms;
+    int32_t* bin_cnt = sorted_atoms + n_atoms;
+    int32_t* bin_start = bin_cnt + bins.ncell + 1;
+    int32_t* cursor = bin_start + bins.ncell + 1;
+    if (hipMemsetAsync(bin_cnt, 0, sizeof(int32_t) * (bins.ncell + 1), st) != hipSuccess) {
+        mdg_set_error("nbr_build_cell: memset failed"); return MDG_ELAUNCH;
+    }
+    const int tb = 256;
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, *cell,
+                       bins, atom_bin, bin_cnt);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, bin_cnt, bins.ncell, bin_start, cursor);
+    hipLaunchKernelGGL(bin_fill_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, atom_bin, n_atoms,
+                       cursor, sorted_atoms);
+    const int wpb = 4;
+    const size_t lds = sizeof(int32_t) * 2 * ROW_CAP * wpb;
+    hipLaunchKernelGGL(nbr_cell_kernel, dim3((n_atoms + wpb - 1) / wpb), dim3(64 * wpb), lds, st, pos, n_atoms,
+                       *cell, bins, cutoff * cutoff, mask, atom_bin, bin_start, sorted_atoms, col, shift, cnt,
+                       max_nbr, overflow);
+    MDG_CHECK_LAUNCH("nbr_cell kernels");
+    return MDG_OK;
+}
+
+extern "C" int mdg_nbr_half_count(const int32_t* col, const int32_t* cnt, int n_atoms, int max_nbr,
+                                  int32_t* row_base, void* stream) {
+    MDG_CHECK_ARG(col && cnt && row_base && n_atoms > 0, "nbr_half_count: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    // row_base doubles as the per-row count buffer before the in-place scan
+    hipLaunchKernelGGL(half_count_kernel, dim3((n_atoms + 255) / 256), dim3(256), 0, st, col, cnt, n_atoms,
+                       max_nbr, row_base);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, row_base, n_atoms, row_base, (int32_t*)nullptr);
+    MDG_CHECK_LAUNCH("nbr_half_count");
+    return MDG_OK;
+}
+
+extern "C" int mdg_nbr_half_fill(const int32_t* col, const int32_t* shift, const int32_t* cnt,
+                                 const int32_t* row_base, int n_atoms, int max_nbr, int64_t* nbr,
+                                 float* offsets, int32_t* edge_id, void* stream) {
+    MDG_CHECK_ARG(col && shift && cnt && row_base && n_atoms > 0, "nbr_half_fill: bad arguments");
+    hipLaunchKernelGGL(half_fill_kernel, dim3(n_atoms), dim3(64), 0, (hipStream_t)stream, col, shift, cnt,
+                       row_base, n_atoms, max_nbr, nbr, offsets, edge_id);
+    MDG_CHECK_LAUNCH("nbr_half_fill");
+    return MDG_OK;
+}

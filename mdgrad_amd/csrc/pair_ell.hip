@@ -1,0 +1,139 @@
+// K2-K4: pair energy / gradient / Hessian-vector product over the per-atom (ELL) list.
+// Replaces compute_dis + pair form + .sum() and both autograd passes through them
+// (torchmd/topology.py:5-12, torchmd/interface.py:298-299, torchmd/md.py:227-228,
+//  torchmd/sovlers.py:229-233).
+//
+// LPA lanes cooperate on one atom: each lane walks a strided slice of the atom's (sorted)
+// neighbour row, the per-atom sums are combined with wave shuffles ("wavefront-level
+// segmented reduction"), scalar sums (energy, parameter gradients) go through a fixed-order
+// block reduction into a per-block partial and a second tiny kernel adds the partials in
+// block order.  No float atomics anywhere => bitwise reproducible.
+#include "common.hpp"
+
+namespace {
+
+constexpr int NSCAL = 1 + 2 * MDG_MAX_THETA;   // energy, gtheta[3], gtheta_w[3]
+
+struct EllArgs {
+    const float* pos; int N; MdgCell cell;
+    const int32_t* col; const int32_t* shift; const int32_t* cnt; int max_nbr;
+    MdgPairTerm term; const float* theta; const float* w;
+    float* grad; float* hw; float* partial;
+};
+
+template <int LPA, int LEVEL>
+__global__ void pair_ell_kernel(const EllArgs A) {
+    __shared__ float red[16 * NSCAL];
+    const int apb = blockDim.x / LPA;
+    const int i = blockIdx.x * apb + threadIdx.x / LPA, sub = threadIdx.x % LPA;
+    float vals[NSCAL];
+#pragma unroll
+    for (int k = 0; k < NSCAL; ++k) vals[k] = 0.f;
+    if (i < A.N) {
+        const float* th = A.theta + A.term.theta_off;
+        const float xi = A.pos[3 * i], yi = A.pos[3 * i + 1], zi = A.pos[3 * i + 2];
+        float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+        if (LEVEL >= 2) { wxi = A.w[3 * i]; wyi = A.w[3 * i + 1]; wzi = A.w[3 * i + 2]; }
+        float gx = 0.f, gy = 0.f, gz = 0.f, hx = 0.f, hy = 0.f, hz = 0.f;
+        const int n = A.cnt[i];
+        const size_t row = (size_t)i * A.max_nbr;
+        for (int k = sub; k < n; k += LPA) {
+            const int j = A.col[row + k];
+            float dx = xi - A.pos[3 * j], dy = yi - A.pos[3 * j + 1], dz = zi - A.pos[3 * j + 2];
+            apply_shift(A.cell, A.shift[row + k], dx, dy, dz);      // d = x_i - x_j - o.h
+            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+            PairOut o;
+            pair_eval<LEVEL>(A.term, th, r, o);
+            vals[0] += 0.5f * o.u;
+            if (LEVEL >= 1) {
+                const float ir = 1.0f / r;
+                const float rx = dx * ir, ry = dy * ir, rz = dz * ir;
+                gx = fmaf(o.du, rx, gx); gy = fmaf(o.du, ry, gy); gz = fmaf(o.du, rz, gz);
+#pragma unroll
+                for (int t = 0; t < MDG_MAX_THETA; ++t)
+                    if (t < A.term.n_theta) vals[1 + t] += 0.5f * o.du_dth[t];
+                if (LEVEL >= 2) {
+                    const float ax = wxi - A.w[3 * j], ay = wyi - A.w[3 * j + 1], az = wzi - A.w[3 * j + 2];
+                    const float a = rx * ax + ry * ay + rz * az;
+                    const float c2 = o.d2u * a, c3 = o.du * ir;
+                    hx += c2 * rx + c3 * (ax - a * rx);
+                    hy += c2 * ry + c3 * (ay - a * ry);
+                    hz += c2 * rz + c3 * (az - a * rz);
+#pragma unroll
+                    for (int t = 0; t < MDG_MAX_THETA; ++t)
+                        if (t < A.term.n_theta) vals[1 + MDG_MAX_THETA + t] += 0.5f * o.ddu_dth[t] * a;
+                }
+            }
+        }
+        if (LEVEL >= 1) {
+            gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
+            if (LEVEL >= 2) { hx = group_sum<LPA>(hx); hy = group_sum<LPA>(hy); hz = group_sum<LPA>(hz); }
+            if (sub == 0) {
+                if (A.grad) { A.grad[3 * i] = gx; A.grad[3 * i + 1] = gy; A.grad[3 * i + 2] = gz; }
+                if (LEVEL >= 2) { A.hw[3 * i] = hx; A.hw[3 * i + 1] = hy; A.hw[3 * i + 2] = hz; }
+            }
+        }
+    }
+    block_sum_n<NSCAL>(vals, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NSCAL; ++k) A.partial[(size_t)blockIdx.x * NSCAL + k] = vals[k];
+    }
+}
+
+__global__ void pair_ell_finish(const float* __restrict__ partial, int nblocks, int n_theta,
+                                float* energy, float* gtheta, float* gtheta_w) {
+    const int k = threadIdx.x;
+    if (k >= NSCAL) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * NSCAL + k];
+    if (k == 0) { if (energy) energy[0] = s; }
+    else if (k <= MDG_MAX_THETA) { if (gtheta && k - 1 < n_theta) gtheta[k - 1] = s; }
+    else if (gtheta_w && k - 1 - MDG_MAX_THETA < n_theta) gtheta_w[k - 1 - MDG_MAX_THETA] = s;
+}
+
+int pick_lpa(int N) {
+    int lpa = 64;
+    while (lpa > 8 && (long long)N * lpa / 2 >= 131072) lpa /= 2;
+    return lpa;
+}
+
+}  // namespace
+
+extern "C" int64_t mdg_pair_partial_size(int n_atoms) {
+    const int lpa = pick_lpa(n_atoms);
+    const int apb = 256 / lpa;
+    return (int64_t)((n_atoms + apb - 1) / apb) * NSCAL;
+}
+
+#define MDG_ELL_LAUNCH(LPA_)                                                                       \
+    case LPA_:                                                                                     \
+        if (level == 2) hipLaunchKernelGGL((pair_ell_kernel<LPA_, 2>), grid, dim3(256), 0, st, a); \
+        else if (level == 1) hipLaunchKernelGGL((pair_ell_kernel<LPA_, 1>), grid, dim3(256), 0, st, a); \
+        else hipLaunchKernelGGL((pair_ell_kernel<LPA_, 0>), grid, dim3(256), 0, st, a);            \
+        break;
+
+extern "C" int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* cell, const int32_t* col,
+                                 const int32_t* shift, const int32_t* cnt, int max_nbr,
+                                 const MdgPairTerm* term, const float* theta, const float* w,
+                                 float* energy, float* grad, float* gtheta, float* hw, float* gtheta_w,
+                                 float* partial, void* stream) {
+    MDG_CHECK_ARG(pos && cell && col && shift && cnt && term && partial, "pair_eval_ell: null buffer");
+    MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0, "pair_eval_ell: bad sizes");
+    MDG_CHECK_ARG(term->kind >= 0 && term->kind <= MDG_PAIR_YUKAWA && term->n_theta <= MDG_MAX_THETA,
+                  "pair_eval_ell: bad pair term");
+    MDG_CHECK_ARG(term->n_theta == 0 || theta, "pair_eval_ell: theta is null");
+    MDG_CHECK_ARG(!w || hw, "pair_eval_ell: w given without hw output");
+    const int level = w ? 2 : ((grad || gtheta) ? 1 : 0);
+    EllArgs a{pos, n_atoms, *cell, col, shift, cnt, max_nbr, *term, theta, w, grad, hw, partial};
+    const int lpa = pick_lpa(n_atoms);
+    const int apb = 256 / lpa;
+    const int nblocks = (n_atoms + apb - 1) / apb;
+    dim3 grid(nblocks);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lpa) { MDG_ELL_LAUNCH(8) MDG_ELL_LAUNCH(16) MDG_ELL_LAUNCH(32) MDG_ELL_LAUNCH(64) }
+    hipLaunchKernelGGL(pair_ell_finish, dim3(1), dim3(64), 0, st, partial, nblocks, term->n_theta, energy,
+                       gtheta, gtheta_w);
+    MDG_CHECK_LAUNCH("pair_ell_kernel");
+    return MDG_OK;
+}

@@ -1,0 +1,475 @@
+// Fused whole-trajectory kernels for small systems (K5-K7 of SURVEY 2.3).
+//
+// One workgroup integrates one replica for ALL steps with the state resident in LDS:
+// the only HBM traffic is the initial state, the saved frames and (adjoint) the incoming
+// frame gradients.  Forces are all-pairs minimum image over the LDS-resident positions,
+// TPA lanes cooperating on one atom and combining with wave shuffles (no atomics, fixed
+// summation order => bitwise reproducible).  Semantics follow the reference exactly:
+//   forward  torchmd/sovlers.py:110-127 (NHverlet_update) / :25-40 (verlet_update),
+//            RHS torchmd/md.py:210-240 (NoseHooverChain) / :133-150 (NVE)
+//   adjoint  torchmd/sovlers.py:211-293 with backward branches :129-164 / :42-101
+//            (vjp of the RHS written out analytically)
+#include "common.hpp"
+
+namespace {
+
+struct TrajArgs {
+    MdgTrajParams prm;
+    MdgCell cell;
+    MdgTerms terms;
+    const float* theta;
+    const float* mass;
+    const float* t;
+    const float* v0; const float* q0; const float* pv0;      // fwd inputs
+    float* v_t; float* q_t; float* pv_t;                      // fwd outputs / adj inputs
+    const float* g_v; const float* g_q; const float* g_pv;    // adj inputs
+    float* adj_v0; float* adj_q0; float* adj_pv0; float* adj_theta;
+    int32_t* nonfinite;
+};
+
+constexpr int KMAX_ALL = MDG_MAX_TERMS * MDG_MAX_THETA;
+constexpr int RED_FLOATS = 16 * (KMAX_ALL + 2);
+// Kernels are specialised on <DIAG, NT, KIND>: NT = compile-time bound on the number of pair
+// terms (1 or MDG_MAX_TERMS), KIND = the functional form when NT == 1 (-1 = run-time switch).
+// The lane-group width TPA is a run-time power of two.
+#define KMAX (NT * MDG_MAX_THETA)
+
+// All-pairs force (LEVEL 1) or force + Hessian-vector product + parameter vjp (LEVEL 2).
+//   f   [3][N] <-  F = -dU/dq
+//   dq  [3][N] <-  d(w.F)/dq = -H w                      (LEVEL 2)
+//   dth [K]    +=  per-thread partial of d(w.F)/dtheta   (LEVEL 2; caller block-reduces)
+template <bool DIAG, int NT, int KIND, int LEVEL>
+__device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
+                                                const float* __restrict__ w, float* __restrict__ f,
+                                                float* __restrict__ dq, float (&dth)[KMAX]) {
+    const int N = A.prm.n_atoms;
+    const int TPA = 1 << tpa_log2;
+    const int slots = blockDim.x >> tpa_log2;
+    const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
+    const int nt = NT == 1 ? 1 : A.terms.n_terms;
+    for (int i = slot; i < N; i += slots) {
+        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int j = sub; j < N; j += TPA) {
+            float dx = q[j] - xi, dy = q[N + j] - yi, dz = q[2 * N + j] - zi;   // D = x_j - x_i
+            min_image<DIAG>(A.cell, dx, dy, dz);
+            const float d2 = norm2_ref(dx, dy, dz);
+            if (d2 == 0.f) continue;                                           // topology.py:67
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                if (m >= nt) break;
+                const MdgPairTerm& tm = A.terms.t[m];
+                if (!(d2 < tm.cutoff * tm.cutoff)) continue;
+                if (tm.mask && !tm.mask[(size_t)i * N + j]) continue;
+                const float r = sqrtf(d2);
+                PairOut o;
+                pair_eval<LEVEL, KIND>(tm, A.theta + tm.theta_off, r, o);
+                const float ir = 1.0f / r;
+                const float c1 = o.du * ir;              // F_i += phi' * D / r   (rhat = -D/r)
+                fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+                if (LEVEL >= 2) {
+                    const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+                    const float ax = wxi - w[j], ay = wyi - w[N + j], az = wzi - w[2 * N + j];
+                    const float a = rx * ax + ry * ay + rz * az;
+                    const float c2 = o.d2u * a, c3 = o.du * ir;
+                    // hv = phi'' a rhat + (phi'/r)(wij - a rhat);   dq_i -= hv
+                    gx -= c2 * rx + c3 * (ax - a * rx);
+                    gy -= c2 * ry + c3 * (ay - a * ry);
+                    gz -= c2 * rz + c3 * (az - a * rz);
+#pragma unroll
+                    for (int k = 0; k < MDG_MAX_THETA; ++k)
+                        if (k < tm.n_theta) dth[m * MDG_MAX_THETA + k] -= 0.5f * o.ddu_dth[k] * a;
+                }
+            }
+        }
+        fx = group_sum_rt(fx, TPA); fy = group_sum_rt(fy, TPA); fz = group_sum_rt(fz, TPA);
+        if (LEVEL >= 2) { gx = group_sum_rt(gx, TPA); gy = group_sum_rt(gy, TPA); gz = group_sum_rt(gz, TPA); }
+        if (sub == 0) {
+            f[i] = fx; f[N + i] = fy; f[2 * N + i] = fz;
+            if (LEVEL >= 2) { dq[i] = gx; dq[N + i] = gy; dq[2 * N + i] = gz; }
+        }
+    }
+}
+
+// Nose-Hoover chain bath right-hand side, entry k (md.py:234-236)
+__device__ __forceinline__ float bath_rhs(const TrajArgs& A, const float* pv, float ke, int k) {
+    const int C = A.prm.n_chains;
+    const float* Q = A.prm.Q;
+    const float T = A.prm.T;
+    if (k == 0) return 2.f * (ke - T * A.prm.n_dof * 0.5f) - pv[0] * pv[1] / Q[1];
+    if (k == C - 1) return pv[C - 2] * pv[C - 2] / Q[C - 2] - T;
+    return (pv[k - 1] * pv[k - 1] / Q[k - 1] - T) - pv[k + 1] * pv[k] / Q[k + 1];
+}
+
+// AoS [N,3] global  <->  SoA [3][N] LDS
+__device__ __forceinline__ void load_soa(float* dst, const float* __restrict__ src, int N) {
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[(e % 3) * N + e / 3] = src[e];
+}
+__device__ __forceinline__ void store_aos(float* __restrict__ dst, const float* src, int N) {
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[e] = src[(e % 3) * N + e / 3];
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <bool DIAG, int NT, int KIND>
+__global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const int tpa_log2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const bool nhc = A.prm.ensemble == 0;
+    const int rep = blockIdx.x;
+    float* q = smem;            // [3][N]
+    float* v = q + 3 * N;       // [3][N]
+    float* vh = v + 3 * N;      // [3][N] half-step velocity increment
+    float* f = vh + 3 * N;      // [3][N]
+    float* ms = f + 3 * N;      // [N]
+    float* pv = ms + N;         // [C]
+    float* ph = pv + MDG_MAX_CHAINS;
+    float* pb = ph + MDG_MAX_CHAINS;
+    float* pvh = pb + MDG_MAX_CHAINS;   // [C] pv + ph
+    float* red = pvh + MDG_MAX_CHAINS;  // [RED_FLOATS]
+    float dth_unused[KMAX];
+
+    load_soa(q, A.q0 + (size_t)rep * N * 3, N);
+    load_soa(v, A.v0 + (size_t)rep * N * 3, N);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) ms[i] = A.mass[i];
+    if (nhc && threadIdx.x < C) pv[threadIdx.x] = A.pv0[(size_t)rep * C + threadIdx.x];
+    __syncthreads();
+    // frame 0 = inputs (tinydiffeq.py:63)
+    store_aos(A.q_t + ((size_t)rep * T) * N * 3, q, N);
+    store_aos(A.v_t + ((size_t)rep * T) * N * 3, v, N);
+    if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
+
+    force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused);
+    __syncthreads();
+
+    for (int k = 0; k + 1 < T; ++k) {
+        const float dt = A.t[k + 1] - A.t[k];
+        // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
+        float ke = 0.f;
+        if (nhc) {
+            float part = 0.f;
+            for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
+                const float m = ms[e % N]; const float p = v[e] * m; part += p * p / m;
+            }
+            ke = 0.5f * block_sum(part, red);
+            if (threadIdx.x < C) pb[threadIdx.x] = bath_rhs(A, pv, ke, threadIdx.x);
+        }
+        const float pv0 = nhc ? pv[0] : 0.f;
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
+            const float m = ms[e % N];
+            float a;
+            if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p / A.prm.Q[0]) / m; }
+            else a = f[e];                                   // md.py:145-148 (no 1/m)
+            const float h = 0.5f * a * dt;
+            vh[e] = h;
+            q[e] = q[e] + (v[e] + h) * dt;
+        }
+        if (nhc && threadIdx.x < C) {
+            const float h = 0.5f * pb[threadIdx.x] * dt;
+            ph[threadIdx.x] = h;
+            pvh[threadIdx.x] = pv[threadIdx.x] + h;
+        }
+        __syncthreads();
+        // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
+        force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused);
+        float pvh0 = 0.f;
+        if (nhc) {
+            float part = 0.f;
+            for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
+                const float m = ms[e % N]; const float p = (v[e] + vh[e]) * m; part += p * p / m;
+            }
+            ke = 0.5f * block_sum(part, red);       // (barriers inside also publish f)
+            pvh0 = pvh[0];
+            float b1 = 0.f;
+            if (threadIdx.x < C) b1 = bath_rhs(A, pvh, ke, threadIdx.x);
+            __syncthreads();
+            if (threadIdx.x < C) pv[threadIdx.x] = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
+        } else {
+            __syncthreads();
+        }
+        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
+            const float m = ms[e % N];
+            float a;
+            if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p / A.prm.Q[0]) / m; }
+            else a = f[e];
+            v[e] = v[e] + (vh[e] + 0.5f * a * dt);
+        }
+        __syncthreads();
+        store_aos(A.q_t + ((size_t)rep * T + k + 1) * N * 3, q, N);
+        store_aos(A.v_t + ((size_t)rep * T + k + 1) * N * 3, v, N);
+        if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = pv[threadIdx.x];
+    }
+    if (A.nonfinite) {
+        int bad = 0;
+        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) bad |= !(isfinite(q[e]) && isfinite(v[e]));
+        if (__syncthreads_or(bad) && threadIdx.x == 0) A.nonfinite[rep] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------ adjoint
+// One evaluation of the augmented dynamics at (v,q,pv ; lv,lq,lp):
+//   f, dq, th[K] (block-reduced), ke, slv = sum(lv.v)
+template <bool DIAG, int NT, int KIND>
+__device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool nhc, const float* q, const float* v,
+                                         const float* lv, const float* ms, float* w, float* f,
+                                         float* dq, float* red, float (&th)[KMAX], float& ke,
+                                         float& slv) {
+    const int N = A.prm.n_atoms;
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) w[e] = nhc ? lv[e] / ms[e % N] : lv[e];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
+    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th);
+    // one fused block reduction: th[0..K), sum p^2/m, sum lv.v
+    float vals[KMAX + 2];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) vals[k] = th[k];
+    float p1 = 0.f, p2 = 0.f;
+    if (nhc) {
+        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
+            const float m = ms[e % N]; const float p = v[e] * m;
+            p1 += p * p / m; p2 += lv[e] * v[e];
+        }
+    }
+    vals[KMAX] = p1; vals[KMAX + 1] = p2;
+    block_sum_n<KMAX + 2>(vals, red);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) th[k] = vals[k];
+    ke = 0.5f * vals[KMAX]; slv = vals[KMAX + 1];
+    __syncthreads();
+}
+
+// lam^T d(bath rhs)/d pv_k  + coupling from dv
+__device__ __forceinline__ float bath_vjp(const TrajArgs& A, const float* pv, const float* lp,
+                                          float slv, int k) {
+    const int C = A.prm.n_chains;
+    const float* Q = A.prm.Q;
+    if (k == 0) return -slv / Q[0] - lp[0] * pv[1] / Q[1] + 2.f * pv[0] * lp[1] / Q[0];
+    if (k == C - 1) return -lp[C - 2] * pv[C - 2] / Q[C - 1];
+    return -lp[k - 1] * pv[k - 1] / Q[k] - lp[k] * pv[k + 1] / Q[k + 1] + 2.f * pv[k] * lp[k + 1] / Q[k];
+}
+
+template <bool DIAG, int NT, int KIND>
+__global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const int tpa_log2) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const bool nhc = A.prm.ensemble == 0;
+    const int rep = blockIdx.x, N3 = 3 * N;
+    float* q = smem;        float* v = q + N3;
+    float* lv = v + N3;     float* lq = lv + N3;
+    float* lvh = lq + N3;   float* lqh = lvh + N3;
+    float* w = lqh + N3;    float* f = w + N3;     float* dq = f + N3;
+    float* ms = dq + N3;
+    float* pv = ms + N;                       // [C] state
+    float* lp = pv + MDG_MAX_CHAINS;          // [C] adjoint
+    float* lph = lp + MDG_MAX_CHAINS;         // [C] midpoint adjoint
+    float* pb = lph + MDG_MAX_CHAINS;         // [C] scratch: bath rhs
+    float* gp = pb + MDG_MAX_CHAINS;          // [C] scratch: bath vjp
+    float* red = gp + MDG_MAX_CHAINS;         // [RED_FLOATS]
+    float th[KMAX], gth[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) gth[k] = 0.f;
+    const size_t fr = (size_t)rep * T;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < N; i += blockDim.x) ms[i] = A.mass[i];
+    // lam = dL/dy_{T-1}                                            sovlers.py:249
+    if (A.g_v) load_soa(lv, A.g_v + (fr + T - 1) * N3, N); else for (int e = tid; e < N3; e += blockDim.x) lv[e] = 0.f;
+    if (A.g_q) load_soa(lq, A.g_q + (fr + T - 1) * N3, N); else for (int e = tid; e < N3; e += blockDim.x) lq[e] = 0.f;
+    if (nhc && tid < C) lp[tid] = A.g_pv ? A.g_pv[(fr + T - 1) * C + tid] : 0.f;
+
+    for (int i = T - 1; i >= 1; --i) {
+        const float h = A.t[i] - A.t[i - 1];
+        __syncthreads();
+        load_soa(q, A.q_t + (fr + i) * N3, N);
+        load_soa(v, A.v_t + (fr + i) * N3, N);
+        if (nhc && tid < C) pv[tid] = A.pv_t[(fr + i) * C + tid];
+        __syncthreads();
+        float ke, slv;
+        // ---------------- first augmented evaluation at (y_i, lam)
+        aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv);
+        if (nhc) {
+            const float pv0 = pv[0], lp0 = lp[0];
+            if (tid < C) { pb[tid] = bath_rhs(A, pv, ke, tid); gp[tid] = bath_vjp(A, pv, lp, slv, tid); }
+            __syncthreads();
+            for (int e = tid; e < N3; e += blockDim.x) {
+                const float m = ms[e % N], ve = v[e], p = ve * m;
+                const float a = (f[e] - pv0 * p / A.prm.Q[0]) / m;
+                const float Gv = -(pv0 / A.prm.Q[0]) * lv[e] + lq[e] + 2.f * m * ve * lp0;
+                const float vhalf = 0.5f * (-a) * h;                  // sovlers.py:132
+                q[e] = q[e] + (ve + vhalf) * h;                      // :138 forward-time sign (quirk)
+                v[e] = ve + vhalf;
+                lvh[e] = lv[e] + Gv * 0.5f * h;                      // :141
+                lqh[e] = lq[e] + dq[e] * 0.5f * h;                   // :142
+            }
+            if (tid < C) {
+                lph[tid] = lp[tid] + gp[tid] * 0.5f * h;             // :143
+            }
+            __syncthreads();
+            if (tid < C) pv[tid] = pv[tid] + 0.5f * (-pb[tid]) * h;   // :135
+            __syncthreads();
+            // ---------------- midpoint evaluation                    :147-150
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
+            const float pvm0 = pv[0], lpm0 = lph[0];
+            if (tid < C) gp[tid] = bath_vjp(A, pv, lph, slv, tid);
+            __syncthreads();
+            for (int e = tid; e < N3; e += blockDim.x) {
+                const float m = ms[e % N];
+                const float Gv = -(pvm0 / A.prm.Q[0]) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
+                float nlv = lv[e] + Gv * h;                          // :156
+                float nlq = lq[e] + dq[e] * h;                       // :157
+                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + (e % N) * 3 + e / N];   // :286
+                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
+                lv[e] = nlv; lq[e] = nlq;
+            }
+            if (tid < C) {
+                float nlp = lp[tid] + gp[tid] * h;                   // :158
+                if (A.g_pv) nlp += A.g_pv[(fr + i - 1) * C + tid];
+                lp[tid] = nlp;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) gth[k] += th[k] * h;     // :160
+        } else {
+            // verlet_update backward branch                          sovlers.py:42-101
+            for (int e = tid; e < N3; e += blockDim.x) {
+                const float dvv = -f[e];
+                const float vhalf = v[e] - 0.5f * dvv * h;           // :49-50
+                q[e] = q[e] - vhalf * h;                             // :51-52
+                v[e] = vhalf;
+                const float dx = dq[e] * h * 0.5f;                   // :71
+                const float dvad = (lq[e] + dx) * h;                 // :72
+                lvh[e] = lv[e] + dvad;
+                lqh[e] = lq[e] + dx;
+            }
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) gth[k] += (th[k] * 0.5f * h) * 2.f;   // :82,101
+            __syncthreads();
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
+            for (int e = tid; e < N3; e += blockDim.x) {
+                float nlv = lvh[e];                                   // lv + dvad
+                float nlq = lqh[e] + dq[e] * h * 0.5f;                // :100
+                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
+                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
+                lv[e] = nlv; lq[e] = nlq;
+            }
+        }
+    }
+    __syncthreads();
+    store_aos(A.adj_v0 + (size_t)rep * N3, lv, N);
+    store_aos(A.adj_q0 + (size_t)rep * N3, lq, N);
+    if (nhc && tid < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + tid] = lp[tid];
+    if (tid == 0 && A.adj_theta) {
+        const int KT = A.terms.n_theta_total;
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int k = 0; k < MDG_MAX_THETA; ++k)
+                if (m < A.terms.n_terms && k < A.terms.t[m].n_theta)
+                    A.adj_theta[(size_t)rep * KT + A.terms.t[m].theta_off + k] = gth[m * MDG_MAX_THETA + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------ launch
+int pick_tpa_log2(int n_atoms, int block) {
+    int l = 0;
+    while (l < 6 && (n_atoms << (l + 1)) <= block) ++l;
+    return l;
+}
+
+int pick_block(const MdgTrajParams& p) {
+    if (p.block > 0) return p.block;
+    // few replicas: widest workgroup (latency); many replicas: 256 threads, several per CU
+    if (p.n_rep >= 1024) return 256;
+    if (p.n_rep >= 256) return 512;
+    return 1024;
+}
+
+// specialisation table: single-term kernels with the functional form fixed at compile time
+// (orthorhombic cell), everything else through the generic <NT = MDG_MAX_TERMS> kernel.
+#define MDG_TRAJ_DISPATCH(KERNEL)                                                                      \
+    do {                                                                                               \
+        const bool single = terms->n_terms == 1 && diag;                                               \
+        const int kind = terms->t[0].kind;                                                             \
+        if (single && kind == MDG_PAIR_LJ)                                                             \
+            hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_LJ>), grid, dim3(block), lds, st, a, tl);     \
+        else if (single && kind == MDG_PAIR_MORSE)                                                     \
+            hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_MORSE>), grid, dim3(block), lds, st, a, tl);  \
+        else if (single && kind == MDG_PAIR_BUCK)                                                      \
+            hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_BUCK>), grid, dim3(block), lds, st, a, tl);   \
+        else if (single && kind == MDG_PAIR_YUKAWA)                                                    \
+            hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_YUKAWA>), grid, dim3(block), lds, st, a, tl); \
+        else if (diag)                                                                                 \
+            hipLaunchKernelGGL((KERNEL<true, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl);  \
+        else                                                                                           \
+            hipLaunchKernelGGL((KERNEL<false, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl); \
+    } while (0)
+
+int validate(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
+    MDG_CHECK_ARG(p && cell && terms, "traj: null descriptor");
+    MDG_CHECK_ARG(p->n_rep > 0 && p->n_atoms > 0 && p->n_frames >= 1, "traj: bad sizes R=%d N=%d T=%d",
+                  p->n_rep, p->n_atoms, p->n_frames);
+    MDG_CHECK_ARG(p->ensemble == 0 || p->ensemble == 1, "traj: ensemble must be 0 (NHC) or 1 (NVE)");
+    MDG_CHECK_ARG(p->ensemble == 1 || (p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS),
+                  "traj: NoseHooverChain needs 2 <= num_chains <= %d (got %d)", MDG_MAX_CHAINS, p->n_chains);
+    MDG_CHECK_ARG(terms->n_terms >= 1 && terms->n_terms <= MDG_MAX_TERMS, "traj: 1..%d pair terms", MDG_MAX_TERMS);
+    for (int m = 0; m < terms->n_terms; ++m)
+        MDG_CHECK_ARG(terms->t[m].kind >= 0 && terms->t[m].kind <= MDG_PAIR_YUKAWA &&
+                      terms->t[m].n_theta <= MDG_MAX_THETA, "traj: bad pair term %d", m);
+    return MDG_OK;
+}
+
+}  // namespace
+
+extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                  const float* theta, const float* mass, const float* t_grid,
+                                  const float* v0, const float* q0, const float* pv0,
+                                  float* v_t, float* q_t, float* pv_t, int32_t* nonfinite, void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v0 && q0 && v_t && q_t, "traj_fwd: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd: NHC needs pv0/pv_t");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
+    const int N = prm->n_atoms;
+    const int block = pick_block(*prm);
+    const size_t lds = sizeof(float) * (13 * (size_t)N + 4 * MDG_MAX_CHAINS + RED_FLOATS);
+    MDG_CHECK_ARG(lds <= 160 * 1024, "traj_fwd: N=%d does not fit the LDS-resident kernel", N);
+    const int tl = pick_tpa_log2(N, block);
+    const bool diag = cell->diag != 0;
+    dim3 grid(prm->n_rep);
+    hipStream_t st = (hipStream_t)stream;
+    MDG_TRAJ_DISPATCH(traj_fwd_kernel);
+    MDG_CHECK_LAUNCH("traj_fwd_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                  const float* theta, const float* mass, const float* t_grid,
+                                  const float* v_t, const float* q_t, const float* pv_t,
+                                  const float* g_v, const float* g_q, const float* g_pv,
+                                  float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                  void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v_t && q_t && adj_v0 && adj_q0, "traj_adj: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || pv_t, "traj_adj: NHC needs pv_t");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
+    a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
+    a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
+    const int N = prm->n_atoms;
+    const int block = pick_block(*prm);
+    const size_t lds = sizeof(float) * (28 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS);
+    MDG_CHECK_ARG(lds <= 160 * 1024, "traj_adj: N=%d does not fit the LDS-resident kernel", N);
+    const int tl = pick_tpa_log2(N, block);
+    const bool diag = cell->diag != 0;
+    dim3 grid(prm->n_rep);
+    hipStream_t st = (hipStream_t)stream;
+    MDG_TRAJ_DISPATCH(traj_adj_kernel);
+    MDG_CHECK_LAUNCH("traj_adj_kernel");
+    return MDG_OK;
+}

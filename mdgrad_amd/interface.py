@@ -1,0 +1,121 @@
+"""Energy calculators with the reference's interface (torchmd/interface.py):
+GeneralInteraction :33-57, PairPotentials :217-300, Stack :364-403 (GNNPotentials lives in
+mdgrad_amd.nn).  forward(xyz) -> energy; _reset_topology(xyz) rebuilds the neighbour list.
+"""
+import inspect
+
+import torch
+from torch.nn import ModuleDict
+
+from . import _lib, ops
+from .potentials import is_builtin_form
+from .topology import compute_dis
+
+
+class GeneralInteraction(torch.nn.Module):
+    def __init__(self, system):
+        super().__init__()
+        self.system = system
+        self.device = system.device
+        self.cell = torch.Tensor(system.get_cell()).to(system.device)     # interface.py:55-56
+        self.cell.requires_grad = True
+        self._cell_struct = _lib.make_cell(system.get_cell())
+
+
+class _LazyTopology:
+    """(nbr_list, pair_dis, offsets) of PairPotentials._reset_topology, materialised on demand
+    (the integrators ignore the return value; materialising costs a host sync)."""
+
+    def __init__(self, owner, xyz):
+        self._owner, self._xyz, self._val = owner, xyz, None
+
+    def _get(self):
+        if self._val is None:
+            nbr, off = self._owner._ell.half_list()
+            dis = compute_dis(self._xyz, nbr, off, self._owner.cell.detach()).reshape(-1)
+            self._val = (nbr, dis, off)
+        return self._val
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __len__(self):
+        return 3
+
+
+class PairPotentials(GeneralInteraction):
+    """torchmd/interface.py:217-300.  `pair_model` is a module instance (the code's signature)
+    or, as in the README snippet, a class plus its keyword arguments."""
+
+    def __init__(self, system, pair_model, cutoff=2.5, index_tuple=None, ex_pairs=None,
+                 nbr_list_device=None, **model_kwargs):
+        super().__init__(system)
+        if inspect.isclass(pair_model):
+            pair_model = pair_model(**model_kwargs)
+        elif model_kwargs:
+            raise TypeError("unexpected keyword arguments %s" % list(model_kwargs))
+        self.nbr_list_device = system.device if nbr_list_device is None else nbr_list_device
+        self.model = pair_model.to(system.device)
+        self.cutoff = cutoff
+        self.index_tuple = index_tuple
+        self.ex_pairs = ex_pairs
+        self._mask = ops.build_mask(system.get_number_of_atoms(), index_tuple, ex_pairs, system.device)
+        self._nbr_override = None
+        self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
+
+    # -- kernel-facing description ------------------------------------------------------
+    def builtin(self):
+        return is_builtin_form(self.model)
+
+    def mdg_term(self, theta_off=0):
+        params = self.model.mdg_params()
+        return ops.make_term(self.model.mdg_term(), self.cutoff, theta_off,
+                             sum(p.numel() for p in params), self._mask)
+
+    # -- reference attributes -----------------------------------------------------------
+    @property
+    def nbr_list(self):
+        """[P,2] int64 half list.  (The reference parks it on the CPU, interface.py:259; it
+        stays on the device here.)"""
+        return self._ell.half_list()[0]
+
+    @property
+    def offsets(self):
+        return self._ell.half_list()[1]
+
+    def _reset_topology(self, xyz):
+        self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask)
+        return _LazyTopology(self, xyz.detach())
+
+    def forward(self, xyz):
+        if self.builtin():
+            params = self.model.mdg_params()
+            theta = (torch.cat([p.reshape(-1) for p in params]) if params
+                     else xyz.new_zeros(0))
+            return ops.PairEnergyFn.apply(xyz.contiguous(), theta, self._ell, self.mdg_term(0))
+        # user-defined pair module (e.g. an MLP): distances with torch ops on the device
+        nbr, off = self._ell.half_list()
+        pair_dis = compute_dis(xyz, nbr, off, self.cell)
+        return self.model(pair_dis).sum()
+
+
+class Stack(torch.nn.Module):
+    """torchmd/interface.py:364-403."""
+
+    def __init__(self, model_dict, mode='sum'):
+        super().__init__()
+        self.models = ModuleDict(model_dict)
+
+    def _reset_topology(self, x):
+        for key in self.models.keys():
+            self.models[key]._reset_topology(x)
+
+    def forward(self, x):
+        result = None
+        for key in self.models.keys():
+            new_result = self.models[key](x).sum().reshape(-1)
+            result = new_result if result is None else result + new_result
+        return result

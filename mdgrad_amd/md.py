@@ -1,0 +1,227 @@
+"""Simulation driver and equations of motion with the reference's interface
+(torchmd/md.py): Simulations :14-96, NVE :98-157, NoseHooverChain :159-249.
+
+`forward(t, state)` is the generic right-hand side (torch ops around the HIP energy ops,
+differentiable twice) that the reference's Python solvers call; `fused_spec(method)` describes
+the same dynamics to the fused HIP trajectory kernels when that is possible.
+"""
+import numpy as np
+import torch
+
+from . import units, ops
+from .interface import PairPotentials, Stack
+from .sovlers import odeint_adjoint, odeint
+from .system import wrap_positions
+from .tinydiffeq import _flatten
+
+FUSED_MAX_ATOMS = 1024
+
+
+def compute_grad(inputs, output, create_graph=True, retain_graph=True):
+    """nff/utils/scatter.py:5-21."""
+    assert inputs.requires_grad
+    (g,) = torch.autograd.grad(output, inputs, grad_outputs=output.data.new(output.shape).fill_(1),
+                               create_graph=create_graph, retain_graph=retain_graph)
+    return g
+
+
+class Simulations():
+    """torchmd/md.py:14-96: runs `steps // frequency` epochs of `frequency` time points each,
+    logs the last frame of every epoch on the host, restarts each epoch from the (wrapped)
+    checkpoint and returns the trajectories of the LAST epoch (only they carry gradient)."""
+
+    def __init__(self, system, integrator, wrap=True, method="NH_verlet"):
+        self.system = system
+        self.device = system.device
+        self.integrator = integrator
+        self.solvemethod = method
+        self.wrap = wrap
+        self.keys = self.integrator.state_keys
+        self.initialize_log()
+
+    def initialize_log(self):
+        self.log = {key: [] for key in self.keys}
+
+    def update_log(self, trajs):
+        for i, key in enumerate(self.keys):
+            self.log[key].append(trajs[i][-1].detach().cpu().numpy())
+
+    def update_states(self):
+        if "positions" in self.log:
+            self.system.set_positions(self.log['positions'][-1])
+        if "velocities" in self.log:
+            self.system.set_velocities(self.log['velocities'][-1])
+
+    def get_check_point(self):
+        if not hasattr(self, 'log'):
+            raise ValueError("No log available")
+        states = [torch.Tensor(self.log[key][-1]).to(self.device) for key in self.log]
+        if self.wrap:
+            wrapped_xyz = wrap_positions(self.log['positions'][-1], self.system.get_cell())
+            states[1] = torch.Tensor(wrapped_xyz).to(self.device)
+        return states
+
+    def simulate(self, steps=1, dt=1.0 * units.fs, frequency=1):
+        if self.log['positions'] == []:
+            states = self.integrator.get_inital_states(self.wrap)
+        else:
+            states = self.get_check_point()
+        sim_epochs = int(steps // frequency)
+        t = torch.Tensor([dt * i for i in range(frequency)]).to(self.device)
+        trajs = None
+        for epoch in range(sim_epochs):
+            if self.integrator.adjoint:
+                trajs = odeint_adjoint(self.integrator, states, t, method=self.solvemethod)
+            else:
+                for var in states:
+                    var.requires_grad = True
+                trajs = odeint(self.integrator, tuple(states), t, method=self.solvemethod)
+            self.update_log(trajs)
+            self.update_states()
+            states = self.get_check_point()
+        return trajs
+
+
+def _pair_terms_of(model):
+    """PairPotentials terms of `model` in parameter order, or None when something else
+    (a GNN, a user module, a non-built-in pair form) takes part."""
+    if isinstance(model, PairPotentials):
+        mods = [model]
+    elif isinstance(model, Stack):
+        mods = list(model.models.values())
+    else:
+        return None
+    for m in mods:
+        if not isinstance(m, PairPotentials) or not m.builtin():
+            return None
+    return mods if 1 <= len(mods) <= 4 else None
+
+
+class _FusedSpec(ops.FusedSpec):
+    def __init__(self, integrator, *a, **k):
+        super().__init__(*a, **k)
+        self._integrator = integrator
+
+    def flat_params(self):
+        return _flatten(self._integrator.parameters())          # sovlers.py:319
+
+
+class _EOM(torch.nn.Module):
+    _ensemble = None
+    _method = None
+
+    def update_topology(self, q):                               # md.py:200-204
+        if self.update_count % self.topology_update_freq == 0:
+            self.model._reset_topology(q)
+        self.update_count += 1
+
+    def fused_spec(self, method):
+        """FusedSpec when the whole trajectory can run in the fused HIP kernels, else None."""
+        if method != self._method or self.topology_update_freq != 1 or self.dim != 3:
+            return None
+        mods = _pair_terms_of(self.model)
+        N = self.mass.shape[0]
+        if mods is None or N > FUSED_MAX_ATOMS or not self.adjoint:
+            return None
+        plist = list(self.parameters())
+        offs, pos = {}, 0
+        for p in plist:
+            offs[id(p)] = pos
+            pos += p.numel()
+        terms, masks = [], []
+        for m in mods:
+            mp = m.model.mdg_params()
+            off = offs[id(mp[0])] if mp else 0
+            for a, b in zip(mp[:-1], mp[1:]):
+                if offs[id(b)] != offs[id(a)] + a.numel():
+                    return None                                   # parameters not contiguous
+            terms.append(ops.make_term(m.model.mdg_term(), m.cutoff, off, sum(p.numel() for p in mp), m._mask))
+            masks.append(m._mask)
+        cs = mods[0]._cell_struct
+        kw = {}
+        if self._ensemble == 0:
+            if not 2 <= self.num_chains <= 16:
+                return None
+            kw = dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
+        return _FusedSpec(self, self._ensemble, N, self.mass.contiguous(), cs, ops.make_terms(terms, pos), pos,
+                          masks, **kw)
+
+
+class NVE(_EOM):
+    """torchmd/md.py:98-157 (dv/dt = F with no 1/m, :145-148)."""
+    _ensemble, _method = 1, 'verlet'
+
+    def __init__(self, potentials, system, adjoint=True, topology_update_freq=1):
+        super().__init__()
+        self.model = potentials
+        self.system = system
+        self.mass = torch.Tensor(system.get_masses()).to(self.system.device)
+        self.N_dof = self.mass.shape[0] * system.dim
+        self.dim = system.dim
+        self.adjoint = adjoint
+        self.state_keys = ['velocities', 'positions']
+        self.topology_update_freq = topology_update_freq
+        self.update_count = 0
+
+    def forward(self, t, state):
+        with torch.set_grad_enabled(True):
+            v, q = state[0], state[1]
+            if self.adjoint:
+                q.requires_grad = True
+            self.update_topology(q)
+            u = self.model(q)
+            f = -compute_grad(inputs=q, output=u.sum(-1))
+        return (f, v)
+
+    def get_inital_states(self, wrap=True):
+        states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap)]
+        return [torch.Tensor(var).to(self.system.device) for var in states]
+
+
+class NoseHooverChain(_EOM):
+    """torchmd/md.py:159-249."""
+    _ensemble, _method = 0, 'NH_verlet'
+
+    def __init__(self, potentials, system, T, num_chains=2, Q=1.0, adjoint=True, topology_update_freq=1):
+        super().__init__()
+        self.model = potentials
+        self.system = system
+        self.device = system.device
+        self.mass = torch.Tensor(system.get_masses()).to(self.device)
+        self.T = T
+        self.N_dof = self.mass.shape[0] * system.dim
+        self.target_ke = (0.5 * self.N_dof * T)
+        self.num_chains = num_chains
+        self.Q = np.array([Q, *[Q / self.system.get_number_of_atoms()] * (num_chains - 1)])
+        self.Q = torch.Tensor(self.Q).to(self.device)
+        self.dim = system.dim
+        self.adjoint = adjoint
+        self.state_keys = ['velocities', 'positions', 'baths']
+        self.topology_update_freq = topology_update_freq
+        self.update_count = 0
+
+    def update_T(self, T):
+        self.T = T
+
+    def forward(self, t, state):
+        with torch.set_grad_enabled(True):
+            v, q, p_v = state[0], state[1], state[2]
+            if self.adjoint:
+                q.requires_grad = True
+            p = v * self.mass[:, None]
+            sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()
+            self.update_topology(q)
+            u = self.model(q)
+            f = -compute_grad(inputs=q, output=u.sum(-1))
+            coupled_forces = (p_v[0] * p.reshape(-1) / self.Q[0]).reshape(-1, 3)
+            dpdt = f - coupled_forces
+            dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[0] * p_v[1] / self.Q[1]
+            dpvdt_mid = (p_v[:-2].pow(2) / self.Q[:-2] - self.T) - p_v[2:] * p_v[1:-1] / self.Q[2:]
+            dpvdt_last = p_v[-2].pow(2) / self.Q[-2] - self.T
+            dvdt = dpdt / self.mass[:, None]
+        return (dvdt, v, torch.cat((dpvdt_0[None], dpvdt_mid, dpvdt_last[None])))
+
+    def get_inital_states(self, wrap=True):
+        states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap),
+                  [0.0] * self.num_chains]
+        return [torch.Tensor(var).to(self.system.device) for var in states]

@@ -1,0 +1,335 @@
+"""Device ops: thin Python over the C ABI (include/mdgrad_hip.h) plus the
+torch.autograd.Function wrappers that own the differentiation contract
+
+    PairEnergyFn -> PairGradFn -> (Hessian-vector product)     pair potentials, any order <= 2
+    FusedTrajFn                                                 whole NH-Verlet/Verlet trajectory + adjoint
+    RdfRawFn                                                    soft histogram
+
+Everything here requires HIP tensors; there is no CPU path.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import MdgCell, MdgPairTerm, MdgTerms, MdgTrajParams, check, ptr, stream_ptr, require_gpu
+
+
+# ----------------------------------------------------------------------------- neighbour lists
+def build_mask(n_atoms, index_tuple=None, ex_pairs=None, device=None):
+    """[N,N] uint8 selection equivalent to the reference's multiplicative masks
+    (torchmd/topology.py:15-27 index_tuple product, :44-53 ex_pairs).  None when unrestricted."""
+    if index_tuple is None and ex_pairs is None:
+        return None
+    keep = torch.ones(n_atoms, n_atoms, dtype=torch.bool)
+    if index_tuple is not None:
+        a = torch.as_tensor(list(index_tuple[0]), dtype=torch.long)
+        b = torch.as_tensor(list(index_tuple[1]), dtype=torch.long)
+        sel = torch.zeros(n_atoms, n_atoms, dtype=torch.bool)
+        sel[a[:, None], b[None, :]] = True
+        keep &= sel | sel.t()
+    if ex_pairs is not None:
+        ex = torch.as_tensor(ex_pairs, dtype=torch.long).reshape(-1, 2).cpu()
+        keep[ex[:, 0], ex[:, 1]] = False
+        keep[ex[:, 1], ex[:, 0]] = False
+    return keep.to(torch.uint8).contiguous().to(device)
+
+
+def estimate_max_nbr(n_atoms, cell_struct, cutoff):
+    h = cell_struct.h
+    vol = abs(h[0] * (h[4] * h[8] - h[5] * h[7]) - h[1] * (h[3] * h[8] - h[5] * h[6])
+              + h[2] * (h[3] * h[7] - h[4] * h[6]))
+    est = n_atoms / max(vol, 1e-30) * 4.0 / 3.0 * math.pi * cutoff ** 3
+    cap = int(est * 1.5) + 16
+    cap = (cap + 7) // 8 * 8
+    return max(8, min(max(n_atoms - 1, 1), cap))
+
+
+class EllList:
+    """Immutable device snapshot of one neighbour list (layout: include/mdgrad_hip.h K1)."""
+
+    def __init__(self, n_atoms, max_nbr, col, shift, cnt, cell_struct, cutoff, mask):
+        self.n_atoms, self.max_nbr = n_atoms, max_nbr
+        self.col, self.shift, self.cnt = col, shift, cnt
+        self.cell_struct, self.cutoff, self.mask = cell_struct, cutoff, mask
+        self._half = None
+
+    def half_list(self, with_edge_id=False):
+        """(nbr int64 [P,2], offsets f32 [P,3][, edge_id int32 [N,max_nbr]]) in the reference's
+        lexicographic i<j order (torchmd/topology.py:68-73).  One host sync (P)."""
+        if self._half is None or (with_edge_id and self._half[2] is None):
+            lib = _lib.load()
+            dev = self.col.device
+            row_base = torch.empty(self.n_atoms + 1, dtype=torch.int32, device=dev)
+            st = stream_ptr(dev)
+            check(lib.mdg_nbr_half_count(ptr(self.col), ptr(self.cnt), self.n_atoms, self.max_nbr,
+                                         ptr(row_base), st), "mdg_nbr_half_count")
+            P = int(row_base[-1].item())
+            nbr = torch.empty(P, 2, dtype=torch.int64, device=dev)
+            off = torch.empty(P, 3, dtype=torch.float32, device=dev)
+            eid = (torch.zeros(self.n_atoms, self.max_nbr, dtype=torch.int32, device=dev)
+                   if with_edge_id else None)
+            check(lib.mdg_nbr_half_fill(ptr(self.col), ptr(self.shift), ptr(self.cnt), ptr(row_base),
+                                        self.n_atoms, self.max_nbr, ptr(nbr), ptr(off), ptr(eid), st),
+                  "mdg_nbr_half_fill")
+            self._half = (nbr, off, eid)
+        return self._half if with_edge_id else self._half[:2]
+
+
+def _use_cell_list(n_atoms, cs, cutoff):
+    if not cs.diag or n_atoms < 512:
+        return False
+    return all(cs.h[4 * d] / cutoff >= 3.0 for d in range(3))
+
+
+def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto"):
+    """Neighbour list of one frame xyz[N,3] (replaces generate_nbr_list).  method: auto|dense|cell."""
+    require_gpu(xyz, "xyz")
+    lib = _lib.load()
+    xyz = xyz.detach().contiguous()
+    N, dev = xyz.shape[0], xyz.device
+    cutoff = float(cutoff)
+    cap = estimate_max_nbr(N, cell_struct, cutoff) if max_nbr is None else int(max_nbr)
+    use_cell = method == "cell" or (method == "auto" and _use_cell_list(N, cell_struct, cutoff))
+    st = stream_ptr(dev)
+    while True:
+        col = torch.empty(N, cap, dtype=torch.int32, device=dev)
+        shift = torch.empty(N, cap, dtype=torch.int32, device=dev)
+        cnt = torch.empty(N, dtype=torch.int32, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        if use_cell:
+            ns = lib.mdg_nbr_cell_scratch(N, C.byref(cell_struct), cutoff)
+            scratch = torch.empty(int(ns), dtype=torch.int32, device=dev)
+            check(lib.mdg_nbr_build_cell(ptr(xyz), N, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
+                                         ptr(shift), ptr(cnt), cap, ptr(overflow), ptr(scratch), st),
+                  "mdg_nbr_build_cell")
+        else:
+            check(lib.mdg_nbr_build_dense(ptr(xyz), N, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
+                                          ptr(shift), ptr(cnt), cap, ptr(overflow), st),
+                  "mdg_nbr_build_dense")
+        if cap >= N - 1:
+            break                                   # cannot overflow
+        need = int(overflow.item())
+        if need <= cap:
+            break
+        cap = min(N - 1, (need + 15) // 8 * 8)
+    return EllList(N, cap, col, shift, cnt, cell_struct, cutoff, mask)
+
+
+# ----------------------------------------------------------------------------- pair potentials
+def make_term(desc, cutoff, theta_off=0, n_theta=0, mask=None):
+    t = MdgPairTerm()
+    t.kind = desc["kind"]
+    t.p, t.q, t.c = desc.get("p", 0), desc.get("q", 0), desc.get("c", 0.0)
+    t.a, t.phi = desc.get("a", 0.0), desc.get("phi", 0.0)
+    t.cutoff = float(cutoff)
+    t.theta_off, t.n_theta = theta_off, n_theta
+    t.mask = mask.data_ptr() if mask is not None else None
+    return t
+
+
+def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True):
+    """One launch of mdg_pair_eval_ell.  Returns dict with the requested outputs."""
+    lib = _lib.load()
+    dev = xyz.device
+    N, K = ell.n_atoms, term.n_theta
+    out = {}
+    e = torch.empty(1, device=dev) if energy else None
+    g = torch.empty(N, 3, device=dev) if grad else None
+    gth = torch.empty(K, device=dev) if (grad and K) else None
+    hw = torch.empty(N, 3, device=dev) if w is not None else None
+    gthw = torch.empty(K, device=dev) if (w is not None and K) else None
+    partial = torch.empty(int(lib.mdg_pair_partial_size(N)), device=dev)
+    check(lib.mdg_pair_eval_ell(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
+                                ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
+                                ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), stream_ptr(dev)),
+          "mdg_pair_eval_ell")
+    out.update(energy=e, grad=g, gtheta=gth, hw=hw, gtheta_w=gthw)
+    return out
+
+
+class PairGradFn(torch.autograd.Function):
+    """(dU/dx, dU/dtheta) as a differentiable op; backward = Hessian-vector product and the
+    mixed theta-derivative (the second autograd pass of torchmd/sovlers.py:229-233).
+    Second derivatives w.r.t. theta alone (a cotangent on dU/dtheta) are not supported."""
+
+    @staticmethod
+    def forward(ctx, xyz, theta, ell, term, cache):
+        ctx.ell, ctx.term = ell, term
+        ctx.save_for_backward(xyz, theta)
+        if cache is not None:
+            g, gth = cache
+        else:
+            o = pair_eval(ell, xyz, term, theta, energy=False, grad=True)
+            g, gth = o["grad"], o["gtheta"]
+        if gth is None:
+            gth = xyz.new_zeros(0)
+        return g, gth
+
+    @staticmethod
+    def backward(ctx, wg, wgth):
+        xyz, theta = ctx.saved_tensors
+        w = wg.detach().contiguous()
+        o = pair_eval(ctx.ell, xyz, ctx.term, theta, w=w, energy=False, grad=False)
+        gthw = o["gtheta_w"] if o["gtheta_w"] is not None else None
+        return o["hw"], gthw, None, None, None
+
+
+class PairEnergyFn(torch.autograd.Function):
+    """U(x, theta) = sum_pairs phi(r)  (torchmd/interface.py:298-300), differentiable twice."""
+
+    @staticmethod
+    def forward(ctx, xyz, theta, ell, term):
+        o = pair_eval(ell, xyz, term, theta, energy=True, grad=True)
+        ctx.ell, ctx.term = ell, term
+        ctx.cache = (o["grad"], o["gtheta"])
+        ctx.save_for_backward(xyz, theta)
+        return o["energy"].reshape(())
+
+    @staticmethod
+    def backward(ctx, gU):
+        xyz, theta = ctx.saved_tensors
+        g, gth = PairGradFn.apply(xyz, theta, ctx.ell, ctx.term, ctx.cache)
+        gtheta = gU * gth if theta.numel() else None
+        return gU * g, gtheta, None, None
+
+
+# ----------------------------------------------------------------------------- fused trajectories
+class FusedSpec:
+    """Host-side descriptor of a fusable integrator (NoseHooverChain / NVE over built-in pair
+    terms, topology_update_freq == 1)."""
+
+    def __init__(self, ensemble, n_atoms, mass, cell_struct, terms, n_theta_total, masks,
+                 T=0.0, n_dof=0.0, Q=(), block=0):
+        self.ensemble, self.n_atoms, self.mass = ensemble, n_atoms, mass
+        self.cell_struct, self.terms, self.n_theta_total, self.masks = cell_struct, terms, n_theta_total, masks
+        self.T, self.n_dof, self.Q, self.block = float(T), float(n_dof), list(Q), block
+
+    def params(self, n_rep, n_frames):
+        p = MdgTrajParams()
+        p.n_rep, p.n_atoms, p.n_frames = n_rep, self.n_atoms, n_frames
+        p.n_chains, p.ensemble, p.block = len(self.Q), self.ensemble, self.block
+        p.T, p.n_dof = self.T, self.n_dof
+        for k, q in enumerate(self.Q):
+            p.Q[k] = q
+        return p
+
+
+def make_terms(term_list, n_theta_total):
+    ts = MdgTerms()
+    ts.n_terms, ts.n_theta_total = len(term_list), n_theta_total
+    for k, t in enumerate(term_list):
+        ts.t[k] = t
+    return ts
+
+
+class FusedTrajFn(torch.autograd.Function):
+    """odeint_adjoint(NoseHooverChain|NVE, (v0,q0[,pv0]), t) in two launches: the forward
+    trajectory and, on backward, the reference's adjoint sweep (torchmd/sovlers.py:196-293).
+    States may carry a leading replica dimension [R,N,3]."""
+
+    @staticmethod
+    def forward(ctx, v0, q0, pv0, t, theta, spec):
+        lib = _lib.load()
+        require_gpu(v0, "v0"), require_gpu(q0, "q0"), require_gpu(t, "t")
+        batched = v0.dim() == 3
+        R = v0.shape[0] if batched else 1
+        N, T = spec.n_atoms, t.shape[0]
+        dev = v0.device
+        nhc = spec.ensemble == 0
+        Cn = len(spec.Q)
+        v0c, q0c = v0.detach().contiguous(), q0.detach().contiguous()
+        pv0c = pv0.detach().contiguous() if nhc else None
+        tc = t.detach().to(torch.float32).contiguous()
+        thc = theta.detach().contiguous() if theta is not None and theta.numel() else None
+        v_t = torch.empty(R, T, N, 3, device=dev)
+        q_t = torch.empty(R, T, N, 3, device=dev)
+        pv_t = torch.empty(R, T, Cn, device=dev) if nhc else None
+        bad = torch.zeros(R, dtype=torch.int32, device=dev)
+        prm = spec.params(R, T)
+        check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                     ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
+                                     ptr(q_t), ptr(pv_t), ptr(bad), stream_ptr(dev)), "mdg_traj_fwd_small")
+        ctx.spec, ctx.batched, ctx.nhc = spec, batched, nhc
+        ctx.nonfinite = bad
+        saved = [tc, v_t, q_t] + ([pv_t] if nhc else []) + ([thc] if thc is not None else [])
+        ctx.has_theta = thc is not None
+        ctx.save_for_backward(*saved)
+        outs = (v_t, q_t, pv_t) if nhc else (v_t, q_t)
+        if not batched:
+            outs = tuple(o[0] for o in outs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        lib = _lib.load()
+        spec, nhc = ctx.spec, ctx.nhc
+        saved = list(ctx.saved_tensors)
+        tc, v_t, q_t = saved[0], saved[1], saved[2]
+        pv_t = saved[3] if nhc else None
+        thc = saved[-1] if ctx.has_theta else None
+        R, T, N = v_t.shape[0], v_t.shape[1], spec.n_atoms
+        dev = v_t.device
+
+        def prep(g, like):
+            if g is None:
+                return None
+            g = g.detach()
+            if not ctx.batched:
+                g = g[None]
+            return g.expand_as(like).contiguous()
+
+        gv = prep(grads[0], v_t)
+        gq = prep(grads[1], q_t)
+        gp = prep(grads[2], pv_t) if nhc else None
+        adj_v = torch.empty(R, N, 3, device=dev)
+        adj_q = torch.empty(R, N, 3, device=dev)
+        adj_p = torch.empty(R, len(spec.Q), device=dev) if nhc else None
+        KT = spec.n_theta_total
+        adj_th = torch.zeros(R, KT, device=dev) if KT else None
+        prm = spec.params(R, T)
+        check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                     ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                     ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                     stream_ptr(dev)), "mdg_traj_adj_small")
+        if not ctx.batched:
+            adj_v, adj_q = adj_v[0], adj_q[0]
+            adj_p = adj_p[0] if nhc else None
+        gth = adj_th.sum(0) if adj_th is not None else None
+        return adj_v, adj_q, adj_p, None, gth, None
+
+
+# ----------------------------------------------------------------------------- rdf
+class RdfRawFn(torch.autograd.Function):
+    """raw[k] = sum over frames and i<j pairs (d < cutoff) of exp(coeff (d - mu_k)^2)
+    (the GaussianSmearing(...).sum(0) of torchmd/observable.py:70)."""
+
+    @staticmethod
+    def forward(ctx, xyz, mu, coeff, cutoff, cell_struct, mask):
+        lib = _lib.load()
+        require_gpu(xyz, "xyz")
+        x = xyz.detach().contiguous()
+        x3 = x.reshape(-1, x.shape[-2], 3)
+        F, N, B = x3.shape[0], x3.shape[1], mu.shape[0]
+        dev = x.device
+        raw = torch.empty(B, device=dev)
+        partial = torch.empty(int(lib.mdg_rdf_partial_size(F, N, B)), device=dev)
+        muc = mu.detach().to(torch.float32).contiguous()
+        check(lib.mdg_rdf_fwd(ptr(x3), F, N, C.byref(cell_struct), float(cutoff), ptr(mask), ptr(muc),
+                              float(coeff), B, ptr(raw), ptr(partial), stream_ptr(dev)), "mdg_rdf_fwd")
+        ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape)
+        ctx.save_for_backward(x3, muc)
+        return raw
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        lib = _lib.load()
+        x3, muc = ctx.saved_tensors
+        coeff, cutoff, cell_struct, mask, shape = ctx.args
+        F, N, B = x3.shape[0], x3.shape[1], muc.shape[0]
+        gx = torch.empty_like(x3)
+        gr = g_raw.detach().to(torch.float32).contiguous()
+        check(lib.mdg_rdf_bwd(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), coeff, B,
+                              ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
+        return gx.reshape(shape), None, None, None, None, None

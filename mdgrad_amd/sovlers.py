@@ -1,0 +1,200 @@
+"""Solvers and the adjoint engine (module name keeps the reference's spelling,
+torchmd/sovlers.py; `mdgrad_amd.solvers` is an alias).
+
+Two execution paths behind the same odeint / odeint_adjoint API:
+
+  fused    the integrator is a NoseHooverChain / NVE over built-in pair potentials with
+           topology_update_freq == 1 and the matching method ('NH_verlet' / 'verlet'):
+           ops.FusedTrajFn runs the whole forward trajectory in ONE HIP launch and the whole
+           adjoint sweep in ONE launch (csrc/traj_small.hip).
+  generic  anything else (GNN potentials, user modules, stale neighbour lists, rk4): the
+           reference's Python control flow, with every energy evaluation and its first and
+           second derivatives served by HIP autograd ops.  Call pattern, update order and
+           the topology counter are the reference's (sovlers.py:106-168, 196-293).
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .tinydiffeq import (FixedGridODESolver, RK4, _check_inputs, _flatten,
+                         _flatten_convert_none_to_zeros)
+
+
+def NHverlet_update(func, t, dt, y):
+    """One NH-Verlet step as increments (sovlers.py:106-168).  3 states = forward, 8 states =
+    augmented (state, adjoint, adj_time, adj_params) integrated on the reversed grid."""
+    if len(y) == 3:
+        v, q, pv = y
+        a0, _, b0 = func(t, y)
+        dv_h = 1 / 2 * a0 * dt
+        dp_h = 1 / 2 * b0 * dt
+        dq = (v + dv_h) * dt
+        a1, _, b1 = func(t, (v + dv_h, q + dq, pv + dp_h))
+        return (dv_h + 1 / 2 * a1 * dt, dq, dp_h + 1 / 2 * b1 * dt)
+    if len(y) == 8:
+        k0 = func(t, y)
+        dv_h = 1 / 2 * k0[0] * dt
+        dp_h = 1 / 2 * k0[2] * dt
+        dq = (y[0] + dv_h) * dt                       # forward-time sign, as the reference
+        half = tuple(k0[i] * 0.5 * dt for i in range(3, 8))
+        k1 = func(t, (y[0] + dv_h, y[1] + dq, y[2] + dp_h) +
+                  tuple(y[i] + half[i - 3] for i in range(3, 8)))
+        return (dv_h + 1 / 2 * k1[0] * dt, dq, dp_h + 1 / 2 * k1[2] * dt) + \
+            tuple(k1[i] * dt for i in range(3, 8))
+    raise ValueError("received {} argumets integration, but should be {} for the forward call or {} "
+                     "for the backward call".format(len(y), 3, 8))
+
+
+def verlet_update(func, t, dt, y):
+    """One velocity-Verlet step as increments (sovlers.py:21-104); 2 states forward, 6 augmented."""
+    if len(y) == 2:
+        v, q = y
+        a0, _ = func(t, y)
+        dv_h = 0.5 * a0 * dt
+        dq = (v + dv_h) * dt
+        a1, _ = func(t, (v + dv_h, q + dq))
+        return (dv_h + 0.5 * a1 * dt, dq)
+    if len(y) == 6:
+        v, x, lv, lx = y[0], y[1], y[2], y[3]
+        dv, _, _, X0, vjp_t, Th0 = func(t, y)
+        dv_h = 1 / 2 * dv * dt
+        v_half = v - dv_h
+        dx = v_half * dt
+        x0 = x - dx
+        dlx = X0 * dt * 0.5
+        dlv = (lx + dlx) * dt
+        dth_half = Th0 * 0.5 * dt
+        dv2, _, _, X1, vjp_t2, _ = func(t, (v_half, x0, lv + dlv, lx + dlx, y[4] + vjp_t * dt,
+                                            y[5] + dth_half))
+        return (dv_h - dv2 * dt * 0.5, dx, dlv, X1 * dt * 0.5 + dlx, vjp_t2 * dt, dth_half * 2)
+    raise ValueError("received {} argumets integration, but should be {} for the forward call or {} "
+                     "for the backward call".format(len(y), 2, 6))
+
+
+class NHVerlet(FixedGridODESolver):
+    def step_func(self, func, t, dt, y):
+        return NHverlet_update(func, t, dt, y)
+
+
+class Verlet(FixedGridODESolver):
+    def step_func(self, func, t, dt, y):
+        return verlet_update(func, t, dt, y)
+
+
+SOLVERS = {'rk4': RK4, 'NH_verlet': NHVerlet, 'verlet': Verlet}
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
+    """sovlers.py:171-193 (generic path)."""
+    tensor_input, func, y0, t = _check_inputs(func, y0, t)
+    if options is None:
+        options = {}
+    elif method is None:
+        raise ValueError('cannot supply `options` without specifying `method`')
+    if method not in SOLVERS:
+        raise KeyError(method)
+    solution = SOLVERS[method](func, y0, rtol=rtol, atol=atol, **options).integrate(t)
+    return solution[0] if tensor_input else solution
+
+
+class OdeintAdjointMethod(torch.autograd.Function):
+    """Generic adjoint (sovlers.py:196-293): forward without graph, backward integrates the
+    augmented system interval by interval through autograd double-backward of func."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        y0, func, t, flat_params, rtol, atol, method, options = \
+            args[:-7], args[-7], args[-6], args[-5], args[-4], args[-3], args[-2], args[-1]
+        ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, rtol, atol, method, options
+        with torch.no_grad():
+            ans = odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
+        ctx.save_for_backward(t, flat_params, *ans)
+        return ans
+
+    @staticmethod
+    def backward(ctx, *grad_output):
+        t, flat_params, *ans = ctx.saved_tensors
+        ans = tuple(ans)
+        func, rtol, atol, method, options = ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options
+        n = len(ans)
+        f_params = tuple(func.parameters())
+
+        def augmented_dynamics(t_, y_aug):                     # sovlers.py:221-245
+            y, adj_y = y_aug[:n], y_aug[n:2 * n]
+            with torch.set_grad_enabled(True):
+                t_ = t_.to(y[0].device).detach().requires_grad_(True)
+                y = tuple(y_.detach().requires_grad_(True) for y_ in y)
+                f_eval = func(t_, y)
+                vjp_t, *vjp_rest = torch.autograd.grad(
+                    f_eval, (t_,) + y + f_params, tuple(-a for a in adj_y),
+                    allow_unused=True, retain_graph=True)
+            vjp_y, vjp_p = vjp_rest[:n], vjp_rest[n:]
+            vjp_t = torch.zeros_like(t_) if vjp_t is None else vjp_t
+            vjp_y = tuple(torch.zeros_like(b) if a is None else a for a, b in zip(vjp_y, y))
+            vjp_p = _flatten_convert_none_to_zeros(vjp_p, f_params)
+            if len(f_params) == 0:
+                vjp_p = torch.tensor(0.).to(vjp_y[0])
+            return (*f_eval, *vjp_y, vjp_t, vjp_p)
+
+        T = ans[0].shape[0]
+        with torch.no_grad():
+            adj_y = tuple(g[-1] for g in grad_output)
+            adj_params = torch.zeros_like(flat_params)
+            adj_time = torch.tensor(0.).to(t)
+            time_vjps = []
+            for i in range(T - 1, 0, -1):
+                ans_i = tuple(a[i] for a in ans)
+                g_i = tuple(g[i] for g in grad_output)
+                f_i = func(t[i], ans_i)                       # sovlers.py:258 (advances the topology counter)
+                dLd_cur_t = sum(torch.dot(a.reshape(-1), b.reshape(-1)).reshape(1) for a, b in zip(f_i, g_i))
+                adj_time = adj_time - dLd_cur_t
+                time_vjps.append(dLd_cur_t)
+                if adj_params.numel() == 0:
+                    adj_params = torch.tensor(0.).to(adj_y[0])
+                aug_y0 = (*ans_i, *adj_y, adj_time, adj_params)
+                aug_ans = odeint(augmented_dynamics, aug_y0, torch.stack([t[i], t[i - 1]]),
+                                 rtol=rtol, atol=atol, method=method, options=options)
+                adj_y = tuple(a[1] for a in aug_ans[n:2 * n])
+                adj_time = aug_ans[2 * n][1]
+                adj_params = aug_ans[2 * n + 1][1]
+                adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
+                del aug_y0, aug_ans
+            time_vjps.append(adj_time)
+            time_vjps = torch.cat([x.reshape(-1) for x in time_vjps[::-1]])
+            return (*adj_y, None, time_vjps, adj_params, None, None, None, None, None)
+
+
+def _fused_spec_for(func, method):
+    get = getattr(func, "fused_spec", None)
+    if get is None:
+        return None
+    return get(method)
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None):
+    """sovlers.py:296-324.  Dispatches to the fused HIP trajectory when `func` allows it."""
+    if not isinstance(func, nn.Module):
+        raise ValueError('func is required to be an instance of nn.Module.')
+    spec = _fused_spec_for(func, method) if (isinstance(y0, (tuple, list)) and not options) else None
+    if spec is not None:
+        flat_params = spec.flat_params()
+        y0 = tuple(y0)
+        pv0 = y0[2] if spec.ensemble == 0 else None
+        return ops.FusedTrajFn.apply(y0[0], y0[1], pv0, t, flat_params, spec)
+
+    tensor_input = False
+    if torch.is_tensor(y0):
+        class TupleFunc(nn.Module):
+            def __init__(self, base_func):
+                super().__init__()
+                self.base_func = base_func
+
+            def forward(self, t, y):
+                return (self.base_func(t, y[0]),)
+
+        tensor_input = True
+        y0 = (y0,)
+        func = TupleFunc(func)
+    flat_params = _flatten(func.parameters())
+    ys = OdeintAdjointMethod.apply(*y0, func, t, flat_params, rtol, atol, method, options)
+    return ys[0] if tensor_input else ys
