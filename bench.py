@@ -41,7 +41,9 @@ def cpu_baseline(frames, dt, budget_s=12.0):
     """The CPU oracle (port of the reference algorithm, oracle/) on this host: the same 108-atom
     workload, one replica at a time, forward + rdf loss + adjoint; bounded to ~budget_s."""
     import oracle as O
-    nthreads = torch.get_num_threads()
+    # 108-atom tensors are far too small for one thread per core on a 100+-core host
+    nthreads = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(nthreads)
     _, pos, vel = make_inputs(1, 123, "cpu")
     cell = torch.tensor([4.8] * 3)
     t = torch.Tensor([dt * i for i in range(frames)])
@@ -138,7 +140,7 @@ def main():
                                   "velocity-Verlet, %d steps fwd + RDF(100 bins) loss + adjoint; "
                                   "%d replicas/GPU per pass" % (T - 1, R),
                       "replicas_per_gpu": R, "md_steps_per_pass": R * (T - 1), "parallelism": "replica-dp%d" % world,
-                      "loss": float(loss)}}
+                      "loss": float(loss.detach())}}
 
     if rank == 0:
         # ---- roofline of the dominant kernel (adjoint sweep), timed with HIP events on the

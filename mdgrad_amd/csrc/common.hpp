@@ -30,9 +30,11 @@ __device__ __forceinline__ int min_image(const MdgCell& c, float& dx, float& dy,
         sy = fmaf(dz, c.inv[7], fmaf(dy, c.inv[4], dx * c.inv[1]));
         sz = fmaf(dz, c.inv[8], fmaf(dy, c.inv[5], dx * c.inv[2]));
     }
-    const float ox = (sx < -0.5f ? 1.f : 0.f) - (sx > 0.5f ? 1.f : 0.f);
-    const float oy = (sy < -0.5f ? 1.f : 0.f) - (sy > 0.5f ? 1.f : 0.f);
-    const float oz = (sz < -0.5f ? 1.f : 0.f) - (sz > 0.5f ? 1.f : 0.f);
+    // -(s > .5) + (s < -.5)  ==  -clamp(rint(s), -1, 1): round-half-even maps the ties at
+    // +-0.5 to 0 exactly like the strict comparisons; the clamp reproduces |s| >= 1.5.
+    const float ox = -__builtin_amdgcn_fmed3f(rintf(sx), -1.f, 1.f);
+    const float oy = -__builtin_amdgcn_fmed3f(rintf(sy), -1.f, 1.f);
+    const float oz = -__builtin_amdgcn_fmed3f(rintf(sz), -1.f, 1.f);
     if (DIAG) {
         dx = fmaf(ox, c.h[0], dx); dy = fmaf(oy, c.h[4], dy); dz = fmaf(oz, c.h[8], dz);
     } else {
@@ -73,41 +75,65 @@ struct PairOut {
     float ddu_dth[MDG_MAX_THETA];
 };
 
+// Per-term constants hoisted out of the pair loop (parameters live in global memory).
+struct TermConst {
+    int kind, p, q;
+    float c, rc2;
+    float k0, k1, k2, k3, k4;   // LJ: sig, eps, 1/sig | Morse: a, phi, A, 1/(1+A) | Buck: A,B,C | Yukawa: eps,kappa
+};
+
+__device__ __forceinline__ TermConst term_prepare(const MdgPairTerm& t, const float* __restrict__ theta) {
+    TermConst c;
+    c.kind = t.kind; c.p = t.p; c.q = t.q; c.c = t.c; c.rc2 = t.cutoff * t.cutoff;
+    c.k0 = c.k1 = c.k2 = c.k3 = c.k4 = 0.f;
+    const float* th = theta + t.theta_off;
+    switch (t.kind) {
+    case MDG_PAIR_LJ: c.k0 = th[0]; c.k1 = th[1]; c.k2 = 1.0f / th[0]; break;
+    case MDG_PAIR_MORSE: {
+        c.k0 = t.a; c.k1 = t.phi;
+        c.k2 = t.phi >= 0.f ? 0.f : (expf(2.f * t.a / t.phi) - 2.f * expf(t.a / t.phi));
+        c.k3 = 1.f / (1.f + c.k2);
+    } break;
+    case MDG_PAIR_BUCK: c.k0 = th[0]; c.k1 = th[1]; c.k2 = th[2]; break;
+    default: c.k0 = th[0]; c.k1 = th[1]; break;
+    }
+    return c;
+}
+
+// phi and derivatives at squared distance d2.  r = d2 * rsq(d2), 1/r = rsq(d2) (v_rsq_f32, 1 ulp).
 // KIND >= 0 fixes the functional form at compile time (single-term specialisations);
-// KIND < 0 dispatches on t.kind at run time.
+// KIND < 0 dispatches on tc.kind at run time.
 template <int LEVEL, int KIND = -1>
-__device__ __forceinline__ void pair_eval(const MdgPairTerm& t, const float* __restrict__ th,
-                                          float r, PairOut& o) {
-    const float ir = 1.0f / r;
-    switch (KIND >= 0 ? KIND : t.kind) {
+__device__ __forceinline__ void pair_eval(const TermConst& tc, float d2, float& r, float& ir, PairOut& o) {
+    ir = __builtin_amdgcn_rsqf(d2);
+    r = d2 * ir;
+    switch (KIND >= 0 ? KIND : tc.kind) {
     case MDG_PAIR_LJ: {
-        const float sig = th[0], eps = th[1];
+        const float sig = tc.k0, eps = tc.k1, isig = tc.k2;
         const float s = sig * ir;
         float sp, sq;
-        if (t.p == 12 && t.q == 6) { const float s2 = s * s; sq = s2 * s2 * s2; sp = sq * sq; }
-        else { sp = ipow(s, t.p); sq = ipow(s, t.q); }
-        sq *= t.c;
-        const float fp = (float)t.p, fq = (float)t.q;
+        if (tc.p == 12 && tc.q == 6) { const float s2 = s * s; sq = s2 * s2 * s2; sp = sq * sq; }
+        else { sp = ipow(s, tc.p); sq = ipow(s, tc.q); }
+        sq *= tc.c;
+        const float fp = (float)tc.p, fq = (float)tc.q;
         o.u = 4.f * eps * (sp - sq);
         if (LEVEL >= 1) {
-            const float m1 = -fp * sp + fq * sq;
+            const float m1 = fq * sq - fp * sp;
             o.du = 4.f * eps * m1 * ir;
-            o.du_dth[0] = 4.f * eps * (-m1) / sig;
+            o.du_dth[0] = -4.f * eps * m1 * isig;
             o.du_dth[1] = 4.f * (sp - sq);
             if (LEVEL >= 2) {
                 o.d2u = 4.f * eps * (fp * (fp + 1.f) * sp - fq * (fq + 1.f) * sq) * ir * ir;
-                o.ddu_dth[0] = 4.f * eps * (-fp * fp * sp + fq * fq * sq) * ir / sig;
+                o.ddu_dth[0] = 4.f * eps * (fq * fq * sq - fp * fp * sp) * ir * isig;
                 o.ddu_dth[1] = 4.f * m1 * ir;
             }
         }
     } break;
     case MDG_PAIR_MORSE: {
-        const float a = t.a, ph = t.phi;
-        const float A = ph >= 0.f ? 0.f : (expf(2.f * a / ph) - 2.f * expf(a / ph));
+        const float a = tc.k0, ph = tc.k1, A = tc.k2, inv = tc.k3;
         const float rp = powf(r, ph);
         const float x = a * (1.f - rp) / ph;
         const float e1 = expf(x), e2 = e1 * e1;
-        const float inv = 1.f / (1.f + A);
         o.u = (e2 - 2.f * e1 - A) * inv;
         if (LEVEL >= 1) {
             const float ux = (2.f * e2 - 2.f * e1) * inv;
@@ -121,7 +147,7 @@ __device__ __forceinline__ void pair_eval(const MdgPairTerm& t, const float* __r
         }
     } break;
     case MDG_PAIR_BUCK: {
-        const float A = th[0], B = th[1], C = th[2];
+        const float A = tc.k0, B = tc.k1, C = tc.k2;
         const float e = expf(-B * r);
         const float ir2 = ir * ir, ir6 = ir2 * ir2 * ir2;
         o.u = A * e - C * ir6;
@@ -136,7 +162,7 @@ __device__ __forceinline__ void pair_eval(const MdgPairTerm& t, const float* __r
         }
     } break;
     default: {  // MDG_PAIR_YUKAWA
-        const float eps = th[0], kap = th[1];
+        const float eps = tc.k0, kap = tc.k1;
         const float e = expf(-kap * r);
         o.u = eps * e * ir;
         if (LEVEL >= 1) {

@@ -30,7 +30,7 @@ __global__ void pair_ell_kernel(const EllArgs A) {
 #pragma unroll
     for (int k = 0; k < NSCAL; ++k) vals[k] = 0.f;
     if (i < A.N) {
-        const float* th = A.theta + A.term.theta_off;
+        const TermConst tc = term_prepare(A.term, A.theta);
         const float xi = A.pos[3 * i], yi = A.pos[3 * i + 1], zi = A.pos[3 * i + 2];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
         if (LEVEL >= 2) { wxi = A.w[3 * i]; wyi = A.w[3 * i + 1]; wzi = A.w[3 * i + 2]; }
@@ -41,12 +41,11 @@ __global__ void pair_ell_kernel(const EllArgs A) {
             const int j = A.col[row + k];
             float dx = xi - A.pos[3 * j], dy = yi - A.pos[3 * j + 1], dz = zi - A.pos[3 * j + 2];
             apply_shift(A.cell, A.shift[row + k], dx, dy, dz);      // d = x_i - x_j - o.h
-            const float r = sqrtf(dx * dx + dy * dy + dz * dz);
             PairOut o;
-            pair_eval<LEVEL>(A.term, th, r, o);
+            float r, ir;
+            pair_eval<LEVEL>(tc, dx * dx + dy * dy + dz * dz, r, ir, o);
             vals[0] += 0.5f * o.u;
             if (LEVEL >= 1) {
-                const float ir = 1.0f / r;
                 const float rx = dx * ir, ry = dy * ir, rz = dz * ir;
                 gx = fmaf(o.du, rx, gx); gy = fmaf(o.du, ry, gy); gz = fmaf(o.du, rz, gz);
 #pragma unroll

@@ -47,6 +47,10 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
     const int nt = NT == 1 ? 1 : A.terms.n_terms;
+    TermConst tc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
     for (int i = slot; i < N; i += slots) {
         const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
@@ -60,27 +64,26 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
 #pragma unroll
             for (int m = 0; m < NT; ++m) {
                 if (m >= nt) break;
-                const MdgPairTerm& tm = A.terms.t[m];
-                if (!(d2 < tm.cutoff * tm.cutoff)) continue;
-                if (tm.mask && !tm.mask[(size_t)i * N + j]) continue;
-                const float r = sqrtf(d2);
+                if (!(d2 < tc[m].rc2)) continue;
+                const uint8_t* mk = A.terms.t[m].mask;
+                if (mk && !mk[(size_t)i * N + j]) continue;
                 PairOut o;
-                pair_eval<LEVEL, KIND>(tm, A.theta + tm.theta_off, r, o);
-                const float ir = 1.0f / r;
+                float r, ir;
+                pair_eval<LEVEL, KIND>(tc[m], d2, r, ir, o);
                 const float c1 = o.du * ir;              // F_i += phi' * D / r   (rhat = -D/r)
                 fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
                 if (LEVEL >= 2) {
                     const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
                     const float ax = wxi - w[j], ay = wyi - w[N + j], az = wzi - w[2 * N + j];
                     const float a = rx * ax + ry * ay + rz * az;
-                    const float c2 = o.d2u * a, c3 = o.du * ir;
-                    // hv = phi'' a rhat + (phi'/r)(wij - a rhat);   dq_i -= hv
-                    gx -= c2 * rx + c3 * (ax - a * rx);
-                    gy -= c2 * ry + c3 * (ay - a * ry);
-                    gz -= c2 * rz + c3 * (az - a * rz);
+                    const float c2 = o.d2u * a - c1 * a, c3 = c1;
+                    // hv = phi'' a rhat + (phi'/r)(wij - a rhat) = (phi'' - phi'/r) a rhat + (phi'/r) wij
+                    gx -= c2 * rx + c3 * ax;
+                    gy -= c2 * ry + c3 * ay;
+                    gz -= c2 * rz + c3 * az;
 #pragma unroll
                     for (int k = 0; k < MDG_MAX_THETA; ++k)
-                        if (k < tm.n_theta) dth[m * MDG_MAX_THETA + k] -= 0.5f * o.ddu_dth[k] * a;
+                        if (k < A.terms.t[m].n_theta) dth[m * MDG_MAX_THETA + k] -= 0.5f * o.ddu_dth[k] * a;
                 }
             }
         }
