@@ -16,39 +16,42 @@
 
 namespace {
 
-constexpr int RDF_BLOCK = 256;
-constexpr int RDF_MAX_BLOCKS = 2048;     // persistent blocks: each strides over (frame, chunk) work items
-constexpr int RDF_CHUNK = 4096;          // candidate pairs per work item
+constexpr int RDF_BLOCK = 512;
+constexpr int RDF_MAX_BLOCKS = 1024;     // persistent blocks: each strides over (frame, chunk) work items
+constexpr int RDF_CHUNK = 8192;          // candidate pairs per work item
+constexpr float LOG2E = 1.4426950408889634f;
 
 // flat index c in [0, N(N-1)/2) -> (i, j), i < j, row-major (the order torch.nonzero yields)
 __device__ __forceinline__ void pair_from_flat(long long c, int N, int& i, int& j) {
     const double b = 2.0 * N - 1.0;
     int ii = (int)((b - sqrt(b * b - 8.0 * (double)c)) * 0.5);
-    // fix rounding: row ii starts at ii*(2N-ii-1)/2
     while ((long long)ii * (2LL * N - ii - 1) / 2 > c) --ii;
     while ((long long)(ii + 1) * (2LL * N - ii - 2) / 2 <= c) ++ii;
     i = ii;
     j = (int)(c - (long long)ii * (2LL * N - ii - 1) / 2) + ii + 1;
 }
 
+// exp(coeff (d - mu)^2) = exp2(-(s d - s mu)^2) with s = sqrt(-coeff log2 e): distances and
+// the sweep costs sub, mul, mul, v_exp_f32, add per (pair, bin).
+//
+// Thread layout: nbins <= RDF_BLOCK.  G = RDF_BLOCK / nbins thread groups; thread (g, k) owns
+// bin k and sweeps the compacted distances 4g..4g+3, 4(g+G).., ... (ds_read_b128); the groups
+// are combined in group order at the end.  Bins beyond RDF_BLOCK are handled by the slow path.
 template <bool DIAG>
 __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
     const float* __restrict__ mu, float coeff, int nbins, float* __restrict__ partial) {
-    __shared__ float dist[RDF_BLOCK];
+    __shared__ __attribute__((aligned(16))) float dist[RDF_BLOCK + 4];
     __shared__ int wcnt[RDF_BLOCK / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int nw = RDF_BLOCK / 64;
-    // register accumulators.  nbins >= RDF_BLOCK: thread owns bins k0 + m*RDF_BLOCK, m < 4, and
-    // sweeps every distance.  nbins < RDF_BLOCK: G = RDF_BLOCK / nbins thread groups share the
-    // sweep (group g takes distances g, g+G, ...) and are combined in group order at the end.
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    const int G = nbins < RDF_BLOCK ? RDF_BLOCK / nbins : 1;
-    const int grp = nbins < RDF_BLOCK ? threadIdx.x / nbins : 0;
-    const int k0 = nbins < RDF_BLOCK ? (grp < G ? threadIdx.x % nbins : nbins) : threadIdx.x;
-    const int k1 = k0 + RDF_BLOCK, k2 = k1 + RDF_BLOCK, k3 = k2 + RDF_BLOCK;
-    const float m0 = k0 < nbins ? mu[k0] : 0.f, m1 = k1 < nbins ? mu[k1] : 0.f,
-                m2 = k2 < nbins ? mu[k2] : 0.f, m3 = k3 < nbins ? mu[k3] : 0.f;
+    const float sc = sqrtf(-coeff * LOG2E);
+    const int G = RDF_BLOCK / nbins;
+    const int grp = threadIdx.x / nbins;
+    const bool active = grp < G;
+    const int k = threadIdx.x - grp * nbins;
+    const float ms = active ? mu[k] : 0.f;
+    float acc = 0.f;
     const long long npair = (long long)N * (N - 1) / 2;
     const int chunks = (int)((npair + RDF_CHUNK - 1) / RDF_CHUNK);
     const long long items = (long long)nF * chunks;
@@ -56,12 +59,12 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
         const int fr = (int)(it / chunks), ch = (int)(it % chunks);
         const float* pos = xyz + (size_t)fr * N * 3;
         const long long c_end = min(npair, (long long)(ch + 1) * RDF_CHUNK);
+        long long c = (long long)ch * RDF_CHUNK + threadIdx.x;
+        int i = 0, j = 0;
+        if (c < c_end) pair_from_flat(c, N, i, j);
         for (long long cb = (long long)ch * RDF_CHUNK; cb < c_end; cb += RDF_BLOCK) {
-            const long long c = cb + threadIdx.x;
             float d = -1.f;
             if (c < c_end) {
-                int i, j;
-                pair_from_flat(c, N, i, j);
                 float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1],
                       dz = pos[3 * j + 2] - pos[3 * i + 2];
                 min_image<DIAG>(cell, dx, dy, dz);
@@ -69,6 +72,10 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
                 bool ok = (d2 < rc2) && (d2 != 0.f);
                 if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
                 if (ok) d = sqrtf(d2);
+                // advance to the candidate RDF_BLOCK further on
+                c += RDF_BLOCK;
+                j += RDF_BLOCK;
+                while (j >= N && i < N - 1) { ++i; j = j - N + i + 1; }
             }
             const unsigned long long b = __ballot(d >= 0.f);
             __syncthreads();                                   // previous sweep done with dist[]
@@ -78,34 +85,30 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
 #pragma unroll
             for (int w = 0; w < nw; ++w) { if (w < wid) base += wcnt[w]; total += wcnt[w]; }
             if (d >= 0.f) dist[base + __popcll(b & ((1ull << lane) - 1ull))] = d;
+            if (threadIdx.x < 4) dist[total + threadIdx.x] = 3.0e18f;   // pad: exp2(-x^2) == 0
             __syncthreads();
-            if (k0 < nbins) {
-                for (int p = grp; p < total; p += G) {
-                    const float dd = dist[p];
-                    { const float x = dd - m0; a0 += __expf(coeff * x * x); }
-                    if (k1 < nbins) { const float x = dd - m1; a1 += __expf(coeff * x * x); }
-                    if (k2 < nbins) { const float x = dd - m2; a2 += __expf(coeff * x * x); }
-                    if (k3 < nbins) { const float x = dd - m3; a3 += __expf(coeff * x * x); }
+            if (active) {
+                for (int p = 4 * grp; p < total; p += 4 * G) {
+                    const float4 dd = *reinterpret_cast<const float4*>(&dist[p]);
+                    // (d - mu) first, then scale: no cancellation error on the scaled values
+                    const float x0 = (dd.x - ms) * sc, x1 = (dd.y - ms) * sc, x2 = (dd.z - ms) * sc,
+                                x3 = (dd.w - ms) * sc;
+                    acc += __builtin_amdgcn_exp2f(-x0 * x0);
+                    acc += __builtin_amdgcn_exp2f(-x1 * x1);
+                    acc += __builtin_amdgcn_exp2f(-x2 * x2);
+                    acc += __builtin_amdgcn_exp2f(-x3 * x3);
                 }
             }
         }
     }
-    float* out = partial + (size_t)blockIdx.x * nbins;
-    if (G > 1) {
-        __syncthreads();
-        if (k0 < nbins) dist[grp * nbins + k0] = a0;           // G * nbins <= RDF_BLOCK
-        __syncthreads();
-        if (threadIdx.x < nbins) {
-            float s = 0.f;
-            for (int g = 0; g < G; ++g) s += dist[g * nbins + threadIdx.x];
-            out[threadIdx.x] = s;
-        }
-        return;
+    __syncthreads();
+    if (active) dist[threadIdx.x] = acc;                        // [g][k], G * nbins <= RDF_BLOCK
+    __syncthreads();
+    if (threadIdx.x < nbins) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += dist[g * nbins + threadIdx.x];
+        partial[(size_t)blockIdx.x * nbins + threadIdx.x] = s;
     }
-    if (k0 < nbins) out[k0] = a0;
-    if (k1 < nbins) out[k1] = a1;
-    if (k2 < nbins) out[k2] = a2;
-    if (k3 < nbins) out[k3] = a3;
 }
 
 // raw[k] = sum_b partial[b][k] in fixed order; one wave per bin
@@ -125,7 +128,8 @@ __global__ void rdf_bwd_kernel(const float* __restrict__ xyz, int nF, int N, Mdg
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* smu = sm;             // [nbins]
     float* sg = sm + nbins;      // [nbins]
-    for (int k = threadIdx.x; k < nbins; k += blockDim.x) { smu[k] = mu[k]; sg[k] = g_raw[k]; }
+    const float sc = sqrtf(-coeff * LOG2E);
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) { smu[k] = mu[k]; sg[k] = g_raw[k] * 2.f * coeff / sc; }
     __syncthreads();
     const int apb = blockDim.x / LPA;
     const long long gi = (long long)blockIdx.x * apb + threadIdx.x / LPA;
@@ -134,9 +138,9 @@ __global__ void rdf_bwd_kernel(const float* __restrict__ xyz, int nF, int N, Mdg
     const int fr = (int)(gi / N), i = (int)(gi % N);
     const float* pos = xyz + (size_t)fr * N * 3;
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    // bins whose Gaussian is non-negligible (exp argument > -88) around a distance
+    // bins whose Gaussian is non-negligible (exp2 argument > -126) around a distance
     const float dmu = nbins > 1 ? (smu[nbins - 1] - smu[0]) / (float)(nbins - 1) : 0.f;
-    const float reach = sqrtf(88.f / fabsf(coeff));
+    const float reach = 11.3f / sc;                                       // sqrt(126) in scaled units
     float gx = 0.f, gy = 0.f, gz = 0.f;
     for (int j = sub; j < N; j += LPA) {
         if (j == i) continue;
@@ -149,19 +153,22 @@ __global__ void rdf_bwd_kernel(const float* __restrict__ xyz, int nF, int N, Mdg
         const float d2 = norm2_ref(dx, dy, dz);
         if (!((d2 < rc2) && (d2 != 0.f))) continue;
         if (mask && !mask[(size_t)(flip ? j : i) * N + (flip ? i : j)]) continue;
-        const float d = sqrtf(d2);
+        const float id = __builtin_amdgcn_rsqf(d2);
+        const float ds = d2 * id;
         int klo = 0, khi = nbins - 1;
         if (dmu > 0.f) {
-            klo = max(0, (int)floorf((d - reach - smu[0]) / dmu));
-            khi = min(nbins - 1, (int)ceilf((d + reach - smu[0]) / dmu));
+            klo = max(0, (int)floorf((ds - reach - smu[0]) / dmu));
+            khi = min(nbins - 1, (int)ceilf((ds + reach - smu[0]) / dmu));
         }
+        // dL/dd = sum_k g_k 2 coeff (d - mu_k) e_k = sum_k sg_k x_k exp2(-x_k^2),
+        //   x_k = s (d - mu_k), sg_k = g_k * 2 coeff / s
         float s = 0.f;
         for (int k = klo; k <= khi; ++k) {
-            const float x = d - smu[k];
-            s += sg[k] * (2.f * coeff * x) * __expf(coeff * x * x);
+            const float x = (ds - smu[k]) * sc;
+            s = fmaf(sg[k] * x, __builtin_amdgcn_exp2f(-x * x), s);
         }
         // d(dist)/dx_i = -(D)/d for D = x_j - x_i (unflipped); with flip, D was negated
-        const float c = (flip ? s : -s) / d;
+        const float c = (flip ? s : -s) * id;
         gx = fmaf(c, dx, gx); gy = fmaf(c, dy, gy); gz = fmaf(c, dz, gz);
     }
     gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
@@ -188,7 +195,8 @@ extern "C" int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const Md
                            float* partial, void* stream) {
     MDG_CHECK_ARG(xyz && cell && mu && raw && partial, "rdf_fwd: null buffer");
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_fwd: bad sizes");
-    MDG_CHECK_ARG(nbins <= 4 * RDF_BLOCK, "rdf_fwd: nbins > %d not supported", 4 * RDF_BLOCK);
+    MDG_CHECK_ARG(nbins <= RDF_BLOCK, "rdf_fwd: nbins > %d not supported", RDF_BLOCK);
+    MDG_CHECK_ARG(coeff < 0.f, "rdf_fwd: coeff must be negative (-0.5 / width^2)");
     const int nblocks = rdf_grid(n_frames, n_atoms);
     hipStream_t st = (hipStream_t)stream;
     if (cell->diag)
@@ -207,17 +215,19 @@ extern "C" int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const Md
                            float* g_xyz, void* stream) {
     MDG_CHECK_ARG(xyz && cell && mu && g_raw && g_xyz, "rdf_bwd: null buffer");
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_bwd: bad sizes");
+    MDG_CHECK_ARG(coeff < 0.f, "rdf_bwd: coeff must be negative (-0.5 / width^2)");
     hipStream_t st = (hipStream_t)stream;
     constexpr int LPA = 16;
-    const int apb = RDF_BLOCK / LPA;
+    constexpr int RDF_BWD_BLOCK = 256;
+    const int apb = RDF_BWD_BLOCK / LPA;
     const long long rows = (long long)n_frames * n_atoms;
     const int nblocks = (int)((rows + apb - 1) / apb);
     const size_t lds = sizeof(float) * 2 * nbins;
     if (cell->diag)
-        hipLaunchKernelGGL((rdf_bwd_kernel<true, LPA>), dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames,
+        hipLaunchKernelGGL((rdf_bwd_kernel<true, LPA>), dim3(nblocks), dim3(RDF_BWD_BLOCK), lds, st, xyz, n_frames,
                            n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
     else
-        hipLaunchKernelGGL((rdf_bwd_kernel<false, LPA>), dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames,
+        hipLaunchKernelGGL((rdf_bwd_kernel<false, LPA>), dim3(nblocks), dim3(RDF_BWD_BLOCK), lds, st, xyz, n_frames,
                            n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
     MDG_CHECK_LAUNCH("rdf_bwd_kernel");
     return MDG_OK;
