@@ -97,9 +97,10 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
 }
 
 // Nose-Hoover chain bath right-hand side, entry k (md.py:234-236)
-__device__ __forceinline__ float bath_rhs(const TrajArgs& A, const float* pv, float ke, int k) {
+// (Q is an LDS copy of prm.Q: indexing the by-value kernel argument with a run-time index
+//  would force the whole argument struct into scratch)
+__device__ __forceinline__ float bath_rhs(const TrajArgs& A, const float* Q, const float* pv, float ke, int k) {
     const int C = A.prm.n_chains;
-    const float* Q = A.prm.Q;
     const float T = A.prm.T;
     if (k == 0) return 2.f * (ke - T * A.prm.n_dof * 0.5f) - pv[0] * pv[1] / Q[1];
     if (k == C - 1) return pv[C - 2] * pv[C - 2] / Q[C - 2] - T;
@@ -130,8 +131,13 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     float* ph = pv + MDG_MAX_CHAINS;
     float* pb = ph + MDG_MAX_CHAINS;
     float* pvh = pb + MDG_MAX_CHAINS;   // [C] pv + ph
-    float* red = pvh + MDG_MAX_CHAINS;  // [RED_FLOATS]
+    float* Qs = pvh + MDG_MAX_CHAINS;   // [C] thermostat masses
+    float* red = Qs + MDG_MAX_CHAINS;   // [RED_FLOATS]
     float dth_unused[KMAX];
+#pragma unroll
+    for (int c = 0; c < MDG_MAX_CHAINS; ++c)
+        if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
+    const float Q0 = A.prm.Q[0];
 
     load_soa(q, A.q0 + (size_t)rep * N * 3, N);
     load_soa(v, A.v0 + (size_t)rep * N * 3, N);
@@ -156,14 +162,14 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
                 const float m = ms[e % N]; const float p = v[e] * m; part += p * p / m;
             }
             ke = 0.5f * block_sum(part, red);
-            if (threadIdx.x < C) pb[threadIdx.x] = bath_rhs(A, pv, ke, threadIdx.x);
+            if (threadIdx.x < C) pb[threadIdx.x] = bath_rhs(A, Qs, pv, ke, threadIdx.x);
         }
         const float pv0 = nhc ? pv[0] : 0.f;
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
             const float m = ms[e % N];
             float a;
-            if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p / A.prm.Q[0]) / m; }
+            if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p / Q0) / m; }
             else a = f[e];                                   // md.py:145-148 (no 1/m)
             const float h = 0.5f * a * dt;
             vh[e] = h;
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
             ke = 0.5f * block_sum(part, red);       // (barriers inside also publish f)
             pvh0 = pvh[0];
             float b1 = 0.f;
-            if (threadIdx.x < C) b1 = bath_rhs(A, pvh, ke, threadIdx.x);
+            if (threadIdx.x < C) b1 = bath_rhs(A, Qs, pvh, ke, threadIdx.x);
             __syncthreads();
             if (threadIdx.x < C) pv[threadIdx.x] = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
         } else {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
             const float m = ms[e % N];
             float a;
-            if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p / A.prm.Q[0]) / m; }
+            if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p / Q0) / m; }
             else a = f[e];
             v[e] = v[e] + (vh[e] + 0.5f * a * dt);
         }
@@ -245,10 +251,9 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
 }
 
 // lam^T d(bath rhs)/d pv_k  + coupling from dv
-__device__ __forceinline__ float bath_vjp(const TrajArgs& A, const float* pv, const float* lp,
+__device__ __forceinline__ float bath_vjp(const TrajArgs& A, const float* Q, const float* pv, const float* lp,
                                           float slv, int k) {
     const int C = A.prm.n_chains;
-    const float* Q = A.prm.Q;
     if (k == 0) return -slv / Q[0] - lp[0] * pv[1] / Q[1] + 2.f * pv[0] * lp[1] / Q[0];
     if (k == C - 1) return -lp[C - 2] * pv[C - 2] / Q[C - 1];
     return -lp[k - 1] * pv[k - 1] / Q[k] - lp[k] * pv[k + 1] / Q[k + 1] + 2.f * pv[k] * lp[k + 1] / Q[k];
@@ -270,7 +275,12 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
     float* lph = lp + MDG_MAX_CHAINS;         // [C] midpoint adjoint
     float* pb = lph + MDG_MAX_CHAINS;         // [C] scratch: bath rhs
     float* gp = pb + MDG_MAX_CHAINS;          // [C] scratch: bath vjp
-    float* red = gp + MDG_MAX_CHAINS;         // [RED_FLOATS]
+    float* Qs = gp + MDG_MAX_CHAINS;          // [C] thermostat masses
+    float* red = Qs + MDG_MAX_CHAINS;         // [RED_FLOATS]
+#pragma unroll
+    for (int c = 0; c < MDG_MAX_CHAINS; ++c)
+        if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
+    const float Q0 = A.prm.Q[0];
     float th[KMAX], gth[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) gth[k] = 0.f;
@@ -295,12 +305,12 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
         aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv);
         if (nhc) {
             const float pv0 = pv[0], lp0 = lp[0];
-            if (tid < C) { pb[tid] = bath_rhs(A, pv, ke, tid); gp[tid] = bath_vjp(A, pv, lp, slv, tid); }
+            if (tid < C) { pb[tid] = bath_rhs(A, Qs, pv, ke, tid); gp[tid] = bath_vjp(A, Qs, pv, lp, slv, tid); }
             __syncthreads();
             for (int e = tid; e < N3; e += blockDim.x) {
                 const float m = ms[e % N], ve = v[e], p = ve * m;
-                const float a = (f[e] - pv0 * p / A.prm.Q[0]) / m;
-                const float Gv = -(pv0 / A.prm.Q[0]) * lv[e] + lq[e] + 2.f * m * ve * lp0;
+                const float a = (f[e] - pv0 * p / Q0) / m;
+                const float Gv = -(pv0 / Q0) * lv[e] + lq[e] + 2.f * m * ve * lp0;
                 const float vhalf = 0.5f * (-a) * h;                  // sovlers.py:132
                 q[e] = q[e] + (ve + vhalf) * h;                      // :138 forward-time sign (quirk)
                 v[e] = ve + vhalf;
@@ -316,11 +326,11 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             // ---------------- midpoint evaluation                    :147-150
             aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
             const float pvm0 = pv[0], lpm0 = lph[0];
-            if (tid < C) gp[tid] = bath_vjp(A, pv, lph, slv, tid);
+            if (tid < C) gp[tid] = bath_vjp(A, Qs, pv, lph, slv, tid);
             __syncthreads();
             for (int e = tid; e < N3; e += blockDim.x) {
                 const float m = ms[e % N];
-                const float Gv = -(pvm0 / A.prm.Q[0]) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
+                const float Gv = -(pvm0 / Q0) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
                 float nlv = lv[e] + Gv * h;                          // :156
                 float nlq = lq[e] + dq[e] * h;                       // :157
                 if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + (e % N) * 3 + e / N];   // :286
@@ -438,7 +448,7 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
     const int N = prm->n_atoms;
     const int block = pick_block(*prm);
-    const size_t lds = sizeof(float) * (13 * (size_t)N + 4 * MDG_MAX_CHAINS + RED_FLOATS);
+    const size_t lds = sizeof(float) * (13 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS);
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_fwd: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;
@@ -466,7 +476,7 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
     const int N = prm->n_atoms;
     const int block = pick_block(*prm);
-    const size_t lds = sizeof(float) * (28 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS);
+    const size_t lds = sizeof(float) * (28 * (size_t)N + 6 * MDG_MAX_CHAINS + RED_FLOATS);
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_adj: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;
