@@ -182,6 +182,25 @@ int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell
                 float cutoff, const uint8_t* mask, const float* mu, float coeff, int nbins,
                 const float* g_raw, float* g_xyz, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K10  graph gather/scatter for the SchNet continuous-filter convolution
+ * (replaces the index / scatter_add_ chains of nff/nn/models/schnet.py:142,
+ *  nff/nn/modules.py:564-571, nff/nn/graphconv.py:43-53 and their autograd transposes).
+ * nbr = int64 [E,2] half list (i<j); col/eid/cnt = ELL list with undirected edge ids
+ * (mdg_nbr_half_fill).  Feature matrices are row-major fp32.
+ *   mdg_edge_diff    out[e,c] = x[i_e,c] - x[j_e,c]
+ *   mdg_edge_scatter out[n,c] = sum_{slots s of n} (+/-) g[eid_s,c]     (+ when n is i_e)
+ *   mdg_cfconv_agg   out[n,f] = sum_{slots s of n} h[col_s,f] * W[eid_s,f]
+ *   mdg_edge_prod    out[e,f] = a[i_e,f] b[j_e,f] + a[j_e,f] b[i_e,f]
+ */
+int mdg_edge_diff(const float* x, const int64_t* nbr, int64_t n_edges, int n_feat, float* out, void* stream);
+int mdg_edge_scatter(const float* g, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                     int n_atoms, int max_nbr, int n_feat, float* out, void* stream);
+int mdg_cfconv_agg(const float* h, const float* W, const int32_t* col, const int32_t* eid,
+                   const int32_t* cnt, int n_atoms, int max_nbr, int n_feat, float* out, void* stream);
+int mdg_edge_prod(const float* a, const float* b, const int64_t* nbr, int64_t n_edges, int n_feat,
+                  float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

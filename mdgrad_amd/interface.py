@@ -46,6 +46,38 @@ class _LazyTopology:
         return 3
 
 
+def batch_to(batch, device):
+    """nff/utils/cuda.py:6-10."""
+    return {k: (v.to(device) if hasattr(v, 'to') else v) for k, v in batch.items()}
+
+
+class GNNPotentials(GeneralInteraction):
+    """torchmd/interface.py:86-136.  `inputs` is the batch dict the SchNet consumes
+    ('nxyz', 'num_atoms', 'energy', 'nbr_list', 'offsets'); `_reset_topology` rebuilds the list
+    with the HIP builder and also stores the per-atom topology the cfconv kernels use."""
+
+    def __init__(self, system, gnn, cutoff, ex_pairs=None):
+        super().__init__(system)
+        self.gnn = gnn
+        self.cutoff = cutoff
+        self.inputs = batch_to(self.system.get_batch(), self.device)
+        self.inputs['cell'] = self.cell.detach()
+        self.ex_pairs = ex_pairs
+        self._mask = ops.build_mask(system.get_number_of_atoms(), None, ex_pairs, system.device)
+        self.to(self.device)
+        self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
+
+    def _reset_topology(self, xyz):
+        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask)
+        topo = ops.GraphTopo(ell)
+        self.inputs['nbr_list'], self.inputs['offsets'] = topo.nbr, topo.offsets
+        self.inputs['_topo'] = topo
+
+    def forward(self, xyz):
+        results = self.gnn(self.inputs, xyz)
+        return results['energy']
+
+
 class PairPotentials(GeneralInteraction):
     """torchmd/interface.py:217-300.  `pair_model` is a module instance (the code's signature)
     or, as in the README snippet, a class plus its keyword arguments."""

@@ -333,3 +333,113 @@ class RdfRawFn(torch.autograd.Function):
         check(lib.mdg_rdf_bwd(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), coeff, B,
                               ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
         return gx.reshape(shape), None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- graph ops (SchNet)
+class GraphTopo:
+    """Edge topology for the message-passing kernels: ELL list + undirected edge ids + the
+    reference-format half list (nbr int64 [E,2], raw image flags [E,3])."""
+
+    def __init__(self, ell):
+        self.ell = ell
+        self.nbr, self.offsets, self.eid = ell.half_list(with_edge_id=True)
+        self.n_atoms, self.n_edges = ell.n_atoms, int(self.nbr.shape[0])
+
+
+def _edge_diff(x, topo):
+    lib = _lib.load()
+    x = x.contiguous()
+    out = torch.empty(topo.n_edges, x.shape[1], device=x.device)
+    check(lib.mdg_edge_diff(ptr(x), ptr(topo.nbr), topo.n_edges, x.shape[1], ptr(out), stream_ptr(x.device)),
+          "mdg_edge_diff")
+    return out
+
+
+def _edge_scatter(g, topo):
+    lib = _lib.load()
+    g = g.contiguous()
+    e = topo.ell
+    out = torch.empty(topo.n_atoms, g.shape[1], device=g.device)
+    check(lib.mdg_edge_scatter(ptr(g), ptr(e.col), ptr(topo.eid), ptr(e.cnt), topo.n_atoms, e.max_nbr, g.shape[1],
+                               ptr(out), stream_ptr(g.device)), "mdg_edge_scatter")
+    return out
+
+
+def _cfconv_agg(h, W, topo):
+    lib = _lib.load()
+    h, W = h.contiguous(), W.contiguous()
+    e = topo.ell
+    out = torch.empty(topo.n_atoms, h.shape[1], device=h.device)
+    check(lib.mdg_cfconv_agg(ptr(h), ptr(W), ptr(e.col), ptr(topo.eid), ptr(e.cnt), topo.n_atoms, e.max_nbr,
+                             h.shape[1], ptr(out), stream_ptr(h.device)), "mdg_cfconv_agg")
+    return out
+
+
+def _edge_prod(a, b, topo):
+    lib = _lib.load()
+    a, b = a.contiguous(), b.contiguous()
+    out = torch.empty(topo.n_edges, a.shape[1], device=a.device)
+    check(lib.mdg_edge_prod(ptr(a), ptr(b), ptr(topo.nbr), topo.n_edges, a.shape[1], ptr(out),
+                            stream_ptr(a.device)), "mdg_edge_prod")
+    return out
+
+
+class EdgeDiffFn(torch.autograd.Function):
+    """out[e] = x[i_e] - x[j_e]  (linear; transpose = EdgeScatterFn)."""
+
+    @staticmethod
+    def forward(ctx, x, topo):
+        ctx.topo = topo
+        return _edge_diff(x.detach(), topo)
+
+    @staticmethod
+    def backward(ctx, g):
+        return EdgeScatterFn.apply(g, ctx.topo), None
+
+
+class EdgeScatterFn(torch.autograd.Function):
+    """out[n] = sum_{e: i_e = n} g[e] - sum_{e: j_e = n} g[e]  (transpose of EdgeDiffFn)."""
+
+    @staticmethod
+    def forward(ctx, g, topo):
+        ctx.topo = topo
+        return _edge_scatter(g.detach(), topo)
+
+    @staticmethod
+    def backward(ctx, gn):
+        return EdgeDiffFn.apply(gn, ctx.topo), None
+
+
+class CfconvAggFn(torch.autograd.Function):
+    """m[n] = sum over neighbours j of n of h[j] * W[edge(n,j)]: the cfconv message plus both
+    scatter_adds of nff/nn/graphconv.py:43-53 in one gather (bilinear, closed under d/d.)."""
+
+    @staticmethod
+    def forward(ctx, h, W, topo):
+        ctx.topo = topo
+        ctx.save_for_backward(h, W)
+        return _cfconv_agg(h.detach(), W.detach(), topo)
+
+    @staticmethod
+    def backward(ctx, gm):
+        h, W = ctx.saved_tensors
+        gh = CfconvAggFn.apply(gm, W, ctx.topo) if ctx.needs_input_grad[0] else None
+        gW = EdgeProdFn.apply(h, gm, ctx.topo) if ctx.needs_input_grad[1] else None
+        return gh, gW, None
+
+
+class EdgeProdFn(torch.autograd.Function):
+    """out[e] = a[i_e] b[j_e] + a[j_e] b[i_e]."""
+
+    @staticmethod
+    def forward(ctx, a, b, topo):
+        ctx.topo = topo
+        ctx.save_for_backward(a, b)
+        return _edge_prod(a.detach(), b.detach(), topo)
+
+    @staticmethod
+    def backward(ctx, gE):
+        a, b = ctx.saved_tensors
+        ga = CfconvAggFn.apply(b, gE, ctx.topo) if ctx.needs_input_grad[0] else None
+        gb = CfconvAggFn.apply(a, gE, ctx.topo) if ctx.needs_input_grad[1] else None
+        return ga, gb, None

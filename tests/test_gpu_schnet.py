@@ -1,0 +1,115 @@
+"""GPU parity of the SchNet / GNNPotentials path against the reference
+goldens G8/G9 and against plain torch index ops for the graph kernels."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_parity import T, close, mk_system, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def sd_of(g):
+    return {k[4:]: T(v) for k, v in g.items() if k.startswith("sd__")}
+
+
+def params_of(g):
+    return {"n_atom_basis": int(g["n_atom_basis"]), "n_filters": int(g["n_filters"]),
+            "n_gaussians": int(g["n_gaussians"]), "n_convolutions": int(g["n_convolutions"]),
+            "cutoff": float(g["cutoff"])}
+
+
+def test_graph_ops_match_torch_index_ops_to_second_order():
+    from mdgrad_amd import ops, _lib
+    g = load_golden("schnet_water192")
+    x = T(g["pos"], DEV)
+    ell = ops.build_ell(x, _lib.make_cell(g["cell"]), 5.0)
+    topo = ops.GraphTopo(ell)
+    assert np.array_equal(topo.nbr.cpu().numpy(), g["nbr"])
+    a0, a1 = topo.nbr[:, 0], topo.nbr[:, 1]
+    torch.manual_seed(0)
+    F = 40
+    h = torch.randn(192, F, device=DEV, requires_grad=True)
+    W = torch.randn(topo.n_edges, F, device=DEV, requires_grad=True)
+    xx = x.clone().requires_grad_(True)
+
+    def ref(h, W, xx):
+        m = torch.zeros_like(h).index_add(0, a1, h[a0] * W).index_add(0, a0, h[a1] * W)
+        d = (xx[a0] - xx[a1]).pow(2).sum(1)
+        return m, d
+
+    def hip(h, W, xx):
+        return ops.CfconvAggFn.apply(h, W, topo), ops.EdgeDiffFn.apply(xx, topo).pow(2).sum(1)
+
+    outs = []
+    for fn in (ref, hip):
+        m, d = fn(h, W, xx)
+        y = (m.tanh() * torch.linspace(0.5, 1.5, F, device=DEV)).sum() + (d.sqrt() * W[:, 0]).sum()
+        g1 = torch.autograd.grad(y, [h, W, xx], create_graph=True)
+        z = sum((gi * gi.detach().cos()).sum() for gi in g1)
+        g2 = torch.autograd.grad(z, [h, W, xx])
+        outs.append([m, d] + list(g1) + list(g2))
+    for a, b in zip(*outs):
+        close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-6, "graph op")
+
+
+@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192"])
+def test_schnet_energy_force_vjp_golden(name):
+    from mdgrad_amd.interface import GNNPotentials
+    from mdgrad_amd.nn import get_model
+    g = load_golden(name)
+    system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    q = T(g["pos"], DEV).requires_grad_(True)
+    gnn._reset_topology(q.detach())
+    assert np.array_equal(gnn.inputs["nbr_list"].cpu().numpy(), g["nbr"])
+    assert np.array_equal(gnn.inputs["offsets"].cpu().numpy(), g["offsets"])
+    U = gnn(q)
+    assert U.shape == (1, 1)
+    close(U.reshape(-1), g["U"], 1e-5, 1e-5, "U")
+    (gq,) = torch.autograd.grad(U.sum(), q, create_graph=True)
+    close(-gq, g["F"], 1e-4, 1e-5 * np.abs(g["F"]).max(), "F")
+    if "w" in g:
+        plist = list(net.parameters())
+        grads = torch.autograd.grad((T(g["w"], DEV) * -gq).sum(), [q] + plist, allow_unused=True)
+        close(grads[0], g["dwF_dq"], 1e-3, 1e-4 * np.abs(g["dwF_dq"]).max(), "d(w.F)/dq")
+        flat = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(grads[1:], plist)])
+        close(flat, g["dwF_dtheta"], 1e-3, 1e-4 * np.abs(g["dwF_dtheta"]).max(), "d(w.F)/dtheta")
+
+
+def test_gnn_stack_trajectory_adjoint_golden():
+    """BASELINE config #3 shape: Stack(SchNet GNN + ExcludedVolume prior), NHC, adjoint of an RDF loss."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("gnn_traj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12),
+                           cutoff=float(g["cutoff"]))
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=float(g["T"]),
+                            num_chains=int(g["chains"]), Q=float(g["Q"]), adjoint=True).to(DEV)
+    assert integ.fused_spec("NH_verlet") is None
+    assert [n for n, _ in integ.named_parameters()] == [str(x) for x in g["param_names"]]
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(g["dt"]) * i for i in range(11)]).to(DEV)
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    for x, k in zip((v_t, q_t, pv_t), ["v_t", "q_t", "pv_t"]):
+        close(x, g[k], 1e-4, 1e-4 * max(1e-3, np.abs(g[k]).max()), k)
+    _, _, gr = rdf(system, nbins=40, r_range=(2.0, 5.5))(q_t[::2])
+    close(gr, g["g"], 1e-3, 2e-4, "g")
+    loss = gr.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3
+    close(loss.reshape(1), g["loss"], 1e-4, 1e-6, "loss")
+    loss.backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
+    close(flat, g["grad_flat"], 5e-3, 2e-4 * np.abs(g["grad_flat"]).max(), "dL/dtheta (14339 params)")
+    close(y0[1].grad, g["grad_q0"], 5e-3, 2e-3 * np.abs(g["grad_q0"]).max(), "grad_q0")
+    close(y0[0].grad, g["grad_v0"], 5e-3, 2e-3 * np.abs(g["grad_v0"]).max(), "grad_v0")
