@@ -201,6 +201,17 @@ int mdg_cfconv_agg(const float* h, const float* W, const int32_t* col, const int
 int mdg_edge_prod(const float* a, const float* b, const int64_t* nbr, int64_t n_edges, int n_feat,
                   float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K9  continuous-filter generator on the matrix cores (fp32-input MFMA, exact f32)
+ * (replaces GaussianSmearing -> Dense(G,G) -> shifted_softplus -> Dense(G,F):
+ *  nff/nn/modules.py:531-541, nff/nn/layers.py:14-31,86-134, nff/nn/activations.py:5-11)
+ *   d [E] distances; mu, width [G] (coeff_k = -0.5 / width_k^2); W1 [G,G], b1 [G], W2 [F,G],
+ *   b2 [F] in torch.nn.Linear layout ([out,in]); out [E,F].   G <= 64.
+ */
+int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* mu, const float* width, int n_gauss,
+                      const float* W1, const float* b1, const float* W2, const float* b2,
+                      int n_filters, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "mdg_edge_scatter": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_cfconv_agg": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_edge_prod": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P]),
+    "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

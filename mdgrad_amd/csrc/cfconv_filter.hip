@@ -1,0 +1,149 @@
+// K9: continuous-filter generator  W[e,:] = Dense2( ssp( Dense1( smear(d_e) ) ) )
+// (nff/nn/modules.py:531-541 with GaussianSmearing nff/nn/layers.py:14-31, Dense :86-134,
+//  shifted_softplus nff/nn/activations.py:5-11), fused into one kernel on the matrix cores.
+//
+// This is the one GEMM-shaped piece of the hot path (K = G = 12..64 radial basis functions,
+// N = G then F filters, M = E edges), so it goes on MFMA: v_mfma_f32_16x16x4_f32 -- f32 in,
+// f32 accumulate, bitwise a k-ordered fmaf chain, which keeps fp32 parity with the reference's
+// F.linear.  Per workgroup: 64 edges (one 16-row tile per wave) x one chunk of <= 128 filters.
+//   layer 1: the A fragment (smearing values) is computed in registers -- the [E,G] Gaussian
+//            matrix never exists; B = W1^T from LDS; bias + shifted softplus in the epilogue;
+//   layer 2: H1 goes through LDS once to turn the C layout into the A layout; B = W2^T chunk
+//            from LDS; bias in the epilogue; the only HBM traffic is d[E] in and W[E,F] out.
+// LDS strides are chosen so the 16x4 operand fetches are bank-conflict free in each half-wave
+// (B: stride = 16 mod 32 floats; A: stride = 2 mod 4 floats).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FT_TM = 64;        // edges per workgroup
+constexpr int FT_FCH = 128;      // filters per workgroup (grid.y chunks)
+constexpr int FT_GMAX = 64;
+
+__host__ __device__ inline int stride16mod32(int n) {   // smallest s >= n with s % 32 == 16
+    int s = (n + 31) / 32 * 32 - 16;
+    if (s < n) s += 32;
+    return s;
+}
+
+__device__ __forceinline__ float ssp(float x) {          // softplus(x) - ln 2, torch threshold 20
+    const float sp = x > 20.f ? x : log1pf(expf(x));
+    return sp - 0.69314718055994531f;
+}
+
+__global__ __launch_bounds__(256) void cfconv_filter_kernel(
+    const float* __restrict__ d, long long E, const float* __restrict__ mu, const float* __restrict__ width,
+    int G, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ b2, int F, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int Gp = (G + 15) / 16 * 16;
+    const int S1 = stride16mod32(Gp);
+    const int f_lo = blockIdx.y * FT_FCH;
+    const int Fc = min(FT_FCH, F - f_lo);
+    const int Fcp = (Fc + 15) / 16 * 16;
+    const int S2 = stride16mod32(Fcp);
+    const int SA = Gp + 2;
+    float* w1s = sm;                       // [Gp][S1]   B1[k][j] = W1[j][k]
+    float* w2s = w1s + Gp * S1;            // [Gp][S2]   B2[k][j] = W2[f_lo + j][k]
+    float* h1s = w2s + Gp * S2;            // [4 waves][16][SA]
+    float* mus = h1s + 4 * 16 * SA;        // [Gp] centres, [Gp] coeff, [Gp] b1
+    float* cfs = mus + Gp;
+    float* b1s = cfs + Gp;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    for (int t = tid; t < Gp * Gp; t += 256) {
+        const int k = t / Gp, j = t % Gp;
+        w1s[k * S1 + j] = (k < G && j < G) ? W1[j * G + k] : 0.f;
+    }
+    for (int t = tid; t < Gp * Fcp; t += 256) {
+        const int k = t / Fcp, j = t % Fcp;
+        w2s[k * S2 + j] = (k < G && j < Fc) ? W2[(size_t)(f_lo + j) * G + k] : 0.f;
+    }
+    for (int k = tid; k < Gp; k += 256) {
+        mus[k] = k < G ? mu[k] : 0.f;
+        const float w = k < G ? width[k] : 1.f;
+        cfs[k] = k < G ? -0.5f / (w * w) : 0.f;
+        b1s[k] = k < G ? b1[k] : 0.f;
+    }
+    __syncthreads();
+
+    const long long e0 = (long long)blockIdx.x * FT_TM + wid * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    // ---- layer 1: A[i][k] = exp(c_k (d_i - mu_k)^2) computed in registers
+    const long long ea = e0 + li;
+    const float da = ea < E ? d[ea] : 0.f;
+    float afrag[FT_GMAX / 4];
+#pragma unroll
+    for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+        const int k = ks * 4 + lk;
+        float v = 0.f;
+        if (ks * 4 < Gp && k < G) { const float x = da - mus[k]; v = expf(cfs[k] * x * x); }
+        afrag[ks] = v;
+    }
+    float* h1w = h1s + wid * 16 * SA;
+    for (int nt = 0; nt < Gp / 16; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+            if (ks * 4 < Gp) {
+                const float b = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+            }
+        }
+        // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+        const int col = nt * 16 + li;
+        const float bias = b1s[col];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = col < G ? ssp(acc[r] + bias) : 0.f;
+            h1w[(lk * 4 + r) * SA + col] = v;
+        }
+    }
+    __syncthreads();
+    // ---- layer 2: A[i][k] = H1[i][k] from LDS
+#pragma unroll
+    for (int ks = 0; ks < FT_GMAX / 4; ++ks)
+        afrag[ks] = (ks * 4 < Gp) ? h1w[li * SA + ks * 4 + lk] : 0.f;
+    for (int nt = 0; nt < Fcp / 16; ++nt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+            if (ks * 4 < Gp) {
+                const float b = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+            }
+        }
+        const int col = nt * 16 + li;
+        if (col < Fc) {
+            const float bias = b2[f_lo + col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long e = e0 + lk * 4 + r;
+                if (e < E) out[(size_t)e * F + f_lo + col] = acc[r] + bias;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* mu, const float* width, int n_gauss,
+                                 const float* W1, const float* b1, const float* W2, const float* b2,
+                                 int n_filters, float* out, void* stream) {
+    MDG_CHECK_ARG(n_edges >= 0 && n_gauss > 0 && n_filters > 0, "cfconv_filter: bad sizes");
+    MDG_CHECK_ARG(n_gauss <= FT_GMAX, "cfconv_filter: n_gaussians > %d not supported", FT_GMAX);
+    if (n_edges == 0) return MDG_OK;
+    MDG_CHECK_ARG(d && mu && width && W1 && b1 && W2 && b2 && out, "cfconv_filter: null buffer");
+    const int Gp = (n_gauss + 15) / 16 * 16;
+    const int Fc = n_filters < FT_FCH ? n_filters : FT_FCH;
+    const int Fcp = (Fc + 15) / 16 * 16;
+    const size_t lds = sizeof(float) * ((size_t)Gp * stride16mod32(Gp) + (size_t)Gp * stride16mod32(Fcp) +
+                                        4 * 16 * (Gp + 2) + 3 * Gp);
+    dim3 grid((unsigned)((n_edges + FT_TM - 1) / FT_TM), (n_filters + FT_FCH - 1) / FT_FCH);
+    hipLaunchKernelGGL(cfconv_filter_kernel, grid, dim3(256), lds, (hipStream_t)stream, d, (long long)n_edges, mu,
+                       width, n_gauss, W1, b1, W2, b2, n_filters, out);
+    MDG_CHECK_LAUNCH("cfconv_filter_kernel");
+    return MDG_OK;
+}

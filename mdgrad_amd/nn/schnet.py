@@ -66,8 +66,20 @@ class SchNetConv(nn.Module):
                 Dense(in_features=n_atom_basis, out_features=n_atom_basis)),
         })
 
+    fused_filter = True          # K9 on the matrix cores (csrc/cfconv_filter.hip)
+
+    def edge_filter(self, e):
+        seq = self.moduledict['message_edge_filter']
+        smear, d1, d2 = seq[0], seq[1], seq[3]
+        if (self.fused_filter and e.is_cuda and not smear.centered and smear.offsets.shape[0] <= 64
+                and d1.activation is None and d2.activation is None and d1.bias is not None
+                and d2.bias is not None):
+            return ops.CfconvFilterFn.apply(e.reshape(-1), smear.offsets, smear.width, d1.weight, d1.bias,
+                                            d2.weight, d2.bias)
+        return seq(e)
+
     def forward(self, r, e, a, aggr_wgt=None, topo=None):
-        W = self.moduledict['message_edge_filter'](e)        # [E,F] continuous filter
+        W = self.edge_filter(e)                              # [E,F] continuous filter
         h = self.moduledict['message_node_filter'](r)        # [N,F]
         if aggr_wgt is not None:
             h = h * aggr_wgt

@@ -443,3 +443,61 @@ class EdgeProdFn(torch.autograd.Function):
         ga = CfconvAggFn.apply(b, gE, ctx.topo) if ctx.needs_input_grad[0] else None
         gb = CfconvAggFn.apply(a, gE, ctx.topo) if ctx.needs_input_grad[1] else None
         return ga, gb, None
+
+
+# ----------------------------------------------------------------------------- cfconv filter (MFMA)
+def filter_reference(d, mu, width, W1, b1, W2, b2):
+    """The filter network in plain torch ops (nff/nn/modules.py:531-541): used for the
+    derivative formulas' cross-check in tests and for inputs the fused kernel does not take."""
+    g = torch.exp(-0.5 / width.pow(2) * (d[:, None] - mu).pow(2))
+    h1 = torch.nn.functional.softplus(torch.nn.functional.linear(g, W1, b1)) - math.log(2.0)
+    return torch.nn.functional.linear(h1, W2, b2)
+
+
+class CfconvFilterFn(torch.autograd.Function):
+    """W[E,F] = Dense2(ssp(Dense1(smear(d)))) in one MFMA kernel (csrc/cfconv_filter.hip).
+    backward is written out with torch ops (GEMMs on rocBLAS), so it is differentiable again:
+    the adjoint's second-order pass goes through it without a hand-derived third kernel."""
+
+    @staticmethod
+    def forward(ctx, d, mu, width, W1, b1, W2, b2):
+        lib = _lib.load()
+        require_gpu(d, "d")
+        args = [x.detach().contiguous() for x in (d, mu, width, W1, b1, W2, b2)]
+        E, G, F = args[0].shape[0], args[1].shape[0], args[5].shape[0]
+        out = torch.empty(E, F, device=d.device)
+        check(lib.mdg_cfconv_filter(ptr(args[0]), E, ptr(args[1]), ptr(args[2]), G, ptr(args[3]), ptr(args[4]),
+                                    ptr(args[5]), ptr(args[6]), F, ptr(out), stream_ptr(d.device)),
+              "mdg_cfconv_filter")
+        ctx.save_for_backward(d, mu, width, W1, b1, W2, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, gW):
+        d, mu, width, W1, b1, W2, b2 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        c = -0.5 / width.pow(2)
+        x = d[:, None] - mu
+        g = torch.exp(c * x.pow(2))
+        a1 = torch.nn.functional.linear(g, W1, b1)
+        gh1 = gW.matmul(W2)
+        ga1 = gh1 * torch.sigmoid(a1)
+        gd = gmu = gwidth = gW1 = gb1 = gW2 = gb2 = None
+        if need[0] or need[1] or need[2]:
+            gg = ga1.matmul(W1) * g
+            if need[0] or need[1]:
+                t = gg * (2 * c * x)
+                gd = t.sum(1) if need[0] else None
+                gmu = -t.sum(0) if need[1] else None
+            if need[2]:
+                gwidth = (gg * x.pow(2)).sum(0) / width.pow(3)
+        if need[3]:
+            gW1 = ga1.t().matmul(g)
+        if need[4]:
+            gb1 = ga1.sum(0)
+        if need[5]:
+            h1 = torch.nn.functional.softplus(a1) - math.log(2.0)
+            gW2 = gW.t().matmul(h1)
+        if need[6]:
+            gb2 = gW.sum(0)
+        return gd, gmu, gwidth, gW1, gb1, gW2, gb2

@@ -54,6 +54,30 @@ def test_graph_ops_match_torch_index_ops_to_second_order():
         close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-6, "graph op")
 
 
+@pytest.mark.parametrize("G,F,E", [(16, 48, 1000), (30, 128, 777), (64, 256, 130), (12, 20, 64), (33, 130, 5)])
+def test_mfma_filter_kernel_vs_torch_to_second_order(G, F, E):
+    from mdgrad_amd import ops
+    torch.manual_seed(G * F)
+    d = (torch.rand(E, device=DEV) * 5.0).requires_grad_(True)
+    mu = torch.linspace(0, 5.0, G, device=DEV).requires_grad_(True)
+    width = torch.full((G,), float(5.0 / (G - 1)), device=DEV).requires_grad_(True)
+    W1 = (torch.randn(G, G, device=DEV) / G ** 0.5).requires_grad_(True)
+    b1 = (torch.randn(G, device=DEV) * 0.1).requires_grad_(True)
+    W2 = (torch.randn(F, G, device=DEV) / G ** 0.5).requires_grad_(True)
+    b2 = (torch.randn(F, device=DEV) * 0.1).requires_grad_(True)
+    ins = [d, mu, width, W1, b1, W2, b2]
+    probe = torch.randn(E, F, device=DEV)
+    outs = []
+    for fn in (ops.filter_reference, ops.CfconvFilterFn.apply):
+        W = fn(*ins)
+        g1 = torch.autograd.grad((W * probe).sum(), ins, create_graph=True)
+        z = sum((gi * gi.detach().sin()).sum() for gi in g1)
+        g2 = torch.autograd.grad(z, ins, allow_unused=True)
+        outs.append([W] + list(g1) + [x if x is not None else torch.zeros(1, device=DEV) for x in g2])
+    for k, (a, b) in enumerate(zip(*outs)):
+        close(b, a, 2e-4, 2e-5 * float(a.abs().max()) + 1e-6, "filter output/derivative #%d" % k)
+
+
 @pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192"])
 def test_schnet_energy_force_vjp_golden(name):
     from mdgrad_amd.interface import GNNPotentials
