@@ -166,6 +166,28 @@ int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
                        void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain): same contract as
+ * mdg_traj_fwd_small / mdg_traj_adj_small, two launches per step (forward) / four per adjoint
+ * interval, enqueued by a host loop; the neighbour search is fused into the force kernel
+ * (per-wave LDS list).  ws: f32 workspace of mdg_traj_large_workspace() floats, shared by the
+ * forward and the adjoint call of one trajectory; flags: int32[2] = {neighbour buffer
+ * overflow (needed entries), non-finite state}, zeroed by the caller.
+ */
+int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_total);
+int mdg_traj_fwd_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                       const MdgTerms* terms /*host*/, const float* theta,
+                       const float* mass, const float* t_grid,
+                       const float* v0, const float* q0, const float* pv0,
+                       float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream);
+int mdg_traj_adj_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                       const MdgTerms* terms /*host*/, const float* theta,
+                       const float* mass, const float* t_grid,
+                       const float* v_t, const float* q_t, const float* pv_t,
+                       const float* g_v, const float* g_q, const float* g_pv,
+                       float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                       float* ws, int32_t* flags, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K8  soft-histogram RDF  (replaces rdf.forward and its autograd backward:
  *     torchmd/observable.py:62-76 with GaussianSmearing nff/nn/layers.py:14-31)
  *   xyz [F,N,3]; pairs i<j with 0 < d < cutoff (min image) over all frames;

@@ -80,12 +80,14 @@ __global__ void pair_ell_kernel(const EllArgs A) {
     }
 }
 
+// one wave per scalar, fixed summation order
 __global__ void pair_ell_finish(const float* __restrict__ partial, int nblocks, int n_theta,
                                 float* energy, float* gtheta, float* gtheta_w) {
-    const int k = threadIdx.x;
-    if (k >= NSCAL) return;
+    const int k = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * NSCAL + k];
+    for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * NSCAL + k];
+    s = wave_sum(s);
+    if (lane != 0) return;
     if (k == 0) { if (energy) energy[0] = s; }
     else if (k <= MDG_MAX_THETA) { if (gtheta && k - 1 < n_theta) gtheta[k - 1] = s; }
     else if (gtheta_w && k - 1 - MDG_MAX_THETA < n_theta) gtheta_w[k - 1 - MDG_MAX_THETA] = s;
@@ -131,7 +133,7 @@ extern "C" int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* c
     dim3 grid(nblocks);
     hipStream_t st = (hipStream_t)stream;
     switch (lpa) { MDG_ELL_LAUNCH(8) MDG_ELL_LAUNCH(16) MDG_ELL_LAUNCH(32) MDG_ELL_LAUNCH(64) }
-    hipLaunchKernelGGL(pair_ell_finish, dim3(1), dim3(64), 0, st, partial, nblocks, term->n_theta, energy,
+    hipLaunchKernelGGL(pair_ell_finish, dim3(NSCAL), dim3(64), 0, st, partial, nblocks, term->n_theta, energy,
                        gtheta, gtheta_w);
     MDG_CHECK_LAUNCH("pair_ell_kernel");
     return MDG_OK;

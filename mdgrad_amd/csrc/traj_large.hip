@@ -1,0 +1,535 @@
+// Fused trajectories for systems too large for one workgroup (BASELINE config #4: 4 096-atom
+// LJ liquid).  Same semantics as traj_small.hip (NoseHooverChain + NH-Verlet forward,
+// torchmd/sovlers.py:110-127 with RHS torchmd/md.py:210-240; adjoint sovlers.py:211-293 with the
+// backward branch :129-164), but the state lives in HBM/L2 and every step is TWO launches
+// enqueued from a C++ host loop (no Python, no host sync):
+//
+//   kick_drift : first RHS (cached force) -> half kick, drift, bath half step
+//   force_step : neighbour search + force (+HVP) + second half kick + frame store, fused:
+//                one wave per atom scans LDS-staged position tiles with the reference's
+//                minimum-image test, compacts the accepted neighbours into a per-wave LDS
+//                list (ordered ballot compaction -- the neighbour list never exists in HBM),
+//                then all 64 lanes evaluate the compact list and combine with wave shuffles.
+//
+// This reproduces topology_update_freq == 1 (pair set re-derived at every force evaluation).
+// Scalars that couple workgroups (kinetic energy, sum(lambda_v . v), parameter gradients)
+// travel as per-block partials and are summed in a fixed order by block 0 of the NEXT launch
+// ("launch-boundary reduce"): deterministic, no atomics, no grid barrier.
+// O(N^2) pair tests per evaluation: meant for N <= ~16k (launch-bound regime); above that the
+// generic path with the cell list applies.
+#include "common.hpp"
+#pragma clang diagnostic ignored "-Wunused-result"
+
+namespace {
+
+constexpr int LG_WAVES = 8;                  // waves (= atoms in flight) per workgroup
+constexpr int LG_BLOCK = LG_WAVES * 64;
+constexpr int LG_TILE = 1024;                // positions staged in LDS per pass
+constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
+constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
+constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
+
+struct LargeArgs {
+    MdgTrajParams prm;
+    MdgCell cell;
+    MdgTerms terms;
+    const float* theta; const float* mass; const float* t;
+    float *q, *v, *vh, *f;                   // [R][N][3] running state
+    float *pv, *ph, *pvh;                    // [R][16]
+    float *partA, *partB;                    // [R][nb] kinetic-energy partials (ping / pong)
+    float *v_t, *q_t, *pv_t;                 // [R][T][N][3] frames
+    int32_t* flags;                          // [0] neighbour-buffer overflow, [1] non-finite
+    const float *g_v, *g_q, *g_pv;           // adjoint: incoming frame gradients (nullable)
+    float *lv, *lq, *lvh, *lqh, *dq, *qm, *vm;   // [R][N][3]
+    float *lp, *lph, *pvm;                   // [R][16]
+    float *partN;                            // [R][nb][LG_NV]
+    float *gth;                              // [R][K_total]
+    float *adj_v0, *adj_q0, *adj_pv0, *adj_theta;
+    int nbF, nbE;                            // workgroups of the per-atom / per-element kernels
+    int step;                                // forward: step index k; adjoint: frame index i
+};
+
+__device__ __forceinline__ float bath_rhs_l(const MdgTrajParams& p, const float* Q, const float* pv, float ke, int k) {
+    const int C = p.n_chains;
+    if (k == 0) return 2.f * (ke - p.T * p.n_dof * 0.5f) - pv[0] * pv[1] / Q[1];
+    if (k == C - 1) return pv[C - 2] * pv[C - 2] / Q[C - 2] - p.T;
+    return (pv[k - 1] * pv[k - 1] / Q[k - 1] - p.T) - pv[k + 1] * pv[k] / Q[k + 1];
+}
+
+__device__ __forceinline__ float bath_vjp_l(const MdgTrajParams& p, const float* Q, const float* pv,
+                                            const float* lp, float slv, int k) {
+    const int C = p.n_chains;
+    if (k == 0) return -slv / Q[0] - lp[0] * pv[1] / Q[1] + 2.f * pv[0] * lp[1] / Q[0];
+    if (k == C - 1) return -lp[C - 2] * pv[C - 2] / Q[C - 1];
+    return -lp[k - 1] * pv[k - 1] / Q[k] - lp[k] * pv[k + 1] / Q[k + 1] + 2.f * pv[k] * lp[k + 1] / Q[k];
+}
+
+// sum of column `col` of a [n][stride] partial array by one workgroup (fixed order)
+__device__ __forceinline__ float reduce_partials(const float* __restrict__ part, int n, int stride, int col,
+                                                 float* red) {
+    float s = 0.f;
+    for (int b = threadIdx.x; b < n; b += blockDim.x) s += part[(size_t)b * stride + col];
+    return block_sum(s, red);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One wave: neighbours of atom i from the LDS-staged tiles, then force (LEVEL 1) or force + HVP +
+// parameter vjp (LEVEL 2) over the compact list.  Results valid on every lane after the call.
+//   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m ; th += d(w.F)/dtheta partial
+template <bool DIAG, int LEVEL>
+__device__ __forceinline__ void wave_neighbours_and_force(
+    const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
+    float* tile, float4* buf, float& fx, float& fy, float& fz, float& gx, float& gy, float& gz,
+    float (&th)[LG_KMAX], const TermConst (&tc)[MDG_MAX_TERMS], float rc2max) {
+    const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
+    const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
+    int n = 0;
+    for (int t0 = 0; t0 < N; t0 += LG_TILE) {
+        const int tn = min(LG_TILE, N - t0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < 3 * tn; e += blockDim.x) tile[(e % 3) * LG_TILE + e / 3] = q[3 * t0 + e];
+        __syncthreads();
+        if (valid) {
+            for (int c0 = 0; c0 < tn; c0 += 64) {
+                const int jl = c0 + lane, j = t0 + jl;
+                bool ok = false;
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                if (jl < tn && j != i) {
+                    dx = tile[jl] - xi; dy = tile[LG_TILE + jl] - yi; dz = tile[2 * LG_TILE + jl] - zi;   // D = x_j - x_i
+                    min_image<DIAG>(A.cell, dx, dy, dz);
+                    const float d2 = norm2_ref(dx, dy, dz);
+                    ok = (d2 < rc2max) && (d2 != 0.f);
+                }
+                const unsigned long long b = __ballot(ok);
+                if (ok) {
+                    const int k = n + __popcll(b & ((1ull << lane) - 1ull));
+                    if (k < LG_CAP) buf[k] = make_float4(dx, dy, dz, __int_as_float(j));
+                }
+                n += __popcll(b);
+            }
+        }
+    }
+    if (n > LG_CAP) { if (lane == 0) atomicMax(&A.flags[0], n); n = LG_CAP; }
+    fx = fy = fz = gx = gy = gz = 0.f;
+    if (!valid) return;
+    float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+    if (LEVEL >= 2) { const float im = 1.0f / A.mass[i]; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
+    const int nt = A.terms.n_terms;
+    for (int k = lane; k < n; k += 64) {
+        const float4 e = buf[k];
+        const float dx = e.x, dy = e.y, dz = e.z;
+        const int j = __float_as_int(e.w);
+        const float d2 = norm2_ref(dx, dy, dz);
+#pragma unroll
+        for (int m = 0; m < MDG_MAX_TERMS; ++m) {
+            if (m >= nt) break;
+            if (!(d2 < tc[m].rc2)) continue;
+            const uint8_t* mk = A.terms.t[m].mask;
+            if (mk && !mk[(size_t)i * N + j]) continue;
+            PairOut o;
+            float r, ir;
+            pair_eval<LEVEL, -1>(tc[m], d2, r, ir, o);
+            const float c1 = o.du * ir;
+            fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+            if (LEVEL >= 2) {
+                const float jm = 1.0f / A.mass[j];
+                const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+                const float ax = wxi - lam[3 * j] * jm, ay = wyi - lam[3 * j + 1] * jm, az = wzi - lam[3 * j + 2] * jm;
+                const float a = rx * ax + ry * ay + rz * az;
+                const float c2 = o.d2u * a - c1 * a;
+                gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
+#pragma unroll
+                for (int p = 0; p < MDG_MAX_THETA; ++p)
+                    if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
+            }
+        }
+    }
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (LEVEL >= 2) { gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); }
+}
+
+__device__ __forceinline__ float prepare_terms(const LargeArgs& A, TermConst (&tc)[MDG_MAX_TERMS]) {
+    float rc2max = 0.f;
+#pragma unroll
+    for (int m = 0; m < MDG_MAX_TERMS; ++m)
+        if (m < A.terms.n_terms) { tc[m] = term_prepare(A.terms.t[m], A.theta); rc2max = fmaxf(rc2max, tc[m].rc2); }
+    return rc2max;
+}
+
+// ------------------------------------------------------------------------------------ forward
+// MODE 0: initial force at q0 + frame 0 + KE(v0) partials.   MODE 1: second half of step k.
+template <bool DIAG, int MODE>
+__global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) {
+    __shared__ float tile[3 * LG_TILE];
+    __shared__ float4 nbuf[LG_WAVES * LG_CAP];
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t so = (size_t)rep * N * 3;
+    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; float* f = A.f + so;
+    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
+    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
+    const int k = A.step;
+    if (threadIdx.x < MDG_MAX_CHAINS) {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+        Qs[threadIdx.x] = qv;
+    }
+    float dt = 0.f;
+    if (MODE == 1) dt = A.t[k + 1] - A.t[k];
+    // ---- block 0: finish the bath with KE(v + vh) from the previous launch's partials
+    if (MODE == 1 && blockIdx.x == 0) {
+        const float ke = 0.5f * reduce_partials(A.partB + (size_t)rep * A.nbE, A.nbE, 1, 0, red);
+        if (threadIdx.x < C) pvs[threadIdx.x] = pvh[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const float b1 = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+            const float np = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
+            pv[threadIdx.x] = np;
+            A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = np;
+        }
+    }
+    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < C)
+        A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
+    TermConst tc[MDG_MAX_TERMS];
+    const float rc2max = prepare_terms(A, tc);
+    const int i = blockIdx.x * LG_WAVES + wid;
+    const bool valid = i < N;
+    float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
+    wave_neighbours_and_force<DIAG, 1>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
+                                       th, tc, rc2max);
+    float kepart = 0.f;
+    if (valid && lane < 3) {
+        const float F = lane == 0 ? fx : (lane == 1 ? fy : fz);
+        const int e = 3 * i + lane;
+        const float m = A.mass[i];
+        float vn;
+        if (MODE == 0) vn = v[e];
+        else {
+            const float vv = v[e] + vh[e];
+            const float p = vv * m;
+            const float a = (F - pvh[0] * p / A.prm.Q[0]) / m;
+            vn = v[e] + (vh[e] + 0.5f * a * dt);
+            v[e] = vn;
+        }
+        f[e] = F;
+        const size_t fr = ((size_t)rep * T + (MODE == 0 ? 0 : k + 1)) * N * 3 + e;
+        A.q_t[fr] = q[e];
+        A.v_t[fr] = vn;
+        const float p = vn * m;
+        kepart = p * p / m;
+        if (!(isfinite(vn) && isfinite(F))) A.flags[1] = 1;
+    }
+    kepart = block_sum(kepart, red);
+    if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = kepart;
+}
+
+// first RHS of step k (cached force): half kick + drift + bath half step
+__global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
+    const size_t so = (size_t)rep * N * 3;
+    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; const float* f = A.f + so;
+    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
+    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
+    const float dt = A.t[k + 1] - A.t[k];
+    if (threadIdx.x < MDG_MAX_CHAINS) {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+        Qs[threadIdx.x] = qv;
+    }
+    if (blockIdx.x == 0) {
+        const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
+        if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const float h = 0.5f * bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x) * dt;
+            ph[threadIdx.x] = h;
+            pvh[threadIdx.x] = pvs[threadIdx.x] + h;
+        }
+    }
+    const float pv0 = pv[0];
+    float part = 0.f;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * N) {
+        const float m = A.mass[e / 3];
+        const float p = v[e] * m;
+        const float a = (f[e] - pv0 * p / A.prm.Q[0]) / m;
+        const float h = 0.5f * a * dt;
+        vh[e] = h;
+        q[e] = q[e] + (v[e] + h) * dt;
+        const float ph2 = (v[e] + h) * m;
+        part = ph2 * ph2 / m;
+    }
+    part = block_sum(part, red);
+    if (threadIdx.x == 0) A.partB[(size_t)rep * A.nbE + blockIdx.x] = part;
+}
+
+// ------------------------------------------------------------------------------------ adjoint
+// force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
+template <bool DIAG>
+__global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, const int second) {
+    __shared__ float tile[3 * LG_TILE];
+    __shared__ float4 nbuf[LG_WAVES * LG_CAP];
+    __shared__ float red[16 * LG_NV];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const size_t so = (size_t)rep * N * 3;
+    const float* qs = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
+    const float* vs = second ? A.vm + so : A.v_t + ((size_t)rep * T + i_fr) * N * 3;
+    const float* lam = second ? A.lvh + so : A.lv + so;
+    TermConst tc[MDG_MAX_TERMS];
+    const float rc2max = prepare_terms(A, tc);
+    const int i = blockIdx.x * LG_WAVES + wid;
+    const bool valid = i < N;
+    float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
+#pragma unroll
+    for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
+    wave_neighbours_and_force<DIAG, 2>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
+                                       tc, rc2max);
+    float vals[LG_NV];
+#pragma unroll
+    for (int p = 0; p < LG_KMAX; ++p) vals[p] = th[p];
+    float p1 = 0.f, p2 = 0.f;
+    if (valid && lane < 3) {
+        const int e = 3 * i + lane;
+        A.f[so + e] = lane == 0 ? fx : (lane == 1 ? fy : fz);
+        A.dq[so + e] = lane == 0 ? gx : (lane == 1 ? gy : gz);
+        const float m = A.mass[i], pp = vs[e] * m;
+        p1 = pp * pp / m;
+        p2 = lam[e] * vs[e];
+    }
+    vals[LG_KMAX] = p1; vals[LG_KMAX + 1] = p2;
+    block_sum_n<LG_NV>(vals, red);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int p = 0; p < LG_NV; ++p) A.partN[((size_t)rep * A.nbF + blockIdx.x) * LG_NV + p] = vals[p];
+    }
+}
+
+// after the first evaluation of interval i: midpoint state and half-step adjoint (sovlers.py:132-145)
+__global__ __launch_bounds__(256) void large_adj_mid(const LargeArgs A) {
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, i_fr = A.step;
+    const size_t so = (size_t)rep * N * 3, fo = ((size_t)rep * T + i_fr) * N * 3;
+    const float h = A.t[i_fr] - A.t[i_fr - 1];
+    if (threadIdx.x < MDG_MAX_CHAINS) {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+        Qs[threadIdx.x] = qv;
+    }
+    const float* pvf = A.pv_t + ((size_t)rep * T + i_fr) * C;
+    float* lp = A.lp + rep * MDG_MAX_CHAINS;
+    if (blockIdx.x == 0) {
+        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+        const float ke = 0.5f * reduce_partials(part, A.nbF, LG_NV, LG_KMAX, red);
+        const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+        if (threadIdx.x < C) { pvs[threadIdx.x] = pvf[threadIdx.x]; lps[threadIdx.x] = lp[threadIdx.x]; }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const float pb = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+            const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
+            A.pvm[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + 0.5f * (-pb) * h;      // :135
+            A.lph[rep * MDG_MAX_CHAINS + threadIdx.x] = lps[threadIdx.x] + gp * 0.5f * h;         // :143
+        }
+    }
+    const float pv0 = pvf[0], lp0 = lp[0];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * N) {
+        const float m = A.mass[e / 3], ve = A.v_t[fo + e], p = ve * m;
+        const float a = (A.f[so + e] - pv0 * p / A.prm.Q[0]) / m;
+        const float Gv = -(pv0 / A.prm.Q[0]) * A.lv[so + e] + A.lq[so + e] + 2.f * m * ve * lp0;
+        const float vhalf = 0.5f * (-a) * h;                                   // :132
+        A.qm[so + e] = A.q_t[fo + e] + (ve + vhalf) * h;                       // :138 (forward-time sign)
+        A.vm[so + e] = ve + vhalf;
+        A.lvh[so + e] = A.lv[so + e] + Gv * 0.5f * h;                          // :141
+        A.lqh[so + e] = A.lq[so + e] + A.dq[so + e] * 0.5f * h;                // :142
+    }
+}
+
+// after the midpoint evaluation: full adjoint update + dL/dy_{i-1}  (sovlers.py:156-160, :286)
+__global__ __launch_bounds__(256) void large_adj_end(const LargeArgs A) {
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, i_fr = A.step;
+    const size_t so = (size_t)rep * N * 3, go = ((size_t)rep * T + i_fr - 1) * N * 3;
+    const float h = A.t[i_fr] - A.t[i_fr - 1];
+    if (threadIdx.x < MDG_MAX_CHAINS) {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+        Qs[threadIdx.x] = qv;
+    }
+    const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
+    const float* lph = A.lph + rep * MDG_MAX_CHAINS;
+    float* lp = A.lp + rep * MDG_MAX_CHAINS;
+    const float pvm0 = pvm[0], lpm0 = lph[0];
+    if (blockIdx.x == 0) {
+        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+        const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+        const int KT = A.terms.n_theta_total;
+#pragma unroll
+        for (int m = 0; m < MDG_MAX_TERMS; ++m)
+#pragma unroll
+            for (int p = 0; p < MDG_MAX_THETA; ++p)
+                if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
+                    const float s = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
+                    if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += s * h;   // :160
+                }
+        if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
+            float nlp = lp[threadIdx.x] + gp * h;                               // :158
+            if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
+            lp[threadIdx.x] = nlp;
+        }
+    }
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 3 * N) {
+        const float m = A.mass[e / 3];
+        const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
+        float nlv = A.lv[so + e] + Gv * h;                                      // :156
+        float nlq = A.lq[so + e] + A.dq[so + e] * h;                            // :157
+        if (A.g_v) nlv += A.g_v[go + e];                                        // :286
+        if (A.g_q) nlq += A.g_q[go + e];
+        A.lv[so + e] = nlv; A.lq[so + e] = nlq;
+    }
+}
+
+struct WsLayout {
+    size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, flags, total;
+};
+
+WsLayout ws_layout(int R, int N, int nb, int KT) {
+    WsLayout w{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
+    const size_t s3 = (size_t)R * N * 3, sc = (size_t)R * MDG_MAX_CHAINS;
+    w.q = take(s3); w.v = take(s3); w.vh = take(s3); w.f = take(s3);
+    w.lv = take(s3); w.lq = take(s3); w.lvh = take(s3); w.lqh = take(s3); w.dq = take(s3); w.qm = take(s3); w.vm = take(s3);
+    w.pv = take(sc); w.ph = take(sc); w.pvh = take(sc); w.lp = take(sc); w.lph = take(sc); w.pvm = take(sc);
+    const int nbmax = nb > (3 * N + 255) / 256 ? nb : (3 * N + 255) / 256;
+    w.partA = take((size_t)R * nbmax); w.partB = take((size_t)R * nbmax);
+    w.partN = take((size_t)R * nbmax * LG_NV);
+    w.gth = take((size_t)R * (KT > 0 ? KT : 1));
+    w.flags = take(16);
+    w.total = o;
+    return w;
+}
+
+int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
+    MDG_CHECK_ARG(p && cell && terms, "traj_large: null descriptor");
+    MDG_CHECK_ARG(p->n_rep > 0 && p->n_atoms > 1 && p->n_frames >= 1, "traj_large: bad sizes");
+    MDG_CHECK_ARG(p->ensemble == 0, "traj_large: NoseHooverChain only (NVE runs the small or generic path)");
+    MDG_CHECK_ARG(p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS, "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
+    MDG_CHECK_ARG(terms->n_terms >= 1 && terms->n_terms <= MDG_MAX_TERMS, "traj_large: 1..%d pair terms", MDG_MAX_TERMS);
+    return MDG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_total) {
+    if (n_rep <= 0 || n_atoms <= 0) return -1;
+    const int nb = (n_atoms + LG_WAVES - 1) / LG_WAVES;
+    return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total).total;
+}
+
+#define LG_SETUP()                                                                                   \
+    const int R = prm->n_rep, N = prm->n_atoms;                                                      \
+    const int nbF = (N + LG_WAVES - 1) / LG_WAVES, nbE = (3 * N + 255) / 256;                        \
+    const int nbmax = nbF > nbE ? nbF : nbE;                                                         \
+    const WsLayout L = ws_layout(R, N, nbF, terms->n_theta_total);                                   \
+    LargeArgs a{};                                                                                   \
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;   \
+    a.q = ws + L.q; a.v = ws + L.v; a.vh = ws + L.vh; a.f = ws + L.f;                                \
+    a.lv = ws + L.lv; a.lq = ws + L.lq; a.lvh = ws + L.lvh; a.lqh = ws + L.lqh; a.dq = ws + L.dq;    \
+    a.qm = ws + L.qm; a.vm = ws + L.vm;                                                              \
+    a.pv = ws + L.pv; a.ph = ws + L.ph; a.pvh = ws + L.pvh; a.lp = ws + L.lp; a.lph = ws + L.lph;    \
+    a.pvm = ws + L.pvm; a.partA = ws + L.partA; a.partB = ws + L.partB; a.partN = ws + L.partN;      \
+    a.gth = ws + L.gth; a.flags = flags; a.nbF = nbF; a.nbE = nbE;                                               \
+    hipStream_t st = (hipStream_t)stream;                                                            \
+    const bool diag = cell->diag != 0;                                                               \
+    (void)nbmax;
+
+extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                  const float* theta, const float* mass, const float* t_grid,
+                                  const float* v0, const float* q0, const float* pv0,
+                                  float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream) {
+    int rc = validate_large(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v0 && q0 && pv0 && v_t && q_t && pv_t && ws && flags, "traj_fwd_large: null buffer");
+    LG_SETUP();
+    a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t;
+    const int C = prm->n_chains, T = prm->n_frames;
+    hipMemcpyAsync(a.q, q0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(a.v, v0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
+    hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
+                     hipMemcpyDeviceToDevice, st);
+    dim3 gF(nbF, R), gE(nbE, R);
+    a.step = 0;
+    if (diag) hipLaunchKernelGGL((large_force_step<true, 0>), gF, dim3(LG_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((large_force_step<false, 0>), gF, dim3(LG_BLOCK), 0, st, a);
+    for (int k = 0; k + 1 < T; ++k) {
+        a.step = k;
+        hipLaunchKernelGGL(large_kick_drift, gE, dim3(256), 0, st, a);
+        if (diag) hipLaunchKernelGGL((large_force_step<true, 1>), gF, dim3(LG_BLOCK), 0, st, a);
+        else hipLaunchKernelGGL((large_force_step<false, 1>), gF, dim3(LG_BLOCK), 0, st, a);
+    }
+    MDG_CHECK_LAUNCH("traj_fwd_large");
+    return MDG_OK;
+}
+
+extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                  const float* theta, const float* mass, const float* t_grid,
+                                  const float* v_t, const float* q_t, const float* pv_t,
+                                  const float* g_v, const float* g_q, const float* g_pv,
+                                  float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                  float* ws, int32_t* flags, void* stream) {
+    int rc = validate_large(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v_t && q_t && pv_t && adj_v0 && adj_q0 && adj_pv0 && ws && flags,
+                  "traj_adj_large: null buffer");
+    LG_SETUP();
+    a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
+    a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
+    const int C = prm->n_chains, T = prm->n_frames, KT = terms->n_theta_total;
+    const size_t fr = sizeof(float) * (size_t)N * 3;
+    // lam = dL/dy_{T-1}
+    for (int r = 0; r < R; ++r) {
+        float* lv = a.lv + (size_t)r * N * 3;
+        float* lq = a.lq + (size_t)r * N * 3;
+        if (g_v) hipMemcpyAsync(lv, g_v + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st);
+        else hipMemsetAsync(lv, 0, fr, st);
+        if (g_q) hipMemcpyAsync(lq, g_q + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st);
+        else hipMemsetAsync(lq, 0, fr, st);
+        if (g_pv) hipMemcpyAsync(a.lp + r * MDG_MAX_CHAINS, g_pv + ((size_t)r * T + T - 1) * C, sizeof(float) * C,
+                                 hipMemcpyDeviceToDevice, st);
+        else hipMemsetAsync(a.lp + r * MDG_MAX_CHAINS, 0, sizeof(float) * MDG_MAX_CHAINS, st);
+    }
+    hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st);
+    dim3 gF(nbF, R), gE(nbE, R);
+    for (int i = T - 1; i >= 1; --i) {
+        a.step = i;
+        if (diag) hipLaunchKernelGGL(large_adj_force<true>, gF, dim3(LG_BLOCK), 0, st, a, 0);
+        else hipLaunchKernelGGL(large_adj_force<false>, gF, dim3(LG_BLOCK), 0, st, a, 0);
+        hipLaunchKernelGGL(large_adj_mid, gE, dim3(256), 0, st, a);
+        if (diag) hipLaunchKernelGGL(large_adj_force<true>, gF, dim3(LG_BLOCK), 0, st, a, 1);
+        else hipLaunchKernelGGL(large_adj_force<false>, gF, dim3(LG_BLOCK), 0, st, a, 1);
+        hipLaunchKernelGGL(large_adj_end, gE, dim3(256), 0, st, a);
+    }
+    hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
+    hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
+                     hipMemcpyDeviceToDevice, st);
+    if (adj_theta && KT > 0)
+        hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st);
+    MDG_CHECK_LAUNCH("traj_adj_large");
+    return MDG_OK;
+}

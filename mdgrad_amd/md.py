@@ -14,7 +14,8 @@ from .sovlers import odeint_adjoint, odeint
 from .system import wrap_positions
 from .tinydiffeq import _flatten
 
-FUSED_MAX_ATOMS = 1024
+FUSED_MAX_ATOMS = 1024          # one workgroup per replica (csrc/traj_small.hip)
+FUSED_MAX_ATOMS_LARGE = 16384   # two launches per step (csrc/traj_large.hip), NoseHooverChain only
 
 
 def compute_grad(inputs, output, create_graph=True, retain_graph=True):
@@ -109,6 +110,7 @@ class _FusedSpec(ops.FusedSpec):
 class _EOM(torch.nn.Module):
     _ensemble = None
     _method = None
+    fused_large = None      # None = by size; True/False forces the multi-launch / one-workgroup kernels
 
     def update_topology(self, q):                               # md.py:200-204
         if self.update_count % self.topology_update_freq == 0:
@@ -121,7 +123,10 @@ class _EOM(torch.nn.Module):
             return None
         mods = _pair_terms_of(self.model)
         N = self.mass.shape[0]
-        if mods is None or N > FUSED_MAX_ATOMS or not self.adjoint:
+        if mods is None or not self.adjoint:
+            return None
+        large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
+        if large and (self._ensemble != 0 or N > FUSED_MAX_ATOMS_LARGE):
             return None
         plist = list(self.parameters())
         offs, pos = {}, 0
@@ -144,7 +149,7 @@ class _EOM(torch.nn.Module):
                 return None
             kw = dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
         return _FusedSpec(self, self._ensemble, N, self.mass.contiguous(), cs, ops.make_terms(terms, pos), pos,
-                          masks, **kw)
+                          masks, large=large, **kw)
 
 
 class NVE(_EOM):

@@ -201,7 +201,8 @@ class FusedSpec:
     terms, topology_update_freq == 1)."""
 
     def __init__(self, ensemble, n_atoms, mass, cell_struct, terms, n_theta_total, masks,
-                 T=0.0, n_dof=0.0, Q=(), block=0):
+                 T=0.0, n_dof=0.0, Q=(), block=0, large=False):
+        self.large = large
         self.ensemble, self.n_atoms, self.mass = ensemble, n_atoms, mass
         self.cell_struct, self.terms, self.n_theta_total, self.masks = cell_struct, terms, n_theta_total, masks
         self.T, self.n_dof, self.Q, self.block = float(T), float(n_dof), list(Q), block
@@ -246,11 +247,25 @@ class FusedTrajFn(torch.autograd.Function):
         v_t = torch.empty(R, T, N, 3, device=dev)
         q_t = torch.empty(R, T, N, 3, device=dev)
         pv_t = torch.empty(R, T, Cn, device=dev) if nhc else None
-        bad = torch.zeros(R, dtype=torch.int32, device=dev)
         prm = spec.params(R, T)
-        check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
-                                     ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
-                                     ptr(q_t), ptr(pv_t), ptr(bad), stream_ptr(dev)), "mdg_traj_fwd_small")
+        ctx.ws = None
+        if spec.large:
+            ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, spec.n_theta_total)), device=dev)
+            flags = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                         ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
+                                         ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
+                  "mdg_traj_fwd_large")
+            need = int(flags[0].item())            # one sync per trajectory (neighbour buffer check)
+            if need:
+                raise RuntimeError("mdgrad_amd: an atom has %d neighbours within the cutoff; the fused large-N "
+                                   "kernel holds 256 per atom" % need)
+            ctx.ws, bad = ws, flags[1:2]
+        else:
+            bad = torch.zeros(R, dtype=torch.int32, device=dev)
+            check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                         ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
+                                         ptr(q_t), ptr(pv_t), ptr(bad), stream_ptr(dev)), "mdg_traj_fwd_small")
         ctx.spec, ctx.batched, ctx.nhc = spec, batched, nhc
         ctx.nonfinite = bad
         saved = [tc, v_t, q_t] + ([pv_t] if nhc else []) + ([thc] if thc is not None else [])
@@ -289,10 +304,17 @@ class FusedTrajFn(torch.autograd.Function):
         KT = spec.n_theta_total
         adj_th = torch.zeros(R, KT, device=dev) if KT else None
         prm = spec.params(R, T)
-        check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
-                                     ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
-                                     ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
-                                     stream_ptr(dev)), "mdg_traj_adj_small")
+        if spec.large:
+            flags = torch.zeros(2, dtype=torch.int32, device=dev)
+            check(lib.mdg_traj_adj_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                         ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                         ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
+                                         ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
+        else:
+            check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                         ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                         ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                         stream_ptr(dev)), "mdg_traj_adj_small")
         if not ctx.batched:
             adj_v, adj_q = adj_v[0], adj_q[0]
             adj_p = adj_p[0] if nhc else None

@@ -137,6 +137,7 @@ class OdeintAdjointMethod(torch.autograd.Function):
             return (*f_eval, *vjp_y, vjp_t, vjp_p)
 
         T = ans[0].shape[0]
+        need_time = ctx.needs_input_grad[n + 1]
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
             adj_params = torch.zeros_like(flat_params)
@@ -145,8 +146,15 @@ class OdeintAdjointMethod(torch.autograd.Function):
             for i in range(T - 1, 0, -1):
                 ans_i = tuple(a[i] for a in ans)
                 g_i = tuple(g[i] for g in grad_output)
-                f_i = func(t[i], ans_i)                       # sovlers.py:258 (advances the topology counter)
-                dLd_cur_t = sum(torch.dot(a.reshape(-1), b.reshape(-1)).reshape(1) for a, b in zip(f_i, g_i))
+                if need_time or not hasattr(func, "update_topology"):
+                    f_i = func(t[i], ans_i)                   # sovlers.py:258
+                    dLd_cur_t = sum(torch.dot(a.reshape(-1), b.reshape(-1)).reshape(1) for a, b in zip(f_i, g_i))
+                else:
+                    # the reference evaluates func here only for dL/dt, which nobody consumes when t
+                    # needs no gradient; keep its side effect (the topology counter / rebuild,
+                    # md.py:200-204) and skip the force evaluation
+                    func.update_topology(ans_i[1])
+                    dLd_cur_t = torch.zeros(1).to(t)
                 adj_time = adj_time - dLd_cur_t
                 time_vjps.append(dLd_cur_t)
                 if adj_params.numel() == 0:

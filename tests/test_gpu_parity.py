@@ -431,3 +431,68 @@ def test_product_has_no_cpu_path():
     from mdgrad_amd.topology import generate_nbr_list
     with pytest.raises(RuntimeError):
         generate_nbr_list(torch.zeros(4, 3), 1.0, torch.ones(3))
+
+
+# ------------------------------------------------------------------ large-N fused path (csrc/traj_large.hip)
+@pytest.mark.parametrize("kind", ["lj", "exvol"])
+def test_large_path_kernels_on_golden_108(kind):
+    """The multi-launch kernels forced onto the 108-atom goldens (same contract as the small path)."""
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from mdgrad_amd.observable import rdf
+    gt, ga = load_golden("nhc_traj_" + kind), load_golden("nhc_adj_" + kind)
+    system, mdl, integ = lj_setup(gt, kind)
+    integ.fused_large = True
+    assert integ.fused_spec("NH_verlet").large
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(gt["dt"]) * i for i in range(50)]).to(DEV)
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    close(q_t, gt["q_t"], 0, 1e-4, "q_t")
+    close(v_t, gt["v_t"], 0, 2e-3, "v_t")
+    close(pv_t, gt["pv_t"], 1e-3, 1e-3, "pv_t")
+    count, bins, gr = rdf(system, nbins=100, r_range=(0.75, 2.5))(q_t)
+    loss = (gr - 1).pow(2).mean() + 0.01 * v_t[-1].pow(2).sum() + 0.1 * pv_t[-1].sum()
+    loss.backward()
+    close(mdl.sigma.grad, ga["grad_sigma"], 2e-3, 1e-4 * abs(float(ga["grad_sigma"][0])), "dL/dsigma")
+    close(mdl.epsilon.grad, ga["grad_epsilon"], 2e-3, 1e-4 * abs(float(ga["grad_sigma"][0])), "dL/depsilon")
+    for y, k in zip(y0, ["grad_v0", "grad_q0", "grad_pv0"]):
+        close(y.grad, ga[k], 5e-3, 2e-3 * np.abs(ga[k]).max(), k)
+
+
+def test_large_path_2744_atoms_vs_generic_and_replicas():
+    """N = 2744 LJ liquid (14^3), 6 steps: fused large kernels == generic reference control flow on
+    HIP ops; two replicas in one call == two single calls; repeated launches bitwise equal."""
+    from mdgrad_amd import ops
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint, OdeintAdjointMethod
+    from mdgrad_amd.tinydiffeq import _flatten
+    pos, cell = liquid(14, seed=5, jitter=0.05)
+    rng = np.random.default_rng(1)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.004 * i for i in range(7)]).to(DEV)
+    res = []
+    for fused in (True, False):
+        system = mk_system(pos, cell, vel)
+        mdl = P.LennardJones(1.0, 1.0)
+        integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3,
+                                Q=30.0).to(DEV)
+        y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+        if fused:
+            assert integ.fused_spec("NH_verlet").large
+            out = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+        else:
+            out = OdeintAdjointMethod.apply(*y0, integ, t, _flatten(integ.parameters()), 1e-6, 1e-12, "NH_verlet", None)
+        (out[1][::2].pow(2).mean() + out[0][-1].pow(2).mean() + out[2][-1].sum() * 1e-3).backward()
+        res.append([o.detach() for o in out] + [y.grad for y in y0] + [mdl.sigma.grad, mdl.epsilon.grad])
+        if fused:
+            spec = integ.fused_spec("NH_verlet")
+            v2 = torch.stack([y0[0].detach(), y0[0].detach() * 0.5])
+            q2 = torch.stack([y0[1].detach(), y0[1].detach()])
+            p2 = torch.zeros(2, 3, device=DEV)
+            a = ops.FusedTrajFn.apply(v2, q2, p2, t, spec.flat_params(), spec)
+            b = ops.FusedTrajFn.apply(v2, q2, p2, t, spec.flat_params(), spec)
+            assert all(torch.equal(x, y) for x, y in zip(a, b)), "bitwise reproducible"
+            assert torch.equal(a[1][0], out[1].detach()), "replica 0 of a batch == single run"
+    for k, (a, b) in enumerate(zip(*res)):
+        close(a, b, 5e-4, 5e-5 * float(b.abs().max()) + 1e-7, "large fused vs generic #%d" % k)

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Step rates of the non-fused configurations (wall clock, synchronised):
+  lj4096   4096-atom LJ liquid (BASELINE config #4), NHC, forward + adjoint of an RDF loss
+  gnn      CG-water SchNet + ExcludedVolume prior (BASELINE configs #3/#5 shape), Diamond lattice
+Usage: python tools/gbench.py [lj4096] [gnn64] [gnn512] [--steps 10]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(integ, system, obs, nsteps, dt, method="NH_verlet", reps=2):
+    from mdgrad_amd.sovlers import odeint_adjoint
+    dev = system.device
+    t = torch.Tensor([dt * i for i in range(nsteps + 1)]).to(dev)
+    out = None
+    for rep in range(reps + 1):
+        y0 = tuple(integ.get_inital_states(wrap=True))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        traj = odeint_adjoint(integ, y0, t, method=method)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        _, _, g = obs(traj[1][::5])
+        loss = (g - 1).pow(2).mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out = (t1 - t0, t2 - t1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["lj4096", "gnn64", "gnn512"])
+    ap.add_argument("--steps", type=int, default=10)
+    args = ap.parse_args()
+    from mdgrad_amd import potentials as P, units
+    from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.system import System, Diamond, Atoms
+    dev = "cuda:0"
+    rng = np.random.default_rng(0)
+    for w in args.which:
+        if w == "lj4096":
+            n = 16
+            L = (n ** 3 / 0.845) ** (1 / 3)
+            g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) * (L / n)
+            pos = np.mod(g + rng.uniform(-0.05, 0.05, g.shape) * (L / n), L)
+            system = System(Atoms(positions=pos, cell=[L, L, L], numbers=np.ones(len(pos))), device=dev)
+            system.set_velocities(rng.normal(0, 1.0, pos.shape))
+            integ = NoseHooverChain(Stack({"pair": PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=2.5)}),
+                                    system, T=1.0, num_chains=5, Q=50.0).to(dev)
+            obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+            tf, tb = run(integ, system, obs, args.steps, 0.005)
+        else:
+            size = 2 if w == "gnn64" else 4
+            a = units.get_unit_len(0.997, 18.01528, 8)
+            atoms = Diamond("O", (size,) * 3, a)
+            pos = np.mod(atoms.get_positions() + rng.normal(0, 0.2, (len(atoms), 3)), a * size)
+            atoms.set_positions(pos)
+            atoms.masses[:] = 18.01528
+            system = System(atoms, device=dev)
+            kT = 298.0 * units.kB
+            system.set_temperature(kT, rng=rng)
+            torch.manual_seed(0)
+            net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2,
+                             "cutoff": 6.0})
+            gnn = GNNPotentials(system, net, cutoff=6.0)
+            prior = PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)
+            integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=kT, num_chains=5, Q=50.0).to(dev)
+            obs = rdf(system, nbins=60, r_range=(2.0, min(6.0, 0.49 * a * size)))
+            tf, tb = run(integ, system, obs, args.steps, 1.0 * units.fs)
+        print("%-8s N=%5d steps=%d  fwd %.4f s  bwd(adjoint+rdf) %.4f s  -> %.1f MD steps/s (fwd+adj)" % (
+            w, system.get_number_of_atoms(), args.steps, tf, tb, args.steps / (tf + tb)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

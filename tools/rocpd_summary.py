@@ -23,6 +23,8 @@ def stats(path):
         agg[name].append(dur)
         meta[name] = (wg, grid, vg, sg, lds, scr)
     total = sum(sum(v) for v in agg.values())
+    n, t0, t1 = cur.execute("select count(*), min(start), max(end) from kernels").fetchone()
+    print("# %d kernel launches, GPU busy %.3f ms, first-start to last-end span %.3f ms" % (n, total / 1e6, (t1 - t0) / 1e6))
     print("%-72s %6s %12s %12s %12s %12s %6s | %5s %8s %5s %5s %7s %5s" % (
         "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%", "wg", "grid", "vgpr", "sgpr", "lds", "scr"))
     for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
