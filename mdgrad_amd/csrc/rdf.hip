@@ -31,44 +31,26 @@ __device__ __forceinline__ void pair_from_flat(long long c, int N, int& i, int& 
     j = (int)(c - (long long)ii * (2LL * N - ii - 1) / 2) + ii + 1;
 }
 
-constexpr int RDF_NSEG = 32;             // distance segments for the windowed sweep
-
-// exp(coeff (d - mu)^2) = exp2(-(s (d - mu))^2) with s = sqrt(-coeff log2 e): the sweep costs
-// sub, mul, mul, v_exp_f32, add per (pair, bin).
+// exp(coeff (d - mu)^2) = exp2(-(s d - s mu)^2) with s = sqrt(-coeff log2 e): distances and
+// the sweep costs sub, mul, mul, v_exp_f32, add per (pair, bin).
 //
-// Windowed sweep.  A Gaussian contributes less than 2^-126 beyond `reach` = 11.3/s from its
-// centre, so bin k only needs distances in [mu_k - reach, mu_k + reach].  Each 512-candidate
-// batch is counting-sorted into RDF_NSEG distance segments in LDS (per-segment ballots, fixed
-// segment-major / wave-major / lane order => deterministic), and thread (g, k) sweeps only the
-// segments its window overlaps.  Distances outside every window (< mu_0 - reach or
-// > mu_last + reach) are dropped: their contribution is below the smallest normal float.
-//
-// Thread layout: nbins <= RDF_BLOCK.  G = RDF_BLOCK / nbins thread groups share the sweep
-// (group g takes entries g, g+G, ... of the window) and are combined in group order at the end.
+// Thread layout: nbins <= RDF_BLOCK.  G = RDF_BLOCK / nbins thread groups; thread (g, k) owns
+// bin k and sweeps the compacted distances 4g..4g+3, 4(g+G).., ... (ds_read_b128); the groups
+// are combined in group order at the end.  Bins beyond RDF_BLOCK are handled by the slow path.
 template <bool DIAG>
 __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
     const float* __restrict__ mu, float coeff, int nbins, float* __restrict__ partial) {
-    constexpr int nw = RDF_BLOCK / 64;
-    __shared__ float dist[RDF_BLOCK];
-    __shared__ int wcnt[RDF_NSEG * nw];          // [seg][wave] counts, then exclusive offsets
-    __shared__ int segstart[RDF_NSEG + 1];
+    __shared__ __attribute__((aligned(16))) float dist[RDF_BLOCK + 4];
+    __shared__ int wcnt[RDF_BLOCK / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int nw = RDF_BLOCK / 64;
     const float sc = sqrtf(-coeff * LOG2E);
-    const float reach = 11.3f / sc;
     const int G = RDF_BLOCK / nbins;
     const int grp = threadIdx.x / nbins;
     const bool active = grp < G;
     const int k = threadIdx.x - grp * nbins;
     const float ms = active ? mu[k] : 0.f;
-    const float d_lo = mu[0] - reach, d_hi = mu[nbins - 1] + reach;
-    const float seg_inv = (float)RDF_NSEG / (d_hi - d_lo);
-    // segments overlapped by this thread's window (conservative by one segment on each side)
-    int s_lo = 0, s_hi = -1;
-    if (active) {
-        s_lo = max(0, (int)floorf((ms - reach - d_lo) * seg_inv) - 1);
-        s_hi = min(RDF_NSEG - 1, (int)floorf((ms + reach - d_lo) * seg_inv) + 1);
-    }
     float acc = 0.f;
     const long long npair = (long long)N * (N - 1) / 2;
     const int chunks = (int)((npair + RDF_CHUNK - 1) / RDF_CHUNK);
@@ -81,8 +63,7 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
         int i = 0, j = 0;
         if (c < c_end) pair_from_flat(c, N, i, j);
         for (long long cb = (long long)ch * RDF_CHUNK; cb < c_end; cb += RDF_BLOCK) {
-            float d = 0.f;
-            int seg = -1;
+            float d = -1.f;
             if (c < c_end) {
                 float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1],
                       dz = pos[3 * j + 2] - pos[3 * i + 2];
@@ -90,49 +71,32 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
                 const float d2 = norm2_ref(dx, dy, dz);
                 bool ok = (d2 < rc2) && (d2 != 0.f);
                 if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
-                if (ok) {
-                    d = sqrtf(d2);
-                    if (d > d_lo && d < d_hi) seg = min(RDF_NSEG - 1, (int)((d - d_lo) * seg_inv));
-                }
+                if (ok) d = sqrtf(d2);
+                // advance to the candidate RDF_BLOCK further on
                 c += RDF_BLOCK;
                 j += RDF_BLOCK;
                 while (j >= N && i < N - 1) { ++i; j = j - N + i + 1; }
             }
-            // ---- deterministic counting sort of this batch by segment
-            int rank = 0;
+            const unsigned long long b = __ballot(d >= 0.f);
             __syncthreads();                                   // previous sweep done with dist[]
-#pragma unroll 4
-            for (int s = 0; s < RDF_NSEG; ++s) {
-                const unsigned long long b = __ballot(seg == s);
-                if (seg == s) rank = __popcll(b & ((1ull << lane) - 1ull));
-                if (lane == 0) wcnt[s * nw + wid] = __popcll(b);
-            }
+            if (lane == 0) wcnt[wid] = __popcll(b);
             __syncthreads();
-            if (wid == 0) {                                    // exclusive scan of the [seg][wave] table
-                int run = 0;
-                for (int base = 0; base < RDF_NSEG * nw; base += 64) {
-                    const int idx = base + lane;
-                    const int v = idx < RDF_NSEG * nw ? wcnt[idx] : 0;
-                    int x = v;
+            int base = 0, total = 0;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-                    const int excl = run + x - v;
-                    if (idx < RDF_NSEG * nw) {
-                        wcnt[idx] = excl;
-                        if (idx % nw == 0) segstart[idx / nw] = excl;
-                    }
-                    run += __shfl(x, 63, 64);
-                }
-                if (lane == 0) segstart[RDF_NSEG] = run;
-            }
-            __syncthreads();
-            if (seg >= 0) dist[wcnt[seg * nw + wid] + rank] = d;
+            for (int w = 0; w < nw; ++w) { if (w < wid) base += wcnt[w]; total += wcnt[w]; }
+            if (d >= 0.f) dist[base + __popcll(b & ((1ull << lane) - 1ull))] = d;
+            if (threadIdx.x < 4) dist[total + threadIdx.x] = 3.0e18f;   // pad: exp2(-x^2) == 0
             __syncthreads();
             if (active) {
-                const int p_lo = segstart[s_lo], p_hi = segstart[s_hi + 1];
-                for (int p = p_lo + grp; p < p_hi; p += G) {
-                    const float x = (dist[p] - ms) * sc;      // (d - mu) first, then scale
-                    acc += __builtin_amdgcn_exp2f(-x * x);
+                for (int p = 4 * grp; p < total; p += 4 * G) {
+                    const float4 dd = *reinterpret_cast<const float4*>(&dist[p]);
+                    // (d - mu) first, then scale: no cancellation error on the scaled values
+                    const float x0 = (dd.x - ms) * sc, x1 = (dd.y - ms) * sc, x2 = (dd.z - ms) * sc,
+                                x3 = (dd.w - ms) * sc;
+                    acc += __builtin_amdgcn_exp2f(-x0 * x0);
+                    acc += __builtin_amdgcn_exp2f(-x1 * x1);
+                    acc += __builtin_amdgcn_exp2f(-x2 * x2);
+                    acc += __builtin_amdgcn_exp2f(-x3 * x3);
                 }
             }
         }
