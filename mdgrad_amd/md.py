@@ -208,6 +208,28 @@ class NoseHooverChain(_EOM):
     def update_T(self, T):
         self.T = T
 
+    def force(self, q):
+        """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to
+        reuse the force between the second evaluation of step k and the first of step k+1 -- same q,
+        bit-identical result; only when topology_update_freq == 1)."""
+        with torch.set_grad_enabled(True):
+            q = q.detach().requires_grad_(True)
+            self.update_topology(q)
+            u = self.model(q)
+            (g,) = torch.autograd.grad(u.sum(), q)
+        return -g
+
+    def rhs_from_force(self, state, f):
+        """md.py:221-240 given F(q)."""
+        v, q, p_v = state
+        p = v * self.mass[:, None]
+        sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()
+        coupled_forces = (p_v[0] * p.reshape(-1) / self.Q[0]).reshape(-1, 3)
+        dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[0] * p_v[1] / self.Q[1]
+        dpvdt_mid = (p_v[:-2].pow(2) / self.Q[:-2] - self.T) - p_v[2:] * p_v[1:-1] / self.Q[2:]
+        dpvdt_last = p_v[-2].pow(2) / self.Q[-2] - self.T
+        return ((f - coupled_forces) / self.mass[:, None], v, torch.cat((dpvdt_0[None], dpvdt_mid, dpvdt_last[None])))
+
     def forward(self, t, state):
         with torch.set_grad_enabled(True):
             v, q, p_v = state[0], state[1], state[2]

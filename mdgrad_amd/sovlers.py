@@ -75,6 +75,30 @@ class NHVerlet(FixedGridODESolver):
     def step_func(self, func, t, dt, y):
         return NHverlet_update(func, t, dt, y)
 
+    def integrate(self, t):
+        """Graph-free forward integration of a NoseHooverChain with the force at q_{k+1} evaluated once
+        and reused by the next step (the reference evaluates it twice, sovlers.py:111,121 -- same q,
+        same value).  Anything else goes through the reference's two-call step."""
+        func = self.func
+        if (torch.is_grad_enabled() or len(self.y0) != 3 or not hasattr(func, "rhs_from_force")
+                or getattr(func, "topology_update_freq", 0) != 1):
+            return super().integrate(t)
+        t = t.type_as(self.y0[0]).to(self.y0[0].device)
+        v, q, pv = self.y0
+        frames = [(v, q, pv)]
+        F = func.force(q)
+        for k in range(t.shape[0] - 1):
+            dt = t[k + 1] - t[k]
+            a0, _, b0 = func.rhs_from_force((v, q, pv), F)
+            dv_h = 1 / 2 * a0 * dt
+            dp_h = 1 / 2 * b0 * dt
+            dq = (v + dv_h) * dt
+            F = func.force(q + dq)
+            a1, _, b1 = func.rhs_from_force((v + dv_h, q + dq, pv + dp_h), F)
+            v, q, pv = v + (dv_h + 1 / 2 * a1 * dt), q + dq, pv + (dp_h + 1 / 2 * b1 * dt)
+            frames.append((v, q, pv))
+        return tuple(torch.stack([f[i] for f in frames]) for i in range(3))
+
 
 class Verlet(FixedGridODESolver):
     def step_func(self, func, t, dt, y):
