@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=4096, help="replicas per GPU")
+    ap.add_argument("--replicas", type=int, default=8192, help="replicas per GPU")
     ap.add_argument("--frames", type=int, default=50, help="saved frames T (T-1 MD steps)")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
@@ -173,9 +173,19 @@ def main():
         Pn = int(ell.half_list()[0].shape[0])
         N = 108
         bytes_adj = (48 * Pn + 208 * N) * (T - 1) * R           # 2 B_H + B_A + 2 B_N per step
+        # HBM bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: FETCH_SIZE and
+        # WRITE_SIZE collected in separate rocprofv3 --pmc runs, FETCH_SIZE doubled per the gfx950 note),
+        # recorded per replica and scaled to this run's replica count
+        traffic = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["traj_adj_kernel"]
+            if pj["frames"] == T:
+                traffic = pj["hbm_bytes_per_replica"] * R
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "traj_adj_kernel", "achieved": bytes_adj / (adj_ms * 1e-3) / 1e9,
                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": bytes_adj / (adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                           "frac": bytes_adj / (adj_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel_ms": adj_ms, "algorithmic_bytes_per_launch": bytes_adj,
                            "note": "algorithmic bytes of the unfused op chain (SURVEY 8d: 48P+208N per adjoint "
                                    "step, P=%d); the fused kernel keeps state in LDS so real HBM traffic is "
@@ -183,6 +193,9 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(T, args.dt)
         print(json.dumps(out))
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.destroy_process_group()
 
 
 if __name__ == "__main__":
