@@ -10,8 +10,9 @@
 //           distances (broadcast reads, register accumulator kept across work items).  Per-block
 //           partial histograms are added by a second kernel in a fixed order => no atomics,
 //           reproducible.  exp uses the hardware v_exp_f32 path (__expf, rel. err ~1e-6).
-// backward: LPA lanes per (frame, atom); each accepted pair contributes
-//           sum_k g_raw[k] * 2 coeff (d - mu_k) e_k  along the unit separation vector.
+// backward: one wave per frame in round-robin-tournament pair order (see rdf_bwd_kernel); each
+//           accepted pair contributes sum_k g_raw[k] * 2 coeff (d - mu_k) e_k along +/- its unit
+//           separation vector, accumulated in LDS without atomics.
 #include "common.hpp"
 
 namespace {
@@ -121,61 +122,73 @@ __global__ void rdf_finish_kernel(const float* __restrict__ partial, int nblocks
     if (lane == 0) raw[k] = s;
 }
 
-template <bool DIAG, int LPA>
-__global__ void rdf_bwd_kernel(const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2,
-                               const uint8_t* __restrict__ mask, const float* __restrict__ mu, float coeff,
-                               int nbins, const float* __restrict__ g_raw, float* __restrict__ g_xyz) {
+// Backward: one WAVE per frame, every unordered pair visited once.  The pairs are walked in
+// round-robin-tournament order (circle method): round r holds floor(N'/2) DISJOINT pairs, so
+// the lanes of one instruction never touch the same atom and the +/- contributions go into a
+// wave-private LDS gradient with plain read-modify-writes -- no atomics, and the rounds are
+// sequential within the wave => fixed summation order, bitwise reproducible.
+template <bool DIAG>
+__global__ __launch_bounds__(256) void rdf_bwd_kernel(
+    const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
+    const float* __restrict__ mu, float coeff, int nbins, const float* __restrict__ g_raw,
+    float* __restrict__ g_xyz) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* smu = sm;             // [nbins]
-    float* sg = sm + nbins;      // [nbins]
+    float* smu = sm;                         // [nbins]
+    float* sg = sm + nbins;                  // [nbins]  g_k * 2 coeff / s
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float* px = sg + nbins + (size_t)wid * 6 * N;   // positions [3][N] then gradient [3][N] of this wave's frame
+    float* gx = px + 3 * N;
     const float sc = sqrtf(-coeff * LOG2E);
     for (int k = threadIdx.x; k < nbins; k += blockDim.x) { smu[k] = mu[k]; sg[k] = g_raw[k] * 2.f * coeff / sc; }
     __syncthreads();
-    const int apb = blockDim.x / LPA;
-    const long long gi = (long long)blockIdx.x * apb + threadIdx.x / LPA;
-    const int sub = threadIdx.x % LPA;
-    if (gi >= (long long)nF * N) return;
-    const int fr = (int)(gi / N), i = (int)(gi % N);
+    const int fr = blockIdx.x * (blockDim.x >> 6) + wid;
+    if (fr >= nF) return;
     const float* pos = xyz + (size_t)fr * N * 3;
-    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    // bins whose Gaussian is non-negligible (exp2 argument > -126) around a distance
+    for (int e = lane; e < 3 * N; e += 64) { px[(e % 3) * N + e / 3] = pos[e]; gx[e] = 0.f; }
     const float dmu = nbins > 1 ? (smu[nbins - 1] - smu[0]) / (float)(nbins - 1) : 0.f;
-    const float reach = 11.3f / sc;                                       // sqrt(126) in scaled units
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int j = sub; j < N; j += LPA) {
-        if (j == i) continue;
-        float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
-        // the half list holds (min(i,j), max(i,j)) with D = x_hi - x_lo: evaluate in that
-        // orientation so the accepted set is the forward pass's
-        const bool flip = j < i;
-        if (flip) { dx = -dx; dy = -dy; dz = -dz; }
-        min_image<DIAG>(cell, dx, dy, dz);
-        const float d2 = norm2_ref(dx, dy, dz);
-        if (!((d2 < rc2) && (d2 != 0.f))) continue;
-        if (mask && !mask[(size_t)(flip ? j : i) * N + (flip ? i : j)]) continue;
-        const float id = __builtin_amdgcn_rsqf(d2);
-        const float ds = d2 * id;
-        int klo = 0, khi = nbins - 1;
-        if (dmu > 0.f) {
-            klo = max(0, (int)floorf((ds - reach - smu[0]) / dmu));
-            khi = min(nbins - 1, (int)ceilf((ds + reach - smu[0]) / dmu));
+    const float reach = 11.3f / sc;          // exp2 argument below -126 beyond this
+    const float mu0 = smu[0];
+    const int Np = N + (N & 1);              // even number of tournament slots (one dummy when N is odd)
+    const int M = Np - 1, half = Np / 2;
+    for (int r = 0; r < M; ++r) {
+        for (int p0 = 0; p0 < half; p0 += 64) {
+            const int p = p0 + lane;
+            int a = -1, b = -1;
+            if (p < half) {
+                if (p == 0) { a = M; b = r; }
+                else { a = r + p; if (a >= M) a -= M; b = r - p; if (b < 0) b += M; }
+                if (a >= N || b >= N) a = -1;                     // pair with the dummy slot
+            }
+            if (a >= 0) {
+                const int i = min(a, b), j = max(a, b);
+                float dx = px[j] - px[i], dy = px[N + j] - px[N + i], dz = px[2 * N + j] - px[2 * N + i];
+                min_image<DIAG>(cell, dx, dy, dz);               // D = x_j - x_i as the forward pass
+                const float d2 = norm2_ref(dx, dy, dz);
+                bool ok = (d2 < rc2) && (d2 != 0.f);
+                if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
+                if (ok) {
+                    const float id = __builtin_amdgcn_rsqf(d2);
+                    const float d = d2 * id;
+                    int klo = 0, khi = nbins - 1;
+                    if (dmu > 0.f) {
+                        klo = max(0, (int)floorf((d - reach - mu0) / dmu));
+                        khi = min(nbins - 1, (int)ceilf((d + reach - mu0) / dmu));
+                    }
+                    // dL/dd = sum_k g_k 2 coeff (d - mu_k) e_k = sum_k sg_k x_k exp2(-x_k^2), x_k = s (d - mu_k)
+                    float sd = 0.f;
+                    for (int k = klo; k <= khi; ++k) {
+                        const float x = (d - smu[k]) * sc;
+                        sd = fmaf(sg[k] * x, __builtin_amdgcn_exp2f(-x * x), sd);
+                    }
+                    const float c = sd * id;                      // d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d
+                    gx[j] += c * dx; gx[N + j] += c * dy; gx[2 * N + j] += c * dz;
+                    gx[i] -= c * dx; gx[N + i] -= c * dy; gx[2 * N + i] -= c * dz;
+                }
+            }
         }
-        // dL/dd = sum_k g_k 2 coeff (d - mu_k) e_k = sum_k sg_k x_k exp2(-x_k^2),
-        //   x_k = s (d - mu_k), sg_k = g_k * 2 coeff / s
-        float s = 0.f;
-        for (int k = klo; k <= khi; ++k) {
-            const float x = (ds - smu[k]) * sc;
-            s = fmaf(sg[k] * x, __builtin_amdgcn_exp2f(-x * x), s);
-        }
-        // d(dist)/dx_i = -(D)/d for D = x_j - x_i (unflipped); with flip, D was negated
-        const float c = (flip ? s : -s) * id;
-        gx = fmaf(c, dx, gx); gy = fmaf(c, dy, gy); gz = fmaf(c, dz, gz);
     }
-    gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
-    if (sub == 0) {
-        float* o = g_xyz + ((size_t)fr * N + i) * 3;
-        o[0] = gx; o[1] = gy; o[2] = gz;
-    }
+    float* out = g_xyz + (size_t)fr * N * 3;
+    for (int e = lane; e < 3 * N; e += 64) out[e] = gx[(e % 3) * N + e / 3];
 }
 
 }  // namespace
@@ -217,18 +230,18 @@ extern "C" int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const Md
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_bwd: bad sizes");
     MDG_CHECK_ARG(coeff < 0.f, "rdf_bwd: coeff must be negative (-0.5 / width^2)");
     hipStream_t st = (hipStream_t)stream;
-    constexpr int LPA = 16;
-    constexpr int RDF_BWD_BLOCK = 256;
-    const int apb = RDF_BWD_BLOCK / LPA;
-    const long long rows = (long long)n_frames * n_atoms;
-    const int nblocks = (int)((rows + apb - 1) / apb);
-    const size_t lds = sizeof(float) * 2 * nbins;
+    // waves (= frames) per workgroup limited by the 6N floats of LDS each one needs
+    int wpb = 4;
+    while (wpb > 1 && sizeof(float) * (2 * (size_t)nbins + (size_t)wpb * 6 * n_atoms) > 150 * 1024) wpb >>= 1;
+    const size_t lds = sizeof(float) * (2 * (size_t)nbins + (size_t)wpb * 6 * n_atoms);
+    MDG_CHECK_ARG(lds <= 160 * 1024, "rdf_bwd: N=%d does not fit the LDS-resident frame kernel", n_atoms);
+    const int nblocks = (n_frames + wpb - 1) / wpb;
     if (cell->diag)
-        hipLaunchKernelGGL((rdf_bwd_kernel<true, LPA>), dim3(nblocks), dim3(RDF_BWD_BLOCK), lds, st, xyz, n_frames,
-                           n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
+        hipLaunchKernelGGL(rdf_bwd_kernel<true>, dim3(nblocks), dim3(64 * wpb), lds, st, xyz, n_frames, n_atoms, *cell,
+                           cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
     else
-        hipLaunchKernelGGL((rdf_bwd_kernel<false, LPA>), dim3(nblocks), dim3(RDF_BWD_BLOCK), lds, st, xyz, n_frames,
-                           n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
+        hipLaunchKernelGGL(rdf_bwd_kernel<false>, dim3(nblocks), dim3(64 * wpb), lds, st, xyz, n_frames, n_atoms, *cell,
+                           cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
     MDG_CHECK_LAUNCH("rdf_bwd_kernel");
     return MDG_OK;
 }
