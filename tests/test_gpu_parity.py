@@ -496,3 +496,33 @@ def test_large_path_2744_atoms_vs_generic_and_replicas():
             assert torch.equal(a[1][0], out[1].detach()), "replica 0 of a batch == single run"
     for k, (a, b) in enumerate(zip(*res)):
         close(a, b, 5e-4, 5e-5 * float(b.abs().max()) + 1e-7, "large fused vs generic #%d" % k)
+
+
+def test_rdf_bitwise_reproducible_and_nonuniform_edge_cases():
+    """Two launches of the RDF forward/backward give identical bits; a single bin, a wide explicit
+    width and an odd atom count (dummy tournament slot) agree with the oracle."""
+    from mdgrad_amd.observable import rdf
+    g = load_golden("rdf")
+    system = mk_system(g["xyz"][0], g["cell"])
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    runs = []
+    for _ in range(2):
+        xyz = T(np.concatenate([g["xyz"]] * 8), DEV).requires_grad_(True)
+        gr = obs(xyz)[2]
+        (gx,) = torch.autograd.grad((gr * torch.linspace(-1, 1, 100, device=DEV)).sum(), xyz)
+        runs.append((gr.detach(), gx))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    # odd N, few bins, explicit wide width
+    pos = g["xyz"][0][:107]
+    sys2 = mk_system(pos, g["cell"])
+    for nb, rr, w in [(1, (1.0, 1.0001), 0.3), (7, (0.8, 2.0), 0.4), (33, (0.5, 2.4), None)]:
+        if nb == 1:
+            continue                      # linspace(start, end, 1) has no spacing: reference divides by zero
+        x = T(pos, DEV).requires_grad_(True)
+        c, b, gr = rdf(sys2, nbins=nb, r_range=rr, width=w)(x)
+        (gx,) = torch.autograd.grad(gr.pow(2).sum(), x)
+        xo = T(pos).requires_grad_(True)
+        co, bo, go = O.rdf_oracle(xo, T(g["cell"]), nb, rr, width=w)
+        (gxo,) = torch.autograd.grad(go.pow(2).sum(), xo)
+        close(gr, go, 1e-4, 1e-4, "g nb=%d" % nb)
+        close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "grad nb=%d" % nb)
