@@ -4,9 +4,12 @@
 // backward through it.  The [pairs, bins] exp matrix of the reference is never
 // materialised.
 //
-// forward : lane = pair; persistent waves stride over (frame, 1024-pair chunk) work items and
-//           add each pair's windowed Gaussians into a wave-private LDS histogram (see
-//           rdf_fwd_kernel).
+// forward : persistent blocks stride over (frame, 4096-candidate chunk) work items.  Threads
+//           compute i<j minimum-image distances 256 candidates at a time, compact the accepted
+//           ones into LDS in a fixed order, then thread k owns bin k and sweeps the LDS
+//           distances (broadcast reads, register accumulator kept across work items).  Per-block
+//           partial histograms are added by a second kernel in a fixed order => no atomics,
+//           reproducible.  exp uses the hardware v_exp_f32 path (__expf, rel. err ~1e-6).
 // backward: one wave per frame in round-robin-tournament pair order (see rdf_bwd_kernel); each
 //           accepted pair contributes sum_k g_raw[k] * 2 coeff (d - mu_k) e_k along +/- its unit
 //           separation vector, accumulated in LDS without atomics.
@@ -14,8 +17,9 @@
 
 namespace {
 
-constexpr int RDF_BLOCK = 256;
-constexpr int RDF_MAX_BLOCKS = 4096;     // persistent blocks: each strides over (frame, chunk) work items
+constexpr int RDF_BLOCK = 512;
+constexpr int RDF_MAX_BLOCKS = 1024;     // persistent blocks: each strides over (frame, chunk) work items
+constexpr int RDF_CHUNK = 8192;          // candidate pairs per work item
 constexpr float LOG2E = 1.4426950408889634f;
 
 // flat index c in [0, N(N-1)/2) -> (i, j), i < j, row-major (the order torch.nonzero yields)
@@ -28,86 +32,83 @@ __device__ __forceinline__ void pair_from_flat(long long c, int N, int& i, int& 
     j = (int)(c - (long long)ii * (2LL * N - ii - 1) / 2) + ii + 1;
 }
 
-// Forward: lane = pair.  exp(coeff (d - mu_k)^2) = exp2(-x_k^2), x_k = s (d - mu_k),
-// s = sqrt(-coeff log2 e).  For equally spaced centres (mu = linspace, spacing D, Ds = s D) the
-// Gaussians of one distance obey a two-term recurrence away from the nearest centre kc:
-//     e_{m+1} = e_m rho_m ,  rho_{m+1} = rho_m exp2(-2 Ds^2) ,  rho_0 = exp2(+-2 Ds x_c - Ds^2)
-// so a pair costs 3 v_exp_f32 plus two multiplies per bin, and only the bins within
-// `reach` = 11.3/s of the distance are touched (beyond that the Gaussian is < 2^-126).  The
-// values are accumulated into a wave-private LDS histogram with ds_add_f32 (no cross-wave
-// traffic; within a wave the order is program order), the four wave histograms of a workgroup
-// are combined in a fixed order, and a second kernel adds the per-workgroup partials in order.
-// Error of the recurrence grows like m^2 ulp away from the centre, i.e. it is largest (~5e-6
-// relative) where the Gaussian itself is ~1e-37.
-constexpr int RDF_PAIRS_PER_ITEM = 1024;
-
+// exp(coeff (d - mu)^2) = exp2(-(s d - s mu)^2) with s = sqrt(-coeff log2 e): distances and
+// the sweep costs sub, mul, mul, v_exp_f32, add per (pair, bin).
+//
+// Thread layout: nbins <= RDF_BLOCK.  G = RDF_BLOCK / nbins thread groups; thread (g, k) owns
+// bin k and sweeps the compacted distances 4g..4g+3, 4(g+G).., ... (ds_read_b128); the groups
+// are combined in group order at the end.  Bins beyond RDF_BLOCK are handled by the slow path.
 template <bool DIAG>
 __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
     const float* __restrict__ mu, float coeff, int nbins, float* __restrict__ partial) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int nw = RDF_BLOCK / 64;
-    float* smu = sm;                                   // [nbins]
-    float* hist = sm + nbins;                          // [nw][nbins]
+    __shared__ __attribute__((aligned(16))) float dist[RDF_BLOCK + 4];
+    __shared__ int wcnt[RDF_BLOCK / 64];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < nbins; k += RDF_BLOCK) smu[k] = mu[k];
-    for (int k = threadIdx.x; k < nw * nbins; k += RDF_BLOCK) hist[k] = 0.f;
-    __syncthreads();
-    float* myh = hist + wid * nbins;
+    constexpr int nw = RDF_BLOCK / 64;
     const float sc = sqrtf(-coeff * LOG2E);
-    const float mu0 = smu[0];
-    const float dmu = nbins > 1 ? (smu[nbins - 1] - mu0) / (float)(nbins - 1) : 1.f;
-    const float inv_dmu = 1.0f / dmu;
-    const float Ds = dmu * sc;
-    const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds * Ds);
-    const int W = (int)ceilf(11.3f / Ds) + 1;          // bins on each side of the nearest centre
+    const int G = RDF_BLOCK / nbins;
+    const int grp = threadIdx.x / nbins;
+    const bool active = grp < G;
+    const int k = threadIdx.x - grp * nbins;
+    const float ms = active ? mu[k] : 0.f;
+    float acc = 0.f;
     const long long npair = (long long)N * (N - 1) / 2;
-    const int chunks = (int)((npair + RDF_PAIRS_PER_ITEM - 1) / RDF_PAIRS_PER_ITEM);
+    const int chunks = (int)((npair + RDF_CHUNK - 1) / RDF_CHUNK);
     const long long items = (long long)nF * chunks;
-    const long long gw = (long long)blockIdx.x * nw + wid, gstride = (long long)gridDim.x * nw;
-    for (long long it = gw; it < items; it += gstride) {
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
         const int fr = (int)(it / chunks), ch = (int)(it % chunks);
         const float* pos = xyz + (size_t)fr * N * 3;
-        const long long c_end = min(npair, (long long)(ch + 1) * RDF_PAIRS_PER_ITEM);
-        long long c = (long long)ch * RDF_PAIRS_PER_ITEM + lane;
+        const long long c_end = min(npair, (long long)(ch + 1) * RDF_CHUNK);
+        long long c = (long long)ch * RDF_CHUNK + threadIdx.x;
         int i = 0, j = 0;
         if (c < c_end) pair_from_flat(c, N, i, j);
-        for (; c < c_end; c += 64) {
-            float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1], dz = pos[3 * j + 2] - pos[3 * i + 2];
-            min_image<DIAG>(cell, dx, dy, dz);
-            const float d2 = norm2_ref(dx, dy, dz);
-            bool ok = (d2 < rc2) && (d2 != 0.f);
-            if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
-            if (ok) {
-                const float d = sqrtf(d2);
-                const int kc = (int)rintf((d - mu0) * inv_dmu);
-                if (kc >= -W && kc < nbins + W) {
-                    const float muc = (kc >= 0 && kc < nbins) ? smu[kc] : mu0 + (float)kc * dmu;
-                    const float xc = (d - muc) * sc;
-                    const float ec = __builtin_amdgcn_exp2f(-xc * xc);
-                    if (kc >= 0 && kc < nbins) atomicAdd(&myh[kc], ec);
-                    float eu = ec, ed = ec;
-                    float ru = __builtin_amdgcn_exp2f(2.f * Ds * xc - Ds * Ds);
-                    float rd = __builtin_amdgcn_exp2f(-2.f * Ds * xc - Ds * Ds);
-                    for (int m = 1; m <= W; ++m) {
-                        eu *= ru; ru *= c2;
-                        ed *= rd; rd *= c2;
-                        const int ku = kc + m, kd = kc - m;
-                        if (ku >= 0 && ku < nbins) atomicAdd(&myh[ku], eu);
-                        if (kd >= 0 && kd < nbins) atomicAdd(&myh[kd], ed);
-                    }
+        for (long long cb = (long long)ch * RDF_CHUNK; cb < c_end; cb += RDF_BLOCK) {
+            float d = -1.f;
+            if (c < c_end) {
+                float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1],
+                      dz = pos[3 * j + 2] - pos[3 * i + 2];
+                min_image<DIAG>(cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                bool ok = (d2 < rc2) && (d2 != 0.f);
+                if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
+                if (ok) d = sqrtf(d2);
+                // advance to the candidate RDF_BLOCK further on
+                c += RDF_BLOCK;
+                j += RDF_BLOCK;
+                while (j >= N && i < N - 1) { ++i; j = j - N + i + 1; }
+            }
+            const unsigned long long b = __ballot(d >= 0.f);
+            __syncthreads();                                   // previous sweep done with dist[]
+            if (lane == 0) wcnt[wid] = __popcll(b);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < nw; ++w) { if (w < wid) base += wcnt[w]; total += wcnt[w]; }
+            if (d >= 0.f) dist[base + __popcll(b & ((1ull << lane) - 1ull))] = d;
+            if (threadIdx.x < 4) dist[total + threadIdx.x] = 3.0e18f;   // pad: exp2(-x^2) == 0
+            __syncthreads();
+            if (active) {
+                for (int p = 4 * grp; p < total; p += 4 * G) {
+                    const float4 dd = *reinterpret_cast<const float4*>(&dist[p]);
+                    // (d - mu) first, then scale: no cancellation error on the scaled values
+                    const float x0 = (dd.x - ms) * sc, x1 = (dd.y - ms) * sc, x2 = (dd.z - ms) * sc,
+                                x3 = (dd.w - ms) * sc;
+                    acc += __builtin_amdgcn_exp2f(-x0 * x0);
+                    acc += __builtin_amdgcn_exp2f(-x1 * x1);
+                    acc += __builtin_amdgcn_exp2f(-x2 * x2);
+                    acc += __builtin_amdgcn_exp2f(-x3 * x3);
                 }
             }
-            j += 64;
-            while (j >= N && i < N - 1) { ++i; j = j - N + i + 1; }
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < nbins; k += RDF_BLOCK) {
+    if (active) dist[threadIdx.x] = acc;                        // [g][k], G * nbins <= RDF_BLOCK
+    __syncthreads();
+    if (threadIdx.x < nbins) {
         float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < nw; ++w) s += hist[w * nbins + k];
-        partial[(size_t)blockIdx.x * nbins + k] = s;
+        for (int g = 0; g < G; ++g) s += dist[g * nbins + threadIdx.x];
+        partial[(size_t)blockIdx.x * nbins + threadIdx.x] = s;
     }
 }
 
@@ -194,9 +195,8 @@ __global__ __launch_bounds__(256) void rdf_bwd_kernel(
 
 static int rdf_grid(int n_frames, int n_atoms) {
     const long long npair = (long long)n_atoms * (n_atoms - 1) / 2;
-    const long long items = (long long)n_frames * ((npair + RDF_PAIRS_PER_ITEM - 1) / RDF_PAIRS_PER_ITEM);
-    const long long blocks = (items + RDF_BLOCK / 64 - 1) / (RDF_BLOCK / 64);
-    return (int)(blocks < RDF_MAX_BLOCKS ? blocks : RDF_MAX_BLOCKS);
+    const long long items = (long long)n_frames * ((npair + RDF_CHUNK - 1) / RDF_CHUNK);
+    return (int)(items < RDF_MAX_BLOCKS ? items : RDF_MAX_BLOCKS);
 }
 
 extern "C" int64_t mdg_rdf_partial_size(int n_frames, int n_atoms, int nbins) {
@@ -208,16 +208,15 @@ extern "C" int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const Md
                            float* partial, void* stream) {
     MDG_CHECK_ARG(xyz && cell && mu && raw && partial, "rdf_fwd: null buffer");
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_fwd: bad sizes");
-    MDG_CHECK_ARG(nbins <= 8192, "rdf_fwd: nbins > 8192 not supported");
+    MDG_CHECK_ARG(nbins <= RDF_BLOCK, "rdf_fwd: nbins > %d not supported", RDF_BLOCK);
     MDG_CHECK_ARG(coeff < 0.f, "rdf_fwd: coeff must be negative (-0.5 / width^2)");
     const int nblocks = rdf_grid(n_frames, n_atoms);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = sizeof(float) * (size_t)nbins * (1 + RDF_BLOCK / 64);
     if (cell->diag)
-        hipLaunchKernelGGL(rdf_fwd_kernel<true>, dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames, n_atoms,
+        hipLaunchKernelGGL(rdf_fwd_kernel<true>, dim3(nblocks), dim3(RDF_BLOCK), 0, st, xyz, n_frames, n_atoms,
                            *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);
     else
-        hipLaunchKernelGGL(rdf_fwd_kernel<false>, dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames, n_atoms,
+        hipLaunchKernelGGL(rdf_fwd_kernel<false>, dim3(nblocks), dim3(RDF_BLOCK), 0, st, xyz, n_frames, n_atoms,
                            *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);
     hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, nblocks, nbins, raw);
     MDG_CHECK_LAUNCH("rdf_fwd_kernel");
