@@ -191,6 +191,65 @@ __global__ __launch_bounds__(256) void rdf_bwd_kernel(
     for (int e = lane; e < 3 * N; e += 64) out[e] = gx[(e % 3) * N + e / 3];
 }
 
+// Backward, few-frames / large-N variant: LPA lanes per (frame, atom) gather (each pair visited from
+// both ends; used when there are too few frames to fill the chip with one wave per frame).
+template <bool DIAG, int LPA>
+__global__ void rdf_bwd_atom_kernel(const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2,
+                               const uint8_t* __restrict__ mask, const float* __restrict__ mu, float coeff,
+                               int nbins, const float* __restrict__ g_raw, float* __restrict__ g_xyz) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* smu = sm;             // [nbins]
+    float* sg = sm + nbins;      // [nbins]
+    const float sc = sqrtf(-coeff * LOG2E);
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) { smu[k] = mu[k]; sg[k] = g_raw[k] * 2.f * coeff / sc; }
+    __syncthreads();
+    const int apb = blockDim.x / LPA;
+    const long long gi = (long long)blockIdx.x * apb + threadIdx.x / LPA;
+    const int sub = threadIdx.x % LPA;
+    if (gi >= (long long)nF * N) return;
+    const int fr = (int)(gi / N), i = (int)(gi % N);
+    const float* pos = xyz + (size_t)fr * N * 3;
+    const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    // bins whose Gaussian is non-negligible (exp2 argument > -126) around a distance
+    const float dmu = nbins > 1 ? (smu[nbins - 1] - smu[0]) / (float)(nbins - 1) : 0.f;
+    const float reach = 11.3f / sc;                                       // sqrt(126) in scaled units
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int j = sub; j < N; j += LPA) {
+        if (j == i) continue;
+        float dx = pos[3 * j] - xi, dy = pos[3 * j + 1] - yi, dz = pos[3 * j + 2] - zi;
+        // the half list holds (min(i,j), max(i,j)) with D = x_hi - x_lo: evaluate in that
+        // orientation so the accepted set is the forward pass's
+        const bool flip = j < i;
+        if (flip) { dx = -dx; dy = -dy; dz = -dz; }
+        min_image<DIAG>(cell, dx, dy, dz);
+        const float d2 = norm2_ref(dx, dy, dz);
+        if (!((d2 < rc2) && (d2 != 0.f))) continue;
+        if (mask && !mask[(size_t)(flip ? j : i) * N + (flip ? i : j)]) continue;
+        const float id = __builtin_amdgcn_rsqf(d2);
+        const float ds = d2 * id;
+        int klo = 0, khi = nbins - 1;
+        if (dmu > 0.f) {
+            klo = max(0, (int)floorf((ds - reach - smu[0]) / dmu));
+            khi = min(nbins - 1, (int)ceilf((ds + reach - smu[0]) / dmu));
+        }
+        // dL/dd = sum_k g_k 2 coeff (d - mu_k) e_k = sum_k sg_k x_k exp2(-x_k^2),
+        //   x_k = s (d - mu_k), sg_k = g_k * 2 coeff / s
+        float s = 0.f;
+        for (int k = klo; k <= khi; ++k) {
+            const float x = (ds - smu[k]) * sc;
+            s = fmaf(sg[k] * x, __builtin_amdgcn_exp2f(-x * x), s);
+        }
+        // d(dist)/dx_i = -(D)/d for D = x_j - x_i (unflipped); with flip, D was negated
+        const float c = (flip ? s : -s) * id;
+        gx = fmaf(c, dx, gx); gy = fmaf(c, dy, gy); gz = fmaf(c, dz, gz);
+    }
+    gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
+    if (sub == 0) {
+        float* o = g_xyz + ((size_t)fr * N + i) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+}
+
 }  // namespace
 
 static int rdf_grid(int n_frames, int n_atoms) {
@@ -230,6 +289,21 @@ extern "C" int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const Md
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_bwd: bad sizes");
     MDG_CHECK_ARG(coeff < 0.f, "rdf_bwd: coeff must be negative (-0.5 / width^2)");
     hipStream_t st = (hipStream_t)stream;
+    // few frames or frames too large for LDS: (frame, atom) gather variant
+    if (n_frames < 1024 || n_atoms > 4096) {
+        constexpr int LPA = 16, BLK = 256;
+        const long long rows = (long long)n_frames * n_atoms;
+        const int nb = (int)((rows + BLK / LPA - 1) / (BLK / LPA));
+        const size_t l2 = sizeof(float) * 2 * nbins;
+        if (cell->diag)
+            hipLaunchKernelGGL((rdf_bwd_atom_kernel<true, LPA>), dim3(nb), dim3(BLK), l2, st, xyz, n_frames, n_atoms,
+                               *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
+        else
+            hipLaunchKernelGGL((rdf_bwd_atom_kernel<false, LPA>), dim3(nb), dim3(BLK), l2, st, xyz, n_frames, n_atoms,
+                               *cell, cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz);
+        MDG_CHECK_LAUNCH("rdf_bwd_atom_kernel");
+        return MDG_OK;
+    }
     // waves (= frames) per workgroup limited by the 6N floats of LDS each one needs
     int wpb = 4;
     while (wpb > 1 && sizeof(float) * (2 * (size_t)nbins + (size_t)wpb * 6 * n_atoms) > 150 * 1024) wpb >>= 1;

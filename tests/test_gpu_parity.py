@@ -526,3 +526,29 @@ def test_rdf_bitwise_reproducible_and_nonuniform_edge_cases():
         (gxo,) = torch.autograd.grad(go.pow(2).sum(), xo)
         close(gr, go, 1e-4, 1e-4, "g nb=%d" % nb)
         close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "grad nb=%d" % nb)
+
+
+def test_rdf_backward_variants_agree():
+    """>= 1024 frames run the wave-per-frame tournament kernel, fewer frames the (frame, atom) gather
+    kernel: same gradients (and the tournament kernel is bitwise reproducible)."""
+    from mdgrad_amd import ops, _lib
+    g = load_golden("rdf")
+    rng = np.random.default_rng(11)
+    base = g["xyz"][0]
+    frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), g["cell"]) for _ in range(1100)]).astype(np.float32)
+    cs = _lib.make_cell(g["cell"])
+    mu = torch.linspace(0.75, 2.5, 100, device=DEV)
+    coeff = float(-0.5 / (mu[1] - mu[0]) ** 2)
+    w = torch.linspace(-1, 1, 100, device=DEV)
+
+    def grad_of(x):
+        x = T(x, DEV).requires_grad_(True)
+        raw = ops.RdfRawFn.apply(x, mu, coeff, 3.0, cs, None)
+        (gx,) = torch.autograd.grad((raw * w).sum(), x)
+        return raw.detach(), gx
+
+    raw_all, g_all = grad_of(frames)
+    raw_b, g_all2 = grad_of(frames)
+    assert torch.equal(g_all, g_all2) and torch.equal(raw_all, raw_b)
+    g_chunks = torch.cat([grad_of(frames[k:k + 550])[1] for k in (0, 550)])
+    close(g_all, g_chunks, 1e-4, 1e-5 * float(g_chunks.abs().max()), "tournament vs gather rdf backward")

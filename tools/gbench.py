@@ -61,7 +61,7 @@ def main():
             obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
             tf, tb = run(integ, system, obs, args.steps, 0.005)
         else:
-            size = 2 if w == "gnn64" else 4
+            size = {"gnn64": 2, "gnn512": 4, "gnn4096": 8}[w]
             a = units.get_unit_len(0.997, 18.01528, 8)
             atoms = Diamond("O", (size,) * 3, a)
             pos = np.mod(atoms.get_positions() + rng.normal(0, 0.2, (len(atoms), 3)), a * size)
