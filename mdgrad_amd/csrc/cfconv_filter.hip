@@ -29,7 +29,9 @@ __host__ __device__ inline int stride16mod32(int n) {   // smallest s >= n with 
 }
 
 __device__ __forceinline__ float ssp(float x) {          // softplus(x) - ln 2, torch threshold 20
-    const float sp = x > 20.f ? x : log1pf(expf(x));
+    // log1p(e^x) as log2(1 + 2^(x log2 e)) * ln 2 on the hardware exp2/log2 (abs. error ~1e-7)
+    const float ex = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    const float sp = x > 20.f ? x : __builtin_amdgcn_logf(1.0f + ex) * 0.69314718055994531f;
     return sp - 0.69314718055994531f;
 }
 
@@ -45,83 +47,101 @@ __global__ __launch_bounds__(256) void cfconv_filter_kernel(
     const int Fcp = (Fc + 15) / 16 * 16;
     const int S2 = stride16mod32(Fcp);
     const int SA = Gp + 2;
+    const int SO = Fcp + 4;                // output staging stride (rows stay 16-B aligned)
     float* w1s = sm;                       // [Gp][S1]   B1[k][j] = W1[j][k]
     float* w2s = w1s + Gp * S1;            // [Gp][S2]   B2[k][j] = W2[f_lo + j][k]
     float* h1s = w2s + Gp * S2;            // [4 waves][16][SA]
-    float* mus = h1s + 4 * 16 * SA;        // [Gp] centres, [Gp] coeff, [Gp] b1
+    float* mus = h1s + 4 * 16 * SA;        // [Gp] centres, [Gp] coeff, [Gp] b1, [Fcp] b2
     float* cfs = mus + Gp;
     float* b1s = cfs + Gp;
+    float* b2s = b1s + Gp;
+    float* outs = b2s + Fcp;               // [4 waves][16][SO] output staging for coalesced row stores
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
+    // weights are staged ONCE per (persistent) workgroup
     for (int t = tid; t < Gp * Gp; t += 256) {
         const int k = t / Gp, j = t % Gp;
         w1s[k * S1 + j] = (k < G && j < G) ? W1[j * G + k] : 0.f;
     }
     for (int t = tid; t < Gp * Fcp; t += 256) {
-        const int k = t / Fcp, j = t % Fcp;
+        const int k = t % Gp, j = t / Gp;              // consecutive threads read consecutive k of one row
         w2s[k * S2 + j] = (k < G && j < Fc) ? W2[(size_t)(f_lo + j) * G + k] : 0.f;
     }
     for (int k = tid; k < Gp; k += 256) {
         mus[k] = k < G ? mu[k] : 0.f;
         const float w = k < G ? width[k] : 1.f;
-        cfs[k] = k < G ? -0.5f / (w * w) : 0.f;
+        cfs[k] = k < G ? -0.5f / (w * w) * 1.4426950408889634f : 0.f;   // exp(c x^2) = exp2(c log2e x^2)
         b1s[k] = k < G ? b1[k] : 0.f;
     }
+    for (int j = tid; j < Fcp; j += 256) b2s[j] = j < Fc ? b2[f_lo + j] : 0.f;
     __syncthreads();
 
-    const long long e0 = (long long)blockIdx.x * FT_TM + wid * 16;
     const int li = lane & 15, lk = lane >> 4;
-    // ---- layer 1: A[i][k] = exp(c_k (d_i - mu_k)^2) computed in registers
-    const long long ea = e0 + li;
-    const float da = ea < E ? d[ea] : 0.f;
-    float afrag[FT_GMAX / 4];
-#pragma unroll
-    for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
-        const int k = ks * 4 + lk;
-        float v = 0.f;
-        if (ks * 4 < Gp && k < G) { const float x = da - mus[k]; v = expf(cfs[k] * x * x); }
-        afrag[ks] = v;
-    }
     float* h1w = h1s + wid * 16 * SA;
-    for (int nt = 0; nt < Gp / 16; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float* ow = outs + wid * 16 * SO;
+    const long long ntiles = (E + FT_TM - 1) / FT_TM;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long e0 = tile * FT_TM + wid * 16;
+        // ---- layer 1: A[i][k] = exp(c_k (d_i - mu_k)^2) computed in registers
+        const long long ea = e0 + li;
+        const float da = ea < E ? d[ea] : 0.f;
+        float afrag[FT_GMAX / 4];
 #pragma unroll
         for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
-            if (ks * 4 < Gp) {
-                const float b = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+            const int k = ks * 4 + lk;
+            float v = 0.f;
+            if (ks * 4 < Gp && k < G) { const float x = da - mus[k]; v = __builtin_amdgcn_exp2f(cfs[k] * x * x); }
+            afrag[ks] = v;
+        }
+        for (int nt = 0; nt < Gp / 16; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+                if (ks * 4 < Gp) {
+                    const float b = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+                }
             }
+            // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+            const int col = nt * 16 + li;
+            const float bias = b1s[col];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h1w[(lk * 4 + r) * SA + col] = col < G ? ssp(acc[r] + bias) : 0.f;
         }
-        // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
-        const int col = nt * 16 + li;
-        const float bias = b1s[col];
+        // (h1w / ow are private to the wave: program order + the LDS counter suffice, no barrier)
+        // ---- layer 2: A[i][k] = H1[i][k] from LDS
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = col < G ? ssp(acc[r] + bias) : 0.f;
-            h1w[(lk * 4 + r) * SA + col] = v;
-        }
-    }
-    __syncthreads();
-    // ---- layer 2: A[i][k] = H1[i][k] from LDS
+        for (int ks = 0; ks < FT_GMAX / 4; ++ks)
+            afrag[ks] = (ks * 4 < Gp) ? h1w[li * SA + ks * 4 + lk] : 0.f;
+        for (int nt = 0; nt < Fcp / 16; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < FT_GMAX / 4; ++ks)
-        afrag[ks] = (ks * 4 < Gp) ? h1w[li * SA + ks * 4 + lk] : 0.f;
-    for (int nt = 0; nt < Fcp / 16; ++nt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
-            if (ks * 4 < Gp) {
-                const float b = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+            for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+                if (ks * 4 < Gp) {
+                    const float b = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
+                }
             }
-        }
-        const int col = nt * 16 + li;
-        if (col < Fc) {
-            const float bias = b2[f_lo + col];
+            const int col = nt * 16 + li;
+            const float bias = b2s[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long long e = e0 + lk * 4 + r;
-                if (e < E) out[(size_t)e * F + f_lo + col] = acc[r] + bias;
+            for (int r = 0; r < 4; ++r) ow[(lk * 4 + r) * SO + col] = acc[r] + bias;
+        }
+        // ---- coalesced row stores: 16 rows x Fc floats, consecutive lanes -> consecutive columns
+        if ((Fc & 3) == 0 && (F & 3) == 0) {
+            const int qpr = Fc / 4;                        // float4 per row
+            for (int t = lane; t < 16 * qpr; t += 64) {
+                const int row = t / qpr, c4 = t % qpr;
+                const long long e = e0 + row;
+                if (e < E)
+                    *reinterpret_cast<float4*>(&out[(size_t)e * F + f_lo + 4 * c4]) =
+                        *reinterpret_cast<const float4*>(&ow[row * SO + 4 * c4]);
+            }
+        } else {
+            for (int t = lane; t < 16 * Fc; t += 64) {
+                const int row = t / Fc, c = t % Fc;
+                const long long e = e0 + row;
+                if (e < E) out[(size_t)e * F + f_lo + c] = ow[row * SO + c];
             }
         }
     }
@@ -140,8 +160,12 @@ extern "C" int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* m
     const int Fc = n_filters < FT_FCH ? n_filters : FT_FCH;
     const int Fcp = (Fc + 15) / 16 * 16;
     const size_t lds = sizeof(float) * ((size_t)Gp * stride16mod32(Gp) + (size_t)Gp * stride16mod32(Fcp) +
-                                        4 * 16 * (Gp + 2) + 3 * Gp);
-    dim3 grid((unsigned)((n_edges + FT_TM - 1) / FT_TM), (n_filters + FT_FCH - 1) / FT_FCH);
+                                        4 * 16 * (Gp + 2) + 3 * Gp + Fcp + 4 * 16 * (Fcp + 4));
+    const long long ntiles = (n_edges + FT_TM - 1) / FT_TM;
+    const int chunks = (n_filters + FT_FCH - 1) / FT_FCH;
+    // persistent workgroups: ~4 per CU share the work, each stages the weights once
+    const long long want = 1024 / chunks > 1 ? 1024 / chunks : 1;
+    dim3 grid((unsigned)(ntiles < want ? ntiles : want), chunks);
     hipLaunchKernelGGL(cfconv_filter_kernel, grid, dim3(256), lds, (hipStream_t)stream, d, (long long)n_edges, mu,
                        width, n_gauss, W1, b1, W2, b2, n_filters, out);
     MDG_CHECK_LAUNCH("cfconv_filter_kernel");
