@@ -35,12 +35,13 @@ __device__ __forceinline__ float ssp(float x) {          // softplus(x) - ln 2, 
     return sp - 0.69314718055994531f;
 }
 
+template <int GP>
 __global__ __launch_bounds__(256) void cfconv_filter_kernel(
     const float* __restrict__ d, long long E, const float* __restrict__ mu, const float* __restrict__ width,
     int G, const float* __restrict__ W1, const float* __restrict__ b1, const float* __restrict__ W2,
     const float* __restrict__ b2, int F, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int Gp = (G + 15) / 16 * 16;
+    constexpr int Gp = GP;                 // G padded to a multiple of 16 (compile time: no run-time guards in the MFMA loops)
     const int S1 = stride16mod32(Gp);
     const int f_lo = blockIdx.y * FT_FCH;
     const int Fc = min(FT_FCH, F - f_lo);
@@ -85,43 +86,42 @@ __global__ __launch_bounds__(256) void cfconv_filter_kernel(
         // ---- layer 1: A[i][k] = exp(c_k (d_i - mu_k)^2) computed in registers
         const long long ea = e0 + li;
         const float da = ea < E ? d[ea] : 0.f;
-        float afrag[FT_GMAX / 4];
+        // (padded k >= G: the matching rows of W1^T in LDS are zero, so the value there is irrelevant)
+        float afrag[GP / 4];
 #pragma unroll
-        for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
+        for (int ks = 0; ks < GP / 4; ++ks) {
             const int k = ks * 4 + lk;
-            float v = 0.f;
-            if (ks * 4 < Gp && k < G) { const float x = da - mus[k]; v = __builtin_amdgcn_exp2f(cfs[k] * x * x); }
-            afrag[ks] = v;
+            const float x = da - mus[k];
+            afrag[ks] = __builtin_amdgcn_exp2f(cfs[k] * x * x);
         }
-        for (int nt = 0; nt < Gp / 16; ++nt) {
+#pragma unroll
+        for (int nt = 0; nt < GP / 16; ++nt) {
+            float bfrag[GP / 4];
+#pragma unroll
+            for (int ks = 0; ks < GP / 4; ++ks) bfrag[ks] = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
-                if (ks * 4 < Gp) {
-                    const float b = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
-                }
-            }
-            // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
+            for (int ks = 0; ks < GP / 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+            // C layout: col = lane & 15, row = (lane >> 4) * 4 + r.  Padded columns: zero weights and
+            // zero bias give ssp(0) = 0.
             const int col = nt * 16 + li;
             const float bias = b1s[col];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h1w[(lk * 4 + r) * SA + col] = col < G ? ssp(acc[r] + bias) : 0.f;
+            for (int r = 0; r < 4; ++r) h1w[(lk * 4 + r) * SA + col] = ssp(acc[r] + bias);
         }
         // (h1w / ow are private to the wave: program order + the LDS counter suffice, no barrier)
         // ---- layer 2: A[i][k] = H1[i][k] from LDS
 #pragma unroll
-        for (int ks = 0; ks < FT_GMAX / 4; ++ks)
-            afrag[ks] = (ks * 4 < Gp) ? h1w[li * SA + ks * 4 + lk] : 0.f;
+        for (int ks = 0; ks < GP / 4; ++ks) afrag[ks] = h1w[li * SA + ks * 4 + lk];
         for (int nt = 0; nt < Fcp / 16; ++nt) {
+            float bfrag[GP / 4];
+#pragma unroll
+            for (int ks = 0; ks < GP / 4; ++ks) bfrag[ks] = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < FT_GMAX / 4; ++ks) {
-                if (ks * 4 < Gp) {
-                    const float b = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], b, acc, 0, 0, 0);
-                }
-            }
+            for (int ks = 0; ks < GP / 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(afrag[ks], bfrag[ks], acc, 0, 0, 0);
             const int col = nt * 16 + li;
             const float bias = b2s[col];
 #pragma unroll
@@ -166,8 +166,13 @@ extern "C" int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* m
     // persistent workgroups: ~4 per CU share the work, each stages the weights once
     const long long want = 1024 / chunks > 1 ? 1024 / chunks : 1;
     dim3 grid((unsigned)(ntiles < want ? ntiles : want), chunks);
-    hipLaunchKernelGGL(cfconv_filter_kernel, grid, dim3(256), lds, (hipStream_t)stream, d, (long long)n_edges, mu,
-                       width, n_gauss, W1, b1, W2, b2, n_filters, out);
+#define MDG_FILTER_LAUNCH(GP_)                                                                         \
+    hipLaunchKernelGGL(cfconv_filter_kernel<GP_>, grid, dim3(256), lds, (hipStream_t)stream, d,        \
+                       (long long)n_edges, mu, width, n_gauss, W1, b1, W2, b2, n_filters, out)
+    if (Gp == 16) MDG_FILTER_LAUNCH(16);
+    else if (Gp == 32) MDG_FILTER_LAUNCH(32);
+    else if (Gp == 48) MDG_FILTER_LAUNCH(48);
+    else MDG_FILTER_LAUNCH(64);
     MDG_CHECK_LAUNCH("cfconv_filter_kernel");
     return MDG_OK;
 }
