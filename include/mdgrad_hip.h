@@ -87,6 +87,12 @@ int mdg_nbr_build_dense(const float* pos, int n_atoms, const MdgCell* cell /*hos
                         float cutoff, const uint8_t* mask,
                         int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
                         int32_t* overflow, void* stream);
+/* replica-batched variant: atoms form n_atoms/group independent systems of `group` consecutive
+ * atoms sharing one cell; pairs never cross groups; mask (optional) is [group, group]. */
+int mdg_nbr_build_dense_groups(const float* pos, int n_atoms, int group, const MdgCell* cell /*host*/,
+                               float cutoff, const uint8_t* mask,
+                               int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
+                               int32_t* overflow, void* stream);
 int64_t mdg_nbr_cell_scratch(int n_atoms, const MdgCell* cell /*host*/, float cutoff);
 int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
                        float cutoff, const uint8_t* mask,

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "mdg_last_error": (C.c_char_p, []),
     "mdg_version": (C.c_int, []),
     "mdg_nbr_build_dense": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, P, P, C.c_int, P, P]),
+    "mdg_nbr_build_dense_groups": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, P, P,
+                                             C.c_int, P, P]),
     "mdg_nbr_cell_scratch": (C.c_int64, [C.c_int, C.POINTER(MdgCell), C.c_float]),
     "mdg_nbr_build_cell": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, P, P, C.c_int, P, P, P]),
     "mdg_nbr_half_count": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),

@@ -40,8 +40,10 @@ __device__ __forceinline__ int pair_test(const MdgCell& c, const float* __restri
     return ok ? code : -1;
 }
 
+// `group` = atoms per independent replica (atoms i and j interact only inside one group of
+// consecutive indices; the mask, when given, is [group, group]); group == N for a single system.
 template <bool DIAG>
-__global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, MdgCell cell, float rc2,
+__global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, float rc2,
                                  const uint8_t* __restrict__ mask, int32_t* __restrict__ col,
                                  int32_t* __restrict__ shift, int32_t* __restrict__ cnt, int max_nbr,
                                  int32_t* __restrict__ overflow) {
@@ -49,11 +51,15 @@ __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, MdgCell c
     const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= N) return;
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    const int g0 = (i / group) * group, g1 = min(N, g0 + group);
     int base = 0;
-    for (int j0 = 0; j0 < N; j0 += 64) {
+    for (int j0 = g0; j0 < g1; j0 += 64) {
         const int j = j0 + lane;
         int code = -1;
-        if (j < N && j != i) code = pair_test<DIAG>(cell, pos, i, j, xi, yi, zi, rc2, mask, N);
+        if (j < g1 && j != i) {
+            code = pair_test<DIAG>(cell, pos, i, j, xi, yi, zi, rc2, nullptr, N);
+            if (code >= 0 && mask && !mask[(size_t)(i - g0) * group + (j - g0)]) code = -1;
+        }
         const unsigned long long b = __ballot(code >= 0);
         if (code >= 0) {
             const int k = base + __popcll(b & lanemask_lt());
@@ -236,20 +242,32 @@ __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t*
 
 }  // namespace
 
+extern "C" int mdg_nbr_build_dense_groups(const float* pos, int n_atoms, int group, const MdgCell* cell,
+                                          float cutoff, const uint8_t* mask, int32_t* col, int32_t* shift,
+                                          int32_t* cnt, int max_nbr, int32_t* overflow, void* stream);
+
 extern "C" int mdg_nbr_build_dense(const float* pos, int n_atoms, const MdgCell* cell, float cutoff,
                                    const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
                                    int max_nbr, int32_t* overflow, void* stream) {
+    return mdg_nbr_build_dense_groups(pos, n_atoms, n_atoms, cell, cutoff, mask, col, shift, cnt, max_nbr, overflow,
+                                      stream);
+}
+
+extern "C" int mdg_nbr_build_dense_groups(const float* pos, int n_atoms, int group, const MdgCell* cell,
+                                          float cutoff, const uint8_t* mask, int32_t* col, int32_t* shift,
+                                          int32_t* cnt, int max_nbr, int32_t* overflow, void* stream) {
     MDG_CHECK_ARG(pos && cell && col && shift && cnt && overflow, "nbr_build_dense: null buffer");
     MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0 && cutoff > 0.f, "nbr_build_dense: bad sizes");
+    MDG_CHECK_ARG(group > 0 && n_atoms % group == 0, "nbr_build_dense: n_atoms must be a multiple of the group size");
     hipStream_t st = (hipStream_t)stream;
     const int wpb = 4;
     dim3 grid((n_atoms + wpb - 1) / wpb), block(64 * wpb);
     const float rc2 = cutoff * cutoff;
     if (cell->diag)
-        hipLaunchKernelGGL(nbr_dense_kernel<true>, grid, block, 0, st, pos, n_atoms, *cell, rc2, mask, col,
+        hipLaunchKernelGGL(nbr_dense_kernel<true>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col,
                            shift, cnt, max_nbr, overflow);
     else
-        hipLaunchKernelGGL(nbr_dense_kernel<false>, grid, block, 0, st, pos, n_atoms, *cell, rc2, mask, col,
+        hipLaunchKernelGGL(nbr_dense_kernel<false>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col,
                            shift, cnt, max_nbr, overflow);
     MDG_CHECK_LAUNCH("nbr_dense_kernel");
     return MDG_OK;

@@ -20,6 +20,7 @@ class GeneralInteraction(torch.nn.Module):
         self.cell = torch.Tensor(system.get_cell()).to(system.device)     # interface.py:55-56
         self.cell.requires_grad = True
         self._cell_struct = _lib.make_cell(system.get_cell())
+        self._group = getattr(system, "group_size", system.get_number_of_atoms())
 
 
 class _LazyTopology:
@@ -63,12 +64,12 @@ class GNNPotentials(GeneralInteraction):
         self.inputs = batch_to(self.system.get_batch(), self.device)
         self.inputs['cell'] = self.cell.detach()
         self.ex_pairs = ex_pairs
-        self._mask = ops.build_mask(system.get_number_of_atoms(), None, ex_pairs, system.device)
+        self._mask = ops.build_mask(self._group, None, ex_pairs, system.device)
         self.to(self.device)
         self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
 
     def _reset_topology(self, xyz):
-        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask)
+        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
         topo = ops.GraphTopo(ell)
         self.inputs['nbr_list'], self.inputs['offsets'] = topo.nbr, topo.offsets
         self.inputs['_topo'] = topo
@@ -94,7 +95,7 @@ class PairPotentials(GeneralInteraction):
         self.cutoff = cutoff
         self.index_tuple = index_tuple
         self.ex_pairs = ex_pairs
-        self._mask = ops.build_mask(system.get_number_of_atoms(), index_tuple, ex_pairs, system.device)
+        self._mask = ops.build_mask(self._group, index_tuple, ex_pairs, system.device)
         self._nbr_override = None
         self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
 
@@ -119,7 +120,7 @@ class PairPotentials(GeneralInteraction):
         return self._ell.half_list()[1]
 
     def _reset_topology(self, xyz):
-        self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask)
+        self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
         return _LazyTopology(self, xyz.detach())
 
     def forward(self, xyz):

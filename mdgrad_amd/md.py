@@ -122,7 +122,7 @@ class _EOM(torch.nn.Module):
         if method != self._method or self.topology_update_freq != 1 or self.dim != 3:
             return None
         mods = _pair_terms_of(self.model)
-        N = self.mass.shape[0]
+        N = getattr(self.system, "group_size", self.mass.shape[0])      # atoms per replica
         if mods is None or not self.adjoint:
             return None
         large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
@@ -148,8 +148,10 @@ class _EOM(torch.nn.Module):
             if not 2 <= self.num_chains <= 16:
                 return None
             kw = dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
-        return _FusedSpec(self, self._ensemble, N, self.mass.contiguous(), cs, ops.make_terms(terms, pos), pos,
+        spec = _FusedSpec(self, self._ensemble, N, self.mass[:N].contiguous(), cs, ops.make_terms(terms, pos), pos,
                           masks, large=large, **kw)
+        spec.n_rep = getattr(self.system, "n_replicas", 1)
+        return spec
 
 
 class NVE(_EOM):
@@ -197,7 +199,12 @@ class NoseHooverChain(_EOM):
         self.N_dof = self.mass.shape[0] * system.dim
         self.target_ke = (0.5 * self.N_dof * T)
         self.num_chains = num_chains
-        self.Q = np.array([Q, *[Q / self.system.get_number_of_atoms()] * (num_chains - 1)])
+        # replica-stacked systems (System.replicate): one thermostat chain per replica of n_group atoms
+        self.n_rep = getattr(system, "n_replicas", 1)
+        self.n_group = getattr(system, "group_size", self.mass.shape[0])
+        self.N_dof = self.n_group * system.dim
+        self.target_ke = (0.5 * self.N_dof * T)
+        self.Q = np.array([Q, *[Q / self.n_group] * (num_chains - 1)])
         self.Q = torch.Tensor(self.Q).to(self.device)
         self.dim = system.dim
         self.adjoint = adjoint
@@ -220,35 +227,39 @@ class NoseHooverChain(_EOM):
         return -g
 
     def rhs_from_force(self, state, f):
-        """md.py:221-240 given F(q)."""
+        """md.py:221-240 given F(q).  With R stacked replicas p_v is [R, C] and every replica has its
+        own kinetic energy / friction (identical arithmetic per replica)."""
         v, q, p_v = state
         p = v * self.mass[:, None]
-        sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()
-        coupled_forces = (p_v[0] * p.reshape(-1) / self.Q[0]).reshape(-1, 3)
-        dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[0] * p_v[1] / self.Q[1]
-        dpvdt_mid = (p_v[:-2].pow(2) / self.Q[:-2] - self.T) - p_v[2:] * p_v[1:-1] / self.Q[2:]
-        dpvdt_last = p_v[-2].pow(2) / self.Q[-2] - self.T
-        return ((f - coupled_forces) / self.mass[:, None], v, torch.cat((dpvdt_0[None], dpvdt_mid, dpvdt_last[None])))
+        if p_v.dim() == 1:
+            sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()
+            coupled_forces = (p_v[0] * p.reshape(-1) / self.Q[0]).reshape(-1, 3)
+            dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[0] * p_v[1] / self.Q[1]
+            dpvdt_mid = (p_v[:-2].pow(2) / self.Q[:-2] - self.T) - p_v[2:] * p_v[1:-1] / self.Q[2:]
+            dpvdt_last = p_v[-2].pow(2) / self.Q[-2] - self.T
+            dpv = torch.cat((dpvdt_0[None], dpvdt_mid, dpvdt_last[None]))
+        else:
+            R = p_v.shape[0]
+            sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).reshape(R, -1).sum(1)
+            coupled_forces = (p_v[:, 0].repeat_interleave(self.n_group)[:, None] * p) / self.Q[0]
+            dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[:, 0] * p_v[:, 1] / self.Q[1]
+            dpvdt_mid = (p_v[:, :-2].pow(2) / self.Q[:-2] - self.T) - p_v[:, 2:] * p_v[:, 1:-1] / self.Q[2:]
+            dpvdt_last = p_v[:, -2].pow(2) / self.Q[-2] - self.T
+            dpv = torch.cat((dpvdt_0[:, None], dpvdt_mid, dpvdt_last[:, None]), 1)
+        return ((f - coupled_forces) / self.mass[:, None], v, dpv)
 
     def forward(self, t, state):
         with torch.set_grad_enabled(True):
             v, q, p_v = state[0], state[1], state[2]
             if self.adjoint:
                 q.requires_grad = True
-            p = v * self.mass[:, None]
-            sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()
             self.update_topology(q)
             u = self.model(q)
             f = -compute_grad(inputs=q, output=u.sum(-1))
-            coupled_forces = (p_v[0] * p.reshape(-1) / self.Q[0]).reshape(-1, 3)
-            dpdt = f - coupled_forces
-            dpvdt_0 = 2 * (sys_ke - self.T * self.N_dof * 0.5) - p_v[0] * p_v[1] / self.Q[1]
-            dpvdt_mid = (p_v[:-2].pow(2) / self.Q[:-2] - self.T) - p_v[2:] * p_v[1:-1] / self.Q[2:]
-            dpvdt_last = p_v[-2].pow(2) / self.Q[-2] - self.T
-            dvdt = dpdt / self.mass[:, None]
-        return (dvdt, v, torch.cat((dpvdt_0[None], dpvdt_mid, dpvdt_last[None])))
+            out = self.rhs_from_force((v, q, p_v), f)
+        return out
 
     def get_inital_states(self, wrap=True):
-        states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap),
-                  [0.0] * self.num_chains]
+        baths = [0.0] * self.num_chains if self.n_rep == 1 else np.zeros((self.n_rep, self.num_chains))
+        states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap), baths]
         return [torch.Tensor(var).to(self.system.device) for var in states]

@@ -26,7 +26,9 @@ class Observable(torch.nn.Module):
         self.device = system.device
         self.volume = system.get_volume()
         self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)
-        self.natoms = system.get_number_of_atoms()
+        # replica-stacked systems: observables are per replica (frames = time x replica)
+        self.n_rep = getattr(system, "n_replicas", 1)
+        self.natoms = getattr(system, "group_size", system.get_number_of_atoms())
 
 
 class rdf(Observable):
@@ -51,6 +53,8 @@ class rdf(Observable):
         self._mask = ops.build_mask(self.natoms, index_tuple, None, self.device)
 
     def forward(self, xyz):
+        if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
+            xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))
         count = ops.RdfRawFn.apply(xyz, self.offsets, self.coeff, self.cutoff_boundary,
                                    self._cell_struct, self._mask)
         norm = count.sum()

@@ -83,15 +83,19 @@ def _use_cell_list(n_atoms, cs, cutoff):
     return all(cs.h[4 * d] / cutoff >= 3.0 for d in range(3))
 
 
-def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto"):
-    """Neighbour list of one frame xyz[N,3] (replaces generate_nbr_list).  method: auto|dense|cell."""
+def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", group=None):
+    """Neighbour list of one frame xyz[N,3] (replaces generate_nbr_list).  method: auto|dense|cell.
+    group: atoms per independent replica when xyz stacks several replicas of one system (pairs stay
+    inside a group; mask is [group, group])."""
     require_gpu(xyz, "xyz")
     lib = _lib.load()
     xyz = xyz.detach().contiguous()
     N, dev = xyz.shape[0], xyz.device
     cutoff = float(cutoff)
-    cap = estimate_max_nbr(N, cell_struct, cutoff) if max_nbr is None else int(max_nbr)
-    use_cell = method == "cell" or (method == "auto" and _use_cell_list(N, cell_struct, cutoff))
+    grouped = group is not None and group != N
+    Ng = group if grouped else N
+    cap = estimate_max_nbr(Ng, cell_struct, cutoff) if max_nbr is None else int(max_nbr)
+    use_cell = (not grouped) and (method == "cell" or (method == "auto" and _use_cell_list(N, cell_struct, cutoff)))
     st = stream_ptr(dev)
     while True:
         col = torch.empty(N, cap, dtype=torch.int32, device=dev)
@@ -105,15 +109,15 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto"):
                                          ptr(shift), ptr(cnt), cap, ptr(overflow), ptr(scratch), st),
                   "mdg_nbr_build_cell")
         else:
-            check(lib.mdg_nbr_build_dense(ptr(xyz), N, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
-                                          ptr(shift), ptr(cnt), cap, ptr(overflow), st),
+            check(lib.mdg_nbr_build_dense_groups(ptr(xyz), N, Ng, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
+                                                 ptr(shift), ptr(cnt), cap, ptr(overflow), st),
                   "mdg_nbr_build_dense")
-        if cap >= N - 1:
+        if cap >= Ng - 1:
             break                                   # cannot overflow
         need = int(overflow.item())
         if need <= cap:
             break
-        cap = min(N - 1, (need + 15) // 8 * 8)
+        cap = min(Ng - 1, (need + 15) // 8 * 8)
     return EllList(N, cap, col, shift, cnt, cell_struct, cutoff, mask)
 
 

@@ -212,6 +212,16 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         flat_params = spec.flat_params()
         y0 = tuple(y0)
         pv0 = y0[2] if spec.ensemble == 0 else None
+        R, N = getattr(spec, "n_rep", 1), spec.n_atoms
+        if R > 1 and y0[0].dim() == 2:
+            # replica-stacked system ([R*N, 3] states): one workgroup (or grid row) per replica
+            outs = ops.FusedTrajFn.apply(y0[0].reshape(R, N, 3), y0[1].reshape(R, N, 3),
+                                         pv0.reshape(R, -1) if pv0 is not None else None, t, flat_params, spec)
+            T_ = t.shape[0]
+            res = [outs[0].transpose(0, 1).reshape(T_, R * N, 3), outs[1].transpose(0, 1).reshape(T_, R * N, 3)]
+            if pv0 is not None:
+                res.append(outs[2].transpose(0, 1))
+            return tuple(res)
         return ops.FusedTrajFn.apply(y0[0], y0[1], pv0, t, flat_params, spec)
 
     tensor_input = False

@@ -155,6 +155,22 @@ class System(Atoms):
         self.props = {} if props is None else props
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         self.dim = dim
+        self.n_replicas = 1
+        self.group_size = len(self)
+
+    def replicate(self, n_replicas):
+        """Stack n independent replicas of this system into one System of n*N atoms (extension; the
+        reference walks a Python list of simulations, demo/fit_rdf_gnn.py:386-399).  Atoms of
+        different replicas never interact; every replica gets its own thermostat chain.  Positions /
+        velocities of the copies start identical -- perturb them with set_positions / set_velocities
+        (shape [n*N, 3], replica-major)."""
+        N = len(self)
+        rep = System(positions=np.tile(self.positions, (n_replicas, 1)), numbers=np.tile(self.numbers, n_replicas),
+                     cell=self.cell, masses=np.tile(self.masses, n_replicas),
+                     momenta=np.tile(self.momenta, (n_replicas, 1)), pbc=self.pbc, device=self.device,
+                     dim=self.dim, props=self.props)
+        rep.n_replicas, rep.group_size = n_replicas, N
+        return rep
 
     def get_nxyz(self):                                      # system.py:39-51
         return np.concatenate([self.get_atomic_numbers().reshape(-1, 1),
@@ -165,7 +181,7 @@ class System(Atoms):
 
     def get_batch(self):                                     # system.py:56-62
         return {"nxyz": torch.Tensor(self.get_nxyz()),
-                "num_atoms": torch.LongTensor([self.get_number_of_atoms()]),
+                "num_atoms": torch.LongTensor([self.group_size] * self.n_replicas),
                 "energy": 0.0}
 
     def set_temperature(self, T, rng=None):                  # system.py:64-70

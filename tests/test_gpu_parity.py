@@ -621,3 +621,50 @@ def test_fit_rdf_recovers_lj_parameters():
     first, last = hist[0], hist[-1]
     assert last[0] < 0.35 * first[0], "loss %.4f -> %.4f" % (first[0], last[0])
     assert abs(last[1] - 1.0) < abs(first[1] - 1.0) and abs(last[1] - 1.0) < 0.04
+
+
+def test_stacked_replicas_fused_lj_through_simulations():
+    """System.replicate + Simulations: R stacked replicas take the fused batched kernels."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain, Simulations
+    from mdgrad_amd.observable import rdf
+    g = load_golden("nhc_traj_lj")
+    R = 4
+    rng = np.random.default_rng(3)
+    pos = np.stack([np.mod(g["pos"] + rng.normal(0, 0.03, g["pos"].shape), g["cell"]) for _ in range(R)])
+    vel = rng.normal(0, 1.0, pos.shape)
+    base = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    st = base.replicate(R)
+    st.set_positions(pos.reshape(-1, 3))
+    st.set_velocities(vel.reshape(-1, 3))
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(st, mdl, cutoff=2.5)}), st, T=1.0, num_chains=5, Q=50.0).to(DEV)
+    spec = integ.fused_spec("NH_verlet")
+    assert spec is not None and spec.n_rep == R and spec.n_atoms == 108
+    sim = Simulations(st, integ)
+    v_t, q_t, pv_t = sim.simulate(steps=12, frequency=12, dt=0.005)
+    assert q_t.shape == (12, R * 108, 3) and pv_t.shape == (12, R, 5)
+    _, _, gr = rdf(st, nbins=100, r_range=(0.75, 2.5))(q_t)
+    gr.pow(2).mean().backward()
+    gs = (float(mdl.sigma.grad), float(mdl.epsilon.grad))
+    # reference: each replica alone
+    t = torch.Tensor([0.005 * i for i in range(12)])
+    frames = []
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        eom = O.NHCOracle(O.ModelOracle([term]), T(g["mass"]), 1.0, 50.0, 5)
+        traj = O.odeint_oracle(eom, (torch.Tensor(vel[r]), torch.Tensor(pos[r]), torch.zeros(5)), t)
+        close(q_t.reshape(12, R, 108, 3)[:, r], traj[1], 1e-4, 2e-5, "q_t replica %d" % r)
+        frames.append(traj)
+    leaves = [[x.clone().requires_grad_(True) for x in tr] for tr in frames]
+    _, _, go = O.rdf_oracle(torch.stack([l[1] for l in leaves], 1), T(g["cell"]), 100, (0.75, 2.5))
+    go.pow(2).mean().backward()
+    gth = np.zeros(2)
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        eom = O.NHCOracle(O.ModelOracle([term]), T(g["mass"]), 1.0, 50.0, 5)
+        term.reset(torch.Tensor(pos[r]))
+        _, gt = O.adjoint_oracle(eom, frames[r], [x.grad for x in leaves[r]], t)
+        gth += gt.numpy()
+    close(np.array(gs), gth, 5e-3, 1e-3 * np.abs(gth).max(), "stacked fused dL/dtheta")

@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["lj4096", "gnn64", "gnn512"])
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--replicas", type=int, default=1, help="stack R replicas (System.replicate) in one trajectory")
     args = ap.parse_args()
     from mdgrad_amd import potentials as P, units
     from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
@@ -69,6 +70,9 @@ def main():
             atoms.masses[:] = 18.01528
             system = System(atoms, device=dev)
             kT = 298.0 * units.kB
+            if args.replicas > 1:
+                system = system.replicate(args.replicas)
+                system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.05, (len(system), 3)), a * size))
             system.set_temperature(kT, rng=rng)
             torch.manual_seed(0)
             net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2,
@@ -78,8 +82,9 @@ def main():
             integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=kT, num_chains=5, Q=50.0).to(dev)
             obs = rdf(system, nbins=60, r_range=(2.0, min(6.0, 0.49 * a * size)))
             tf, tb = run(integ, system, obs, args.steps, 1.0 * units.fs)
-        print("%-8s N=%5d steps=%d  fwd %.4f s  bwd(adjoint+rdf) %.4f s  -> %.1f MD steps/s (fwd+adj)" % (
-            w, system.get_number_of_atoms(), args.steps, tf, tb, args.steps / (tf + tb)), flush=True)
+        R = getattr(system, "n_replicas", 1)
+        print("%-8s N=%5d x %d replicas  steps=%d  fwd %.4f s  bwd(adjoint+rdf) %.4f s  -> %.1f MD steps/s (fwd+adj, all replicas)" % (
+            w, system.group_size, R, args.steps, tf, tb, R * args.steps / (tf + tb)), flush=True)
 
 
 if __name__ == "__main__":
