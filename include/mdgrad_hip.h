@@ -240,6 +240,15 @@ int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* mu, const fl
                       const float* W1, const float* b1, const float* W2, const float* b2,
                       int n_filters, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Tall-skinny contraction C[M,N] = A[E,M]^T B[E,N] (split-K on the f32 MFMA, ordered reduction):
+ * the weight gradients of edge-wise Dense layers in the adjoint's parameter vjp (autograd of
+ * nff/nn/layers.py:86-134 on [E, .] inputs).  workspace: mdg_atb_workspace() floats.
+ */
+int64_t mdg_atb_workspace(int64_t n_rows, int m, int n);
+int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float* C, float* workspace,
+            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

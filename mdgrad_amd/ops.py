@@ -471,6 +471,58 @@ class EdgeProdFn(torch.autograd.Function):
         return ga, gb, None
 
 
+# ----------------------------------------------------------------------------- dense algebra closure
+def _atb(A, B):
+    lib = _lib.load()
+    A, B = A.contiguous(), B.contiguous()
+    E, M, N = A.shape[0], A.shape[1], B.shape[1]
+    out = torch.empty(M, N, device=A.device)
+    ws = torch.empty(max(1, int(lib.mdg_atb_workspace(E, M, N))), device=A.device)
+    check(lib.mdg_atb(ptr(A), ptr(B), E, M, N, ptr(out), ptr(ws), stream_ptr(A.device)), "mdg_atb")
+    return out
+
+
+class MMFn(torch.autograd.Function):
+    """A[E,K] @ W[K,N] on the library GEMM (tall A: fine there); its weight gradient is the tall-skinny
+    A^T g, which goes to AtBFn.  {MMFn, AtBFn} is closed under differentiation."""
+
+    @staticmethod
+    def forward(ctx, A, W):
+        ctx.save_for_backward(A, W)
+        return A.detach().matmul(W.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        A, W = ctx.saved_tensors
+        gA = MMFn.apply(g, W.t()) if ctx.needs_input_grad[0] else None
+        gW = AtBFn.apply(A, g) if ctx.needs_input_grad[1] else None
+        return gA, gW
+
+
+class AtBFn(torch.autograd.Function):
+    """A[E,M]^T @ B[E,N] with split-K over the edges on the f32 MFMA (csrc/atb.hip)."""
+
+    @staticmethod
+    def forward(ctx, A, B):
+        ctx.save_for_backward(A, B)
+        if A.is_cuda and A.dtype == torch.float32:
+            return _atb(A.detach(), B.detach())
+        return A.detach().t().matmul(B.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        A, B = ctx.saved_tensors
+        gA = MMFn.apply(B, g.t()) if ctx.needs_input_grad[0] else None
+        gB = MMFn.apply(A, g) if ctx.needs_input_grad[1] else None
+        return gA, gB
+
+
+def linear(x, weight, bias=None):
+    """F.linear for 2-D x whose weight gradient (x^T g, tall-skinny) runs on AtBFn."""
+    y = MMFn.apply(x, weight.t())
+    return y if bias is None else y + bias
+
+
 # ----------------------------------------------------------------------------- cfconv filter (MFMA)
 def filter_reference(d, mu, width, W1, b1, W2, b2):
     """The filter network in plain torch ops (nff/nn/modules.py:531-541): used for the
@@ -505,12 +557,12 @@ class CfconvFilterFn(torch.autograd.Function):
         c = -0.5 / width.pow(2)
         x = d[:, None] - mu
         g = torch.exp(c * x.pow(2))
-        a1 = torch.nn.functional.linear(g, W1, b1)
-        gh1 = gW.matmul(W2)
+        a1 = linear(g, W1, b1)
+        gh1 = MMFn.apply(gW, W2)
         ga1 = gh1 * torch.sigmoid(a1)
         gd = gmu = gwidth = gW1 = gb1 = gW2 = gb2 = None
         if need[0] or need[1] or need[2]:
-            gg = ga1.matmul(W1) * g
+            gg = MMFn.apply(ga1, W1) * g
             if need[0] or need[1]:
                 t = gg * (2 * c * x)
                 gd = t.sum(1) if need[0] else None
@@ -518,12 +570,12 @@ class CfconvFilterFn(torch.autograd.Function):
             if need[2]:
                 gwidth = (gg * x.pow(2)).sum(0) / width.pow(3)
         if need[3]:
-            gW1 = ga1.t().matmul(g)
+            gW1 = AtBFn.apply(ga1, g)
         if need[4]:
             gb1 = ga1.sum(0)
         if need[5]:
             h1 = torch.nn.functional.softplus(a1) - math.log(2.0)
-            gW2 = gW.t().matmul(h1)
+            gW2 = AtBFn.apply(gW, h1)
         if need[6]:
             gb2 = gW.sum(0)
         return gd, gmu, gwidth, gW1, gb1, gW2, gb2

@@ -200,3 +200,27 @@ def test_stacked_replicas_generic_gnn_equals_separate_runs():
     g_sep = sum(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1)
                            for p in ir.parameters()]) for ir in integs)
     close(g_stack, g_sep, 5e-3, 5e-4 * float(g_sep.abs().max()), "stacked vs separate dL/dtheta")
+
+
+@pytest.mark.parametrize("E,M,N", [(100000, 128, 30), (7, 5, 3), (4099, 48, 16), (250000, 16, 130), (0, 8, 8)])
+def test_tall_skinny_atb_kernel_and_closure(E, M, N):
+    from mdgrad_amd import ops
+    torch.manual_seed(E + M)
+    A = torch.randn(E, M, device=DEV, requires_grad=True)
+    B = torch.randn(E, N, device=DEV, requires_grad=True)
+    ref = A.t().matmul(B)
+    got = ops.AtBFn.apply(A, B)
+    close(got, ref, 1e-4, 1e-4 * (float(ref.abs().max()) + 1e-3), "A^T B")
+    assert torch.equal(got, ops.AtBFn.apply(A, B)), "deterministic"
+    if E == 0:
+        return
+    W = torch.randn(M, N, device=DEV, requires_grad=True)
+    outs = []
+    for mm, atb in ((lambda a, w: a.matmul(w), lambda a, b: a.t().matmul(b)), (ops.MMFn.apply, ops.AtBFn.apply)):
+        y = (mm(A, W) * B).sum() + atb(A, B).pow(2).sum() * 1e-3
+        g1 = torch.autograd.grad(y, [A, B, W], create_graph=True)
+        z = sum((x * x.detach().cos()).sum() for x in g1)
+        g2 = torch.autograd.grad(z, [A, B, W])
+        outs.append(list(g1) + list(g2))
+    for a, b in zip(*outs):
+        close(b, a, 2e-3, 2e-4 * float(a.abs().max()) + 1e-5, "MM/AtB closure")
