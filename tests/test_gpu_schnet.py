@@ -215,11 +215,12 @@ def test_tall_skinny_atb_kernel_and_closure(E, M, N):
     if E == 0:
         return
     W = torch.randn(M, N, device=DEV, requires_grad=True)
+    probes = [torch.randn(E, M, device=DEV), torch.randn(E, N, device=DEV), torch.randn(M, N, device=DEV)]
     outs = []
     for mm, atb in ((lambda a, w: a.matmul(w), lambda a, b: a.t().matmul(b)), (ops.MMFn.apply, ops.AtBFn.apply)):
-        y = (mm(A, W) * B).sum() + atb(A, B).pow(2).sum() * 1e-3
+        y = (mm(A, W) * B).sum() + (atb(A, B) / E ** 0.5).pow(2).sum()
         g1 = torch.autograd.grad(y, [A, B, W], create_graph=True)
-        z = sum((x * x.detach().cos()).sum() for x in g1)
+        z = sum((x * p).sum() for x, p in zip(g1, probes))        # linear probe: well conditioned
         g2 = torch.autograd.grad(z, [A, B, W])
         outs.append(list(g1) + list(g2))
     for a, b in zip(*outs):
