@@ -58,7 +58,7 @@ class Dense(nn.Linear):
             self.bias_init(self.bias)
 
     def forward(self, inputs):
-        if inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32:
+        if inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.shape[0] >= 8192:
             from .. import ops
             y = ops.linear(inputs, self.weight, self.bias)      # weight gradient on the split-K MFMA kernel
         else:

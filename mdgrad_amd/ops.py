@@ -517,10 +517,23 @@ class AtBFn(torch.autograd.Function):
         return gA, gB
 
 
+TALL_ROWS = 8192      # below this the library GEMM is launch-bound anyway and native autograd is cheaper
+
+
 def linear(x, weight, bias=None):
-    """F.linear for 2-D x whose weight gradient (x^T g, tall-skinny) runs on AtBFn."""
+    """F.linear for 2-D x; for tall x the weight gradient (x^T g, tall-skinny) runs on AtBFn."""
+    if x.shape[0] < TALL_ROWS:
+        return torch.nn.functional.linear(x, weight, bias)
     y = MMFn.apply(x, weight.t())
     return y if bias is None else y + bias
+
+
+def mm(a, w):
+    return MMFn.apply(a, w) if a.shape[0] >= TALL_ROWS else a.matmul(w)
+
+
+def atb(a, b):
+    return AtBFn.apply(a, b) if a.shape[0] >= TALL_ROWS else a.t().matmul(b)
 
 
 # ----------------------------------------------------------------------------- cfconv filter (MFMA)
@@ -558,11 +571,11 @@ class CfconvFilterFn(torch.autograd.Function):
         x = d[:, None] - mu
         g = torch.exp(c * x.pow(2))
         a1 = linear(g, W1, b1)
-        gh1 = MMFn.apply(gW, W2)
+        gh1 = mm(gW, W2)
         ga1 = gh1 * torch.sigmoid(a1)
         gd = gmu = gwidth = gW1 = gb1 = gW2 = gb2 = None
         if need[0] or need[1] or need[2]:
-            gg = MMFn.apply(ga1, W1) * g
+            gg = mm(ga1, W1) * g
             if need[0] or need[1]:
                 t = gg * (2 * c * x)
                 gd = t.sum(1) if need[0] else None
@@ -570,12 +583,12 @@ class CfconvFilterFn(torch.autograd.Function):
             if need[2]:
                 gwidth = (gg * x.pow(2)).sum(0) / width.pow(3)
         if need[3]:
-            gW1 = AtBFn.apply(ga1, g)
+            gW1 = atb(ga1, g)
         if need[4]:
             gb1 = ga1.sum(0)
         if need[5]:
             h1 = torch.nn.functional.softplus(a1) - math.log(2.0)
-            gW2 = AtBFn.apply(gW, h1)
+            gW2 = atb(gW, h1)
         if need[6]:
             gb2 = gW.sum(0)
         return gd, gmu, gwidth, gW1, gb1, gW2, gb2
