@@ -11,60 +11,80 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// One wave = one 16-row strip of C (16 values of m) x up to NT column tiles, for one K-slab: the A
+// fragment is loaded once per 4 rows and reused by every column tile; 8 rows are in flight per
+// iteration (two independent accumulator sets hide the 40-cycle dependent MFMA latency).
+template <int NT>
 __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                           long long E, int M, int N, long long slab,
                                                           float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int tilesN = (N + 15) / 16, tilesM = (M + 15) / 16;
-    const int tile = blockIdx.x * 4 + wid;
-    if (tile >= tilesM * tilesN) return;
-    const int tm = tile / tilesN, tn = tile % tilesN;
+    const int tilesM = (M + 15) / 16;
+    const int strips_n = ((N + 15) / 16 + NT - 1) / NT;            // groups of NT column tiles
+    const int unit = blockIdx.x * 4 + wid;
+    if (unit >= tilesM * strips_n) return;
+    const int tm = unit / strips_n, tn0 = (unit % strips_n) * NT;
     const int split = blockIdx.y;
     const long long k0 = (long long)split * slab, k1 = min(E, k0 + slab);
     const int li = lane & 15, lk = lane >> 4;
-    const int am = tm * 16 + li, bn = tn * 16 + li;
-    const bool aok = am < M, bok = bn < N;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    long long k = k0;
-    // two independent accumulators (the 16x16x4 MFMA has a 40-cycle dependent latency, 32-cycle issue)
-    for (; k + 8 <= k1; k += 8) {
+    const int am = tm * 16 + li;
+    const bool aok = am < M;
+    f32x4 acc0[NT], acc1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (long long k = k0; k < k1; k += 8) {
         const long long r0 = k + lk, r1 = k + 4 + lk;
-        const float a0 = aok ? A[r0 * M + am] : 0.f, b0 = bok ? B[r0 * N + bn] : 0.f;
-        const float a1 = aok ? A[r1 * M + am] : 0.f, b1 = bok ? B[r1 * N + bn] : 0.f;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-    }
-    for (; k < k1; k += 4) {
-        const long long r = k + lk;
-        const bool rok = r < k1;
-        const float a = (aok && rok) ? A[r * M + am] : 0.f, b = (bok && rok) ? B[r * N + bn] : 0.f;
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+        const bool ok0 = r0 < k1, ok1 = r1 < k1;
+        const float a0 = (aok && ok0) ? A[r0 * M + am] : 0.f;
+        const float a1 = (aok && ok1) ? A[r1 * M + am] : 0.f;
+        float b0[NT], b1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int bn = (tn0 + t) * 16 + li;
+            b0[t] = (bn < N && ok0) ? B[r0 * N + bn] : 0.f;
+            b1[t] = (bn < N && ok1) ? B[r1 * N + bn] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc0[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc1[t], 0, 0, 0);
+        }
     }
     // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
     float* out = partial + (size_t)split * M * N;
-    const int col = tn * 16 + li;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = tm * 16 + lk * 4 + r;
-        if (row < M && col < N) out[(size_t)row * N + col] = acc0[r] + acc1[r];
+    for (int t = 0; t < NT; ++t) {
+        const int col = (tn0 + t) * 16 + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = tm * 16 + lk * 4 + r;
+            if (row < M && col < N) out[(size_t)row * N + col] = acc0[t][r] + acc1[t][r];
+        }
     }
 }
 
+// C[t] = sum_p partial[p][t]: 4 lanes per output element walk the splits, fixed combine order
 __global__ void atb_reduce_kernel(const float* __restrict__ partial, int splits, int MN, float* __restrict__ C) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= MN) return;
+    const int t = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, sub = threadIdx.x & 3;
     float s = 0.f;
-    for (int p = 0; p < splits; ++p) s += partial[(size_t)p * MN + t];
-    C[t] = s;
+    if (t < MN)
+        for (int p = sub; p < splits; p += 4) s += partial[(size_t)p * MN + t];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (t < MN && sub == 0) C[t] = s;
 }
 
+constexpr int ATB_NT = 2;
+
+int atb_units(int M, int N) { return ((M + 15) / 16) * (((N + 15) / 16 + ATB_NT - 1) / ATB_NT); }
+
 int atb_splits(long long E, int M, int N) {
-    const int tiles = ((M + 15) / 16) * ((N + 15) / 16);
-    long long want = (2048 + tiles - 1) / tiles;          // ~2048 waves in flight
-    const long long maxs = (E + 255) / 256;               // at least 256 rows per slab
+    const int tiles = atb_units(M, N);
+    long long want = (1024 + tiles - 1) / tiles;          // ~1024 waves in flight
+    const long long maxs = (E + 511) / 512;               // at least 512 rows per slab
     if (want > maxs) want = maxs;
     if (want < 1) want = 1;
-    if (want > 1024) want = 1024;
+    if (want > 256) want = 256;
     return (int)want;
 }
 
@@ -87,10 +107,10 @@ extern "C" int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, in
     const int splits = atb_splits(n_rows, m, n);
     long long slab = (n_rows + splits - 1) / splits;
     slab = (slab + 7) / 8 * 8;
-    const int tiles = ((m + 15) / 16) * ((n + 15) / 16);
+    const int tiles = atb_units(m, n);
     dim3 grid((tiles + 3) / 4, (unsigned)((n_rows + slab - 1) / slab));
-    hipLaunchKernelGGL(atb_partial_kernel, grid, dim3(256), 0, st, A, B, (long long)n_rows, m, n, slab, workspace);
-    hipLaunchKernelGGL(atb_reduce_kernel, dim3((m * n + 255) / 256), dim3(256), 0, st, workspace, (int)grid.y, m * n, C);
+    hipLaunchKernelGGL(atb_partial_kernel<ATB_NT>, grid, dim3(256), 0, st, A, B, (long long)n_rows, m, n, slab, workspace);
+    hipLaunchKernelGGL(atb_reduce_kernel, dim3((m * n * 4 + 255) / 256), dim3(256), 0, st, workspace, (int)grid.y, m * n, C);
     MDG_CHECK_LAUNCH("atb kernels");
     return MDG_OK;
 }
