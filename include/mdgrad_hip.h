@@ -206,6 +206,11 @@ int64_t mdg_rdf_partial_size(int n_frames, int n_atoms, int nbins);
 int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                 float cutoff, const uint8_t* mask, const float* mu /*[nbins]*/, float coeff,
                 int nbins, float* raw, float* partial, void* stream);
+/* same, with the caller's guarantee that mu is an equally spaced grid (mu_k = mu[0] + k*spacing, as
+ * torch.linspace gives): enables the 8-bins-per-thread recurrence kernel when spacing*s <= 1. */
+int mdg_rdf_fwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
+                        float cutoff, const uint8_t* mask, const float* mu, float spacing, float coeff,
+                        int nbins, float* raw, float* partial, void* stream);
 int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                 float cutoff, const uint8_t* mask, const float* mu, float coeff, int nbins,
                 const float* g_raw, float* g_xyz, void* stream);

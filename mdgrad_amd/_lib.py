@@ -63,6 +63,8 @@ _SIGNATURES = {
     "mdg_rdf_partial_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "mdg_rdf_fwd": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float,
                               C.c_int, P, P, P]),
+    "mdg_rdf_fwd_uniform": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float, C.c_float,
+                                      C.c_int, P, P, P]),
     "mdg_rdf_bwd": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float,
                               C.c_int, P, P, P]),
     "mdg_edge_diff": (C.c_int, [P, P, C.c_int64, C.c_int, P, P]),

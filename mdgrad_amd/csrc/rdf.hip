@@ -112,6 +112,107 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_kernel(
     }
 }
 
+// Variant for equally spaced centres with Ds = s * spacing <= 1 (the default width == spacing gives
+// Ds = 0.85): a thread owns a block of 8 consecutive bins and gets their 8 Gaussians of one distance
+// from ONE centre evaluation and a two-term recurrence outwards from the block's middle bin
+//     e_{j+1} = e_j rho_j , rho_{j+1} = rho_j exp2(-2 Ds^2) , rho = exp2(+-2 Ds x - Ds^2)
+// i.e. 3 v_exp_f32 + 14 multiplies per 8 (pair, bin) values instead of 8 exps + 16 multiplies.  The
+// recurrence runs at most 4 steps (relative error ~1e-6); a block whose middle bin is farther than the
+// exp2 underflow reach from the distance can only miss terms below 2^-60.
+constexpr int RDF_KB = 8;
+
+template <bool DIAG>
+__global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_block8_kernel(
+    const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
+    const float* __restrict__ mu, float coeff, int nbins, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* dist = sm;                                   // [RDF_BLOCK]
+    int* wcnt = (int*)(sm + RDF_BLOCK);                 // [nw]
+    float* comb = sm + RDF_BLOCK + 16;                  // [G][nblk*8] final combine
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int nw = RDF_BLOCK / 64;
+    const float sc = sqrtf(-coeff * LOG2E);
+    const int nblk = (nbins + RDF_KB - 1) / RDF_KB;     // bin blocks
+    const int G = RDF_BLOCK / nblk;                     // thread groups sharing the sweep
+    const int grp = threadIdx.x / nblk;
+    const bool active = grp < G;
+    const int kb = threadIdx.x - grp * nblk;            // this thread's bin block
+    const float mu0 = mu[0];
+    const float dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
+    const float Ds = dmu * sc;
+    const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds * Ds);
+    const int kmid = min(nbins - 1, kb * RDF_KB + 4);
+    const float mum = active ? mu[kmid] : 0.f;          // centre of the block's middle bin (exact value)
+    const float off = (float)(kb * RDF_KB + 4 - kmid) * dmu;   // 0 unless the last block is partial
+    float acc[RDF_KB];
+#pragma unroll
+    for (int j = 0; j < RDF_KB; ++j) acc[j] = 0.f;
+    const long long npair = (long long)N * (N - 1) / 2;
+    const int chunks = (int)((npair + RDF_CHUNK - 1) / RDF_CHUNK);
+    const long long items = (long long)nF * chunks;
+    for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int fr = (int)(it / chunks), ch = (int)(it % chunks);
+        const float* pos = xyz + (size_t)fr * N * 3;
+        const long long c_end = min(npair, (long long)(ch + 1) * RDF_CHUNK);
+        long long c = (long long)ch * RDF_CHUNK + threadIdx.x;
+        int i = 0, j = 0;
+        if (c < c_end) pair_from_flat(c, N, i, j);
+        for (long long cb = (long long)ch * RDF_CHUNK; cb < c_end; cb += RDF_BLOCK) {
+            float d = -1.f;
+            if (c < c_end) {
+                float dx = pos[3 * j] - pos[3 * i], dy = pos[3 * j + 1] - pos[3 * i + 1],
+                      dz = pos[3 * j + 2] - pos[3 * i + 2];
+                min_image<DIAG>(cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                bool ok = (d2 < rc2) && (d2 != 0.f);
+                if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
+                if (ok) d = sqrtf(d2);
+                c += RDF_BLOCK;
+                j += RDF_BLOCK;
+                while (j >= N && i < N - 1) { ++i; j = j - N + i + 1; }
+            }
+            const unsigned long long b = __ballot(d >= 0.f);
+            __syncthreads();                                   // previous sweep done with dist[]
+            if (lane == 0) wcnt[wid] = __popcll(b);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < nw; ++w) { if (w < wid) base += wcnt[w]; total += wcnt[w]; }
+            if (d >= 0.f) dist[base + __popcll(b & ((1ull << lane) - 1ull))] = d;
+            __syncthreads();
+            if (active) {
+                for (int p = grp; p < total; p += G) {
+                    const float x4 = (dist[p] - mum - off) * sc;          // x at block bin 4
+                    const float e4 = __builtin_amdgcn_exp2f(-x4 * x4);
+                    float eu = e4, ed = e4;
+                    float ru = __builtin_amdgcn_exp2f(2.f * Ds * x4 - Ds * Ds);     // towards larger mu
+                    float rd = __builtin_amdgcn_exp2f(-2.f * Ds * x4 - Ds * Ds);    // towards smaller mu
+                    acc[4] += e4;
+                    eu *= ru; ru *= c2; acc[5] += eu;
+                    ed *= rd; rd *= c2; acc[3] += ed;
+                    eu *= ru; ru *= c2; acc[6] += eu;
+                    ed *= rd; rd *= c2; acc[2] += ed;
+                    eu *= ru;           acc[7] += eu;
+                    ed *= rd; rd *= c2; acc[1] += ed;
+                    ed *= rd;           acc[0] += ed;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nk = nblk * RDF_KB;
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < RDF_KB; ++j) comb[grp * nk + kb * RDF_KB + j] = acc[j];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += RDF_BLOCK) {
+        float s = 0.f;
+        for (int g = 0; g < G; ++g) s += comb[g * nk + k];
+        partial[(size_t)blockIdx.x * nbins + k] = s;
+    }
+}
+
 // raw[k] = sum_b partial[b][k] in fixed order; one wave per bin
 __global__ void rdf_finish_kernel(const float* __restrict__ partial, int nblocks, int nbins,
                                   float* __restrict__ raw) {
@@ -262,16 +363,29 @@ extern "C" int64_t mdg_rdf_partial_size(int n_frames, int n_atoms, int nbins) {
     return (int64_t)rdf_grid(n_frames, n_atoms) * nbins;
 }
 
-extern "C" int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,
-                           const uint8_t* mask, const float* mu, float coeff, int nbins, float* raw,
-                           float* partial, void* stream) {
+static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,
+                        const uint8_t* mask, const float* mu, float coeff, int nbins, float* raw,
+                        float* partial, float spacing_s, void* stream) {
     MDG_CHECK_ARG(xyz && cell && mu && raw && partial, "rdf_fwd: null buffer");
     MDG_CHECK_ARG(n_frames > 0 && n_atoms > 1 && nbins > 0, "rdf_fwd: bad sizes");
     MDG_CHECK_ARG(nbins <= RDF_BLOCK, "rdf_fwd: nbins > %d not supported", RDF_BLOCK);
     MDG_CHECK_ARG(coeff < 0.f, "rdf_fwd: coeff must be negative (-0.5 / width^2)");
     const int nblocks = rdf_grid(n_frames, n_atoms);
     hipStream_t st = (hipStream_t)stream;
-    if (cell->diag)
+    // equally spaced centres with Ds = s * spacing <= 1: 8-bin blocks + recurrence (spacing_s is the
+    // caller's statement that mu is a linspace; <= 0 selects the direct kernel)
+    const int nblk = (nbins + RDF_KB - 1) / RDF_KB;
+    const bool block8 = spacing_s > 0.f && spacing_s <= 1.0f && nbins >= 2 * RDF_KB && nblk <= RDF_BLOCK;
+    if (block8) {
+        const int G = RDF_BLOCK / nblk;
+        const size_t lds = sizeof(float) * (RDF_BLOCK + 16 + (size_t)G * nblk * RDF_KB);
+        if (cell->diag)
+            hipLaunchKernelGGL(rdf_fwd_block8_kernel<true>, dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames,
+                               n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);
+        else
+            hipLaunchKernelGGL(rdf_fwd_block8_kernel<false>, dim3(nblocks), dim3(RDF_BLOCK), lds, st, xyz, n_frames,
+                               n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);
+    } else if (cell->diag)
         hipLaunchKernelGGL(rdf_fwd_kernel<true>, dim3(nblocks), dim3(RDF_BLOCK), 0, st, xyz, n_frames, n_atoms,
                            *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);
     else
@@ -280,6 +394,19 @@ extern "C" int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const Md
     hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, nblocks, nbins, raw);
     MDG_CHECK_LAUNCH("rdf_fwd_kernel");
     return MDG_OK;
+}
+
+extern "C" int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,
+                           const uint8_t* mask, const float* mu, float coeff, int nbins, float* raw,
+                           float* partial, void* stream) {
+    return rdf_fwd_impl(xyz, n_frames, n_atoms, cell, cutoff, mask, mu, coeff, nbins, raw, partial, 0.f, stream);
+}
+
+extern "C" int mdg_rdf_fwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,
+                                   const uint8_t* mask, const float* mu, float spacing, float coeff, int nbins,
+                                   float* raw, float* partial, void* stream) {
+    const float spacing_s = spacing > 0.f && coeff < 0.f ? spacing * sqrtf(-coeff * 1.4426950408889634f) : 0.f;
+    return rdf_fwd_impl(xyz, n_frames, n_atoms, cell, cutoff, mask, mu, coeff, nbins, raw, partial, spacing_s, stream);
 }
 
 extern "C" int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,

@@ -44,6 +44,7 @@ class rdf(Observable):
         offsets = torch.linspace(start, float(bins[-1]), nbins)
         w = (offsets[1] - offsets[0]) if width is None else torch.tensor(float(width))
         self.register_buffer("offsets", offsets.to(self.device))
+        self.spacing = float(offsets[1] - offsets[0]) if nbins > 1 else 0.0     # linspace: equally spaced
         self.width = float(w)
         self.coeff = float(-0.5 / torch.pow(w.to(torch.float32), 2))
         self.nbins = nbins
@@ -56,7 +57,7 @@ class rdf(Observable):
         if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
             xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))
         count = ops.RdfRawFn.apply(xyz, self.offsets, self.coeff, self.cutoff_boundary,
-                                   self._cell_struct, self._mask)
+                                   self._cell_struct, self._mask, self.spacing)
         norm = count.sum()
         count = count / norm
         rdf = count / (self.vol_bins / self.V)

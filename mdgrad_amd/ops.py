@@ -332,7 +332,7 @@ class RdfRawFn(torch.autograd.Function):
     (the GaussianSmearing(...).sum(0) of torchmd/observable.py:70)."""
 
     @staticmethod
-    def forward(ctx, xyz, mu, coeff, cutoff, cell_struct, mask):
+    def forward(ctx, xyz, mu, coeff, cutoff, cell_struct, mask, spacing=0.0):
         lib = _lib.load()
         require_gpu(xyz, "xyz")
         x = xyz.detach().contiguous()
@@ -342,8 +342,9 @@ class RdfRawFn(torch.autograd.Function):
         raw = torch.empty(B, device=dev)
         partial = torch.empty(int(lib.mdg_rdf_partial_size(F, N, B)), device=dev)
         muc = mu.detach().to(torch.float32).contiguous()
-        check(lib.mdg_rdf_fwd(ptr(x3), F, N, C.byref(cell_struct), float(cutoff), ptr(mask), ptr(muc),
-                              float(coeff), B, ptr(raw), ptr(partial), stream_ptr(dev)), "mdg_rdf_fwd")
+        check(lib.mdg_rdf_fwd_uniform(ptr(x3), F, N, C.byref(cell_struct), float(cutoff), ptr(mask), ptr(muc),
+                                      float(spacing), float(coeff), B, ptr(raw), ptr(partial), stream_ptr(dev)),
+              "mdg_rdf_fwd")
         ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape)
         ctx.save_for_backward(x3, muc)
         return raw
@@ -358,7 +359,7 @@ class RdfRawFn(torch.autograd.Function):
         gr = g_raw.detach().to(torch.float32).contiguous()
         check(lib.mdg_rdf_bwd(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), coeff, B,
                               ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
-        return gx.reshape(shape), None, None, None, None, None
+        return gx.reshape(shape), None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- graph ops (SchNet)
