@@ -183,6 +183,9 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_block8_kernel(
             if (active) {
                 for (int p = grp; p < total; p += G) {
                     const float x4 = (dist[p] - mum - off) * sc;          // x at block bin 4
+                    // beyond 12 the block's nearest bin is > 12 - 4 Ds >= 8 away: all eight terms are
+                    // below 2^-64 (and the ratio below would overflow against an underflowed e4)
+                    if (fabsf(x4) >= 12.f) continue;
                     const float e4 = __builtin_amdgcn_exp2f(-x4 * x4);
                     float eu = e4, ed = e4;
                     float ru = __builtin_amdgcn_exp2f(2.f * Ds * x4 - Ds * Ds);     // towards larger mu
