@@ -1,54 +1,51 @@
-"""nff/nn/layers.py:14-134 and nff/nn/activations.py:5-11 (same names, same state_dict keys)."""
+"""Radial basis, dense layer and activation used by the SchNet blocks.  Public names, constructor
+arguments and state_dict keys follow nff/nn/layers.py:14-134 and nff/nn/activations.py:5-11 so that
+reference checkpoints load unchanged; the code is this package's own."""
 import math
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn.init import xavier_uniform_, constant_
+
+_LN2 = math.log(2.0)
 
 
 def gaussian_smearing(distances, offset, widths, centered=False):
-    """exp(-0.5/width^2 (d - mu)^2)  (layers.py:14-31)."""
-    if not centered:
-        coeff = -0.5 / torch.pow(widths, 2)
-        diff = distances - offset
-    else:
-        coeff = -0.5 / torch.pow(offset, 2)
-        diff = distances
-    return torch.exp(coeff * torch.pow(diff, 2))
+    """Gaussian radial basis.  Regular mode: exp(-(d - mu_k)^2 / (2 w_k^2)); centred mode: the offsets
+    act as widths of origin-centred Gaussians, exp(-d^2 / (2 mu_k^2))  (layers.py:14-31)."""
+    sigma, shift = (offset, 0.0) if centered else (widths, offset)
+    return torch.exp((distances - shift).pow(2) * (-0.5 / sigma.pow(2)))
 
 
 class GaussianSmearing(nn.Module):
-    """layers.py:34-83: offsets = linspace(start, stop, n), width = offsets[1]-offsets[0]
-    unless given; buffers unless trainable."""
+    """n_gaussians centres on linspace(start, stop); one shared width (centre spacing unless `width`
+    is given).  `width` / `offsets` are buffers, or Parameters when trainable (layers.py:34-83)."""
 
     def __init__(self, start, stop, n_gaussians, width=None, centered=False, trainable=False):
         super().__init__()
-        offset = torch.linspace(start, stop, n_gaussians)
-        if width is None:
-            widths = torch.FloatTensor((offset[1] - offset[0]) * torch.ones_like(offset))
-        else:
-            widths = torch.FloatTensor(width * torch.ones_like(offset))
-        if trainable:
-            self.width = nn.Parameter(widths)
-            self.offsets = nn.Parameter(offset)
-        else:
-            self.register_buffer('width', widths)
-            self.register_buffer('offsets', offset)
+        centres = torch.linspace(start, stop, n_gaussians)
+        w = (centres[1] - centres[0]) if width is None else width
+        widths = torch.ones_like(centres) * w
         self.centered = centered
+        for name, value in (("width", widths), ("offsets", centres)):
+            if trainable:
+                setattr(self, name, nn.Parameter(value))
+            else:
+                self.register_buffer(name, value)
 
     def forward(self, distances):
         return gaussian_smearing(distances, self.offsets, self.width, centered=self.centered)
 
 
 class Dense(nn.Linear):
-    """y = activation(x W^T + b), xavier-uniform W, zero b (layers.py:86-134).  The GEMM is the
-    library one (rocBLAS/hipBLASLt through torch)."""
+    """Linear layer with optional activation, Xavier-uniform weight and zero bias by default
+    (layers.py:86-134).  2-D HIP inputs with many rows route their weight gradient to the split-K MFMA
+    kernel (ops.linear); everything else is the library GEMM."""
 
     def __init__(self, in_features, out_features, bias=True, activation=None,
-                 weight_init=xavier_uniform_, bias_init=None):
+                 weight_init=nn.init.xavier_uniform_, bias_init=None):
         self.weight_init = weight_init
-        self.bias_init = bias_init if bias_init is not None else (lambda b: constant_(b, 0.))
+        self.bias_init = nn.init.zeros_ if bias_init is None else bias_init
         self.activation = activation
         super().__init__(in_features, out_features, bias)
 
@@ -58,18 +55,17 @@ class Dense(nn.Linear):
             self.bias_init(self.bias)
 
     def forward(self, inputs):
-        if inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.shape[0] >= 8192:
+        tall = inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.shape[0] >= 8192
+        if tall:
             from .. import ops
-            y = ops.linear(inputs, self.weight, self.bias)      # weight gradient on the split-K MFMA kernel
+            y = ops.linear(inputs, self.weight, self.bias)
         else:
-            y = super().forward(inputs)
-        if self.activation:
-            y = self.activation(y)
-        return y
+            y = F.linear(inputs, self.weight, self.bias)
+        return self.activation(y) if self.activation else y
 
 
 class shifted_softplus(nn.Module):
-    """softplus(x) - ln 2  (activations.py:5-11)."""
+    """softplus(x) - ln 2."""
 
     def forward(self, input):
-        return F.softplus(input) - math.log(2.0)
+        return F.softplus(input) - _LN2

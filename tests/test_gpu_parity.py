@@ -668,3 +668,45 @@ def test_stacked_replicas_fused_lj_through_simulations():
         _, gt = O.adjoint_oracle(eom, frames[r], [x.grad for x in leaves[r]], t)
         gth += gt.numpy()
     close(np.array(gs), gth, 5e-3, 1e-3 * np.abs(gth).max(), "stacked fused dL/dtheta")
+
+
+# ------------------------------------------------------------------ edge cases
+def test_edge_cases_empty_lists_tiny_systems_single_frame():
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain, NVE
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from mdgrad_amd.topology import generate_nbr_list
+    g = load_golden("nhc_traj_lj")
+    # no pair within the cutoff: empty list in the reference's shapes, zero energy / forces
+    nbr, dis, off = generate_nbr_list(T(g["pos"], DEV), 0.2, T(g["cell"]), get_dis=True)
+    assert nbr.shape == (0, 2) and off.shape == (0, 3) and dis.shape == (0,)
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    pp = PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=0.2)
+    q = T(g["pos"], DEV).requires_grad_(True)
+    U = pp(q)
+    (gq,) = torch.autograd.grad(U, q)
+    assert float(U) == 0.0 and float(gq.abs().max()) == 0.0
+    # a single frame (no step): trajectory = the input, adjoint = the incoming gradient
+    _, mdl, integ = lj_setup(g)
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), torch.Tensor([0.0]).to(DEV), method="NH_verlet")
+    assert v_t.shape == (1, 108, 3) and torch.equal(q_t[0], y0[1].detach())
+    (q_t.sum() * 2 + v_t.sum() * 3).backward()
+    assert torch.equal(y0[1].grad, torch.full_like(y0[1], 2.0)) and torch.equal(y0[0].grad, torch.full_like(y0[0], 3.0))
+    # two atoms, NVE, fused: energy conservation-ish and symmetric forces
+    s2 = mk_system(np.array([[1.0, 1.0, 1.0], [2.1, 1.0, 1.0]]), np.array([6.0, 6.0, 6.0]),
+                   np.zeros((2, 3)), np.array([1.0, 1.0]))
+    m2 = P.LennardJones(1.0, 1.0)
+    nve = NVE(Stack({"p": PairPotentials(s2, m2, cutoff=2.5)}), s2).to(DEV)
+    assert nve.fused_spec("verlet") is not None
+    tt = torch.Tensor([0.002 * i for i in range(20)]).to(DEV)
+    v2, q2 = odeint_adjoint(nve, tuple(nve.get_inital_states(wrap=True)), tt, method="verlet")
+    close(v2[:, 0], -v2[:, 1], 1e-6, 1e-7, "momentum conservation (two atoms)")
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, torch.tensor([6.0] * 3), p=12, q=6, c=1)
+    traj = O.odeint_oracle(O.NVEOracle(O.ModelOracle([term])), (torch.zeros(2, 3), torch.Tensor(s2.get_positions())),
+                           tt.cpu())
+    close(q2, traj[1], 1e-5, 1e-6, "two-atom NVE trajectory")
+    # wrong device / dtype fail loudly
+    with pytest.raises((RuntimeError, TypeError)):
+        pp(q.detach().double())
