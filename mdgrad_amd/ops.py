@@ -136,6 +136,13 @@ def make_term(desc, cutoff, theta_off=0, n_theta=0, mask=None):
 def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True):
     """One launch of mdg_pair_eval_ell.  Returns dict with the requested outputs."""
     lib = _lib.load()
+    require_gpu(xyz, "xyz")
+    if theta is not None and theta.numel():
+        require_gpu(theta, "theta")
+    if w is not None:
+        require_gpu(w, "w")
+    if xyz.shape != (ell.n_atoms, 3):
+        raise ValueError("mdgrad_amd: xyz must be [%d, 3] (got %s)" % (ell.n_atoms, tuple(xyz.shape)))
     dev = xyz.device
     N, K = ell.n_atoms, term.n_theta
     out = {}
@@ -375,6 +382,7 @@ class GraphTopo:
 
 def _edge_diff(x, topo):
     lib = _lib.load()
+    require_gpu(x, "x")
     x = x.contiguous()
     out = torch.empty(topo.n_edges, x.shape[1], device=x.device)
     check(lib.mdg_edge_diff(ptr(x), ptr(topo.nbr), topo.n_edges, x.shape[1], ptr(out), stream_ptr(x.device)),
@@ -384,6 +392,7 @@ def _edge_diff(x, topo):
 
 def _edge_scatter(g, topo):
     lib = _lib.load()
+    require_gpu(g, "g")
     g = g.contiguous()
     e = topo.ell
     out = torch.empty(topo.n_atoms, g.shape[1], device=g.device)
@@ -394,6 +403,7 @@ def _edge_scatter(g, topo):
 
 def _cfconv_agg(h, W, topo):
     lib = _lib.load()
+    require_gpu(h, "h"), require_gpu(W, "W")
     h, W = h.contiguous(), W.contiguous()
     e = topo.ell
     out = torch.empty(topo.n_atoms, h.shape[1], device=h.device)
@@ -404,6 +414,7 @@ def _cfconv_agg(h, W, topo):
 
 def _edge_prod(a, b, topo):
     lib = _lib.load()
+    require_gpu(a, "a"), require_gpu(b, "b")
     a, b = a.contiguous(), b.contiguous()
     out = torch.empty(topo.n_edges, a.shape[1], device=a.device)
     check(lib.mdg_edge_prod(ptr(a), ptr(b), ptr(topo.nbr), topo.n_edges, a.shape[1], ptr(out),
@@ -475,6 +486,7 @@ class EdgeProdFn(torch.autograd.Function):
 # ----------------------------------------------------------------------------- dense algebra closure
 def _atb(A, B):
     lib = _lib.load()
+    require_gpu(A, "A"), require_gpu(B, "B")
     A, B = A.contiguous(), B.contiguous()
     E, M, N = A.shape[0], A.shape[1], B.shape[1]
     out = torch.empty(M, N, device=A.device)
