@@ -195,6 +195,7 @@ def main():
         print(json.dumps(out))
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
+        mdist.barrier()
         tdist.destroy_process_group()
 
 

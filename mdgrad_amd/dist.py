@@ -21,10 +21,14 @@ def init(backend=None, device_index=None):
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     use_gpu = torch.cuda.is_available()
     if backend is None:
-        backend = "nccl" if use_gpu else "gloo"
+        # MDG_DIST_BACKEND=gloo lets several ranks share one GPU (control-flow tests on a 1-GPU box;
+        # RCCL refuses two ranks on one device)
+        backend = os.environ.get("MDG_DIST_BACKEND", "nccl" if use_gpu else "gloo")
     device = torch.device("cpu")
-    if use_gpu and backend == "nccl":
+    if use_gpu:
         idx = local if device_index is None else device_index
+        if os.environ.get("MDG_SINGLE_DEVICE") == "1":
+            idx = 0
         torch.cuda.set_device(idx)
         device = torch.device("cuda", idx)
     if world > 1 and not dist.is_initialized():
@@ -58,6 +62,16 @@ def unflatten_to_grads(flat, params):
         pos += n
 
 
+def _all_reduce(t, op):
+    """all_reduce that also works when a CPU-only backend (gloo) is given a HIP tensor."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+
+
 def all_reduce_grads(params, average=False):
     """One collective per outer step: SUM (or mean) of the flat gradient over all ranks,
     written back into p.grad.  No-op for world_size 1."""
@@ -65,7 +79,7 @@ def all_reduce_grads(params, average=False):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not params:
         return
     flat = flatten_grads(params)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _all_reduce(flat, dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
     unflatten_to_grads(flat, params)
@@ -80,7 +94,7 @@ def max_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    _all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
@@ -88,5 +102,5 @@ def sum_over_ranks(value, device):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    _all_reduce(t, dist.ReduceOp.SUM)
     return float(t.item())
