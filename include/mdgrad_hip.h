@@ -245,6 +245,11 @@ int mdg_cfconv_filter(const float* d, int64_t n_edges, const float* mu, const fl
                       const float* W1, const float* b1, const float* W2, const float* b2,
                       int n_filters, float* out, void* stream);
 
+/* bf16-operand variant (v_mfma_f32_16x16x32_bf16, fp32 accumulate / bias / output). */
+int mdg_cfconv_filter_bf16(const float* d, int64_t n_edges, const float* mu, const float* width, int n_gauss,
+                           const float* W1, const float* b1, const float* W2, const float* b2,
+                           int n_filters, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Tall-skinny contraction C[M,N] = A[E,M]^T B[E,N] (split-K on the f32 MFMA, ordered reduction):
  * the weight gradients of edge-wise Dense layers in the adjoint's parameter vjp (autograd of

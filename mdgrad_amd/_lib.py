@@ -74,6 +74,7 @@ _SIGNATURES = {
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
+    "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

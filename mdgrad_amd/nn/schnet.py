@@ -67,6 +67,7 @@ class SchNetConv(nn.Module):
         })
 
     fused_filter = True          # K9 on the matrix cores (csrc/cfconv_filter.hip)
+    filter_bf16 = False          # bf16 MFMA operands (fp32 accumulate); default fp32 MFMA = exact f32
 
     def edge_filter(self, e):
         seq = self.moduledict['message_edge_filter']
@@ -75,7 +76,7 @@ class SchNetConv(nn.Module):
                 and d1.activation is None and d2.activation is None and d1.bias is not None
                 and d2.bias is not None):
             return ops.CfconvFilterFn.apply(e.reshape(-1), smear.offsets, smear.width, d1.weight, d1.bias,
-                                            d2.weight, d2.bias)
+                                            d2.weight, d2.bias, self.filter_bf16)
         return seq(e)
 
     def forward(self, r, e, a, aggr_wgt=None, topo=None):

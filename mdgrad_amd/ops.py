@@ -564,15 +564,15 @@ class CfconvFilterFn(torch.autograd.Function):
     the adjoint's second-order pass goes through it without a hand-derived third kernel."""
 
     @staticmethod
-    def forward(ctx, d, mu, width, W1, b1, W2, b2):
+    def forward(ctx, d, mu, width, W1, b1, W2, b2, bf16=False):
         lib = _lib.load()
         require_gpu(d, "d")
         args = [x.detach().contiguous() for x in (d, mu, width, W1, b1, W2, b2)]
         E, G, F = args[0].shape[0], args[1].shape[0], args[5].shape[0]
         out = torch.empty(E, F, device=d.device)
-        check(lib.mdg_cfconv_filter(ptr(args[0]), E, ptr(args[1]), ptr(args[2]), G, ptr(args[3]), ptr(args[4]),
-                                    ptr(args[5]), ptr(args[6]), F, ptr(out), stream_ptr(d.device)),
-              "mdg_cfconv_filter")
+        fn = lib.mdg_cfconv_filter_bf16 if bf16 else lib.mdg_cfconv_filter
+        check(fn(ptr(args[0]), E, ptr(args[1]), ptr(args[2]), G, ptr(args[3]), ptr(args[4]),
+                 ptr(args[5]), ptr(args[6]), F, ptr(out), stream_ptr(d.device)), "mdg_cfconv_filter")
         ctx.save_for_backward(d, mu, width, W1, b1, W2, b2)
         return out
 
@@ -604,4 +604,4 @@ class CfconvFilterFn(torch.autograd.Function):
             gW2 = atb(gW, h1)
         if need[6]:
             gb2 = gW.sum(0)
-        return gd, gmu, gwidth, gW1, gb1, gW2, gb2
+        return gd, gmu, gwidth, gW1, gb1, gW2, gb2, None

@@ -225,3 +225,26 @@ def test_tall_skinny_atb_kernel_and_closure(E, M, N):
         outs.append(list(g1) + list(g2))
     for a, b in zip(*outs):
         close(b, a, 2e-3, 2e-4 * float(a.abs().max()) + 1e-5, "MM/AtB closure")
+
+
+@pytest.mark.parametrize("G,F,E", [(30, 128, 5000), (16, 48, 333), (64, 200, 1000)])
+def test_bf16_mfma_filter_variant(G, F, E):
+    """bf16-operand MFMA filter (fp32 accumulate): within bf16 rounding of the fp32 network; gradients come
+    from the fp32 formulas."""
+    from mdgrad_amd import ops
+    torch.manual_seed(G + F)
+    d = (torch.rand(E, device=DEV) * 5.0).requires_grad_(True)
+    mu = torch.linspace(0, 5.0, G, device=DEV)
+    width = torch.full((G,), float(5.0 / (G - 1)), device=DEV)
+    W1 = (torch.randn(G, G, device=DEV) / G ** 0.5).requires_grad_(True)
+    b1 = torch.randn(G, device=DEV) * 0.1
+    W2 = (torch.randn(F, G, device=DEV) / G ** 0.5).requires_grad_(True)
+    b2 = torch.randn(F, device=DEV) * 0.1
+    ref = ops.filter_reference(d, mu, width, W1, b1, W2, b2)
+    got = ops.CfconvFilterFn.apply(d, mu, width, W1, b1, W2, b2, True)
+    scale = float(ref.abs().max())
+    close(got, ref, 0, 2e-2 * scale, "bf16 filter")            # ~2^-8 relative per operand, K <= 64 terms
+    g_ref = torch.autograd.grad(ref.sum(), [d, W1, W2])
+    g_got = torch.autograd.grad(got.sum(), [d, W1, W2])
+    for a, b in zip(g_got, g_ref):
+        close(a, b, 1e-4, 1e-5 * float(b.abs().max()), "bf16 filter gradient (fp32 formulas)")

@@ -14,7 +14,7 @@ from tools.kbench import timeit  # noqa: E402
 def main():
     from mdgrad_amd import ops
     dev = "cuda:0"
-    print("%9s %4s %4s | %9s %9s %9s %9s | %9s" % ("E", "G", "F", "hip us", "TFLOP/s", "GB/s out", "%HBM 8T", "torch us"))
+    print("%9s %4s %4s | %9s %9s %9s %9s | %9s | %9s %9s" % ("E", "G", "F", "f32 us", "TFLOP/s", "GB/s out", "%HBM 8T", "torch us", "bf16 us", "GB/s out"))
     for E, G, F in [(57344, 30, 128), (57344, 32, 128), (57344, 64, 256), (458752, 30, 128), (1048576, 32, 128),
                     (1048576, 64, 256), (4194304, 32, 128)]:
         torch.manual_seed(0)
@@ -29,11 +29,14 @@ def main():
         with torch.no_grad():
             t_hip = timeit(lambda: ops.CfconvFilterFn.apply(*args), 20) * 1e3
             t_ref = timeit(lambda: ops.filter_reference(*args), 10) * 1e3
+            t_bf = timeit(lambda: ops.CfconvFilterFn.apply(*args, True), 20) * 1e3
             err = float((ops.CfconvFilterFn.apply(*args) - ops.filter_reference(*args)).abs().max())
+            errb = float((ops.CfconvFilterFn.apply(*args, True) - ops.filter_reference(*args)).abs().max())
         flop = 2.0 * E * G * (G + F)
         byts = 4.0 * E * (F + 1)
-        print("%9d %4d %4d | %9.1f %9.2f %9.1f %9.1f | %9.1f   max|diff| %.1e" % (
-            E, G, F, t_hip, flop / t_hip / 1e6, byts / t_hip / 1e3, 100 * byts / t_hip / 1e3 / 8000.0, t_ref, err))
+        print("%9d %4d %4d | %9.1f %9.2f %9.1f %9.1f | %9.1f | %9.1f %9.1f   max|diff| f32 %.1e bf16 %.1e" % (
+            E, G, F, t_hip, flop / t_hip / 1e6, byts / t_hip / 1e3, 100 * byts / t_hip / 1e3 / 8000.0, t_ref,
+            t_bf, byts / t_bf / 1e3, err, errb))
 
 
 if __name__ == "__main__":
