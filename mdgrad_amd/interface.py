@@ -123,6 +123,33 @@ class PairPotentials(GeneralInteraction):
         self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
         return _LazyTopology(self, xyz.detach())
 
+    # -- analytic-adjoint protocol (no autograd): used by the integrators' rhs_vjp ------------------
+    def supports_force_vjp(self):
+        return self.builtin()
+
+    def _theta(self, like):
+        params = self.model.mdg_params()
+        return (torch.cat([p.detach().reshape(-1) for p in params]) if params else like.new_zeros(0)), params
+
+    def force(self, xyz):
+        """F = -dU/dx in one kernel launch."""
+        theta, _ = self._theta(xyz)
+        o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True)
+        return -o["grad"]
+
+    def force_vjp(self, xyz, w):
+        """(F, d(w.F)/dx, [d(w.F)/dtheta_p for p in parameters()]) -- what double autograd yields at
+        torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term)."""
+        theta, params = self._theta(xyz)
+        o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, w=w.detach().contiguous(),
+                          energy=False, grad=True)
+        gth, pos = [], 0
+        for p in params:
+            n = p.numel()
+            gth.append(-o["gtheta_w"][pos:pos + n].reshape(p.shape))
+            pos += n
+        return -o["grad"], -o["hw"], gth
+
     def forward(self, xyz):
         if self.builtin():
             params = self.model.mdg_params()
@@ -141,6 +168,29 @@ class Stack(torch.nn.Module):
     def __init__(self, model_dict, mode='sum'):
         super().__init__()
         self.models = ModuleDict(model_dict)
+
+    # analytic-adjoint protocol: available when every member provides it
+    def supports_force_vjp(self):
+        return all(getattr(m, "supports_force_vjp", lambda: False)() for m in self.models.values())
+
+    def force(self, x):
+        out = None
+        for m in self.models.values():
+            f = m.force(x)
+            out = f if out is None else out + f
+        return out
+
+    def force_vjp(self, x, w):
+        """Sum over members; the parameter gradients come back as a list aligned with self.parameters()."""
+        F = dq = None
+        by_id = {}
+        for m in self.models.values():
+            f, g, gth = m.force_vjp(x, w)
+            F = f if F is None else F + f
+            dq = g if dq is None else dq + g
+            for p, gp in zip(m.parameters(), gth):
+                by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp
+        return F, dq, [by_id.get(id(p), torch.zeros_like(p)) for p in self.parameters()]
 
     def _reset_topology(self, x):
         for key in self.models.keys():

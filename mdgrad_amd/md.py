@@ -215,10 +215,52 @@ class NoseHooverChain(_EOM):
     def update_T(self, T):
         self.T = T
 
+    def supports_rhs_vjp(self):
+        return getattr(self.model, "supports_force_vjp", lambda: False)()
+
+    def rhs_vjp(self, state, adj):
+        """f(y) and adj^T df/d(y, theta) written out analytically: what
+        augmented_dynamics gets from autograd at torchmd/sovlers.py:229-233, with the model's
+        force / Hessian-vector product / parameter vjp coming from its force_vjp (HIP kernels, no
+        autograd graph).  Returns (f_eval tuple, vjp_y tuple, [vjp per parameter])."""
+        v, q, p_v = state
+        lv, lq, lp = adj
+        self.update_topology(q)
+        m = self.mass[:, None]
+        F, dwF_dq, gth = self.model.force_vjp(q, lv / m)
+        f_eval = self.rhs_from_force((v, q, p_v), F)
+        Q = self.Q
+        if p_v.dim() == 1:
+            pv0, lp0, slv = p_v[0], lp[0], (lv * v).sum()
+            Gv = -(pv0 / Q[0]) * lv + lq + 2 * m * v * lp0
+            Gp = torch.zeros_like(p_v)
+            Gp[0] = -slv / Q[0] - lp[0] * p_v[1] / Q[1] + 2 * p_v[0] * lp[1] / Q[0]
+            if p_v.shape[0] > 2:
+                Gp[1:-1] = (-lp[:-2] * p_v[:-2] / Q[1:-1] - lp[1:-1] * p_v[2:] / Q[2:]
+                            + 2 * p_v[1:-1] * lp[2:] / Q[1:-1])
+            Gp[-1] = -lp[-2] * p_v[-2] / Q[-1]
+        else:
+            R, n = p_v.shape[0], self.n_group
+            pv0 = p_v[:, 0].repeat_interleave(n)[:, None]
+            lp0 = lp[:, 0].repeat_interleave(n)[:, None]
+            slv = (lv * v).reshape(R, -1).sum(1)
+            Gv = -(pv0 / Q[0]) * lv + lq + 2 * m * v * lp0
+            Gp = torch.zeros_like(p_v)
+            Gp[:, 0] = -slv / Q[0] - lp[:, 0] * p_v[:, 1] / Q[1] + 2 * p_v[:, 0] * lp[:, 1] / Q[0]
+            if p_v.shape[1] > 2:
+                Gp[:, 1:-1] = (-lp[:, :-2] * p_v[:, :-2] / Q[1:-1] - lp[:, 1:-1] * p_v[:, 2:] / Q[2:]
+                               + 2 * p_v[:, 1:-1] * lp[:, 2:] / Q[1:-1])
+            Gp[:, -1] = -lp[:, -2] * p_v[:, -2] / Q[-1]
+        by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
+        return f_eval, (Gv, dwF_dq, Gp), [by_id.get(id(p), torch.zeros_like(p)) for p in self.parameters()]
+
     def force(self, q):
         """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to
         reuse the force between the second evaluation of step k and the first of step k+1 -- same q,
         bit-identical result; only when topology_update_freq == 1)."""
+        if getattr(self.model, "supports_force_vjp", lambda: False)():
+            self.update_topology(q)
+            return self.model.force(q)
         with torch.set_grad_enabled(True):
             q = q.detach().requires_grad_(True)
             self.update_topology(q)

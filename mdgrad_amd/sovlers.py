@@ -143,8 +143,16 @@ class OdeintAdjointMethod(torch.autograd.Function):
         n = len(ans)
         f_params = tuple(func.parameters())
 
+        analytic = (not ctx.needs_input_grad[n + 1]) and getattr(func, "supports_rhs_vjp", lambda: False)()
+
         def augmented_dynamics(t_, y_aug):                     # sovlers.py:221-245
             y, adj_y = y_aug[:n], y_aug[n:2 * n]
+            if analytic:
+                # same quantities without an autograd graph: func.rhs_vjp returns adj^T df/d(y, theta);
+                # the reference feeds -adj to autograd.grad (:232), hence the sign flips
+                f_eval, vjp_y, vjp_p = func.rhs_vjp(tuple(a.detach() for a in y), tuple(a.detach() for a in adj_y))
+                vjp_p = _flatten([-g for g in vjp_p]) if len(vjp_p) else torch.tensor(0.).to(y[0])
+                return (*f_eval, *(-g for g in vjp_y), torch.zeros(()).to(y[0]), vjp_p)
             with torch.set_grad_enabled(True):
                 t_ = t_.to(y[0].device).detach().requires_grad_(True)
                 y = tuple(y_.detach().requires_grad_(True) for y_ in y)
