@@ -78,6 +78,25 @@ class GNNPotentials(GeneralInteraction):
         results = self.gnn(self.inputs, xyz)
         return results['energy']
 
+    # -- analytic-adjoint protocol: hand-derived SchNet passes (mdgrad_amd/nn/analytic.py) ---------
+    analytic = True
+
+    def supports_force_vjp(self):
+        from .nn import analytic
+        return self.analytic and analytic.supported(self.gnn) and not getattr(self.gnn, "cartesian_offsets", False)
+
+    def _z(self):
+        return self.inputs['nxyz'][:, 0].long()
+
+    def force(self, xyz):
+        from .nn import analytic
+        return analytic.force(self.gnn, self._z(), xyz, self.inputs['_topo'], self.inputs['offsets'])[1]
+
+    def force_vjp(self, xyz, w):
+        from .nn import analytic
+        _, F, dq, gth = analytic.force_vjp(self.gnn, self._z(), xyz, w, self.inputs['_topo'], self.inputs['offsets'])
+        return F, dq, gth
+
 
 class PairPotentials(GeneralInteraction):
     """torchmd/interface.py:217-300.  `pair_model` is a module instance (the code's signature)

@@ -1,0 +1,198 @@
+"""Hand-derived first- and second-order passes of the SchNet energy (no autograd graph).
+
+The adjoint of the MD step needs, per evaluation, the force F = -dU/dx and, for a given atom
+vector w (= lambda_v / m), the vjps d(w.F)/dx and d(w.F)/dtheta.  PyTorch gets them by
+differentiating the energy twice (reverse-over-reverse through ~500 small ops).  Here the same
+quantities come from ONE primal forward, ONE forward-mode (tangent) sweep along x_dot = w -- which
+gives U_dot = dU/dx . w = -(w.F) -- and ONE reverse sweep of U_dot, all written out explicitly on
+top of the graph kernels (csrc/graph.hip), the split-K A^T B kernel and library GEMMs:
+
+    force(...)      primal forward + reverse of U                      (E1)
+    force_vjp(...)  primal + tangent forward, reverse of U, reverse of U_dot      (E2)
+
+Notation follows SURVEY A.9 / nff/nn/models/schnet.py:113-171 (reference parameter names in
+brackets): per layer  g = smear(d) -> a = W1 g + b1 [edge_filter.1] -> s = ssp(a) -> Wf = W2 s + b2
+[edge_filter.3];  h = Wn r + bn [node_filter];  m = agg(h, Wf);  u = U1 m + c1 [update.0];
+t = ssp(u);  r <- r + U2 t + c2 [update.2];  readout y = L1 r + l1, U = sum L2 ssp(y) + l2.
+"""
+import math
+
+import torch
+
+from .. import ops
+
+_LN2 = math.log(2.0)
+
+
+def _ssp(x):
+    return torch.nn.functional.softplus(x) - _LN2
+
+
+def _atb(a, b):
+    """a^T b, tall-skinny aware."""
+    if a.shape[0] >= ops.TALL_ROWS and a.is_cuda:
+        return ops._atb(a, b)
+    return a.t().matmul(b)
+
+
+def supported(net):
+    from .schnet import SchNet
+    if not isinstance(net, SchNet) or list(net.atomwisereadout.readout.keys()) != ["energy"]:
+        return False
+    ro = net.atomwisereadout.readout["energy"]
+    if len(ro) != 3 or net.atomwisereadout.post_readout is not None:
+        return False
+    for conv in net.convolutions:
+        seq = conv.moduledict["message_edge_filter"]
+        if isinstance(seq[0].width, torch.nn.Parameter) or seq[0].centered:
+            return False                        # trainable / centred Gaussians: autograd path
+    return True
+
+
+def _layer_params(conv):
+    md = conv.moduledict
+    f, n, u = md["message_edge_filter"], md["message_node_filter"], md["update_function"]
+    return dict(mu=f[0].offsets, c=-0.5 / f[0].width.pow(2), W1=f[1].weight, b1=f[1].bias, W2=f[3].weight,
+                b2=f[3].bias, Wn=n.weight, bn=n.bias, U1=u[0].weight, c1=u[0].bias, U2=u[2].weight, c2=u[2].bias)
+
+
+@torch.no_grad()
+def _primal(net, z, x, topo, offsets):
+    delta = ops._edge_diff(x, topo) - offsets                 # schnet.py:142 (raw image flags by default)
+    d = delta.pow(2).sum(1).sqrt()
+    uhat = delta / d[:, None]
+    r = net.atom_embed.weight[z]
+    layers = []
+    for conv in net.convolutions:
+        P = _layer_params(conv)
+        xm = d[:, None] - P["mu"]
+        g = torch.exp(P["c"] * xm.pow(2))
+        a = torch.addmm(P["b1"], g, P["W1"].t())
+        s = _ssp(a)
+        Wf = torch.addmm(P["b2"], s, P["W2"].t())
+        h = torch.addmm(P["bn"], r, P["Wn"].t())
+        m = ops._cfconv_agg(h, Wf, topo)
+        u = torch.addmm(P["c1"], m, P["U1"].t())
+        t = _ssp(u)
+        layers.append(dict(P=P, r=r, phi=2 * P["c"] * xm, g=g, a=a, s=s, Wf=Wf, h=h, m=m, u=u, t=t))
+        r = r + torch.addmm(P["c2"], t, P["U2"].t())
+    ro = net.atomwisereadout.readout["energy"]
+    L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
+    y = torch.addmm(l1, r, L1.t())
+    U = (_ssp(y).matmul(L2.t()) + l2).sum()
+    return dict(d=d, uhat=uhat, layers=layers, r=r, y=y, L1=L1, L2=L2, U=U)
+
+
+@torch.no_grad()
+def _reverse_U(fw, topo):
+    """dU/dd per edge -> force."""
+    rb = (torch.sigmoid(fw["y"]) * fw["L2"]).matmul(fw["L1"])
+    d_b = torch.zeros_like(fw["d"])
+    for L in reversed(fw["layers"]):
+        P = L["P"]
+        ub = torch.sigmoid(L["u"]) * rb.matmul(P["U2"])
+        mb = ub.matmul(P["U1"])
+        hb = ops._cfconv_agg(mb, L["Wf"], topo)
+        Wfb = ops._edge_prod(mb, L["h"], topo)
+        rb = rb + hb.matmul(P["Wn"])
+        ab = torch.sigmoid(L["a"]) * Wfb.matmul(P["W2"])
+        d_b += (ab.matmul(P["W1"]) * L["g"] * L["phi"]).sum(1)
+    return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
+
+
+@torch.no_grad()
+def force(net, z, x, topo, offsets):
+    fw = _primal(net, z, x.detach().contiguous(), topo, offsets)
+    return fw["U"], _reverse_U(fw, topo)
+
+
+@torch.no_grad()
+def force_vjp(net, z, x, w, topo, offsets):
+    """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()])."""
+    x, w = x.detach().contiguous(), w.detach().contiguous()
+    fw = _primal(net, z, x, topo, offsets)
+    F = _reverse_U(fw, topo)
+    d, uhat = fw["d"], fw["uhat"]
+    # ---------------- tangent sweep along x_dot = w
+    ddel = ops._edge_diff(w, topo)
+    dd = (uhat * ddel).sum(1)
+    rd = None                                                     # r_dot^0 = 0
+    for L in fw["layers"]:
+        P = L["P"]
+        gd = L["g"] * L["phi"] * dd[:, None]
+        ad = gd.matmul(P["W1"].t())
+        sa = torch.sigmoid(L["a"])
+        sd = sa * ad
+        Wfd = sd.matmul(P["W2"].t())
+        md = ops._cfconv_agg(L["h"], Wfd, topo)
+        hd = None
+        if rd is not None:
+            hd = rd.matmul(P["Wn"].t())
+            md = md + ops._cfconv_agg(hd, L["Wf"], topo)
+        su = torch.sigmoid(L["u"])
+        ud = md.matmul(P["U1"].t())
+        td = su * ud
+        L.update(gd=gd, ad=ad, sa=sa, sd=sd, Wfd=Wfd, hd=hd, md=md, su=su, ud=ud, td=td, rd=rd)
+        rd = td.matmul(P["U2"].t()) if rd is None else rd + td.matmul(P["U2"].t())
+    L1, L2, y = fw["L1"], fw["L2"], fw["y"]
+    yd = rd.matmul(L1.t())
+    sy = torch.sigmoid(y)
+    # ---------------- reverse sweep of U_dot = sum_i L2 . (sig(y_i) * yd_i)
+    ydb = sy * L2
+    yb = sy * (1 - sy) * yd * L2
+    grads = {}
+    ro = net.atomwisereadout.readout["energy"]
+    grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
+    grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
+    grads[id(ro[0].weight)] = yb.t().matmul(fw["r"]) + ydb.t().matmul(rd)
+    grads[id(ro[0].bias)] = yb.sum(0)
+    rdb, rb = ydb.matmul(L1), yb.matmul(L1)
+    d_b = torch.zeros_like(d)
+    dd_b = torch.zeros_like(d)
+    for conv, L in zip(reversed(list(net.convolutions)), reversed(fw["layers"])):
+        P = L["P"]
+        md_ = conv.moduledict
+        tb, tdb = rb.matmul(P["U2"]), rdb.matmul(P["U2"])
+        grads[id(md_["update_function"][2].weight)] = rb.t().matmul(L["t"]) + rdb.t().matmul(L["td"])
+        grads[id(md_["update_function"][2].bias)] = rb.sum(0)
+        su = L["su"]
+        udb = su * tdb
+        ub = su * (1 - su) * L["ud"] * tdb + su * tb
+        mdb, mb = udb.matmul(P["U1"]), ub.matmul(P["U1"])
+        grads[id(md_["update_function"][0].weight)] = udb.t().matmul(L["md"]) + ub.t().matmul(L["m"])
+        grads[id(md_["update_function"][0].bias)] = ub.sum(0)
+        hdb = ops._cfconv_agg(mdb, L["Wf"], topo)
+        hb = ops._cfconv_agg(mdb, L["Wfd"], topo) + ops._cfconv_agg(mb, L["Wf"], topo)
+        Wfb = ops._edge_prod(mb, L["h"], topo)
+        if L["hd"] is not None:
+            Wfb = Wfb + ops._edge_prod(mdb, L["hd"], topo)
+        Wfdb = ops._edge_prod(mdb, L["h"], topo)
+        gWn = hb.t().matmul(L["r"])
+        if L["rd"] is not None:
+            gWn = gWn + hdb.t().matmul(L["rd"])
+        grads[id(md_["message_node_filter"].weight)] = gWn
+        grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
+        rdb = rdb + hdb.matmul(P["Wn"])
+        rb = rb + hb.matmul(P["Wn"])
+        # filter network
+        sdb, sb = Wfdb.matmul(P["W2"]), Wfb.matmul(P["W2"])
+        grads[id(md_["message_edge_filter"][3].weight)] = _atb(Wfdb, L["sd"]) + _atb(Wfb, L["s"])
+        grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
+        sa = L["sa"]
+        adb = sa * sdb
+        ab = sa * (1 - sa) * L["ad"] * sdb + sa * sb
+        gdb, gb = adb.matmul(P["W1"]), ab.matmul(P["W1"])
+        grads[id(md_["message_edge_filter"][1].weight)] = _atb(adb, L["gd"]) + _atb(ab, L["g"])
+        grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
+        gphi = L["g"] * L["phi"]
+        gb = gb + gdb * L["phi"] * dd[:, None]
+        d_b += (gdb * L["g"] * (2 * P["c"]) * dd[:, None]).sum(1) + (gb * gphi).sum(1)
+        dd_b += (gdb * gphi).sum(1)
+    # geometry: dd = uhat . ddel, d = |delta|
+    delta_b = d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)
+    xb = ops._edge_scatter(delta_b, topo)
+    emb = torch.zeros_like(net.atom_embed.weight)
+    emb.index_add_(0, z, rb)
+    grads[id(net.atom_embed.weight)] = emb
+    # w.F = -U_dot
+    return fw["U"], F, -xb, [-grads[id(p)].reshape(p.shape) for p in net.parameters()]
