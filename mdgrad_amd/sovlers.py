@@ -170,6 +170,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
 
         T = ans[0].shape[0]
         need_time = ctx.needs_input_grad[n + 1]
+        if analytic and method == 'NH_verlet' and n == 3:
+            return _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params)
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
             adj_params = torch.zeros_like(flat_params)
@@ -202,6 +204,33 @@ class OdeintAdjointMethod(torch.autograd.Function):
             time_vjps.append(adj_time)
             time_vjps = torch.cat([x.reshape(-1) for x in time_vjps[::-1]])
             return (*adj_y, None, time_vjps, adj_params, None, None, None, None, None)
+
+
+def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
+    """The same sweep as OdeintAdjointMethod.backward + the backward branch of NHverlet_update
+    (sovlers.py:129-164, 253-288) for integrators that provide rhs_vjp: per interval the counter-only
+    call, two analytic augmented evaluations and the explicit-midpoint adjoint update, written with
+    the handful of tensor ops it needs instead of 8-tuple solver algebra."""
+    with torch.no_grad():
+        T = ans[0].shape[0]
+        lam = [g[-1].clone() for g in grad_output]
+        gth = torch.zeros_like(flat_params)
+        for i in range(T - 1, 0, -1):
+            h = t[i] - t[i - 1]
+            v, q, pv = ans[0][i], ans[1][i], ans[2][i]
+            func.update_topology(q)                                   # :258 (dL/dt call: counter / rebuild only)
+            (a, _, b), G0, _ = func.rhs_vjp((v, q, pv), lam)
+            hh = 0.5 * h
+            vh = v - a * hh                                           # :132  v + 1/2 (-a) h
+            qm = q + vh * h                                           # :138  forward-time sign (quirk)
+            pm = pv - b * hh                                          # :135
+            lam_h = [l + g * hh for l, g in zip(lam, G0)]             # :141-143
+            _, G1, th1 = func.rhs_vjp((vh, qm, pm), lam_h)
+            for k in range(3):
+                lam[k] = lam[k] + G1[k] * h + grad_output[k][i - 1]   # :156-158, :286
+            if th1:
+                gth = gth + _flatten(th1) * h                         # :160
+        return (*lam, None, None, gth, None, None, None, None, None)
 
 
 def _fused_spec_for(func, method):
