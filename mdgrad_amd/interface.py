@@ -209,7 +209,7 @@ class Stack(torch.nn.Module):
             dq = g if dq is None else dq + g
             for p, gp in zip(m.parameters(), gth):
                 by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp
-        return F, dq, [by_id.get(id(p), torch.zeros_like(p)) for p in self.parameters()]
+        return F, dq, [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
 
     def _reset_topology(self, x):
         for key in self.models.keys():

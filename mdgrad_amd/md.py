@@ -252,7 +252,8 @@ class NoseHooverChain(_EOM):
                                + 2 * p_v[:, 1:-1] * lp[:, 2:] / Q[1:-1])
             Gp[:, -1] = -lp[:, -2] * p_v[:, -2] / Q[-1]
         by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
-        return f_eval, (Gv, dwF_dq, Gp), [by_id.get(id(p), torch.zeros_like(p)) for p in self.parameters()]
+        return f_eval, (Gv, dwF_dq, Gp), [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p)
+                                         for p in self.parameters()]
 
     def force(self, q):
         """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to

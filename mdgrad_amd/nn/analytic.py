@@ -32,7 +32,7 @@ def _atb(a, b):
     """a^T b, tall-skinny aware."""
     if a.shape[0] >= ops.TALL_ROWS and a.is_cuda:
         return ops._atb(a, b)
-    return a.t().matmul(b)
+    return a.t().mm(b)
 
 
 def supported(net):
@@ -79,24 +79,24 @@ def _primal(net, z, x, topo, offsets):
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     y = torch.addmm(l1, r, L1.t())
-    U = (_ssp(y).matmul(L2.t()) + l2).sum()
+    U = (_ssp(y).mm(L2.t()) + l2).sum()
     return dict(d=d, uhat=uhat, layers=layers, r=r, y=y, L1=L1, L2=L2, U=U)
 
 
 @torch.no_grad()
 def _reverse_U(fw, topo):
     """dU/dd per edge -> force."""
-    rb = (torch.sigmoid(fw["y"]) * fw["L2"]).matmul(fw["L1"])
+    rb = (torch.sigmoid(fw["y"]) * fw["L2"]).mm(fw["L1"])
     d_b = torch.zeros_like(fw["d"])
     for L in reversed(fw["layers"]):
         P = L["P"]
-        ub = torch.sigmoid(L["u"]) * rb.matmul(P["U2"])
-        mb = ub.matmul(P["U1"])
+        ub = torch.sigmoid(L["u"]) * rb.mm(P["U2"])
+        mb = ub.mm(P["U1"])
         hb = ops._cfconv_agg(mb, L["Wf"], topo)
         Wfb = ops._edge_prod(mb, L["h"], topo)
-        rb = rb + hb.matmul(P["Wn"])
-        ab = torch.sigmoid(L["a"]) * Wfb.matmul(P["W2"])
-        d_b += (ab.matmul(P["W1"]) * L["g"] * L["phi"]).sum(1)
+        rb = rb + hb.mm(P["Wn"])
+        ab = torch.sigmoid(L["a"]) * Wfb.mm(P["W2"])
+        d_b += (ab.mm(P["W1"]) * L["g"] * L["phi"]).sum(1)
     return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
 
 
@@ -120,22 +120,22 @@ def force_vjp(net, z, x, w, topo, offsets):
     for L in fw["layers"]:
         P = L["P"]
         gd = L["g"] * L["phi"] * dd[:, None]
-        ad = gd.matmul(P["W1"].t())
+        ad = gd.mm(P["W1"].t())
         sa = torch.sigmoid(L["a"])
         sd = sa * ad
-        Wfd = sd.matmul(P["W2"].t())
+        Wfd = sd.mm(P["W2"].t())
         md = ops._cfconv_agg(L["h"], Wfd, topo)
         hd = None
         if rd is not None:
-            hd = rd.matmul(P["Wn"].t())
+            hd = rd.mm(P["Wn"].t())
             md = md + ops._cfconv_agg(hd, L["Wf"], topo)
         su = torch.sigmoid(L["u"])
-        ud = md.matmul(P["U1"].t())
+        ud = md.mm(P["U1"].t())
         td = su * ud
         L.update(gd=gd, ad=ad, sa=sa, sd=sd, Wfd=Wfd, hd=hd, md=md, su=su, ud=ud, td=td, rd=rd)
-        rd = td.matmul(P["U2"].t()) if rd is None else rd + td.matmul(P["U2"].t())
+        rd = td.mm(P["U2"].t()) if rd is None else rd + td.mm(P["U2"].t())
     L1, L2, y = fw["L1"], fw["L2"], fw["y"]
-    yd = rd.matmul(L1.t())
+    yd = rd.mm(L1.t())
     sy = torch.sigmoid(y)
     # ---------------- reverse sweep of U_dot = sum_i L2 . (sig(y_i) * yd_i)
     ydb = sy * L2
@@ -144,22 +144,22 @@ def force_vjp(net, z, x, w, topo, offsets):
     ro = net.atomwisereadout.readout["energy"]
     grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
     grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
-    grads[id(ro[0].weight)] = yb.t().matmul(fw["r"]) + ydb.t().matmul(rd)
+    grads[id(ro[0].weight)] = yb.t().mm(fw["r"]) + ydb.t().mm(rd)
     grads[id(ro[0].bias)] = yb.sum(0)
-    rdb, rb = ydb.matmul(L1), yb.matmul(L1)
+    rdb, rb = ydb.mm(L1), yb.mm(L1)
     d_b = torch.zeros_like(d)
     dd_b = torch.zeros_like(d)
     for conv, L in zip(reversed(list(net.convolutions)), reversed(fw["layers"])):
         P = L["P"]
         md_ = conv.moduledict
-        tb, tdb = rb.matmul(P["U2"]), rdb.matmul(P["U2"])
-        grads[id(md_["update_function"][2].weight)] = rb.t().matmul(L["t"]) + rdb.t().matmul(L["td"])
+        tb, tdb = rb.mm(P["U2"]), rdb.mm(P["U2"])
+        grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
         grads[id(md_["update_function"][2].bias)] = rb.sum(0)
         su = L["su"]
         udb = su * tdb
         ub = su * (1 - su) * L["ud"] * tdb + su * tb
-        mdb, mb = udb.matmul(P["U1"]), ub.matmul(P["U1"])
-        grads[id(md_["update_function"][0].weight)] = udb.t().matmul(L["md"]) + ub.t().matmul(L["m"])
+        mdb, mb = udb.mm(P["U1"]), ub.mm(P["U1"])
+        grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
         grads[id(md_["update_function"][0].bias)] = ub.sum(0)
         hdb = ops._cfconv_agg(mdb, L["Wf"], topo)
         hb = ops._cfconv_agg(mdb, L["Wfd"], topo) + ops._cfconv_agg(mb, L["Wf"], topo)
@@ -167,22 +167,26 @@ def force_vjp(net, z, x, w, topo, offsets):
         if L["hd"] is not None:
             Wfb = Wfb + ops._edge_prod(mdb, L["hd"], topo)
         Wfdb = ops._edge_prod(mdb, L["h"], topo)
-        gWn = hb.t().matmul(L["r"])
+        gWn = hb.t().mm(L["r"])
         if L["rd"] is not None:
-            gWn = gWn + hdb.t().matmul(L["rd"])
+            gWn = gWn + hdb.t().mm(L["rd"])
         grads[id(md_["message_node_filter"].weight)] = gWn
         grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
-        rdb = rdb + hdb.matmul(P["Wn"])
-        rb = rb + hb.matmul(P["Wn"])
+        rdb = rdb + hdb.mm(P["Wn"])
+        rb = rb + hb.mm(P["Wn"])
         # filter network
-        sdb, sb = Wfdb.matmul(P["W2"]), Wfb.matmul(P["W2"])
-        grads[id(md_["message_edge_filter"][3].weight)] = _atb(Wfdb, L["sd"]) + _atb(Wfb, L["s"])
+        E_ = Wfb.shape[0]
+        both = torch.cat((Wfdb, Wfb)).mm(P["W2"])                       # one GEMM for primal + tangent adjoints
+        sdb, sb = both[:E_], both[E_:]
+        grads[id(md_["message_edge_filter"][3].weight)] = _atb(torch.cat((Wfdb, Wfb)), torch.cat((L["sd"], L["s"])))
         grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
         sa = L["sa"]
         adb = sa * sdb
         ab = sa * (1 - sa) * L["ad"] * sdb + sa * sb
-        gdb, gb = adb.matmul(P["W1"]), ab.matmul(P["W1"])
-        grads[id(md_["message_edge_filter"][1].weight)] = _atb(adb, L["gd"]) + _atb(ab, L["g"])
+        both = torch.cat((adb, ab))
+        bg = both.mm(P["W1"])
+        gdb, gb = bg[:E_], bg[E_:]
+        grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
         grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
         gphi = L["g"] * L["phi"]
         gb = gb + gdb * L["phi"] * dd[:, None]
