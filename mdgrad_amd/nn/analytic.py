@@ -100,15 +100,45 @@ def _reverse_U(fw, topo):
     return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
 
 
+class _blas_for:
+    """The library GEMMs here are tiny next to their dispatch cost: rocBLAS ("hipblas") issues a GEMM in
+    ~7 us where the hipBLASLt default needs ~19 us (measured, tools/mmbench.py), but its kernels are up
+    to 3x slower on [E, .] operands with E ~ 1e5.  Pick per evaluation by edge count; restore on exit."""
+
+    def __init__(self, n_edges):
+        self.want = "hipblas" if n_edges < 65536 else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.want is not None and torch.cuda.is_available():
+            try:
+                self.prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library(self.want)
+            except Exception:
+                self.prev = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.backends.cuda.preferred_blas_library(self.prev)
+        return False
+
+
 @torch.no_grad()
 def force(net, z, x, topo, offsets):
-    fw = _primal(net, z, x.detach().contiguous(), topo, offsets)
-    return fw["U"], _reverse_U(fw, topo)
+    with _blas_for(topo.n_edges):
+        fw = _primal(net, z, x.detach().contiguous(), topo, offsets)
+        return fw["U"], _reverse_U(fw, topo)
 
 
 @torch.no_grad()
 def force_vjp(net, z, x, w, topo, offsets):
     """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()])."""
+    with _blas_for(topo.n_edges):
+        return _force_vjp(net, z, x, w, topo, offsets)
+
+
+def _force_vjp(net, z, x, w, topo, offsets):
     x, w = x.detach().contiguous(), w.detach().contiguous()
     fw = _primal(net, z, x, topo, offsets)
     F = _reverse_U(fw, topo)
