@@ -106,7 +106,7 @@ class _blas_for:
     to 3x slower on [E, .] operands with E ~ 1e5.  Pick per evaluation by edge count; restore on exit."""
 
     def __init__(self, n_edges):
-        self.want = "hipblas" if n_edges < 65536 else None
+        self.want = "hipblas" if n_edges < 24576 else None
         self.prev = None
 
     def __enter__(self):
