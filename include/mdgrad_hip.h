@@ -251,6 +251,24 @@ int mdg_cfconv_filter_bf16(const float* d, int64_t n_edges, const float* mu, con
                            int n_filters, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Fused elementwise / row-reduction pieces of the hand-derived SchNet passes (each replaces a chain of
+ * PyTorch elementwise ops; nff/nn/layers.py:14-31, nff/nn/activations.py:5-11 and their derivatives):
+ *   mdg_smear        g = exp(c_k (d - mu_k)^2), phi = 2 c_k (d - mu_k)              [E,G]
+ *   mdg_ssp          s = softplus(a) - ln 2 (, sa = sigmoid(a))
+ *   mdg_mul_row      o = x * y (* r[row])
+ *   mdg_ssp_dual_bwd xdb = sa sdb ; xb = sa (1 - sa) xd sdb + sa sb
+ *   mdg_smear_bwd    d_b[e] += sum_k (...), dd_b[e] += sum_k (...)   (see csrc/elem.hip)
+ */
+int mdg_smear(const float* d, const float* mu, const float* c, int64_t n_edges, int n_gauss, float* g, float* phi,
+              void* stream);
+int mdg_ssp(const float* a, int64_t n, float* s, float* sa, void* stream);
+int mdg_mul_row(const float* x, const float* y, const float* r, int64_t n_rows, int n_cols, float* o, void* stream);
+int mdg_ssp_dual_bwd(const float* sa, const float* xd, const float* sdb, const float* sb, int64_t n, float* xdb,
+                     float* xb, void* stream);
+int mdg_smear_bwd(const float* gdb, const float* gb, const float* g, const float* phi, const float* dd,
+                  const float* c, int64_t n_edges, int n_gauss, float* d_b, float* dd_b, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Tall-skinny contraction C[M,N] = A[E,M]^T B[E,N] (split-K on the f32 MFMA, ordered reduction):
  * the weight gradients of edge-wise Dense layers in the adjoint's parameter vjp (autograd of
  * nff/nn/layers.py:86-134 on [E, .] inputs).  workspace: mdg_atb_workspace() floats.

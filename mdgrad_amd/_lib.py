@@ -71,6 +71,11 @@ _SIGNATURES = {
     "mdg_edge_scatter": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_cfconv_agg": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_edge_prod": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P]),
+    "mdg_smear": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P, P]),
+    "mdg_ssp": (C.c_int, [P, C.c_int64, P, P, P]),
+    "mdg_mul_row": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P]),
+    "mdg_ssp_dual_bwd": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
+    "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),

@@ -65,16 +65,15 @@ def _primal(net, z, x, topo, offsets):
     layers = []
     for conv in net.convolutions:
         P = _layer_params(conv)
-        xm = d[:, None] - P["mu"]
-        g = torch.exp(P["c"] * xm.pow(2))
+        g, phi = ops.smear(d, P["mu"], P["c"])
         a = torch.addmm(P["b1"], g, P["W1"].t())
-        s = _ssp(a)
+        s, sa = ops.ssp(a, True)
         Wf = torch.addmm(P["b2"], s, P["W2"].t())
         h = torch.addmm(P["bn"], r, P["Wn"].t())
         m = ops._cfconv_agg(h, Wf, topo)
         u = torch.addmm(P["c1"], m, P["U1"].t())
-        t = _ssp(u)
-        layers.append(dict(P=P, r=r, phi=2 * P["c"] * xm, g=g, a=a, s=s, Wf=Wf, h=h, m=m, u=u, t=t))
+        t, su = ops.ssp(u, True)
+        layers.append(dict(P=P, r=r, phi=phi, g=g, a=a, s=s, sa=sa, Wf=Wf, h=h, m=m, u=u, t=t, su=su))
         r = r + torch.addmm(P["c2"], t, P["U2"].t())
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
@@ -90,13 +89,13 @@ def _reverse_U(fw, topo):
     d_b = torch.zeros_like(fw["d"])
     for L in reversed(fw["layers"]):
         P = L["P"]
-        ub = torch.sigmoid(L["u"]) * rb.mm(P["U2"])
+        ub = ops.mul_row(L["su"], rb.mm(P["U2"]))
         mb = ub.mm(P["U1"])
         hb = ops._cfconv_agg(mb, L["Wf"], topo)
         Wfb = ops._edge_prod(mb, L["h"], topo)
-        rb = rb + hb.mm(P["Wn"])
-        ab = torch.sigmoid(L["a"]) * Wfb.mm(P["W2"])
-        d_b += (ab.mm(P["W1"]) * L["g"] * L["phi"]).sum(1)
+        rb = torch.addmm(rb, hb, P["Wn"])
+        ab = ops.mul_row(L["sa"], Wfb.mm(P["W2"]))
+        ops.smear_bwd(None, ab.mm(P["W1"]), L["g"], L["phi"], None, P["c"], d_b, None)
     return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
 
 
@@ -149,19 +148,19 @@ def _force_vjp(net, z, x, w, topo, offsets):
     rd = None                                                     # r_dot^0 = 0
     for L in fw["layers"]:
         P = L["P"]
-        gd = L["g"] * L["phi"] * dd[:, None]
+        gd = ops.mul_row(L["g"], L["phi"], dd)
         ad = gd.mm(P["W1"].t())
-        sa = torch.sigmoid(L["a"])
-        sd = sa * ad
+        sa = L["sa"]
+        sd = ops.mul_row(sa, ad)
         Wfd = sd.mm(P["W2"].t())
         md = ops._cfconv_agg(L["h"], Wfd, topo)
         hd = None
         if rd is not None:
             hd = rd.mm(P["Wn"].t())
             md = md + ops._cfconv_agg(hd, L["Wf"], topo)
-        su = torch.sigmoid(L["u"])
+        su = L["su"]
         ud = md.mm(P["U1"].t())
-        td = su * ud
+        td = ops.mul_row(su, ud)
         L.update(gd=gd, ad=ad, sa=sa, sd=sd, Wfd=Wfd, hd=hd, md=md, su=su, ud=ud, td=td, rd=rd)
         rd = td.mm(P["U2"].t()) if rd is None else rd + td.mm(P["U2"].t())
     L1, L2, y = fw["L1"], fw["L2"], fw["y"]
@@ -185,9 +184,7 @@ def _force_vjp(net, z, x, w, topo, offsets):
         tb, tdb = rb.mm(P["U2"]), rdb.mm(P["U2"])
         grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
         grads[id(md_["update_function"][2].bias)] = rb.sum(0)
-        su = L["su"]
-        udb = su * tdb
-        ub = su * (1 - su) * L["ud"] * tdb + su * tb
+        udb, ub = ops.ssp_dual_bwd(L["su"], L["ud"], tdb, tb)
         mdb, mb = udb.mm(P["U1"]), ub.mm(P["U1"])
         grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
         grads[id(md_["update_function"][0].bias)] = ub.sum(0)
@@ -210,18 +207,13 @@ def _force_vjp(net, z, x, w, topo, offsets):
         sdb, sb = both[:E_], both[E_:]
         grads[id(md_["message_edge_filter"][3].weight)] = _atb(torch.cat((Wfdb, Wfb)), torch.cat((L["sd"], L["s"])))
         grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
-        sa = L["sa"]
-        adb = sa * sdb
-        ab = sa * (1 - sa) * L["ad"] * sdb + sa * sb
+        adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
         both = torch.cat((adb, ab))
         bg = both.mm(P["W1"])
         gdb, gb = bg[:E_], bg[E_:]
         grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
         grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
-        gphi = L["g"] * L["phi"]
-        gb = gb + gdb * L["phi"] * dd[:, None]
-        d_b += (gdb * L["g"] * (2 * P["c"]) * dd[:, None]).sum(1) + (gb * gphi).sum(1)
-        dd_b += (gdb * gphi).sum(1)
+        ops.smear_bwd(gdb, gb, L["g"], L["phi"], dd, P["c"], d_b, dd_b)
     # geometry: dd = uhat . ddel, d = |delta|
     delta_b = d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)
     xb = ops._edge_scatter(delta_b, topo)

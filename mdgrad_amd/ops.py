@@ -605,3 +605,49 @@ class CfconvFilterFn(torch.autograd.Function):
         if need[6]:
             gb2 = gW.sum(0)
         return gd, gmu, gwidth, gW1, gb1, gW2, gb2, None
+
+
+# ----------------------------------------------------------------------------- fused elementwise pieces
+def smear(d, mu, c):
+    lib = _lib.load()
+    E, G = d.shape[0], mu.shape[0]
+    g, phi = torch.empty(E, G, device=d.device), torch.empty(E, G, device=d.device)
+    check(lib.mdg_smear(ptr(d.contiguous()), ptr(mu.contiguous()), ptr(c.contiguous()), E, G, ptr(g), ptr(phi),
+                        stream_ptr(d.device)), "mdg_smear")
+    return g, phi
+
+
+def ssp(a, with_sigmoid=False):
+    lib = _lib.load()
+    a = a.contiguous()
+    s = torch.empty_like(a)
+    sa = torch.empty_like(a) if with_sigmoid else None
+    check(lib.mdg_ssp(ptr(a), a.numel(), ptr(s), ptr(sa), stream_ptr(a.device)), "mdg_ssp")
+    return (s, sa) if with_sigmoid else s
+
+
+def mul_row(x, y, r=None):
+    lib = _lib.load()
+    x, y = x.contiguous(), y.contiguous()
+    o = torch.empty_like(x)
+    check(lib.mdg_mul_row(ptr(x), ptr(y), ptr(r.contiguous()) if r is not None else None, x.shape[0], x.shape[1],
+                          ptr(o), stream_ptr(x.device)), "mdg_mul_row")
+    return o
+
+
+def ssp_dual_bwd(sa, xd, sdb, sb):
+    lib = _lib.load()
+    sa, xd, sdb, sb = sa.contiguous(), xd.contiguous(), sdb.contiguous(), sb.contiguous()
+    xdb, xb = torch.empty_like(sa), torch.empty_like(sa)
+    check(lib.mdg_ssp_dual_bwd(ptr(sa), ptr(xd), ptr(sdb), ptr(sb), sa.numel(), ptr(xdb), ptr(xb),
+                               stream_ptr(sa.device)), "mdg_ssp_dual_bwd")
+    return xdb, xb
+
+
+def smear_bwd(gdb, gb, g, phi, dd, c, d_b, dd_b):
+    """Accumulates into d_b (and dd_b when gdb is given) in place."""
+    lib = _lib.load()
+    gb = gb.contiguous()
+    gdb = gdb.contiguous() if gdb is not None else None
+    check(lib.mdg_smear_bwd(ptr(gdb), ptr(gb), ptr(g), ptr(phi), ptr(dd), ptr(c.contiguous()), g.shape[0], g.shape[1],
+                            ptr(d_b), ptr(dd_b), stream_ptr(g.device)), "mdg_smear_bwd")
