@@ -70,13 +70,103 @@ def cpu_baseline(frames, dt, budget_s=12.0):
                       "torch threads, %.1f s" % (n, frames - 1, nthreads, el)}
 
 
+def schnet_workload(args, rank, world, dev, mdist):
+    """Second headline (north_star: 4 096-bead SchNet water): CG-water Diamond 8^3 box, SchNet
+    A64/F128/G30/2 conv + ExcludedVolume prior, NoseHooverChain, R stacked replicas per GPU,
+    forward + RDF loss + analytic adjoint + grad all-reduce + Adam.  `--replicas` = replicas per GPU
+    (default 4 for this workload), `--frames` = saved frames."""
+    from mdgrad_amd import ops, potentials as P, units
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from mdgrad_amd.system import System, Diamond
+    R, T = args.replicas, args.frames
+    rng = np.random.default_rng(2000 + rank)
+    a = units.get_unit_len(0.997, 18.01528, 8)
+    size = 8
+    atoms = Diamond("O", (size,) * 3, a)
+    atoms.masses[:] = 18.01528
+    base = System(atoms, device=dev)
+    system = base.replicate(R) if R > 1 else base
+    L = a * size
+    system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.2, (len(system), 3)), L))
+    kT = 298.0 * units.kB
+    system.set_temperature(kT, rng=rng)
+    torch.manual_seed(0)
+    net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2, "cutoff": 6.0})
+    integ = NoseHooverChain(Stack({"gnn": GNNPotentials(system, net, cutoff=6.0),
+                                   "prior": PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)}),
+                            system, T=kT, num_chains=5, Q=50.0).to(dev)
+    obs = rdf(system, nbins=60, r_range=(2.0, 6.0))
+    target = torch.ones(60, device=dev)
+    t = torch.Tensor([units.fs * i for i in range(T)]).to(dev)
+    params = list(integ.parameters())
+    opt = torch.optim.Adam(params, lr=1e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y0 = tuple(integ.get_inital_states(wrap=True))
+        v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        loss = (obs(q_t[::5])[2] - target).pow(2).mean()
+        loss.backward()
+        mdist.all_reduce_grads(params)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    mdist.barrier()
+    el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    N = base.get_number_of_atoms()
+    md_steps = R * (T - 1) * world * args.steps
+    out = {"metric": "MD steps/sec (fwd+adjoint), 4096-bead SchNet CG water NHC", "value": md_steps / el,
+           "unit": "MD steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "CG water Diamond 8^3 (%d beads), SchNet A64 F128 G30 2 conv + ExcludedVolume prior, "
+                                  "cutoff 6, NoseHooverChain(Q=50, 5 chains), %d steps fwd + RDF(60 bins) loss + analytic "
+                                  "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
+                      "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
+    if rank == 0:
+        # roofline of the MFMA filter kernel (K9) at this workload's edge count
+        topo = integ.model.models["gnn"].inputs["_topo"]
+        E, G, F = topo.n_edges, 30, 128
+        conv = net.convolutions[0].moduledict["message_edge_filter"]
+        d = torch.rand(E, device=dev) * 6.0
+        fa = (d, conv[0].offsets, conv[0].width, conv[1].weight, conv[1].bias, conv[3].weight, conv[3].bias)
+        with torch.no_grad():
+            ops.CfconvFilterFn.apply(*fa)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                ops.CfconvFilterFn.apply(*fa)
+            e1.record()
+            torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        flop = 2.0 * E * G * (G + F)
+        out["roofline"] = {"bound": "mfma", "kernel": "cfconv_filter_kernel<32>", "achieved": flop / (ms * 1e-3) / 1e12,
+                           "peak": 157.3, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None,
+                           "kernel_ms": ms, "note": "f32-input MFMA (exact f32); E=%d edges; the kernel is co-limited "
+                                                    "by the HBM write of W[E,F] (%.0f GB/s)" % (E, 4.0 * E * F / ms / 1e6)}
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="lj108", choices=["lj108", "schnet4096"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=8192, help="replicas per GPU")
-    ap.add_argument("--frames", type=int, default=50, help="saved frames T (T-1 MD steps)")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 8192 for lj108, 4 for schnet4096)")
+    ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,6 +184,17 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU implementation)")
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if args.workload == "schnet4096":
+        args.replicas = 4 if args.replicas is None else args.replicas
+        args.frames = 11 if args.frames is None else args.frames
+        schnet_workload(args, rank, world, dev, mdist)
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            mdist.barrier()
+            tdist.destroy_process_group()
+        return
+    args.replicas = 8192 if args.replicas is None else args.replicas
+    args.frames = 50 if args.frames is None else args.frames
     R, T = args.replicas, args.frames
     atoms, pos, vel = make_inputs(R, 1000 + rank, dev)
     system = System(atoms, device=dev)
