@@ -91,11 +91,13 @@ def schnet_workload(args, rank, world, dev, mdist):
     base = System(atoms, device=dev)
     system = base.replicate(R) if R > 1 else base
     L = a * size
-    system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.2, (len(system), 3)), L))
+    system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.05, (len(system), 3)), L))
     kT = 298.0 * units.kB
     system.set_temperature(kT, rng=rng)
     torch.manual_seed(0)
     net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2, "cutoff": 6.0})
+    with torch.no_grad():        # random-init SchNet forces are O(100 eV/A): scale the readout so the synthetic
+        net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)   # dynamics stay stable (checked below)
     integ = NoseHooverChain(Stack({"gnn": GNNPotentials(system, net, cutoff=6.0),
                                    "prior": PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)}),
                             system, T=kT, num_chains=5, Q=50.0).to(dev)
@@ -113,7 +115,7 @@ def schnet_workload(args, rank, world, dev, mdist):
         loss.backward()
         mdist.all_reduce_grads(params)
         opt.step()
-        return loss
+        return loss, q_t
 
     for _ in range(args.warmup):
         step()
@@ -121,10 +123,12 @@ def schnet_workload(args, rank, world, dev, mdist):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss, q_last = step()
     torch.cuda.synchronize()
     mdist.barrier()
     el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    if not (bool(torch.isfinite(q_last).all()) and all(bool(torch.isfinite(p).all()) for p in params)):
+        raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     N = base.get_number_of_atoms()
     md_steps = R * (T - 1) * world * args.steps
     out = {"metric": "MD steps/sec (fwd+adjoint), 4096-bead SchNet CG water NHC", "value": md_steps / el,
@@ -219,6 +223,7 @@ def main():
         loss.backward()
         mdist.all_reduce_grads(params)           # the one collective per outer step
         opt.step()
+        step.last_q = q_t
         return loss
 
     for _ in range(args.warmup):
@@ -232,6 +237,8 @@ def main():
     mdist.barrier()
     el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
 
+    if not (bool(torch.isfinite(step.last_q).all()) and all(bool(torch.isfinite(p).all()) for p in params)):
+        raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     md_steps = R * (T - 1) * world * args.steps
     out = {"metric": "MD steps/sec (fwd+adjoint), 108-atom LJ NHC", "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
