@@ -28,6 +28,11 @@ def _ssp(x):
     return torch.nn.functional.softplus(x) - _LN2
 
 
+def _addmm(bias, x, wt):
+    """x @ wt + bias without the hipBLASLt epilogue path (see _blas_for)."""
+    return x.mm(wt).add_(bias)
+
+
 def _atb(a, b):
     """a^T b, tall-skinny aware."""
     if a.shape[0] >= ops.TALL_ROWS and a.is_cuda:
@@ -66,18 +71,18 @@ def _primal(net, z, x, topo, offsets):
     for conv in net.convolutions:
         P = _layer_params(conv)
         g, phi = ops.smear(d, P["mu"], P["c"])
-        a = torch.addmm(P["b1"], g, P["W1"].t())
+        a = _addmm(P["b1"], g, P["W1"].t())
         s, sa = ops.ssp(a, True)
-        Wf = torch.addmm(P["b2"], s, P["W2"].t())
-        h = torch.addmm(P["bn"], r, P["Wn"].t())
+        Wf = _addmm(P["b2"], s, P["W2"].t())
+        h = _addmm(P["bn"], r, P["Wn"].t())
         m = ops._cfconv_agg(h, Wf, topo)
-        u = torch.addmm(P["c1"], m, P["U1"].t())
+        u = _addmm(P["c1"], m, P["U1"].t())
         t, su = ops.ssp(u, True)
         layers.append(dict(P=P, r=r, phi=phi, g=g, a=a, s=s, sa=sa, Wf=Wf, h=h, m=m, u=u, t=t, su=su))
-        r = r + torch.addmm(P["c2"], t, P["U2"].t())
+        r = r + _addmm(P["c2"], t, P["U2"].t())
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
-    y = torch.addmm(l1, r, L1.t())
+    y = _addmm(l1, r, L1.t())
     U = (_ssp(y).mm(L2.t()) + l2).sum()
     return dict(d=d, uhat=uhat, layers=layers, r=r, y=y, L1=L1, L2=L2, U=U)
 
@@ -93,7 +98,7 @@ def _reverse_U(fw, topo):
         mb = ub.mm(P["U1"])
         hb = ops._cfconv_agg(mb, L["Wf"], topo)
         Wfb = ops._edge_prod(mb, L["h"], topo)
-        rb = torch.addmm(rb, hb, P["Wn"])
+        rb = rb + hb.mm(P["Wn"])
         ab = ops.mul_row(L["sa"], Wfb.mm(P["W2"]))
         ops.smear_bwd(None, ab.mm(P["W1"]), L["g"], L["phi"], None, P["c"], d_b, None)
     return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
@@ -105,7 +110,9 @@ class _blas_for:
     to 3x slower on [E, .] operands with E ~ 1e5.  Pick per evaluation by edge count; restore on exit."""
 
     def __init__(self, n_edges):
-        self.want = "hipblas" if n_edges < 24576 else None
+        # also for large E: the edge count changes at every neighbour rebuild, and hipBLASLt's
+        # per-shape heuristic lookup then costs ~1 ms per GEMM call (measured, tools/prof_fwd.py)
+        self.want = "hipblas"
         self.prev = None
 
     def __enter__(self):

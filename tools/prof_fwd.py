@@ -1,0 +1,27 @@
+import cProfile, pstats, io, sys, os, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdgrad_amd import potentials as P, units
+from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
+from mdgrad_amd.md import NoseHooverChain
+from mdgrad_amd.nn import get_model
+from mdgrad_amd.system import System, Diamond
+from mdgrad_amd.sovlers import odeint_adjoint
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dev="cuda:0"; rng=np.random.default_rng(0)
+a = units.get_unit_len(0.997, 18.01528, 8); size=4
+atoms = Diamond("O",(size,)*3,a); atoms.masses[:]=18.01528
+system=System(atoms,device=dev).replicate(R)
+system.set_positions(np.mod(system.get_positions()+rng.normal(0,0.05,(len(system),3)),a*size))
+kT=298*units.kB; system.set_temperature(kT,rng=rng)
+torch.manual_seed(0)
+net=get_model({"n_atom_basis":64,"n_filters":128,"n_gaussians":30,"n_convolutions":2,"cutoff":6.0})
+with torch.no_grad(): net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
+integ=NoseHooverChain(Stack({"gnn":GNNPotentials(system,net,cutoff=6.0),"prior":PairPotentials(system,P.ExcludedVolume(2.6,0.01,12),cutoff=6.0)}),system,T=kT,num_chains=5,Q=50.0).to(dev)
+t=torch.Tensor([units.fs*i for i in range(6)]).to(dev)
+def fwd():
+    y0=tuple(integ.get_inital_states(wrap=True)); torch.cuda.synchronize(); t0=time.perf_counter()
+    traj=odeint_adjoint(integ,y0,t,method="NH_verlet"); torch.cuda.synchronize(); return time.perf_counter()-t0
+for _ in range(3): print("fwd s", fwd())
+pr=cProfile.Profile(); pr.enable(); print("profiled", fwd()); pr.disable()
+s=io.StringIO(); pstats.Stats(pr,stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:4500])
