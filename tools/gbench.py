@@ -19,6 +19,9 @@ def run(integ, system, obs, nsteps, dt, method="NH_verlet", reps=3):
     dev = system.device
     t = torch.Tensor([dt * i for i in range(nsteps + 1)]).to(dev)
     out, samples = None, []
+    if os.environ.get("GBENCH_NOGC"):
+        import gc
+        gc.collect(); gc.freeze(); gc.disable()
     for rep in range(reps + 1):
         y0 = tuple(integ.get_inital_states(wrap=True))
         torch.cuda.synchronize()
@@ -33,6 +36,8 @@ def run(integ, system, obs, nsteps, dt, method="NH_verlet", reps=3):
         t2 = time.perf_counter()
         if not bool(torch.isfinite(traj[1]).all()):
             raise SystemExit("gbench: non-finite trajectory -- timing would be meaningless")
+        if os.environ.get("GBENCH_VERBOSE"):
+            print("   rep %d fwd %.4f bwd %.4f" % (rep, t1 - t0, t2 - t1), flush=True)
         if rep > 0:
             samples.append((t1 - t0, t2 - t1))
     samples.sort(key=lambda x: x[0] + x[1])

@@ -19,9 +19,16 @@ net=get_model({"n_atom_basis":64,"n_filters":128,"n_gaussians":30,"n_convolution
 with torch.no_grad(): net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
 integ=NoseHooverChain(Stack({"gnn":GNNPotentials(system,net,cutoff=6.0),"prior":PairPotentials(system,P.ExcludedVolume(2.6,0.01,12),cutoff=6.0)}),system,T=kT,num_chains=5,Q=50.0).to(dev)
 t=torch.Tensor([units.fs*i for i in range(6)]).to(dev)
+from mdgrad_amd.observable import rdf
+obs = rdf(system, nbins=60, r_range=(2.0, min(6.0, 0.49 * a * size)))
+BWD = len(sys.argv) > 2
 def fwd():
     y0=tuple(integ.get_inital_states(wrap=True)); torch.cuda.synchronize(); t0=time.perf_counter()
-    traj=odeint_adjoint(integ,y0,t,method="NH_verlet"); torch.cuda.synchronize(); return time.perf_counter()-t0
+    traj=odeint_adjoint(integ,y0,t,method="NH_verlet"); torch.cuda.synchronize(); dt=time.perf_counter()-t0
+    if BWD:
+        _, _, g = obs(traj[1][::5]); (g - 1).pow(2).mean().backward(); torch.cuda.synchronize()
+        print("   mem", torch.cuda.memory_allocated()>>20, torch.cuda.memory_reserved()>>20)
+    return dt
 for _ in range(3): print("fwd s", fwd())
 pr=cProfile.Profile(); pr.enable(); print("profiled", fwd()); pr.disable()
 s=io.StringIO(); pstats.Stats(pr,stream=s).sort_stats("tottime").print_stats(22); print(s.getvalue()[:4500])
