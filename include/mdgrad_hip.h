@@ -207,13 +207,18 @@ int mdg_rdf_fwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell
                 float cutoff, const uint8_t* mask, const float* mu /*[nbins]*/, float coeff,
                 int nbins, float* raw, float* partial, void* stream);
 /* same, with the caller's guarantee that mu is an equally spaced grid (mu_k = mu[0] + k*spacing, as
- * torch.linspace gives): enables the 8-bins-per-thread recurrence kernel when spacing*s <= 1. */
+ * torch.linspace gives): enables the recurrence kernels (one lane per pair with wave-private LDS
+ * histograms when there are >= 1024 frames, 8 bins per thread otherwise). */
 int mdg_rdf_fwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                         float cutoff, const uint8_t* mask, const float* mu, float spacing, float coeff,
                         int nbins, float* raw, float* partial, void* stream);
 int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                 float cutoff, const uint8_t* mask, const float* mu, float coeff, int nbins,
                 const float* g_raw, float* g_xyz, void* stream);
+/* backward with the same equally-spaced-centres guarantee (mdg_rdf_bwd makes no assumption on mu). */
+int mdg_rdf_bwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
+                        float cutoff, const uint8_t* mask, const float* mu, float spacing, float coeff,
+                        int nbins, const float* g_raw, float* g_xyz, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K10  graph gather/scatter for the SchNet continuous-filter convolution

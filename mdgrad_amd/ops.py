@@ -352,7 +352,7 @@ class RdfRawFn(torch.autograd.Function):
         check(lib.mdg_rdf_fwd_uniform(ptr(x3), F, N, C.byref(cell_struct), float(cutoff), ptr(mask), ptr(muc),
                                       float(spacing), float(coeff), B, ptr(raw), ptr(partial), stream_ptr(dev)),
               "mdg_rdf_fwd")
-        ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape)
+        ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape, float(spacing))
         ctx.save_for_backward(x3, muc)
         return raw
 
@@ -360,12 +360,12 @@ class RdfRawFn(torch.autograd.Function):
     def backward(ctx, g_raw):
         lib = _lib.load()
         x3, muc = ctx.saved_tensors
-        coeff, cutoff, cell_struct, mask, shape = ctx.args
+        coeff, cutoff, cell_struct, mask, shape, spacing = ctx.args
         F, N, B = x3.shape[0], x3.shape[1], muc.shape[0]
         gx = torch.empty_like(x3)
         gr = g_raw.detach().to(torch.float32).contiguous()
-        check(lib.mdg_rdf_bwd(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), coeff, B,
-                              ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
+        check(lib.mdg_rdf_bwd_uniform(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), spacing,
+                                      coeff, B, ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
         return gx.reshape(shape), None, None, None, None, None, None
 
 

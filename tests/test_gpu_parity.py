@@ -528,30 +528,49 @@ def test_rdf_bitwise_reproducible_and_nonuniform_edge_cases():
         close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "grad nb=%d" % nb)
 
 
-def test_rdf_backward_variants_agree():
-    """>= 1024 frames run the wave-per-frame tournament kernel, fewer frames the (frame, atom) gather
-    kernel: same gradients (and the tournament kernel is bitwise reproducible)."""
+def test_rdf_kernel_variants_agree():
+    """>= 1024 frames with equally spaced centres run the lane-per-pair forward and the wave-per-frame
+    tournament backward (both with the Gaussian recurrence); fewer frames the 8-bin-block forward and the
+    (frame, atom) gather backward; spacing 0 the direct kernels.  Same histogram and gradients, and the
+    many-frame kernels are bitwise reproducible."""
     from mdgrad_amd import ops, _lib
     g = load_golden("rdf")
     rng = np.random.default_rng(11)
     base = g["xyz"][0]
     frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), g["cell"]) for _ in range(1100)]).astype(np.float32)
     cs = _lib.make_cell(g["cell"])
-    mu = torch.linspace(0.75, 2.5, 100, device=DEV)
-    coeff = float(-0.5 / (mu[1] - mu[0]) ** 2)
     w = torch.linspace(-1, 1, 100, device=DEV)
+    for width_scale in (1.0, 1.6):                     # reach 7 and reach 12 kernels
+        mu = torch.linspace(0.75, 2.5, 100, device=DEV)
+        spacing = float(mu[1] - mu[0])
+        coeff = float(-0.5 / (width_scale * spacing) ** 2)
 
-    def grad_of(x):
-        x = T(x, DEV).requires_grad_(True)
-        raw = ops.RdfRawFn.apply(x, mu, coeff, 3.0, cs, None)
-        (gx,) = torch.autograd.grad((raw * w).sum(), x)
-        return raw.detach(), gx
+        def grad_of(x, sp):
+            x = T(x, DEV).requires_grad_(True)
+            raw = ops.RdfRawFn.apply(x, mu, coeff, 3.0, cs, None, sp)
+            (gx,) = torch.autograd.grad((raw * w).sum(), x)
+            return raw.detach(), gx
 
-    raw_all, g_all = grad_of(frames)
-    raw_b, g_all2 = grad_of(frames)
-    assert torch.equal(g_all, g_all2) and torch.equal(raw_all, raw_b)
-    g_chunks = torch.cat([grad_of(frames[k:k + 550])[1] for k in (0, 550)])
-    close(g_all, g_chunks, 1e-4, 1e-5 * float(g_chunks.abs().max()), "tournament vs gather rdf backward")
+        raw_all, g_all = grad_of(frames, spacing)
+        raw_b, g_all2 = grad_of(frames, spacing)
+        assert torch.equal(g_all, g_all2) and torch.equal(raw_all, raw_b)
+        parts = [grad_of(frames[k:k + 550], spacing) for k in (0, 550)]
+        raw_direct, g_direct = grad_of(frames, 0.0)
+        close(raw_all, raw_direct, 2e-5, 1e-6 * float(raw_direct.max()), "lane vs direct rdf forward")
+        close(raw_all, parts[0][0] + parts[1][0], 2e-5, 1e-6 * float(raw_direct.max()), "lane vs block8 rdf forward")
+        close(g_all, g_direct, 1e-4, 3e-5 * float(g_direct.abs().max()), "recurrence vs direct rdf backward")
+        close(g_all, torch.cat([p_[1] for p_ in parts]), 1e-4, 3e-5 * float(g_direct.abs().max()),
+              "tournament vs gather rdf backward")
+    # an odd atom count and a masked (species-selected) histogram through the lane kernel
+    sub = frames[:, :107]
+    mask = ops.build_mask(107, index_tuple=(list(range(0, 50)), list(range(50, 107))), device=DEV)
+    mu = torch.linspace(0.75, 2.5, 100, device=DEV)
+    spacing = float(mu[1] - mu[0])
+    coeff = float(-0.5 / spacing ** 2)
+    xs = T(sub, DEV)
+    a = ops.RdfRawFn.apply(xs, mu, coeff, 3.0, cs, mask, spacing)
+    b = ops.RdfRawFn.apply(xs, mu, coeff, 3.0, cs, mask, 0.0)
+    close(a, b, 2e-5, 1e-6 * float(b.max()), "masked lane vs direct")
 
 
 # ------------------------------------------------------------------ SURVEY 8f "next" rows
