@@ -21,6 +21,7 @@ constexpr int RDF_BLOCK = 512;
 constexpr int RDF_MAX_BLOCKS = 1024;     // persistent blocks: each strides over (frame, chunk) work items
 constexpr int RDF_CHUNK = 8192;          // candidate pairs per work item
 constexpr float LOG2E = 1.4426950408889634f;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // flat index c in [0, N(N-1)/2) -> (i, j), i < j, row-major (the order torch.nonzero yields)
 __device__ __forceinline__ void pair_from_flat(long long c, int N, int& i, int& j) {
@@ -221,8 +222,8 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_block8_kernel(
 // per pair.  Each lane owns a private column of a wave-private LDS histogram [rows][64], so a pair's
 // Gaussians are deposited with plain (conflict-free, order-fixed) LDS adds -- no bin-owner sweep, every
 // pair is looked at exactly once.  Only the 2R+1 bins around the nearest centre kc are touched: the
-// centre value and two outward recurrences (as in the block-of-8 kernel); beyond (R - 1/2) Ds >= 5.3 the
-// Gaussian is below 2^-28 of the peak, i.e. under fp32 rounding of the sums.  Real bin k lives in row
+// centre value and two outward recurrences (as in the block-of-8 kernel); the nearest bin left out is
+// (R + 1/2) Ds >= 5.3 away, where the Gaussian is below 2^-28 of the peak, i.e. under fp32 rounding of the sums.  Real bin k lives in row
 // k + 2R; rows outside [2R, 2R + nbins) are write-only padding so that no deposit needs a bounds test.
 // The columns are summed in a fixed order at the end => bitwise reproducible.
 template <bool DIAG, int R, bool MASKED>
@@ -276,32 +277,34 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             const float d2 = norm2_ref(dx, dy, dz);
             ok = valid && (d2 < rc2) && (d2 != 0.f);
             if constexpr (MASKED) ok = ok && mask[(size_t)i * N + j] != 0;   // unconditional load: no branch
-            d = sqrtf(d2);
+            d = __builtin_amdgcn_sqrtf(d2);            // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
             kc = (int)rintf((d - mu0) * inv_dmu);
             ok = ok && kc >= -R && kc <= nbins - 1 + R;
             kc = ok ? kc : 0;
             m = smu[kc + R];
         };
-        // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0
+        // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0.  The outward and
+        // inward recurrences run as one packed (v_pk_mul_f32 / v_pk_add_f32) chain.  Plain read-add-write
+        // on the lane-private column: ds_add_f32 is serialised per lane in the LDS atomic unit (measured
+        // 9x slower); prefetching the rows one stage earlier did not pay either (-4 %).
         auto deposit = [&](float d, float m, int kc, bool ok) {
             const float x0 = (d - m) * sc;
             const float a_ = ok ? 2.f * Ds * x0 : 0.f;
-            float eu = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f, ed = eu;
-            float ru = __builtin_amdgcn_exp2f(a_ - Ds2), rd = __builtin_amdgcn_exp2f(-a_ - Ds2);
+            const float e0 = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f;
+            f32x2 e = {e0, e0};
+            f32x2 r = {__builtin_amdgcn_exp2f(a_ - Ds2), __builtin_amdgcn_exp2f(-a_ - Ds2)};
+            const f32x2 cc = {c2, c2};
             float* h = hist + (size_t)(kc + R) * 64 + lane;      // row of bin kc - R
-            // plain read-add-write on the lane-private column (ds_add_f32 is serialised per lane in the
-            // LDS atomic unit: measured 9x slower than this)
-            float v[2 * R + 1];
+            float vc = h[R * 64];
+            f32x2 v[R];
 #pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) v[t] = h[t * 64];
-            v[R] += eu;
+            for (int s_ = 1; s_ <= R; ++s_) v[s_ - 1] = f32x2{h[(R + s_) * 64], h[(R - s_) * 64]};
+            vc += e0;
 #pragma unroll
-            for (int s_ = 1; s_ <= R; ++s_) {
-                eu *= ru; ru *= c2; v[R + s_] += eu;
-                ed *= rd; rd *= c2; v[R - s_] += ed;
-            }
+            for (int s_ = 1; s_ <= R; ++s_) { e *= r; r *= cc; v[s_ - 1] += e; }
+            h[R * 64] = vc;
 #pragma unroll
-            for (int t = 0; t <= 2 * R; ++t) h[t * 64] = v[t];
+            for (int s_ = 1; s_ <= R; ++s_) { h[(R + s_) * 64] = v[s_ - 1].x; h[(R - s_) * 64] = v[s_ - 1].y; }
         };
         {
             float ca[6], cb[6];
@@ -521,8 +524,9 @@ extern "C" int64_t mdg_rdf_partial_size(int n_frames, int n_atoms, int nbins) {
 
 // lane-per-pair kernel: reach R (bins) for the scaled spacing Ds, waves per workgroup that fit the LDS
 static int rdf_lane_reach(float spacing_s) {
-    if (spacing_s >= 0.82f) return 7;            // (R - 1/2) Ds >= 5.3
-    if (spacing_s >= 0.46f) return 12;
+    // the nearest uncovered bin is R + 1/2 spacings from the distance: (R + 1/2) Ds >= 5.3 => below 2^-28
+    if (spacing_s >= 0.82f) return 6;
+    if (spacing_s >= 0.465f) return 11;
     return 0;
 }
 static size_t rdf_lane_lds(int nw, int R, int n_atoms, int nbins) {
@@ -557,8 +561,8 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
             hipLaunchKernelGGL((rdf_fwd_lane_kernel<D, RR, false>), dim3(grid), dim3(64 * nw), lds, st, xyz, n_frames, \
                                n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);                      \
     } while (0)
-            if (cell->diag) { if (R == 7) MDG_RDF_LANE(true, 7); else MDG_RDF_LANE(true, 12); }
-            else            { if (R == 7) MDG_RDF_LANE(false, 7); else MDG_RDF_LANE(false, 12); }
+            if (cell->diag) { if (R == 6) MDG_RDF_LANE(true, 6); else MDG_RDF_LANE(true, 11); }
+            else            { if (R == 6) MDG_RDF_LANE(false, 6); else MDG_RDF_LANE(false, 11); }
 #undef MDG_RDF_LANE
             hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, grid * nw, nbins, raw);
             MDG_CHECK_LAUNCH("rdf_fwd_lane_kernel");
@@ -634,8 +638,8 @@ static int rdf_bwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
 #define MDG_RDF_BWD(D, RR)                                                                                        \
     hipLaunchKernelGGL((rdf_bwd_kernel<D, RR>), dim3(nblocks), dim3(64 * wpb), lds, st, xyz, n_frames, n_atoms, *cell, \
                        cutoff * cutoff, mask, mu, coeff, nbins, g_raw, g_xyz, uniform)
-    if (cell->diag) { if (R == 7) MDG_RDF_BWD(true, 7); else if (R == 12) MDG_RDF_BWD(true, 12); else MDG_RDF_BWD(true, 0); }
-    else            { if (R == 7) MDG_RDF_BWD(false, 7); else if (R == 12) MDG_RDF_BWD(false, 12); else MDG_RDF_BWD(false, 0); }
+    if (cell->diag) { if (R == 6) MDG_RDF_BWD(true, 6); else if (R == 11) MDG_RDF_BWD(true, 11); else MDG_RDF_BWD(true, 0); }
+    else            { if (R == 6) MDG_RDF_BWD(false, 6); else if (R == 11) MDG_RDF_BWD(false, 11); else MDG_RDF_BWD(false, 0); }
 #undef MDG_RDF_BWD
     MDG_CHECK_LAUNCH("rdf_bwd_kernel");
     return MDG_OK;
