@@ -61,6 +61,23 @@ __device__ __forceinline__ float norm2_ref(float x, float y, float z) {
     return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
 }
 
+// two-wide variants for the packed-math (v_pk_*_f32) pair loops
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 norm2_ref2(f32x2 x, f32x2 y, f32x2 z) {
+#pragma clang fp contract(off)
+    const f32x2 a = x * x;
+    const f32x2 b = y * y;
+    const f32x2 s = a + b;
+    const f32x2 c = z * z;
+    return s + c;
+}
+// orthorhombic minimum image of one component, two pairs at a time (see min_image)
+__device__ __forceinline__ f32x2 min_image_diag2(f32x2 d, float inv, float h) {
+    const f32x2 s = d * inv;
+    const f32x2 o = {__builtin_amdgcn_fmed3f(rintf(s.x), -1.f, 1.f), __builtin_amdgcn_fmed3f(rintf(s.y), -1.f, 1.f)};
+    return d - o * h;
+}
+
 // ----------------------------------------------------------------------------- pair forms
 __device__ __forceinline__ float ipow(float x, int n) {
     float r = 1.f;
@@ -100,6 +117,13 @@ __device__ __forceinline__ TermConst term_prepare(const MdgPairTerm& t, const fl
     return c;
 }
 
+// compile-time kind of the single-term kernels: MDG_PAIR_LJ with the exponents fixed to 12-6
+constexpr int KIND_LJ126 = 16;
+// trainable parameters per functional form (the theta slots pair_eval fills)
+__host__ __device__ constexpr int kind_ntheta(int kind) {
+    return kind == MDG_PAIR_MORSE ? 0 : (kind == MDG_PAIR_BUCK ? 3 : 2);
+}
+
 // phi and derivatives at squared distance d2.  r = d2 * rsq(d2), 1/r = rsq(d2) (v_rsq_f32, 1 ulp).
 // KIND >= 0 fixes the functional form at compile time (single-term specialisations);
 // KIND < 0 dispatches on tc.kind at run time.
@@ -107,15 +131,16 @@ template <int LEVEL, int KIND = -1>
 __device__ __forceinline__ void pair_eval(const TermConst& tc, float d2, float& r, float& ir, PairOut& o) {
     ir = __builtin_amdgcn_rsqf(d2);
     r = d2 * ir;
-    switch (KIND >= 0 ? KIND : tc.kind) {
+    constexpr bool F126 = KIND == KIND_LJ126;
+    switch (F126 ? MDG_PAIR_LJ : (KIND >= 0 ? KIND : tc.kind)) {
     case MDG_PAIR_LJ: {
         const float sig = tc.k0, eps = tc.k1, isig = tc.k2;
         const float s = sig * ir;
         float sp, sq;
-        if (tc.p == 12 && tc.q == 6) { const float s2 = s * s; sq = s2 * s2 * s2; sp = sq * sq; }
+        if (F126 || (tc.p == 12 && tc.q == 6)) { const float s2 = s * s; sq = s2 * s2 * s2; sp = sq * sq; }
         else { sp = ipow(s, tc.p); sq = ipow(s, tc.q); }
         sq *= tc.c;
-        const float fp = (float)tc.p, fq = (float)tc.q;
+        const float fp = F126 ? 12.f : (float)tc.p, fq = F126 ? 6.f : (float)tc.q;
         o.u = 4.f * eps * (sp - sq);
         if (LEVEL >= 1) {
             const float m1 = fq * sq - fp * sp;

@@ -34,6 +34,84 @@ constexpr int RED_FLOATS = 16 * (KMAX_ALL + 2);
 // The lane-group width TPA is a run-time power of two.
 #define KMAX (NT * MDG_MAX_THETA)
 
+// LJ 12-6 (times the q-term coefficient c), orthorhombic cell, no mask: two pairs per lane and iteration
+// in packed fp32 (v_pk_fma/mul/add_f32), written in even powers of 1/r only -- one v_rcp_f32 per pair, no
+// square root:   s2 = sig^2/d2, s6 = s2^3, s12 = s6^2
+//   phi'/r        = 4 eps (6 c s6 - 12 s12) / d2                                  =: c1
+//   phi''         = 4 eps (156 s12 - 42 c s6) / d2
+//   -H_ij w_ij    = -[(phi'' - phi'/r) (D.w_ij) D / d2 + (phi'/r) w_ij]           (D = x_j - x_i)
+//   d(w.F)/dsig  += 1/2 4 eps (36 c s6 - 144 s12) (D.w_ij) / (sig d2)
+//   d(w.F)/deps  += 2 (6 c s6 - 12 s12) (D.w_ij) / d2
+// (the same quantities force_all_pairs gets from pair_eval<LEVEL, MDG_PAIR_LJ> through r and 1/r).
+template <int LEVEL>
+__device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
+                                                   const float* __restrict__ w, float* __restrict__ f,
+                                                   float* __restrict__ dq, float& th_sig, float& th_eps) {
+    const int N = A.prm.n_atoms;
+    const int TPA = 1 << tpa_log2;
+    const int slots = blockDim.x >> tpa_log2;
+    const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
+    const TermConst t0 = term_prepare(A.terms.t[0], A.theta);
+    const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
+    const float e4_isig_half = 0.5f * e4 * t0.k2;
+    const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+    const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+    f32x2 ts = {0.f, 0.f}, te = {0.f, 0.f};
+    for (int i = slot; i < N; i += slots) {
+        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
+        for (int j = sub; j < N; j += 2 * TPA) {
+            const bool live2 = j + TPA < N;
+            const int j2 = live2 ? j + TPA : j;
+            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[N + j] - yi, q[N + j2] - yi},
+                  dz = {q[2 * N + j] - zi, q[2 * N + j2] - zi};                    // D = x_j - x_i
+            f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
+            if (LEVEL >= 2) {
+                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[N + j], wyi - w[N + j2]};
+                az = f32x2{wzi - w[2 * N + j], wzi - w[2 * N + j2]};
+            }
+            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);                         // topology.py:67
+            const bool ok1 = live2 && (d2.y != 0.f) && (d2.y < rc2);
+            const f32x2 sel = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
+            const f32x2 i2 = {__builtin_amdgcn_rcpf(ok0 ? d2.x : rc2), __builtin_amdgcn_rcpf(ok1 ? d2.y : rc2)};
+            const f32x2 s2 = sig2 * i2;
+            const f32x2 s6 = s2 * s2 * s2;
+            const f32x2 s12 = s6 * s6;
+            const f32x2 s6c = cq * s6;
+            const f32x2 i2s = i2 * sel;                       // rejected pairs contribute exactly zero
+            const f32x2 m1 = 6.f * s6c - 12.f * s12;
+            const f32x2 c1 = (e4 * m1) * i2s;
+            fx += c1 * dx; fy += c1 * dy; fz += c1 * dz;      // F_i += (phi'/r) D
+            if (LEVEL >= 2) {
+                const f32x2 b = dx * ax + dy * ay + dz * az;
+                const f32x2 bi = b * i2s;
+                const f32x2 d2u = (e4 * (156.f * s12 - 42.f * s6c)) * i2;
+                const f32x2 k2 = (d2u - c1) * bi;
+                gx -= k2 * dx + c1 * ax;
+                gy -= k2 * dy + c1 * ay;
+                gz -= k2 * dz + c1 * az;
+                ts += (e4_isig_half * (36.f * s6c - 144.f * s12)) * bi;
+                te += (2.f * m1) * bi;
+            }
+        }
+        float sx = group_sum_rt(fx.x + fx.y, TPA), sy = group_sum_rt(fy.x + fy.y, TPA), sz = group_sum_rt(fz.x + fz.y, TPA);
+        float ux = 0.f, uy = 0.f, uz = 0.f;
+        if (LEVEL >= 2) {
+            ux = group_sum_rt(gx.x + gx.y, TPA); uy = group_sum_rt(gy.x + gy.y, TPA); uz = group_sum_rt(gz.x + gz.y, TPA);
+        }
+        if (sub == 0) {
+            f[i] = sx; f[N + i] = sy; f[2 * N + i] = sz;
+            if (LEVEL >= 2) { dq[i] = ux; dq[N + i] = uy; dq[2 * N + i] = uz; }
+        }
+    }
+    th_sig += ts.x + ts.y;
+    th_eps += te.x + te.y;
+}
+
 // All-pairs force (LEVEL 1) or force + Hessian-vector product + parameter vjp (LEVEL 2).
 //   f   [3][N] <-  F = -dU/dq
 //   dq  [3][N] <-  d(w.F)/dq = -H w                      (LEVEL 2)
@@ -51,6 +129,54 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
 #pragma unroll
     for (int m = 0; m < NT; ++m)
         if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
+    if constexpr (KIND == KIND_LJ126) {
+        force_lj126_packed<LEVEL>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
+        return;
+    }
+    if constexpr (KIND >= 0) {
+        // single unmasked term of a fixed form: branch-free body (a rejected pair is evaluated at the
+        // cutoff and multiplied by zero), so the unrolled iterations interleave and every LDS operand of a
+        // pair is fetched in one round trip
+        constexpr int NTH = kind_ntheta(KIND == KIND_LJ126 ? MDG_PAIR_LJ : KIND);
+        const TermConst t0 = tc[0];
+        for (int i = slot; i < N; i += slots) {
+            const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+            float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+            if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+            float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 2
+            for (int j = sub; j < N; j += TPA) {
+                float dx = q[j] - xi, dy = q[N + j] - yi, dz = q[2 * N + j] - zi;   // D = x_j - x_i
+                float ax = 0.f, ay = 0.f, az = 0.f;
+                if (LEVEL >= 2) { ax = wxi - w[j]; ay = wyi - w[N + j]; az = wzi - w[2 * N + j]; }
+                min_image<DIAG>(A.cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                const bool ok = (d2 != 0.f) && (d2 < t0.rc2);                       // topology.py:67
+                PairOut o;
+                float r, ir;
+                pair_eval<LEVEL, KIND>(t0, ok ? d2 : t0.rc2, r, ir, o);
+                const float c1 = ok ? o.du * ir : 0.f;       // F_i += phi' * D / r   (rhat = -D/r)
+                fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+                if (LEVEL >= 2) {
+                    const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+                    const float a = rx * ax + ry * ay + rz * az;
+                    const float c2 = (ok ? o.d2u : 0.f) * a - c1 * a, c3 = c1;
+                    gx -= c2 * rx + c3 * ax;
+                    gy -= c2 * ry + c3 * ay;
+                    gz -= c2 * rz + c3 * az;
+#pragma unroll
+                    for (int k = 0; k < NTH; ++k) dth[k] -= 0.5f * (ok ? o.ddu_dth[k] : 0.f) * a;
+                }
+            }
+            fx = group_sum_rt(fx, TPA); fy = group_sum_rt(fy, TPA); fz = group_sum_rt(fz, TPA);
+            if (LEVEL >= 2) { gx = group_sum_rt(gx, TPA); gy = group_sum_rt(gy, TPA); gz = group_sum_rt(gz, TPA); }
+            if (sub == 0) {
+                f[i] = fx; f[N + i] = fy; f[2 * N + i] = fz;
+                if (LEVEL >= 2) { dq[i] = gx; dq[N + i] = gy; dq[2 * N + i] = gz; }
+            }
+        }
+        return;
+    }
     for (int i = slot; i < N; i += slots) {
         const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
@@ -107,6 +233,11 @@ __device__ __forceinline__ float bath_rhs(const TrajArgs& A, const float* Q, con
     return (pv[k - 1] * pv[k - 1] / Q[k - 1] - T) - pv[k + 1] * pv[k] / Q[k + 1];
 }
 
+// the 3N degrees of freedom of an SoA [3][N] array without div/mod: e = c * N + i
+#define MDG_FOR_DOF(e, i, c)    \
+    for (int c = 0; c < 3; ++c) \
+        for (int i = threadIdx.x, e = c * N + threadIdx.x; i < N; i += blockDim.x, e += blockDim.x)
+
 // AoS [N,3] global  <->  SoA [3][N] LDS
 __device__ __forceinline__ void load_soa(float* dst, const float* __restrict__ src, int N) {
     for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[(e % 3) * N + e / 3] = src[e];
@@ -158,16 +289,16 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         float ke = 0.f;
         if (nhc) {
             float part = 0.f;
-            for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
-                const float m = ms[e % N]; const float p = v[e] * m; part += p * p / m;
+            MDG_FOR_DOF(e, ia, ca) {
+                const float m = ms[ia]; const float p = v[e] * m; part += p * p / m;
             }
             ke = 0.5f * block_sum(part, red);
             if (threadIdx.x < C) pb[threadIdx.x] = bath_rhs(A, Qs, pv, ke, threadIdx.x);
         }
         const float pv0 = nhc ? pv[0] : 0.f;
         __syncthreads();
-        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
-            const float m = ms[e % N];
+        MDG_FOR_DOF(e, ia, ca) {
+            const float m = ms[ia];
             float a;
             if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p / Q0) / m; }
             else a = f[e];                                   // md.py:145-148 (no 1/m)
@@ -186,8 +317,8 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         float pvh0 = 0.f;
         if (nhc) {
             float part = 0.f;
-            for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
-                const float m = ms[e % N]; const float p = (v[e] + vh[e]) * m; part += p * p / m;
+            MDG_FOR_DOF(e, ia, ca) {
+                const float m = ms[ia]; const float p = (v[e] + vh[e]) * m; part += p * p / m;
             }
             ke = 0.5f * block_sum(part, red);       // (barriers inside also publish f)
             pvh0 = pvh[0];
@@ -198,8 +329,8 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         } else {
             __syncthreads();
         }
-        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
-            const float m = ms[e % N];
+        MDG_FOR_DOF(e, ia, ca) {
+            const float m = ms[ia];
             float a;
             if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p / Q0) / m; }
             else a = f[e];
@@ -226,7 +357,7 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
                                          float& slv) {
     const int N = A.prm.n_atoms;
-    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) w[e] = nhc ? lv[e] / ms[e % N] : lv[e];
+    MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] / ms[ia] : lv[e];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
@@ -237,8 +368,8 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
     for (int k = 0; k < KMAX; ++k) vals[k] = th[k];
     float p1 = 0.f, p2 = 0.f;
     if (nhc) {
-        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) {
-            const float m = ms[e % N]; const float p = v[e] * m;
+        MDG_FOR_DOF(e, ia, ca) {
+            const float m = ms[ia]; const float p = v[e] * m;
             p1 += p * p / m; p2 += lv[e] * v[e];
         }
     }
@@ -307,8 +438,8 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             const float pv0 = pv[0], lp0 = lp[0];
             if (tid < C) { pb[tid] = bath_rhs(A, Qs, pv, ke, tid); gp[tid] = bath_vjp(A, Qs, pv, lp, slv, tid); }
             __syncthreads();
-            for (int e = tid; e < N3; e += blockDim.x) {
-                const float m = ms[e % N], ve = v[e], p = ve * m;
+            MDG_FOR_DOF(e, ia, ca) {
+                const float m = ms[ia], ve = v[e], p = ve * m;
                 const float a = (f[e] - pv0 * p / Q0) / m;
                 const float Gv = -(pv0 / Q0) * lv[e] + lq[e] + 2.f * m * ve * lp0;
                 const float vhalf = 0.5f * (-a) * h;                  // sovlers.py:132
@@ -328,13 +459,13 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             const float pvm0 = pv[0], lpm0 = lph[0];
             if (tid < C) gp[tid] = bath_vjp(A, Qs, pv, lph, slv, tid);
             __syncthreads();
-            for (int e = tid; e < N3; e += blockDim.x) {
-                const float m = ms[e % N];
+            MDG_FOR_DOF(e, ia, ca) {
+                const float m = ms[ia];
                 const float Gv = -(pvm0 / Q0) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
                 float nlv = lv[e] + Gv * h;                          // :156
                 float nlq = lq[e] + dq[e] * h;                       // :157
-                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + (e % N) * 3 + e / N];   // :286
-                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
+                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + ia * 3 + ca];   // :286
+                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + ia * 3 + ca];
                 lv[e] = nlv; lq[e] = nlq;
             }
             if (tid < C) {
@@ -346,7 +477,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             for (int k = 0; k < KMAX; ++k) gth[k] += th[k] * h;     // :160
         } else {
             // verlet_update backward branch                          sovlers.py:42-101
-            for (int e = tid; e < N3; e += blockDim.x) {
+            MDG_FOR_DOF(e, ia, ca) {
                 const float dvv = -f[e];
                 const float vhalf = v[e] - 0.5f * dvv * h;           // :49-50
                 q[e] = q[e] - vhalf * h;                             // :51-52
@@ -360,11 +491,11 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             for (int k = 0; k < KMAX; ++k) gth[k] += (th[k] * 0.5f * h) * 2.f;   // :82,101
             __syncthreads();
             aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
-            for (int e = tid; e < N3; e += blockDim.x) {
+            MDG_FOR_DOF(e, ia, ca) {
                 float nlv = lvh[e];                                   // lv + dvad
                 float nlq = lqh[e] + dq[e] * h * 0.5f;                // :100
-                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
-                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + (e % N) * 3 + e / N];
+                if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + ia * 3 + ca];
+                if (A.g_q) nlq += A.g_q[(fr + i - 1) * N3 + ia * 3 + ca];
                 lv[e] = nlv; lq[e] = nlq;
             }
         }
@@ -403,9 +534,11 @@ int pick_block(const MdgTrajParams& p) {
 // (orthorhombic cell), everything else through the generic <NT = MDG_MAX_TERMS> kernel.
 #define MDG_TRAJ_DISPATCH(KERNEL)                                                                      \
     do {                                                                                               \
-        const bool single = terms->n_terms == 1 && diag;                                               \
+        const bool single = terms->n_terms == 1 && diag && !terms->t[0].mask;                          \
         const int kind = terms->t[0].kind;                                                             \
-        if (single && kind == MDG_PAIR_LJ)                                                             \
+        if (single && kind == MDG_PAIR_LJ && terms->t[0].p == 12 && terms->t[0].q == 6)                \
+            hipLaunchKernelGGL((KERNEL<true, 1, KIND_LJ126>), grid, dim3(block), lds, st, a, tl);      \
+        else if (single && kind == MDG_PAIR_LJ)                                                        \
             hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_LJ>), grid, dim3(block), lds, st, a, tl);     \
         else if (single && kind == MDG_PAIR_MORSE)                                                     \
             hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_MORSE>), grid, dim3(block), lds, st, a, tl);  \
