@@ -21,7 +21,6 @@ constexpr int RDF_BLOCK = 512;
 constexpr int RDF_MAX_BLOCKS = 1024;     // persistent blocks: each strides over (frame, chunk) work items
 constexpr int RDF_CHUNK = 8192;          // candidate pairs per work item
 constexpr float LOG2E = 1.4426950408889634f;
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // flat index c in [0, N(N-1)/2) -> (i, j), i < j, row-major (the order torch.nonzero yields)
 __device__ __forceinline__ void pair_from_flat(long long c, int N, int& i, int& j) {
@@ -242,6 +241,13 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
     const float inv_dmu = 1.f / dmu;
     const float Ds = dmu * sc, Ds2 = Ds * Ds;
     const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds2);
+    float Ks[R];                                               // K_s = c2^(s(s-1)/2), s = 1..R
+    {
+        float cp = 1.f;                                        // c2^(s-1)
+        Ks[0] = 1.f;
+#pragma unroll
+        for (int s_ = 1; s_ < R; ++s_) { cp *= c2; Ks[s_] = Ks[s_ - 1] * cp; }
+    }
     for (int k = threadIdx.x; k < nbins + 2 * R; k += blockDim.x) {
         const int kk = k - R;
         smu[k] = (kk >= 0 && kk < nbins) ? mu[kk] : fmaf((float)kk, dmu, mu0);
@@ -266,22 +272,41 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             int a_ = r + p; a_ = a_ >= M ? a_ - M : a_;
             int b_ = r - p; b_ = b_ < 0 ? b_ + M : b_;
             if (p == 0) { a_ = M; b_ = r; }
-            valid = live && a_ < N && b_ < N;            // a slot paired with the dummy of an odd N is idle
+            valid = live & (a_ < N) & (b_ < N);          // a slot paired with the dummy of an odd N is idle
             a_ = valid ? a_ : 0; b_ = valid ? b_ : 1;
             i = min(a_, b_); j = max(a_, b_);
             c[0] = px[j]; c[1] = px[i]; c[2] = px[N + j]; c[3] = px[N + i]; c[4] = px[2 * N + j]; c[5] = px[2 * N + i];
         };
-        auto locate = [&](const float (&c)[6], int i, int j, bool valid, float& d, float& m, int& kc, bool& ok) {
-            float dx = c[0] - c[1], dy = c[2] - c[3], dz = c[4] - c[5];
-            min_image<DIAG>(cell, dx, dy, dz);
-            const float d2 = norm2_ref(dx, dy, dz);
-            ok = valid && (d2 < rc2) && (d2 != 0.f);
-            if constexpr (MASKED) ok = ok && mask[(size_t)i * N + j] != 0;   // unconditional load: no branch
-            d = __builtin_amdgcn_sqrtf(d2);            // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
-            kc = (int)rintf((d - mu0) * inv_dmu);
-            ok = ok && kc >= -R && kc <= nbins - 1 + R;
-            kc = ok ? kc : 0;
-            m = smu[kc + R];
+        // distances of the two pairs of an iteration in packed fp32
+        auto locate2 = [&](const float (&ca)[6], const float (&cb)[6], int ia, int ja, int ib, int jb, bool va, bool vb) {
+            f32x2 dx = {ca[0] - ca[1], cb[0] - cb[1]}, dy = {ca[2] - ca[3], cb[2] - cb[3]},
+                  dz = {ca[4] - ca[5], cb[4] - cb[5]};
+            if constexpr (DIAG) {
+                dx = min_image_diag2(dx, cell.inv[0], cell.h[0]);
+                dy = min_image_diag2(dy, cell.inv[4], cell.h[4]);
+                dz = min_image_diag2(dz, cell.inv[8], cell.h[8]);
+            } else {
+                float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
+                min_image<false>(cell, ax_, ay_, az_);
+                min_image<false>(cell, bx_, by_, bz_);
+                dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
+            }
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            okA = va & (d2.x < rc2) & (d2.x != 0.f);                         // (bitwise: no short-circuit branches)
+            okB = vb & (d2.y < rc2) & (d2.y != 0.f);
+            if constexpr (MASKED) {                                          // unconditional loads: no branch
+                okA = okA & (mask[(size_t)ia * N + ja] != 0);
+                okB = okB & (mask[(size_t)ib * N + jb] != 0);
+            }
+            // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
+            const f32x2 d = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+            const f32x2 tk = (d - mu0) * inv_dmu;
+            kA = (int)rintf(tk.x); kB = (int)rintf(tk.y);
+            okA = okA & (kA >= -R) & (kA <= nbins - 1 + R);
+            okB = okB & (kB >= -R) & (kB <= nbins - 1 + R);
+            kA = okA ? kA : 0; kB = okB ? kB : 0;
+            dA = d.x; dB = d.y;
+            mA = smu[kA + R]; mB = smu[kB + R];
         };
         // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0.  The outward and
         // inward recurrences run as one packed (v_pk_mul_f32 / v_pk_add_f32) chain.  Plain read-add-write
@@ -291,9 +316,10 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             const float x0 = (d - m) * sc;
             const float a_ = ok ? 2.f * Ds * x0 : 0.f;
             const float e0 = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f;
-            f32x2 e = {e0, e0};
-            f32x2 r = {__builtin_amdgcn_exp2f(a_ - Ds2), __builtin_amdgcn_exp2f(-a_ - Ds2)};
-            const f32x2 cc = {c2, c2};
+            // e_{+-s} = e0 r^s c2^{s(s-1)/2} with r = exp2(+-2 Ds x0 - Ds^2) <= 1: P_s = e0 r^s by one packed
+            // multiply per step, the constant K_s = c2^{s(s-1)/2} folded into the accumulating fma
+            const f32x2 r = {__builtin_amdgcn_exp2f(a_ - Ds2), __builtin_amdgcn_exp2f(-a_ - Ds2)};
+            f32x2 P = {e0, e0};
             float* h = hist + (size_t)(kc + R) * 64 + lane;      // row of bin kc - R
             float vc = h[R * 64];
             f32x2 v[R];
@@ -301,7 +327,7 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             for (int s_ = 1; s_ <= R; ++s_) v[s_ - 1] = f32x2{h[(R + s_) * 64], h[(R - s_) * 64]};
             vc += e0;
 #pragma unroll
-            for (int s_ = 1; s_ <= R; ++s_) { e *= r; r *= cc; v[s_ - 1] += e; }
+            for (int s_ = 1; s_ <= R; ++s_) { P *= r; v[s_ - 1] += Ks[s_ - 1] * P; }
             h[R * 64] = vc;
 #pragma unroll
             for (int s_ = 1; s_ <= R; ++s_) { h[(R + s_) * 64] = v[s_ - 1].x; h[(R - s_) * 64] = v[s_ - 1].y; }
@@ -312,9 +338,11 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             bool va, vb;
             fetch(rA, pA, lane < total, ca, ia, ja, va);
             fetch(rB, pB, lane + 64 < total, cb, ib, jb, vb);
-            locate(ca, ia, ja, va, dA, mA, kA, okA);
-            locate(cb, ib, jb, vb, dB, mB, kB, okB);
+            locate2(ca, cb, ia, ja, ib, jb, va, vb);
         }
+        // (measured: the kernel is VALU-issue bound at one wave per SIMD -- pinning a latency-optimal
+        //  load/compute order with scheduling barriers, or prefetching the rows a stage early, is 4-7 % slower
+        //  than the compiler's own schedule)
         for (int q = lane; q < total; q += 128) {
             rA += adv_r; pA += adv_p; if (pA >= half) { pA -= half; ++rA; }
             rB += adv_r; pB += adv_p; if (pB >= half) { pB -= half; ++rB; }
@@ -325,8 +353,7 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             fetch(rB, pB, q + 192 < total, cb, ib, jb, vb);
             deposit(dA, mA, kA, okA);
             deposit(dB, mB, kB, okB);
-            locate(ca, ia, ja, va, dA, mA, kA, okA);
-            locate(cb, ib, jb, vb, dB, mB, kB, okB);
+            locate2(ca, cb, ia, ja, ib, jb, va, vb);
         }
     }
     // column sums in a fixed (lane-rotated) order; one partial histogram per wave
