@@ -40,6 +40,22 @@ def _atb(a, b):
     return a.t().mm(b)
 
 
+_CAT_EDGES = 65536
+_onehot_cache = {}
+
+
+def _species_onehot(z, n_types):
+    """[n_types, N] fp32 one-hot of the atomic numbers (cached per index tensor)."""
+    key = (z.data_ptr(), z.shape[0], n_types, z.device)
+    hit = _onehot_cache.get(key)
+    if hit is None or hit[0] is not z:
+        if len(_onehot_cache) > 16:
+            _onehot_cache.clear()
+        hit = (z, torch.nn.functional.one_hot(z, n_types).to(torch.float32).t().contiguous())
+        _onehot_cache[key] = hit
+    return hit[1]
+
+
 def supported(net):
     from .schnet import SchNet
     if not isinstance(net, SchNet) or list(net.atomwisereadout.readout.keys()) != ["energy"]:
@@ -210,22 +226,32 @@ def _force_vjp(net, z, x, w, topo, offsets):
         rb = rb + hb.mm(P["Wn"])
         # filter network
         E_ = Wfb.shape[0]
-        both = torch.cat((Wfdb, Wfb)).mm(P["W2"])                       # one GEMM for primal + tangent adjoints
-        sdb, sb = both[:E_], both[E_:]
-        grads[id(md_["message_edge_filter"][3].weight)] = _atb(torch.cat((Wfdb, Wfb)), torch.cat((L["sd"], L["s"])))
+        if E_ <= _CAT_EDGES:
+            # launch-bound sizes: primal + tangent adjoints stacked so that each pair of GEMMs is one
+            cat_w = torch.cat((Wfdb, Wfb))
+            both = cat_w.mm(P["W2"])
+            sdb, sb = both[:E_], both[E_:]
+            grads[id(md_["message_edge_filter"][3].weight)] = _atb(cat_w, torch.cat((L["sd"], L["s"])))
+            adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
+            both = torch.cat((adb, ab))
+            bg = both.mm(P["W1"])
+            gdb, gb = bg[:E_], bg[E_:]
+            grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
+        else:
+            # bandwidth-bound sizes: the [2E, F] copies would cost more than the launches they save
+            sdb, sb = Wfdb.mm(P["W2"]), Wfb.mm(P["W2"])
+            grads[id(md_["message_edge_filter"][3].weight)] = _atb(Wfdb, L["sd"]) + _atb(Wfb, L["s"])
+            adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
+            gdb, gb = adb.mm(P["W1"]), ab.mm(P["W1"])
+            grads[id(md_["message_edge_filter"][1].weight)] = _atb(adb, L["gd"]) + _atb(ab, L["g"])
         grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
-        adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
-        both = torch.cat((adb, ab))
-        bg = both.mm(P["W1"])
-        gdb, gb = bg[:E_], bg[E_:]
-        grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
         grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
         ops.smear_bwd(gdb, gb, L["g"], L["phi"], dd, P["c"], d_b, dd_b)
     # geometry: dd = uhat . ddel, d = |delta|
     delta_b = d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)
     xb = ops._edge_scatter(delta_b, topo)
-    emb = torch.zeros_like(net.atom_embed.weight)
-    emb.index_add_(0, z, rb)
-    grads[id(net.atom_embed.weight)] = emb
+    # embedding rows: one-hot(z)^T rb as a GEMM (no float atomics: index_add_ on a handful of species
+    # serialises and is not reproducible)
+    grads[id(net.atom_embed.weight)] = _species_onehot(z, net.atom_embed.weight.shape[0]).mm(rb)
     # w.F = -U_dot
     return fw["U"], F, -xb, [-grads[id(p)].reshape(p.shape) for p in net.parameters()]
