@@ -107,6 +107,13 @@ int mdg_nbr_half_count(const int32_t* col, const int32_t* cnt, int n_atoms, int 
 int mdg_nbr_half_fill(const int32_t* col, const int32_t* shift, const int32_t* cnt,
                       const int32_t* row_base, int n_atoms, int max_nbr,
                       int64_t* nbr, float* offsets, int32_t* edge_id, void* stream);
+/* Fixed-capacity variant for capture into HIP graphs (no host-side pair count): rows [P, capacity) hold
+ * the sentinel pair (-1,-1) -- mdg_edge_diff / mdg_edge_prod return 0 for them -- and the image flag
+ * (pad_offset,0,0); n_valid[0] <- min(P, capacity); need[0] <- max(need[0], P) when P > capacity. */
+int mdg_nbr_half_fill_padded(const int32_t* col, const int32_t* shift, const int32_t* cnt,
+                             const int32_t* row_base, int n_atoms, int max_nbr, int64_t capacity,
+                             float pad_offset, int64_t* nbr, float* offsets, int32_t* edge_id,
+                             int32_t* n_valid, int32_t* need, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K2-K4  pair energy / gradient / Hessian-vector product over an ELL list

@@ -22,7 +22,9 @@ __global__ void edge_diff_kernel(const float* __restrict__ x, const int64_t* __r
     if (t >= E * C) return;
     const long long e = t / C;
     const int c = (int)(t % C);
-    out[t] = x[nbr[2 * e] * C + c] - x[nbr[2 * e + 1] * C + c];
+    const long long i = nbr[2 * e];
+    // rows of a capacity-padded list (mdg_nbr_half_fill_padded) carry the sentinel -1: they yield 0
+    out[t] = i < 0 ? 0.f : x[i * C + c] - x[nbr[2 * e + 1] * C + c];
 }
 
 // one wave per atom, lanes over the feature dimension (looped)
@@ -74,7 +76,7 @@ __global__ void edge_prod_kernel(const float* __restrict__ a, const float* __res
     const long long e = t / F;
     const int f = (int)(t % F);
     const long long i = nbr[2 * e], j = nbr[2 * e + 1];
-    out[t] = a[i * F + f] * b[j * F + f] + a[j * F + f] * b[i * F + f];
+    out[t] = i < 0 ? 0.f : a[i * F + f] * b[j * F + f] + a[j * F + f] * b[i * F + f];   // (-1: padding row)
 }
 
 }  // namespace

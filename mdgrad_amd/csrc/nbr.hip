@@ -211,7 +211,7 @@ __global__ void half_count_kernel(const int32_t* __restrict__ col, const int32_t
 __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ shift,
                                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ row_base,
                                  int N, int max_nbr, int64_t* __restrict__ nbr, float* __restrict__ offsets,
-                                 int32_t* __restrict__ edge_id) {
+                                 int32_t* __restrict__ edge_id, long long capacity) {
     const int i = blockIdx.x;
     const int32_t* row = col + (size_t)i * max_nbr;
     const int n = cnt[i];
@@ -221,6 +221,10 @@ __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t*
         const int j = row[k];
         if (k >= fg) {
             const int e = base + (k - fg);
+            if (e >= capacity) {                              // padded list too small (flagged by half_pad_kernel):
+                if (edge_id) edge_id[(size_t)i * max_nbr + k] = 0;   // keep every edge id inside the buffers
+                continue;
+            }
             if (nbr) { nbr[2 * (size_t)e] = i; nbr[2 * (size_t)e + 1] = j; }
             if (offsets) {
                 const int code = shift[(size_t)i * max_nbr + k];
@@ -235,9 +239,26 @@ __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t*
             const int nj = cnt[j];
             const int fgj = first_greater(rj, nj, j);
             const int pos_i = first_greater(rj, nj, i - 1);        // index of i in row j
-            edge_id[(size_t)i * max_nbr + k] = row_base[j] + (pos_i - fgj);
+            const int er = row_base[j] + (pos_i - fgj);
+            edge_id[(size_t)i * max_nbr + k] = er < capacity ? er : 0;
         }
     }
+}
+
+// rows [P, capacity) of a fixed-capacity half list: sentinel pair (-1,-1) and an image flag that puts the
+// "distance" far outside any radial basis; P > capacity is reported through need[0] (atomic max).
+__global__ void half_pad_kernel(const int32_t* __restrict__ row_base, int N, long long capacity, float pad_offset,
+                                int64_t* __restrict__ nbr, float* __restrict__ offsets, int32_t* __restrict__ n_valid,
+                                int32_t* __restrict__ need) {
+    const long long P = row_base[N];
+    const long long e = P + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n_valid) *n_valid = (int32_t)(P < capacity ? P : capacity);
+        if (P > capacity && need) atomicMax(need, (int32_t)P);
+    }
+    if (e >= capacity) return;
+    nbr[2 * e] = -1; nbr[2 * e + 1] = -1;
+    offsets[3 * e] = pad_offset; offsets[3 * e + 1] = 0.f; offsets[3 * e + 2] = 0.f;
 }
 
 }  // namespace
@@ -330,7 +351,23 @@ extern "C" int mdg_nbr_half_fill(const int32_t* col, const int32_t* shift, const
                                  float* offsets, int32_t* edge_id, void* stream) {
     MDG_CHECK_ARG(col && shift && cnt && row_base && n_atoms > 0, "nbr_half_fill: bad arguments");
     hipLaunchKernelGGL(half_fill_kernel, dim3(n_atoms), dim3(64), 0, (hipStream_t)stream, col, shift, cnt,
-                       row_base, n_atoms, max_nbr, nbr, offsets, edge_id);
+                       row_base, n_atoms, max_nbr, nbr, offsets, edge_id, (long long)1 << 62);
     MDG_CHECK_LAUNCH("nbr_half_fill");
+    return MDG_OK;
+}
+
+extern "C" int mdg_nbr_half_fill_padded(const int32_t* col, const int32_t* shift, const int32_t* cnt,
+                                        const int32_t* row_base, int n_atoms, int max_nbr, int64_t capacity,
+                                        float pad_offset, int64_t* nbr, float* offsets, int32_t* edge_id,
+                                        int32_t* n_valid, int32_t* need, void* stream) {
+    MDG_CHECK_ARG(col && shift && cnt && row_base && nbr && offsets && n_atoms > 0 && capacity > 0,
+                  "nbr_half_fill_padded: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(half_fill_kernel, dim3(n_atoms), dim3(64), 0, st, col, shift, cnt, row_base, n_atoms,
+                       max_nbr, nbr, offsets, edge_id, (long long)capacity);
+    // the pad sweep covers the whole capacity (the pair count is only known on the device)
+    hipLaunchKernelGGL(half_pad_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, row_base,
+                       n_atoms, (long long)capacity, pad_offset, nbr, offsets, n_valid, need);
+    MDG_CHECK_LAUNCH("nbr_half_fill_padded");
     return MDG_OK;
 }

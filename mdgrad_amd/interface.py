@@ -21,6 +21,32 @@ class GeneralInteraction(torch.nn.Module):
         self.cell.requires_grad = True
         self._cell_struct = _lib.make_cell(system.get_cell())
         self._group = getattr(system, "group_size", system.get_number_of_atoms())
+        self._static = None          # fixed-capacity configuration (persistent once created)
+        self._static_on = False      # ... and whether _reset_topology uses it
+
+    # -- fixed-capacity neighbour lists (HIP-graph capture of the integrator steps, mdgrad_amd/graphs.py) --
+    def supports_static_topology(self):
+        return False
+
+    def static_overflow(self):
+        """True when a fixed-capacity rebuild since the last check did not fit (one host sync); the
+        capacities are enlarged so that the caller can redo the pass."""
+        st = self._static
+        if st is None:
+            return False
+        need = st["need"].tolist()
+        if need[0] <= st["max_nbr"] and need[1] <= st.get("capacity", 1 << 62):
+            return False
+        if need[0] > st["max_nbr"]:
+            st["max_nbr"] = min(self._group - 1, (int(need[0] * 1.25) + 15) // 8 * 8)
+        if need[1] > st.get("capacity", 1 << 62):
+            st["capacity"] = (int(need[1] * 1.25) + 1023) // 1024 * 1024
+        st["need"].zero_()
+        st["version"] += 1
+        return True
+
+    def static_version(self):
+        return -1 if self._static is None else self._static["version"]
 
 
 class _LazyTopology:
@@ -69,10 +95,29 @@ class GNNPotentials(GeneralInteraction):
         self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
 
     def _reset_topology(self, xyz):
-        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
-        topo = ops.GraphTopo(ell)
+        st = self._static if self._static_on else None
+        if st is not None:
+            ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, max_nbr=st["max_nbr"],
+                                group=self._group, need=st["need"])
+            topo = ops.StaticTopo(ell, st["capacity"], st["need"])
+        else:
+            ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
+            topo = ops.GraphTopo(ell)
         self.inputs['nbr_list'], self.inputs['offsets'] = topo.nbr, topo.offsets
         self.inputs['_topo'] = topo
+
+    def supports_static_topology(self):
+        return self.supports_force_vjp()
+
+    def set_static_topology(self, on=True):
+        """Fixed capacities (neighbours per atom, edges) sized from the current list with ~25 % head room."""
+        self._static_on = bool(on)
+        if on and self._static is None:
+            topo = self.inputs['_topo']
+            longest = int(topo.ell.cnt.max().item())
+            self._static = dict(max_nbr=min(self._group - 1, (int(longest * 1.25) + 15) // 8 * 8),
+                                capacity=(int(topo.n_edges * 1.25) + 1023) // 1024 * 1024,
+                                need=torch.zeros(2, dtype=torch.int32, device=self.device), version=0)
 
     def forward(self, xyz):
         results = self.gnn(self.inputs, xyz)
@@ -86,15 +131,19 @@ class GNNPotentials(GeneralInteraction):
         return self.analytic and analytic.supported(self.gnn) and not getattr(self.gnn, "cartesian_offsets", False)
 
     def _z(self):
-        return self.inputs['nxyz'][:, 0].long()
+        z = getattr(self, "_z_cache", None)
+        if z is None or z.shape[0] != self.inputs['nxyz'].shape[0]:
+            z = self._z_cache = self.inputs['nxyz'][:, 0].long()
+        return z
 
     def force(self, xyz):
         from .nn import analytic
         return analytic.force(self.gnn, self._z(), xyz, self.inputs['_topo'], self.inputs['offsets'])[1]
 
-    def force_vjp(self, xyz, w):
+    def force_vjp(self, xyz, w, want_theta=True):
         from .nn import analytic
-        _, F, dq, gth = analytic.force_vjp(self.gnn, self._z(), xyz, w, self.inputs['_topo'], self.inputs['offsets'])
+        _, F, dq, gth = analytic.force_vjp(self.gnn, self._z(), xyz, w, self.inputs['_topo'], self.inputs['offsets'],
+                                           want_theta=want_theta)
         return F, dq, gth
 
 
@@ -139,8 +188,23 @@ class PairPotentials(GeneralInteraction):
         return self._ell.half_list()[1]
 
     def _reset_topology(self, xyz):
-        self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
+        st = self._static if self._static_on else None
+        if st is not None:
+            self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask,
+                                      max_nbr=st["max_nbr"], group=self._group, need=st["need"])
+        else:
+            self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
         return _LazyTopology(self, xyz.detach())
+
+    def supports_static_topology(self):
+        return self.builtin()
+
+    def set_static_topology(self, on=True):
+        self._static_on = bool(on)
+        if on and self._static is None:
+            longest = int(self._ell.cnt.max().item())
+            self._static = dict(max_nbr=min(self._group - 1, (int(longest * 1.25) + 15) // 8 * 8),
+                                need=torch.zeros(2, dtype=torch.int32, device=self.device), version=0)
 
     # -- analytic-adjoint protocol (no autograd): used by the integrators' rhs_vjp ------------------
     def supports_force_vjp(self):
@@ -156,7 +220,7 @@ class PairPotentials(GeneralInteraction):
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True)
         return -o["grad"]
 
-    def force_vjp(self, xyz, w):
+    def force_vjp(self, xyz, w, want_theta=True):
         """(F, d(w.F)/dx, [d(w.F)/dtheta_p for p in parameters()]) -- what double autograd yields at
         torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term)."""
         theta, params = self._theta(xyz)
@@ -199,21 +263,39 @@ class Stack(torch.nn.Module):
             out = f if out is None else out + f
         return out
 
-    def force_vjp(self, x, w):
-        """Sum over members; the parameter gradients come back as a list aligned with self.parameters()."""
+    def force_vjp(self, x, w, want_theta=True):
+        """Sum over members; the parameter gradients come back as a list aligned with self.parameters()
+        (None when want_theta is False: the first augmented evaluation of an adjoint interval discards
+        them, sovlers.py:141-143)."""
         F = dq = None
         by_id = {}
         for m in self.models.values():
-            f, g, gth = m.force_vjp(x, w)
+            f, g, gth = m.force_vjp(x, w, want_theta=want_theta)
             F = f if F is None else F + f
             dq = g if dq is None else dq + g
-            for p, gp in zip(m.parameters(), gth):
-                by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp
+            if want_theta:
+                for p, gp in zip(m.parameters(), gth):
+                    by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp
+        if not want_theta:
+            return F, dq, None
         return F, dq, [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
 
     def _reset_topology(self, x):
         for key in self.models.keys():
             self.models[key]._reset_topology(x)
+
+    def supports_static_topology(self):
+        return all(getattr(m, "supports_static_topology", lambda: False)() for m in self.models.values())
+
+    def set_static_topology(self, on=True):
+        for m in self.models.values():
+            m.set_static_topology(on)
+
+    def static_overflow(self):
+        return any([m.static_overflow() for m in self.models.values()])     # (no short-circuit: all get enlarged)
+
+    def static_version(self):
+        return tuple(m.static_version() for m in self.models.values())
 
     def forward(self, x):
         result = None

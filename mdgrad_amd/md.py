@@ -218,7 +218,7 @@ class NoseHooverChain(_EOM):
     def supports_rhs_vjp(self):
         return getattr(self.model, "supports_force_vjp", lambda: False)()
 
-    def rhs_vjp(self, state, adj):
+    def rhs_vjp(self, state, adj, want_theta=True):
         """f(y) and adj^T df/d(y, theta) written out analytically: what
         augmented_dynamics gets from autograd at torchmd/sovlers.py:229-233, with the model's
         force / Hessian-vector product / parameter vjp coming from its force_vjp (HIP kernels, no
@@ -227,7 +227,7 @@ class NoseHooverChain(_EOM):
         lv, lq, lp = adj
         self.update_topology(q)
         m = self.mass[:, None]
-        F, dwF_dq, gth = self.model.force_vjp(q, lv / m)
+        F, dwF_dq, gth = self.model.force_vjp(q, lv / m, want_theta=want_theta)
         f_eval = self.rhs_from_force((v, q, p_v), F)
         Q = self.Q
         if p_v.dim() == 1:
@@ -251,6 +251,8 @@ class NoseHooverChain(_EOM):
                 Gp[:, 1:-1] = (-lp[:, :-2] * p_v[:, :-2] / Q[1:-1] - lp[:, 1:-1] * p_v[:, 2:] / Q[2:]
                                + 2 * p_v[:, 1:-1] * lp[:, 2:] / Q[1:-1])
             Gp[:, -1] = -lp[:, -2] * p_v[:, -2] / Q[-1]
+        if not want_theta:
+            return f_eval, (Gv, dwF_dq, Gp), None
         by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
         return f_eval, (Gv, dwF_dq, Gp), [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p)
                                          for p in self.parameters()]

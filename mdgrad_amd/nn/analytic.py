@@ -44,16 +44,18 @@ _CAT_EDGES = 65536
 _onehot_cache = {}
 
 
-def _species_onehot(z, n_types):
-    """[n_types, N] fp32 one-hot of the atomic numbers (cached per index tensor)."""
-    key = (z.data_ptr(), z.shape[0], n_types, z.device)
+def _species_onehot(z):
+    """(species present [S] int64, one-hot [N, S] fp32) of the atomic numbers, cached per index tensor
+    (one host sync for `unique` the first time)."""
+    key = (z.data_ptr(), z.shape[0], z.device)
     hit = _onehot_cache.get(key)
     if hit is None or hit[0] is not z:
         if len(_onehot_cache) > 16:
             _onehot_cache.clear()
-        hit = (z, torch.nn.functional.one_hot(z, n_types).to(torch.float32).t().contiguous())
+        uniq, inv = torch.unique(z, return_inverse=True)
+        hit = (z, uniq, torch.nn.functional.one_hot(inv, uniq.shape[0]).to(torch.float32).contiguous())
         _onehot_cache[key] = hit
-    return hit[1]
+    return hit[1], hit[2]
 
 
 def supported(net):
@@ -154,13 +156,14 @@ def force(net, z, x, topo, offsets):
 
 
 @torch.no_grad()
-def force_vjp(net, z, x, w, topo, offsets):
-    """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()])."""
+def force_vjp(net, z, x, w, topo, offsets, want_theta=True):
+    """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()]); the parameter part is skipped
+    (None) when want_theta is False."""
     with _blas_for(topo.n_edges):
-        return _force_vjp(net, z, x, w, topo, offsets)
+        return _force_vjp(net, z, x, w, topo, offsets, want_theta)
 
 
-def _force_vjp(net, z, x, w, topo, offsets):
+def _force_vjp(net, z, x, w, topo, offsets, want_theta=True):
     x, w = x.detach().contiguous(), w.detach().contiguous()
     fw = _primal(net, z, x, topo, offsets)
     F = _reverse_U(fw, topo)
@@ -194,10 +197,11 @@ def _force_vjp(net, z, x, w, topo, offsets):
     yb = sy * (1 - sy) * yd * L2
     grads = {}
     ro = net.atomwisereadout.readout["energy"]
-    grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
-    grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
-    grads[id(ro[0].weight)] = yb.t().mm(fw["r"]) + ydb.t().mm(rd)
-    grads[id(ro[0].bias)] = yb.sum(0)
+    if want_theta:
+        grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
+        grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
+        grads[id(ro[0].weight)] = yb.t().mm(fw["r"]) + ydb.t().mm(rd)
+        grads[id(ro[0].bias)] = yb.sum(0)
     rdb, rb = ydb.mm(L1), yb.mm(L1)
     d_b = torch.zeros_like(d)
     dd_b = torch.zeros_like(d)
@@ -205,23 +209,26 @@ def _force_vjp(net, z, x, w, topo, offsets):
         P = L["P"]
         md_ = conv.moduledict
         tb, tdb = rb.mm(P["U2"]), rdb.mm(P["U2"])
-        grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
-        grads[id(md_["update_function"][2].bias)] = rb.sum(0)
+        if want_theta:
+            grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
+            grads[id(md_["update_function"][2].bias)] = rb.sum(0)
         udb, ub = ops.ssp_dual_bwd(L["su"], L["ud"], tdb, tb)
         mdb, mb = udb.mm(P["U1"]), ub.mm(P["U1"])
-        grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
-        grads[id(md_["update_function"][0].bias)] = ub.sum(0)
+        if want_theta:
+            grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
+            grads[id(md_["update_function"][0].bias)] = ub.sum(0)
         hdb = ops._cfconv_agg(mdb, L["Wf"], topo)
         hb = ops._cfconv_agg(mdb, L["Wfd"], topo) + ops._cfconv_agg(mb, L["Wf"], topo)
         Wfb = ops._edge_prod(mb, L["h"], topo)
         if L["hd"] is not None:
             Wfb = Wfb + ops._edge_prod(mdb, L["hd"], topo)
         Wfdb = ops._edge_prod(mdb, L["h"], topo)
-        gWn = hb.t().mm(L["r"])
-        if L["rd"] is not None:
-            gWn = gWn + hdb.t().mm(L["rd"])
-        grads[id(md_["message_node_filter"].weight)] = gWn
-        grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
+        if want_theta:
+            gWn = hb.t().mm(L["r"])
+            if L["rd"] is not None:
+                gWn = gWn + hdb.t().mm(L["rd"])
+            grads[id(md_["message_node_filter"].weight)] = gWn
+            grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
         rdb = rdb + hdb.mm(P["Wn"])
         rb = rb + hb.mm(P["Wn"])
         # filter network
@@ -231,27 +238,35 @@ def _force_vjp(net, z, x, w, topo, offsets):
             cat_w = torch.cat((Wfdb, Wfb))
             both = cat_w.mm(P["W2"])
             sdb, sb = both[:E_], both[E_:]
-            grads[id(md_["message_edge_filter"][3].weight)] = _atb(cat_w, torch.cat((L["sd"], L["s"])))
             adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
             both = torch.cat((adb, ab))
             bg = both.mm(P["W1"])
             gdb, gb = bg[:E_], bg[E_:]
-            grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
+            if want_theta:
+                grads[id(md_["message_edge_filter"][3].weight)] = _atb(cat_w, torch.cat((L["sd"], L["s"])))
+                grads[id(md_["message_edge_filter"][1].weight)] = _atb(both, torch.cat((L["gd"], L["g"])))
         else:
             # bandwidth-bound sizes: the [2E, F] copies would cost more than the launches they save
             sdb, sb = Wfdb.mm(P["W2"]), Wfb.mm(P["W2"])
-            grads[id(md_["message_edge_filter"][3].weight)] = _atb(Wfdb, L["sd"]) + _atb(Wfb, L["s"])
             adb, ab = ops.ssp_dual_bwd(L["sa"], L["ad"], sdb, sb)
             gdb, gb = adb.mm(P["W1"]), ab.mm(P["W1"])
-            grads[id(md_["message_edge_filter"][1].weight)] = _atb(adb, L["gd"]) + _atb(ab, L["g"])
-        grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
-        grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
+            if want_theta:
+                grads[id(md_["message_edge_filter"][3].weight)] = _atb(Wfdb, L["sd"]) + _atb(Wfb, L["s"])
+                grads[id(md_["message_edge_filter"][1].weight)] = _atb(adb, L["gd"]) + _atb(ab, L["g"])
+        if want_theta:
+            grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
+            grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
         ops.smear_bwd(gdb, gb, L["g"], L["phi"], dd, P["c"], d_b, dd_b)
     # geometry: dd = uhat . ddel, d = |delta|
     delta_b = d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)
     xb = ops._edge_scatter(delta_b, topo)
+    if not want_theta:
+        return fw["U"], F, -xb, None
     # embedding rows: one-hot(z)^T rb as a GEMM (no float atomics: index_add_ on a handful of species
     # serialises and is not reproducible)
-    grads[id(net.atom_embed.weight)] = _species_onehot(z, net.atom_embed.weight.shape[0]).mm(rb)
+    uniq, onehot = _species_onehot(z)
+    emb = torch.zeros_like(net.atom_embed.weight)
+    emb[uniq] = _atb(onehot, rb)                  # [S, N] x [N, A] on the split-K kernel when N is large
+    grads[id(net.atom_embed.weight)] = emb
     # w.F = -U_dot
     return fw["U"], F, -xb, [-grads[id(p)].reshape(p.shape) for p in net.parameters()]

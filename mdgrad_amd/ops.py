@@ -76,6 +76,26 @@ class EllList:
             self._half = (nbr, off, eid)
         return self._half if with_edge_id else self._half[:2]
 
+    def half_list_padded(self, capacity, pad_offset, need):
+        """Fixed-capacity half list for HIP-graph capture (no host sync): (nbr [capacity,2] with (-1,-1)
+        padding rows, offsets [capacity,3] with (pad_offset,0,0) there, edge_id, n_valid int32[1]).
+        need: persistent int32 buffer, need[1] <- max(need[1], pairs) when the capacity is exceeded."""
+        lib = _lib.load()
+        dev = self.col.device
+        row_base = torch.empty(self.n_atoms + 1, dtype=torch.int32, device=dev)
+        st = stream_ptr(dev)
+        check(lib.mdg_nbr_half_count(ptr(self.col), ptr(self.cnt), self.n_atoms, self.max_nbr, ptr(row_base), st),
+              "mdg_nbr_half_count")
+        nbr = torch.empty(capacity, 2, dtype=torch.int64, device=dev)
+        off = torch.empty(capacity, 3, dtype=torch.float32, device=dev)
+        eid = torch.zeros(self.n_atoms, self.max_nbr, dtype=torch.int32, device=dev)
+        n_valid = torch.empty(1, dtype=torch.int32, device=dev)
+        check(lib.mdg_nbr_half_fill_padded(ptr(self.col), ptr(self.shift), ptr(self.cnt), ptr(row_base),
+                                           self.n_atoms, self.max_nbr, int(capacity), float(pad_offset), ptr(nbr),
+                                           ptr(off), ptr(eid), ptr(n_valid), C.c_void_p(need.data_ptr() + 4), st),
+              "mdg_nbr_half_fill_padded")
+        return nbr, off, eid, n_valid
+
 
 def _use_cell_list(n_atoms, cs, cutoff):
     if not cs.diag or n_atoms < 512:
@@ -83,10 +103,12 @@ def _use_cell_list(n_atoms, cs, cutoff):
     return all(cs.h[4 * d] / cutoff >= 3.0 for d in range(3))
 
 
-def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", group=None):
+def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", group=None, need=None):
     """Neighbour list of one frame xyz[N,3] (replaces generate_nbr_list).  method: auto|dense|cell.
     group: atoms per independent replica when xyz stacks several replicas of one system (pairs stay
-    inside a group; mask is [group, group])."""
+    inside a group; mask is [group, group]).
+    need: persistent int32[2] buffer => fixed-capacity mode for HIP-graph capture: one pass with the
+    given max_nbr, no host sync; need[0] <- max(need[0], longest row) when a row does not fit."""
     require_gpu(xyz, "xyz")
     lib = _lib.load()
     xyz = xyz.detach().contiguous()
@@ -98,10 +120,12 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
     use_cell = (not grouped) and (method == "cell" or (method == "auto" and _use_cell_list(N, cell_struct, cutoff)))
     st = stream_ptr(dev)
     while True:
+        if need is not None and max_nbr is None:
+            raise ValueError("build_ell: fixed-capacity mode needs max_nbr")
         col = torch.empty(N, cap, dtype=torch.int32, device=dev)
         shift = torch.empty(N, cap, dtype=torch.int32, device=dev)
         cnt = torch.empty(N, dtype=torch.int32, device=dev)
-        overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        overflow = torch.zeros(1, dtype=torch.int32, device=dev) if need is None else need
         if use_cell:
             ns = lib.mdg_nbr_cell_scratch(N, C.byref(cell_struct), cutoff)
             scratch = torch.empty(int(ns), dtype=torch.int32, device=dev)
@@ -112,8 +136,8 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
             check(lib.mdg_nbr_build_dense_groups(ptr(xyz), N, Ng, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
                                                  ptr(shift), ptr(cnt), cap, ptr(overflow), st),
                   "mdg_nbr_build_dense")
-        if cap >= Ng - 1:
-            break                                   # cannot overflow
+        if cap >= Ng - 1 or need is not None:
+            break                                   # cannot overflow / checked later by the caller
         need = int(overflow.item())
         if need <= cap:
             break
@@ -378,6 +402,19 @@ class GraphTopo:
         self.ell = ell
         self.nbr, self.offsets, self.eid = ell.half_list(with_edge_id=True)
         self.n_atoms, self.n_edges = ell.n_atoms, int(self.nbr.shape[0])
+
+
+class StaticTopo:
+    """GraphTopo with a fixed edge capacity (see EllList.half_list_padded): every edge-wise tensor has
+    `capacity` rows whatever the current pair count, so the whole evaluation can be captured into a
+    HIP graph and replayed after each neighbour rebuild."""
+
+    PAD_OFFSET = 1.0e4            # raw image flag of a padding row: |delta| = 1e4, every Gaussian is exactly 0
+
+    def __init__(self, ell, capacity, need):
+        self.ell = ell
+        self.nbr, self.offsets, self.eid, self.n_valid = ell.half_list_padded(capacity, self.PAD_OFFSET, need)
+        self.n_atoms, self.n_edges = ell.n_atoms, int(capacity)
 
 
 def _edge_diff(x, topo):

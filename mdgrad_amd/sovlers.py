@@ -15,7 +15,7 @@ Two execution paths behind the same odeint / odeint_adjoint API:
 import torch
 from torch import nn
 
-from . import ops
+from . import graphs, ops
 from .tinydiffeq import (FixedGridODESolver, RK4, _check_inputs, _flatten,
                          _flatten_convert_none_to_zeros)
 
@@ -84,6 +84,10 @@ class NHVerlet(FixedGridODESolver):
                 or getattr(func, "topology_update_freq", 0) != 1):
             return super().integrate(t)
         t = t.type_as(self.y0[0]).to(self.y0[0].device)
+        if graphs.enabled(func) and t.shape[0] > 3:
+            out = graphs.forward(func, tuple(self.y0), t)          # HIP-graph replay, one launch per step
+            if out is not None:
+                return out
         v, q, pv = self.y0
         frames = [(v, q, pv)]
         F = func.force(q)
@@ -213,13 +217,17 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
     the handful of tensor ops it needs instead of 8-tuple solver algebra."""
     with torch.no_grad():
         T = ans[0].shape[0]
+        if graphs.enabled(func) and T > 3:
+            out = graphs.adjoint(func, t, ans, grad_output, flat_params.numel())   # one graph launch per interval
+            if out is not None:
+                return (*out[0], None, None, out[1], None, None, None, None, None)
         lam = [g[-1].clone() for g in grad_output]
         gth = torch.zeros_like(flat_params)
         for i in range(T - 1, 0, -1):
             h = t[i] - t[i - 1]
             v, q, pv = ans[0][i], ans[1][i], ans[2][i]
             func.update_topology(q)                                   # :258 (dL/dt call: counter / rebuild only)
-            (a, _, b), G0, _ = func.rhs_vjp((v, q, pv), lam)
+            (a, _, b), G0, _ = func.rhs_vjp((v, q, pv), lam, want_theta=False)
             hh = 0.5 * h
             vh = v - a * hh                                           # :132  v + 1/2 (-a) h
             qm = q + vh * h                                           # :138  forward-time sign (quirk)

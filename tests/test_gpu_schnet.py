@@ -282,3 +282,65 @@ def test_analytic_schnet_passes_golden_and_autograd(name):
     close(dq, ga[0], 1e-3, 1e-4 * float(ga[0].abs().max()), "analytic vs autograd d(w.F)/dq")
     fa = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(ga[1:], plist)])
     close(flat, fa, 1e-3, 1e-4 * float(fa.abs().max()), "analytic vs autograd d(w.F)/dtheta")
+
+
+def _traj_and_grads(integ, system, t, frames_stride=1):
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    for p in integ.parameters():
+        p.grad = None
+    y0 = tuple(integ.get_inital_states(wrap=True))
+    v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+    obs = rdf(system, nbins=40, r_range=(2.0, 5.5))
+    (obs(q_t[::frames_stride])[2].pow(2).mean() + 1e-3 * v_t[-1].pow(2).mean() + 1e-3 * pv_t[-1].pow(2).sum()).backward()
+    gth = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
+    return v_t.detach(), q_t.detach(), pv_t.detach(), gth
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("replicas", [1, 3])
+def test_hip_graph_replay_equals_eager(replicas):
+    """mdgrad_amd/graphs.py: forward steps and adjoint intervals replayed from captured HIP graphs (padded
+    fixed-capacity neighbour lists) give the eager path's trajectory and gradients; a second pass reuses
+    the graphs; too small a capacity is detected and the pass falls back to the eager path."""
+    from mdgrad_amd import graphs
+    g = load_golden("gnn_traj")
+    base = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    system = base
+    if replicas > 1:
+        rng = np.random.default_rng(2)
+        system = base.replicate(replicas)
+        system.set_positions(np.concatenate([np.mod(g["pos"] + rng.normal(0, 0.05, g["pos"].shape), g["cell"])
+                                             for _ in range(replicas)]))
+        system.set_velocities(np.concatenate([g["vel"] * (1 + 0.1 * r) for r in range(replicas)]))
+    t = torch.Tensor([float(g["dt"]) * i for i in range(7)]).to(DEV)
+    integ = _gnn_integrator(g, system)
+    assert graphs.enabled(integ)
+    integ.use_graphs = False
+    ref = _traj_and_grads(integ, system, t)
+    integ.use_graphs = True
+    out = _traj_and_grads(integ, system, t)
+    assert len(integ._graph_cache) == 2, "forward and adjoint graphs captured"
+    for a, b, name in zip(out, ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "graph vs eager " + name)
+    cached = dict(integ._graph_cache)
+    out2 = _traj_and_grads(integ, system, t)
+    assert all(integ._graph_cache[k] is v for k, v in cached.items()), "graphs reused"
+    for a, b in zip(out2, out):
+        assert torch.equal(a, b), "replay is reproducible"
+    # exact-size lists again outside the graphed passes (the autograd path must not see padding rows)
+    gnn = integ.model.models["gnn"]
+    assert not gnn._static_on and int(gnn.inputs["nbr_list"].min()) >= 0
+    # capacity overflow: shrink the edge capacity below the current pair count
+    gnn._static["capacity"] = 256
+    gnn._static["version"] += 1
+    out3 = _traj_and_grads(integ, system, t)
+    # (the forward pass overflowed, fell back to the eager loop and dropped its graph; the adjoint pass
+    #  that followed captured a new graph with the enlarged capacity)
+    assert gnn._static["capacity"] > 256 and [k[0] for k in integ._graph_cache] == ["adj"]
+    for a, b, name in zip(out3, ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "overflow fallback " + name)
+    out4 = _traj_and_grads(integ, system, t)                    # re-captured with the enlarged capacity
+    assert len(integ._graph_cache) == 2
+    for a, b, name in zip(out4, ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "after regrow " + name)
