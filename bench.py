@@ -169,7 +169,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 8192 for lj108, 4 for schnet4096)")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 8192 for lj108, 8 for schnet4096)")
     ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
@@ -189,7 +189,7 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if args.workload == "schnet4096":
-        args.replicas = 4 if args.replicas is None else args.replicas
+        args.replicas = 8 if args.replicas is None else args.replicas
         args.frames = 11 if args.frames is None else args.frames
         schnet_workload(args, rank, world, dev, mdist)
         import torch.distributed as tdist
