@@ -289,6 +289,21 @@ int64_t mdg_atb_workspace(int64_t n_rows, int m, int n);
 int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float* C, float* workspace,
             void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Nose-Hoover-chain algebra of the generic (non-fused) integrator path as single launches
+ * (replaces the elementwise/reduction ops of NoseHooverChain.forward after the force,
+ *  torchmd/md.py:221-240, and the thermostat part of its vjp).
+ * State of R stacked replicas: v, f, lv, lq [R*n, 3]; pv, lp [R, C]; mass [R*n]; Q [C].
+ *   mdg_nhc_rhs:  a = (f - pv0 m v / Q0) / m ;  dpv = bath right-hand side (KE per replica)
+ *   mdg_nhc_vjp:  Gv = -(pv0/Q0) lv + lq + 2 m v lp0 ;  Gp = lam^T d(bath rhs)/d pv - (lv.v)/Q0 e0
+ */
+int mdg_nhc_rhs(const float* v, const float* f, const float* pv, const float* mass, const float* Q,
+                float T, float n_dof, int n_rep, int n_atoms, int n_chains, float* a, float* dpv,
+                void* stream);
+int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, const float* lq, const float* lp,
+                const float* mass, const float* Q, int n_rep, int n_atoms, int n_chains, float* Gv,
+                float* Gp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -230,7 +230,9 @@ class NoseHooverChain(_EOM):
         F, dwF_dq, gth = self.model.force_vjp(q, lv / m, want_theta=want_theta)
         f_eval = self.rhs_from_force((v, q, p_v), F)
         Q = self.Q
-        if p_v.dim() == 1:
+        if self._hip_algebra(v, lv, lq, lp, p_v):
+            Gv, Gp = ops.nhc_vjp(v, p_v, lv, lq, lp, self.mass, Q, self.n_rep, self.n_group)
+        elif p_v.dim() == 1:
             pv0, lp0, slv = p_v[0], lp[0], (lv * v).sum()
             Gv = -(pv0 / Q[0]) * lv + lq + 2 * m * v * lp0
             Gp = torch.zeros_like(p_v)
@@ -271,10 +273,22 @@ class NoseHooverChain(_EOM):
             (g,) = torch.autograd.grad(u.sum(), q)
         return -g
 
+    def _hip_algebra(self, *tensors):
+        """The single-launch thermostat kernels (csrc/nhc.hip) apply to fp32 device states outside
+        autograd (the analytic-adjoint and graph-replay paths); autograd callers keep the torch ops."""
+        if getattr(self, "hip_algebra", True) is False or self.dim != 3:
+            return False
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in tensors):
+            return False
+        return not (torch.is_grad_enabled() and any(t.requires_grad for t in tensors))
+
     def rhs_from_force(self, state, f):
         """md.py:221-240 given F(q).  With R stacked replicas p_v is [R, C] and every replica has its
         own kinetic energy / friction (identical arithmetic per replica)."""
         v, q, p_v = state
+        if self._hip_algebra(v, f, p_v):
+            a, dpv = ops.nhc_rhs(v, f, p_v, self.mass, self.Q, float(self.T), self.N_dof, self.n_rep, self.n_group)
+            return (a, v, dpv)
         p = v * self.mass[:, None]
         if p_v.dim() == 1:
             sys_ke = 0.5 * (p.pow(2) / self.mass[:, None]).sum()

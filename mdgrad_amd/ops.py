@@ -393,6 +393,31 @@ class RdfRawFn(torch.autograd.Function):
         return gx.reshape(shape), None, None, None, None, None, None
 
 
+# ----------------------------------------------------------------------------- thermostat algebra
+def nhc_rhs(v, f, pv, mass, Q, T, n_dof, n_rep, n_group):
+    """(a, dpv) of NoseHooverChain.forward given the force (torchmd/md.py:221-240), one launch."""
+    lib = _lib.load()
+    for t_, nm in ((v, "v"), (f, "f"), (pv, "p_v")):
+        require_gpu(t_, nm)
+    v, f, pv = v.contiguous(), f.contiguous(), pv.contiguous()
+    a, dpv = torch.empty_like(v), torch.empty_like(pv)
+    check(lib.mdg_nhc_rhs(ptr(v), ptr(f), ptr(pv), ptr(mass), ptr(Q), float(T), float(n_dof), int(n_rep),
+                          int(n_group), int(pv.shape[-1]), ptr(a), ptr(dpv), stream_ptr(v.device)), "mdg_nhc_rhs")
+    return a, dpv
+
+
+def nhc_vjp(v, pv, lv, lq, lp, mass, Q, n_rep, n_group):
+    """(Gv, Gp): thermostat part of the vjp of the NHC right-hand side, one launch."""
+    lib = _lib.load()
+    for t_, nm in ((v, "v"), (lv, "lv"), (lq, "lq")):
+        require_gpu(t_, nm)
+    v, pv, lv, lq, lp = v.contiguous(), pv.contiguous(), lv.contiguous(), lq.contiguous(), lp.contiguous()
+    Gv, Gp = torch.empty_like(v), torch.empty_like(pv)
+    check(lib.mdg_nhc_vjp(ptr(v), ptr(pv), ptr(lv), ptr(lq), ptr(lp), ptr(mass), ptr(Q), int(n_rep), int(n_group),
+                          int(pv.shape[-1]), ptr(Gv), ptr(Gp), stream_ptr(v.device)), "mdg_nhc_vjp")
+    return Gv, Gp
+
+
 # ----------------------------------------------------------------------------- graph ops (SchNet)
 class GraphTopo:
     """Edge topology for the message-passing kernels: ELL list + undirected edge ids + the

@@ -573,6 +573,37 @@ def test_rdf_kernel_variants_agree():
     close(a, b, 2e-5, 1e-6 * float(b.max()), "masked lane vs direct")
 
 
+@pytest.mark.parametrize("replicas,chains", [(1, 5), (3, 2), (4, 3)])
+def test_nhc_algebra_kernels_match_torch_ops(replicas, chains):
+    """mdg_nhc_rhs / mdg_nhc_vjp (one launch each) against the torch-op restatement of md.py:221-240 and of
+    the thermostat vjp, single and replica-stacked states."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    g = load_golden("nhc_traj_lj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    if replicas > 1:
+        system = system.replicate(replicas)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=2.5)}), system,
+                            T=1.3, num_chains=chains, Q=7.0).to(DEV)
+    gen = torch.Generator(device="cpu").manual_seed(replicas * 10 + chains)
+    N = len(system)
+    shape_pv = (chains,) if replicas == 1 else (replicas, chains)
+    v, f, lv, lq = (torch.randn(N, 3, generator=gen).to(DEV) for _ in range(4))
+    pv, lp = (torch.randn(*shape_pv, generator=gen).to(DEV) for _ in range(2))
+    q = torch.Tensor(system.get_positions()).to(DEV)
+    with torch.no_grad():
+        a1, _, b1 = integ.rhs_from_force((v, q, pv), f)
+        _, (Gv1, _, Gp1), _ = integ.rhs_vjp((v, q, pv), (lv, lq, lp), want_theta=False)
+        integ.hip_algebra = False
+        a0, _, b0 = integ.rhs_from_force((v, q, pv), f)
+        _, (Gv0, _, Gp0), _ = integ.rhs_vjp((v, q, pv), (lv, lq, lp), want_theta=False)
+    close(a1, a0, 1e-5, 1e-6, "a")
+    close(b1, b0, 1e-5, 1e-5 * float(b0.abs().max()), "dpv")
+    close(Gv1, Gv0, 1e-5, 1e-6, "Gv")
+    close(Gp1, Gp0, 1e-5, 1e-5 * float(Gp0.abs().max()), "Gp")
+
+
 # ------------------------------------------------------------------ SURVEY 8f "next" rows
 def test_readme_snippet_runs():
     """The reference README's pipeline (with its class-plus-kwargs PairPotentials sugar)."""
