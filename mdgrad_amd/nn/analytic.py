@@ -122,15 +122,26 @@ def _reverse_U(fw, topo):
     return -ops._edge_scatter(d_b[:, None] * fw["uhat"], topo)
 
 
-class _blas_for:
-    """The library GEMMs here are tiny next to their dispatch cost: rocBLAS ("hipblas") issues a GEMM in
-    ~7 us where the hipBLASLt default needs ~19 us (measured, tools/mmbench.py), but its kernels are up
-    to 3x slower on [E, .] operands with E ~ 1e5.  Pick per evaluation by edge count; restore on exit."""
+BUCKET_EDGES, BUCKET = 65536, 8192
 
-    def __init__(self, n_edges):
-        # also for large E: the edge count changes at every neighbour rebuild, and hipBLASLt's
-        # per-shape heuristic lookup then costs ~1 ms per GEMM call (measured, tools/prof_fwd.py)
-        self.want = "hipblas"
+
+def _stable(topo):
+    """Above BUCKET_EDGES edges (GPU-bound) work on the bucket-padded topology so that GEMM shapes repeat."""
+    if topo.n_edges >= BUCKET_EDGES and not getattr(topo, "padded", False):
+        return topo.bucketed(BUCKET)
+    return topo
+
+
+class _blas_for:
+    """Library-GEMM backend per evaluation (restored on exit).  rocBLAS ("hipblas") issues a GEMM in ~7 us
+    where hipBLASLt needs ~19 us (tools/mmbench.py) -- what matters for small, launch-bound systems -- but on
+    [E,128] operands with E ~ 1e5..1e6 the hipBLASLt kernels are ~2x faster (tools/mmbench2.py).  hipBLASLt
+    searches its heuristics once per new shape (~1 ms per GEMM call, tools/prof_fwd.py), so it is only used
+    when the edge count is padded to a repeating size (bucketed / fixed-capacity topologies)."""
+
+    def __init__(self, topo):
+        big = topo.n_edges >= 16384 and getattr(topo, "padded", False)
+        self.want = "hipblaslt" if big else "hipblas"
         self.prev = None
 
     def __enter__(self):
@@ -149,18 +160,21 @@ class _blas_for:
 
 
 @torch.no_grad()
-def force(net, z, x, topo, offsets):
-    with _blas_for(topo.n_edges):
-        fw = _primal(net, z, x.detach().contiguous(), topo, offsets)
+def force(net, z, x, topo, offsets=None):
+    topo = _stable(topo)
+    with _blas_for(topo):
+        fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
         return fw["U"], _reverse_U(fw, topo)
 
 
 @torch.no_grad()
-def force_vjp(net, z, x, w, topo, offsets, want_theta=True):
+def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True):
     """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()]); the parameter part is skipped
-    (None) when want_theta is False."""
-    with _blas_for(topo.n_edges):
-        return _force_vjp(net, z, x, w, topo, offsets, want_theta)
+    (None) when want_theta is False.  (`offsets` is the topology's own image-flag array; the argument is
+    kept for callers that pass it explicitly.)"""
+    topo = _stable(topo)
+    with _blas_for(topo):
+        return _force_vjp(net, z, x, w, topo, topo.offsets, want_theta)
 
 
 def _force_vjp(net, z, x, w, topo, offsets, want_theta=True):
