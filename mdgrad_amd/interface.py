@@ -197,6 +197,8 @@ class PairPotentials(GeneralInteraction):
         return _LazyTopology(self, xyz.detach())
 
     def supports_static_topology(self):
+        # module pair models differentiate phi(r) with the autograd engine, whose worker thread cannot
+        # take part in a stream capture here (segfault at capture end on ROCm 7): eager launches for them
         return self.builtin()
 
     def set_static_topology(self, on=True):
@@ -205,10 +207,55 @@ class PairPotentials(GeneralInteraction):
             longest = int(self._ell.cnt.max().item())
             self._static = dict(max_nbr=min(self._group - 1, (int(longest * 1.25) + 15) // 8 * 8),
                                 need=torch.zeros(2, dtype=torch.int32, device=self.device), version=0)
+            if not self.builtin():                    # module path works on the half list: edge capacity too
+                pairs = int(self._ell.half_list()[0].shape[0])
+                self._static["capacity"] = (int(pairs * 1.25) + 1023) // 1024 * 1024
 
-    # -- analytic-adjoint protocol (no autograd): used by the integrators' rhs_vjp ------------------
+    # -- analytic-adjoint protocol: used by the integrators' rhs_vjp --------------------------------
+    analytic = True            # False: user-defined pair modules go through the autograd double-backward path
+
     def supports_force_vjp(self):
-        return self.builtin()
+        return self.builtin() or self.analytic
+
+    # user-defined pair module phi(r) (pairMLP ...): phi', phi'' and the parameter vjp by autograd over the
+    # [P] pair distances only; geometry and the per-atom sums on the HIP list (no float atomics)
+    def _phi(self, r):
+        return self.model(r)
+
+    def _module_pairs(self, xyz):
+        st = self._static if self._static_on else None
+        topo = ops.GraphTopo(self._ell) if st is None else ops.StaticTopo(self._ell, st["capacity"], st["need"])
+        cellm = self.cell.detach()
+        cellm = torch.diag(cellm) if cellm.dim() == 1 else cellm
+        delta = ops._edge_diff(xyz, topo) - topo.offsets.matmul(cellm)        # compute_dis, topology.py:9-10
+        d = delta.pow(2).sum(1).sqrt()
+        return topo, delta / d[:, None], d
+
+    def _module_force(self, xyz):
+        topo, uhat, d = self._module_pairs(xyz)
+        with torch.enable_grad():
+            r = d.detach().requires_grad_(True)
+            (g1,) = torch.autograd.grad(self._phi(r[:, None]).sum(), r)
+        return -ops._edge_scatter(g1[:, None] * uhat, topo)
+
+    def _module_force_vjp(self, xyz, w, want_theta):
+        topo, uhat, d = self._module_pairs(xyz)
+        ddel = ops._edge_diff(w, topo)
+        a = (uhat * ddel).sum(1)                                             # rhat . (w_i - w_j)
+        params = [p for p in self.model.parameters() if p.requires_grad] if want_theta else []
+        with torch.enable_grad():
+            r = d.detach().requires_grad_(True)
+            (g1,) = torch.autograd.grad(self._phi(r[:, None]).sum(), r, create_graph=True)
+            # S = w . grad U = sum_p phi'(r_p) a_p :  dS/dr_p = phi''(r_p) a_p ,  dS/dtheta = d(w . grad U)/dtheta
+            grads = torch.autograd.grad((g1 * a).sum(), [r] + params, allow_unused=True)
+        g1 = g1.detach()
+        g2a = grads[0]
+        hv = g2a[:, None] * uhat + (g1 / d)[:, None] * (ddel - a[:, None] * uhat)
+        F = -ops._edge_scatter(g1[:, None] * uhat, topo)
+        by_id = {id(p): g_ for p, g_ in zip(params, grads[1:])}
+        gth = [(-by_id[id(p)] if by_id.get(id(p)) is not None else torch.zeros_like(p))
+               for p in self.model.parameters()] if want_theta else None
+        return F, -ops._edge_scatter(hv, topo), gth
 
     def _theta(self, like):
         params = self.model.mdg_params()
@@ -216,6 +263,8 @@ class PairPotentials(GeneralInteraction):
 
     def force(self, xyz):
         """F = -dU/dx in one kernel launch."""
+        if not self.builtin():
+            return self._module_force(xyz.detach().contiguous())
         theta, _ = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True)
         return -o["grad"]
@@ -223,6 +272,8 @@ class PairPotentials(GeneralInteraction):
     def force_vjp(self, xyz, w, want_theta=True):
         """(F, d(w.F)/dx, [d(w.F)/dtheta_p for p in parameters()]) -- what double autograd yields at
         torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term)."""
+        if not self.builtin():
+            return self._module_force_vjp(xyz.detach().contiguous(), w.detach().contiguous(), want_theta)
         theta, params = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, w=w.detach().contiguous(),
                           energy=False, grad=True)
@@ -243,6 +294,26 @@ class PairPotentials(GeneralInteraction):
         nbr, off = self._ell.half_list()
         pair_dis = compute_dis(xyz, nbr, off, self.cell)
         return self.model(pair_dis).sum()
+
+
+class TPairPotentials(PairPotentials):
+    """Temperature-dependent pair model u(r, kB T) (torchmd/interface.py:139-215; e.g. potentials.TpairMLP)."""
+
+    def __init__(self, system, pair_model, T, cutoff=2.5, index_tuple=None, ex_pairs=None, nbr_list_device=None):
+        super().__init__(system, pair_model, cutoff=cutoff, index_tuple=index_tuple, ex_pairs=ex_pairs,
+                         nbr_list_device=nbr_list_device)
+        self.T = T
+
+    def builtin(self):
+        return False
+
+    def _phi(self, r):
+        from . import units
+        return self.model(r, units.kB * self.T)
+
+    def forward(self, xyz):
+        nbr, off = self._ell.half_list()
+        return self._phi(compute_dis(xyz, nbr, off, self.cell)).sum()            # interface.py:207-215
 
 
 class Stack(torch.nn.Module):

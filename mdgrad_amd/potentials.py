@@ -134,3 +134,49 @@ class Yukawa(_PairForm):
 
 def is_builtin_form(model):
     return isinstance(model, _PairForm)
+
+
+# ----------------------------------------------------------------------------- per-pair neural potentials
+# torchmd/potentials.py:13-22: the activation table of the LJ-fitting scripts (one shared module instance
+# per name, as there)
+nlr_dict = {name: getattr(nn, name)() for name in
+            ("ReLU", "ELU", "Tanh", "LeakyReLU", "ReLU6", "SELU", "CELU", "Tanhshrink")}
+
+
+class pairMLP(nn.Module):
+    """phi(r) as an MLP over a trainable Gaussian expansion of the pair distance
+    (torchmd/potentials.py:163-206; same layer order, so reference state_dicts load).  With `res`,
+    width-preserving layers are residual.  Not a built-in kernel form: PairPotentials evaluates it per
+    pair on the device from the HIP neighbour list (interface.PairPotentials module path)."""
+
+    def __init__(self, n_gauss, r_start, r_end, n_layers, n_width, nonlinear, res=False):
+        super().__init__()
+        from .nn.layers import GaussianSmearing
+        act = nlr_dict[nonlinear]
+        self.smear = GaussianSmearing(start=r_start, stop=r_end, n_gaussians=n_gauss, trainable=True)
+        widths = [n_gauss, n_gauss, n_width] + [n_width] * n_layers + [n_gauss]
+        mods = []
+        for a, b in zip(widths[:-1], widths[1:]):
+            mods += [nn.Linear(a, b), act]
+        mods.append(nn.Linear(n_gauss, 1))
+        self.layers = nn.ModuleList(mods)
+        self.res = res
+
+    def forward(self, r):
+        x = self.smear(r)
+        for layer in self.layers:
+            y = layer(x)
+            x = x + y if (self.res and y.shape[-1] == x.shape[-1]) else y
+        return x
+
+
+class TpairMLP(nn.Module):
+    """u(r, T) = energy(r) - T entropy(r), two pairMLPs (torchmd/potentials.py:208-217)."""
+
+    def __init__(self, n_gauss, r_start, r_end, n_layers, n_width, nonlinear, res=False):
+        super().__init__()
+        self.energy = pairMLP(n_gauss, r_start, r_end, n_layers, n_width, nonlinear, res=res)
+        self.entropy = pairMLP(n_gauss, r_start, r_end, n_layers, n_width, nonlinear, res=res)
+
+    def forward(self, r, T):
+        return self.energy(r) - T * self.entropy(r)

@@ -18,6 +18,8 @@ Golden sets:
   G8 schnet_*   SchNet energy/forces/hvp     nff/nn/models/schnet.py:23-171
   G9 gnn_traj   Stack(GNN+pair) NHC + adj    torchmd/interface.py:86-136,364-403
   G10 sim_*     Simulations 2 epochs         torchmd/md.py:14-96
+  G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
+                                             torchmd/potentials.py:163-217, interface.py:139-215
 """
 import os
 import sys
@@ -35,7 +37,7 @@ import torch  # noqa: E402
 from torchmd.topology import generate_nbr_list, compute_dis  # noqa: E402
 from torchmd.system import System  # noqa: E402
 from torchmd import potentials as P  # noqa: E402
-from torchmd.interface import PairPotentials, GNNPotentials, Stack  # noqa: E402
+from torchmd.interface import PairPotentials, TPairPotentials, GNNPotentials, Stack  # noqa: E402
 from torchmd.md import NoseHooverChain, NVE, Simulations  # noqa: E402
 from torchmd.sovlers import odeint, odeint_adjoint  # noqa: E402
 from torchmd.observable import rdf  # noqa: E402
@@ -420,8 +422,63 @@ def g10():
          sys_positions=system.get_positions(), sys_velocities=system.get_velocities())
 
 
+# ------------------------------------------------------------------ G11
+def g11():
+    """pairMLP / TpairMLP: the per-pair MLP potentials of the LJ-fitting scripts."""
+    pos, cell, vel = lj_inputs(seed=3)
+    kw = dict(n_gauss=16, r_start=0.0, r_end=2.5, n_layers=1, n_width=24)
+    out = dict(pos=pos.astype(F32), cell=cell.astype(F32), vel=vel.astype(F32), cutoff=2.5, T=1.0, Q=50.0,
+               chains=5, dt=0.005, n_gauss=16, n_layers=1, n_width=24, r_end=2.5)
+    r = torch.linspace(0.6, 2.4, 37)[:, None]
+    for tag, nonlinear, res in [("elu", "ELU", False), ("tanh_res", "Tanh", True)]:
+        torch.manual_seed(11)
+        mlp = P.pairMLP(nonlinear=nonlinear, res=res, **kw)
+        for k, v in mlp.state_dict().items():
+            out["%s_sd_%s" % (tag, k)] = v.clone()
+        out[tag + "_r"] = r[:, 0]
+        out[tag + "_u"] = mlp(r)[:, 0].detach()
+    # energies / forces through PairPotentials, and the temperature-dependent pair model
+    torch.manual_seed(11)
+    mlp = P.pairMLP(nonlinear="ELU", res=False, **kw)
+    system = make_system(pos, cell, vel=vel)
+    pp = PairPotentials(system, mlp, cutoff=2.5)
+    q = torch.Tensor(pos).requires_grad_(True)
+    u = pp(q)
+    (gq,) = torch.autograd.grad(u, q)
+    out["pp_energy"], out["pp_force"] = u.detach().reshape(1), -gq
+    torch.manual_seed(12)
+    tm = P.TpairMLP(nonlinear="ELU", res=False, **kw)
+    for k, v in tm.state_dict().items():
+        out["t_sd_" + k] = v.clone()
+    tp = TPairPotentials(system, tm, T=150.0, cutoff=2.5)
+    q = torch.Tensor(pos).requires_grad_(True)
+    ut = tp(q)
+    (gqt,) = torch.autograd.grad(ut, q)
+    out["tp_T"], out["tp_energy"], out["tp_force"] = 150.0, ut.detach().reshape(1), -gqt
+    # Stack(pairMLP + LJFamily prior) NHC trajectory and adjoint of an RDF loss (scripts/fit_rdf_pair.py:355-368)
+    torch.manual_seed(11)
+    mlp = P.pairMLP(nonlinear="ELU", res=False, **kw)
+    prior = P.LJFamily(epsilon=2.0, sigma=0.9, rep_pow=6, attr_pow=3)
+    system = make_system(pos, cell, vel=vel)
+    stack = Stack({"pairnn": PairPotentials(system, mlp, cutoff=2.5), "pair": PairPotentials(system, prior, cutoff=2.5)})
+    integ = NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0, adjoint=True)
+    y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([0.005 * i for i in range(9)])
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    obs = rdf(system, nbins=60, r_range=(0.75, 2.4))
+    _, _, g = obs(q_t)
+    loss = (g - 1).pow(2).mean() + 0.01 * v_t[-1].pow(2).sum()
+    loss.backward()
+    out.update(v_t=v_t.detach(), q_t=q_t.detach(), pv_t=pv_t.detach(), g=g.detach(), loss=loss.detach().reshape(1),
+               grad_v0=y0[0].grad, grad_q0=y0[1].grad,
+               grad_mlp=torch.cat([p_.grad.reshape(-1) for p_ in mlp.parameters()]),
+               grad_prior=torch.cat([p_.grad.reshape(-1) for p_ in prior.parameters()]),
+               prior_sigma=0.9, prior_epsilon=2.0, mass=system.get_masses().astype(F32))
+    save("pair_mlp", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10"]
-    table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10}
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11"]
+    table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11}
     for w in which:
         table[w]()

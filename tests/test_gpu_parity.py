@@ -760,3 +760,84 @@ def test_edge_cases_empty_lists_tiny_systems_single_frame():
     # wrong device / dtype fail loudly
     with pytest.raises((RuntimeError, TypeError)):
         pp(q.detach().double())
+
+
+# ------------------------------------------------------------------ per-pair MLP potentials
+def _load_sd(module, g, prefix):
+    module.load_state_dict({k[len(prefix):]: T(g[k]) for k in list(g.keys()) if k.startswith(prefix)})
+    return module
+
+
+def _pair_mlp_setup(g, analytic=True):
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    kw = dict(n_gauss=int(g["n_gauss"]), r_start=0.0, r_end=float(g["r_end"]), n_layers=int(g["n_layers"]),
+              n_width=int(g["n_width"]))
+    mlp = _load_sd(P.pairMLP(nonlinear="ELU", res=False, **kw), g, "elu_sd_")
+    prior = P.LJFamily(epsilon=float(g["prior_epsilon"]), sigma=float(g["prior_sigma"]), rep_pow=6, attr_pow=3)
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    pnn = PairPotentials(system, mlp, cutoff=float(g["cutoff"]))
+    pnn.analytic = analytic
+    integ = NoseHooverChain(Stack({"pairnn": pnn, "pair": PairPotentials(system, prior, cutoff=float(g["cutoff"]))}),
+                            system, T=float(g["T"]), num_chains=int(g["chains"]), Q=float(g["Q"])).to(DEV)
+    return system, mlp, prior, integ
+
+
+def test_pair_mlp_energy_force_golden():
+    """pairMLP / TpairMLP (torchmd/potentials.py:163-217) through PairPotentials / TPairPotentials
+    (interface.py:139-215): phi(r) tables, total energy and forces against the reference."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, TPairPotentials
+    g = load_golden("pair_mlp")
+    kw = dict(n_gauss=int(g["n_gauss"]), r_start=0.0, r_end=float(g["r_end"]), n_layers=int(g["n_layers"]),
+              n_width=int(g["n_width"]))
+    for tag, nl, res in [("elu", "ELU", False), ("tanh_res", "Tanh", True)]:
+        m = _load_sd(P.pairMLP(nonlinear=nl, res=res, **kw), g, tag + "_sd_").to(DEV)
+        close(m(T(g[tag + "_r"], DEV)[:, None])[:, 0], g[tag + "_u"], 1e-5, 1e-6, "phi(r) " + tag)
+    system = mk_system(g["pos"], g["cell"], g["vel"])
+    mlp = _load_sd(P.pairMLP(nonlinear="ELU", res=False, **kw), g, "elu_sd_")
+    pp = PairPotentials(system, mlp, cutoff=float(g["cutoff"])).to(DEV)
+    q = T(g["pos"], DEV).requires_grad_(True)
+    u = pp(q)
+    (gq,) = torch.autograd.grad(u, q)
+    close(u.reshape(1), g["pp_energy"], 1e-5, 1e-4, "pairMLP energy")
+    close(-gq, g["pp_force"], 1e-4, 2e-6 * float(np.abs(g["pp_force"]).max()) + 1e-6, "pairMLP force (autograd)")
+    close(pp.force(q.detach()), g["pp_force"], 1e-4, 2e-6 * float(np.abs(g["pp_force"]).max()) + 1e-6,
+          "pairMLP force (analytic protocol)")
+    tm = _load_sd(P.TpairMLP(nonlinear="ELU", res=False, **kw), g, "t_sd_")
+    tp = TPairPotentials(system, tm, T=float(g["tp_T"]), cutoff=float(g["cutoff"])).to(DEV)
+    q = T(g["pos"], DEV).requires_grad_(True)
+    ut = tp(q)
+    (gqt,) = torch.autograd.grad(ut, q)
+    close(ut.reshape(1), g["tp_energy"], 1e-5, 1e-4, "TpairMLP energy")
+    close(-gqt, g["tp_force"], 1e-4, 2e-6 * float(np.abs(g["tp_force"]).max()) + 1e-6, "TpairMLP force")
+    close(tp.force(q.detach()), g["tp_force"], 1e-4, 2e-6 * float(np.abs(g["tp_force"]).max()) + 1e-6,
+          "TpairMLP force (analytic protocol)")
+
+
+@pytest.mark.parametrize("mode", ["autograd", "analytic"])
+def test_pair_mlp_trajectory_adjoint_golden(mode):
+    """Stack(pairMLP + LJFamily prior) NHC trajectory and the adjoint of an RDF loss (the set-up of
+    scripts/fit_rdf_pair.py:355-368) against the reference, through the autograd double-backward path and the
+    analytic-adjoint protocol (phi', phi'' by autograd over the pair distances only)."""
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("pair_mlp")
+    system, mlp, prior, integ = _pair_mlp_setup(g, analytic=(mode != "autograd"))
+    assert integ.supports_rhs_vjp() == (mode != "autograd")
+    y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(g["dt"]) * i for i in range(9)]).to(DEV)
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    close(q_t, g["q_t"], 1e-4, 1e-5, "q_t")
+    close(v_t, g["v_t"], 1e-3, 1e-4, "v_t")
+    close(pv_t, g["pv_t"], 1e-3, 1e-5, "pv_t")
+    _, _, gr = rdf(system, nbins=60, r_range=(0.75, 2.4))(q_t)
+    close(gr, g["g"], 1e-3, 2e-4, "g(r)")
+    ((gr - 1).pow(2).mean() + 0.01 * v_t[-1].pow(2).sum()).backward()
+    gm = torch.cat([p_.grad.reshape(-1) for p_ in mlp.parameters()])
+    gp = torch.cat([p_.grad.reshape(-1) for p_ in prior.parameters()])
+    close(gm, g["grad_mlp"], 5e-3, 2e-4 * float(np.abs(g["grad_mlp"]).max()), "dL/dtheta_mlp")
+    close(gp, g["grad_prior"], 5e-3, 2e-4 * float(np.abs(g["grad_prior"]).max()), "dL/dtheta_prior")
+    close(y0[0].grad, g["grad_v0"], 5e-3, 2e-4 * float(np.abs(g["grad_v0"]).max()), "dL/dv0")
+    close(y0[1].grad, g["grad_q0"], 5e-3, 2e-4 * float(np.abs(g["grad_q0"]).max()), "dL/dq0")
