@@ -36,6 +36,14 @@ extern "C" {
 #define MDG_PAIR_MORSE    1   /* ModifiedMorse :75-93; constants a, phi; no parameters */
 #define MDG_PAIR_BUCK     2   /* Buck :354-365; theta=(A,B,C) */
 #define MDG_PAIR_YUKAWA   3   /* eps exp(-kappa r)/r; theta=(eps,kappa); NOT in the reference */
+#define MDG_PAIR_TABLE    4   /* tabulated pair model (user modules such as pairMLP, torchmd/potentials.py:163-206,
+                                 or a whole Stack of pair terms with one cutoff): theta = 2 p floats,
+                                 theta[2g] = c1(u_g), theta[2g+1] = du * dc1/du(u_g) on the uniform grid
+                                 u_g = a + g * phi in u = r^2, where c1(u) = phi'(r)/r; cubic-Hermite
+                                 interpolation (force = c1 D; (phi'' - phi'/r)/r^2 = 2 dc1/du).  The adjoint
+                                 returns dL/dtheta (the table gradient).  c = fixed-point scale of that
+                                 accumulation (a power of two).  Fused small-system kernels only, single
+                                 unmasked term, orthorhombic cell. */
 
 typedef struct MdgPairTerm {
     int32_t kind;          /* MDG_PAIR_*                                                    */

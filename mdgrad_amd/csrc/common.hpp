@@ -119,6 +119,7 @@ __device__ __forceinline__ TermConst term_prepare(const MdgPairTerm& t, const fl
 
 // compile-time kind of the single-term kernels: MDG_PAIR_LJ with the exponents fixed to 12-6
 constexpr int KIND_LJ126 = 16;
+constexpr int KIND_TABLE = 17;         // MDG_PAIR_TABLE in the fused small-system kernels
 // trainable parameters per functional form (the theta slots pair_eval fills)
 __host__ __device__ constexpr int kind_ntheta(int kind) {
     return kind == MDG_PAIR_MORSE ? 0 : (kind == MDG_PAIR_BUCK ? 3 : 2);

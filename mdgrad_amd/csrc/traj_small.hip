@@ -112,6 +112,106 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
     th_eps += te.x + te.y;
 }
 
+// Tabulated pair model (MDG_PAIR_TABLE): c1(u) = phi'(r)/r on a uniform grid in u = r^2, cubic-Hermite
+// nodes (value, du * slope) resident in LDS.  Force = c1 D; Hessian term (phi'' - phi'/r)/r^2 = 2 dc1/du is
+// the derivative of the SAME interpolant, so force and Hessian-vector product stay consistent.
+// The parameter vjp is the gradient w.r.t. the table nodes: d(w.F)/dnode += 1/2 (D.w_ij) basis_node(u) per
+// directed pair, scattered into LDS.  Float LDS atomics are ~13x slower than integer ones on gfx950
+// (tools/micro/lds_atomics.hip), so the scatter is fixed point, split into two int32 planes
+// (value = HI * 2^20 + LO): order-independent => bitwise reproducible, like every other reduction here.
+struct TableRef {
+    const float2* tab;      // [M] (c1_g, du * dc1/du_g)
+    int32_t* ghi;           // [2M] or nullptr (no accumulation in this evaluation)
+    int32_t* glo;
+    float gw;               // weight of this evaluation's contributions: 1/2 * h * 2^S
+};
+
+__device__ __forceinline__ void table_scatter(const TableRef& T, int idx, float val, float& vmax) {
+    vmax = fmaxf(vmax, fabsf(val));
+    const float hi = rintf(val * (1.f / 1048576.f));
+    const float lo = fmaf(hi, -1048576.f, val);
+    atomicAdd(T.ghi + idx, (int)hi);
+    atomicAdd(T.glo + idx, (int)rintf(lo));
+}
+
+template <int LEVEL>
+__device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
+                                                   const float* __restrict__ w, float* __restrict__ f,
+                                                   float* __restrict__ dq, const TableRef& T, float& vmax) {
+    const int N = A.prm.n_atoms;
+    const int TPA = 1 << tpa_log2;
+    const int slots = blockDim.x >> tpa_log2;
+    const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
+    const MdgPairTerm& t0 = A.terms.t[0];
+    const float rc2 = t0.cutoff * t0.cutoff, u0 = t0.a, inv_du = 1.f / t0.phi;
+    const float tmax = (float)(t0.p - 1) - 1e-3f;
+    const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+    const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+    const bool acc = LEVEL >= 2 && T.ghi != nullptr;
+    for (int i = slot; i < N; i += slots) {
+        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
+        for (int j = sub; j < N; j += 2 * TPA) {
+            const bool live2 = j + TPA < N;
+            const int j2 = live2 ? j + TPA : j;
+            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[N + j] - yi, q[N + j2] - yi},
+                  dz = {q[2 * N + j] - zi, q[2 * N + j2] - zi};                    // D = x_j - x_i
+            f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
+            if (LEVEL >= 2) {
+                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[N + j], wyi - w[N + j2]};
+                az = f32x2{wzi - w[2 * N + j], wzi - w[2 * N + j2]};
+            }
+            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);                         // topology.py:67
+            const bool ok1 = live2 && (d2.y != 0.f) && (d2.y < rc2);
+            const f32x2 sel = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
+            // grid coordinate (clamped: below the first node the first cell is extrapolated with fr = 0)
+            f32x2 tt = (d2 - u0) * inv_du;
+            tt.x = fminf(fmaxf(ok0 ? tt.x : 0.f, 0.f), tmax); tt.y = fminf(fmaxf(ok1 ? tt.y : 0.f, 0.f), tmax);
+            const int g0 = (int)tt.x, g1 = (int)tt.y;
+            const f32x2 fr = {tt.x - (float)g0, tt.y - (float)g1};
+            const float2 a0 = T.tab[g0], b0 = T.tab[g0 + 1], a1 = T.tab[g1], b1 = T.tab[g1 + 1];
+            const f32x2 v0 = {a0.x, a1.x}, s0 = {a0.y, a1.y}, v1 = {b0.x, b1.x}, s1 = {b0.y, b1.y};
+            const f32x2 om = 1.f - fr, fr2 = fr * fr, om2 = om * om;
+            const f32x2 h00 = (1.f + 2.f * fr) * om2, h10 = fr * om2, h01 = fr2 * (3.f - 2.f * fr), h11 = fr2 * (fr - 1.f);
+            const f32x2 c1 = (h00 * v0 + h10 * s0 + h01 * v1 + h11 * s1) * sel;
+            fx += c1 * dx; fy += c1 * dy; fz += c1 * dz;      // F_i += (phi'/r) D
+            if (LEVEL >= 2) {
+                const f32x2 b = dx * ax + dy * ay + dz * az;
+                const f32x2 e00 = 6.f * fr * (fr - 1.f), e10 = (3.f * fr - 4.f) * fr + 1.f, e11 = (3.f * fr - 2.f) * fr;
+                const f32x2 c1u = (e00 * (v0 - v1) + e10 * s0 + e11 * s1) * (inv_du * sel);
+                const f32x2 k2 = (2.f * c1u) * b;
+                gx -= k2 * dx + c1 * ax;
+                gy -= k2 * dy + c1 * ay;
+                gz -= k2 * dz + c1 * az;
+                if (acc) {
+                    const f32x2 x = (T.gw * b) * sel;
+                    if (ok0) {
+                        table_scatter(T, 2 * g0, x.x * h00.x, vmax); table_scatter(T, 2 * g0 + 1, x.x * h10.x, vmax);
+                        table_scatter(T, 2 * g0 + 2, x.x * h01.x, vmax); table_scatter(T, 2 * g0 + 3, x.x * h11.x, vmax);
+                    }
+                    if (ok1) {
+                        table_scatter(T, 2 * g1, x.y * h00.y, vmax); table_scatter(T, 2 * g1 + 1, x.y * h10.y, vmax);
+                        table_scatter(T, 2 * g1 + 2, x.y * h01.y, vmax); table_scatter(T, 2 * g1 + 3, x.y * h11.y, vmax);
+                    }
+                }
+            }
+        }
+        float sx = group_sum_rt(fx.x + fx.y, TPA), sy = group_sum_rt(fy.x + fy.y, TPA), sz = group_sum_rt(fz.x + fz.y, TPA);
+        float ux = 0.f, uy = 0.f, uz = 0.f;
+        if (LEVEL >= 2) {
+            ux = group_sum_rt(gx.x + gx.y, TPA); uy = group_sum_rt(gy.x + gy.y, TPA); uz = group_sum_rt(gz.x + gz.y, TPA);
+        }
+        if (sub == 0) {
+            f[i] = sx; f[N + i] = sy; f[2 * N + i] = sz;
+            if (LEVEL >= 2) { dq[i] = ux; dq[N + i] = uy; dq[2 * N + i] = uz; }
+        }
+    }
+}
+
 // All-pairs force (LEVEL 1) or force + Hessian-vector product + parameter vjp (LEVEL 2).
 //   f   [3][N] <-  F = -dU/dq
 //   dq  [3][N] <-  d(w.F)/dq = -H w                      (LEVEL 2)
@@ -119,7 +219,12 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
 template <bool DIAG, int NT, int KIND, int LEVEL>
 __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                 const float* __restrict__ w, float* __restrict__ f,
-                                                float* __restrict__ dq, float (&dth)[KMAX]) {
+                                                float* __restrict__ dq, float (&dth)[KMAX], const TableRef& TB,
+                                                float& vmax) {
+    if constexpr (KIND == KIND_TABLE) {
+        force_table_packed<LEVEL>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        return;
+    }
     const int N = A.prm.n_atoms;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
@@ -265,6 +370,14 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     float* Qs = pvh + MDG_MAX_CHAINS;   // [C] thermostat masses
     float* red = Qs + MDG_MAX_CHAINS;   // [RED_FLOATS]
     float dth_unused[KMAX];
+    float vmax_unused = 0.f;
+    TableRef TB{nullptr, nullptr, nullptr, 0.f};
+    if constexpr (KIND == KIND_TABLE) {                    // table nodes resident in LDS for the whole trajectory
+        float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS + ((13 * N) & 1));       // 8-byte aligned
+        const float* th = A.theta + A.terms.t[0].theta_off;
+        for (int g = threadIdx.x; g < A.terms.t[0].p; g += blockDim.x) tab[g] = make_float2(th[2 * g], th[2 * g + 1]);
+        TB.tab = tab;
+    }
 #pragma unroll
     for (int c = 0; c < MDG_MAX_CHAINS; ++c)
         if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
@@ -280,7 +393,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     store_aos(A.v_t + ((size_t)rep * T) * N * 3, v, N);
     if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
 
-    force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused);
+    force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
     __syncthreads();
 
     for (int k = 0; k + 1 < T; ++k) {
@@ -313,7 +426,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         }
         __syncthreads();
         // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-        force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused);
+        force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
         float pvh0 = 0.f;
         if (nhc) {
             float part = 0.f;
@@ -355,13 +468,13 @@ template <bool DIAG, int NT, int KIND>
 __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool nhc, const float* q, const float* v,
                                          const float* lv, const float* ms, float* w, float* f,
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
-                                         float& slv) {
+                                         float& slv, const TableRef& TB, float& vmax) {
     const int N = A.prm.n_atoms;
     MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] / ms[ia] : lv[e];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
-    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th);
+    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th, TB, vmax);
     // one fused block reduction: th[0..K), sum p^2/m, sum lv.v
     float vals[KMAX + 2];
 #pragma unroll
@@ -415,6 +528,19 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
     float th[KMAX], gth[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) gth[k] = 0.f;
+    float vmax = 0.f;
+    TableRef TB{nullptr, nullptr, nullptr, 0.f}, TBacc = TB;
+    if constexpr (KIND == KIND_TABLE) {
+        const int M = A.terms.t[0].p;
+        float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS);
+        int32_t* ghi = reinterpret_cast<int32_t*>(tab + M);
+        int32_t* glo = ghi + 2 * M;
+        const float* thp = A.theta + A.terms.t[0].theta_off;
+        for (int g = threadIdx.x; g < M; g += blockDim.x) tab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
+        for (int g = threadIdx.x; g < 2 * M; g += blockDim.x) { ghi[g] = 0; glo[g] = 0; }
+        TB.tab = tab;
+        TBacc = TableRef{tab, ghi, glo, 0.f};
+    }
     const size_t fr = (size_t)rep * T;
     const int tid = threadIdx.x;
 
@@ -433,7 +559,10 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
         __syncthreads();
         float ke, slv;
         // ---------------- first augmented evaluation at (y_i, lam)
-        aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv);
+        // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC,
+        //  sovlers.py:160, and from this first one for NVE, :82,101 -- both with total weight h)
+        TBacc.gw = 0.5f * h * A.terms.t[0].c;
+        aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv, nhc ? TB : TBacc, vmax);
         if (nhc) {
             const float pv0 = pv[0], lp0 = lp[0];
             if (tid < C) { pb[tid] = bath_rhs(A, Qs, pv, ke, tid); gp[tid] = bath_vjp(A, Qs, pv, lp, slv, tid); }
@@ -455,7 +584,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             if (tid < C) pv[tid] = pv[tid] + 0.5f * (-pb[tid]) * h;   // :135
             __syncthreads();
             // ---------------- midpoint evaluation                    :147-150
-            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TBacc, vmax);
             const float pvm0 = pv[0], lpm0 = lph[0];
             if (tid < C) gp[tid] = bath_vjp(A, Qs, pv, lph, slv, tid);
             __syncthreads();
@@ -490,7 +619,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) gth[k] += (th[k] * 0.5f * h) * 2.f;   // :82,101
             __syncthreads();
-            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv);
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TB, vmax);
             MDG_FOR_DOF(e, ia, ca) {
                 float nlv = lvh[e];                                   // lv + dvad
                 float nlq = lqh[e] + dq[e] * h * 0.5f;                // :100
@@ -504,6 +633,20 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
     store_aos(A.adj_v0 + (size_t)rep * N3, lv, N);
     store_aos(A.adj_q0 + (size_t)rep * N3, lq, N);
     if (nhc && tid < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + tid] = lp[tid];
+    if constexpr (KIND == KIND_TABLE) {
+        // table gradient: fixed point -> float; an out-of-range contribution poisons the output (the
+        // host re-scales and reports it)
+        const float worst = block_sum(vmax >= 3.5e13f ? 1.f : 0.f, red);          // 2^45
+        if (A.adj_theta) {
+            const int KT = A.terms.n_theta_total, M2 = 2 * A.terms.t[0].p;
+            const double inv = 1.0 / (double)A.terms.t[0].c;
+            float* out = A.adj_theta + (size_t)rep * KT + A.terms.t[0].theta_off;
+            for (int g = tid; g < M2; g += blockDim.x)
+                out[g] = worst > 0.f ? __builtin_inff()
+                                     : (float)(((double)TBacc.ghi[g] * 1048576.0 + (double)TBacc.glo[g]) * inv);
+        }
+        return;
+    }
     if (tid == 0 && A.adj_theta) {
         const int KT = A.terms.n_theta_total;
 #pragma unroll
@@ -536,7 +679,9 @@ int pick_block(const MdgTrajParams& p) {
     do {                                                                                               \
         const bool single = terms->n_terms == 1 && diag && !terms->t[0].mask;                          \
         const int kind = terms->t[0].kind;                                                             \
-        if (single && kind == MDG_PAIR_LJ && terms->t[0].p == 12 && terms->t[0].q == 6)                \
+        if (kind == MDG_PAIR_TABLE)                                                                    \
+            hipLaunchKernelGGL((KERNEL<true, 1, KIND_TABLE>), grid, dim3(block), lds, st, a, tl);      \
+        else if (single && kind == MDG_PAIR_LJ && terms->t[0].p == 12 && terms->t[0].q == 6)           \
             hipLaunchKernelGGL((KERNEL<true, 1, KIND_LJ126>), grid, dim3(block), lds, st, a, tl);      \
         else if (single && kind == MDG_PAIR_LJ)                                                        \
             hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_LJ>), grid, dim3(block), lds, st, a, tl);     \
@@ -560,6 +705,14 @@ int validate(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms)
     MDG_CHECK_ARG(p->ensemble == 1 || (p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS),
                   "traj: NoseHooverChain needs 2 <= num_chains <= %d (got %d)", MDG_MAX_CHAINS, p->n_chains);
     MDG_CHECK_ARG(terms->n_terms >= 1 && terms->n_terms <= MDG_MAX_TERMS, "traj: 1..%d pair terms", MDG_MAX_TERMS);
+    if (terms->t[0].kind == MDG_PAIR_TABLE) {
+        const MdgPairTerm& t = terms->t[0];
+        MDG_CHECK_ARG(terms->n_terms == 1 && !t.mask && cell->diag, "traj: a tabulated pair model must be the only "
+                      "term, unmasked, in an orthorhombic cell");
+        MDG_CHECK_ARG(t.p >= 4 && t.p <= 4096 && t.n_theta == 2 * t.p && t.phi > 0.f && t.c > 0.f,
+                      "traj: bad table (nodes %d, n_theta %d, du %g, scale %g)", t.p, t.n_theta, t.phi, t.c);
+        return MDG_OK;
+    }
     for (int m = 0; m < terms->n_terms; ++m)
         MDG_CHECK_ARG(terms->t[m].kind >= 0 && terms->t[m].kind <= MDG_PAIR_YUKAWA &&
                       terms->t[m].n_theta <= MDG_MAX_THETA, "traj: bad pair term %d", m);
@@ -581,7 +734,9 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
     const int N = prm->n_atoms;
     const int block = pick_block(*prm);
-    const size_t lds = sizeof(float) * (13 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS);
+    const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 2 * (size_t)terms->t[0].p : 0;
+    MDG_CHECK_ARG(!tab || theta, "traj_fwd: the table is passed through theta");
+    const size_t lds = sizeof(float) * (13 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS + tab + (tab ? 1 : 0));
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_fwd: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;
@@ -609,7 +764,9 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
     const int N = prm->n_atoms;
     const int block = pick_block(*prm);
-    const size_t lds = sizeof(float) * (28 * (size_t)N + 6 * MDG_MAX_CHAINS + RED_FLOATS);
+    const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + two int32 planes
+    MDG_CHECK_ARG(!tab || theta, "traj_adj: the table is passed through theta");
+    const size_t lds = sizeof(float) * (28 * (size_t)N + 6 * MDG_MAX_CHAINS + RED_FLOATS + tab);
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_adj: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;

@@ -107,10 +107,51 @@ class _FusedSpec(ops.FusedSpec):
         return _flatten(self._integrator.parameters())          # sovlers.py:319
 
 
+def _table_members(model):
+    """Members of a (Stack of) PairPotentials of which at least one is a user module (pairMLP ...), all
+    unmasked with one cutoff: the whole pair energy is then tabulated for the fused kernels."""
+    mods = [model] if isinstance(model, PairPotentials) else (list(model.models.values()) if isinstance(model, Stack) else None)
+    if not mods or not all(isinstance(m, PairPotentials) for m in mods):
+        return None
+    if all(m.builtin() for m in mods) or any(m._mask is not None for m in mods):
+        return None
+    if len({float(m.cutoff) for m in mods}) != 1 or not mods[0]._cell_struct.diag:
+        return None
+    return mods
+
+
+class _TableSpec(ops.FusedSpec):
+    """FusedSpec whose single term is MDG_PAIR_TABLE: `flat_params()` evaluates c1(u) = phi'(r)/r = 2 dphi/du
+    and its slope on the uniform u = r^2 grid with autograd (differentiable w.r.t. every module parameter),
+    so the table gradient the adjoint kernel returns flows on into the modules."""
+
+    def __init__(self, integrator, members, nodes, r_min, *a, **k):
+        super().__init__(*a, **k)
+        self._integrator, self._members = integrator, members
+        rc = float(members[0].cutoff)
+        self.u0, self.nodes = float(r_min) ** 2, int(nodes)
+        self.du = (rc * rc - self.u0) / (self.nodes - 1)
+        self.table = True
+
+    def flat_params(self):
+        dev = self._integrator.mass.device
+        with torch.enable_grad():
+            u = (self.u0 + self.du * torch.arange(self.nodes, device=dev, dtype=torch.float32)).requires_grad_(True)
+            r = u.sqrt()[:, None]
+            phi = sum(m._phi(r).reshape(-1) for m in self._members)
+            (dphi,) = torch.autograd.grad(phi.sum(), u, create_graph=True)
+            c1 = 2.0 * dphi                                          # phi'(r) / r
+            (dc1,) = torch.autograd.grad(c1.sum(), u, create_graph=True)
+            return torch.stack((c1, self.du * dc1), 1).reshape(-1)
+
+
 class _EOM(torch.nn.Module):
     _ensemble = None
     _method = None
     fused_large = None      # None = by size; True/False forces the multi-launch / one-workgroup kernels
+    fused_table = True      # tabulate user pair modules for the fused kernels (N <= 1024); False: generic path
+    table_nodes = 1024      # nodes of the u = r^2 grid on [ (table_rmin * cutoff)^2 , cutoff^2 ]
+    table_rmin = 0.2
 
     def update_topology(self, q):                               # md.py:200-204
         if self.update_count % self.topology_update_freq == 0:
@@ -123,6 +164,17 @@ class _EOM(torch.nn.Module):
             return None
         mods = _pair_terms_of(self.model)
         N = getattr(self.system, "group_size", self.mass.shape[0])      # atoms per replica
+        if mods is None and self.adjoint and self.fused_table and N <= FUSED_MAX_ATOMS:
+            members = _table_members(self.model)
+            if members is not None and (self._ensemble == 1 or 2 <= self.num_chains <= 16):
+                kw = {} if self._ensemble != 0 else dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
+                nodes = int(self.table_nodes)
+                spec = _TableSpec(self, members, nodes, self.table_rmin * float(members[0].cutoff), self._ensemble, N,
+                                  self.mass[:N].contiguous(), members[0]._cell_struct, None, 2 * nodes, [None], **kw)
+                desc = dict(kind=ops.MDG_PAIR_TABLE, p=nodes, a=spec.u0, phi=spec.du, c=1.0)
+                spec.terms = ops.make_terms([ops.make_term(desc, members[0].cutoff, 0, 2 * nodes, None)], 2 * nodes)
+                spec.n_rep = getattr(self.system, "n_replicas", 1)
+                return spec
         if mods is None or not self.adjoint:
             return None
         large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)

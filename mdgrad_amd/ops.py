@@ -146,6 +146,9 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
 
 
 # ----------------------------------------------------------------------------- pair potentials
+MDG_PAIR_TABLE = 4
+
+
 def make_term(desc, cutoff, theta_off=0, n_theta=0, mask=None):
     t = MdgPairTerm()
     t.kind = desc["kind"]
@@ -345,6 +348,26 @@ class FusedTrajFn(torch.autograd.Function):
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
                                          ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
                                          ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
+        elif getattr(spec, "table", False):
+            # fixed-point scale of the in-kernel table-gradient scatter: the largest single contribution
+            # 1/2 h (D . w_ij) is put near 2^30 (the kernel accepts up to 2^45); one host sync
+            lam = max([float(g.abs().max()) for g in (gv, gq) if g is not None] + [1e-30])
+            h = float((tc[1:] - tc[:-1]).abs().max())
+            est = max(0.5 * h * 2.0 * spec.terms.t[0].cutoff * lam / float(spec.mass.min()), 1e-30)
+            S = max(-100, min(100, int(math.floor(30 - math.log2(est)))))
+            for attempt in range(4):
+                terms = type(spec.terms).from_buffer_copy(spec.terms)
+                terms.t[0].c = 2.0 ** S
+                check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                             ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                             ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                             stream_ptr(dev)), "mdg_traj_adj_small")
+                if bool(torch.isfinite(adj_th[:, 0]).all()):
+                    break
+                S -= 14                                    # adjoint grew past the range: coarser fixed point
+            else:
+                raise RuntimeError("mdgrad_amd: the table-gradient accumulation overflowed (adjoint magnitudes "
+                                   "above 2^%d of the incoming gradients)" % (45 - S))
         else:
             check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),

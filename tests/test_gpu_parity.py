@@ -650,6 +650,7 @@ def test_user_defined_pair_module_runs_generic_path():
     mlp = PairMLP()
     integ = NoseHooverChain(Stack({"mlp": PairPotentials(system, mlp, cutoff=2.0)}), system, T=1.0, num_chains=3,
                             Q=20.0).to(DEV)
+    integ.fused_table = False
     assert integ.fused_spec("NH_verlet") is None
     y0 = tuple(integ.get_inital_states(wrap=True))
     t = torch.Tensor([0.004 * i for i in range(6)]).to(DEV)
@@ -816,16 +817,27 @@ def test_pair_mlp_energy_force_golden():
           "TpairMLP force (analytic protocol)")
 
 
-@pytest.mark.parametrize("mode", ["autograd", "analytic"])
+@pytest.mark.parametrize("mode", ["autograd", "analytic", "table", "table4096"])
 def test_pair_mlp_trajectory_adjoint_golden(mode):
     """Stack(pairMLP + LJFamily prior) NHC trajectory and the adjoint of an RDF loss (the set-up of
-    scripts/fit_rdf_pair.py:355-368) against the reference, through the autograd double-backward path and the
-    analytic-adjoint protocol (phi', phi'' by autograd over the pair distances only)."""
+    scripts/fit_rdf_pair.py:355-368) against the reference, through the autograd double-backward path, the
+    analytic-adjoint protocol (phi', phi'' by autograd over the pair distances only) and the fused
+    trajectory kernels on the tabulated pair energy (MDG_PAIR_TABLE: cubic-Hermite table of phi'(r)/r in
+    LDS, table gradient by fixed-point LDS scatter, module gradients by autograd through the table)."""
     from mdgrad_amd.observable import rdf
     from mdgrad_amd.sovlers import odeint_adjoint
     g = load_golden("pair_mlp")
     system, mlp, prior, integ = _pair_mlp_setup(g, analytic=(mode != "autograd"))
     assert integ.supports_rhs_vjp() == (mode != "autograd")
+    integ.fused_table = mode.startswith("table")
+    if mode == "table4096":
+        integ.table_nodes = 4096
+    assert (integ.fused_spec("NH_verlet") is not None) == mode.startswith("table")
+    # The table is an approximation of the module: forces to ~1e-7 (trajectories below match to 5e-7), but
+    # ELU has a discontinuous second derivative, so phi'' has kinks the cubic table smooths -- the MLP
+    # gradient is first-order accurate in the node spacing: 1e-3 of its largest entry with the default 1 024
+    # nodes, 4e-4 with 4 096 (smooth activations do not have this limit).
+    gtol = {"table": 1.5e-3, "table4096": 6e-4}.get(mode, 2e-4)
     y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
     t = torch.Tensor([float(g["dt"]) * i for i in range(9)]).to(DEV)
     v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
@@ -835,9 +847,58 @@ def test_pair_mlp_trajectory_adjoint_golden(mode):
     _, _, gr = rdf(system, nbins=60, r_range=(0.75, 2.4))(q_t)
     close(gr, g["g"], 1e-3, 2e-4, "g(r)")
     ((gr - 1).pow(2).mean() + 0.01 * v_t[-1].pow(2).sum()).backward()
-    gm = torch.cat([p_.grad.reshape(-1) for p_ in mlp.parameters()])
+    # (a parameter the forces do not depend on -- the last bias -- gets no gradient through the table)
+    gm = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in mlp.parameters()])
     gp = torch.cat([p_.grad.reshape(-1) for p_ in prior.parameters()])
-    close(gm, g["grad_mlp"], 5e-3, 2e-4 * float(np.abs(g["grad_mlp"]).max()), "dL/dtheta_mlp")
+    close(gm, g["grad_mlp"], 5e-3, gtol * float(np.abs(g["grad_mlp"]).max()), "dL/dtheta_mlp")
     close(gp, g["grad_prior"], 5e-3, 2e-4 * float(np.abs(g["grad_prior"]).max()), "dL/dtheta_prior")
     close(y0[0].grad, g["grad_v0"], 5e-3, 2e-4 * float(np.abs(g["grad_v0"]).max()), "dL/dv0")
     close(y0[1].grad, g["grad_q0"], 5e-3, 2e-4 * float(np.abs(g["grad_q0"]).max()), "dL/dq0")
+
+
+@pytest.mark.parametrize("ensemble", ["nve", "nhc_stacked"])
+def test_tabulated_pair_module_fused_matches_generic(ensemble):
+    """MDG_PAIR_TABLE in the fused kernels against the generic path (module evaluated per pair, autograd
+    adjoint) for an NVE run and for replica-stacked NoseHooverChain states; smooth (tanh) module, so the
+    table gradient is accurate to the interpolation error."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain, NVE
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("pair_mlp")
+    R = 3 if ensemble == "nhc_stacked" else 1
+    rng = np.random.default_rng(4)
+    base = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    system = base
+    if R > 1:
+        system = base.replicate(R)
+        system.set_positions(np.concatenate([np.mod(g["pos"] + rng.normal(0, 0.02, g["pos"].shape), g["cell"])
+                                             for _ in range(R)]))
+        system.set_velocities(np.concatenate([g["vel"] * (1 + 0.1 * r) for r in range(R)]))
+    torch.manual_seed(5)
+    mlp = P.pairMLP(n_gauss=12, r_start=0.0, r_end=2.5, n_layers=1, n_width=16, nonlinear="Tanh")
+    prior = P.LJFamily(epsilon=2.0, sigma=0.9, rep_pow=6, attr_pow=3)
+    stack = Stack({"pairnn": PairPotentials(system, mlp, cutoff=2.5), "pair": PairPotentials(system, prior, cutoff=2.5)})
+    if ensemble == "nve":
+        integ, method = NVE(stack, system).to(DEV), "verlet"
+    else:
+        integ, method = NoseHooverChain(stack, system, T=1.0, num_chains=3, Q=30.0).to(DEV), "NH_verlet"
+    t = torch.Tensor([0.004 * i for i in range(8)]).to(DEV)
+    params = list(mlp.parameters()) + list(prior.parameters())
+
+    def run(fused):
+        integ.fused_table = fused
+        assert (integ.fused_spec(method) is not None) == fused
+        for p_ in params:
+            p_.grad = None
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        out = odeint_adjoint(integ, tuple(y0), t, method=method)
+        (out[1][-1].pow(2).mean() + out[0][::2].pow(2).mean()).backward()
+        gth = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in params])
+        return out[1].detach(), y0[1].grad, gth
+
+    q_f, gq_f, gth_f = run(True)
+    q_g, gq_g, gth_g = run(False)
+    close(q_f, q_g, 1e-4, 1e-5, "q_t")
+    close(gq_f, gq_g, 2e-3, 1e-4 * float(gq_g.abs().max()), "dL/dq0")
+    close(gth_f, gth_g, 5e-3, 3e-4 * float(gth_g.abs().max()), "dL/dtheta")

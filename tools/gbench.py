@@ -49,6 +49,7 @@ def main():
     ap.add_argument("which", nargs="*", default=["lj4096", "gnn64", "gnn512"])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--replicas", type=int, default=1, help="stack R replicas (System.replicate) in one trajectory")
+    ap.add_argument("--table-nodes", type=int, default=0, help="mlp108: nodes of the tabulated pair energy (0 = default)")
     args = ap.parse_args()
     from mdgrad_amd import potentials as P, units
     from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
@@ -59,7 +60,30 @@ def main():
     dev = "cuda:0"
     rng = np.random.default_rng(0)
     for w in args.which:
-        if w == "lj4096":
+        if w in ("mlp108", "mlp108_autograd"):
+            # Stack(pairMLP + LJFamily prior), the LJ-fitting set-up of scripts/fit_rdf_pair.py:355-368
+            from mdgrad_amd.system import FaceCenteredCubic
+            atoms = FaceCenteredCubic("H", (3, 3, 3), 1.6)
+            system = System(atoms, device=dev)
+            system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.03, (108, 3)), 4.8))
+            system.set_velocities(rng.normal(0, 1.0, (108, 3)))
+            if args.replicas > 1:
+                system = system.replicate(args.replicas)
+                system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.03, (len(system), 3)), 4.8))
+                system.set_velocities(rng.normal(0, 1.0, (len(system), 3)))
+            torch.manual_seed(0)
+            mlp = P.pairMLP(n_gauss=25, r_start=0.0, r_end=2.5, n_layers=3, n_width=128, nonlinear="ELU")
+            with torch.no_grad():
+                mlp.layers[-1].weight.mul_(0.05)
+            pnn = PairPotentials(system, mlp, cutoff=2.5)
+            pnn.analytic = w == "mlp108"
+            prior = PairPotentials(system, P.LJFamily(epsilon=2.0, sigma=0.9, rep_pow=6, attr_pow=3), cutoff=2.5)
+            integ = NoseHooverChain(Stack({"pairnn": pnn, "pair": prior}), system, T=1.0, num_chains=5, Q=50.0).to(dev)
+            if args.table_nodes:
+                integ.table_nodes = args.table_nodes
+            obs = rdf(system, nbins=100, r_range=(0.75, 2.4))
+            tf, tb = run(integ, system, obs, args.steps, 0.005)
+        elif w == "lj4096":
             n = 16
             L = (n ** 3 / 0.845) ** (1 / 3)
             g = np.stack(np.meshgrid(*[np.arange(n)] * 3, indexing="ij"), -1).reshape(-1, 3) * (L / n)
