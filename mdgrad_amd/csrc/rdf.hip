@@ -340,6 +340,9 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             fetch(rB, pB, lane + 64 < total, cb, ib, jb, vb);
             locate2(ca, cb, ia, ja, ib, jb, va, vb);
         }
+        // (measured: a single row of fixed-point counters per wave updated with ds_add_u32 -- 2 KB of LDS
+        //  instead of 32 KB, many waves per SIMD -- is 3.5x SLOWER: the lanes of a wave hit the same few
+        //  bins around the g(r) peak and the atomics serialise; the lane-private columns never conflict.)
         // (measured: the kernel is VALU-issue bound at one wave per SIMD -- pinning a latency-optimal
         //  load/compute order with scheduling barriers, or prefetching the rows a stage early, is 4-7 % slower
         //  than the compiler's own schedule)
