@@ -902,3 +902,18 @@ def test_tabulated_pair_module_fused_matches_generic(ensemble):
     close(q_f, q_g, 1e-4, 1e-5, "q_t")
     close(gq_f, gq_g, 2e-3, 1e-4 * float(gq_g.abs().max()), "dL/dq0")
     close(gth_f, gth_g, 5e-3, 3e-4 * float(gth_g.abs().max()), "dL/dtheta")
+
+
+def test_fit_rdf_pairmlp_example_learns():
+    """examples/fit_rdf_pairmlp.py (the loop of scripts/fit_rdf_pair.py on the tabulated fused path):
+    the JS + MSE loss against the target RDF falls."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "fit_rdf_pairmlp", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples",
+                                        "fit_rdf_pairmlp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    hist = mod.main(["--replicas", "128", "--epochs", "30"])
+    first, last = np.mean([h[0] for h in hist[:3]]), np.mean([h[0] for h in hist[-3:]])
+    assert np.isfinite(last) and last < 0.6 * first, "loss %.4f -> %.4f" % (first, last)
