@@ -9,7 +9,7 @@ from torch.nn import ModuleDict
 
 from . import _lib, ops
 from .potentials import is_builtin_form
-from .topology import compute_dis
+from .topology import compute_dis, get_offsets
 
 
 class GeneralInteraction(torch.nn.Module):
@@ -314,6 +314,50 @@ class TPairPotentials(PairPotentials):
     def forward(self, xyz):
         nbr, off = self._ell.half_list()
         return self._phi(compute_dis(xyz, nbr, off, self.cell)).sum()            # interface.py:207-215
+
+
+class BondPotentials(torch.nn.Module):
+    """Harmonic term in the SQUARED bond length, 1/2 k (|b|^2 - ro)^2 (torchmd/interface.py:406-456; the
+    polymer demo's bonded term).  `top` = [n_bonds, 2] atom indices; orthorhombic minimum image with the
+    non-strict test of topology.get_offsets.  A few torch ops on the device (outside the pair hot path)."""
+
+    def __init__(self, system, top, k, ro):
+        super().__init__()
+        self.device = system.device
+        self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)
+        self.k, self.ro = k, ro
+        self.top = top.to(self.device)
+
+    def _reset_topology(self, xyz):
+        pass
+
+    def forward(self, xyz):
+        b = xyz[self.top[:, 0]] - xyz[self.top[:, 1]]
+        b = b + get_offsets(b, self.cell, self.device) * self.cell
+        return 0.5 * self.k * (b.pow(2).sum(-1) - self.ro).pow(2).sum(-1)
+
+
+class AnglePotentials(torch.nn.Module):
+    """Harmonic angle term 1/2 k (theta - theta0)^2 over triples (i, j, k) centred on j
+    (torchmd/interface.py:457-510)."""
+
+    def __init__(self, system, top, k, thetao):
+        super().__init__()
+        self.device = system.device
+        self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)
+        self.k, self.thetao = k, thetao
+        self.top = top.to(self.device)
+
+    def _reset_topology(self, xyz):          # (absent in the reference, which therefore cannot Stack it)
+        pass
+
+    def forward(self, xyz):
+        b1 = xyz[self.top[:, 0]] - xyz[self.top[:, 1]]
+        b2 = xyz[self.top[:, 2]] - xyz[self.top[:, 1]]
+        b1 = b1 + get_offsets(b1, self.cell, self.device) * self.cell
+        b2 = b2 + get_offsets(b2, self.cell, self.device) * self.cell
+        cos = (b1 * b2).sum(-1) / (b1.pow(2).sum(-1) * b2.pow(2).sum(-1)).sqrt()
+        return 0.5 * self.k * (torch.acos(cos) - self.thetao).pow(2).sum(-1)
 
 
 class Stack(torch.nn.Module):

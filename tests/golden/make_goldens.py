@@ -18,6 +18,7 @@ Golden sets:
   G8 schnet_*   SchNet energy/forces/hvp     nff/nn/models/schnet.py:23-171
   G9 gnn_traj   Stack(GNN+pair) NHC + adj    torchmd/interface.py:86-136,364-403
   G10 sim_*     Simulations 2 epochs         torchmd/md.py:14-96
+  G12 bonded    BondPotentials / AnglePotentials energy + forces   torchmd/interface.py:406-510
   G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
                                              torchmd/potentials.py:163-217, interface.py:139-215
 """
@@ -37,7 +38,8 @@ import torch  # noqa: E402
 from torchmd.topology import generate_nbr_list, compute_dis  # noqa: E402
 from torchmd.system import System  # noqa: E402
 from torchmd import potentials as P  # noqa: E402
-from torchmd.interface import PairPotentials, TPairPotentials, GNNPotentials, Stack  # noqa: E402
+from torchmd.interface import (PairPotentials, TPairPotentials, GNNPotentials, Stack,  # noqa: E402
+                               BondPotentials, AnglePotentials)
 from torchmd.md import NoseHooverChain, NVE, Simulations  # noqa: E402
 from torchmd.sovlers import odeint, odeint_adjoint  # noqa: E402
 from torchmd.observable import rdf  # noqa: E402
@@ -477,8 +479,31 @@ def g11():
     save("pair_mlp", **out)
 
 
+# ------------------------------------------------------------------ G12
+def g12():
+    """BondPotentials / AnglePotentials: a 24-bead chain across the periodic boundary."""
+    rng = np.random.default_rng(7)
+    n, L = 24, 6.0
+    steps = rng.normal(0, 1, (n, 3))
+    steps = 1.1 * steps / np.linalg.norm(steps, axis=1)[:, None]
+    pos = np.mod(np.cumsum(steps, 0) + 2.5, L)
+    cell = np.array([L, L, L])
+    system = make_system(pos, cell)
+    bonds = torch.LongTensor([[i, i + 1] for i in range(n - 1)])
+    angles = torch.LongTensor([[i, i + 1, i + 2] for i in range(n - 2)])
+    out = dict(pos=pos.astype(F32), cell=cell.astype(F32), bonds=bonds.numpy(), angles=angles.numpy(),
+               k_bond=3.0, ro=1.21, k_angle=2.0, theta0=1.9)
+    for tag, mod in [("bond", BondPotentials(system, bonds, 3.0, 1.21)), ("angle", AnglePotentials(system, angles, 2.0, 1.9))]:
+        q = torch.Tensor(pos).requires_grad_(True)
+        u = mod(q)
+        (gq,) = torch.autograd.grad(u, q)
+        out[tag + "_energy"], out[tag + "_force"] = u.detach().reshape(1), -gq
+    save("bonded", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11"]
-    table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11}
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12"]
+    table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11,
+             "g12": g12}
     for w in which:
         table[w]()

@@ -917,3 +917,26 @@ def test_fit_rdf_pairmlp_example_learns():
     hist = mod.main(["--replicas", "128", "--epochs", "30"])
     first, last = np.mean([h[0] for h in hist[:3]]), np.mean([h[0] for h in hist[-3:]])
     assert np.isfinite(last) and last < 0.6 * first, "loss %.4f -> %.4f" % (first, last)
+
+
+def test_bonded_terms_golden():
+    """BondPotentials / AnglePotentials (torchmd/interface.py:406-510) energies and forces against the
+    reference on a chain crossing the periodic boundary, and inside a Stack with a pair term."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import AnglePotentials, BondPotentials, PairPotentials, Stack
+    g = load_golden("bonded")
+    system = mk_system(g["pos"], g["cell"])
+    bonds, angles = torch.as_tensor(g["bonds"]), torch.as_tensor(g["angles"])
+    mods = {"bond": BondPotentials(system, bonds, float(g["k_bond"]), float(g["ro"])),
+            "angle": AnglePotentials(system, angles, float(g["k_angle"]), float(g["theta0"]))}
+    for tag, mod in mods.items():
+        q = T(g["pos"], DEV).requires_grad_(True)
+        u = mod(q)
+        (gq,) = torch.autograd.grad(u, q)
+        close(u.reshape(1), g[tag + "_energy"], 1e-5, 1e-5, tag + " energy")
+        close(-gq, g[tag + "_force"], 1e-4, 1e-5 * float(np.abs(g[tag + "_force"]).max()) + 1e-6, tag + " force")
+    stack = Stack(dict(mods, pair=PairPotentials(system, P.ExcludedVolume(1.0, 1.0, 12), cutoff=2.5)))
+    q = T(g["pos"], DEV).requires_grad_(True)
+    stack._reset_topology(q.detach())
+    (gq,) = torch.autograd.grad(stack(q).sum(), q)
+    assert torch.isfinite(gq).all() and not stack.supports_force_vjp()
