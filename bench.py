@@ -277,6 +277,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         adj_ms = e0.elapsed_time(e1) / reps
+        # phase breakdown of one pass (HIP events on the launch stream): SURVEY 8d defines the metric on
+        # t_fwd + t_adjoint with the RDF reported separately; `value` above is the stricter whole-pass rate
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        opt.zero_grad(set_to_none=True)
+        ev[0].record()
+        v2, q2, p2 = ops.FusedTrajFn.apply(vel, pos, pv0, t, spec.flat_params(), spec)
+        ev[1].record()
+        l2 = (obs(q2)[2] - target).pow(2).mean()
+        ev[2].record()
+        l2.backward()
+        ev[3].record()
+        torch.cuda.synchronize()
+        fwd_ms, rdf_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+        out["config"]["phase_ms"] = {"traj_fwd": fwd_ms, "rdf_fwd": rdf_ms, "rdf_bwd_plus_traj_adj": bwd_ms,
+                                     "traj_adj_kernel": adj_ms}
+        out["config"]["md_steps_per_s_traj_only_per_gpu"] = R * (T - 1) / ((fwd_ms + adj_ms) * 1e-3)
         ell = ops.build_ell(pos[0], spec.cell_struct, 2.5)
         Pn = int(ell.half_list()[0].shape[0])
         N = 108
