@@ -223,6 +223,11 @@ class NVE(_EOM):
         self.update_count = 0
 
     def forward(self, t, state):
+        if not torch.is_grad_enabled() and self.supports_rhs_vjp():
+            # graph-free callers (forward integration): the model's own force kernels, no autograd
+            v, q = state[0], state[1]
+            self.update_topology(q)
+            return (self.model.force(q), v)
         with torch.set_grad_enabled(True):
             v, q = state[0], state[1]
             if self.adjoint:
@@ -231,6 +236,21 @@ class NVE(_EOM):
             u = self.model(q)
             f = -compute_grad(inputs=q, output=u.sum(-1))
         return (f, v)
+
+    # analytic-adjoint protocol (see NoseHooverChain.rhs_vjp): f = (F(q), v) -- no 1/m, md.py:145-148
+    def supports_rhs_vjp(self):
+        return getattr(self.model, "supports_force_vjp", lambda: False)()
+
+    def rhs_vjp(self, state, adj, want_theta=True):
+        v, q = state
+        lv, lq = adj
+        self.update_topology(q)
+        F, dwF_dq, gth = self.model.force_vjp(q, lv, want_theta=want_theta)
+        if not want_theta:
+            return (F, v), (lq, dwF_dq), None
+        by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
+        return (F, v), (lq, dwF_dq), [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p)
+                                      for p in self.parameters()]
 
     def get_inital_states(self, wrap=True):
         states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap)]

@@ -344,3 +344,42 @@ def test_hip_graph_replay_equals_eager(replicas):
     assert len(integ._graph_cache) == 2
     for a, b, name in zip(out4, ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
         close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "after regrow " + name)
+
+
+@pytest.mark.gpu
+def test_nve_generic_analytic_adjoint_equals_autograd():
+    """NVE (torchmd/md.py:98-157) over GNN + prior on the generic path: the analytic-adjoint protocol
+    (NVE.rhs_vjp, the verlet backward branch of sovlers.py:42-101 unchanged) against the reference's
+    autograd double backward."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NVE
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("gnn_traj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12),
+                           cutoff=float(g["cutoff"]))
+    integ = NVE(Stack({"gnn": gnn, "prior": prior}), system).to(DEV)
+    t = torch.Tensor([float(g["dt"]) * i for i in range(6)]).to(DEV)
+    params = list(integ.parameters())
+
+    def run(analytic):
+        gnn.analytic = analytic
+        assert integ.supports_rhs_vjp() == analytic
+        for p_ in params:
+            p_.grad = None
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        v_t, q_t = odeint_adjoint(integ, tuple(y0), t, method="verlet")
+        (q_t[-1].pow(2).mean() + v_t[::2].pow(2).mean()).backward()
+        gth = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in params])
+        return q_t.detach(), y0[0].grad, y0[1].grad, gth
+
+    a, b = run(True), run(False)
+    close(a[0], b[0], 1e-4, 1e-5, "q_t")
+    close(a[1], b[1], 2e-3, 1e-4 * float(b[1].abs().max()), "dL/dv0")
+    close(a[2], b[2], 2e-3, 1e-4 * float(b[2].abs().max()), "dL/dq0")
+    close(a[3], b[3], 5e-3, 2e-4 * float(b[3].abs().max()), "dL/dtheta")
