@@ -140,26 +140,30 @@ def schnet_workload(args, rank, world, dev, mdist):
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
     if rank == 0:
-        # roofline of the MFMA filter kernel (K9) at this workload's edge count
-        topo = integ.model.models["gnn"].inputs["_topo"]
-        E, G, F = topo.n_edges, 30, 128
-        conv = net.convolutions[0].moduledict["message_edge_filter"]
-        d = torch.rand(E, device=dev) * 6.0
-        fa = (d, conv[0].offsets, conv[0].width, conv[1].weight, conv[1].bias, conv[3].weight, conv[3].bias)
-        with torch.no_grad():
-            ops.CfconvFilterFn.apply(*fa)
+        # roofline of the dominant kernel of this workload (profiles/r01d_schnet4096x8_kernel_stats.txt): the
+        # edge-wise f32 GEMM [E,128] x [128,128] of the filter network and of its tangent / reverse sweeps,
+        # issued through the library (hipBLASLt on the bucket-padded edge count, as mdgrad_amd/nn/analytic.py
+        # does); f32 MFMA peak 157.3 TFLOP/s
+        from mdgrad_amd.nn import analytic
+        topo = analytic._stable(integ.model.models["gnn"].inputs["_topo"])
+        E, F = topo.n_edges, 128
+        A_ = torch.randn(E, F, device=dev)
+        W_ = torch.randn(F, F, device=dev)
+        with torch.no_grad(), analytic._blas_for(topo):
+            A_.mm(W_)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(10):
-                ops.CfconvFilterFn.apply(*fa)
+                A_.mm(W_)
             e1.record()
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        flop = 2.0 * E * G * (G + F)
-        out["roofline"] = {"bound": "mfma", "kernel": "cfconv_filter_kernel<32>", "achieved": flop / (ms * 1e-3) / 1e12,
-                           "peak": 157.3, "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None,
-                           "kernel_ms": ms, "note": "f32-input MFMA (exact f32); E=%d edges; the kernel is co-limited "
-                                                    "by the HBM write of W[E,F] (%.0f GB/s)" % (E, 4.0 * E * F / ms / 1e6)}
+        flop = 2.0 * E * F * F
+        out["roofline"] = {"bound": "mfma", "kernel": "library f32 GEMM [E,128]x[128,128] (hipBLASLt)",
+                           "achieved": flop / (ms * 1e-3) / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                           "frac": flop / (ms * 1e-3) / 1e12 / 157.3, "traffic": None, "kernel_ms": ms,
+                           "note": "E=%d padded edges; each row reads 512 B of A and writes 512 B of C for 32 768 flop: "
+                                   "%.0f GB/s of operand traffic alongside the MFMA rate" % (E, 8.0 * E * F / ms / 1e6)}
         print(json.dumps(out))
 
 
