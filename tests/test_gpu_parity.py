@@ -940,3 +940,35 @@ def test_bonded_terms_golden():
     stack._reset_topology(q.detach())
     (gq,) = torch.autograd.grad(stack(q).sum(), q)
     assert torch.isfinite(gq).all() and not stack.supports_force_vjp()
+
+
+@pytest.mark.parametrize("n_side,large", [(10, False), (25, True)])
+def test_fused_kernels_at_their_size_limits(n_side, large):
+    """The one-workgroup kernels at ~their largest system (1 000 of 1 024 atoms, state in 160 KB of LDS)
+    and the multi-launch kernels near theirs (15 625 of 16 384 atoms): 3 steps forward + adjoint against
+    the generic path (reference control flow on the HIP pair ops)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint, OdeintAdjointMethod
+    from mdgrad_amd.tinydiffeq import _flatten
+    pos, cell = liquid(n_side, seed=7, jitter=0.05)
+    vel = np.random.default_rng(2).normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.004 * i for i in range(4)]).to(DEV)
+    res = []
+    for fused in (True, False):
+        system = mk_system(pos, cell, vel)
+        mdl = P.LennardJones(1.0, 1.0)
+        integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3,
+                                Q=30.0).to(DEV)
+        y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+        if fused:
+            spec = integ.fused_spec("NH_verlet")
+            assert spec is not None and bool(spec.large) == large
+            out = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+        else:
+            out = OdeintAdjointMethod.apply(*y0, integ, t, _flatten(integ.parameters()), 1e-6, 1e-12, "NH_verlet", None)
+        (out[1][-1].pow(2).mean() + out[0][-1].pow(2).mean()).backward()
+        res.append([o.detach() for o in out] + [y0[0].grad, y0[1].grad, mdl.sigma.grad, mdl.epsilon.grad])
+    for k, (a, b) in enumerate(zip(*res)):
+        close(a, b, 5e-4, 5e-5 * float(b.abs().max()) + 1e-7, "fused vs generic #%d" % k)
