@@ -306,8 +306,8 @@ int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float*
  *   mdg_nhc_vjp:  Gv = -(pv0/Q0) lv + lq + 2 m v lp0 ;  Gp = lam^T d(bath rhs)/d pv - (lv.v)/Q0 e0
  */
 int mdg_nhc_rhs(const float* v, const float* f, const float* pv, const float* mass, const float* Q,
-                float T, float n_dof, int n_rep, int n_atoms, int n_chains, float* a, float* dpv,
-                void* stream);
+                const float* T /*device, [1]*/, float n_dof, int n_rep, int n_atoms, int n_chains, float* a,
+                float* dpv, void* stream);
 int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, const float* lq, const float* lp,
                 const float* mass, const float* Q, int n_rep, int n_atoms, int n_chains, float* Gv,
                 float* Gp, void* stream);

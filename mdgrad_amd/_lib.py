@@ -70,7 +70,7 @@ _SIGNATURES = {
                               C.c_int, P, P, P]),
     "mdg_rdf_bwd_uniform": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float, C.c_float,
                                       C.c_int, P, P, P]),
-    "mdg_nhc_rhs": (C.c_int, [P, P, P, P, P, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, P, P, P]),
+    "mdg_nhc_rhs": (C.c_int, [P, P, P, P, P, P, C.c_float, C.c_int, C.c_int, C.c_int, P, P, P]),
     "mdg_nhc_vjp": (C.c_int, [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P]),
     "mdg_edge_diff": (C.c_int, [P, P, C.c_int64, C.c_int, P, P]),
     "mdg_edge_scatter": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),

@@ -12,9 +12,10 @@ constexpr int NHC_BLOCK = 256;
 // a = (F - pv0 p / Q0) / m ,  p = m v ;  dpv = bath rhs (md.py:234-236) with KE = 1/2 sum p^2/m
 __global__ __launch_bounds__(NHC_BLOCK) void nhc_rhs_kernel(
     const float* __restrict__ v, const float* __restrict__ f, const float* __restrict__ pv,
-    const float* __restrict__ mass, const float* __restrict__ Q, float T, float n_dof, int n, int C,
-    float* __restrict__ a, float* __restrict__ dpv) {
+    const float* __restrict__ mass, const float* __restrict__ Q, const float* __restrict__ Tp, float n_dof, int n,
+    int C, float* __restrict__ a, float* __restrict__ dpv) {
     __shared__ float red[32];
+    const float T = Tp[0];            // thermostat temperature read from the device: a captured graph follows update_T
     const int r = blockIdx.x;
     const float* vr = v + (size_t)r * n * 3;
     const float* fr = f + (size_t)r * n * 3;
@@ -67,9 +68,9 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhc_vjp_kernel(
 }  // namespace
 
 extern "C" int mdg_nhc_rhs(const float* v, const float* f, const float* pv, const float* mass, const float* Q,
-                           float T, float n_dof, int n_rep, int n_atoms, int n_chains, float* a, float* dpv,
+                           const float* T, float n_dof, int n_rep, int n_atoms, int n_chains, float* a, float* dpv,
                            void* stream) {
-    MDG_CHECK_ARG(v && f && pv && mass && Q && a && dpv, "nhc_rhs: null buffer");
+    MDG_CHECK_ARG(v && f && pv && mass && Q && T && a && dpv, "nhc_rhs: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2, "nhc_rhs: bad sizes R=%d n=%d C=%d", n_rep, n_atoms, n_chains);
     hipLaunchKernelGGL(nhc_rhs_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, f, pv, mass, Q, T,
                        n_dof, n_atoms, n_chains, a, dpv);

@@ -13,7 +13,7 @@ captured once into a HIP graph and replayed per step.  What makes the capture po
     T-1 graph launches and nothing else.
 
 The arithmetic is the eager path's (same functions, same order): results are bitwise identical.
-Graphs are cached on the integrator per (kind, shapes, T, thermostat temperature, capacities).
+Graphs are cached on the integrator per (kind, shapes, frames, capacities, parameter identities).
 """
 import os
 
@@ -65,7 +65,9 @@ def _too_large(func):
 
 
 def _key(func, kind, y, T):
-    return (kind, tuple(tuple(x.shape) for x in y), int(T), float(func.T), func.model.static_version(),
+    # (the thermostat temperature is read from a device scalar, see NoseHooverChain._T_device: annealing
+    #  schedules that call update_T every epoch keep their graphs)
+    return (kind, tuple(tuple(x.shape) for x in y), int(T), func.model.static_version(),
             tuple(id(p) for p in func.parameters()))
 
 

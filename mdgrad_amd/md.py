@@ -286,6 +286,18 @@ class NoseHooverChain(_EOM):
 
     def update_T(self, T):
         self.T = T
+        self._T_device()
+
+    def _T_device(self):
+        """self.T mirrored in a device scalar (what the thermostat kernel reads)."""
+        buf = getattr(self, "_T_buf", None)
+        if buf is None or buf.device != self.mass.device:
+            buf = self._T_buf = torch.empty(1, device=self.mass.device)
+            self._T_val = None
+        if self._T_val != float(self.T):
+            self._T_val = float(self.T)
+            buf.fill_(self._T_val)
+        return buf
 
     def supports_rhs_vjp(self):
         return getattr(self.model, "supports_force_vjp", lambda: False)()
@@ -359,7 +371,7 @@ class NoseHooverChain(_EOM):
         own kinetic energy / friction (identical arithmetic per replica)."""
         v, q, p_v = state
         if self._hip_algebra(v, f, p_v):
-            a, dpv = ops.nhc_rhs(v, f, p_v, self.mass, self.Q, float(self.T), self.N_dof, self.n_rep, self.n_group)
+            a, dpv = ops.nhc_rhs(v, f, p_v, self.mass, self.Q, self._T_device(), self.N_dof, self.n_rep, self.n_group)
             return (a, v, dpv)
         p = v * self.mass[:, None]
         if p_v.dim() == 1:

@@ -418,13 +418,14 @@ class RdfRawFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------- thermostat algebra
 def nhc_rhs(v, f, pv, mass, Q, T, n_dof, n_rep, n_group):
-    """(a, dpv) of NoseHooverChain.forward given the force (torchmd/md.py:221-240), one launch."""
+    """(a, dpv) of NoseHooverChain.forward given the force (torchmd/md.py:221-240), one launch.
+    T: device tensor [1] (read by the kernel, so that a captured graph follows update_T)."""
     lib = _lib.load()
     for t_, nm in ((v, "v"), (f, "f"), (pv, "p_v")):
         require_gpu(t_, nm)
     v, f, pv = v.contiguous(), f.contiguous(), pv.contiguous()
     a, dpv = torch.empty_like(v), torch.empty_like(pv)
-    check(lib.mdg_nhc_rhs(ptr(v), ptr(f), ptr(pv), ptr(mass), ptr(Q), float(T), float(n_dof), int(n_rep),
+    check(lib.mdg_nhc_rhs(ptr(v), ptr(f), ptr(pv), ptr(mass), ptr(Q), ptr(T), float(n_dof), int(n_rep),
                           int(n_group), int(pv.shape[-1]), ptr(a), ptr(dpv), stream_ptr(v.device)), "mdg_nhc_rhs")
     return a, dpv
 

@@ -328,6 +328,18 @@ def test_hip_graph_replay_equals_eager(replicas):
     assert all(integ._graph_cache[k] is v for k, v in cached.items()), "graphs reused"
     for a, b in zip(out2, out):
         assert torch.equal(a, b), "replay is reproducible"
+    # a new thermostat temperature (annealing schedules call update_T every epoch) reuses the graphs
+    T0 = integ.T
+    integ.update_T(1.7 * T0)
+    hot = _traj_and_grads(integ, system, t)
+    assert all(integ._graph_cache[k] is v for k, v in cached.items()), "graphs survive update_T"
+    integ.use_graphs = False
+    hot_ref = _traj_and_grads(integ, system, t)
+    integ.use_graphs = True
+    for a, b, name in zip(hot, hot_ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "graph vs eager after update_T " + name)
+    assert float((hot[2] - out[2]).abs().max()) > 0, "the new temperature reached the captured kernels"
+    integ.update_T(T0)
     # exact-size lists again outside the graphed passes (the autograd path must not see padding rows)
     gnn = integ.model.models["gnn"]
     assert not gnn._static_on and int(gnn.inputs["nbr_list"].min()) >= 0
