@@ -18,6 +18,7 @@ Golden sets:
   G8 schnet_*   SchNet energy/forces/hvp     nff/nn/models/schnet.py:23-171
   G9 gnn_traj   Stack(GNN+pair) NHC + adj    torchmd/interface.py:86-136,364-403
   G10 sim_*     Simulations 2 epochs         torchmd/md.py:14-96
+  G13 exp_rdf   get_exp_rdf target normalisation                   scripts/data.py:11-31
   G12 bonded    BondPotentials / AnglePotentials energy + forces   torchmd/interface.py:406-510
   G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
                                              torchmd/potentials.py:163-217, interface.py:139-215
@@ -501,9 +502,27 @@ def g12():
     save("bonded", **out)
 
 
+# ------------------------------------------------------------------ G13
+def g13():
+    """get_exp_rdf (scripts/data.py:11-31): target g(r) on the observable's grid from tabulated data.
+    scripts/data.py cannot be imported as a module here (its module-level tables need torchcubicspline), so
+    only that function is compiled out of the reference file and run."""
+    import ast
+    from scipy import interpolate
+    from torchmd.observable import generate_vol_bins
+    src = open("/root/reference/scripts/data.py").read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "get_exp_rdf"]
+    ns = dict(torch=torch, np=np, interpolate=interpolate, generate_vol_bins=generate_vol_bins)
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "scripts/data.py", "exec"), ns)
+    r = np.linspace(0.5, 8, 200)
+    g = 1 + np.exp(-(r - 3) ** 2) * np.cos(4 * r)
+    x, g_obs = ns["get_exp_rdf"](np.stack([r, g]).T, 33, (1.0, 7.5), "cpu")
+    save("exp_rdf", r=r.astype(F32), g=g.astype(F32), x=x.astype(F32), g_obs=g_obs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13"]
     table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11,
-             "g12": g12}
+             "g12": g12, "g13": g13}
     for w in which:
         table[w]()
