@@ -1,3 +1,4 @@
+"""cProfile of a stacked SchNet forward pass (host-side launch cost): python tools/prof_fwd.py [replicas] [bwd]"""
 import cProfile, pstats, io, sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

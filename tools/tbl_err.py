@@ -1,3 +1,5 @@
+"""Accuracy of the tabulated pair path (MDG_PAIR_TABLE) against the reference golden as a function of the
+node count: python tools/tbl_err.py   (MI355X)"""
 import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import numpy as np, torch
