@@ -90,6 +90,10 @@ struct PairOut {
     float u, du, d2u;
     float du_dth[MDG_MAX_THETA];
     float ddu_dth[MDG_MAX_THETA];
+    // MDG_PAIR_TABLE only: first node of the bracketing cell and the four Hermite basis values there
+    // (d phi'/d node = r * basis: the table gradient is a scatter, not a du_dth entry)
+    int tg;
+    float tb[4];
 };
 
 // Per-term constants hoisted out of the pair loop (parameters live in global memory).
@@ -97,14 +101,20 @@ struct TermConst {
     int kind, p, q;
     float c, rc2;
     float k0, k1, k2, k3, k4;   // LJ: sig, eps, 1/sig | Morse: a, phi, A, 1/(1+A) | Buck: A,B,C | Yukawa: eps,kappa
+                                // Table: k0 = u0, k1 = 1/du, k2 = nodes - 1 - eps
+    const float* tab;           // Table: [2 p] nodes (c1_g, du * dc1/du_g) in global memory (L1/L2 resident)
 };
 
 __device__ __forceinline__ TermConst term_prepare(const MdgPairTerm& t, const float* __restrict__ theta) {
     TermConst c;
     c.kind = t.kind; c.p = t.p; c.q = t.q; c.c = t.c; c.rc2 = t.cutoff * t.cutoff;
     c.k0 = c.k1 = c.k2 = c.k3 = c.k4 = 0.f;
+    c.tab = nullptr;
     const float* th = theta + t.theta_off;
     switch (t.kind) {
+    case MDG_PAIR_TABLE:
+        c.k0 = t.a; c.k1 = 1.f / t.phi; c.k2 = (float)(t.p - 1) - 1e-3f; c.tab = th;
+        break;
     case MDG_PAIR_LJ: c.k0 = th[0]; c.k1 = th[1]; c.k2 = 1.0f / th[0]; break;
     case MDG_PAIR_MORSE: {
         c.k0 = t.a; c.k1 = t.phi;
@@ -186,6 +196,30 @@ __device__ __forceinline__ void pair_eval(const TermConst& tc, float d2, float& 
                 o.ddu_dth[2] = 6.f * ir6 * ir;
             }
         }
+    } break;
+    case MDG_PAIR_TABLE: {
+        // c1(u) = phi'(r)/r and its u-derivative from the cubic-Hermite table (see traj_small.hip,
+        // force_table_packed): phi' = c1 r, phi'' = 2 u dc1/du + c1
+        const float tt = fminf(fmaxf((d2 - tc.k0) * tc.k1, 0.f), tc.k2);
+        const int g = (int)tt;
+        const float fr = tt - (float)g;
+        const float2 n0 = *reinterpret_cast<const float2*>(tc.tab + 2 * g);
+        const float2 n1 = *reinterpret_cast<const float2*>(tc.tab + 2 * g + 2);
+        const float om = 1.f - fr, fr2 = fr * fr, om2 = om * om;
+        o.tg = g;
+        o.tb[0] = (1.f + 2.f * fr) * om2; o.tb[1] = fr * om2; o.tb[2] = fr2 * (3.f - 2.f * fr); o.tb[3] = fr2 * (fr - 1.f);
+        const float c1 = o.tb[0] * n0.x + o.tb[1] * n0.y + o.tb[2] * n1.x + o.tb[3] * n1.y;
+        o.u = 0.f;                                   // (the energy is not tabulated: forces and HVP only)
+        if (LEVEL >= 1) {
+            o.du = c1 * r;
+            if (LEVEL >= 2) {
+                const float c1u = (6.f * fr * (fr - 1.f) * (n0.x - n1.x) + ((3.f * fr - 4.f) * fr + 1.f) * n0.y +
+                                   (3.f * fr - 2.f) * fr * n1.y) * tc.k1;
+                o.d2u = 2.f * c1u * d2 + c1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < MDG_MAX_THETA; ++k) { o.du_dth[k] = 0.f; o.ddu_dth[k] = 0.f; }
     } break;
     default: {  // MDG_PAIR_YUKAWA
         const float eps = tc.k0, kap = tc.k1;

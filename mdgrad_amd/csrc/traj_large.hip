@@ -44,6 +44,7 @@ struct LargeArgs {
     float *lp, *lph, *pvm;                   // [R][16]
     float *partN;                            // [R][nb][LG_NV]
     float *gth;                              // [R][K_total]
+    int32_t *ghi, *glo;                      // MDG_PAIR_TABLE: fixed-point table gradient, two planes [R][K_total]
     float *adj_v0, *adj_q0, *adj_pv0, *adj_theta;
     int nbF, nbE;                            // workgroups of the per-atom / per-element kernels
     int step;                                // forward: step index k; adjoint: frame index i
@@ -80,7 +81,7 @@ template <bool DIAG, int LEVEL>
 __device__ __forceinline__ void wave_neighbours_and_force(
     const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
     float* tile, float4* buf, float& fx, float& fy, float& fz, float& gx, float& gy, float& gz,
-    float (&th)[LG_KMAX], const TermConst (&tc)[MDG_MAX_TERMS], float rc2max) {
+    float (&th)[LG_KMAX], const TermConst (&tc)[MDG_MAX_TERMS], float rc2max, float gw = 0.f, int rep = 0) {
     const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
     const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
     int n = 0;
@@ -138,9 +139,27 @@ __device__ __forceinline__ void wave_neighbours_and_force(
                 const float a = rx * ax + ry * ay + rz * az;
                 const float c2 = o.d2u * a - c1 * a;
                 gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
+                if (tc[m].kind == MDG_PAIR_TABLE) {
+                    // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (two int32
+                    // planes, see traj_small.hip) with integer global atomics: order-independent
+                    if (gw != 0.f) {
+                        const float x = -gw * a * r;                         // D . w_ij = -a r
+                        int32_t* hi = A.ghi + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
+                        int32_t* lo = A.glo + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
 #pragma unroll
-                for (int p = 0; p < MDG_MAX_THETA; ++p)
-                    if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
+                        for (int b_ = 0; b_ < 4; ++b_) {
+                            const float val = x * o.tb[b_];
+                            if (fabsf(val) >= 3.5e13f) atomicOr(&A.flags[2], 1);          // 2^45: out of range
+                            const float vh_ = rintf(val * (1.f / 1048576.f));
+                            atomicAdd(hi + b_, (int)vh_);
+                            atomicAdd(lo + b_, (int)rintf(fmaf(vh_, -1048576.f, val)));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int p = 0; p < MDG_MAX_THETA; ++p)
+                        if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
+                }
             }
         }
     }
@@ -289,8 +308,10 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
+    // (table kind: the parameter term of an interval comes from the midpoint evaluation with weight h, :160)
+    const float gw = (second && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
     wave_neighbours_and_force<DIAG, 2>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
-                                       tc, rc2max);
+                                       tc, rc2max, gw, rep);
     float vals[LG_NV];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) vals[p] = th[p];
@@ -403,8 +424,16 @@ __global__ __launch_bounds__(256) void large_adj_end(const LargeArgs A) {
     }
 }
 
+// fixed point -> float table gradient
+__global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t* __restrict__ glo, size_t n, float scale,
+                                 float* __restrict__ out) {
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) out[k] = (float)(((double)ghi[k] * 1048576.0 + (double)glo[k]) / (double)scale);
+}
+
 struct WsLayout {
-    size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, flags, total;
+    size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
+        total;
 };
 
 WsLayout ws_layout(int R, int N, int nb, int KT) {
@@ -419,6 +448,8 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
     w.partA = take((size_t)R * nbmax); w.partB = take((size_t)R * nbmax);
     w.partN = take((size_t)R * nbmax * LG_NV);
     w.gth = take((size_t)R * (KT > 0 ? KT : 1));
+    w.ghi = take((size_t)R * (KT > 0 ? KT : 1));        // (int32 planes of the table kind; a few words otherwise)
+    w.glo = take((size_t)R * (KT > 0 ? KT : 1));
     w.flags = take(16);
     w.total = o;
     return w;
@@ -430,6 +461,13 @@ int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* 
     MDG_CHECK_ARG(p->ensemble == 0, "traj_large: NoseHooverChain only (NVE runs the small or generic path)");
     MDG_CHECK_ARG(p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS, "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
     MDG_CHECK_ARG(terms->n_terms >= 1 && terms->n_terms <= MDG_MAX_TERMS, "traj_large: 1..%d pair terms", MDG_MAX_TERMS);
+    for (int m = 0; m < terms->n_terms; ++m) {
+        const MdgPairTerm& t = terms->t[m];
+        if (t.kind != MDG_PAIR_TABLE) continue;
+        MDG_CHECK_ARG(terms->n_terms == 1 && !t.mask, "traj_large: a tabulated pair model must be the only term, unmasked");
+        MDG_CHECK_ARG(t.p >= 4 && t.p <= 4096 && t.n_theta == 2 * t.p && t.phi > 0.f && t.c > 0.f,
+                      "traj_large: bad table (nodes %d, n_theta %d, du %g, scale %g)", t.p, t.n_theta, t.phi, t.c);
+    }
     return MDG_OK;
 }
 
@@ -454,6 +492,9 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     a.pv = ws + L.pv; a.ph = ws + L.ph; a.pvh = ws + L.pvh; a.lp = ws + L.lp; a.lph = ws + L.lph;    \
     a.pvm = ws + L.pvm; a.partA = ws + L.partA; a.partB = ws + L.partB; a.partN = ws + L.partN;      \
     a.gth = ws + L.gth; a.flags = flags; a.nbF = nbF; a.nbE = nbE;                                               \
+    const bool table = terms->t[0].kind == MDG_PAIR_TABLE;                                           \
+    a.ghi = table ? reinterpret_cast<int32_t*>(ws + L.ghi) : nullptr;                                \
+    a.glo = table ? reinterpret_cast<int32_t*>(ws + L.glo) : nullptr;                                \
     hipStream_t st = (hipStream_t)stream;                                                            \
     const bool diag = cell->diag != 0;                                                               \
     (void)nbmax;
@@ -514,6 +555,10 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         else hipMemsetAsync(a.lp + r * MDG_MAX_CHAINS, 0, sizeof(float) * MDG_MAX_CHAINS, st);
     }
     hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st);
+    if (table) {
+        hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st);
+        hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st);
+    }
     dim3 gF(nbF, R), gE(nbE, R);
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
@@ -528,7 +573,11 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
     hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
                      hipMemcpyDeviceToDevice, st);
-    if (adj_theta && KT > 0)
+    if (adj_theta && table) {
+        const size_t n = (size_t)R * KT;
+        hipLaunchKernelGGL(large_table_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.ghi, a.glo, n,
+                           terms->t[0].c, adj_theta);
+    } else if (adj_theta && KT > 0)
         hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st);
     MDG_CHECK_LAUNCH("traj_adj_large");
     return MDG_OK;

@@ -164,13 +164,16 @@ class _EOM(torch.nn.Module):
             return None
         mods = _pair_terms_of(self.model)
         N = getattr(self.system, "group_size", self.mass.shape[0])      # atoms per replica
-        if mods is None and self.adjoint and self.fused_table and N <= FUSED_MAX_ATOMS:
+        table_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
+        if (mods is None and self.adjoint and self.fused_table
+                and (N <= FUSED_MAX_ATOMS_LARGE and self._ensemble == 0 if table_large else N <= FUSED_MAX_ATOMS)):
             members = _table_members(self.model)
             if members is not None and (self._ensemble == 1 or 2 <= self.num_chains <= 16):
                 kw = {} if self._ensemble != 0 else dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
                 nodes = int(self.table_nodes)
                 spec = _TableSpec(self, members, nodes, self.table_rmin * float(members[0].cutoff), self._ensemble, N,
-                                  self.mass[:N].contiguous(), members[0]._cell_struct, None, 2 * nodes, [None], **kw)
+                                  self.mass[:N].contiguous(), members[0]._cell_struct, None, 2 * nodes, [None],
+                                  large=table_large, **kw)
                 desc = dict(kind=ops.MDG_PAIR_TABLE, p=nodes, a=spec.u0, phi=spec.du, c=1.0)
                 spec.terms = ops.make_terms([ops.make_term(desc, members[0].cutoff, 0, 2 * nodes, None)], 2 * nodes)
                 spec.n_rep = getattr(self.system, "n_replicas", 1)

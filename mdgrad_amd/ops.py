@@ -289,7 +289,7 @@ class FusedTrajFn(torch.autograd.Function):
         ctx.ws = None
         if spec.large:
             ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, spec.n_theta_total)), device=dev)
-            flags = torch.zeros(2, dtype=torch.int32, device=dev)
+            flags = torch.zeros(4, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
                                          ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
@@ -342,15 +342,25 @@ class FusedTrajFn(torch.autograd.Function):
         KT = spec.n_theta_total
         adj_th = torch.zeros(R, KT, device=dev) if KT else None
         prm = spec.params(R, T)
-        if spec.large:
-            flags = torch.zeros(2, dtype=torch.int32, device=dev)
-            check(lib.mdg_traj_adj_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+        table = getattr(spec, "table", False)
+
+        def launch(terms):
+            if spec.large:
+                flags = torch.zeros(4, dtype=torch.int32, device=dev)
+                check(lib.mdg_traj_adj_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                             ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                             ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
+                                             ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
+                return flags
+            check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
-                                         ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
-                                         ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
-        elif getattr(spec, "table", False):
+                                         ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                         stream_ptr(dev)), "mdg_traj_adj_small")
+            return None
+
+        if table:
             # fixed-point scale of the in-kernel table-gradient scatter: the largest single contribution
-            # 1/2 h (D . w_ij) is put near 2^30 (the kernel accepts up to 2^45); one host sync
+            # 1/2 h (D . w_ij) is put near 2^30 (the kernels accept up to 2^45); one host sync
             lam = max([float(g.abs().max()) for g in (gv, gq) if g is not None] + [1e-30])
             h = float((tc[1:] - tc[:-1]).abs().max())
             est = max(0.5 * h * 2.0 * spec.terms.t[0].cutoff * lam / float(spec.mass.min()), 1e-30)
@@ -358,21 +368,16 @@ class FusedTrajFn(torch.autograd.Function):
             for attempt in range(4):
                 terms = type(spec.terms).from_buffer_copy(spec.terms)
                 terms.t[0].c = 2.0 ** S
-                check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
-                                             ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
-                                             ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
-                                             stream_ptr(dev)), "mdg_traj_adj_small")
-                if bool(torch.isfinite(adj_th[:, 0]).all()):
+                flags = launch(terms)
+                bad = bool(flags[2].item()) if flags is not None else not bool(torch.isfinite(adj_th[:, 0]).all())
+                if not bad:
                     break
                 S -= 14                                    # adjoint grew past the range: coarser fixed point
             else:
                 raise RuntimeError("mdgrad_amd: the table-gradient accumulation overflowed (adjoint magnitudes "
                                    "above 2^%d of the incoming gradients)" % (45 - S))
         else:
-            check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
-                                         ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
-                                         ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
-                                         stream_ptr(dev)), "mdg_traj_adj_small")
+            launch(spec.terms)
         if not ctx.batched:
             adj_v, adj_q = adj_v[0], adj_q[0]
             adj_p = adj_p[0] if nhc else None
