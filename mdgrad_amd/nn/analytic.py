@@ -283,4 +283,11 @@ def _force_vjp(net, z, x, w, topo, offsets, want_theta=True):
     emb[uniq] = _atb(onehot, rb)                  # [S, N] x [N, A] on the split-K kernel when N is large
     grads[id(net.atom_embed.weight)] = emb
     # w.F = -U_dot
-    return fw["U"], F, -xb, [-grads[id(p)].reshape(p.shape) for p in net.parameters()]
+    # one negation for all parameters (views of a flat buffer) instead of one tiny kernel per tensor
+    plist = list(net.parameters())
+    flat = torch.cat([grads[id(p)].reshape(-1) for p in plist]).neg_()
+    out, pos = [], 0
+    for p in plist:
+        out.append(flat[pos:pos + p.numel()].reshape(p.shape))
+        pos += p.numel()
+    return fw["U"], F, -xb, out
