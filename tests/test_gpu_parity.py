@@ -571,6 +571,12 @@ def test_rdf_kernel_variants_agree():
     a = ops.RdfRawFn.apply(xs, mu, coeff, 3.0, cs, mask, spacing)
     b = ops.RdfRawFn.apply(xs, mu, coeff, 3.0, cs, mask, 0.0)
     close(a, b, 2e-5, 1e-6 * float(b.max()), "masked lane vs direct")
+    grads = []
+    for sp in (spacing, 0.0):                       # backward: fine-grid table kernel vs direct sum
+        xg = T(sub, DEV).requires_grad_(True)
+        (gx,) = torch.autograd.grad((ops.RdfRawFn.apply(xg, mu, coeff, 3.0, cs, mask, sp) * w).sum(), xg)
+        grads.append(gx)
+    close(grads[0], grads[1], 1e-4, 3e-5 * float(grads[1].abs().max()), "masked odd-N backward, table vs direct")
 
 
 @pytest.mark.parametrize("replicas,chains", [(1, 5), (3, 2), (4, 3)])
