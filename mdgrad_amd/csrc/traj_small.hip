@@ -25,6 +25,8 @@ struct TrajArgs {
     const float* g_v; const float* g_q; const float* g_pv;    // adj inputs
     float* adj_v0; float* adj_q0; float* adj_pv0; float* adj_theta;
     int32_t* nonfinite;
+    int ld;                 // leading dimension of the SoA [3][ld] LDS arrays: 128 for N <= 128 (compile-time
+                            // offsets, 8-byte pair loads in the packed loops), N rounded up to even otherwise
 };
 
 constexpr int KMAX_ALL = MDG_MAX_TERMS * MDG_MAX_THETA;
@@ -47,7 +49,7 @@ template <int LEVEL>
 __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, float& th_sig, float& th_eps) {
-    const int N = A.prm.n_atoms;
+    const int N = A.prm.n_atoms, LD = A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -58,19 +60,19 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
     const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
     f32x2 ts = {0.f, 0.f}, te = {0.f, 0.f};
     for (int i = slot; i < N; i += slots) {
-        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
         for (int j = sub; j < N; j += 2 * TPA) {
             const bool live2 = j + TPA < N;
             const int j2 = live2 ? j + TPA : j;
-            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[N + j] - yi, q[N + j2] - yi},
-                  dz = {q[2 * N + j] - zi, q[2 * N + j2] - zi};                    // D = x_j - x_i
+            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[LD + j] - yi, q[LD + j2] - yi},
+                  dz = {q[2 * LD + j] - zi, q[2 * LD + j2] - zi};                    // D = x_j - x_i
             f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
             if (LEVEL >= 2) {
-                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[N + j], wyi - w[N + j2]};
-                az = f32x2{wzi - w[2 * N + j], wzi - w[2 * N + j2]};
+                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[LD + j], wyi - w[LD + j2]};
+                az = f32x2{wzi - w[2 * LD + j], wzi - w[2 * LD + j2]};
             }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
@@ -104,8 +106,8 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
             ux = group_sum_rt(gx.x + gx.y, TPA); uy = group_sum_rt(gy.x + gy.y, TPA); uz = group_sum_rt(gz.x + gz.y, TPA);
         }
         if (sub == 0) {
-            f[i] = sx; f[N + i] = sy; f[2 * N + i] = sz;
-            if (LEVEL >= 2) { dq[i] = ux; dq[N + i] = uy; dq[2 * N + i] = uz; }
+            f[i] = sx; f[LD + i] = sy; f[2 * LD + i] = sz;
+            if (LEVEL >= 2) { dq[i] = ux; dq[LD + i] = uy; dq[2 * LD + i] = uz; }
         }
     }
     th_sig += ts.x + ts.y;
@@ -138,7 +140,7 @@ template <int LEVEL>
 __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, const TableRef& T, float& vmax) {
-    const int N = A.prm.n_atoms;
+    const int N = A.prm.n_atoms, LD = A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -149,19 +151,19 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
     const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
     const bool acc = LEVEL >= 2 && T.ghi != nullptr;
     for (int i = slot; i < N; i += slots) {
-        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
         for (int j = sub; j < N; j += 2 * TPA) {
             const bool live2 = j + TPA < N;
             const int j2 = live2 ? j + TPA : j;
-            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[N + j] - yi, q[N + j2] - yi},
-                  dz = {q[2 * N + j] - zi, q[2 * N + j2] - zi};                    // D = x_j - x_i
+            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[LD + j] - yi, q[LD + j2] - yi},
+                  dz = {q[2 * LD + j] - zi, q[2 * LD + j2] - zi};                    // D = x_j - x_i
             f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
             if (LEVEL >= 2) {
-                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[N + j], wyi - w[N + j2]};
-                az = f32x2{wzi - w[2 * N + j], wzi - w[2 * N + j2]};
+                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[LD + j], wyi - w[LD + j2]};
+                az = f32x2{wzi - w[2 * LD + j], wzi - w[2 * LD + j2]};
             }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
@@ -206,8 +208,8 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
             ux = group_sum_rt(gx.x + gx.y, TPA); uy = group_sum_rt(gy.x + gy.y, TPA); uz = group_sum_rt(gz.x + gz.y, TPA);
         }
         if (sub == 0) {
-            f[i] = sx; f[N + i] = sy; f[2 * N + i] = sz;
-            if (LEVEL >= 2) { dq[i] = ux; dq[N + i] = uy; dq[2 * N + i] = uz; }
+            f[i] = sx; f[LD + i] = sy; f[2 * LD + i] = sz;
+            if (LEVEL >= 2) { dq[i] = ux; dq[LD + i] = uy; dq[2 * LD + i] = uz; }
         }
     }
 }
@@ -225,7 +227,7 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
         force_table_packed<LEVEL>(A, tpa_log2, q, w, f, dq, TB, vmax);
         return;
     }
-    const int N = A.prm.n_atoms;
+    const int N = A.prm.n_atoms, LD = A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -245,15 +247,15 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
         constexpr int NTH = kind_ntheta(KIND == KIND_LJ126 ? MDG_PAIR_LJ : KIND);
         const TermConst t0 = tc[0];
         for (int i = slot; i < N; i += slots) {
-            const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+            const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
             float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-            if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+            if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
             float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll 2
             for (int j = sub; j < N; j += TPA) {
-                float dx = q[j] - xi, dy = q[N + j] - yi, dz = q[2 * N + j] - zi;   // D = x_j - x_i
+                float dx = q[j] - xi, dy = q[LD + j] - yi, dz = q[2 * LD + j] - zi;   // D = x_j - x_i
                 float ax = 0.f, ay = 0.f, az = 0.f;
-                if (LEVEL >= 2) { ax = wxi - w[j]; ay = wyi - w[N + j]; az = wzi - w[2 * N + j]; }
+                if (LEVEL >= 2) { ax = wxi - w[j]; ay = wyi - w[LD + j]; az = wzi - w[2 * LD + j]; }
                 min_image<DIAG>(A.cell, dx, dy, dz);
                 const float d2 = norm2_ref(dx, dy, dz);
                 const bool ok = (d2 != 0.f) && (d2 < t0.rc2);                       // topology.py:67
@@ -276,19 +278,19 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
             fx = group_sum_rt(fx, TPA); fy = group_sum_rt(fy, TPA); fz = group_sum_rt(fz, TPA);
             if (LEVEL >= 2) { gx = group_sum_rt(gx, TPA); gy = group_sum_rt(gy, TPA); gz = group_sum_rt(gz, TPA); }
             if (sub == 0) {
-                f[i] = fx; f[N + i] = fy; f[2 * N + i] = fz;
-                if (LEVEL >= 2) { dq[i] = gx; dq[N + i] = gy; dq[2 * N + i] = gz; }
+                f[i] = fx; f[LD + i] = fy; f[2 * LD + i] = fz;
+                if (LEVEL >= 2) { dq[i] = gx; dq[LD + i] = gy; dq[2 * LD + i] = gz; }
             }
         }
         return;
     }
     for (int i = slot; i < N; i += slots) {
-        const float xi = q[i], yi = q[N + i], zi = q[2 * N + i];
+        const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-        if (LEVEL >= 2) { wxi = w[i]; wyi = w[N + i]; wzi = w[2 * N + i]; }
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
         for (int j = sub; j < N; j += TPA) {
-            float dx = q[j] - xi, dy = q[N + j] - yi, dz = q[2 * N + j] - zi;   // D = x_j - x_i
+            float dx = q[j] - xi, dy = q[LD + j] - yi, dz = q[2 * LD + j] - zi;   // D = x_j - x_i
             min_image<DIAG>(A.cell, dx, dy, dz);
             const float d2 = norm2_ref(dx, dy, dz);
             if (d2 == 0.f) continue;                                           // topology.py:67
@@ -305,7 +307,7 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
                 fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
                 if (LEVEL >= 2) {
                     const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
-                    const float ax = wxi - w[j], ay = wyi - w[N + j], az = wzi - w[2 * N + j];
+                    const float ax = wxi - w[j], ay = wyi - w[LD + j], az = wzi - w[2 * LD + j];
                     const float a = rx * ax + ry * ay + rz * az;
                     const float c2 = o.d2u * a - c1 * a, c3 = c1;
                     // hv = phi'' a rhat + (phi'/r)(wij - a rhat) = (phi'' - phi'/r) a rhat + (phi'/r) wij
@@ -321,8 +323,8 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
         fx = group_sum_rt(fx, TPA); fy = group_sum_rt(fy, TPA); fz = group_sum_rt(fz, TPA);
         if (LEVEL >= 2) { gx = group_sum_rt(gx, TPA); gy = group_sum_rt(gy, TPA); gz = group_sum_rt(gz, TPA); }
         if (sub == 0) {
-            f[i] = fx; f[N + i] = fy; f[2 * N + i] = fz;
-            if (LEVEL >= 2) { dq[i] = gx; dq[N + i] = gy; dq[2 * N + i] = gz; }
+            f[i] = fx; f[LD + i] = fy; f[2 * LD + i] = fz;
+            if (LEVEL >= 2) { dq[i] = gx; dq[LD + i] = gy; dq[2 * LD + i] = gz; }
         }
     }
 }
@@ -338,32 +340,34 @@ __device__ __forceinline__ float bath_rhs(const TrajArgs& A, const float* Q, con
     return (pv[k - 1] * pv[k - 1] / Q[k - 1] - T) - pv[k + 1] * pv[k] / Q[k + 1];
 }
 
-// the 3N degrees of freedom of an SoA [3][N] array without div/mod: e = c * N + i
+// the 3N degrees of freedom of an SoA [3][LD] array without div/mod: e = c * LD + i
 #define MDG_FOR_DOF(e, i, c)    \
     for (int c = 0; c < 3; ++c) \
-        for (int i = threadIdx.x, e = c * N + threadIdx.x; i < N; i += blockDim.x, e += blockDim.x)
+        for (int i = threadIdx.x, e = c * LD + threadIdx.x; i < N; i += blockDim.x, e += blockDim.x)
 
 // AoS [N,3] global  <->  SoA [3][N] LDS
-__device__ __forceinline__ void load_soa(float* dst, const float* __restrict__ src, int N) {
-    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[(e % 3) * N + e / 3] = src[e];
+__device__ __forceinline__ void load_soa(float* dst, const float* __restrict__ src, int N, int LD) {
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[(e % 3) * LD + e / 3] = src[e];
 }
-__device__ __forceinline__ void store_aos(float* __restrict__ dst, const float* src, int N) {
-    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[e] = src[(e % 3) * N + e / 3];
+__device__ __forceinline__ void store_aos(float* __restrict__ dst, const float* src, int N, int LD) {
+    for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) dst[e] = src[(e % 3) * LD + e / 3];
 }
 
 // ------------------------------------------------------------------------------------ forward
 template <bool DIAG, int NT, int KIND>
 __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const int tpa_log2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, LD = A.ld;
     const bool nhc = A.prm.ensemble == 0;
     const int rep = blockIdx.x;
-    float* q = smem;            // [3][N]
-    float* v = q + 3 * N;       // [3][N]
-    float* vh = v + 3 * N;      // [3][N] half-step velocity increment
-    float* f = vh + 3 * N;      // [3][N]
-    float* ms = f + 3 * N;      // [N]
-    float* pv = ms + N;         // [C]
+    float* q = smem;            // [3][LD]
+    float* v = q + 3 * LD;      // [3][LD]
+    float* vh = v + 3 * LD;     // [3][LD] half-step velocity increment
+    float* f = vh + 3 * LD;     // [3][LD]
+    float* ms = f + 3 * LD;     // [LD]
+    float* pv = ms + LD;        // [C]
+    for (int e = threadIdx.x; e < 13 * LD; e += blockDim.x) smem[e] = 0.f;      // padding columns stay finite
+    __syncthreads();
     float* ph = pv + MDG_MAX_CHAINS;
     float* pb = ph + MDG_MAX_CHAINS;
     float* pvh = pb + MDG_MAX_CHAINS;   // [C] pv + ph
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     float vmax_unused = 0.f;
     TableRef TB{nullptr, nullptr, nullptr, 0.f};
     if constexpr (KIND == KIND_TABLE) {                    // table nodes resident in LDS for the whole trajectory
-        float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS + ((13 * N) & 1));       // 8-byte aligned
+        float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS);       // (13 LD + chains + RED_FLOATS is even)
         const float* th = A.theta + A.terms.t[0].theta_off;
         for (int g = threadIdx.x; g < A.terms.t[0].p; g += blockDim.x) tab[g] = make_float2(th[2 * g], th[2 * g + 1]);
         TB.tab = tab;
@@ -383,14 +387,14 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
     const float Q0 = A.prm.Q[0];
 
-    load_soa(q, A.q0 + (size_t)rep * N * 3, N);
-    load_soa(v, A.v0 + (size_t)rep * N * 3, N);
+    load_soa(q, A.q0 + (size_t)rep * N * 3, N, LD);
+    load_soa(v, A.v0 + (size_t)rep * N * 3, N, LD);
     for (int i = threadIdx.x; i < N; i += blockDim.x) ms[i] = A.mass[i];
     if (nhc && threadIdx.x < C) pv[threadIdx.x] = A.pv0[(size_t)rep * C + threadIdx.x];
     __syncthreads();
     // frame 0 = inputs (tinydiffeq.py:63)
-    store_aos(A.q_t + ((size_t)rep * T) * N * 3, q, N);
-    store_aos(A.v_t + ((size_t)rep * T) * N * 3, v, N);
+    store_aos(A.q_t + ((size_t)rep * T) * N * 3, q, N, LD);
+    store_aos(A.v_t + ((size_t)rep * T) * N * 3, v, N, LD);
     if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
 
     force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
@@ -450,13 +454,13 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
             v[e] = v[e] + (vh[e] + 0.5f * a * dt);
         }
         __syncthreads();
-        store_aos(A.q_t + ((size_t)rep * T + k + 1) * N * 3, q, N);
-        store_aos(A.v_t + ((size_t)rep * T + k + 1) * N * 3, v, N);
+        store_aos(A.q_t + ((size_t)rep * T + k + 1) * N * 3, q, N, LD);
+        store_aos(A.v_t + ((size_t)rep * T + k + 1) * N * 3, v, N, LD);
         if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = pv[threadIdx.x];
     }
     if (A.nonfinite) {
         int bad = 0;
-        for (int e = threadIdx.x; e < 3 * N; e += blockDim.x) bad |= !(isfinite(q[e]) && isfinite(v[e]));
+        MDG_FOR_DOF(e, ia, ca) bad |= !(isfinite(q[e]) && isfinite(v[e]));
         if (__syncthreads_or(bad) && threadIdx.x == 0) A.nonfinite[rep] = 1;
     }
 }
@@ -469,7 +473,7 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
                                          const float* lv, const float* ms, float* w, float* f,
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
                                          float& slv, const TableRef& TB, float& vmax) {
-    const int N = A.prm.n_atoms;
+    const int N = A.prm.n_atoms, LD = A.ld;
     MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] / ms[ia] : lv[e];
     __syncthreads();
 #pragma unroll
@@ -506,15 +510,17 @@ __device__ __forceinline__ float bath_vjp(const TrajArgs& A, const float* Q, con
 template <bool DIAG, int NT, int KIND>
 __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const int tpa_log2) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, LD = A.ld;
     const bool nhc = A.prm.ensemble == 0;
-    const int rep = blockIdx.x, N3 = 3 * N;
-    float* q = smem;        float* v = q + N3;
-    float* lv = v + N3;     float* lq = lv + N3;
-    float* lvh = lq + N3;   float* lqh = lvh + N3;
-    float* w = lqh + N3;    float* f = w + N3;     float* dq = f + N3;
-    float* ms = dq + N3;
-    float* pv = ms + N;                       // [C] state
+    const int rep = blockIdx.x, N3 = 3 * N, L3 = 3 * LD;      // N3: frame stride in HBM (AoS), L3: SoA array in LDS
+    float* q = smem;        float* v = q + L3;
+    float* lv = v + L3;     float* lq = lv + L3;
+    float* lvh = lq + L3;   float* lqh = lvh + L3;
+    float* w = lqh + L3;    float* f = w + L3;     float* dq = f + L3;
+    float* ms = dq + L3;
+    float* pv = ms + LD;                      // [C] state
+    for (int e = threadIdx.x; e < 28 * LD; e += blockDim.x) smem[e] = 0.f;      // padding columns stay finite
+    __syncthreads();
     float* lp = pv + MDG_MAX_CHAINS;          // [C] adjoint
     float* lph = lp + MDG_MAX_CHAINS;         // [C] midpoint adjoint
     float* pb = lph + MDG_MAX_CHAINS;         // [C] scratch: bath rhs
@@ -546,15 +552,15 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 
     for (int i = tid; i < N; i += blockDim.x) ms[i] = A.mass[i];
     // lam = dL/dy_{T-1}                                            sovlers.py:249
-    if (A.g_v) load_soa(lv, A.g_v + (fr + T - 1) * N3, N); else for (int e = tid; e < N3; e += blockDim.x) lv[e] = 0.f;
-    if (A.g_q) load_soa(lq, A.g_q + (fr + T - 1) * N3, N); else for (int e = tid; e < N3; e += blockDim.x) lq[e] = 0.f;
+    if (A.g_v) load_soa(lv, A.g_v + (fr + T - 1) * N3, N, LD);          // (else: zero from the fill above)
+    if (A.g_q) load_soa(lq, A.g_q + (fr + T - 1) * N3, N, LD);
     if (nhc && tid < C) lp[tid] = A.g_pv ? A.g_pv[(fr + T - 1) * C + tid] : 0.f;
 
     for (int i = T - 1; i >= 1; --i) {
         const float h = A.t[i] - A.t[i - 1];
         __syncthreads();
-        load_soa(q, A.q_t + (fr + i) * N3, N);
-        load_soa(v, A.v_t + (fr + i) * N3, N);
+        load_soa(q, A.q_t + (fr + i) * N3, N, LD);
+        load_soa(v, A.v_t + (fr + i) * N3, N, LD);
         if (nhc && tid < C) pv[tid] = A.pv_t[(fr + i) * C + tid];
         __syncthreads();
         float ke, slv;
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
         }
     }
     __syncthreads();
-    store_aos(A.adj_v0 + (size_t)rep * N3, lv, N);
-    store_aos(A.adj_q0 + (size_t)rep * N3, lq, N);
+    store_aos(A.adj_v0 + (size_t)rep * N3, lv, N, LD);
+    store_aos(A.adj_q0 + (size_t)rep * N3, lq, N, LD);
     if (nhc && tid < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + tid] = lp[tid];
     if constexpr (KIND == KIND_TABLE) {
         // table gradient: fixed point -> float; an out-of-range contribution poisons the output (the
@@ -736,7 +742,8 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int block = pick_block(*prm);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 2 * (size_t)terms->t[0].p : 0;
     MDG_CHECK_ARG(!tab || theta, "traj_fwd: the table is passed through theta");
-    const size_t lds = sizeof(float) * (13 * (size_t)N + 5 * MDG_MAX_CHAINS + RED_FLOATS + tab + (tab ? 1 : 0));
+    a.ld = N <= 128 ? 128 : (N + 1) & ~1;
+    const size_t lds = sizeof(float) * (13 * (size_t)a.ld + 5 * MDG_MAX_CHAINS + RED_FLOATS + tab);
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_fwd: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;
@@ -766,7 +773,8 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int block = pick_block(*prm);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + two int32 planes
     MDG_CHECK_ARG(!tab || theta, "traj_adj: the table is passed through theta");
-    const size_t lds = sizeof(float) * (28 * (size_t)N + 6 * MDG_MAX_CHAINS + RED_FLOATS + tab);
+    a.ld = N <= 128 ? 128 : (N + 1) & ~1;
+    const size_t lds = sizeof(float) * (28 * (size_t)a.ld + 6 * MDG_MAX_CHAINS + RED_FLOATS + tab);
     MDG_CHECK_ARG(lds <= 160 * 1024, "traj_adj: N=%d does not fit the LDS-resident kernel", N);
     const int tl = pick_tpa_log2(N, block);
     const bool diag = cell->diag != 0;
