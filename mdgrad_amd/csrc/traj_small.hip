@@ -45,11 +45,15 @@ constexpr int RED_FLOATS = 16 * (KMAX_ALL + 2);
 //   d(w.F)/dsig  += 1/2 4 eps (36 c s6 - 144 s12) (D.w_ij) / (sig d2)
 //   d(w.F)/deps  += 2 (6 c s6 - 12 s12) (D.w_ij) / d2
 // (the same quantities force_all_pairs gets from pair_eval<LEVEL, MDG_PAIR_LJ> through r and 1/r).
-template <int LEVEL>
+// A lane takes the CONSECUTIVE neighbours (j, j+1): with the SoA rows 8-byte aligned and of even length one
+// ds_read_b64 per component delivers both operands of the packed arithmetic; LDC = 128 (every N <= 128)
+// turns the row offsets into instruction immediates -- 6 LDS instructions and one address per iteration
+// instead of 12 + 12.  (Row padding is zero-filled, so the odd-N tail reads finite values.)
+template <int LEVEL, int LDC>
 __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, float& th_sig, float& th_eps) {
-    const int N = A.prm.n_atoms, LD = A.ld;
+    const int N = A.prm.n_atoms, LD = LDC ? LDC : A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -64,15 +68,17 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
         if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
-        for (int j = sub; j < N; j += 2 * TPA) {
-            const bool live2 = j + TPA < N;
-            const int j2 = live2 ? j + TPA : j;
-            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[LD + j] - yi, q[LD + j2] - yi},
-                  dz = {q[2 * LD + j] - zi, q[2 * LD + j2] - zi};                    // D = x_j - x_i
+        for (int j = 2 * sub; j < N; j += 2 * TPA) {
+            const bool live2 = j + 1 < N;
+            const float* qj = q + j;
+            const f32x2 qx = *reinterpret_cast<const f32x2*>(qj), qy = *reinterpret_cast<const f32x2*>(qj + LD),
+                        qz = *reinterpret_cast<const f32x2*>(qj + 2 * LD);
+            f32x2 dx = qx - xi, dy = qy - yi, dz = qz - zi;                        // D = x_j - x_i
             f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
             if (LEVEL >= 2) {
-                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[LD + j], wyi - w[LD + j2]};
-                az = f32x2{wzi - w[2 * LD + j], wzi - w[2 * LD + j2]};
+                const float* wj = w + j;
+                ax = wxi - *reinterpret_cast<const f32x2*>(wj); ay = wyi - *reinterpret_cast<const f32x2*>(wj + LD);
+                az = wzi - *reinterpret_cast<const f32x2*>(wj + 2 * LD);
             }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
@@ -136,11 +142,11 @@ __device__ __forceinline__ void table_scatter(const TableRef& T, int idx, float 
     atomicAdd(T.glo + idx, (int)rintf(lo));
 }
 
-template <int LEVEL>
+template <int LEVEL, int LDC>
 __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, const TableRef& T, float& vmax) {
-    const int N = A.prm.n_atoms, LD = A.ld;
+    const int N = A.prm.n_atoms, LD = LDC ? LDC : A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -155,15 +161,16 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
         if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
-        for (int j = sub; j < N; j += 2 * TPA) {
-            const bool live2 = j + TPA < N;
-            const int j2 = live2 ? j + TPA : j;
-            f32x2 dx = {q[j] - xi, q[j2] - xi}, dy = {q[LD + j] - yi, q[LD + j2] - yi},
-                  dz = {q[2 * LD + j] - zi, q[2 * LD + j2] - zi};                    // D = x_j - x_i
+        for (int j = 2 * sub; j < N; j += 2 * TPA) {                             // consecutive pair (j, j+1): see force_lj126_packed
+            const bool live2 = j + 1 < N;
+            const float* qj = q + j;
+            f32x2 dx = *reinterpret_cast<const f32x2*>(qj) - xi, dy = *reinterpret_cast<const f32x2*>(qj + LD) - yi,
+                  dz = *reinterpret_cast<const f32x2*>(qj + 2 * LD) - zi;          // D = x_j - x_i
             f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;
             if (LEVEL >= 2) {
-                ax = f32x2{wxi - w[j], wxi - w[j2]}; ay = f32x2{wyi - w[LD + j], wyi - w[LD + j2]};
-                az = f32x2{wzi - w[2 * LD + j], wzi - w[2 * LD + j2]};
+                const float* wj = w + j;
+                ax = wxi - *reinterpret_cast<const f32x2*>(wj); ay = wyi - *reinterpret_cast<const f32x2*>(wj + LD);
+                az = wzi - *reinterpret_cast<const f32x2*>(wj + 2 * LD);
             }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
@@ -224,7 +231,8 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
                                                 float* __restrict__ dq, float (&dth)[KMAX], const TableRef& TB,
                                                 float& vmax) {
     if constexpr (KIND == KIND_TABLE) {
-        force_table_packed<LEVEL>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        if (A.ld == 128) force_table_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        else force_table_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, TB, vmax);
         return;
     }
     const int N = A.prm.n_atoms, LD = A.ld;
@@ -237,7 +245,8 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     for (int m = 0; m < NT; ++m)
         if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
     if constexpr (KIND == KIND_LJ126) {
-        force_lj126_packed<LEVEL>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
+        if (A.ld == 128) force_lj126_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
+        else force_lj126_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
         return;
     }
     if constexpr (KIND >= 0) {
