@@ -52,14 +52,19 @@ constexpr int RED_FLOATS = 16 * (KMAX_ALL + 2);
 template <int LEVEL, int LDC>
 __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
-                                                   float* __restrict__ dq, float& th_sig, float& th_eps) {
+                                                   float* __restrict__ dq, float& th_sig, float& th_eps, bool th_on) {
     const int N = A.prm.n_atoms, LD = LDC ? LDC : A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
     const TermConst t0 = term_prepare(A.terms.t[0], A.theta);
     const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
-    const float e4_isig_half = 0.5f * e4 * t0.k2;
+    // 4 eps and the q-term coefficient folded into the polynomial coefficients (A = s6, B = s12)
+    const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;                 // phi'/r  = (m1a A - m1b B) / d2
+    const float dua = 42.f * e4 * cq, dub = 156.f * e4;               // phi''   = (dub B - dua A) / d2
+    const float tsa = 18.f * e4 * t0.k2 * cq, tsb = 72.f * e4 * t0.k2;   // 1/2 d(phi'/r)/dsig r-part
+    const float tea = 12.f * cq, teb = 24.f;                          // 2 m1 / (4 eps)
+    const bool want_th = LEVEL >= 2 && th_on;
     const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
     const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
     f32x2 ts = {0.f, 0.f}, te = {0.f, 0.f};
@@ -89,21 +94,21 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
             const f32x2 s2 = sig2 * i2;
             const f32x2 s6 = s2 * s2 * s2;
             const f32x2 s12 = s6 * s6;
-            const f32x2 s6c = cq * s6;
             const f32x2 i2s = i2 * sel;                       // rejected pairs contribute exactly zero
-            const f32x2 m1 = 6.f * s6c - 12.f * s12;
-            const f32x2 c1 = (e4 * m1) * i2s;
+            const f32x2 c1 = (m1a * s6 - m1b * s12) * i2s;
             fx += c1 * dx; fy += c1 * dy; fz += c1 * dz;      // F_i += (phi'/r) D
             if (LEVEL >= 2) {
                 const f32x2 b = dx * ax + dy * ay + dz * az;
                 const f32x2 bi = b * i2s;
-                const f32x2 d2u = (e4 * (156.f * s12 - 42.f * s6c)) * i2;
+                const f32x2 d2u = (dub * s12 - dua * s6) * i2;
                 const f32x2 k2 = (d2u - c1) * bi;
                 gx -= k2 * dx + c1 * ax;
                 gy -= k2 * dy + c1 * ay;
                 gz -= k2 * dz + c1 * az;
-                ts += (e4_isig_half * (36.f * s6c - 144.f * s12)) * bi;
-                te += (2.f * m1) * bi;
+                if (want_th) {                                // (uniform branch: the first NHC evaluation skips it)
+                    ts += (tsa * s6 - tsb * s12) * bi;
+                    te += (tea * s6 - teb * s12) * bi;
+                }
             }
         }
         float sx = group_sum_rt(fx.x + fx.y, TPA), sy = group_sum_rt(fy.x + fy.y, TPA), sz = group_sum_rt(fz.x + fz.y, TPA);
@@ -229,7 +234,7 @@ template <bool DIAG, int NT, int KIND, int LEVEL>
 __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                 const float* __restrict__ w, float* __restrict__ f,
                                                 float* __restrict__ dq, float (&dth)[KMAX], const TableRef& TB,
-                                                float& vmax) {
+                                                float& vmax, bool th_on = true) {
     if constexpr (KIND == KIND_TABLE) {
         if (A.ld == 128) force_table_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, TB, vmax);
         else force_table_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, TB, vmax);
@@ -245,8 +250,8 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     for (int m = 0; m < NT; ++m)
         if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
     if constexpr (KIND == KIND_LJ126) {
-        if (A.ld == 128) force_lj126_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
-        else force_lj126_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, dth[0], dth[1]);
+        if (A.ld == 128) force_lj126_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+        else force_lj126_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
         return;
     }
     if constexpr (KIND >= 0) {
@@ -481,13 +486,13 @@ template <bool DIAG, int NT, int KIND>
 __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool nhc, const float* q, const float* v,
                                          const float* lv, const float* ms, float* w, float* f,
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
-                                         float& slv, const TableRef& TB, float& vmax) {
+                                         float& slv, const TableRef& TB, float& vmax, bool th_on = true) {
     const int N = A.prm.n_atoms, LD = A.ld;
     MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] / ms[ia] : lv[e];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
-    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th, TB, vmax);
+    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th, TB, vmax, th_on);
     // one fused block reduction: th[0..K), sum p^2/m, sum lv.v
     float vals[KMAX + 2];
 #pragma unroll
@@ -577,7 +582,8 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
         // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC,
         //  sovlers.py:160, and from this first one for NVE, :82,101 -- both with total weight h)
         TBacc.gw = 0.5f * h * A.terms.t[0].c;
-        aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv, nhc ? TB : TBacc, vmax);
+        aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv, nhc ? TB : TBacc, vmax,
+                                 /*th_on=*/!nhc);
         if (nhc) {
             const float pv0 = pv[0], lp0 = lp[0];
             if (tid < C) { pb[tid] = bath_rhs(A, Qs, pv, ke, tid); gp[tid] = bath_vjp(A, Qs, pv, lp, slv, tid); }
