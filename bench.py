@@ -140,7 +140,7 @@ def schnet_workload(args, rank, world, dev, mdist):
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
     if rank == 0:
-        # roofline of the dominant kernel of this workload (profiles/r01e_schnet4096x8_kernel_stats.txt): the
+        # roofline of the dominant kernel of this workload (profiles/r01f_schnet4096x8_kernel_stats.txt): the
         # edge-wise f32 GEMM [E,128] x [128,128] of the filter network and of its tangent / reverse sweeps,
         # issued through the library (hipBLASLt on the bucket-padded edge count, as mdgrad_amd/nn/analytic.py
         # does); f32 MFMA peak 157.3 TFLOP/s
