@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 8192 for lj108, 8 for schnet4096)")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 for lj108, 8 for schnet4096)")
     ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
@@ -201,7 +201,7 @@ def main():
             mdist.barrier()
             tdist.destroy_process_group()
         return
-    args.replicas = 8192 if args.replicas is None else args.replicas
+    args.replicas = 16384 if args.replicas is None else args.replicas
     args.frames = 50 if args.frames is None else args.frames
     R, T = args.replicas, args.frames
     atoms, pos, vel = make_inputs(R, 1000 + rank, dev)
