@@ -238,6 +238,15 @@ __device__ __forceinline__ void pair_eval(const TermConst& tc, float d2, float& 
     }
 }
 
+// Workgroups are dispatched round-robin over the 8 XCDs, each with its own 4 MB L2: with the identity mapping
+// neighbouring atoms -- which gather the same h rows -- land on different XCDs and every L2 sees the whole
+// feature matrix.  xcd_chunk() gives XCD x the x-th contiguous eighth of the blocks instead.
+__device__ __forceinline__ int xcd_chunk(int bid, int nblocks) {
+    const int per = nblocks >> 3;
+    if (per == 0 || bid >= (per << 3)) return bid;              // tail blocks keep their index
+    return (bid & 7) * per + (bid >> 3);
+}
+
 // ----------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

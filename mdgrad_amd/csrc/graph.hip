@@ -31,7 +31,7 @@ __global__ void edge_diff_kernel(const float* __restrict__ x, const int64_t* __r
 __global__ void edge_scatter_kernel(const float* __restrict__ g, const int32_t* __restrict__ col,
                                     const int32_t* __restrict__ eid, const int32_t* __restrict__ cnt,
                                     int N, int max_nbr, int C, float* __restrict__ out) {
-    const int n = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = xcd_chunk(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (n >= N) return;
     const int m = cnt[n];
     const size_t row = (size_t)n * max_nbr;
@@ -81,15 +81,6 @@ __global__ void edge_prod_kernel(const float* __restrict__ a, const float* __res
 
 // 16-byte variants for F = 4 * LPE with LPE (lanes per edge) a power of two <= 64: a wave works on
 // 64 / LPE edges at a time; the per-group partial sums are combined in a fixed order.
-// Workgroups are dispatched round-robin over the 8 XCDs, each with its own 4 MB L2: with the identity mapping
-// neighbouring atoms -- which gather the same h rows -- land on different XCDs and every L2 sees the whole
-// feature matrix.  xcd_chunk() gives XCD x the x-th contiguous eighth of the blocks instead.
-__device__ __forceinline__ int xcd_chunk(int bid, int nblocks) {
-    const int per = nblocks >> 3;
-    if (per == 0 || bid >= (per << 3)) return bid;              // tail blocks keep their index
-    return (bid & 7) * per + (bid >> 3);
-}
-
 template <int LPE>
 __global__ void cfconv_agg_v4_kernel(const float4* __restrict__ h, const float4* __restrict__ W,
                                      const int32_t* __restrict__ col, const int32_t* __restrict__ eid,

@@ -48,7 +48,7 @@ __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group
                                  int32_t* __restrict__ shift, int32_t* __restrict__ cnt, int max_nbr,
                                  int32_t* __restrict__ overflow) {
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int i = xcd_chunk(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // XCD-aware atom order
     if (i >= N) return;
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     const int g0 = (i / group) * group, g1 = min(N, g0 + group);
