@@ -24,6 +24,17 @@ class GeneralInteraction(torch.nn.Module):
         self._static = None          # fixed-capacity configuration (persistent once created)
         self._static_on = False      # ... and whether _reset_topology uses it
 
+    def _shared_ell(self, xyz, cache):
+        """Exact-size ELL list at xyz; members of one Stack with the same cutoff / selection / grouping share
+        it within a rebuild (`cache` is the Stack's per-call dict)."""
+        key = (float(self.cutoff), None if self._mask is None else self._mask.data_ptr(), self._group)
+        if cache is not None and key in cache:
+            return cache[key]
+        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
+        if cache is not None:
+            cache[key] = ell
+        return ell
+
     # -- fixed-capacity neighbour lists (HIP-graph capture of the integrator steps, mdgrad_amd/graphs.py) --
     def supports_static_topology(self):
         return False
@@ -94,15 +105,14 @@ class GNNPotentials(GeneralInteraction):
         self.to(self.device)
         self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
 
-    def _reset_topology(self, xyz):
+    def _reset_topology(self, xyz, _cache=None):
         st = self._static if self._static_on else None
         if st is not None:
             ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, max_nbr=st["max_nbr"],
                                 group=self._group, need=st["need"])
             topo = ops.StaticTopo(ell, st["capacity"], st["need"])
         else:
-            ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
-            topo = ops.GraphTopo(ell)
+            topo = ops.GraphTopo(self._shared_ell(xyz, _cache))
         self.inputs['nbr_list'], self.inputs['offsets'] = topo.nbr, topo.offsets
         self.inputs['_topo'] = topo
 
@@ -187,13 +197,13 @@ class PairPotentials(GeneralInteraction):
     def offsets(self):
         return self._ell.half_list()[1]
 
-    def _reset_topology(self, xyz):
+    def _reset_topology(self, xyz, _cache=None):
         st = self._static if self._static_on else None
         if st is not None:
             self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask,
                                       max_nbr=st["max_nbr"], group=self._group, need=st["need"])
         else:
-            self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, group=self._group)
+            self._ell = self._shared_ell(xyz, _cache)
         return _LazyTopology(self, xyz.detach())
 
     def supports_static_topology(self):
@@ -396,8 +406,13 @@ class Stack(torch.nn.Module):
         return F, dq, [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
 
     def _reset_topology(self, x):
+        shared = {}                          # one neighbour search per distinct (cutoff, selection, grouping)
         for key in self.models.keys():
-            self.models[key]._reset_topology(x)
+            m = self.models[key]
+            if isinstance(m, GeneralInteraction):
+                m._reset_topology(x, _cache=shared)
+            else:
+                m._reset_topology(x)
 
     def supports_static_topology(self):
         return all(getattr(m, "supports_static_topology", lambda: False)() for m in self.models.values())
