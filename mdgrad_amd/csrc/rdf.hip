@@ -14,6 +14,7 @@
 //           accepted pair contributes sum_k g_raw[k] * 2 coeff (d - mu_k) e_k along +/- its unit
 //           separation vector, accumulated in LDS without atomics.
 #include "common.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -225,139 +226,224 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_block8_kernel(
 // (R + 1/2) Ds >= 5.3 away, where the Gaussian is below 2^-28 of the peak, i.e. under fp32 rounding of the sums.  Real bin k lives in row
 // k + 2R; rows outside [2R, 2R + nbins) are write-only padding so that no deposit needs a bounds test.
 // The columns are summed in a fixed order at the end => bitwise reproducible.
-template <bool DIAG, int R, bool MASKED>
+//
+// The pairs come from a table built once per call (it stays in L1/L2): entry = (4 i) | (4 j2) << 16 stands for
+// the TWO pairs (i, j2), (i, j2 + 1) with j2 even, rows in order, j2 from (i + 1) & ~1.  No index arithmetic in
+// the loop (the closed-form round-robin order this replaces spent 27 of its 95 VALU instructions per pair on
+// it); the i coordinates are an LDS broadcast, the two j's one aligned ds_read_b64 per component, already in
+// packed-fp32 register pairs.  Slots that are not pairs need no flags: (i, i) -- the first slot of an even
+// row -- is rejected by the d2 != 0 test of topology.py:67, column N of an odd N and the columns the padding
+// entries point at hold NaN, and NaN < cutoff^2 is false.
+__host__ __device__ inline int rdf_row_entries(int i, int N) { return (N + 1 - ((i + 1) & ~1)) >> 1; }
+
+__global__ __launch_bounds__(256) void rdf_pair_table_kernel(uint32_t* __restrict__ tab, int N, int n_entries,
+                                                             int n_padded, uint32_t pad_entry) {
+    __shared__ int off_s;
+    const int i = blockIdx.x;
+    if (i < N - 1) {
+        if (threadIdx.x == 0) off_s = 0;
+        __syncthreads();
+        int part = 0;
+        for (int k = threadIdx.x; k < i; k += blockDim.x) part += rdf_row_entries(k, N);
+        if (part) atomicAdd(&off_s, part);
+        __syncthreads();
+        const int off = off_s, j0 = (i + 1) & ~1, cnt = rdf_row_entries(i, N);
+        for (int e = threadIdx.x; e < cnt; e += blockDim.x)
+            tab[off + e] = (uint32_t)(4 * i) | ((uint32_t)(4 * (j0 + 2 * e)) << 16);
+    } else {
+        for (int p_ = n_entries + threadIdx.x; p_ < n_padded; p_ += blockDim.x) tab[p_] = pad_entry;
+    }
+}
+
+constexpr int RDF_TABLE_MAX_ATOMS = 4096;      // 4 j < 2^16 and a table of at most 16 MB
+
+template <bool DIAG, int R, bool MASKED, int PXC>
 __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
-    const float* __restrict__ mu, float coeff, int nbins, float* __restrict__ partial) {
+    const float* __restrict__ mu, float coeff, int nbins, const uint32_t* __restrict__ tab, int iters, int pxld,
+    float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int rows = nbins + 4 * R;
-    float* smu = sm;                                            // [nbins + 2R] centres incl. extrapolated pads
-    float* hist = sm + (nbins + 2 * R) + (size_t)wid * ((size_t)rows * 64 + 3 * N);
-    float* px = hist + (size_t)rows * 64;                       // [3][N]
+    const int PXLD = PXC ? PXC : pxld;                          // row stride of the SoA coordinates (even, >= N + 2)
+    float* hist = sm + (size_t)wid * ((size_t)rows * 64 + 3 * PXLD);
+    float* px = hist + (size_t)rows * 64;                       // [3][PXLD]   (8-byte aligned: rows * 64 and PXLD are even)
+    float* smu = sm + (size_t)nw * ((size_t)rows * 64 + 3 * PXLD);   // [nbins + 2R] centres incl. extrapolated pads
     const float sc = sqrtf(-coeff * LOG2E);
     const float mu0 = mu[0];
     const float dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
     const float inv_dmu = 1.f / dmu;
     const float Ds = dmu * sc, Ds2 = Ds * Ds;
     const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds2);
-    float Ks[R];                                               // K_s = c2^(s(s-1)/2), s = 1..R
+    // e_{+-s} = e0 r^s K_s with r = exp2(+-2 Ds x0 - Ds^2) <= 1 and K_s = c2^(s(s-1)/2), K_0 = K_1 = 1.  Bins are
+    // handled two adjacent rows at a time (one ds_read2st64 / ds_write2st64 and one packed fma per two bins): the
+    // packed power {r^s, r^(s+1)} advances by r^2.  Outward chain s = 0 (the centre) .. R, inward chain s = 1 .. R.
+    constexpr int NPO = (R + 1) / 2, NPI = R / 2;
+    constexpr bool TAIL_O = ((R + 1) & 1) != 0, TAIL_I = (R & 1) != 0;     // one unpaired row at the far end
+    f32x2 Ko[NPO], Ki[NPI > 0 ? NPI : 1];                       // outward {K_2m, K_2m+1}, inward {K_2m+2, K_2m+1}
+    float Klast = 1.f;                                          // K_R
     {
-        float cp = 1.f;                                        // c2^(s-1)
-        Ks[0] = 1.f;
+        float cp = 1.f, K = 1.f, Ks[R + 2];
+        Ks[0] = 1.f; Ks[1] = 1.f;
 #pragma unroll
-        for (int s_ = 1; s_ < R; ++s_) { cp *= c2; Ks[s_] = Ks[s_ - 1] * cp; }
+        for (int s_ = 2; s_ <= R; ++s_) { cp *= c2; K *= cp; Ks[s_] = K; }
+#pragma unroll
+        for (int m = 0; m < NPO; ++m) Ko[m] = f32x2{Ks[2 * m], Ks[2 * m + 1]};
+#pragma unroll
+        for (int m = 0; m < NPI; ++m) Ki[m] = f32x2{Ks[2 * m + 2], Ks[2 * m + 1]};
+        Klast = Ks[R];
     }
     for (int k = threadIdx.x; k < nbins + 2 * R; k += blockDim.x) {
         const int kk = k - R;
         smu[k] = (kk >= 0 && kk < nbins) ? mu[kk] : fmaf((float)kk, dmu, mu0);
     }
     for (int e = lane; e < rows * 64; e += 64) hist[e] = 0.f;
+    for (int e = lane; e < 3 * PXLD; e += 64) px[e] = (e >= N && e < PXLD) ? __builtin_nanf("") : 0.f;
     __syncthreads();
+    const float ivx = cell.inv[0], ivy = cell.inv[4], ivz = cell.inv[8];
     const int gw = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
     for (int fr = gw; fr < nF; fr += nwaves) {
         const float* pos = xyz + (size_t)fr * N * 3;
-        for (int e = lane; e < 3 * N; e += 64) px[(e % 3) * N + e / 3] = pos[e];
-        // Pairs in round-robin-tournament order (round r, slot p -> a closed-form pair, no triangular
-        // index arithmetic); two pairs per lane and iteration (slots q and q + 64), software-pipelined:
-        // the coordinates of the next two pairs are fetched from LDS before the current two are
-        // deposited, so the LDS round trips hide behind the deposit arithmetic with one wave per SIMD.
-        const int Np = N + (N & 1), M = Np - 1, half = Np / 2, total = M * half;
-        const int adv_r = 128 / half, adv_p = 128 % half;
-        int rA = lane / half, pA = lane % half, rB = (lane + 64) / half, pB = (lane + 64) % half;
-        float dA, dB, mA, mB;
+        bool out = false;
+        for (int e = lane; e < 3 * N; e += 64) {
+            const int c = e % 3;
+            const float v = pos[e];
+            px[c * PXLD + e / 3] = v;
+            if (DIAG) {
+                const float s_ = v * (c == 0 ? ivx : c == 1 ? ivy : ivz);
+                out |= !(s_ > -0.24f && s_ < 1.24f);
+            }
+        }
+        // every atom within [-0.24, 1.24] cell lengths (trajectories are wrapped at every epoch, md.py:66):
+        // the image shift is a plain rint, see min_image_diag2_near
+        const bool near = DIAG && !__any(out);
+        f32x2 dd, mm;                 // distances and nearest centres of the two pairs of the current entry
         int kA, kB;
         bool okA, okB;
-        auto fetch = [&](int r, int p, bool live, float (&c)[6], int& i, int& j, bool& valid) {
-            int a_ = r + p; a_ = a_ >= M ? a_ - M : a_;
-            int b_ = r - p; b_ = b_ < 0 ? b_ + M : b_;
-            if (p == 0) { a_ = M; b_ = r; }
-            valid = live & (a_ < N) & (b_ < N);          // a slot paired with the dummy of an odd N is idle
-            a_ = valid ? a_ : 0; b_ = valid ? b_ : 1;
-            i = min(a_, b_); j = max(a_, b_);
-            c[0] = px[j]; c[1] = px[i]; c[2] = px[N + j]; c[3] = px[N + i]; c[4] = px[2 * N + j]; c[5] = px[2 * N + i];
-        };
-        // distances of the two pairs of an iteration in packed fp32
-        auto locate2 = [&](const float (&ca)[6], const float (&cb)[6], int ia, int ja, int ib, int jb, bool va, bool vb) {
-            f32x2 dx = {ca[0] - ca[1], cb[0] - cb[1]}, dy = {ca[2] - ca[3], cb[2] - cb[3]},
-                  dz = {ca[4] - ca[5], cb[4] - cb[5]};
-            if constexpr (DIAG) {
-                dx = min_image_diag2(dx, cell.inv[0], cell.h[0]);
-                dy = min_image_diag2(dy, cell.inv[4], cell.h[4]);
-                dz = min_image_diag2(dz, cell.inv[8], cell.h[8]);
-            } else {
-                float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
-                min_image<false>(cell, ax_, ay_, az_);
-                min_image<false>(cell, bx_, by_, bz_);
-                dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
-            }
-            const f32x2 d2 = norm2_ref2(dx, dy, dz);
-            okA = va & (d2.x < rc2) & (d2.x != 0.f);                         // (bitwise: no short-circuit branches)
-            okB = vb & (d2.y < rc2) & (d2.y != 0.f);
-            if constexpr (MASKED) {                                          // unconditional loads: no branch
-                okA = okA & (mask[(size_t)ia * N + ja] != 0);
-                okB = okB & (mask[(size_t)ib * N + jb] != 0);
-            }
-            // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
-            const f32x2 d = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
-            const f32x2 tk = (d - mu0) * inv_dmu;
-            kA = (int)rintf(tk.x); kB = (int)rintf(tk.y);
-            okA = okA & (kA >= -R) & (kA <= nbins - 1 + R);
-            okB = okB & (kB >= -R) & (kB <= nbins - 1 + R);
-            kA = okA ? kA : 0; kB = okB ? kB : 0;
-            dA = d.x; dB = d.y;
-            mA = smu[kA + R]; mB = smu[kB + R];
-        };
-        // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0.  The outward and
-        // inward recurrences run as one packed (v_pk_mul_f32 / v_pk_add_f32) chain.  Plain read-add-write
+        // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0.  Plain read-add-write
         // on the lane-private column: ds_add_f32 is serialised per lane in the LDS atomic unit (measured
-        // 9x slower); prefetching the rows one stage earlier did not pay either (-4 %).
-        auto deposit = [&](float d, float m, int kc, bool ok) {
+        // 9x slower).  In two halves, so that the sweep can put independent work behind the row reads.
+        struct Rows { f32x2 vo[NPO]; f32x2 vi[NPI > 0 ? NPI : 1]; float vlo, vli; float* h; };
+        auto rows_load = [&](int kc, Rows& w) {
+            float* h = hist + (size_t)(kc + R) * 64 + lane;      // row of bin kc - R
+            w.h = h;
+#pragma unroll
+            for (int m_ = 0; m_ < NPO; ++m_) w.vo[m_] = f32x2{h[(R + 2 * m_) * 64], h[(R + 2 * m_ + 1) * 64]};
+#pragma unroll
+            for (int m_ = 0; m_ < NPI; ++m_) w.vi[m_] = f32x2{h[(R - 2 * m_ - 2) * 64], h[(R - 2 * m_ - 1) * 64]};
+            w.vlo = 0.f; w.vli = 0.f;
+            if (TAIL_O) w.vlo = h[2 * R * 64];
+            if (TAIL_I) w.vli = h[0];
+        };
+        auto rows_add_store = [&](Rows& w, float d, float m, bool ok) {
             const float x0 = (d - m) * sc;
             const float a_ = ok ? 2.f * Ds * x0 : 0.f;
             const float e0 = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f;
-            // e_{+-s} = e0 r^s c2^{s(s-1)/2} with r = exp2(+-2 Ds x0 - Ds^2) <= 1: P_s = e0 r^s by one packed
-            // multiply per step, the constant K_s = c2^{s(s-1)/2} folded into the accumulating fma
-            const f32x2 r = {__builtin_amdgcn_exp2f(a_ - Ds2), __builtin_amdgcn_exp2f(-a_ - Ds2)};
-            f32x2 P = {e0, e0};
-            float* h = hist + (size_t)(kc + R) * 64 + lane;      // row of bin kc - R
-            float vc = h[R * 64];
-            f32x2 v[R];
+            const float rp = __builtin_amdgcn_exp2f(a_ - Ds2), rm = __builtin_amdgcn_exp2f(-a_ - Ds2);
+            const float rp2 = rp * rp, rm2 = rm * rm;
+            f32x2 Po = e0 * f32x2{1.f, rp}, Pi = e0 * f32x2{rm2, rm};
 #pragma unroll
-            for (int s_ = 1; s_ <= R; ++s_) v[s_ - 1] = f32x2{h[(R + s_) * 64], h[(R - s_) * 64]};
-            vc += e0;
+            for (int m_ = 0; m_ < NPO; ++m_) {
+                w.vo[m_] += Ko[m_] * Po;
+                if (m_ + 1 < NPO || TAIL_O) Po *= rp2;
+            }
 #pragma unroll
-            for (int s_ = 1; s_ <= R; ++s_) { P *= r; v[s_ - 1] += Ks[s_ - 1] * P; }
-            h[R * 64] = vc;
+            for (int m_ = 0; m_ < NPI; ++m_) {
+                w.vi[m_] += Ki[m_] * Pi;
+                if (m_ + 1 < NPI || TAIL_I) Pi *= rm2;
+            }
+            if (TAIL_O) w.vlo += Klast * Po.x;                   // Po = {e0 r^R, .} after NPO steps (R even)
+            if (TAIL_I) w.vli += Klast * Pi.y;                   // Pi = {., e0 r^R} after NPI steps (R odd)
+            float* h = w.h;
 #pragma unroll
-            for (int s_ = 1; s_ <= R; ++s_) { h[(R + s_) * 64] = v[s_ - 1].x; h[(R - s_) * 64] = v[s_ - 1].y; }
+            for (int m_ = 0; m_ < NPO; ++m_) { h[(R + 2 * m_) * 64] = w.vo[m_].x; h[(R + 2 * m_ + 1) * 64] = w.vo[m_].y; }
+#pragma unroll
+            for (int m_ = 0; m_ < NPI; ++m_) { h[(R - 2 * m_ - 2) * 64] = w.vi[m_].x; h[(R - 2 * m_ - 1) * 64] = w.vi[m_].y; }
+            if (TAIL_O) h[2 * R * 64] = w.vlo;
+            if (TAIL_I) h[0] = w.vli;
         };
-        {
-            float ca[6], cb[6];
-            int ia, ja, ib, jb;
-            bool va, vb;
-            fetch(rA, pA, lane < total, ca, ia, ja, va);
-            fetch(rB, pB, lane + 64 < total, cb, ib, jb, vb);
-            locate2(ca, cb, ia, ja, ib, jb, va, vb);
-        }
         // (measured: a single row of fixed-point counters per wave updated with ds_add_u32 -- 2 KB of LDS
         //  instead of 32 KB, many waves per SIMD -- is 3.5x SLOWER: the lanes of a wave hit the same few
         //  bins around the g(r) peak and the atomics serialise; the lane-private columns never conflict.)
         // (measured: the kernel is VALU-issue bound at one wave per SIMD -- pinning a latency-optimal
         //  load/compute order with scheduling barriers, or prefetching the rows a stage early, is 4-7 % slower
         //  than the compiler's own schedule)
-        for (int q = lane; q < total; q += 128) {
-            rA += adv_r; pA += adv_p; if (pA >= half) { pA -= half; ++rA; }
-            rB += adv_r; pB += adv_p; if (pB >= half) { pB -= half; ++rB; }
-            float ca[6], cb[6];
-            int ia, ja, ib, jb;
-            bool va, vb;
-            fetch(rA, pA, q + 128 < total, ca, ia, ja, va);
-            fetch(rB, pB, q + 192 < total, cb, ib, jb, vb);
-            deposit(dA, mA, kA, okA);
-            deposit(dB, mB, kB, okB);
-            locate2(ca, cb, ia, ja, ib, jb, va, vb);
-        }
+        auto sweep = [&](auto near_c) {
+            constexpr bool NEAR = decltype(near_c)::value;
+            // first half: coordinates of the entry's atoms, squared distances of its two pairs in packed fp32;
+            // second half: distances, nearest centres, acceptance
+            f32x2 d2;
+            int mi = 0, mj = 0;
+            auto locate_a = [&](uint32_t t) {
+                const int i4 = (int)(t & 0xffffu), j4 = (int)(t >> 16);
+                const float* pi = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + i4);
+                const float* pj = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + j4);
+                f32x2 dx = *reinterpret_cast<const f32x2*>(pj) - pi[0],
+                      dy = *reinterpret_cast<const f32x2*>(pj + PXLD) - pi[PXLD],
+                      dz = *reinterpret_cast<const f32x2*>(pj + 2 * PXLD) - pi[2 * PXLD];
+                if constexpr (NEAR) {
+                    dx = min_image_diag2_near(dx, ivx, cell.h[0]);
+                    dy = min_image_diag2_near(dy, ivy, cell.h[4]);
+                    dz = min_image_diag2_near(dz, ivz, cell.h[8]);
+                } else if constexpr (DIAG) {
+                    dx = min_image_diag2(dx, ivx, cell.h[0]);
+                    dy = min_image_diag2(dy, ivy, cell.h[4]);
+                    dz = min_image_diag2(dz, ivz, cell.h[8]);
+                } else {
+                    float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
+                    min_image<false>(cell, ax_, ay_, az_);
+                    min_image<false>(cell, bx_, by_, bz_);
+                    dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
+                }
+                d2 = norm2_ref2(dx, dy, dz);
+                if constexpr (MASKED) { mi = i4 >> 2; mj = j4 >> 2; }
+            };
+            auto locate_b = [&]() {
+                okA = (d2.x < rc2) & (d2.x != 0.f);                              // (bitwise: no short-circuit branches)
+                okB = (d2.y < rc2) & (d2.y != 0.f);
+                if constexpr (MASKED) {                                          // unconditional loads: no branch
+                    okA = okA & (mask[(size_t)mi * N + min(mj, N - 1)] != 0);
+                    okB = okB & (mask[(size_t)mi * N + min(mj + 1, N - 1)] != 0);
+                }
+                // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
+                dd = f32x2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                const f32x2 tk = (dd - mu0) * inv_dmu;
+                kA = (int)rintf(tk.x); kB = (int)rintf(tk.y);
+                okA = okA & (kA >= -R) & (kA <= nbins - 1 + R);
+                okB = okB & (kB >= -R) & (kB <= nbins - 1 + R);
+                kA = okA ? kA : 0; kB = okB ? kB : 0;
+                mm = f32x2{smu[kA + R], smu[kB + R]};
+            };
+            // software pipeline, unrolled by four so that no register rotates.  Each step deposits the entry
+            // located by the previous step and locates the one of the next iteration in the shadow of the row
+            // reads: first pair's rows | coordinates, squared distances | first deposit | second pair's rows
+            // (after the first pair's stores: the two windows may overlap) | distances, bins | second deposit;
+            // the table register is reloaded for four iterations later.
+            const uint32_t* tp = tab + lane;
+            uint32_t t0 = tp[64], t1 = tp[128], t2 = tp[192], t3 = tp[256];
+            locate_a(tp[0]);
+            locate_b();
+            auto step = [&](uint32_t& t, const uint32_t* next) {
+                const f32x2 d_ = dd, m_ = mm; const int kb = kB; const bool oa = okA, ob = okB;
+                Rows w;
+                rows_load(kA, w);
+                locate_a(t);
+                t = *next;
+                rows_add_store(w, d_.x, m_.x, oa);
+                rows_load(kb, w);
+                locate_b();
+                rows_add_store(w, d_.y, m_.y, ob);
+            };
+            for (int it = 0; it < iters; it += 4) {
+                tp += 256;
+                step(t0, tp + 64);
+                step(t1, tp + 128);
+                step(t2, tp + 192);
+                step(t3, tp + 256);
+            }
+        };
+        if (near) sweep(std::true_type{});
+        else sweep(std::false_type{});
     }
     // column sums in a fixed (lane-rotated) order; one partial histogram per wave
     for (int k = lane; k < nbins; k += 64) {
@@ -367,7 +453,6 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
         partial[(size_t)gw * nbins + k] = s;
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Fine-grid backward for equally spaced centres (width ~ spacing): dL/dd(d) = sum_k g_k 2 coeff (d - mu_k) e_k(d)
@@ -663,8 +748,8 @@ static int rdf_lane_reach(float spacing_s) {
     if (spacing_s >= 0.465f) return 11;
     return 0;
 }
-static size_t rdf_lane_lds(int nw, int R, int n_atoms, int nbins) {
-    return sizeof(float) * ((size_t)(nbins + 2 * R) + (size_t)nw * ((size_t)(nbins + 4 * R) * 64 + 3 * (size_t)n_atoms));
+static size_t rdf_lane_lds(int nw, int R, int pxld, int nbins) {
+    return sizeof(float) * ((size_t)(nbins + 2 * R) + (size_t)nw * ((size_t)(nbins + 4 * R) * 64 + 3 * (size_t)pxld));
 }
 
 static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell, float cutoff,
@@ -678,30 +763,47 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
     hipStream_t st = (hipStream_t)stream;
     // equally spaced centres with Ds = s * spacing <= 1: 8-bin blocks + recurrence (spacing_s is the
     // caller's statement that mu is a linspace; <= 0 selects the direct kernel)
-    const int R = n_frames >= 1024 && nbins >= 2 && n_atoms < 32768 ? rdf_lane_reach(spacing_s) : 0;
+    const int R = n_frames >= 1024 && nbins >= 2 && n_atoms <= RDF_TABLE_MAX_ATOMS ? rdf_lane_reach(spacing_s) : 0;
     if (R) {
+        // coordinate stride: even, with at least two NaN columns after the atoms for the padding entries;
+        // compile-time (immediate LDS offsets) for the common shape: orthorhombic, no mask
+        const int npad_col = (n_atoms + 1) & ~1;
+        const bool px128 = npad_col + 2 <= 128 && cell->diag && !mask;
+        const int pxld = px128 ? 128 : npad_col + 2;
         int nw = 4;
-        while (nw > 1 && rdf_lane_lds(nw, R, n_atoms, nbins) > 156 * 1024) nw >>= 1;
-        const size_t lds = rdf_lane_lds(nw, R, n_atoms, nbins);
-        if (lds <= 156 * 1024) {
+        while (nw > 1 && rdf_lane_lds(nw, R, pxld, nbins) > 156 * 1024) nw >>= 1;
+        const size_t lds = rdf_lane_lds(nw, R, pxld, nbins);
+        int n_entries = 0;
+        for (int i = 0; i + 1 < n_atoms; ++i) n_entries += rdf_row_entries(i, n_atoms);
+        const int iters = (((n_entries + 63) / 64) + 3) & ~3;               // (the loop is unrolled by four)
+        const int n_padded = (iters + 5) * 64;
+        const uint32_t pad_entry = (uint32_t)(4 * npad_col) | ((uint32_t)(4 * npad_col) << 16);
+        uint32_t* tab = nullptr;
+        if (lds <= 156 * 1024 && hipMallocAsync((void**)&tab, sizeof(uint32_t) * (size_t)n_padded, st) == hipSuccess && tab) {
+            hipLaunchKernelGGL(rdf_pair_table_kernel, dim3(n_atoms), dim3(256), 0, st, tab, n_atoms, n_entries, n_padded,
+                               pad_entry);
             int grid = (n_frames + nw - 1) / nw;
             if (grid > RDF_MAX_BLOCKS / nw) grid = RDF_MAX_BLOCKS / nw;
-#define MDG_RDF_LANE(D, RR)                                                                                            \
-    do {                                                                                                               \
-        if (mask)                                                                                                      \
-            hipLaunchKernelGGL((rdf_fwd_lane_kernel<D, RR, true>), dim3(grid), dim3(64 * nw), lds, st, xyz, n_frames,  \
-                               n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);                      \
-        else                                                                                                           \
-            hipLaunchKernelGGL((rdf_fwd_lane_kernel<D, RR, false>), dim3(grid), dim3(64 * nw), lds, st, xyz, n_frames, \
-                               n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, partial);                      \
+#define MDG_RDF_LANE(D, RR, MK, PX)                                                                                    \
+    hipLaunchKernelGGL((rdf_fwd_lane_kernel<D, RR, MK, PX>), dim3(grid), dim3(64 * nw), lds, st, xyz, n_frames,        \
+                       n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, tab, iters, pxld, partial)
+#define MDG_RDF_LANE_R(RR)                                             \
+    do {                                                               \
+        if (px128) MDG_RDF_LANE(true, RR, false, 128);                 \
+        else if (cell->diag && mask) MDG_RDF_LANE(true, RR, true, 0);  \
+        else if (cell->diag) MDG_RDF_LANE(true, RR, false, 0);         \
+        else if (mask) MDG_RDF_LANE(false, RR, true, 0);               \
+        else MDG_RDF_LANE(false, RR, false, 0);                        \
     } while (0)
-            if (cell->diag) { if (R == 6) MDG_RDF_LANE(true, 6); else MDG_RDF_LANE(true, 11); }
-            else            { if (R == 6) MDG_RDF_LANE(false, 6); else MDG_RDF_LANE(false, 11); }
+            if (R == 6) MDG_RDF_LANE_R(6); else MDG_RDF_LANE_R(11);
+#undef MDG_RDF_LANE_R
 #undef MDG_RDF_LANE
             hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, grid * nw, nbins, raw);
+            (void)hipFreeAsync(tab, st);
             MDG_CHECK_LAUNCH("rdf_fwd_lane_kernel");
             return MDG_OK;
         }
+        if (tab) (void)hipFreeAsync(tab, st);
     }
     const int nblk = (nbins + RDF_KB - 1) / RDF_KB;
     const bool block8 = spacing_s > 0.f && spacing_s <= 1.0f && nbins >= 2 * RDF_KB && nblk <= RDF_BLOCK;

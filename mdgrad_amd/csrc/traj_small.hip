@@ -49,7 +49,7 @@ constexpr int RED_FLOATS = 16 * (KMAX_ALL + 2);
 // ds_read_b64 per component delivers both operands of the packed arithmetic; LDC = 128 (every N <= 128)
 // turns the row offsets into instruction immediates -- 6 LDS instructions and one address per iteration
 // instead of 12 + 12.  (Row padding is zero-filled, so the odd-N tail reads finite values.)
-template <int LEVEL, int LDC>
+template <int LEVEL, int LDC, bool EVEN, bool NEAR>
 __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, float& th_sig, float& th_eps, bool th_on) {
@@ -61,20 +61,21 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
     const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
     // 4 eps and the q-term coefficient folded into the polynomial coefficients (A = s6, B = s12)
     const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;                 // phi'/r  = (m1a A - m1b B) / d2
-    const float dua = 42.f * e4 * cq, dub = 156.f * e4;               // phi''   = (dub B - dua A) / d2
+    const float ka = (42.f + 6.f) * e4 * cq, kb = (156.f + 12.f) * e4;   // phi'' - phi'/r = (kb B - ka A) / d2
     const float tsa = 18.f * e4 * t0.k2 * cq, tsb = 72.f * e4 * t0.k2;   // 1/2 d(phi'/r)/dsig r-part
     const float tea = 12.f * cq, teb = 24.f;                          // 2 m1 / (4 eps)
-    const bool want_th = LEVEL >= 2 && th_on;
     const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
     const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
-    f32x2 ts = {0.f, 0.f}, te = {0.f, 0.f};
+    // theta gradients: both are linear in  S6 = sum s6 (w.D)/d2  and  S12 = sum s12 (w.D)/d2, so the loop
+    // carries those two sums only (2 packed fma per pair-of-pairs, no branch on th_on)
+    f32x2 S6 = {0.f, 0.f}, S12 = {0.f, 0.f};
     for (int i = slot; i < N; i += slots) {
         const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
         if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
         for (int j = 2 * sub; j < N; j += 2 * TPA) {
-            const bool live2 = j + 1 < N;
+            const bool live2 = EVEN || j + 1 < N;           // (EVEN: N is even, every lane pair is live)
             const float* qj = q + j;
             const f32x2 qx = *reinterpret_cast<const f32x2*>(qj), qy = *reinterpret_cast<const f32x2*>(qj + LD),
                         qz = *reinterpret_cast<const f32x2*>(qj + 2 * LD);
@@ -85,44 +86,49 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
                 ax = wxi - *reinterpret_cast<const f32x2*>(wj); ay = wyi - *reinterpret_cast<const f32x2*>(wj + LD);
                 az = wzi - *reinterpret_cast<const f32x2*>(wj + 2 * LD);
             }
-            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            if constexpr (NEAR) {
+                dx = min_image_diag2_near(dx, ivx, hx); dy = min_image_diag2_near(dy, ivy, hy);
+                dz = min_image_diag2_near(dz, ivz, hz);
+            } else {
+                dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            }
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
             const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);                         // topology.py:67
             const bool ok1 = live2 && (d2.y != 0.f) && (d2.y < rc2);
-            const f32x2 sel = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
-            const f32x2 i2 = {__builtin_amdgcn_rcpf(ok0 ? d2.x : rc2), __builtin_amdgcn_rcpf(ok1 ? d2.y : rc2)};
+            // 1/d2 selected to 0 for a rejected pair (the rcp of a self pair's 0 is never used): s6, s12 and
+            // everything below are then exactly zero
+            const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
             const f32x2 s2 = sig2 * i2;
             const f32x2 s6 = s2 * s2 * s2;
             const f32x2 s12 = s6 * s6;
-            const f32x2 i2s = i2 * sel;                       // rejected pairs contribute exactly zero
-            const f32x2 c1 = (m1a * s6 - m1b * s12) * i2s;
+            const f32x2 c1 = (m1a * s6 - m1b * s12) * i2;
             fx += c1 * dx; fy += c1 * dy; fz += c1 * dz;      // F_i += (phi'/r) D
             if (LEVEL >= 2) {
                 const f32x2 b = dx * ax + dy * ay + dz * az;
-                const f32x2 bi = b * i2s;
-                const f32x2 d2u = (dub * s12 - dua * s6) * i2;
-                const f32x2 k2 = (d2u - c1) * bi;
-                gx -= k2 * dx + c1 * ax;
-                gy -= k2 * dy + c1 * ay;
-                gz -= k2 * dz + c1 * az;
-                if (want_th) {                                // (uniform branch: the first NHC evaluation skips it)
-                    ts += (tsa * s6 - tsb * s12) * bi;
-                    te += (tea * s6 - teb * s12) * bi;
-                }
+                const f32x2 bi = b * i2;                      // (w.D) / d2
+                const f32x2 k2 = (kb * s12 - ka * s6) * (bi * i2);   // (phi'' - phi'/r) (w.D) / d2
+                gx += k2 * dx; gx += c1 * ax;                 // (accumulated with the opposite sign: two fma per
+                gy += k2 * dy; gy += c1 * ay;                 //  component; negated once after the reduction)
+                gz += k2 * dz; gz += c1 * az;
+                S6 += s6 * bi; S12 += s12 * bi;
             }
         }
         float sx = group_sum_rt(fx.x + fx.y, TPA), sy = group_sum_rt(fy.x + fy.y, TPA), sz = group_sum_rt(fz.x + fz.y, TPA);
         float ux = 0.f, uy = 0.f, uz = 0.f;
         if (LEVEL >= 2) {
-            ux = group_sum_rt(gx.x + gx.y, TPA); uy = group_sum_rt(gy.x + gy.y, TPA); uz = group_sum_rt(gz.x + gz.y, TPA);
+            ux = -group_sum_rt(gx.x + gx.y, TPA); uy = -group_sum_rt(gy.x + gy.y, TPA);
+            uz = -group_sum_rt(gz.x + gz.y, TPA);
         }
         if (sub == 0) {
             f[i] = sx; f[LD + i] = sy; f[2 * LD + i] = sz;
             if (LEVEL >= 2) { dq[i] = ux; dq[LD + i] = uy; dq[2 * LD + i] = uz; }
         }
     }
-    th_sig += ts.x + ts.y;
-    th_eps += te.x + te.y;
+    if (LEVEL >= 2 && th_on) {                                // (the first NHC evaluation of an interval skips it)
+        const float a6 = S6.x + S6.y, a12 = S12.x + S12.y;
+        th_sig += tsa * a6 - tsb * a12;
+        th_eps += tea * a6 - teb * a12;
+    }
 }
 
 // Tabulated pair model (MDG_PAIR_TABLE): c1(u) = phi'(r)/r on a uniform grid in u = r^2, cubic-Hermite
@@ -250,8 +256,25 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     for (int m = 0; m < NT; ++m)
         if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
     if constexpr (KIND == KIND_LJ126) {
-        if (A.ld == 128) force_lj126_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
-        else force_lj126_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+        // fast variant: even N and every atom within [-0.24, 1.24] cell lengths (one block-wide vote per
+        // evaluation; positions are wrapped at every epoch, md.py:66, so a trajectory leaves the window only
+        // after drifting a quarter cell), else the general one
+        bool out = false;
+        for (int c = 0; c < 3; ++c) {
+            const float iv = A.cell.inv[4 * c];
+            for (int i = threadIdx.x; i < N; i += blockDim.x) {
+                const float sc = q[c * LD + i] * iv;
+                out |= !(sc > -0.24f && sc < 1.24f);
+            }
+        }
+        const bool near = !(N & 1) && !__syncthreads_or(out);
+        if (A.ld == 128) {
+            if (near) force_lj126_packed<LEVEL, 128, true, true>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+            else force_lj126_packed<LEVEL, 128, false, false>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+        } else {
+            if (near) force_lj126_packed<LEVEL, 0, true, true>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+            else force_lj126_packed<LEVEL, 0, false, false>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
+        }
         return;
     }
     if constexpr (KIND >= 0) {
