@@ -223,7 +223,8 @@ __global__ __launch_bounds__(RDF_BLOCK) void rdf_fwd_block8_kernel(
 // Gaussians are deposited with plain (conflict-free, order-fixed) LDS adds -- no bin-owner sweep, every
 // pair is looked at exactly once.  Only the 2R+1 bins around the nearest centre kc are touched: the
 // centre value and two outward recurrences (as in the block-of-8 kernel); the nearest bin left out is
-// (R + 1/2) Ds >= 5.3 away, where the Gaussian is below 2^-28 of the peak, i.e. under fp32 rounding of the sums.  Real bin k lives in row
+// (R + 1/2) Ds >= 4.65 away, where the Gaussian is below 2^-21.6 of the peak: a relative 3e-7 of a bin's count
+// in the worst case, under the fp32 rounding of a sum of thousands of terms.  Real bin k lives in row
 // k + 2R; rows outside [2R, 2R + nbins) are write-only padding so that no deposit needs a bounds test.
 // The columns are summed in a fixed order at the end => bitwise reproducible.
 //
@@ -482,11 +483,8 @@ __device__ __forceinline__ FineGrid fine_grid(const float* __restrict__ mu, int 
 }
 
 // node table of dL/dd: tab[n] = (sum_k sg_k x e , hf * d/dd of that), x = s (x_n - mu_k), e = exp2(-x^2)
-__global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, int nbins,
-                                     const float* __restrict__ g_raw, int R, float2* __restrict__ tab) {
-    const FineGrid G = fine_grid(mu, nbins, R);
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= G.nn) return;
+__device__ __forceinline__ float2 rdf_fine_node(const FineGrid& G, const float* __restrict__ mu, float coeff, int nbins,
+                                                const float* __restrict__ g_raw, int R, int n) {
     const float sc = sqrtf(-coeff * LOG2E);
     const float mu0 = mu[0], dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
     const float x = fmaf((float)n, G.hf, G.xlo);
@@ -499,62 +497,133 @@ __global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, 
         val = fmaf(sg * xs, e, val);
         der = fmaf(sg * sc * (1.f - 2.f * 0.69314718056f * xs * xs), e, der);
     }
-    tab[n] = make_float2(val, der * G.hf);
+    return make_float2(val, der * G.hf);
+}
+// cell n = nodes n and n + 1: {value, hf slope, value, hf slope}
+__global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, int nbins,
+                                     const float* __restrict__ g_raw, int R, float4* __restrict__ tab) {
+    const FineGrid G = fine_grid(mu, nbins, R);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= G.nn - 1) return;
+    const float2 a_ = rdf_fine_node(G, mu, coeff, nbins, g_raw, R, n), b_ = rdf_fine_node(G, mu, coeff, nbins, g_raw, R, n + 1);
+    tab[n] = make_float4(a_.x, a_.y, b_.x, b_.y);
 }
 
+// Fine-grid backward, one wave per frame.  Pair order: lane <-> atom i (64 at a time), step s <-> partner
+// j = (i + s) mod N, s = 1 .. N/2 (for an even N the last step only for i < N/2): every unordered pair once, and
+// in one step the partners of the 64 lanes are all different, so the partners' gradient read-add-writes never
+// collide, while atom i's own gradient accumulates in registers (half the LDS traffic of a pair order that
+// scatters both ends).  Positions and partner gradients live in index-doubled arrays (entry k and k + N are the
+// same atom; the two gradient halves are folded at the end): the partner address is affine in s, no modulo.
+// Two steps per iteration in packed fp32; the stores of step s precede the reads of step s + 1 (lane l's second
+// partner is lane l + 1's first).  The table holds one float4 per cell, {value, hf slope} of both end nodes.
 template <bool DIAG>
 __global__ __launch_bounds__(256) void rdf_bwd_fine_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
-    const float* __restrict__ mu, int nbins, int R, const float2* __restrict__ tab_g, float* __restrict__ g_xyz) {
+    const float* __restrict__ mu, int nbins, int R, const float4* __restrict__ tab_g, int LDW,
+    float* __restrict__ g_xyz) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const FineGrid G = fine_grid(mu, nbins, R);
-    float2* tab = reinterpret_cast<float2*>(sm);                     // [nn]
+    float4* tab = reinterpret_cast<float4*>(sm);                     // [nn - 1] cells
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float* px = sm + 2 * ((G.nn + 1) & ~1) + (size_t)wid * 6 * N;    // positions [3][N] then gradient [3][N]
-    float* gx = px + 3 * N;
-    for (int n = threadIdx.x; n < G.nn; n += blockDim.x) tab[n] = tab_g[n];
+    float* px = sm + 4 * (size_t)(G.nn - 1) + (size_t)wid * 6 * LDW; // positions [3][LDW] then gradient [3][LDW]
+    float* gx = px + 3 * LDW;
+    for (int n = threadIdx.x; n < G.nn - 1; n += blockDim.x) tab[n] = tab_g[n];
+    for (int e = lane; e < 6 * LDW; e += 64) px[e] = 0.f;
     __syncthreads();
     const int fr = blockIdx.x * (blockDim.x >> 6) + wid;
     if (fr >= nF) return;
     const float* pos = xyz + (size_t)fr * N * 3;
-    for (int e = lane; e < 3 * N; e += 64) { px[(e % 3) * N + e / 3] = pos[e]; gx[e] = 0.f; }
-    const float tmax = (float)(G.nn - 1);
-    const int Np = N + (N & 1);              // even number of tournament slots (one dummy when N is odd)
-    const int M = Np - 1, half = Np / 2;
-    for (int r = 0; r < M; ++r) {
-        for (int p0 = 0; p0 < half; p0 += 64) {
-            const int p = p0 + lane;
-            int a = -1, b = -1;
-            if (p < half) {
-                if (p == 0) { a = M; b = r; }
-                else { a = r + p; if (a >= M) a -= M; b = r - p; if (b < 0) b += M; }
-                if (a >= N || b >= N) a = -1;                     // pair with the dummy slot
-            }
-            if (a >= 0) {
-                const int i = min(a, b), j = max(a, b);
-                float dx = px[j] - px[i], dy = px[N + j] - px[N + i], dz = px[2 * N + j] - px[2 * N + i];
-                min_image<DIAG>(cell, dx, dy, dz);               // D = x_j - x_i as the forward pass
-                const float d2 = norm2_ref(dx, dy, dz);
-                bool ok = (d2 < rc2) && (d2 != 0.f);
-                if (ok && mask) ok = mask[(size_t)i * N + j] != 0;
-                const float id = __builtin_amdgcn_rsqf(ok ? d2 : 1.f);
-                const float t = (d2 * id - G.xlo) * G.inv_hf;
-                ok = ok && t >= 0.f && t < tmax;
-                if (ok) {
-                    const int g = (int)t;
-                    const float f = t - (float)g, om = 1.f - f, f2 = f * f, om2 = om * om;
-                    const float2 n0 = tab[g], n1 = tab[g + 1];
-                    const float sd = (1.f + 2.f * f) * om2 * n0.x + f * om2 * n0.y + f2 * (3.f - 2.f * f) * n1.x +
-                                     f2 * (f - 1.f) * n1.y;
-                    const float c = sd * id;                      // d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d
-                    gx[j] += c * dx; gx[N + j] += c * dy; gx[2 * N + j] += c * dz;
-                    gx[i] -= c * dx; gx[N + i] -= c * dy; gx[2 * N + i] -= c * dz;
-                }
-            }
+    const float ivx = cell.inv[0], ivy = cell.inv[4], ivz = cell.inv[8];
+    bool out = false;
+    for (int e = lane; e < 3 * N; e += 64) {
+        const int c = e % 3, a = e / 3;
+        const float v = pos[e];
+        px[c * LDW + a] = v;
+        px[c * LDW + a + N] = v;
+        if (DIAG) {
+            const float s_ = v * (c == 0 ? ivx : c == 1 ? ivy : ivz);
+            out |= !(s_ > -0.24f && s_ < 1.24f);
         }
     }
-    float* out = g_xyz + (size_t)fr * N * 3;
-    for (int e = lane; e < 3 * N; e += 64) out[e] = gx[(e % 3) * N + e / 3];
+    const bool near = DIAG && !__any(out);                           // see rdf_fwd_lane_kernel
+    const float tmax = (float)(G.nn - 1);
+    const int smax = N / 2;                                          // steps (the last one is the half step of an even N)
+    auto sweep = [&](auto near_c) {
+        constexpr bool NEAR = decltype(near_c)::value;
+        for (int i0 = 0; i0 < N; i0 += 64) {
+            const int i = i0 + lane;                                 // (lanes past N run on zeros and add +-0)
+            const bool live = i < N;
+            const int lim = !live ? 0 : ((N & 1) ? (N - 1) / 2 : (i >= N / 2 ? smax - 1 : smax));
+            const float xi = px[i], yi = px[LDW + i], zi = px[2 * LDW + i];
+            f32x2 ax = {0.f, 0.f}, ay = ax, az = ax;                 // - gradient of atom i, two partial sums
+            const float* pj = px + i;
+            float* gj = gx + i;
+            for (int s_ = 1; s_ <= smax; s_ += 2) {
+                pj += 2; gj += 2;                                    // -> partner i + s_ + 1 (the first one is at [-1])
+                f32x2 dx = f32x2{pj[-1], pj[0]} - xi, dy = f32x2{pj[LDW - 1], pj[LDW]} - yi,
+                      dz = f32x2{pj[2 * LDW - 1], pj[2 * LDW]} - zi;   // D = x_j - x_i
+                if constexpr (NEAR) {
+                    dx = min_image_diag2_near(dx, ivx, cell.h[0]);
+                    dy = min_image_diag2_near(dy, ivy, cell.h[4]);
+                    dz = min_image_diag2_near(dz, ivz, cell.h[8]);
+                } else if constexpr (DIAG) {
+                    dx = min_image_diag2(dx, ivx, cell.h[0]);
+                    dy = min_image_diag2(dy, ivy, cell.h[4]);
+                    dz = min_image_diag2(dz, ivz, cell.h[8]);
+                } else {
+                    float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
+                    min_image<false>(cell, ax_, ay_, az_);
+                    min_image<false>(cell, bx_, by_, bz_);
+                    dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
+                }
+                const f32x2 d2 = norm2_ref2(dx, dy, dz);
+                bool okA = (s_ <= lim) & (d2.x < rc2) & (d2.x != 0.f), okB = (s_ + 1 <= lim) & (d2.y < rc2) & (d2.y != 0.f);
+                if (mask) {                                                  // (uniform)
+                    const int ii = live ? i : 0;
+                    int ja = ii + s_, jb = ii + s_ + 1;
+                    ja = ja >= N ? ja - N : ja; jb = jb >= N ? jb - N : jb;
+                    jb = jb >= N ? jb - N : jb;
+                    okA = okA & (mask[(size_t)min(ii, ja) * N + max(ii, ja)] != 0);
+                    okB = okB & (mask[(size_t)min(ii, jb) * N + max(ii, jb)] != 0);
+                }
+                const f32x2 id = {__builtin_amdgcn_rsqf(okA ? d2.x : 1.f), __builtin_amdgcn_rsqf(okB ? d2.y : 1.f)};
+                f32x2 t = (d2 * id - G.xlo) * G.inv_hf;
+                okA = okA & (t.x >= 0.f) & (t.x < tmax);
+                okB = okB & (t.y >= 0.f) & (t.y < tmax);
+                t = f32x2{okA ? t.x : 0.f, okB ? t.y : 0.f};
+                const int gA = (int)t.x, gB = (int)t.y;
+                const f32x2 f = t - f32x2{(float)gA, (float)gB};
+                const float4 ca = tab[gA], cb = tab[gB];
+                const f32x2 om = 1.f - f, f2 = f * f, om2 = om * om;
+                const f32x2 h00 = (1.f + 2.f * f) * om2, h10 = f * om2, h01 = f2 * (3.f - 2.f * f), h11 = f2 * (f - 1.f);
+                const float sdA = h00.x * ca.x + h10.x * ca.y + h01.x * ca.z + h11.x * ca.w;
+                const float sdB = h00.y * cb.x + h10.y * cb.y + h01.y * cb.z + h11.y * cb.w;
+                // d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d; a rejected pair adds +-0
+                const f32x2 cw = f32x2{okA ? sdA : 0.f, okB ? sdB : 0.f} * id;
+                const f32x2 cx = cw * dx, cy = cw * dy, cz = cw * dz;
+                ax += cx; ay += cy; az += cz;
+                {
+                    const float g0 = gj[-1], g1 = gj[LDW - 1], g2 = gj[2 * LDW - 1];
+                    gj[-1] = g0 + cx.x; gj[LDW - 1] = g1 + cy.x; gj[2 * LDW - 1] = g2 + cz.x;
+                }
+                {
+                    const float g0 = gj[0], g1 = gj[LDW], g2 = gj[2 * LDW];
+                    gj[0] = g0 + cx.y; gj[LDW] = g1 + cy.y; gj[2 * LDW] = g2 + cz.y;
+                }
+            }
+            if (live) {
+                gx[i] -= ax.x + ax.y; gx[LDW + i] -= ay.x + ay.y; gx[2 * LDW + i] -= az.x + az.y;
+            }
+        }
+    };
+    if (near) sweep(std::true_type{});
+    else sweep(std::false_type{});
+    float* out_g = g_xyz + (size_t)fr * N * 3;
+    for (int e = lane; e < 3 * N; e += 64) {
+        const int c = e % 3, a = e / 3;
+        out_g[e] = gx[c * LDW + a] + gx[c * LDW + a + N];
+    }
 }
 
 // raw[k] = sum_b partial[b][k] in fixed order; one wave per bin
@@ -748,6 +817,13 @@ static int rdf_lane_reach(float spacing_s) {
     if (spacing_s >= 0.465f) return 11;
     return 0;
 }
+// reach of the forward lane kernel (the 2R+1 rows a pair touches are its LDS traffic, so it is cut closer than
+// the backward table's): (R + 1/2) Ds >= 4.65
+static int rdf_fwd_reach(float spacing_s) {
+    if (spacing_s >= 0.8455f) return 5;
+    if (spacing_s >= 0.405f) return 11;
+    return 0;
+}
 static size_t rdf_lane_lds(int nw, int R, int pxld, int nbins) {
     return sizeof(float) * ((size_t)(nbins + 2 * R) + (size_t)nw * ((size_t)(nbins + 4 * R) * 64 + 3 * (size_t)pxld));
 }
@@ -763,7 +839,7 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
     hipStream_t st = (hipStream_t)stream;
     // equally spaced centres with Ds = s * spacing <= 1: 8-bin blocks + recurrence (spacing_s is the
     // caller's statement that mu is a linspace; <= 0 selects the direct kernel)
-    const int R = n_frames >= 1024 && nbins >= 2 && n_atoms <= RDF_TABLE_MAX_ATOMS ? rdf_lane_reach(spacing_s) : 0;
+    const int R = n_frames >= 1024 && nbins >= 2 && n_atoms <= RDF_TABLE_MAX_ATOMS ? rdf_fwd_reach(spacing_s) : 0;
     if (R) {
         // coordinate stride: even, with at least two NaN columns after the atoms for the padding entries;
         // compile-time (immediate LDS offsets) for the common shape: orthorhombic, no mask
@@ -795,7 +871,7 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
         else if (mask) MDG_RDF_LANE(false, RR, true, 0);               \
         else MDG_RDF_LANE(false, RR, false, 0);                        \
     } while (0)
-            if (R == 6) MDG_RDF_LANE_R(6); else MDG_RDF_LANE_R(11);
+            if (R == 5) MDG_RDF_LANE_R(5); else MDG_RDF_LANE_R(11);
 #undef MDG_RDF_LANE_R
 #undef MDG_RDF_LANE
             hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, grid * nw, nbins, raw);
@@ -868,24 +944,26 @@ static int rdf_bwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
         // table of dL/dd on the fine nodes (stream-ordered scratch: no state, re-entrant), then the
         // tournament kernel with a table lookup per pair
         const int nn = fine_nodes(nbins, R);
-        const size_t tabf = 2 * (size_t)((nn + 1) & ~1);
+        const size_t tabf = 4 * (size_t)(nn - 1);
+        // index-doubled rows: the last lane group's idle lanes reach index 64 ceil(N/64) - 1 + N/2 + 1
+        const int ldw = (max(2 * n_atoms, 64 * ((n_atoms + 63) / 64) + n_atoms / 2 + 1) + 2) & ~1;
         int wpb = 4;
-        while (wpb > 1 && sizeof(float) * (tabf + (size_t)wpb * 6 * n_atoms) > 150 * 1024) wpb >>= 1;
-        const size_t lds = sizeof(float) * (tabf + (size_t)wpb * 6 * n_atoms);
+        while (wpb > 1 && sizeof(float) * (tabf + (size_t)wpb * 6 * ldw) > 150 * 1024) wpb >>= 1;
+        const size_t lds = sizeof(float) * (tabf + (size_t)wpb * 6 * ldw);
         if (lds <= 160 * 1024) {
-            float2* tab = nullptr;
-            if (hipMallocAsync((void**)&tab, sizeof(float2) * (size_t)nn, st) != hipSuccess || !tab) {
+            float4* tab = nullptr;
+            if (hipMallocAsync((void**)&tab, sizeof(float4) * (size_t)(nn - 1), st) != hipSuccess || !tab) {
                 mdg_set_error("rdf_bwd: scratch allocation failed");
                 return MDG_ELAUNCH;
             }
-            hipLaunchKernelGGL(rdf_bwd_table_kernel, dim3((nn + 255) / 256), dim3(256), 0, st, mu, coeff, nbins, g_raw, R, tab);
+            hipLaunchKernelGGL(rdf_bwd_table_kernel, dim3((nn + 254) / 256), dim3(256), 0, st, mu, coeff, nbins, g_raw, R, tab);
             const int nblocks = (n_frames + wpb - 1) / wpb;
             if (cell->diag)
                 hipLaunchKernelGGL(rdf_bwd_fine_kernel<true>, dim3(nblocks), dim3(64 * wpb), lds, st, xyz, n_frames, n_atoms,
-                                   *cell, cutoff * cutoff, mask, mu, nbins, R, tab, g_xyz);
+                                   *cell, cutoff * cutoff, mask, mu, nbins, R, tab, ldw, g_xyz);
             else
                 hipLaunchKernelGGL(rdf_bwd_fine_kernel<false>, dim3(nblocks), dim3(64 * wpb), lds, st, xyz, n_frames, n_atoms,
-                                   *cell, cutoff * cutoff, mask, mu, nbins, R, tab, g_xyz);
+                                   *cell, cutoff * cutoff, mask, mu, nbins, R, tab, ldw, g_xyz);
             (void)hipFreeAsync(tab, st);
             MDG_CHECK_LAUNCH("rdf_bwd_fine_kernel");
             return MDG_OK;
