@@ -1049,3 +1049,85 @@ def test_fused_lj_odd_and_tiny_atom_counts_vs_oracle(n_atoms):
     close(y0[1].grad, lam[1], 5e-3, 1e-3 * float(lam[1].abs().max()) + 1e-6, "adj q0")
     got = np.array([float(mdl.sigma.grad), float(mdl.epsilon.grad)])
     close(got, gth.numpy(), 5e-3, 1e-3 * float(np.abs(gth.numpy()).max()) + 1e-6, "dL/dtheta")
+
+
+@pytest.mark.parametrize("shift,n_cells", [(0.3, 3), (0.0, 4)])
+def test_fused_lj_outside_the_near_window_and_256_atoms_vs_oracle(shift, n_cells):
+    """The packed LJ 12-6 loops use a plain-rint minimum image while every atom is within [-0.24, 1.24] cell
+    lengths and fall back to the clamped one otherwise: (a) all positions translated by 0.3 cell (general
+    variant; pair geometry unchanged), (b) 256 atoms (run-time LDS row stride, even N, fast variant)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("nhc_traj_lj")
+    if n_cells == 3:
+        pos, vel, mass, cell = g["pos"], g["vel"], g["mass"], g["cell"]
+    else:
+        rng = np.random.default_rng(5)
+        a = 1.6
+        basis = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+        pos = np.array([(np.array([i, j, k]) + b) * a for i in range(4) for j in range(4) for k in range(4) for b in basis])
+        pos = (pos + rng.uniform(-0.05, 0.05, pos.shape)).astype(np.float32) % (4 * a)
+        vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+        mass = np.full(len(pos), 1.008, np.float32)
+        cell = np.array([4 * a] * 3, np.float32)
+    pos = (pos + shift * np.asarray(cell)).astype(np.float32)
+    system = mk_system(pos, cell, vel, mass)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5,
+                            Q=50.0).to(DEV)
+    assert integ.fused_spec("NH_verlet") is not None
+    t = torch.Tensor([0.005 * i for i in range(6)])
+    y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=False)]
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="NH_verlet")
+    (q_t[::2].pow(2).sum() * 1e-2 + v_t[-1].pow(2).sum() + pv_t[-1].sum()).backward()
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1)
+    traj, lam, gth = oracle_run(pos, cell, vel, mass, [term], 1.0, 50.0, 5, t,
+                                lambda L: L[1][::2].pow(2).sum() * 1e-2 + L[0][-1].pow(2).sum() + L[2][-1].sum())
+    close(q_t, traj[1], 1e-4, 2e-5, "q_t")
+    close(v_t, traj[0], 1e-3, 2e-4, "v_t")
+    close(y0[0].grad, lam[0], 5e-3, 1e-3 * float(lam[0].abs().max()) + 1e-6, "adj v0")
+    close(y0[1].grad, lam[1], 5e-3, 1e-3 * float(lam[1].abs().max()) + 1e-6, "adj q0")
+    got = np.array([float(mdl.sigma.grad), float(mdl.epsilon.grad)])
+    close(got, gth.numpy(), 5e-3, 1e-3 * float(np.abs(gth.numpy()).max()) + 1e-6, "dL/dtheta")
+
+
+def test_rdf_lane_kernels_general_variants():
+    """The many-frame RDF kernels outside their fast path: frames translated by 0.3 cell (clamped minimum
+    image), a triclinic cell, 150 atoms (run-time coordinate stride, no 128-column rows), and an even atom
+    count with a species mask (the half step of the backward's cyclic order) -- each against the direct
+    kernels on the same input."""
+    from mdgrad_amd import ops, _lib
+    g = load_golden("rdf")
+    rng = np.random.default_rng(12)
+    base = g["xyz"][0]
+    L = np.asarray(g["cell"], np.float32)
+    frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), L) for _ in range(1030)]).astype(np.float32)
+    mu = torch.linspace(0.75, 2.5, 100, device=DEV)
+    spacing = float(mu[1] - mu[0])
+    coeff = float(-0.5 / spacing ** 2)
+    w = torch.linspace(-1, 1, 100, device=DEV)
+
+    def both(x, cs, mask, cutoff=3.0):
+        out = []
+        for sp in (spacing, 0.0):
+            xg = T(x, DEV).requires_grad_(True)
+            raw = ops.RdfRawFn.apply(xg, mu, coeff, cutoff, cs, mask, sp)
+            (gx,) = torch.autograd.grad((raw * w).sum(), xg)
+            out.append((raw.detach(), gx))
+        return out
+
+    def check(x, cs, mask, what, cutoff=3.0):
+        (ra, ga), (rb, gb) = both(x, cs, mask, cutoff)
+        close(ra, rb, 2e-5, 1e-6 * float(rb.max()), what + ": forward")
+        close(ga, gb, 1e-4, 3e-5 * float(gb.abs().max()), what + ": backward")
+
+    cs = _lib.make_cell(g["cell"])
+    check(frames + 0.3 * L, cs, None, "translated frames")
+    tri = np.array([[4.8, 0, 0], [0.7, 4.8, 0], [-0.5, 0.4, 4.8]], np.float32)
+    check(frames, _lib.make_cell(tri), None, "triclinic cell", cutoff=2.3)
+    big = np.concatenate([frames, frames[:, :42] + np.float32(0.37)], axis=1)        # 150 atoms
+    check(np.mod(big, L), cs, None, "150 atoms")
+    mask = ops.build_mask(108, index_tuple=(list(range(0, 40)), list(range(40, 108))), device=DEV)
+    check(frames, cs, mask, "even N with a mask")
