@@ -153,7 +153,7 @@ __device__ __forceinline__ void table_scatter(const TableRef& T, int idx, float 
     atomicAdd(T.glo + idx, (int)rintf(lo));
 }
 
-template <int LEVEL, int LDC>
+template <int LEVEL, int LDC, bool NEAR>
 __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
                                                    const float* __restrict__ w, float* __restrict__ f,
                                                    float* __restrict__ dq, const TableRef& T, float& vmax) {
@@ -173,7 +173,7 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
         if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
         for (int j = 2 * sub; j < N; j += 2 * TPA) {                             // consecutive pair (j, j+1): see force_lj126_packed
-            const bool live2 = j + 1 < N;
+            const bool live2 = NEAR || j + 1 < N;                                 // (NEAR implies an even N)
             const float* qj = q + j;
             f32x2 dx = *reinterpret_cast<const f32x2*>(qj) - xi, dy = *reinterpret_cast<const f32x2*>(qj + LD) - yi,
                   dz = *reinterpret_cast<const f32x2*>(qj + 2 * LD) - zi;          // D = x_j - x_i
@@ -183,7 +183,12 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
                 ax = wxi - *reinterpret_cast<const f32x2*>(wj); ay = wyi - *reinterpret_cast<const f32x2*>(wj + LD);
                 az = wzi - *reinterpret_cast<const f32x2*>(wj + 2 * LD);
             }
-            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            if constexpr (NEAR) {
+                dx = min_image_diag2_near(dx, ivx, hx); dy = min_image_diag2_near(dy, ivy, hy);
+                dz = min_image_diag2_near(dz, ivz, hz);
+            } else {
+                dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            }
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
             const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);                         // topology.py:67
             const bool ok1 = live2 && (d2.y != 0.f) && (d2.y < rc2);
@@ -241,12 +246,32 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
                                                 const float* __restrict__ w, float* __restrict__ f,
                                                 float* __restrict__ dq, float (&dth)[KMAX], const TableRef& TB,
                                                 float& vmax, bool th_on = true) {
+    const int N = A.prm.n_atoms, LD = A.ld;
+    // fast variant of the packed loops: even N and every atom within [-0.24, 1.24] cell lengths (one block-wide
+    // vote per evaluation; positions are wrapped at every epoch, md.py:66, so a trajectory leaves the window
+    // only after drifting a quarter cell), else the general one
+    bool near = false;
+    if constexpr (KIND == KIND_TABLE || KIND == KIND_LJ126) {
+        bool out = false;
+        for (int c = 0; c < 3; ++c) {
+            const float iv = A.cell.inv[4 * c];
+            for (int i = threadIdx.x; i < N; i += blockDim.x) {
+                const float sc = q[c * LD + i] * iv;
+                out |= !(sc > -0.24f && sc < 1.24f);
+            }
+        }
+        near = !(N & 1) && !__syncthreads_or(out);
+    }
     if constexpr (KIND == KIND_TABLE) {
-        if (A.ld == 128) force_table_packed<LEVEL, 128>(A, tpa_log2, q, w, f, dq, TB, vmax);
-        else force_table_packed<LEVEL, 0>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        if (A.ld == 128) {
+            if (near) force_table_packed<LEVEL, 128, true>(A, tpa_log2, q, w, f, dq, TB, vmax);
+            else force_table_packed<LEVEL, 128, false>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        } else {
+            if (near) force_table_packed<LEVEL, 0, true>(A, tpa_log2, q, w, f, dq, TB, vmax);
+            else force_table_packed<LEVEL, 0, false>(A, tpa_log2, q, w, f, dq, TB, vmax);
+        }
         return;
     }
-    const int N = A.prm.n_atoms, LD = A.ld;
     const int TPA = 1 << tpa_log2;
     const int slots = blockDim.x >> tpa_log2;
     const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
@@ -256,18 +281,6 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     for (int m = 0; m < NT; ++m)
         if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
     if constexpr (KIND == KIND_LJ126) {
-        // fast variant: even N and every atom within [-0.24, 1.24] cell lengths (one block-wide vote per
-        // evaluation; positions are wrapped at every epoch, md.py:66, so a trajectory leaves the window only
-        // after drifting a quarter cell), else the general one
-        bool out = false;
-        for (int c = 0; c < 3; ++c) {
-            const float iv = A.cell.inv[4 * c];
-            for (int i = threadIdx.x; i < N; i += blockDim.x) {
-                const float sc = q[c * LD + i] * iv;
-                out |= !(sc > -0.24f && sc < 1.24f);
-            }
-        }
-        const bool near = !(N & 1) && !__syncthreads_or(out);
         if (A.ld == 128) {
             if (near) force_lj126_packed<LEVEL, 128, true, true>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
             else force_lj126_packed<LEVEL, 128, false, false>(A, tpa_log2, q, w, f, dq, dth[0], dth[1], th_on);
