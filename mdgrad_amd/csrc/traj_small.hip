@@ -722,10 +722,16 @@ int pick_tpa_log2(int n_atoms, int block) {
     return l;
 }
 
-int pick_block(const MdgTrajParams& p) {
+int pick_block(const MdgTrajParams& p, bool table) {
     if (p.block > 0) return p.block;
-    // few replicas: widest workgroup (latency); many replicas: 256 threads, several per CU
-    if (p.n_rep >= 1024) return 256;
+    // few replicas: widest workgroup (latency); many replicas: one lane per atom (no cross-lane reduction of
+    // the per-atom sums, small workgroups interleave better: 128 vs 256 threads at N = 108 is -11 % adjoint time)
+    // (the tabulated kind keeps 256: its gradient scatter into LDS likes two lanes per atom, measured +16 %)
+    if (p.n_rep >= 1024 && table) return 256;
+    if (p.n_rep >= 1024) {
+        const int b = (p.n_atoms + 63) & ~63;
+        return b < 128 ? 128 : (b > 1024 ? 1024 : b);
+    }
     if (p.n_rep >= 256) return 512;
     return 1024;
 }
@@ -790,7 +796,7 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
     a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
     const int N = prm->n_atoms;
-    const int block = pick_block(*prm);
+    const int block = pick_block(*prm, terms->t[0].kind == MDG_PAIR_TABLE);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 2 * (size_t)terms->t[0].p : 0;
     MDG_CHECK_ARG(!tab || theta, "traj_fwd: the table is passed through theta");
     a.ld = N <= 128 ? 128 : (N + 1) & ~1;
@@ -821,7 +827,7 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
     a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
     const int N = prm->n_atoms;
-    const int block = pick_block(*prm);
+    const int block = pick_block(*prm, terms->t[0].kind == MDG_PAIR_TABLE);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + two int32 planes
     MDG_CHECK_ARG(!tab || theta, "traj_adj: the table is passed through theta");
     a.ld = N <= 128 ? 128 : (N + 1) & ~1;
