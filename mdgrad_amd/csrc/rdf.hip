@@ -258,6 +258,123 @@ __global__ __launch_bounds__(256) void rdf_pair_table_kernel(uint32_t* __restric
 
 constexpr int RDF_TABLE_MAX_ATOMS = 4096;      // 4 j < 2^16 and a table of at most 16 MB
 
+// Constants of the deposit: e_{+-s} = e0 r^s K_s with r = exp2(+-2 Ds x0 - Ds^2) <= 1 and K_s = c2^(s(s-1)/2),
+// K_0 = K_1 = 1.  Bins are handled two adjacent rows at a time (one ds_read2st64 / ds_write2st64 and one packed
+// fma per two bins): the packed power {r^s, r^(s+1)} advances by r^2.  Outward chain s = 0 (the centre) .. R,
+// inward chain s = 1 .. R.
+template <int R>
+struct RdfLane {
+    static constexpr int NPO = (R + 1) / 2, NPI = R / 2;
+    static constexpr bool TAIL_O = ((R + 1) & 1) != 0, TAIL_I = (R & 1) != 0;   // one unpaired row at the far end
+    float sc, mu0, inv_dmu, dmu, Ds, Ds2, Klast;
+    f32x2 Ko[NPO], Ki[NPI > 0 ? NPI : 1];                       // outward {K_2m, K_2m+1}, inward {K_2m+2, K_2m+1}
+    struct Rows { f32x2 vo[NPO]; f32x2 vi[NPI > 0 ? NPI : 1]; float vlo, vli; float* h; };
+
+    __device__ __forceinline__ void init(const float* __restrict__ mu, float coeff, int nbins) {
+        sc = sqrtf(-coeff * LOG2E);
+        mu0 = mu[0];
+        dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
+        inv_dmu = 1.f / dmu;
+        Ds = dmu * sc; Ds2 = Ds * Ds;
+        const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds2);
+        float cp = 1.f, K = 1.f, Ks[R + 2];
+        Ks[0] = 1.f; Ks[1] = 1.f;
+#pragma unroll
+        for (int s_ = 2; s_ <= R; ++s_) { cp *= c2; K *= cp; Ks[s_] = K; }
+#pragma unroll
+        for (int m = 0; m < NPO; ++m) Ko[m] = f32x2{Ks[2 * m], Ks[2 * m + 1]};
+#pragma unroll
+        for (int m = 0; m < NPI; ++m) Ki[m] = f32x2{Ks[2 * m + 2], Ks[2 * m + 1]};
+        Klast = Ks[R];
+    }
+    // the 2R + 1 rows around bin kc of this lane's column (col = hist + lane)
+    __device__ __forceinline__ void rows_load(float* col, int kc, Rows& w) const {
+        float* h = col + (size_t)(kc + R) * 64;                  // row of bin kc - R
+        w.h = h;
+#pragma unroll
+        for (int m_ = 0; m_ < NPO; ++m_) w.vo[m_] = f32x2{h[(R + 2 * m_) * 64], h[(R + 2 * m_ + 1) * 64]};
+#pragma unroll
+        for (int m_ = 0; m_ < NPI; ++m_) w.vi[m_] = f32x2{h[(R - 2 * m_ - 2) * 64], h[(R - 2 * m_ - 1) * 64]};
+        w.vlo = 0.f; w.vli = 0.f;
+        if (TAIL_O) w.vlo = h[2 * R * 64];
+        if (TAIL_I) w.vli = h[0];
+    }
+    // branch-free: a rejected pair adds +0 (a bitwise no-op) around bin 0.  Plain read-add-write on the
+    // lane-private column: ds_add_f32 is serialised per lane in the LDS atomic unit (measured 9x slower).
+    __device__ __forceinline__ void rows_add_store(Rows& w, float d, float m, bool ok) const {
+        const float x0 = (d - m) * sc;
+        const float a_ = ok ? 2.f * Ds * x0 : 0.f;
+        const float e0 = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f;
+        const float rp = __builtin_amdgcn_exp2f(a_ - Ds2), rm = __builtin_amdgcn_exp2f(-a_ - Ds2);
+        const float rp2 = rp * rp, rm2 = rm * rm;
+        f32x2 Po = e0 * f32x2{1.f, rp}, Pi = e0 * f32x2{rm2, rm};
+#pragma unroll
+        for (int m_ = 0; m_ < NPO; ++m_) {
+            w.vo[m_] += Ko[m_] * Po;
+            if (m_ + 1 < NPO || TAIL_O) Po *= rp2;
+        }
+#pragma unroll
+        for (int m_ = 0; m_ < NPI; ++m_) {
+            w.vi[m_] += Ki[m_] * Pi;
+            if (m_ + 1 < NPI || TAIL_I) Pi *= rm2;
+        }
+        if (TAIL_O) w.vlo += Klast * Po.x;                       // Po = {e0 r^R, .} after NPO steps (R even)
+        if (TAIL_I) w.vli += Klast * Pi.y;                       // Pi = {., e0 r^R} after NPI steps (R odd)
+        float* h = w.h;
+#pragma unroll
+        for (int m_ = 0; m_ < NPO; ++m_) { h[(R + 2 * m_) * 64] = w.vo[m_].x; h[(R + 2 * m_ + 1) * 64] = w.vo[m_].y; }
+#pragma unroll
+        for (int m_ = 0; m_ < NPI; ++m_) { h[(R - 2 * m_ - 2) * 64] = w.vi[m_].x; h[(R - 2 * m_ - 1) * 64] = w.vi[m_].y; }
+        if (TAIL_O) h[2 * R * 64] = w.vlo;
+        if (TAIL_I) h[0] = w.vli;
+    }
+};
+
+// the table entry's two pairs: squared minimum-image distances in packed fp32 (px: SoA rows of stride PXLD)
+template <bool DIAG, bool NEAR>
+__device__ __forceinline__ f32x2 rdf_entry_d2(const float* px, int PXLD, const MdgCell& cell, float ivx, float ivy, float ivz,
+                                              uint32_t t, int& i4, int& j4) {
+    i4 = (int)(t & 0xffffu); j4 = (int)(t >> 16);
+    const float* pi = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + i4);
+    const float* pj = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + j4);
+    f32x2 dx = *reinterpret_cast<const f32x2*>(pj) - pi[0], dy = *reinterpret_cast<const f32x2*>(pj + PXLD) - pi[PXLD],
+          dz = *reinterpret_cast<const f32x2*>(pj + 2 * PXLD) - pi[2 * PXLD];
+    if constexpr (NEAR) {
+        dx = min_image_diag2_near(dx, ivx, cell.h[0]);
+        dy = min_image_diag2_near(dy, ivy, cell.h[4]);
+        dz = min_image_diag2_near(dz, ivz, cell.h[8]);
+    } else if constexpr (DIAG) {
+        dx = min_image_diag2(dx, ivx, cell.h[0]);
+        dy = min_image_diag2(dy, ivy, cell.h[4]);
+        dz = min_image_diag2(dz, ivz, cell.h[8]);
+    } else {
+        float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
+        min_image<false>(cell, ax_, ay_, az_);
+        min_image<false>(cell, bx_, by_, bz_);
+        dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
+    }
+    return norm2_ref2(dx, dy, dz);
+}
+
+// a frame's coordinates into SoA LDS rows; true when every atom is within [-0.24, 1.24] cell lengths
+// (trajectories are wrapped at every epoch, md.py:66): the image shift is then a plain rint, see
+// min_image_diag2_near
+template <bool DIAG>
+__device__ __forceinline__ bool rdf_load_frame(float* px, int PXLD, const float* __restrict__ pos, int N, int lane,
+                                               float ivx, float ivy, float ivz) {
+    bool out = false;
+    for (int e = lane; e < 3 * N; e += 64) {
+        const int c = e % 3;
+        const float v = pos[e];
+        px[c * PXLD + e / 3] = v;
+        if (DIAG) {
+            const float s_ = v * (c == 0 ? ivx : c == 1 ? ivy : ivz);
+            out |= !(s_ > -0.24f && s_ < 1.24f);
+        }
+    }
+    return DIAG && !__any(out);
+}
+
 template <bool DIAG, int R, bool MASKED, int PXC>
 __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
@@ -270,133 +387,33 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
     float* hist = sm + (size_t)wid * ((size_t)rows * 64 + 3 * PXLD);
     float* px = hist + (size_t)rows * 64;                       // [3][PXLD]   (8-byte aligned: rows * 64 and PXLD are even)
     float* smu = sm + (size_t)nw * ((size_t)rows * 64 + 3 * PXLD);   // [nbins + 2R] centres incl. extrapolated pads
-    const float sc = sqrtf(-coeff * LOG2E);
-    const float mu0 = mu[0];
-    const float dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
-    const float inv_dmu = 1.f / dmu;
-    const float Ds = dmu * sc, Ds2 = Ds * Ds;
-    const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds2);
-    // e_{+-s} = e0 r^s K_s with r = exp2(+-2 Ds x0 - Ds^2) <= 1 and K_s = c2^(s(s-1)/2), K_0 = K_1 = 1.  Bins are
-    // handled two adjacent rows at a time (one ds_read2st64 / ds_write2st64 and one packed fma per two bins): the
-    // packed power {r^s, r^(s+1)} advances by r^2.  Outward chain s = 0 (the centre) .. R, inward chain s = 1 .. R.
-    constexpr int NPO = (R + 1) / 2, NPI = R / 2;
-    constexpr bool TAIL_O = ((R + 1) & 1) != 0, TAIL_I = (R & 1) != 0;     // one unpaired row at the far end
-    f32x2 Ko[NPO], Ki[NPI > 0 ? NPI : 1];                       // outward {K_2m, K_2m+1}, inward {K_2m+2, K_2m+1}
-    float Klast = 1.f;                                          // K_R
-    {
-        float cp = 1.f, K = 1.f, Ks[R + 2];
-        Ks[0] = 1.f; Ks[1] = 1.f;
-#pragma unroll
-        for (int s_ = 2; s_ <= R; ++s_) { cp *= c2; K *= cp; Ks[s_] = K; }
-#pragma unroll
-        for (int m = 0; m < NPO; ++m) Ko[m] = f32x2{Ks[2 * m], Ks[2 * m + 1]};
-#pragma unroll
-        for (int m = 0; m < NPI; ++m) Ki[m] = f32x2{Ks[2 * m + 2], Ks[2 * m + 1]};
-        Klast = Ks[R];
-    }
+    RdfLane<R> K;
+    K.init(mu, coeff, nbins);
     for (int k = threadIdx.x; k < nbins + 2 * R; k += blockDim.x) {
         const int kk = k - R;
-        smu[k] = (kk >= 0 && kk < nbins) ? mu[kk] : fmaf((float)kk, dmu, mu0);
+        smu[k] = (kk >= 0 && kk < nbins) ? mu[kk] : fmaf((float)kk, K.dmu, K.mu0);
     }
     for (int e = lane; e < rows * 64; e += 64) hist[e] = 0.f;
     for (int e = lane; e < 3 * PXLD; e += 64) px[e] = (e >= N && e < PXLD) ? __builtin_nanf("") : 0.f;
     __syncthreads();
     const float ivx = cell.inv[0], ivy = cell.inv[4], ivz = cell.inv[8];
     const int gw = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
+    float* col = hist + lane;
     for (int fr = gw; fr < nF; fr += nwaves) {
-        const float* pos = xyz + (size_t)fr * N * 3;
-        bool out = false;
-        for (int e = lane; e < 3 * N; e += 64) {
-            const int c = e % 3;
-            const float v = pos[e];
-            px[c * PXLD + e / 3] = v;
-            if (DIAG) {
-                const float s_ = v * (c == 0 ? ivx : c == 1 ? ivy : ivz);
-                out |= !(s_ > -0.24f && s_ < 1.24f);
-            }
-        }
-        // every atom within [-0.24, 1.24] cell lengths (trajectories are wrapped at every epoch, md.py:66):
-        // the image shift is a plain rint, see min_image_diag2_near
-        const bool near = DIAG && !__any(out);
+        const bool near = rdf_load_frame<DIAG>(px, PXLD, xyz + (size_t)fr * N * 3, N, lane, ivx, ivy, ivz);
         f32x2 dd, mm;                 // distances and nearest centres of the two pairs of the current entry
         int kA, kB;
         bool okA, okB;
-        // branch-free deposit: a rejected pair adds +0 (a bitwise no-op) around bin 0.  Plain read-add-write
-        // on the lane-private column: ds_add_f32 is serialised per lane in the LDS atomic unit (measured
-        // 9x slower).  In two halves, so that the sweep can put independent work behind the row reads.
-        struct Rows { f32x2 vo[NPO]; f32x2 vi[NPI > 0 ? NPI : 1]; float vlo, vli; float* h; };
-        auto rows_load = [&](int kc, Rows& w) {
-            float* h = hist + (size_t)(kc + R) * 64 + lane;      // row of bin kc - R
-            w.h = h;
-#pragma unroll
-            for (int m_ = 0; m_ < NPO; ++m_) w.vo[m_] = f32x2{h[(R + 2 * m_) * 64], h[(R + 2 * m_ + 1) * 64]};
-#pragma unroll
-            for (int m_ = 0; m_ < NPI; ++m_) w.vi[m_] = f32x2{h[(R - 2 * m_ - 2) * 64], h[(R - 2 * m_ - 1) * 64]};
-            w.vlo = 0.f; w.vli = 0.f;
-            if (TAIL_O) w.vlo = h[2 * R * 64];
-            if (TAIL_I) w.vli = h[0];
-        };
-        auto rows_add_store = [&](Rows& w, float d, float m, bool ok) {
-            const float x0 = (d - m) * sc;
-            const float a_ = ok ? 2.f * Ds * x0 : 0.f;
-            const float e0 = ok ? __builtin_amdgcn_exp2f(-x0 * x0) : 0.f;
-            const float rp = __builtin_amdgcn_exp2f(a_ - Ds2), rm = __builtin_amdgcn_exp2f(-a_ - Ds2);
-            const float rp2 = rp * rp, rm2 = rm * rm;
-            f32x2 Po = e0 * f32x2{1.f, rp}, Pi = e0 * f32x2{rm2, rm};
-#pragma unroll
-            for (int m_ = 0; m_ < NPO; ++m_) {
-                w.vo[m_] += Ko[m_] * Po;
-                if (m_ + 1 < NPO || TAIL_O) Po *= rp2;
-            }
-#pragma unroll
-            for (int m_ = 0; m_ < NPI; ++m_) {
-                w.vi[m_] += Ki[m_] * Pi;
-                if (m_ + 1 < NPI || TAIL_I) Pi *= rm2;
-            }
-            if (TAIL_O) w.vlo += Klast * Po.x;                   // Po = {e0 r^R, .} after NPO steps (R even)
-            if (TAIL_I) w.vli += Klast * Pi.y;                   // Pi = {., e0 r^R} after NPI steps (R odd)
-            float* h = w.h;
-#pragma unroll
-            for (int m_ = 0; m_ < NPO; ++m_) { h[(R + 2 * m_) * 64] = w.vo[m_].x; h[(R + 2 * m_ + 1) * 64] = w.vo[m_].y; }
-#pragma unroll
-            for (int m_ = 0; m_ < NPI; ++m_) { h[(R - 2 * m_ - 2) * 64] = w.vi[m_].x; h[(R - 2 * m_ - 1) * 64] = w.vi[m_].y; }
-            if (TAIL_O) h[2 * R * 64] = w.vlo;
-            if (TAIL_I) h[0] = w.vli;
-        };
         // (measured: a single row of fixed-point counters per wave updated with ds_add_u32 -- 2 KB of LDS
         //  instead of 32 KB, many waves per SIMD -- is 3.5x SLOWER: the lanes of a wave hit the same few
         //  bins around the g(r) peak and the atomics serialise; the lane-private columns never conflict.)
-        // (measured: the kernel is VALU-issue bound at one wave per SIMD -- pinning a latency-optimal
-        //  load/compute order with scheduling barriers, or prefetching the rows a stage early, is 4-7 % slower
-        //  than the compiler's own schedule)
         auto sweep = [&](auto near_c) {
             constexpr bool NEAR = decltype(near_c)::value;
-            // first half: coordinates of the entry's atoms, squared distances of its two pairs in packed fp32;
-            // second half: distances, nearest centres, acceptance
             f32x2 d2;
             int mi = 0, mj = 0;
             auto locate_a = [&](uint32_t t) {
-                const int i4 = (int)(t & 0xffffu), j4 = (int)(t >> 16);
-                const float* pi = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + i4);
-                const float* pj = reinterpret_cast<const float*>(reinterpret_cast<const char*>(px) + j4);
-                f32x2 dx = *reinterpret_cast<const f32x2*>(pj) - pi[0],
-                      dy = *reinterpret_cast<const f32x2*>(pj + PXLD) - pi[PXLD],
-                      dz = *reinterpret_cast<const f32x2*>(pj + 2 * PXLD) - pi[2 * PXLD];
-                if constexpr (NEAR) {
-                    dx = min_image_diag2_near(dx, ivx, cell.h[0]);
-                    dy = min_image_diag2_near(dy, ivy, cell.h[4]);
-                    dz = min_image_diag2_near(dz, ivz, cell.h[8]);
-                } else if constexpr (DIAG) {
-                    dx = min_image_diag2(dx, ivx, cell.h[0]);
-                    dy = min_image_diag2(dy, ivy, cell.h[4]);
-                    dz = min_image_diag2(dz, ivz, cell.h[8]);
-                } else {
-                    float ax_ = dx.x, ay_ = dy.x, az_ = dz.x, bx_ = dx.y, by_ = dy.y, bz_ = dz.y;
-                    min_image<false>(cell, ax_, ay_, az_);
-                    min_image<false>(cell, bx_, by_, bz_);
-                    dx = f32x2{ax_, bx_}; dy = f32x2{ay_, by_}; dz = f32x2{az_, bz_};
-                }
-                d2 = norm2_ref2(dx, dy, dz);
+                int i4, j4;
+                d2 = rdf_entry_d2<DIAG, NEAR>(px, PXLD, cell, ivx, ivy, ivz, t, i4, j4);
                 if constexpr (MASKED) { mi = i4 >> 2; mj = j4 >> 2; }
             };
             auto locate_b = [&]() {
@@ -408,7 +425,7 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
                 }
                 // v_sqrt_f32 (1 ulp): far below the Gaussian's own rounding
                 dd = f32x2{__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
-                const f32x2 tk = (dd - mu0) * inv_dmu;
+                const f32x2 tk = (dd - K.mu0) * K.inv_dmu;
                 kA = (int)rintf(tk.x); kB = (int)rintf(tk.y);
                 okA = okA & (kA >= -R) & (kA <= nbins - 1 + R);
                 okB = okB & (kB >= -R) & (kB <= nbins - 1 + R);
@@ -426,14 +443,14 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
             locate_b();
             auto step = [&](uint32_t& t, const uint32_t* next) {
                 const f32x2 d_ = dd, m_ = mm; const int kb = kB; const bool oa = okA, ob = okB;
-                Rows w;
-                rows_load(kA, w);
+                typename RdfLane<R>::Rows w;
+                K.rows_load(col, kA, w);
                 locate_a(t);
                 t = *next;
-                rows_add_store(w, d_.x, m_.x, oa);
-                rows_load(kb, w);
+                K.rows_add_store(w, d_.x, m_.x, oa);
+                K.rows_load(col, kb, w);
                 locate_b();
-                rows_add_store(w, d_.y, m_.y, ob);
+                K.rows_add_store(w, d_.y, m_.y, ob);
             };
             for (int it = 0; it < iters; it += 4) {
                 tp += 256;
@@ -454,6 +471,11 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
         partial[(size_t)gw * nbins + k] = s;
     }
 }
+
+// (measured: the same sweep with the two halves of the work on different waves -- four producer waves turning
+//  table entries into distances through a double-buffered LDS ring, four consumer waves in the SIMDs' second
+//  slots depositing them, one barrier per four entries -- gives the same bits and is 6 % SLOWER, 18.3 vs 17.3 ms:
+//  the wave that deposits is bound by the LDS pipe itself, not by the exposed round trips.  Removed.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Fine-grid backward for equally spaced centres (width ~ spacing): dL/dd(d) = sum_k g_k 2 coeff (d - mu_k) e_k(d)

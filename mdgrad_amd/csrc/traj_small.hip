@@ -435,7 +435,8 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
 #pragma unroll
     for (int c = 0; c < MDG_MAX_CHAINS; ++c)
         if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
-    const float Q0 = A.prm.Q[0];
+    const float Q0 = A.prm.Q[0], iQ0 = 1.f / Q0;
+    (void)Q0;   // (per-element divisions by the atom's mass and by Q0 run as v_rcp_f32 / a multiply: 1 ulp)
 
     load_soa(q, A.q0 + (size_t)rep * N * 3, N, LD);
     load_soa(v, A.v0 + (size_t)rep * N * 3, N, LD);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         if (nhc) {
             float part = 0.f;
             MDG_FOR_DOF(e, ia, ca) {
-                const float m = ms[ia]; const float p = v[e] * m; part += p * p / m;
+                const float p = v[e] * ms[ia]; part += p * v[e];             // p^2 / m
             }
             ke = 0.5f * block_sum(part, red);
             if (threadIdx.x < C) pb[threadIdx.x] = bath_rhs(A, Qs, pv, ke, threadIdx.x);
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         MDG_FOR_DOF(e, ia, ca) {
             const float m = ms[ia];
             float a;
-            if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p / Q0) / m; }
+            if (nhc) { const float p = v[e] * m; a = (f[e] - pv0 * p * iQ0) * __builtin_amdgcn_rcpf(m); }
             else a = f[e];                                   // md.py:145-148 (no 1/m)
             const float h = 0.5f * a * dt;
             vh[e] = h;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         if (nhc) {
             float part = 0.f;
             MDG_FOR_DOF(e, ia, ca) {
-                const float m = ms[ia]; const float p = (v[e] + vh[e]) * m; part += p * p / m;
+                const float vv = v[e] + vh[e]; const float p = vv * ms[ia]; part += p * vv;
             }
             ke = 0.5f * block_sum(part, red);       // (barriers inside also publish f)
             pvh0 = pvh[0];
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         MDG_FOR_DOF(e, ia, ca) {
             const float m = ms[ia];
             float a;
-            if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p / Q0) / m; }
+            if (nhc) { const float p = (v[e] + vh[e]) * m; a = (f[e] - pvh0 * p * iQ0) * __builtin_amdgcn_rcpf(m); }
             else a = f[e];
             v[e] = v[e] + (vh[e] + 0.5f * a * dt);
         }
@@ -524,7 +525,7 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
                                          float& slv, const TableRef& TB, float& vmax, bool th_on = true) {
     const int N = A.prm.n_atoms, LD = A.ld;
-    MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] / ms[ia] : lv[e];
+    MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] * __builtin_amdgcn_rcpf(ms[ia]) : lv[e];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
@@ -537,7 +538,7 @@ __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool n
     if (nhc) {
         MDG_FOR_DOF(e, ia, ca) {
             const float m = ms[ia]; const float p = v[e] * m;
-            p1 += p * p / m; p2 += lv[e] * v[e];
+            p1 += p * v[e]; p2 += lv[e] * v[e];
         }
     }
     vals[KMAX] = p1; vals[KMAX + 1] = p2;
@@ -580,7 +581,8 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 #pragma unroll
     for (int c = 0; c < MDG_MAX_CHAINS; ++c)
         if (threadIdx.x == c) Qs[c] = A.prm.Q[c];
-    const float Q0 = A.prm.Q[0];
+    const float Q0 = A.prm.Q[0], iQ0 = 1.f / Q0;
+    (void)Q0;   // (per-element divisions by the atom's mass and by Q0 run as v_rcp_f32 / a multiply: 1 ulp)
     float th[KMAX], gth[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) gth[k] = 0.f;
@@ -626,8 +628,8 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             __syncthreads();
             MDG_FOR_DOF(e, ia, ca) {
                 const float m = ms[ia], ve = v[e], p = ve * m;
-                const float a = (f[e] - pv0 * p / Q0) / m;
-                const float Gv = -(pv0 / Q0) * lv[e] + lq[e] + 2.f * m * ve * lp0;
+                const float a = (f[e] - pv0 * p * iQ0) * __builtin_amdgcn_rcpf(m);
+                const float Gv = -(pv0 * iQ0) * lv[e] + lq[e] + 2.f * m * ve * lp0;
                 const float vhalf = 0.5f * (-a) * h;                  // sovlers.py:132
                 q[e] = q[e] + (ve + vhalf) * h;                      // :138 forward-time sign (quirk)
                 v[e] = ve + vhalf;
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             __syncthreads();
             MDG_FOR_DOF(e, ia, ca) {
                 const float m = ms[ia];
-                const float Gv = -(pvm0 / Q0) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
+                const float Gv = -(pvm0 * iQ0) * lvh[e] + lqh[e] + 2.f * m * v[e] * lpm0;
                 float nlv = lv[e] + Gv * h;                          // :156
                 float nlq = lq[e] + dq[e] * h;                       // :157
                 if (A.g_v) nlv += A.g_v[(fr + i - 1) * N3 + ia * 3 + ca];   // :286
