@@ -74,6 +74,7 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
         if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
         f32x2 fx = {0.f, 0.f}, fy = fx, fz = fx, gx = fx, gy = fx, gz = fx;
+#pragma unroll 2
         for (int j = 2 * sub; j < N; j += 2 * TPA) {
             const bool live2 = EVEN || j + 1 < N;           // (EVEN: N is even, every lane pair is live)
             const float* qj = q + j;
