@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int RDF_BLOCK = 512;
-constexpr int RDF_MAX_BLOCKS = 1024;     // persistent blocks: each strides over (frame, chunk) work items
+constexpr int RDF_MAX_BLOCKS = 2048;     // persistent blocks: each strides over (frame, chunk) work items
 constexpr int RDF_CHUNK = 8192;          // candidate pairs per work item
 constexpr float LOG2E = 1.4426950408889634f;
 
@@ -472,6 +472,121 @@ __global__ __launch_bounds__(256) void rdf_fwd_lane_kernel(
     }
 }
 
+// Half-width columns: EIGHT depositing waves per CU (two per SIMD, so one wave's LDS round trips and
+// transcendentals hide behind the other's arithmetic).  A wave's histogram is [rows][32]: lanes l and l + 32
+// share column l & 31 and split every deposit -- lane l adds the R + 1 rows from the nearest bin upwards, lane
+// l + 32 the R + 1 rows below it -- so the two never touch the same row.  Each lane still locates its own table
+// entry (two pairs); v_permlane32_swap hands both entries of the lane pair to both lanes (4 instructions for 2 x
+// {distance, bin}), and the four pairs are deposited in the same order on both.  One instruction stream for
+// both roles: a deposit is R + 1 ascending rows from a per-lane base row, the Gaussian values by the two-term
+// recurrence E_(t+1) = E_t rho_t, rho_(t+1) = rho_t c2 (packed: two rows per step, multiplier {rho_t rho_(t+1)}
+// advancing by c2^4), anchored at the base row -- for the lower half that is 2^-26 growing towards the centre.
+// +46 % VALU instructions per pair against the full-column kernel, at twice the occupancy.
+template <bool DIAG, int R, bool MASKED, int PXC>
+__global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
+    const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
+    const float* __restrict__ mu, float coeff, int nbins, const uint32_t* __restrict__ tab, int iters, int pxld,
+    float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int HR = R + 1;                                   // rows per half deposit
+    static_assert(HR % 2 == 0, "rows are handled in adjacent pairs");
+    constexpr int PADL = 2 * R + 1;                             // rows below bin 0
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int col = lane & 31;
+    const int boff = (lane >> 5) ? -HR : 0;                     // this lane's rows start at bin k + boff
+    const int rows = (nbins + PADL + 2 * R + 2) & ~1;
+    const int PXLD = PXC ? PXC : pxld;
+    float* hist = sm + (size_t)wid * ((size_t)rows * 32 + 3 * PXLD);
+    float* px = hist + (size_t)rows * 32;                       // [3][PXLD]
+    float* smu = sm + (size_t)nw * ((size_t)rows * 32 + 3 * PXLD);   // [rows] centre of every row
+    const float sc = sqrtf(-coeff * LOG2E);
+    const float mu0 = mu[0];
+    const float dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1), inv_dmu = 1.f / dmu;
+    const float Ds = dmu * sc, Ds2 = Ds * Ds, twoDs = 2.f * Ds;
+    const float c2 = __builtin_amdgcn_exp2f(-2.f * Ds2), c4 = (c2 * c2) * (c2 * c2);
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const int kk = r - PADL;
+        smu[r] = (kk >= 0 && kk < nbins) ? mu[kk] : fmaf((float)kk, dmu, mu0);
+    }
+    for (int e = lane; e < rows * 32; e += 64) hist[e] = 0.f;
+    for (int e = lane; e < 3 * PXLD; e += 64) px[e] = (e >= N && e < PXLD) ? __builtin_nanf("") : 0.f;
+    __syncthreads();
+    const float ivx = cell.inv[0], ivy = cell.inv[4], ivz = cell.inv[8];
+    const int gw = blockIdx.x * nw + wid, nwaves = gridDim.x * nw;
+    float* hcol = hist + col + (size_t)(boff + PADL) * 32;      // row of bin boff
+    const float* smub = smu + boff + PADL;
+    // R + 1 rows upwards from bin k + boff.  A rejected pair comes in as (1e4, bin 0): y0 clamps to 20, E0
+    // underflows to an exact 0 and every product with the (finite) multipliers stays 0.
+    auto half_deposit = [&](float d, int k) {
+        float* h = hcol + k * 32;
+        const float y0 = fminf((d - smub[k]) * sc, 20.f);
+        const float E0 = __builtin_amdgcn_exp2f(-y0 * y0), r0 = __builtin_amdgcn_exp2f(fmaf(y0, twoDs, -Ds2));
+        const float r1 = r0 * c2;
+        f32x2 P = {E0, E0 * r0}, M = {r0 * r1, (r1 * r1) * c2};
+        f32x2 v[HR / 2];
+#pragma unroll
+        for (int m_ = 0; m_ < HR / 2; ++m_) v[m_] = f32x2{h[(2 * m_) * 32], h[(2 * m_ + 1) * 32]};
+#pragma unroll
+        for (int m_ = 0; m_ < HR / 2; ++m_) {
+            v[m_] += P;
+            if (m_ + 1 < HR / 2) { P *= M; M *= c4; }
+        }
+#pragma unroll
+        for (int m_ = 0; m_ < HR / 2; ++m_) { h[(2 * m_) * 32] = v[m_].x; h[(2 * m_ + 1) * 32] = v[m_].y; }
+    };
+    for (int fr = gw; fr < nF; fr += nwaves) {
+        const bool near = rdf_load_frame<DIAG>(px, PXLD, xyz + (size_t)fr * N * 3, N, lane, ivx, ivy, ivz);
+        auto sweep = [&](auto near_c) {
+            constexpr bool NEAR = decltype(near_c)::value;
+            const uint32_t* tp = tab + lane;
+            uint32_t t0 = tp[0], t1 = tp[64], t2 = tp[128], t3 = tp[192];
+            auto step = [&](uint32_t& t, const uint32_t* next) {
+                int i4, j4;
+                const f32x2 d2 = rdf_entry_d2<DIAG, NEAR>(px, PXLD, cell, ivx, ivy, ivz, t, i4, j4);
+                t = *next;
+                bool okA = (d2.x < rc2) & (d2.x != 0.f), okB = (d2.y < rc2) & (d2.y != 0.f);
+                if constexpr (MASKED) {
+                    const int mi = i4 >> 2, mj = j4 >> 2;
+                    okA = okA & (mask[(size_t)mi * N + min(mj, N - 1)] != 0);
+                    okB = okB & (mask[(size_t)mi * N + min(mj + 1, N - 1)] != 0);
+                }
+                const f32x2 dd = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
+                const f32x2 tk = (dd - mu0) * inv_dmu;
+                int kA = (int)rintf(tk.x), kB = (int)rintf(tk.y);
+                okA = okA & (kA >= -R) & (kA <= nbins - 1 + R);
+                okB = okB & (kB >= -R) & (kB <= nbins - 1 + R);
+                const uint32_t uda = __float_as_uint(okA ? dd.x : 1e4f), udb = __float_as_uint(okB ? dd.y : 1e4f);
+                const uint32_t uka = (uint32_t)(okA ? kA : 0), ukb = (uint32_t)(okB ? kB : 0);
+                // [0]: the value of the lower lane of the pair on both lanes, [1]: the upper lane's
+                const auto sda = __builtin_amdgcn_permlane32_swap(uda, uda, false, false);
+                const auto sdb = __builtin_amdgcn_permlane32_swap(udb, udb, false, false);
+                const auto ska = __builtin_amdgcn_permlane32_swap(uka, uka, false, false);
+                const auto skb = __builtin_amdgcn_permlane32_swap(ukb, ukb, false, false);
+                half_deposit(__uint_as_float(sda[0]), (int)ska[0]);
+                half_deposit(__uint_as_float(sdb[0]), (int)skb[0]);
+                half_deposit(__uint_as_float(sda[1]), (int)ska[1]);
+                half_deposit(__uint_as_float(sdb[1]), (int)skb[1]);
+            };
+            for (int it = 0; it < iters; it += 4) {
+                tp += 256;
+                step(t0, tp);
+                step(t1, tp + 64);
+                step(t2, tp + 128);
+                step(t3, tp + 192);
+            }
+        };
+        if (near) sweep(std::true_type{});
+        else sweep(std::false_type{});
+    }
+    // column sums in a fixed (lane-rotated) order; one partial histogram per wave
+    for (int k = lane; k < nbins; k += 64) {
+        const float* row = hist + (size_t)(k + PADL) * 32;
+        float s_ = 0.f;
+        for (int t = 0; t < 32; ++t) s_ += row[(t + lane) & 31];
+        partial[(size_t)gw * nbins + k] = s_;
+    }
+}
+
 // (measured: the same sweep with the two halves of the work on different waves -- four producer waves turning
 //  table entries into distances through a double-buffered LDS ring, four consumer waves in the SIMDs' second
 //  slots depositing them, one barrier per four entries -- gives the same bits and is 6 % SLOWER, 18.3 vs 17.3 ms:
@@ -880,6 +995,26 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
         if (lds <= 156 * 1024 && hipMallocAsync((void**)&tab, sizeof(uint32_t) * (size_t)n_padded, st) == hipSuccess && tab) {
             hipLaunchKernelGGL(rdf_pair_table_kernel, dim3(n_atoms), dim3(256), 0, st, tab, n_atoms, n_entries, n_padded,
                                pad_entry);
+            // half-width columns, eight waves per workgroup, when they fit (R = 5, 100 bins: 137 KB)
+            const size_t rows_h = (size_t)((nbins + 4 * R + 3) & ~1);
+            const size_t lds_half = sizeof(float) * (rows_h + 8 * (rows_h * 32 + 3 * (size_t)pxld));
+            if (R == 5 && lds_half <= 156 * 1024) {
+                int gridh = (n_frames + 7) / 8;
+                if (gridh > RDF_MAX_BLOCKS / 8) gridh = RDF_MAX_BLOCKS / 8;
+#define MDG_RDF_HALF(D, MK, PX)                                                                                        \
+    hipLaunchKernelGGL((rdf_fwd_half_kernel<D, 5, MK, PX>), dim3(gridh), dim3(512), lds_half, st, xyz, n_frames,       \
+                       n_atoms, *cell, cutoff * cutoff, mask, mu, coeff, nbins, tab, iters, pxld, partial)
+                if (px128) MDG_RDF_HALF(true, false, 128);
+                else if (cell->diag && mask) MDG_RDF_HALF(true, true, 0);
+                else if (cell->diag) MDG_RDF_HALF(true, false, 0);
+                else if (mask) MDG_RDF_HALF(false, true, 0);
+                else MDG_RDF_HALF(false, false, 0);
+#undef MDG_RDF_HALF
+                hipLaunchKernelGGL(rdf_finish_kernel, dim3(nbins), dim3(64), 0, st, partial, gridh * 8, nbins, raw);
+                (void)hipFreeAsync(tab, st);
+                MDG_CHECK_LAUNCH("rdf_fwd_half_kernel");
+                return MDG_OK;
+            }
             int grid = (n_frames + nw - 1) / nw;
             if (grid > RDF_MAX_BLOCKS / nw) grid = RDF_MAX_BLOCKS / nw;
 #define MDG_RDF_LANE(D, RR, MK, PX)                                                                                    \
