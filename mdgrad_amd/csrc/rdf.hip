@@ -517,20 +517,29 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
     const float* smub = smu + boff + PADL;
     // R + 1 rows upwards from bin k + boff.  A rejected pair comes in as (1e4, bin 0): y0 clamps to 20, E0
     // underflows to an exact 0 and every product with the (finite) multipliers stays 0.
-    auto half_deposit = [&](float d, int k) {
-        float* h = hcol + k * 32;
+    // In two parts: the values of all four deposits of a step are computed first, so that the four dependent
+    // read-add-write round trips that follow carry one packed add per row pair and nothing else -- that stretch
+    // is where the SIMD's other wave runs its arithmetic.
+    struct Half { float* h; f32x2 P[HR / 2]; };
+    auto half_values = [&](float d, int k, Half& w) {
+        w.h = hcol + k * 32;
         const float y0 = fminf((d - smub[k]) * sc, 20.f);
         const float E0 = __builtin_amdgcn_exp2f(-y0 * y0), r0 = __builtin_amdgcn_exp2f(fmaf(y0, twoDs, -Ds2));
         const float r1 = r0 * c2;
         f32x2 P = {E0, E0 * r0}, M = {r0 * r1, (r1 * r1) * c2};
+#pragma unroll
+        for (int m_ = 0; m_ < HR / 2; ++m_) {
+            w.P[m_] = P;
+            if (m_ + 1 < HR / 2) { P *= M; M *= c4; }
+        }
+    };
+    auto half_add = [&](const Half& w) {
+        float* h = w.h;
         f32x2 v[HR / 2];
 #pragma unroll
         for (int m_ = 0; m_ < HR / 2; ++m_) v[m_] = f32x2{h[(2 * m_) * 32], h[(2 * m_ + 1) * 32]};
 #pragma unroll
-        for (int m_ = 0; m_ < HR / 2; ++m_) {
-            v[m_] += P;
-            if (m_ + 1 < HR / 2) { P *= M; M *= c4; }
-        }
+        for (int m_ = 0; m_ < HR / 2; ++m_) v[m_] += w.P[m_];
 #pragma unroll
         for (int m_ = 0; m_ < HR / 2; ++m_) { h[(2 * m_) * 32] = v[m_].x; h[(2 * m_ + 1) * 32] = v[m_].y; }
     };
@@ -562,10 +571,12 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
                 const auto sdb = __builtin_amdgcn_permlane32_swap(udb, udb, false, false);
                 const auto ska = __builtin_amdgcn_permlane32_swap(uka, uka, false, false);
                 const auto skb = __builtin_amdgcn_permlane32_swap(ukb, ukb, false, false);
-                half_deposit(__uint_as_float(sda[0]), (int)ska[0]);
-                half_deposit(__uint_as_float(sdb[0]), (int)skb[0]);
-                half_deposit(__uint_as_float(sda[1]), (int)ska[1]);
-                half_deposit(__uint_as_float(sdb[1]), (int)skb[1]);
+                Half w0, w1, w2, w3;
+                half_values(__uint_as_float(sda[0]), (int)ska[0], w0);
+                half_values(__uint_as_float(sdb[0]), (int)skb[0], w1);
+                half_values(__uint_as_float(sda[1]), (int)ska[1], w2);
+                half_values(__uint_as_float(sdb[1]), (int)skb[1], w3);
+                half_add(w0); half_add(w1); half_add(w2); half_add(w3);
             };
             for (int it = 0; it < iters; it += 4) {
                 tp += 256;
