@@ -549,7 +549,17 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
             constexpr bool NEAR = decltype(near_c)::value;
             const uint32_t* tp = tab + lane;
             uint32_t t0 = tp[0], t1 = tp[64], t2 = tp[128], t3 = tp[192];
-            auto step = [&](uint32_t& t, const uint32_t* next) {
+            // software pipeline over steps: the four read-add-writes of the previous entry pair are spread
+            // between the pieces of this one's arithmetic (two register sets, no rotation)
+            Half A[4], B[4];
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) {
+                A[q_].h = hcol;
+#pragma unroll
+                for (int m_ = 0; m_ < HR / 2; ++m_) A[q_].P[m_] = f32x2{0.f, 0.f};
+            }
+            auto step = [&](uint32_t& t, const uint32_t* next, const Half (&prev)[4], Half (&cur)[4]) {
+                half_add(prev[0]);
                 int i4, j4;
                 const f32x2 d2 = rdf_entry_d2<DIAG, NEAR>(px, PXLD, cell, ivx, ivy, ivz, t, i4, j4);
                 t = *next;
@@ -559,6 +569,7 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
                     okA = okA & (mask[(size_t)mi * N + min(mj, N - 1)] != 0);
                     okB = okB & (mask[(size_t)mi * N + min(mj + 1, N - 1)] != 0);
                 }
+                half_add(prev[1]);
                 const f32x2 dd = {__builtin_amdgcn_sqrtf(d2.x), __builtin_amdgcn_sqrtf(d2.y)};
                 const f32x2 tk = (dd - mu0) * inv_dmu;
                 int kA = (int)rintf(tk.x), kB = (int)rintf(tk.y);
@@ -571,20 +582,22 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
                 const auto sdb = __builtin_amdgcn_permlane32_swap(udb, udb, false, false);
                 const auto ska = __builtin_amdgcn_permlane32_swap(uka, uka, false, false);
                 const auto skb = __builtin_amdgcn_permlane32_swap(ukb, ukb, false, false);
-                Half w0, w1, w2, w3;
-                half_values(__uint_as_float(sda[0]), (int)ska[0], w0);
-                half_values(__uint_as_float(sdb[0]), (int)skb[0], w1);
-                half_values(__uint_as_float(sda[1]), (int)ska[1], w2);
-                half_values(__uint_as_float(sdb[1]), (int)skb[1], w3);
-                half_add(w0); half_add(w1); half_add(w2); half_add(w3);
+                half_values(__uint_as_float(sda[0]), (int)ska[0], cur[0]);
+                half_values(__uint_as_float(sdb[0]), (int)skb[0], cur[1]);
+                half_add(prev[2]);
+                half_values(__uint_as_float(sda[1]), (int)ska[1], cur[2]);
+                half_add(prev[3]);
+                half_values(__uint_as_float(sdb[1]), (int)skb[1], cur[3]);
             };
             for (int it = 0; it < iters; it += 4) {
                 tp += 256;
-                step(t0, tp);
-                step(t1, tp + 64);
-                step(t2, tp + 128);
-                step(t3, tp + 192);
+                step(t0, tp, A, B);
+                step(t1, tp + 64, B, A);
+                step(t2, tp + 128, A, B);
+                step(t3, tp + 192, B, A);
             }
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) half_add(A[q_]);
         };
         if (near) sweep(std::true_type{});
         else sweep(std::false_type{});
