@@ -1022,7 +1022,8 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
             // half-width columns, eight waves per workgroup, when they fit (R = 5, 100 bins: 137 KB)
             const size_t rows_h = (size_t)((nbins + 4 * R + 3) & ~1);
             const size_t lds_half = sizeof(float) * (rows_h + 8 * (rows_h * 32 + 3 * (size_t)pxld));
-            if (R == 5 && lds_half <= 156 * 1024) {
+            // (spacing_s <= 1.5: the recurrence multipliers of a rejected pair, y0 clamped to 20, stay finite)
+            if (R == 5 && spacing_s <= 1.5f && lds_half <= 156 * 1024) {
                 int gridh = (n_frames + 7) / 8;
                 if (gridh > RDF_MAX_BLOCKS / 8) gridh = RDF_MAX_BLOCKS / 8;
 #define MDG_RDF_HALF(D, MK, PX)                                                                                        \

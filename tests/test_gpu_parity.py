@@ -540,7 +540,7 @@ def test_rdf_kernel_variants_agree():
     frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), g["cell"]) for _ in range(1100)]).astype(np.float32)
     cs = _lib.make_cell(g["cell"])
     w = torch.linspace(-1, 1, 100, device=DEV)
-    for width_scale in (1.0, 1.6):                     # reach 7 and reach 12 kernels
+    for width_scale in (1.0, 1.6, 0.4):                # half-column R=5, full-column R=11, full-column R=5 (narrow)
         mu = torch.linspace(0.75, 2.5, 100, device=DEV)
         spacing = float(mu[1] - mu[0])
         coeff = float(-0.5 / (width_scale * spacing) ** 2)
