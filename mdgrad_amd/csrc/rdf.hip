@@ -660,14 +660,15 @@ __device__ __forceinline__ float2 rdf_fine_node(const FineGrid& G, const float* 
     }
     return make_float2(val, der * G.hf);
 }
-// cell n = nodes n and n + 1: {value, hf slope, value, hf slope}
+// cell n = nodes n and n + 1: the cubic Hermite interpolant of {value, hf slope} at both ends, stored as its
+// monomial coefficients in the cell coordinate f in [0, 1) (c0 + f (c1 + f (c2 + f c3)): three fma per pair)
 __global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, int nbins,
                                      const float* __restrict__ g_raw, int R, float4* __restrict__ tab) {
     const FineGrid G = fine_grid(mu, nbins, R);
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= G.nn - 1) return;
     const float2 a_ = rdf_fine_node(G, mu, coeff, nbins, g_raw, R, n), b_ = rdf_fine_node(G, mu, coeff, nbins, g_raw, R, n + 1);
-    tab[n] = make_float4(a_.x, a_.y, b_.x, b_.y);
+    tab[n] = make_float4(a_.x, a_.y, 3.f * (b_.x - a_.x) - 2.f * a_.y - b_.y, 2.f * (a_.x - b_.x) + a_.y + b_.y);
 }
 
 // Fine-grid backward, one wave per frame.  Pair order: lane <-> atom i (64 at a time), step s <-> partner
@@ -677,7 +678,7 @@ __global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, 
 // scatters both ends).  Positions and partner gradients live in index-doubled arrays (entry k and k + N are the
 // same atom; the two gradient halves are folded at the end): the partner address is affine in s, no modulo.
 // Two steps per iteration in packed fp32; the stores of step s precede the reads of step s + 1 (lane l's second
-// partner is lane l + 1's first).  The table holds one float4 per cell, {value, hf slope} of both end nodes.
+// partner is lane l + 1's first).  The table holds one float4 per cell: the cell's cubic in monomial form.
 template <bool DIAG>
 __global__ __launch_bounds__(256) void rdf_bwd_fine_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint8_t* __restrict__ mask,
@@ -756,10 +757,8 @@ __global__ __launch_bounds__(256) void rdf_bwd_fine_kernel(
                 const int gA = (int)t.x, gB = (int)t.y;
                 const f32x2 f = t - f32x2{(float)gA, (float)gB};
                 const float4 ca = tab[gA], cb = tab[gB];
-                const f32x2 om = 1.f - f, f2 = f * f, om2 = om * om;
-                const f32x2 h00 = (1.f + 2.f * f) * om2, h10 = f * om2, h01 = f2 * (3.f - 2.f * f), h11 = f2 * (f - 1.f);
-                const float sdA = h00.x * ca.x + h10.x * ca.y + h01.x * ca.z + h11.x * ca.w;
-                const float sdB = h00.y * cb.x + h10.y * cb.y + h01.y * cb.z + h11.y * cb.w;
+                const float sdA = fmaf(f.x, fmaf(f.x, fmaf(f.x, ca.w, ca.z), ca.y), ca.x);
+                const float sdB = fmaf(f.y, fmaf(f.y, fmaf(f.y, cb.w, cb.z), cb.y), cb.x);
                 // d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d; a rejected pair adds +-0
                 const f32x2 cw = f32x2{okA ? sdA : 0.f, okB ? sdB : 0.f} * id;
                 const f32x2 cx = cw * dx, cy = cw * dy, cz = cw * dz;
