@@ -79,14 +79,19 @@ __device__ __forceinline__ f32x2 min_image_diag2(f32x2 d, float inv, float h) {
 }
 
 // The same for |d * inv| < 1.5 (every atom inside a window 1.5 cells wide): the clamp is then the identity and
-// rint runs as two packed adds around 1.5 * 2^23 -- 3 packed instructions instead of 6 scalar + packed ones.
-// (d * inv is not rounded before the rint here: the two forms can differ only for a component within one ulp of
-//  half the cell, where both images are equidistant.)
+// rint runs as two packed adds around 1.5 * 2^23 (round-to-nearest-even of s to an integer, exactly rint(s)) --
+// 4 packed instructions instead of 6 scalar + packed ones, bit-identical to min_image_diag2 there.
+// (s = d * inv is rounded before the rint like the reference's matrix product: folding it into an fma would
+//  pick the other image for a component within one ulp of half the cell -- measured: 3e-7 of the pairs.)
 __device__ __forceinline__ f32x2 min_image_diag2_near(f32x2 d, float inv, float h) {
     const float M = 12582912.f;
-    const f32x2 t = __builtin_elementwise_fma(d, f32x2{inv, inv}, f32x2{M, M});
-    const f32x2 o = t - M;
-    return __builtin_elementwise_fma(o, f32x2{-h, -h}, d);
+    f32x2 o;
+    {
+#pragma clang fp contract(off)
+        const f32x2 s = d * inv;                 // (rounded on its own: no fma with the add below)
+        o = (s + M) - M;
+    }
+    return d - o * h;
 }
 
 // ----------------------------------------------------------------------------- pair forms

@@ -1131,3 +1131,32 @@ def test_rdf_lane_kernels_general_variants():
     check(np.mod(big, L), cs, None, "150 atoms")
     mask = ops.build_mask(108, index_tuple=(list(range(0, 40)), list(range(40, 108))), device=DEV)
     check(frames, cs, mask, "even N with a mask")
+
+
+@pytest.mark.parametrize("nbins,n_atoms", [(37, 108), (200, 108), (100, 20), (64, 7)])
+def test_rdf_lane_kernels_other_bin_and_atom_counts(nbins, n_atoms):
+    """Many-frame RDF kernels away from the 100-bin / 108-atom shape: odd and large bin counts (the half-width
+    kernel only fits ~100 bins; more rows fall back to full-width columns with fewer waves), tiny atom counts
+    (most lanes idle, padding entries dominate the pair table) -- against the direct kernels."""
+    from mdgrad_amd import ops, _lib
+    g = load_golden("rdf")
+    rng = np.random.default_rng(100 + nbins + n_atoms)
+    L = np.asarray(g["cell"], np.float32)
+    base = g["xyz"][0][:n_atoms]
+    frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), L) for _ in range(1040)]).astype(np.float32)
+    mu = torch.linspace(0.75, 2.5, nbins, device=DEV)
+    spacing = float(mu[1] - mu[0])
+    coeff = float(-0.5 / spacing ** 2)
+    w = torch.linspace(-1, 1, nbins, device=DEV)
+    cs = _lib.make_cell(g["cell"])
+    out = []
+    for sp in (spacing, 0.0):
+        xg = T(frames, DEV).requires_grad_(True)
+        raw = ops.RdfRawFn.apply(xg, mu, coeff, 3.0, cs, None, sp)
+        (gx,) = torch.autograd.grad((raw * w).sum(), xg)
+        out.append((raw.detach(), gx))
+    (ra, ga), (rb, gb) = out
+    close(ra, rb, 2e-5, 1e-6 * float(rb.max()), "forward")
+    # (this seed contains pairs separated by half the cell to the last ulp in one component: the fast and the
+    #  clamped minimum-image forms must pick the same image, as the reference's arithmetic does)
+    close(ga, gb, 1e-4, 3e-5 * float(gb.abs().max()), "backward")
