@@ -4,15 +4,18 @@
 // backward through it.  The [pairs, bins] exp matrix of the reference is never
 // materialised.
 //
-// forward : persistent blocks stride over (frame, 4096-candidate chunk) work items.  Threads
-//           compute i<j minimum-image distances 256 candidates at a time, compact the accepted
-//           ones into LDS in a fixed order, then thread k owns bin k and sweeps the LDS
-//           distances (broadcast reads, register accumulator kept across work items).  Per-block
-//           partial histograms are added by a second kernel in a fixed order => no atomics,
-//           reproducible.  exp uses the hardware v_exp_f32 path (__expf, rel. err ~1e-6).
-// backward: one wave per frame in round-robin-tournament pair order (see rdf_bwd_kernel); each
-//           accepted pair contributes sum_k g_raw[k] * 2 coeff (d - mu_k) e_k along +/- its unit
-//           separation vector, accumulated in LDS without atomics.
+// forward : few frames / arbitrary centres -- persistent blocks stride over (frame, candidate chunk) work
+//           items, compact the accepted i<j distances into LDS in a fixed order, thread k owns bin k (or
+//           an 8-bin block with the Gaussian recurrence) and sweeps them (rdf_fwd_kernel,
+//           rdf_fwd_block8_kernel).  Many frames, equally spaced centres (the replica-batched training
+//           shape) -- one wave per frame, one lane per pair, lane-private LDS histogram columns
+//           (rdf_fwd_half_kernel / rdf_fwd_lane_kernel).  Per-block / per-wave partial histograms are added
+//           by a second kernel in a fixed order => no atomics, reproducible.  exp is v_exp_f32.
+// backward: each accepted pair contributes dL/dd = sum_k g_raw[k] * 2 coeff (d - mu_k) e_k along +/- its
+//           unit separation vector.  Many frames: one wave per frame, dL/dd from a fine table, cyclic pair
+//           order with one end's gradient in registers (rdf_bwd_fine_kernel) or the bin recurrence in
+//           round-robin-tournament order (rdf_bwd_kernel); few frames: (frame, atom) gather
+//           (rdf_bwd_atom_kernel).  LDS accumulation without atomics.
 #include "common.hpp"
 #include <type_traits>
 
@@ -619,9 +622,9 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
 // ---------------------------------------------------------------------------------------------------------
 // Fine-grid backward for equally spaced centres (width ~ spacing): dL/dd(d) = sum_k g_k 2 coeff (d - mu_k) e_k(d)
 // is ONE smooth function of the distance.  A tiny kernel tabulates it -- value and hf * slope on RDF_SUB nodes
-// per centre spacing, x_n = xlo + n hf -- and the per-pair work of the tournament kernel shrinks from a 13-bin
-// Gaussian sum to a cubic-Hermite lookup from LDS (interpolation error ~ (hf/sigma)^4 / 384 * 3 < 2e-6 of a
-// unit contribution for hf = sigma / 8).
+// per centre spacing, x_n = xlo + n hf -- and the per-pair work shrinks from a 13-bin Gaussian sum to the
+// evaluation of the cell's cubic Hermite interpolant from LDS (interpolation error ~ (hf/sigma)^4 / 384 * 3
+// < 2e-6 of a unit contribution for hf = sigma / 8).
 // (The transposed idea for the forward pass -- every pair deposits its four Hermite weights into per-wave
 //  node accumulators with fixed-point ds_add_u32, Gaussians evaluated once per wave at the end -- halves the
 //  arithmetic but is bound by the LDS atomic unit, ~15 cycles per wave instruction and CU plus 2-3-way address
@@ -1123,7 +1126,7 @@ static int rdf_bwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
     const int R = nbins >= 2 ? rdf_lane_reach(spacing_s) : 0;
     if (R && spacing_s <= 1.0f && fine_nodes(nbins, R) <= 4096) {
         // table of dL/dd on the fine nodes (stream-ordered scratch: no state, re-entrant), then the
-        // tournament kernel with a table lookup per pair
+        // wave-per-frame kernel with a table lookup per pair
         const int nn = fine_nodes(nbins, R);
         const size_t tabf = 4 * (size_t)(nn - 1);
         // index-doubled rows: the last lane group's idle lanes reach index 64 ceil(N/64) - 1 + N/2 + 1
