@@ -528,8 +528,8 @@ __global__ __launch_bounds__(512) void rdf_fwd_half_kernel(
         w.h = hcol + k * 32;
         const float y0 = fminf((d - smub[k]) * sc, 20.f);
         const float E0 = __builtin_amdgcn_exp2f(-y0 * y0), r0 = __builtin_amdgcn_exp2f(fmaf(y0, twoDs, -Ds2));
-        const float r1 = r0 * c2;
-        f32x2 P = {E0, E0 * r0}, M = {r0 * r1, (r1 * r1) * c2};
+        const float r1 = r0 * c2, r2 = r1 * c2;
+        f32x2 P = {E0, E0 * r0}, M = f32x2{r0, r1} * f32x2{r1, r2};     // {rho_0 rho_1, rho_1 rho_2}
 #pragma unroll
         for (int m_ = 0; m_ < HR / 2; ++m_) {
             w.P[m_] = P;
