@@ -12,6 +12,12 @@ void mdg_set_error(const char* fmt, ...);
 #define MDG_CHECK_ARG(cond, ...)                                                       \
     do { if (!(cond)) { mdg_set_error(__VA_ARGS__); return MDG_EINVAL; } } while (0)
 
+// runtime calls on the launch path (stream-ordered copies / fills): fail loudly, with the call site
+#define MDG_HIP(call)                                                                  \
+    do { hipError_t e_ = (call);                                                       \
+         if (e_ != hipSuccess) { mdg_set_error("%s:%d: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+                                 return MDG_ELAUNCH; } } while (0)
+
 #define MDG_CHECK_LAUNCH(name)                                                         \
     do { hipError_t e_ = hipGetLastError();                                            \
          if (e_ != hipSuccess) { mdg_set_error("%s: %s", name, hipGetErrorString(e_)); \

@@ -509,10 +509,10 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     LG_SETUP();
     a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t;
     const int C = prm->n_chains, T = prm->n_frames;
-    hipMemcpyAsync(a.q, q0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(a.v, v0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
-    hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
-                     hipMemcpyDeviceToDevice, st);
+    MDG_HIP(hipMemcpyAsync(a.q, q0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
+    MDG_HIP(hipMemcpyAsync(a.v, v0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
+    MDG_HIP(hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
+                     hipMemcpyDeviceToDevice, st));
     dim3 gF(nbF, R), gE(nbE, R);
     a.step = 0;
     if (diag) hipLaunchKernelGGL((large_force_step<true, 0>), gF, dim3(LG_BLOCK), 0, st, a);
@@ -546,18 +546,18 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     for (int r = 0; r < R; ++r) {
         float* lv = a.lv + (size_t)r * N * 3;
         float* lq = a.lq + (size_t)r * N * 3;
-        if (g_v) hipMemcpyAsync(lv, g_v + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st);
-        else hipMemsetAsync(lv, 0, fr, st);
-        if (g_q) hipMemcpyAsync(lq, g_q + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st);
-        else hipMemsetAsync(lq, 0, fr, st);
-        if (g_pv) hipMemcpyAsync(a.lp + r * MDG_MAX_CHAINS, g_pv + ((size_t)r * T + T - 1) * C, sizeof(float) * C,
-                                 hipMemcpyDeviceToDevice, st);
-        else hipMemsetAsync(a.lp + r * MDG_MAX_CHAINS, 0, sizeof(float) * MDG_MAX_CHAINS, st);
+        if (g_v) MDG_HIP(hipMemcpyAsync(lv, g_v + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st));
+        else MDG_HIP(hipMemsetAsync(lv, 0, fr, st));
+        if (g_q) MDG_HIP(hipMemcpyAsync(lq, g_q + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st));
+        else MDG_HIP(hipMemsetAsync(lq, 0, fr, st));
+        if (g_pv) MDG_HIP(hipMemcpyAsync(a.lp + r * MDG_MAX_CHAINS, g_pv + ((size_t)r * T + T - 1) * C, sizeof(float) * C,
+                                 hipMemcpyDeviceToDevice, st));
+        else MDG_HIP(hipMemsetAsync(a.lp + r * MDG_MAX_CHAINS, 0, sizeof(float) * MDG_MAX_CHAINS, st));
     }
-    hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st);
+    MDG_HIP(hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st));
     if (table) {
-        hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st);
-        hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st);
+        MDG_HIP(hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st));
+        MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
     }
     dim3 gF(nbF, R), gE(nbE, R);
     for (int i = T - 1; i >= 1; --i) {
@@ -569,16 +569,16 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         else hipLaunchKernelGGL(large_adj_force<false>, gF, dim3(LG_BLOCK), 0, st, a, 1);
         hipLaunchKernelGGL(large_adj_end, gE, dim3(256), 0, st, a);
     }
-    hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st);
-    hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
-                     hipMemcpyDeviceToDevice, st);
+    MDG_HIP(hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
+    MDG_HIP(hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
+    MDG_HIP(hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
+                     hipMemcpyDeviceToDevice, st));
     if (adj_theta && table) {
         const size_t n = (size_t)R * KT;
         hipLaunchKernelGGL(large_table_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.ghi, a.glo, n,
                            terms->t[0].c, adj_theta);
     } else if (adj_theta && KT > 0)
-        hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st);
+        MDG_HIP(hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st));
     MDG_CHECK_LAUNCH("traj_adj_large");
     return MDG_OK;
 }
