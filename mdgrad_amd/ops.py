@@ -13,7 +13,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import MdgCell, MdgPairTerm, MdgTerms, MdgTrajParams, check, ptr, stream_ptr, require_gpu
+from ._lib import MdgPairTerm, MdgTerms, MdgTrajParams, check, ptr, stream_ptr, require_gpu
 
 
 # ----------------------------------------------------------------------------- neighbour lists
