@@ -1133,7 +1133,7 @@ def test_rdf_lane_kernels_general_variants():
     check(frames, cs, mask, "even N with a mask")
 
 
-@pytest.mark.parametrize("nbins,n_atoms", [(37, 108), (200, 108), (100, 20), (64, 7)])
+@pytest.mark.parametrize("nbins,n_atoms", [(37, 108), (200, 108), (100, 20), (64, 7), (100, 300), (100, 400)])
 def test_rdf_lane_kernels_other_bin_and_atom_counts(nbins, n_atoms):
     """Many-frame RDF kernels away from the 100-bin / 108-atom shape: odd and large bin counts (the half-width
     kernel only fits ~100 bins; more rows fall back to full-width columns with fewer waves), tiny atom counts
@@ -1142,7 +1142,10 @@ def test_rdf_lane_kernels_other_bin_and_atom_counts(nbins, n_atoms):
     g = load_golden("rdf")
     rng = np.random.default_rng(100 + nbins + n_atoms)
     L = np.asarray(g["cell"], np.float32)
-    base = g["xyz"][0][:n_atoms]
+    if n_atoms <= 108:
+        base = g["xyz"][0][:n_atoms]
+    else:                                   # (300: half-width columns with a run-time stride; 400: full-width)
+        base = rng.uniform(0, 1, (n_atoms, 3)) * L
     frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), L) for _ in range(1040)]).astype(np.float32)
     mu = torch.linspace(0.75, 2.5, nbins, device=DEV)
     spacing = float(mu[1] - mu[0])
