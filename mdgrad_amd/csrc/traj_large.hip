@@ -90,7 +90,34 @@ __device__ __forceinline__ void wave_neighbours_and_force(
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * tn; e += blockDim.x) tile[(e % 3) * LG_TILE + e / 3] = q[3 * t0 + e];
         __syncthreads();
-        if (valid) {
+        if (valid && DIAG) {
+            // two candidates per lane (jl, jl + 64) in packed fp32 -- the same arithmetic, and the same
+            // ascending-j order of the compacted list, as the scalar loop below
+            const float iv0 = A.cell.inv[0], iv1 = A.cell.inv[4], iv2 = A.cell.inv[8];
+            const float h0 = A.cell.h[0], h1 = A.cell.h[4], h2 = A.cell.h[8];
+            for (int c0 = 0; c0 < tn; c0 += 128) {                 // (LG_TILE is a multiple of 128: reads stay in the tile)
+                const int jlA = c0 + lane, jlB = jlA + 64;
+                f32x2 dx = f32x2{tile[jlA], tile[jlB]} - xi, dy = f32x2{tile[LG_TILE + jlA], tile[LG_TILE + jlB]} - yi,
+                      dz = f32x2{tile[2 * LG_TILE + jlA], tile[2 * LG_TILE + jlB]} - zi;   // D = x_j - x_i
+                dx = min_image_diag2(dx, iv0, h0); dy = min_image_diag2(dy, iv1, h1); dz = min_image_diag2(dz, iv2, h2);
+                const f32x2 d2 = norm2_ref2(dx, dy, dz);
+                const bool okA = (jlA < tn) & (t0 + jlA != i) & (d2.x < rc2max) & (d2.x != 0.f);
+                const bool okB = (jlB < tn) & (t0 + jlB != i) & (d2.y < rc2max) & (d2.y != 0.f);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const unsigned long long bA = __ballot(okA);
+                if (okA) {
+                    const int k = n + __popcll(bA & below);
+                    if (k < LG_CAP) buf[k] = make_float4(dx.x, dy.x, dz.x, __int_as_float(t0 + jlA));
+                }
+                n += __popcll(bA);
+                const unsigned long long bB = __ballot(okB);
+                if (okB) {
+                    const int k = n + __popcll(bB & below);
+                    if (k < LG_CAP) buf[k] = make_float4(dx.y, dy.y, dz.y, __int_as_float(t0 + jlB));
+                }
+                n += __popcll(bB);
+            }
+        } else if (valid) {
             for (int c0 = 0; c0 < tn; c0 += 64) {
                 const int jl = c0 + lane, j = t0 + jl;
                 bool ok = false;
