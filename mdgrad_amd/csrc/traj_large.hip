@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int LG_WAVES = 8;                  // waves (= atoms in flight) per workgroup
+constexpr int LG_WAVES = 16;                 // waves (= atoms in flight) per workgroup
 constexpr int LG_BLOCK = LG_WAVES * 64;
 constexpr int LG_TILE = 1024;                // positions staged in LDS per pass
 constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
