@@ -24,7 +24,7 @@ namespace {
 
 constexpr int LG_WAVES = 16;                 // waves (= atoms in flight) per workgroup
 constexpr int LG_BLOCK = LG_WAVES * 64;
-constexpr int LG_TILE = 1024;                // positions staged in LDS per pass
+constexpr int LG_TILE = 2048;               // positions staged in LDS per pass
 constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
 constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
 constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
