@@ -38,7 +38,7 @@ struct LargeArgs {
     float *pv, *ph, *pvh;                    // [R][16]
     float *partA, *partB;                    // [R][nb] kinetic-energy partials (ping / pong)
     float *v_t, *q_t, *pv_t;                 // [R][T][N][3] frames
-    int32_t* flags;                          // [0] neighbour-buffer overflow, [1] non-finite
+    int32_t* flags;                          // [0] neighbour-buffer overflow, [1] non-finite, [2] table-gradient range, [3] pair below the table
     const float *g_v, *g_q, *g_pv;           // adjoint: incoming frame gradients (nullable)
     float *lv, *lq, *lvh, *lqh, *dq, *qm, *vm;   // [R][N][3]
     float *lp, *lph, *pvm;                   // [R][16]
@@ -157,6 +157,7 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             PairOut o;
             float r, ir;
             pair_eval<LEVEL, -1>(tc[m], d2, r, ir, o);
+            if (tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
             const float c1 = o.du * ir;
             fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
             if (LEVEL >= 2) {

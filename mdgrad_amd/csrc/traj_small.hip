@@ -194,6 +194,9 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
             const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);                         // topology.py:67
             const bool ok1 = live2 && (d2.y != 0.f) && (d2.y < rc2);
             const f32x2 sel = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
+            // a live pair below the first node: the table does not cover it (the forward kernel reports it through
+            // the per-replica flag, bit 1, and the host raises instead of returning clamped forces)
+            if (LEVEL == 1 && ((ok0 && d2.x < u0) || (ok1 && d2.y < u0))) vmax = 1.f;
             // grid coordinate (clamped: below the first node the first cell is extrapolated with fr = 0)
             f32x2 tt = (d2 - u0) * inv_du;
             tt.x = fminf(fmaxf(ok0 ? tt.x : 0.f, 0.f), tmax); tt.y = fminf(fmaxf(ok1 ? tt.y : 0.f, 0.f), tmax);
@@ -513,7 +516,10 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     if (A.nonfinite) {
         int bad = 0;
         MDG_FOR_DOF(e, ia, ca) bad |= !(isfinite(q[e]) && isfinite(v[e]));
-        if (__syncthreads_or(bad) && threadIdx.x == 0) A.nonfinite[rep] = 1;
+        const int nf = __syncthreads_or(bad) ? 1 : 0;
+        int below = 0;
+        if constexpr (KIND == KIND_TABLE) below = __syncthreads_or(vmax_unused > 0.f) ? 2 : 0;
+        if ((nf | below) && threadIdx.x == 0) A.nonfinite[rep] = nf | below;
     }
 }
 

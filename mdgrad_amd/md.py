@@ -287,6 +287,18 @@ class NoseHooverChain(_EOM):
         self.topology_update_freq = topology_update_freq
         self.update_count = 0
 
+    @property
+    def T(self):
+        return self._T
+
+    @T.setter
+    def T(self, value):
+        # the thermostat kernels (and the captured HIP graphs that replay them) read the temperature from a
+        # device scalar: keep it in step with plain attribute assignment as well as update_T
+        self._T = value
+        if getattr(self, "_T_buf", None) is not None:
+            self._T_device()
+
     def update_T(self, T):
         self.T = T
         self._T_device()
@@ -297,8 +309,8 @@ class NoseHooverChain(_EOM):
         if buf is None or buf.device != self.mass.device:
             buf = self._T_buf = torch.empty(1, device=self.mass.device)
             self._T_val = None
-        if self._T_val != float(self.T):
-            self._T_val = float(self.T)
+        if self._T_val != float(self._T):
+            self._T_val = float(self._T)
             buf.fill_(self._T_val)
         return buf
 

@@ -138,10 +138,10 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
                   "mdg_nbr_build_dense")
         if cap >= Ng - 1 or need is not None:
             break                                   # cannot overflow / checked later by the caller
-        need = int(overflow.item())
-        if need <= cap:
+        longest = int(overflow.item())              # longest row the builder met (one host sync)
+        if longest <= cap:
             break
-        cap = min(Ng - 1, (need + 15) // 8 * 8)
+        cap = min(Ng - 1, (longest + 15) // 8 * 8)  # grow to fit and rebuild
     return EllList(N, cap, col, shift, cnt, cell_struct, cutoff, mask)
 
 
@@ -208,6 +208,9 @@ class PairGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, wg, wgth):
         xyz, theta = ctx.saved_tensors
+        if wgth is not None and wgth.numel() and (wgth.requires_grad or bool((wgth != 0).any())):
+            raise NotImplementedError("mdgrad_amd: second derivatives of a pair energy w.r.t. its parameters alone "
+                                      "(a cotangent on dU/dtheta) are not provided by the HIP pair kernels")
         w = wg.detach().contiguous()
         o = pair_eval(ctx.ell, xyz, ctx.term, theta, w=w, energy=False, grad=False)
         gthw = o["gtheta_w"] if o["gtheta_w"] is not None else None
@@ -294,16 +297,27 @@ class FusedTrajFn(torch.autograd.Function):
                                          ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
                                          ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
                   "mdg_traj_fwd_large")
-            need = int(flags[0].item())            # one sync per trajectory (neighbour buffer check)
-            if need:
+            fl = flags.tolist()                    # one sync per trajectory (neighbour buffer / table range check)
+            if fl[0]:
                 raise RuntimeError("mdgrad_amd: an atom has %d neighbours within the cutoff; the fused large-N "
-                                   "kernel holds 256 per atom" % need)
+                                   "kernel holds 256 per atom" % fl[0])
+            if fl[3]:
+                raise RuntimeError("mdgrad_amd: a pair came closer than the first node of the tabulated pair "
+                                   "potential; lower `table_rmin` on the integrator or set `fused_table = False`")
             ctx.ws, bad = ws, flags[1:2]
         else:
             bad = torch.zeros(R, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
                                          ptr(q_t), ptr(pv_t), ptr(bad), stream_ptr(dev)), "mdg_traj_fwd_small")
+        if getattr(spec, "table", False) and not spec.large:
+            # tabulated user pair module: a live pair closer than the first table node has no valid entry
+            # (one host sync per trajectory, table mode only)
+            if bool((bad & 2).any()):
+                raise RuntimeError(
+                    "mdgrad_amd: a pair came closer than table_rmin * cutoff = %.4g, below the first node of the "
+                    "tabulated pair potential; lower `table_rmin` on the integrator or set `fused_table = False` "
+                    "to evaluate the module per pair" % math.sqrt(spec.u0))
         ctx.spec, ctx.batched, ctx.nhc = spec, batched, nhc
         ctx.nonfinite = bad
         saved = [tc, v_t, q_t] + ([pv_t] if nhc else []) + ([thc] if thc is not None else [])
@@ -324,6 +338,9 @@ class FusedTrajFn(torch.autograd.Function):
         thc = saved[-1] if ctx.has_theta else None
         R, T, N = v_t.shape[0], v_t.shape[1], spec.n_atoms
         dev = v_t.device
+        if ctx.nonfinite is not None and bool((ctx.nonfinite & 1).any()):
+            raise RuntimeError("mdgrad_amd: the forward trajectory reached a non-finite state (time step too large "
+                               "or overlapping atoms); its adjoint is undefined")
 
         def prep(g, like):
             if g is None:
@@ -358,6 +375,17 @@ class FusedTrajFn(torch.autograd.Function):
                                          stream_ptr(dev)), "mdg_traj_adj_small")
             return None
 
+        def check_large(flags):
+            # the adjoint evaluates forces / Hessian-vector products at its own (midpoint) positions: a neighbour
+            # buffer overflow or a blow-up there must not pass silently (one host sync, large path only)
+            f = flags.tolist()
+            if f[0]:
+                raise RuntimeError("mdgrad_amd: an atom has %d neighbours within the cutoff in the adjoint sweep; "
+                                   "the fused large-N kernel holds 256 per atom" % f[0])
+            if f[1]:
+                raise RuntimeError("mdgrad_amd: non-finite state in the fused large-N adjoint sweep")
+            return f
+
         if table:
             # fixed-point scale of the in-kernel table-gradient scatter: the largest single contribution
             # 1/2 h (D . w_ij) is put near 2^30 (the kernels accept up to 2^45); one host sync
@@ -369,7 +397,7 @@ class FusedTrajFn(torch.autograd.Function):
                 terms = type(spec.terms).from_buffer_copy(spec.terms)
                 terms.t[0].c = 2.0 ** S
                 flags = launch(terms)
-                bad = bool(flags[2].item()) if flags is not None else not bool(torch.isfinite(adj_th[:, 0]).all())
+                bad = bool(check_large(flags)[2]) if flags is not None else not bool(torch.isfinite(adj_th[:, 0]).all())
                 if not bad:
                     break
                 S -= 14                                    # adjoint grew past the range: coarser fixed point
@@ -377,7 +405,9 @@ class FusedTrajFn(torch.autograd.Function):
                 raise RuntimeError("mdgrad_amd: the table-gradient accumulation overflowed (adjoint magnitudes "
                                    "above 2^%d of the incoming gradients)" % (45 - S))
         else:
-            launch(spec.terms)
+            flags = launch(spec.terms)
+            if flags is not None:
+                check_large(flags)
         if not ctx.batched:
             adj_v, adj_q = adj_v[0], adj_q[0]
             adj_p = adj_p[0] if nhc else None

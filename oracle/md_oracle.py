@@ -13,7 +13,8 @@ import torch
 
 __all__ = [
     "cell_matrix", "nbr_list", "compute_dis", "pair_phi", "PairTerm", "ModelOracle",
-    "NHCOracle", "NVEOracle", "odeint_oracle", "adjoint_oracle", "rdf_oracle",
+    "NHCOracle", "NVEOracle", "odeint_oracle", "adjoint_oracle", "rdf_oracle", "rdf_raw_oracle",
+    "rdf_normalise_oracle", "vacf_oracle", "temperature_oracle",
     "vol_bins_oracle", "wrap_positions_oracle", "fcc_lattice", "diamond_lattice",
 ]
 
@@ -412,9 +413,10 @@ def vol_bins_oracle(start, end, nbins, dim=3):
     return V, vb, bins
 
 
-def rdf_oracle(xyz, cell, nbins, r_range, index_tuple=None, width=None, dim=3):
-    """rdf.forward (torchmd/observable.py:33-76) with GaussianSmearing
-    (nff/nn/layers.py:14-31,34-83).  Differentiable w.r.t. xyz through torch autograd."""
+def rdf_raw_oracle(xyz, cell, nbins, r_range, index_tuple=None, width=None, dim=3):
+    """The un-normalised soft histogram of rdf.forward: GaussianSmearing(pair distances).sum(0)
+    (torchmd/observable.py:64-70, nff/nn/layers.py:14-31).  Additive over frames, so callers with many
+    frames can accumulate it chunk by chunk."""
     start, end = r_range
     V, vb, bins = vol_bins_oracle(start, end, nbins, dim)
     mu = torch.linspace(start, float(bins[-1]), nbins).to(xyz)
@@ -428,10 +430,37 @@ def rdf_oracle(xyz, cell, nbins, r_range, index_tuple=None, width=None, dim=3):
         d = flat[nbr[:, 0], nbr[:, 1]] - flat[nbr[:, 0], nbr[:, 2]] - off.matmul(cellm)
     r = d.pow(2).sum(-1).sqrt()
     coeff = -0.5 / wd ** 2
-    count = torch.exp(coeff * (r[:, None] - mu[None, :]) ** 2).sum(0)
-    count = count / count.sum()
-    g = count / (vb.to(xyz) / V)
-    return count, bins, g
+    return torch.exp(coeff * (r[:, None] - mu[None, :]) ** 2).sum(0)
+
+
+def rdf_normalise_oracle(raw, nbins, r_range, dim=3):
+    """count / g(r) from the raw histogram (torchmd/observable.py:71-76)."""
+    V, vb, bins = vol_bins_oracle(r_range[0], r_range[1], nbins, dim)
+    count = raw / raw.sum()
+    return count, bins, count / (vb.to(raw) / V)
+
+
+def rdf_oracle(xyz, cell, nbins, r_range, index_tuple=None, width=None, dim=3):
+    """rdf.forward (torchmd/observable.py:33-76) with GaussianSmearing
+    (nff/nn/layers.py:14-31,34-83).  Differentiable w.r.t. xyz through torch autograd."""
+    raw = rdf_raw_oracle(xyz, cell, nbins, r_range, index_tuple, width, dim)
+    return rdf_normalise_oracle(raw, nbins, r_range, dim)
+
+
+def vacf_oracle(vel, t_range):
+    """vacf.forward (torchmd/observable.py:153-163): <v(s+t) . v(s)> as the MEAN over frames, atoms and
+    components for lags t = 0 .. t_range-1; vel [T, N, 3]."""
+    out = [(vel * vel).mean()[None]]
+    out += [(vel[t:] * vel[:-t]).mean()[None] for t in range(1, t_range)]
+    return torch.stack(out).reshape(-1)
+
+
+def temperature_oracle(vel, mass, dim=3):
+    """Temperature.forward (torchmd/thermo.py:57-66) of one frame vel [N, 3]: 2 KE / N_dof, N_dof = N dim,
+    in energy units."""
+    p = vel * mass[:, None]
+    ke = 0.5 * (p.pow(2) / mass[:, None]).sum()
+    return ke / (mass.shape[0] * dim * 0.5)
 
 
 # --------------------------------------------------------------------------- host utilities

@@ -20,6 +20,9 @@ Golden sets:
   G10 sim_*     Simulations 2 epochs         torchmd/md.py:14-96
   G13 exp_rdf   get_exp_rdf target normalisation                   scripts/data.py:11-31
   G12 bonded    BondPotentials / AnglePotentials energy + forces   torchmd/interface.py:406-510
+  G14 gnn_traj_water192  config #3: 192-atom water, SchNet A128/F128/G32/3 conv + prior, NHC + adjoint
+  G15 schnet_cg64_wide   SchNet A64/F128/G30/2 conv (config #5 widths): U, F, H.w, d(w.F)/dtheta
+  G16 vacf_temp          vacf / Temperature observables      torchmd/observable.py:153-163, thermo.py:57-66
   G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
                                              torchmd/potentials.py:163-217, interface.py:139-215
 """
@@ -405,6 +408,101 @@ def g8_g9():
          grad_q0=y0[1].grad, grad_v0=y0[0].grad, **sd)
 
 
+# ------------------------------------------------------------------ G14 / G15
+def g14_g15():
+    """G14: BASELINE config #3 -- the 192-atom all-atom water box with a SchNet (A128/F128/G32/3 conv, cutoff 5) +
+    ExcludedVolume prior, NHC trajectory and adjoint of an RDF loss.  G15: energy / force / H.w / d(w.F)/dtheta of a
+    SchNet with the widths of BASELINE config #5 (A64/F128/G30/2 conv, cutoff 6) on the 64-bead CG box."""
+    from torchmd.thermo import Temperature  # noqa: F401  (import check only)
+    wpos, wnum, wcell = read_water()
+    wpos = np.mod(wpos, wcell).astype(F32).astype(np.float64)
+    wmass = np.where(wnum == 8, 15.999, 1.008)
+    rng = np.random.default_rng(14)
+    kT = 298.0 * 8.617330337217213e-05
+    wvel = (rng.normal(0, 1, wpos.shape) * np.sqrt(kT / wmass)[:, None]).astype(F32).astype(np.float64)
+    params = {"n_atom_basis": 128, "n_filters": 128, "n_gaussians": 32, "n_convolutions": 3,
+              "cutoff": 5.0, "trainable_gauss": False}
+    system = make_system(wpos, wcell, numbers=wnum, masses=wmass, vel=wvel)
+    torch.manual_seed(0)
+    net = SchNet(params)
+    with torch.no_grad():                      # random-init forces are O(100 eV/A): scale the readout (stable dynamics)
+        net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
+    gnn = GNNPotentials(system, net, cutoff=5.0)
+    prior_model = P.ExcludedVolume(sigma=0.9, epsilon=0.01, power=12)
+    prior = PairPotentials(system, prior_model, cutoff=5.0)
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=kT, num_chains=5, Q=50.0, adjoint=True)
+    y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+    dt = 0.25 * 0.09822694788464063
+    t = torch.Tensor([dt * i for i in range(9)])
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    O_idx, H_idx = np.where(wnum == 8)[0].tolist(), np.where(wnum == 1)[0].tolist()
+    obs = rdf(system, nbins=40, r_range=(0.6, 5.0), index_tuple=(O_idx, H_idx))
+    _, _, g = obs(q_t[::2])
+    loss = g.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3 + v_t[-1].pow(2).sum() * 1e-2
+    loss.backward()
+    plist = list(integ.parameters())
+    flatg = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in plist])
+    names = [n for n, _ in integ.named_parameters()]
+    sd = {"sd__" + k: v for k, v in net.state_dict().items()}
+    save("gnn_traj_water192", pos=wpos.astype(F32), cell=wcell.astype(F32), numbers=wnum, masses=wmass.astype(F32),
+         vel=wvel.astype(F32), T=kT, Q=50.0, chains=5, dt=dt, cutoff=5.0, prior_sigma=0.9, prior_epsilon=0.01,
+         n_atom_basis=128, n_filters=128, n_gaussians=32, n_convolutions=3,
+         v_t=v_t.detach(), q_t=q_t.detach(), pv_t=pv_t.detach(), g=g.detach(), loss=loss.detach().reshape(1),
+         grad_flat=flatg, param_names=np.array(names), grad_q0=y0[1].grad, grad_v0=y0[0].grad,
+         idx_O=np.array(O_idx), idx_H=np.array(H_idx), **sd)
+
+    # G15: bench widths on the CG box
+    a = 6.2148
+    pos, cell = diamond(2, a)
+    rng = np.random.default_rng(15)
+    pos = np.mod(pos + rng.normal(0, 0.3, pos.shape), cell).astype(F32).astype(np.float64)
+    numbers = np.full(len(pos), 8)
+    masses = np.full(len(pos), 18.01528)
+    system = make_system(pos, cell, numbers=numbers, masses=masses)
+    params = {"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2,
+              "cutoff": 6.0, "trainable_gauss": False}
+    torch.manual_seed(5)
+    net = SchNet(params)
+    gnn = GNNPotentials(system, net, cutoff=6.0)
+    q = torch.Tensor(pos).requires_grad_(True)
+    gnn._reset_topology(q.detach())
+    U = gnn(q)
+    (gq,) = torch.autograd.grad(U.sum(), q, create_graph=True)
+    w = torch.Tensor(rng.normal(0, 1, pos.shape))
+    plist = list(net.parameters())
+    grads = torch.autograd.grad((w * -gq).sum(), [q] + plist, allow_unused=True)
+    flat = torch.cat([(g_ if g_ is not None else torch.zeros_like(p_)).reshape(-1) for g_, p_ in zip(grads[1:], plist)])
+    sd = {"sd__" + k: v for k, v in net.state_dict().items()}
+    save("schnet_cg64_wide", pos=pos.astype(F32), cell=cell.astype(F32), numbers=numbers, masses=masses.astype(F32),
+         n_atom_basis=64, n_filters=128, n_gaussians=30, n_convolutions=2, cutoff=6.0,
+         nbr=gnn.inputs["nbr_list"], offsets=gnn.inputs["offsets"], U=U.detach().reshape(-1), F=-gq.detach(), w=w,
+         dwF_dq=grads[0], dwF_dtheta=flat, **sd)
+
+
+# ------------------------------------------------------------------ G16
+def g16():
+    """vacf (torchmd/observable.py:153-163) and Temperature (torchmd/thermo.py:57-66) on a seeded velocity
+    trajectory, with the gradient of a weighted sum w.r.t. the velocities."""
+    from torchmd.observable import vacf
+    from torchmd.thermo import Temperature
+    rng = np.random.default_rng(16)
+    pos, cell, vel = lj_inputs(seed=16)
+    masses = rng.uniform(0.8, 3.0, len(pos)).astype(F32).astype(np.float64)
+    system = make_system(pos, cell, masses=masses, vel=vel)
+    v_t = torch.Tensor(rng.normal(0, 1, (30, len(pos), 3)).astype(F32)).requires_grad_(True)
+    wgt = torch.Tensor(rng.normal(0, 1, 12).astype(F32))
+    c = vacf(system, t_range=12)(v_t)
+    (gv,) = torch.autograd.grad((c * wgt).sum(), v_t)
+    temp = Temperature(system)
+    v1 = torch.Tensor(vel).requires_grad_(True)
+    T1 = temp(v1)
+    (gT,) = torch.autograd.grad(T1, v1)
+    Tt = torch.stack([temp(v_t[k]) for k in range(v_t.shape[0])])
+    save("vacf_temp", pos=pos.astype(F32), cell=cell.astype(F32), masses=masses.astype(F32), vel=vel.astype(F32),
+         v_t=v_t.detach(), wgt=wgt, vacf=c.detach(), vacf_grad=gv, T_single=T1.detach().reshape(1), T_grad=gT,
+         T_frames=Tt.detach())
+
+
 # ------------------------------------------------------------------ G10
 def g10():
     pos, cell, vel = lj_inputs(seed=0)
@@ -521,8 +619,8 @@ def g13():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13", "g1415", "g16"]
     table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11,
-             "g12": g12, "g13": g13}
+             "g12": g12, "g13": g13, "g1415": g14_g15, "g16": g16}
     for w in which:
         table[w]()

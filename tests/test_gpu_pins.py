@@ -1,0 +1,219 @@
+"""The kernel variants that bench.py actually times, pinned to the CPU oracle (which is itself pinned to the
+reference goldens, tests/test_oracle_golden.py):
+
+  * the one-lane-per-atom trajectory kernels (workgroup = 128 threads; picked when >= 1024 replicas run in one
+    launch, csrc/traj_small.hip pick_block) -- forward, adjoint and parameter gradients;
+  * the many-frame (>= 1024 frames) RDF kernels: half-width and full-width lane-per-pair forward, fine-table and
+    recurrence backward (csrc/rdf.hip);
+  * the multi-launch large-N trajectory kernels (csrc/traj_large.hip) at 1 000, 2 744 and 4 096 atoms;
+  * BASELINE config #3 (192-atom water, SchNet + prior) as a trajectory + adjoint golden from the reference.
+
+fp32 tolerances are written at each assert (about 10x the errors observed on MI355X)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import load_golden
+from test_gpu_parity import T, close, mk_system, lj_setup, oracle_run, liquid, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ timed trajectory geometry
+@pytest.mark.parametrize("R,block", [(6, 128), (1024, 0)])
+def test_one_lane_per_atom_trajectory_kernels_vs_oracle(R, block):
+    """block = 128 forced on a few replicas, and the default launch at R = 1024 (which picks it): sampled
+    replicas' trajectories, adjoints w.r.t. the initial state and the summed parameter gradient == oracle."""
+    from mdgrad_amd import ops
+    g = load_golden("nhc_traj_lj")
+    system, mdl, integ = lj_setup(g)
+    spec = integ.fused_spec("NH_verlet")
+    spec.block = block
+    nT = 12
+    rng = np.random.default_rng(7 + R)
+    pos = np.mod(g["pos"][None] + rng.normal(0, 0.03, (R,) + g["pos"].shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(nT)])
+    sample = [0, 1, R // 2, R - 1]
+    wr = torch.zeros(R, device=DEV)
+    wr[sample] = 1.0                                     # only the sampled replicas feed the loss
+    v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+    pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True)
+    v_t, q_t, pv_t = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+    mdl.zero_grad()
+    loss = ((q_t[:, ::2].pow(2).sum((1, 2, 3)) / (6 * 108 * 3) + v_t[:, -1].pow(2).sum((1, 2)) / (108 * 3)
+             + pv_t[:, -1].sum(1)) * wr).sum()
+    loss.backward()
+    gth_sum = np.zeros(2)
+    for r in sample:
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        traj, lam, gth = oracle_run(
+            pos[r], g["cell"], vel[r], g["mass"], [term], 1.0, 50.0, 5, t,
+            lambda L: L[1][::2].pow(2).sum() / (6 * 108 * 3) + L[0][-1].pow(2).sum() / (108 * 3) + L[2][-1].sum())
+        close(q_t[r], traj[1], 0, 2e-5, "q_t[%d]" % r)
+        close(v_t[r], traj[0], 0, 2e-4, "v_t[%d]" % r)
+        close(pv_t[r], traj[2], 1e-4, 1e-4, "pv_t[%d]" % r)
+        close(v0.grad[r], lam[0], 1e-3, 2e-4 * float(lam[0].abs().max()), "adj v0[%d]" % r)
+        close(q0.grad[r], lam[1], 1e-3, 2e-4 * float(lam[1].abs().max()), "adj q0[%d]" % r)
+        close(pv0.grad[r], lam[2], 1e-3, 2e-4 * float(lam[2].abs().max()) + 1e-6, "adj pv0[%d]" % r)
+        gth_sum += gth.numpy()
+    got = np.array([float(mdl.sigma.grad), float(mdl.epsilon.grad)])
+    close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max(), "sum over sampled replicas of dL/dtheta")
+    rest = [r for r in range(R) if r not in sample]
+    assert float(q0.grad[rest].abs().max()) == 0.0, "replicas outside the loss get exactly zero adjoint"
+
+
+# ------------------------------------------------------------------ many-frame RDF kernels
+def _oracle_rdf_chunked(frames, cell, nbins, r_range, width, wgt, chunk=100):
+    """g(r) and d(sum g wgt)/dxyz from the oracle, the raw histogram accumulated over chunks of frames."""
+    raws = []
+    for k in range(0, frames.shape[0], chunk):
+        with torch.no_grad():
+            raws.append(O.rdf_raw_oracle(T(frames[k:k + chunk]), T(cell), nbins, r_range, width=width))
+    raw = torch.stack(raws).sum(0).requires_grad_(True)
+    _, _, g = O.rdf_normalise_oracle(raw, nbins, r_range)
+    (g_raw,) = torch.autograd.grad((g * wgt).sum(), raw)
+    grads = []
+    for k in range(0, frames.shape[0], chunk):
+        x = T(frames[k:k + chunk]).requires_grad_(True)
+        (gx,) = torch.autograd.grad((O.rdf_raw_oracle(x, T(cell), nbins, r_range, width=width) * g_raw).sum(), x)
+        grads.append(gx)
+    return g.detach(), torch.cat(grads)
+
+
+@pytest.mark.parametrize("width_scale", [1.0, 1.6, 0.4])
+def test_many_frame_rdf_kernels_vs_oracle(width_scale):
+    """1 100 frames of the 108-atom box through rdf(): half-width forward + fine-table backward (width =
+    spacing), full-width forward + recurrence backward (1.6 x), narrow full-width (0.4 x) -- g(r) and
+    d(sum g w)/dxyz against the oracle itself (not a sibling kernel)."""
+    from mdgrad_amd.observable import rdf
+    g = load_golden("rdf")
+    rng = np.random.default_rng(11)
+    base = g["xyz"][0]
+    frames = np.stack([np.mod(base + rng.normal(0, 0.05, base.shape), g["cell"]) for _ in range(1100)]).astype(np.float32)
+    nbins, rr = 100, (0.75, 2.5)
+    spacing = (rr[1] - rr[0]) / (nbins - 1)
+    width = None if width_scale == 1.0 else width_scale * spacing
+    wgt = torch.linspace(-1, 1, nbins)
+    system = mk_system(base, g["cell"])
+    x = T(frames, DEV).requires_grad_(True)
+    count, bins, gr = rdf(system, nbins=nbins, r_range=rr, width=width)(x)
+    (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    g_o, gx_o = _oracle_rdf_chunked(frames, g["cell"], nbins, rr, width, wgt)
+    close(gr, g_o, 1e-4, 1e-4, "g(r), 1100 frames, width x%.1f" % width_scale)            # g(r): abs 1e-4
+    close(gx, gx_o, 1e-3, 1e-4 * float(gx_o.abs().max()), "d(g.w)/dxyz, 1100 frames, width x%.1f" % width_scale)
+
+
+# ------------------------------------------------------------------ large-N fused path vs the oracle
+def _large_case(n_side, n_frames, adjoint, seed):
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    pos, cell = liquid(n_side, seed=seed, jitter=0.05)
+    rng = np.random.default_rng(seed + 100)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    mass = np.full(len(pos), 1.008, dtype=np.float32)
+    t = torch.Tensor([0.004 * i for i in range(n_frames)])
+    system = mk_system(pos, cell, vel, mass)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3,
+                            Q=30.0).to(DEV)
+    integ.fused_large = True
+    assert integ.fused_spec("NH_verlet").large
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="NH_verlet")
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1)
+    N = len(pos)
+
+    def loss_fn(L):
+        return L[1][::2].pow(2).sum() / (L[1][::2].numel()) + L[0][-1].pow(2).sum() / (N * 3) + L[2][-1].sum() * 1e-3
+
+    if adjoint:
+        loss_fn((v_t, q_t, pv_t)).backward()
+        traj, lam, gth = oracle_run(pos, cell, vel, mass, [term], 1.0, 30.0, 3, t, loss_fn)
+    else:
+        eom = O.NHCOracle(O.ModelOracle([term]), T(mass), 1.0, 30.0, 3)
+        traj = O.odeint_oracle(eom, (T(vel), T(pos), torch.zeros(3)), t)
+    close(q_t, traj[1], 0, 2e-5, "q_t (N=%d)" % N)
+    close(v_t, traj[0], 0, 5e-4, "v_t (N=%d)" % N)
+    close(pv_t, traj[2], 1e-3, 1e-4, "pv_t (N=%d)" % N)
+    if adjoint:
+        got = torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])
+        close(got, gth, 2e-3, 2e-4 * float(gth.abs().max()), "dL/dtheta (N=%d)" % N)
+        for y, l, nm in zip(y0, lam, ("adj v0", "adj q0", "adj pv0")):
+            close(y.grad, l, 2e-3, 5e-4 * float(l.abs().max()) + 1e-9, "%s (N=%d)" % (nm, N))
+
+
+@pytest.mark.parametrize("n_side", [10, 14])
+def test_large_path_vs_oracle_forward_and_adjoint(n_side):
+    """traj_large at N = 1 000 and N = 2 744 (tile staging, multi-block partial reduction, neighbour buffer
+    all exercised), 3 steps forward + adjoint, against the oracle."""
+    _large_case(n_side, 4, True, seed=20 + n_side)
+
+
+def test_large_path_4096_atoms_one_step_vs_oracle():
+    """BASELINE config #4's size: one forward NH-Verlet step of the 4 096-atom LJ liquid against the oracle."""
+    _large_case(16, 2, False, seed=36)
+
+
+# ------------------------------------------------------------------ BASELINE config #3 as a golden
+def test_config3_water192_schnet_trajectory_adjoint_golden():
+    """192-atom all-atom water box, SchNet A128/F128/G32/3 conv + ExcludedVolume prior, NHC, O-H RDF loss:
+    trajectory, g(r), 185 571 parameter gradients and the adjoint w.r.t. the initial state vs the
+    reference (golden G14)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from test_gpu_schnet import params_of, sd_of
+    g = load_golden("gnn_traj_water192")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12),
+                           cutoff=float(g["cutoff"]))
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=float(g["T"]),
+                            num_chains=int(g["chains"]), Q=float(g["Q"]), adjoint=True).to(DEV)
+    assert [n for n, _ in integ.named_parameters()] == [str(x) for x in g["param_names"]]
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(g["dt"]) * i for i in range(g["q_t"].shape[0])]).to(DEV)
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    for x, k in zip((v_t, q_t, pv_t), ["v_t", "q_t", "pv_t"]):
+        close(x, g[k], 1e-4, 1e-4 * max(1e-3, np.abs(g[k]).max()), k)
+    obs = rdf(system, nbins=40, r_range=(0.6, 5.0), index_tuple=(g["idx_O"].tolist(), g["idx_H"].tolist()))
+    _, _, gr = obs(q_t[::2])
+    close(gr, g["g"], 1e-3, 2e-4, "g_OH")
+    loss = gr.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3 + v_t[-1].pow(2).sum() * 1e-2
+    close(loss.reshape(1), g["loss"], 1e-4, 1e-6, "loss")
+    loss.backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
+    close(flat, g["grad_flat"], 5e-3, 2e-4 * np.abs(g["grad_flat"]).max(), "dL/dtheta (185 571 params)")
+    close(y0[1].grad, g["grad_q0"], 5e-3, 2e-3 * np.abs(g["grad_q0"]).max(), "grad_q0")
+    close(y0[0].grad, g["grad_v0"], 5e-3, 2e-3 * np.abs(g["grad_v0"]).max(), "grad_v0")
+
+
+# ------------------------------------------------------------------ neighbour-list capacity growth
+def test_build_ell_grows_when_a_cluster_exceeds_the_density_estimate():
+    """A dilute box with one dense droplet: the longest row is far above 1.5 x the mean density, so the first
+    pass overflows and the list is rebuilt with the capacity the builder reported; the result equals the oracle."""
+    from mdgrad_amd import ops, _lib
+    rng = np.random.default_rng(3)
+    L = 30.0
+    gas = rng.uniform(0, L, (300, 3))
+    drop = 15.0 + rng.normal(0, 0.9, (120, 3))
+    pos = np.concatenate([gas, drop]).astype(np.float32)
+    cell = np.array([L, L, L], dtype=np.float32)
+    cs = _lib.make_cell(cell)
+    est = ops.estimate_max_nbr(len(pos), cs, 2.5)
+    ell = ops.build_ell(T(pos, DEV), cs, 2.5)
+    longest = int(ell.cnt.max())
+    assert longest > est, "the droplet must overflow the estimate for this test to mean anything"
+    assert ell.max_nbr >= longest
+    nbr, off = ell.half_list()
+    onbr, ooff = O.nbr_list(T(pos), 2.5, T(cell))
+    assert np.array_equal(nbr.cpu().numpy(), onbr.numpy()) and np.array_equal(off.cpu().numpy(), ooff.numpy())
