@@ -271,6 +271,53 @@ int mdg_cfconv_filter_bf16(const float* d, int64_t n_edges, const float* mu, con
                            int n_filters, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K9 + K10 fused: the whole SchNet interaction block on the MD path, nothing edge-sized in HBM
+ * (replaces SchNetConv.message/aggregate -- nff/nn/modules.py:531-541,564-571, nff/nn/graphconv.py:43-53,
+ *  the distance line nff/nn/models/schnet.py:142 -- and what autograd / double autograd derive from them for
+ *  the force -dU/dx and for the adjoint's d(w.F)/dx, d(w.F)/dtheta, torchmd/sovlers.py:229-233).
+ * Filter network: mu, coef [G] (coef_k = -0.5 / width_k^2), W1 [G,G], b1 [G], W2 [F,G], b2 [F] in
+ * torch.nn.Linear layout.  G <= 64; F <= 128, a multiple of 4 (F <= 64) or 8 (mdg_cfconv_supported).
+ *
+ *   mdg_edge_geom      d_e = |x_i - x_j - o_e|, uhat_e; with w: dd_e = uhat_e . (w_i - w_j), ddel_e = w_i - w_j
+ *   mdg_cfconv_fwd     m[n] = sum_{slots s of n} h[col_s] (.) W(d_s)                        (dd == NULL)
+ *                      md[n] = sum_s h[col_s] (.) dW/dd(d_s) dd_s + hd[col_s] (.) W(d_s)    (tangent; hd nullable)
+ *                      hsum[n] = sum_s h[col_s], hdsum likewise (nullable; feed the bias gradient of Dense2)
+ *                      Symmetric in the adjacency: called with (h, hd) := (mdb, mb) it returns the adjoints
+ *                      (hdb, hb) of (hd, h) in the reverse sweep.
+ *   mdg_cfconv_bwd     with Wdb_e = mdb_i h_j + mdb_j h_i and (dual sweep, mb != NULL)
+ *                      Wb_e = mb_i h_j + mb_j h_i + mdb_i hd_j + mdb_j hd_i:
+ *                        dd_b[e] += d(Wdb_e . Wd_e)/d(dd_e)        d_b[e] += d(Wdb_e . Wd_e + Wb_e . W_e)/d(d_e)
+ *                        gW1, gb1, gW2 <- gradients of sum_e (Wdb_e . Wd_e + Wb_e . W_e)   (gW1 != NULL; dual only)
+ *                      Called with mdb := dU/dm and mb == NULL it is the plain reverse sweep: dd_b[e] += dU/dd_e.
+ *                      workspace: mdg_cfconv_bwd_workspace() floats when gW1 is requested.
+ *   mdg_edge_geom_bwd  force[n] = -sum_s sgn_s dd_b uhat ;  dwf[n] = -sum_s sgn_s [d_b uhat + dd_b/d (ddel - dd uhat)]
+ *                      (d_b nullable: force only)
+ */
+typedef struct {
+    const float* mu;
+    const float* coef;
+    const float* W1;
+    const float* b1;
+    const float* W2;
+    const float* b2;
+    int32_t n_gauss, n_filters;
+} MdgFilterNet;               /* host struct of DEVICE pointers */
+
+int mdg_cfconv_supported(int n_gauss, int n_filters);
+int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                  float* d, float* uhat, float* dd, float* ddel, void* stream);
+int mdg_edge_geom_bwd(const float* d_b, const float* dd_b, const float* d, const float* dd, const float* uhat,
+                      const float* ddel, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                      int n_atoms, int max_nbr, float* force, float* dwf, void* stream);
+int mdg_cfconv_fwd(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const float* h, const float* hd,
+                   const int32_t* col, const int32_t* eid, const int32_t* cnt, int n_atoms, int max_nbr,
+                   float* m, float* md, float* hsum, float* hdsum, void* stream);
+int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges);
+int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
+                   int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                   float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused elementwise / row-reduction pieces of the hand-derived SchNet passes (each replaces a chain of
  * PyTorch elementwise ops; nff/nn/layers.py:14-31, nff/nn/activations.py:5-11 and their derivatives):
  *   mdg_smear        g = exp(c_k (d - mu_k)^2), phi = 2 c_k (d - mu_k)              [E,G]

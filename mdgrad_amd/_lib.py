@@ -37,6 +37,12 @@ class MdgTrajParams(C.Structure):
                 ("T", C.c_float), ("n_dof", C.c_float), ("Q", C.c_float * MAX_CHAINS)]
 
 
+class MdgFilterNet(C.Structure):
+    """Host struct of device pointers describing one SchNet filter network (include/mdgrad_hip.h)."""
+    _fields_ = [("mu", C.c_void_p), ("coef", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("W2", C.c_void_p), ("b2", C.c_void_p), ("n_gauss", C.c_int32), ("n_filters", C.c_int32)]
+
+
 P = C.c_void_p
 _SIGNATURES = {
     "mdg_last_error": (C.c_char_p, []),
@@ -83,6 +89,12 @@ _SIGNATURES = {
     "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
+    "mdg_cfconv_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mdg_edge_geom": (C.c_int, [P, P, P, P, C.c_int64, P, P, P, P, P]),
+    "mdg_edge_geom_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P]),
+    "mdg_cfconv_fwd": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),
+    "mdg_cfconv_bwd_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
+    "mdg_cfconv_bwd": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
 }

@@ -1,0 +1,819 @@
+// Fused SchNet interaction block for the MD path (K9 + K10 in one kernel family):
+//
+//   W_e = Dense2( ssp( Dense1( smear(d_e) ) ) )                 nff/nn/modules.py:531-541, layers.py:14-31
+//   m_n = sum_{j in nbr(n)} h_j (.) W_{nj}                      nff/nn/modules.py:564-571, graphconv.py:43-53
+//
+// and every derivative of it that a force evaluation and the adjoint's force-vjp need
+// (mdgrad_amd/nn/analytic.py: primal, forward-mode tangent along x_dot = w, and the reverse sweep of U_dot).
+// Nothing edge-sized ever reaches HBM: the Gaussian basis is computed in registers as the MFMA A fragment, both
+// Dense layers run on v_mfma_f32_16x16x4_f32 with W1 / W2 resident in LDS, the filter rows are multiplied with
+// the gathered node rows in the accumulator layout and summed per atom in the wave.  The reverse sweeps
+// RECOMPUTE the filter network instead of loading saved [E,G] / [E,F] tensors.
+//
+//   cfconv_fwd_kernel<GP,FT,TANGENT>   atom-centric (one wave per atom, 16 neighbour slots per MFMA tile):
+//       m_n  = sum_s h[col_s] (.) W(d_s)
+//       md_n = sum_s h[col_s] (.) Wd_s + hd[col_s] (.) W(d_s)          Wd = dW/dd * dd      (TANGENT)
+//     The same kernel serves the reverse sweeps, because the aggregation is symmetric in the adjacency:
+//     fed (mdb, mb) it returns (hdb, hb) = the adjoints of (hd, h).
+//   cfconv_bwd_kernel<GP,FT,DUAL,THETA> edge-centric (16 undirected edges per tile): the adjoints of the filter
+//     network.  With the adjoint rows  Wdb_e = mdb_i h_j + mdb_j h_i  (adjoint of Wd) and
+//     Wb_e = mb_i h_j + mb_j h_i + mdb_i hd_j + mdb_j hd_i  (adjoint of W, DUAL):
+//       dd_b[e] += d(Wdb . Wd)/d(dd)          d_b[e] += d(Wdb . Wd + Wb . W)/d(d)
+//       gW1, gb1, gW2  += the parameter gradients of the same scalar                     (THETA)
+//     dd_b is at the same time dU/dd of the plain reverse sweep (the adjoint of a tangent is the reverse-mode
+//     adjoint of the primal), so the force falls out of the dual sweep: there is no separate reverse pass of U.
+//
+// MFMA operand conventions (v_mfma_f32_16x16x4_f32; lane = li + 16 lk, li < 16, lk < 4):
+//   A: lane holds A[row li][k = lk]      B: lane holds B[k = lk][col li]      C: acc[r] = C[row 4 lk + r][col li]
+// The contraction index may be any permutation as long as A and B use the same one; the kernels pick
+// permutations that make the global gathers 16-byte vectors:
+//   forward:  output column (nt, li) of the second layer <-> filter f = li*FT + nt, so a lane owns FT consecutive
+//             filters of its 4 neighbour rows (one or two float4 per gathered row);
+//   backward: k-step ks = 4 q + c of the [16 edges x F] x [F x G] product <-> filter f = 16 q + 4 lk + c
+//             (float4 gathers, 64-byte segments per row and instruction); the weight-gradient products contract
+//             over the 16 edges of the tile with edge = 4 lk + r, which is exactly the accumulator layout, so the
+//             C registers of one product are the A / B operands of the next without passing through LDS.
+// All sums have a fixed order (per-wave accumulators, ordered cross-wave / cross-block reduction): bitwise
+// reproducible, no atomics.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.69314718055994531f;
+constexpr float PAD_D = 1.0e4f;         // distance of an inert row: every Gaussian is exactly 0 there
+
+__host__ __device__ inline int s16m32(int n) {   // smallest s >= n with s % 32 == 16 (conflict-free B fetches)
+    int s = (n + 31) / 32 * 32 - 16;
+    if (s < n) s += 32;
+    return s;
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// softplus(x) - ln 2 and sigmoid(x) from one exp2 (torch's softplus threshold 20)
+__device__ __forceinline__ void ssp_sig(float x, float& s, float& sg) {
+    const float ex = __builtin_amdgcn_exp2f(x * LOG2E);
+    const bool big = x > 20.f;
+    const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2;
+    s = (big ? x : sp) - LN2;
+    sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
+}
+
+struct FilterDev {
+    const float *mu, *coef, *W1, *b1, *W2, *b2;
+    int G, F;
+};
+
+// ============================================================================================ forward
+struct FwdArgs {
+    FilterDev net;
+    const float *d, *dd, *h, *hd;
+    const int32_t *col, *eid, *cnt;
+    int N, max_nbr;
+    float *m, *md, *hsum, *hdsum;
+};
+
+template <int FT>
+__device__ __forceinline__ void load_row(const float* __restrict__ base, long long row, int F, int li, bool ok,
+                                         float (&out)[FT]) {
+    // FT consecutive filters li*FT .. li*FT+FT-1 of one gathered row (zero outside the row / for an inert slot)
+    if (ok && li * FT + FT <= F) {
+        const float4* p = reinterpret_cast<const float4*>(base + row * F + li * FT);
+#pragma unroll
+        for (int v = 0; v < FT / 4; ++v) {
+            const float4 x = p[v];
+            out[4 * v] = x.x; out[4 * v + 1] = x.y; out[4 * v + 2] = x.z; out[4 * v + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < FT; ++v) out[v] = 0.f;
+    }
+}
+
+template <int FT>
+__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int F, int li, const float (&v)[FT]) {
+    if (li * FT + FT <= F) {
+        float4* p = reinterpret_cast<float4*>(base + row * F + li * FT);
+#pragma unroll
+        for (int q = 0; q < FT / 4; ++q) p[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    }
+}
+
+template <int GP, int FT, bool TANGENT>
+__global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;          // s16m32(GP) for GP in {16,32,48,64}
+    constexpr int FP = 16 * FT;
+    constexpr int S2 = FP % 32 == 16 ? FP : FP + 16;
+    constexpr int SA = GP + 2;
+    constexpr int KS = GP / 4;
+    float* w1s = sm;                        // [GP][S1]  B1[k][j] = W1[j][k]
+    float* w2s = w1s + GP * S1;             // [GP][S2]  B2[k][nt*16+li] = W2[li*FT+nt][k]
+    float* mus = w2s + GP * S2;             // [GP] centres, [GP] c log2e, [GP] 2c, [GP] b1, [FP] b2 (permuted)
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    float* b2s = b1s + GP;
+    float* h1s = b2s + FP;                  // [4 waves][16][SA]  (, [4][16][SA] tangent)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = A.net.G, F = A.net.F;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int k = t / GP, j = t % GP;
+        w1s[k * S1 + j] = (k < G && j < G) ? A.net.W1[j * G + k] : 0.f;
+    }
+    for (int t = tid; t < GP * FP; t += 256) {
+        const int k = t % GP, c = t / GP;                       // consecutive threads: consecutive k of one W2 row
+        const int f = (c & 15) * FT + (c >> 4);
+        w2s[k * S2 + c] = (k < G && f < F) ? A.net.W2[(size_t)f * G + k] : 0.f;
+    }
+    for (int k = tid; k < GP; k += 256) {
+        const float c = k < G ? A.net.coef[k] : 0.f;
+        mus[k] = k < G ? A.net.mu[k] : 0.f;
+        cfs[k] = c * LOG2E;
+        c2s[k] = 2.f * c;
+        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+    }
+    for (int c = tid; c < FP; c += 256) {
+        const int f = (c & 15) * FT + (c >> 4);
+        b2s[c] = f < F ? A.net.b2[f] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    float* h1w = h1s + wid * 16 * SA;
+    float* h1dw = h1s + (4 + wid) * 16 * SA;
+    // contiguous chunk of atoms per workgroup, XCD-aware order (neighbouring atoms gather the same rows)
+    const int nb = gridDim.x;
+    const int per = (A.N + nb - 1) / nb;
+    const int b = xcd_chunk(blockIdx.x, nb);
+    const int n_lo = b * per, n_hi = min(A.N, n_lo + per);
+    for (int n = n_lo + wid; n < n_hi; n += 4) {
+        const int cnt = A.cnt[n];
+        const size_t rowb = (size_t)n * A.max_nbr;
+        float macc[FT], mdacc[FT], hs[FT], hds[FT];
+#pragma unroll
+        for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
+        for (int t0 = 0; t0 < cnt; t0 += 16) {
+            // ---- A-layout row (slot t0 + li): distance (and its tangent)
+            const bool va = t0 + li < cnt;
+            const int ea = va ? A.eid[rowb + t0 + li] : 0;
+            const float da = va ? A.d[ea] : PAD_D;
+            float dda = 0.f;
+            if (TANGENT) dda = va ? A.dd[ea] : 0.f;
+            // ---- C-layout rows (slots t0 + 4 lk + r): gathered node rows, FT consecutive filters per lane
+            float hreg[4][FT], hdreg[4][FT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = t0 + 4 * lk + r;
+                const bool vc = s < cnt;
+                const int j = vc ? A.col[rowb + s] : 0;
+                load_row<FT>(A.h, j, F, li, vc, hreg[r]);
+                if (TANGENT) load_row<FT>(A.hd, j, F, li, vc && A.hd != nullptr, hdreg[r]);
+            }
+            // ---- layer 1: Gaussians (and d/dd of them) in registers as A fragments
+            float af[KS], adf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 4 + lk;
+                const float x = da - mus[k];
+                const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                af[ks] = g;
+                if (TANGENT) adf[ks] = g * (c2s[k] * x) * dda;
+            }
+#pragma unroll
+            for (int nt = 0; nt < GP / 16; ++nt) {
+                float bf[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bf[ks] = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc = MFMA(af[ks], bf[ks], acc);
+                    if (TANGENT) accd = MFMA(adf[ks], bf[ks], accd);
+                }
+                const int c = nt * 16 + li;
+                const float bias = b1s[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s, sg;
+                    ssp_sig(acc[r] + bias, s, sg);
+                    h1w[(lk * 4 + r) * SA + c] = s;             // (padded columns: zero weights and bias -> ssp(0) = 0)
+                    if (TANGENT) h1dw[(lk * 4 + r) * SA + c] = sg * accd[r];
+                }
+            }
+            // (h1w / h1dw are private to the wave: program order + the LDS counter suffice, no barrier)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                af[ks] = h1w[li * SA + ks * 4 + lk];
+                if (TANGENT) adf[ks] = h1dw[li * SA + ks * 4 + lk];
+            }
+            // ---- layer 2 + multiply with the gathered rows + sum over the 4 rows of the lane
+#pragma unroll
+            for (int nt = 0; nt < FT; ++nt) {
+                float bf[KS];
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) bf[ks] = w2s[(ks * 4 + lk) * S2 + nt * 16 + li];
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    acc = MFMA(af[ks], bf[ks], acc);
+                    if (TANGENT) accd = MFMA(adf[ks], bf[ks], accd);
+                }
+                const float bias = b2s[nt * 16 + li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float W = acc[r] + bias;
+                    macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
+                    hs[nt] += hreg[r][nt];
+                    if (TANGENT) {
+                        mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
+                        mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
+                        hds[nt] += hdreg[r][nt];
+                    }
+                }
+            }
+        }
+        // ---- sum over the 4 row groups (lanes li, li+16, li+32, li+48) and store the atom's row
+#pragma unroll
+        for (int v = 0; v < FT; ++v) {
+            macc[v] += __shfl_xor(macc[v], 16, 64); macc[v] += __shfl_xor(macc[v], 32, 64);
+            if (TANGENT) { mdacc[v] += __shfl_xor(mdacc[v], 16, 64); mdacc[v] += __shfl_xor(mdacc[v], 32, 64); }
+        }
+        if (A.hsum) {
+#pragma unroll
+            for (int v = 0; v < FT; ++v) {
+                hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
+                if (TANGENT) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
+            }
+        }
+        if (lk == 0) {
+            store_row<FT>(A.m, n, F, li, macc);
+            if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
+            if (A.hsum) store_row<FT>(A.hsum, n, F, li, hs);
+            if (TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+        }
+    }
+}
+
+template <int GP, int FT>
+size_t fwd_lds_bytes(bool tangent) {
+    constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;
+    constexpr int FP = 16 * FT;
+    constexpr int S2 = FP % 32 == 16 ? FP : FP + 16;
+    return sizeof(float) * ((size_t)GP * S1 + (size_t)GP * S2 + 4 * GP + FP + (tangent ? 8 : 4) * 16 * (GP + 2));
+}
+
+// ============================================================================================ backward
+struct BwdArgs {
+    FilterDev net;
+    const float *d, *dd;
+    const int64_t* nbr;
+    long long E;
+    const float *h, *hd, *mb, *mdb;
+    float *d_b, *dd_b;
+    float* part;              // THETA: [gridDim.x][GP*GP + GP + FP*GP] per-workgroup partial gradients
+};
+
+// physical row of filter f in the LDS copy of W2 used as the B operand of  [16 x F] x [F x G]:
+// k-step ks = 4 (f / 16) + f % 4, k-lane lk = (f % 16) / 4
+__host__ __device__ inline int w2_row(int f) { return (4 * (f >> 4) + (f & 3)) * 4 + ((f & 15) >> 2); }
+
+template <int GP, int FT, bool DUAL, bool THETA>
+__global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;
+    constexpr int FP = 16 * FT;
+    constexpr int SA = GP + 2;
+    constexpr int SW = FP + 4;                                   // tile stride: 4 mod 32, rows 16-B aligned
+    constexpr int KS = GP / 4, NT = GP / 16;
+    constexpr int WSZ = THETA ? 16 * SW : 16 * SA;               // per-wave scratch (tile / transposes)
+    static_assert(!THETA || DUAL, "parameter gradients come from the dual sweep");
+    float* w1s = sm;                         // [GP][S1]  B[k][j] = W1[j][k]      (a = g W1^T)
+    float* w1n = w1s + GP * S1;              // [GP][S1]  B[j][k] = W1[j][k]      (g_b = a_b W1)
+    float* w2b = w1n + GP * S1;              // [FP][S1]  row w2_row(f): W2[f][k] (s_b = W_b W2)
+    float* mus = w2b + FP * S1;
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    float* wsc = b1s + GP;                   // [4 waves][WSZ]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = A.net.G, F = A.net.F;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int k = t / GP, j = t % GP;
+        const bool in = k < G && j < G;
+        w1s[k * S1 + j] = in ? A.net.W1[j * G + k] : 0.f;
+        w1n[k * S1 + j] = in ? A.net.W1[k * G + j] : 0.f;
+    }
+    for (int t = tid; t < FP * GP; t += 256) {
+        const int f = t / GP, k = t % GP;
+        w2b[w2_row(f) * S1 + k] = (f < F && k < G) ? A.net.W2[(size_t)f * G + k] : 0.f;
+    }
+    for (int k = tid; k < GP; k += 256) {
+        const float c = k < G ? A.net.coef[k] : 0.f;
+        mus[k] = k < G ? A.net.mu[k] : 0.f;
+        cfs[k] = c * LOG2E;
+        c2s[k] = 2.f * c;
+        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    float* ws = wsc + wid * WSZ;
+    // persistent per-wave gradient accumulators (THETA)
+    f32x4 gW2[THETA ? FT : 1][THETA ? NT : 1], gW1[THETA ? NT : 1][THETA ? NT : 1];
+    float gb1[NT];
+    if (THETA) {
+#pragma unroll
+        for (int a = 0; a < FT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) gW2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) gW1[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) gb1[c] = 0.f;
+
+    const long long ntiles = (A.E + 63) / 64;                    // 64 edges per workgroup step, 16 per wave
+    const int nb = gridDim.x;
+    const long long per = (ntiles + nb - 1) / nb;
+    const long long t_lo = (long long)xcd_chunk(blockIdx.x, nb) * per, t_hi = min(ntiles, t_lo + per);
+    for (long long tile = t_lo; tile < t_hi; ++tile) {
+        const long long e0 = tile * 64 + wid * 16;
+        // ---- A-layout row: edge e0 + li
+        const long long ea = e0 + li;
+        long long ia = -1, ja = -1;
+        if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
+        const bool va = ia >= 0;                                  // (-1: padding row of a fixed-capacity list)
+        const float da = va ? A.d[ea] : PAD_D;
+        float dda = 0.f;
+        if (DUAL) dda = va ? A.dd[ea] : 0.f;
+        // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
+        float wdb[4 * FT], wb[DUAL ? 4 * FT : 1];
+#pragma unroll
+        for (int q = 0; q < FT; ++q) {
+            const int f0 = 16 * q + 4 * lk;
+            float4 hi = {0.f, 0.f, 0.f, 0.f}, hj = hi, pi = hi, pj = hi;
+            const bool ok = va && f0 + 4 <= F;
+            if (ok) {
+                hi = *reinterpret_cast<const float4*>(A.h + ia * F + f0);
+                hj = *reinterpret_cast<const float4*>(A.h + ja * F + f0);
+                pi = *reinterpret_cast<const float4*>(A.mdb + ia * F + f0);
+                pj = *reinterpret_cast<const float4*>(A.mdb + ja * F + f0);
+            }
+            wdb[4 * q] = pi.x * hj.x + pj.x * hi.x; wdb[4 * q + 1] = pi.y * hj.y + pj.y * hi.y;
+            wdb[4 * q + 2] = pi.z * hj.z + pj.z * hi.z; wdb[4 * q + 3] = pi.w * hj.w + pj.w * hi.w;
+            if (DUAL) {
+                float4 bi = {0.f, 0.f, 0.f, 0.f}, bj = bi;
+                if (ok) {
+                    bi = *reinterpret_cast<const float4*>(A.mb + ia * F + f0);
+                    bj = *reinterpret_cast<const float4*>(A.mb + ja * F + f0);
+                }
+                float4 w = {bi.x * hj.x + bj.x * hi.x, bi.y * hj.y + bj.y * hi.y, bi.z * hj.z + bj.z * hi.z,
+                            bi.w * hj.w + bj.w * hi.w};
+                if (A.hd != nullptr && ok) {
+                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * F + f0);
+                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * F + f0);
+                    w.x += pi.x * tj.x + pj.x * ti.x; w.y += pi.y * tj.y + pj.y * ti.y;
+                    w.z += pi.z * tj.z + pj.z * ti.z; w.w += pi.w * tj.w + pj.w * ti.w;
+                }
+                wb[4 * q] = w.x; wb[4 * q + 1] = w.y; wb[4 * q + 2] = w.z; wb[4 * q + 3] = w.w;
+            }
+        }
+        // ---- recompute layer 1: a = g W1^T + b1 (and its tangent) in the accumulator layout
+        float sg[NT][4], qd[DUAL ? NT : 1][4], sc[THETA ? NT : 1][4], sdc[THETA ? NT : 1][4];
+        {
+            float af[KS], adf[DUAL ? KS : 1];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = ks * 4 + lk;
+                const float x = da - mus[k];
+                const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                af[ks] = g;
+                if (DUAL) adf[ks] = g * (c2s[k] * x) * dda;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const float bfr = w1s[(ks * 4 + lk) * S1 + nt * 16 + li];
+                    acc = MFMA(af[ks], bfr, acc);
+                    if (DUAL) accd = MFMA(adf[ks], bfr, accd);
+                }
+                const float bias = b1s[nt * 16 + li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s, g1;
+                    ssp_sig(acc[r] + bias, s, g1);
+                    sg[nt][r] = g1;
+                    if (DUAL) qd[nt][r] = g1 * (1.f - g1) * accd[r];
+                    if (THETA) { sc[nt][r] = s; sdc[nt][r] = g1 * accd[r]; }
+                }
+            }
+        }
+        // ---- THETA: gW2[f][k] += sum_e Wdb[e][f] sd[e][k] + Wb[e][f] s[e][k]  (contraction over the 16 edges,
+        //      edge = 4 lk + r: B operands are the accumulator-layout registers; A through the LDS tile)
+        if (THETA) {
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int q = 0; q < FT; ++q)
+                    *reinterpret_cast<float4*>(&ws[li * SW + 16 * q + 4 * lk]) =
+                        pass == 0 ? make_float4(wdb[4 * q], wdb[4 * q + 1], wdb[4 * q + 2], wdb[4 * q + 3])
+                                  : make_float4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+#pragma unroll
+                for (int mt = 0; mt < FT; ++mt) {
+                    float at[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) at[r] = ws[(4 * lk + r) * SW + mt * 16 + li];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            gW2[mt][nt] = MFMA(at[r], pass == 0 ? sdc[nt][r] : sc[nt][r], gW2[mt][nt]);
+                }
+            }
+        }
+        // ---- s_db = Wdb W2, s_b = Wb W2   ([16 x F] x [F x G])
+        f32x4 sdb[NT], sb[DUAL ? NT : 1];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4 * FT; ++ks) {
+                const float bfr = w2b[(ks * 4 + lk) * S1 + nt * 16 + li];
+                acc = MFMA(wdb[ks], bfr, acc);
+                if (DUAL) acc2 = MFMA(wb[ks], bfr, acc2);
+            }
+            sdb[nt] = acc;
+            if (DUAL) sb[nt] = acc2;
+        }
+        // ---- through the shifted softplus: a_db = s_db sig(a) ; a_b = s_b sig(a) + s_db sig'(a) a_dot
+        float adb[NT][4], ab[DUAL ? NT : 1][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                adb[nt][r] = sdb[nt][r] * sg[nt][r];
+                if (DUAL) {
+                    ab[nt][r] = sb[nt][r] * sg[nt][r] + sdb[nt][r] * qd[nt][r];
+                    gb1[nt] += ab[nt][r];
+                }
+            }
+        // ---- g_db = a_db W1, g_b = a_b W1: accumulator layout -> A layout through the wave's scratch
+        f32x4 gdb[NT], gb[DUAL ? NT : 1];
+#pragma unroll
+        for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ws[(4 * lk + r) * SA + nt * 16 + li] = pass == 0 ? adb[nt][r] : ab[DUAL ? nt : 0][r];
+            float af[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) af[ks] = ws[li * SA + ks * 4 + lk];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) acc = MFMA(af[ks], w1n[(ks * 4 + lk) * S1 + nt * 16 + li], acc);
+                if (pass == 0) gdb[nt] = acc; else gb[DUAL ? nt : 0] = acc;
+            }
+        }
+        // ---- contract with the Gaussian derivatives in the accumulator layout (rows 4 lk + r, Gaussian nt*16 + li)
+        float s_dd[4] = {0.f, 0.f, 0.f, 0.f}, s_d[4] = {0.f, 0.f, 0.f, 0.f};
+        float gc[THETA ? NT : 1][4], gdc[THETA ? NT : 1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dr = __shfl(da, 4 * lk + r, 64);
+            const float ddr = DUAL ? __shfl(dda, 4 * lk + r, 64) : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int k = nt * 16 + li;
+                const float x = dr - mus[k];
+                const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                const float ph = c2s[k] * x;
+                const float gp = g * ph;
+                s_dd[r] = fmaf(gdb[nt][r], gp, s_dd[r]);
+                if (DUAL) {
+                    s_d[r] = fmaf(gb[nt][r], gp, s_d[r]);
+                    s_d[r] = fmaf(gdb[nt][r] * ddr, g * (ph * ph + c2s[k]), s_d[r]);
+                }
+                if (THETA) { gc[nt][r] = g; gdc[nt][r] = gp * ddr; }
+            }
+        }
+        // ---- THETA: gW1[j][k] += sum_e a_db[e][j] gd[e][k] + a_b[e][j] g[e][k]  (all operands already in the
+        //      accumulator layout: A = the adjoint of a, B = the Gaussians)
+        if (THETA) {
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gW1[mt][nt] = MFMA(adb[mt][r], gdc[nt][r], gW1[mt][nt]);
+                        gW1[mt][nt] = MFMA(ab[mt][r], gc[nt][r], gW1[mt][nt]);
+                    }
+        }
+        // ---- row sums over the 16 Gaussian lanes, then read-add-write of the edge's own entries
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s_dd[r] += __shfl_xor(s_dd[r], o, 64);
+                if (DUAL) s_d[r] += __shfl_xor(s_d[r], o, 64);
+            }
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long e = e0 + 4 * lk + r;
+                if (e < A.E) {
+                    A.dd_b[e] += s_dd[r];
+                    if (DUAL) A.d_b[e] += s_d[r];
+                }
+            }
+        }
+    }
+
+    // ---- THETA: ordered cross-wave reduction through LDS, one partial record per workgroup
+    if (THETA) {
+        constexpr int REC = GP * GP + GP + FP * GP;              // [gW1 | gb1 | gW2], padded sizes
+        __syncthreads();                                         // everyone is done with the weights / scratch
+        float* buf = sm;                                         // REC floats: reuses the weight area (GP*S1*2 + FP*S1 >= REC)
+#pragma unroll
+        for (int v = 0; v < NT; ++v) { gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64); }
+        for (int w = 0; w < 4; ++w) {
+            if (wid == w) {
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = (mt * 16 + 4 * lk + r) * GP + nt * 16 + li;       // gW1[j][k]
+                            buf[idx] = (w ? buf[idx] : 0.f) + gW1[mt][nt][r];
+                        }
+                if (lk == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int idx = GP * GP + nt * 16 + li;
+                        buf[idx] = (w ? buf[idx] : 0.f) + gb1[nt];
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < FT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = GP * GP + GP + (mt * 16 + 4 * lk + r) * GP + nt * 16 + li;   // gW2[f][k]
+                            buf[idx] = (w ? buf[idx] : 0.f) + gW2[mt][nt][r];
+                        }
+            }
+            __syncthreads();
+        }
+        float* out = A.part + (size_t)blockIdx.x * REC;
+        for (int t = tid; t < REC; t += 256) out[t] = buf[t];
+    }
+}
+
+template <int GP, int FT>
+size_t bwd_lds_bytes(bool theta) {
+    constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;
+    constexpr int FP = 16 * FT;
+    const size_t wsz = theta ? 16 * (FP + 4) : 16 * (GP + 2);
+    return sizeof(float) * ((size_t)2 * GP * S1 + (size_t)FP * S1 + 4 * GP + 4 * wsz);
+}
+
+// sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes
+__global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nrec, int GP, int FP, int G, int F,
+                                         float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2) {
+    const int REC = GP * GP + GP + FP * GP;
+    const int t = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    float s = 0.f;
+    if (t < REC)
+        for (int p = sub; p < nrec; p += 4) s += part[(size_t)p * REC + t];
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (t >= REC || sub) return;
+    if (t < GP * GP) {
+        const int j = t / GP, k = t % GP;
+        if (j < G && k < G) gW1[j * G + k] = s;
+    } else if (t < GP * GP + GP) {
+        const int j = t - GP * GP;
+        if (j < G) gb1[j] = s;
+    } else {
+        const int u = t - GP * GP - GP, f = u / GP, k = u % GP;
+        if (f < F && k < G) gW2[(size_t)f * G + k] = s;
+    }
+}
+
+// ============================================================================================ geometry
+// d_e = |x_i - x_j - o_e| (nff/nn/models/schnet.py:142, raw image flags by default), unit vector, and for the
+// tangent sweep dd_e = uhat . (w_i - w_j).  Padding rows (i = -1): |delta| = |o| (= 1e4), tangent 0.
+__global__ void edge_geom_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                 const int64_t* __restrict__ nbr, const float* __restrict__ off, long long E,
+                                 float* __restrict__ d, float* __restrict__ uhat, float* __restrict__ dd,
+                                 float* __restrict__ ddel) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const long long i = nbr[2 * e], j = nbr[2 * e + 1];
+    float dx = -off[3 * e], dy = -off[3 * e + 1], dz = -off[3 * e + 2];
+    float wx = 0.f, wy = 0.f, wz = 0.f;
+    if (i >= 0) {
+        dx += x[3 * i] - x[3 * j]; dy += x[3 * i + 1] - x[3 * j + 1]; dz += x[3 * i + 2] - x[3 * j + 2];
+        if (w) { wx = w[3 * i] - w[3 * j]; wy = w[3 * i + 1] - w[3 * j + 1]; wz = w[3 * i + 2] - w[3 * j + 2]; }
+    }
+    const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float ir = 1.0f / r;
+    const float ux = dx * ir, uy = dy * ir, uz = dz * ir;
+    d[e] = r;
+    uhat[3 * e] = ux; uhat[3 * e + 1] = uy; uhat[3 * e + 2] = uz;
+    if (w) {
+        dd[e] = ux * wx + uy * wy + uz * wz;
+        ddel[3 * e] = wx; ddel[3 * e + 1] = wy; ddel[3 * e + 2] = wz;
+    }
+}
+
+// F_n = -sum_slots sgn dU/dd uhat ;  (d(w.F)/dx)_n = -sum_slots sgn [ d_b uhat + dd_b / d (ddel - dd uhat) ]
+// (sgn = +1 when n is the first atom of the edge).  16 lanes per atom, fixed combine order.
+__global__ void edge_geom_bwd_kernel(const float* __restrict__ d_b, const float* __restrict__ dd_b,
+                                     const float* __restrict__ d, const float* __restrict__ dd,
+                                     const float* __restrict__ uhat, const float* __restrict__ ddel,
+                                     const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+                                     const int32_t* __restrict__ cnt, int N, int max_nbr, float* __restrict__ force,
+                                     float* __restrict__ dwf) {
+    const int n = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    if (n < N) {
+        const int m = cnt[n];
+        const size_t row = (size_t)n * max_nbr;
+        for (int k = sub; k < m; k += 16) {
+            const int e = eid[row + k];
+            const float sgn = col[row + k] > n ? 1.f : -1.f;
+            const float ux = uhat[3 * e], uy = uhat[3 * e + 1], uz = uhat[3 * e + 2];
+            const float a = sgn * dd_b[e];
+            fx -= a * ux; fy -= a * uy; fz -= a * uz;
+            if (d_b) {
+                const float b = sgn * d_b[e], c = a / d[e], t = dd[e];
+                gx -= b * ux + c * (ddel[3 * e] - t * ux);
+                gy -= b * uy + c * (ddel[3 * e + 1] - t * uy);
+                gz -= b * uz + c * (ddel[3 * e + 2] - t * uz);
+            }
+        }
+    }
+    fx = group_sum<16>(fx); fy = group_sum<16>(fy); fz = group_sum<16>(fz);
+    if (d_b) { gx = group_sum<16>(gx); gy = group_sum<16>(gy); gz = group_sum<16>(gz); }
+    if (n < N && sub == 0) {
+        force[3 * n] = fx; force[3 * n + 1] = fy; force[3 * n + 2] = fz;
+        if (d_b) { dwf[3 * n] = gx; dwf[3 * n + 1] = gy; dwf[3 * n + 2] = gz; }
+    }
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int shape_ok(const MdgFilterNet* net, int& GP, int& FT) {
+    MDG_CHECK_ARG(net && net->mu && net->coef && net->W1 && net->b1 && net->W2 && net->b2, "cfconv: null filter weights");
+    const int G = net->n_gauss, F = net->n_filters;
+    MDG_CHECK_ARG(G >= 1 && G <= 64, "cfconv: 1 <= n_gaussians <= 64 (got %d)", G);
+    MDG_CHECK_ARG(F >= 4 && F <= 128 && F % (F <= 64 ? 4 : 8) == 0,
+                  "cfconv: n_filters must be a multiple of 4 up to 64 or of 8 up to 128 (got %d)", F);
+    GP = G <= 32 ? 32 : 64;
+    FT = F <= 64 ? 4 : 8;
+    return MDG_OK;
+}
+
+FilterDev dev_of(const MdgFilterNet* net) {
+    return FilterDev{net->mu, net->coef, net->W1, net->b1, net->W2, net->b2, net->n_gauss, net->n_filters};
+}
+
+int bwd_blocks(long long n_edges, bool theta) {
+    const long long tiles = (n_edges + 63) / 64;
+    const long long want = theta ? 512 : 768;
+    return (int)(tiles < want ? (tiles > 0 ? tiles : 1) : want);
+}
+
+}  // namespace
+
+extern "C" int mdg_cfconv_supported(int n_gauss, int n_filters) {
+    return n_gauss >= 1 && n_gauss <= 64 && n_filters >= 4 && n_filters <= 128 &&
+           n_filters % (n_filters <= 64 ? 4 : 8) == 0;
+}
+
+extern "C" int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                             float* d, float* uhat, float* dd, float* ddel, void* stream) {
+    MDG_CHECK_ARG(n_edges >= 0, "edge_geom: bad size");
+    if (n_edges == 0) return MDG_OK;
+    MDG_CHECK_ARG(x && nbr && offsets && d && uhat && (!w || (dd && ddel)), "edge_geom: null buffer");
+    hipLaunchKernelGGL(edge_geom_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       nbr, offsets, (long long)n_edges, d, uhat, dd, ddel);
+    MDG_CHECK_LAUNCH("edge_geom_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_edge_geom_bwd(const float* d_b, const float* dd_b, const float* d, const float* dd, const float* uhat,
+                                 const float* ddel, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                                 int n_atoms, int max_nbr, float* force, float* dwf, void* stream) {
+    MDG_CHECK_ARG(dd_b && uhat && col && eid && cnt && force && n_atoms > 0, "edge_geom_bwd: bad arguments");
+    MDG_CHECK_ARG(!d_b || (d && dd && ddel && dwf), "edge_geom_bwd: the second-order output needs d, dd, ddel");
+    hipLaunchKernelGGL(edge_geom_bwd_kernel, dim3((n_atoms * 16 + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_b, dd_b,
+                       d, dd, uhat, ddel, col, eid, cnt, n_atoms, max_nbr, force, dwf);
+    MDG_CHECK_LAUNCH("edge_geom_bwd_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const float* dd, const float* h, const float* hd,
+                              const int32_t* col, const int32_t* eid, const int32_t* cnt, int n_atoms, int max_nbr,
+                              float* m, float* md, float* hsum, float* hdsum, void* stream) {
+    int GP, FT;
+    int rc = shape_ok(net, GP, FT);
+    if (rc) return rc;
+    MDG_CHECK_ARG(d && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd: bad arguments");
+    const bool tangent = dd != nullptr;
+    MDG_CHECK_ARG(!tangent || md, "cfconv_fwd: the tangent sweep needs md");
+    MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd: tangent buffers without dd");
+    MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
+                  "cfconv_fwd: node feature matrices must be 16-byte aligned");
+    FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
+    const int want = 768;
+    const int nb = (n_atoms + 3) / 4 < want ? (n_atoms + 3) / 4 : want;
+    hipStream_t st = (hipStream_t)stream;
+#define MDG_FWD(GP_, FT_)                                                                                          \
+    do {                                                                                                           \
+        if (tangent)                                                                                               \
+            hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, true>), dim3(nb), dim3(256), (fwd_lds_bytes<GP_, FT_>(true)), st, a); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, false>), dim3(nb), dim3(256), (fwd_lds_bytes<GP_, FT_>(false)), st, a); \
+    } while (0)
+    if (GP == 32 && FT == 4) MDG_FWD(32, 4);
+    else if (GP == 32) MDG_FWD(32, 8);
+    else if (FT == 4) MDG_FWD(64, 4);
+    else MDG_FWD(64, 8);
+#undef MDG_FWD
+    MDG_CHECK_LAUNCH("cfconv_fwd_kernel");
+    return MDG_OK;
+}
+
+extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges) {
+    if (!mdg_cfconv_supported(n_gauss, n_filters) || n_edges <= 0) return 0;
+    const int GP = n_gauss <= 32 ? 32 : 64, FP = n_filters <= 64 ? 64 : 128;
+    return (int64_t)bwd_blocks(n_edges, true) * (GP * GP + GP + FP * GP);
+}
+
+extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                              int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                              float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                              void* stream) {
+    int GP, FT;
+    int rc = shape_ok(net, GP, FT);
+    if (rc) return rc;
+    MDG_CHECK_ARG(n_edges >= 0, "cfconv_bwd: bad size");
+    const bool dual = mb != nullptr, theta = gW1 != nullptr;
+    MDG_CHECK_ARG(!theta || (dual && gb1 && gW2), "cfconv_bwd: parameter gradients come from the dual sweep");
+    hipStream_t st = (hipStream_t)stream;
+    if (n_edges == 0) {
+        if (theta) {
+            const int G = net->n_gauss, F = net->n_filters;
+            MDG_HIP(hipMemsetAsync(gW1, 0, sizeof(float) * G * G, st));
+            MDG_HIP(hipMemsetAsync(gb1, 0, sizeof(float) * G, st));
+            MDG_HIP(hipMemsetAsync(gW2, 0, sizeof(float) * F * G, st));
+        }
+        return MDG_OK;
+    }
+    MDG_CHECK_ARG(d && nbr && h && mdb && dd_b, "cfconv_bwd: null buffer");
+    MDG_CHECK_ARG(!dual || (dd && d_b), "cfconv_bwd: the dual sweep needs dd and d_b");
+    MDG_CHECK_ARG(dual || !hd, "cfconv_bwd: hd without the dual sweep");
+    MDG_CHECK_ARG(!theta || workspace, "cfconv_bwd: workspace missing");
+    MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb),
+                  "cfconv_bwd: node feature matrices must be 16-byte aligned");
+    BwdArgs a{dev_of(net), d, dd, nbr, (long long)n_edges, h, hd, mb, mdb, d_b, dd_b, workspace};
+    const int nb = bwd_blocks(n_edges, theta);
+#define MDG_BWD(GP_, FT_)                                                                                          \
+    do {                                                                                                           \
+        if (theta)                                                                                                 \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, true>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(true)), st, a); \
+        else if (dual)                                                                                             \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, false>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(false)), st, a); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, false, false>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(false)), st, a); \
+    } while (0)
+    if (GP == 32 && FT == 4) MDG_BWD(32, 4);
+    else if (GP == 32) MDG_BWD(32, 8);
+    else if (FT == 4) MDG_BWD(64, 4);
+    else MDG_BWD(64, 8);
+#undef MDG_BWD
+    MDG_CHECK_LAUNCH("cfconv_bwd_kernel");
+    if (theta) {
+        const int FP = 16 * FT, REC = GP * GP + GP + FP * GP;
+        hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC * 4 + 255) / 256), dim3(256), 0, st, workspace, nb, GP, FP,
+                           net->n_gauss, net->n_filters, gW1, gb1, gW2);
+        MDG_CHECK_LAUNCH("cfconv_bwd_reduce_kernel");
+    }
+    return MDG_OK;
+}

@@ -5,10 +5,20 @@ vector w (= lambda_v / m), the vjps d(w.F)/dx and d(w.F)/dtheta.  PyTorch gets t
 differentiating the energy twice (reverse-over-reverse through ~500 small ops).  Here the same
 quantities come from ONE primal forward, ONE forward-mode (tangent) sweep along x_dot = w -- which
 gives U_dot = dU/dx . w = -(w.F) -- and ONE reverse sweep of U_dot, all written out explicitly on
-top of the graph kernels (csrc/graph.hip), the split-K A^T B kernel and library GEMMs:
+top of the HIP kernels:
 
     force(...)      primal forward + reverse of U                      (E1)
-    force_vjp(...)  primal + tangent forward, reverse of U, reverse of U_dot      (E2)
+    force_vjp(...)  primal + tangent forward, reverse of U_dot          (E2)
+
+The reverse sweep of U_dot already contains the reverse sweep of U: U_dot is linear in the tangents with the
+partial derivatives of U as coefficients, so the adjoint of every tangent quantity IS the reverse-mode adjoint
+of its primal (rdb = dU/dr, mdb = dU/dm, ..., dd_b = dU/dd) and the force -dU/dx falls out of the same sweep.
+
+Edge level (everything of size [E, .]): the fused interaction-block kernels of csrc/cfconv_fused.hip -- filter
+network on the MFMA, gather-multiply-sum per atom, and the adjoints with the filter recomputed -- so no
+[E,G] / [E,F] tensor exists.  Node level ([N, .]): GEMMs + small fused elementwise kernels.  Shapes the fused
+kernels do not take (n_filters > 128, n_gaussians > 64) run the unfused chain (`_force_vjp_unfused`): graph
+kernels of csrc/graph.hip, the split-K A^T B kernel and library GEMMs.
 
 Notation follows SURVEY A.9 / nff/nn/models/schnet.py:113-171 (reference parameter names in
 brackets): per layer  g = smear(d) -> a = W1 g + b1 [edge_filter.1] -> s = ssp(a) -> Wf = W2 s + b2
@@ -159,8 +169,159 @@ class _blas_for:
         return False
 
 
+def fused_ok(net):
+    """The fused interaction-block kernels take every layer of this network (and are not switched off)."""
+    if getattr(net, "fused_block", True) is False:
+        return False
+    for conv in net.convolutions:
+        seq = conv.moduledict["message_edge_filter"]
+        if not ops.FilterNet.supported(seq[0].offsets.shape[0], seq[3].weight.shape[0]):
+            return False
+    return True
+
+
+class _node_blas:
+    """Node-level GEMMs ([N, A..F] operands) go through rocBLAS: its launch costs ~7 us against hipBLASLt's
+    ~19 us, and the shapes are small (see _blas_for)."""
+
+    def __enter__(self):
+        self.prev = None
+        if torch.cuda.is_available():
+            try:
+                self.prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library("hipblas")
+            except Exception:
+                self.prev = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.backends.cuda.preferred_blas_library(self.prev)
+        return False
+
+
+@torch.no_grad()
+def _forward_fused(net, z, x, topo, w=None, want_sums=False):
+    """Primal (and, with w, forward-mode tangent along x_dot = w) sweep on the fused kernels."""
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    r, rd = net.atom_embed.weight[z], None                        # r_dot^0 = 0
+    layers = []
+    for conv in net.convolutions:
+        P = _layer_params(conv)
+        fn = ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"])
+        h = _addmm(P["bn"], r, P["Wn"].t())
+        hd = rd.mm(P["Wn"].t()) if rd is not None else None
+        m, md, hsum, hdsum = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums)
+        u = _addmm(P["c1"], m, P["U1"].t())
+        t, su = ops.ssp(u, True)
+        L = dict(P=P, fn=fn, r=r, rd=rd, h=h, hd=hd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=t, su=su)
+        if w is not None:
+            ud = md.mm(P["U1"].t())
+            td = ops.mul_row(su, ud)
+            L.update(ud=ud, td=td)
+            rd = td.mm(P["U2"].t()) if rd is None else rd + td.mm(P["U2"].t())
+        layers.append(L)
+        r = r + _addmm(P["c2"], t, P["U2"].t())
+    ro = net.atomwisereadout.readout["energy"]
+    L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
+    y = _addmm(l1, r, L1.t())
+    U = (_ssp(y).mm(L2.t()) + l2).sum()
+    return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, y=y, L1=L1, L2=L2, U=U)
+
+
+@torch.no_grad()
+def _force_fused(net, z, x, topo):
+    fw = _forward_fused(net, z, x, topo)
+    d = fw["d"]
+    rb = (torch.sigmoid(fw["y"]) * fw["L2"]).mm(fw["L1"])
+    dU_dd = torch.zeros_like(d)
+    for idx in range(len(fw["layers"]) - 1, -1, -1):
+        L = fw["layers"][idx]
+        P = L["P"]
+        mb = ops.mul_row(L["su"], rb.mm(P["U2"])).mm(P["U1"])
+        ops.cfconv_bwd(L["fn"], d, None, topo, L["h"], None, None, mb, None, dU_dd)
+        if idx > 0:                                               # (the embedding below layer 0 is not needed)
+            hb = ops.cfconv_fwd(L["fn"], d, None, mb, None, topo)[0]
+            rb = rb + hb.mm(P["Wn"])
+    F, _ = ops.edge_geom_bwd(None, dU_dd, None, None, fw["uhat"], None, topo)
+    return fw["U"], F
+
+
+@torch.no_grad()
+def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
+    fw = _forward_fused(net, z, x, topo, w, want_sums=want_theta)
+    d, dd = fw["d"], fw["dd"]
+    L1, L2, y, rd = fw["L1"], fw["L2"], fw["y"], fw["rd"]
+    yd = rd.mm(L1.t())
+    sy = torch.sigmoid(y)
+    # ---------------- reverse sweep of U_dot = sum_i L2 . (sig(y_i) * yd_i)
+    ydb = sy * L2
+    yb = sy * (1 - sy) * yd * L2
+    grads = {}
+    ro = net.atomwisereadout.readout["energy"]
+    if want_theta:
+        grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
+        grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
+        grads[id(ro[0].weight)] = yb.t().mm(fw["r"]) + ydb.t().mm(rd)
+        grads[id(ro[0].bias)] = yb.sum(0)
+    rdb, rb = ydb.mm(L1), yb.mm(L1)
+    d_b, dd_b = torch.zeros_like(d), torch.zeros_like(d)
+    convs = list(net.convolutions)
+    for idx in range(len(convs) - 1, -1, -1):
+        L, md_ = fw["layers"][idx], convs[idx].moduledict
+        P = L["P"]
+        tb, tdb = rb.mm(P["U2"]), rdb.mm(P["U2"])
+        if want_theta:
+            grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
+            grads[id(md_["update_function"][2].bias)] = rb.sum(0)
+        udb, ub = ops.ssp_dual_bwd(L["su"], L["ud"], tdb, tb)
+        mdb, mb = udb.mm(P["U1"]), ub.mm(P["U1"])
+        if want_theta:
+            grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
+            grads[id(md_["update_function"][0].bias)] = ub.sum(0)
+        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta)
+        if want_theta:
+            gb2 = (mb * L["hsum"]).sum(0)                        # sum_e W_b[e] = sum_n mb_n (.) sum_{j in nbr(n)} h_j
+            if L["hdsum"] is not None:
+                gb2 = gb2 + (mdb * L["hdsum"]).sum(0)
+            grads[id(md_["message_edge_filter"][1].weight)] = th[0]
+            grads[id(md_["message_edge_filter"][1].bias)] = th[1]
+            grads[id(md_["message_edge_filter"][3].weight)] = th[2]
+            grads[id(md_["message_edge_filter"][3].bias)] = gb2
+        if want_theta or idx > 0:
+            # the aggregation is symmetric in the adjacency: fed (mdb, mb) the forward kernel returns the
+            # adjoints (hdb, hb) of (hd, h)
+            hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
+            if want_theta:
+                gWn = hb.t().mm(L["r"])
+                if L["rd"] is not None:
+                    gWn = gWn + hdb.t().mm(L["rd"])
+                grads[id(md_["message_node_filter"].weight)] = gWn
+                grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
+            rdb = rdb + hdb.mm(P["Wn"])
+            rb = rb + hb.mm(P["Wn"])
+    # dd_b = dU/dd (see the module docstring): force and d(w.F)/dx from one scatter
+    F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
+    if not want_theta:
+        return fw["U"], F, dwf, None
+    uniq, onehot = _species_onehot(z)
+    emb = torch.zeros_like(net.atom_embed.weight)
+    emb[uniq] = _atb(onehot, rb)
+    grads[id(net.atom_embed.weight)] = emb
+    plist = list(net.parameters())
+    flat = torch.cat([grads[id(p)].reshape(-1) for p in plist]).neg_()          # w.F = -U_dot
+    out, pos = [], 0
+    for p in plist:
+        out.append(flat[pos:pos + p.numel()].reshape(p.shape))
+        pos += p.numel()
+    return fw["U"], F, dwf, out
+
+
 @torch.no_grad()
 def force(net, z, x, topo, offsets=None):
+    if fused_ok(net):
+        with _node_blas():
+            return _force_fused(net, z, x.detach().contiguous(), topo)
     topo = _stable(topo)
     with _blas_for(topo):
         fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
@@ -172,15 +333,17 @@ def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True):
     """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()]); the parameter part is skipped
     (None) when want_theta is False.  (`offsets` is the topology's own image-flag array; the argument is
     kept for callers that pass it explicitly.)"""
+    if fused_ok(net):
+        with _node_blas():
+            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta)
     topo = _stable(topo)
     with _blas_for(topo):
-        return _force_vjp(net, z, x, w, topo, topo.offsets, want_theta)
+        return _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)
 
 
-def _force_vjp(net, z, x, w, topo, offsets, want_theta=True):
+def _force_vjp_unfused(net, z, x, w, topo, offsets, want_theta=True):
     x, w = x.detach().contiguous(), w.detach().contiguous()
     fw = _primal(net, z, x, topo, offsets)
-    F = _reverse_U(fw, topo)
     d, uhat = fw["d"], fw["uhat"]
     # ---------------- tangent sweep along x_dot = w
     ddel = ops._edge_diff(w, topo)
@@ -271,9 +434,10 @@ def _force_vjp(net, z, x, w, topo, offsets, want_theta=True):
             grads[id(md_["message_edge_filter"][3].bias)] = Wfb.sum(0)
             grads[id(md_["message_edge_filter"][1].bias)] = ab.sum(0)
         ops.smear_bwd(gdb, gb, L["g"], L["phi"], dd, P["c"], d_b, dd_b)
-    # geometry: dd = uhat . ddel, d = |delta|
+    # geometry: dd = uhat . ddel, d = |delta|;  dd_b = dU/dd (module docstring), so the force comes from this sweep too
     delta_b = d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)
     xb = ops._edge_scatter(delta_b, topo)
+    F = -ops._edge_scatter(dd_b[:, None] * uhat, topo)
     if not want_theta:
         return fw["U"], F, -xb, None
     # embedding rows: one-hot(z)^T rb as a GEMM (no float atomics: index_add_ on a handful of species

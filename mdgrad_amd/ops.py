@@ -749,6 +749,90 @@ class CfconvFilterFn(torch.autograd.Function):
         return gd, gmu, gwidth, gW1, gb1, gW2, gb2, None
 
 
+# ----------------------------------------------------------------------------- fused interaction block
+class FilterNet:
+    """Device-side description of one SchNetConv filter network for the fused kernels (csrc/cfconv_fused.hip):
+    Gaussian centres / coefficients and the two Dense layers, as contiguous fp32 tensors kept alive here."""
+
+    def __init__(self, mu, coef, W1, b1, W2, b2):
+        self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
+        self.G, self.F = int(self.t[0].shape[0]), int(self.t[4].shape[0])
+        s = _lib.MdgFilterNet()
+        s.mu, s.coef, s.W1, s.b1, s.W2, s.b2 = (x.data_ptr() for x in self.t)
+        s.n_gauss, s.n_filters = self.G, self.F
+        self.struct = s
+
+    @staticmethod
+    def supported(n_gauss, n_filters):
+        return bool(_lib.load().mdg_cfconv_supported(int(n_gauss), int(n_filters)))
+
+
+def edge_geom(x, topo, w=None):
+    """(d, uhat[, dd, ddel]) per edge of the half list: nff/nn/models/schnet.py:142 and its tangent along w."""
+    lib = _lib.load()
+    require_gpu(x, "x")
+    x = x.contiguous()
+    E, dev = topo.n_edges, x.device
+    d, uhat = torch.empty(E, device=dev), torch.empty(E, 3, device=dev)
+    dd = ddel = None
+    if w is not None:
+        w = w.contiguous()
+        dd, ddel = torch.empty(E, device=dev), torch.empty(E, 3, device=dev)
+    check(lib.mdg_edge_geom(ptr(x), ptr(w), ptr(topo.nbr), ptr(topo.offsets), E, ptr(d), ptr(uhat), ptr(dd), ptr(ddel),
+                            stream_ptr(dev)), "mdg_edge_geom")
+    return d, uhat, dd, ddel
+
+
+def edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, topo):
+    """(F, d(w.F)/dx) per atom from the per-edge adjoints (d_b None: force only)."""
+    lib = _lib.load()
+    e = topo.ell
+    dev = dd_b.device
+    force = torch.empty(topo.n_atoms, 3, device=dev)
+    dwf = torch.empty(topo.n_atoms, 3, device=dev) if d_b is not None else None
+    check(lib.mdg_edge_geom_bwd(ptr(d_b), ptr(dd_b), ptr(d), ptr(dd), ptr(uhat), ptr(ddel), ptr(e.col), ptr(topo.eid),
+                                ptr(e.cnt), topo.n_atoms, e.max_nbr, ptr(force), ptr(dwf), stream_ptr(dev)),
+          "mdg_edge_geom_bwd")
+    return force, dwf
+
+
+def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
+    """(m, md, hsum, hdsum): filter generation + gather-multiply + per-atom sum in one kernel; with dd the
+    forward-mode tangent rides along (hd may be None: no node tangent yet)."""
+    lib = _lib.load()
+    require_gpu(h, "h")
+    h = h.contiguous()
+    hd = hd.contiguous() if hd is not None else None
+    e = topo.ell
+    N, dev = topo.n_atoms, h.device
+    m = torch.empty(N, fnet.F, device=dev)
+    md = torch.empty(N, fnet.F, device=dev) if dd is not None else None
+    hsum = torch.empty(N, fnet.F, device=dev) if want_sums else None
+    hdsum = torch.empty(N, fnet.F, device=dev) if (want_sums and hd is not None) else None
+    check(lib.mdg_cfconv_fwd(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(h), ptr(hd), ptr(e.col), ptr(topo.eid), ptr(e.cnt),
+                             N, e.max_nbr, ptr(m), ptr(md), ptr(hsum), ptr(hdsum), stream_ptr(dev)), "mdg_cfconv_fwd")
+    return m, md, hsum, hdsum
+
+
+def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
+    """Adjoint of the filter network (see include/mdgrad_hip.h): accumulates into d_b / dd_b in place and returns
+    (gW1, gb1, gW2) when want_theta."""
+    lib = _lib.load()
+    dev = h.device
+    h, mdb = h.contiguous(), mdb.contiguous()
+    hd = hd.contiguous() if hd is not None else None
+    mb = mb.contiguous() if mb is not None else None
+    gW1 = gb1 = gW2 = ws = None
+    if want_theta:
+        gW1, gb1 = torch.empty(fnet.G, fnet.G, device=dev), torch.empty(fnet.G, device=dev)
+        gW2 = torch.empty(fnet.F, fnet.G, device=dev)
+        ws = torch.empty(max(1, int(lib.mdg_cfconv_bwd_workspace(fnet.G, fnet.F, topo.n_edges))), device=dev)
+    check(lib.mdg_cfconv_bwd(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
+                             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws), stream_ptr(dev)),
+          "mdg_cfconv_bwd")
+    return (gW1, gb1, gW2) if want_theta else None
+
+
 # ----------------------------------------------------------------------------- fused elementwise pieces
 def smear(d, mu, c):
     lib = _lib.load()

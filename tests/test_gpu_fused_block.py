@@ -1,0 +1,186 @@
+"""The fused SchNet interaction-block kernels (csrc/cfconv_fused.hip) against plain torch formulas of the same
+maps (nff/nn/modules.py:531-541,564-571, nff/nn/graphconv.py:43-53 and their derivatives by torch autograd), one
+kernel at a time so that a failure names the sweep, and the fused analytic path against the unfused one.
+fp32 tolerances: 2e-4 relative + 2e-5 of the largest entry (MFMA f32 = k-ordered fma chains; exp2/log2 hardware
+transcendentals, abs. error ~1e-7)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_parity import T, close, mk_system, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(G, F, seed, n_side=6, cutoff=5.0):
+    from mdgrad_amd import ops, _lib
+    rng = np.random.default_rng(seed)
+    L = 2.9 * n_side
+    g = np.stack(np.meshgrid(*[np.arange(n_side)] * 3, indexing="ij"), -1).reshape(-1, 3) * (L / n_side)
+    pos = np.mod(g + rng.normal(0, 0.35, g.shape), L).astype(np.float32)
+    x = T(pos, DEV)
+    ell = ops.build_ell(x, _lib.make_cell(np.array([L, L, L], dtype=np.float32)), cutoff)
+    topo = ops.GraphTopo(ell)
+    torch.manual_seed(seed)
+    mu = torch.linspace(0, cutoff, G, device=DEV)
+    coef = torch.full((G,), -0.5 / float(mu[1] - mu[0]) ** 2, device=DEV)
+    W1 = torch.randn(G, G, device=DEV) / G ** 0.5
+    b1 = torch.randn(G, device=DEV) * 0.1
+    W2 = torch.randn(F, G, device=DEV) / G ** 0.5
+    b2 = torch.randn(F, device=DEV) * 0.1
+    return x, topo, (mu, coef, W1, b1, W2, b2)
+
+
+def _filter(d, mu, coef, W1, b1, W2, b2):
+    g = torch.exp(coef * (d[:, None] - mu).pow(2))
+    s = torch.nn.functional.softplus(torch.nn.functional.linear(g, W1, b1)) - np.log(2.0)
+    return torch.nn.functional.linear(s, W2, b2)
+
+
+def _agg(h, W, topo):
+    i, j = topo.nbr[:, 0], topo.nbr[:, 1]
+    return torch.zeros_like(h).index_add(0, j, h[i] * W).index_add(0, i, h[j] * W)
+
+
+def _close(a, b, what):
+    close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-7, what)
+
+
+@pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (32, 64, 6), (41, 128, 6), (64, 32, 6), (12, 8, 6),
+                                        (30, 128, 16)])
+def test_fused_forward_kernel_primal_and_tangent(G, F, n_side):
+    from mdgrad_amd import ops
+    x, topo, net = _setup(G, F, seed=G + F, n_side=n_side)
+    N = topo.n_atoms
+    w = torch.randn(N, 3, device=DEV)
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    i, j = topo.nbr[:, 0], topo.nbr[:, 1]
+    delta = x[i] - x[j] - topo.offsets
+    close(d, delta.norm(dim=1), 1e-6, 1e-6, "d")
+    close(uhat, delta / delta.norm(dim=1)[:, None], 1e-6, 1e-6, "uhat")
+    close(ddel, w[i] - w[j], 0, 1e-6, "ddel")
+    close(dd, ((w[i] - w[j]) * delta).sum(1) / delta.norm(dim=1), 1e-5, 1e-5, "dd")
+    fn = ops.FilterNet(*net)
+    h, hd = torch.randn(N, F, device=DEV), torch.randn(N, F, device=DEV)
+    Wf, Wfd = torch.autograd.functional.jvp(lambda dv: _filter(dv, *net), d, dd)
+    m, md, hsum, hdsum = ops.cfconv_fwd(fn, d, None, h, None, topo, want_sums=True)
+    assert md is None and hdsum is None
+    _close(m, _agg(h, Wf, topo), "m (primal)")
+    _close(hsum, _agg(h, torch.ones_like(Wf), topo), "hsum")
+    m2, md2, hs2, hds2 = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums=True)
+    assert torch.equal(m2, m), "the tangent variant computes the same primal bits"
+    _close(md2, _agg(h, Wfd, topo) + _agg(hd, Wf, topo), "md (tangent)")
+    _close(hds2, _agg(hd, torch.ones_like(Wf), topo), "hdsum")
+    m3, md3, _, _ = ops.cfconv_fwd(fn, d, dd, h, None, topo)
+    _close(md3, _agg(h, Wfd, topo), "md (tangent, no node tangent)")
+    assert torch.equal(ops.cfconv_fwd(fn, d, dd, h, hd, topo)[1], md2), "bitwise reproducible"
+
+
+@pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (32, 64, 6), (41, 128, 6), (64, 32, 6), (12, 8, 6),
+                                        (30, 128, 16)])
+def test_fused_backward_kernel_plain_dual_and_theta(G, F, n_side):
+    from mdgrad_amd import ops
+    x, topo, net = _setup(G, F, seed=3 * G + F, n_side=n_side)
+    N, E = topo.n_atoms, topo.n_edges
+    w = torch.randn(N, 3, device=DEV)
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    fn = ops.FilterNet(*net)
+    h, hd, mb, mdb = [torch.randn(N, F, device=DEV) for _ in range(4)]
+    i, j = topo.nbr[:, 0], topo.nbr[:, 1]
+    Wdb = mdb[i] * h[j] + mdb[j] * h[i]
+    mu, coef, W1, b1, W2, b2 = net
+    for with_hd in (True, False):
+        Wb = mb[i] * h[j] + mb[j] * h[i]
+        if with_hd:
+            Wb = Wb + mdb[i] * hd[j] + mdb[j] * hd[i]
+        leaves = [t.clone().requires_grad_(True) for t in (d, dd, W1, b1, W2)]
+
+        def S(dv, ddv, w1, bb1, w2):
+            Wf, Wfd = torch.autograd.functional.jvp(lambda z: _filter(z, mu, coef, w1, bb1, w2, b2), dv, ddv,
+                                                    create_graph=True)
+            return (Wdb * Wfd).sum() + (Wb * Wf).sum()
+
+        ref = torch.autograd.grad(S(*leaves), leaves)
+        d_b, dd_b = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        th = ops.cfconv_bwd(fn, d, dd, topo, h, hd if with_hd else None, mb, mdb, d_b, dd_b, want_theta=True)
+        _close(dd_b, ref[1], "dd_b (dual, hd=%s)" % with_hd)
+        _close(d_b, ref[0], "d_b (dual, hd=%s)" % with_hd)
+        _close(th[0], ref[2], "gW1")
+        _close(th[1], ref[3], "gb1")
+        _close(th[2], ref[4], "gW2")
+        d_b2, dd_b2 = torch.ones(E, device=DEV), torch.ones(E, device=DEV)        # accumulate onto existing values
+        assert ops.cfconv_bwd(fn, d, dd, topo, h, hd if with_hd else None, mb, mdb, d_b2, dd_b2) is None
+        _close(d_b2 - 1, ref[0], "d_b (dual, no theta)")
+        _close(dd_b2 - 1, ref[1], "dd_b (dual, no theta)")
+    # plain reverse sweep: dU/dd with mdb in the role of dU/dm
+    dleaf = d.clone().requires_grad_(True)
+    (ref_d,) = torch.autograd.grad((Wdb * _filter(dleaf, *net)).sum(), dleaf)
+    out = torch.zeros(E, device=DEV)
+    ops.cfconv_bwd(fn, d, None, topo, h, None, None, mdb, None, out)
+    _close(out, ref_d, "dU/dd (plain reverse)")
+    # geometry backward
+    d_b, dd_b = torch.randn(E, device=DEV), torch.randn(E, device=DEV)
+    F_, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, topo)
+    sc = lambda g: torch.zeros(N, 3, device=DEV).index_add(0, i, g).index_add(0, j, -g)
+    _close(F_, -sc(dd_b[:, None] * uhat), "force scatter")
+    _close(dwf, -sc(d_b[:, None] * uhat + (dd_b / d)[:, None] * (ddel - dd[:, None] * uhat)), "d(w.F)/dx scatter")
+    F2, none = ops.edge_geom_bwd(None, dd_b, None, None, uhat, None, topo)
+    assert none is None and torch.equal(F2, F_)
+
+
+def test_fused_kernels_on_a_padded_fixed_capacity_topology():
+    """StaticTopo (HIP-graph capture): padding rows (-1, -1) are inert in the edge-centric kernel."""
+    from mdgrad_amd import ops
+    G, F = 30, 128
+    x, topo, net = _setup(G, F, seed=5)
+    need = torch.zeros(2, dtype=torch.int32, device=DEV)
+    st = ops.StaticTopo(topo.ell, topo.n_edges + 777, need)
+    assert st.n_edges == topo.n_edges + 777
+    N = topo.n_atoms
+    w = torch.randn(N, 3, device=DEV)
+    fn = ops.FilterNet(*net)
+    h, hd, mb, mdb = [torch.randn(N, F, device=DEV) for _ in range(4)]
+    outs = []
+    for tp in (topo, st):
+        d, uhat, dd, ddel = ops.edge_geom(x, tp, w)
+        m = ops.cfconv_fwd(fn, d, dd, h, hd, tp)
+        d_b, dd_b = torch.zeros(tp.n_edges, device=DEV), torch.zeros(tp.n_edges, device=DEV)
+        th = ops.cfconv_bwd(fn, d, dd, tp, h, hd, mb, mdb, d_b, dd_b, want_theta=True)
+        F_, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, tp)
+        outs.append([m[0], m[1], d_b[:topo.n_edges], dd_b[:topo.n_edges], F_, dwf] + list(th))
+        if tp is st:
+            assert float(d_b[topo.n_edges:].abs().max()) == 0.0 and float(dd_b[topo.n_edges:].abs().max()) == 0.0
+    for k, (a, b) in enumerate(zip(*outs)):
+        if k < 6:
+            assert torch.equal(a, b), "padded topology output %d" % k
+        else:                                    # partial sums are grouped by tile, so the split over workgroups differs
+            _close(b, a, "padded topology theta %d" % k)
+
+
+@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide"])
+def test_fused_analytic_path_equals_unfused(name):
+    from mdgrad_amd.interface import GNNPotentials
+    from mdgrad_amd.nn import get_model, analytic
+    from test_gpu_schnet import params_of, sd_of
+    g = load_golden(name)
+    system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    q = T(g["pos"], DEV)
+    gnn._reset_topology(q)
+    assert analytic.fused_ok(net)
+    rng = np.random.default_rng(1)
+    w = T(rng.normal(0, 1, g["pos"].shape).astype(np.float32), DEV)
+    res = []
+    for fused in (True, False):
+        net.fused_block = fused
+        U, F = analytic.force(net, gnn._z(), q, gnn.inputs["_topo"])
+        U2, F2, dq, gth = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+        _, F3, dq3, none = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"], want_theta=False)
+        assert none is None
+        res.append([U.reshape(1), F, U2.reshape(1), F2, dq, F3, dq3, torch.cat([t.reshape(-1) for t in gth])])
+    for k, (a, b) in enumerate(zip(*res)):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "fused vs unfused #%d" % k)
+    close(res[0][1], g["F"], 1e-4, 1e-5 * np.abs(g["F"]).max(), "fused F vs golden")
