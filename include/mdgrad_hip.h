@@ -106,6 +106,12 @@ int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* cell /*host
                        float cutoff, const uint8_t* mask,
                        int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
                        int32_t* overflow, int32_t* scratch, void* stream);
+/* cell list for replica-batched systems (see mdg_nbr_build_dense_groups): every group bins on its own */
+int64_t mdg_nbr_cell_scratch_groups(int n_atoms, int group, const MdgCell* cell /*host*/, float cutoff);
+int mdg_nbr_build_cell_groups(const float* pos, int n_atoms, int group, const MdgCell* cell /*host*/,
+                              float cutoff, const uint8_t* mask,
+                              int32_t* col, int32_t* shift, int32_t* cnt, int max_nbr,
+                              int32_t* overflow, int32_t* scratch, void* stream);
 /* half list in the reference's order: row_base = exclusive scan of per-row (j>i) counts.
  * nbr int64[P,2], offsets f32[P,3]; P must be the value returned in *n_pairs by
  * mdg_nbr_half_count (device int32).  edge_id (optional, int32[N*max_nbr]) receives for
@@ -318,6 +324,19 @@ int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float
                    float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K11/K12  node-level Dense layers with fused epilogues on the f32 MFMA
+ * (replaces nff/nn/layers.py:86-134 Dense + nff/nn/activations.py:5-11 on [N, .] node features: message_node_filter,
+ *  the update MLP + residual nff/nn/modules.py:543-547 / schnet.py:149-151, the readout's first Linear, and the
+ *  transposed products of the hand-derived reverse sweeps):
+ *     z0 = x0 B + bias0 ;  out0 = act(z0) * mul0 + res0 ;  sig0 = sigmoid(z0)            (act = 1: shifted softplus)
+ *     z1 = x1 B          ;  out1 = act'(z0) z1 + res1                                     (x1 nullable)
+ *  B[k][m] = W[m*k_dim + k] (trans = 0, torch.nn.Linear layout) or W[k*m_dim + m] (trans = 1).  k <= 256.
+ */
+int mdg_dense(const float* W, int trans, int act, int n_rows, int k, int m,
+              const float* x0, const float* bias0, const float* mul0, const float* res0, float* out0, float* sig0,
+              const float* x1, const float* res1, float* out1, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Fused elementwise / row-reduction pieces of the hand-derived SchNet passes (each replaces a chain of
  * PyTorch elementwise ops; nff/nn/layers.py:14-31, nff/nn/activations.py:5-11 and their derivatives):
  *   mdg_smear        g = exp(c_k (d - mu_k)^2), phi = 2 c_k (d - mu_k)              [E,G]
@@ -332,6 +351,9 @@ int mdg_ssp(const float* a, int64_t n, float* s, float* sa, void* stream);
 int mdg_mul_row(const float* x, const float* y, const float* r, int64_t n_rows, int n_cols, float* o, void* stream);
 int mdg_ssp_dual_bwd(const float* sa, const float* xd, const float* sdb, const float* sb, int64_t n, float* xdb,
                      float* xb, void* stream);
+/* the same with the tangent given as t_dot = sa * x_dot:  xdb = sa sdb ; xb = (1 - sa) t_dot sdb + sa sb */
+int mdg_ssp_dual_bwd_t(const float* sa, const float* td, const float* sdb, const float* sb, int64_t n, float* xdb,
+                       float* xb, void* stream);
 int mdg_smear_bwd(const float* gdb, const float* gb, const float* g, const float* phi, const float* dd,
                   const float* c, int64_t n_edges, int n_gauss, float* d_b, float* dd_b, void* stream);
 

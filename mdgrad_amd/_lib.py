@@ -52,6 +52,9 @@ _SIGNATURES = {
                                              C.c_int, P, P]),
     "mdg_nbr_cell_scratch": (C.c_int64, [C.c_int, C.POINTER(MdgCell), C.c_float]),
     "mdg_nbr_build_cell": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, P, P, C.c_int, P, P, P]),
+    "mdg_nbr_cell_scratch_groups": (C.c_int64, [C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float]),
+    "mdg_nbr_build_cell_groups": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, P, P, C.c_int,
+                                            P, P, P]),
     "mdg_nbr_half_count": (C.c_int, [P, P, C.c_int, C.c_int, P, P]),
     "mdg_nbr_half_fill": (C.c_int, [P, P, P, P, C.c_int, C.c_int, P, P, P, P]),
     "mdg_nbr_half_fill_padded": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int64, C.c_float, P, P, P, P, P, P]),
@@ -86,6 +89,7 @@ _SIGNATURES = {
     "mdg_ssp": (C.c_int, [P, C.c_int64, P, P, P]),
     "mdg_mul_row": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P]),
     "mdg_ssp_dual_bwd": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
+    "mdg_ssp_dual_bwd_t": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
     "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
@@ -95,6 +99,7 @@ _SIGNATURES = {
     "mdg_cfconv_fwd": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),
     "mdg_cfconv_bwd_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
     "mdg_cfconv_bwd": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P]),
+    "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
 }

@@ -1,0 +1,168 @@
+// K11 / K12: node-level Dense layers of the SchNet block with their epilogues fused
+// (nff/nn/layers.py:86-134 `Dense` = act(x W^T + b), nff/nn/activations.py:5-11 shifted softplus; the
+//  update MLP and the residual of nff/nn/modules.py:543-547 / nff/nn/models/schnet.py:149-151, the readout's first
+//  Linear, and the transposed products x W of the reverse sweeps in mdgrad_amd/nn/analytic.py):
+//
+//     z   = x B (+ bias)            B[k][m] = W[m][k] (Linear layout, forward)  or  W[k][m] (reverse sweeps)
+//     out = act(z) (* mul) (+ res)  act = identity | shifted softplus (then sig = sigmoid(z) is stored as well)
+//
+// One launch serves up to two inputs that share the weight (DUAL): the primal rows and their forward-mode tangent
+// (z1 = x1 B ; out1 = act'(z0) z1 (+ res1)), or the two adjoints of the dual reverse sweep -- one set of B
+// fragments from LDS feeds both accumulator sets.  v_mfma_f32_16x16x4_f32 (exact f32): persistent workgroups
+// stage one chunk of <= 128 output columns of the weight (all k <= 256) in LDS once and walk 64-row tiles (16 rows
+// per wave); LDS rows are permuted so that the A operand is gathered as 16-byte vectors (k-step 4 q + c of a
+// 64-chunk <-> k = 16 q + 4 lk + c).
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr float LOG2E_D = 1.4426950408889634f;
+constexpr float LN2_D = 0.69314718055994531f;
+constexpr int DN_KC = 64;          // k chunk
+constexpr int DN_MC = 128;         // output columns per workgroup
+constexpr int DN_SB = 144;         // LDS row stride of the weight chunk (16 mod 32)
+
+struct DenseProb {
+    const float* x;      // [N, K]
+    const float* bias;   // [M] or null        (row 0 only)
+    const float* mul;    // [N, M] or null     (row 0 only)
+    const float* res;    // [N, M] or null
+    float* out;          // [N, M]
+    float* sig;          // [N, M] or null     (row 0, act == 1)
+};
+
+struct DenseArgs {
+    DenseProb p[2];      // p[1] = the tangent / second adjoint sharing the weight (DUAL)
+    const float* W;
+    int trans;           // 0: B[k][m] = W[m*K + k] ; 1: B[k][m] = W[k*M + m]
+    int act;             // 0 identity, 1 shifted softplus: out0 = ssp(z0), sig0 = sigmoid(z0), out1 = sigmoid(z0) z1
+    int N, K, M;
+};
+
+__device__ __forceinline__ void load_a(const float* __restrict__ x, int arow, bool aok, int K, bool vec, int kc, int lk,
+                                       float (&af)[16]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k0 = kc + 16 * q + 4 * lk;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (aok) {
+            if (vec && k0 + 4 <= K) v = *reinterpret_cast<const float4*>(x + (size_t)arow * K + k0);
+            else {
+                const float* px = x + (size_t)arow * K;
+                if (k0 < K) v.x = px[k0];
+                if (k0 + 1 < K) v.y = px[k0 + 1];
+                if (k0 + 2 < K) v.z = px[k0 + 2];
+                if (k0 + 3 < K) v.w = px[k0 + 3];
+            }
+        }
+        af[4 * q] = v.x; af[4 * q + 1] = v.y; af[4 * q + 2] = v.z; af[4 * q + 3] = v.w;
+    }
+}
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float bs[];          // [Kpad][DN_SB]: the whole weight chunk, staged once
+    const DenseProb P0 = A.p[0], P1 = A.p[1];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int m_lo = blockIdx.y * DN_MC;
+    const int Mc = min(DN_MC, A.M - m_lo);
+    const int ntiles = (Mc + 15) >> 4;
+    const int Kpad = (A.K + DN_KC - 1) / DN_KC * DN_KC;
+    // physical row kc + (4 q + c) * 4 + lk holds k = kc + 16 q + 4 lk + c  (kc = 64-chunk base)
+    for (int t = tid; t < Kpad * DN_MC; t += 256) {
+        int k, m;
+        if (A.trans) { k = t / DN_MC; m = t % DN_MC; } else { m = t / Kpad; k = t % Kpad; }
+        float v = 0.f;
+        if (k < A.K && m < Mc) v = A.trans ? A.W[(size_t)k * A.M + m_lo + m] : A.W[(size_t)(m_lo + m) * A.K + k];
+        const int kk = k & (DN_KC - 1);
+        const int prow = (k - kk) + (4 * (kk >> 4) + (kk & 3)) * 4 + ((kk & 15) >> 2);
+        bs[prow * DN_SB + m] = v;
+    }
+    __syncthreads();
+    const bool vec = (A.K & 3) == 0;
+    const int row_tiles = (A.N + 63) >> 6;
+    for (int tile = blockIdx.x; tile < row_tiles; tile += gridDim.x) {
+        const int row0 = tile * 64 + wid * 16;
+        const int arow = row0 + li;
+        const bool aok = arow < A.N;
+        f32x4 acc0[DN_MC / 16], acc1[DUAL ? DN_MC / 16 : 1];
+#pragma unroll
+        for (int t = 0; t < DN_MC / 16; ++t) {
+            acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (DUAL) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        for (int kc = 0; kc < A.K; kc += DN_KC) {
+            float a0[16], a1[16];
+            load_a(P0.x, arow, aok, A.K, vec, kc, lk, a0);
+            if (DUAL) load_a(P1.x, arow, aok, A.K, vec, kc, lk, a1);
+            const float* bk = bs + (size_t)kc * DN_SB;
+#pragma unroll
+            for (int t = 0; t < DN_MC / 16; ++t) {
+                if (t < ntiles) {
+#pragma unroll
+                    for (int ks = 0; ks < 16; ++ks) {
+                        const float bfr = bk[(ks * 4 + lk) * DN_SB + t * 16 + li];
+                        acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], bfr, acc0[t], 0, 0, 0);
+                        if (DUAL) acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], bfr, acc1[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // epilogue in the accumulator layout: row = row0 + 4 lk + r, column = m_lo + 16 t + li
+#pragma unroll
+        for (int t = 0; t < DN_MC / 16; ++t) {
+            if (t >= ntiles) continue;
+            const int m = t * 16 + li;
+            if (m >= Mc) continue;
+            const float b0 = P0.bias ? P0.bias[m_lo + m] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = row0 + 4 * lk + r;
+                if (row >= A.N) continue;
+                const size_t o = (size_t)row * A.M + m_lo + m;
+                float z = acc0[t][r] + b0;
+                float z1 = DUAL ? acc1[t][r] : 0.f;
+                if (A.act == 1) {
+                    const float ex = __builtin_amdgcn_exp2f(z * LOG2E_D);
+                    const bool big = z > 20.f;
+                    const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_D;
+                    const float sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
+                    if (P0.sig) P0.sig[o] = sg;
+                    z = (big ? z : sp) - LN2_D;
+                    z1 *= sg;                                   // tangent of the activation
+                }
+                if (P0.mul) z *= P0.mul[o];
+                if (P0.res) z += P0.res[o];
+                P0.out[o] = z;
+                if (DUAL) {
+                    if (P1.res) z1 += P1.res[o];
+                    P1.out[o] = z1;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdg_dense(const float* W, int trans, int act, int n_rows, int k, int m,
+                         const float* x0, const float* bias0, const float* mul0, const float* res0, float* out0,
+                         float* sig0, const float* x1, const float* res1, float* out1, void* stream) {
+    MDG_CHECK_ARG(n_rows >= 0 && k > 0 && k <= 256 && m > 0, "dense: bad sizes (1 <= k <= 256)");
+    if (n_rows == 0) return MDG_OK;
+    MDG_CHECK_ARG(W && x0 && out0 && (!x1 || out1), "dense: null buffer");
+    MDG_CHECK_ARG(act == 0 || act == 1, "dense: act must be 0 (identity) or 1 (shifted softplus)");
+    MDG_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, "dense: inputs must be 16-byte aligned");
+    DenseArgs a{};
+    a.p[0] = DenseProb{x0, bias0, mul0, res0, out0, sig0};
+    a.p[1] = DenseProb{x1, nullptr, nullptr, res1, out1, nullptr};
+    a.W = W; a.trans = trans; a.act = act; a.N = n_rows; a.K = k; a.M = m;
+    const int row_tiles = (n_rows + 63) / 64;
+    dim3 grid(row_tiles < 256 ? row_tiles : 256, (m + DN_MC - 1) / DN_MC);
+    const size_t lds = sizeof(float) * (size_t)((k + DN_KC - 1) / DN_KC * DN_KC) * DN_SB;
+    if (x1) hipLaunchKernelGGL(dense_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dense_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    MDG_CHECK_LAUNCH("dense_kernel");
+    return MDG_OK;
+}

@@ -54,6 +54,18 @@ __global__ void ssp_dual_bwd_kernel(const float* __restrict__ sa, const float* _
     xb[t] = s * (1.f - s) * xd[t] * db + s * sb[t];
 }
 
+// the same with the tangent stored as t_dot = sa * x_dot (what the fused Dense epilogue writes):
+//   xdb = sa * sdb ;  xb = (1 - sa) t_dot sdb + sa sb
+__global__ void ssp_dual_bwd_t_kernel(const float* __restrict__ sa, const float* __restrict__ td,
+                                      const float* __restrict__ sdb, const float* __restrict__ sb, long long n,
+                                      float* __restrict__ xdb, float* __restrict__ xb) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float s = sa[t], db = sdb[t];
+    xdb[t] = s * db;
+    xb[t] = (1.f - s) * td[t] * db + s * sb[t];
+}
+
 // reverse of the smearing (and its tangent), reduced over the G Gaussians of each edge:
 //   gb' = gb + gdb * phi * dd ;  d_b += sum_k gdb g 2c dd + gb' g phi ;  dd_b += sum_k gdb g phi
 // gdb may be NULL (first-order pass): d_b += sum_k gb g phi.   16 lanes per edge row.
@@ -134,6 +146,16 @@ extern "C" int mdg_ssp_dual_bwd(const float* sa, const float* xd, const float* s
     hipLaunchKernelGGL(ssp_dual_bwd_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sa, xd, sdb, sb,
                        (long long)n, xdb, xb);
     MDG_CHECK_LAUNCH("ssp_dual_bwd_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_ssp_dual_bwd_t(const float* sa, const float* td, const float* sdb, const float* sb, int64_t n,
+                                  float* xdb, float* xb, void* stream) {
+    ELEM_CHECK(n, "ssp_dual_bwd_t");
+    MDG_CHECK_ARG(sa && td && sdb && sb && xdb && xb, "ssp_dual_bwd_t: bad arguments");
+    hipLaunchKernelGGL(ssp_dual_bwd_t_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sa, td, sdb, sb,
+                       (long long)n, xdb, xb);
+    MDG_CHECK_LAUNCH("ssp_dual_bwd_t_kernel");
     return MDG_OK;
 }
 

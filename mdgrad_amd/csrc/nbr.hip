@@ -93,14 +93,16 @@ __device__ __forceinline__ int bin_coord(float x, float inv, int nb) {
     return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
 }
 
-__global__ void bin_count_kernel(const float* __restrict__ pos, int N, MdgCell cell, Bins bins,
+// (replica-stacked systems: every group of `group` consecutive atoms has its own set of bins, group g owning
+//  bins [g ncell, (g+1) ncell) -- pairs never cross groups)
+__global__ void bin_count_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, Bins bins,
                                  int32_t* __restrict__ atom_bin, int32_t* __restrict__ bin_cnt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int bx = bin_coord(pos[3 * i], cell.inv[0], bins.nb[0]);
     const int by = bin_coord(pos[3 * i + 1], cell.inv[4], bins.nb[1]);
     const int bz = bin_coord(pos[3 * i + 2], cell.inv[8], bins.nb[2]);
-    const int b = (bx * bins.nb[1] + by) * bins.nb[2] + bz;
+    const int b = (i / group) * bins.ncell + (bx * bins.nb[1] + by) * bins.nb[2] + bz;
     atom_bin[i] = b;
     atomicAdd(&bin_cnt[b], 1);
 }
@@ -144,7 +146,7 @@ __global__ void bin_fill_kernel(const int32_t* __restrict__ atom_bin, int N, int
 
 constexpr int ROW_CAP = 512;   // LDS row buffer per wave (entries)
 
-__global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, MdgCell cell, Bins bins, float rc2,
+__global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, Bins bins, float rc2,
                                 const uint8_t* __restrict__ mask, const int32_t* __restrict__ atom_bin,
                                 const int32_t* __restrict__ bin_start, const int32_t* __restrict__ sorted_atoms,
                                 int32_t* __restrict__ col, int32_t* __restrict__ shift,
@@ -156,21 +158,25 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, MdgCell ce
     const int i = blockIdx.x * (blockDim.x >> 6) + wid;
     if (i >= N) return;
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
-    const int b = atom_bin[i];
+    const int g0 = (i / group) * group, gbin = (i / group) * bins.ncell;
+    const int b = atom_bin[i] - gbin;
     const int bz = b % bins.nb[2], by = (b / bins.nb[2]) % bins.nb[1], bx = b / (bins.nb[2] * bins.nb[1]);
     int base = 0;
     for (int s = 0; s < 27; ++s) {
         const int cx = (bx + s / 9 - 1 + bins.nb[0]) % bins.nb[0];
         const int cy = (by + (s / 3) % 3 - 1 + bins.nb[1]) % bins.nb[1];
         const int cz = (bz + s % 3 - 1 + bins.nb[2]) % bins.nb[2];
-        const int c = (cx * bins.nb[1] + cy) * bins.nb[2] + cz;
+        const int c = gbin + (cx * bins.nb[1] + cy) * bins.nb[2] + cz;
         const int a0 = bin_start[c], a1 = bin_start[c + 1];
         for (int a = a0; a < a1; a += 64) {
             const int idx = a + lane;
             int code = -1, j = -1;
             if (idx < a1) {
                 j = sorted_atoms[idx];
-                if (j != i) code = pair_test<true>(cell, pos, i, j, xi, yi, zi, rc2, mask, N);
+                if (j != i) {
+                    code = pair_test<true>(cell, pos, i, j, xi, yi, zi, rc2, nullptr, N);
+                    if (code >= 0 && mask && !mask[(size_t)(i - g0) * group + (j - g0)]) code = -1;
+                }
             }
             const unsigned long long bal = __ballot(code >= 0);
             if (code >= 0) {
@@ -294,19 +300,36 @@ extern "C" int mdg_nbr_build_dense_groups(const float* pos, int n_atoms, int gro
     return MDG_OK;
 }
 
-extern "C" int64_t mdg_nbr_cell_scratch(int n_atoms, const MdgCell* cell, float cutoff) {
-    if (!cell || n_atoms <= 0 || cutoff <= 0.f) return -1;
+extern "C" int64_t mdg_nbr_cell_scratch_groups(int n_atoms, int group, const MdgCell* cell, float cutoff) {
+    if (!cell || n_atoms <= 0 || group <= 0 || n_atoms % group || cutoff <= 0.f) return -1;
     const Bins b = make_bins(*cell, cutoff);
-    return 2 * (int64_t)n_atoms + 3 * (int64_t)(b.ncell + 1) + 8;
+    return 2 * (int64_t)n_atoms + 3 * ((int64_t)b.ncell * (n_atoms / group) + 1) + 8;
 }
+
+extern "C" int64_t mdg_nbr_cell_scratch(int n_atoms, const MdgCell* cell, float cutoff) {
+    return mdg_nbr_cell_scratch_groups(n_atoms, n_atoms, cell, cutoff);
+}
+
+extern "C" int mdg_nbr_build_cell_groups(const float* pos, int n_atoms, int group, const MdgCell* cell, float cutoff,
+                                         const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
+                                         int max_nbr, int32_t* overflow, int32_t* scratch, void* stream);
 
 extern "C" int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* cell, float cutoff,
                                   const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
                                   int max_nbr, int32_t* overflow, int32_t* scratch, void* stream) {
+    return mdg_nbr_build_cell_groups(pos, n_atoms, n_atoms, cell, cutoff, mask, col, shift, cnt, max_nbr, overflow,
+                                     scratch, stream);
+}
+
+extern "C" int mdg_nbr_build_cell_groups(const float* pos, int n_atoms, int group, const MdgCell* cell, float cutoff,
+                                         const uint8_t* mask, int32_t* col, int32_t* shift, int32_t* cnt,
+                                         int max_nbr, int32_t* overflow, int32_t* scratch, void* stream) {
     MDG_CHECK_ARG(pos && cell && col && shift && cnt && overflow && scratch, "nbr_build_cell: null buffer");
     MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0 && cutoff > 0.f, "nbr_build_cell: bad sizes");
+    MDG_CHECK_ARG(group > 0 && n_atoms % group == 0, "nbr_build_cell: n_atoms must be a multiple of the group size");
     MDG_CHECK_ARG(cell->diag, "nbr_build_cell: orthorhombic cells only (use mdg_nbr_build_dense)");
-    const Bins bins = make_bins(*cell, cutoff);
+    Bins bins = make_bins(*cell, cutoff);
+    const int nbins_total = bins.ncell * (n_atoms / group);
     MDG_CHECK_ARG(bins.nb[0] >= 3 && bins.nb[1] >= 3 && bins.nb[2] >= 3,
                   "nbr_build_cell: box shorter than 3 cutoffs (use mdg_nbr_build_dense)");
     MDG_CHECK_ARG(max_nbr <= ROW_CAP, "nbr_build_cell: max_nbr > %d", ROW_CAP);
@@ -314,20 +337,20 @@ extern "C" int mdg_nbr_build_cell(const float* pos, int n_atoms, const MdgCell* 
     int32_t* atom_bin = scratch;
     int32_t* sorted_atoms = atom_bin + n_atoms;
     int32_t* bin_cnt = sorted_atoms + n_atoms;
-    int32_t* bin_start = bin_cnt + bins.ncell + 1;
-    int32_t* cursor = bin_start + bins.ncell + 1;
-    if (hipMemsetAsync(bin_cnt, 0, sizeof(int32_t) * (bins.ncell + 1), st) != hipSuccess) {
+    int32_t* bin_start = bin_cnt + nbins_total + 1;
+    int32_t* cursor = bin_start + nbins_total + 1;
+    if (hipMemsetAsync(bin_cnt, 0, sizeof(int32_t) * (nbins_total + 1), st) != hipSuccess) {
         mdg_set_error("nbr_build_cell: memset failed"); return MDG_ELAUNCH;
     }
     const int tb = 256;
-    hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, *cell,
+    hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, group, *cell,
                        bins, atom_bin, bin_cnt);
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, bin_cnt, bins.ncell, bin_start, cursor);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, bin_cnt, nbins_total, bin_start, cursor);
     hipLaunchKernelGGL(bin_fill_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, atom_bin, n_atoms,
                        cursor, sorted_atoms);
     const int wpb = 4;
     const size_t lds = sizeof(int32_t) * 2 * ROW_CAP * wpb;
-    hipLaunchKernelGGL(nbr_cell_kernel, dim3((n_atoms + wpb - 1) / wpb), dim3(64 * wpb), lds, st, pos, n_atoms,
+    hipLaunchKernelGGL(nbr_cell_kernel, dim3((n_atoms + wpb - 1) / wpb), dim3(64 * wpb), lds, st, pos, n_atoms, group,
                        *cell, bins, cutoff * cutoff, mask, atom_bin, bin_start, sorted_atoms, col, shift, cnt,
                        max_nbr, overflow);
     MDG_CHECK_LAUNCH("nbr_cell kernels");

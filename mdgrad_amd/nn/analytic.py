@@ -200,6 +200,31 @@ class _node_blas:
         return False
 
 
+def _dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None, res1=None, want_sig=False):
+    """(out0, sig0, out1) of ops.dense -- the MFMA node kernel with fused bias / shifted softplus / product /
+    residual, one launch for a primal row and its tangent (or both adjoints); layers wider than its LDS-resident
+    weight chunk (k > 256) go through the library GEMM with the same epilogue in torch ops."""
+    if x0.shape[1] <= ops.DENSE_MAX_K and x0.is_cuda:
+        return ops.dense(W, x0, trans, bias, act, mul, res, x1, res1, want_sig)
+    B = W if trans else W.t()
+    z0 = x0.mm(B)
+    if bias is not None:
+        z0 = z0 + bias
+    z1 = x1.mm(B) if x1 is not None else None
+    sig = None
+    if act:
+        sig = torch.sigmoid(z0)
+        z0 = _ssp(z0)
+        z1 = sig * z1 if z1 is not None else None
+    if mul is not None:
+        z0 = z0 * mul
+    if res is not None:
+        z0 = z0 + res
+    if res1 is not None and z1 is not None:
+        z1 = z1 + res1
+    return z0, sig, z1
+
+
 @torch.no_grad()
 def _forward_fused(net, z, x, topo, w=None, want_sums=False):
     """Primal (and, with w, forward-mode tangent along x_dot = w) sweep on the fused kernels."""
@@ -209,40 +234,34 @@ def _forward_fused(net, z, x, topo, w=None, want_sums=False):
     for conv in net.convolutions:
         P = _layer_params(conv)
         fn = ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"])
-        h = _addmm(P["bn"], r, P["Wn"].t())
-        hd = rd.mm(P["Wn"].t()) if rd is not None else None
+        h, _, hd = _dense(P["Wn"], r, bias=P["bn"], x1=rd)                       # message_node_filter (+ tangent)
         m, md, hsum, hdsum = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums)
-        u = _addmm(P["c1"], m, P["U1"].t())
-        t, su = ops.ssp(u, True)
-        L = dict(P=P, fn=fn, r=r, rd=rd, h=h, hd=hd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=t, su=su)
-        if w is not None:
-            ud = md.mm(P["U1"].t())
-            td = ops.mul_row(su, ud)
-            L.update(ud=ud, td=td)
-            rd = td.mm(P["U2"].t()) if rd is None else rd + td.mm(P["U2"].t())
-        layers.append(L)
-        r = r + _addmm(P["c2"], t, P["U2"].t())
+        # update MLP: t = ssp(U1 m + c1), su = sigmoid(.), td = su * (U1 md)
+        t, su, td = _dense(P["U1"], m, bias=P["c1"], act=True, x1=md, want_sig=True)
+        layers.append(dict(P=P, fn=fn, r=r, rd=rd, h=h, hd=hd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=t, su=su, td=td))
+        r, _, rd = _dense(P["U2"], t, bias=P["c2"], res=r, x1=td, res1=rd)       # residual (schnet.py:149-151)
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
-    y = _addmm(l1, r, L1.t())
+    y, _, yd = _dense(L1, r, bias=l1, x1=rd)
     U = (_ssp(y).mm(L2.t()) + l2).sum()
-    return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, y=y, L1=L1, L2=L2, U=U)
+    return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, y=y, yd=yd, L1=L1, L2=L2, U=U)
 
 
 @torch.no_grad()
 def _force_fused(net, z, x, topo):
     fw = _forward_fused(net, z, x, topo)
     d = fw["d"]
-    rb = (torch.sigmoid(fw["y"]) * fw["L2"]).mm(fw["L1"])
+    rb = _dense(fw["L1"], torch.sigmoid(fw["y"]) * fw["L2"], trans=True)[0]
     dU_dd = torch.zeros_like(d)
     for idx in range(len(fw["layers"]) - 1, -1, -1):
         L = fw["layers"][idx]
         P = L["P"]
-        mb = ops.mul_row(L["su"], rb.mm(P["U2"])).mm(P["U1"])
+        ub = _dense(P["U2"], rb, trans=True, mul=L["su"])[0]
+        mb = _dense(P["U1"], ub, trans=True)[0]
         ops.cfconv_bwd(L["fn"], d, None, topo, L["h"], None, None, mb, None, dU_dd)
         if idx > 0:                                               # (the embedding below layer 0 is not needed)
             hb = ops.cfconv_fwd(L["fn"], d, None, mb, None, topo)[0]
-            rb = rb + hb.mm(P["Wn"])
+            rb = _dense(P["Wn"], hb, trans=True, res=rb)[0]
     F, _ = ops.edge_geom_bwd(None, dU_dd, None, None, fw["uhat"], None, topo)
     return fw["U"], F
 
@@ -251,8 +270,7 @@ def _force_fused(net, z, x, topo):
 def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
     fw = _forward_fused(net, z, x, topo, w, want_sums=want_theta)
     d, dd = fw["d"], fw["dd"]
-    L1, L2, y, rd = fw["L1"], fw["L2"], fw["y"], fw["rd"]
-    yd = rd.mm(L1.t())
+    L1, L2, y, yd, rd = fw["L1"], fw["L2"], fw["y"], fw["yd"], fw["rd"]
     sy = torch.sigmoid(y)
     # ---------------- reverse sweep of U_dot = sum_i L2 . (sig(y_i) * yd_i)
     ydb = sy * L2
@@ -262,22 +280,22 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
     if want_theta:
         grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
         grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
-        grads[id(ro[0].weight)] = yb.t().mm(fw["r"]) + ydb.t().mm(rd)
+        grads[id(ro[0].weight)] = _atb(yb, fw["r"]) + _atb(ydb, rd)
         grads[id(ro[0].bias)] = yb.sum(0)
-    rdb, rb = ydb.mm(L1), yb.mm(L1)
+    rdb, _, rb = _dense(L1, ydb, trans=True, x1=yb)
     d_b, dd_b = torch.zeros_like(d), torch.zeros_like(d)
     convs = list(net.convolutions)
     for idx in range(len(convs) - 1, -1, -1):
         L, md_ = fw["layers"][idx], convs[idx].moduledict
         P = L["P"]
-        tb, tdb = rb.mm(P["U2"]), rdb.mm(P["U2"])
+        tdb, _, tb = _dense(P["U2"], rdb, trans=True, x1=rb)
         if want_theta:
-            grads[id(md_["update_function"][2].weight)] = rb.t().mm(L["t"]) + rdb.t().mm(L["td"])
+            grads[id(md_["update_function"][2].weight)] = _atb(rb, L["t"]) + _atb(rdb, L["td"])
             grads[id(md_["update_function"][2].bias)] = rb.sum(0)
-        udb, ub = ops.ssp_dual_bwd(L["su"], L["ud"], tdb, tb)
-        mdb, mb = udb.mm(P["U1"]), ub.mm(P["U1"])
+        udb, ub = ops.ssp_dual_bwd_t(L["su"], L["td"], tdb, tb)
+        mdb, _, mb = _dense(P["U1"], udb, trans=True, x1=ub)
         if want_theta:
-            grads[id(md_["update_function"][0].weight)] = udb.t().mm(L["md"]) + ub.t().mm(L["m"])
+            grads[id(md_["update_function"][0].weight)] = _atb(udb, L["md"]) + _atb(ub, L["m"])
             grads[id(md_["update_function"][0].bias)] = ub.sum(0)
         th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta)
         if want_theta:
@@ -293,13 +311,12 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
             # adjoints (hdb, hb) of (hd, h)
             hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
             if want_theta:
-                gWn = hb.t().mm(L["r"])
+                gWn = _atb(hb, L["r"])
                 if L["rd"] is not None:
-                    gWn = gWn + hdb.t().mm(L["rd"])
+                    gWn = gWn + _atb(hdb, L["rd"])
                 grads[id(md_["message_node_filter"].weight)] = gWn
                 grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
-            rdb = rdb + hdb.mm(P["Wn"])
-            rb = rb + hb.mm(P["Wn"])
+            rdb, _, rb = _dense(P["Wn"], hdb, trans=True, res=rdb, x1=hb, res1=rb)
     # dd_b = dU/dd (see the module docstring): force and d(w.F)/dx from one scatter
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
     if not want_theta:

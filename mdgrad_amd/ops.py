@@ -117,7 +117,7 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
     grouped = group is not None and group != N
     Ng = group if grouped else N
     cap = estimate_max_nbr(Ng, cell_struct, cutoff) if max_nbr is None else int(max_nbr)
-    use_cell = (not grouped) and (method == "cell" or (method == "auto" and _use_cell_list(N, cell_struct, cutoff)))
+    use_cell = method == "cell" or (method == "auto" and _use_cell_list(Ng, cell_struct, cutoff))
     st = stream_ptr(dev)
     while True:
         if need is not None and max_nbr is None:
@@ -126,11 +126,11 @@ def build_ell(xyz, cell_struct, cutoff, mask=None, max_nbr=None, method="auto", 
         shift = torch.empty(N, cap, dtype=torch.int32, device=dev)
         cnt = torch.empty(N, dtype=torch.int32, device=dev)
         overflow = torch.zeros(1, dtype=torch.int32, device=dev) if need is None else need
-        if use_cell:
-            ns = lib.mdg_nbr_cell_scratch(N, C.byref(cell_struct), cutoff)
+        if use_cell and cap <= 512:                 # (the cell-list kernel sorts rows of up to 512 entries in LDS)
+            ns = lib.mdg_nbr_cell_scratch_groups(N, Ng, C.byref(cell_struct), cutoff)
             scratch = torch.empty(int(ns), dtype=torch.int32, device=dev)
-            check(lib.mdg_nbr_build_cell(ptr(xyz), N, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
-                                         ptr(shift), ptr(cnt), cap, ptr(overflow), ptr(scratch), st),
+            check(lib.mdg_nbr_build_cell_groups(ptr(xyz), N, Ng, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
+                                                ptr(shift), ptr(cnt), cap, ptr(overflow), ptr(scratch), st),
                   "mdg_nbr_build_cell")
         else:
             check(lib.mdg_nbr_build_dense_groups(ptr(xyz), N, Ng, C.byref(cell_struct), cutoff, ptr(mask), ptr(col),
@@ -833,6 +833,34 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
     return (gW1, gb1, gW2) if want_theta else None
 
 
+DENSE_MAX_K = 256
+
+
+def dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None, res1=None, want_sig=False):
+    """Node-level Dense with fused epilogue on the f32 MFMA (csrc/dense.hip):
+    out0 = act(x0 B + bias) * mul + res ; out1 = act'(.) (x1 B) + res1 with B = W^T (trans False) or W (True).
+    Returns (out0, sig0, out1)."""
+    lib = _lib.load()
+    require_gpu(x0, "x0")
+    x0 = x0.contiguous()
+    W = W.detach().contiguous()
+    N, K = x0.shape
+    M = W.shape[1] if trans else W.shape[0]
+    assert (W.shape[0] if trans else W.shape[1]) == K, "dense: shape mismatch"
+    dev = x0.device
+    out0 = torch.empty(N, M, device=dev)
+    sig = torch.empty(N, M, device=dev) if (act and want_sig) else None
+    out1 = None
+    if x1 is not None:
+        x1 = x1.contiguous()
+        out1 = torch.empty(N, M, device=dev)
+    cont = lambda t: t.contiguous() if t is not None else None
+    check(lib.mdg_dense(ptr(W), int(bool(trans)), int(bool(act)), N, K, M, ptr(x0), ptr(cont(bias)), ptr(cont(mul)),
+                        ptr(cont(res)), ptr(out0), ptr(sig), ptr(x1), ptr(cont(res1)), ptr(out1), stream_ptr(dev)),
+          "mdg_dense")
+    return out0, sig, out1
+
+
 # ----------------------------------------------------------------------------- fused elementwise pieces
 def smear(d, mu, c):
     lib = _lib.load()
@@ -867,6 +895,16 @@ def ssp_dual_bwd(sa, xd, sdb, sb):
     xdb, xb = torch.empty_like(sa), torch.empty_like(sa)
     check(lib.mdg_ssp_dual_bwd(ptr(sa), ptr(xd), ptr(sdb), ptr(sb), sa.numel(), ptr(xdb), ptr(xb),
                                stream_ptr(sa.device)), "mdg_ssp_dual_bwd")
+    return xdb, xb
+
+
+def ssp_dual_bwd_t(sa, td, sdb, sb):
+    """ssp_dual_bwd with the tangent stored as t_dot = sa * x_dot."""
+    lib = _lib.load()
+    sa, td, sdb, sb = sa.contiguous(), td.contiguous(), sdb.contiguous(), sb.contiguous()
+    xdb, xb = torch.empty_like(sa), torch.empty_like(sa)
+    check(lib.mdg_ssp_dual_bwd_t(ptr(sa), ptr(td), ptr(sdb), ptr(sb), sa.numel(), ptr(xdb), ptr(xb),
+                                 stream_ptr(sa.device)), "mdg_ssp_dual_bwd_t")
     return xdb, xb
 
 

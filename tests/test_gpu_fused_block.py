@@ -184,3 +184,32 @@ def test_fused_analytic_path_equals_unfused(name):
     for k, (a, b) in enumerate(zip(*res)):
         close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "fused vs unfused #%d" % k)
     close(res[0][1], g["F"], 1e-4, 1e-5 * np.abs(g["F"]).max(), "fused F vs golden")
+
+
+@pytest.mark.parametrize("N,K,M", [(1000, 64, 128), (4096, 128, 64), (37, 30, 30), (513, 200, 130), (64, 32, 1), (300, 64, 64)])
+def test_dense_node_kernel_epilogues(N, K, M):
+    """csrc/dense.hip against torch: linear / transposed weight, bias, shifted softplus with its tangent row,
+    elementwise product and residuals, single and dual inputs."""
+    from mdgrad_amd import ops
+    torch.manual_seed(N + K + M)
+    x0, x1 = torch.randn(N, K, device=DEV), torch.randn(N, K, device=DEV)
+    W = torch.randn(M, K, device=DEV) / K ** 0.5
+    bias = torch.randn(M, device=DEV)
+    mul, res, res1 = [torch.randn(N, M, device=DEV) for _ in range(3)]
+    ln2 = float(np.log(2.0))
+    out0, sig, out1 = ops.dense(W, x0, bias=bias, act=True, x1=x1, res1=res1, want_sig=True)
+    z = x0 @ W.t() + bias
+    _close(out0, torch.nn.functional.softplus(z) - ln2, "ssp(x W^T + b)")
+    _close(sig, torch.sigmoid(z), "sigmoid")
+    _close(out1, torch.sigmoid(z) * (x1 @ W.t()) + res1, "tangent row")
+    out0, sig, out1 = ops.dense(W, x0, bias=bias, res=res, x1=x1)
+    assert sig is None
+    _close(out0, z + res, "x W^T + b + res")
+    _close(out1, x1 @ W.t(), "second row, no residual")
+    Wt = W.t().contiguous()                                    # [K, M]: trans = True contracts over the first index
+    out0, _, out1 = ops.dense(Wt, x0, trans=True, mul=mul, x1=x1, res1=res1)
+    _close(out0, (x0 @ Wt) * mul, "(x W) * mul")
+    _close(out1, x1 @ Wt + res1, "x1 W + res1")
+    single = ops.dense(W, x0, bias=bias)[0]
+    _close(single, z, "single input")
+    assert torch.equal(single, ops.dense(W, x0, bias=bias)[0])

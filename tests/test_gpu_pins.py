@@ -217,3 +217,24 @@ def test_build_ell_grows_when_a_cluster_exceeds_the_density_estimate():
     nbr, off = ell.half_list()
     onbr, ooff = O.nbr_list(T(pos), 2.5, T(cell))
     assert np.array_equal(nbr.cpu().numpy(), onbr.numpy()) and np.array_equal(off.cpu().numpy(), ooff.numpy())
+
+
+def test_cell_list_for_replica_stacked_systems_equals_dense():
+    """Grouped (System.replicate) neighbour search through the cell list: every replica bins on its own; the list
+    is identical to the dense group-restricted search, with and without an exclusion mask."""
+    from mdgrad_amd import ops, _lib
+    R = 3
+    pos, cell = liquid(10, seed=4)
+    rng = np.random.default_rng(8)
+    stack = np.concatenate([np.mod(pos + rng.normal(0, 0.1, pos.shape), cell) for _ in range(R)]).astype(np.float32)
+    stack[5::13] += cell[0]                               # unwrapped atoms bin correctly too
+    cs = _lib.make_cell(cell)
+    x = T(stack, DEV)
+    n = len(pos)
+    for mask in (None, ops.build_mask(n, ex_pairs=[[0, 1], [7, 400], [10, 11]], device=DEV)):
+        a = ops.build_ell(x, cs, 2.5, mask=mask, method="dense", group=n)
+        b = ops.build_ell(x, cs, 2.5, mask=mask, method="cell", group=n, max_nbr=a.max_nbr)
+        assert torch.equal(a.cnt, b.cnt)
+        k = torch.arange(a.max_nbr, device=DEV)[None, :] < a.cnt[:, None]
+        assert torch.equal(a.col[k], b.col[k]) and torch.equal(a.shift[k], b.shift[k])
+        assert int((a.col[k] // n != torch.arange(R * n, device=DEV)[:, None].expand_as(a.col)[k] // n).sum()) == 0
