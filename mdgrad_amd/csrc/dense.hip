@@ -60,35 +60,56 @@ __device__ __forceinline__ void load_a(const float* __restrict__ x, int arow, bo
     }
 }
 
-template <bool DUAL>
+// VEC: the chunk has 4 or 8 column tiles (64 / 128 columns) -- LDS column (nt, li) then holds output column
+// li * NT + nt, so a lane owns NT consecutive columns of its 4 rows and the epilogue moves 16-byte vectors.
+template <bool DUAL, int NT>          // NT = 0: general (scalar epilogue, natural column order)
 __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
     extern __shared__ __attribute__((aligned(16))) float bs[];          // [Kpad][DN_SB]: the whole weight chunk, staged once
     const DenseProb P0 = A.p[0], P1 = A.p[1];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int m_lo = blockIdx.y * DN_MC;
     const int Mc = min(DN_MC, A.M - m_lo);
-    const int ntiles = (Mc + 15) >> 4;
+    const int ntiles = NT ? NT : (Mc + 15) >> 4;
     const int Kpad = (A.K + DN_KC - 1) / DN_KC * DN_KC;
+    const int Mp = ntiles * 16;
     // physical row kc + (4 q + c) * 4 + lk holds k = kc + 16 q + 4 lk + c  (kc = 64-chunk base)
-    for (int t = tid; t < Kpad * DN_MC; t += 256) {
-        int k, m;
-        if (A.trans) { k = t / DN_MC; m = t % DN_MC; } else { m = t / Kpad; k = t % Kpad; }
-        float v = 0.f;
-        if (k < A.K && m < Mc) v = A.trans ? A.W[(size_t)k * A.M + m_lo + m] : A.W[(size_t)(m_lo + m) * A.K + k];
+    auto put = [&](int k, int m, float v) {
         const int kk = k & (DN_KC - 1);
         const int prow = (k - kk) + (4 * (kk >> 4) + (kk & 3)) * 4 + ((kk & 15) >> 2);
-        bs[prow * DN_SB + m] = v;
+        const int col = NT ? (m % NT) * 16 + m / NT : m;
+        bs[prow * DN_SB + col] = v;
+    };
+    if (!A.trans && (A.K & 3) == 0) {
+        // Linear layout W[m][k]: 16-byte loads along k, several in flight
+        const int kq = Kpad >> 2;
+#pragma unroll 4
+        for (int t = tid; t < kq * Mp; t += 256) {
+            const int m = t / kq, k = (t % kq) * 4;
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < A.K && m < Mc) v = *reinterpret_cast<const float4*>(A.W + (size_t)(m_lo + m) * A.K + k);
+            put(k, m, v.x); put(k + 1, m, v.y); put(k + 2, m, v.z); put(k + 3, m, v.w);
+        }
+    } else {
+#pragma unroll 4
+        for (int t = tid; t < Kpad * Mp; t += 256) {
+            int k, m;
+            if (A.trans) { k = t / Mp; m = t % Mp; } else { m = t / Kpad; k = t % Kpad; }
+            float v = 0.f;
+            if (k < A.K && m < Mc) v = A.trans ? A.W[(size_t)k * A.M + m_lo + m] : A.W[(size_t)(m_lo + m) * A.K + k];
+            put(k, m, v);
+        }
     }
     __syncthreads();
     const bool vec = (A.K & 3) == 0;
     const int row_tiles = (A.N + 63) >> 6;
+    constexpr int TT = NT ? NT : DN_MC / 16;
     for (int tile = blockIdx.x; tile < row_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wid * 16;
         const int arow = row0 + li;
         const bool aok = arow < A.N;
-        f32x4 acc0[DN_MC / 16], acc1[DUAL ? DN_MC / 16 : 1];
+        f32x4 acc0[TT], acc1[DUAL ? TT : 1];
 #pragma unroll
-        for (int t = 0; t < DN_MC / 16; ++t) {
+        for (int t = 0; t < TT; ++t) {
             acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (DUAL) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -98,8 +119,8 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
             if (DUAL) load_a(P1.x, arow, aok, A.K, vec, kc, lk, a1);
             const float* bk = bs + (size_t)kc * DN_SB;
 #pragma unroll
-            for (int t = 0; t < DN_MC / 16; ++t) {
-                if (t < ntiles) {
+            for (int t = 0; t < TT; ++t) {
+                if (NT || t < ntiles) {
 #pragma unroll
                     for (int ks = 0; ks < 16; ++ks) {
                         const float bfr = bk[(ks * 4 + lk) * DN_SB + t * 16 + li];
@@ -109,35 +130,85 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
                 }
             }
         }
-        // epilogue in the accumulator layout: row = row0 + 4 lk + r, column = m_lo + 16 t + li
+        if constexpr (NT != 0) {
+            // lane: rows row0 + 4 lk + r, columns m_lo + li * NT + [0, NT)
+            const int mb = m_lo + li * NT;
+            float bv[NT];
 #pragma unroll
-        for (int t = 0; t < DN_MC / 16; ++t) {
-            if (t >= ntiles) continue;
-            const int m = t * 16 + li;
-            if (m >= Mc) continue;
-            const float b0 = P0.bias ? P0.bias[m_lo + m] : 0.f;
+            for (int t = 0; t < NT; ++t) bv[t] = P0.bias ? P0.bias[mb + t] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = row0 + 4 * lk + r;
                 if (row >= A.N) continue;
-                const size_t o = (size_t)row * A.M + m_lo + m;
-                float z = acc0[t][r] + b0;
-                float z1 = DUAL ? acc1[t][r] : 0.f;
-                if (A.act == 1) {
-                    const float ex = __builtin_amdgcn_exp2f(z * LOG2E_D);
-                    const bool big = z > 20.f;
-                    const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_D;
-                    const float sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
-                    if (P0.sig) P0.sig[o] = sg;
-                    z = (big ? z : sp) - LN2_D;
-                    z1 *= sg;                                   // tangent of the activation
+                const size_t o = (size_t)row * A.M + mb;
+                float z[NT], z1[NT], sg[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    z[t] = acc0[t][r] + bv[t];
+                    z1[t] = DUAL ? acc1[t][r] : 0.f;
+                    if (A.act == 1) {
+                        const float ex = __builtin_amdgcn_exp2f(z[t] * LOG2E_D);
+                        const bool big = z[t] > 20.f;
+                        const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_D;
+                        sg[t] = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
+                        z[t] = (big ? z[t] : sp) - LN2_D;
+                        z1[t] *= sg[t];
+                    }
                 }
-                if (P0.mul) z *= P0.mul[o];
-                if (P0.res) z += P0.res[o];
-                P0.out[o] = z;
-                if (DUAL) {
-                    if (P1.res) z1 += P1.res[o];
-                    P1.out[o] = z1;
+#pragma unroll
+                for (int v = 0; v < NT / 4; ++v) {
+                    if (A.act == 1 && P0.sig)
+                        *reinterpret_cast<float4*>(P0.sig + o + 4 * v) = make_float4(sg[4 * v], sg[4 * v + 1], sg[4 * v + 2], sg[4 * v + 3]);
+                    if (P0.mul) {
+                        const float4 q = *reinterpret_cast<const float4*>(P0.mul + o + 4 * v);
+                        z[4 * v] *= q.x; z[4 * v + 1] *= q.y; z[4 * v + 2] *= q.z; z[4 * v + 3] *= q.w;
+                    }
+                    if (P0.res) {
+                        const float4 q = *reinterpret_cast<const float4*>(P0.res + o + 4 * v);
+                        z[4 * v] += q.x; z[4 * v + 1] += q.y; z[4 * v + 2] += q.z; z[4 * v + 3] += q.w;
+                    }
+                    *reinterpret_cast<float4*>(P0.out + o + 4 * v) = make_float4(z[4 * v], z[4 * v + 1], z[4 * v + 2], z[4 * v + 3]);
+                    if (DUAL) {
+                        if (P1.res) {
+                            const float4 q = *reinterpret_cast<const float4*>(P1.res + o + 4 * v);
+                            z1[4 * v] += q.x; z1[4 * v + 1] += q.y; z1[4 * v + 2] += q.z; z1[4 * v + 3] += q.w;
+                        }
+                        *reinterpret_cast<float4*>(P1.out + o + 4 * v) =
+                            make_float4(z1[4 * v], z1[4 * v + 1], z1[4 * v + 2], z1[4 * v + 3]);
+                    }
+                }
+            }
+        } else {
+            // general: accumulator layout, row = row0 + 4 lk + r, column = m_lo + 16 t + li
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                if (t >= ntiles) continue;
+                const int m = t * 16 + li;
+                if (m >= Mc) continue;
+                const float b0 = P0.bias ? P0.bias[m_lo + m] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = row0 + 4 * lk + r;
+                    if (row >= A.N) continue;
+                    const size_t o = (size_t)row * A.M + m_lo + m;
+                    float z = acc0[t][r] + b0;
+                    float z1 = DUAL ? acc1[t][r] : 0.f;
+                    if (A.act == 1) {
+                        const float ex = __builtin_amdgcn_exp2f(z * LOG2E_D);
+                        const bool big = z > 20.f;
+                        const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_D;
+                        const float sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
+                        if (P0.sig) P0.sig[o] = sg;
+                        z = (big ? z : sp) - LN2_D;
+                        z1 *= sg;                                   // tangent of the activation
+                    }
+                    if (P0.mul) z *= P0.mul[o];
+                    if (P0.res) z += P0.res[o];
+                    P0.out[o] = z;
+                    if (DUAL) {
+                        if (P1.res) z1 += P1.res[o];
+                        P1.out[o] = z1;
+                    }
                 }
             }
         }
@@ -161,8 +232,15 @@ extern "C" int mdg_dense(const float* W, int trans, int act, int n_rows, int k, 
     const int row_tiles = (n_rows + 63) / 64;
     dim3 grid(row_tiles < 256 ? row_tiles : 256, (m + DN_MC - 1) / DN_MC);
     const size_t lds = sizeof(float) * (size_t)((k + DN_KC - 1) / DN_KC * DN_KC) * DN_SB;
-    if (x1) hipLaunchKernelGGL(dense_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(dense_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    // 16-byte epilogue when every column chunk is 64 or 128 wide and all row pointers are 16-byte aligned
+    const uintptr_t al = (uintptr_t)mul0 | (uintptr_t)res0 | (uintptr_t)out0 | (uintptr_t)sig0 | (uintptr_t)res1 |
+                         (uintptr_t)out1 | (uintptr_t)bias0;
+    const int nt = ((al & 15) == 0 && m % 64 == 0 && (m <= DN_MC ? true : m % DN_MC == 0)) ? (m >= DN_MC ? 8 : 4) : 0;
+    hipStream_t st = (hipStream_t)stream;
+#define MDG_DENSE(D_, N_) hipLaunchKernelGGL((dense_kernel<D_, N_>), grid, dim3(256), lds, st, a)
+    if (x1) { if (nt == 8) MDG_DENSE(true, 8); else if (nt == 4) MDG_DENSE(true, 4); else MDG_DENSE(true, 0); }
+    else { if (nt == 8) MDG_DENSE(false, 8); else if (nt == 4) MDG_DENSE(false, 4); else MDG_DENSE(false, 0); }
+#undef MDG_DENSE
     MDG_CHECK_LAUNCH("dense_kernel");
     return MDG_OK;
 }

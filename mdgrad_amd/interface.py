@@ -106,6 +106,7 @@ class GNNPotentials(GeneralInteraction):
         self._reset_topology(torch.Tensor(system.get_positions()).to(system.device))
 
     def _reset_topology(self, xyz, _cache=None):
+        self._topo_stamp = object()                  # identity of this rebuild (see md._EOM.update_topology)
         st = self._static if self._static_on else None
         if st is not None:
             ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, max_nbr=st["max_nbr"],
@@ -198,6 +199,7 @@ class PairPotentials(GeneralInteraction):
         return self._ell.half_list()[1]
 
     def _reset_topology(self, xyz, _cache=None):
+        self._topo_stamp = object()
         st = self._static if self._static_on else None
         if st is not None:
             self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask,
@@ -406,6 +408,7 @@ class Stack(torch.nn.Module):
         return F, dq, [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
 
     def _reset_topology(self, x):
+        self._topo_stamp = object()
         shared = {}                          # one neighbour search per distinct (cutoff, selection, grouping)
         for key in self.models.keys():
             m = self.models[key]

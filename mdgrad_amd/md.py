@@ -155,7 +155,16 @@ class _EOM(torch.nn.Module):
 
     def update_topology(self, q):                               # md.py:200-204
         if self.update_count % self.topology_update_freq == 0:
-            self.model._reset_topology(q)
+            # The reference rebuilds here unconditionally; its adjoint asks twice in a row for the list at the
+            # very same saved frame (the dL/dt call of sovlers.py:258, then the first augmented evaluation).  A
+            # rebuild at the same tensor object (unchanged version, nobody else touched the model's topology in
+            # between) returns the same list, so it is skipped; the counter still advances.
+            m = self.model
+            same = (getattr(self, "_topo_q", None) is q and self._topo_ver == q._version
+                    and getattr(m, "_topo_stamp", None) is self._topo_stamp)
+            if not same:
+                m._reset_topology(q)
+                self._topo_q, self._topo_ver, self._topo_stamp = q, q._version, getattr(m, "_topo_stamp", None)
         self.update_count += 1
 
     def fused_spec(self, method):
