@@ -48,7 +48,111 @@ struct LargeArgs {
     float *adj_v0, *adj_q0, *adj_pv0, *adj_theta;
     int nbF, nbE;                            // workgroups of the per-atom / per-element kernels
     int step;                                // forward: step index k; adjoint: frame index i
+    // cell-binned neighbour scan (orthorhombic cell, >= 3 bins of >= cutoff per dimension): positions sorted by
+    // (bin, atom index) as (x, y, z, index) and the first slot of every bin, rebuilt before each force evaluation
+    float4* spos;                            // [R][N]
+    int32_t* bstart;                         // [R][ncell + 1]
+    int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
 };
+
+// ---------------------------------------------------------------------------------------------
+// Binning: one workgroup per replica.  Counting sort with LDS atomics, then every bin is put in ascending atom
+// order (bins hold ~20 atoms), so the candidate order of the force kernels -- and with it every sum -- is fixed.
+// src: 0 = running positions A.q, 1 = saved frame A.step of q_t, 2 = the adjoint's midpoint positions A.qm
+constexpr int LG_BIN_THREADS = 1024;
+constexpr int LG_MAX_CELLS = 4096;
+
+__device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
+    float fr = x * inv;
+    fr -= floorf(fr);
+    const int b = (int)(fr * (float)nb);
+    return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
+}
+
+__global__ __launch_bounds__(LG_BIN_THREADS) void large_bin_kernel(const LargeArgs A, const int src) {
+    __shared__ int32_t cnt[LG_MAX_CELLS + 1];
+    __shared__ int32_t wsum[LG_BIN_THREADS / 64];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.x, nc = A.ncell;
+    const size_t so = (size_t)rep * N * 3;
+    const float* q = src == 0 ? A.q + so : (src == 1 ? A.q_t + ((size_t)rep * T + A.step) * N * 3 : A.qm + so);
+    float4* sp = A.spos + (size_t)rep * N;
+    int32_t* bs = A.bstart + (size_t)rep * (nc + 1);
+    for (int c = threadIdx.x; c <= nc; c += blockDim.x) cnt[c] = 0;
+    __syncthreads();
+    // pass 1: bin of every atom, slot inside the bin from an LDS atomic (order fixed later)
+    constexpr int PER = 16;                                      // atoms per thread kept in registers (N <= 16 384)
+    int mybin[PER], myslot[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = threadIdx.x + u * LG_BIN_THREADS;
+        mybin[u] = -1; myslot[u] = 0;
+        if (i < N) {
+            const int bx = bin_coord_l(q[3 * i], A.cell.inv[0], A.nb[0]);
+            const int by = bin_coord_l(q[3 * i + 1], A.cell.inv[4], A.nb[1]);
+            const int bz = bin_coord_l(q[3 * i + 2], A.cell.inv[8], A.nb[2]);
+            mybin[u] = (bx * A.nb[1] + by) * A.nb[2] + bz;
+            myslot[u] = atomicAdd(&cnt[mybin[u]], 1);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts (in place), fixed order
+    {
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        int carry = 0;
+        for (int base = 0; base < nc; base += LG_BIN_THREADS) {
+            const int k = base + threadIdx.x;
+            const int v = k < nc ? cnt[k] : 0;
+            int x = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+            if (lane == 63) wsum[wid] = x;
+            __syncthreads();
+            int woff = 0, tot = 0;
+            for (int w = 0; w < LG_BIN_THREADS / 64; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
+            if (k < nc) cnt[k] = carry + woff + x - v;
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) cnt[nc] = carry;
+        __syncthreads();
+    }
+    for (int c = threadIdx.x; c <= nc; c += blockDim.x) bs[c] = cnt[c];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int i = threadIdx.x + u * LG_BIN_THREADS;
+        if (i < N) sp[cnt[mybin[u]] + myslot[u]] = make_float4(q[3 * i], q[3 * i + 1], q[3 * i + 2], __int_as_float(i));
+    }
+    __threadfence_block();
+    __syncthreads();
+    // pass 2: ascending atom index inside every bin (one wave per bin, rank sort; entries are distinct)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int c = wid; c < nc; c += LG_BIN_THREADS / 64) {
+        const int a0 = cnt[c], n = cnt[c + 1] - a0;
+        if (n <= 1) continue;
+        // (n <= 64 for any liquid; larger bins take the strided loop)
+        float4 mine[4];
+        int rank[4];
+        const int per = (n + 63) / 64;
+        if (per > 4) continue;                                   // > 256 atoms in one bin: left in atomic order (still exact)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + 64 * u;
+            rank[u] = 0;
+            mine[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (u < per && k < n) {
+                mine[u] = sp[a0 + k];
+                const int key = __float_as_int(mine[u].w);
+                for (int l = 0; l < n; ++l) rank[u] += __float_as_int(sp[a0 + l].w) < key;
+            }
+        }
+        // (all reads of this bin happen before its writes: same wave, program order)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = lane + 64 * u;
+            if (u < per && k < n) sp[a0 + rank[u]] = mine[u];
+        }
+    }
+}
 
 __device__ __forceinline__ float bath_rhs_l(const MdgTrajParams& p, const float* Q, const float* pv, float ke, int k) {
     const int C = p.n_chains;
@@ -77,7 +181,7 @@ __device__ __forceinline__ float reduce_partials(const float* __restrict__ part,
 // One wave: neighbours of atom i from the LDS-staged tiles, then force (LEVEL 1) or force + HVP +
 // parameter vjp (LEVEL 2) over the compact list.  Results valid on every lane after the call.
 //   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m ; th += d(w.F)/dtheta partial
-template <bool DIAG, int LEVEL>
+template <bool DIAG, int LEVEL, int KIND = -1>
 __device__ __forceinline__ void wave_neighbours_and_force(
     const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
     float* tile, float4* buf, float& fx, float& fy, float& fz, float& gx, float& gy, float& gz,
@@ -85,6 +189,50 @@ __device__ __forceinline__ void wave_neighbours_and_force(
     const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
     const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
     int n = 0;
+    if (DIAG && A.ncell > 0) {
+        // ---- cell-binned scan: the 3 x 3 stencil columns around atom i's bin, each column's three z-bins being one
+        // contiguous range of the (bin, index)-sorted positions (two when it wraps); same pair test as below
+        if (valid) {
+            const float iv0 = A.cell.inv[0], iv1 = A.cell.inv[4], iv2 = A.cell.inv[8];
+            const float h0 = A.cell.h[0], h1 = A.cell.h[4], h2 = A.cell.h[8];
+            const float4* sp = A.spos + (size_t)rep * N;
+            const int32_t* bs = A.bstart + (size_t)rep * (A.ncell + 1);
+            const int nbx = A.nb[0], nby = A.nb[1], nbz = A.nb[2];
+            const int bx = bin_coord_l(xi, iv0, nbx), by = bin_coord_l(yi, iv1, nby), bz = bin_coord_l(zi, iv2, nbz);
+            for (int s = 0; s < 18; ++s) {
+                const int colm = s >> 1, part = s & 1;
+                const int cx = (bx + colm / 3 - 1 + nbx) % nbx, cy = (by + colm % 3 - 1 + nby) % nby;
+                const int cb = (cx * nby + cy) * nbz;
+                int zlo = bz - 1, zhi = bz + 1;
+                if (part == 0) { zlo = max(zlo, 0); zhi = min(zhi, nbz - 1); }
+                else if (bz == 0) { zlo = zhi = nbz - 1; }
+                else if (bz == nbz - 1) { zlo = zhi = 0; }
+                else continue;
+                const int a0 = bs[cb + zlo], a1 = bs[cb + zhi + 1];
+                for (int a = a0; a < a1; a += 64) {
+                    const int idx = a + lane;
+                    bool ok = false;
+                    float dx = 0.f, dy = 0.f, dz = 0.f;
+                    int j = -1;
+                    if (idx < a1) {
+                        const float4 pj = sp[idx];
+                        j = __float_as_int(pj.w);
+                        f32x2 ddx = f32x2{pj.x, 0.f} - xi, ddy = f32x2{pj.y, 0.f} - yi, ddz = f32x2{pj.z, 0.f} - zi;
+                        ddx = min_image_diag2(ddx, iv0, h0); ddy = min_image_diag2(ddy, iv1, h1); ddz = min_image_diag2(ddz, iv2, h2);
+                        const f32x2 d2 = norm2_ref2(ddx, ddy, ddz);
+                        dx = ddx.x; dy = ddy.x; dz = ddz.x;
+                        ok = (j != i) & (d2.x < rc2max) & (d2.x != 0.f);
+                    }
+                    const unsigned long long b = __ballot(ok);
+                    if (ok) {
+                        const int k = n + __popcll(b & ((1ull << lane) - 1ull));
+                        if (k < LG_CAP) buf[k] = make_float4(dx, dy, dz, __int_as_float(j));
+                    }
+                    n += __popcll(b);
+                }
+            }
+        }
+    } else
     for (int t0 = 0; t0 < N; t0 += LG_TILE) {
         const int tn = min(LG_TILE, N - t0);
         __syncthreads();
@@ -156,7 +304,7 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             if (mk && !mk[(size_t)i * N + j]) continue;
             PairOut o;
             float r, ir;
-            pair_eval<LEVEL, -1>(tc[m], d2, r, ir, o);
+            pair_eval<LEVEL, KIND>(tc[m], d2, r, ir, o);
             if (tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
             const float c1 = o.du * ir;
             fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
@@ -205,7 +353,7 @@ __device__ __forceinline__ float prepare_terms(const LargeArgs& A, TermConst (&t
 
 // ------------------------------------------------------------------------------------ forward
 // MODE 0: initial force at q0 + frame 0 + KE(v0) partials.   MODE 1: second half of step k.
-template <bool DIAG, int MODE>
+template <bool DIAG, int MODE, int KIND>
 __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) {
     __shared__ float tile[3 * LG_TILE];
     __shared__ float4 nbuf[LG_WAVES * LG_CAP];
@@ -245,8 +393,8 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     const int i = blockIdx.x * LG_WAVES + wid;
     const bool valid = i < N;
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
-    wave_neighbours_and_force<DIAG, 1>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
-                                       th, tc, rc2max);
+    wave_neighbours_and_force<DIAG, 1, KIND>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
+                                             th, tc, rc2max, 0.f, rep);
     float kepart = 0.f;
     if (valid && lane < 3) {
         const float F = lane == 0 ? fx : (lane == 1 ? fy : fz);
@@ -318,7 +466,7 @@ __global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
 
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
-template <bool DIAG>
+template <bool DIAG, int KIND>
 __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, const int second) {
     __shared__ float tile[3 * LG_TILE];
     __shared__ float4 nbuf[LG_WAVES * LG_CAP];
@@ -338,8 +486,8 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
     for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
     // (table kind: the parameter term of an interval comes from the midpoint evaluation with weight h, :160)
     const float gw = (second && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
-    wave_neighbours_and_force<DIAG, 2>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
-                                       tc, rc2max, gw, rep);
+    wave_neighbours_and_force<DIAG, 2, KIND>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
+                                             tc, rc2max, gw, rep);
     float vals[LG_NV];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) vals[p] = th[p];
@@ -461,7 +609,7 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        total;
+        spos, bstart, total;
 };
 
 WsLayout ws_layout(int R, int N, int nb, int KT) {
@@ -479,6 +627,8 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
     w.ghi = take((size_t)R * (KT > 0 ? KT : 1));        // (int32 planes of the table kind; a few words otherwise)
     w.glo = take((size_t)R * (KT > 0 ? KT : 1));
     w.flags = take(16);
+    w.spos = take((size_t)R * N * 4);
+    w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
     w.total = o;
     return w;
 }
@@ -525,6 +675,21 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     a.glo = table ? reinterpret_cast<int32_t*>(ws + L.glo) : nullptr;                                \
     hipStream_t st = (hipStream_t)stream;                                                            \
     const bool diag = cell->diag != 0;                                                               \
+    a.spos = reinterpret_cast<float4*>(ws + L.spos);                                                 \
+    a.bstart = reinterpret_cast<int32_t*>(ws + L.bstart);                                            \
+    a.ncell = 0;                                                                                     \
+    if (diag && N <= 16 * LG_BIN_THREADS) {                                                          \
+        float rcmax = 0.f;                                                                           \
+        for (int m = 0; m < terms->n_terms; ++m) rcmax = terms->t[m].cutoff > rcmax ? terms->t[m].cutoff : rcmax; \
+        int nbx[3];                                                                                  \
+        bool ok = rcmax > 0.f;                                                                       \
+        for (int d = 0; d < 3 && ok; ++d) { nbx[d] = (int)floorf(cell->h[4 * d] / rcmax); ok = nbx[d] >= 3; } \
+        if (ok && (long long)nbx[0] * nbx[1] * nbx[2] <= LG_MAX_CELLS) {                             \
+            a.nb[0] = nbx[0]; a.nb[1] = nbx[1]; a.nb[2] = nbx[2]; a.ncell = nbx[0] * nbx[1] * nbx[2]; \
+        }                                                                                            \
+    }                                                                                                \
+    const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
+                       terms->t[0].p == 12 && terms->t[0].q == 6;                                    \
     (void)nbmax;
 
 extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
@@ -543,14 +708,20 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
                      hipMemcpyDeviceToDevice, st));
     dim3 gF(nbF, R), gE(nbE, R);
     a.step = 0;
-    if (diag) hipLaunchKernelGGL((large_force_step<true, 0>), gF, dim3(LG_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((large_force_step<false, 0>), gF, dim3(LG_BLOCK), 0, st, a);
+#define LG_FORCE_STEP(MODE_)                                                                                    \
+    do {                                                                                                        \
+        if (a.ncell) hipLaunchKernelGGL(large_bin_kernel, dim3(R), dim3(LG_BIN_THREADS), 0, st, a, 0);          \
+        if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a); \
+        else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);    \
+        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);            \
+    } while (0)
+    LG_FORCE_STEP(0);
     for (int k = 0; k + 1 < T; ++k) {
         a.step = k;
         hipLaunchKernelGGL(large_kick_drift, gE, dim3(256), 0, st, a);
-        if (diag) hipLaunchKernelGGL((large_force_step<true, 1>), gF, dim3(LG_BLOCK), 0, st, a);
-        else hipLaunchKernelGGL((large_force_step<false, 1>), gF, dim3(LG_BLOCK), 0, st, a);
+        LG_FORCE_STEP(1);
     }
+#undef LG_FORCE_STEP
     MDG_CHECK_LAUNCH("traj_fwd_large");
     return MDG_OK;
 }
@@ -590,12 +761,18 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     dim3 gF(nbF, R), gE(nbE, R);
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
-        if (diag) hipLaunchKernelGGL(large_adj_force<true>, gF, dim3(LG_BLOCK), 0, st, a, 0);
-        else hipLaunchKernelGGL(large_adj_force<false>, gF, dim3(LG_BLOCK), 0, st, a, 0);
+#define LG_ADJ_FORCE(SECOND_)                                                                                       \
+    do {                                                                                                            \
+        if (a.ncell) hipLaunchKernelGGL(large_bin_kernel, dim3(R), dim3(LG_BIN_THREADS), 0, st, a, (SECOND_) ? 2 : 1); \
+        if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);   \
+        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);       \
+        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);               \
+    } while (0)
+        LG_ADJ_FORCE(0);
         hipLaunchKernelGGL(large_adj_mid, gE, dim3(256), 0, st, a);
-        if (diag) hipLaunchKernelGGL(large_adj_force<true>, gF, dim3(LG_BLOCK), 0, st, a, 1);
-        else hipLaunchKernelGGL(large_adj_force<false>, gF, dim3(LG_BLOCK), 0, st, a, 1);
+        LG_ADJ_FORCE(1);
         hipLaunchKernelGGL(large_adj_end, gE, dim3(256), 0, st, a);
+#undef LG_ADJ_FORCE
     }
     MDG_HIP(hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     MDG_HIP(hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
