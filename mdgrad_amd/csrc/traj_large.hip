@@ -51,15 +51,20 @@ struct LargeArgs {
     // cell-binned neighbour scan (orthorhombic cell, >= 3 bins of >= cutoff per dimension): positions sorted by
     // (bin, atom index) as (x, y, z, index) and the first slot of every bin, rebuilt before each force evaluation
     float4* spos;                            // [R][N]
-    int32_t* bstart;                         // [R][ncell + 1]
+    int32_t* bstart;                         // [R][LG_MAX_CELLS + 1]
+    int32_t* bcount;                         // [2][R][LG_MAX_CELLS] ping-pong bin counters
+    int32_t* binslot;                        // [R][N] (slot << 12) | bin
     int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
 };
 
 // ---------------------------------------------------------------------------------------------
-// Binning: one workgroup per replica.  Counting sort with LDS atomics, then every bin is put in ascending atom
-// order (bins hold ~20 atoms), so the candidate order of the force kernels -- and with it every sum -- is fixed.
+// Binning, two small launches per force evaluation (all replicas at once):
+//   count: thread per atom -> bin, slot inside the bin from a global integer atomic
+//   fill : every workgroup scans its replica's bin counts in LDS (<= 4096 bins), then scatters its atoms'
+//          (x, y, z, index) to start[bin] + slot; it also clears the OTHER count buffer for the next evaluation
+// The slot order inside a bin depends on the atomic order; the force kernels therefore sort every atom's compacted
+// neighbour buffer by index, which restores the ascending-j order of the all-atom scan (same sums, same bits).
 // src: 0 = running positions A.q, 1 = saved frame A.step of q_t, 2 = the adjoint's midpoint positions A.qm
-constexpr int LG_BIN_THREADS = 1024;
 constexpr int LG_MAX_CELLS = 4096;
 
 __device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
@@ -69,89 +74,73 @@ __device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
     return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
 }
 
-__global__ __launch_bounds__(LG_BIN_THREADS) void large_bin_kernel(const LargeArgs A, const int src) {
-    __shared__ int32_t cnt[LG_MAX_CELLS + 1];
-    __shared__ int32_t wsum[LG_BIN_THREADS / 64];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.x, nc = A.ncell;
+__device__ __forceinline__ const float* bin_source(const LargeArgs& A, int src, int rep) {
+    const int N = A.prm.n_atoms, T = A.prm.n_frames;
     const size_t so = (size_t)rep * N * 3;
-    const float* q = src == 0 ? A.q + so : (src == 1 ? A.q_t + ((size_t)rep * T + A.step) * N * 3 : A.qm + so);
-    float4* sp = A.spos + (size_t)rep * N;
-    int32_t* bs = A.bstart + (size_t)rep * (nc + 1);
-    for (int c = threadIdx.x; c <= nc; c += blockDim.x) cnt[c] = 0;
+    return src == 0 ? A.q + so : (src == 1 ? A.q_t + ((size_t)rep * T + A.step) * N * 3 : A.qm + so);
+}
+
+__global__ __launch_bounds__(256) void large_bin_count(const LargeArgs A, const int src, const int which) {
+    const int N = A.prm.n_atoms, rep = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* q = bin_source(A, src, rep);
+    const int bx = bin_coord_l(q[3 * i], A.cell.inv[0], A.nb[0]);
+    const int by = bin_coord_l(q[3 * i + 1], A.cell.inv[4], A.nb[1]);
+    const int bz = bin_coord_l(q[3 * i + 2], A.cell.inv[8], A.nb[2]);
+    const int bin = (bx * A.nb[1] + by) * A.nb[2] + bz;
+    int32_t* cnt = A.bcount + ((size_t)which * A.prm.n_rep + rep) * LG_MAX_CELLS;
+    const int slot = atomicAdd(&cnt[bin], 1);
+    A.binslot[(size_t)rep * N + i] = (slot << 12) | bin;
+}
+
+__global__ __launch_bounds__(256) void large_bin_fill(const LargeArgs A, const int src, const int which) {
+    __shared__ int32_t start[LG_MAX_CELLS + 1];
+    __shared__ int32_t tsum[256];
+    const int N = A.prm.n_atoms, rep = blockIdx.y, nc = A.ncell;
+    const int32_t* cnt = A.bcount + ((size_t)which * A.prm.n_rep + rep) * LG_MAX_CELLS;
+    // exclusive scan of the replica's bin counts: 16 consecutive bins per thread + scan of the thread totals
+    int loc[16], tot = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int c = threadIdx.x * 16 + u;
+        loc[u] = c < nc ? cnt[c] : 0;
+        tot += loc[u];
+    }
+    tsum[threadIdx.x] = tot;
     __syncthreads();
-    // pass 1: bin of every atom, slot inside the bin from an LDS atomic (order fixed later)
-    constexpr int PER = 16;                                      // atoms per thread kept in registers (N <= 16 384)
-    int mybin[PER], myslot[PER];
+    if (threadIdx.x < 64) {                                     // wave 0: scan of 256 totals, 4 per lane
+        int v[4], s = 0;
 #pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int i = threadIdx.x + u * LG_BIN_THREADS;
-        mybin[u] = -1; myslot[u] = 0;
-        if (i < N) {
-            const int bx = bin_coord_l(q[3 * i], A.cell.inv[0], A.nb[0]);
-            const int by = bin_coord_l(q[3 * i + 1], A.cell.inv[4], A.nb[1]);
-            const int bz = bin_coord_l(q[3 * i + 2], A.cell.inv[8], A.nb[2]);
-            mybin[u] = (bx * A.nb[1] + by) * A.nb[2] + bz;
-            myslot[u] = atomicAdd(&cnt[mybin[u]], 1);
-        }
+        for (int u = 0; u < 4; ++u) { v[u] = tsum[threadIdx.x * 4 + u]; s += v[u]; }
+        int x = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)threadIdx.x >= o) x += y; }
+        int run = x - s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { tsum[threadIdx.x * 4 + u] = run; run += v[u]; }
     }
     __syncthreads();
-    // exclusive scan of the bin counts (in place), fixed order
-    {
-        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        int carry = 0;
-        for (int base = 0; base < nc; base += LG_BIN_THREADS) {
-            const int k = base + threadIdx.x;
-            const int v = k < nc ? cnt[k] : 0;
-            int x = v;
+    int run = tsum[threadIdx.x];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-            if (lane == 63) wsum[wid] = x;
-            __syncthreads();
-            int woff = 0, tot = 0;
-            for (int w = 0; w < LG_BIN_THREADS / 64; ++w) { if (w < wid) woff += wsum[w]; tot += wsum[w]; }
-            if (k < nc) cnt[k] = carry + woff + x - v;
-            carry += tot;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) cnt[nc] = carry;
-        __syncthreads();
+    for (int u = 0; u < 16; ++u) {
+        const int c = threadIdx.x * 16 + u;
+        if (c <= nc) start[c] = run;
+        run += loc[u];
     }
-    for (int c = threadIdx.x; c <= nc; c += blockDim.x) bs[c] = cnt[c];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int i = threadIdx.x + u * LG_BIN_THREADS;
-        if (i < N) sp[cnt[mybin[u]] + myslot[u]] = make_float4(q[3 * i], q[3 * i + 1], q[3 * i + 2], __int_as_float(i));
-    }
-    __threadfence_block();
     __syncthreads();
-    // pass 2: ascending atom index inside every bin (one wave per bin, rank sort; entries are distinct)
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int c = wid; c < nc; c += LG_BIN_THREADS / 64) {
-        const int a0 = cnt[c], n = cnt[c + 1] - a0;
-        if (n <= 1) continue;
-        // (n <= 64 for any liquid; larger bins take the strided loop)
-        float4 mine[4];
-        int rank[4];
-        const int per = (n + 63) / 64;
-        if (per > 4) continue;                                   // > 256 atoms in one bin: left in atomic order (still exact)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = lane + 64 * u;
-            rank[u] = 0;
-            mine[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (u < per && k < n) {
-                mine[u] = sp[a0 + k];
-                const int key = __float_as_int(mine[u].w);
-                for (int l = 0; l < n; ++l) rank[u] += __float_as_int(sp[a0 + l].w) < key;
-            }
-        }
-        // (all reads of this bin happen before its writes: same wave, program order)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int k = lane + 64 * u;
-            if (u < per && k < n) sp[a0 + rank[u]] = mine[u];
-        }
+    if (blockIdx.x == 0) {
+        int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
+        for (int c = threadIdx.x; c <= nc; c += blockDim.x) bs[c] = start[c];
+        int32_t* other = A.bcount + ((size_t)(which ^ 1) * A.prm.n_rep + rep) * LG_MAX_CELLS;
+        for (int c = threadIdx.x; c < nc; c += blockDim.x) other[c] = 0;
     }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* q = bin_source(A, src, rep);
+    const int bsl = A.binslot[(size_t)rep * N + i];
+    A.spos[(size_t)rep * N + start[bsl & 4095] + (bsl >> 12)] =
+        make_float4(q[3 * i], q[3 * i + 1], q[3 * i + 2], __int_as_float(i));
 }
 
 __device__ __forceinline__ float bath_rhs_l(const MdgTrajParams& p, const float* Q, const float* pv, float ke, int k) {
@@ -196,7 +185,7 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             const float iv0 = A.cell.inv[0], iv1 = A.cell.inv[4], iv2 = A.cell.inv[8];
             const float h0 = A.cell.h[0], h1 = A.cell.h[4], h2 = A.cell.h[8];
             const float4* sp = A.spos + (size_t)rep * N;
-            const int32_t* bs = A.bstart + (size_t)rep * (A.ncell + 1);
+            const int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
             const int nbx = A.nb[0], nby = A.nb[1], nbz = A.nb[2];
             const int bx = bin_coord_l(xi, iv0, nbx), by = bin_coord_l(yi, iv1, nby), bz = bin_coord_l(zi, iv2, nbz);
             for (int s = 0; s < 18; ++s) {
@@ -231,6 +220,24 @@ __device__ __forceinline__ void wave_neighbours_and_force(
                     n += __popcll(b);
                 }
             }
+            // ascending neighbour index (entries are distinct): rank sort inside the wave's buffer
+            const int m = n < LG_CAP ? n : LG_CAP;
+            float4 mine[LG_CAP / 64];
+            int rank[LG_CAP / 64];
+#pragma unroll
+            for (int u = 0; u < LG_CAP / 64; ++u) {
+                const int k = lane + 64 * u;
+                rank[u] = 0;
+                mine[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < m) {
+                    mine[u] = buf[k];
+                    const int key = __float_as_int(mine[u].w);
+                    for (int l = 0; l < m; ++l) rank[u] += __float_as_int(buf[l].w) < key;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < LG_CAP / 64; ++u)
+                if (lane + 64 * u < m) buf[rank[u]] = mine[u];
         }
     } else
     for (int t0 = 0; t0 < N; t0 += LG_TILE) {
@@ -609,7 +616,7 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, total;
+        spos, bstart, bcount, binslot, total;
 };
 
 WsLayout ws_layout(int R, int N, int nb, int KT) {
@@ -629,6 +636,8 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
     w.flags = take(16);
     w.spos = take((size_t)R * N * 4);
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
+    w.bcount = take((size_t)2 * R * LG_MAX_CELLS);
+    w.binslot = take((size_t)R * N);
     w.total = o;
     return w;
 }
@@ -677,8 +686,11 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     const bool diag = cell->diag != 0;                                                               \
     a.spos = reinterpret_cast<float4*>(ws + L.spos);                                                 \
     a.bstart = reinterpret_cast<int32_t*>(ws + L.bstart);                                            \
+    a.bcount = reinterpret_cast<int32_t*>(ws + L.bcount);                                            \
+    a.binslot = reinterpret_cast<int32_t*>(ws + L.binslot);                                          \
     a.ncell = 0;                                                                                     \
-    if (diag && N <= 16 * LG_BIN_THREADS) {                                                          \
+    int bin_phase = 0;                                                                               \
+    if (diag) {                                                                                      \
         float rcmax = 0.f;                                                                           \
         for (int m = 0; m < terms->n_terms; ++m) rcmax = terms->t[m].cutoff > rcmax ? terms->t[m].cutoff : rcmax; \
         int nbx[3];                                                                                  \
@@ -686,8 +698,10 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
         for (int d = 0; d < 3 && ok; ++d) { nbx[d] = (int)floorf(cell->h[4 * d] / rcmax); ok = nbx[d] >= 3; } \
         if (ok && (long long)nbx[0] * nbx[1] * nbx[2] <= LG_MAX_CELLS) {                             \
             a.nb[0] = nbx[0]; a.nb[1] = nbx[1]; a.nb[2] = nbx[2]; a.ncell = nbx[0] * nbx[1] * nbx[2]; \
+            MDG_HIP(hipMemsetAsync(a.bcount, 0, sizeof(int32_t) * (size_t)2 * R * LG_MAX_CELLS, st)); \
         }                                                                                            \
     }                                                                                                \
+    const dim3 gB((N + 255) / 256, R);                                                               \
     const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
                        terms->t[0].p == 12 && terms->t[0].q == 6;                                    \
     (void)nbmax;
@@ -710,7 +724,11 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     a.step = 0;
 #define LG_FORCE_STEP(MODE_)                                                                                    \
     do {                                                                                                        \
-        if (a.ncell) hipLaunchKernelGGL(large_bin_kernel, dim3(R), dim3(LG_BIN_THREADS), 0, st, a, 0);          \
+        if (a.ncell) {                                                                                          \
+            hipLaunchKernelGGL(large_bin_count, gB, dim3(256), 0, st, a, 0, bin_phase);                         \
+            hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, 0, bin_phase);                          \
+            bin_phase ^= 1;                                                                                     \
+        }                                                                                                       \
         if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a); \
         else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);    \
         else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);            \
@@ -763,7 +781,11 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
-        if (a.ncell) hipLaunchKernelGGL(large_bin_kernel, dim3(R), dim3(LG_BIN_THREADS), 0, st, a, (SECOND_) ? 2 : 1); \
+        if (a.ncell) {                                                                                              \
+            hipLaunchKernelGGL(large_bin_count, gB, dim3(256), 0, st, a, (SECOND_) ? 2 : 1, bin_phase);             \
+            hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, (SECOND_) ? 2 : 1, bin_phase);              \
+            bin_phase ^= 1;                                                                                         \
+        }                                                                                                           \
         if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);   \
         else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);       \
         else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);               \
