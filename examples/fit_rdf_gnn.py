@@ -3,10 +3,18 @@
 demo/fit_rdf_gnn.py:215-513 without plotting: CG-water Diamond box, SchNet + ExcludedVolume prior in a
 Stack, NoseHooverChain, `Simulations` epochs of `tau` steps continuing from the last frame, temperature
 annealing through `update_T`, RDF on every 20th frame, JS divergence + volume-weighted deviation
-(`compute_D`) loss, Adam + ReduceLROnPlateau.  R replicas are stacked in one state (System.replicate); small
-systems replay each integrator step from a captured HIP graph.
+(`compute_D`) loss, Adam + ReduceLROnPlateau.
+
+BASELINE config #5 ("8 replica trajectories x SchNet, bf16 cfconv MFMA, full fwd+adjoint, 8 x MI355X"): the
+`--replicas` independent trajectories (replica k is seeded with k, like the reference's `sim_list` loop,
+demo/fit_rdf_gnn.py:386-399) are sharded over the ranks with mdgrad_amd.dist -- one process per GPU, the
+replicas of a rank stacked in one state (System.replicate) -- forward + adjoint need no communication, ONE
+all-reduce of the parameter gradient per epoch precedes identical optimizer steps on every rank.  `--bf16` runs
+the filter network of the fused interaction block on bf16 MFMA operands.
 
     python examples/fit_rdf_gnn.py --size 4 --replicas 8 --epochs 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 \
+        examples/fit_rdf_gnn.py --size 8 --replicas 8 --bf16
     python examples/fit_rdf_gnn.py --target my_rdf.csv     # (r, g) columns instead of the synthetic target
 """
 import argparse
@@ -37,6 +45,8 @@ def main(argv=None):
     ap.add_argument("--T", type=float, default=298.0)
     ap.add_argument("--anneal-rate", type=float, default=5.0)
     ap.add_argument("--target", default=None)
+    ap.add_argument("--filters", type=int, default=128, help="n_filters of the SchNet (config #5: 128)")
+    ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands in the cfconv filter network")
     args = ap.parse_args(argv)
     from mdgrad_amd import fit, potentials as P, units
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
@@ -44,17 +54,26 @@ def main(argv=None):
     from mdgrad_amd.nn import get_model
     from mdgrad_amd.observable import rdf
     from mdgrad_amd.system import System, Diamond
-    dev = "cuda:0"
-    rng = np.random.default_rng(0)
+    from mdgrad_amd import dist as mdist
+    rank, world, dev = mdist.init()
+    lo, hi = mdist.shard_range(args.replicas, rank, world)      # this rank's replicas
+    if hi == lo:
+        raise SystemExit("fit_rdf_gnn: more ranks than replicas")
     a = fit.get_unit_len(0.997, 18.01528, 8)
     atoms = Diamond("O", (args.size,) * 3, a)
     atoms.masses[:] = 18.01528
     system = System(atoms, device=dev)
-    if args.replicas > 1:
-        system = system.replicate(args.replicas)
+    if hi - lo > 1:
+        system = system.replicate(hi - lo)
     L = a * args.size
-    system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.05, (len(system), 3)), L))
-    system.set_temperature(args.start_T * units.kB, rng=rng)
+    lat = atoms.get_positions()
+    pos, vel = [], []
+    for k in range(lo, hi):                                     # replica k: its own seed, whatever the sharding
+        rk = np.random.default_rng(k)
+        pos.append(np.mod(lat + rk.normal(0, 0.05, lat.shape), L))
+        vel.append(rk.normal(0, np.sqrt(args.start_T * units.kB / 18.01528), lat.shape))
+    system.set_positions(np.concatenate(pos))
+    system.set_velocities(np.concatenate(vel))
 
     cutoff, nbins = 6.0, 60
     r_range = (2.0, min(cutoff, 0.49 * L))
@@ -63,7 +82,9 @@ def main(argv=None):
     bins, g_target = fit.get_exp_rdf(data, nbins, r_range, dev)
 
     torch.manual_seed(0)
-    net = get_model({"n_atom_basis": 64, "n_filters": 64, "n_gaussians": 30, "n_convolutions": 2, "cutoff": cutoff})
+    net = get_model({"n_atom_basis": 64, "n_filters": args.filters, "n_gaussians": 30, "n_convolutions": 2,
+                     "cutoff": cutoff})
+    net.filter_bf16 = bool(args.bf16)
     with torch.no_grad():                                       # start from a gentle correction to the prior
         net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
     prior = P.ExcludedVolume(2.6, 0.01, 12)
@@ -86,11 +107,22 @@ def main(argv=None):
         loss_js = fit.JS_rdf(g_target, g)
         loss = fit.compute_D(g - g_target, rho, rrange)
         loss.backward()
+        mdist.all_reduce_grads(net.parameters(), average=True)   # the one collective per outer step
         opt.step()
         opt.zero_grad()
-        sched.step(float(loss.detach()))
-        hist.append((float(loss.detach()), float(loss_js.detach()), new_T))
-        print("epoch %3d | T %.1f K | loss %.5f | JS %.5f" % (i, new_T, hist[-1][0], hist[-1][1]), flush=True)
+        gl = mdist.sum_over_ranks(float(loss.detach()), dev) / world
+        gjs = mdist.sum_over_ranks(float(loss_js.detach()), dev) / world
+        sched.step(gl)
+        hist.append((gl, gjs, new_T))
+        if rank == 0:
+            print("epoch %3d | T %.1f K | loss %.5f | JS %.5f" % (i, new_T, gl, gjs), flush=True)
+    # every rank applied the same updates: the parameters must agree bit for bit
+    checksum = float(sum(p.detach().double().sum() for p in net.parameters()))
+    print("PARAM_CHECKSUM rank %d of %d replicas [%d,%d) %.12e" % (rank, world, lo, hi, checksum), flush=True)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        mdist.barrier()
+        tdist.destroy_process_group()
     return hist
 
 

@@ -318,6 +318,11 @@ int mdg_edge_geom_bwd(const float* d_b, const float* dd_b, const float* d, const
 int mdg_cfconv_fwd(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const float* h, const float* hd,
                    const int32_t* col, const int32_t* eid, const int32_t* cnt, int n_atoms, int max_nbr,
                    float* m, float* md, float* hsum, float* hdsum, void* stream);
+/* bf16-operand MFMA variant of mdg_cfconv_fwd (v_mfma_f32_16x16x32_bf16; fp32 accumulate, biases, activation,
+ * products with the node rows and sums): BASELINE config #5's "bf16 cfconv MFMA" on the trajectory path. */
+int mdg_cfconv_fwd_bf16(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const float* h,
+                        const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt, int n_atoms,
+                        int max_nbr, float* m, float* md, float* hsum, float* hdsum, void* stream);
 int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges);
 int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
                    int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,

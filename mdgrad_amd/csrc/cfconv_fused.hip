@@ -258,6 +258,172 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand variant of the forward / tangent kernel (BASELINE config #5: "bf16 cfconv MFMA"):
+// v_mfma_f32_16x16x32_bf16 -- K = 32 per instruction, so G <= 32 needs ONE MFMA per 16 x 16 tile of either Dense
+// layer (20 per 16-slot tile for primal + tangent instead of 160 f32 ones).  Operands (Gaussians, W1, ssp output,
+// W2) are rounded to bf16 (round-to-nearest-even); accumulation, biases, activation, the multiply with the gathered
+// node rows and the per-atom sums stay fp32.  Operand layout: lane (li, lk) holds k = 32 ks + 8 lk + [0, 8).
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+template <int GP, int FT, bool TANGENT>          // GP in {32, 64}
+__global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int FP = 16 * FT;
+    constexpr int KSB = GP + 8;                    // bf16 row stride (elements): 16-B aligned rows, conflict-free b128 reads
+    constexpr int KB = GP / 32;
+    float* mus = sm;                               // [GP] centres, [GP] c log2e, [GP] 2c, [GP] b1, [FP] b2 (permuted)
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    float* b2s = b1s + GP;
+    unsigned short* w1b = reinterpret_cast<unsigned short*>(b2s + FP);      // [GP rows j][KSB]   W1[j][k]
+    unsigned short* w2b = w1b + GP * KSB;                                    // [FP rows c][KSB]   W2[f(c)][k]
+    unsigned short* h1s = w2b + FP * KSB;                                    // [4 (+4) waves][16][KSB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = A.net.G, F = A.net.F;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int j = t / GP, k = t % GP;
+        w1b[j * KSB + k] = (j < G && k < G) ? f2bf(A.net.W1[j * G + k]) : 0;
+    }
+    for (int t = tid; t < FP * GP; t += 256) {
+        const int c = t / GP, k = t % GP;
+        const int f = (c & 15) * FT + (c >> 4);
+        w2b[c * KSB + k] = (f < F && k < G) ? f2bf(A.net.W2[(size_t)f * G + k]) : 0;
+    }
+    for (int k = tid; k < GP; k += 256) {
+        const float c = k < G ? A.net.coef[k] : 0.f;
+        mus[k] = k < G ? A.net.mu[k] : 0.f;
+        cfs[k] = c * LOG2E;
+        c2s[k] = 2.f * c;
+        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+    }
+    for (int c = tid; c < FP; c += 256) {
+        const int f = (c & 15) * FT + (c >> 4);
+        b2s[c] = f < F ? A.net.b2[f] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    unsigned short* h1w = h1s + wid * 16 * KSB;
+    unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
+    const int nb = gridDim.x;
+    const int per = (A.N + nb - 1) / nb;
+    const int b = xcd_chunk(blockIdx.x, nb);
+    const int n_lo = b * per, n_hi = min(A.N, n_lo + per);
+    for (int n = n_lo + wid; n < n_hi; n += 4) {
+        const int cnt = A.cnt[n];
+        const size_t rowb = (size_t)n * A.max_nbr;
+        float macc[FT], mdacc[FT], hs[FT], hds[FT];
+#pragma unroll
+        for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
+        for (int t0 = 0; t0 < cnt; t0 += 16) {
+            const bool va = t0 + li < cnt;
+            const int ea = va ? A.eid[rowb + t0 + li] : 0;
+            const float da = va ? A.d[ea] : PAD_D;
+            float dda = 0.f;
+            if (TANGENT) dda = va ? A.dd[ea] : 0.f;
+            float hreg[4][FT], hdreg[4][FT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = t0 + 4 * lk + r;
+                const bool vc = s < cnt;
+                const int j = vc ? A.col[rowb + s] : 0;
+                load_row<FT>(A.h, j, F, li, vc, hreg[r]);
+                if (TANGENT) load_row<FT>(A.hd, j, F, li, vc && A.hd != nullptr, hdreg[r]);
+            }
+            bf16x8 af[KB], adf[KB];
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int k = ks * 32 + lk * 8 + t;
+                    const float x = da - mus[k];
+                    const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                    af[ks][t] = (short)f2bf(g);
+                    if (TANGENT) adf[ks][t] = (short)f2bf(g * (c2s[k] * x) * dda);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < GP / 16; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&w1b[(nt * 16 + li) * KSB + ks * 32 + lk * 8]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr, acc, 0, 0, 0);
+                    if (TANGENT) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adf[ks], bfr, accd, 0, 0, 0);
+                }
+                const int c = nt * 16 + li;
+                const float bias = b1s[c];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s, sg;
+                    ssp_sig(acc[r] + bias, s, sg);
+                    h1w[(lk * 4 + r) * KSB + c] = f2bf(s);
+                    if (TANGENT) h1dw[(lk * 4 + r) * KSB + c] = f2bf(sg * accd[r]);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+                af[ks] = *reinterpret_cast<const bf16x8*>(&h1w[li * KSB + ks * 32 + lk * 8]);
+                if (TANGENT) adf[ks] = *reinterpret_cast<const bf16x8*>(&h1dw[li * KSB + ks * 32 + lk * 8]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < FT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&w2b[(nt * 16 + li) * KSB + ks * 32 + lk * 8]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr, acc, 0, 0, 0);
+                    if (TANGENT) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adf[ks], bfr, accd, 0, 0, 0);
+                }
+                const float bias = b2s[nt * 16 + li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float W = acc[r] + bias;
+                    macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
+                    hs[nt] += hreg[r][nt];
+                    if (TANGENT) {
+                        mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
+                        mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
+                        hds[nt] += hdreg[r][nt];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < FT; ++v) {
+            macc[v] += __shfl_xor(macc[v], 16, 64); macc[v] += __shfl_xor(macc[v], 32, 64);
+            if (TANGENT) { mdacc[v] += __shfl_xor(mdacc[v], 16, 64); mdacc[v] += __shfl_xor(mdacc[v], 32, 64); }
+        }
+        if (A.hsum) {
+#pragma unroll
+            for (int v = 0; v < FT; ++v) {
+                hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
+                if (TANGENT) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
+            }
+        }
+        if (lk == 0) {
+            store_row<FT>(A.m, n, F, li, macc);
+            if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
+            if (A.hsum) store_row<FT>(A.hsum, n, F, li, hs);
+            if (TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+        }
+    }
+}
+
+template <int GP, int FT>
+size_t fwd_bf16_lds_bytes(bool tangent) {
+    constexpr int FP = 16 * FT, KSB = GP + 8;
+    return sizeof(float) * (4 * GP + FP) + sizeof(unsigned short) * ((size_t)GP * KSB + (size_t)FP * KSB + (tangent ? 8 : 4) * 16 * KSB);
+}
+
 template <int GP, int FT>
 size_t fwd_lds_bytes(bool tangent) {
     constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;
@@ -757,6 +923,39 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     else MDG_FWD(64, 8);
 #undef MDG_FWD
     MDG_CHECK_LAUNCH("cfconv_fwd_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, const float* dd, const float* h,
+                                   const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                                   int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
+                                   void* stream) {
+    int GP, FT;
+    int rc = shape_ok(net, GP, FT);
+    if (rc) return rc;
+    MDG_CHECK_ARG(d && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd_bf16: bad arguments");
+    const bool tangent = dd != nullptr;
+    MDG_CHECK_ARG(!tangent || md, "cfconv_fwd_bf16: the tangent sweep needs md");
+    MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd_bf16: tangent buffers without dd");
+    MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
+                  "cfconv_fwd_bf16: node feature matrices must be 16-byte aligned");
+    FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
+    const int want = 768;
+    const int nb = (n_atoms + 3) / 4 < want ? (n_atoms + 3) / 4 : want;
+    hipStream_t st = (hipStream_t)stream;
+#define MDG_FWDB(GP_, FT_)                                                                                         \
+    do {                                                                                                           \
+        if (tangent)                                                                                               \
+            hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, true>), dim3(nb), dim3(256), (fwd_bf16_lds_bytes<GP_, FT_>(true)), st, a); \
+        else                                                                                                       \
+            hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, false>), dim3(nb), dim3(256), (fwd_bf16_lds_bytes<GP_, FT_>(false)), st, a); \
+    } while (0)
+    if (GP == 32 && FT == 4) MDG_FWDB(32, 4);
+    else if (GP == 32) MDG_FWDB(32, 8);
+    else if (FT == 4) MDG_FWDB(64, 4);
+    else MDG_FWDB(64, 8);
+#undef MDG_FWDB
+    MDG_CHECK_LAUNCH("cfconv_fwd_bf16_kernel");
     return MDG_OK;
 }
 

@@ -233,7 +233,8 @@ def _forward_fused(net, z, x, topo, w=None, want_sums=False):
     layers = []
     for conv in net.convolutions:
         P = _layer_params(conv)
-        fn = ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"])
+        fn = ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"],
+                           bf16=getattr(conv, "filter_bf16", False) or getattr(net, "filter_bf16", False))
         h, _, hd = _dense(P["Wn"], r, bias=P["bn"], x1=rd)                       # message_node_filter (+ tangent)
         m, md, hsum, hdsum = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums)
         # update MLP: t = ssp(U1 m + c1), su = sigmoid(.), td = su * (U1 md)

@@ -754,7 +754,8 @@ class FilterNet:
     """Device-side description of one SchNetConv filter network for the fused kernels (csrc/cfconv_fused.hip):
     Gaussian centres / coefficients and the two Dense layers, as contiguous fp32 tensors kept alive here."""
 
-    def __init__(self, mu, coef, W1, b1, W2, b2):
+    def __init__(self, mu, coef, W1, b1, W2, b2, bf16=False):
+        self.bf16 = bool(bf16)                   # bf16 MFMA operands in the forward / tangent / aggregation sweeps
         self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
         self.G, self.F = int(self.t[0].shape[0]), int(self.t[4].shape[0])
         s = _lib.MdgFilterNet()
@@ -809,8 +810,9 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     md = torch.empty(N, fnet.F, device=dev) if dd is not None else None
     hsum = torch.empty(N, fnet.F, device=dev) if want_sums else None
     hdsum = torch.empty(N, fnet.F, device=dev) if (want_sums and hd is not None) else None
-    check(lib.mdg_cfconv_fwd(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(h), ptr(hd), ptr(e.col), ptr(topo.eid), ptr(e.cnt),
-                             N, e.max_nbr, ptr(m), ptr(md), ptr(hsum), ptr(hdsum), stream_ptr(dev)), "mdg_cfconv_fwd")
+    fn = lib.mdg_cfconv_fwd_bf16 if fnet.bf16 else lib.mdg_cfconv_fwd
+    check(fn(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(h), ptr(hd), ptr(e.col), ptr(topo.eid), ptr(e.cnt),
+             N, e.max_nbr, ptr(m), ptr(md), ptr(hsum), ptr(hdsum), stream_ptr(dev)), "mdg_cfconv_fwd")
     return m, md, hsum, hdsum
 
 

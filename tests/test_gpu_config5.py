@@ -1,0 +1,105 @@
+"""BASELINE config #5 -- demo/fit_rdf_gnn.py's training loop with replica trajectories sharded over the GPUs of a node
+and the cfconv filter network on bf16 MFMA operands:
+
+  * the bf16 variant of the fused forward / tangent kernel against its f32 sibling (bf16 tolerance);
+  * a 10-step SchNet + prior NHC trajectory and the adjoint of an RDF loss with `filter_bf16` against the REFERENCE
+    golden (G9), with the tolerance bf16 operands allow;
+  * examples/fit_rdf_gnn.py under torch.distributed.run with TWO ranks sharing device 0 (gloo carries the one
+    gradient all-reduce; RCCL refuses two ranks on one device): the N > 1 code path of the loop, end to end.
+
+bf16 tolerance: operands carry 8 significant bits (2^-9 relative rounding); a filter value is a K <= 64 term dot
+product of such operands, so outputs agree to ~1e-2 of their scale; trajectories over 10 steps stay within 2e-3 A."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_parity import T, close, mk_system, DEV
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("G,F", [(30, 128), (16, 48), (41, 64)])
+def test_bf16_forward_kernel_vs_f32(G, F):
+    from mdgrad_amd import ops
+    from test_gpu_fused_block import _setup
+    x, topo, net = _setup(G, F, seed=11 * G + F)
+    N = topo.n_atoms
+    w = torch.randn(N, 3, device=DEV)
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    h, hd = torch.randn(N, F, device=DEV), torch.randn(N, F, device=DEV)
+    ref = ops.cfconv_fwd(ops.FilterNet(*net), d, dd, h, hd, topo, want_sums=True)
+    got = ops.cfconv_fwd(ops.FilterNet(*net, bf16=True), d, dd, h, hd, topo, want_sums=True)
+    for a, b, nm in zip(got, ref, ("m", "md", "hsum", "hdsum")):
+        tol = 0.0 if nm.startswith("h") else 2e-2 * float(b.abs().max())     # the plain neighbour sums are fp32 in both
+        close(a, b, 0, tol + 1e-6, "bf16 " + nm)
+    again = ops.cfconv_fwd(ops.FilterNet(*net, bf16=True), d, dd, h, hd, topo)
+    assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1]), "bitwise reproducible"
+    prim = ops.cfconv_fwd(ops.FilterNet(*net, bf16=True), d, None, h, None, topo)
+    assert torch.equal(prim[0], got[0]), "primal bits do not depend on the tangent riding along"
+
+
+def test_bf16_filter_trajectory_and_adjoint_vs_reference_golden():
+    """Stack(SchNet + ExcludedVolume prior), NHC, 10 steps, RDF loss, adjoint -- the golden G9 of the fp32 reference,
+    run with the filter network on bf16 MFMA operands."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from test_gpu_schnet import params_of, sd_of
+    g = load_golden("gnn_traj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    net.filter_bf16 = True
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12),
+                           cutoff=float(g["cutoff"]))
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=float(g["T"]), num_chains=int(g["chains"]),
+                            Q=float(g["Q"]), adjoint=True).to(DEV)
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(g["dt"]) * i for i in range(11)]).to(DEV)
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    close(q_t, g["q_t"], 0, 2e-3, "q_t (bf16 filter)")
+    close(v_t, g["v_t"], 0, 2e-2 * np.abs(g["v_t"]).max(), "v_t (bf16 filter)")
+    _, _, gr = rdf(system, nbins=40, r_range=(2.0, 5.5))(q_t[::2])
+    close(gr, g["g"], 0, 2e-2, "g(r) (bf16 filter)")
+    loss = gr.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3
+    loss.backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
+    ref = g["grad_flat"]
+    assert torch.isfinite(flat).all()
+    cos = float((flat.cpu().double() * torch.tensor(ref).double()).sum() / (flat.cpu().double().norm() * np.linalg.norm(ref)))
+    assert cos > 0.999, "dL/dtheta direction (cosine %.5f)" % cos
+    close(flat, ref, 0, 5e-2 * np.abs(ref).max(), "dL/dtheta (bf16 filter)")
+    close(y0[1].grad, g["grad_q0"], 0, 5e-2 * np.abs(g["grad_q0"]).max(), "grad_q0 (bf16 filter)")
+
+
+def test_fit_rdf_gnn_two_ranks_on_one_device():
+    """torch.distributed.run, 2 ranks, both on cuda:0 (MDG_SINGLE_DEVICE=1), gloo for the one all-reduce per epoch:
+    4 replica trajectories sharded 2 + 2, bf16 filter, 2 epochs.  Both ranks must finish with bit-identical
+    parameters and a finite loss."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1", MDG_GRAPHS="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "examples", "fit_rdf_gnn.py"), "--size", "2", "--replicas", "4",
+           "--epochs", "2", "--tau", "20", "--bf16"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    sums = re.findall(r"PARAM_CHECKSUM rank (\d) of 2 replicas \[(\d),(\d)\) (\S+)", r.stdout)
+    assert sorted((a, b, c) for a, b, c, _ in sums) == [("0", "0", "2"), ("1", "2", "4")], r.stdout[-1000:]
+    assert sums[0][3] == sums[1][3], "ranks diverged: %s" % sums
+    losses = [float(x) for x in re.findall(r"loss (\S+) \|", r.stdout)]
+    assert len(losses) == 2 and all(np.isfinite(losses))
