@@ -277,6 +277,21 @@ int mdg_cfconv_filter_bf16(const float* d, int64_t n_edges, const float* mu, con
                            int n_filters, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Velocity observables as single fused passes over v_t [T, N, 3]:
+ *   mdg_vacf_fwd     out[t] = mean over frames s, atoms, components of v[s+t] v[s], t = 0 .. n_lags-1
+ *                    (torchmd/observable.py:153-163 vacf.forward; n_dof_per_frame = N * 3)
+ *   mdg_vacf_bwd     g_v = d(sum_t g_out[t] out[t]) / dv
+ *   mdg_temperature  out[f] = sum_n m_n |v_n|^2 / n_dof   (torchmd/thermo.py:57-66 on every frame; n_dof = N * dim)
+ * workspace: mdg_vacf_workspace(n_lags) floats.
+ */
+int64_t mdg_vacf_workspace(int n_lags);
+int mdg_vacf_fwd(const float* v, int n_frames, int64_t n_dof_per_frame, int n_lags, float* out, float* workspace,
+                 void* stream);
+int mdg_vacf_bwd(const float* v, const float* g_out, int n_frames, int64_t n_dof_per_frame, int n_lags, float* g_v,
+                 void* stream);
+int mdg_temperature(const float* v, const float* mass, int n_frames, int n_atoms, float n_dof, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K9 + K10 fused: the whole SchNet interaction block on the MD path, nothing edge-sized in HBM
  * (replaces SchNetConv.message/aggregate -- nff/nn/modules.py:531-541,564-571, nff/nn/graphconv.py:43-53,
  *  the distance line nff/nn/models/schnet.py:142 -- and what autograd / double autograd derive from them for

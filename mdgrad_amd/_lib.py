@@ -93,6 +93,10 @@ _SIGNATURES = {
     "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
+    "mdg_vacf_workspace": (C.c_int64, [C.c_int]),
+    "mdg_vacf_fwd": (C.c_int, [P, C.c_int, C.c_int64, C.c_int, P, P, P]),
+    "mdg_vacf_bwd": (C.c_int, [P, P, C.c_int, C.c_int64, C.c_int, P, P]),
+    "mdg_temperature": (C.c_int, [P, P, C.c_int, C.c_int, C.c_float, P, P]),
     "mdg_cfconv_supported": (C.c_int, [C.c_int, C.c_int]),
     "mdg_edge_geom": (C.c_int, [P, P, P, P, C.c_int64, P, P, P, P, P]),
     "mdg_edge_geom_bwd": (C.c_int, [P, P, P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P]),

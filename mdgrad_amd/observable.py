@@ -1,6 +1,7 @@
 """Observables with the reference's interface (torchmd/observable.py): generate_vol_bins
 :10-21, Observable :24-31, rdf :33-76, vacf :153-163.  The pair search + Gaussian smearing +
-histogram of rdf.forward is one HIP op (ops.RdfRawFn, csrc/rdf.hip)."""
+histogram of rdf.forward is one HIP op (ops.RdfRawFn, csrc/rdf.hip); vacf is one fused reduction over the
+velocity trajectory (ops.VacfFn, csrc/observe.hip)."""
 import numpy as np
 import torch
 
@@ -70,6 +71,6 @@ class vacf(Observable):
         self.t_window = [i for i in range(1, t_range, 1)]
 
     def forward(self, vel):
-        vacf = [(vel * vel).mean()[None]]
-        vacf += [(vel[t:] * vel[:-t]).mean()[None] for t in self.t_window]
-        return torch.stack(vacf).reshape(-1)
+        """Lags 0 .. t_range-1 of the velocity autocorrelation of vel [T, N, 3] (mean over frames, atoms and
+        components per lag, torchmd/observable.py:158-163) from one fused HIP reduction (ops.VacfFn)."""
+        return ops.VacfFn.apply(vel, len(self.t_window) + 1)

@@ -412,7 +412,50 @@ class FusedTrajFn(torch.autograd.Function):
             adj_v, adj_q = adj_v[0], adj_q[0]
             adj_p = adj_p[0] if nhc else None
         gth = adj_th.sum(0) if adj_th is not None else None
-        return adj_v, adj_q, adj_p, None, gth, None
+        g_t = None
+        if ctx.needs_input_grad[3]:
+            g_t = _time_vjps(spec, tc, v_t, q_t, pv_t, gv, gq, gp)
+        return adj_v, adj_q, adj_p, g_t, gth, None
+
+
+def _time_vjps(spec, t, v_t, q_t, pv_t, gv, gq, gp):
+    """dL/dt of the adjoint (`time_vjps`, torchmd/sovlers.py:258-266,289-293): dL/dt_k = f(y_k) . dL/dy_k for
+    k >= 1 and dL/dt_0 = -(their sum); the right-hand side does not depend on t, so the adjoint of time is not
+    changed by the augmented integration.  Nobody on the hot path consumes it (the reference's drivers do not
+    either), so it is computed on request only -- one force evaluation per saved frame on the generic HIP ops."""
+    integ = getattr(spec, "_integrator", None)
+    if integ is None:
+        raise NotImplementedError("mdgrad_amd: dL/dt needs the integrator behind the fused spec")
+    R, T = v_t.shape[0], v_t.shape[1]
+    nhc = pv_t is not None
+    stacked = getattr(spec, "n_rep", 1) > 1
+    zero = lambda like: torch.zeros_like(like)
+    out = torch.zeros(T, device=v_t.device, dtype=t.dtype)
+    with torch.no_grad():
+        for k in range(1, T):
+            frames = [None] if stacked else range(R)
+            for r in frames:
+                if stacked:                                     # System.replicate: the model takes the stacked state
+                    v, q = v_t[:, k].reshape(-1, 3), q_t[:, k].reshape(-1, 3)
+                    pv = pv_t[:, k] if nhc else None
+                    g_v = gv[:, k].reshape(-1, 3) if gv is not None else zero(v)
+                    g_q = gq[:, k].reshape(-1, 3) if gq is not None else zero(q)
+                    g_p = (gp[:, k] if gp is not None else zero(pv)) if nhc else None
+                else:
+                    v, q = v_t[r, k], q_t[r, k]
+                    pv = pv_t[r, k] if nhc else None
+                    g_v = gv[r, k] if gv is not None else zero(v)
+                    g_q = gq[r, k] if gq is not None else zero(q)
+                    g_p = (gp[r, k] if gp is not None else zero(pv)) if nhc else None
+                integ.model._reset_topology(q)
+                F = integ.model.force(q)
+                if nhc:
+                    a, _, b = integ.rhs_from_force((v, q, pv), F)
+                    out[k] += (a * g_v).sum() + (v * g_q).sum() + (b * g_p).sum()
+                else:
+                    out[k] += (F * g_v).sum() + (v * g_q).sum()              # NVE: dv/dt = F (md.py:145-148)
+        out[0] = -out[1:].sum()
+    return out
 
 
 # ----------------------------------------------------------------------------- rdf
@@ -449,6 +492,55 @@ class RdfRawFn(torch.autograd.Function):
         check(lib.mdg_rdf_bwd_uniform(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), spacing,
                                       coeff, B, ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
         return gx.reshape(shape), None, None, None, None, None, None
+
+
+# ----------------------------------------------------------------------------- velocity observables
+class VacfFn(torch.autograd.Function):
+    """vacf[t] = mean(v[t:] * v[:-t]) for t = 0 .. n_lags-1 (torchmd/observable.py:153-163) as one fused pass."""
+
+    @staticmethod
+    def forward(ctx, vel, n_lags):
+        lib = _lib.load()
+        require_gpu(vel, "vel")
+        v = vel.detach().contiguous()
+        T, M = v.shape[0], v[0].numel()
+        out = torch.empty(n_lags, device=v.device)
+        ws = torch.empty(int(lib.mdg_vacf_workspace(n_lags)), device=v.device)
+        check(lib.mdg_vacf_fwd(ptr(v), T, M, n_lags, ptr(out), ptr(ws), stream_ptr(v.device)), "mdg_vacf_fwd")
+        ctx.save_for_backward(v)
+        ctx.n_lags = n_lags
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (v,) = ctx.saved_tensors
+        gv = torch.empty_like(v)
+        gc = g.detach().to(torch.float32).contiguous()
+        check(lib.mdg_vacf_bwd(ptr(v), ptr(gc), v.shape[0], v[0].numel(), ctx.n_lags, ptr(gv), stream_ptr(v.device)),
+              "mdg_vacf_bwd")
+        return gv, None
+
+
+class TemperatureFn(torch.autograd.Function):
+    """Kinetic temperature sum_n m_n |v_n|^2 / n_dof of every frame of v [F, N, 3] in one launch."""
+
+    @staticmethod
+    def forward(ctx, vel, mass, n_dof):
+        lib = _lib.load()
+        require_gpu(vel, "vel")
+        v = vel.detach().contiguous()
+        F, N = v.shape[0], v.shape[1]
+        out = torch.empty(F, device=v.device)
+        check(lib.mdg_temperature(ptr(v), ptr(mass), F, N, float(n_dof), ptr(out), stream_ptr(v.device)), "mdg_temperature")
+        ctx.save_for_backward(v, mass)
+        ctx.n_dof = float(n_dof)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        v, mass = ctx.saved_tensors
+        return (2.0 / ctx.n_dof) * g[:, None, None] * mass[None, :, None] * v, None, None
 
 
 # ----------------------------------------------------------------------------- thermostat algebra

@@ -238,3 +238,59 @@ def test_cell_list_for_replica_stacked_systems_equals_dense():
         k = torch.arange(a.max_nbr, device=DEV)[None, :] < a.cnt[:, None]
         assert torch.equal(a.col[k], b.col[k]) and torch.equal(a.shift[k], b.shift[k])
         assert int((a.col[k] // n != torch.arange(R * n, device=DEV)[:, None].expand_as(a.col)[k] // n).sum()) == 0
+
+
+def test_vacf_and_temperature_kernels_golden():
+    """Golden G16 (the reference's vacf / Temperature incl. the gradient of a weighted sum w.r.t. the velocities)."""
+    from mdgrad_amd.observable import vacf
+    from mdgrad_amd.thermo import Temperature
+    g = load_golden("vacf_temp")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"])
+    v = T(g["v_t"], DEV).requires_grad_(True)
+    c = vacf(system, t_range=12)(v)
+    close(c, g["vacf"], 1e-5, 1e-7, "vacf")
+    (gv,) = torch.autograd.grad((c * T(g["wgt"], DEV)).sum(), v)
+    close(gv, g["vacf_grad"], 1e-5, 1e-7 * np.abs(g["vacf_grad"]).max() + 1e-10, "d vacf / dv")
+    temp = Temperature(system)
+    v1 = T(g["vel"], DEV).requires_grad_(True)
+    T1 = temp(v1)
+    assert T1.dim() == 0
+    close(T1.reshape(1), g["T_single"], 2e-6, 0, "T")
+    (gT,) = torch.autograd.grad(T1, v1)
+    close(gT, g["T_grad"], 2e-6, 1e-9, "dT/dv")
+    close(temp(T(g["v_t"], DEV)), g["T_frames"], 2e-6, 0, "T per frame")
+    assert torch.equal(vacf(system, t_range=12)(v), c), "bitwise reproducible"
+
+
+def test_fused_adjoint_returns_time_vjps_like_the_generic_path():
+    """dL/dt (`time_vjps`, sovlers.py:258-266,293): the fused trajectory op returns it when t requires grad --
+    compared with the generic path (the reference's control flow on the HIP autograd ops) and with the closed form
+    f(y_k) . dL/dy_k built from the oracle's right-hand side."""
+    from mdgrad_amd.sovlers import odeint_adjoint, OdeintAdjointMethod
+    from mdgrad_amd.tinydiffeq import _flatten
+    g = load_golden("nhc_traj_lj")
+    res = []
+    for fused in (True, False):
+        system, mdl, integ = lj_setup(g)
+        y0 = tuple(integ.get_inital_states(wrap=True))
+        t = torch.Tensor([0.005 * i for i in range(8)]).to(DEV).requires_grad_(True)
+        if fused:
+            out = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        else:
+            out = OdeintAdjointMethod.apply(*y0, integ, t, _flatten(integ.parameters()), 1e-6, 1e-12, "NH_verlet", None)
+        (out[1].pow(2).mean() + out[0][-1].pow(2).mean() + out[2][-1].sum()).backward()
+        res.append((t.grad.clone(), [o.detach() for o in out]))
+    close(res[0][0], res[1][0], 1e-4, 1e-5 * float(res[1][0].abs().max()), "time_vjps fused vs generic")
+    assert abs(float(res[0][0].sum())) <= 1e-4 * float(res[0][0].abs().max()), "dL/dt_0 = -sum of the others"
+    # closed form from the oracle's RHS at the saved frames
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+    eom = O.NHCOracle(O.ModelOracle([term]), T(g["mass"]), 1.0, 50.0, 5)
+    v_t, q_t, pv_t = [o.cpu() for o in res[0][1]]
+    n = q_t.shape[0]
+    for k in (1, n - 1):
+        a, vv, b = eom.rhs((v_t[k], q_t[k], pv_t[k]))
+        gq = 2 * q_t[k] / q_t.numel()
+        expect = float((vv * gq).sum())
+        if k == n - 1:
+            expect += float((a * 2 * v_t[k] / v_t[k].numel()).sum() + b.sum())
+        assert abs(float(res[0][0][k]) - expect) <= 1e-3 * abs(expect) + 1e-6, "time_vjps[%d]" % k
