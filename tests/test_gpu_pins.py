@@ -294,3 +294,65 @@ def test_fused_adjoint_returns_time_vjps_like_the_generic_path():
         if k == n - 1:
             expect += float((a * 2 * v_t[k] / v_t[k].numel()).sum() + b.sum())
         assert abs(float(res[0][0][k]) - expect) <= 1e-3 * abs(expect) + 1e-6, "time_vjps[%d]" % k
+
+
+def test_fit_loop_parameter_trajectory_matches_an_oracle_run_loop():
+    """the outer training loop (simulate -> rdf -> loss -> adjoint -> Adam) run on the HIP
+    path and, with the same inputs, on the CPU oracle: losses and the (sigma, epsilon) trajectory over 4 optimizer
+    steps agree (2 replicas x 11 MD steps per epoch, pooled RDF, target g = 1)."""
+    from mdgrad_amd import ops
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.observable import rdf
+    g = load_golden("nhc_traj_lj")
+    R, nT, epochs, lr = 2, 12, 4, 0.02
+    rng = np.random.default_rng(21)
+    pos = np.stack([np.mod(g["pos"] + rng.normal(0, 0.03, g["pos"].shape), g["cell"]) for _ in range(R)]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(nT)])
+    # ---- HIP loop
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    mdl = P.LennardJones(0.95, 0.9)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5,
+                            Q=50.0).to(DEV)
+    obs = rdf(system, nbins=60, r_range=(0.75, 2.4))
+    opt = torch.optim.Adam(integ.parameters(), lr=lr)
+    spec = integ.fused_spec("NH_verlet")
+    hip = []
+    for _ in range(epochs):
+        opt.zero_grad()
+        v_t, q_t, pv_t = ops.FusedTrajFn.apply(T(vel, DEV), T(pos, DEV), torch.zeros(R, 5, device=DEV), t.to(DEV),
+                                               spec.flat_params(), spec)
+        loss = (obs(q_t)[2] - 1).pow(2).mean()
+        loss.backward()
+        opt.step()
+        hip.append((float(loss.detach()), float(mdl.sigma.detach()), float(mdl.epsilon.detach())))
+    # ---- the same loop on the oracle
+    theta = torch.tensor([0.95, 0.9], requires_grad=True)
+    opt_o = torch.optim.Adam([theta], lr=lr)
+    cell = T(g["cell"])
+    ora = []
+    for _ in range(epochs):
+        opt_o.zero_grad()
+        th = theta.detach().clone()
+        trajs, eoms = [], []
+        for r in range(R):
+            term = O.PairTerm("lj", th, 2.5, cell, p=12, q=6, c=1)
+            eom = O.NHCOracle(O.ModelOracle([term]), T(g["mass"]), 1.0, 50.0, 5)
+            trajs.append(O.odeint_oracle(eom, (T(vel[r]), T(pos[r]), torch.zeros(5)), t))
+            eoms.append(eom)
+        qs = [tr[1].clone().requires_grad_(True) for tr in trajs]
+        loss = (O.rdf_oracle(torch.stack(qs), cell, 60, (0.75, 2.4))[2] - 1).pow(2).mean()
+        loss.backward()
+        gth = torch.zeros(2)
+        for r in range(R):
+            grads = [torch.zeros_like(trajs[r][0]), qs[r].grad, torch.zeros_like(trajs[r][2])]
+            gth = gth + O.adjoint_oracle(eoms[r], trajs[r], grads, t)[1]
+        theta.grad = gth
+        opt_o.step()
+        ora.append((float(loss.detach()), float(theta[0]), float(theta[1])))
+    for k, (a, b) in enumerate(zip(hip, ora)):
+        assert abs(a[0] - b[0]) <= 2e-4 * abs(b[0]) + 1e-7, "loss at epoch %d: %r vs %r" % (k, a[0], b[0])
+        assert abs(a[1] - b[1]) <= 2e-5 and abs(a[2] - b[2]) <= 2e-5, "(sigma, epsilon) at epoch %d: %r vs %r" % (k, a, b)
+    assert hip[-1][1] != hip[0][1], "parameters moved"
