@@ -62,6 +62,25 @@ __device__ __forceinline__ void ssp_sig(float x, float& s, float& sg) {
     sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
 }
 
+// Work split of a persistent grid over `n` items in units of `unit` consecutive items per workgroup step: XCD x owns the
+// x-th contiguous eighth; inside it workgroup w of W starts at unit w and advances by W units.  [begin, end) and the
+// step are in items.  Grids that are not a multiple of 8 fall back to one interleaved sweep over everything.
+__device__ __forceinline__ void xcd_sweep(int n, int unit, int& begin, int& end, int& step) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    if ((nb & 7) == 0 && nb >= 8) {
+        const int W = nb >> 3, x = b & 7, w = b >> 3;
+        const int units = (n + unit - 1) / unit;
+        const int per = (units + 7) >> 3;                        // units per XCD
+        const int u_lo = x * per, u_hi = min(units, u_lo + per);
+        begin = (u_lo + w) * unit;
+        end = min(n, u_hi * unit);
+        step = W * unit;
+        if (u_lo + w >= u_hi) begin = end;
+    } else {
+        begin = b * unit; end = n; step = nb * unit;
+    }
+}
+
 struct FilterDev {
     const float *mu, *coef, *W1, *b1, *W2, *b2;
     int G, F;
@@ -102,7 +121,7 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
     }
 }
 
-template <int GP, int FT, bool TANGENT>
+template <int GP, int FT, bool TANGENT, bool SUMS>
 __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;          // s16m32(GP) for GP in {16,32,48,64}
@@ -145,12 +164,14 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
     const int li = lane & 15, lk = lane >> 4;
     float* h1w = h1s + wid * 16 * SA;
     float* h1dw = h1s + (4 + wid) * 16 * SA;
-    // contiguous chunk of atoms per workgroup, XCD-aware order (neighbouring atoms gather the same rows)
-    const int nb = gridDim.x;
-    const int per = (A.N + nb - 1) / nb;
-    const int b = xcd_chunk(blockIdx.x, nb);
-    const int n_lo = b * per, n_hi = min(A.N, n_lo + per);
-    for (int n = n_lo + wid; n < n_hi; n += 4) {
+    // XCD x (= blockIdx.x % 8: workgroups are dispatched round-robin over the XCDs) owns the x-th contiguous eighth of
+    // the atoms, and its workgroups sweep that eighth TOGETHER (workgroup w takes atoms 4 (t W + w) + wave, t = 0, 1, ...):
+    // at any time the XCD works on a window of consecutive -- i.e. spatially close -- atoms, so the node rows their
+    // neighbours gather stay in its 4 MB L2 (a contiguous chunk per workgroup spreads the XCD over the whole replica:
+    // 8 MB of rows in flight, measured gather-bound)
+    int n_begin, n_end, n_step;
+    xcd_sweep(A.N, 4, n_begin, n_end, n_step);
+    for (int n = n_begin + wid; n < n_end; n += n_step) {
         const int cnt = A.cnt[n];
         const size_t rowb = (size_t)n * A.max_nbr;
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
@@ -227,11 +248,11 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
                 for (int r = 0; r < 4; ++r) {
                     const float W = acc[r] + bias;
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    hs[nt] += hreg[r][nt];
+                    if (SUMS) hs[nt] += hreg[r][nt];
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        hds[nt] += hdreg[r][nt];
+                        if (SUMS) hds[nt] += hdreg[r][nt];
                     }
                 }
             }
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
             macc[v] += __shfl_xor(macc[v], 16, 64); macc[v] += __shfl_xor(macc[v], 32, 64);
             if (TANGENT) { mdacc[v] += __shfl_xor(mdacc[v], 16, 64); mdacc[v] += __shfl_xor(mdacc[v], 32, 64); }
         }
-        if (A.hsum) {
+        if (SUMS) {
 #pragma unroll
             for (int v = 0; v < FT; ++v) {
                 hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
@@ -252,8 +273,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
         if (lk == 0) {
             store_row<FT>(A.m, n, F, li, macc);
             if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
-            if (A.hsum) store_row<FT>(A.hsum, n, F, li, hs);
-            if (TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+            if (SUMS) store_row<FT>(A.hsum, n, F, li, hs);
+            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
         }
     }
 }
@@ -272,7 +293,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
-template <int GP, int FT, bool TANGENT>          // GP in {32, 64}
+template <int GP, int FT, bool TANGENT, bool SUMS>          // GP in {32, 64}
 __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
@@ -313,11 +334,9 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     const int li = lane & 15, lk = lane >> 4;
     unsigned short* h1w = h1s + wid * 16 * KSB;
     unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
-    const int nb = gridDim.x;
-    const int per = (A.N + nb - 1) / nb;
-    const int b = xcd_chunk(blockIdx.x, nb);
-    const int n_lo = b * per, n_hi = min(A.N, n_lo + per);
-    for (int n = n_lo + wid; n < n_hi; n += 4) {
+    int n_begin, n_end, n_step;
+    xcd_sweep(A.N, 4, n_begin, n_end, n_step);              // (see cfconv_fwd_kernel)
+    for (int n = n_begin + wid; n < n_end; n += n_step) {
         const int cnt = A.cnt[n];
         const size_t rowb = (size_t)n * A.max_nbr;
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
@@ -388,11 +407,11 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 for (int r = 0; r < 4; ++r) {
                     const float W = acc[r] + bias;
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    hs[nt] += hreg[r][nt];
+                    if (SUMS) hs[nt] += hreg[r][nt];
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        hds[nt] += hdreg[r][nt];
+                        if (SUMS) hds[nt] += hdreg[r][nt];
                     }
                 }
             }
@@ -402,7 +421,7 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             macc[v] += __shfl_xor(macc[v], 16, 64); macc[v] += __shfl_xor(macc[v], 32, 64);
             if (TANGENT) { mdacc[v] += __shfl_xor(mdacc[v], 16, 64); mdacc[v] += __shfl_xor(mdacc[v], 32, 64); }
         }
-        if (A.hsum) {
+        if (SUMS) {
 #pragma unroll
             for (int v = 0; v < FT; ++v) {
                 hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
@@ -412,8 +431,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
         if (lk == 0) {
             store_row<FT>(A.m, n, F, li, macc);
             if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
-            if (A.hsum) store_row<FT>(A.hsum, n, F, li, hs);
-            if (TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+            if (SUMS) store_row<FT>(A.hsum, n, F, li, hs);
+            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
         }
     }
 }
@@ -505,10 +524,9 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
     for (int c = 0; c < NT; ++c) gb1[c] = 0.f;
 
     const long long ntiles = (A.E + 63) / 64;                    // 64 edges per workgroup step, 16 per wave
-    const int nb = gridDim.x;
-    const long long per = (ntiles + nb - 1) / nb;
-    const long long t_lo = (long long)xcd_chunk(blockIdx.x, nb) * per, t_hi = min(ntiles, t_lo + per);
-    for (long long tile = t_lo; tile < t_hi; ++tile) {
+    int t_begin, t_end, t_step;
+    xcd_sweep((int)ntiles, 1, t_begin, t_end, t_step);           // the half list is sorted by atom: same locality argument
+    for (long long tile = t_begin; tile < t_end; tile += t_step) {
         const long long e0 = tile * 64 + wid * 16;
         // ---- A-layout row: edge e0 + li
         const long long ea = e0 + li;
@@ -844,6 +862,27 @@ __global__ void edge_geom_bwd_kernel(const float* __restrict__ d_b, const float*
 
 bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Persistent grids are sized to ONE resident round: workgroups per CU from the occupancy API (registers + LDS of
+// this instantiation) times the CU count.  (768 workgroups on 256 CUs at 2 resident per CU ran as a full round
+// plus a half-empty one: -25 %.)  Cached per kernel instantiation and LDS size.
+template <typename K>
+int resident_blocks(K kernel, size_t lds) {
+    struct Entry { const void* k; size_t l; int n; };
+    static thread_local Entry cache[48];
+    static thread_local int used = 0;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].k == (const void*)kernel && cache[i].l == lds) return cache[i].n;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (per_cu > 4) per_cu = 4;
+    const int n = per_cu * cus;
+    if (used < 48) cache[used++] = Entry{(const void*)kernel, lds, n};
+    return n;
+}
+
 int shape_ok(const MdgFilterNet* net, int& GP, int& FT) {
     MDG_CHECK_ARG(net && net->mu && net->coef && net->W1 && net->b1 && net->W2 && net->b2, "cfconv: null filter weights");
     const int G = net->n_gauss, F = net->n_filters;
@@ -907,21 +946,25 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd: node feature matrices must be 16-byte aligned");
     FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
-    const int want = 768;
-    const int nb = (n_atoms + 3) / 4 < want ? (n_atoms + 3) / 4 : want;
+    const int most = (n_atoms + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
+#define MDG_FWD1(GP_, FT_, T_, S_)                                                                                 \
+    do {                                                                                                           \
+        const size_t lds = fwd_lds_bytes<GP_, FT_>(T_);                                                            \
+        const int want = resident_blocks(cfconv_fwd_kernel<GP_, FT_, T_, S_>, lds);                                \
+        hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, T_, S_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+    } while (0)
 #define MDG_FWD(GP_, FT_)                                                                                          \
     do {                                                                                                           \
-        if (tangent)                                                                                               \
-            hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, true>), dim3(nb), dim3(256), (fwd_lds_bytes<GP_, FT_>(true)), st, a); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, false>), dim3(nb), dim3(256), (fwd_lds_bytes<GP_, FT_>(false)), st, a); \
+        if (tangent) { if (hsum) MDG_FWD1(GP_, FT_, true, true); else MDG_FWD1(GP_, FT_, true, false); }           \
+        else { if (hsum) MDG_FWD1(GP_, FT_, false, true); else MDG_FWD1(GP_, FT_, false, false); }                 \
     } while (0)
     if (GP == 32 && FT == 4) MDG_FWD(32, 4);
     else if (GP == 32) MDG_FWD(32, 8);
     else if (FT == 4) MDG_FWD(64, 4);
     else MDG_FWD(64, 8);
 #undef MDG_FWD
+#undef MDG_FWD1
     MDG_CHECK_LAUNCH("cfconv_fwd_kernel");
     return MDG_OK;
 }
@@ -940,21 +983,25 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd_bf16: node feature matrices must be 16-byte aligned");
     FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
-    const int want = 768;
-    const int nb = (n_atoms + 3) / 4 < want ? (n_atoms + 3) / 4 : want;
+    const int most = (n_atoms + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
+#define MDG_FWDB1(GP_, FT_, T_, S_)                                                                                \
+    do {                                                                                                           \
+        const size_t lds = fwd_bf16_lds_bytes<GP_, FT_>(T_);                                                       \
+        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_>, lds);                           \
+        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+    } while (0)
 #define MDG_FWDB(GP_, FT_)                                                                                         \
     do {                                                                                                           \
-        if (tangent)                                                                                               \
-            hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, true>), dim3(nb), dim3(256), (fwd_bf16_lds_bytes<GP_, FT_>(true)), st, a); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, false>), dim3(nb), dim3(256), (fwd_bf16_lds_bytes<GP_, FT_>(false)), st, a); \
+        if (tangent) { if (hsum) MDG_FWDB1(GP_, FT_, true, true); else MDG_FWDB1(GP_, FT_, true, false); }         \
+        else { if (hsum) MDG_FWDB1(GP_, FT_, false, true); else MDG_FWDB1(GP_, FT_, false, false); }               \
     } while (0)
     if (GP == 32 && FT == 4) MDG_FWDB(32, 4);
     else if (GP == 32) MDG_FWDB(32, 8);
     else if (FT == 4) MDG_FWDB(64, 4);
     else MDG_FWDB(64, 8);
 #undef MDG_FWDB
+#undef MDG_FWDB1
     MDG_CHECK_LAUNCH("cfconv_fwd_bf16_kernel");
     return MDG_OK;
 }
@@ -992,15 +1039,26 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb),
                   "cfconv_bwd: node feature matrices must be 16-byte aligned");
     BwdArgs a{dev_of(net), d, dd, nbr, (long long)n_edges, h, hd, mb, mdb, d_b, dd_b, workspace};
-    const int nb = bwd_blocks(n_edges, theta);
+    int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
+    const long long tiles64 = (n_edges + 63) / 64;
 #define MDG_BWD(GP_, FT_)                                                                                          \
     do {                                                                                                           \
-        if (theta)                                                                                                 \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, true>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(true)), st, a); \
-        else if (dual)                                                                                             \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, false>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(false)), st, a); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, false, false>), dim3(nb), dim3(256), (bwd_lds_bytes<GP_, FT_>(false)), st, a); \
+        if (theta) {                                                                                               \
+            const size_t lds = bwd_lds_bytes<GP_, FT_>(true);                                                      \
+            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, true, true>, lds);                        \
+            if (want < nb) nb = want;                                                                              \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, true>), dim3(nb), dim3(256), lds, st, a);        \
+        } else if (dual) {                                                                                         \
+            const size_t lds = bwd_lds_bytes<GP_, FT_>(false);                                                     \
+            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, true, false>, lds);                       \
+            nb = (int)(tiles64 < want ? tiles64 : want);                                                           \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, false>), dim3(nb), dim3(256), lds, st, a);       \
+        } else {                                                                                                   \
+            const size_t lds = bwd_lds_bytes<GP_, FT_>(false);                                                     \
+            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, false, false>, lds);                      \
+            nb = (int)(tiles64 < want ? tiles64 : want);                                                           \
+            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, false, false>), dim3(nb), dim3(256), lds, st, a);      \
+        }                                                                                                          \
     } while (0)
     if (GP == 32 && FT == 4) MDG_BWD(32, 4);
     else if (GP == 32) MDG_BWD(32, 8);
