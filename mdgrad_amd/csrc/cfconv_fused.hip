@@ -533,6 +533,7 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
         long long ia = -1, ja = -1;
         if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
         const bool va = ia >= 0;                                  // (-1: padding row of a fixed-capacity list)
+        if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
         const float da = va ? A.d[ea] : PAD_D;
         float dda = 0.f;
         if (DUAL) dda = va ? A.dd[ea] : 0.f;

@@ -191,6 +191,24 @@ def _finish(func, cache, q_last):
     return overflow
 
 
+def eager_static(func, body, q_last_of):
+    """Run `body()` (an eager integration / adjoint sweep) on fixed-capacity neighbour lists: systems too large for
+    graph replay still profit from them, because a rebuild then needs NO host sync (the exact-size path reads the
+    longest row and the pair count back at every rebuild, which keeps the launch thread from running ahead of the
+    GPU).  Capacities are checked once after the pass; on overflow they grow and None is returned (the caller
+    redoes the pass on exact-size lists)."""
+    if not enabled(func):
+        return None
+    func.model.set_static_topology(True)
+    try:
+        out = body()
+    finally:
+        overflow = func.model.static_overflow()
+        func.model.set_static_topology(False)
+    func.model._reset_topology(q_last_of(out))
+    return None if overflow else out
+
+
 def forward(func, y0, t):
     """Frames (v_t, q_t, pv_t) of NHVerlet.integrate by graph replay, or None when graphs do not apply or
     the capacities overflowed (the caller then integrates eagerly)."""

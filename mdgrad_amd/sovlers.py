@@ -84,24 +84,30 @@ class NHVerlet(FixedGridODESolver):
                 or getattr(func, "topology_update_freq", 0) != 1):
             return super().integrate(t)
         t = t.type_as(self.y0[0]).to(self.y0[0].device)
+
+        def eager():
+            v, q, pv = self.y0
+            frames = [(v, q, pv)]
+            F = func.force(q)
+            for k in range(t.shape[0] - 1):
+                dt = t[k + 1] - t[k]
+                a0, _, b0 = func.rhs_from_force((v, q, pv), F)
+                dv_h = 1 / 2 * a0 * dt
+                dp_h = 1 / 2 * b0 * dt
+                dq = (v + dv_h) * dt
+                F = func.force(q + dq)
+                a1, _, b1 = func.rhs_from_force((v + dv_h, q + dq, pv + dp_h), F)
+                v, q, pv = v + (dv_h + 1 / 2 * a1 * dt), q + dq, pv + (dp_h + 1 / 2 * b1 * dt)
+                frames.append((v, q, pv))
+            return tuple(torch.stack([f[i] for f in frames]) for i in range(3))
+
         if graphs.enabled(func) and t.shape[0] > 3:
             out = graphs.forward(func, tuple(self.y0), t)          # HIP-graph replay, one launch per step
+            if out is None:                                         # too large for replay: eager, but sync-free lists
+                out = graphs.eager_static(func, eager, lambda o: o[1][-1])
             if out is not None:
                 return out
-        v, q, pv = self.y0
-        frames = [(v, q, pv)]
-        F = func.force(q)
-        for k in range(t.shape[0] - 1):
-            dt = t[k + 1] - t[k]
-            a0, _, b0 = func.rhs_from_force((v, q, pv), F)
-            dv_h = 1 / 2 * a0 * dt
-            dp_h = 1 / 2 * b0 * dt
-            dq = (v + dv_h) * dt
-            F = func.force(q + dq)
-            a1, _, b1 = func.rhs_from_force((v + dv_h, q + dq, pv + dp_h), F)
-            v, q, pv = v + (dv_h + 1 / 2 * a1 * dt), q + dq, pv + (dp_h + 1 / 2 * b1 * dt)
-            frames.append((v, q, pv))
-        return tuple(torch.stack([f[i] for f in frames]) for i in range(3))
+        return eager()
 
 
 class Verlet(FixedGridODESolver):
@@ -217,28 +223,35 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
     the handful of tensor ops it needs instead of 8-tuple solver algebra."""
     with torch.no_grad():
         T = ans[0].shape[0]
+
+        def eager():
+            lam = [g[-1].clone() for g in grad_output]
+            gth = torch.zeros_like(flat_params)
+            for i in range(T - 1, 0, -1):
+                h = t[i] - t[i - 1]
+                v, q, pv = ans[0][i], ans[1][i], ans[2][i]
+                func.update_topology(q)                                   # :258 (dL/dt call: counter / rebuild only)
+                (a, _, b), G0, _ = func.rhs_vjp((v, q, pv), lam, want_theta=False)
+                hh = 0.5 * h
+                vh = v - a * hh                                           # :132  v + 1/2 (-a) h
+                qm = q + vh * h                                           # :138  forward-time sign (quirk)
+                pm = pv - b * hh                                          # :135
+                lam_h = [l + g * hh for l, g in zip(lam, G0)]             # :141-143
+                _, G1, th1 = func.rhs_vjp((vh, qm, pm), lam_h)
+                for k in range(3):
+                    lam[k] = lam[k] + G1[k] * h + grad_output[k][i - 1]   # :156-158, :286
+                if th1:
+                    gth = gth + _flatten(th1) * h                         # :160
+            return lam, gth
+
+        out = None
         if graphs.enabled(func) and T > 3:
             out = graphs.adjoint(func, t, ans, grad_output, flat_params.numel())   # one graph launch per interval
-            if out is not None:
-                return (*out[0], None, None, out[1], None, None, None, None, None)
-        lam = [g[-1].clone() for g in grad_output]
-        gth = torch.zeros_like(flat_params)
-        for i in range(T - 1, 0, -1):
-            h = t[i] - t[i - 1]
-            v, q, pv = ans[0][i], ans[1][i], ans[2][i]
-            func.update_topology(q)                                   # :258 (dL/dt call: counter / rebuild only)
-            (a, _, b), G0, _ = func.rhs_vjp((v, q, pv), lam, want_theta=False)
-            hh = 0.5 * h
-            vh = v - a * hh                                           # :132  v + 1/2 (-a) h
-            qm = q + vh * h                                           # :138  forward-time sign (quirk)
-            pm = pv - b * hh                                          # :135
-            lam_h = [l + g * hh for l, g in zip(lam, G0)]             # :141-143
-            _, G1, th1 = func.rhs_vjp((vh, qm, pm), lam_h)
-            for k in range(3):
-                lam[k] = lam[k] + G1[k] * h + grad_output[k][i - 1]   # :156-158, :286
-            if th1:
-                gth = gth + _flatten(th1) * h                         # :160
-        return (*lam, None, None, gth, None, None, None, None, None)
+            if out is None:                                               # too large for replay: sync-free lists
+                out = graphs.eager_static(func, eager, lambda o: ans[1][0])
+        if out is None:
+            out = eager()
+        return (*out[0], None, None, out[1], None, None, None, None, None)
 
 
 def _fused_spec_for(func, method):

@@ -213,3 +213,36 @@ def test_dense_node_kernel_epilogues(N, K, M):
     single = ops.dense(W, x0, bias=bias)[0]
     _close(single, z, "single input")
     assert torch.equal(single, ops.dense(W, x0, bias=bias)[0])
+
+
+def test_large_system_eager_pass_on_fixed_capacity_lists_equals_exact_lists():
+    """Systems above graphs.MAX_EDGES run eagerly but on fixed-capacity (sync-free) neighbour lists: same trajectory
+    and gradients as the plain eager path on exact-size lists; an undersized capacity is detected and the pass redone."""
+    from mdgrad_amd import graphs
+    from test_gpu_schnet import _gnn_integrator, _traj_and_grads
+    g = load_golden("gnn_traj")
+    t = torch.Tensor([float(g["dt"]) * i for i in range(6)]).to(DEV)
+    res = []
+    saved = graphs.MAX_EDGES
+    try:
+        for mode in ("exact", "static", "static-overflow"):
+            system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+            integ = _gnn_integrator(g, system)
+            if mode == "exact":
+                integ.use_graphs = False
+            else:
+                graphs.MAX_EDGES = 0                              # every system counts as "too large for replay"
+                if mode == "static-overflow":
+                    integ.model.set_static_topology(True)
+                    for m in integ.model.models.values():         # capacities far too small: must be detected
+                        m._static["max_nbr"] = 8
+                        if "capacity" in m._static:
+                            m._static["capacity"] = 64
+                    integ.model.set_static_topology(False)
+            res.append(_traj_and_grads(integ, system, t))
+            assert not any(m._static_on for m in integ.model.models.values()), "exact-size lists restored"
+    finally:
+        graphs.MAX_EDGES = saved
+    for k in (1, 2):
+        for a, b, nm in zip(res[k], res[0], ("v_t", "q_t", "pv_t", "dL/dtheta")):
+            close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "%s, mode %d" % (nm, k))
