@@ -341,7 +341,8 @@ int mdg_cfconv_fwd_bf16(const MdgFilterNet* net /*host*/, const float* d, const 
 int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges);
 int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
                    int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
-                   float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace, void* stream);
+                   float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                   const int32_t* n_valid /*device, nullable: real rows of a capacity-padded list*/, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K11/K12  node-level Dense layers with fused epilogues on the f32 MFMA

@@ -460,6 +460,7 @@ struct BwdArgs {
     const float *h, *hd, *mb, *mdb;
     float *d_b, *dd_b;
     float* part;              // THETA: [gridDim.x][GP*GP + GP + FP*GP] per-workgroup partial gradients
+    const int32_t* n_valid;   // fixed-capacity lists: device count of real rows (rows beyond are padding), or null
 };
 
 // physical row of filter f in the LDS copy of W2 used as the B operand of  [16 x F] x [F x G]:
@@ -523,7 +524,10 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
 #pragma unroll
     for (int c = 0; c < NT; ++c) gb1[c] = 0.f;
 
-    const long long ntiles = (A.E + 63) / 64;                    // 64 edges per workgroup step, 16 per wave
+    // 64 edges per workgroup step, 16 per wave; a fixed-capacity list is swept over its real rows only (the split over
+    // the XCDs then stays balanced)
+    const long long nrows = A.n_valid ? min((long long)*A.n_valid, A.E) : A.E;
+    const long long ntiles = (nrows + 63) / 64;
     int t_begin, t_end, t_step;
     xcd_sweep((int)ntiles, 1, t_begin, t_end, t_step);           // the half list is sorted by atom: same locality argument
     for (long long tile = t_begin; tile < t_end; tile += t_step) {
@@ -1016,7 +1020,7 @@ extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t 
 extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
                               int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                               float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
-                              void* stream) {
+                              const int32_t* n_valid, void* stream) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1039,7 +1043,7 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(!theta || workspace, "cfconv_bwd: workspace missing");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb),
                   "cfconv_bwd: node feature matrices must be 16-byte aligned");
-    BwdArgs a{dev_of(net), d, dd, nbr, (long long)n_edges, h, hd, mb, mdb, d_b, dd_b, workspace};
+    BwdArgs a{dev_of(net), d, dd, nbr, (long long)n_edges, h, hd, mb, mdb, d_b, dd_b, workspace, n_valid};
     int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
     const long long tiles64 = (n_edges + 63) / 64;
 #define MDG_BWD(GP_, FT_)                                                                                          \

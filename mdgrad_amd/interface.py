@@ -35,6 +35,20 @@ class GeneralInteraction(torch.nn.Module):
             cache[key] = ell
         return ell
 
+    def _shared_static_ell(self, xyz, cache, st):
+        """Fixed-capacity ELL list (no host sync); members of one Stack with the same cutoff / selection / grouping
+        and row capacity share one search per rebuild, like _shared_ell (the first member's `need` buffer carries
+        the overflow report for all of them)."""
+        key = ("static", float(self.cutoff), None if self._mask is None else self._mask.data_ptr(), self._group,
+               int(st["max_nbr"]))
+        if cache is not None and key in cache:
+            return cache[key]
+        ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, max_nbr=st["max_nbr"],
+                            group=self._group, need=st["need"])
+        if cache is not None:
+            cache[key] = ell
+        return ell
+
     # -- fixed-capacity neighbour lists (HIP-graph capture of the integrator steps, mdgrad_amd/graphs.py) --
     def supports_static_topology(self):
         return False
@@ -109,9 +123,7 @@ class GNNPotentials(GeneralInteraction):
         self._topo_stamp = object()                  # identity of this rebuild (see md._EOM.update_topology)
         st = self._static if self._static_on else None
         if st is not None:
-            ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask, max_nbr=st["max_nbr"],
-                                group=self._group, need=st["need"])
-            topo = ops.StaticTopo(ell, st["capacity"], st["need"])
+            topo = ops.StaticTopo(self._shared_static_ell(xyz, _cache, st), st["capacity"], st["need"])
         else:
             topo = ops.GraphTopo(self._shared_ell(xyz, _cache))
         self.inputs['nbr_list'], self.inputs['offsets'] = topo.nbr, topo.offsets
@@ -202,8 +214,7 @@ class PairPotentials(GeneralInteraction):
         self._topo_stamp = object()
         st = self._static if self._static_on else None
         if st is not None:
-            self._ell = ops.build_ell(xyz.detach(), self._cell_struct, self.cutoff, self._mask,
-                                      max_nbr=st["max_nbr"], group=self._group, need=st["need"])
+            self._ell = self._shared_static_ell(xyz, _cache, st)
         else:
             self._ell = self._shared_ell(xyz, _cache)
         return _LazyTopology(self, xyz.detach())

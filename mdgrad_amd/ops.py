@@ -922,8 +922,8 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
         gW2 = torch.empty(fnet.F, fnet.G, device=dev)
         ws = torch.empty(max(1, int(lib.mdg_cfconv_bwd_workspace(fnet.G, fnet.F, topo.n_edges))), device=dev)
     check(lib.mdg_cfconv_bwd(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
-                             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws), stream_ptr(dev)),
-          "mdg_cfconv_bwd")
+                             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws),
+                             ptr(getattr(topo, "n_valid", None)), stream_ptr(dev)), "mdg_cfconv_bwd")
     return (gW1, gb1, gW2) if want_theta else None
 
 
