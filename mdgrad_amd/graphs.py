@@ -21,7 +21,11 @@ import torch
 
 from .tinydiffeq import _flatten
 
-MAX_EDGES = 1 << 18          # above this the evaluation is GPU-bound and the graph's private pool is large
+# Largest fixed edge capacity that is still replayed from a captured graph.  With the fused interaction-block kernels
+# no edge-sized tensor exists any more, so the graph's private pool holds node-level tensors only (a few hundred MB at
+# 32 768 atoms) and replay pays off well beyond the launch-bound sizes: the ~320 launches of an MD step cost the host
+# ~25 us each through Python, more than the GPU needs for them at 4096 beads x 8 replicas.
+MAX_EDGES = int(os.environ.get("MDG_GRAPH_MAX_EDGES", str(1 << 21)))
 
 
 def enabled(func):
