@@ -796,13 +796,15 @@ __global__ __launch_bounds__(256) void rdf_bwd_fine_kernel(
 // `ds_add_u32` instead of the 11 float read-add-writes of the lane-private columns), and the fine counts are smeared
 // onto the centres once at the end:  raw[k] = sum_m H[m] exp2(-(s (x_m - mu_k))^2),  x_m = centre of fine bin m.
 // Error: moving a pair to its bin centre changes its Gaussian by (delta^2 / 2) G'' on average (the first-order
-// term averages out over the bin), relative (s h)^2 ln2 / 12 at the peak; with s h <= 0.01 that is <= 5.8e-6 of
-// a bin's count (the tests allow 2e-5).  Integer counts commute, so the result is independent of the order in
-// which waves and workgroups deposit: bitwise reproducible without lane-private columns -- eight waves share one
-// histogram per workgroup and the workgroups merge into a global integer histogram.
+// term averages out over the bin): relative (s h)^2 [(2 ln2 u)^2 - 2 ln2] / 24 at u = s |d - mu|, i.e. 9e-7 at the
+// peak and 1.1e-5 three widths out (where the Gaussian is 2^-9 of its peak) for s h = 0.004 -- the tests allow 2e-5
+// per bin.  Integer counts commute, so the result is independent of the order in which waves and workgroups
+// deposit: bitwise reproducible without lane-private columns -- the sixteen waves of a workgroup share ONE histogram
+// (~24 000 fine bins = 95 KB at 100 centres) and the workgroups merge into a global integer histogram.
 // Pairs come from a table (i | j << 16), row-major in (i, j): the lanes of one step share atom i (LDS broadcast) and
 // read consecutive j (conflict-free), and masked (species-selected) histograms simply have a shorter table.
-constexpr int RDF_FINE_MAX = 16384;       // fine bins that fit the workgroup's LDS histogram (64 KB)
+constexpr int RDF_FINE_MAX = 36864;       // fine bins that fit the workgroup's LDS histogram (144 KB)
+constexpr int RDF_FINE_WAVES = 16;
 constexpr int RDF_FINE_ATOMS = 1024;
 
 __global__ __launch_bounds__(1024) void rdf_fine_table_kernel(int N, const uint8_t* __restrict__ mask,
@@ -831,13 +833,13 @@ __global__ __launch_bounds__(1024) void rdf_fine_table_kernel(int N, const uint8
 }
 
 template <bool DIAG>
-__global__ __launch_bounds__(512) void rdf_fwd_fine_kernel(
+__global__ __launch_bounds__(64 * RDF_FINE_WAVES) void rdf_fwd_fine_kernel(
     const float* __restrict__ xyz, int nF, int N, MdgCell cell, float rc2, const uint32_t* __restrict__ tab,
     const int32_t* __restrict__ count, const float* __restrict__ mu, float reach, float inv_h, int nfine, int ld,
     uint32_t* __restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     const float lo = mu[0] - reach;                             // lower edge of the fine grid
-    uint32_t* hist = reinterpret_cast<uint32_t*>(smf);          // [nfine] shared by the 8 waves
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smf);          // [nfine] shared by the workgroup's waves
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     float* px = smf + nfine + wid * 3 * ld;                     // wave-private SoA frame
     float* py = px + ld;
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(512) void rdf_fwd_fine_kernel(
     for (int m = threadIdx.x; m < nfine; m += blockDim.x) hist[m] = 0u;
     __syncthreads();
     const int P = *count;
-    for (int fr = blockIdx.x * 8 + wid; fr < nF; fr += gridDim.x * 8) {
+    for (int fr = blockIdx.x * RDF_FINE_WAVES + wid; fr < nF; fr += gridDim.x * RDF_FINE_WAVES) {
         const float* pos = xyz + (size_t)fr * N * 3;
         for (int e = lane; e < 3 * N; e += 64) {                // AoS -> SoA (coalesced read)
             const int a = e / 3, c = e - 3 * a;
@@ -1108,16 +1110,18 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
     // equally spaced centres with Ds = s * spacing <= 1: 8-bin blocks + recurrence (spacing_s is the
     // caller's statement that mu is a linspace; <= 0 selects the direct kernel)
     // ---- many frames, equally spaced centres: fine integer histogram (see rdf_fwd_fine_kernel) when it fits the LDS
-    if (n_frames >= 1024 && nbins >= 2 && spacing_s > 0.f && n_atoms <= RDF_FINE_ATOMS) {
+    // (the first-order term of the binning error averages out statistically, ~ (s h) 0.4 / sqrt(pairs near a centre):
+    //  small systems -- cheap anyway -- keep the exact lane-private kernels below)
+    if (n_frames >= 1024 && nbins >= 2 && spacing_s > 0.f && n_atoms >= 64 && n_atoms <= RDF_FINE_ATOMS) {
         const float sc = sqrtf(-coeff * LOG2E);                   // exp(coeff x^2) = exp2(-(sc x)^2)
         const float spacing = spacing_s / sc;
         const float reach = 5.3f / sc;                            // beyond: below 2^-28 of the peak
-        const float h = 0.01f / sc;                               // sc h = 0.01
+        const float h = 0.004f / sc;                              // sc h = 0.004 (error bound: see the kernel)
         const double span = (double)(nbins - 1) * spacing + 2.0 * reach;
         const long long nfine = (long long)ceil(span / h) + 1;
         const int ld = (n_atoms + 1) & ~1;
-        const size_t lds = sizeof(float) * ((size_t)nfine + 8 * 3 * (size_t)ld);
-        if (nfine <= RDF_FINE_MAX && lds <= 150 * 1024) {
+        const size_t lds = sizeof(float) * ((size_t)nfine + RDF_FINE_WAVES * 3 * (size_t)ld);
+        if (nfine <= RDF_FINE_MAX && lds <= 156 * 1024) {
             const long long npair = (long long)n_atoms * (n_atoms - 1) / 2;
             uint32_t* scratch = nullptr;                          // [nfine] global histogram | count | pair table
             const size_t words = (size_t)nfine + 4 + (size_t)npair;
@@ -1127,14 +1131,14 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
                 uint32_t* tab = scratch + nfine + 4;
                 MDG_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)(nfine + 4), st));
                 hipLaunchKernelGGL(rdf_fine_table_kernel, dim3(1), dim3(1024), 0, st, n_atoms, mask, tab, count);
-                int grid = (n_frames + 7) / 8;
-                if (grid > 768) grid = 768;                       // three resident workgroups per CU at 100 bins
+                int grid = (n_frames + RDF_FINE_WAVES - 1) / RDF_FINE_WAVES;
+                if (grid > 256) grid = 256;                       // one resident workgroup (16 waves) per CU
                 // (the fine grid starts at mu[0] - reach; the kernels read mu[0] themselves: no host copy)
                 if (cell->diag)
-                    hipLaunchKernelGGL(rdf_fwd_fine_kernel<true>, dim3(grid), dim3(512), lds, st, xyz, n_frames, n_atoms,
+                    hipLaunchKernelGGL(rdf_fwd_fine_kernel<true>, dim3(grid), dim3(64 * RDF_FINE_WAVES), lds, st, xyz, n_frames, n_atoms,
                                        *cell, cutoff * cutoff, tab, count, mu, reach, 1.0f / h, (int)nfine, ld, ghist);
                 else
-                    hipLaunchKernelGGL(rdf_fwd_fine_kernel<false>, dim3(grid), dim3(512), lds, st, xyz, n_frames, n_atoms,
+                    hipLaunchKernelGGL(rdf_fwd_fine_kernel<false>, dim3(grid), dim3(64 * RDF_FINE_WAVES), lds, st, xyz, n_frames, n_atoms,
                                        *cell, cutoff * cutoff, tab, count, mu, reach, 1.0f / h, (int)nfine, ld, ghist);
                 hipLaunchKernelGGL(rdf_fine_finish_kernel, dim3(nbins), dim3(64), 0, st, ghist, (int)nfine, h, mu, sc, reach,
                                    nbins, raw);
