@@ -854,17 +854,37 @@ __global__ __launch_bounds__(64 * RDF_FINE_WAVES) void rdf_fwd_fine_kernel(
             px[c * ld + a] = pos[e];
         }
         // (px is private to the wave: program order + the LDS counter suffice)
-        for (int p0 = 0; p0 < P; p0 += 64) {
-            const int p_ = p0 + lane;
-            const uint32_t ent = p_ < P ? tab[p_] : 0u;
-            const int i = (int)(ent & 0xFFFFu), j = (int)(ent >> 16);
-            float dx = px[j] - px[i], dy = py[j] - py[i], dz = pz[j] - pz[i];
-            min_image<DIAG>(cell, dx, dy, dz);
-            const float d2 = norm2_ref(dx, dy, dz);
-            const float t = (sqrtf(d2) - lo) * inv_h;
-            // accepted: a real pair, inside the cutoff (topology.py:67) and inside the fine range (beyond it every
-            // Gaussian is below 2^-28 of its peak)
-            if (p_ < P && d2 < rc2 && d2 != 0.f && t >= 0.f && t < (float)nfine) atomicAdd(&hist[(int)t], 1u);
+        // accepted: a real pair, inside the cutoff (topology.py:67) and inside the fine range (beyond it every
+        // Gaussian is below 2^-28 of its peak)
+        if constexpr (DIAG) {
+            // two table entries per lane and step in packed fp32 (the same image arithmetic as min_image<true>)
+            const float iv0 = cell.inv[0], iv1 = cell.inv[4], iv2 = cell.inv[8];
+            const float h0 = cell.h[0], h1 = cell.h[4], h2 = cell.h[8];
+            const float fmax = (float)nfine;
+            for (int p0 = 0; p0 < P; p0 += 128) {
+                const int pa = p0 + lane, pb = pa + 64;
+                const uint32_t ea = pa < P ? tab[pa] : 0u, eb = pb < P ? tab[pb] : 0u;
+                const int ia = (int)(ea & 0xFFFFu), ja = (int)(ea >> 16), ib = (int)(eb & 0xFFFFu), jb = (int)(eb >> 16);
+                f32x2 dx = f32x2{px[ja], px[jb]} - f32x2{px[ia], px[ib]};
+                f32x2 dy = f32x2{py[ja], py[jb]} - f32x2{py[ia], py[ib]};
+                f32x2 dz = f32x2{pz[ja], pz[jb]} - f32x2{pz[ia], pz[ib]};
+                dx = min_image_diag2(dx, iv0, h0); dy = min_image_diag2(dy, iv1, h1); dz = min_image_diag2(dz, iv2, h2);
+                const f32x2 d2 = norm2_ref2(dx, dy, dz);
+                const f32x2 t = (f32x2{sqrtf(d2.x), sqrtf(d2.y)} - lo) * inv_h;
+                if (pa < P && d2.x < rc2 && d2.x != 0.f && t.x >= 0.f && t.x < fmax) atomicAdd(&hist[(int)t.x], 1u);
+                if (pb < P && d2.y < rc2 && d2.y != 0.f && t.y >= 0.f && t.y < fmax) atomicAdd(&hist[(int)t.y], 1u);
+            }
+        } else {
+            for (int p0 = 0; p0 < P; p0 += 64) {
+                const int p_ = p0 + lane;
+                const uint32_t ent = p_ < P ? tab[p_] : 0u;
+                const int i = (int)(ent & 0xFFFFu), j = (int)(ent >> 16);
+                float dx = px[j] - px[i], dy = py[j] - py[i], dz = pz[j] - pz[i];
+                min_image<DIAG>(cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                const float t = (sqrtf(d2) - lo) * inv_h;
+                if (p_ < P && d2 < rc2 && d2 != 0.f && t >= 0.f && t < (float)nfine) atomicAdd(&hist[(int)t], 1u);
+            }
         }
     }
     __syncthreads();
