@@ -827,9 +827,57 @@ __global__ __launch_bounds__(1024) void rdf_fine_table_kernel(int N, const uint8
     __syncthreads();
     if (i < N) {
         int o = cnt[i];
-        for (int j = i + 1; j < N; ++j)
-            if (!mask || mask[(size_t)i * N + j]) tab[o++] = (uint32_t)i | ((uint32_t)j << 16);
+        for (int j = i + 1; j < N; ++j)                   // entries hold BYTE offsets (4 i | 4 j << 16): no shifts in the loop
+            if (!mask || mask[(size_t)i * N + j]) tab[o++] = (uint32_t)(4 * i) | ((uint32_t)(4 * j) << 16);
     }
+    // padding up to the next multiple of 128 entries: the pair (0, 0) has distance 0, which lies below the fine grid
+    const int total = cnt[N], padded = (total + 127) & ~127;
+    for (int o = total + threadIdx.x; o < padded; o += blockDim.x) tab[o] = 0u;
+}
+
+// One frame of one wave.  SAFE: the fine grid starts above 0 and ends inside the cutoff (checked once per kernel), so
+// `0 <= t < nfine` alone accepts exactly the pairs of topology.py:67 that can contribute -- a zero distance (padding
+// entries, coincident atoms) falls below the grid, a distance beyond the cutoff above it.
+template <bool DIAG, bool SAFE>
+__device__ __forceinline__ void rdf_fine_frame(const MdgCell& cell, const uint32_t* __restrict__ tab, int P, float rc2,
+                                               float inv_h, float tlo, float fmax, const float* px, const float* py,
+                                               const float* pz, uint32_t* hist, int lane) {
+    const char* bx = reinterpret_cast<const char*>(px);
+    const char* by = reinterpret_cast<const char*>(py);
+    const char* bz = reinterpret_cast<const char*>(pz);
+#define LDF(base, off) (*reinterpret_cast<const float*>((base) + (off)))
+    if constexpr (DIAG) {
+        // two table entries per lane and step in packed fp32 (the same image arithmetic as min_image<true>)
+        const float iv0 = cell.inv[0], iv1 = cell.inv[4], iv2 = cell.inv[8];
+        const float h0 = cell.h[0], h1 = cell.h[4], h2 = cell.h[8];
+        for (int p0 = 0; p0 < P; p0 += 128) {
+            const uint32_t ea = tab[p0 + lane], eb = tab[p0 + 64 + lane];
+            const int ia = (int)(ea & 0xFFFFu), ja = (int)(ea >> 16), ib = (int)(eb & 0xFFFFu), jb = (int)(eb >> 16);
+            f32x2 dx = f32x2{LDF(bx, ja), LDF(bx, jb)} - f32x2{LDF(bx, ia), LDF(bx, ib)};
+            f32x2 dy = f32x2{LDF(by, ja), LDF(by, jb)} - f32x2{LDF(by, ia), LDF(by, ib)};
+            f32x2 dz = f32x2{LDF(bz, ja), LDF(bz, jb)} - f32x2{LDF(bz, ia), LDF(bz, ib)};
+            dx = min_image_diag2(dx, iv0, h0); dy = min_image_diag2(dy, iv1, h1); dz = min_image_diag2(dz, iv2, h2);
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            const float ta = fmaf(__builtin_amdgcn_sqrtf(d2.x), inv_h, tlo), tb = fmaf(__builtin_amdgcn_sqrtf(d2.y), inv_h, tlo);
+            bool oka = ta >= 0.f && ta < fmax, okb = tb >= 0.f && tb < fmax;
+            if (!SAFE) { oka = oka && d2.x < rc2 && d2.x != 0.f; okb = okb && d2.y < rc2 && d2.y != 0.f; }
+            if (oka) atomicAdd(&hist[(int)ta], 1u);
+            if (okb) atomicAdd(&hist[(int)tb], 1u);
+        }
+    } else {
+        for (int p0 = 0; p0 < P; p0 += 64) {
+            const uint32_t ent = tab[p0 + lane];
+            const int i = (int)(ent & 0xFFFFu), j = (int)(ent >> 16);
+            float dx = LDF(bx, j) - LDF(bx, i), dy = LDF(by, j) - LDF(by, i), dz = LDF(bz, j) - LDF(bz, i);
+            min_image<DIAG>(cell, dx, dy, dz);
+            const float d2 = norm2_ref(dx, dy, dz);
+            const float t = fmaf(__builtin_amdgcn_sqrtf(d2), inv_h, tlo);
+            bool ok = t >= 0.f && t < fmax;
+            if (!SAFE) ok = ok && d2 < rc2 && d2 != 0.f;
+            if (ok) atomicAdd(&hist[(int)t], 1u);
+        }
+    }
+#undef LDF
 }
 
 template <bool DIAG>
@@ -846,7 +894,10 @@ __global__ __launch_bounds__(64 * RDF_FINE_WAVES) void rdf_fwd_fine_kernel(
     float* pz = py + ld;
     for (int m = threadIdx.x; m < nfine; m += blockDim.x) hist[m] = 0u;
     __syncthreads();
-    const int P = *count;
+    const int P = *count;                                       // (the table is padded to a multiple of 128 entries)
+    const float fmax = (float)nfine, tlo = -lo * inv_h;
+    const float hi = lo + fmax / inv_h;
+    const bool safe = lo > 0.f && hi * hi <= rc2;
     for (int fr = blockIdx.x * RDF_FINE_WAVES + wid; fr < nF; fr += gridDim.x * RDF_FINE_WAVES) {
         const float* pos = xyz + (size_t)fr * N * 3;
         for (int e = lane; e < 3 * N; e += 64) {                // AoS -> SoA (coalesced read)
@@ -854,38 +905,8 @@ __global__ __launch_bounds__(64 * RDF_FINE_WAVES) void rdf_fwd_fine_kernel(
             px[c * ld + a] = pos[e];
         }
         // (px is private to the wave: program order + the LDS counter suffice)
-        // accepted: a real pair, inside the cutoff (topology.py:67) and inside the fine range (beyond it every
-        // Gaussian is below 2^-28 of its peak)
-        if constexpr (DIAG) {
-            // two table entries per lane and step in packed fp32 (the same image arithmetic as min_image<true>)
-            const float iv0 = cell.inv[0], iv1 = cell.inv[4], iv2 = cell.inv[8];
-            const float h0 = cell.h[0], h1 = cell.h[4], h2 = cell.h[8];
-            const float fmax = (float)nfine;
-            for (int p0 = 0; p0 < P; p0 += 128) {
-                const int pa = p0 + lane, pb = pa + 64;
-                const uint32_t ea = pa < P ? tab[pa] : 0u, eb = pb < P ? tab[pb] : 0u;
-                const int ia = (int)(ea & 0xFFFFu), ja = (int)(ea >> 16), ib = (int)(eb & 0xFFFFu), jb = (int)(eb >> 16);
-                f32x2 dx = f32x2{px[ja], px[jb]} - f32x2{px[ia], px[ib]};
-                f32x2 dy = f32x2{py[ja], py[jb]} - f32x2{py[ia], py[ib]};
-                f32x2 dz = f32x2{pz[ja], pz[jb]} - f32x2{pz[ia], pz[ib]};
-                dx = min_image_diag2(dx, iv0, h0); dy = min_image_diag2(dy, iv1, h1); dz = min_image_diag2(dz, iv2, h2);
-                const f32x2 d2 = norm2_ref2(dx, dy, dz);
-                const f32x2 t = (f32x2{sqrtf(d2.x), sqrtf(d2.y)} - lo) * inv_h;
-                if (pa < P && d2.x < rc2 && d2.x != 0.f && t.x >= 0.f && t.x < fmax) atomicAdd(&hist[(int)t.x], 1u);
-                if (pb < P && d2.y < rc2 && d2.y != 0.f && t.y >= 0.f && t.y < fmax) atomicAdd(&hist[(int)t.y], 1u);
-            }
-        } else {
-            for (int p0 = 0; p0 < P; p0 += 64) {
-                const int p_ = p0 + lane;
-                const uint32_t ent = p_ < P ? tab[p_] : 0u;
-                const int i = (int)(ent & 0xFFFFu), j = (int)(ent >> 16);
-                float dx = px[j] - px[i], dy = py[j] - py[i], dz = pz[j] - pz[i];
-                min_image<DIAG>(cell, dx, dy, dz);
-                const float d2 = norm2_ref(dx, dy, dz);
-                const float t = (sqrtf(d2) - lo) * inv_h;
-                if (p_ < P && d2 < rc2 && d2 != 0.f && t >= 0.f && t < (float)nfine) atomicAdd(&hist[(int)t], 1u);
-            }
-        }
+        if (safe) rdf_fine_frame<DIAG, true>(cell, tab, P, rc2, inv_h, tlo, fmax, px, py, pz, hist, lane);
+        else rdf_fine_frame<DIAG, false>(cell, tab, P, rc2, inv_h, tlo, fmax, px, py, pz, hist, lane);
     }
     __syncthreads();
     for (int m = threadIdx.x; m < nfine; m += blockDim.x) {
@@ -1144,7 +1165,7 @@ static int rdf_fwd_impl(const float* xyz, int n_frames, int n_atoms, const MdgCe
         if (nfine <= RDF_FINE_MAX && lds <= 156 * 1024) {
             const long long npair = (long long)n_atoms * (n_atoms - 1) / 2;
             uint32_t* scratch = nullptr;                          // [nfine] global histogram | count | pair table
-            const size_t words = (size_t)nfine + 4 + (size_t)npair;
+            const size_t words = (size_t)nfine + 4 + (size_t)npair + 128;
             if (hipMallocAsync((void**)&scratch, sizeof(uint32_t) * words, st) == hipSuccess && scratch) {
                 uint32_t* ghist = scratch;
                 int32_t* count = reinterpret_cast<int32_t*>(scratch + nfine);
