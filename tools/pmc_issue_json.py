@@ -11,12 +11,13 @@ cur = sqlite3.connect(sys.argv[1]).cursor()
 rows = cur.execute("select kernel_name, counter_name, value, duration from counters_collection").fetchall()
 agg = defaultdict(list)
 for name, cn, val, dur in rows:
-    agg[(name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", ""), cn)].append((float(val), float(dur)))
+    clean = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    agg[(clean.split("<")[0].split("(")[0], cn)].append((float(val), float(dur)))
 out = {}
 for (name, cn), v in agg.items():
     if cn != "SQ_ACTIVE_INST_VALU":
         continue
-    short = name.split("<")[0]
+    short = name
     val = sum(x[0] for x in v) / len(v)
     dur_s = sum(x[1] for x in v) / len(v) * 1e-9
     if dur_s < 1e-4:
