@@ -187,37 +187,59 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             const float4* sp = A.spos + (size_t)rep * N;
             const int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
             const int nbx = A.nb[0], nby = A.nb[1], nbz = A.nb[2];
-            const int bx = bin_coord_l(xi, iv0, nbx), by = bin_coord_l(yi, iv1, nby), bz = bin_coord_l(zi, iv2, nbz);
-            for (int s = 0; s < 18; ++s) {
-                const int colm = s >> 1, part = s & 1;
-                const int cx = (bx + colm / 3 - 1 + nbx) % nbx, cy = (by + colm % 3 - 1 + nby) % nby;
-                const int cb = (cx * nby + cy) * nbz;
-                int zlo = bz - 1, zhi = bz + 1;
-                if (part == 0) { zlo = max(zlo, 0); zhi = min(zhi, nbz - 1); }
-                else if (bz == 0) { zlo = zhi = nbz - 1; }
-                else if (bz == nbz - 1) { zlo = zhi = 0; }
-                else continue;
-                const int a0 = bs[cb + zlo], a1 = bs[cb + zhi + 1];
-                for (int a = a0; a < a1; a += 64) {
-                    const int idx = a + lane;
-                    bool ok = false;
-                    float dx = 0.f, dy = 0.f, dz = 0.f;
-                    int j = -1;
-                    if (idx < a1) {
-                        const float4 pj = sp[idx];
-                        j = __float_as_int(pj.w);
-                        f32x2 ddx = f32x2{pj.x, 0.f} - xi, ddy = f32x2{pj.y, 0.f} - yi, ddz = f32x2{pj.z, 0.f} - zi;
-                        ddx = min_image_diag2(ddx, iv0, h0); ddy = min_image_diag2(ddy, iv1, h1); ddz = min_image_diag2(ddz, iv2, h2);
-                        const f32x2 d2 = norm2_ref2(ddx, ddy, ddz);
-                        dx = ddx.x; dy = ddy.x; dz = ddz.x;
-                        ok = (j != i) & (d2.x < rc2max) & (d2.x != 0.f);
+            // the atom's bin is the same on every lane: keep the stencil arithmetic on the scalar unit (and off integer
+            // division: the wrapped neighbours of a bin are one compare-and-add away)
+            const int bx = __builtin_amdgcn_readfirstlane(bin_coord_l(xi, iv0, nbx));
+            const int by = __builtin_amdgcn_readfirstlane(bin_coord_l(yi, iv1, nby));
+            const int bz = __builtin_amdgcn_readfirstlane(bin_coord_l(zi, iv2, nbz));
+            const int zl0 = max(bz - 1, 0), zh0 = min(bz + 1, nbz - 1);          // in-range part of the z column
+            const int zw = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);          // wrapped remainder (or none)
+            // one candidate of every range per lane is requested BEFORE any of them is tested (the ranges hold ~57
+            // atoms: the nine loads of a batch are in flight together instead of nine dependent round trips to L2);
+            // batch 0 = the in-range z-parts of the 9 columns, batch 1 = their wrapped remainders (border bins only)
+            auto test = [&](const float4 pj, bool live) {
+                bool ok = false;
+                float dx = 0.f, dy = 0.f, dz = 0.f;
+                const int j = __float_as_int(pj.w);
+                if (live) {
+                    f32x2 ddx = f32x2{pj.x, 0.f} - xi, ddy = f32x2{pj.y, 0.f} - yi, ddz = f32x2{pj.z, 0.f} - zi;
+                    ddx = min_image_diag2(ddx, iv0, h0); ddy = min_image_diag2(ddy, iv1, h1); ddz = min_image_diag2(ddz, iv2, h2);
+                    const f32x2 d2 = norm2_ref2(ddx, ddy, ddz);
+                    dx = ddx.x; dy = ddy.x; dz = ddz.x;
+                    ok = (j != i) & (d2.x < rc2max) & (d2.x != 0.f);
+                }
+                const unsigned long long bal = __ballot(ok);
+                if (ok) {
+                    const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (k < LG_CAP) buf[k] = make_float4(dx, dy, dz, __int_as_float(j));
+                }
+                n += __popcll(bal);
+            };
+            for (int part = 0; part < 2; ++part) {
+                if (part && zw < 0) break;
+                const int zlo = part ? zw : zl0, zhi = part ? zw : zh0;
+                int a0[9], a1[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    int cx = bx + c / 3 - 1, cy = by + c % 3 - 1;
+                    cx += cx < 0 ? nbx : 0; cx -= cx >= nbx ? nbx : 0;
+                    cy += cy < 0 ? nby : 0; cy -= cy >= nby ? nby : 0;
+                    const int cb = (cx * nby + cy) * nbz;
+                    a0[c] = bs[cb + zlo]; a1[c] = bs[cb + zhi + 1];
+                }
+                float4 pj[9];
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    const int idx = a0[c] + lane;
+                    pj[c] = idx < a1[c] ? sp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int c = 0; c < 9; ++c) {
+                    test(pj[c], a0[c] + lane < a1[c]);
+                    for (int a = a0[c] + 64; a < a1[c]; a += 64) {      // ranges longer than a wave (dense bins)
+                        const int idx = a + lane;
+                        test(idx < a1[c] ? sp[idx] : make_float4(0.f, 0.f, 0.f, 0.f), idx < a1[c]);
                     }
-                    const unsigned long long b = __ballot(ok);
-                    if (ok) {
-                        const int k = n + __popcll(b & ((1ull << lane) - 1ull));
-                        if (k < LG_CAP) buf[k] = make_float4(dx, dy, dz, __int_as_float(j));
-                    }
-                    n += __popcll(b);
                 }
             }
             // ascending neighbour index (entries are distinct): rank sort inside the wave's buffer
