@@ -22,7 +22,8 @@
 
 namespace {
 
-constexpr int LG_WAVES = 16;                 // waves (= atoms in flight) per workgroup
+constexpr int LG_WAVES = 16;                 // waves (= atoms in flight) per workgroup: all-atom scan (tile staging amortised)
+constexpr int LG_WAVES_CELL = 4;             // ... cell-binned scan: small workgroups (no tile; short barriers; 5 resident per CU)
 constexpr int LG_BLOCK = LG_WAVES * 64;
 constexpr int LG_TILE = 2048;               // positions staged in LDS per pass
 constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
@@ -384,8 +385,9 @@ __device__ __forceinline__ float prepare_terms(const LargeArgs& A, TermConst (&t
 // MODE 0: initial force at q0 + frame 0 + KE(v0) partials.   MODE 1: second half of step k.
 template <bool DIAG, int MODE, int KIND>
 __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) {
-    __shared__ float tile[3 * LG_TILE];
-    __shared__ float4 nbuf[LG_WAVES * LG_CAP];
+    // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
+    extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
+    float* tile = reinterpret_cast<float*>(nbuf + (blockDim.x >> 6) * LG_CAP);
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y;
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
         A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
     TermConst tc[MDG_MAX_TERMS];
     const float rc2max = prepare_terms(A, tc);
-    const int i = blockIdx.x * LG_WAVES + wid;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wid;
     const bool valid = i < N;
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
     wave_neighbours_and_force<DIAG, 1, KIND>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
@@ -497,8 +499,9 @@ __global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
 template <bool DIAG, int KIND>
 __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, const int second) {
-    __shared__ float tile[3 * LG_TILE];
-    __shared__ float4 nbuf[LG_WAVES * LG_CAP];
+    // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
+    extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
+    float* tile = reinterpret_cast<float*>(nbuf + (blockDim.x >> 6) * LG_CAP);
     __shared__ float red[16 * LG_NV];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
     const float* lam = second ? A.lvh + so : A.lv + so;
     TermConst tc[MDG_MAX_TERMS];
     const float rc2max = prepare_terms(A, tc);
-    const int i = blockIdx.x * LG_WAVES + wid;
+    const int i = blockIdx.x * (blockDim.x >> 6) + wid;
     const bool valid = i < N;
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
 #pragma unroll
@@ -684,15 +687,14 @@ int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* 
 
 extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_total) {
     if (n_rep <= 0 || n_atoms <= 0) return -1;
-    const int nb = (n_atoms + LG_WAVES - 1) / LG_WAVES;
+    const int nb = (n_atoms + LG_WAVES_CELL - 1) / LG_WAVES_CELL;       // (the larger of the two workgroup shapes)
     return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total).total;
 }
 
 #define LG_SETUP()                                                                                   \
     const int R = prm->n_rep, N = prm->n_atoms;                                                      \
-    const int nbF = (N + LG_WAVES - 1) / LG_WAVES, nbE = (3 * N + 255) / 256;                        \
-    const int nbmax = nbF > nbE ? nbF : nbE;                                                         \
-    const WsLayout L = ws_layout(R, N, nbF, terms->n_theta_total);                                   \
+    const int nbE = (3 * N + 255) / 256;                                                             \
+    const WsLayout L = ws_layout(R, N, (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL, terms->n_theta_total); \
     LargeArgs a{};                                                                                   \
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;   \
     a.q = ws + L.q; a.v = ws + L.v; a.vh = ws + L.vh; a.f = ws + L.f;                                \
@@ -700,7 +702,7 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     a.qm = ws + L.qm; a.vm = ws + L.vm;                                                              \
     a.pv = ws + L.pv; a.ph = ws + L.ph; a.pvh = ws + L.pvh; a.lp = ws + L.lp; a.lph = ws + L.lph;    \
     a.pvm = ws + L.pvm; a.partA = ws + L.partA; a.partB = ws + L.partB; a.partN = ws + L.partN;      \
-    a.gth = ws + L.gth; a.flags = flags; a.nbF = nbF; a.nbE = nbE;                                               \
+    a.gth = ws + L.gth; a.flags = flags; a.nbE = nbE;                                                \
     const bool table = terms->t[0].kind == MDG_PAIR_TABLE;                                           \
     a.ghi = table ? reinterpret_cast<int32_t*>(ws + L.ghi) : nullptr;                                \
     a.glo = table ? reinterpret_cast<int32_t*>(ws + L.glo) : nullptr;                                \
@@ -724,9 +726,13 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
         }                                                                                            \
     }                                                                                                \
     const dim3 gB((N + 255) / 256, R);                                                               \
+    const int wpb = a.ncell ? LG_WAVES_CELL : LG_WAVES;                                              \
+    const int nbF = (N + wpb - 1) / wpb;                                                             \
+    a.nbF = nbF;                                                                                     \
+    const size_t tile_lds = sizeof(float4) * (size_t)wpb * LG_CAP + (a.ncell ? 0 : sizeof(float) * 3 * LG_TILE); \
     const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
                        terms->t[0].p == 12 && terms->t[0].q == 6;                                    \
-    (void)nbmax;
+    (void)0;
 
 extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
                                   const float* theta, const float* mass, const float* t_grid,
@@ -751,9 +757,9 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
             hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, 0, bin_phase);                          \
             bin_phase ^= 1;                                                                                     \
         }                                                                                                       \
-        if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a); \
-        else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);    \
-        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(LG_BLOCK), 0, st, a);            \
+        if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a); \
+        else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);    \
+        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);            \
     } while (0)
     LG_FORCE_STEP(0);
     for (int k = 0; k + 1 < T; ++k) {
@@ -808,9 +814,9 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
             hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, (SECOND_) ? 2 : 1, bin_phase);              \
             bin_phase ^= 1;                                                                                         \
         }                                                                                                           \
-        if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);   \
-        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);       \
-        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(LG_BLOCK), 0, st, a, SECOND_);               \
+        if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);   \
+        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);       \
+        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);               \
     } while (0)
         LG_ADJ_FORCE(0);
         hipLaunchKernelGGL(large_adj_mid, gE, dim3(256), 0, st, a);

@@ -21,11 +21,12 @@ import torch
 
 from .tinydiffeq import _flatten
 
-# Largest fixed edge capacity that is still replayed from a captured graph.  With the fused interaction-block kernels
-# no edge-sized tensor exists any more, so the graph's private pool holds node-level tensors only (a few hundred MB at
-# 32 768 atoms) and replay pays off well beyond the launch-bound sizes: the ~320 launches of an MD step cost the host
-# ~25 us each through Python, more than the GPU needs for them at 4096 beads x 8 replicas.
-MAX_EDGES = int(os.environ.get("MDG_GRAPH_MAX_EDGES", str(1 << 21)))
+# Largest fixed edge capacity that is still replayed from a captured graph; larger systems run eagerly on the same
+# fixed-capacity lists (eager_static: no host sync per rebuild).  Replay was measured up to 2 M edges: at 4096 beads x 8
+# replicas it is no faster than the sync-free eager pass (the GPU is busy 75 of 85 ms either way), and capturing
+# half-million-pair graphs from the autograd thread aborted once in three runs on ROCm 7.2, so the limit stays where
+# launches, not kernels, bound the step.
+MAX_EDGES = int(os.environ.get("MDG_GRAPH_MAX_EDGES", str(1 << 18)))
 
 
 def enabled(func):
