@@ -15,6 +15,7 @@ captured once into a HIP graph and replayed per step.  What makes the capture po
 The arithmetic is the eager path's (same functions, same order): results are bitwise identical.
 Graphs are cached on the integrator per (kind, shapes, frames, capacities, parameter identities).
 """
+import gc
 import os
 
 import torch
@@ -55,9 +56,20 @@ def _capture(body, reset):
             body()
     torch.cuda.current_stream().wait_stream(side)
     reset()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        body()
+    # No cyclic garbage collection while the stream is capturing: an integrator that went out of scope earlier keeps
+    # its graphs alive through a reference cycle (integrator -> cache -> graph -> integrator), and the collector
+    # destroying such a graph (hipGraphExecDestroy + its private pool) in the middle of a capture aborts the process
+    # on ROCm 7.2 (seen once in three cold runs).  Collect first, then hold the collector off until the capture ends.
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+    finally:
+        if was_enabled:
+            gc.enable()
     return g
 
 
