@@ -236,6 +236,14 @@ int mdg_rdf_fwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCe
 int mdg_rdf_bwd(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                 float cutoff, const uint8_t* mask, const float* mu, float coeff, int nbins,
                 const float* g_raw, float* g_xyz, void* stream);
+/* Soft histogram of a system given as a per-atom neighbour list (large systems, few frames; frames stacked as groups of
+ * the list): every pair (slot neighbour index above the atom's) counted once on a fine integer grid, then smeared onto
+ * the equally spaced centres -- the pair search of torchmd/observable.py:64-66 is the list build.  The gradient is a
+ * tabulated pair force (mdg_pair_eval_ell with an MDG_PAIR_TABLE term built from g_raw). */
+int mdg_rdf_ell_supported(float spacing, float coeff, int nbins);
+int mdg_rdf_fwd_ell(const float* pos, int64_t n_atoms_total, const MdgCell* cell /*host*/, const int32_t* col,
+                    const int32_t* shift, const int32_t* cnt, int max_nbr, const float* mu, float spacing, float coeff,
+                    int nbins, float* raw, void* stream);
 /* backward with the same equally-spaced-centres guarantee (mdg_rdf_bwd makes no assumption on mu). */
 int mdg_rdf_bwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                         float cutoff, const uint8_t* mask, const float* mu, float spacing, float coeff,

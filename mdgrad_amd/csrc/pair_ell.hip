@@ -121,7 +121,9 @@ extern "C" int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* c
                                  float* partial, void* stream) {
     MDG_CHECK_ARG(pos && cell && col && shift && cnt && term && partial, "pair_eval_ell: null buffer");
     MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0, "pair_eval_ell: bad sizes");
-    MDG_CHECK_ARG(term->kind >= 0 && term->kind <= MDG_PAIR_YUKAWA && term->n_theta <= MDG_MAX_THETA,
+    // (MDG_PAIR_TABLE: theta is the table itself -- 2 p floats -- and carries no parameter gradient here)
+    MDG_CHECK_ARG((term->kind >= 0 && term->kind <= MDG_PAIR_YUKAWA && term->n_theta <= MDG_MAX_THETA) ||
+                  (term->kind == MDG_PAIR_TABLE && term->p >= 4 && term->n_theta == 2 * term->p && term->phi > 0.f),
                   "pair_eval_ell: bad pair term");
     MDG_CHECK_ARG(term->n_theta == 0 || theta, "pair_eval_ell: theta is null");
     MDG_CHECK_ARG(!w || hw, "pair_eval_ell: w given without hw output");

@@ -915,6 +915,35 @@ __global__ __launch_bounds__(64 * RDF_FINE_WAVES) void rdf_fwd_fine_kernel(
     }
 }
 
+// The same fine histogram fed from a neighbour list (large systems, few frames: config #4's 4 096-atom liquid):
+// thread per (atom, slot) of the per-atom list, every pair counted once (slot's neighbour index above the atom's).
+// Frames are stacked as groups of the list (mdg_nbr_build_cell_groups), so one launch covers all of them.
+__global__ __launch_bounds__(1024) void rdf_fwd_ell_kernel(
+    const float* __restrict__ pos, long long n_slots, MdgCell cell, const int32_t* __restrict__ col,
+    const int32_t* __restrict__ shift, const int32_t* __restrict__ cnt, int max_nbr, const float* __restrict__ mu,
+    float reach, float inv_h, int nfine, uint32_t* __restrict__ ghist) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smf);
+    for (int m = threadIdx.x; m < nfine; m += blockDim.x) hist[m] = 0u;
+    __syncthreads();
+    const float lo = mu[0] - reach, tlo = -lo * inv_h, fmax = (float)nfine;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n_slots; t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / max_nbr), k = (int)(t - (long long)i * max_nbr);
+        if (k >= cnt[i]) continue;
+        const int j = col[t];
+        if (j <= i) continue;
+        float dx = pos[3 * i] - pos[3 * j], dy = pos[3 * i + 1] - pos[3 * j + 1], dz = pos[3 * i + 2] - pos[3 * j + 2];
+        apply_shift(cell, shift[t], dx, dy, dz);
+        const float tt = fmaf(__builtin_amdgcn_sqrtf(norm2_ref(dx, dy, dz)), inv_h, tlo);
+        if (tt >= 0.f && tt < fmax) atomicAdd(&hist[(int)tt], 1u);
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < nfine; m += blockDim.x) {
+        const uint32_t v = hist[m];
+        if (v) atomicAdd(&ghist[m], v);
+    }
+}
+
 // raw[k] = sum_m H[m] exp2(-(s (x_m - mu_k))^2): one wave per centre over the fine bins within reach
 __global__ void rdf_fine_finish_kernel(const uint32_t* __restrict__ ghist, int nfine, float h,
                                        const float* __restrict__ mu, float sc, float reach, int nbins,
@@ -1368,4 +1397,44 @@ extern "C" int mdg_rdf_bwd_uniform(const float* xyz, int n_frames, int n_atoms, 
                                    const float* g_raw, float* g_xyz, void* stream) {
     const float spacing_s = spacing > 0.f && coeff < 0.f ? spacing * sqrtf(-coeff * 1.4426950408889634f) : 0.f;
     return rdf_bwd_impl(xyz, n_frames, n_atoms, cell, cutoff, mask, mu, coeff, nbins, g_raw, g_xyz, spacing_s, stream);
+}
+
+// fine grid of the integer-histogram forward for centres mu0 + k spacing and exp(coeff x^2): number of fine bins, or
+// 0 when it does not fit the workgroup's LDS histogram
+static long long rdf_fine_bins(float spacing, float coeff, int nbins, float* reach, float* h) {
+    if (!(spacing > 0.f) || !(coeff < 0.f) || nbins < 2) return 0;
+    const float sc = sqrtf(-coeff * LOG2E);
+    *reach = 5.3f / sc;
+    *h = 0.004f / sc;
+    const double span = (double)(nbins - 1) * spacing + 2.0 * (*reach);
+    const long long nfine = (long long)ceil(span / *h) + 1;
+    return nfine <= RDF_FINE_MAX ? nfine : 0;
+}
+
+extern "C" int mdg_rdf_ell_supported(float spacing, float coeff, int nbins) {
+    float reach, h;
+    return rdf_fine_bins(spacing, coeff, nbins, &reach, &h) > 0;
+}
+
+extern "C" int mdg_rdf_fwd_ell(const float* pos, int64_t n_atoms_total, const MdgCell* cell, const int32_t* col,
+                               const int32_t* shift, const int32_t* cnt, int max_nbr, const float* mu, float spacing,
+                               float coeff, int nbins, float* raw, void* stream) {
+    MDG_CHECK_ARG(pos && cell && col && shift && cnt && mu && raw && n_atoms_total > 0 && max_nbr > 0, "rdf_fwd_ell: bad arguments");
+    float reach, h;
+    const long long nfine = rdf_fine_bins(spacing, coeff, nbins, &reach, &h);
+    MDG_CHECK_ARG(nfine > 0, "rdf_fwd_ell: the fine grid for these centres does not fit (see mdg_rdf_ell_supported)");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* ghist = nullptr;
+    MDG_HIP(hipMallocAsync((void**)&ghist, sizeof(uint32_t) * (size_t)nfine, st));
+    MDG_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)nfine, st));
+    const long long n_slots = (long long)n_atoms_total * max_nbr;
+    long long grid = (n_slots + 1023) / 1024;
+    if (grid > 256) grid = 256;
+    const float sc = sqrtf(-coeff * LOG2E);
+    hipLaunchKernelGGL(rdf_fwd_ell_kernel, dim3((unsigned)grid), dim3(1024), sizeof(uint32_t) * (size_t)nfine, st, pos, n_slots,
+                       *cell, col, shift, cnt, max_nbr, mu, reach, 1.0f / h, (int)nfine, ghist);
+    hipLaunchKernelGGL(rdf_fine_finish_kernel, dim3(nbins), dim3(64), 0, st, ghist, (int)nfine, h, mu, sc, reach, nbins, raw);
+    (void)hipFreeAsync(ghist, st);
+    MDG_CHECK_LAUNCH("rdf_fwd_ell_kernel");
+    return MDG_OK;
 }

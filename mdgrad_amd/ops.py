@@ -459,6 +459,26 @@ def _time_vjps(spec, t, v_t, q_t, pv_t, gv, gq, gp):
 
 
 # ----------------------------------------------------------------------------- rdf
+RDF_LIST_ATOMS = 2048        # from this size on the RDF runs over a cell-list neighbour list instead of all N^2 pairs
+
+
+def _rdf_pair_table(g_raw, mu, coeff, cutoff, nodes=4096):
+    """The RDF loss as a pair 'potential' phi(d) = sum_k g_k exp(coeff (d - mu_k)^2): its table for the
+    MDG_PAIR_TABLE kind -- c1(u) = phi'(r)/r and du * dc1/du on a uniform grid in u = r^2 (csrc/common.hpp)."""
+    lo = max(float(mu[0]) - 6.0 / math.sqrt(-2.0 * coeff), 0.05)
+    u0, u1 = lo * lo, float(cutoff) ** 2
+    du = (u1 - u0) / (nodes - 1)
+    r = (u0 + du * torch.arange(nodes, device=mu.device, dtype=torch.float32)).sqrt()[:, None]
+    x = r - mu[None, :]
+    e = torch.exp(coeff * x * x) * g_raw[None, :]
+    p1 = (2.0 * coeff * x * e).sum(1)                                    # phi'
+    p2 = ((2.0 * coeff + (2.0 * coeff * x) ** 2) * e).sum(1)             # phi''
+    r = r[:, 0]
+    c1 = p1 / r
+    dc1 = (p2 / r - p1 / (r * r)) / (2.0 * r)                            # d(phi'/r)/du
+    return torch.stack((c1, du * dc1), 1).reshape(-1).contiguous(), u0, du
+
+
 class RdfRawFn(torch.autograd.Function):
     """raw[k] = sum over frames and i<j pairs (d < cutoff) of exp(coeff (d - mu_k)^2)
     (the GaussianSmearing(...).sum(0) of torchmd/observable.py:70)."""
@@ -472,6 +492,22 @@ class RdfRawFn(torch.autograd.Function):
         F, N, B = x3.shape[0], x3.shape[1], mu.shape[0]
         dev = x.device
         raw = torch.empty(B, device=dev)
+        ctx.ell = None
+        if (N >= RDF_LIST_ATOMS and mask is None and spacing > 0 and cell_struct.diag
+                and _use_cell_list(N, cell_struct, float(cutoff))
+                and lib.mdg_rdf_ell_supported(float(spacing), float(coeff), B)):
+            # large systems: pair search through the cell list (frames = groups of one list), every listed pair
+            # counted on the fine integer grid; the gradient is a tabulated pair force over the same list
+            flat = x3.reshape(F * N, 3)
+            ell = build_ell(flat, cell_struct, cutoff, group=N)
+            muc = mu.detach().to(torch.float32).contiguous()
+            check(lib.mdg_rdf_fwd_ell(ptr(flat), F * N, C.byref(cell_struct), ptr(ell.col), ptr(ell.shift), ptr(ell.cnt),
+                                      ell.max_nbr, ptr(muc), float(spacing), float(coeff), B, ptr(raw), stream_ptr(dev)),
+                  "mdg_rdf_fwd_ell")
+            ctx.ell = ell
+            ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape, float(spacing))
+            ctx.save_for_backward(flat, muc)
+            return raw
         partial = torch.empty(int(lib.mdg_rdf_partial_size(F, N, B)), device=dev)
         muc = mu.detach().to(torch.float32).contiguous()
         check(lib.mdg_rdf_fwd_uniform(ptr(x3), F, N, C.byref(cell_struct), float(cutoff), ptr(mask), ptr(muc),
@@ -486,6 +522,12 @@ class RdfRawFn(torch.autograd.Function):
         lib = _lib.load()
         x3, muc = ctx.saved_tensors
         coeff, cutoff, cell_struct, mask, shape, spacing = ctx.args
+        if ctx.ell is not None:
+            nodes = 4096
+            table, u0, du = _rdf_pair_table(g_raw.detach().to(torch.float32), muc, coeff, cutoff, nodes)
+            term = make_term(dict(kind=MDG_PAIR_TABLE, p=nodes, a=u0, phi=du, c=1.0), cutoff, 0, 2 * nodes, None)
+            o = pair_eval(ctx.ell, x3, term, table, energy=False, grad=True)
+            return o["grad"].reshape(shape), None, None, None, None, None, None
         F, N, B = x3.shape[0], x3.shape[1], muc.shape[0]
         gx = torch.empty_like(x3)
         gr = g_raw.detach().to(torch.float32).contiguous()
