@@ -9,7 +9,7 @@ script = one such pass; value = R*(T-1)*N_gpus*K / time.  Inputs are resident in
 The same JSON line nests, under "secondary", the two other north-star workloads measured the same way (each
 with its own value / ms_per_step / roofline / cpu_baseline):
   schnet4096   4 096-bead CG water, SchNet A64/F128/G30/2 conv + ExcludedVolume prior, 8 stacked replicas / GPU
-  lj4096       4 096-atom LJ liquid (BASELINE config #4), fused large-N kernels, 4 replicas / GPU
+  lj4096       4 096-atom LJ liquid (BASELINE config #4), fused large-N kernels, 16 replicas / GPU
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -469,7 +469,7 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     from mdgrad_amd.system import System, Atoms
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    R = 4 if args.replicas is None or args.workload != "lj4096" else args.replicas
+    R = 16 if args.replicas is None or args.workload != "lj4096" else args.replicas
     T = 51 if args.frames is None or args.workload != "lj4096" else args.frames
     rng = np.random.default_rng(3000 + rank)
     pos1, L = lj_liquid(16, 0.845, rng)
@@ -516,7 +516,7 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "LJ(1,1) liquid, 4096 atoms, rho 0.845, cutoff 2.5, NoseHooverChain(Q=50, 5 chains), %d "
                                   "steps fwd + RDF(100 bins, every 5th frame) loss + adjoint; %d replicas/GPU per pass, "
-                                  "neighbour search fused into every force evaluation" % (T - 1, R),
+                                  "cell-binned neighbour search fused into every force evaluation" % (T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
     if rank != 0:
         return out
@@ -541,7 +541,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 4)")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 16)")
     ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11 / 51")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
