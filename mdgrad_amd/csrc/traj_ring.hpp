@@ -1,0 +1,421 @@
+// Wave-per-replica, register-resident variant of the fused trajectory kernels (included by traj_small.hip
+// inside its anonymous namespace; TrajArgs and the bath formulas are the ones defined there).
+//
+// Many-replica launches of a small system (N <= 128, one unmasked LJ 12-6 term, orthorhombic cell) are bound by
+// VALU issue, and the all-pairs sweep of traj_*_kernel evaluates every pair twice (once from each end) and
+// fetches the j-side operands from LDS.  Here ONE wave integrates one replica with the whole state in VGPRs:
+//
+//   * lane l owns atoms (2l, 2l+1) as the two halves of packed f32x2 registers -- every update of the
+//     integrator and of the adjoint is v_pk_*_f32 on both atoms, no LDS, no barrier;
+//   * the force sweep is a systolic ring with Newton's third law over the nl = ceil(N/2) lanes that own atoms:
+//     at step k lane l meets the atoms of lane (l - k) mod nl and evaluates the four pairs between its two atoms
+//     and the two visitors as two packed operations ("straight" (i0,j0),(i1,j1) and "crossed" (i0,j1),(i1,j0)
+//     -- the crossing is an op_sel modifier, not an instruction), adding +F to its own accumulators and -F to
+//     the visitors' accumulators, which travel with them from lane to lane (ds_bpermute_b32: the LDS crossbar,
+//     no VALU slot).  The visitors' positions and adjoint direction w are read from a 3 KB LDS copy written once
+//     per evaluation (conflict-free ds_read_b64).  Steps 1..(nl-1)/2 cover every pair of lanes once; step 0 (the
+//     pair inside a lane) and, for even nl, the antipodal step nl/2 (lanes that meet from both sides) are
+//     evaluated in both directions without the travelling update.  Afterwards one more bpermute brings the
+//     travelling accumulators home.  N = 108: 55 packed pair operations per evaluation instead of 2 x 54.
+//     (A 64-lane ring rotated by DPP wave_ror:1 -- full rate, tools/micro/dpp_rot.hip -- spends 65 operations
+//     and 24 VALU moves per step: measured slower.)
+//   * sums over atoms (kinetic energy, lam.v, the two LJ parameter sums) are wave reductions; the Nose-Hoover
+//     chain lives one entry per lane (neighbours through DPP row shifts).
+//
+// Summation order differs from traj_*_kernel (tolerance-level differences, tests/test_gpu_pins.py); the pair
+// set is identical: the same un-contracted |D|^2 < rc^2 test on the same minimum-image components.
+// Semantics: torchmd/sovlers.py:110-127 / :25-40 (forward), :211-293 with :129-164 / :42-101 (adjoint),
+// torchmd/md.py:210-240 / :133-150 (right-hand sides), torchmd/topology.py:59-67 (pair set).
+
+// ------------------------------------------------------------------------------------------------ lane moves
+__device__ __forceinline__ float ring_move(float v, int src4) {      // value of lane src4 / 4
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src4, __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f32x2 ring_move(f32x2 v, int src4) { return f32x2{ring_move(v.x, src4), ring_move(v.y, src4)}; }
+__device__ __forceinline__ float row_up(float v) {              // lane l <- lane l+1 within a row of 16, else 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row_down(float v) {            // lane l <- lane l-1 within a row of 16, else 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ f32x2 rcp2(f32x2 v) { return f32x2{__builtin_amdgcn_rcpf(v.x), __builtin_amdgcn_rcpf(v.y)}; }
+__device__ __forceinline__ float hsum(f32x2 v) { return v.x + v.y; }
+
+struct Vec3x2 { f32x2 x, y, z; };
+__device__ __forceinline__ Vec3x2 vzero() { const f32x2 z = {0.f, 0.f}; return Vec3x2{z, z, z}; }
+__device__ __forceinline__ Vec3x2 ring_move(const Vec3x2& a, int s) { return Vec3x2{ring_move(a.x, s), ring_move(a.y, s), ring_move(a.z, s)}; }
+
+// ------------------------------------------------------------------------------------------------ pair sweep
+struct RingLJ {
+    float sig2, rc2, m1a, m1b, ka, kb, tsa, tsb, tea, teb;
+    float ivx, ivy, ivz, hx, hy, hz;
+};
+
+__device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
+    const TermConst t0 = term_prepare(A.terms.t[0], A.theta);
+    const float e4 = 4.f * t0.k1, cq = t0.c;
+    RingLJ K;
+    K.sig2 = t0.k0 * t0.k0; K.rc2 = t0.rc2;
+    K.m1a = 6.f * e4 * cq; K.m1b = 12.f * e4;                          // phi'/r  = (m1a s6 - m1b s12) / d2
+    K.ka = (42.f + 6.f) * e4 * cq; K.kb = (156.f + 12.f) * e4;         // phi'' - phi'/r = (kb s12 - ka s6) / d2
+    K.tsa = 18.f * e4 * t0.k2 * cq; K.tsb = 72.f * e4 * t0.k2;         // d(w.F)/dsig from (S6, S12)
+    K.tea = 12.f * cq; K.teb = 24.f;                                   // d(w.F)/deps
+    K.ivx = A.cell.inv[0]; K.ivy = A.cell.inv[4]; K.ivz = A.cell.inv[8];
+    K.hx = A.cell.h[0]; K.hy = A.cell.h[4]; K.hz = A.cell.h[8];
+    return K;
+}
+
+// One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
+// v0 / v1: both atoms of the pair in .x / .y exist.  JSIDE: also update the visitors' accumulators.
+template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE>
+__device__ __forceinline__ void ring_pair(const RingLJ& K, const Vec3x2& qi, const Vec3x2& wi, const Vec3x2& qj,
+                                          const Vec3x2& wj, bool v0, bool v1, Vec3x2& fi, Vec3x2& gi, Vec3x2& fj,
+                                          Vec3x2& gj, f32x2& S6, f32x2& S12) {
+    f32x2 dx = (CROSS ? qj.x.yx : qj.x) - qi.x, dy = (CROSS ? qj.y.yx : qj.y) - qi.y,
+          dz = (CROSS ? qj.z.yx : qj.z) - qi.z;                                       // D = x_j - x_i
+    if constexpr (NEAR) {
+        dx = min_image_diag2_near(dx, K.ivx, K.hx); dy = min_image_diag2_near(dy, K.ivy, K.hy);
+        dz = min_image_diag2_near(dz, K.ivz, K.hz);
+    } else {
+        dx = min_image_diag2(dx, K.ivx, K.hx); dy = min_image_diag2(dy, K.ivy, K.hy); dz = min_image_diag2(dz, K.ivz, K.hz);
+    }
+    const f32x2 d2 = norm2_ref2(dx, dy, dz);
+    const bool ok0 = v0 && (d2.x != 0.f) && (d2.x < K.rc2);                           // topology.py:67
+    const bool ok1 = v1 && (d2.y != 0.f) && (d2.y < K.rc2);
+    const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+    const f32x2 s2 = K.sig2 * i2;
+    const f32x2 s6 = s2 * s2 * s2;
+    const f32x2 s12 = s6 * s6;
+    const f32x2 c1 = (K.m1a * s6 - K.m1b * s12) * i2;
+    fi.x += c1 * dx; fi.y += c1 * dy; fi.z += c1 * dz;                                // F_i += (phi'/r) D
+    if constexpr (JSIDE) {
+        if constexpr (CROSS) {
+            fj.x = __builtin_elementwise_fma(-c1.yx, dx.yx, fj.x); fj.y = __builtin_elementwise_fma(-c1.yx, dy.yx, fj.y);
+            fj.z = __builtin_elementwise_fma(-c1.yx, dz.yx, fj.z);
+        } else {
+            fj.x -= c1 * dx; fj.y -= c1 * dy; fj.z -= c1 * dz;
+        }
+    }
+    if constexpr (LEVEL >= 2) {
+        const f32x2 ax = wi.x - (CROSS ? wj.x.yx : wj.x), ay = wi.y - (CROSS ? wj.y.yx : wj.y),
+                    az = wi.z - (CROSS ? wj.z.yx : wj.z);
+        const f32x2 b = dx * ax + dy * ay + dz * az;
+        const f32x2 bi = b * i2;                                                      // (w.D) / d2
+        const f32x2 k2 = (K.kb * s12 - K.ka * s6) * (bi * i2);                        // (phi'' - phi'/r)(w.D)/d2
+        const f32x2 tx = __builtin_elementwise_fma(k2, dx, c1 * ax), ty = __builtin_elementwise_fma(k2, dy, c1 * ay),
+                    tz = __builtin_elementwise_fma(k2, dz, c1 * az);                  // -(H w) contribution
+        gi.x += tx; gi.y += ty; gi.z += tz;
+        if constexpr (JSIDE) {
+            gj.x -= CROSS ? tx.yx : tx; gj.y -= CROSS ? ty.yx : ty; gj.z -= CROSS ? tz.yx : tz;
+        }
+        S6 += s6 * bi; S12 += s12 * bi;
+    }
+}
+
+// All pair terms of one replica.  Outputs: f (force), g (= dq of the augmented dynamics, already negated),
+// a6 / a12 = sums over DIRECTED pairs of s6 (w.D)/d2 and s12 (w.D)/d2 for this lane (LEVEL 2).
+// The ring has nl = ceil(N/2) lanes (the lanes that own atoms).  The visitors' positions and w do not move at all:
+// they sit in LDS ([6][64] f32x2, written once per evaluation) and lane l reads entry (l - k) mod nl at step k;
+// only the visitors' accumulators travel, through ds_bpermute_b32 (the LDS crossbar: no VALU slot, no memory).
+template <int LEVEL, bool NEAR>
+__device__ __forceinline__ void ring_sweep(const RingLJ& K, int N, int lane, const Vec3x2& q, const Vec3x2& w,
+                                           Vec3x2& f, Vec3x2& g, float& a6, float& a12, f32x2* __restrict__ lds) {
+    const int nl = (N + 1) >> 1;
+    const bool vi0 = 2 * lane < N, vi1 = 2 * lane + 1 < N;
+    f32x2* sqx = lds; f32x2* sqy = lds + 64; f32x2* sqz = lds + 128;
+    f32x2* swx = lds + 192; f32x2* swy = lds + 256; f32x2* swz = lds + 320;
+    __syncthreads();                                       // (one wave: orders the LDS accesses of its lanes)
+    sqx[lane] = q.x; sqy[lane] = q.y; sqz[lane] = q.z;
+    if constexpr (LEVEL >= 2) { swx[lane] = w.x; swy[lane] = w.y; swz[lane] = w.z; }
+    __syncthreads();
+    Vec3x2 fi = vzero(), gi = vzero(), fj = vzero(), gj = vzero();
+    f32x2 S6 = {0.f, 0.f}, S12 = S6, D6 = S6, D12 = S6;
+    // step 0: the pair inside the lane, both directions
+    ring_pair<LEVEL, NEAR, true, false>(K, q, w, q, w, vi0 && vi1, vi0 && vi1, fi, gi, fj, gj, D6, D12);
+    const int prev = lane < nl ? ((lane == 0 ? nl : lane) - 1) * 4 : lane * 4;     // bpermute address of lane l-1
+    const int nsteps = (nl - 1) >> 1;
+    int idx = lane;
+    Vec3x2 qj, wj = vzero();
+#pragma unroll 1
+    for (int k = 1; k <= nsteps; ++k) {
+        idx -= 1; idx = idx < 0 ? idx + nl : idx;
+        qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
+        fj = ring_move(fj, prev);
+        if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; gj = ring_move(gj, prev); }
+        const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
+        ring_pair<LEVEL, NEAR, false, true>(K, q, w, qj, wj, vi0 && vj0, vi1 && vj1, fi, gi, fj, gj, S6, S12);
+        ring_pair<LEVEL, NEAR, true, true>(K, q, w, qj, wj, vi0 && vj1, vi1 && vj0, fi, gi, fj, gj, S6, S12);
+    }
+    if (!(nl & 1)) {
+        // antipodal lanes (k = nl/2) see each other from both sides -> directed evaluation, visitors not updated
+        idx -= 1; idx = idx < 0 ? idx + nl : idx;
+        qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
+        if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; }
+        const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
+        Vec3x2 fu = vzero(), gu = vzero();
+        ring_pair<LEVEL, NEAR, false, false>(K, q, w, qj, wj, vi0 && vj0, vi1 && vj1, fi, gi, fu, gu, D6, D12);
+        ring_pair<LEVEL, NEAR, true, false>(K, q, w, qj, wj, vi0 && vj1, vi1 && vj0, fi, gi, fu, gu, D6, D12);
+    }
+    // the travelling accumulators are nsteps lanes ahead of their owners
+    int home = lane + nsteps; home = home >= nl ? home - nl : home;
+    home = (lane < nl ? home : lane) * 4;
+    fj = ring_move(fj, home);
+    f.x = fi.x + fj.x; f.y = fi.y + fj.y; f.z = fi.z + fj.z;
+    if constexpr (LEVEL >= 2) {
+        gj = ring_move(gj, home);
+        g.x = -(gi.x + gj.x); g.y = -(gi.y + gj.y); g.z = -(gi.z + gj.z);
+        a6 = 2.f * hsum(S6) + hsum(D6);            // an undirected pair of the ring steps stands for both directions
+        a12 = 2.f * hsum(S12) + hsum(D12);
+    }
+}
+
+// window test of the fast minimum image (see force_all_pairs): every atom within [-0.24, 1.24] cell lengths
+__device__ __forceinline__ bool ring_near(const RingLJ& K, const Vec3x2& q) {
+    const f32x2 sx = q.x * K.ivx, sy = q.y * K.ivy, sz = q.z * K.ivz;
+    bool out = false;
+    out |= !(sx.x > -0.24f && sx.x < 1.24f) | !(sx.y > -0.24f && sx.y < 1.24f);
+    out |= !(sy.x > -0.24f && sy.x < 1.24f) | !(sy.y > -0.24f && sy.y < 1.24f);
+    out |= !(sz.x > -0.24f && sz.x < 1.24f) | !(sz.y > -0.24f && sz.y < 1.24f);
+    return __builtin_amdgcn_ballot_w64(out) == 0;
+}
+
+template <int LEVEL>
+__device__ __forceinline__ void ring_force(const RingLJ& K, int N, int lane, const Vec3x2& q, const Vec3x2& w,
+                                           Vec3x2& f, Vec3x2& g, float& a6, float& a12, f32x2* __restrict__ lds) {
+    if (ring_near(K, q)) ring_sweep<LEVEL, true>(K, N, lane, q, w, f, g, a6, a12, lds);
+    else ring_sweep<LEVEL, false>(K, N, lane, q, w, f, g, a6, a12, lds);
+}
+
+// ------------------------------------------------------------------------------------------------ frame I/O
+// AoS [N,3] frames in HBM: lane l reads / writes the six consecutive floats of its two atoms.
+__device__ __forceinline__ Vec3x2 ring_load(const float* __restrict__ src, int N, int lane) {
+    Vec3x2 r = vzero();
+    const float* p = src + 6 * lane;
+    if (2 * lane + 1 < N) {
+        const f32x2 a = *reinterpret_cast<const f32x2*>(p), b = *reinterpret_cast<const f32x2*>(p + 2),
+                    c = *reinterpret_cast<const f32x2*>(p + 4);
+        r.x = f32x2{a.x, b.y}; r.y = f32x2{a.y, c.x}; r.z = f32x2{b.x, c.y};
+    } else if (2 * lane < N) {
+        r.x.x = p[0]; r.y.x = p[1]; r.z.x = p[2];
+    }
+    return r;
+}
+__device__ __forceinline__ void ring_store(float* __restrict__ dst, const Vec3x2& v, int N, int lane) {
+    float* p = dst + 6 * lane;
+    if (2 * lane + 1 < N) {
+        *reinterpret_cast<f32x2*>(p) = f32x2{v.x.x, v.y.x};
+        *reinterpret_cast<f32x2*>(p + 2) = f32x2{v.z.x, v.x.y};
+        *reinterpret_cast<f32x2*>(p + 4) = f32x2{v.y.y, v.z.y};
+    } else if (2 * lane < N) {
+        p[0] = v.x.x; p[1] = v.y.x; p[2] = v.z.x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bath
+// Nose-Hoover chain, entry k in lane k (md.py:234-236): same formulas as bath_rhs / bath_vjp
+__device__ __forceinline__ float ring_bath_rhs(const TrajArgs& A, int lane, float Qk, float pv, float ke) {
+    const int C = A.prm.n_chains;
+    const float T = A.prm.T;
+    const float dn = row_down(pv), dnQ = row_down(Qk), up = row_up(pv), upQ = row_up(Qk);
+    const float ta = lane == 0 ? 2.f * (ke - T * A.prm.n_dof * 0.5f) : dn * dn / dnQ - T;
+    const float tb = lane == C - 1 ? 0.f : up * pv / upQ;
+    return lane < C ? ta - tb : 0.f;
+}
+__device__ __forceinline__ float ring_bath_vjp(const TrajArgs& A, int lane, float Qk, float pv, float lp, float slv) {
+    const int C = A.prm.n_chains;
+    // (every cross-lane read happens here, with all lanes active: a DPP move inside a divergent branch would read
+    //  zeros from the lanes that took the other side)
+    const float dnlp = row_down(lp), dnpv = row_down(pv), uppv = row_up(pv), upQ = row_up(Qk), uplp = row_up(lp);
+    const float t1 = lane == 0 ? -slv / Qk : -dnlp * dnpv / Qk;
+    const float t2 = lane == C - 1 ? 0.f : -lp * uppv / upQ + 2.f * pv * uplp / Qk;
+    return lane < C ? t1 + t2 : 0.f;
+}
+
+// Q[lane] (a chain of selects: indexing the by-value kernel argument with a run-time index would put it in scratch)
+__device__ __forceinline__ float ring_chain_mass(const TrajArgs& A, int lane) {
+    float Qk = 1.f;
+#pragma unroll
+    for (int c = 0; c < MDG_MAX_CHAINS; ++c)
+        if (lane == c && c < A.prm.n_chains) Qk = A.prm.Q[c];
+    return Qk;
+}
+
+__device__ __forceinline__ float ring_dot(const Vec3x2& a, const Vec3x2& b) {      // per-lane partial of sum a.b
+    return hsum(a.x * b.x + a.y * b.y + a.z * b.z);
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(64) void traj_fwd_ring_kernel(const TrajArgs A) {
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const bool nhc = A.prm.ensemble == 0;
+    const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
+    const RingLJ K = ring_constants(A);
+    __shared__ f32x2 lds[3 * 64];
+    const size_t fr = (size_t)rep * T;
+    Vec3x2 q = ring_load(A.q0 + (size_t)rep * N3, N, lane), v = ring_load(A.v0 + (size_t)rep * N3, N, lane);
+    f32x2 ms = {1.f, 1.f};                                       // (absent atoms: unit mass, zero state)
+    if (2 * lane < N) ms.x = A.mass[2 * lane];
+    if (2 * lane + 1 < N) ms.y = A.mass[2 * lane + 1];
+    const f32x2 ims = rcp2(ms);
+    float pv = 0.f;
+    if (nhc && lane < C) pv = A.pv0[(size_t)rep * C + lane];
+    const float Qk = ring_chain_mass(A, lane);
+    const float iQ0 = 1.f / A.prm.Q[0];
+    // frame 0 = inputs (tinydiffeq.py:63)
+    ring_store(A.q_t + fr * N3, q, N, lane);
+    ring_store(A.v_t + fr * N3, v, N, lane);
+    if (nhc && lane < C) A.pv_t[fr * C + lane] = pv;
+    Vec3x2 f, gu, wu = vzero();
+    float u6, u12;
+    ring_force<1>(K, N, lane, q, wu, f, gu, u6, u12, lds);
+    for (int k = 0; k + 1 < T; ++k) {
+        const float dt = A.t[k + 1] - A.t[k];
+        // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
+        float pb = 0.f, pv0 = 0.f;
+        Vec3x2 vh;
+        if (nhc) {
+            const Vec3x2 p{v.x * ms, v.y * ms, v.z * ms};
+            const float ke = 0.5f * wave_sum(ring_dot(p, v));
+            pb = ring_bath_rhs(A, lane, Qk, pv, ke);
+            pv0 = lane0(pv);
+            const float c0 = pv0 * iQ0;
+            vh.x = 0.5f * ((f.x - c0 * p.x) * ims) * dt;
+            vh.y = 0.5f * ((f.y - c0 * p.y) * ims) * dt;
+            vh.z = 0.5f * ((f.z - c0 * p.z) * ims) * dt;
+        } else {
+            vh.x = 0.5f * f.x * dt; vh.y = 0.5f * f.y * dt; vh.z = 0.5f * f.z * dt;      // md.py:145-148 (no 1/m)
+        }
+        q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
+        const float ph = 0.5f * pb * dt, pvh = pv + ph;
+        // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
+        ring_force<1>(K, N, lane, q, wu, f, gu, u6, u12, lds);
+        const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
+        if (nhc) {
+            const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
+            const float ke = 0.5f * wave_sum(ring_dot(p, vv));
+            const float b1 = ring_bath_rhs(A, lane, Qk, pvh, ke);
+            const float c0 = lane0(pvh) * iQ0;
+            pv = pv + (ph + 0.5f * b1 * dt);
+            v.x = v.x + (vh.x + 0.5f * ((f.x - c0 * p.x) * ims) * dt);
+            v.y = v.y + (vh.y + 0.5f * ((f.y - c0 * p.y) * ims) * dt);
+            v.z = v.z + (vh.z + 0.5f * ((f.z - c0 * p.z) * ims) * dt);
+        } else {
+            v.x = v.x + (vh.x + 0.5f * f.x * dt); v.y = v.y + (vh.y + 0.5f * f.y * dt); v.z = v.z + (vh.z + 0.5f * f.z * dt);
+        }
+        ring_store(A.q_t + (fr + k + 1) * N3, q, N, lane);
+        ring_store(A.v_t + (fr + k + 1) * N3, v, N, lane);
+        if (nhc && lane < C) A.pv_t[(fr + k + 1) * C + lane] = pv;
+    }
+    if (A.nonfinite) {
+        const bool bad = !(isfinite(hsum(q.x + q.y + q.z)) && isfinite(hsum(v.x + v.y + v.z)));
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) A.nonfinite[rep] = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ adjoint
+__global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A) {
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
+    const bool nhc = A.prm.ensemble == 0;
+    const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
+    const RingLJ K = ring_constants(A);
+    __shared__ f32x2 lds[6 * 64];
+    const size_t fr = (size_t)rep * T;
+    f32x2 ms = {1.f, 1.f};
+    if (2 * lane < N) ms.x = A.mass[2 * lane];
+    if (2 * lane + 1 < N) ms.y = A.mass[2 * lane + 1];
+    const f32x2 ims = rcp2(ms);
+    const float Qk = ring_chain_mass(A, lane);
+    const float iQ0 = 1.f / A.prm.Q[0];
+    // lam = dL/dy_{T-1}                                            sovlers.py:249
+    Vec3x2 lv = A.g_v ? ring_load(A.g_v + (fr + T - 1) * N3, N, lane) : vzero();
+    Vec3x2 lq = A.g_q ? ring_load(A.g_q + (fr + T - 1) * N3, N, lane) : vzero();
+    float lp = (nhc && lane < C && A.g_pv) ? A.g_pv[(fr + T - 1) * C + lane] : 0.f;
+    float gsig = 0.f, geps = 0.f;
+    for (int i = T - 1; i >= 1; --i) {
+        const float h = A.t[i] - A.t[i - 1];
+        Vec3x2 q = ring_load(A.q_t + (fr + i) * N3, N, lane), v = ring_load(A.v_t + (fr + i) * N3, N, lane);
+        float pv = (nhc && lane < C) ? A.pv_t[(fr + i) * C + lane] : 0.f;
+        Vec3x2 w, f, dq;
+        float a6, a12;
+        // ---------------- first augmented evaluation at (y_i, lam)
+        if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
+        ring_force<2>(K, N, lane, q, w, f, dq, a6, a12, lds);
+        Vec3x2 lvh, lqh;
+        if (nhc) {
+            const Vec3x2 p{v.x * ms, v.y * ms, v.z * ms};
+            const float ke = 0.5f * wave_sum(ring_dot(p, v)), slv = wave_sum(ring_dot(lv, v));
+            const float pv0 = lane0(pv), lp0 = lane0(lp), c0 = pv0 * iQ0;
+            const float pb = ring_bath_rhs(A, lane, Qk, pv, ke), gp = ring_bath_vjp(A, lane, Qk, pv, lp, slv);
+            const float hh = 0.5f * h;
+#define MDG_RING_HALF(c)                                                                     \
+            {                                                                                \
+                const f32x2 a = (f.c - c0 * p.c) * ims;                                      \
+                const f32x2 Gv = -c0 * lv.c + lq.c + 2.f * ms * v.c * lp0;                   \
+                const f32x2 vhalf = 0.5f * (-a) * h;                  /* sovlers.py:132 */   \
+                q.c = q.c + (v.c + vhalf) * h;                        /* :138 (quirk)   */   \
+                v.c = v.c + vhalf;                                                           \
+                lvh.c = lv.c + Gv * hh;                               /* :141 */             \
+                lqh.c = lq.c + dq.c * hh;                             /* :142 */             \
+            }
+            MDG_RING_HALF(x) MDG_RING_HALF(y) MDG_RING_HALF(z)
+#undef MDG_RING_HALF
+            const float lph = lp + gp * hh;                           // :143
+            pv = pv + 0.5f * (-pb) * h;                               // :135
+            // ---------------- midpoint evaluation                    :147-150
+            w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
+            ring_force<2>(K, N, lane, q, w, f, dq, a6, a12, lds);
+            const float slm = wave_sum(ring_dot(lvh, v));
+            const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
+            const float gpm = ring_bath_vjp(A, lane, Qk, pv, lph, slm);
+            const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
+            const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
+#define MDG_RING_FULL(c)                                                                     \
+            {                                                                                \
+                const f32x2 Gv = -cm * lvh.c + lqh.c + 2.f * ms * v.c * lpm0;                \
+                lv.c = (lv.c + Gv * h) + gv.c;                        /* :156, :286 */       \
+                lq.c = (lq.c + dq.c * h) + gq.c;                      /* :157 */             \
+            }
+            MDG_RING_FULL(x) MDG_RING_FULL(y) MDG_RING_FULL(z)
+#undef MDG_RING_FULL
+            float nlp = lp + gpm * h;                                 // :158
+            if (lane < C && A.g_pv) nlp += A.g_pv[(fr + i - 1) * C + lane];
+            lp = nlp;
+            const float t6 = wave_sum(a6), t12 = wave_sum(a12);       // :160
+            gsig += (K.tsa * t6 - K.tsb * t12) * h;
+            geps += (K.tea * t6 - K.teb * t12) * h;
+        } else {
+            // verlet_update backward branch                          sovlers.py:42-101
+            const float t6 = wave_sum(a6), t12 = wave_sum(a12);
+            gsig += ((K.tsa * t6 - K.tsb * t12) * 0.5f * h) * 2.f;    // :82,101
+            geps += ((K.tea * t6 - K.teb * t12) * 0.5f * h) * 2.f;
+#define MDG_RING_NVE(c)                                                                      \
+            {                                                                                \
+                const f32x2 vhalf = v.c - 0.5f * (-f.c) * h;          /* :49-50 */           \
+                q.c = q.c - vhalf * h;                                /* :51-52 */           \
+                v.c = vhalf;                                                                 \
+                const f32x2 dx = dq.c * h * 0.5f;                     /* :71 */              \
+                lvh.c = lv.c + (lq.c + dx) * h;                       /* :72 */              \
+                lqh.c = lq.c + dx;                                                           \
+            }
+            MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
+#undef MDG_RING_NVE
+            ring_force<2>(K, N, lane, q, lvh, f, dq, a6, a12, lds);
+            const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
+            const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
+            lv.x = lvh.x + gv.x; lv.y = lvh.y + gv.y; lv.z = lvh.z + gv.z;
+            lq.x = (lqh.x + dq.x * h * 0.5f) + gq.x;                  // :100
+            lq.y = (lqh.y + dq.y * h * 0.5f) + gq.y;
+            lq.z = (lqh.z + dq.z * h * 0.5f) + gq.z;
+        }
+    }
+    ring_store(A.adj_v0 + (size_t)rep * N3, lv, N, lane);
+    ring_store(A.adj_q0 + (size_t)rep * N3, lq, N, lane);
+    if (nhc && lane < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + lane] = lp;
+    if (lane == 0 && A.adj_theta) {
+        float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
+        out[0] = gsig; out[1] = geps;
+    }
+}

@@ -724,7 +724,17 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
     }
 }
 
+#include "traj_ring.hpp"
+
 // ------------------------------------------------------------------------------------ launch
+// wave-per-replica kernels (traj_ring.hpp): one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and either
+// asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
+bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
+    const MdgPairTerm& t = terms.t[0];
+    const bool form = terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && t.q == 6;
+    return form && p.n_atoms <= 128 && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
+}
+
 int pick_tpa_log2(int n_atoms, int block) {
     int l = 0;
     while (l < 6 && (n_atoms << (l + 1)) <= block) ++l;
@@ -805,6 +815,12 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
     a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
     const int N = prm->n_atoms;
+    if (use_ring(*prm, *cell, *terms)) {
+        MDG_CHECK_ARG(theta, "traj_fwd: null theta");
+        hipLaunchKernelGGL(traj_fwd_ring_kernel, dim3(prm->n_rep), dim3(64), 0, (hipStream_t)stream, a);
+        MDG_CHECK_LAUNCH("traj_fwd_ring_kernel");
+        return MDG_OK;
+    }
     const int block = pick_block(*prm, terms->t[0].kind == MDG_PAIR_TABLE);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 2 * (size_t)terms->t[0].p : 0;
     MDG_CHECK_ARG(!tab || theta, "traj_fwd: the table is passed through theta");
@@ -836,6 +852,12 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
     a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
     const int N = prm->n_atoms;
+    if (use_ring(*prm, *cell, *terms)) {
+        MDG_CHECK_ARG(theta, "traj_adj: null theta");
+        hipLaunchKernelGGL(traj_adj_ring_kernel, dim3(prm->n_rep), dim3(64), 0, (hipStream_t)stream, a);
+        MDG_CHECK_LAUNCH("traj_adj_ring_kernel");
+        return MDG_OK;
+    }
     const int block = pick_block(*prm, terms->t[0].kind == MDG_PAIR_TABLE);
     const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + two int32 planes
     MDG_CHECK_ARG(!tab || theta, "traj_adj: the table is passed through theta");

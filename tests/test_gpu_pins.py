@@ -21,10 +21,12 @@ pytestmark = pytest.mark.gpu
 
 
 # ------------------------------------------------------------------ timed trajectory geometry
-@pytest.mark.parametrize("R,block", [(6, 128), (1024, 0)])
+@pytest.mark.parametrize("R,block", [(6, 128), (6, 64), (1024, 0)])
 def test_one_lane_per_atom_trajectory_kernels_vs_oracle(R, block):
-    """block = 128 forced on a few replicas, and the default launch at R = 1024 (which picks it): sampled
-    replicas' trajectories, adjoints w.r.t. the initial state and the summed parameter gradient == oracle."""
+    """block = 128 (one lane per atom, LDS-resident) and block = 64 (wave per replica, register-resident ring
+    sweep, csrc/traj_ring.hpp) forced on a few replicas, and the default launch at R = 1024 (which picks the ring
+    kernels for LJ 12-6): sampled replicas' trajectories, adjoints w.r.t. the initial state and the summed
+    parameter gradient == oracle."""
     from mdgrad_amd import ops
     g = load_golden("nhc_traj_lj")
     system, mdl, integ = lj_setup(g)
@@ -62,6 +64,58 @@ def test_one_lane_per_atom_trajectory_kernels_vs_oracle(R, block):
     close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max(), "sum over sampled replicas of dL/dtheta")
     rest = [r for r in range(R) if r not in sample]
     assert float(q0.grad[rest].abs().max()) == 0.0, "replicas outside the loss get exactly zero adjoint"
+
+
+@pytest.mark.parametrize("n_atoms,ensemble", [(108, "nve"), (107, "nhc"), (31, "nve"), (54, "nhc"), (3, "nhc"),
+                                              (2, "nve")])
+def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
+    """The wave-per-replica ring kernels (block = 64) for ring lengths that are odd / even / tiny, a lane with one
+    atom, and the NVE branch of the adjoint (sovlers.py:42-101): trajectory, adjoints and parameter gradient of 3
+    replicas == oracle."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE, NoseHooverChain
+    g = load_golden("nhc_traj_lj")
+    R, nT = 3, 9
+    rng = np.random.default_rng(n_atoms)
+    base = g["pos"][:n_atoms]
+    system = mk_system(base, g["cell"], g["vel"][:n_atoms], g["mass"][:n_atoms])
+    mdl = P.LennardJones(1.0, 1.0)
+    stack = Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)})
+    nhc = ensemble == "nhc"
+    integ = (NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0) if nhc else NVE(stack, system)).to(DEV)
+    spec = integ.fused_spec("NH_verlet" if nhc else "verlet")
+    spec.block = 64
+    pos = np.mod(base[None] + rng.normal(0, 0.03, (R,) + base.shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(nT)])
+    v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+    pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True) if nhc else None
+    out = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+    v_t, q_t = out[0], out[1]
+    mdl.zero_grad()
+    nrm = n_atoms * 3
+    loss = (q_t[:, ::2].pow(2).sum((1, 2, 3)) / (5 * nrm) + v_t[:, -1].pow(2).sum((1, 2)) / nrm).sum()
+    if nhc:
+        loss = loss + out[2][:, -1].sum()
+    loss.backward()
+    gth_sum = np.zeros(2)
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        traj, lam, gth = oracle_run(
+            pos[r], g["cell"], vel[r], g["mass"][:n_atoms], [term], 1.0, 50.0, 5, t,
+            lambda L: L[1][::2].pow(2).sum() / (5 * nrm) + L[0][-1].pow(2).sum() / nrm
+            + (L[2][-1].sum() if nhc else 0.0), ensemble=ensemble)
+        close(q_t[r], traj[1], 0, 2e-5, "q_t[%d]" % r)
+        close(v_t[r], traj[0], 0, 2e-4, "v_t[%d]" % r)
+        close(v0.grad[r], lam[0], 1e-3, 2e-4 * float(lam[0].abs().max()), "adj v0[%d]" % r)
+        close(q0.grad[r], lam[1], 1e-3, 2e-4 * float(lam[1].abs().max()), "adj q0[%d]" % r)
+        if nhc:
+            close(out[2][r], traj[2], 1e-4, 1e-4, "pv_t[%d]" % r)
+            close(pv0.grad[r], lam[2], 1e-3, 2e-4 * float(lam[2].abs().max()) + 1e-6, "adj pv0[%d]" % r)
+        gth_sum += gth.numpy()
+    got = np.array([float(mdl.sigma.grad), float(mdl.epsilon.grad)])
+    close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max() + 1e-7, "dL/dtheta")
 
 
 # ------------------------------------------------------------------ many-frame RDF kernels
