@@ -192,6 +192,37 @@ int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
                        float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
                        void* stream);
 
+/* Fused observable (extension): the radial distribution function of torchmd/observable.py:62-76 evaluated on frames
+ * of the trajectory INSIDE the trajectory kernels -- the force sweep already holds every pair distance of a frame, so
+ * the forward launch also fills the raw soft histogram (sum over the selected frames of all replicas, the quantity
+ * mdg_rdf_fwd_uniform returns for those frames) and the adjoint launch takes g_raw = dL/d(raw) in place of the
+ * frame gradients dL/dq_t that mdg_rdf_bwd_uniform would have written to HBM (an additional g_q is still accepted).
+ * Available where the wave-per-replica kernels run (one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and
+ * block = 64 or n_rep >= 1024) and for equally spaced centres whose fine grids fit the LDS: mdg_traj_rdf_supported() != 0. */
+typedef struct MdgRdfFuse {
+    const float* mu;               /* device [nbins] centres, equally spaced (GaussianSmearing offsets) */
+    int32_t nbins;
+    float   coeff;                 /* -0.5 / width^2 */
+    float   spacing;               /* mu[1] - mu[0] */
+    float   cutoff;                /* pair cutoff of the observable (observable.py:52: r_range end + 0.5) */
+    int32_t frame_start, frame_stride;   /* frames frame_start + k frame_stride of every replica */
+} MdgRdfFuse;
+int mdg_traj_rdf_supported(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                           const MdgTerms* terms /*host*/, const MdgRdfFuse* rdf /*host*/);
+int mdg_traj_fwd_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                           const MdgTerms* terms /*host*/, const float* theta,
+                           const float* mass, const float* t_grid,
+                           const float* v0, const float* q0, const float* pv0,
+                           float* v_t, float* q_t, float* pv_t, int32_t* nonfinite,
+                           const MdgRdfFuse* rdf /*host*/, float* raw /*[nbins]*/, void* stream);
+int mdg_traj_adj_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
+                           const MdgTerms* terms /*host*/, const float* theta,
+                           const float* mass, const float* t_grid,
+                           const float* v_t, const float* q_t, const float* pv_t,
+                           const float* g_v, const float* g_q, const float* g_pv,
+                           float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                           const MdgRdfFuse* rdf /*host*/, const float* g_raw /*[nbins]*/, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain): same contract as
  * mdg_traj_fwd_small / mdg_traj_adj_small, two launches per step (forward) / four per adjoint

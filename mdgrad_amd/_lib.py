@@ -37,6 +37,12 @@ class MdgTrajParams(C.Structure):
                 ("T", C.c_float), ("n_dof", C.c_float), ("Q", C.c_float * MAX_CHAINS)]
 
 
+class MdgRdfFuse(C.Structure):
+    """Fused RDF observable of the wave-per-replica trajectory kernels (include/mdgrad_hip.h)."""
+    _fields_ = [("mu", C.c_void_p), ("nbins", C.c_int32), ("coeff", C.c_float), ("spacing", C.c_float),
+                ("cutoff", C.c_float), ("frame_start", C.c_int32), ("frame_stride", C.c_int32)]
+
+
 class MdgFilterNet(C.Structure):
     """Host struct of device pointers describing one SchNet filter network (include/mdgrad_hip.h)."""
     _fields_ = [("mu", C.c_void_p), ("coef", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
@@ -65,6 +71,12 @@ _SIGNATURES = {
                                      P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_traj_adj_small": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                      P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mdg_traj_rdf_supported": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
+                                         C.POINTER(MdgRdfFuse)]),
+    "mdg_traj_fwd_small_rdf": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
+                                         P, P, P, P, P, P, P, P, P, P, C.POINTER(MdgRdfFuse), P, P]),
+    "mdg_traj_adj_small_rdf": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
+                                         P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(MdgRdfFuse), P, P]),
     "mdg_traj_large_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "mdg_traj_fwd_large": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                      P, P, P, P, P, P, P, P, P, P, P, P]),

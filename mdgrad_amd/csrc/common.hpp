@@ -23,6 +23,19 @@ void mdg_set_error(const char* fmt, ...);
          if (e_ != hipSuccess) { mdg_set_error("%s: %s", name, hipGetErrorString(e_)); \
                                  return MDG_ELAUNCH; } } while (0)
 
+// internal: the fine grids of the many-frame RDF kernels (csrc/rdf.hip), shared with the fused observable of the
+// trajectory kernels (csrc/traj_small.hip).  Not part of the C ABI.
+struct RdfFinePlan {
+    float sc;                  // exp(coeff x^2) = exp2(-(sc x)^2)
+    float reach, h;            // forward: fine integer histogram over [mu0 - reach, ...), bin width h
+    long long nfine;           //          bins (0: does not fit)
+    int reach_bins, ncell;     // backward: R of the derivative table, cells of the cubic-Hermite table (0: no table)
+};
+RdfFinePlan mdg_rdf_fine_plan(float spacing, float coeff, int nbins);
+int mdg_rdf_fine_finish(const uint32_t* ghist, const RdfFinePlan& P, const float* mu, int nbins, float* raw, hipStream_t st);
+int mdg_rdf_bwd_table(const float* mu, float coeff, int nbins, const float* g_raw, const RdfFinePlan& P, float4* tab,
+                      hipStream_t st);
+
 // ----------------------------------------------------------------------------- cell
 // Minimum image exactly as topology.py:59-64: s = D . inv ; o = -(s > .5) + (s < -.5) ;
 // D += o . h   (D = x_j - x_i).  Returns the packed image code (ox+1)+3(oy+1)+9(oz+1).

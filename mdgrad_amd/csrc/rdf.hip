@@ -1411,6 +1411,31 @@ static long long rdf_fine_bins(float spacing, float coeff, int nbins, float* rea
     return nfine <= RDF_FINE_MAX ? nfine : 0;
 }
 
+// ---- shared with the fused observable of the trajectory kernels (common.hpp)
+RdfFinePlan mdg_rdf_fine_plan(float spacing, float coeff, int nbins) {
+    RdfFinePlan P{};
+    if (!(spacing > 0.f) || !(coeff < 0.f) || nbins < 2) return P;
+    P.sc = sqrtf(-coeff * LOG2E);
+    P.nfine = rdf_fine_bins(spacing, coeff, nbins, &P.reach, &P.h);
+    const float spacing_s = spacing * P.sc;
+    const int R = rdf_lane_reach(spacing_s);
+    if (R && spacing_s <= 1.0f && fine_nodes(nbins, R) <= 4096) { P.reach_bins = R; P.ncell = fine_nodes(nbins, R) - 1; }
+    return P;
+}
+int mdg_rdf_fine_finish(const uint32_t* ghist, const RdfFinePlan& P, const float* mu, int nbins, float* raw, hipStream_t st) {
+    hipLaunchKernelGGL(rdf_fine_finish_kernel, dim3(nbins), dim3(64), 0, st, ghist, (int)P.nfine, P.h, mu, P.sc, P.reach,
+                       nbins, raw);
+    MDG_CHECK_LAUNCH("rdf_fine_finish_kernel");
+    return MDG_OK;
+}
+int mdg_rdf_bwd_table(const float* mu, float coeff, int nbins, const float* g_raw, const RdfFinePlan& P, float4* tab,
+                      hipStream_t st) {
+    const int nn = P.ncell + 1;
+    hipLaunchKernelGGL(rdf_bwd_table_kernel, dim3((nn + 254) / 256), dim3(256), 0, st, mu, coeff, nbins, g_raw, P.reach_bins, tab);
+    MDG_CHECK_LAUNCH("rdf_bwd_table_kernel");
+    return MDG_OK;
+}
+
 extern "C" int mdg_rdf_ell_supported(float spacing, float coeff, int nbins) {
     float reach, h;
     return rdf_fine_bins(spacing, coeff, nbins, &reach, &h) > 0;

@@ -68,12 +68,27 @@ __device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
     return K;
 }
 
+// Fused RDF observable (torchmd/observable.py:62-76 on the frames of this trajectory, see csrc/rdf.hip for the two
+// formulations it shares): the sweep already holds |D|^2 of every pair of a frame, so
+//   RDF = 1 (forward)  counts each pair on the fine integer grid of rdf_fwd_fine_kernel (one ds_add_u32 into the
+//                      workgroup's LDS histogram) instead of re-reading the frame in a second kernel;
+//   RDF = 2 (adjoint)  evaluates dL/dd from the cubic-Hermite cell table of rdf_bwd_fine_kernel and accumulates the
+//                      frame gradient dL/dq_t that the adjoint would otherwise load from HBM.
+struct RingRdf {
+    uint32_t* hist; float inv_h, tlo, fmax;                 // RDF = 1: fine histogram [nfine], t = d inv_h + tlo
+    const float4* tab; float xlo, inv_hf, tmax;             // RDF = 2: cell cubics [nn-1], t = (d - xlo) inv_hf
+    float rc2;                                              // the observable's own pair cutoff (squared)
+};
+
 // One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
 // v0 / v1: both atoms of the pair in .x / .y exist.  JSIDE: also update the visitors' accumulators.
-template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE>
-__device__ __forceinline__ void ring_pair(const RingLJ& K, const Vec3x2& qi, const Vec3x2& wi, const Vec3x2& qj,
-                                          const Vec3x2& wj, bool v0, bool v1, Vec3x2& fi, Vec3x2& gi, Vec3x2& fj,
-                                          Vec3x2& gj, f32x2& S6, f32x2& S12) {
+// LEVEL 0: geometry only (RDF gradient of a frame the adjoint does not evaluate forces at).
+// r0 / r1: the pair in .x / .y feeds the RDF (exists and, for RDF = 1, is the one copy of a pair met twice).
+template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE, int RDF>
+__device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, const Vec3x2& qi, const Vec3x2& wi,
+                                          const Vec3x2& qj, const Vec3x2& wj, bool v0, bool v1, bool r0, bool r1,
+                                          Vec3x2& fi, Vec3x2& gi, Vec3x2& fj, Vec3x2& gj, f32x2& S6, f32x2& S12,
+                                          Vec3x2& ri, Vec3x2& rj) {
     f32x2 dx = (CROSS ? qj.x.yx : qj.x) - qi.x, dy = (CROSS ? qj.y.yx : qj.y) - qi.y,
           dz = (CROSS ? qj.z.yx : qj.z) - qi.z;                                       // D = x_j - x_i
     if constexpr (NEAR) {
@@ -83,58 +98,98 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const Vec3x2& qi, con
         dx = min_image_diag2(dx, K.ivx, K.hx); dy = min_image_diag2(dy, K.ivy, K.hy); dz = min_image_diag2(dz, K.ivz, K.hz);
     }
     const f32x2 d2 = norm2_ref2(dx, dy, dz);
-    const bool ok0 = v0 && (d2.x != 0.f) && (d2.x < K.rc2);                           // topology.py:67
-    const bool ok1 = v1 && (d2.y != 0.f) && (d2.y < K.rc2);
-    const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
-    const f32x2 s2 = K.sig2 * i2;
-    const f32x2 s6 = s2 * s2 * s2;
-    const f32x2 s12 = s6 * s6;
-    const f32x2 c1 = (K.m1a * s6 - K.m1b * s12) * i2;
-    fi.x += c1 * dx; fi.y += c1 * dy; fi.z += c1 * dz;                                // F_i += (phi'/r) D
-    if constexpr (JSIDE) {
-        if constexpr (CROSS) {
-            fj.x = __builtin_elementwise_fma(-c1.yx, dx.yx, fj.x); fj.y = __builtin_elementwise_fma(-c1.yx, dy.yx, fj.y);
-            fj.z = __builtin_elementwise_fma(-c1.yx, dz.yx, fj.z);
-        } else {
-            fj.x -= c1 * dx; fj.y -= c1 * dy; fj.z -= c1 * dz;
-        }
+    if constexpr (RDF == 1) {
+        // rdf_fine_frame: t = sqrt(d2) / h - lo / h, accepted pairs are those of topology.py:67 inside the grid
+        const float ta = fmaf(__builtin_amdgcn_sqrtf(d2.x), X.inv_h, X.tlo), tb = fmaf(__builtin_amdgcn_sqrtf(d2.y), X.inv_h, X.tlo);
+        const bool oka = r0 && ta >= 0.f && ta < X.fmax && d2.x < X.rc2 && d2.x != 0.f;
+        const bool okb = r1 && tb >= 0.f && tb < X.fmax && d2.y < X.rc2 && d2.y != 0.f;
+        if (oka) atomicAdd(&X.hist[(int)ta], 1u);
+        if (okb) atomicAdd(&X.hist[(int)tb], 1u);
     }
-    if constexpr (LEVEL >= 2) {
-        const f32x2 ax = wi.x - (CROSS ? wj.x.yx : wj.x), ay = wi.y - (CROSS ? wj.y.yx : wj.y),
-                    az = wi.z - (CROSS ? wj.z.yx : wj.z);
-        const f32x2 b = dx * ax + dy * ay + dz * az;
-        const f32x2 bi = b * i2;                                                      // (w.D) / d2
-        const f32x2 k2 = (K.kb * s12 - K.ka * s6) * (bi * i2);                        // (phi'' - phi'/r)(w.D)/d2
-        const f32x2 tx = __builtin_elementwise_fma(k2, dx, c1 * ax), ty = __builtin_elementwise_fma(k2, dy, c1 * ay),
-                    tz = __builtin_elementwise_fma(k2, dz, c1 * az);                  // -(H w) contribution
-        gi.x += tx; gi.y += ty; gi.z += tz;
+    if constexpr (RDF == 2) {
+        // rdf_bwd_fine_kernel: d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d; a rejected pair adds +-0
+        bool oka = r0 && d2.x < X.rc2 && d2.x != 0.f, okb = r1 && d2.y < X.rc2 && d2.y != 0.f;
+        const f32x2 id = {__builtin_amdgcn_rsqf(oka ? d2.x : 1.f), __builtin_amdgcn_rsqf(okb ? d2.y : 1.f)};
+        f32x2 t = (d2 * id - X.xlo) * X.inv_hf;
+        oka = oka && t.x >= 0.f && t.x < X.tmax;
+        okb = okb && t.y >= 0.f && t.y < X.tmax;
+        t = f32x2{oka ? t.x : 0.f, okb ? t.y : 0.f};
+        const int gA = (int)t.x, gB = (int)t.y;
+        const f32x2 fr = t - f32x2{(float)gA, (float)gB};
+        const float4 ca = X.tab[gA], cb = X.tab[gB];
+        const float sdA = fmaf(fr.x, fmaf(fr.x, fmaf(fr.x, ca.w, ca.z), ca.y), ca.x);
+        const float sdB = fmaf(fr.y, fmaf(fr.y, fmaf(fr.y, cb.w, cb.z), cb.y), cb.x);
+        const f32x2 cw = f32x2{oka ? sdA : 0.f, okb ? sdB : 0.f} * id;
+        const f32x2 cx = cw * dx, cy = cw * dy, cz = cw * dz;
+        ri.x -= cx; ri.y -= cy; ri.z -= cz;
+        if constexpr (JSIDE) { rj.x += CROSS ? cx.yx : cx; rj.y += CROSS ? cy.yx : cy; rj.z += CROSS ? cz.yx : cz; }
+    }
+    if constexpr (LEVEL >= 1) {
+        const bool ok0 = v0 && (d2.x != 0.f) && (d2.x < K.rc2);                       // topology.py:67
+        const bool ok1 = v1 && (d2.y != 0.f) && (d2.y < K.rc2);
+        const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+        const f32x2 s2 = K.sig2 * i2;
+        const f32x2 s6 = s2 * s2 * s2;
+        const f32x2 s12 = s6 * s6;
+        const f32x2 c1 = (K.m1a * s6 - K.m1b * s12) * i2;
+        fi.x += c1 * dx; fi.y += c1 * dy; fi.z += c1 * dz;                            // F_i += (phi'/r) D
         if constexpr (JSIDE) {
-            gj.x -= CROSS ? tx.yx : tx; gj.y -= CROSS ? ty.yx : ty; gj.z -= CROSS ? tz.yx : tz;
+            if constexpr (CROSS) {
+                fj.x = __builtin_elementwise_fma(-c1.yx, dx.yx, fj.x); fj.y = __builtin_elementwise_fma(-c1.yx, dy.yx, fj.y);
+                fj.z = __builtin_elementwise_fma(-c1.yx, dz.yx, fj.z);
+            } else {
+                fj.x -= c1 * dx; fj.y -= c1 * dy; fj.z -= c1 * dz;
+            }
         }
-        S6 += s6 * bi; S12 += s12 * bi;
+        if constexpr (LEVEL >= 2) {
+            const f32x2 ax = wi.x - (CROSS ? wj.x.yx : wj.x), ay = wi.y - (CROSS ? wj.y.yx : wj.y),
+                        az = wi.z - (CROSS ? wj.z.yx : wj.z);
+            const f32x2 b = dx * ax + dy * ay + dz * az;
+            const f32x2 bi = b * i2;                                                  // (w.D) / d2
+            const f32x2 k2 = (K.kb * s12 - K.ka * s6) * (bi * i2);                    // (phi'' - phi'/r)(w.D)/d2
+            const f32x2 tx = __builtin_elementwise_fma(k2, dx, c1 * ax), ty = __builtin_elementwise_fma(k2, dy, c1 * ay),
+                        tz = __builtin_elementwise_fma(k2, dz, c1 * az);              // -(H w) contribution
+            gi.x += tx; gi.y += ty; gi.z += tz;
+            if constexpr (JSIDE) {
+                gj.x -= CROSS ? tx.yx : tx; gj.y -= CROSS ? ty.yx : ty; gj.z -= CROSS ? tz.yx : tz;
+            }
+            S6 += s6 * bi; S12 += s12 * bi;
+        }
     }
 }
 
+// The lanes of one wave exchange data through LDS: order its accesses (DS instructions of a wave execute in issue
+// order, so a compiler-level fence is all that is needed; no s_barrier -- the waves of a workgroup are independent)
+__device__ __forceinline__ void ring_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // All pair terms of one replica.  Outputs: f (force), g (= dq of the augmented dynamics, already negated),
-// a6 / a12 = sums over DIRECTED pairs of s6 (w.D)/d2 and s12 (w.D)/d2 for this lane (LEVEL 2).
+// a6 / a12 = sums over DIRECTED pairs of s6 (w.D)/d2 and s12 (w.D)/d2 for this lane (LEVEL 2), rq = dL/dq of the
+// fused RDF for this frame (RDF = 2).
 // The ring has nl = ceil(N/2) lanes (the lanes that own atoms).  The visitors' positions and w do not move at all:
 // they sit in LDS ([6][64] f32x2, written once per evaluation) and lane l reads entry (l - k) mod nl at step k;
 // only the visitors' accumulators travel, through ds_bpermute_b32 (the LDS crossbar: no VALU slot, no memory).
-template <int LEVEL, bool NEAR>
-__device__ __forceinline__ void ring_sweep(const RingLJ& K, int N, int lane, const Vec3x2& q, const Vec3x2& w,
-                                           Vec3x2& f, Vec3x2& g, float& a6, float& a12, f32x2* __restrict__ lds) {
+template <int LEVEL, bool NEAR, int RDF>
+__device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, int N, int lane, const Vec3x2& q,
+                                           const Vec3x2& w, Vec3x2& f, Vec3x2& g, float& a6, float& a12, Vec3x2& rq,
+                                           f32x2* __restrict__ lds) {
     const int nl = (N + 1) >> 1;
     const bool vi0 = 2 * lane < N, vi1 = 2 * lane + 1 < N;
     f32x2* sqx = lds; f32x2* sqy = lds + 64; f32x2* sqz = lds + 128;
     f32x2* swx = lds + 192; f32x2* swy = lds + 256; f32x2* swz = lds + 320;
-    __syncthreads();                                       // (one wave: orders the LDS accesses of its lanes)
+    ring_lds_fence();
     sqx[lane] = q.x; sqy[lane] = q.y; sqz[lane] = q.z;
     if constexpr (LEVEL >= 2) { swx[lane] = w.x; swy[lane] = w.y; swz[lane] = w.z; }
-    __syncthreads();
-    Vec3x2 fi = vzero(), gi = vzero(), fj = vzero(), gj = vzero();
+    ring_lds_fence();
+    Vec3x2 fi = vzero(), gi = vzero(), fj = vzero(), gj = vzero(), ri = vzero(), rj = vzero();
     f32x2 S6 = {0.f, 0.f}, S12 = S6, D6 = S6, D12 = S6;
-    // step 0: the pair inside the lane, both directions
-    ring_pair<LEVEL, NEAR, true, false>(K, q, w, q, w, vi0 && vi1, vi0 && vi1, fi, gi, fj, gj, D6, D12);
+    // step 0: the pair inside the lane, both directions (one copy for the histogram)
+    {
+        const bool v = vi0 && vi1;
+        ring_pair<LEVEL, NEAR, true, false, RDF>(K, X, q, w, q, w, v, v, v, RDF == 2 && v, fi, gi, fj, gj, D6, D12, ri, rj);
+    }
     const int prev = lane < nl ? ((lane == 0 ? nl : lane) - 1) * 4 : lane * 4;     // bpermute address of lane l-1
     const int nsteps = (nl - 1) >> 1;
     int idx = lane;
@@ -143,32 +198,43 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, int N, int lane, con
     for (int k = 1; k <= nsteps; ++k) {
         idx -= 1; idx = idx < 0 ? idx + nl : idx;
         qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
-        fj = ring_move(fj, prev);
+        if constexpr (LEVEL >= 1) fj = ring_move(fj, prev);
         if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; gj = ring_move(gj, prev); }
+        if constexpr (RDF == 2) rj = ring_move(rj, prev);
         const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
-        ring_pair<LEVEL, NEAR, false, true>(K, q, w, qj, wj, vi0 && vj0, vi1 && vj1, fi, gi, fj, gj, S6, S12);
-        ring_pair<LEVEL, NEAR, true, true>(K, q, w, qj, wj, vi0 && vj1, vi1 && vj0, fi, gi, fj, gj, S6, S12);
+        const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
+        ring_pair<LEVEL, NEAR, false, true, RDF>(K, X, q, w, qj, wj, s0, s1, s0, s1, fi, gi, fj, gj, S6, S12, ri, rj);
+        ring_pair<LEVEL, NEAR, true, true, RDF>(K, X, q, w, qj, wj, c0, c1, c0, c1, fi, gi, fj, gj, S6, S12, ri, rj);
     }
     if (!(nl & 1)) {
         // antipodal lanes (k = nl/2) see each other from both sides -> directed evaluation, visitors not updated
+        // (the lower lane of the two feeds the histogram)
         idx -= 1; idx = idx < 0 ? idx + nl : idx;
         qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
         if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; }
         const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
-        Vec3x2 fu = vzero(), gu = vzero();
-        ring_pair<LEVEL, NEAR, false, false>(K, q, w, qj, wj, vi0 && vj0, vi1 && vj1, fi, gi, fu, gu, D6, D12);
-        ring_pair<LEVEL, NEAR, true, false>(K, q, w, qj, wj, vi0 && vj1, vi1 && vj0, fi, gi, fu, gu, D6, D12);
+        const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
+        const bool once = RDF == 2 || 2 * lane < nl;
+        Vec3x2 fu = vzero(), gu = vzero(), ru = vzero();
+        ring_pair<LEVEL, NEAR, false, false, RDF>(K, X, q, w, qj, wj, s0, s1, s0 && once, s1 && once, fi, gi, fu, gu, D6, D12, ri, ru);
+        ring_pair<LEVEL, NEAR, true, false, RDF>(K, X, q, w, qj, wj, c0, c1, c0 && once, c1 && once, fi, gi, fu, gu, D6, D12, ri, ru);
     }
     // the travelling accumulators are nsteps lanes ahead of their owners
     int home = lane + nsteps; home = home >= nl ? home - nl : home;
     home = (lane < nl ? home : lane) * 4;
-    fj = ring_move(fj, home);
-    f.x = fi.x + fj.x; f.y = fi.y + fj.y; f.z = fi.z + fj.z;
+    if constexpr (LEVEL >= 1) {
+        fj = ring_move(fj, home);
+        f.x = fi.x + fj.x; f.y = fi.y + fj.y; f.z = fi.z + fj.z;
+    }
     if constexpr (LEVEL >= 2) {
         gj = ring_move(gj, home);
         g.x = -(gi.x + gj.x); g.y = -(gi.y + gj.y); g.z = -(gi.z + gj.z);
         a6 = 2.f * hsum(S6) + hsum(D6);            // an undirected pair of the ring steps stands for both directions
         a12 = 2.f * hsum(S12) + hsum(D12);
+    }
+    if constexpr (RDF == 2) {
+        rj = ring_move(rj, home);
+        rq.x = ri.x + rj.x; rq.y = ri.y + rj.y; rq.z = ri.z + rj.z;
     }
 }
 
@@ -182,11 +248,23 @@ __device__ __forceinline__ bool ring_near(const RingLJ& K, const Vec3x2& q) {
     return __builtin_amdgcn_ballot_w64(out) == 0;
 }
 
-template <int LEVEL>
-__device__ __forceinline__ void ring_force(const RingLJ& K, int N, int lane, const Vec3x2& q, const Vec3x2& w,
-                                           Vec3x2& f, Vec3x2& g, float& a6, float& a12, f32x2* __restrict__ lds) {
-    if (ring_near(K, q)) ring_sweep<LEVEL, true>(K, N, lane, q, w, f, g, a6, a12, lds);
-    else ring_sweep<LEVEL, false>(K, N, lane, q, w, f, g, a6, a12, lds);
+// RDF: compile-time mode of the kernel; with_rdf: this frame is one of the observable's frames (wave-uniform)
+template <int LEVEL, int RDF>
+__device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, bool with_rdf, int N, int lane,
+                                           const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g, float& a6, float& a12,
+                                           Vec3x2& rq, f32x2* __restrict__ lds) {
+    const bool near = ring_near(K, q);
+    if constexpr (RDF != 0) {
+        if (with_rdf) {
+            if (near) ring_sweep<LEVEL, true, RDF>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+            else ring_sweep<LEVEL, false, RDF>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+            return;
+        }
+    }
+    if constexpr (LEVEL >= 1) {
+        if (near) ring_sweep<LEVEL, true, 0>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+        else ring_sweep<LEVEL, false, 0>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ frame I/O
@@ -247,81 +325,136 @@ __device__ __forceinline__ float ring_dot(const Vec3x2& a, const Vec3x2& b) {   
     return hsum(a.x * b.x + a.y * b.y + a.z * b.z);
 }
 
+// ------------------------------------------------------------------------------------------------ fused RDF
+// Device-side description of the fused observable (host: MdgRdfFuse + the fine-grid plan of csrc/rdf.hip)
+struct RingRdfArgs {
+    const float* mu; int nbins;             // equally spaced centres (device)
+    float rc2;                              // the observable's pair cutoff^2
+    int f_start, f_stride;                  // frames f_start, f_start + f_stride, ... of every replica
+    float reach, inv_h; int nfine;          // forward: fine integer histogram
+    uint32_t* ghist;                        //          [nfine] global, zeroed by the host
+    const float4* tab; int reach_bins;      // adjoint: cell cubics of dL/dd (rdf_bwd_table_kernel), R of the grid
+};
+__device__ __forceinline__ bool ring_frame_selected(const RingRdfArgs& F, int k) {
+    return k >= F.f_start && (k - F.f_start) % F.f_stride == 0;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(64) void traj_fwd_ring_kernel(const TrajArgs A) {
+// RDF = false: one wave (= one replica) per workgroup.  RDF = true: sixteen waves share the workgroup's fine
+// histogram in LDS and stride over the replicas (persistent grid: the histogram is merged into HBM once per
+// workgroup); the waves are otherwise independent.
+template <bool RDF>
+__global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
+    extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
-    const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, N3 = 3 * N;
     const RingLJ K = ring_constants(A);
-    __shared__ f32x2 lds[3 * 64];
-    const size_t fr = (size_t)rep * T;
-    Vec3x2 q = ring_load(A.q0 + (size_t)rep * N3, N, lane), v = ring_load(A.v0 + (size_t)rep * N3, N, lane);
+    const int nf2 = RDF ? (F.nfine + 1) & ~1 : 0;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smr);
+    f32x2* lds = reinterpret_cast<f32x2*>(smr + nf2) + wid * 3 * 64;
+    RingRdf X{};
+    if constexpr (RDF) {
+        for (int m = threadIdx.x; m < F.nfine; m += blockDim.x) hist[m] = 0u;
+        __syncthreads();
+        const float lo = F.mu[0] - F.reach;                      // lower edge of the fine grid
+        X.hist = hist; X.inv_h = F.inv_h; X.tlo = -lo * F.inv_h; X.fmax = (float)F.nfine; X.rc2 = F.rc2;
+    }
     f32x2 ms = {1.f, 1.f};                                       // (absent atoms: unit mass, zero state)
     if (2 * lane < N) ms.x = A.mass[2 * lane];
     if (2 * lane + 1 < N) ms.y = A.mass[2 * lane + 1];
     const f32x2 ims = rcp2(ms);
-    float pv = 0.f;
-    if (nhc && lane < C) pv = A.pv0[(size_t)rep * C + lane];
     const float Qk = ring_chain_mass(A, lane);
     const float iQ0 = 1.f / A.prm.Q[0];
-    // frame 0 = inputs (tinydiffeq.py:63)
-    ring_store(A.q_t + fr * N3, q, N, lane);
-    ring_store(A.v_t + fr * N3, v, N, lane);
-    if (nhc && lane < C) A.pv_t[fr * C + lane] = pv;
-    Vec3x2 f, gu, wu = vzero();
-    float u6, u12;
-    ring_force<1>(K, N, lane, q, wu, f, gu, u6, u12, lds);
-    for (int k = 0; k + 1 < T; ++k) {
-        const float dt = A.t[k + 1] - A.t[k];
-        // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
-        float pb = 0.f, pv0 = 0.f;
-        Vec3x2 vh;
-        if (nhc) {
-            const Vec3x2 p{v.x * ms, v.y * ms, v.z * ms};
-            const float ke = 0.5f * wave_sum(ring_dot(p, v));
-            pb = ring_bath_rhs(A, lane, Qk, pv, ke);
-            pv0 = lane0(pv);
-            const float c0 = pv0 * iQ0;
-            vh.x = 0.5f * ((f.x - c0 * p.x) * ims) * dt;
-            vh.y = 0.5f * ((f.y - c0 * p.y) * ims) * dt;
-            vh.z = 0.5f * ((f.z - c0 * p.z) * ims) * dt;
-        } else {
-            vh.x = 0.5f * f.x * dt; vh.y = 0.5f * f.y * dt; vh.z = 0.5f * f.z * dt;      // md.py:145-148 (no 1/m)
+    for (int rep = blockIdx.x * nw + wid; rep < A.prm.n_rep; rep += gridDim.x * nw) {
+        const size_t fr = (size_t)rep * T;
+        Vec3x2 q = ring_load(A.q0 + (size_t)rep * N3, N, lane), v = ring_load(A.v0 + (size_t)rep * N3, N, lane);
+        float pv = 0.f;
+        if (nhc && lane < C) pv = A.pv0[(size_t)rep * C + lane];
+        // frame 0 = inputs (tinydiffeq.py:63)
+        ring_store(A.q_t + fr * N3, q, N, lane);
+        ring_store(A.v_t + fr * N3, v, N, lane);
+        if (nhc && lane < C) A.pv_t[fr * C + lane] = pv;
+        Vec3x2 f, gu, ru, wu = vzero();
+        float u6, u12;
+        // (every force evaluation of the forward pass is at the positions of a stored frame: the RDF rides along)
+        ring_force<1, RDF ? 1 : 0>(K, X, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, u6, u12, ru, lds);
+        for (int k = 0; k + 1 < T; ++k) {
+            const float dt = A.t[k + 1] - A.t[k];
+            // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
+            float pb = 0.f, pv0 = 0.f;
+            Vec3x2 vh;
+            if (nhc) {
+                const Vec3x2 p{v.x * ms, v.y * ms, v.z * ms};
+                const float ke = 0.5f * wave_sum(ring_dot(p, v));
+                pb = ring_bath_rhs(A, lane, Qk, pv, ke);
+                pv0 = lane0(pv);
+                const float c0 = pv0 * iQ0;
+                vh.x = 0.5f * ((f.x - c0 * p.x) * ims) * dt;
+                vh.y = 0.5f * ((f.y - c0 * p.y) * ims) * dt;
+                vh.z = 0.5f * ((f.z - c0 * p.z) * ims) * dt;
+            } else {
+                vh.x = 0.5f * f.x * dt; vh.y = 0.5f * f.y * dt; vh.z = 0.5f * f.z * dt;      // md.py:145-148 (no 1/m)
+            }
+            q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
+            const float ph = 0.5f * pb * dt, pvh = pv + ph;
+            // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
+            ring_force<1, RDF ? 1 : 0>(K, X, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, u6, u12, ru, lds);
+            const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
+            if (nhc) {
+                const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
+                const float ke = 0.5f * wave_sum(ring_dot(p, vv));
+                const float b1 = ring_bath_rhs(A, lane, Qk, pvh, ke);
+                const float c0 = lane0(pvh) * iQ0;
+                pv = pv + (ph + 0.5f * b1 * dt);
+                v.x = v.x + (vh.x + 0.5f * ((f.x - c0 * p.x) * ims) * dt);
+                v.y = v.y + (vh.y + 0.5f * ((f.y - c0 * p.y) * ims) * dt);
+                v.z = v.z + (vh.z + 0.5f * ((f.z - c0 * p.z) * ims) * dt);
+            } else {
+                v.x = v.x + (vh.x + 0.5f * f.x * dt); v.y = v.y + (vh.y + 0.5f * f.y * dt); v.z = v.z + (vh.z + 0.5f * f.z * dt);
+            }
+            ring_store(A.q_t + (fr + k + 1) * N3, q, N, lane);
+            ring_store(A.v_t + (fr + k + 1) * N3, v, N, lane);
+            if (nhc && lane < C) A.pv_t[(fr + k + 1) * C + lane] = pv;
         }
-        q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
-        const float ph = 0.5f * pb * dt, pvh = pv + ph;
-        // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-        ring_force<1>(K, N, lane, q, wu, f, gu, u6, u12, lds);
-        const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
-        if (nhc) {
-            const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
-            const float ke = 0.5f * wave_sum(ring_dot(p, vv));
-            const float b1 = ring_bath_rhs(A, lane, Qk, pvh, ke);
-            const float c0 = lane0(pvh) * iQ0;
-            pv = pv + (ph + 0.5f * b1 * dt);
-            v.x = v.x + (vh.x + 0.5f * ((f.x - c0 * p.x) * ims) * dt);
-            v.y = v.y + (vh.y + 0.5f * ((f.y - c0 * p.y) * ims) * dt);
-            v.z = v.z + (vh.z + 0.5f * ((f.z - c0 * p.z) * ims) * dt);
-        } else {
-            v.x = v.x + (vh.x + 0.5f * f.x * dt); v.y = v.y + (vh.y + 0.5f * f.y * dt); v.z = v.z + (vh.z + 0.5f * f.z * dt);
+        if (A.nonfinite) {
+            const bool bad = !(isfinite(hsum(q.x + q.y + q.z)) && isfinite(hsum(v.x + v.y + v.z)));
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) A.nonfinite[rep] = 1;
         }
-        ring_store(A.q_t + (fr + k + 1) * N3, q, N, lane);
-        ring_store(A.v_t + (fr + k + 1) * N3, v, N, lane);
-        if (nhc && lane < C) A.pv_t[(fr + k + 1) * C + lane] = pv;
     }
-    if (A.nonfinite) {
-        const bool bad = !(isfinite(hsum(q.x + q.y + q.z)) && isfinite(hsum(v.x + v.y + v.z)));
-        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) A.nonfinite[rep] = 1;
+    if constexpr (RDF) {
+        __syncthreads();
+        for (int m = threadIdx.x; m < F.nfine; m += blockDim.x) {
+            const uint32_t c = hist[m];
+            if (c) atomicAdd(&F.ghist[m], c);
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ adjoint
-__global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A) {
+// RDF = true: the frame gradients of the fused observable are produced here -- in the first augmented evaluation
+// of interval i (which sits at frame i) for frames T-1 .. 1, and in one geometry-only sweep for frame 0 -- and
+// added to lam_q where the adjoint adds the incoming g_q (sovlers.py:249, :286).
+template <bool RDF>
+__global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
+    extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
     const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
     const RingLJ K = ring_constants(A);
-    __shared__ f32x2 lds[6 * 64];
+    RingRdf X{};
+    int ncell = 0;
+    if constexpr (RDF) {
+        // the fine grid of rdf_bwd_fine_kernel (fine_grid() in csrc/rdf.hip): RDF_SUB = 8 cells per centre spacing
+        const float mu0 = F.mu[0], dmu = (F.mu[F.nbins - 1] - mu0) / (float)(F.nbins - 1);
+        ncell = (F.nbins - 1 + 2 * (F.reach_bins + 1)) * 8;
+        float4* tab = reinterpret_cast<float4*>(smr);
+        for (int n = lane; n < ncell; n += 64) tab[n] = F.tab[n];
+        X.tab = tab; X.xlo = mu0 - (float)(F.reach_bins + 1) * dmu; X.inv_hf = 8.f / dmu; X.tmax = (float)ncell;
+        X.rc2 = F.rc2;
+        __syncthreads();
+    }
+    f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell);
     const size_t fr = (size_t)rep * T;
     f32x2 ms = {1.f, 1.f};
     if (2 * lane < N) ms.x = A.mass[2 * lane];
@@ -338,11 +471,13 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A) {
         const float h = A.t[i] - A.t[i - 1];
         Vec3x2 q = ring_load(A.q_t + (fr + i) * N3, N, lane), v = ring_load(A.v_t + (fr + i) * N3, N, lane);
         float pv = (nhc && lane < C) ? A.pv_t[(fr + i) * C + lane] : 0.f;
-        Vec3x2 w, f, dq;
+        Vec3x2 w, f, dq, rq = vzero(), ru;
         float a6, a12;
         // ---------------- first augmented evaluation at (y_i, lam)
         if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
-        ring_force<2>(K, N, lane, q, w, f, dq, a6, a12, lds);
+        const bool with_rdf = RDF && ring_frame_selected(F, i);
+        ring_force<2, RDF ? 2 : 0>(K, X, with_rdf, N, lane, q, w, f, dq, a6, a12, rq, lds);
+        if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
         if (nhc) {
             const Vec3x2 p{v.x * ms, v.y * ms, v.z * ms};
@@ -366,7 +501,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A) {
             pv = pv + 0.5f * (-pb) * h;                               // :135
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
-            ring_force<2>(K, N, lane, q, w, f, dq, a6, a12, lds);
+            ring_force<2, 0>(K, X, false, N, lane, q, w, f, dq, a6, a12, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
             const float gpm = ring_bath_vjp(A, lane, Qk, pv, lph, slm);
@@ -402,13 +537,22 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A) {
             }
             MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
 #undef MDG_RING_NVE
-            ring_force<2>(K, N, lane, q, lvh, f, dq, a6, a12, lds);
+            ring_force<2, 0>(K, X, false, N, lane, q, lvh, f, dq, a6, a12, ru, lds);
             const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
             const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
             lv.x = lvh.x + gv.x; lv.y = lvh.y + gv.y; lv.z = lvh.z + gv.z;
             lq.x = (lqh.x + dq.x * h * 0.5f) + gq.x;                  // :100
             lq.y = (lqh.y + dq.y * h * 0.5f) + gq.y;
             lq.z = (lqh.z + dq.z * h * 0.5f) + gq.z;
+        }
+    }
+    if constexpr (RDF) {
+        if (ring_frame_selected(F, 0)) {                              // frame 0: no force evaluation there
+            const Vec3x2 q = ring_load(A.q_t + fr * N3, N, lane), wu = vzero();
+            Vec3x2 fu, gu, rq = vzero();
+            float u6, u12;
+            ring_force<0, 2>(K, X, true, N, lane, q, wu, fu, gu, u6, u12, rq, lds);
+            lq.x += rq.x; lq.y += rq.y; lq.z += rq.z;
         }
     }
     ring_store(A.adj_v0 + (size_t)rep * N3, lv, N, lane);

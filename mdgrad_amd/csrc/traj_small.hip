@@ -729,10 +729,35 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 // ------------------------------------------------------------------------------------ launch
 // wave-per-replica kernels (traj_ring.hpp): one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and either
 // asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
-bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
+bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
-    const bool form = terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && t.q == 6;
-    return form && p.n_atoms <= 128 && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
+    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && t.q == 6 && p.n_atoms <= 128;
+}
+bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
+    return ring_form(p, cell, terms) && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
+}
+constexpr size_t RING_LDS_FWD = sizeof(f32x2) * 3 * 64;      // per wave: the visitors' positions
+constexpr size_t RING_LDS_ADJ = sizeof(f32x2) * 6 * 64;      //           ... and adjoint directions
+constexpr int RING_RDF_WAVES = 16;                           // waves sharing the fine histogram of the fused RDF
+constexpr int RING_RDF_MAX_CELLS = 1088;                     // derivative table <= 17 KB: eight adjoint waves per CU
+
+// the fused RDF observable: fine-grid plan (csrc/rdf.hip) + what fits beside the kernels' own LDS
+bool ring_rdf_plan(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms, const MdgRdfFuse* rdf, RdfFinePlan* plan) {
+    if (!rdf || !rdf->mu || !use_ring(p, cell, terms)) return false;     // (only where the ring kernels run anyway)
+    if (rdf->frame_stride < 1 || rdf->frame_start < 0 || !(rdf->cutoff > 0.f)) return false;
+    const RdfFinePlan P = mdg_rdf_fine_plan(rdf->spacing, rdf->coeff, rdf->nbins);
+    if (P.nfine <= 0 || P.ncell <= 0 || P.ncell > RING_RDF_MAX_CELLS) return false;
+    if (sizeof(float) * (size_t)((P.nfine + 1) & ~1LL) + RING_RDF_WAVES * RING_LDS_FWD > 156 * 1024) return false;
+    *plan = P;
+    return true;
+}
+
+RingRdfArgs ring_rdf_args(const MdgRdfFuse& rdf, const RdfFinePlan& P) {
+    RingRdfArgs F{};
+    F.mu = rdf.mu; F.nbins = rdf.nbins; F.rc2 = rdf.cutoff * rdf.cutoff;
+    F.f_start = rdf.frame_start; F.f_stride = rdf.frame_stride;
+    F.reach = P.reach; F.inv_h = 1.0f / P.h; F.nfine = (int)P.nfine; F.reach_bins = P.reach_bins;
+    return F;
 }
 
 int pick_tpa_log2(int n_atoms, int block) {
@@ -817,7 +842,8 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
         MDG_CHECK_ARG(theta, "traj_fwd: null theta");
-        hipLaunchKernelGGL(traj_fwd_ring_kernel, dim3(prm->n_rep), dim3(64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(traj_fwd_ring_kernel<false>, dim3(prm->n_rep), dim3(64), RING_LDS_FWD, (hipStream_t)stream, a,
+                           RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_fwd_ring_kernel");
         return MDG_OK;
     }
@@ -854,7 +880,8 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
         MDG_CHECK_ARG(theta, "traj_adj: null theta");
-        hipLaunchKernelGGL(traj_adj_ring_kernel, dim3(prm->n_rep), dim3(64), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(traj_adj_ring_kernel<false>, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ, (hipStream_t)stream, a,
+                           RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_adj_ring_kernel");
         return MDG_OK;
     }
@@ -870,5 +897,78 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     hipStream_t st = (hipStream_t)stream;
     MDG_TRAJ_DISPATCH(traj_adj_kernel);
     MDG_CHECK_LAUNCH("traj_adj_kernel");
+    return MDG_OK;
+}
+
+// ------------------------------------------------------------------------------------ fused RDF observable
+extern "C" int mdg_traj_rdf_supported(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                      const MdgRdfFuse* rdf) {
+    RdfFinePlan P;
+    return prm && cell && terms && validate(prm, cell, terms) == MDG_OK && ring_rdf_plan(*prm, *cell, *terms, rdf, &P);
+}
+
+extern "C" int mdg_traj_fwd_small_rdf(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                      const float* theta, const float* mass, const float* t_grid,
+                                      const float* v0, const float* q0, const float* pv0,
+                                      float* v_t, float* q_t, float* pv_t, int32_t* nonfinite,
+                                      const MdgRdfFuse* rdf, float* raw, void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(theta && mass && t_grid && v0 && q0 && v_t && q_t && raw, "traj_fwd_rdf: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd_rdf: NHC needs pv0/pv_t");
+    RdfFinePlan P;
+    MDG_CHECK_ARG(ring_rdf_plan(*prm, *cell, *terms, rdf, &P), "traj_fwd_rdf: not available for this system / observable "
+                  "(see mdg_traj_rdf_supported)");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* ghist = nullptr;
+    MDG_HIP(hipMallocAsync((void**)&ghist, sizeof(uint32_t) * (size_t)P.nfine, st));
+    MDG_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)P.nfine, st));
+    RingRdfArgs F = ring_rdf_args(*rdf, P);
+    F.ghist = ghist;
+    int grid = (prm->n_rep + RING_RDF_WAVES - 1) / RING_RDF_WAVES;
+    if (grid > 256) grid = 256;                                   // one resident workgroup (16 waves) per CU
+    const size_t lds = sizeof(float) * (size_t)((P.nfine + 1) & ~1LL) + RING_RDF_WAVES * RING_LDS_FWD;
+    hipLaunchKernelGGL(traj_fwd_ring_kernel<true>, dim3(grid), dim3(64 * RING_RDF_WAVES), lds, st, a, F);
+    rc = mdg_rdf_fine_finish(ghist, P, rdf->mu, rdf->nbins, raw, st);
+    (void)hipFreeAsync(ghist, st);
+    if (rc) return rc;
+    MDG_CHECK_LAUNCH("traj_fwd_ring_kernel<rdf>");
+    return MDG_OK;
+}
+
+extern "C" int mdg_traj_adj_small_rdf(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                      const float* theta, const float* mass, const float* t_grid,
+                                      const float* v_t, const float* q_t, const float* pv_t,
+                                      const float* g_v, const float* g_q, const float* g_pv,
+                                      float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                      const MdgRdfFuse* rdf, const float* g_raw, void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(theta && mass && t_grid && v_t && q_t && adj_v0 && adj_q0 && g_raw, "traj_adj_rdf: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || pv_t, "traj_adj_rdf: NHC needs pv_t");
+    RdfFinePlan P;
+    MDG_CHECK_ARG(ring_rdf_plan(*prm, *cell, *terms, rdf, &P), "traj_adj_rdf: not available for this system / observable "
+                  "(see mdg_traj_rdf_supported)");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
+    a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
+    a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
+    hipStream_t st = (hipStream_t)stream;
+    float4* tab = nullptr;                                        // (stream-ordered scratch: no state, re-entrant)
+    MDG_HIP(hipMallocAsync((void**)&tab, sizeof(float4) * (size_t)P.ncell, st));
+    rc = mdg_rdf_bwd_table(rdf->mu, rdf->coeff, rdf->nbins, g_raw, P, tab, st);
+    if (rc == MDG_OK) {
+        RingRdfArgs F = ring_rdf_args(*rdf, P);
+        F.tab = tab;
+        hipLaunchKernelGGL(traj_adj_ring_kernel<true>, dim3(prm->n_rep), dim3(64), sizeof(float4) * (size_t)P.ncell + RING_LDS_ADJ,
+                           st, a, F);
+    }
+    (void)hipFreeAsync(tab, st);
+    if (rc) return rc;
+    MDG_CHECK_LAUNCH("traj_adj_ring_kernel<rdf>");
     return MDG_OK;
 }

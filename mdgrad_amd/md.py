@@ -215,6 +215,9 @@ class _EOM(torch.nn.Module):
         spec = _FusedSpec(self, self._ensemble, N, self.mass[:N].contiguous(), cs, ops.make_terms(terms, pos), pos,
                           masks, large=large, **kw)
         spec.n_rep = getattr(self.system, "n_replicas", 1)
+        # an rdf observable that was evaluated on an earlier trajectory of this integrator (observable.py) is
+        # computed inside the next fused launch; `fuse_observables = False` on the integrator switches that off
+        spec.rdf_hint = getattr(self, "_rdf_hint", None) if getattr(self, "fuse_observables", True) else None
         return spec
 
 

@@ -54,11 +54,43 @@ class rdf(Observable):
         self._cell_struct = _lib.make_cell(self.cell)      # diagonal of the cell, as the reference
         self._mask = ops.build_mask(self.natoms, index_tuple, None, self.device)
 
+    def _fused_raw(self, xyz):
+        """The raw histogram of `xyz` if a fused trajectory launch already produced it (ops.fused_traj); otherwise
+        None -- after registering this observable and the frame selection with the integrator, so that the NEXT
+        launch produces it.  `xyz` must be the trajectory tensor itself or a slice of it along time that runs to
+        the last frame (q_t, q_t[::k], q_t[s:], q_t[s::k])."""
+        base = xyz if hasattr(xyz, "_mdg_traj") else getattr(xyz, "_base", None)
+        tag = getattr(base, "_mdg_traj", None) if base is not None else None
+        if tag is None or self._mask is not None or self.nbins < 2:
+            return None
+        spec, td, hint, raw = tag
+        start, stride = 0, 1
+        if xyz is not base:
+            if (xyz.dim() != base.dim() or base.stride(td) == 0 or
+                    any(xyz.shape[d] != base.shape[d] or xyz.stride(d) != base.stride(d) for d in range(base.dim()) if d != td)):
+                return None
+            off, bs = xyz.storage_offset() - base.storage_offset(), base.stride(td)
+            if off < 0 or off % bs or xyz.stride(td) % bs or xyz.shape[td] < 1:
+                return None
+            start, stride = off // bs, max(1, xyz.stride(td) // bs)
+            if start >= base.shape[td] or xyz.shape[td] != (base.shape[td] - start + stride - 1) // stride:
+                return None
+        if hint is not None and raw is not None and hint.matches(self, start, stride):
+            return raw
+        new = ops.RdfFuse(self, start, stride)
+        spec.rdf_hint = new
+        integ = getattr(spec, "_integrator", None)
+        if integ is not None and getattr(integ, "fuse_observables", True):
+            integ._rdf_hint = new
+        return None
+
     def forward(self, xyz):
-        if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
-            xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))
-        count = ops.RdfRawFn.apply(xyz, self.offsets, self.coeff, self.cutoff_boundary,
-                                   self._cell_struct, self._mask, self.spacing)
+        count = self._fused_raw(xyz)
+        if count is None:
+            if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
+                xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))
+            count = ops.RdfRawFn.apply(xyz, self.offsets, self.coeff, self.cutoff_boundary,
+                                       self._cell_struct, self._mask, self.spacing)
         norm = count.sum()
         count = count / norm
         rdf = count / (self.vol_bins / self.V)

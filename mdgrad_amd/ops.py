@@ -266,6 +266,54 @@ def make_terms(term_list, n_theta_total):
     return ts
 
 
+class RdfFuse:
+    """An `rdf` observable (observable.py) that a fused trajectory launch evaluates on the fly: centres, width and
+    pair cutoff of the observable and the frames frame_start + k frame_stride it is called on.  Registered on the
+    integrator by the observable itself the first time it sees (a time slice of) a fused trajectory; later launches
+    deposit the histogram inside the trajectory kernels (mdg_traj_fwd_small_rdf) and take dL/d(raw) in the adjoint
+    (mdg_traj_adj_small_rdf) -- see `fused_traj` and `rdf.forward`."""
+
+    def __init__(self, obs, start, stride):
+        import weakref
+        self.obs = weakref.ref(obs)
+        self.mu = obs.offsets.detach().to(torch.float32).contiguous()
+        self.nbins, self.coeff, self.spacing = int(obs.nbins), float(obs.coeff), float(obs.spacing)
+        self.cutoff, self.n_atoms = float(obs.cutoff_boundary), int(obs.natoms)
+        self.cell = tuple(float(x) for x in obs.cell.tolist())
+        self.start, self.stride = int(start), int(stride)
+
+    def struct(self):
+        return _lib.MdgRdfFuse(self.mu.data_ptr(), self.nbins, self.coeff, self.spacing, self.cutoff, self.start,
+                               self.stride)
+
+    def matches(self, obs, start, stride):
+        return self.obs() is obs and self.start == int(start) and self.stride == int(stride)
+
+    def fits(self, spec, dev):
+        cs = spec.cell_struct
+        return (self.obs() is not None and self.n_atoms == spec.n_atoms and self.mu.device == dev
+                and bool(cs.diag) and all(abs(cs.h[4 * c] - self.cell[c]) <= 1e-6 * abs(self.cell[c]) for c in range(3)))
+
+
+def fused_traj(v0, q0, pv0, t, theta, spec, time_dim=None):
+    """FusedTrajFn.apply plus the bookkeeping of the fused observable: returns (v_t, q_t[, pv_t]) with q_t tagged so
+    that an `rdf` called on it (or on a slice of it along time) finds the histogram the launch already made, or
+    registers itself for the next launch."""
+    spec._fuse_now = True                  # (direct callers of FusedTrajFn.apply keep its plain output tuple)
+    try:
+        outs = FusedTrajFn.apply(v0, q0, pv0, t, theta, spec)
+    finally:
+        spec._fuse_now = False
+    n = 3 if spec.ensemble == 0 else 2
+    tag_trajectory(outs[1], spec, outs[n] if len(outs) > n else None,
+                   (1 if v0.dim() == 3 else 0) if time_dim is None else time_dim)
+    return tuple(outs[:n])
+
+
+def tag_trajectory(q_t, spec, raw, time_dim):
+    q_t._mdg_traj = (spec, time_dim, getattr(spec, "rdf_hint", None) if raw is not None else None, raw)
+
+
 class FusedTrajFn(torch.autograd.Function):
     """odeint_adjoint(NoseHooverChain|NVE, (v0,q0[,pv0]), t) in two launches: the forward
     trajectory and, on backward, the reference's adjoint sweep (torchmd/sovlers.py:196-293).
@@ -290,7 +338,22 @@ class FusedTrajFn(torch.autograd.Function):
         pv_t = torch.empty(R, T, Cn, device=dev) if nhc else None
         prm = spec.params(R, T)
         ctx.ws = None
-        if spec.large:
+        fuse = getattr(spec, "rdf_hint", None) if getattr(spec, "_fuse_now", False) else None
+        if fuse is not None and (spec.large or getattr(spec, "table", False) or thc is None or not fuse.fits(spec, dev)
+                                 or not lib.mdg_traj_rdf_supported(C.byref(prm), C.byref(spec.cell_struct),
+                                                                   C.byref(spec.terms), C.byref(fuse.struct()))):
+            fuse = None
+        ctx.fuse = fuse
+        raw = None
+        if fuse is not None:
+            # the observable rides along: raw soft histogram of the selected frames of all replicas
+            raw = torch.empty(fuse.nbins, device=dev)
+            bad = torch.zeros(R, dtype=torch.int32, device=dev)
+            check(lib.mdg_traj_fwd_small_rdf(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                             ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
+                                             ptr(q_t), ptr(pv_t), ptr(bad), C.byref(fuse.struct()), ptr(raw),
+                                             stream_ptr(dev)), "mdg_traj_fwd_small_rdf")
+        elif spec.large:
             ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, spec.n_theta_total)), device=dev)
             flags = torch.zeros(4, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
@@ -326,6 +389,8 @@ class FusedTrajFn(torch.autograd.Function):
         outs = (v_t, q_t, pv_t) if nhc else (v_t, q_t)
         if not batched:
             outs = tuple(o[0] for o in outs)
+        if raw is not None:
+            outs = outs + (raw,)
         return outs
 
     @staticmethod
@@ -353,6 +418,20 @@ class FusedTrajFn(torch.autograd.Function):
         gv = prep(grads[0], v_t)
         gq = prep(grads[1], q_t)
         gp = prep(grads[2], pv_t) if nhc else None
+        fuse = ctx.fuse
+        g_raw = grads[3 if nhc else 2] if fuse is not None else None
+        if g_raw is not None and ctx.needs_input_grad[3]:
+            # gradients w.r.t. the time grid read the frame gradients: materialise the observable's share
+            sel = q_t[:, fuse.start::fuse.stride].contiguous()
+            gsel = torch.empty_like(sel)
+            cs = spec.cell_struct
+            check(lib.mdg_rdf_bwd_uniform(ptr(sel), sel.shape[0] * sel.shape[1], N, C.byref(cs), fuse.cutoff, None,
+                                          ptr(fuse.mu), fuse.spacing, fuse.coeff, fuse.nbins,
+                                          ptr(g_raw.detach().to(torch.float32).contiguous()), ptr(gsel), stream_ptr(dev)),
+                  "mdg_rdf_bwd")
+            gq = torch.zeros_like(q_t) if gq is None else gq.clone()
+            gq[:, fuse.start::fuse.stride] += gsel
+            g_raw = None
         adj_v = torch.empty(R, N, 3, device=dev)
         adj_q = torch.empty(R, N, 3, device=dev)
         adj_p = torch.empty(R, len(spec.Q), device=dev) if nhc else None
@@ -362,6 +441,14 @@ class FusedTrajFn(torch.autograd.Function):
         table = getattr(spec, "table", False)
 
         def launch(terms):
+            if g_raw is not None:
+                gr = g_raw.detach().to(torch.float32).contiguous()
+                check(lib.mdg_traj_adj_small_rdf(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                                 ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv),
+                                                 ptr(gq), ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                                 C.byref(fuse.struct()), ptr(gr), stream_ptr(dev)),
+                      "mdg_traj_adj_small_rdf")
+                return None
             if spec.large:
                 flags = torch.zeros(4, dtype=torch.int32, device=dev)
                 check(lib.mdg_traj_adj_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),

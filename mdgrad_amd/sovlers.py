@@ -273,14 +273,20 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         R, N = getattr(spec, "n_rep", 1), spec.n_atoms
         if R > 1 and y0[0].dim() == 2:
             # replica-stacked system ([R*N, 3] states): one workgroup (or grid row) per replica
-            outs = ops.FusedTrajFn.apply(y0[0].reshape(R, N, 3), y0[1].reshape(R, N, 3),
-                                         pv0.reshape(R, -1) if pv0 is not None else None, t, flat_params, spec)
+            spec._fuse_now = True
+            try:
+                outs = ops.FusedTrajFn.apply(y0[0].reshape(R, N, 3), y0[1].reshape(R, N, 3),
+                                             pv0.reshape(R, -1) if pv0 is not None else None, t, flat_params, spec)
+            finally:
+                spec._fuse_now = False
             T_ = t.shape[0]
             res = [outs[0].transpose(0, 1).reshape(T_, R * N, 3), outs[1].transpose(0, 1).reshape(T_, R * N, 3)]
             if pv0 is not None:
                 res.append(outs[2].transpose(0, 1))
+            n = 3 if pv0 is not None else 2
+            ops.tag_trajectory(res[1], spec, outs[n] if len(outs) > n else None, 0)
             return tuple(res)
-        return ops.FusedTrajFn.apply(y0[0], y0[1], pv0, t, flat_params, spec)
+        return ops.fused_traj(y0[0], y0[1], pv0, t, flat_params, spec)
 
     tensor_input = False
     if torch.is_tensor(y0):

@@ -17,7 +17,7 @@ def mean(db, counter, kernel):
 
 fetch_db, write_db, R, T = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 out = {}
-for k in ("traj_adj_kernel", "traj_fwd_kernel", "rdf_fwd_fine_kernel", "rdf_fwd_half_kernel", "rdf_fwd_lane_kernel", "rdf_fwd_block8_kernel",
+for k in ("traj_adj_ring_kernel", "traj_fwd_ring_kernel", "traj_adj_kernel", "traj_fwd_kernel", "rdf_fwd_fine_kernel", "rdf_fwd_half_kernel", "rdf_fwd_lane_kernel", "rdf_fwd_block8_kernel",
           "rdf_bwd_fine_kernel", "rdf_bwd_kernel"):
     f, w = mean(fetch_db, "FETCH_SIZE", k), mean(write_db, "WRITE_SIZE", k)
     if f is None or w is None:
