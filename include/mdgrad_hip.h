@@ -198,12 +198,12 @@ int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
  * mdg_rdf_fwd_uniform returns for those frames) and the adjoint launch takes g_raw = dL/d(raw) in place of the
  * frame gradients dL/dq_t that mdg_rdf_bwd_uniform would have written to HBM (an additional g_q is still accepted).
  * Available where the wave-per-replica kernels run (one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and
- * block = 64 or n_rep >= 1024) and for equally spaced centres whose fine grids fit the LDS: mdg_traj_rdf_supported() != 0. */
+ * block = 64 or n_rep >= 1024) and for equally spaced centres whose fine grids fit the LDS and start above zero: mdg_traj_rdf_supported() != 0. */
 typedef struct MdgRdfFuse {
     const float* mu;               /* device [nbins] centres, equally spaced (GaussianSmearing offsets) */
     int32_t nbins;
     float   coeff;                 /* -0.5 / width^2 */
-    float   spacing;               /* mu[1] - mu[0] */
+    float   mu0, spacing;          /* mu[0], mu[1] - mu[0] */
     float   cutoff;                /* pair cutoff of the observable (observable.py:52: r_range end + 0.5) */
     int32_t frame_start, frame_stride;   /* frames frame_start + k frame_stride of every replica */
 } MdgRdfFuse;

@@ -39,7 +39,7 @@ class MdgTrajParams(C.Structure):
 
 class MdgRdfFuse(C.Structure):
     """Fused RDF observable of the wave-per-replica trajectory kernels (include/mdgrad_hip.h)."""
-    _fields_ = [("mu", C.c_void_p), ("nbins", C.c_int32), ("coeff", C.c_float), ("spacing", C.c_float),
+    _fields_ = [("mu", C.c_void_p), ("nbins", C.c_int32), ("coeff", C.c_float), ("mu0", C.c_float), ("spacing", C.c_float),
                 ("cutoff", C.c_float), ("frame_start", C.c_int32), ("frame_stride", C.c_int32)]
 
 

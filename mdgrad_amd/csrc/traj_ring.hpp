@@ -75,9 +75,9 @@ __device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
 //   RDF = 2 (adjoint)  evaluates dL/dd from the cubic-Hermite cell table of rdf_bwd_fine_kernel and accumulates the
 //                      frame gradient dL/dq_t that the adjoint would otherwise load from HBM.
 struct RingRdf {
-    uint32_t* hist; float inv_h, tlo, fmax;                 // RDF = 1: fine histogram [nfine], t = d inv_h + tlo
-    const float4* tab; float xlo, inv_hf, tmax;             // RDF = 2: cell cubics [nn-1], t = (d - xlo) inv_hf
-    float rc2;                                              // the observable's own pair cutoff (squared)
+    uint32_t* hist; float inv_h, tlo, fmax;                 // RDF = 1: fine histogram [nfine], t = d inv_h + tlo < fmax
+    const float4* tab; float xlo, inv_hf, tmax;             // RDF = 2: cell cubics [nn-1], t = (d - xlo) inv_hf < tmax
+                                                            // (fmax / tmax: end of the grid or the observable's cutoff)
 };
 
 // One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
@@ -98,28 +98,31 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
         dx = min_image_diag2(dx, K.ivx, K.hx); dy = min_image_diag2(dy, K.ivy, K.hy); dz = min_image_diag2(dz, K.ivz, K.hz);
     }
     const f32x2 d2 = norm2_ref2(dx, dy, dz);
+    // Range tests of the fused observable: for a float t, `bits(t) < bits(tmax)` as unsigned integers is exactly
+    // 0 <= t < tmax (a negative t has the sign bit set, a NaN lies above every finite value) -- one compare per
+    // pair.  The host folds the observable's own cutoff into tmax / fmax, and the grids start above zero, so
+    // this accepts precisely the pairs of topology.py:67 that can contribute.
     if constexpr (RDF == 1) {
-        // rdf_fine_frame: t = sqrt(d2) / h - lo / h, accepted pairs are those of topology.py:67 inside the grid
+        // rdf_fine_frame: t = sqrt(d2) / h - lo / h
         const float ta = fmaf(__builtin_amdgcn_sqrtf(d2.x), X.inv_h, X.tlo), tb = fmaf(__builtin_amdgcn_sqrtf(d2.y), X.inv_h, X.tlo);
-        const bool oka = r0 && ta >= 0.f && ta < X.fmax && d2.x < X.rc2 && d2.x != 0.f;
-        const bool okb = r1 && tb >= 0.f && tb < X.fmax && d2.y < X.rc2 && d2.y != 0.f;
-        if (oka) atomicAdd(&X.hist[(int)ta], 1u);
-        if (okb) atomicAdd(&X.hist[(int)tb], 1u);
+        const uint32_t lim = __float_as_uint(X.fmax);
+        if (r0 && __float_as_uint(ta) < lim) atomicAdd(&X.hist[(int)ta], 1u);
+        if (r1 && __float_as_uint(tb) < lim) atomicAdd(&X.hist[(int)tb], 1u);
     }
     if constexpr (RDF == 2) {
         // rdf_bwd_fine_kernel: d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d; a rejected pair adds +-0
-        bool oka = r0 && d2.x < X.rc2 && d2.x != 0.f, okb = r1 && d2.y < X.rc2 && d2.y != 0.f;
-        const f32x2 id = {__builtin_amdgcn_rsqf(oka ? d2.x : 1.f), __builtin_amdgcn_rsqf(okb ? d2.y : 1.f)};
+        // (d2 = 0: rsq = inf, t = NaN -> rejected, and the selects below never let the inf through)
+        const f32x2 id = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
         f32x2 t = (d2 * id - X.xlo) * X.inv_hf;
-        oka = oka && t.x >= 0.f && t.x < X.tmax;
-        okb = okb && t.y >= 0.f && t.y < X.tmax;
+        const uint32_t lim = __float_as_uint(X.tmax);
+        const bool oka = r0 && __float_as_uint(t.x) < lim, okb = r1 && __float_as_uint(t.y) < lim;
         t = f32x2{oka ? t.x : 0.f, okb ? t.y : 0.f};
         const int gA = (int)t.x, gB = (int)t.y;
         const f32x2 fr = t - f32x2{(float)gA, (float)gB};
         const float4 ca = X.tab[gA], cb = X.tab[gB];
         const float sdA = fmaf(fr.x, fmaf(fr.x, fmaf(fr.x, ca.w, ca.z), ca.y), ca.x);
         const float sdB = fmaf(fr.y, fmaf(fr.y, fmaf(fr.y, cb.w, cb.z), cb.y), cb.x);
-        const f32x2 cw = f32x2{oka ? sdA : 0.f, okb ? sdB : 0.f} * id;
+        const f32x2 cw = {oka ? sdA * id.x : 0.f, okb ? sdB * id.y : 0.f};
         const f32x2 cx = cw * dx, cy = cw * dy, cz = cw * dz;
         ri.x -= cx; ri.y -= cy; ri.z -= cz;
         if constexpr (JSIDE) { rj.x += CROSS ? cx.yx : cx; rj.y += CROSS ? cy.yx : cy; rj.z += CROSS ? cz.yx : cz; }
@@ -329,7 +332,7 @@ __device__ __forceinline__ float ring_dot(const Vec3x2& a, const Vec3x2& b) {   
 // Device-side description of the fused observable (host: MdgRdfFuse + the fine-grid plan of csrc/rdf.hip)
 struct RingRdfArgs {
     const float* mu; int nbins;             // equally spaced centres (device)
-    float rc2;                              // the observable's pair cutoff^2
+    float rc;                               // the observable's pair cutoff
     int f_start, f_stride;                  // frames f_start, f_start + f_stride, ... of every replica
     float reach, inv_h; int nfine;          // forward: fine integer histogram
     uint32_t* ghist;                        //          [nfine] global, zeroed by the host
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
         for (int m = threadIdx.x; m < F.nfine; m += blockDim.x) hist[m] = 0u;
         __syncthreads();
         const float lo = F.mu[0] - F.reach;                      // lower edge of the fine grid
-        X.hist = hist; X.inv_h = F.inv_h; X.tlo = -lo * F.inv_h; X.fmax = (float)F.nfine; X.rc2 = F.rc2;
+        X.hist = hist; X.inv_h = F.inv_h; X.tlo = -lo * F.inv_h;
+        X.fmax = fminf((float)F.nfine, fmaf(F.rc, F.inv_h, X.tlo));
     }
     f32x2 ms = {1.f, 1.f};                                       // (absent atoms: unit mass, zero state)
     if (2 * lane < N) ms.x = A.mass[2 * lane];
@@ -450,8 +454,8 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         ncell = (F.nbins - 1 + 2 * (F.reach_bins + 1)) * 8;
         float4* tab = reinterpret_cast<float4*>(smr);
         for (int n = lane; n < ncell; n += 64) tab[n] = F.tab[n];
-        X.tab = tab; X.xlo = mu0 - (float)(F.reach_bins + 1) * dmu; X.inv_hf = 8.f / dmu; X.tmax = (float)ncell;
-        X.rc2 = F.rc2;
+        X.tab = tab; X.xlo = mu0 - (float)(F.reach_bins + 1) * dmu; X.inv_hf = 8.f / dmu;
+        X.tmax = fminf((float)ncell, (F.rc - X.xlo) * X.inv_hf);
         __syncthreads();
     }
     f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell);

@@ -747,6 +747,8 @@ bool ring_rdf_plan(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& 
     if (rdf->frame_stride < 1 || rdf->frame_start < 0 || !(rdf->cutoff > 0.f)) return false;
     const RdfFinePlan P = mdg_rdf_fine_plan(rdf->spacing, rdf->coeff, rdf->nbins);
     if (P.nfine <= 0 || P.ncell <= 0 || P.ncell > RING_RDF_MAX_CELLS) return false;
+    // both fine grids must start above zero: the kernels' single range compare then also rejects a zero distance
+    if (!(rdf->mu0 - P.reach > 0.f) || !(rdf->mu0 - (float)(P.reach_bins + 1) * rdf->spacing > 0.f)) return false;
     if (sizeof(float) * (size_t)((P.nfine + 1) & ~1LL) + RING_RDF_WAVES * RING_LDS_FWD > 156 * 1024) return false;
     *plan = P;
     return true;
@@ -754,7 +756,7 @@ bool ring_rdf_plan(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& 
 
 RingRdfArgs ring_rdf_args(const MdgRdfFuse& rdf, const RdfFinePlan& P) {
     RingRdfArgs F{};
-    F.mu = rdf.mu; F.nbins = rdf.nbins; F.rc2 = rdf.cutoff * rdf.cutoff;
+    F.mu = rdf.mu; F.nbins = rdf.nbins; F.rc = rdf.cutoff;
     F.f_start = rdf.frame_start; F.f_stride = rdf.frame_stride;
     F.reach = P.reach; F.inv_h = 1.0f / P.h; F.nfine = (int)P.nfine; F.reach_bins = P.reach_bins;
     return F;

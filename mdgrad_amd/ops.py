@@ -278,12 +278,13 @@ class RdfFuse:
         self.obs = weakref.ref(obs)
         self.mu = obs.offsets.detach().to(torch.float32).contiguous()
         self.nbins, self.coeff, self.spacing = int(obs.nbins), float(obs.coeff), float(obs.spacing)
+        self.mu0 = float(obs.r_axis[0])
         self.cutoff, self.n_atoms = float(obs.cutoff_boundary), int(obs.natoms)
         self.cell = tuple(float(x) for x in obs.cell.tolist())
         self.start, self.stride = int(start), int(stride)
 
     def struct(self):
-        return _lib.MdgRdfFuse(self.mu.data_ptr(), self.nbins, self.coeff, self.spacing, self.cutoff, self.start,
+        return _lib.MdgRdfFuse(self.mu.data_ptr(), self.nbins, self.coeff, self.mu0, self.spacing, self.cutoff, self.start,
                                self.stride)
 
     def matches(self, obs, start, stride):
