@@ -57,5 +57,34 @@ def build_library(verbose=True):
     return LIB
 
 
+TORCH_SRC = os.path.join(HERE, "csrc_torch", "mdgrad_torch.cpp")
+TORCH_LIB = os.path.join(LIBDIR, "libmdgrad_torch.so")
+
+
+def build_torch_ops(verbose=True):
+    """torch.ops.mdgrad.*: the TORCH_LIBRARY layer over the C ABI (csrc_torch/mdgrad_torch.cpp), host-only C++ built
+    with g++ against this interpreter's torch; links libmdgrad_hip.so through $ORIGIN."""
+    import torch
+    from torch.utils import cpp_extension as ce
+    deps = [os.path.join(HERE, "..", "include", "mdgrad_hip.h"), LIB]
+    if not _newer(TORCH_SRC, TORCH_LIB, deps):
+        if verbose:
+            print("libmdgrad_torch.so: %s (up to date)" % TORCH_LIB)
+        return TORCH_LIB
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ([os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+           + ["-I" + d for d in ce.include_paths()] + ["-I/opt/rocm/include", TORCH_SRC, "-o", TORCH_LIB,
+              "-L" + tlib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-L" + LIBDIR, "-lmdgrad_hip",
+              "-Wl,-rpath,$ORIGIN"])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building the torch op library failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("libmdgrad_torch.so: %s (rebuilt)" % TORCH_LIB)
+    return TORCH_LIB
+
+
 if __name__ == "__main__":
     build_library()
+    build_torch_ops()

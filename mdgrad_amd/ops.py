@@ -13,6 +13,7 @@ import math
 import torch
 
 from . import _lib
+from . import _torch_ops
 from ._lib import MdgPairTerm, MdgTerms, MdgTrajParams, check, ptr, stream_ptr, require_gpu
 
 
@@ -852,6 +853,9 @@ def _atb(A, B):
     lib = _lib.load()
     require_gpu(A, "A"), require_gpu(B, "B")
     A, B = A.contiguous(), B.contiguous()
+    tops = _torch_ops.get()
+    if tops is not None:
+        return tops.atb(A, B)
     E, M, N = A.shape[0], A.shape[1], B.shape[1]
     out = torch.empty(M, N, device=A.device)
     ws = torch.empty(max(1, int(lib.mdg_atb_workspace(E, M, N))), device=A.device)
@@ -980,6 +984,7 @@ class FilterNet:
         self.bf16 = bool(bf16)                   # bf16 MFMA operands in the forward / tangent / aggregation sweeps
         self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
         self.G, self.F = int(self.t[0].shape[0]), int(self.t[4].shape[0])
+        self.mu, self.coef, self.W1, self.b1, self.W2, self.b2 = self.t
         s = _lib.MdgFilterNet()
         s.mu, s.coef, s.W1, s.b1, s.W2, s.b2 = (x.data_ptr() for x in self.t)
         s.n_gauss, s.n_filters = self.G, self.F
@@ -995,6 +1000,10 @@ def edge_geom(x, topo, w=None):
     lib = _lib.load()
     require_gpu(x, "x")
     x = x.contiguous()
+    tops = _torch_ops.get()
+    if tops is not None:
+        d, uhat, dd, ddel = tops.edge_geom(x, w.contiguous() if w is not None else None, topo.nbr, topo.offsets)
+        return (d, uhat, dd, ddel) if w is not None else (d, uhat, None, None)
     E, dev = topo.n_edges, x.device
     d, uhat = torch.empty(E, device=dev), torch.empty(E, 3, device=dev)
     dd = ddel = None
@@ -1011,6 +1020,10 @@ def edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, topo):
     lib = _lib.load()
     e = topo.ell
     dev = dd_b.device
+    tops = _torch_ops.get()
+    if tops is not None:
+        force, dwf = tops.edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, e.col, topo.eid, e.cnt)
+        return force, (dwf if d_b is not None else None)
     force = torch.empty(topo.n_atoms, 3, device=dev)
     dwf = torch.empty(topo.n_atoms, 3, device=dev) if d_b is not None else None
     check(lib.mdg_edge_geom_bwd(ptr(d_b), ptr(dd_b), ptr(d), ptr(dd), ptr(uhat), ptr(ddel), ptr(e.col), ptr(topo.eid),
@@ -1028,6 +1041,12 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     hd = hd.contiguous() if hd is not None else None
     e = topo.ell
     N, dev = topo.n_atoms, h.device
+    tops = _torch_ops.get()
+    if tops is not None:
+        m, md, hsum, hdsum = tops.cfconv_fwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, bool(fnet.bf16), d, dd,
+                                             h, hd, e.col, topo.eid, e.cnt, bool(want_sums))
+        return (m, md if dd is not None else None, hsum if want_sums else None,
+                hdsum if (want_sums and hd is not None) else None)
     m = torch.empty(N, fnet.F, device=dev)
     md = torch.empty(N, fnet.F, device=dev) if dd is not None else None
     hsum = torch.empty(N, fnet.F, device=dev) if want_sums else None
@@ -1046,6 +1065,11 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
     h, mdb = h.contiguous(), mdb.contiguous()
     hd = hd.contiguous() if hd is not None else None
     mb = mb.contiguous() if mb is not None else None
+    tops = _torch_ops.get()
+    if tops is not None:
+        out = tops.cfconv_bwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, d, dd, topo.nbr, int(topo.n_edges), h, hd,
+                              mb, mdb, d_b, dd_b, getattr(topo, "n_valid", None), bool(want_theta))
+        return tuple(out) if want_theta else None
     gW1 = gb1 = gW2 = ws = None
     if want_theta:
         gW1, gb1 = torch.empty(fnet.G, fnet.G, device=dev), torch.empty(fnet.G, device=dev)
@@ -1072,6 +1096,12 @@ def dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None,
     M = W.shape[1] if trans else W.shape[0]
     assert (W.shape[0] if trans else W.shape[1]) == K, "dense: shape mismatch"
     dev = x0.device
+    cont = lambda t: t.contiguous() if t is not None else None
+    tops = _torch_ops.get()
+    if tops is not None:
+        out0, sig, out1 = tops.dense_ssp(W, bool(trans), bool(act), x0, cont(bias), cont(mul), cont(res), cont(x1), cont(res1),
+                                         bool(want_sig))
+        return out0, (sig if (act and want_sig) else None), (out1 if x1 is not None else None)
     out0 = torch.empty(N, M, device=dev)
     sig = torch.empty(N, M, device=dev) if (act and want_sig) else None
     out1 = None
@@ -1126,6 +1156,9 @@ def ssp_dual_bwd_t(sa, td, sdb, sb):
     """ssp_dual_bwd with the tangent stored as t_dot = sa * x_dot."""
     lib = _lib.load()
     sa, td, sdb, sb = sa.contiguous(), td.contiguous(), sdb.contiguous(), sb.contiguous()
+    tops = _torch_ops.get()
+    if tops is not None:
+        return tuple(tops.ssp_dual_bwd_t(sa, td, sdb, sb))
     xdb, xb = torch.empty_like(sa), torch.empty_like(sa)
     check(lib.mdg_ssp_dual_bwd_t(ptr(sa), ptr(td), ptr(sdb), ptr(sb), sa.numel(), ptr(xdb), ptr(xb),
                                  stream_ptr(sa.device)), "mdg_ssp_dual_bwd_t")

@@ -129,3 +129,17 @@ def test_potential_descriptors():
         assert torch.allclose(mod(r).reshape(-1), O.pair_phi(kind, r.reshape(-1), th, consts)[0], rtol=1e-5)
     with pytest.raises(ValueError):
         P.LJFamily(rep_pow=12.5).mdg_term()
+
+
+def test_torch_op_library_loads_and_registers_every_op():
+    """libmdgrad_torch.so (csrc_torch/mdgrad_torch.cpp): TORCH_LIBRARY(mdgrad, ...) registers the op list of SURVEY 8b;
+    there is no CPU implementation behind it (product path = HIP only)."""
+    import torch
+    from mdgrad_amd import _torch_ops
+    ns = _torch_ops.get()
+    assert ns is not None, "build it: python -c 'import __graft_entry__ as g; g.build()'"
+    for op in _torch_ops.OPS:
+        schema = str(getattr(ns, op).default._schema)
+        assert schema.startswith("mdgrad::" + op + "("), schema
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        ns.atb(torch.zeros(8, 4), torch.zeros(8, 4))

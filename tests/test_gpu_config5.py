@@ -88,15 +88,18 @@ def test_fit_rdf_gnn_two_ranks_on_one_device():
     4 replica trajectories sharded 2 + 2, bf16 filter, 2 epochs.  Both ranks must finish with bit-identical
     parameters and a finite loss."""
     import socket
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1", MDG_GRAPHS="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "examples", "fit_rdf_gnn.py"), "--size", "2", "--replicas", "4",
-           "--epochs", "2", "--tau", "20", "--bf16"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    for attempt in range(2):                       # (the probed port can be taken between the probe and the rendezvous)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "examples", "fit_rdf_gnn.py"), "--size", "2",
+               "--replicas", "4", "--epochs", "2", "--tau", "20", "--bf16"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0 or "address already in use" not in (r.stderr + r.stdout).lower():
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     sums = re.findall(r"PARAM_CHECKSUM rank (\d) of 2 replicas \[(\d),(\d)\) (\S+)", r.stdout)
     assert sorted((a, b, c) for a, b, c, _ in sums) == [("0", "0", "2"), ("1", "2", "4")], r.stdout[-1000:]
