@@ -224,7 +224,7 @@ int mdg_traj_adj_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cel
                            const MdgRdfFuse* rdf /*host*/, const float* g_raw /*[nbins]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain): same contract as
+ * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain or NVE): same contract as
  * mdg_traj_fwd_small / mdg_traj_adj_small, two launches per step (forward) / four per adjoint
  * interval, enqueued by a host loop; the neighbour search is fused into the force kernel
  * (per-wave LDS list).  ws: f32 workspace of mdg_traj_large_workspace() floats, shared by the

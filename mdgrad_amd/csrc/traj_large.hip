@@ -170,7 +170,7 @@ __device__ __forceinline__ float reduce_partials(const float* __restrict__ part,
 // ---------------------------------------------------------------------------------------------
 // One wave: neighbours of atom i from the LDS-staged tiles, then force (LEVEL 1) or force + HVP +
 // parameter vjp (LEVEL 2) over the compact list.  Results valid on every lane after the call.
-//   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m ; th += d(w.F)/dtheta partial
+//   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m (NVE: w = lam_v) ; th += d(w.F)/dtheta partial
 template <bool DIAG, int LEVEL, int KIND = -1>
 __device__ __forceinline__ void wave_neighbours_and_force(
     const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
@@ -319,7 +319,8 @@ __device__ __forceinline__ void wave_neighbours_and_force(
     fx = fy = fz = gx = gy = gz = 0.f;
     if (!valid) return;
     float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-    if (LEVEL >= 2) { const float im = 1.0f / A.mass[i]; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
+    const bool nhc_w = A.prm.ensemble == 0;
+    if (LEVEL >= 2) { const float im = nhc_w ? 1.0f / A.mass[i] : 1.0f; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
     const int nt = A.terms.n_terms;
     for (int k = lane; k < n; k += 64) {
         const float4 e = buf[k];
@@ -339,7 +340,7 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             const float c1 = o.du * ir;
             fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
             if (LEVEL >= 2) {
-                const float jm = 1.0f / A.mass[j];
+                const float jm = nhc_w ? 1.0f / A.mass[j] : 1.0f;
                 const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
                 const float ax = wxi - lam[3 * j] * jm, ay = wyi - lam[3 * j + 1] * jm, az = wzi - lam[3 * j + 2] * jm;
                 const float a = rx * ax + ry * ay + rz * az;
@@ -403,10 +404,11 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
         for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
         Qs[threadIdx.x] = qv;
     }
+    const bool nhc = A.prm.ensemble == 0;
     float dt = 0.f;
     if (MODE == 1) dt = A.t[k + 1] - A.t[k];
     // ---- block 0: finish the bath with KE(v + vh) from the previous launch's partials
-    if (MODE == 1 && blockIdx.x == 0) {
+    if (MODE == 1 && nhc && blockIdx.x == 0) {
         const float ke = 0.5f * reduce_partials(A.partB + (size_t)rep * A.nbE, A.nbE, 1, 0, red);
         if (threadIdx.x < C) pvs[threadIdx.x] = pvh[threadIdx.x];
         __syncthreads();
@@ -417,7 +419,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
             A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = np;
         }
     }
-    if (MODE == 0 && blockIdx.x == 0 && threadIdx.x < C)
+    if (MODE == 0 && nhc && blockIdx.x == 0 && threadIdx.x < C)
         A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
     TermConst tc[MDG_MAX_TERMS];
     const float rc2max = prepare_terms(A, tc);
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
         else {
             const float vv = v[e] + vh[e];
             const float p = vv * m;
-            const float a = (F - pvh[0] * p / A.prm.Q[0]) / m;
+            const float a = nhc ? (F - pvh[0] * p / A.prm.Q[0]) / m : F;      // (NVE: md.py:145-148, no 1/m)
             vn = v[e] + (vh[e] + 0.5f * a * dt);
             v[e] = vn;
         }
@@ -468,7 +470,8 @@ __global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
         for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
         Qs[threadIdx.x] = qv;
     }
-    if (blockIdx.x == 0) {
+    const bool nhc = A.prm.ensemble == 0;
+    if (nhc && blockIdx.x == 0) {
         const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
         if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
         __syncthreads();
@@ -478,13 +481,13 @@ __global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
             pvh[threadIdx.x] = pvs[threadIdx.x] + h;
         }
     }
-    const float pv0 = pv[0];
+    const float pv0 = nhc ? pv[0] : 0.f;
     float part = 0.f;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 3 * N) {
         const float m = A.mass[e / 3];
         const float p = v[e] * m;
-        const float a = (f[e] - pv0 * p / A.prm.Q[0]) / m;
+        const float a = nhc ? (f[e] - pv0 * p / A.prm.Q[0]) / m : f[e];
         const float h = 0.5f * a * dt;
         vh[e] = h;
         q[e] = q[e] + (v[e] + h) * dt;
@@ -517,7 +520,9 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
     // (table kind: the parameter term of an interval comes from the midpoint evaluation with weight h, :160)
-    const float gw = (second && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    // (NVE: from the first evaluation, sovlers.py:82,101 -- both with total weight h)
+    const bool tab_eval = (A.prm.ensemble == 0) == (second != 0);
+    const float gw = (tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
     wave_neighbours_and_force<DIAG, 2, KIND>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
                                              tc, rc2max, gw, rep);
     float vals[LG_NV];
@@ -552,6 +557,33 @@ __global__ __launch_bounds__(256) void large_adj_mid(const LargeArgs A) {
 #pragma unroll
         for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
         Qs[threadIdx.x] = qv;
+    }
+    if (A.prm.ensemble != 0) {
+        // verlet_update backward branch, first half (sovlers.py:42-82): the parameter term of the interval comes
+        // from this first evaluation
+        if (blockIdx.x == 0) {
+            const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+            const int KT = A.terms.n_theta_total;
+#pragma unroll
+            for (int m = 0; m < MDG_MAX_TERMS; ++m)
+#pragma unroll
+                for (int p = 0; p < MDG_MAX_THETA; ++p)
+                    if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
+                        const float s = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
+                        if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (s * 0.5f * h) * 2.f;   // :82,101
+                    }
+        }
+        const int e = blockIdx.x * blockDim.x + threadIdx.x;
+        if (e < 3 * N) {
+            const float ve = A.v_t[fo + e];
+            const float vhalf = ve - 0.5f * (-A.f[so + e]) * h;                    // :49-50
+            A.qm[so + e] = A.q_t[fo + e] - vhalf * h;                              // :51-52
+            A.vm[so + e] = vhalf;
+            const float dx = A.dq[so + e] * h * 0.5f;                              // :71
+            A.lvh[so + e] = A.lv[so + e] + (A.lq[so + e] + dx) * h;                // :72
+            A.lqh[so + e] = A.lq[so + e] + dx;
+        }
+        return;
     }
     const float* pvf = A.pv_t + ((size_t)rep * T + i_fr) * C;
     float* lp = A.lp + rep * MDG_MAX_CHAINS;
@@ -594,6 +626,18 @@ __global__ __launch_bounds__(256) void large_adj_end(const LargeArgs A) {
 #pragma unroll
         for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
         Qs[threadIdx.x] = qv;
+    }
+    if (A.prm.ensemble != 0) {
+        // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
+        const int e = blockIdx.x * blockDim.x + threadIdx.x;
+        if (e < 3 * N) {
+            float nlv = A.lvh[so + e];
+            float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
+            if (A.g_v) nlv += A.g_v[go + e];
+            if (A.g_q) nlq += A.g_q[go + e];
+            A.lv[so + e] = nlv; A.lq[so + e] = nlq;
+        }
+        return;
     }
     const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
     const float* lph = A.lph + rep * MDG_MAX_CHAINS;
@@ -670,8 +714,9 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
 int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
     MDG_CHECK_ARG(p && cell && terms, "traj_large: null descriptor");
     MDG_CHECK_ARG(p->n_rep > 0 && p->n_atoms > 1 && p->n_frames >= 1, "traj_large: bad sizes");
-    MDG_CHECK_ARG(p->ensemble == 0, "traj_large: NoseHooverChain only (NVE runs the small or generic path)");
-    MDG_CHECK_ARG(p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS, "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
+    MDG_CHECK_ARG(p->ensemble == 0 || p->ensemble == 1, "traj_large: ensemble must be 0 (NHC) or 1 (NVE)");
+    MDG_CHECK_ARG(p->ensemble == 1 || (p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS),
+                  "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
     MDG_CHECK_ARG(terms->n_terms >= 1 && terms->n_terms <= MDG_MAX_TERMS, "traj_large: 1..%d pair terms", MDG_MAX_TERMS);
     for (int m = 0; m < terms->n_terms; ++m) {
         const MdgPairTerm& t = terms->t[m];
@@ -740,14 +785,16 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
                                   float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream) {
     int rc = validate_large(prm, cell, terms);
     if (rc) return rc;
-    MDG_CHECK_ARG(mass && t_grid && v0 && q0 && pv0 && v_t && q_t && pv_t && ws && flags, "traj_fwd_large: null buffer");
+    MDG_CHECK_ARG(mass && t_grid && v0 && q0 && v_t && q_t && ws && flags, "traj_fwd_large: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd_large: NHC needs pv0/pv_t");
     LG_SETUP();
     a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t;
     const int C = prm->n_chains, T = prm->n_frames;
     MDG_HIP(hipMemcpyAsync(a.q, q0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     MDG_HIP(hipMemcpyAsync(a.v, v0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
-    MDG_HIP(hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
-                     hipMemcpyDeviceToDevice, st));
+    if (prm->ensemble == 0)
+        MDG_HIP(hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
+                                 hipMemcpyDeviceToDevice, st));
     dim3 gF(nbF, R), gE(nbE, R);
     a.step = 0;
 #define LG_FORCE_STEP(MODE_)                                                                                    \
@@ -780,8 +827,8 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
                                   float* ws, int32_t* flags, void* stream) {
     int rc = validate_large(prm, cell, terms);
     if (rc) return rc;
-    MDG_CHECK_ARG(mass && t_grid && v_t && q_t && pv_t && adj_v0 && adj_q0 && adj_pv0 && ws && flags,
-                  "traj_adj_large: null buffer");
+    MDG_CHECK_ARG(mass && t_grid && v_t && q_t && adj_v0 && adj_q0 && ws && flags, "traj_adj_large: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || (pv_t && adj_pv0), "traj_adj_large: NHC needs pv_t/adj_pv0");
     LG_SETUP();
     a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
     a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
@@ -826,8 +873,9 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     }
     MDG_HIP(hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     MDG_HIP(hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
-    MDG_HIP(hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
-                     hipMemcpyDeviceToDevice, st));
+    if (prm->ensemble == 0)
+        MDG_HIP(hipMemcpy2DAsync(adj_pv0, sizeof(float) * C, a.lp, sizeof(float) * MDG_MAX_CHAINS, sizeof(float) * C, R,
+                                 hipMemcpyDeviceToDevice, st));
     if (adj_theta && table) {
         const size_t n = (size_t)R * KT;
         hipLaunchKernelGGL(large_table_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.ghi, a.glo, n,

@@ -175,7 +175,7 @@ class _EOM(torch.nn.Module):
         N = getattr(self.system, "group_size", self.mass.shape[0])      # atoms per replica
         table_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if (mods is None and self.adjoint and self.fused_table
-                and (N <= FUSED_MAX_ATOMS_LARGE and self._ensemble == 0 if table_large else N <= FUSED_MAX_ATOMS)):
+                and (N <= FUSED_MAX_ATOMS_LARGE if table_large else N <= FUSED_MAX_ATOMS)):
             members = _table_members(self.model)
             if members is not None and (self._ensemble == 1 or 2 <= self.num_chains <= 16):
                 kw = {} if self._ensemble != 0 else dict(T=self.T, n_dof=self.N_dof, Q=[float(x) for x in self.Q.tolist()])
@@ -190,7 +190,7 @@ class _EOM(torch.nn.Module):
         if mods is None or not self.adjoint:
             return None
         large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
-        if large and (self._ensemble != 0 or N > FUSED_MAX_ATOMS_LARGE):
+        if large and N > FUSED_MAX_ATOMS_LARGE:
             return None
         plist = list(self.parameters())
         offs, pos = {}, 0

@@ -160,6 +160,40 @@ def test_many_frame_rdf_kernels_vs_oracle(width_scale):
 
 
 # ------------------------------------------------------------------ large-N fused path vs the oracle
+def _large_case_nve(n_side, n_frames, seed):
+    """The NVE branch of the multi-launch kernels (md.py:133-150, sovlers.py:42-101) against the oracle."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE
+    from mdgrad_amd.sovlers import odeint_adjoint
+    pos, cell = liquid(n_side, seed=seed, jitter=0.05)
+    rng = np.random.default_rng(seed + 100)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    mass = np.full(len(pos), 1.008, dtype=np.float32)
+    t = torch.Tensor([0.004 * i for i in range(n_frames)])
+    system = mk_system(pos, cell, vel, mass)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NVE(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system).to(DEV)
+    integ.fused_large = True
+    assert integ.fused_spec("verlet").large
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    v_t, q_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="verlet")
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1)
+    N = len(pos)
+
+    def loss_fn(L):
+        return L[1][::2].pow(2).sum() / (L[1][::2].numel()) + L[0][-1].pow(2).sum() / (N * 3)
+
+    loss_fn((v_t, q_t)).backward()
+    traj, lam, gth = oracle_run(pos, cell, vel, mass, [term], 1.0, 30.0, 3, t, loss_fn, ensemble="nve")
+    close(q_t, traj[1], 0, 2e-5, "q_t (NVE, N=%d)" % N)
+    close(v_t, traj[0], 0, 5e-4, "v_t (NVE, N=%d)" % N)
+    got = torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])
+    close(got, gth, 2e-3, 2e-4 * float(gth.abs().max()), "dL/dtheta (NVE, N=%d)" % N)
+    for y, l, nm in zip(y0, lam, ("adj v0", "adj q0")):
+        close(y.grad, l, 2e-3, 5e-4 * float(l.abs().max()) + 1e-9, "%s (NVE, N=%d)" % (nm, N))
+
+
 def _large_case(n_side, n_frames, adjoint, seed):
     from mdgrad_amd import potentials as P
     from mdgrad_amd.interface import PairPotentials, Stack
@@ -205,6 +239,13 @@ def test_large_path_vs_oracle_forward_and_adjoint(n_side):
     """traj_large at N = 1 000 and N = 2 744 (tile staging, multi-block partial reduction, neighbour buffer
     all exercised), 3 steps forward + adjoint, against the oracle."""
     _large_case(n_side, 4, True, seed=20 + n_side)
+
+
+@pytest.mark.parametrize("n_side", [5, 11])
+def test_large_path_nve_vs_oracle_forward_and_adjoint(n_side):
+    """NVE above one workgroup's reach: 125 atoms forced onto the multi-launch kernels (all-atom scan) and 1 331 atoms
+    (cell-binned scan), 4 frames forward + adjoint."""
+    _large_case_nve(n_side, 4, seed=50 + n_side)
 
 
 def test_large_path_4096_atoms_one_step_vs_oracle():
