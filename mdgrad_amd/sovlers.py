@@ -131,89 +131,83 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     return solution[0] if tensor_input else solution
 
 
+class _BackwardSystem:
+    """Right-hand side of the system the generic adjoint integrates backwards over one interval
+    (torchmd/sovlers.py:221-245): packed state = (y_1..y_n, lam_1..lam_n, accumulated dL/dt, accumulated
+    dL/dtheta).  d(y)/dt = f(t, y); the other three blocks are the vector-Jacobian products of f with -lam, taken
+    either in closed form (integrators that implement `rhs_vjp`) or by autograd through `func`."""
+
+    def __init__(self, func, n_state, closed_form):
+        self.func, self.n, self.closed_form = func, n_state, closed_form
+        self.theta = tuple(func.parameters())
+
+    def __call__(self, time, packed):
+        state, costate = packed[:self.n], packed[self.n:2 * self.n]
+        if self.closed_form:
+            # rhs_vjp returns lam^T df/d(y, theta); the reference contracts with -lam (:232), hence the signs
+            rhs, by_state, by_theta = self.func.rhs_vjp(tuple(x.detach() for x in state), tuple(x.detach() for x in costate))
+            by_theta = _flatten([-g for g in by_theta]) if len(by_theta) else torch.tensor(0.).to(state[0])
+            return (*rhs, *(-g for g in by_state), torch.zeros(()).to(state[0]), by_theta)
+        with torch.enable_grad():
+            time = time.to(state[0].device).detach().requires_grad_(True)
+            state = tuple(x.detach().requires_grad_(True) for x in state)
+            rhs = self.func(time, state)
+            by_time, *others = torch.autograd.grad(rhs, (time,) + state + self.theta, tuple(-c for c in costate),
+                                                   allow_unused=True, retain_graph=True)
+        by_state = tuple(torch.zeros_like(x) if g is None else g for g, x in zip(others[:self.n], state))
+        by_theta = (_flatten_convert_none_to_zeros(others[self.n:], self.theta) if self.theta
+                    else torch.tensor(0.).to(by_state[0]))
+        return (*rhs, *by_state, torch.zeros_like(time) if by_time is None else by_time, by_theta)
+
+
 class OdeintAdjointMethod(torch.autograd.Function):
-    """Generic adjoint (sovlers.py:196-293): forward without graph, backward integrates the
-    augmented system interval by interval through autograd double-backward of func."""
+    """Generic adjoint (torchmd/sovlers.py:196-293) for whatever the fused / analytic paths do not take: the forward
+    pass keeps no graph; the backward pass walks the saved frames from the last to the first, integrating
+    `_BackwardSystem` over each interval with the SAME solver (so `NH_verlet` / `verlet` run their backward branches,
+    :129-164 / :42-101) and adding the incoming frame cotangents at every grid point (:286)."""
 
     @staticmethod
     def forward(ctx, *args):
-        y0, func, t, flat_params, rtol, atol, method, options = \
-            args[:-7], args[-7], args[-6], args[-5], args[-4], args[-3], args[-2], args[-1]
-        ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options = func, rtol, atol, method, options
+        *y0, func, t, flat_params, rtol, atol, method, options = args
+        ctx.func, ctx.solver = func, dict(rtol=rtol, atol=atol, method=method, options=options)
         with torch.no_grad():
-            ans = odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
-        ctx.save_for_backward(t, flat_params, *ans)
-        return ans
+            frames = odeint(func, tuple(y0), t, **ctx.solver)
+        ctx.save_for_backward(t, flat_params, *frames)
+        return frames
 
     @staticmethod
-    def backward(ctx, *grad_output):
-        t, flat_params, *ans = ctx.saved_tensors
-        ans = tuple(ans)
-        func, rtol, atol, method, options = ctx.func, ctx.rtol, ctx.atol, ctx.method, ctx.options
-        n = len(ans)
-        f_params = tuple(func.parameters())
-
-        analytic = (not ctx.needs_input_grad[n + 1]) and getattr(func, "supports_rhs_vjp", lambda: False)()
-
-        def augmented_dynamics(t_, y_aug):                     # sovlers.py:221-245
-            y, adj_y = y_aug[:n], y_aug[n:2 * n]
-            if analytic:
-                # same quantities without an autograd graph: func.rhs_vjp returns adj^T df/d(y, theta);
-                # the reference feeds -adj to autograd.grad (:232), hence the sign flips
-                f_eval, vjp_y, vjp_p = func.rhs_vjp(tuple(a.detach() for a in y), tuple(a.detach() for a in adj_y))
-                vjp_p = _flatten([-g for g in vjp_p]) if len(vjp_p) else torch.tensor(0.).to(y[0])
-                return (*f_eval, *(-g for g in vjp_y), torch.zeros(()).to(y[0]), vjp_p)
-            with torch.set_grad_enabled(True):
-                t_ = t_.to(y[0].device).detach().requires_grad_(True)
-                y = tuple(y_.detach().requires_grad_(True) for y_ in y)
-                f_eval = func(t_, y)
-                vjp_t, *vjp_rest = torch.autograd.grad(
-                    f_eval, (t_,) + y + f_params, tuple(-a for a in adj_y),
-                    allow_unused=True, retain_graph=True)
-            vjp_y, vjp_p = vjp_rest[:n], vjp_rest[n:]
-            vjp_t = torch.zeros_like(t_) if vjp_t is None else vjp_t
-            vjp_y = tuple(torch.zeros_like(b) if a is None else a for a, b in zip(vjp_y, y))
-            vjp_p = _flatten_convert_none_to_zeros(vjp_p, f_params)
-            if len(f_params) == 0:
-                vjp_p = torch.tensor(0.).to(vjp_y[0])
-            return (*f_eval, *vjp_y, vjp_t, vjp_p)
-
-        T = ans[0].shape[0]
-        need_time = ctx.needs_input_grad[n + 1]
-        if analytic and method == 'NH_verlet' and n == 3:
-            return _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params)
+    def backward(ctx, *cotangents):
+        t, flat_params, *saved = ctx.saved_tensors
+        frames, n = tuple(saved), len(saved)
+        func, solver = ctx.func, ctx.solver
+        wants_time = ctx.needs_input_grad[n + 1]
+        closed_form = (not wants_time) and getattr(func, "supports_rhs_vjp", lambda: False)()
+        if closed_form and solver["method"] == 'NH_verlet' and n == 3:
+            return _analytic_nhc_adjoint(func, t, frames, cotangents, flat_params)
+        system = _BackwardSystem(func, n, closed_form)
         with torch.no_grad():
-            adj_y = tuple(g[-1] for g in grad_output)
-            adj_params = torch.zeros_like(flat_params)
-            adj_time = torch.tensor(0.).to(t)
-            time_vjps = []
-            for i in range(T - 1, 0, -1):
-                ans_i = tuple(a[i] for a in ans)
-                g_i = tuple(g[i] for g in grad_output)
-                if need_time or not hasattr(func, "update_topology"):
-                    f_i = func(t[i], ans_i)                   # sovlers.py:258
-                    dLd_cur_t = sum(torch.dot(a.reshape(-1), b.reshape(-1)).reshape(1) for a, b in zip(f_i, g_i))
+            costate = tuple(c[-1] for c in cotangents)                     # lam(t_last) = dL/dy_last   (:249)
+            theta_bar = torch.zeros_like(flat_params) if flat_params.numel() else torch.tensor(0.).to(costate[0])
+            time_bar = torch.tensor(0.).to(t)
+            per_point = []                                                 # dL/dt_i, last grid point first
+            for i in reversed(range(1, frames[0].shape[0])):
+                y_i = tuple(x[i] for x in frames)
+                if wants_time or not hasattr(func, "update_topology"):
+                    f_i = func(t[i], y_i)                                  # :258
+                    sens = sum(torch.dot(f.reshape(-1), c[i].reshape(-1)).reshape(1) for f, c in zip(f_i, cotangents))
                 else:
-                    # the reference evaluates func here only for dL/dt, which nobody consumes when t
-                    # needs no gradient; keep its side effect (the topology counter / rebuild,
-                    # md.py:200-204) and skip the force evaluation
-                    func.update_topology(ans_i[1])
-                    dLd_cur_t = torch.zeros(1).to(t)
-                adj_time = adj_time - dLd_cur_t
-                time_vjps.append(dLd_cur_t)
-                if adj_params.numel() == 0:
-                    adj_params = torch.tensor(0.).to(adj_y[0])
-                aug_y0 = (*ans_i, *adj_y, adj_time, adj_params)
-                aug_ans = odeint(augmented_dynamics, aug_y0, torch.stack([t[i], t[i - 1]]),
-                                 rtol=rtol, atol=atol, method=method, options=options)
-                adj_y = tuple(a[1] for a in aug_ans[n:2 * n])
-                adj_time = aug_ans[2 * n][1]
-                adj_params = aug_ans[2 * n + 1][1]
-                adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
-                del aug_y0, aug_ans
-            time_vjps.append(adj_time)
-            time_vjps = torch.cat([x.reshape(-1) for x in time_vjps[::-1]])
-            return (*adj_y, None, time_vjps, adj_params, None, None, None, None, None)
+                    # the reference evaluates func here only for dL/dt, which nobody consumes when t needs no
+                    # gradient; keep its side effect (the topology counter / rebuild, md.py:200-204), skip the force
+                    func.update_topology(y_i[1])
+                    sens = torch.zeros(1).to(t)
+                time_bar = time_bar - sens
+                per_point.append(sens)
+                packed = odeint(system, (*y_i, *costate, time_bar, theta_bar), torch.stack([t[i], t[i - 1]]), **solver)
+                costate = tuple(lam[1] + c[i - 1] for lam, c in zip(packed[n:2 * n], cotangents))
+                time_bar, theta_bar = packed[2 * n][1], packed[2 * n + 1][1]
+            per_point.append(time_bar)
+            time_grad = torch.cat([x.reshape(-1) for x in reversed(per_point)])
+        return (*costate, None, time_grad, theta_bar, None, None, None, None, None)
 
 
 def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
@@ -288,19 +282,20 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
             return tuple(res)
         return ops.fused_traj(y0[0], y0[1], pv0, t, flat_params, spec)
 
-    tensor_input = False
-    if torch.is_tensor(y0):
-        class TupleFunc(nn.Module):
-            def __init__(self, base_func):
-                super().__init__()
-                self.base_func = base_func
-
-            def forward(self, t, y):
-                return (self.base_func(t, y[0]),)
-
-        tensor_input = True
-        y0 = (y0,)
-        func = TupleFunc(func)
+    single = torch.is_tensor(y0)
+    if single:
+        func, y0 = _AsTuple(func), (y0,)                   # a bare tensor state travels as a 1-tuple
     flat_params = _flatten(func.parameters())
     ys = OdeintAdjointMethod.apply(*y0, func, t, flat_params, rtol, atol, method, options)
-    return ys[0] if tensor_input else ys
+    return ys[0] if single else ys
+
+
+class _AsTuple(nn.Module):
+    """Adapter for a right-hand side written for a single tensor state."""
+
+    def __init__(self, rhs):
+        super().__init__()
+        self.rhs = rhs
+
+    def forward(self, t, y):
+        return (self.rhs(t, y[0]),)
