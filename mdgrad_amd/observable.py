@@ -10,14 +10,15 @@ from .system import check_system
 
 
 def generate_vol_bins(start, end, nbins, dim):
-    bins = torch.linspace(start, end, nbins + 1)
-    if dim == 3:
-        Vbins = 4 * np.pi / 3 * (bins[1:] ** 3 - bins[:-1] ** 3)
-        V = (4 / 3) * np.pi * (end) ** 3
-    elif dim == 2:
-        Vbins = np.pi * (bins[1:] ** 2 - bins[:-1] ** 2)
-        V = np.pi * (end) ** 2
-    return V, torch.Tensor(Vbins), bins
+    """(volume of the ball of radius `end`, volumes of the nbins shells between the equally spaced edges, the edges):
+    the ideal-gas normalisation of g(r) (torchmd/observable.py:10-21).  Same constants in the same association as
+    the reference, so the float32 results agree to the last bit."""
+    if dim not in (2, 3):
+        raise ValueError("generate_vol_bins: dim must be 2 or 3")
+    edges = torch.linspace(start, end, nbins + 1)
+    shell_coef, ball = (4 * np.pi / 3, (4 / 3) * np.pi * end ** 3) if dim == 3 else (np.pi, np.pi * end ** 2)
+    shells = shell_coef * (edges[1:] ** dim - edges[:-1] ** dim)
+    return ball, torch.Tensor(shells), edges
 
 
 class Observable(torch.nn.Module):
