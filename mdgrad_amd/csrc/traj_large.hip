@@ -4,12 +4,15 @@
 // backward branch :129-164), but the state lives in HBM/L2 and every step is TWO launches
 // enqueued from a C++ host loop (no Python, no host sync):
 //
-//   kick_drift : first RHS (cached force) -> half kick, drift, bath half step
+//   prep       : one 1 024-thread workgroup per replica: first RHS (cached force) -> half kick, drift, bath half
+//                step; sums the per-block partials of the previous force launch; bins the new positions
 //   force_step : neighbour search + force (+HVP) + second half kick + frame store, fused:
-//                one wave per atom scans LDS-staged position tiles with the reference's
+//                one wave per atom walks the 3 x 3 stencil columns of the bin-sorted positions (or, for cells the
+//                binning does not take, scans LDS-staged tiles of all positions) with the reference's
 //                minimum-image test, compacts the accepted neighbours into a per-wave LDS
 //                list (ordered ballot compaction -- the neighbour list never exists in HBM),
 //                then all 64 lanes evaluate the compact list and combine with wave shuffles.
+// The adjoint interval is FOUR launches (prep, force + HVP, prep, force + HVP), NHC or NVE.
 //
 // This reproduces topology_update_freq == 1 (pair set re-derived at every force evaluation).
 // Scalars that couple workgroups (kinetic energy, sum(lambda_v . v), parameter gradients)
@@ -59,13 +62,11 @@ struct LargeArgs {
 };
 
 // ---------------------------------------------------------------------------------------------
-// Binning, two small launches per force evaluation (all replicas at once):
-//   count: thread per atom -> bin, slot inside the bin from a global integer atomic
-//   fill : every workgroup scans its replica's bin counts in LDS (<= 4096 bins), then scatters its atoms'
-//          (x, y, z, index) to start[bin] + slot; it also clears the OTHER count buffer for the next evaluation
+// Binning: ONE workgroup of 1 024 threads per replica (large_prep below) counts its atoms into <= 4 096 bins with
+// LDS integer atomics (slot inside the bin = the atomic's return value), scans the counts in LDS and scatters
+// (x, y, z, index) to start[bin] + slot -- one launch, no global atomics, no counter buffers.
 // The slot order inside a bin depends on the atomic order; the force kernels therefore sort every atom's compacted
 // neighbour buffer by index, which restores the ascending-j order of the all-atom scan (same sums, same bits).
-// src: 0 = running positions A.q, 1 = saved frame A.step of q_t, 2 = the adjoint's midpoint positions A.qm
 constexpr int LG_MAX_CELLS = 4096;
 
 __device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
@@ -73,75 +74,6 @@ __device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
     fr -= floorf(fr);
     const int b = (int)(fr * (float)nb);
     return b >= nb ? nb - 1 : (b < 0 ? 0 : b);
-}
-
-__device__ __forceinline__ const float* bin_source(const LargeArgs& A, int src, int rep) {
-    const int N = A.prm.n_atoms, T = A.prm.n_frames;
-    const size_t so = (size_t)rep * N * 3;
-    return src == 0 ? A.q + so : (src == 1 ? A.q_t + ((size_t)rep * T + A.step) * N * 3 : A.qm + so);
-}
-
-__global__ __launch_bounds__(256) void large_bin_count(const LargeArgs A, const int src, const int which) {
-    const int N = A.prm.n_atoms, rep = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const float* q = bin_source(A, src, rep);
-    const int bx = bin_coord_l(q[3 * i], A.cell.inv[0], A.nb[0]);
-    const int by = bin_coord_l(q[3 * i + 1], A.cell.inv[4], A.nb[1]);
-    const int bz = bin_coord_l(q[3 * i + 2], A.cell.inv[8], A.nb[2]);
-    const int bin = (bx * A.nb[1] + by) * A.nb[2] + bz;
-    int32_t* cnt = A.bcount + ((size_t)which * A.prm.n_rep + rep) * LG_MAX_CELLS;
-    const int slot = atomicAdd(&cnt[bin], 1);
-    A.binslot[(size_t)rep * N + i] = (slot << 12) | bin;
-}
-
-__global__ __launch_bounds__(256) void large_bin_fill(const LargeArgs A, const int src, const int which) {
-    __shared__ int32_t start[LG_MAX_CELLS + 1];
-    __shared__ int32_t tsum[256];
-    const int N = A.prm.n_atoms, rep = blockIdx.y, nc = A.ncell;
-    const int32_t* cnt = A.bcount + ((size_t)which * A.prm.n_rep + rep) * LG_MAX_CELLS;
-    // exclusive scan of the replica's bin counts: 16 consecutive bins per thread + scan of the thread totals
-    int loc[16], tot = 0;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int c = threadIdx.x * 16 + u;
-        loc[u] = c < nc ? cnt[c] : 0;
-        tot += loc[u];
-    }
-    tsum[threadIdx.x] = tot;
-    __syncthreads();
-    if (threadIdx.x < 64) {                                     // wave 0: scan of 256 totals, 4 per lane
-        int v[4], s = 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { v[u] = tsum[threadIdx.x * 4 + u]; s += v[u]; }
-        int x = s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)threadIdx.x >= o) x += y; }
-        int run = x - s;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { tsum[threadIdx.x * 4 + u] = run; run += v[u]; }
-    }
-    __syncthreads();
-    int run = tsum[threadIdx.x];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int c = threadIdx.x * 16 + u;
-        if (c <= nc) start[c] = run;
-        run += loc[u];
-    }
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
-        for (int c = threadIdx.x; c <= nc; c += blockDim.x) bs[c] = start[c];
-        int32_t* other = A.bcount + ((size_t)(which ^ 1) * A.prm.n_rep + rep) * LG_MAX_CELLS;
-        for (int c = threadIdx.x; c < nc; c += blockDim.x) other[c] = 0;
-    }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    const float* q = bin_source(A, src, rep);
-    const int bsl = A.binslot[(size_t)rep * N + i];
-    A.spos[(size_t)rep * N + start[bsl & 4095] + (bsl >> 12)] =
-        make_float4(q[3 * i], q[3 * i + 1], q[3 * i + 2], __int_as_float(i));
 }
 
 __device__ __forceinline__ float bath_rhs_l(const MdgTrajParams& p, const float* Q, const float* pv, float ke, int k) {
@@ -165,6 +97,258 @@ __device__ __forceinline__ float reduce_partials(const float* __restrict__ part,
     float s = 0.f;
     for (int b = threadIdx.x; b < n; b += blockDim.x) s += part[(size_t)b * stride + col];
     return block_sum(s, red);
+}
+
+// ------------------------------------------------------------------------------------ per-replica preparation
+// Everything between two force launches runs in ONE launch of one 1 024-thread workgroup per replica: the
+// elementwise update of the integrator / adjoint (which ends in the positions of the next force evaluation), the
+// cross-workgroup scalars of the previous force launch (kinetic energy, sum lam.v, parameter partials: summed here in
+// a fixed order), the thermostat chain, and the binning of those positions for the cell-binned scan.
+//   PHASE 0  forward, before the initial force: bin q0
+//   PHASE 1  forward step k: first RHS with the cached force -> half kick, drift, bath half step
+//            (sovlers.py:111-118 / :25-33); bin the new positions
+//   PHASE 2  adjoint, before the first evaluation of interval i = A.step: finish interval i + 1 (full adjoint update
+//            + dL/dy_i, sovlers.py:156-160, :286 / :100) unless i is the last frame; bin frame i
+//   PHASE 3  adjoint, before the midpoint evaluation: midpoint state and half-step adjoint (sovlers.py:132-145 /
+//            :42-82); bin the midpoint positions
+//   PHASE 4  adjoint, after the last interval: finish interval 1 (A.step = 0), no binning
+constexpr int LG_PREP = 1024;
+constexpr int LG_PREP_ATOMS = 16;            // atoms per thread: N <= 16 384
+
+// NA = atoms per thread (compile-time: their positions stay in registers between the update and the binning)
+template <int PHASE, int NA>
+__global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
+    __shared__ int32_t start[LG_MAX_CELLS + 1];
+    __shared__ int32_t tsum[LG_PREP];
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.x, nc = A.ncell;
+    const bool nhc = A.prm.ensemble == 0;
+    const size_t so = (size_t)rep * N * 3;
+    if (threadIdx.x < MDG_MAX_CHAINS) {
+        float qv = 0.f;
+#pragma unroll
+        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+        Qs[threadIdx.x] = qv;
+    }
+    float px[NA], py[NA], pz[NA];       // positions of the next force evaluation
+
+    if constexpr (PHASE == 0) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int a = threadIdx.x + u * LG_PREP;
+            if (a < N) { px[u] = A.q[so + 3 * a]; py[u] = A.q[so + 3 * a + 1]; pz[u] = A.q[so + 3 * a + 2]; }
+        }
+    }
+    if constexpr (PHASE == 1) {
+        const int k = A.step;
+        const float dt = A.t[k + 1] - A.t[k];
+        float* pv = A.pv + rep * MDG_MAX_CHAINS;
+        if (nhc) {
+            const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
+            if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const float h = 0.5f * bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x) * dt;
+                A.ph[rep * MDG_MAX_CHAINS + threadIdx.x] = h;
+                A.pvh[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + h;
+            }
+        }
+        const float pv0 = nhc ? pv[0] : 0.f;
+        float part = 0.f;
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int a = threadIdx.x + u * LG_PREP;
+            if (a < N) {
+                const float m = A.mass[a];
+                float qn[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const size_t e = so + 3 * a + c;
+                    const float ve = A.v[e], p = ve * m;
+                    const float acc = nhc ? (A.f[e] - pv0 * p / A.prm.Q[0]) / m : A.f[e];     // (NVE: md.py:145-148)
+                    const float h = 0.5f * acc * dt;
+                    A.vh[e] = h;
+                    qn[c] = A.q[e] + (ve + h) * dt;
+                    A.q[e] = qn[c];
+                    const float ph2 = (ve + h) * m;
+                    part += ph2 * ph2 / m;
+                }
+                px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
+            }
+        }
+        part = block_sum(part, red);
+        if (threadIdx.x == 0) A.partB[rep] = part;                     // (nbE = 1: KE(v + vh) for the force launch)
+    }
+    if constexpr (PHASE == 2 || PHASE == 4) {
+        const int i_fr = A.step + 1;                                   // the interval being finished
+        if (i_fr <= T - 1) {
+            const size_t go = ((size_t)rep * T + i_fr - 1) * N * 3;
+            const float h = A.t[i_fr] - A.t[i_fr - 1];
+            if (nhc) {
+                const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
+                const float* lph = A.lph + rep * MDG_MAX_CHAINS;
+                float* lp = A.lp + rep * MDG_MAX_CHAINS;
+                const float pvm0 = pvm[0], lpm0 = lph[0];
+                const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+                const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+                const int KT = A.terms.n_theta_total;
+#pragma unroll
+                for (int m = 0; m < MDG_MAX_TERMS; ++m)
+#pragma unroll
+                    for (int p = 0; p < MDG_MAX_THETA; ++p)
+                        if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
+                            const float s_ = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
+                            if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += s_ * h;   // :160
+                        }
+                if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
+                __syncthreads();
+                if (threadIdx.x < C) {
+                    const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
+                    float nlp = lp[threadIdx.x] + gp * h;                               // :158
+                    if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
+                    lp[threadIdx.x] = nlp;
+                }
+                for (int e = threadIdx.x; e < 3 * N; e += LG_PREP) {
+                    const float m = A.mass[e / 3];
+                    const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
+                    float nlv = A.lv[so + e] + Gv * h;                                  // :156
+                    float nlq = A.lq[so + e] + A.dq[so + e] * h;                        // :157
+                    if (A.g_v) nlv += A.g_v[go + e];                                    // :286
+                    if (A.g_q) nlq += A.g_q[go + e];
+                    A.lv[so + e] = nlv; A.lq[so + e] = nlq;
+                }
+            } else {
+                // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
+                for (int e = threadIdx.x; e < 3 * N; e += LG_PREP) {
+                    float nlv = A.lvh[so + e];
+                    float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
+                    if (A.g_v) nlv += A.g_v[go + e];
+                    if (A.g_q) nlq += A.g_q[go + e];
+                    A.lv[so + e] = nlv; A.lq[so + e] = nlq;
+                }
+            }
+        }
+        if constexpr (PHASE == 2) {
+            const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int a = threadIdx.x + u * LG_PREP;
+                if (a < N) { px[u] = qf[3 * a]; py[u] = qf[3 * a + 1]; pz[u] = qf[3 * a + 2]; }
+            }
+        }
+    }
+    if constexpr (PHASE == 3) {
+        const int i_fr = A.step;
+        const size_t fo = ((size_t)rep * T + i_fr) * N * 3;
+        const float h = A.t[i_fr] - A.t[i_fr - 1];
+        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+        float pv0 = 0.f, lp0 = 0.f;
+        if (nhc) {
+            const float* pvf = A.pv_t + ((size_t)rep * T + i_fr) * C;
+            float* lp = A.lp + rep * MDG_MAX_CHAINS;
+            const float ke = 0.5f * reduce_partials(part, A.nbF, LG_NV, LG_KMAX, red);
+            const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+            if (threadIdx.x < C) { pvs[threadIdx.x] = pvf[threadIdx.x]; lps[threadIdx.x] = lp[threadIdx.x]; }
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const float pb = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+                const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
+                A.pvm[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + 0.5f * (-pb) * h;      // :135
+                A.lph[rep * MDG_MAX_CHAINS + threadIdx.x] = lps[threadIdx.x] + gp * 0.5f * h;         // :143
+            }
+            pv0 = pvs[0]; lp0 = lps[0];
+        } else {
+            // the parameter term of an NVE interval comes from the first evaluation (sovlers.py:82,101)
+            const int KT = A.terms.n_theta_total;
+#pragma unroll
+            for (int m = 0; m < MDG_MAX_TERMS; ++m)
+#pragma unroll
+                for (int p = 0; p < MDG_MAX_THETA; ++p)
+                    if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
+                        const float s_ = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
+                        if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (s_ * 0.5f * h) * 2.f;
+                    }
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int a = threadIdx.x + u * LG_PREP;
+            if (a < N) {
+                const float m = A.mass[a];
+                float qn[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const size_t e = so + 3 * a + c, ef = fo + 3 * a + c;
+                    const float ve = A.v_t[ef];
+                    if (nhc) {
+                        const float p = ve * m;
+                        const float acc = (A.f[e] - pv0 * p / A.prm.Q[0]) / m;
+                        const float Gv = -(pv0 / A.prm.Q[0]) * A.lv[e] + A.lq[e] + 2.f * m * ve * lp0;
+                        const float vhalf = 0.5f * (-acc) * h;                           // :132
+                        qn[c] = A.q_t[ef] + (ve + vhalf) * h;                            // :138 (forward-time sign)
+                        A.vm[e] = ve + vhalf;
+                        A.lvh[e] = A.lv[e] + Gv * 0.5f * h;                              // :141
+                        A.lqh[e] = A.lq[e] + A.dq[e] * 0.5f * h;                         // :142
+                    } else {
+                        const float vhalf = ve - 0.5f * (-A.f[e]) * h;                   // :49-50
+                        qn[c] = A.q_t[ef] - vhalf * h;                                   // :51-52
+                        A.vm[e] = vhalf;
+                        const float dx = A.dq[e] * h * 0.5f;                             // :71
+                        A.lvh[e] = A.lv[e] + (A.lq[e] + dx) * h;                         // :72
+                        A.lqh[e] = A.lq[e] + dx;
+                    }
+                    A.qm[e] = qn[c];
+                }
+                px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
+            }
+        }
+    }
+    if (PHASE == 4 || nc == 0) return;                      // (all-atom scan: nothing to bin)
+
+    // ---- binning of (px, py, pz)
+    __syncthreads();
+    for (int c = threadIdx.x; c <= LG_MAX_CELLS; c += LG_PREP) start[c] = 0;
+    __syncthreads();
+    int bsl[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int a = threadIdx.x + u * LG_PREP;
+        if (a < N) {
+            const int bx = bin_coord_l(px[u], A.cell.inv[0], A.nb[0]);
+            const int by = bin_coord_l(py[u], A.cell.inv[4], A.nb[1]);
+            const int bz = bin_coord_l(pz[u], A.cell.inv[8], A.nb[2]);
+            const int bin = (bx * A.nb[1] + by) * A.nb[2] + bz;
+            bsl[u] = (atomicAdd(&start[bin], 1) << 12) | bin;
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bin counts: 4 consecutive bins per thread + scan of the thread totals (16 waves)
+    int loc[4], tot = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { loc[u] = start[threadIdx.x * 4 + u]; tot += loc[u]; }
+    {
+        int x = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if ((int)(threadIdx.x & 63) >= o) x += y; }
+        tsum[threadIdx.x] = x;                                           // inclusive within the wave
+    }
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += tsum[w * 64 + 63];
+    int run = base + tsum[threadIdx.x] - tot;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { start[threadIdx.x * 4 + u] = run; run += loc[u]; }
+    if (threadIdx.x == LG_PREP - 1) start[LG_MAX_CELLS] = run;
+    __syncthreads();
+    int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
+    for (int c = threadIdx.x; c <= nc; c += LG_PREP) bs[c] = start[c];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int a = threadIdx.x + u * LG_PREP;
+        if (a < N)
+            A.spos[(size_t)rep * N + start[bsl[u] & 4095] + (bsl[u] >> 12)] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -454,50 +638,6 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = kepart;
 }
 
-// first RHS of step k (cached force): half kick + drift + bath half step
-__global__ __launch_bounds__(256) void large_kick_drift(const LargeArgs A) {
-    __shared__ float red[32];
-    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
-    const size_t so = (size_t)rep * N * 3;
-    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; const float* f = A.f + so;
-    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
-    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
-    const float dt = A.t[k + 1] - A.t[k];
-    if (threadIdx.x < MDG_MAX_CHAINS) {
-        float qv = 0.f;
-#pragma unroll
-        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
-        Qs[threadIdx.x] = qv;
-    }
-    const bool nhc = A.prm.ensemble == 0;
-    if (nhc && blockIdx.x == 0) {
-        const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
-        if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x < C) {
-            const float h = 0.5f * bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x) * dt;
-            ph[threadIdx.x] = h;
-            pvh[threadIdx.x] = pvs[threadIdx.x] + h;
-        }
-    }
-    const float pv0 = nhc ? pv[0] : 0.f;
-    float part = 0.f;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 3 * N) {
-        const float m = A.mass[e / 3];
-        const float p = v[e] * m;
-        const float a = nhc ? (f[e] - pv0 * p / A.prm.Q[0]) / m : f[e];
-        const float h = 0.5f * a * dt;
-        vh[e] = h;
-        q[e] = q[e] + (v[e] + h) * dt;
-        const float ph2 = (v[e] + h) * m;
-        part = ph2 * ph2 / m;
-    }
-    part = block_sum(part, red);
-    if (threadIdx.x == 0) A.partB[(size_t)rep * A.nbE + blockIdx.x] = part;
-}
-
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
 template <bool DIAG, int KIND>
@@ -545,137 +685,6 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
     }
 }
 
-// after the first evaluation of interval i: midpoint state and half-step adjoint (sovlers.py:132-145)
-__global__ __launch_bounds__(256) void large_adj_mid(const LargeArgs A) {
-    __shared__ float red[32];
-    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, i_fr = A.step;
-    const size_t so = (size_t)rep * N * 3, fo = ((size_t)rep * T + i_fr) * N * 3;
-    const float h = A.t[i_fr] - A.t[i_fr - 1];
-    if (threadIdx.x < MDG_MAX_CHAINS) {
-        float qv = 0.f;
-#pragma unroll
-        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
-        Qs[threadIdx.x] = qv;
-    }
-    if (A.prm.ensemble != 0) {
-        // verlet_update backward branch, first half (sovlers.py:42-82): the parameter term of the interval comes
-        // from this first evaluation
-        if (blockIdx.x == 0) {
-            const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
-            const int KT = A.terms.n_theta_total;
-#pragma unroll
-            for (int m = 0; m < MDG_MAX_TERMS; ++m)
-#pragma unroll
-                for (int p = 0; p < MDG_MAX_THETA; ++p)
-                    if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
-                        const float s = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
-                        if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (s * 0.5f * h) * 2.f;   // :82,101
-                    }
-        }
-        const int e = blockIdx.x * blockDim.x + threadIdx.x;
-        if (e < 3 * N) {
-            const float ve = A.v_t[fo + e];
-            const float vhalf = ve - 0.5f * (-A.f[so + e]) * h;                    // :49-50
-            A.qm[so + e] = A.q_t[fo + e] - vhalf * h;                              // :51-52
-            A.vm[so + e] = vhalf;
-            const float dx = A.dq[so + e] * h * 0.5f;                              // :71
-            A.lvh[so + e] = A.lv[so + e] + (A.lq[so + e] + dx) * h;                // :72
-            A.lqh[so + e] = A.lq[so + e] + dx;
-        }
-        return;
-    }
-    const float* pvf = A.pv_t + ((size_t)rep * T + i_fr) * C;
-    float* lp = A.lp + rep * MDG_MAX_CHAINS;
-    if (blockIdx.x == 0) {
-        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
-        const float ke = 0.5f * reduce_partials(part, A.nbF, LG_NV, LG_KMAX, red);
-        const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
-        if (threadIdx.x < C) { pvs[threadIdx.x] = pvf[threadIdx.x]; lps[threadIdx.x] = lp[threadIdx.x]; }
-        __syncthreads();
-        if (threadIdx.x < C) {
-            const float pb = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
-            const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
-            A.pvm[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + 0.5f * (-pb) * h;      // :135
-            A.lph[rep * MDG_MAX_CHAINS + threadIdx.x] = lps[threadIdx.x] + gp * 0.5f * h;         // :143
-        }
-    }
-    const float pv0 = pvf[0], lp0 = lp[0];
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 3 * N) {
-        const float m = A.mass[e / 3], ve = A.v_t[fo + e], p = ve * m;
-        const float a = (A.f[so + e] - pv0 * p / A.prm.Q[0]) / m;
-        const float Gv = -(pv0 / A.prm.Q[0]) * A.lv[so + e] + A.lq[so + e] + 2.f * m * ve * lp0;
-        const float vhalf = 0.5f * (-a) * h;                                   // :132
-        A.qm[so + e] = A.q_t[fo + e] + (ve + vhalf) * h;                       // :138 (forward-time sign)
-        A.vm[so + e] = ve + vhalf;
-        A.lvh[so + e] = A.lv[so + e] + Gv * 0.5f * h;                          // :141
-        A.lqh[so + e] = A.lq[so + e] + A.dq[so + e] * 0.5f * h;                // :142
-    }
-}
-
-// after the midpoint evaluation: full adjoint update + dL/dy_{i-1}  (sovlers.py:156-160, :286)
-__global__ __launch_bounds__(256) void large_adj_end(const LargeArgs A) {
-    __shared__ float red[32];
-    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, i_fr = A.step;
-    const size_t so = (size_t)rep * N * 3, go = ((size_t)rep * T + i_fr - 1) * N * 3;
-    const float h = A.t[i_fr] - A.t[i_fr - 1];
-    if (threadIdx.x < MDG_MAX_CHAINS) {
-        float qv = 0.f;
-#pragma unroll
-        for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
-        Qs[threadIdx.x] = qv;
-    }
-    if (A.prm.ensemble != 0) {
-        // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
-        const int e = blockIdx.x * blockDim.x + threadIdx.x;
-        if (e < 3 * N) {
-            float nlv = A.lvh[so + e];
-            float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
-            if (A.g_v) nlv += A.g_v[go + e];
-            if (A.g_q) nlq += A.g_q[go + e];
-            A.lv[so + e] = nlv; A.lq[so + e] = nlq;
-        }
-        return;
-    }
-    const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
-    const float* lph = A.lph + rep * MDG_MAX_CHAINS;
-    float* lp = A.lp + rep * MDG_MAX_CHAINS;
-    const float pvm0 = pvm[0], lpm0 = lph[0];
-    if (blockIdx.x == 0) {
-        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
-        const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
-        const int KT = A.terms.n_theta_total;
-#pragma unroll
-        for (int m = 0; m < MDG_MAX_TERMS; ++m)
-#pragma unroll
-            for (int p = 0; p < MDG_MAX_THETA; ++p)
-                if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
-                    const float s = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
-                    if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += s * h;   // :160
-                }
-        if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
-        __syncthreads();
-        if (threadIdx.x < C) {
-            const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
-            float nlp = lp[threadIdx.x] + gp * h;                               // :158
-            if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
-            lp[threadIdx.x] = nlp;
-        }
-    }
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e < 3 * N) {
-        const float m = A.mass[e / 3];
-        const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
-        float nlv = A.lv[so + e] + Gv * h;                                      // :156
-        float nlq = A.lq[so + e] + A.dq[so + e] * h;                            // :157
-        if (A.g_v) nlv += A.g_v[go + e];                                        // :286
-        if (A.g_q) nlq += A.g_q[go + e];
-        A.lv[so + e] = nlv; A.lq[so + e] = nlq;
-    }
-}
-
 // fixed point -> float table gradient
 __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t* __restrict__ glo, size_t n, float scale,
                                  float* __restrict__ out) {
@@ -714,6 +723,7 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
 int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
     MDG_CHECK_ARG(p && cell && terms, "traj_large: null descriptor");
     MDG_CHECK_ARG(p->n_rep > 0 && p->n_atoms > 1 && p->n_frames >= 1, "traj_large: bad sizes");
+    MDG_CHECK_ARG(p->n_atoms <= LG_PREP * LG_PREP_ATOMS, "traj_large: at most %d atoms", LG_PREP * LG_PREP_ATOMS);
     MDG_CHECK_ARG(p->ensemble == 0 || p->ensemble == 1, "traj_large: ensemble must be 0 (NHC) or 1 (NVE)");
     MDG_CHECK_ARG(p->ensemble == 1 || (p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS),
                   "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
@@ -736,9 +746,15 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total).total;
 }
 
+#define LG_PREP_LAUNCH(PH_)                                                                          \
+    do {                                                                                             \
+        if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(R), dim3(LG_PREP), 0, st, a); \
+        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(R), dim3(LG_PREP), 0, st, a);  \
+    } while (0)
+
 #define LG_SETUP()                                                                                   \
     const int R = prm->n_rep, N = prm->n_atoms;                                                      \
-    const int nbE = (3 * N + 255) / 256;                                                             \
+    const int nbE = 1;              /* the element-wise work of a replica runs in one workgroup (large_prep) */ \
     const WsLayout L = ws_layout(R, N, (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL, terms->n_theta_total); \
     LargeArgs a{};                                                                                   \
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;   \
@@ -758,7 +774,6 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     a.bcount = reinterpret_cast<int32_t*>(ws + L.bcount);                                            \
     a.binslot = reinterpret_cast<int32_t*>(ws + L.binslot);                                          \
     a.ncell = 0;                                                                                     \
-    int bin_phase = 0;                                                                               \
     if (diag) {                                                                                      \
         float rcmax = 0.f;                                                                           \
         for (int m = 0; m < terms->n_terms; ++m) rcmax = terms->t[m].cutoff > rcmax ? terms->t[m].cutoff : rcmax; \
@@ -767,10 +782,8 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
         for (int d = 0; d < 3 && ok; ++d) { nbx[d] = (int)floorf(cell->h[4 * d] / rcmax); ok = nbx[d] >= 3; } \
         if (ok && (long long)nbx[0] * nbx[1] * nbx[2] <= LG_MAX_CELLS) {                             \
             a.nb[0] = nbx[0]; a.nb[1] = nbx[1]; a.nb[2] = nbx[2]; a.ncell = nbx[0] * nbx[1] * nbx[2]; \
-            MDG_HIP(hipMemsetAsync(a.bcount, 0, sizeof(int32_t) * (size_t)2 * R * LG_MAX_CELLS, st)); \
         }                                                                                            \
     }                                                                                                \
-    const dim3 gB((N + 255) / 256, R);                                                               \
     const int wpb = a.ncell ? LG_WAVES_CELL : LG_WAVES;                                              \
     const int nbF = (N + wpb - 1) / wpb;                                                             \
     a.nbF = nbF;                                                                                     \
@@ -795,23 +808,19 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     if (prm->ensemble == 0)
         MDG_HIP(hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
                                  hipMemcpyDeviceToDevice, st));
-    dim3 gF(nbF, R), gE(nbE, R);
+    dim3 gF(nbF, R);
     a.step = 0;
 #define LG_FORCE_STEP(MODE_)                                                                                    \
     do {                                                                                                        \
-        if (a.ncell) {                                                                                          \
-            hipLaunchKernelGGL(large_bin_count, gB, dim3(256), 0, st, a, 0, bin_phase);                         \
-            hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, 0, bin_phase);                          \
-            bin_phase ^= 1;                                                                                     \
-        }                                                                                                       \
         if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a); \
         else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);    \
         else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);            \
     } while (0)
+    if (a.ncell) LG_PREP_LAUNCH(0);
     LG_FORCE_STEP(0);
     for (int k = 0; k + 1 < T; ++k) {
         a.step = k;
-        hipLaunchKernelGGL(large_kick_drift, gE, dim3(256), 0, st, a);
+        LG_PREP_LAUNCH(1);                                                          // kick + drift + bath half step + binning
         LG_FORCE_STEP(1);
     }
 #undef LG_FORCE_STEP
@@ -851,26 +860,23 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         MDG_HIP(hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st));
         MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
     }
-    dim3 gF(nbF, R), gE(nbE, R);
+    dim3 gF(nbF, R);
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
-        if (a.ncell) {                                                                                              \
-            hipLaunchKernelGGL(large_bin_count, gB, dim3(256), 0, st, a, (SECOND_) ? 2 : 1, bin_phase);             \
-            hipLaunchKernelGGL(large_bin_fill, gB, dim3(256), 0, st, a, (SECOND_) ? 2 : 1, bin_phase);              \
-            bin_phase ^= 1;                                                                                         \
-        }                                                                                                           \
         if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);   \
         else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);       \
         else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);               \
     } while (0)
+        LG_PREP_LAUNCH(2);                                                          // finish interval i + 1, bin frame i
         LG_ADJ_FORCE(0);
-        hipLaunchKernelGGL(large_adj_mid, gE, dim3(256), 0, st, a);
+        LG_PREP_LAUNCH(3);                                                          // midpoint state, bin it
         LG_ADJ_FORCE(1);
-        hipLaunchKernelGGL(large_adj_end, gE, dim3(256), 0, st, a);
 #undef LG_ADJ_FORCE
     }
+    a.step = 0;
+    LG_PREP_LAUNCH(4);                                                              // finish interval 1
     MDG_HIP(hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     MDG_HIP(hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     if (prm->ensemble == 0)

@@ -91,7 +91,7 @@ class rdf(Observable):
             if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
                 xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))
             count = ops.RdfRawFn.apply(xyz, self.offsets, self.coeff, self.cutoff_boundary,
-                                       self._cell_struct, self._mask, self.spacing)
+                                       self._cell_struct, self._mask, self.spacing, float(self.r_axis[-1]))
         norm = count.sum()
         count = count / norm
         rdf = count / (self.vol_bins / self.V)

@@ -573,7 +573,7 @@ class RdfRawFn(torch.autograd.Function):
     (the GaussianSmearing(...).sum(0) of torchmd/observable.py:70)."""
 
     @staticmethod
-    def forward(ctx, xyz, mu, coeff, cutoff, cell_struct, mask, spacing=0.0):
+    def forward(ctx, xyz, mu, coeff, cutoff, cell_struct, mask, spacing=0.0, mu_last=None):
         lib = _lib.load()
         require_gpu(xyz, "xyz")
         x = xyz.detach().contiguous()
@@ -582,12 +582,19 @@ class RdfRawFn(torch.autograd.Function):
         dev = x.device
         raw = torch.empty(B, device=dev)
         ctx.ell = None
+        list_cut = float(cutoff)
+        if mu_last is not None and coeff < 0:
+            # the fine grid of the list kernels ends mu_last + 5.3 / s beyond the last centre (a Gaussian there is
+            # below 2^-28 of its peak): pairs farther out are rejected by the histogram anyway, so the neighbour list
+            # need not hold them (the reference's cutoff_boundary = end + 0.5 reaches ~ 20 widths past the last centre)
+            list_cut = min(list_cut, float(mu_last) + 1.02 * 5.3 / math.sqrt(-coeff * 1.4426950408889634) + 1e-6)
         if (N >= RDF_LIST_ATOMS and mask is None and spacing > 0 and cell_struct.diag
-                and _use_cell_list(N, cell_struct, float(cutoff))
+                and _use_cell_list(N, cell_struct, list_cut)
                 and lib.mdg_rdf_ell_supported(float(spacing), float(coeff), B)):
             # large systems: pair search through the cell list (frames = groups of one list), every listed pair
             # counted on the fine integer grid; the gradient is a tabulated pair force over the same list
             flat = x3.reshape(F * N, 3)
+            cutoff = list_cut
             ell = build_ell(flat, cell_struct, cutoff, group=N)
             muc = mu.detach().to(torch.float32).contiguous()
             check(lib.mdg_rdf_fwd_ell(ptr(flat), F * N, C.byref(cell_struct), ptr(ell.col), ptr(ell.shift), ptr(ell.cnt),
@@ -616,13 +623,13 @@ class RdfRawFn(torch.autograd.Function):
             table, u0, du = _rdf_pair_table(g_raw.detach().to(torch.float32), muc, coeff, cutoff, nodes)
             term = make_term(dict(kind=MDG_PAIR_TABLE, p=nodes, a=u0, phi=du, c=1.0), cutoff, 0, 2 * nodes, None)
             o = pair_eval(ctx.ell, x3, term, table, energy=False, grad=True)
-            return o["grad"].reshape(shape), None, None, None, None, None, None
+            return o["grad"].reshape(shape), None, None, None, None, None, None, None
         F, N, B = x3.shape[0], x3.shape[1], muc.shape[0]
         gx = torch.empty_like(x3)
         gr = g_raw.detach().to(torch.float32).contiguous()
         check(lib.mdg_rdf_bwd_uniform(ptr(x3), F, N, C.byref(cell_struct), cutoff, ptr(mask), ptr(muc), spacing,
                                       coeff, B, ptr(gr), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd")
-        return gx.reshape(shape), None, None, None, None, None, None
+        return gx.reshape(shape), None, None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- velocity observables
