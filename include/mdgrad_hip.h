@@ -227,11 +227,17 @@ int mdg_traj_adj_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cel
  * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain or NVE): same contract as
  * mdg_traj_fwd_small / mdg_traj_adj_small, two launches per step (forward) / four per adjoint
  * interval, enqueued by a host loop; the neighbour search is fused into the force kernel
- * (per-wave LDS list).  ws: f32 workspace of mdg_traj_large_workspace() floats, shared by the
- * forward and the adjoint call of one trajectory; flags: int32[2] = {neighbour buffer
- * overflow (needed entries), non-finite state}, zeroed by the caller.
+ * (per-wave LDS list; the forward pass keeps every frame's candidate indices -- searched with a 4 % skin -- in the
+ * workspace, and the adjoint's two evaluations per interval re-test those candidates instead of searching again).
+ * (MdgTrajParams.block = -1 switches the reuse off: a fresh search at every evaluation; the adjoint run with the
+ * lists reports through flags[5] when that is required.)
+ * ws: f32 workspace of mdg_traj_large_workspace() floats, shared by the
+ * forward and the adjoint call of one trajectory; flags: int32[8], zeroed by the caller = {neighbour buffer overflow
+ * (needed entries), non-finite state, table-gradient range, pair below the table, [4] forward: a stored candidate row
+ * overflowed -- call the adjoint with block = -1, [5] adjoint: the stored candidates did not cover an evaluation (row
+ * overflow, or a midpoint farther than skin/2 from its frame) -- repeat the adjoint with block = -1}.
  */
-int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_total);
+int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames, int n_theta_total);
 int mdg_traj_fwd_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
                        const MdgTerms* terms /*host*/, const float* theta,
                        const float* mass, const float* t_grid,

@@ -30,6 +30,9 @@ constexpr int LG_WAVES_CELL = 4;             // ... cell-binned scan: small work
 constexpr int LG_BLOCK = LG_WAVES * 64;
 constexpr int LG_TILE = 2048;               // positions staged in LDS per pass
 constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
+constexpr int LG_LIST = 96;                  // stored neighbour indices per atom and frame (forward -> adjoint reuse)
+constexpr float LG_SKIN = 0.04f;             // skin of the stored lists, as a fraction of the largest cutoff
+constexpr long long LG_LIST_MAX_WORDS = 1ll << 31;   // at most 8 GiB of stored lists; beyond that the adjoint searches again
 constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
 constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
 
@@ -59,6 +62,16 @@ struct LargeArgs {
     int32_t* bcount;                         // [2][R][LG_MAX_CELLS] ping-pong bin counters
     int32_t* binslot;                        // [R][N] (slot << 12) | bin
     int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
+    // neighbour lists of the forward pass, kept for the adjoint (nullptr: not kept).  The forward force evaluation at
+    // frame k searches with cutoff (1 + LG_SKIN) rc and stores the ascending indices; the adjoint's two evaluations
+    // of interval k gather those candidates and re-apply the exact cutoff test -- the same pair set as a fresh
+    // search as long as no atom has moved more than skin/2 since frame k (the midpoint state: checked on the device
+    // by large_prep<3>; flags[5] then asks the caller for an adjoint with fresh searches) -- instead of two more
+    // searches + sorts.
+    int32_t* nl_idx;                         // [R][T][N][LG_LIST]
+    int32_t* nl_cnt;                         // [R][T][N]
+    int32_t* nl_bad;                         // [R][T]  an atom of this frame had more than LG_LIST candidates
+    float skin;                              // absolute skin (0: lists not kept)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -209,7 +222,10 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                     if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
                     lp[threadIdx.x] = nlp;
                 }
-                for (int e = threadIdx.x; e < 3 * N; e += LG_PREP) {
+#pragma unroll
+                for (int u = 0; u < 3 * NA; ++u) {
+                    const int e = threadIdx.x + u * LG_PREP;
+                    if (e >= 3 * N) break;
                     const float m = A.mass[e / 3];
                     const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
                     float nlv = A.lv[so + e] + Gv * h;                                  // :156
@@ -220,7 +236,10 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 }
             } else {
                 // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
-                for (int e = threadIdx.x; e < 3 * N; e += LG_PREP) {
+#pragma unroll
+                for (int u = 0; u < 3 * NA; ++u) {
+                    const int e = threadIdx.x + u * LG_PREP;
+                    if (e >= 3 * N) break;
                     float nlv = A.lvh[so + e];
                     float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
                     if (A.g_v) nlv += A.g_v[go + e];
@@ -230,6 +249,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             }
         }
         if constexpr (PHASE == 2) {
+            if (A.nl_idx) return;                                       // the stored candidates of frame i serve
             const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
@@ -270,12 +290,13 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                         if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (s_ * 0.5f * h) * 2.f;
                     }
         }
+        float far2 = 0.f;                                           // largest |q_mid - q_frame|^2 of this thread's atoms
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int a = threadIdx.x + u * LG_PREP;
             if (a < N) {
                 const float m = A.mass[a];
-                float qn[3];
+                float qn[3], mv2 = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const size_t e = so + 3 * a + c, ef = fo + 3 * a + c;
@@ -298,9 +319,19 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                         A.lqh[e] = A.lq[e] + dx;
                     }
                     A.qm[e] = qn[c];
+                    const float mv = qn[c] - A.q_t[ef];
+                    mv2 = fmaf(mv, mv, mv2);
                 }
+                far2 = fmaxf(far2, mv2);
                 px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
             }
+        }
+        if (A.nl_idx) {
+            // the stored candidates of frame i_fr (searched with rc + skin) stay a superset of the midpoint's pair set
+            // while no atom has moved more than skin / 2; otherwise the midpoint evaluation searches again
+            const int moved = __syncthreads_or(!(far2 <= 0.25f * A.skin * A.skin));
+            if (moved && threadIdx.x == 0) A.flags[5] = 1;              // the caller repeats the adjoint with searches
+            return;
         }
     }
     if (PHASE == 4 || nc == 0) return;                      // (all-atom scan: nothing to bin)
@@ -351,15 +382,105 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     }
 }
 
+// Every pair term of one accepted candidate: F_i += phi'/r D; (LEVEL 2) -(H w) and the parameter vjp with
+// w_ij = w_i - w_j  (w = lam_v / m for NHC, lam_v for NVE).
+template <int LEVEL, int KIND>
+__device__ __forceinline__ void pair_terms(const LargeArgs& A, const TermConst (&tc)[MDG_MAX_TERMS], int nt, int N, int i, int j,
+                                           float dx, float dy, float dz, float d2, float wxi, float wyi, float wzi, float wjx,
+                                           float wjy, float wjz, float gw, int rep, float& fx, float& fy, float& fz,
+                                           float& gx, float& gy, float& gz, float (&th)[LG_KMAX]) {
+    constexpr int NTC = KIND >= 0 ? 1 : MDG_MAX_TERMS;          // (the single-term specialisations carry one term)
+#pragma unroll
+    for (int m = 0; m < NTC; ++m) {
+        if (m >= nt) break;
+        if (!(d2 < tc[m].rc2)) continue;
+        const uint8_t* mk = KIND >= 0 ? nullptr : A.terms.t[m].mask;
+        if (mk && !mk[(size_t)i * N + j]) continue;
+        PairOut o;
+        float r, ir;
+        pair_eval<LEVEL, KIND>(tc[m], d2, r, ir, o);
+        if (tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
+        const float c1 = o.du * ir;
+        fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+        if (LEVEL >= 2) {
+            const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+            const float ax = wxi - wjx, ay = wyi - wjy, az = wzi - wjz;
+            const float a = rx * ax + ry * ay + rz * az;
+            const float c2 = o.d2u * a - c1 * a;
+            gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
+            if (tc[m].kind == MDG_PAIR_TABLE) {
+                // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (two int32
+                // planes, see traj_small.hip) with integer global atomics: order-independent
+                if (gw != 0.f) {
+                    const float x = -gw * a * r;                         // D . w_ij = -a r
+                    int32_t* hi = A.ghi + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
+                    int32_t* lo = A.glo + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
+#pragma unroll
+                    for (int b_ = 0; b_ < 4; ++b_) {
+                        const float val = x * o.tb[b_];
+                        if (fabsf(val) >= 3.5e13f) atomicOr(&A.flags[2], 1);          // 2^45: out of range
+                        const float vh_ = rintf(val * (1.f / 1048576.f));
+                        atomicAdd(hi + b_, (int)vh_);
+                        atomicAdd(lo + b_, (int)rintf(fmaf(vh_, -1048576.f, val)));
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < MDG_MAX_THETA; ++p)
+                    if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
+            }
+        }
+    }
+}
+
+// The adjoint's evaluation over the STORED candidates of frame `frame` (no search, no LDS buffer): lane k takes
+// stored candidate k; its position, adjoint direction and mass are requested together, and the row is read before
+// the count is known -- two dependent round trips per atom.  Exact cutoff test per term as everywhere.
+template <bool DIAG, int LEVEL, int KIND>
+__device__ __forceinline__ void wave_list_force(
+    const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
+    float& fx, float& fy, float& fz, float& gx, float& gy, float& gz, float (&th)[LG_KMAX],
+    const TermConst (&tc)[MDG_MAX_TERMS], float gw, int rep, int frame) {
+    const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
+    const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
+    int n = 0;
+    fx = fy = fz = gx = gy = gz = 0.f;
+    if (!valid) return;
+    const size_t at = ((size_t)rep * A.prm.n_frames + frame) * N + i;
+    const int32_t* idx = A.nl_idx + at * LG_LIST;
+    const int j0 = idx[lane];                                   // (LG_LIST >= 64: inside the row)
+    n = A.nl_cnt[at];
+    const bool nhc_l = A.prm.ensemble == 0;
+    float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+    if (LEVEL >= 2) { const float im = nhc_l ? 1.0f / A.mass[i] : 1.0f; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
+    const int ntl = A.terms.n_terms;
+    for (int k = lane; k < n; k += 64) {
+        const int j = k < 64 ? j0 : idx[k];
+        float dx = q[3 * j] - xi, dy = q[3 * j + 1] - yi, dz = q[3 * j + 2] - zi;           // D = x_j - x_i
+        float lx = 0.f, ly = 0.f, lz = 0.f, jm = 1.f;
+        if (LEVEL >= 2) { lx = lam[3 * j]; ly = lam[3 * j + 1]; lz = lam[3 * j + 2]; if (nhc_l) jm = 1.0f / A.mass[j]; }
+        min_image<DIAG>(A.cell, dx, dy, dz);
+        const float d2 = norm2_ref(dx, dy, dz);
+        if (d2 == 0.f) continue;                                 // topology.py:67
+        pair_terms<LEVEL, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, lx * jm, ly * jm, lz * jm, gw, rep,
+                                fx, fy, fz, gx, gy, gz, th);
+    }
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (LEVEL >= 2) { gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); }
+    return;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One wave: neighbours of atom i from the LDS-staged tiles, then force (LEVEL 1) or force + HVP +
 // parameter vjp (LEVEL 2) over the compact list.  Results valid on every lane after the call.
 //   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m (NVE: w = lam_v) ; th += d(w.F)/dtheta partial
-template <bool DIAG, int LEVEL, int KIND = -1>
+// LIST 0: search (cutoff^2 = rc2max).  LIST 1 (forward): search, then store the ascending indices for frame `frame`
+// (wave_list_force is the adjoint's consumer).
+template <bool DIAG, int LEVEL, int KIND = -1, int LIST = 0>
 __device__ __forceinline__ void wave_neighbours_and_force(
     const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
     float* tile, float4* buf, float& fx, float& fy, float& fz, float& gx, float& gy, float& gz,
-    float (&th)[LG_KMAX], const TermConst (&tc)[MDG_MAX_TERMS], float rc2max, float gw = 0.f, int rep = 0) {
+    float (&th)[LG_KMAX], const TermConst (&tc)[MDG_MAX_TERMS], float rc2max, float gw = 0.f, int rep = 0, int frame = 0) {
     const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
     const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
     int n = 0;
@@ -500,6 +621,16 @@ __device__ __forceinline__ void wave_neighbours_and_force(
         }
     }
     if (n > LG_CAP) { if (lane == 0) atomicMax(&A.flags[0], n); n = LG_CAP; }
+    if constexpr (LIST == 1) {
+        if (valid && A.nl_idx) {
+            // (all-atom scan: the buffer is in ascending index order by construction; cell scan: rank-sorted above)
+            const size_t at = ((size_t)rep * A.prm.n_frames + frame) * N + i;
+            if (n <= LG_LIST) {
+                for (int k = lane; k < n; k += 64) A.nl_idx[at * LG_LIST + k] = __float_as_int(buf[k].w);
+                if (lane == 0) A.nl_cnt[at] = n;
+            } else if (lane == 0) { A.nl_bad[(size_t)rep * A.prm.n_frames + frame] = 1; A.flags[4] = 1; }
+        }
+    }
     fx = fy = fz = gx = gy = gz = 0.f;
     if (!valid) return;
     float wxi = 0.f, wyi = 0.f, wzi = 0.f;
@@ -511,48 +642,12 @@ __device__ __forceinline__ void wave_neighbours_and_force(
         const float dx = e.x, dy = e.y, dz = e.z;
         const int j = __float_as_int(e.w);
         const float d2 = norm2_ref(dx, dy, dz);
-#pragma unroll
-        for (int m = 0; m < MDG_MAX_TERMS; ++m) {
-            if (m >= nt) break;
-            if (!(d2 < tc[m].rc2)) continue;
-            const uint8_t* mk = A.terms.t[m].mask;
-            if (mk && !mk[(size_t)i * N + j]) continue;
-            PairOut o;
-            float r, ir;
-            pair_eval<LEVEL, KIND>(tc[m], d2, r, ir, o);
-            if (tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
-            const float c1 = o.du * ir;
-            fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
-            if (LEVEL >= 2) {
-                const float jm = nhc_w ? 1.0f / A.mass[j] : 1.0f;
-                const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
-                const float ax = wxi - lam[3 * j] * jm, ay = wyi - lam[3 * j + 1] * jm, az = wzi - lam[3 * j + 2] * jm;
-                const float a = rx * ax + ry * ay + rz * az;
-                const float c2 = o.d2u * a - c1 * a;
-                gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
-                if (tc[m].kind == MDG_PAIR_TABLE) {
-                    // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (two int32
-                    // planes, see traj_small.hip) with integer global atomics: order-independent
-                    if (gw != 0.f) {
-                        const float x = -gw * a * r;                         // D . w_ij = -a r
-                        int32_t* hi = A.ghi + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
-                        int32_t* lo = A.glo + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
-#pragma unroll
-                        for (int b_ = 0; b_ < 4; ++b_) {
-                            const float val = x * o.tb[b_];
-                            if (fabsf(val) >= 3.5e13f) atomicOr(&A.flags[2], 1);          // 2^45: out of range
-                            const float vh_ = rintf(val * (1.f / 1048576.f));
-                            atomicAdd(hi + b_, (int)vh_);
-                            atomicAdd(lo + b_, (int)rintf(fmaf(vh_, -1048576.f, val)));
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int p = 0; p < MDG_MAX_THETA; ++p)
-                        if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
-                }
-            }
+        float wjx = 0.f, wjy = 0.f, wjz = 0.f;
+        if (LEVEL >= 2) {
+            const float jm = nhc_w ? 1.0f / A.mass[j] : 1.0f;
+            wjx = lam[3 * j] * jm; wjy = lam[3 * j + 1] * jm; wjz = lam[3 * j + 2] * jm;
         }
+        pair_terms<LEVEL, KIND>(A, tc, nt, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, wjx, wjy, wjz, gw, rep, fx, fy, fz, gx, gy, gz, th);
     }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (LEVEL >= 2) { gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); }
@@ -610,8 +705,9 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     const int i = blockIdx.x * (blockDim.x >> 6) + wid;
     const bool valid = i < N;
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
-    wave_neighbours_and_force<DIAG, 1, KIND>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
-                                             th, tc, rc2max, 0.f, rep);
+    const float rs = sqrtf(rc2max) + A.skin;                    // (skin 0 unless the lists are kept for the adjoint)
+    wave_neighbours_and_force<DIAG, 1, KIND, 1>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
+                                                th, tc, rs * rs, 0.f, rep, MODE == 0 ? 0 : k + 1);
     float kepart = 0.f;
     if (valid && lane < 3) {
         const float F = lane == 0 ? fx : (lane == 1 ? fy : fz);
@@ -640,8 +736,12 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
 
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
-template <bool DIAG, int KIND>
-__global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, const int second) {
+// LISTED: the candidates are the forward pass's stored indices of frame A.step (no LDS, lean registers); a frame whose
+// list overflowed, or a midpoint that moved past the skin (flagged by large_prep<3>), raises flags[5]: the caller
+// repeats the adjoint with searches (MdgTrajParams.block = -1).
+template <bool DIAG, int KIND, bool LISTED>
+__global__ __launch_bounds__(LG_BLOCK) __attribute__((amdgpu_waves_per_eu(LISTED ? 6 : 4, 8)))
+void large_adj_force(const LargeArgs A, const int second) {
     // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
     extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
     float* tile = reinterpret_cast<float*>(nbuf + (blockDim.x >> 6) * LG_CAP);
@@ -663,8 +763,13 @@ __global__ __launch_bounds__(LG_BLOCK) void large_adj_force(const LargeArgs A, c
     // (NVE: from the first evaluation, sovlers.py:82,101 -- both with total weight h)
     const bool tab_eval = (A.prm.ensemble == 0) == (second != 0);
     const float gw = (tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
-    wave_neighbours_and_force<DIAG, 2, KIND>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
-                                             tc, rc2max, gw, rep);
+    if constexpr (LISTED) {
+        if (blockIdx.x == 0 && threadIdx.x == 0 && A.nl_bad[(size_t)rep * T + i_fr]) A.flags[5] = 1;
+        wave_list_force<DIAG, 2, KIND>(A, qs, lam, i, valid, fx, fy, fz, gx, gy, gz, th, tc, gw, rep, i_fr);
+    } else {
+        wave_neighbours_and_force<DIAG, 2, KIND, 0>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
+                                                    tc, rc2max, gw, rep);
+    }
     float vals[LG_NV];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) vals[p] = th[p];
@@ -694,10 +799,11 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, bcount, binslot, total;
+        spos, bstart, bcount, binslot, nl_idx, nl_cnt, nl_bad, disp_bad, total;
+    bool keep_lists;
 };
 
-WsLayout ws_layout(int R, int N, int nb, int KT) {
+WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     WsLayout w{};
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
@@ -716,6 +822,13 @@ WsLayout ws_layout(int R, int N, int nb, int KT) {
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
     w.bcount = take((size_t)2 * R * LG_MAX_CELLS);
     w.binslot = take((size_t)R * N);
+    // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
+    const long long lw = (long long)R * T * N * (LG_LIST + 1) + (long long)R * T + R;
+    w.keep_lists = T > 1 && lw <= LG_LIST_MAX_WORDS;
+    if (w.keep_lists) {
+        w.nl_idx = take((size_t)R * T * N * LG_LIST); w.nl_cnt = take((size_t)R * T * N);
+        w.nl_bad = take((size_t)R * T); w.disp_bad = take((size_t)R);
+    }
     w.total = o;
     return w;
 }
@@ -740,10 +853,10 @@ int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* 
 
 }  // namespace
 
-extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_total) {
-    if (n_rep <= 0 || n_atoms <= 0) return -1;
+extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames, int n_theta_total) {
+    if (n_rep <= 0 || n_atoms <= 0 || n_frames <= 0) return -1;
     const int nb = (n_atoms + LG_WAVES_CELL - 1) / LG_WAVES_CELL;       // (the larger of the two workgroup shapes)
-    return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total).total;
+    return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total, n_frames).total;
 }
 
 #define LG_PREP_LAUNCH(PH_)                                                                          \
@@ -755,7 +868,7 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
 #define LG_SETUP()                                                                                   \
     const int R = prm->n_rep, N = prm->n_atoms;                                                      \
     const int nbE = 1;              /* the element-wise work of a replica runs in one workgroup (large_prep) */ \
-    const WsLayout L = ws_layout(R, N, (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL, terms->n_theta_total); \
+    const WsLayout L = ws_layout(R, N, (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL, terms->n_theta_total, prm->n_frames); \
     LargeArgs a{};                                                                                   \
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;   \
     a.q = ws + L.q; a.v = ws + L.v; a.vh = ws + L.vh; a.f = ws + L.f;                                \
@@ -774,12 +887,19 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_theta_
     a.bcount = reinterpret_cast<int32_t*>(ws + L.bcount);                                            \
     a.binslot = reinterpret_cast<int32_t*>(ws + L.binslot);                                          \
     a.ncell = 0;                                                                                     \
+    if (L.keep_lists && prm->block != -1) {          /* (block = -1: search at every evaluation) */       \
+        a.nl_idx = reinterpret_cast<int32_t*>(ws + L.nl_idx); a.nl_cnt = reinterpret_cast<int32_t*>(ws + L.nl_cnt); \
+        a.nl_bad = reinterpret_cast<int32_t*>(ws + L.nl_bad); \
+        float rcm = 0.f;                                                                             \
+        for (int m = 0; m < terms->n_terms; ++m) rcm = terms->t[m].cutoff > rcm ? terms->t[m].cutoff : rcm; \
+        a.skin = LG_SKIN * rcm;                                                                      \
+    }                                                                                                \
     if (diag) {                                                                                      \
         float rcmax = 0.f;                                                                           \
         for (int m = 0; m < terms->n_terms; ++m) rcmax = terms->t[m].cutoff > rcmax ? terms->t[m].cutoff : rcmax; \
         int nbx[3];                                                                                  \
         bool ok = rcmax > 0.f;                                                                       \
-        for (int d = 0; d < 3 && ok; ++d) { nbx[d] = (int)floorf(cell->h[4 * d] / rcmax); ok = nbx[d] >= 3; } \
+        for (int d = 0; d < 3 && ok; ++d) { nbx[d] = (int)floorf(cell->h[4 * d] / (rcmax + a.skin)); ok = nbx[d] >= 3; } \
         if (ok && (long long)nbx[0] * nbx[1] * nbx[2] <= LG_MAX_CELLS) {                             \
             a.nb[0] = nbx[0]; a.nb[1] = nbx[1]; a.nb[2] = nbx[2]; a.ncell = nbx[0] * nbx[1] * nbx[2]; \
         }                                                                                            \
@@ -810,6 +930,7 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
                                  hipMemcpyDeviceToDevice, st));
     dim3 gF(nbF, R);
     a.step = 0;
+    if (a.nl_idx) MDG_HIP(hipMemsetAsync(a.nl_bad, 0, sizeof(int32_t) * (size_t)R * T, st));
 #define LG_FORCE_STEP(MODE_)                                                                                    \
     do {                                                                                                        \
         if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a); \
@@ -865,9 +986,13 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
-        if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);   \
-        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);       \
-        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);               \
+        if (a.nl_idx) {                                                                                             \
+            if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_); \
+            else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_);    \
+            else hipLaunchKernelGGL((large_adj_force<false, -1, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_);            \
+        } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
+        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);    \
+        else hipLaunchKernelGGL((large_adj_force<false, -1, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);            \
     } while (0)
         LG_PREP_LAUNCH(2);                                                          // finish interval i + 1, bin frame i
         LG_ADJ_FORCE(0);

@@ -267,6 +267,11 @@ def make_terms(term_list, n_theta_total):
     return ts
 
 
+# diagnostics of the multi-launch (large-N) trajectory path: how often the adjoint could not use the stored candidate
+# lists of the forward pass (tests read these)
+LARGE_STATS = {"lists_incomplete": 0, "adjoint_redone_with_searches": 0}
+
+
 class RdfFuse:
     """An `rdf` observable (observable.py) that a fused trajectory launch evaluates on the fly: centres, width and
     pair cutoff of the observable and the frames frame_start + k frame_stride it is called on.  Registered on the
@@ -356,8 +361,8 @@ class FusedTrajFn(torch.autograd.Function):
                                              ptr(q_t), ptr(pv_t), ptr(bad), C.byref(fuse.struct()), ptr(raw),
                                              stream_ptr(dev)), "mdg_traj_fwd_small_rdf")
         elif spec.large:
-            ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, spec.n_theta_total)), device=dev)
-            flags = torch.zeros(4, dtype=torch.int32, device=dev)
+            ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, T, spec.n_theta_total)), device=dev)
+            flags = torch.zeros(8, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
                                          ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
@@ -370,6 +375,8 @@ class FusedTrajFn(torch.autograd.Function):
                 raise RuntimeError("mdgrad_amd: a pair came closer than the first node of the tabulated pair "
                                    "potential; lower `table_rmin` on the integrator or set `fused_table = False`")
             ctx.ws, bad = ws, flags[1:2]
+            ctx.lists_ok = not fl[4]               # every frame's candidate list was stored: the adjoint re-tests them
+            LARGE_STATS["lists_incomplete"] += int(bool(fl[4]))
         else:
             bad = torch.zeros(R, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
@@ -442,7 +449,7 @@ class FusedTrajFn(torch.autograd.Function):
         prm = spec.params(R, T)
         table = getattr(spec, "table", False)
 
-        def launch(terms):
+        def launch(terms, search=False):
             if g_raw is not None:
                 gr = g_raw.detach().to(torch.float32).contiguous()
                 check(lib.mdg_traj_adj_small_rdf(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
@@ -452,11 +459,18 @@ class FusedTrajFn(torch.autograd.Function):
                       "mdg_traj_adj_small_rdf")
                 return None
             if spec.large:
-                flags = torch.zeros(4, dtype=torch.int32, device=dev)
-                check(lib.mdg_traj_adj_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                # the stored candidate lists of the forward pass serve the adjoint unless one overflowed there (or, flag
+                # 5 below, a midpoint moved past their skin): block = -1 asks for fresh searches
+                pl = type(prm).from_buffer_copy(prm)
+                pl.block = -1 if (search or not getattr(ctx, "lists_ok", False) or spec.block == -1) else 0
+                flags = torch.zeros(8, dtype=torch.int32, device=dev)
+                check(lib.mdg_traj_adj_large(C.byref(pl), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                              ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
                                              ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
                                              ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
+                if pl.block != -1 and int(flags[5]):
+                    LARGE_STATS["adjoint_redone_with_searches"] += 1
+                    return launch(terms, search=True)
                 return flags
             check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),

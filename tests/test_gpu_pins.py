@@ -248,6 +248,59 @@ def test_large_path_nve_vs_oracle_forward_and_adjoint(n_side):
     _large_case_nve(n_side, 4, seed=50 + n_side)
 
 
+@pytest.mark.parametrize("case", ["reuse", "moved", "crowded"])
+def test_large_path_stored_lists_equal_fresh_searches(case):
+    """The adjoint of the multi-launch kernels re-tests the forward pass's stored candidates (4 % skin) instead of
+    searching again; `block = -1` searches at every evaluation.  Same pair sets, so the same numbers up to summation
+    order -- also when the midpoint moves farther than skin / 2 (time step 0.06: the device-side check sends that
+    evaluation back to a search) and when an atom has more candidates than a stored row holds (a crowded cluster: the
+    frame is marked and searched)."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    pos, cell = liquid(9, seed=77, jitter=0.05)
+    rng = np.random.default_rng(5)
+    vscale = 1.0
+    if case == "crowded":
+        # a 5 x 5 x 5 cluster at spacing 0.5 in place of the liquid there: its inner atoms have > 96 candidates
+        g5 = np.stack(np.meshgrid(*[np.arange(5)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.5 + 1.25
+        keep = ~np.all((pos > 0.9) & (pos < 3.6), axis=1)
+        pos = np.concatenate([g5.astype(np.float32), pos[keep]])
+    if case == "moved":
+        vscale = 8.0                                       # |v| h / 2 ~ 0.08 > skin / 2 = 0.05 for many atoms
+    vel = (vscale * rng.normal(0, 1.0, pos.shape)).astype(np.float32)
+    mass = np.full(len(pos), 1.008, dtype=np.float32)
+    dt = 0.02 if case == "moved" else 0.003
+    t = torch.Tensor([dt * i for i in range(4)]).to(DEV)
+    system = mk_system(pos, cell, vel, mass)
+    # (a soft, weak repulsion keeps these contrived states finite; the test is about the pair sets, not the physics)
+    mdl = (P.LennardJones(1.0, 1.0) if case == "reuse" else
+           P.ExcludedVolume(0.3, 1e-3, 12) if case == "crowded" else P.ExcludedVolume(0.8, 1e-5, 12))
+    from mdgrad_amd.md import NVE
+    stack = Stack({"p": PairPotentials(system, mdl, cutoff=2.5)})
+    nhc = case != "moved"                                  # (fast atoms would blow the thermostat up: NVE there)
+    integ = (NoseHooverChain(stack, system, T=1.0, num_chains=3, Q=30.0) if nhc else NVE(stack, system)).to(DEV)
+    integ.fused_large = True
+    res = []
+    stats0 = dict(ops.LARGE_STATS)
+    for block in (0, -1):
+        spec = integ.fused_spec("NH_verlet" if nhc else "verlet")
+        spec.block = block
+        y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+        out = ops.FusedTrajFn.apply(y0[0], y0[1], y0[2] if nhc else None, t, spec.flat_params(), spec)
+        v_t, q_t = out[0], out[1]
+        mdl.zero_grad()
+        (q_t[::2].pow(2).mean() + v_t[-1].pow(2).mean() + (out[2][-1].sum() * 1e-3 if nhc else 0.0)).backward()
+        res.append([q_t.detach(), v_t.detach(), y0[0].grad.clone(), y0[1].grad.clone(),
+                    torch.stack([p.grad.reshape(()) for p in mdl.parameters()])])
+    assert ops.LARGE_STATS["adjoint_redone_with_searches"] - stats0["adjoint_redone_with_searches"] == (case == "moved")
+    assert ops.LARGE_STATS["lists_incomplete"] - stats0["lists_incomplete"] == (case == "crowded")
+    # (the forward pass searches with the skin when it keeps the lists: extra candidates beyond the cutoff contribute
+    #  nothing but change the lane assignment of the sums)
+    for a, b, nm in zip(res[0], res[1], ("q_t", "v_t", "adj v0", "adj q0", "dL/dtheta")):
+        close(a, b, 1e-4, 1e-5 * float(b.abs().max()) + 1e-12, "%s (%s)" % (nm, case))
+
+
 def test_large_path_4096_atoms_one_step_vs_oracle():
     """BASELINE config #4's size: one forward NH-Verlet step of the 4 096-atom LJ liquid against the oracle."""
     _large_case(16, 2, False, seed=36)
