@@ -112,6 +112,17 @@ __device__ __forceinline__ float reduce_partials(const float* __restrict__ part,
     return block_sum(s, red);
 }
 
+// column sums of a [n][LG_NV] partial array by one workgroup: one pass over the rows, fixed order (red: 16 * LG_NV floats)
+__device__ __forceinline__ void sum_partial_rows(const float* __restrict__ part, int n, float (&tot)[LG_NV], float* red) {
+#pragma unroll
+    for (int p = 0; p < LG_NV; ++p) tot[p] = 0.f;
+    for (int b = threadIdx.x; b < n; b += blockDim.x) {
+#pragma unroll
+        for (int p = 0; p < LG_NV; ++p) tot[p] += part[(size_t)b * LG_NV + p];
+    }
+    block_sum_n<LG_NV>(tot, red);
+}
+
 // ------------------------------------------------------------------------------------ per-replica preparation
 // Everything between two force launches runs in ONE launch of one 1 024-thread workgroup per replica: the
 // elementwise update of the integrator / adjoint (which ends in the positions of the next force evaluation), the
@@ -134,8 +145,13 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     __shared__ int32_t start[LG_MAX_CELLS + 1];
     __shared__ int32_t tsum[LG_PREP];
     __shared__ float red[32];
+    __shared__ float redN[16 * LG_NV];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.x, nc = A.ncell;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, nc = A.ncell;
+    // gridDim.x workgroups share a replica's atoms when nothing has to be binned (the adjoint over stored lists); the
+    // scalar work (partial sums, thermostat chain) is repeated by each, written by the first
+    const int tid = blockIdx.x * LG_PREP + threadIdx.x, stride = gridDim.x * LG_PREP;
+    const bool first = blockIdx.x == 0;
     const bool nhc = A.prm.ensemble == 0;
     const size_t so = (size_t)rep * N * 3;
     if (threadIdx.x < MDG_MAX_CHAINS) {
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     if constexpr (PHASE == 0) {
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int a = threadIdx.x + u * LG_PREP;
+            const int a = tid + u * stride;
             if (a < N) { px[u] = A.q[so + 3 * a]; py[u] = A.q[so + 3 * a + 1]; pz[u] = A.q[so + 3 * a + 2]; }
         }
     }
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
             if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
             __syncthreads();
-            if (threadIdx.x < C) {
+            if (first && threadIdx.x < C) {
                 const float h = 0.5f * bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x) * dt;
                 A.ph[rep * MDG_MAX_CHAINS + threadIdx.x] = h;
                 A.pvh[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + h;
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         float part = 0.f;
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int a = threadIdx.x + u * LG_PREP;
+            const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
                 float qn[3];
@@ -191,7 +207,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             }
         }
         part = block_sum(part, red);
-        if (threadIdx.x == 0) A.partB[rep] = part;                     // (nbE = 1: KE(v + vh) for the force launch)
+        if (threadIdx.x == 0) A.partB[rep] = part;                     // (one workgroup per replica in this phase)                     // (nbE = 1: KE(v + vh) for the force launch)
     }
     if constexpr (PHASE == 2 || PHASE == 4) {
         const int i_fr = A.step + 1;                                   // the interval being finished
@@ -203,20 +219,21 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 const float* lph = A.lph + rep * MDG_MAX_CHAINS;
                 float* lp = A.lp + rep * MDG_MAX_CHAINS;
                 const float pvm0 = pvm[0], lpm0 = lph[0];
-                const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
-                const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+                float tot[LG_NV];
+                sum_partial_rows(A.partN + (size_t)rep * A.nbF * LG_NV, A.nbF, tot, redN);
+                const float slv = tot[LG_KMAX + 1];
                 const int KT = A.terms.n_theta_total;
+                if (first && threadIdx.x == 0) {
 #pragma unroll
-                for (int m = 0; m < MDG_MAX_TERMS; ++m)
+                    for (int m = 0; m < MDG_MAX_TERMS; ++m)
 #pragma unroll
-                    for (int p = 0; p < MDG_MAX_THETA; ++p)
-                        if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
-                            const float s_ = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
-                            if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += s_ * h;   // :160
-                        }
+                        for (int p = 0; p < MDG_MAX_THETA; ++p)
+                            if (m < A.terms.n_terms && p < A.terms.t[m].n_theta)
+                                A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += tot[m * MDG_MAX_THETA + p] * h;   // :160
+                }
                 if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
                 __syncthreads();
-                if (threadIdx.x < C) {
+                if (first && threadIdx.x < C) {
                     const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
                     float nlp = lp[threadIdx.x] + gp * h;                               // :158
                     if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
@@ -224,7 +241,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 }
 #pragma unroll
                 for (int u = 0; u < 3 * NA; ++u) {
-                    const int e = threadIdx.x + u * LG_PREP;
+                    const int e = tid + u * stride;
                     if (e >= 3 * N) break;
                     const float m = A.mass[e / 3];
                     const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
 #pragma unroll
                 for (int u = 0; u < 3 * NA; ++u) {
-                    const int e = threadIdx.x + u * LG_PREP;
+                    const int e = tid + u * stride;
                     if (e >= 3 * N) break;
                     float nlv = A.lvh[so + e];
                     float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
-                const int a = threadIdx.x + u * LG_PREP;
+                const int a = tid + u * stride;
                 if (a < N) { px[u] = qf[3 * a]; py[u] = qf[3 * a + 1]; pz[u] = qf[3 * a + 2]; }
             }
         }
@@ -262,38 +279,36 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         const int i_fr = A.step;
         const size_t fo = ((size_t)rep * T + i_fr) * N * 3;
         const float h = A.t[i_fr] - A.t[i_fr - 1];
-        const float* part = A.partN + (size_t)rep * A.nbF * LG_NV;
+        float tot[LG_NV];
+        sum_partial_rows(A.partN + (size_t)rep * A.nbF * LG_NV, A.nbF, tot, redN);
         float pv0 = 0.f, lp0 = 0.f;
         if (nhc) {
             const float* pvf = A.pv_t + ((size_t)rep * T + i_fr) * C;
             float* lp = A.lp + rep * MDG_MAX_CHAINS;
-            const float ke = 0.5f * reduce_partials(part, A.nbF, LG_NV, LG_KMAX, red);
-            const float slv = reduce_partials(part, A.nbF, LG_NV, LG_KMAX + 1, red);
+            const float ke = 0.5f * tot[LG_KMAX], slv = tot[LG_KMAX + 1];
             if (threadIdx.x < C) { pvs[threadIdx.x] = pvf[threadIdx.x]; lps[threadIdx.x] = lp[threadIdx.x]; }
             __syncthreads();
-            if (threadIdx.x < C) {
+            if (first && threadIdx.x < C) {
                 const float pb = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
                 const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
                 A.pvm[rep * MDG_MAX_CHAINS + threadIdx.x] = pvs[threadIdx.x] + 0.5f * (-pb) * h;      // :135
                 A.lph[rep * MDG_MAX_CHAINS + threadIdx.x] = lps[threadIdx.x] + gp * 0.5f * h;         // :143
             }
             pv0 = pvs[0]; lp0 = lps[0];
-        } else {
+        } else if (first && threadIdx.x == 0) {
             // the parameter term of an NVE interval comes from the first evaluation (sovlers.py:82,101)
             const int KT = A.terms.n_theta_total;
 #pragma unroll
             for (int m = 0; m < MDG_MAX_TERMS; ++m)
 #pragma unroll
                 for (int p = 0; p < MDG_MAX_THETA; ++p)
-                    if (m < A.terms.n_terms && p < A.terms.t[m].n_theta) {
-                        const float s_ = reduce_partials(part, A.nbF, LG_NV, m * MDG_MAX_THETA + p, red);
-                        if (threadIdx.x == 0) A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (s_ * 0.5f * h) * 2.f;
-                    }
+                    if (m < A.terms.n_terms && p < A.terms.t[m].n_theta)
+                        A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (tot[m * MDG_MAX_THETA + p] * 0.5f * h) * 2.f;
         }
         float far2 = 0.f;                                           // largest |q_mid - q_frame|^2 of this thread's atoms
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
-            const int a = threadIdx.x + u * LG_PREP;
+            const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
                 float qn[3], mv2 = 0.f;
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     int bsl[NA];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-        const int a = threadIdx.x + u * LG_PREP;
+        const int a = tid + u * stride;
         if (a < N) {
             const int bx = bin_coord_l(px[u], A.cell.inv[0], A.nb[0]);
             const int by = bin_coord_l(py[u], A.cell.inv[4], A.nb[1]);
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     for (int c = threadIdx.x; c <= nc; c += LG_PREP) bs[c] = start[c];
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
-        const int a = threadIdx.x + u * LG_PREP;
+        const int a = tid + u * stride;
         if (a < N)
             A.spos[(size_t)rep * N + start[bsl[u] & 4095] + (bsl[u] >> 12)] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
     }
@@ -859,10 +874,13 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames
     return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total, n_frames).total;
 }
 
+// (phases that bin need the replica in ONE workgroup; the adjoint over stored lists does not: one atom per thread)
 #define LG_PREP_LAUNCH(PH_)                                                                          \
     do {                                                                                             \
-        if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(R), dim3(LG_PREP), 0, st, a); \
-        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(R), dim3(LG_PREP), 0, st, a);  \
+        if ((PH_) >= 2 && a.nl_idx)                                                                  \
+            hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP - 1) / LG_PREP, R), dim3(LG_PREP), 0, st, a); \
+        else if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(1, R), dim3(LG_PREP), 0, st, a); \
+        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, R), dim3(LG_PREP), 0, st, a);  \
     } while (0)
 
 #define LG_SETUP()                                                                                   \
