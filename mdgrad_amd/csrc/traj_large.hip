@@ -927,7 +927,7 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames
     a.nbF = nbF;                                                                                     \
     const size_t tile_lds = sizeof(float4) * (size_t)wpb * LG_CAP + (a.ncell ? 0 : sizeof(float) * 3 * LG_TILE); \
     const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
-                       terms->t[0].p == 12 && terms->t[0].q == 6;                                    \
+                       terms->t[0].p == 12 && (terms->t[0].q == 6 || terms->t[0].c == 0.f);          \
     (void)0;
 
 extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,

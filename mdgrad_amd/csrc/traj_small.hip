@@ -731,7 +731,9 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 // asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
 bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
-    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && t.q == 6 && p.n_atoms <= 128;
+    // LJ 12-6, or ExcludedVolume with power 12 (the same polynomial with the attractive coefficient c = 0)
+    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && (t.q == 6 || t.c == 0.f) &&
+           p.n_atoms <= 128;
 }
 bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     return ring_form(p, cell, terms) && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
@@ -790,7 +792,7 @@ int pick_block(const MdgTrajParams& p, bool table) {
         const int kind = terms->t[0].kind;                                                             \
         if (kind == MDG_PAIR_TABLE)                                                                    \
             hipLaunchKernelGGL((KERNEL<true, 1, KIND_TABLE>), grid, dim3(block), lds, st, a, tl);      \
-        else if (single && kind == MDG_PAIR_LJ && terms->t[0].p == 12 && terms->t[0].q == 6)           \
+        else if (single && kind == MDG_PAIR_LJ && terms->t[0].p == 12 && (terms->t[0].q == 6 || terms->t[0].c == 0.f)) \
             hipLaunchKernelGGL((KERNEL<true, 1, KIND_LJ126>), grid, dim3(block), lds, st, a, tl);      \
         else if (single && kind == MDG_PAIR_LJ)                                                        \
             hipLaunchKernelGGL((KERNEL<true, 1, MDG_PAIR_LJ>), grid, dim3(block), lds, st, a, tl);     \

@@ -67,7 +67,7 @@ def test_one_lane_per_atom_trajectory_kernels_vs_oracle(R, block):
 
 
 @pytest.mark.parametrize("n_atoms,ensemble", [(108, "nve"), (107, "nhc"), (31, "nve"), (54, "nhc"), (3, "nhc"),
-                                              (2, "nve")])
+                                              (2, "nve"), (108, "nhc-exvol"), (53, "nve-exvol")])
 def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
     """The wave-per-replica ring kernels (block = 64) for ring lengths that are odd / even / tiny, a lane with one
     atom, and the NVE branch of the adjoint (sovlers.py:42-101): trajectory, adjoints and parameter gradient of 3
@@ -77,10 +77,12 @@ def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
     from mdgrad_amd.md import NVE, NoseHooverChain
     g = load_golden("nhc_traj_lj")
     R, nT = 3, 9
+    exvol = ensemble.endswith("-exvol")               # ExcludedVolume(power 12): the same kernels with c = 0
+    ensemble = ensemble.split("-")[0]
     rng = np.random.default_rng(n_atoms)
     base = g["pos"][:n_atoms]
     system = mk_system(base, g["cell"], g["vel"][:n_atoms], g["mass"][:n_atoms])
-    mdl = P.LennardJones(1.0, 1.0)
+    mdl = P.ExcludedVolume(1.0, 1.0, 12) if exvol else P.LennardJones(1.0, 1.0)
     stack = Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)})
     nhc = ensemble == "nhc"
     integ = (NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0) if nhc else NVE(stack, system)).to(DEV)
@@ -101,7 +103,7 @@ def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
     loss.backward()
     gth_sum = np.zeros(2)
     for r in range(R):
-        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=0 if exvol else 6, c=0 if exvol else 1)
         traj, lam, gth = oracle_run(
             pos[r], g["cell"], vel[r], g["mass"][:n_atoms], [term], 1.0, 50.0, 5, t,
             lambda L: L[1][::2].pow(2).sum() / (5 * nrm) + L[0][-1].pow(2).sum() / nrm
