@@ -143,3 +143,57 @@ def test_torch_op_library_loads_and_registers_every_op():
         assert schema.startswith("mdgrad::" + op + "("), schema
     with pytest.raises((RuntimeError, NotImplementedError)):
         ns.atb(torch.zeros(8, 4), torch.zeros(8, 4))
+
+
+def test_struct_layout_of_the_fused_observable_descriptor():
+    from mdgrad_amd import _lib
+    assert ctypes.sizeof(_lib.MdgRdfFuse) == 8 + 7 * 4 + 4          # pointer + 7 words, padded to 8
+
+
+def test_rdf_recognises_time_slices_of_a_fused_trajectory():
+    """Host logic of the fused observable (observable.rdf._fused_raw): which views of a tagged trajectory tensor are
+    'the frames start, start + stride, ... up to the last one' -- q_t, q_t[::k], q_t[s:], q_t[s::k], along the
+    time axis the tag names -- and which are not (a cut-off end, a replica subset, a copy).  No kernel runs."""
+    from mdgrad_amd import ops
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.system import System, FaceCenteredCubic
+
+    class Spec:                                   # what the observable touches on a FusedSpec
+        rdf_hint = None
+        _integrator = None
+
+    system = System(FaceCenteredCubic("H", (3, 3, 3), 1.6), device="cpu")
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+
+    def hint_after(view_of, time_dim, shape):
+        spec = Spec()
+        q_t = torch.zeros(shape)
+        ops.tag_trajectory(q_t, spec, None, time_dim)
+        assert obs._fused_raw(view_of(q_t)) is None         # nothing cached yet: registers (or not) for the next launch
+        return None if spec.rdf_hint is None else (spec.rdf_hint.start, spec.rdf_hint.stride)
+
+    batched, single = (4, 12, 108, 3), (12, 108, 3)
+    assert hint_after(lambda q: q, 1, batched) == (0, 1)
+    assert hint_after(lambda q: q[:, ::3], 1, batched) == (0, 3)
+    assert hint_after(lambda q: q[:, 2:], 1, batched) == (2, 1)
+    assert hint_after(lambda q: q[:, 1::2], 1, batched) == (1, 2)
+    assert hint_after(lambda q: q[::4], 0, single) == (0, 4)
+    assert hint_after(lambda q: q[11:], 0, single) == (11, 1)
+    assert hint_after(lambda q: q[:, :5], 1, batched) is None        # does not run to the last frame
+    assert hint_after(lambda q: q[:, 1:9:2], 1, batched) is None
+    assert hint_after(lambda q: q[:2], 1, batched) is None           # a replica subset
+    assert hint_after(lambda q: q[:, :, :50], 1, batched) is None    # an atom subset
+    assert hint_after(lambda q: q.clone(), 1, batched) is None       # a copy carries no tag
+    # a cached histogram is returned only to the observable and frame selection it was made for
+    spec, q_t = Spec(), torch.zeros(batched)
+    hint = ops.RdfFuse(obs, 0, 2)
+    spec.rdf_hint = hint
+    raw = torch.arange(100.0)
+    ops.tag_trajectory(q_t, spec, raw, 1)
+    assert obs._fused_raw(q_t[:, ::2]) is raw
+    assert obs._fused_raw(q_t[:, ::3]) is None and spec.rdf_hint.stride == 3        # re-registered for the new selection
+    other = rdf(system, nbins=50, r_range=(0.75, 2.5))
+    ops.tag_trajectory(q_t, spec, raw, 1)
+    spec.rdf_hint = hint
+    q_t._mdg_traj = (spec, 1, hint, raw)
+    assert other._fused_raw(q_t[:, ::2]) is None
