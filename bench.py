@@ -564,7 +564,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="all", choices=["all", "lj108", "schnet4096", "lj4096"])
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200,
+                    help="timed passes (default: ~4.5 s of GPU time on the headline workload, so that a coarse utilisation "
+                         "sampler sees the device busy)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 16)")
     ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11 / 51")
