@@ -197,7 +197,7 @@ int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
  * the forward launch also fills the raw soft histogram (sum over the selected frames of all replicas, the quantity
  * mdg_rdf_fwd_uniform returns for those frames) and the adjoint launch takes g_raw = dL/d(raw) in place of the
  * frame gradients dL/dq_t that mdg_rdf_bwd_uniform would have written to HBM (an additional g_q is still accepted).
- * Available where the wave-per-replica kernels run (one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and
+ * Available where the wave-per-replica kernels run (one unmasked built-in pair term, orthorhombic cell, N <= 128, and
  * block = 64 or n_rep >= 1024) and for equally spaced centres whose fine grids fit the LDS and start above zero: mdg_traj_rdf_supported() != 0. */
 typedef struct MdgRdfFuse {
     const float* mu;               /* device [nbins] centres, equally spaced (GaussianSmearing offsets) */

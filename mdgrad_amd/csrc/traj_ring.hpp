@@ -50,8 +50,9 @@ __device__ __forceinline__ Vec3x2 ring_move(const Vec3x2& a, int s) { return Vec
 
 // ------------------------------------------------------------------------------------------------ pair sweep
 struct RingLJ {
-    float sig2, rc2, m1a, m1b, ka, kb, tsa, tsb, tea, teb;
+    float sig2, rc2, m1a, m1b, ka, kb, tsa, tsb, tea, teb;      // LJ 12-6 polynomial (KIND_LJ126)
     float ivx, ivy, ivz, hx, hy, hz;
+    TermConst t0;                                               // any other single-term form goes through pair_eval
 };
 
 __device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
@@ -65,6 +66,7 @@ __device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
     K.tea = 12.f * cq; K.teb = 24.f;                                   // d(w.F)/deps
     K.ivx = A.cell.inv[0]; K.ivy = A.cell.inv[4]; K.ivz = A.cell.inv[8];
     K.hx = A.cell.h[0]; K.hy = A.cell.h[4]; K.hz = A.cell.h[8];
+    K.t0 = t0;
     return K;
 }
 
@@ -84,10 +86,10 @@ struct RingRdf {
 // v0 / v1: both atoms of the pair in .x / .y exist.  JSIDE: also update the visitors' accumulators.
 // LEVEL 0: geometry only (RDF gradient of a frame the adjoint does not evaluate forces at).
 // r0 / r1: the pair in .x / .y feeds the RDF (exists and, for RDF = 1, is the one copy of a pair met twice).
-template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE, int RDF>
+template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE, int RDF, int KIND>
 __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, const Vec3x2& qi, const Vec3x2& wi,
                                           const Vec3x2& qj, const Vec3x2& wj, bool v0, bool v1, bool r0, bool r1,
-                                          Vec3x2& fi, Vec3x2& gi, Vec3x2& fj, Vec3x2& gj, f32x2& S6, f32x2& S12,
+                                          Vec3x2& fi, Vec3x2& gi, Vec3x2& fj, Vec3x2& gj, f32x2 (&TH)[MDG_MAX_THETA],
                                           Vec3x2& ri, Vec3x2& rj) {
     f32x2 dx = (CROSS ? qj.x.yx : qj.x) - qi.x, dy = (CROSS ? qj.y.yx : qj.y) - qi.y,
           dz = (CROSS ? qj.z.yx : qj.z) - qi.z;                                       // D = x_j - x_i
@@ -130,11 +132,35 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
     if constexpr (LEVEL >= 1) {
         const bool ok0 = v0 && (d2.x != 0.f) && (d2.x < K.rc2);                       // topology.py:67
         const bool ok1 = v1 && (d2.y != 0.f) && (d2.y < K.rc2);
-        const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
-        const f32x2 s2 = K.sig2 * i2;
-        const f32x2 s6 = s2 * s2 * s2;
-        const f32x2 s12 = s6 * s6;
-        const f32x2 c1 = (K.m1a * s6 - K.m1b * s12) * i2;
+        // per pair: c1 = phi'/r, kk = (phi'' - phi'/r)/r^2 and the parameter factors tk (dth_k += tk (w.D) per directed
+        // pair) -- from the even-power polynomial for LJ 12-6, from pair_eval for every other form
+        f32x2 c1, kk, tk[MDG_MAX_THETA];
+        constexpr int NTH = KIND == KIND_LJ126 ? 2 : kind_ntheta(KIND);
+        if constexpr (KIND == KIND_LJ126) {
+            // 1/d2 selected to 0 for a rejected pair: s6, s12 and everything below are then exactly zero
+            const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+            const f32x2 s2 = K.sig2 * i2;
+            const f32x2 s6 = s2 * s2 * s2;
+            const f32x2 s12 = s6 * s6;
+            c1 = (K.m1a * s6 - K.m1b * s12) * i2;
+            if constexpr (LEVEL >= 2) {
+                kk = (K.kb * s12 - K.ka * s6) * (i2 * i2);
+                tk[0] = s6 * i2; tk[1] = s12 * i2;       // (S6, S12: both parameter gradients are linear in these sums)
+            }
+        } else {
+            // branch-free: a rejected pair is evaluated at the cutoff and multiplied by zero
+            PairOut o0, o1;
+            float r0, ir0, r1, ir1;
+            pair_eval<LEVEL, KIND>(K.t0, ok0 ? d2.x : K.rc2, r0, ir0, o0);
+            pair_eval<LEVEL, KIND>(K.t0, ok1 ? d2.y : K.rc2, r1, ir1, o1);
+            c1 = f32x2{ok0 ? o0.du * ir0 : 0.f, ok1 ? o1.du * ir1 : 0.f};
+            if constexpr (LEVEL >= 2) {
+                kk = f32x2{ok0 ? (o0.d2u - o0.du * ir0) * (ir0 * ir0) : 0.f, ok1 ? (o1.d2u - o1.du * ir1) * (ir1 * ir1) : 0.f};
+#pragma unroll
+                for (int k = 0; k < NTH; ++k)
+                    tk[k] = f32x2{ok0 ? 0.5f * o0.ddu_dth[k] * ir0 : 0.f, ok1 ? 0.5f * o1.ddu_dth[k] * ir1 : 0.f};
+            }
+        }
         fi.x += c1 * dx; fi.y += c1 * dy; fi.z += c1 * dz;                            // F_i += (phi'/r) D
         if constexpr (JSIDE) {
             if constexpr (CROSS) {
@@ -147,16 +173,16 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
         if constexpr (LEVEL >= 2) {
             const f32x2 ax = wi.x - (CROSS ? wj.x.yx : wj.x), ay = wi.y - (CROSS ? wj.y.yx : wj.y),
                         az = wi.z - (CROSS ? wj.z.yx : wj.z);
-            const f32x2 b = dx * ax + dy * ay + dz * az;
-            const f32x2 bi = b * i2;                                                  // (w.D) / d2
-            const f32x2 k2 = (K.kb * s12 - K.ka * s6) * (bi * i2);                    // (phi'' - phi'/r)(w.D)/d2
+            const f32x2 b = dx * ax + dy * ay + dz * az;                              // w_ij . D
+            const f32x2 k2 = kk * b;                                                  // (phi'' - phi'/r)(w.D)/d2
             const f32x2 tx = __builtin_elementwise_fma(k2, dx, c1 * ax), ty = __builtin_elementwise_fma(k2, dy, c1 * ay),
                         tz = __builtin_elementwise_fma(k2, dz, c1 * az);              // -(H w) contribution
             gi.x += tx; gi.y += ty; gi.z += tz;
             if constexpr (JSIDE) {
                 gj.x -= CROSS ? tx.yx : tx; gj.y -= CROSS ? ty.yx : ty; gj.z -= CROSS ? tz.yx : tz;
             }
-            S6 += s6 * bi; S12 += s12 * bi;
+#pragma unroll
+            for (int k = 0; k < NTH; ++k) TH[k] += tk[k] * b;
         }
     }
 }
@@ -169,14 +195,14 @@ __device__ __forceinline__ void ring_lds_fence() {
 }
 
 // All pair terms of one replica.  Outputs: f (force), g (= dq of the augmented dynamics, already negated),
-// a6 / a12 = sums over DIRECTED pairs of s6 (w.D)/d2 and s12 (w.D)/d2 for this lane (LEVEL 2), rq = dL/dq of the
-// fused RDF for this frame (RDF = 2).
+// th[k] = this lane's part of the parameter sums over DIRECTED pairs (LEVEL 2; LJ 12-6: of s6 (w.D)/d2 and
+// s12 (w.D)/d2, other forms: of 1/2 d2phi/(dr dtheta_k) (w.D)/r), rq = dL/dq of the fused RDF for this frame (RDF = 2).
 // The ring has nl = ceil(N/2) lanes (the lanes that own atoms).  The visitors' positions and w do not move at all:
 // they sit in LDS ([6][64] f32x2, written once per evaluation) and lane l reads entry (l - k) mod nl at step k;
 // only the visitors' accumulators travel, through ds_bpermute_b32 (the LDS crossbar: no VALU slot, no memory).
-template <int LEVEL, bool NEAR, int RDF>
+template <int LEVEL, bool NEAR, int RDF, int KIND>
 __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, int N, int lane, const Vec3x2& q,
-                                           const Vec3x2& w, Vec3x2& f, Vec3x2& g, float& a6, float& a12, Vec3x2& rq,
+                                           const Vec3x2& w, Vec3x2& f, Vec3x2& g, float (&th)[MDG_MAX_THETA], Vec3x2& rq,
                                            f32x2* __restrict__ lds) {
     const int nl = (N + 1) >> 1;
     const bool vi0 = 2 * lane < N, vi1 = 2 * lane + 1 < N;
@@ -187,11 +213,13 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
     if constexpr (LEVEL >= 2) { swx[lane] = w.x; swy[lane] = w.y; swz[lane] = w.z; }
     ring_lds_fence();
     Vec3x2 fi = vzero(), gi = vzero(), fj = vzero(), gj = vzero(), ri = vzero(), rj = vzero();
-    f32x2 S6 = {0.f, 0.f}, S12 = S6, D6 = S6, D12 = S6;
+    f32x2 S[MDG_MAX_THETA], D[MDG_MAX_THETA];                 // parameter sums: ring steps (undirected) / directed steps
+#pragma unroll
+    for (int k = 0; k < MDG_MAX_THETA; ++k) { S[k] = f32x2{0.f, 0.f}; D[k] = S[k]; }
     // step 0: the pair inside the lane, both directions (one copy for the histogram)
     {
         const bool v = vi0 && vi1;
-        ring_pair<LEVEL, NEAR, true, false, RDF>(K, X, q, w, q, w, v, v, v, RDF == 2 && v, fi, gi, fj, gj, D6, D12, ri, rj);
+        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, q, w, v, v, v, RDF == 2 && v, fi, gi, fj, gj, D, ri, rj);
     }
     const int prev = lane < nl ? ((lane == 0 ? nl : lane) - 1) * 4 : lane * 4;     // bpermute address of lane l-1
     const int nsteps = (nl - 1) >> 1;
@@ -206,8 +234,8 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
         if constexpr (RDF == 2) rj = ring_move(rj, prev);
         const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
         const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
-        ring_pair<LEVEL, NEAR, false, true, RDF>(K, X, q, w, qj, wj, s0, s1, s0, s1, fi, gi, fj, gj, S6, S12, ri, rj);
-        ring_pair<LEVEL, NEAR, true, true, RDF>(K, X, q, w, qj, wj, c0, c1, c0, c1, fi, gi, fj, gj, S6, S12, ri, rj);
+        ring_pair<LEVEL, NEAR, false, true, RDF, KIND>(K, X, q, w, qj, wj, s0, s1, s0, s1, fi, gi, fj, gj, S, ri, rj);
+        ring_pair<LEVEL, NEAR, true, true, RDF, KIND>(K, X, q, w, qj, wj, c0, c1, c0, c1, fi, gi, fj, gj, S, ri, rj);
     }
     if (!(nl & 1)) {
         // antipodal lanes (k = nl/2) see each other from both sides -> directed evaluation, visitors not updated
@@ -219,8 +247,8 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
         const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
         const bool once = RDF == 2 || 2 * lane < nl;
         Vec3x2 fu = vzero(), gu = vzero(), ru = vzero();
-        ring_pair<LEVEL, NEAR, false, false, RDF>(K, X, q, w, qj, wj, s0, s1, s0 && once, s1 && once, fi, gi, fu, gu, D6, D12, ri, ru);
-        ring_pair<LEVEL, NEAR, true, false, RDF>(K, X, q, w, qj, wj, c0, c1, c0 && once, c1 && once, fi, gi, fu, gu, D6, D12, ri, ru);
+        ring_pair<LEVEL, NEAR, false, false, RDF, KIND>(K, X, q, w, qj, wj, s0, s1, s0 && once, s1 && once, fi, gi, fu, gu, D, ri, ru);
+        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, qj, wj, c0, c1, c0 && once, c1 && once, fi, gi, fu, gu, D, ri, ru);
     }
     // the travelling accumulators are nsteps lanes ahead of their owners
     int home = lane + nsteps; home = home >= nl ? home - nl : home;
@@ -232,8 +260,9 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
     if constexpr (LEVEL >= 2) {
         gj = ring_move(gj, home);
         g.x = -(gi.x + gj.x); g.y = -(gi.y + gj.y); g.z = -(gi.z + gj.z);
-        a6 = 2.f * hsum(S6) + hsum(D6);            // an undirected pair of the ring steps stands for both directions
-        a12 = 2.f * hsum(S12) + hsum(D12);
+#pragma unroll
+        for (int k = 0; k < MDG_MAX_THETA; ++k)
+            th[k] = 2.f * hsum(S[k]) + hsum(D[k]);  // an undirected pair of the ring steps stands for both directions
     }
     if constexpr (RDF == 2) {
         rj = ring_move(rj, home);
@@ -252,21 +281,21 @@ __device__ __forceinline__ bool ring_near(const RingLJ& K, const Vec3x2& q) {
 }
 
 // RDF: compile-time mode of the kernel; with_rdf: this frame is one of the observable's frames (wave-uniform)
-template <int LEVEL, int RDF>
+template <int LEVEL, int RDF, int KIND>
 __device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, bool with_rdf, int N, int lane,
-                                           const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g, float& a6, float& a12,
+                                           const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g, float (&th)[MDG_MAX_THETA],
                                            Vec3x2& rq, f32x2* __restrict__ lds) {
     const bool near = ring_near(K, q);
     if constexpr (RDF != 0) {
         if (with_rdf) {
-            if (near) ring_sweep<LEVEL, true, RDF>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
-            else ring_sweep<LEVEL, false, RDF>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+            if (near) ring_sweep<LEVEL, true, RDF, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
+            else ring_sweep<LEVEL, false, RDF, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
             return;
         }
     }
     if constexpr (LEVEL >= 1) {
-        if (near) ring_sweep<LEVEL, true, 0>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
-        else ring_sweep<LEVEL, false, 0>(K, X, N, lane, q, w, f, g, a6, a12, rq, lds);
+        if (near) ring_sweep<LEVEL, true, 0, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
+        else ring_sweep<LEVEL, false, 0, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
     }
 }
 
@@ -346,7 +375,7 @@ __device__ __forceinline__ bool ring_frame_selected(const RingRdfArgs& F, int k)
 // RDF = false: one wave (= one replica) per workgroup.  RDF = true: sixteen waves share the workgroup's fine
 // histogram in LDS and stride over the replicas (persistent grid: the histogram is merged into HBM once per
 // workgroup); the waves are otherwise independent.
-template <bool RDF>
+template <bool RDF, int KIND>
 __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
@@ -380,9 +409,9 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
         ring_store(A.v_t + fr * N3, v, N, lane);
         if (nhc && lane < C) A.pv_t[fr * C + lane] = pv;
         Vec3x2 f, gu, ru, wu = vzero();
-        float u6, u12;
+        float tu[MDG_MAX_THETA];
         // (every force evaluation of the forward pass is at the positions of a stored frame: the RDF rides along)
-        ring_force<1, RDF ? 1 : 0>(K, X, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, u6, u12, ru, lds);
+        ring_force<1, RDF ? 1 : 0, KIND>(K, X, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, tu, ru, lds);
         for (int k = 0; k + 1 < T; ++k) {
             const float dt = A.t[k + 1] - A.t[k];
             // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
@@ -403,7 +432,7 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
             q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
             const float ph = 0.5f * pb * dt, pvh = pv + ph;
             // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-            ring_force<1, RDF ? 1 : 0>(K, X, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, u6, u12, ru, lds);
+            ring_force<1, RDF ? 1 : 0, KIND>(K, X, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, tu, ru, lds);
             const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
             if (nhc) {
                 const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
@@ -435,11 +464,30 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
     }
 }
 
+// parameter gradient of one augmented evaluation: wave totals of the sweep's sums, weighted with the interval
+// (NVE: both half steps carry the first evaluation's term, sovlers.py:82,101)
+template <int KIND>
+__device__ __forceinline__ void ring_theta(const RingLJ& K, const float (&th)[MDG_MAX_THETA], float (&gth)[MDG_MAX_THETA],
+                                           float h, bool nve) {
+    if constexpr (KIND == KIND_LJ126) {
+        const float t6 = wave_sum(th[0]), t12 = wave_sum(th[1]);
+        const float gs = K.tsa * t6 - K.tsb * t12, ge = K.tea * t6 - K.teb * t12;
+        gth[0] += nve ? (gs * 0.5f * h) * 2.f : gs * h;
+        gth[1] += nve ? (ge * 0.5f * h) * 2.f : ge * h;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kind_ntheta(KIND); ++k) {
+            const float tk = wave_sum(th[k]);
+            gth[k] += nve ? (tk * 0.5f * h) * 2.f : tk * h;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ adjoint
 // RDF = true: the frame gradients of the fused observable are produced here -- in the first augmented evaluation
 // of interval i (which sits at frame i) for frames T-1 .. 1, and in one geometry-only sweep for frame 0 -- and
 // added to lam_q where the adjoint adds the incoming g_q (sovlers.py:249, :286).
-template <bool RDF>
+template <bool RDF, int KIND>
 __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
@@ -470,17 +518,19 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
     Vec3x2 lv = A.g_v ? ring_load(A.g_v + (fr + T - 1) * N3, N, lane) : vzero();
     Vec3x2 lq = A.g_q ? ring_load(A.g_q + (fr + T - 1) * N3, N, lane) : vzero();
     float lp = (nhc && lane < C && A.g_pv) ? A.g_pv[(fr + T - 1) * C + lane] : 0.f;
-    float gsig = 0.f, geps = 0.f;
+    float gth[MDG_MAX_THETA];
+#pragma unroll
+    for (int k = 0; k < MDG_MAX_THETA; ++k) gth[k] = 0.f;
     for (int i = T - 1; i >= 1; --i) {
         const float h = A.t[i] - A.t[i - 1];
         Vec3x2 q = ring_load(A.q_t + (fr + i) * N3, N, lane), v = ring_load(A.v_t + (fr + i) * N3, N, lane);
         float pv = (nhc && lane < C) ? A.pv_t[(fr + i) * C + lane] : 0.f;
         Vec3x2 w, f, dq, rq = vzero(), ru;
-        float a6, a12;
+        float th[MDG_MAX_THETA];
         // ---------------- first augmented evaluation at (y_i, lam)
         if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
         const bool with_rdf = RDF && ring_frame_selected(F, i);
-        ring_force<2, RDF ? 2 : 0>(K, X, with_rdf, N, lane, q, w, f, dq, a6, a12, rq, lds);
+        ring_force<2, RDF ? 2 : 0, KIND>(K, X, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
         if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
         if (nhc) {
@@ -505,7 +555,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             pv = pv + 0.5f * (-pb) * h;                               // :135
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
-            ring_force<2, 0>(K, X, false, N, lane, q, w, f, dq, a6, a12, ru, lds);
+            ring_force<2, 0, KIND>(K, X, false, N, lane, q, w, f, dq, th, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
             const float gpm = ring_bath_vjp(A, lane, Qk, pv, lph, slm);
@@ -522,14 +572,10 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             float nlp = lp + gpm * h;                                 // :158
             if (lane < C && A.g_pv) nlp += A.g_pv[(fr + i - 1) * C + lane];
             lp = nlp;
-            const float t6 = wave_sum(a6), t12 = wave_sum(a12);       // :160
-            gsig += (K.tsa * t6 - K.tsb * t12) * h;
-            geps += (K.tea * t6 - K.teb * t12) * h;
+            ring_theta<KIND>(K, th, gth, h, false);                   // :160
         } else {
             // verlet_update backward branch                          sovlers.py:42-101
-            const float t6 = wave_sum(a6), t12 = wave_sum(a12);
-            gsig += ((K.tsa * t6 - K.tsb * t12) * 0.5f * h) * 2.f;    // :82,101
-            geps += ((K.tea * t6 - K.teb * t12) * 0.5f * h) * 2.f;
+            ring_theta<KIND>(K, th, gth, h, true);                    // :82,101
 #define MDG_RING_NVE(c)                                                                      \
             {                                                                                \
                 const f32x2 vhalf = v.c - 0.5f * (-f.c) * h;          /* :49-50 */           \
@@ -541,7 +587,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             }
             MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
 #undef MDG_RING_NVE
-            ring_force<2, 0>(K, X, false, N, lane, q, lvh, f, dq, a6, a12, ru, lds);
+            ring_force<2, 0, KIND>(K, X, false, N, lane, q, lvh, f, dq, th, ru, lds);
             const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
             const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
             lv.x = lvh.x + gv.x; lv.y = lvh.y + gv.y; lv.z = lvh.z + gv.z;
@@ -554,8 +600,8 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         if (ring_frame_selected(F, 0)) {                              // frame 0: no force evaluation there
             const Vec3x2 q = ring_load(A.q_t + fr * N3, N, lane), wu = vzero();
             Vec3x2 fu, gu, rq = vzero();
-            float u6, u12;
-            ring_force<0, 2>(K, X, true, N, lane, q, wu, fu, gu, u6, u12, rq, lds);
+            float tu[MDG_MAX_THETA];
+            ring_force<0, 2, KIND>(K, X, true, N, lane, q, wu, fu, gu, tu, rq, lds);
             lq.x += rq.x; lq.y += rq.y; lq.z += rq.z;
         }
     }
@@ -564,6 +610,8 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
     if (nhc && lane < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + lane] = lp;
     if (lane == 0 && A.adj_theta) {
         float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
-        out[0] = gsig; out[1] = geps;
+#pragma unroll
+        for (int k = 0; k < MDG_MAX_THETA; ++k)
+            if (k < A.terms.t[0].n_theta) out[k] = gth[k];
     }
 }

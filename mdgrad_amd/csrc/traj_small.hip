@@ -731,13 +731,28 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 // asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
 bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
-    // LJ 12-6, or ExcludedVolume with power 12 (the same polynomial with the attractive coefficient c = 0)
-    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind == MDG_PAIR_LJ && t.p == 12 && (t.q == 6 || t.c == 0.f) &&
-           p.n_atoms <= 128;
+    // one unmasked built-in pair form (LJ 12-6 / ExcludedVolume(12) on the even-power polynomial, the others through
+    // pair_eval) in an orthorhombic cell
+    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA && p.n_atoms <= 128;
 }
 bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     return ring_form(p, cell, terms) && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
 }
+int ring_kind(const MdgPairTerm& t) {
+    return (t.kind == MDG_PAIR_LJ && t.p == 12 && (t.q == 6 || t.c == 0.f)) ? KIND_LJ126 : t.kind;
+}
+// launch of a ring kernel specialised on the pair form
+#define MDG_RING_LAUNCH(KERNEL, RDF_, grid, block, lds, st, ...)                                              \
+    do {                                                                                                      \
+        switch (ring_kind(terms->t[0])) {                                                                     \
+        case KIND_LJ126: hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126>), grid, block, lds, st, __VA_ARGS__); break;        \
+        case MDG_PAIR_LJ: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ>), grid, block, lds, st, __VA_ARGS__); break;      \
+        case MDG_PAIR_MORSE: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_MORSE>), grid, block, lds, st, __VA_ARGS__); break; \
+        case MDG_PAIR_BUCK: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_BUCK>), grid, block, lds, st, __VA_ARGS__); break;  \
+        default: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_YUKAWA>), grid, block, lds, st, __VA_ARGS__); break;          \
+        }                                                                                                     \
+    } while (0)
+
 constexpr size_t RING_LDS_FWD = sizeof(f32x2) * 3 * 64;      // per wave: the visitors' positions
 constexpr size_t RING_LDS_ADJ = sizeof(f32x2) * 6 * 64;      //           ... and adjoint directions
 constexpr int RING_RDF_WAVES = 16;                           // waves sharing the fine histogram of the fused RDF
@@ -845,9 +860,8 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
-        MDG_CHECK_ARG(theta, "traj_fwd: null theta");
-        hipLaunchKernelGGL(traj_fwd_ring_kernel<false>, dim3(prm->n_rep), dim3(64), RING_LDS_FWD, (hipStream_t)stream, a,
-                           RingRdfArgs{});
+        MDG_CHECK_ARG(theta || terms->n_theta_total == 0, "traj_fwd: null theta");
+        MDG_RING_LAUNCH(traj_fwd_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_FWD, (hipStream_t)stream, a, RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_fwd_ring_kernel");
         return MDG_OK;
     }
@@ -883,9 +897,8 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
-        MDG_CHECK_ARG(theta, "traj_adj: null theta");
-        hipLaunchKernelGGL(traj_adj_ring_kernel<false>, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ, (hipStream_t)stream, a,
-                           RingRdfArgs{});
+        MDG_CHECK_ARG(theta || terms->n_theta_total == 0, "traj_adj: null theta");
+        MDG_RING_LAUNCH(traj_adj_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ, (hipStream_t)stream, a, RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_adj_ring_kernel");
         return MDG_OK;
     }
@@ -918,7 +931,7 @@ extern "C" int mdg_traj_fwd_small_rdf(const MdgTrajParams* prm, const MdgCell* c
                                       const MdgRdfFuse* rdf, float* raw, void* stream) {
     int rc = validate(prm, cell, terms);
     if (rc) return rc;
-    MDG_CHECK_ARG(theta && mass && t_grid && v0 && q0 && v_t && q_t && raw, "traj_fwd_rdf: null buffer");
+    MDG_CHECK_ARG((theta || terms->n_theta_total == 0) && mass && t_grid && v0 && q0 && v_t && q_t && raw, "traj_fwd_rdf: null buffer");
     MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd_rdf: NHC needs pv0/pv_t");
     RdfFinePlan P;
     MDG_CHECK_ARG(ring_rdf_plan(*prm, *cell, *terms, rdf, &P), "traj_fwd_rdf: not available for this system / observable "
@@ -935,7 +948,7 @@ extern "C" int mdg_traj_fwd_small_rdf(const MdgTrajParams* prm, const MdgCell* c
     int grid = (prm->n_rep + RING_RDF_WAVES - 1) / RING_RDF_WAVES;
     if (grid > 256) grid = 256;                                   // one resident workgroup (16 waves) per CU
     const size_t lds = sizeof(float) * (size_t)((P.nfine + 1) & ~1LL) + RING_RDF_WAVES * RING_LDS_FWD;
-    hipLaunchKernelGGL(traj_fwd_ring_kernel<true>, dim3(grid), dim3(64 * RING_RDF_WAVES), lds, st, a, F);
+    MDG_RING_LAUNCH(traj_fwd_ring_kernel, true, dim3(grid), dim3(64 * RING_RDF_WAVES), lds, st, a, F);
     rc = mdg_rdf_fine_finish(ghist, P, rdf->mu, rdf->nbins, raw, st);
     (void)hipFreeAsync(ghist, st);
     if (rc) return rc;
@@ -951,7 +964,7 @@ extern "C" int mdg_traj_adj_small_rdf(const MdgTrajParams* prm, const MdgCell* c
                                       const MdgRdfFuse* rdf, const float* g_raw, void* stream) {
     int rc = validate(prm, cell, terms);
     if (rc) return rc;
-    MDG_CHECK_ARG(theta && mass && t_grid && v_t && q_t && adj_v0 && adj_q0 && g_raw, "traj_adj_rdf: null buffer");
+    MDG_CHECK_ARG((theta || terms->n_theta_total == 0) && mass && t_grid && v_t && q_t && adj_v0 && adj_q0 && g_raw, "traj_adj_rdf: null buffer");
     MDG_CHECK_ARG(prm->ensemble == 1 || pv_t, "traj_adj_rdf: NHC needs pv_t");
     RdfFinePlan P;
     MDG_CHECK_ARG(ring_rdf_plan(*prm, *cell, *terms, rdf, &P), "traj_adj_rdf: not available for this system / observable "
@@ -968,8 +981,7 @@ extern "C" int mdg_traj_adj_small_rdf(const MdgTrajParams* prm, const MdgCell* c
     if (rc == MDG_OK) {
         RingRdfArgs F = ring_rdf_args(*rdf, P);
         F.tab = tab;
-        hipLaunchKernelGGL(traj_adj_ring_kernel<true>, dim3(prm->n_rep), dim3(64), sizeof(float4) * (size_t)P.ncell + RING_LDS_ADJ,
-                           st, a, F);
+        MDG_RING_LAUNCH(traj_adj_ring_kernel, true, dim3(prm->n_rep), dim3(64), sizeof(float4) * (size_t)P.ncell + RING_LDS_ADJ, st, a, F);
     }
     (void)hipFreeAsync(tab, st);
     if (rc) return rc;

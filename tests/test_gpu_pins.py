@@ -120,6 +120,61 @@ def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
     close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max() + 1e-7, "dL/dtheta")
 
 
+@pytest.mark.parametrize("name,ensemble", [("ljfam_8_4", "nhc"), ("lj69", "nve"), ("exvol10", "nhc"), ("morse_pos", "nhc"),
+                                           ("morse_neg", "nve"), ("buck", "nhc"), ("yukawa", "nhc")])
+def test_ring_kernels_other_pair_forms_vs_oracle(name, ensemble):
+    """Every built-in single-term form on the wave-per-replica kernels (through pair_eval instead of the LJ 12-6
+    polynomial): trajectory, adjoints and parameter gradients of 3 replicas == oracle."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE, NoseHooverChain
+    from test_gpu_parity import form
+    g = load_golden("nhc_traj_lj")
+    R, nT, n_atoms = 3, 7, 108
+    rng = np.random.default_rng(len(name))
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    oracle_of = {"ljfam_8_4": ("lj", [0.95, 1.1], dict(p=8, q=4, c=1)), "lj69": ("lj", [1.0, 1.2], dict(p=9, q=6, c=1)),
+                 "exvol10": ("lj", [1.1, 0.7], dict(p=10, q=0, c=0)), "morse_pos": ("morse", [], dict(a=3.0, phi=1.5)),
+                 "morse_neg": ("morse", [], dict(a=2.5, phi=-1.2)), "buck": ("buck", [1000.0, 3.5, 5.0], {}),
+                 "yukawa": ("yukawa", [1.3, 0.8], {})}[name]
+    mdl = P.Yukawa(epsilon=1.3, kappa=0.8) if name == "yukawa" else form(name)
+    stack = Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)})
+    nhc = ensemble == "nhc"
+    integ = (NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0) if nhc else NVE(stack, system)).to(DEV)
+    spec = integ.fused_spec("NH_verlet" if nhc else "verlet")
+    spec.block = 64
+    pos = np.mod(g["pos"][None] + rng.normal(0, 0.02, (R,) + g["pos"].shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 0.5, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.004 * i for i in range(nT)])
+    v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+    pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True) if nhc else None
+    out = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+    v_t, q_t = out[0], out[1]
+    mdl.zero_grad()
+    nrm = n_atoms * 3
+    loss = (q_t[:, ::2].pow(2).sum((1, 2, 3)) / (4 * nrm) + v_t[:, -1].pow(2).sum((1, 2)) / nrm).sum()
+    if nhc:
+        loss = loss + out[2][:, -1].sum()
+    loss.backward()
+    params = list(mdl.parameters())
+    gth_sum = np.zeros(len(params))
+    for r in range(R):
+        term = O.PairTerm(oracle_of[0], torch.tensor(oracle_of[1]), 2.5, T(g["cell"]), **oracle_of[2])
+        traj, lam, gth = oracle_run(
+            pos[r], g["cell"], vel[r], g["mass"], [term], 1.0, 50.0, 5, t,
+            lambda L: L[1][::2].pow(2).sum() / (4 * nrm) + L[0][-1].pow(2).sum() / nrm + (L[2][-1].sum() if nhc else 0.0),
+            ensemble=ensemble)
+        close(q_t[r], traj[1], 0, 3e-5, "q_t[%d]" % r)
+        close(v_t[r], traj[0], 0, 3e-4, "v_t[%d]" % r)
+        close(v0.grad[r], lam[0], 2e-3, 3e-4 * float(lam[0].abs().max()), "adj v0[%d]" % r)
+        close(q0.grad[r], lam[1], 2e-3, 3e-4 * float(lam[1].abs().max()), "adj q0[%d]" % r)
+        if params:
+            gth_sum += gth.numpy()
+    if params:
+        got = np.array([float(p.grad) for p in params])
+        close(got, gth_sum, 2e-3, 3e-4 * np.abs(gth_sum).max() + 1e-7, "dL/dtheta")
+
+
 # ------------------------------------------------------------------ many-frame RDF kernels
 def _oracle_rdf_chunked(frames, cell, nbins, r_range, width, wgt, chunk=100):
     """g(r) and d(sum g wgt)/dxyz from the oracle, the raw histogram accumulated over chunks of frames."""
