@@ -106,3 +106,29 @@ def test_fit_rdf_gnn_two_ranks_on_one_device():
     assert sums[0][3] == sums[1][3], "ranks diverged: %s" % sums
     losses = [float(x) for x in re.findall(r"loss (\S+) \|", r.stdout)]
     assert len(losses) == 2 and all(np.isfinite(losses))
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py the way the driver launches it for N > 1 (torch.distributed.run, one rank per GPU; here both ranks on
+    cuda:0 with gloo): barrier + max-over-ranks timing, rank 0 prints ONE JSON line with the whole-job rate."""
+    import json
+    import socket
+    env = dict(os.environ, MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1")
+    for attempt in range(2):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+               "--warmup", "2", "--replicas", "1024", "--no-secondary", "--no-cpu-baseline"]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode == 0 or "address already in use" not in (r.stderr + r.stdout).lower():
+            break
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "replica-dp2"
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1024 * 49 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert out["config"]["rdf_fused_into_trajectory_kernels"] is True and "roofline" in out
