@@ -446,6 +446,35 @@ int mdg_nhc_rhs(const float* v, const float* f, const float* pv, const float* ma
 int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, const float* lq, const float* lp,
                 const float* mass, const float* Q, int n_rep, int n_atoms, int n_chains, float* Gv,
                 float* Gp, void* stream);
+/* Whole half-steps of the generic NH-Verlet path (interactions that are not pair-fusable, e.g. SchNet) as single
+ * launches: torchmd/sovlers.py:110-127 (forward) and :129-164 with :253-288 (adjoint interval), the force / force-vjp
+ * evaluations in between stay separate calls.  Time-major frames [T, R*n, 3] / [T, R, C]; idx: device int64[1], the
+ * step k (forward) or frame i (adjoint) -- a captured HIP graph advances it itself; dt = t[k+1] - t[k] is read on the
+ * device.
+ *   mdg_nhv_kick     dv_h = 1/2 a dt, dp_h = 1/2 b dt, qn = q + (v + dv_h) dt           (rhs at (v, q, pv), cached force f)
+ *   mdg_nhv_finish   v += dv_h + 1/2 a1 dt, pv += dp_h + 1/2 b1 dt, q = qn, f = fn ; frame k+1 stored
+ *   mdg_nhv_adj_pre  (v, q, pv) <- frame i ;  w = lam_v / m
+ *   mdg_nhv_adj_mid  vh = v - a hh, qm = q + vh h, pm = pv - b hh, lam_h = lam + G0 hh, wh = lam_h_v / m
+ *   mdg_nhv_adj_end  lam += G1 h + dL/dy_{i-1} */
+int mdg_nhv_kick(const float* v, const float* q, const float* pv, const float* f, const float* mass, const float* Q,
+                 const float* T, float n_dof, const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains,
+                 float* dv_h, float* dp_h, float* qn, void* stream);
+int mdg_nhv_finish(float* v, float* q, float* pv, float* f, const float* dv_h, const float* dp_h, const float* qn,
+                   const float* fn, const float* mass, const float* Q, const float* T, float n_dof, const float* t,
+                   const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* out_v, float* out_q, float* out_pv,
+                   void* stream);
+int mdg_nhv_adj_pre(const float* v_t, const float* q_t, const float* pv_t, const float* lv, const float* mass,
+                    const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* v, float* q, float* pv, float* w,
+                    void* stream);
+int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, const float* lv, const float* lq, const float* lp,
+                    const float* f, const float* dwf, const float* mass, const float* Q, const float* T, float n_dof,
+                    const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* vh, float* qm, float* pm,
+                    float* lvh, float* lqh, float* lph, float* wh, void* stream);
+int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const float* lqh, const float* lph, const float* dwf,
+                    const float* mass, const float* Q, const float* t, const int64_t* idx, const float* g_v,
+                    const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains, float* lv, float* lq,
+                    float* lp, void* stream);
+
 
 #ifdef __cplusplus
 }

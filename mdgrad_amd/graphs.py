@@ -103,6 +103,14 @@ class _ForwardGraph:
 
     def _step(self):
         func, (v, q, pv), F, k = self.func, self.state, self.F, self.k
+        if getattr(func, "fused_steps_ok", lambda *a: False)(v, q, pv):
+            # both halves of the step as one launch each (csrc/nhc.hip): rhs + half kick + drift, force, rhs + finish
+            # + frame store
+            w = func.nhv_work(v, pv)
+            qn = w.kick(v, q, pv, F, self.t, k)
+            w.finish(v, q, pv, F, func.force(qn), self.t, k, self.out)
+            k.add_(1)
+            return
         dt = self.t.index_select(0, k + 1) - self.t.index_select(0, k)
         a0, _, b0 = func.rhs_from_force((v, q, pv), F)
         dv_h = 1 / 2 * a0 * dt
@@ -150,6 +158,21 @@ class _AdjointGraph:
 
     def _interval(self):
         func, lam, i = self.func, self.lam, self.i
+        if getattr(func, "fused_steps_ok", lambda *a: False)(*lam):
+            # sovlers.py:258 (counter / rebuild only), two force-vjp evaluations, three launches of algebra around them
+            w = func.nhv_work(lam[0], lam[2])
+            q, wv = w.adj_pre(self.ans, lam[0], i)
+            func.update_topology(q)
+            func.update_topology(q)
+            F, dwf, _ = func.model.force_vjp(q, wv, want_theta=False)
+            qm, wh = w.adj_mid(lam, F, dwf, self.t, i)
+            func.update_topology(qm)
+            _, dwf1, th1 = func.model.force_vjp(qm, wh)
+            w.adj_end(lam, dwf1, self.t, i, self.gout)
+            if th1:
+                self.gth.add_(_flatten(func.theta_in_parameter_order(th1)) * (self.t.index_select(0, i) - self.t.index_select(0, i - 1)))
+            i.sub_(1)
+            return
         h = self.t.index_select(0, i) - self.t.index_select(0, i - 1)
         v, q, pv = (a.index_select(0, i)[0] for a in self.ans)
         func.update_topology(q)                                   # sovlers.py:258 (counter / rebuild only)

@@ -370,6 +370,25 @@ class NoseHooverChain(_EOM):
         return f_eval, (Gv, dwF_dq, Gp), [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p)
                                          for p in self.parameters()]
 
+    def fused_steps_ok(self, v, q, p_v):
+        """The whole-half-step kernels (csrc/nhc.hip mdg_nhv_*) apply: analytic force / force-vjp from the model,
+        contiguous fp32 device states, chain entries per replica."""
+        return (getattr(self.model, "supports_force_vjp", lambda: False)() and self._hip_algebra(v, q, p_v)
+                and v.is_contiguous() and q.is_contiguous() and p_v.is_contiguous()
+                and 2 <= p_v.shape[-1] <= 16 and v.shape[0] == self.n_rep * self.n_group
+                and getattr(self, "fused_steps", True))
+
+    def nhv_work(self, v, p_v):
+        w = getattr(self, "_nhv_work", None)
+        if w is None or w.dv_h.shape != v.shape or w.dv_h.device != v.device or w.dp_h.shape != p_v.shape:
+            w = self._nhv_work = ops.NhvWork(self, v, p_v)
+        return w
+
+    def theta_in_parameter_order(self, gth):
+        """force_vjp's parameter gradients (model.parameters() order) as a list in self.parameters() order."""
+        by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
+        return [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
+
     def force(self, q):
         """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to
         reuse the force between the second evaluation of step k and the first of step k+1 -- same q,

@@ -721,6 +721,74 @@ def nhc_vjp(v, pv, lv, lq, lp, mass, Q, n_rep, n_group):
     return Gv, Gp
 
 
+def _touched(*tensors):
+    """Tensors a kernel wrote through raw pointers: bump their version counters (md._EOM.update_topology skips a
+    rebuild for the same tensor object at the same version)."""
+    for x in tensors:
+        torch.autograd.graph.increment_version(x)
+
+
+class NhvWork:
+    """Buffers of the fused NH-Verlet half-step kernels (csrc/nhc.hip: mdg_nhv_*) for one integrator: the
+    intermediate states of a forward step / an adjoint interval, allocated once (a captured HIP graph needs fixed
+    addresses anyway)."""
+
+    def __init__(self, integ, like_v, like_pv):
+        z = lambda x: torch.empty_like(x)
+        self.mass, self.Q, self.n_dof = integ.mass, integ.Q, float(integ.N_dof)
+        self.R, self.n, self.C = int(integ.n_rep), int(integ.n_group), int(like_pv.shape[-1])
+        self.dv_h, self.qn, self.dp_h = z(like_v), z(like_v), z(like_pv)
+        self.v, self.q, self.pv, self.w = z(like_v), z(like_v), z(like_pv), z(like_v)
+        self.vh, self.qm, self.pm = z(like_v), z(like_v), z(like_pv)
+        self.lvh, self.lqh, self.lph, self.wh = z(like_v), z(like_v), z(like_pv), z(like_v)
+        self._T = integ._T_device
+
+    def _a(self):
+        return ptr(self.mass), ptr(self.Q), ptr(self._T()), self.n_dof
+
+    def kick(self, v, q, pv, f, t, k):
+        lib = _lib.load()
+        m, Q, T, nd = self._a()
+        check(lib.mdg_nhv_kick(ptr(v), ptr(q), ptr(pv), ptr(f), m, Q, T, nd, ptr(t), ptr(k), self.R, self.n, self.C,
+                               ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn), stream_ptr(v.device)), "mdg_nhv_kick")
+        _touched(self.qn)
+        return self.qn
+
+    def finish(self, v, q, pv, f, fn, t, k, out):
+        lib = _lib.load()
+        m, Q, T, nd = self._a()
+        check(lib.mdg_nhv_finish(ptr(v), ptr(q), ptr(pv), ptr(f), ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn),
+                                 ptr(fn.contiguous()), m, Q, T, nd, ptr(t), ptr(k), self.R, self.n, self.C, ptr(out[0]),
+                                 ptr(out[1]), ptr(out[2]), stream_ptr(v.device)), "mdg_nhv_finish")
+        _touched(v, q, pv, f, *out)
+
+    def adj_pre(self, ans, lv, i):
+        lib = _lib.load()
+        check(lib.mdg_nhv_adj_pre(ptr(ans[0]), ptr(ans[1]), ptr(ans[2]), ptr(lv), ptr(self.mass), ptr(i), self.R, self.n,
+                                  self.C, ptr(self.v), ptr(self.q), ptr(self.pv), ptr(self.w), stream_ptr(lv.device)),
+              "mdg_nhv_adj_pre")
+        _touched(self.q, self.w)
+        return self.q, self.w
+
+    def adj_mid(self, lam, f, dwf, t, i):
+        lib = _lib.load()
+        m, Q, T, nd = self._a()
+        check(lib.mdg_nhv_adj_mid(ptr(self.v), ptr(self.q), ptr(self.pv), ptr(lam[0]), ptr(lam[1]), ptr(lam[2]),
+                                  ptr(f.contiguous()), ptr(dwf.contiguous()), m, Q, T, nd, ptr(t), ptr(i), self.R, self.n,
+                                  self.C, ptr(self.vh), ptr(self.qm), ptr(self.pm), ptr(self.lvh), ptr(self.lqh),
+                                  ptr(self.lph), ptr(self.wh), stream_ptr(f.device)), "mdg_nhv_adj_mid")
+        _touched(self.qm, self.wh)
+        return self.qm, self.wh
+
+    def adj_end(self, lam, dwf, t, i, gout):
+        lib = _lib.load()
+        check(lib.mdg_nhv_adj_end(ptr(self.vh), ptr(self.pm), ptr(self.lvh), ptr(self.lqh), ptr(self.lph),
+                                  ptr(dwf.contiguous()), ptr(self.mass), ptr(self.Q), ptr(t), ptr(i), ptr(gout[0]),
+                                  ptr(gout[1]), ptr(gout[2]), self.R, self.n, self.C, ptr(lam[0]), ptr(lam[1]), ptr(lam[2]),
+                                  stream_ptr(dwf.device)), "mdg_nhv_adj_end")
+        _touched(*lam)
+
+
 # ----------------------------------------------------------------------------- graph ops (SchNet)
 class GraphTopo:
     """Edge topology for the message-passing kernels: ELL list + undirected edge ids + the

@@ -87,6 +87,8 @@ class NHVerlet(FixedGridODESolver):
 
         def eager():
             v, q, pv = self.y0
+            if getattr(func, "fused_steps_ok", lambda *a: False)(v, q, pv):
+                return _nhv_forward(func, self.y0, t)
             frames = [(v, q, pv)]
             F = func.force(q)
             for k in range(t.shape[0] - 1):
@@ -108,6 +110,25 @@ class NHVerlet(FixedGridODESolver):
             if out is not None:
                 return out
         return eager()
+
+
+def _nhv_forward(func, y0, t):
+    """The loop of NHVerlet.integrate with each half of a step as ONE launch (csrc/nhc.hip mdg_nhv_kick /
+    mdg_nhv_finish: rhs + half kick + drift; rhs + finish + frame store) around the force evaluation."""
+    v, q, pv = (x.clone() for x in y0)
+    T = t.shape[0]
+    out = [torch.empty((T,) + tuple(x.shape), device=x.device, dtype=x.dtype) for x in y0]
+    for o, x in zip(out, y0):
+        o[0].copy_(x)
+    F = func.force(q).contiguous().clone()
+    w = func.nhv_work(v, pv)
+    k = torch.zeros(1, dtype=torch.int64, device=v.device)
+    t = t.contiguous()
+    for _ in range(T - 1):
+        qn = w.kick(v, q, pv, F, t, k)
+        w.finish(v, q, pv, F, func.force(qn), t, k, out)
+        k.add_(1)
+    return tuple(out)
 
 
 class Verlet(FixedGridODESolver):
@@ -221,6 +242,27 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
         def eager():
             lam = [g[-1].clone() for g in grad_output]
             gth = torch.zeros_like(flat_params)
+            if getattr(func, "fused_steps_ok", lambda *a: False)(*lam):
+                # per interval: frame gather + w = lam_v / m, force-vjp, midpoint algebra, force-vjp, adjoint update --
+                # three launches of algebra (csrc/nhc.hip mdg_nhv_adj_*) instead of ~45 tensor ops
+                w = func.nhv_work(lam[0], lam[2])
+                frames = [a.contiguous() for a in ans]
+                gout = [g.contiguous() for g in grad_output]
+                tc = t.contiguous()
+                idx = torch.full((1,), T - 1, dtype=torch.int64, device=lam[0].device)
+                for i in range(T - 1, 0, -1):
+                    q, wv = w.adj_pre(frames, lam[0], idx)
+                    func.update_topology(q)                               # :258 (dL/dt call: counter / rebuild only)
+                    func.update_topology(q)
+                    F, dwf, _ = func.model.force_vjp(q, wv, want_theta=False)
+                    qm, wh = w.adj_mid(lam, F, dwf, tc, idx)
+                    func.update_topology(qm)
+                    _, dwf1, th1 = func.model.force_vjp(qm, wh)
+                    w.adj_end(lam, dwf1, tc, idx, gout)
+                    if th1:
+                        gth = gth + _flatten(func.theta_in_parameter_order(th1)) * (t[i] - t[i - 1])   # :160
+                    idx.sub_(1)
+                return lam, gth
             for i in range(T - 1, 0, -1):
                 h = t[i] - t[i - 1]
                 v, q, pv = ans[0][i], ans[1][i], ans[2][i]

@@ -101,7 +101,8 @@ def test_fit_rdf_gnn_two_ranks_on_one_device():
         if r.returncode == 0 or "address already in use" not in (r.stderr + r.stdout).lower():
             break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    sums = re.findall(r"PARAM_CHECKSUM rank (\d) of 2 replicas \[(\d),(\d)\) (\S+)", r.stdout)
+    # (the two ranks' lines can land on one line of the merged stdout: match the number, not "the rest of the line")
+    sums = re.findall(r"PARAM_CHECKSUM rank (\d) of 2 replicas \[(\d),(\d)\) ([-+]?\d\.\d+e[-+]\d+)", r.stdout)
     assert sorted((a, b, c) for a, b, c, _ in sums) == [("0", "0", "2"), ("1", "2", "4")], r.stdout[-1000:]
     assert sums[0][3] == sums[1][3], "ranks diverged: %s" % sums
     losses = [float(x) for x in re.findall(r"loss (\S+) \|", r.stdout)]
