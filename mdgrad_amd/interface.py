@@ -161,12 +161,12 @@ class GNNPotentials(GeneralInteraction):
 
     def force(self, xyz):
         from .nn import analytic
-        return analytic.force(self.gnn, self._z(), xyz, self.inputs['_topo'], self.inputs['offsets'])[1]
+        return analytic.force(self.gnn, self._z(), xyz, self.inputs['_topo'], self.inputs['offsets'], want_energy=False)[1]
 
     def force_vjp(self, xyz, w, want_theta=True):
         from .nn import analytic
         _, F, dq, gth = analytic.force_vjp(self.gnn, self._z(), xyz, w, self.inputs['_topo'], self.inputs['offsets'],
-                                           want_theta=want_theta)
+                                           want_theta=want_theta, want_energy=False)
         return F, dq, gth
 
 

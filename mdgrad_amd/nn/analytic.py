@@ -226,10 +226,23 @@ def _dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None
 
 
 @torch.no_grad()
-def _forward_fused(net, z, x, topo, w=None, want_sums=False):
+def _embedded(net, z):
+    """atom_embed.weight[z], kept until the weights (an optimizer step bumps their version) or the species change: a
+    trajectory evaluates it three times per MD step on the same inputs."""
+    wt = net.atom_embed.weight
+    if wt.is_cuda and torch.cuda.is_current_stream_capturing():
+        return wt.detach()[z]                    # (inside a HIP-graph capture the gather must be part of the graph)
+    key = (wt.data_ptr(), wt._version, z.data_ptr(), z._version, tuple(z.shape))
+    c = getattr(net, "_embed_cache", None)
+    if c is None or c[0] != key:
+        c = net._embed_cache = (key, wt.detach()[z])
+    return c[1]
+
+
+def _forward_fused(net, z, x, topo, w=None, want_sums=False, want_energy=True):
     """Primal (and, with w, forward-mode tangent along x_dot = w) sweep on the fused kernels."""
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
-    r, rd = net.atom_embed.weight[z], None                        # r_dot^0 = 0
+    r, rd = _embedded(net, z), None                               # r_dot^0 = 0
     layers = []
     for conv in net.convolutions:
         P = _layer_params(conv)
@@ -244,13 +257,13 @@ def _forward_fused(net, z, x, topo, w=None, want_sums=False):
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     y, _, yd = _dense(L1, r, bias=l1, x1=rd)
-    U = (_ssp(y).mm(L2.t()) + l2).sum()
+    U = (_ssp(y).mm(L2.t()) + l2).sum() if want_energy else None    # (the integrators only ask for forces)
     return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, y=y, yd=yd, L1=L1, L2=L2, U=U)
 
 
 @torch.no_grad()
-def _force_fused(net, z, x, topo):
-    fw = _forward_fused(net, z, x, topo)
+def _force_fused(net, z, x, topo, want_energy=True):
+    fw = _forward_fused(net, z, x, topo, want_energy=want_energy)
     d = fw["d"]
     rb = _dense(fw["L1"], torch.sigmoid(fw["y"]) * fw["L2"], trans=True)[0]
     dU_dd = torch.zeros_like(d)
@@ -268,8 +281,8 @@ def _force_fused(net, z, x, topo):
 
 
 @torch.no_grad()
-def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
-    fw = _forward_fused(net, z, x, topo, w, want_sums=want_theta)
+def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
+    fw = _forward_fused(net, z, x, topo, w, want_sums=want_theta, want_energy=want_energy)
     d, dd = fw["d"], fw["dd"]
     L1, L2, y, yd, rd = fw["L1"], fw["L2"], fw["y"], fw["yd"], fw["rd"]
     sy = torch.sigmoid(y)
@@ -336,10 +349,10 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True):
 
 
 @torch.no_grad()
-def force(net, z, x, topo, offsets=None):
+def force(net, z, x, topo, offsets=None, want_energy=True):
     if fused_ok(net):
         with _node_blas():
-            return _force_fused(net, z, x.detach().contiguous(), topo)
+            return _force_fused(net, z, x.detach().contiguous(), topo, want_energy)
     topo = _stable(topo)
     with _blas_for(topo):
         fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
@@ -347,13 +360,13 @@ def force(net, z, x, topo, offsets=None):
 
 
 @torch.no_grad()
-def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True):
+def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=True):
     """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()]); the parameter part is skipped
     (None) when want_theta is False.  (`offsets` is the topology's own image-flag array; the argument is
     kept for callers that pass it explicitly.)"""
     if fused_ok(net):
         with _node_blas():
-            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta)
+            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy)
     topo = _stable(topo)
     with _blas_for(topo):
         return _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)
