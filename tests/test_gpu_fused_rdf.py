@@ -179,3 +179,49 @@ def test_single_replica_trajectories_keep_the_plain_observable():
         assert q_t._mdg_traj[3] is None
     for a, b in zip(res[1], res[0]):
         assert torch.equal(a, b)
+
+
+def test_fused_rdf_through_the_reference_api_with_stacked_replicas():
+    """System.replicate(R) + Simulations.simulate + rdf(q_t[::k]) -- the reference's own call sequence on a
+    replica-stacked system ([T, R*N, 3] trajectories): the second pass is fused, its g(r) and parameter gradients
+    equal the unfused ones."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain, Simulations
+    from mdgrad_amd.observable import rdf
+    g = load_golden("nhc_traj_lj")
+    R = 1024
+    base = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    system = base.replicate(R)
+    rng = np.random.default_rng(11)
+    pos0 = np.mod(np.tile(g["pos"], (R, 1)) + rng.normal(0, 0.03, (R * 108, 3)), g["cell"]).astype(np.float32)
+    vel0 = rng.normal(0, 1.0, pos0.shape).astype(np.float32)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5,
+                            Q=50.0).to(DEV)
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    res = {}
+    for fuse in (False, True, True):
+        integ.fuse_observables = fuse
+        system.set_positions(pos0)
+        system.set_velocities(vel0)
+        sim = Simulations(system, integ)
+        v_t, q_t, pv_t = sim.simulate(steps=10, frequency=10, dt=0.005)
+        assert q_t.shape == (10, R * 108, 3)
+        _, _, gr = obs(q_t[::3])
+        mdl.zero_grad()
+        (gr - 1).pow(2).mean().backward()
+        res[fuse] = (gr.detach().clone(), mdl.sigma.grad.clone(), mdl.epsilon.grad.clone(), q_t._mdg_traj[3] is not None)
+    assert res[True][3], "the pass after the registering one must be fused"
+    ref = None
+    integ.fuse_observables = False
+    system.set_positions(pos0)
+    system.set_velocities(vel0)
+    q_ref = Simulations(system, integ).simulate(steps=10, frequency=10, dt=0.005)[1]
+    _, _, gr = obs(q_ref[::3])
+    mdl.zero_grad()
+    (gr - 1).pow(2).mean().backward()
+    assert q_ref._mdg_traj[3] is None
+    close(res[True][0], gr, 2e-5, 2e-5, "g(r): fused vs separate, 4096 frames")
+    close(res[True][1], mdl.sigma.grad, 1e-3, 1e-6, "dsigma")
+    close(res[True][2], mdl.epsilon.grad, 1e-3, 1e-6, "depsilon")
