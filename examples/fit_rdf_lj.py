@@ -38,8 +38,10 @@ def trajectories(system, integ, R, frames, dt, seed, dev):
     vel = rng.normal(0, np.sqrt(1.0 / 1.008), pos.shape).astype(np.float32)
     t = torch.Tensor([dt * i for i in range(frames)]).to(dev)
     spec = integ.fused_spec("NH_verlet")
-    return ops.FusedTrajFn.apply(torch.from_numpy(vel).to(dev), torch.from_numpy(pos).to(dev),
-                                 torch.zeros(R, 5, device=dev), t, spec.flat_params(), spec)
+    # (fused_traj = FusedTrajFn + the bookkeeping that lets `rdf` ride inside the trajectory kernels from the second
+    #  epoch on when there are >= 1 024 replicas: the observable registers itself the first time it sees q_t)
+    return ops.fused_traj(torch.from_numpy(vel).to(dev), torch.from_numpy(pos).to(dev),
+                          torch.zeros(R, 5, device=dev), t, spec.flat_params(), spec)
 
 
 def main(argv=None):
