@@ -34,19 +34,19 @@ def generate_nbr_list(xyz, cutoff, cell, index_tuple=None, ex_pairs=None, get_di
     frames = xyz.reshape(-1, N, 3)
     cellm = torch.as_tensor(cell, dtype=torch.float32, device=xyz.device)
     cellm = torch.diag(cellm) if cellm.dim() == 1 else cellm
-    nbrs, offs, diss = [], [], []
-    for f in range(frames.shape[0]):
-        ell = ops.build_ell(frames[f], cs, cutoff, mask)
-        nbr, off = ell.half_list()
-        if xyz.dim() > 2:
-            nbr = torch.cat([torch.full((nbr.shape[0], 1), f, dtype=nbr.dtype, device=nbr.device), nbr], 1)
-        nbrs.append(nbr)
-        offs.append(off)
-        if get_dis:
-            diss.append(compute_dis(frames[f], nbr[:, -2:], off, cellm).reshape(-1))
-    nbr, off = torch.cat(nbrs), torch.cat(offs)
+    F = frames.shape[0]
+    # all frames in ONE list build: the frames are groups of one stacked system (pairs never cross groups), so the
+    # half list comes out sorted by (frame, i, j) -- the reference's order -- with one host sync for the pair count
+    ell = ops.build_ell(frames.reshape(F * N, 3), cs, cutoff, mask, group=N if F > 1 else None)
+    nbr, off = ell.half_list()
     if get_dis:
-        return nbr, torch.cat(diss), off
+        flat = frames.reshape(F * N, 3)
+        dis = compute_dis(flat, nbr, off, cellm).reshape(-1)
+    if xyz.dim() > 2:
+        frame = torch.div(nbr[:, :1], N, rounding_mode="floor")
+        nbr = torch.cat([frame, nbr - frame * N], 1)
+    if get_dis:
+        return nbr, dis, off
     return nbr, off
 
 
