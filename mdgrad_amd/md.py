@@ -167,6 +167,13 @@ class _EOM(torch.nn.Module):
                 self._topo_q, self._topo_ver, self._topo_stamp = q, q._version, getattr(m, "_topo_stamp", None)
         self.update_count += 1
 
+    def attach_observable(self, obs, start=0, stride=1):
+        """Ask the fused trajectory launches of this integrator to evaluate `obs` (an `observable.rdf`) on the frames
+        start, start + stride, ... of every trajectory from now on -- what the observable otherwise arranges itself
+        the first time it is called on (a time slice of) a fused trajectory.  `attach_observable(None)` detaches;
+        `fuse_observables = False` switches the mechanism off."""
+        self._rdf_hint = None if obs is None else ops.RdfFuse(obs, start, stride)
+
     def fused_spec(self, method):
         """FusedSpec when the whole trajectory can run in the fused HIP kernels, else None."""
         if method != self._method or self.topology_update_freq != 1 or self.dim != 3:

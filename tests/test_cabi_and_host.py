@@ -184,6 +184,13 @@ def test_rdf_recognises_time_slices_of_a_fused_trajectory():
     assert hint_after(lambda q: q[:2], 1, batched) is None           # a replica subset
     assert hint_after(lambda q: q[:, :, :50], 1, batched) is None    # an atom subset
     assert hint_after(lambda q: q.clone(), 1, batched) is None       # a copy carries no tag
+    # explicit registration on an integrator (what the observable otherwise does itself on first use)
+    from mdgrad_amd import md
+    integ = md._EOM()                              # (the integrators' base class: the method needs no device)
+    integ.attach_observable(obs, start=5, stride=5)
+    assert (integ._rdf_hint.start, integ._rdf_hint.stride) == (5, 5) and integ._rdf_hint.obs() is obs
+    integ.attach_observable(None)
+    assert integ._rdf_hint is None
     # a cached histogram is returned only to the observable and frame selection it was made for
     spec, q_t = Spec(), torch.zeros(batched)
     hint = ops.RdfFuse(obs, 0, 2)
