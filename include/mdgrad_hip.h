@@ -431,6 +431,9 @@ int mdg_smear_bwd(const float* gdb, const float* gb, const float* g, const float
 int64_t mdg_atb_workspace(int64_t n_rows, int m, int n);
 int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float* C, float* workspace,
             void* stream);
+/* C = A^T B + A2^T B2 (same shapes; A2 = B2 = NULL: mdg_atb): primal + tangent halves of a weight gradient at once */
+int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, int64_t n_rows, int m, int n, float* C,
+             float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Nose-Hoover-chain algebra of the generic (non-fused) integrator path as single launches

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
+    "mdg_atb2": (C.c_int, [P, P, P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
     "mdg_vacf_workspace": (C.c_int64, [C.c_int]),
     "mdg_vacf_fwd": (C.c_int, [P, C.c_int, C.c_int64, C.c_int, P, P, P]),
     "mdg_vacf_bwd": (C.c_int, [P, P, C.c_int, C.c_int64, C.c_int, P, P]),

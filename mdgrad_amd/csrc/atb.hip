@@ -14,8 +14,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // One wave = one 16-row strip of C (16 values of m) x up to NT column tiles, for one K-slab: the A
 // fragment is loaded once per 4 rows and reused by every column tile; 8 rows are in flight per
 // iteration (two independent accumulator sets hide the 40-cycle dependent MFMA latency).
+// (A2, B2): optional second pair of the same shapes, C = A^T B + A2^T B2 -- the primal + tangent halves of a weight
+// gradient in one launch instead of two products and an add.
 template <int NT>
 __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                          const float* __restrict__ A2, const float* __restrict__ B2,
                                                           long long E, int M, int N, long long slab,
                                                           float* __restrict__ partial) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -32,22 +35,26 @@ __global__ __launch_bounds__(256) void atb_partial_kernel(const float* __restric
     f32x4 acc0[NT], acc1[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    for (long long k = k0; k < k1; k += 8) {
-        const long long r0 = k + lk, r1 = k + 4 + lk;
-        const bool ok0 = r0 < k1, ok1 = r1 < k1;
-        const float a0 = (aok && ok0) ? A[r0 * M + am] : 0.f;
-        const float a1 = (aok && ok1) ? A[r1 * M + am] : 0.f;
-        float b0[NT], b1[NT];
+    for (int pass = 0; pass < (A2 ? 2 : 1); ++pass) {
+        const float* __restrict__ Ap = pass ? A2 : A;
+        const float* __restrict__ Bp = pass ? B2 : B;
+        for (long long k = k0; k < k1; k += 8) {
+            const long long r0 = k + lk, r1 = k + 4 + lk;
+            const bool ok0 = r0 < k1, ok1 = r1 < k1;
+            const float a0 = (aok && ok0) ? Ap[r0 * M + am] : 0.f;
+            const float a1 = (aok && ok1) ? Ap[r1 * M + am] : 0.f;
+            float b0[NT], b1[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int bn = (tn0 + t) * 16 + li;
-            b0[t] = (bn < N && ok0) ? B[r0 * N + bn] : 0.f;
-            b1[t] = (bn < N && ok1) ? B[r1 * N + bn] : 0.f;
-        }
+            for (int t = 0; t < NT; ++t) {
+                const int bn = (tn0 + t) * 16 + li;
+                b0[t] = (bn < N && ok0) ? Bp[r0 * N + bn] : 0.f;
+                b1[t] = (bn < N && ok1) ? Bp[r1 * N + bn] : 0.f;
+            }
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc0[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc1[t], 0, 0, 0);
+            for (int t = 0; t < NT; ++t) {
+                acc0[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[t], acc0[t], 0, 0, 0);
+                acc1[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[t], acc1[t], 0, 0, 0);
+            }
         }
     }
     // C layout: col = lane & 15, row = (lane >> 4) * 4 + r
@@ -95,10 +102,19 @@ extern "C" int64_t mdg_atb_workspace(int64_t n_rows, int m, int n) {
     return (int64_t)atb_splits(n_rows, m, n) * m * n;
 }
 
+extern "C" int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, int64_t n_rows, int m, int n,
+                        float* C, float* workspace, void* stream);
+
 extern "C" int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float* C, float* workspace,
                        void* stream) {
+    return mdg_atb2(A, B, nullptr, nullptr, n_rows, m, n, C, workspace, stream);
+}
+
+extern "C" int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, int64_t n_rows, int m, int n,
+                        float* C, float* workspace, void* stream) {
     MDG_CHECK_ARG(m > 0 && n > 0 && n_rows >= 0, "atb: bad sizes");
     MDG_CHECK_ARG(C && (n_rows == 0 || (A && B && workspace)), "atb: null buffer");
+    MDG_CHECK_ARG((A2 == nullptr) == (B2 == nullptr), "atb: the second pair needs both operands");
     hipStream_t st = (hipStream_t)stream;
     if (n_rows == 0) {
         if (hipMemsetAsync(C, 0, sizeof(float) * (size_t)m * n, st) != hipSuccess) { mdg_set_error("atb: memset failed"); return MDG_ELAUNCH; }
@@ -109,7 +125,7 @@ extern "C" int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, in
     slab = (slab + 7) / 8 * 8;
     const int tiles = atb_units(m, n);
     dim3 grid((tiles + 3) / 4, (unsigned)((n_rows + slab - 1) / slab));
-    hipLaunchKernelGGL(atb_partial_kernel<ATB_NT>, grid, dim3(256), 0, st, A, B, (long long)n_rows, m, n, slab, workspace);
+    hipLaunchKernelGGL(atb_partial_kernel<ATB_NT>, grid, dim3(256), 0, st, A, B, A2, B2, (long long)n_rows, m, n, slab, workspace);
     hipLaunchKernelGGL(atb_reduce_kernel, dim3((m * n * 4 + 255) / 256), dim3(256), 0, st, workspace, (int)grid.y, m * n, C);
     MDG_CHECK_LAUNCH("atb kernels");
     return MDG_OK;

@@ -50,6 +50,15 @@ def _atb(a, b):
     return a.t().mm(b)
 
 
+def _atb_sum(a, b, c, d):
+    """a^T b + c^T d (primal + tangent halves of one weight gradient; c may be None)."""
+    if c is None:
+        return _atb(a, b)
+    if a.is_cuda and a.dtype == torch.float32 and a.shape[0] >= ops.TALL_ROWS:
+        return ops._atb2(a, b, c, d)             # one split-K launch pair instead of two products and an add
+    return a.t().mm(b) + c.t().mm(d)
+
+
 _CAT_EDGES = 65536
 _onehot_cache = {}
 
@@ -82,10 +91,24 @@ def supported(net):
     return True
 
 
+def _gauss_coeff(smear):
+    """-0.5 / width^2 of a (non-trainable, `supported`) GaussianSmearing, computed once: three tiny launches per
+    layer and evaluation otherwise."""
+    w = smear.width
+    key = (w.data_ptr(), w._version)
+    c = getattr(smear, "_mdg_coeff", None)
+    if c is None or c[0] != key:
+        val = (-0.5 / w.detach().pow(2)).contiguous()
+        if w.is_cuda and torch.cuda.is_current_stream_capturing():
+            return val                           # (memory of a graph's private pool must not outlive the capture)
+        c = smear._mdg_coeff = (key, val)
+    return c[1]
+
+
 def _layer_params(conv):
     md = conv.moduledict
     f, n, u = md["message_edge_filter"], md["message_node_filter"], md["update_function"]
-    return dict(mu=f[0].offsets, c=-0.5 / f[0].width.pow(2), W1=f[1].weight, b1=f[1].bias, W2=f[3].weight,
+    return dict(mu=f[0].offsets, c=_gauss_coeff(f[0]), W1=f[1].weight, b1=f[1].bias, W2=f[3].weight,
                 b2=f[3].bias, Wn=n.weight, bn=n.bias, U1=u[0].weight, c1=u[0].bias, U2=u[2].weight, c2=u[2].bias)
 
 
@@ -294,7 +317,7 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
     if want_theta:
         grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
         grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
-        grads[id(ro[0].weight)] = _atb(yb, fw["r"]) + _atb(ydb, rd)
+        grads[id(ro[0].weight)] = _atb_sum(yb, fw["r"], ydb, rd)
         grads[id(ro[0].bias)] = yb.sum(0)
     rdb, _, rb = _dense(L1, ydb, trans=True, x1=yb)
     d_b, dd_b = torch.zeros_like(d), torch.zeros_like(d)
@@ -304,12 +327,12 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
         P = L["P"]
         tdb, _, tb = _dense(P["U2"], rdb, trans=True, x1=rb)
         if want_theta:
-            grads[id(md_["update_function"][2].weight)] = _atb(rb, L["t"]) + _atb(rdb, L["td"])
+            grads[id(md_["update_function"][2].weight)] = _atb_sum(rb, L["t"], rdb, L["td"])
             grads[id(md_["update_function"][2].bias)] = rb.sum(0)
         udb, ub = ops.ssp_dual_bwd_t(L["su"], L["td"], tdb, tb)
         mdb, _, mb = _dense(P["U1"], udb, trans=True, x1=ub)
         if want_theta:
-            grads[id(md_["update_function"][0].weight)] = _atb(udb, L["md"]) + _atb(ub, L["m"])
+            grads[id(md_["update_function"][0].weight)] = _atb_sum(udb, L["md"], ub, L["m"])
             grads[id(md_["update_function"][0].bias)] = ub.sum(0)
         th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta)
         if want_theta:
@@ -325,10 +348,7 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
             # adjoints (hdb, hb) of (hd, h)
             hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
             if want_theta:
-                gWn = _atb(hb, L["r"])
-                if L["rd"] is not None:
-                    gWn = gWn + _atb(hdb, L["rd"])
-                grads[id(md_["message_node_filter"].weight)] = gWn
+                grads[id(md_["message_node_filter"].weight)] = _atb_sum(hb, L["r"], hdb if L["rd"] is not None else None, L["rd"])
                 grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
             rdb, _, rb = _dense(P["Wn"], hdb, trans=True, res=rdb, x1=hb, res1=rb)
     # dd_b = dU/dd (see the module docstring): force and d(w.F)/dx from one scatter

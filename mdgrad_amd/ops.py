@@ -952,6 +952,20 @@ def _atb(A, B):
     return out
 
 
+def _atb2(A, B, A2, B2):
+    """A^T B + A2^T B2 (same shapes) in one split-K launch pair (csrc/atb.hip mdg_atb2)."""
+    lib = _lib.load()
+    for x, nm in ((A, "A"), (B, "B"), (A2, "A2"), (B2, "B2")):
+        require_gpu(x, nm)
+    A, B, A2, B2 = A.contiguous(), B.contiguous(), A2.contiguous(), B2.contiguous()
+    E, M, N = A.shape[0], A.shape[1], B.shape[1]
+    assert A2.shape == A.shape and B2.shape == B.shape, "atb2: the two pairs must have the same shapes"
+    out = torch.empty(M, N, device=A.device)
+    ws = torch.empty(max(1, int(lib.mdg_atb_workspace(E, M, N))), device=A.device)
+    check(lib.mdg_atb2(ptr(A), ptr(B), ptr(A2), ptr(B2), E, M, N, ptr(out), ptr(ws), stream_ptr(A.device)), "mdg_atb2")
+    return out
+
+
 class MMFn(torch.autograd.Function):
     """A[E,K] @ W[K,N] on the library GEMM (tall A: fine there); its weight gradient is the tall-skinny
     A^T g, which goes to AtBFn.  {MMFn, AtBFn} is closed under differentiation."""

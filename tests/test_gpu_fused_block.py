@@ -246,3 +246,15 @@ def test_large_system_eager_pass_on_fixed_capacity_lists_equals_exact_lists():
     for k in (1, 2):
         for a, b, nm in zip(res[k], res[0], ("v_t", "q_t", "pv_t", "dL/dtheta")):
             close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "%s, mode %d" % (nm, k))
+
+
+def test_atb2_kernel():
+    """mdg_atb2: a^T b + a2^T b2 in one split-K launch pair -- against torch."""
+    from mdgrad_amd import ops
+    torch.manual_seed(5)
+    for rows, m, n in ((4096, 64, 128), (32768, 128, 64), (300, 30, 7)):
+        A, A2 = torch.randn(rows, m, device=DEV), torch.randn(rows, m, device=DEV)
+        B, B2 = torch.randn(rows, n, device=DEV), torch.randn(rows, n, device=DEV)
+        ref = (A.double().t() @ B.double() + A2.double().t() @ B2.double()).float()
+        _close(ops._atb2(A, B, A2, B2), ref, "atb2")
+        assert torch.equal(ops._atb2(A, B, A2, B2), ops._atb2(A, B, A2, B2)), "bitwise reproducible"
