@@ -120,6 +120,45 @@ def test_ring_kernels_odd_sizes_and_nve_vs_oracle(n_atoms, ensemble):
     close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max() + 1e-7, "dL/dtheta")
 
 
+def test_ring_kernels_unwrapped_positions_vs_oracle():
+    """Atoms outside the [-0.24, 1.24] cell window send the ring sweep to the clamped minimum image (the reference's
+    -[s > .5] + [s < -.5], one image only): a third of the atoms shifted by a whole cell, forward + adjoint + fused
+    RDF against the oracle."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    g = load_golden("nhc_traj_lj")
+    R, nT = 2, 7
+    rng = np.random.default_rng(3)
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5,
+                            Q=50.0).to(DEV)
+    spec = integ.fused_spec("NH_verlet")
+    spec.block = 64
+    pos = np.mod(g["pos"][None] + rng.normal(0, 0.03, (R,) + g["pos"].shape), g["cell"]).astype(np.float32)
+    pos[:, ::3, 0] += g["cell"][0]                        # unwrapped: one cell to the right
+    pos[:, 1::5, 2] -= g["cell"][2]                       # ... and one down
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(nT)])
+    v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+    pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True)
+    v_t, q_t, pv_t = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+    mdl.zero_grad()
+    (q_t[:, ::2].pow(2).sum() / 1296 + v_t[:, -1].pow(2).sum() / 324).backward()
+    gth_sum = np.zeros(2)
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+        traj, lam, gth = oracle_run(pos[r], g["cell"], vel[r], g["mass"], [term], 1.0, 50.0, 5, t,
+                                    lambda L: L[1][::2].pow(2).sum() / 1296 + L[0][-1].pow(2).sum() / 324)
+        close(q_t[r], traj[1], 0, 4e-5, "q_t[%d]" % r)
+        close(v0.grad[r], lam[0], 1e-3, 2e-4 * float(lam[0].abs().max()), "adj v0[%d]" % r)
+        close(q0.grad[r], lam[1], 1e-3, 2e-4 * float(lam[1].abs().max()), "adj q0[%d]" % r)
+        gth_sum += gth.numpy()
+    got = np.array([float(mdl.sigma.grad), float(mdl.epsilon.grad)])
+    close(got, gth_sum, 1e-3, 2e-4 * np.abs(gth_sum).max(), "dL/dtheta")
+
+
 @pytest.mark.parametrize("chains", [2, 3, 16])
 def test_ring_kernels_chain_lengths_vs_oracle(chains):
     """The thermostat chain lives one entry per lane in the ring kernels (DPP row shifts between neighbours): the
