@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VEC_F32_PEAK_TF = 157.3      # MI355X_MICROARCH.md: fp32 vector (packed v_pk_fma_f32) = fp32 MFMA peak, TFLOP/s
 MFMA_F32_PEAK_TF = 157.3
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
 # arithmetic of one directed pair in the adjoint's fused sweep (force + Hessian.w + d/dtheta, csrc/traj_small.hip
 # force_lj126_packed LEVEL 2): minimum image 12, d^2 5, 1/d^2 and the even-power polynomial 14, force 6, w-difference
 # and projections 11, Hessian terms 14, theta sums 8  ~= 70 flop
@@ -410,7 +411,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     NN, E = topo.n_atoms, topo.n_edges
     conv = net.convolutions[0]
     Pm = analytic._layer_params(conv)
-    fn = ops.FilterNet(Pm["mu"], Pm["c"], Pm["W1"], Pm["b1"], Pm["W2"], Pm["b2"])
+    fn = ops.FilterNet(Pm["mu"], Pm["c"], Pm["W1"], Pm["b1"], Pm["W2"], Pm["b2"], bf16=bool(args.bf16))
     x = torch.Tensor(system.get_positions()).to(dev)
     w = torch.randn(NN, 3, device=dev)
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
@@ -425,21 +426,31 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     k_ms = e0.elapsed_time(e1) / 10
     tiles = int(((topo.ell.cnt + 15) // 16).sum())
     GP, FT = (32 if G_ <= 32 else 64), (4 if F_ <= 64 else 8)
-    mfma_per_tile = 2 * (GP // 4) * (GP // 16) + 2 * (GP // 4) * FT        # primal + tangent, both Dense layers
-    executed = tiles * mfma_per_tile * 2048.0
+    if args.bf16:                                   # v_mfma_f32_16x16x32_bf16: K = 32 per instruction, 16384 flop
+        mfma_per_tile = 2 * (GP // 32) * (GP // 16) + 2 * (GP // 32) * FT
+        executed, peak, insn = tiles * mfma_per_tile * 16384.0, MFMA_BF16_PEAK_TF, "v_mfma_f32_16x16x32_bf16 x 16384"
+        kname = "cfconv_fwd_bf16_kernel<32,8,true>"
+    else:                                           # v_mfma_f32_16x16x4_f32: 2048 flop
+        mfma_per_tile = 2 * (GP // 4) * (GP // 16) + 2 * (GP // 4) * FT    # primal + tangent, both Dense layers
+        executed, peak, insn = tiles * mfma_per_tile * 2048.0, MFMA_F32_PEAK_TF, "v_mfma_f32_16x16x4_f32 x 2048"
+        kname = "cfconv_fwd_kernel<32,8,true>"
     useful = 2.0 * (2 * E) * 2.0 * G_ * (G_ + F_)                            # directed slots x (primal + tangent)
     step_flops = 21.0 * schnet_flops_forward(N, E / R, A_, F_, G_, NC) * R * (T - 1)
     out["roofline"] = {
-        "bound": "mfma", "kernel": "cfconv_fwd_kernel<32,8,true> (filter MLP + gather-multiply-sum, primal + tangent)",
-        "achieved": executed / (k_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-        "frac": executed / (k_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "traffic": None, "kernel_ms": k_ms,
+        "bound": "mfma", "kernel": kname + " (filter MLP + gather-multiply-sum, primal + tangent)",
+        "achieved": executed / (k_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+        "frac": executed / (k_ms * 1e-3) / 1e12 / peak, "traffic": None, "kernel_ms": k_ms,
         "useful_tflops": useful / (k_ms * 1e-3) / 1e12,
         "step_mfma_frac": step_flops / (el / steps) / 1e12 / MFMA_F32_PEAK_TF,
         "step_tflops": step_flops / (el / steps) / 1e12,
-        "note": "executed = %d 16-slot tiles x %d v_mfma_f32_16x16x4_f32 x 2048 flop (G padded to %d; every undirected edge "
+        "note": "executed = %d 16-slot tiles x %d %s flop (G padded to %d; every undirected edge "
                 "is evaluated from both ends: no [E,F] tensor in HBM); useful = 2 x 2E x 2G(G+F), E = %d edges.  "
-                "step_* = SURVEY 8d's 21 x forward flops per MD step over the measured step time" % (
-                    tiles, mfma_per_tile, GP, E)}
+                "step_* = SURVEY 8d's 21 x forward flops per MD step over the measured step time, priced against the f32 "
+                "MFMA peak%s" % (tiles, mfma_per_tile, insn, GP, E,
+                                 "; with bf16 operands the Dense layers shrink to 20 MFMAs per tile and the kernel is bound by "
+                                 "its f32 VALU work (2G exp2 per slot for the Gaussians and their tangents, the ssp activations, "
+                                 "the multiply with the gathered rows), so frac against the 2.5 PF bf16 peak is small by "
+                                 "construction" if args.bf16 else "")}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_schnet()
     return out

@@ -30,8 +30,10 @@ constexpr int LG_WAVES_CELL = 4;             // ... cell-binned scan: small work
 constexpr int LG_BLOCK = LG_WAVES * 64;
 constexpr int LG_TILE = 2048;               // positions staged in LDS per pass
 constexpr int LG_CAP = 256;                  // per-wave neighbour buffer (entries)
-constexpr int LG_LIST = 96;                  // stored neighbour indices per atom and frame (forward -> adjoint reuse)
-constexpr float LG_SKIN = 0.04f;             // skin of the stored lists, as a fraction of the largest cutoff
+constexpr int LG_LIST = 128;                 // stored neighbour indices per atom and list build
+constexpr float LG_SKIN = 0.12f;             // skin of the stored lists, as a fraction of the largest cutoff
+constexpr float LG_REUSE = 0.45f;            // the forward pass searches again once an atom has moved this fraction of the skin
+                                             // (< 1/2: room for the adjoint's midpoint states between two frames)
 constexpr long long LG_LIST_MAX_WORDS = 1ll << 31;   // at most 8 GiB of stored lists; beyond that the adjoint searches again
 constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
 constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
@@ -62,15 +64,22 @@ struct LargeArgs {
     int32_t* bcount;                         // [2][R][LG_MAX_CELLS] ping-pong bin counters
     int32_t* binslot;                        // [R][N] (slot << 12) | bin
     int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
-    // neighbour lists of the forward pass, kept for the adjoint (nullptr: not kept).  The forward force evaluation at
-    // frame k searches with cutoff (1 + LG_SKIN) rc and stores the ascending indices; the adjoint's two evaluations
-    // of interval k gather those candidates and re-apply the exact cutoff test -- the same pair set as a fresh
-    // search as long as no atom has moved more than skin/2 since frame k (the midpoint state: checked on the device
-    // by large_prep<3>; flags[5] then asks the caller for an adjoint with fresh searches) -- instead of two more
-    // searches + sorts.
+    // neighbour lists of the forward pass, kept for the adjoint (nullptr: not kept).  A forward search uses the cutoff
+    // (1 + LG_SKIN) rc and stores the ascending indices; later forward steps and the adjoint's two evaluations per
+    // interval gather those candidates and re-apply the exact cutoff test -- the same pair set as a fresh search as
+    // long as no atom has moved more than skin/2 since the build (forward frames: by construction, see nl_build; the
+    // adjoint's midpoint states: checked on the device by large_prep<3>; flags[5] then asks the caller for an adjoint
+    // with fresh searches).
     int32_t* nl_idx;                         // [R][T][N][LG_LIST]
     int32_t* nl_cnt;                         // [R][T][N]
     int32_t* nl_bad;                         // [R][T]  an atom of this frame had more than LG_LIST candidates
+    // Verlet reuse: a list serves every later frame until an atom has moved LG_REUSE x skin from its build positions
+    // (checked on the device by large_prep<1>, which then asks the next force launch for a search).  Forces over a
+    // stored list re-apply the exact cutoff test: the pair set of every evaluation is the one a fresh search gives
+    // (topology_update_freq = 1, sovlers.py:114) -- the search itself runs every few steps only.
+    int32_t* nl_build;                       // [R][T]  the frame whose stored rows serve frame f
+    int32_t* nl_state;                       // [R][2]  {the coming force launch searches, frame of the current list}
+    int nbL;                                 // workgroups (partial rows) of the listed force launches
     float skin;                              // absolute skin (0: lists not kept)
 };
 
@@ -173,8 +182,14 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         const int k = A.step;
         const float dt = A.t[k + 1] - A.t[k];
         float* pv = A.pv + rep * MDG_MAX_CHAINS;
+        const bool lists = A.nl_idx != nullptr;
+        // (the previous force launch was a search with nbF workgroups or a listed one with nbL)
+        const int rows = (lists && !A.nl_state[2 * rep]) ? A.nbL : A.nbF;
+        const int bfr = lists ? A.nl_state[2 * rep + 1] : 0;
+        const float* qb = A.q_t + ((size_t)rep * T + bfr) * N * 3;      // positions the current list was built at
+        float far2 = 0.f;
         if (nhc) {
-            const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, A.nbF, 1, 0, red);
+            const float ke = 0.5f * reduce_partials(A.partA + (size_t)rep * A.nbF, rows, 1, 0, red);
             if (threadIdx.x < C) pvs[threadIdx.x] = pv[threadIdx.x];
             __syncthreads();
             if (first && threadIdx.x < C) {
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
-                float qn[3];
+                float qn[3], mv2 = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const size_t e = so + 3 * a + c;
@@ -202,12 +217,23 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                     A.q[e] = qn[c];
                     const float ph2 = (ve + h) * m;
                     part += ph2 * ph2 / m;
+                    if (lists) { const float mv = qn[c] - qb[3 * a + c]; mv2 = fmaf(mv, mv, mv2); }
                 }
+                far2 = fmaxf(far2, mv2);
                 px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
             }
         }
         part = block_sum(part, red);
-        if (threadIdx.x == 0) A.partB[rep] = part;                     // (one workgroup per replica in this phase)                     // (nbE = 1: KE(v + vh) for the force launch)
+        if (threadIdx.x == 0) A.partB[rep] = part;                     // (one workgroup per replica in this phase; nbE = 1: KE(v + vh) for the force launch)
+        if (lists) {
+            // the current list still holds every pair inside the cutoff unless an atom has left its LG_REUSE x skin ball
+            // (or the build was incomplete): then the coming force launch searches, and the positions are binned for it
+            // (the last frame has no successor whose build could serve its midpoint: it keeps a wider margin itself)
+            const float lim = (k + 2 >= T ? 0.5f * LG_REUSE : LG_REUSE) * A.skin;
+            const int search = __syncthreads_or(!(far2 <= lim * lim)) || A.nl_bad[(size_t)rep * T + bfr] != 0;
+            if (threadIdx.x == 0) A.nl_state[2 * rep] = search;
+            if (!search) return;
+        }
     }
     if constexpr (PHASE == 2 || PHASE == 4) {
         const int i_fr = A.step + 1;                                   // the interval being finished
@@ -278,6 +304,14 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     if constexpr (PHASE == 3) {
         const int i_fr = A.step;
         const size_t fo = ((size_t)rep * T + i_fr) * N * 3;
+        // The reference's backward half step drifts with the state's own velocity (sovlers.py:138 under the negated
+        // dynamics): the NHC "midpoint" positions lie about one step AHEAD of frame i -- next to frame i + 1, whose
+        // list may be a newer build.  Both builds are candidates; the distance to each is measured here and the
+        // midpoint launch (large_adj_listed, second = 1) takes one that holds.
+        const int slotA = A.nl_idx ? A.nl_build[(size_t)rep * T + i_fr] : i_fr;
+        const int slotB = (A.nl_idx && i_fr + 1 < T) ? A.nl_build[(size_t)rep * T + i_fr + 1] : slotA;
+        const float* qbA = A.q_t + ((size_t)rep * T + slotA) * N * 3;
+        const float* qbB = A.q_t + ((size_t)rep * T + slotB) * N * 3;
         const float h = A.t[i_fr] - A.t[i_fr - 1];
         float tot[LG_NV];
         sum_partial_rows(A.partN + (size_t)rep * A.nbF * LG_NV, A.nbF, tot, redN);
@@ -305,13 +339,13 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                     if (m < A.terms.n_terms && p < A.terms.t[m].n_theta)
                         A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += (tot[m * MDG_MAX_THETA + p] * 0.5f * h) * 2.f;
         }
-        float far2 = 0.f;                                           // largest |q_mid - q_frame|^2 of this thread's atoms
+        float far2 = 0.f, far2B = 0.f;                              // largest |q_mid - q_build|^2 of this thread's atoms
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
-                float qn[3], mv2 = 0.f;
+                float qn[3], mv2 = 0.f, mv2B = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const size_t e = so + 3 * a + c, ef = fo + 3 * a + c;
@@ -334,18 +368,24 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                         A.lqh[e] = A.lq[e] + dx;
                     }
                     A.qm[e] = qn[c];
-                    const float mv = qn[c] - A.q_t[ef];
+                    const float mv = qn[c] - qbA[3 * a + c], mvB = qn[c] - qbB[3 * a + c];
                     mv2 = fmaf(mv, mv, mv2);
+                    mv2B = fmaf(mvB, mvB, mv2B);
                 }
                 far2 = fmaxf(far2, mv2);
+                far2B = fmaxf(far2B, mv2B);
                 px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
             }
         }
         if (A.nl_idx) {
-            // the stored candidates of frame i_fr (searched with rc + skin) stay a superset of the midpoint's pair set
-            // while no atom has moved more than skin / 2; otherwise the midpoint evaluation searches again
-            const int moved = __syncthreads_or(!(far2 <= 0.25f * A.skin * A.skin));
-            if (moved && threadIdx.x == 0) A.flags[5] = 1;              // the caller repeats the adjoint with searches
+            // the stored candidates that serve frame i_fr (searched with rc + skin) stay a superset of the midpoint's pair
+            // set while no atom is farther than skin / 2 from where the list was built
+            const float lim2 = 0.25f * A.skin * A.skin;
+            const int movedA = __syncthreads_or(!(far2 <= lim2)), movedB = __syncthreads_or(!(far2B <= lim2));
+            if (threadIdx.x == 0) {                                     // (several workgroups share a replica here)
+                if (movedA) atomicOr(&A.nl_state[2 * rep], 1);
+                if (movedB) atomicOr(&A.nl_state[2 * rep + 1], 1);
+            }
             return;
         }
     }
@@ -414,7 +454,7 @@ __device__ __forceinline__ void pair_terms(const LargeArgs& A, const TermConst (
         PairOut o;
         float r, ir;
         pair_eval<LEVEL, KIND>(tc[m], d2, r, ir, o);
-        if (tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
+        if (KIND < 0 && tc[m].kind == MDG_PAIR_TABLE && d2 < tc[m].k0) A.flags[3] = 1;   // below the first table node
         const float c1 = o.du * ir;
         fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
         if (LEVEL >= 2) {
@@ -423,7 +463,7 @@ __device__ __forceinline__ void pair_terms(const LargeArgs& A, const TermConst (
             const float a = rx * ax + ry * ay + rz * az;
             const float c2 = o.d2u * a - c1 * a;
             gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
-            if (tc[m].kind == MDG_PAIR_TABLE) {
+            if (KIND < 0 && tc[m].kind == MDG_PAIR_TABLE) {
                 // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (two int32
                 // planes, see traj_small.hip) with integer global atomics: order-independent
                 if (gw != 0.f) {
@@ -448,49 +488,12 @@ __device__ __forceinline__ void pair_terms(const LargeArgs& A, const TermConst (
     }
 }
 
-// The adjoint's evaluation over the STORED candidates of frame `frame` (no search, no LDS buffer): lane k takes
-// stored candidate k; its position, adjoint direction and mass are requested together, and the row is read before
-// the count is known -- two dependent round trips per atom.  Exact cutoff test per term as everywhere.
-template <bool DIAG, int LEVEL, int KIND>
-__device__ __forceinline__ void wave_list_force(
-    const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
-    float& fx, float& fy, float& fz, float& gx, float& gy, float& gz, float (&th)[LG_KMAX],
-    const TermConst (&tc)[MDG_MAX_TERMS], float gw, int rep, int frame) {
-    const int N = A.prm.n_atoms, lane = threadIdx.x & 63;
-    const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
-    int n = 0;
-    fx = fy = fz = gx = gy = gz = 0.f;
-    if (!valid) return;
-    const size_t at = ((size_t)rep * A.prm.n_frames + frame) * N + i;
-    const int32_t* idx = A.nl_idx + at * LG_LIST;
-    const int j0 = idx[lane];                                   // (LG_LIST >= 64: inside the row)
-    n = A.nl_cnt[at];
-    const bool nhc_l = A.prm.ensemble == 0;
-    float wxi = 0.f, wyi = 0.f, wzi = 0.f;
-    if (LEVEL >= 2) { const float im = nhc_l ? 1.0f / A.mass[i] : 1.0f; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
-    const int ntl = A.terms.n_terms;
-    for (int k = lane; k < n; k += 64) {
-        const int j = k < 64 ? j0 : idx[k];
-        float dx = q[3 * j] - xi, dy = q[3 * j + 1] - yi, dz = q[3 * j + 2] - zi;           // D = x_j - x_i
-        float lx = 0.f, ly = 0.f, lz = 0.f, jm = 1.f;
-        if (LEVEL >= 2) { lx = lam[3 * j]; ly = lam[3 * j + 1]; lz = lam[3 * j + 2]; if (nhc_l) jm = 1.0f / A.mass[j]; }
-        min_image<DIAG>(A.cell, dx, dy, dz);
-        const float d2 = norm2_ref(dx, dy, dz);
-        if (d2 == 0.f) continue;                                 // topology.py:67
-        pair_terms<LEVEL, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, lx * jm, ly * jm, lz * jm, gw, rep,
-                                fx, fy, fz, gx, gy, gz, th);
-    }
-    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
-    if (LEVEL >= 2) { gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); }
-    return;
-}
-
 // ---------------------------------------------------------------------------------------------
 // One wave: neighbours of atom i from the LDS-staged tiles, then force (LEVEL 1) or force + HVP +
 // parameter vjp (LEVEL 2) over the compact list.  Results valid on every lane after the call.
 //   F_i = -dU/dq_i ; dq_i = d(w.F)/dq_i = -(H w)_i with w = lam_v / m (NVE: w = lam_v) ; th += d(w.F)/dtheta partial
 // LIST 0: search (cutoff^2 = rc2max).  LIST 1 (forward): search, then store the ascending indices for frame `frame`
-// (wave_list_force is the adjoint's consumer).
+// (large_adj_listed is the adjoint's consumer).
 template <bool DIAG, int LEVEL, int KIND = -1, int LIST = 0>
 __device__ __forceinline__ void wave_neighbours_and_force(
     const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid,
@@ -686,12 +689,19 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y;
+    if (MODE == 1 && A.nl_idx && !A.nl_state[2 * rep]) return;      // the current list serves this step (large_fwd_listed)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t so = (size_t)rep * N * 3;
     float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; float* f = A.f + so;
     float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
     float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
     const int k = A.step;
+    if (A.nl_idx && blockIdx.x == 0 && threadIdx.x == 0) {          // this launch builds the list of frame k + 1 (0)
+        const int frame = MODE == 0 ? 0 : k + 1;
+        A.nl_build[(size_t)rep * T + frame] = frame;
+        A.nl_state[2 * rep + 1] = frame;
+        if (MODE == 0) A.nl_state[2 * rep] = 1;
+    }
     if (threadIdx.x < MDG_MAX_CHAINS) {
         float qv = 0.f;
 #pragma unroll
@@ -749,13 +759,134 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = kepart;
 }
 
+// Second half of step k over the CURRENT list (large_prep<1> found every atom inside its reuse ball): the same four-
+// atoms-per-wave rows as large_adj_listed below, force only, then large_force_step<1>'s epilogue.  Exits at once when
+// this step searched instead.
+struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };      // one [3] row of a [N][3] array: global_load_dwordx3
+__device__ __forceinline__ Row3 row3(const float* __restrict__ a, int j) { return *reinterpret_cast<const Row3*>(a + 3 * (size_t)j); }
+
+constexpr int LG_ROW_ATOMS = 16;                 // atoms per workgroup of the listed kernels (4 waves x 4 rows)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, on every lane of the row (row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2])
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_get<0x128>(v);
+    v += dpp_get<0x124>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0xB1>(v);
+    return v;
+}
+// ... then across the four rows: v_permlane16_swap / v_permlane32_swap hand each half its partner's sum
+__device__ __forceinline__ float wave_sum_rows(float v) {
+    v = row16_sum(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+template <bool DIAG, int KIND>
+__global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
+    constexpr int NP = LG_LIST / 16;
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
+    if (A.nl_state[2 * rep]) return;                                   // this step searched (large_force_step<1>)
+    const int slot = A.nl_state[2 * rep + 1];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15;
+    const size_t so = (size_t)rep * N * 3;
+    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; float* f = A.f + so;
+    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
+    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
+    const bool nhc = A.prm.ensemble == 0;
+    const float dt = A.t[k + 1] - A.t[k];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) A.nl_build[(size_t)rep * T + k + 1] = slot;
+        if (nhc) {                                                      // finish the bath with KE(v + vh), as large_force_step<1>
+            if (threadIdx.x < MDG_MAX_CHAINS) {
+                float qv = 0.f;
+#pragma unroll
+                for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+                Qs[threadIdx.x] = qv;
+            }
+            const float ke = 0.5f * reduce_partials(A.partB + (size_t)rep * A.nbE, A.nbE, 1, 0, red);
+            if (threadIdx.x < C) pvs[threadIdx.x] = pvh[threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const float b1 = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+                const float np = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
+                pv[threadIdx.x] = np;
+                A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = np;
+            }
+            __syncthreads();
+        }
+    }
+    TermConst tc[MDG_MAX_TERMS];
+    if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
+    else prepare_terms(A, tc);
+    const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
+    const int i = (blockIdx.x * 4 + wid) * 4 + (lane >> 4);
+    const bool valid = i < N;
+    const int ic = valid ? i : N - 1;
+    const size_t at = ((size_t)rep * T + slot) * N + ic;
+    const int32_t* idx = A.nl_idx + at * LG_LIST;
+    int jj[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) jj[p] = idx[s + 16 * p];
+    const int n = valid ? min(A.nl_cnt[at], LG_LIST) : 0;
+    const Row3 qi = row3(q, ic);
+    float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+    int jn = s < n ? jj[0] : ic;
+    Row3 qn = row3(q, jn);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+        const int j = jn;
+        float dx = qn.x - qi.x, dy = qn.y - qi.y, dz = qn.z - qi.z;
+        if (p + 1 < NP) {
+            jn = s + 16 * (p + 1) < n ? jj[p + 1] : ic;
+            qn = row3(q, jn);
+        }
+        min_image<DIAG>(A.cell, dx, dy, dz);
+        const float d2 = norm2_ref(dx, dy, dz);
+        if (d2 == 0.f) continue;
+        pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx, gy, gz, th);
+    }
+    fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
+    float kepart = 0.f;
+    if (valid && s < 3) {
+        const float F = s == 0 ? fx : (s == 1 ? fy : fz);
+        const int e = 3 * i + s;
+        const float m = A.mass[i];
+        const float vv = v[e] + vh[e];
+        const float p = vv * m;
+        const float a = nhc ? (F - pvh[0] * p / A.prm.Q[0]) / m : F;          // (NVE: md.py:145-148, no 1/m)
+        const float vn = v[e] + (vh[e] + 0.5f * a * dt);
+        v[e] = vn;
+        f[e] = F;
+        const size_t fr = ((size_t)rep * T + k + 1) * N * 3 + e;
+        A.q_t[fr] = q[e];
+        A.v_t[fr] = vn;
+        const float pn = vn * m;
+        kepart = pn * pn / m;
+        if (!(isfinite(vn) && isfinite(F))) A.flags[1] = 1;
+    }
+    kepart = wave_sum_rows(kepart);
+    if (lane == 0) red[wid] = kepart;
+    __syncthreads();
+    if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
-// LISTED: the candidates are the forward pass's stored indices of frame A.step (no LDS, lean registers); a frame whose
-// list overflowed, or a midpoint that moved past the skin (flagged by large_prep<3>), raises flags[5]: the caller
-// repeats the adjoint with searches (MdgTrajParams.block = -1).
-template <bool DIAG, int KIND, bool LISTED>
-__global__ __launch_bounds__(LG_BLOCK) __attribute__((amdgpu_waves_per_eu(LISTED ? 6 : 4, 8)))
+// by a fresh search (large_adj_listed below evaluates the forward pass's stored candidates instead).
+template <bool DIAG, int KIND>
+__global__ __launch_bounds__(LG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void large_adj_force(const LargeArgs A, const int second) {
     // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
     extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
@@ -778,13 +909,8 @@ void large_adj_force(const LargeArgs A, const int second) {
     // (NVE: from the first evaluation, sovlers.py:82,101 -- both with total weight h)
     const bool tab_eval = (A.prm.ensemble == 0) == (second != 0);
     const float gw = (tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
-    if constexpr (LISTED) {
-        if (blockIdx.x == 0 && threadIdx.x == 0 && A.nl_bad[(size_t)rep * T + i_fr]) A.flags[5] = 1;
-        wave_list_force<DIAG, 2, KIND>(A, qs, lam, i, valid, fx, fy, fz, gx, gy, gz, th, tc, gw, rep, i_fr);
-    } else {
-        wave_neighbours_and_force<DIAG, 2, KIND, 0>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
-                                                    tc, rc2max, gw, rep);
-    }
+    wave_neighbours_and_force<DIAG, 2, KIND, 0>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
+                                                tc, rc2max, gw, rep);
     float vals[LG_NV];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) vals[p] = th[p];
@@ -805,6 +931,119 @@ void large_adj_force(const LargeArgs A, const int second) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The adjoint's evaluation over the STORED candidates, four atoms per wave: a DPP row (16 lanes) per atom, lane s of
+// the row takes candidates s, s + 16, ...  A liquid's ~60 candidates fill 4 passes of 16 lanes where a whole wave per
+// atom ran one full and one nearly empty pass of 64; the per-atom sums stay inside the row (4 DPP adds each, no LDS
+// crossbar), and the per-wave fixed work (term constants, partial sums) is shared by four atoms.  The six index words
+// of a lane are read up front, the next pass's positions / adjoint directions are requested before the current pass
+// is evaluated.  Lanes beyond an atom's count gather the atom itself: D = 0 is skipped like everywhere (topology.py:67).
+// The candidates are the stored indices of the build that serves frame A.step; a build that overflowed, or a midpoint
+// that moved past the skin (flagged by large_prep<3>), raises flags[5]: the caller repeats the adjoint with searches
+// (MdgTrajParams.block = -1).
+// Launch: 256 threads = 16 atoms per workgroup, grid (ceil(N / 16), R); A.nbF = ceil(N / 16) rows of partN.
+template <bool DIAG, int KIND>
+__global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const int second) {
+    constexpr int NP = LG_LIST / 16;                                   // passes a full row takes
+    constexpr int NTH = KIND >= 0 ? MDG_MAX_THETA : LG_KMAX;           // live parameter partials
+    __shared__ float red[4 * (NTH + 2)];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15;
+    const size_t so = (size_t)rep * N * 3;
+    const float* q = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
+    const float* vs = second ? A.vm + so : A.v_t + ((size_t)rep * T + i_fr) * N * 3;
+    const float* lam = second ? A.lvh + so : A.lv + so;
+    TermConst tc[MDG_MAX_TERMS];
+    if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
+    else prepare_terms(A, tc);
+    const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
+    const int i = (blockIdx.x * 4 + wid) * 4 + (lane >> 4);
+    const bool valid = i < N;
+    const int ic = valid ? i : N - 1;                                  // (rows past the end read the last atom, count 0)
+    const bool nhc = A.prm.ensemble == 0;
+    const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
+    const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    // first evaluation: the build that serves frame i_fr (valid there by the forward pass's construction).  Midpoint:
+    // that one or frame i_fr + 1's, whichever large_prep<3> found within skin / 2 of the midpoint positions
+    // (nl_state[2 rep + {0, 1}] = {first, second} candidate is too far; cleared by the first evaluation's launch).
+    int slot = A.nl_build[(size_t)rep * T + i_fr];
+    bool bad = A.nl_bad[(size_t)rep * T + slot] != 0;                   // (rows of such a build were not all written)
+    if (second) {
+        const int slotB = i_fr + 1 < T ? A.nl_build[(size_t)rep * T + i_fr + 1] : slot;
+        const bool okA = !bad && !A.nl_state[2 * rep];
+        const bool okB = !A.nl_bad[(size_t)rep * T + slotB] && !A.nl_state[2 * rep + 1];
+        if (okB) slot = slotB;
+        bad = !(okA || okB);
+    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.nl_state[2 * rep] = 0; A.nl_state[2 * rep + 1] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && bad) A.flags[5] = 1;
+    const size_t at = ((size_t)rep * T + slot) * N + ic;
+    const int32_t* idx = A.nl_idx + at * LG_LIST;
+    int jj[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) jj[p] = idx[s + 16 * p];
+    const int n = (valid && !bad) ? min(A.nl_cnt[at], LG_LIST) : 0;
+    const Row3 qi = row3(q, ic), li = row3(lam, ic);
+    const float xi = qi.x, yi = qi.y, zi = qi.z;
+    const float mi = A.mass[ic], imi = nhc ? 1.0f / mi : 1.0f;
+    const float wxi = li.x * imi, wyi = li.y * imi, wzi = li.z * imi;
+    float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+#pragma unroll
+    for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
+    // software pipeline over the passes: (position, direction, mass) of pass p + 1 in flight while pass p is evaluated
+    int jn = s < n ? jj[0] : ic;
+    Row3 qn = row3(q, jn), ln = row3(lam, jn);
+    float mj = nhc ? A.mass[jn] : 1.0f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        if (p > 0 && __ballot(s + 16 * p < n) == 0) break;            // (wave-uniform: every row is through)
+        const int j = jn;
+        float dx = qn.x - xi, dy = qn.y - yi, dz = qn.z - zi;           // D = x_j - x_i
+        const float ax = ln.x, ay = ln.y, az = ln.z, am = mj;
+        if (p + 1 < NP) {
+            jn = s + 16 * (p + 1) < n ? jj[p + 1] : ic;
+            qn = row3(q, jn); ln = row3(lam, jn);
+            if (nhc) mj = A.mass[jn];
+        }
+        min_image<DIAG>(A.cell, dx, dy, dz);
+        const float d2 = norm2_ref(dx, dy, dz);
+        if (d2 == 0.f) continue;                                        // the atom itself (idle lanes) -- topology.py:67
+        const float jm = nhc ? __builtin_amdgcn_rcpf(am) : 1.0f;
+        pair_terms<2, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, ax * jm, ay * jm, az * jm, gw, rep,
+                            fx, fy, fz, gx, gy, gz, th);
+    }
+    fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
+    gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);
+    float vals[NTH + 2];
+#pragma unroll
+    for (int p = 0; p < NTH; ++p) vals[p] = th[p];
+    float p1 = 0.f, p2 = 0.f;
+    if (valid && s < 3) {
+        const int e = 3 * i + s;
+        A.f[so + e] = s == 0 ? fx : (s == 1 ? fy : fz);
+        A.dq[so + e] = s == 0 ? gx : (s == 1 ? gy : gz);
+        const float pp = vs[e] * mi;
+        p1 = pp * pp / mi;
+        p2 = lam[e] * vs[e];
+    }
+    vals[NTH] = p1; vals[NTH + 1] = p2;
+#pragma unroll
+    for (int p = 0; p < NTH + 2; ++p) vals[p] = wave_sum_rows(vals[p]);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < NTH + 2; ++p) red[wid * (NTH + 2) + p] = vals[p];
+    }
+    __syncthreads();
+    if (threadIdx.x < LG_NV) {
+        const int p = threadIdx.x;
+        const int c = p < LG_KMAX ? (p < NTH ? p : -1) : NTH + (p - LG_KMAX);
+        float t_ = 0.f;
+        if (c >= 0) t_ = (red[c] + red[(NTH + 2) + c]) + (red[2 * (NTH + 2) + c] + red[3 * (NTH + 2) + c]);
+        A.partN[((size_t)rep * A.nbF + blockIdx.x) * LG_NV + p] = t_;
+    }
+}
+
 // fixed point -> float table gradient
 __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t* __restrict__ glo, size_t n, float scale,
                                  float* __restrict__ out) {
@@ -814,7 +1053,7 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, bcount, binslot, nl_idx, nl_cnt, nl_bad, disp_bad, total;
+        spos, bstart, bcount, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
     bool keep_lists;
 };
 
@@ -838,11 +1077,11 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.bcount = take((size_t)2 * R * LG_MAX_CELLS);
     w.binslot = take((size_t)R * N);
     // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
-    const long long lw = (long long)R * T * N * (LG_LIST + 1) + (long long)R * T + R;
+    const long long lw = (long long)R * T * N * (LG_LIST + 1) + 2ll * R * T + 2ll * R;
     w.keep_lists = T > 1 && lw <= LG_LIST_MAX_WORDS;
     if (w.keep_lists) {
         w.nl_idx = take((size_t)R * T * N * LG_LIST); w.nl_cnt = take((size_t)R * T * N);
-        w.nl_bad = take((size_t)R * T); w.disp_bad = take((size_t)R);
+        w.nl_bad = take((size_t)R * T); w.nl_build = take((size_t)R * T); w.nl_state = take((size_t)2 * R);
     }
     w.total = o;
     return w;
@@ -907,7 +1146,9 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames
     a.ncell = 0;                                                                                     \
     if (L.keep_lists && prm->block != -1) {          /* (block = -1: search at every evaluation) */       \
         a.nl_idx = reinterpret_cast<int32_t*>(ws + L.nl_idx); a.nl_cnt = reinterpret_cast<int32_t*>(ws + L.nl_cnt); \
-        a.nl_bad = reinterpret_cast<int32_t*>(ws + L.nl_bad); \
+        a.nl_bad = reinterpret_cast<int32_t*>(ws + L.nl_bad);                                        \
+        a.nl_build = reinterpret_cast<int32_t*>(ws + L.nl_build);                                    \
+        a.nl_state = reinterpret_cast<int32_t*>(ws + L.nl_state);                                    \
         float rcm = 0.f;                                                                             \
         for (int m = 0; m < terms->n_terms; ++m) rcm = terms->t[m].cutoff > rcm ? terms->t[m].cutoff : rcm; \
         a.skin = LG_SKIN * rcm;                                                                      \
@@ -925,6 +1166,8 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames
     const int wpb = a.ncell ? LG_WAVES_CELL : LG_WAVES;                                              \
     const int nbF = (N + wpb - 1) / wpb;                                                             \
     a.nbF = nbF;                                                                                     \
+    const dim3 gL((N + LG_ROW_ATOMS - 1) / LG_ROW_ATOMS, R);       /* the listed kernels: 16 atoms per workgroup */ \
+    a.nbL = (int)gL.x;                                                                               \
     const size_t tile_lds = sizeof(float4) * (size_t)wpb * LG_CAP + (a.ncell ? 0 : sizeof(float) * 3 * LG_TILE); \
     const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
                        terms->t[0].p == 12 && (terms->t[0].q == 6 || terms->t[0].c == 0.f);          \
@@ -959,8 +1202,13 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     LG_FORCE_STEP(0);
     for (int k = 0; k + 1 < T; ++k) {
         a.step = k;
-        LG_PREP_LAUNCH(1);                                                          // kick + drift + bath half step + binning
-        LG_FORCE_STEP(1);
+        LG_PREP_LAUNCH(1);                                  // kick + drift + bath half step; search needed? then binning
+        LG_FORCE_STEP(1);                                   // (returns at once while the current list serves)
+        if (a.nl_idx) {                                     // (returns at once when the step searched)
+            if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gL, dim3(256), 0, st, a);
+            else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gL, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((large_fwd_listed<false, -1>), gL, dim3(256), 0, st, a);
+        }
     }
 #undef LG_FORCE_STEP
     MDG_CHECK_LAUNCH("traj_fwd_large");
@@ -1000,17 +1248,18 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
     }
     dim3 gF(nbF, R);
+    if (a.nl_idx) a.nbF = (int)gL.x;                   // (rows of partN the listed launches write, the prep launches sum)
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
         if (a.nl_idx) {                                                                                             \
-            if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_); \
-            else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_);    \
-            else hipLaunchKernelGGL((large_adj_force<false, -1, true>), gF, dim3(64 * wpb), 0, st, a, SECOND_);            \
-        } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
-        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);    \
-        else hipLaunchKernelGGL((large_adj_force<false, -1, false>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);            \
+            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gL, dim3(256), 0, st, a, SECOND_);       \
+            else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gL, dim3(256), 0, st, a, SECOND_);            \
+            else hipLaunchKernelGGL((large_adj_listed<false, -1>), gL, dim3(256), 0, st, a, SECOND_);                     \
+        } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
+        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);    \
+        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);            \
     } while (0)
         LG_PREP_LAUNCH(2);                                                          // finish interval i + 1, bin frame i
         LG_ADJ_FORCE(0);
