@@ -225,12 +225,16 @@ int mdg_traj_adj_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cel
 
 /* ------------------------------------------------------------------------------------
  * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain or NVE): same contract as
- * mdg_traj_fwd_small / mdg_traj_adj_small, two launches per step (forward) / four per adjoint
- * interval, enqueued by a host loop; the neighbour search is fused into the force kernel
- * (per-wave LDS list; the forward pass keeps every frame's candidate indices -- searched with a 4 % skin -- in the
- * workspace, and the adjoint's two evaluations per interval re-test those candidates instead of searching again).
+ * mdg_traj_fwd_small / mdg_traj_adj_small, three launches per step (forward) / four per adjoint
+ * interval, enqueued by a host loop; the neighbour search is fused into the force kernel (per-wave LDS list).
+ * Verlet reuse: a search uses the cutoff rc + skin (skin = 12 % of the largest cutoff) and keeps the candidate
+ * indices in the workspace; later force evaluations -- forward steps until an atom has moved 0.45 skin from where the
+ * list was built (checked on the device every step), and the adjoint's two evaluations per interval -- gather those
+ * candidates and re-apply the exact cutoff test, so every evaluation sees the pair set of a fresh search
+ * (topology_update_freq = 1, torchmd/sovlers.py:114) while the search itself runs every few steps.
  * (MdgTrajParams.block = -1 switches the reuse off: a fresh search at every evaluation; the adjoint run with the
- * lists reports through flags[5] when that is required.)
+ * lists reports through flags[5] when that is required.)  mdg_traj_large_list_builds() reports which search served
+ * each frame (diagnostics / tests).
  * ws: f32 workspace of mdg_traj_large_workspace() floats, shared by the
  * forward and the adjoint call of one trajectory; flags: int32[8], zeroed by the caller = {neighbour buffer overflow
  * (needed entries), non-finite state, table-gradient range, pair below the table, [4] forward: a stored candidate row
@@ -243,6 +247,10 @@ int mdg_traj_fwd_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
                        const float* mass, const float* t_grid,
                        const float* v0, const float* q0, const float* pv0,
                        float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream);
+/* after mdg_traj_fwd_large on `ws` (same sizes): build_of_frame[r][f] (device int32 [n_rep][n_frames]) = the frame whose
+ * search produced the candidate list that served frame f; returns 1 (nothing written) when the lists are not kept */
+int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atoms, int n_frames, int n_theta_total,
+                               int32_t* build_of_frame, void* stream);
 int mdg_traj_adj_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/,
                        const MdgTerms* terms /*host*/, const float* theta,
                        const float* mass, const float* t_grid,

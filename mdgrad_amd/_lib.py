@@ -78,6 +78,7 @@ _SIGNATURES = {
     "mdg_traj_adj_small_rdf": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                          P, P, P, P, P, P, P, P, P, P, P, P, P, C.POINTER(MdgRdfFuse), P, P]),
     "mdg_traj_large_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mdg_traj_large_list_builds": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_traj_fwd_large": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                      P, P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_traj_adj_large": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),

@@ -1113,6 +1113,16 @@ extern "C" int64_t mdg_traj_large_workspace(int n_rep, int n_atoms, int n_frames
     return (int64_t)ws_layout(n_rep, n_atoms, nb, n_theta_total, n_frames).total;
 }
 
+extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atoms, int n_frames, int n_theta_total,
+                                          int32_t* build_of_frame, void* stream) {
+    MDG_CHECK_ARG(ws && build_of_frame && n_rep > 0 && n_atoms > 0 && n_frames > 0, "traj_large_list_builds: bad arguments");
+    const WsLayout L = ws_layout(n_rep, n_atoms, (n_atoms + LG_WAVES_CELL - 1) / LG_WAVES_CELL, n_theta_total, n_frames);
+    if (!L.keep_lists) return 1;
+    MDG_HIP(hipMemcpyAsync(build_of_frame, ws + L.nl_build, sizeof(int32_t) * (size_t)n_rep * n_frames,
+                           hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MDG_OK;
+}
+
 // (phases that bin need the replica in ONE workgroup; the adjoint over stored lists does not: one atom per thread)
 #define LG_PREP_LAUNCH(PH_)                                                                          \
     do {                                                                                             \

@@ -9,6 +9,7 @@ Everything here requires HIP tensors; there is no CPU path.
 """
 import ctypes as C
 import math
+import weakref
 
 import torch
 
@@ -272,6 +273,23 @@ def make_terms(term_list, n_theta_total):
 LARGE_STATS = {"lists_incomplete": 0, "adjoint_redone_with_searches": 0}
 
 
+def large_list_builds(spec):
+    """After a forward pass of the multi-launch (large-N) kernels on `spec` (and before its workspace is released by the
+    backward pass): int32 [R, T], entry (r, f) = the frame whose neighbour search produced the candidate list that
+    served frame f (Verlet reuse, csrc/traj_large.hip); None when the lists were not kept.  Diagnostics:
+    `len(set(row))` searches ran for that replica."""
+    ref, (R, N, T, KT) = spec._last_large
+    ws = ref()
+    if ws is None:
+        raise RuntimeError("mdgrad_amd: the trajectory's workspace has been released")
+    out = torch.empty(R, T, dtype=torch.int32, device=ws.device)
+    rc = _lib.load().mdg_traj_large_list_builds(ptr(ws), R, N, T, KT, ptr(out), stream_ptr(ws.device))
+    if rc == 1:
+        return None
+    check(rc, "mdg_traj_large_list_builds")
+    return out
+
+
 class RdfFuse:
     """An `rdf` observable (observable.py) that a fused trajectory launch evaluates on the fly: centres, width and
     pair cutoff of the observable and the frames frame_start + k frame_stride it is called on.  Registered on the
@@ -375,6 +393,7 @@ class FusedTrajFn(torch.autograd.Function):
                 raise RuntimeError("mdgrad_amd: a pair came closer than the first node of the tabulated pair "
                                    "potential; lower `table_rmin` on the integrator or set `fused_table = False`")
             ctx.ws, bad = ws, flags[1:2]
+            spec._last_large = (weakref.ref(ws), (R, N, T, spec.n_theta_total))    # (ops.large_list_builds)
             ctx.lists_ok = not fl[4]               # every frame's candidate list was stored: the adjoint re-tests them
             LARGE_STATS["lists_incomplete"] += int(bool(fl[4]))
         else:

@@ -436,6 +436,62 @@ def test_large_path_stored_lists_equal_fresh_searches(case):
         close(a, b, 1e-4, 1e-5 * float(b.abs().max()) + 1e-12, "%s (%s)" % (nm, case))
 
 
+def test_large_path_lists_reused_across_forward_steps_vs_oracle_and_fresh_searches():
+    """Verlet reuse in the forward pass: 1 000 atoms, 17 frames at dt 0.005 with thermal velocities -- the first list
+    serves several steps, an atom then leaves its 0.45-skin ball and the device asks for a new search (more than one
+    build, far fewer than frames; the last frame keeps the wider margin its adjoint midpoint needs).  Trajectory,
+    adjoints and dL/dtheta against the oracle (exact neighbour list at every evaluation), and against the same
+    kernels searching at every evaluation (block = -1)."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    pos, cell = liquid(10, seed=31, jitter=0.05)
+    rng = np.random.default_rng(131)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    mass = np.full(len(pos), 1.008, dtype=np.float32)
+    n_frames = 17
+    t = torch.Tensor([0.005 * i for i in range(n_frames)])
+    system = mk_system(pos, cell, vel, mass)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3,
+                            Q=30.0).to(DEV)
+    integ.fused_large = True
+    N = len(pos)
+
+    def loss_fn(L):
+        return L[1][::4].pow(2).sum() / (L[1][::4].numel()) + L[0][-1].pow(2).sum() / (N * 3) + L[2][-1].sum() * 1e-3
+
+    res = []
+    stats0 = dict(ops.LARGE_STATS)
+    for block in (0, -1):
+        spec = integ.fused_spec("NH_verlet")
+        assert spec.large
+        spec.block = block
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        v_t, q_t, pv_t = ops.FusedTrajFn.apply(y0[0], y0[1], y0[2], t.to(DEV), spec.flat_params(), spec)
+        if block == 0:
+            builds = ops.large_list_builds(spec)[0].tolist()
+            assert builds[0] == 0 and all(b <= f for f, b in enumerate(builds)) and builds == sorted(builds)
+            assert 2 <= len(set(builds)) <= n_frames // 2, builds          # reused, and rebuilt at least once
+        mdl.zero_grad()
+        loss_fn((v_t, q_t, pv_t)).backward()
+        res.append([q_t.detach(), v_t.detach(), pv_t.detach(), y0[0].grad.clone(), y0[1].grad.clone(), y0[2].grad.clone(),
+                    torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])])
+    assert ops.LARGE_STATS["adjoint_redone_with_searches"] == stats0["adjoint_redone_with_searches"]
+    assert ops.LARGE_STATS["lists_incomplete"] == stats0["lists_incomplete"]
+    names = ("q_t", "v_t", "pv_t", "adj v0", "adj q0", "adj pv0", "dL/dtheta")
+    for a, b, nm in zip(res[0], res[1], names):
+        close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-12, "%s (lists vs searches)" % nm)
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1)
+    traj, lam, gth = oracle_run(pos, cell, vel, mass, [term], 1.0, 30.0, 3, t, loss_fn)
+    close(res[0][0], traj[1], 0, 1e-4, "q_t vs oracle")
+    close(res[0][1], traj[0], 0, 2e-3, "v_t vs oracle")
+    close(res[0][2], traj[2], 2e-3, 5e-4, "pv_t vs oracle")
+    close(res[0][6], gth, 5e-3, 5e-4 * float(gth.abs().max()), "dL/dtheta vs oracle")
+    for g, l, nm in zip(res[0][3:6], lam, ("adj v0", "adj q0", "adj pv0")):
+        close(g, l, 5e-3, 1e-3 * float(l.abs().max()) + 1e-9, "%s vs oracle" % nm)
+
+
 def test_large_path_4096_atoms_one_step_vs_oracle():
     """BASELINE config #4's size: one forward NH-Verlet step of the 4 096-atom LJ liquid against the oracle."""
     _large_case(16, 2, False, seed=36)
