@@ -562,16 +562,17 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     sec_per_step = el / md_steps * world
     # per MD step + adjoint interval: one force sweep (40 flop per directed pair) and two force + Hessian.w sweeps (70)
     useful = (40.0 + 2.0 * FLOP_PER_PAIR_ADJ) * 2.0 * Pn / sec_per_step
-    out["roofline"] = {"bound": "hbm", "kernel": "large_adj_force / large_force_step (whole step)",
+    out["roofline"] = {"bound": "hbm", "kernel": "large_adj_listed / large_fwd_listed / large_force_step (whole step)",
                        "achieved": bytes_step / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": bytes_step / sec_per_step / 1e9 / HBM_PEAK_GBS, "traffic": None,
                        "useful_tflops": useful / 1e12, "useful_frac_of_vector_peak": useful / 1e12 / VEC_F32_PEAK_TF,
                        "note": "SURVEY 8d: B_step = 60 P + 316 N bytes per MD step (P = %d half-list pairs) over the measured "
                                "time per MD step of the whole pass; the kernels keep positions in L2/LDS and never write a "
                                "full neighbour list, so this is the algorithmic figure of the unfused chain.  Neither roof "
-                               "binds: the forward launch is bound by the instruction issue of its wave-per-atom search "
-                               "(~1300 instructions per atom, most of them candidate tests and the sort), the adjoint launches "
-                               "by gather latency over the stored candidate lists (DESIGN.md section 4)" % Pn}
+                               "binds: a searching forward launch (one step in ~7, Verlet reuse with a device-side rebuild "
+                               "decision) is bound by the instruction issue of its wave-per-atom search (~1300 instructions "
+                               "per atom, most of them candidate tests and the sort); the listed launches (four atoms per "
+                               "wave over the stored candidate lists) by VALU issue and gather latency (DESIGN.md section 4)" % Pn}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_lj4096()
     return out
