@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/${TAG}_bench.json 2> /tmp/bench.err; tail -c 300 $O/${TAG}_bench.json
 # kernel-time tables (rocprofv3 --kernel-trace --stats) of the three workloads
 for W in lj108 schnet4096 lj4096; do LINES_SHOWN=3 bash $R/tools/prof_workload.sh $W ${TAG} > /dev/null 2>&1; done
+LINES_SHOWN=3 bash $R/tools/prof_workload.sh schnet4096 ${TAG}bf16 --bf16 > /dev/null 2>&1      # (the bench line's secondary runs bf16 operands)
 # HBM traffic of the headline kernels: FETCH_SIZE and WRITE_SIZE in separate passes
 rm -rf /tmp/p2 /tmp/p3
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/p2 -o run -- python $R/bench.py --workload lj108 --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
