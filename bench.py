@@ -9,7 +9,7 @@ script = one such pass; value = R*(T-1)*N_gpus*K / time.  Inputs are resident in
 The same JSON line nests, under "secondary", the two other north-star workloads measured the same way (each
 with its own value / ms_per_step / roofline / cpu_baseline):
   schnet4096   4 096-bead CG water, SchNet A64/F128/G30/2 conv + ExcludedVolume prior, 8 stacked replicas / GPU
-  lj4096       4 096-atom LJ liquid (BASELINE config #4), fused large-N kernels, 16 replicas / GPU
+  lj4096       4 096-atom LJ liquid (BASELINE config #4), fused large-N kernels, 64 replicas / GPU
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -505,7 +505,7 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     from mdgrad_amd.system import System, Atoms
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
-    R = 16 if args.replicas is None or args.workload != "lj4096" else args.replicas
+    R = 64 if args.replicas is None or args.workload != "lj4096" else args.replicas
     T = 51 if args.frames is None or args.workload != "lj4096" else args.frames
     rng = np.random.default_rng(3000 + rank)
     pos1, L = lj_liquid(16, 0.845, rng)
@@ -586,7 +586,7 @@ def main():
                     help="timed passes (default: ~4.5 s of GPU time on the headline workload, so that a coarse utilisation "
                          "sampler sees the device busy)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 16)")
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 64)")
     ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11 / 51")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)

@@ -34,7 +34,7 @@ constexpr int LG_LIST = 128;                 // stored neighbour indices per ato
 constexpr float LG_SKIN = 0.12f;             // skin of the stored lists, as a fraction of the largest cutoff
 constexpr float LG_REUSE = 0.45f;            // the forward pass searches again once an atom has moved this fraction of the skin
                                              // (< 1/2: room for the adjoint's midpoint states between two frames)
-constexpr long long LG_LIST_MAX_WORDS = 1ll << 31;   // at most 8 GiB of stored lists; beyond that the adjoint searches again
+constexpr long long LG_LIST_MAX_WORDS = 1ll << 33;   // at most 32 GiB of stored lists (of 288); beyond that every evaluation searches
 constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
 constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
 
