@@ -289,6 +289,21 @@ int mdg_rdf_ell_supported(float spacing, float coeff, int nbins);
 int mdg_rdf_fwd_ell(const float* pos, int64_t n_atoms_total, const MdgCell* cell /*host*/, const int32_t* col,
                     const int32_t* shift, const int32_t* cnt, int max_nbr, const float* mu, float spacing, float coeff,
                     int nbins, float* raw, void* stream);
+/* The same observable straight from the cell bins, without materialising a neighbour list (the list build costs more
+ * than the histogram): per frame, positions sorted by (bin, atom index); a wave per atom walks the 27-bin stencil and
+ * counts every pair once on the fine integer grid (forward), or sums the tabulated pair force of
+ * phi(d) = sum_k g_k exp(coeff (d - mu_k)^2) (backward: term/theta = the MDG_PAIR_TABLE built from dL/d raw, as for
+ * mdg_pair_eval_ell; g_xyz [F][N][3] = dL/dxyz).  Orthorhombic cells of >= 3 `cutoff` per side, N <= 16 384
+ * (mdg_rdf_cell_supported); cutoff = the list cutoff (>= the reach of the fine grid).  scratch: int32 words of
+ * mdg_rdf_cell_scratch(), 16-byte aligned, filled by the forward call and read by the backward call of the same frames.
+ * Replaces torchmd/observable.py:62-76 (generate_nbr_list + GaussianSmearing(...).sum(0)) and its autograd transpose. */
+int mdg_rdf_cell_supported(int n_atoms, const MdgCell* cell /*host*/, float cutoff);
+int64_t mdg_rdf_cell_scratch(int n_frames, int n_atoms, const MdgCell* cell /*host*/, float cutoff);
+int mdg_rdf_fwd_cell(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/, float cutoff,
+                     const float* mu, float spacing, float coeff, int nbins, float* raw, int32_t* scratch, void* stream);
+int mdg_rdf_bwd_cell(int n_frames, int n_atoms, const MdgCell* cell /*host*/, float cutoff,
+                     const MdgPairTerm* term /*host*/, const float* theta, const int32_t* scratch, float* g_xyz,
+                     void* stream);
 /* backward with the same equally-spaced-centres guarantee (mdg_rdf_bwd makes no assumption on mu). */
 int mdg_rdf_bwd_uniform(const float* xyz, int n_frames, int n_atoms, const MdgCell* cell /*host*/,
                         float cutoff, const uint8_t* mask, const float* mu, float spacing, float coeff,

@@ -90,6 +90,11 @@ _SIGNATURES = {
                                       C.c_int, P, P, P]),
     "mdg_rdf_ell_supported": (C.c_int, [C.c_float, C.c_float, C.c_int]),
     "mdg_rdf_fwd_ell": (C.c_int, [P, C.c_int64, C.POINTER(MdgCell), P, P, P, C.c_int, P, C.c_float, C.c_float, C.c_int, P, P]),
+    "mdg_rdf_cell_supported": (C.c_int, [C.c_int, C.POINTER(MdgCell), C.c_float]),
+    "mdg_rdf_cell_scratch": (C.c_int64, [C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float]),
+    "mdg_rdf_fwd_cell": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, C.c_float, C.c_float, C.c_int,
+                                   P, P, P]),
+    "mdg_rdf_bwd_cell": (C.c_int, [C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, C.POINTER(MdgPairTerm), P, P, P, P]),
     "mdg_rdf_bwd": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float,
                               C.c_int, P, P, P]),
     "mdg_rdf_bwd_uniform": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float, C.c_float,

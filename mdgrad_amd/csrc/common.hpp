@@ -302,6 +302,30 @@ __device__ __forceinline__ float group_sum_rt(float v, int w) {
     return v;
 }
 
+// ---- lane groups of 16 (one DPP row): sums without the LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row, on every lane of the row (row_ror:8, row_ror:4, quad_perm [2,3,0,1], [1,0,3,2])
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_get<0x128>(v);
+    v += dpp_get<0x124>(v);
+    v += dpp_get<0x4E>(v);
+    v += dpp_get<0xB1>(v);
+    return v;
+}
+// ... then across the four rows: v_permlane16_swap / v_permlane32_swap hand each half its partner's sum
+__device__ __forceinline__ float wave_sum_rows(float v) {
+    v = row16_sum(v);
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned w = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
 // Block-wide sum, result broadcast to every thread.  `red` = LDS scratch of >= 17 floats.
 // Deterministic (fixed tree).  Contains two barriers.
 __device__ __forceinline__ float block_sum(float v, float* red) {

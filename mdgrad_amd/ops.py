@@ -271,6 +271,8 @@ def make_terms(term_list, n_theta_total):
 # diagnostics of the multi-launch (large-N) trajectory path: how often the adjoint could not use the stored candidate
 # lists of the forward pass (tests read these)
 LARGE_STATS = {"lists_incomplete": 0, "adjoint_redone_with_searches": 0}
+# the RDF of large systems searches and counts in one sweep over the cell bins (False: through a neighbour list)
+RDF_CELL_DIRECT = True
 
 
 def large_list_builds(spec):
@@ -468,6 +470,8 @@ class FusedTrajFn(torch.autograd.Function):
         prm = spec.params(R, T)
         table = getattr(spec, "table", False)
 
+        ws, lists_ok = getattr(ctx, "ws", None), getattr(ctx, "lists_ok", False)
+
         def launch(terms, search=False):
             if g_raw is not None:
                 gr = g_raw.detach().to(torch.float32).contiguous()
@@ -480,16 +484,19 @@ class FusedTrajFn(torch.autograd.Function):
             if spec.large:
                 # the stored candidate lists of the forward pass serve the adjoint unless one overflowed there (or, flag
                 # 5 below, a midpoint moved past their skin): block = -1 asks for fresh searches
+                # (a loop, not a recursive call: a closure that names itself is a reference cycle, and this one would
+                #  keep ctx -- with the trajectory's multi-GB workspace -- alive until the cyclic collector runs)
                 pl = type(prm).from_buffer_copy(prm)
-                pl.block = -1 if (search or not getattr(ctx, "lists_ok", False) or spec.block == -1) else 0
-                flags = torch.zeros(8, dtype=torch.int32, device=dev)
-                check(lib.mdg_traj_adj_large(C.byref(pl), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
-                                             ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
-                                             ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ctx.ws),
-                                             ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
-                if pl.block != -1 and int(flags[5]):
+                for search in ((search,) if (search or not lists_ok or spec.block == -1) else (False, True)):
+                    pl.block = -1 if (search or not lists_ok or spec.block == -1) else 0
+                    flags = torch.zeros(8, dtype=torch.int32, device=dev)
+                    check(lib.mdg_traj_adj_large(C.byref(pl), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                                 ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                                 ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ws),
+                                                 ptr(flags), stream_ptr(dev)), "mdg_traj_adj_large")
+                    if pl.block == -1 or not int(flags[5]):
+                        break
                     LARGE_STATS["adjoint_redone_with_searches"] += 1
-                    return launch(terms, search=True)
                 return flags
             check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
@@ -628,8 +635,19 @@ class RdfRawFn(torch.autograd.Function):
             # counted on the fine integer grid; the gradient is a tabulated pair force over the same list
             flat = x3.reshape(F * N, 3)
             cutoff = list_cut
-            ell = build_ell(flat, cell_struct, cutoff, group=N)
             muc = mu.detach().to(torch.float32).contiguous()
+            if RDF_CELL_DIRECT and lib.mdg_rdf_cell_supported(N, C.byref(cell_struct), float(cutoff)):
+                # ... without materialising the list: search + count in one sweep over the cell bins (csrc/rdf_cell.hip);
+                # the backward pass sweeps the same bins with the tabulated pair force
+                scratch = torch.empty(int(lib.mdg_rdf_cell_scratch(F, N, C.byref(cell_struct), float(cutoff))) + 4,
+                                      dtype=torch.int32, device=dev)
+                check(lib.mdg_rdf_fwd_cell(ptr(flat), F, N, C.byref(cell_struct), float(cutoff), ptr(muc), float(spacing),
+                                           float(coeff), B, ptr(raw), ptr(scratch), stream_ptr(dev)), "mdg_rdf_fwd_cell")
+                ctx.ell = scratch
+                ctx.args = (float(coeff), float(cutoff), cell_struct, mask, xyz.shape, float(spacing))
+                ctx.save_for_backward(flat, muc)
+                return raw
+            ell = build_ell(flat, cell_struct, cutoff, group=N)
             check(lib.mdg_rdf_fwd_ell(ptr(flat), F * N, C.byref(cell_struct), ptr(ell.col), ptr(ell.shift), ptr(ell.cnt),
                                       ell.max_nbr, ptr(muc), float(spacing), float(coeff), B, ptr(raw), stream_ptr(dev)),
                   "mdg_rdf_fwd_ell")
@@ -655,6 +673,13 @@ class RdfRawFn(torch.autograd.Function):
             nodes = 4096
             table, u0, du = _rdf_pair_table(g_raw.detach().to(torch.float32), muc, coeff, cutoff, nodes)
             term = make_term(dict(kind=MDG_PAIR_TABLE, p=nodes, a=u0, phi=du, c=1.0), cutoff, 0, 2 * nodes, None)
+            if torch.is_tensor(ctx.ell):                              # the forward call's cell bins (csrc/rdf_cell.hip)
+                Nn = int(shape[-2])
+                Fn = int(x3.shape[0]) // Nn                                # (saved positions are flat [F N, 3])
+                gx = torch.empty_like(x3)
+                check(lib.mdg_rdf_bwd_cell(Fn, Nn, C.byref(cell_struct), float(cutoff), C.byref(term), ptr(table),
+                                           ptr(ctx.ell), ptr(gx), stream_ptr(x3.device)), "mdg_rdf_bwd_cell")
+                return gx.reshape(shape), None, None, None, None, None, None, None
             o = pair_eval(ctx.ell, x3, term, table, energy=False, grad=True)
             return o["grad"].reshape(shape), None, None, None, None, None, None, None
         F, N, B = x3.shape[0], x3.shape[1], muc.shape[0]

@@ -697,20 +697,61 @@ def test_fit_loop_parameter_trajectory_matches_an_oracle_run_loop():
     assert hip[-1][1] != hip[0][1], "parameters moved"
 
 
-def test_list_based_rdf_for_large_systems_vs_oracle():
-    """N >= 2048 atoms: rdf() searches pairs through the cell list and counts them on the fine integer grid; its
-    gradient is a tabulated pair force over the same list.  3 frames of the 2 744-atom liquid against the oracle."""
+@pytest.mark.parametrize("direct", [True, False])
+def test_list_based_rdf_for_large_systems_vs_oracle(direct):
+    """N >= 2048 atoms: rdf() searches pairs through the cell bins and counts them on the fine integer grid -- in one
+    sweep without a neighbour list (csrc/rdf_cell.hip), or over a cell-list neighbour list (`ops.RDF_CELL_DIRECT =
+    False`); its gradient is a tabulated pair force over the same bins / list.  3 frames of the 2 744-atom liquid, a
+    third of the atoms of one frame shifted by whole cells (unwrapped coordinates), against the oracle."""
+    from mdgrad_amd import ops
     from mdgrad_amd.observable import rdf
     pos, cell = liquid(14, seed=9, jitter=0.08)
     rng = np.random.default_rng(2)
     frames = np.stack([np.mod(pos + rng.normal(0, 0.05, pos.shape), cell) for _ in range(3)]).astype(np.float32)
+    frames[1, ::3] += (np.asarray(cell) * np.array([1.0, -1.0, 0.0])).astype(np.float32)
     system = mk_system(pos, cell)
     wgt = torch.linspace(-1, 1, 100)
     x = T(frames, DEV).requires_grad_(True)
-    count, bins, gr = rdf(system, nbins=100, r_range=(0.75, 2.5))(x)
-    (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    was = ops.RDF_CELL_DIRECT
+    ops.RDF_CELL_DIRECT = direct
+    try:
+        count, bins, gr = rdf(system, nbins=100, r_range=(0.75, 2.5))(x)
+        (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    finally:
+        ops.RDF_CELL_DIRECT = was
     xo = T(frames).requires_grad_(True)
     _, _, go = O.rdf_oracle(xo, T(cell), 100, (0.75, 2.5))
     (gxo,) = torch.autograd.grad((go * wgt).sum(), xo)
-    close(gr, go, 1e-4, 1e-4, "g(r), list-based")
-    close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, list-based")
+    close(gr, go, 1e-4, 1e-4, "g(r), cell-based")
+    close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, cell-based")
+
+
+def test_cell_sweep_rdf_equals_list_rdf_and_is_reproducible():
+    """The direct sweep and the list-based kernels count the same pairs on the same integer grid: the same raw
+    histograms (4 096 atoms, 5 frames, one of them a dense cluster that makes bins longer than a wave), and two runs of
+    the sweep give bitwise equal gradients (bin order = rank by atom index, no float atomics)."""
+    from mdgrad_amd import ops
+    from mdgrad_amd.observable import rdf
+    pos, cell = liquid(16, seed=3, jitter=0.08)
+    rng = np.random.default_rng(4)
+    frames = np.stack([np.mod(pos + rng.normal(0, 0.06, pos.shape), cell) for _ in range(5)]).astype(np.float32)
+    frames[3, :200] = (np.asarray(cell) * 0.5 + rng.normal(0, 0.35, (200, 3))).astype(np.float32)      # a crowded bin
+    system = mk_system(pos, cell)
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    wgt = torch.linspace(1, -1, 100, device=DEV)
+    out = []
+    was = ops.RDF_CELL_DIRECT
+    try:
+        for direct in (True, True, False):
+            ops.RDF_CELL_DIRECT = direct
+            x = T(frames, DEV).requires_grad_(True)
+            count, _, gr = obs(x)
+            (gx,) = torch.autograd.grad((gr * wgt).sum(), x)
+            out.append((count.clone(), gx.clone()))
+    finally:
+        ops.RDF_CELL_DIRECT = was
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]), "two runs of the sweep differ"
+    # (the list kernels apply the stored image shift, the sweep the minimum image on the fly: a last-bit difference in a
+    #  distance can move a pair across a fine-bin edge)
+    close(out[0][0], out[2][0], 1e-5, 1e-8, "histogram: sweep vs list")
+    close(out[0][1], out[2][1], 1e-4, 1e-6 * float(out[2][1].abs().max()), "gradient: sweep vs list")
