@@ -492,6 +492,43 @@ def test_large_path_lists_reused_across_forward_steps_vs_oracle_and_fresh_search
         close(g, l, 5e-3, 1e-3 * float(l.abs().max()) + 1e-9, "%s vs oracle" % nm)
 
 
+def test_large_path_nve_two_replicas_lists_reused_equal_fresh_searches():
+    """NVE, two stacked replicas of 1 331 atoms with different velocities (their lists are rebuilt at different steps:
+    the rebuild decision is per replica, on the device), 21 frames: stored lists reused across steps == a search at
+    every evaluation, forward and adjoint."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE
+    pos, cell = liquid(11, seed=41, jitter=0.05)
+    rng = np.random.default_rng(141)
+    N = len(pos)
+    mass = np.full(N, 1.008, dtype=np.float32)
+    system = mk_system(pos, cell, rng.normal(0, 1.0, pos.shape).astype(np.float32), mass)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NVE(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system).to(DEV)
+    integ.fused_large = True
+    t = torch.Tensor([0.005 * i for i in range(21)]).to(DEV)
+    q0 = T(np.stack([pos, np.mod(pos + rng.normal(0, 0.02, pos.shape), cell)]).astype(np.float32), DEV)
+    v0 = T(np.stack([rng.normal(0, 0.7, pos.shape), rng.normal(0, 1.6, pos.shape)]).astype(np.float32), DEV)
+    res = []
+    for block in (0, -1):
+        spec = integ.fused_spec("verlet")
+        assert spec.large
+        spec.block = block
+        v, q = v0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+        v_t, q_t = ops.FusedTrajFn.apply(v, q, None, t, spec.flat_params(), spec)
+        if block == 0:
+            builds = ops.large_list_builds(spec).tolist()
+            assert all(2 <= len(set(b)) <= 12 for b in builds), builds
+            assert len(set(builds[1])) > len(set(builds[0])), "the hotter replica searches more often: %r" % (builds,)
+        mdl.zero_grad()
+        (q_t[:, ::4].pow(2).mean() + v_t[:, -1].pow(2).mean()).backward()
+        res.append([q_t.detach(), v_t.detach(), v.grad.clone(), q.grad.clone(),
+                    torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])])
+    for a, b, nm in zip(res[0], res[1], ("q_t", "v_t", "adj v0", "adj q0", "dL/dtheta")):
+        close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-12, "%s (NVE, lists vs searches)" % nm)
+
+
 def test_large_path_4096_atoms_one_step_vs_oracle():
     """BASELINE config #4's size: one forward NH-Verlet step of the 4 096-atom LJ liquid against the oracle."""
     _large_case(16, 2, False, seed=36)
