@@ -184,7 +184,8 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         float* pv = A.pv + rep * MDG_MAX_CHAINS;
         const bool lists = A.nl_idx != nullptr;
         // (the previous force launch was a search with nbF workgroups or a listed one with nbL)
-        const int rows = (lists && !A.nl_state[2 * rep]) ? A.nbL : A.nbF;
+        // (... or, in a binned box, by large_search_rows, which shares the listed kernels' launch shape)
+        const int rows = (lists && (nc > 0 || !A.nl_state[2 * rep])) ? A.nbL : A.nbF;
         const int bfr = lists ? A.nl_state[2 * rep + 1] : 0;
         const float* qb = A.q_t + ((size_t)rep * T + bfr) * N * 3;      // positions the current list was built at
         float far2 = 0.f;
@@ -429,11 +430,24 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     __syncthreads();
     int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
     for (int c = threadIdx.x; c <= nc; c += LG_PREP) bs[c] = start[c];
+    // slot inside the bin = the atom's RANK by index among its bin mates (the atomic's order is not reproducible): the
+    // sorted array is then the same on every run, and so is every sum taken in its order (large_search_rows)
+    int32_t* prov = A.binslot + (size_t)rep * N;
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
         const int a = tid + u * stride;
-        if (a < N)
-            A.spos[(size_t)rep * N + start[bsl[u] & 4095] + (bsl[u] >> 12)] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
+        if (a < N) prov[start[bsl[u] & 4095] + (bsl[u] >> 12)] = a;
+    }
+    __syncthreads();                                         // (one workgroup per replica bins: its global writes are visible)
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int a = tid + u * stride;
+        if (a < N) {
+            const int bin = bsl[u] & 4095, s0 = start[bin], s1 = start[bin + 1];
+            int rank = 0;
+            for (int l = s0; l < s1; ++l) rank += prov[l] < a;
+            A.spos[(size_t)rep * N + s0 + rank] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
+        }
     }
 }
 
@@ -859,6 +873,163 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The forward force launch that SEARCHES (first frame, and every Verlet rebuild) in a binned box with kept lists: the
+// rows of the listed kernels -- four atoms per wave, a 16-lane DPP row each, atoms taken in sorted-slot order so that a
+// workgroup's sixteen atoms share their stencil.  An atom's 9 stencil columns are contiguous ranges of the sorted
+// positions (its three z-bins; the bin reached through a z face in a second round); the 18 bounds of a round are
+// requested together, the next column's four 16-entry chunks while the current column is tested.  One sweep does
+// everything large_force_step spreads over a search, a rank sort, a store and a second pass over an LDS buffer: a
+// candidate inside rc + skin is appended to the atom's stored row (slot = the row's running count + the prefix of the
+// row's ballot bits) and, inside the exact cutoff, its force is added on the spot.  The order of a stored row is the
+// order of the sweep over the (bin, atom index)-sorted array: reproducible, not ascending -- its consumers do not care.
+template <int MODE, int KIND>
+__global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
+    if (MODE == 1 && !A.nl_state[2 * rep]) return;                  // the current list serves this step (large_fwd_listed)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15, row = lane >> 4;
+    const size_t so = (size_t)rep * N * 3;
+    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; float* f = A.f + so;
+    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
+    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
+    const bool nhc = A.prm.ensemble == 0;
+    const int frame = MODE == 0 ? 0 : k + 1;
+    float dt = 0.f;
+    if (MODE == 1) dt = A.t[k + 1] - A.t[k];
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) {                                      // this launch builds the list of `frame`
+            A.nl_build[(size_t)rep * T + frame] = frame;
+            A.nl_state[2 * rep + 1] = frame;
+            if (MODE == 0) A.nl_state[2 * rep] = 1;
+        }
+        if (MODE == 1 && nhc) {                                      // finish the bath with KE(v + vh), as large_force_step<1>
+            if (threadIdx.x < MDG_MAX_CHAINS) {
+                float qv = 0.f;
+#pragma unroll
+                for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+                Qs[threadIdx.x] = qv;
+            }
+            const float ke = 0.5f * reduce_partials(A.partB + (size_t)rep * A.nbE, A.nbE, 1, 0, red);
+            if (threadIdx.x < C) pvs[threadIdx.x] = pvh[threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const float b1 = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+                const float np = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
+                pv[threadIdx.x] = np;
+                A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = np;
+            }
+            __syncthreads();
+        }
+        if (MODE == 0 && nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
+    }
+    TermConst tc[MDG_MAX_TERMS];
+    float rc2max;
+    if (KIND >= 0) { tc[0] = term_prepare(A.terms.t[0], A.theta); rc2max = tc[0].rc2; }
+    else rc2max = prepare_terms(A, tc);
+    const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
+    const float rs = sqrtf(rc2max) + A.skin, rs2 = rs * rs;
+    const int slot = (blockIdx.x * 4 + wid) * 4 + row;
+    const bool valid = slot < N;
+    const float4* sp = A.spos + (size_t)rep * N;
+    const int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
+    const float4 pi = sp[valid ? slot : N - 1];
+    const int i = __float_as_int(pi.w);
+    const size_t at = ((size_t)rep * T + frame) * N + i;
+    int32_t* lrow = A.nl_idx + at * LG_LIST;
+    int cnt = 0;                                                     // candidates of the row's atom so far (row-uniform)
+    float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+    // every lane runs this for every chunk (live = it holds a candidate): the row's ballot bits give the slots
+    auto take = [&](const float4 pj, bool live) {
+        const int j = __float_as_int(pj.w);
+        float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;            // D = x_j - x_i
+        min_image<true>(A.cell, dx, dy, dz);
+        const float d2 = norm2_ref(dx, dy, dz);
+        const bool in = live && j != i && d2 < rs2;
+        const unsigned rowmask = (unsigned)(__ballot(in) >> (16 * row)) & 0xffffu;
+        if (in) {
+            const int at_ = cnt + __popc(rowmask & ((1u << s) - 1u));
+            if (at_ < LG_LIST) lrow[at_] = j;
+            if (d2 != 0.f)                                                    // topology.py:67
+                pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx,
+                                    gy, gz, th);
+        }
+        cnt += __popc(rowmask);
+    };
+    {
+        const int nbx = A.nb[0], nby = A.nb[1], nbz = A.nb[2];
+        const int bx = bin_coord_l(pi.x, A.cell.inv[0], nbx), by = bin_coord_l(pi.y, A.cell.inv[4], nby);
+        const int bz = bin_coord_l(pi.z, A.cell.inv[8], nbz);
+        const int wrapped = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);     // the z bin reached through the face
+        int col[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            int cx = bx + c / 3 - 1, cy = by + c % 3 - 1;
+            cx = cx < 0 ? cx + nbx : (cx >= nbx ? cx - nbx : cx);
+            cy = cy < 0 ? cy + nby : (cy >= nby ? cy - nby : cy);
+            col[c] = (cx * nby + cy) * nbz;
+        }
+#pragma unroll 1
+        for (int part = 0; part < 2; ++part) {
+            const bool on = valid && (part == 0 || wrapped >= 0);             // (rows without an atom / a face: empty ranges)
+            if (part == 1 && !__any(on)) break;
+            const int zlo = part ? max(wrapped, 0) : max(bz - 1, 0), zhi = part ? max(wrapped, 0) : min(bz + 1, nbz - 1);
+            int a0[9], a1[9];
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { a0[c] = bs[col[c] + zlo]; a1[c] = bs[col[c] + zhi + 1]; }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) { a0[c] += s; if (!on) a1[c] = 0; }
+            float4 P[4], Q[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int a = a0[0] + 16 * u; P[u] = sp[a < a1[0] ? a : 0]; }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                if (c + 1 < 9) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int a = a0[c + 1] + 16 * u; Q[u] = sp[a < a1[c + 1] ? a : 0]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (__any(a0[c] + 16 * u < a1[c])) take(P[u], a0[c] + 16 * u < a1[c]);
+                for (int a = a0[c] + 64; __any(a < a1[c]); a += 16) take(sp[a < a1[c] ? a : 0], a < a1[c]);   // (dense bins)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) P[u] = Q[u];
+            }
+        }
+    }
+    fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
+    if (valid && s == 0) {
+        if (cnt <= LG_LIST) A.nl_cnt[at] = cnt;
+        else { A.nl_bad[(size_t)rep * T + frame] = 1; A.flags[4] = 1; }      // (the row does not hold them all: see nl_bad)
+    }
+    float kepart = 0.f;
+    if (valid && s < 3) {
+        const float F = s == 0 ? fx : (s == 1 ? fy : fz);
+        const int e = 3 * i + s;
+        const float m = A.mass[i];
+        float vn;
+        if (MODE == 0) vn = v[e];
+        else {
+            const float vv = v[e] + vh[e];
+            const float p = vv * m;
+            const float a = nhc ? (F - pvh[0] * p / A.prm.Q[0]) / m : F;      // (NVE: md.py:145-148, no 1/m)
+            vn = v[e] + (vh[e] + 0.5f * a * dt);
+            v[e] = vn;
+        }
+        f[e] = F;
+        const size_t fr = ((size_t)rep * T + frame) * N * 3 + e;
+        A.q_t[fr] = q[e];
+        A.v_t[fr] = vn;
+        const float pn = vn * m;
+        kepart = pn * pn / m;
+        if (!(isfinite(vn) && isfinite(F))) A.flags[1] = 1;
+    }
+    kepart = wave_sum_rows(kepart);
+    if (lane == 0) red[wid] = kepart;
+    __syncthreads();
+    if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
 // by a fresh search (large_adj_listed below evaluates the forward pass's stored candidates instead).
@@ -1181,6 +1352,10 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     if (a.nl_idx) MDG_HIP(hipMemsetAsync(a.nl_bad, 0, sizeof(int32_t) * (size_t)R * T, st));
 #define LG_FORCE_STEP(MODE_)                                                                                    \
     do {                                                                                                        \
+        if (a.nl_idx && a.ncell) {         /* binned box, lists kept: the row-based search (one sweep) */      \
+            if (lj126) hipLaunchKernelGGL((large_search_rows<MODE_, KIND_LJ126>), gL, dim3(256), 0, st, a);   \
+            else hipLaunchKernelGGL((large_search_rows<MODE_, -1>), gL, dim3(256), 0, st, a);                  \
+        } else                                                                                                  \
         if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a); \
         else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);    \
         else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);            \
