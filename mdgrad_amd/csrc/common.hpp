@@ -35,6 +35,19 @@ RdfFinePlan mdg_rdf_fine_plan(float spacing, float coeff, int nbins);
 int mdg_rdf_fine_finish(const uint32_t* ghist, const RdfFinePlan& P, const float* mu, int nbins, float* raw, hipStream_t st);
 int mdg_rdf_bwd_table(const float* mu, float coeff, int nbins, const float* g_raw, const RdfFinePlan& P, float4* tab,
                       hipStream_t st);
+// ... the same cells, equally spaced in u = d^2 over the same distance range, holding (dL/dd)/d: a consumer that has d^2
+// (the ring adjoint, csrc/traj_ring.hpp) needs neither the square root nor the division by d
+int mdg_rdf_bwd_table_u(const float* mu, float coeff, int nbins, const float* g_raw, const RdfFinePlan& P, float4* tab,
+                        hipStream_t st);
+// grid of that table, derived from the (device-resident) centres: P.ncell cells over [xlo^2, xhi^2), xlo = mu0 - (R + 1) dmu,
+// xhi = xlo + ncell dmu / 8  (R = P.reach_bins; the r-space grid of csrc/rdf.hip's fine_grid())
+__device__ __forceinline__ void rdf_u_grid(const float* __restrict__ mu, int nbins, int R, float& ulo, float& hu, int& ncell) {
+    const float mu0 = mu[0], dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
+    ncell = (nbins - 1 + 2 * (R + 1)) * 8;
+    const float xlo = mu0 - (float)(R + 1) * dmu, xhi = fmaf((float)ncell, dmu * 0.125f, xlo);
+    ulo = xlo * xlo;
+    hu = (xhi * xhi - ulo) / (float)ncell;
+}
 
 // ----------------------------------------------------------------------------- cell
 // Minimum image exactly as topology.py:59-64: s = D . inv ; o = -(s > .5) + (s < -.5) ;

@@ -674,6 +674,35 @@ __global__ void rdf_bwd_table_kernel(const float* __restrict__ mu, float coeff, 
     tab[n] = make_float4(a_.x, a_.y, 3.f * (b_.x - a_.x) - 2.f * a_.y - b_.y, 2.f * (a_.x - b_.x) + a_.y + b_.y);
 }
 
+// The u-space variant (rdf_u_grid in common.hpp): node n at u_n = ulo + n hu, r = sqrt(u_n), holds
+// W = (dL/dd)(r) / r and hu dW/du = hu (S' / r - S / r^2) / (2 r)  with S = dL/dd, S' = dS/dd.
+__global__ void rdf_bwd_table_u_kernel(const float* __restrict__ mu, float coeff, int nbins,
+                                       const float* __restrict__ g_raw, int R, float4* __restrict__ tab) {
+    float ulo, hu;
+    int ncell;
+    rdf_u_grid(mu, nbins, R, ulo, hu, ncell);
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= ncell) return;
+    const float sc = sqrtf(-coeff * LOG2E);
+    const float mu0 = mu[0], dmu = (mu[nbins - 1] - mu0) / (float)(nbins - 1);
+    auto node = [&](int m) {
+        const float r = sqrtf(fmaf((float)m, hu, ulo));
+        const int kc = (int)rintf((r - mu0) / dmu);
+        float val = 0.f, der = 0.f;                                  // S and dS/dd, as rdf_fine_node
+        for (int k = max(0, kc - R - 1); k <= min(nbins - 1, kc + R + 1); ++k) {
+            const float xs = (r - mu[k]) * sc;
+            const float e = __builtin_amdgcn_exp2f(-xs * xs);
+            const float sg = g_raw[k] * 2.f * coeff / sc;
+            val = fmaf(sg * xs, e, val);
+            der = fmaf(sg * sc * (1.f - 2.f * 0.69314718056f * xs * xs), e, der);
+        }
+        const float ir = 1.0f / r;
+        return make_float2(val * ir, hu * (der * ir - val * ir * ir) * (0.5f * ir));
+    };
+    const float2 a_ = node(n), b_ = node(n + 1);
+    tab[n] = make_float4(a_.x, a_.y, 3.f * (b_.x - a_.x) - 2.f * a_.y - b_.y, 2.f * (a_.x - b_.x) + a_.y + b_.y);
+}
+
 // Fine-grid backward, one wave per frame.  Pair order: lane <-> atom i (64 at a time), step s <-> partner
 // j = (i + s) mod N, s = 1 .. N/2 (for an even N the last step only for i < N/2): every unordered pair once, and
 // in one step the partners of the 64 lanes are all different, so the partners' gradient read-add-writes never
@@ -1433,6 +1462,14 @@ int mdg_rdf_bwd_table(const float* mu, float coeff, int nbins, const float* g_ra
     const int nn = P.ncell + 1;
     hipLaunchKernelGGL(rdf_bwd_table_kernel, dim3((nn + 254) / 256), dim3(256), 0, st, mu, coeff, nbins, g_raw, P.reach_bins, tab);
     MDG_CHECK_LAUNCH("rdf_bwd_table_kernel");
+    return MDG_OK;
+}
+
+int mdg_rdf_bwd_table_u(const float* mu, float coeff, int nbins, const float* g_raw, const RdfFinePlan& P, float4* tab,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(rdf_bwd_table_u_kernel, dim3((P.ncell + 255) / 256), dim3(256), 0, st, mu, coeff, nbins, g_raw,
+                       P.reach_bins, tab);
+    MDG_CHECK_LAUNCH("rdf_bwd_table_u_kernel");
     return MDG_OK;
 }
 

@@ -61,8 +61,7 @@ struct LargeArgs {
     // (bin, atom index) as (x, y, z, index) and the first slot of every bin, rebuilt before each force evaluation
     float4* spos;                            // [R][N]
     int32_t* bstart;                         // [R][LG_MAX_CELLS + 1]
-    int32_t* bcount;                         // [2][R][LG_MAX_CELLS] ping-pong bin counters
-    int32_t* binslot;                        // [R][N] (slot << 12) | bin
+    int32_t* binslot;                        // [R][N] atom indices in provisional bin order (scratch of the binning)
     int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
     // neighbour lists of the forward pass, kept for the adjoint (nullptr: not kept).  A forward search uses the cutoff
     // (1 + LG_SKIN) rc and stores the ascending indices; later forward steps and the adjoint's two evaluations per
@@ -1201,7 +1200,7 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, bcount, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
+        spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
     bool keep_lists;
 };
 
@@ -1222,7 +1221,6 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.flags = take(16);
     w.spos = take((size_t)R * N * 4);
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
-    w.bcount = take((size_t)2 * R * LG_MAX_CELLS);
     w.binslot = take((size_t)R * N);
     // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
     const long long lw = (long long)R * T * N * (LG_LIST + 1) + 2ll * R * T + 2ll * R;
@@ -1299,7 +1297,6 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
     const bool diag = cell->diag != 0;                                                               \
     a.spos = reinterpret_cast<float4*>(ws + L.spos);                                                 \
     a.bstart = reinterpret_cast<int32_t*>(ws + L.bstart);                                            \
-    a.bcount = reinterpret_cast<int32_t*>(ws + L.bcount);                                            \
     a.binslot = reinterpret_cast<int32_t*>(ws + L.binslot);                                          \
     a.ncell = 0;                                                                                     \
     if (L.keep_lists && prm->block != -1) {          /* (block = -1: search at every evaluation) */       \

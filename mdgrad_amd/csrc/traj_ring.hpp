@@ -78,7 +78,7 @@ __device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
 //                      frame gradient dL/dq_t that the adjoint would otherwise load from HBM.
 struct RingRdf {
     uint32_t* hist; float inv_h, tlo, fmax;                 // RDF = 1: fine histogram [nfine], t = d inv_h + tlo < fmax
-    const float4* tab; float xlo, inv_hf, tmax;             // RDF = 2: cell cubics [nn-1], t = (d - xlo) inv_hf < tmax
+    const float4* tab; float ulo, inv_hu, tmax;             // RDF = 2: cell cubics of (dL/dd)/d in u = d^2, t = (d2 - ulo) inv_hu < tmax
                                                             // (fmax / tmax: end of the grid or the observable's cutoff)
 };
 
@@ -112,10 +112,10 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
         if (r1 && __float_as_uint(tb) < lim) atomicAdd(&X.hist[(int)tb], 1u);
     }
     if constexpr (RDF == 2) {
-        // rdf_bwd_fine_kernel: d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d; a rejected pair adds +-0
-        // (d2 = 0: rsq = inf, t = NaN -> rejected, and the selects below never let the inf through)
-        const f32x2 id = {__builtin_amdgcn_rsqf(d2.x), __builtin_amdgcn_rsqf(d2.y)};
-        f32x2 t = (d2 * id - X.xlo) * X.inv_hf;
+        // rdf_bwd_fine_kernel's gradient, d(dist)/dx_j = +D/d, d(dist)/dx_i = -D/d, from the table of (dL/dd)/d over
+        // u = d^2 (rdf_bwd_table_u_kernel): no square root, no division; a rejected pair adds +-0
+        // (d2 = 0: t = -ulo inv_hu < 0 -> rejected: the grid starts above zero)
+        f32x2 t = (d2 - X.ulo) * X.inv_hu;
         const uint32_t lim = __float_as_uint(X.tmax);
         const bool oka = r0 && __float_as_uint(t.x) < lim, okb = r1 && __float_as_uint(t.y) < lim;
         t = f32x2{oka ? t.x : 0.f, okb ? t.y : 0.f};
@@ -124,7 +124,7 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
         const float4 ca = X.tab[gA], cb = X.tab[gB];
         const float sdA = fmaf(fr.x, fmaf(fr.x, fmaf(fr.x, ca.w, ca.z), ca.y), ca.x);
         const float sdB = fmaf(fr.y, fmaf(fr.y, fmaf(fr.y, cb.w, cb.z), cb.y), cb.x);
-        const f32x2 cw = {oka ? sdA * id.x : 0.f, okb ? sdB * id.y : 0.f};
+        const f32x2 cw = {oka ? sdA : 0.f, okb ? sdB : 0.f};
         const f32x2 cx = cw * dx, cy = cw * dy, cz = cw * dz;
         ri.x -= cx; ri.y -= cy; ri.z -= cz;
         if constexpr (JSIDE) { rj.x += CROSS ? cx.yx : cx; rj.y += CROSS ? cy.yx : cy; rj.z += CROSS ? cz.yx : cz; }
@@ -497,13 +497,13 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
     RingRdf X{};
     int ncell = 0;
     if constexpr (RDF) {
-        // the fine grid of rdf_bwd_fine_kernel (fine_grid() in csrc/rdf.hip): RDF_SUB = 8 cells per centre spacing
-        const float mu0 = F.mu[0], dmu = (F.mu[F.nbins - 1] - mu0) / (float)(F.nbins - 1);
-        ncell = (F.nbins - 1 + 2 * (F.reach_bins + 1)) * 8;
+        // the cells of rdf_bwd_fine_kernel's table (8 per centre spacing over the same distances), equally spaced in d^2
+        float hu;
+        rdf_u_grid(F.mu, F.nbins, F.reach_bins, X.ulo, hu, ncell);
         float4* tab = reinterpret_cast<float4*>(smr);
         for (int n = lane; n < ncell; n += 64) tab[n] = F.tab[n];
-        X.tab = tab; X.xlo = mu0 - (float)(F.reach_bins + 1) * dmu; X.inv_hf = 8.f / dmu;
-        X.tmax = fminf((float)ncell, (F.rc - X.xlo) * X.inv_hf);
+        X.tab = tab; X.inv_hu = 1.0f / hu;
+        X.tmax = fminf((float)ncell, (F.rc * F.rc - X.ulo) * X.inv_hu);
         __syncthreads();
     }
     f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell);

@@ -977,7 +977,7 @@ extern "C" int mdg_traj_adj_small_rdf(const MdgTrajParams* prm, const MdgCell* c
     hipStream_t st = (hipStream_t)stream;
     float4* tab = nullptr;                                        // (stream-ordered scratch: no state, re-entrant)
     MDG_HIP(hipMallocAsync((void**)&tab, sizeof(float4) * (size_t)P.ncell, st));
-    rc = mdg_rdf_bwd_table(rdf->mu, rdf->coeff, rdf->nbins, g_raw, P, tab, st);
+    rc = mdg_rdf_bwd_table_u(rdf->mu, rdf->coeff, rdf->nbins, g_raw, P, tab, st);
     if (rc == MDG_OK) {
         RingRdfArgs F = ring_rdf_args(*rdf, P);
         F.tab = tab;
