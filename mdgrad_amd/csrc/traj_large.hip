@@ -64,7 +64,7 @@ struct LargeArgs {
     int32_t* binslot;                        // [R][N] atom indices in provisional bin order (scratch of the binning)
     int nb[3], ncell;                        // ncell == 0: scan all atoms through LDS tiles
     // neighbour lists of the forward pass, kept for the adjoint (nullptr: not kept).  A forward search uses the cutoff
-    // (1 + LG_SKIN) rc and stores the ascending indices; later forward steps and the adjoint's two evaluations per
+    // (1 + LG_SKIN) rc and stores the candidate indices; later forward steps and the adjoint's two evaluations per
     // interval gather those candidates and re-apply the exact cutoff test -- the same pair set as a fresh search as
     // long as no atom has moved more than skin/2 since the build (forward frames: by construction, see nl_build; the
     // adjoint's midpoint states: checked on the device by large_prep<3>; flags[5] then asks the caller for an adjoint
@@ -86,8 +86,9 @@ struct LargeArgs {
 // Binning: ONE workgroup of 1 024 threads per replica (large_prep below) counts its atoms into <= 4 096 bins with
 // LDS integer atomics (slot inside the bin = the atomic's return value), scans the counts in LDS and scatters
 // (x, y, z, index) to start[bin] + slot -- one launch, no global atomics, no counter buffers.
-// The slot order inside a bin depends on the atomic order; the force kernels therefore sort every atom's compacted
-// neighbour buffer by index, which restores the ascending-j order of the all-atom scan (same sums, same bits).
+// The atomic's order is only provisional: the final slot inside a bin is the atom's rank by index among its bin
+// mates, so the sorted array is the same on every run.  (The wave-per-atom kernels additionally sort every atom's
+// compacted neighbour buffer by index, which restores the ascending-j order of the all-atom scan: same sums, same bits.)
 constexpr int LG_MAX_CELLS = 4096;
 
 __device__ __forceinline__ int bin_coord_l(float x, float inv, int nb) {
