@@ -280,10 +280,13 @@ def large_list_builds(spec):
     backward pass): int32 [R, T], entry (r, f) = the frame whose neighbour search produced the candidate list that
     served frame f (Verlet reuse, csrc/traj_large.hip); None when the lists were not kept.  Diagnostics:
     `len(set(row))` searches ran for that replica."""
-    ref, (R, N, T, KT) = spec._last_large
+    last = getattr(spec, "_last_large", None)
+    if last is None:
+        raise RuntimeError("mdgrad_amd: no trajectory of the multi-launch (large-N) kernels has run on this spec")
+    ref, (R, N, T, KT) = last
     ws = ref()
     if ws is None:
-        raise RuntimeError("mdgrad_amd: the trajectory's workspace has been released")
+        raise RuntimeError("mdgrad_amd: the trajectory's workspace has been released (ask before the backward pass ends)")
     out = torch.empty(R, T, dtype=torch.int32, device=ws.device)
     rc = _lib.load().mdg_traj_large_list_builds(ptr(ws), R, N, T, KT, ptr(out), stream_ptr(ws.device))
     if rc == 1:
