@@ -529,6 +529,37 @@ def test_large_path_nve_two_replicas_lists_reused_equal_fresh_searches():
         close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-12, "%s (NVE, lists vs searches)" % nm)
 
 
+def test_three_bins_per_side_large_path_and_cell_rdf_vs_oracle():
+    """The smallest box the cell-binned kernels accept: exactly three bins per side (512-atom LJ liquid, L = 8.46 =
+    3 x 2.82), where every stencil wraps around and covers the whole box.  The multi-launch trajectory kernels
+    (row-based search, listed kernels) forward + adjoint, and the list-free RDF sweeps (half stencil forward, full
+    stencil backward), each against the oracle."""
+    from mdgrad_amd import ops
+    from mdgrad_amd.observable import rdf
+    pos, cell = liquid(8, seed=61, jitter=0.08)
+    assert 3 * 2.8 <= float(cell[0]) < 4 * 2.8
+    _large_case(8, 9, True, seed=61)
+    rng = np.random.default_rng(62)
+    frames = np.stack([np.mod(pos + rng.normal(0, 0.06, pos.shape), cell) for _ in range(4)]).astype(np.float32)
+    frames[2, ::5] -= np.asarray(cell, dtype=np.float32)                  # unwrapped coordinates
+    system = mk_system(pos, cell)
+    wgt = torch.linspace(-1, 1, 100)
+    x = T(frames, DEV).requires_grad_(True)
+    was = ops.RDF_LIST_ATOMS
+    ops.RDF_LIST_ATOMS = 256                                          # (the cell path normally starts at 2 048 atoms)
+    try:
+        obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+        count, bins, gr = obs(x)
+        (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    finally:
+        ops.RDF_LIST_ATOMS = was
+    xo = T(frames).requires_grad_(True)
+    _, _, go = O.rdf_oracle(xo, T(cell), 100, (0.75, 2.5))
+    (gxo,) = torch.autograd.grad((go * wgt).sum(), xo)
+    close(gr, go, 1e-4, 1e-4, "g(r), three bins per side")
+    close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, three bins per side")
+
+
 def test_large_path_4096_atoms_one_step_vs_oracle():
     """BASELINE config #4's size: one forward NH-Verlet step of the 4 096-atom LJ liquid against the oracle."""
     _large_case(16, 2, False, seed=36)
