@@ -50,6 +50,7 @@ struct LargeArgs {
     int32_t* flags;                          // [0] neighbour-buffer overflow, [1] non-finite, [2] table-gradient range, [3] pair below the table
     const float *g_v, *g_q, *g_pv;           // adjoint: incoming frame gradients (nullable)
     float *lv, *lq, *lvh, *lqh, *dq, *qm, *vm;   // [R][N][3]
+    float *wl;                               // [R][N][3] adjoint direction of the coming listed evaluation: lam_v / m (NVE: lam_v)
     float *lp, *lph, *pvm;                   // [R][16]
     float *partN;                            // [R][nb][LG_NV]
     float *gth;                              // [R][K_total]
@@ -293,7 +294,17 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             }
         }
         if constexpr (PHASE == 2) {
-            if (A.nl_idx) return;                                       // the stored candidates of frame i serve
+            if (A.nl_idx) {
+                // the stored candidates of frame i serve; the listed evaluation gathers w = lam_v / m (NVE: lam_v) of
+                // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic)
+#pragma unroll
+                for (int u = 0; u < 3 * NA; ++u) {
+                    const int e = tid + u * stride;
+                    if (e >= 3 * N) break;
+                    A.wl[so + e] = nhc ? A.lv[so + e] * (1.0f / A.mass[e / 3]) : A.lv[so + e];
+                }
+                return;
+            }
             const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
@@ -358,14 +369,18 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                         const float vhalf = 0.5f * (-acc) * h;                           // :132
                         qn[c] = A.q_t[ef] + (ve + vhalf) * h;                            // :138 (forward-time sign)
                         A.vm[e] = ve + vhalf;
-                        A.lvh[e] = A.lv[e] + Gv * 0.5f * h;                              // :141
+                        const float lvh_ = A.lv[e] + Gv * 0.5f * h;                      // :141
+                        A.lvh[e] = lvh_;
+                        if (A.nl_idx) A.wl[e] = lvh_ * (1.0f / m);                       // (the listed midpoint evaluation's w)
                         A.lqh[e] = A.lq[e] + A.dq[e] * 0.5f * h;                         // :142
                     } else {
                         const float vhalf = ve - 0.5f * (-A.f[e]) * h;                   // :49-50
                         qn[c] = A.q_t[ef] - vhalf * h;                                   // :51-52
                         A.vm[e] = vhalf;
                         const float dx = A.dq[e] * h * 0.5f;                             // :71
-                        A.lvh[e] = A.lv[e] + (A.lq[e] + dx) * h;                         // :72
+                        const float lvh_ = A.lv[e] + (A.lq[e] + dx) * h;                 // :72
+                        A.lvh[e] = lvh_;
+                        if (A.nl_idx) A.wl[e] = lvh_;
                         A.lqh[e] = A.lq[e] + dx;
                     }
                     A.qm[e] = qn[c];
@@ -1132,34 +1147,31 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
 #pragma unroll
     for (int p = 0; p < NP; ++p) jj[p] = idx[s + 16 * p];
     const int n = (valid && !bad) ? min(A.nl_cnt[at], LG_LIST) : 0;
-    const Row3 qi = row3(q, ic), li = row3(lam, ic);
+    const float* wl = A.wl + so;                                       // w = lam_v / m (NVE: lam_v), written by large_prep<2|3>
+    const Row3 qi = row3(q, ic), li = row3(wl, ic);
     const float xi = qi.x, yi = qi.y, zi = qi.z;
-    const float mi = A.mass[ic], imi = nhc ? 1.0f / mi : 1.0f;
-    const float wxi = li.x * imi, wyi = li.y * imi, wzi = li.z * imi;
+    const float mi = A.mass[ic];
+    const float wxi = li.x, wyi = li.y, wzi = li.z;
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
-    // software pipeline over the passes: (position, direction, mass) of pass p + 1 in flight while pass p is evaluated
+    // software pipeline over the passes: (position, direction) of pass p + 1 in flight while pass p is evaluated
     int jn = s < n ? jj[0] : ic;
-    Row3 qn = row3(q, jn), ln = row3(lam, jn);
-    float mj = nhc ? A.mass[jn] : 1.0f;
+    Row3 qn = row3(q, jn), ln = row3(wl, jn);
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
         if (p > 0 && __ballot(s + 16 * p < n) == 0) break;            // (wave-uniform: every row is through)
         const int j = jn;
         float dx = qn.x - xi, dy = qn.y - yi, dz = qn.z - zi;           // D = x_j - x_i
-        const float ax = ln.x, ay = ln.y, az = ln.z, am = mj;
+        const float ax = ln.x, ay = ln.y, az = ln.z;
         if (p + 1 < NP) {
             jn = s + 16 * (p + 1) < n ? jj[p + 1] : ic;
-            qn = row3(q, jn); ln = row3(lam, jn);
-            if (nhc) mj = A.mass[jn];
+            qn = row3(q, jn); ln = row3(wl, jn);
         }
         min_image<DIAG>(A.cell, dx, dy, dz);
         const float d2 = norm2_ref(dx, dy, dz);
         if (d2 == 0.f) continue;                                        // the atom itself (idle lanes) -- topology.py:67
-        const float jm = nhc ? __builtin_amdgcn_rcpf(am) : 1.0f;
-        pair_terms<2, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, ax * jm, ay * jm, az * jm, gw, rep,
-                            fx, fy, fz, gx, gy, gz, th);
+        pair_terms<2, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, ax, ay, az, gw, rep, fx, fy, fz, gx, gy, gz, th);
     }
     fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
     gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);
@@ -1200,7 +1212,7 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
 }
 
 struct WsLayout {
-    size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
+    size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, wl, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
         spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
     bool keep_lists;
 };
@@ -1211,7 +1223,7 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     auto take = [&](size_t n) { size_t r = o; o += (n + 63) / 64 * 64; return r; };
     const size_t s3 = (size_t)R * N * 3, sc = (size_t)R * MDG_MAX_CHAINS;
     w.q = take(s3); w.v = take(s3); w.vh = take(s3); w.f = take(s3);
-    w.lv = take(s3); w.lq = take(s3); w.lvh = take(s3); w.lqh = take(s3); w.dq = take(s3); w.qm = take(s3); w.vm = take(s3);
+    w.lv = take(s3); w.lq = take(s3); w.lvh = take(s3); w.lqh = take(s3); w.dq = take(s3); w.qm = take(s3); w.vm = take(s3); w.wl = take(s3);
     w.pv = take(sc); w.ph = take(sc); w.pvh = take(sc); w.lp = take(sc); w.lph = take(sc); w.pvm = take(sc);
     const int nbmax = nb > (3 * N + 255) / 256 ? nb : (3 * N + 255) / 256;
     w.partA = take((size_t)R * nbmax); w.partB = take((size_t)R * nbmax);
@@ -1287,7 +1299,7 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
     a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;   \
     a.q = ws + L.q; a.v = ws + L.v; a.vh = ws + L.vh; a.f = ws + L.f;                                \
     a.lv = ws + L.lv; a.lq = ws + L.lq; a.lvh = ws + L.lvh; a.lqh = ws + L.lqh; a.dq = ws + L.dq;    \
-    a.qm = ws + L.qm; a.vm = ws + L.vm;                                                              \
+    a.qm = ws + L.qm; a.vm = ws + L.vm; a.wl = ws + L.wl;                                            \
     a.pv = ws + L.pv; a.ph = ws + L.ph; a.pvh = ws + L.pvh; a.lp = ws + L.lp; a.lph = ws + L.lph;    \
     a.pvm = ws + L.pvm; a.partA = ws + L.partA; a.partB = ws + L.partB; a.partN = ws + L.partN;      \
     a.gth = ws + L.gth; a.flags = flags; a.nbE = nbE;                                                \
