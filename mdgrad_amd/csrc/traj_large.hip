@@ -70,7 +70,7 @@ struct LargeArgs {
     // long as no atom has moved more than skin/2 since the build (forward frames: by construction, see nl_build; the
     // adjoint's midpoint states: checked on the device by large_prep<3>; flags[5] then asks the caller for an adjoint
     // with fresh searches).
-    int32_t* nl_idx;                         // [R][T][N][LG_LIST]
+    uint16_t* nl_idx;                        // [R][T][N][LG_LIST]  (16-bit: N <= 16 384; the rows are the HBM traffic of the listed launches)
     int32_t* nl_cnt;                         // [R][T][N]
     int32_t* nl_bad;                         // [R][T]  an atom of this frame had more than LG_LIST candidates
     // Verlet reuse: a list serves every later frame until an atom has moved LG_REUSE x skin from its build positions
@@ -673,7 +673,7 @@ __device__ __forceinline__ void wave_neighbours_and_force(
             // (all-atom scan: the buffer is in ascending index order by construction; cell scan: rank-sorted above)
             const size_t at = ((size_t)rep * A.prm.n_frames + frame) * N + i;
             if (n <= LG_LIST) {
-                for (int k = lane; k < n; k += 64) A.nl_idx[at * LG_LIST + k] = __float_as_int(buf[k].w);
+                for (int k = lane; k < n; k += 64) A.nl_idx[at * LG_LIST + k] = (uint16_t)__float_as_int(buf[k].w);
                 if (lane == 0) A.nl_cnt[at] = n;
             } else if (lane == 0) { A.nl_bad[(size_t)rep * A.prm.n_frames + frame] = 1; A.flags[4] = 1; }
         }
@@ -840,10 +840,11 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     const bool valid = i < N;
     const int ic = valid ? i : N - 1;
     const size_t at = ((size_t)rep * T + slot) * N + ic;
-    const int32_t* idx = A.nl_idx + at * LG_LIST;
+    // (entry s + 16 p of the row: two 16-bit entries per word, lanes 2t and 2t + 1 read the same word)
+    const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
     int jj[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) jj[p] = idx[s + 16 * p];
+    for (int p = 0; p < NP; ++p) jj[p] = (int)((idx[(s >> 1) + 8 * p] >> (16 * (s & 1))) & 0xffffu);
     const int n = valid ? min(A.nl_cnt[at], LG_LIST) : 0;
     const Row3 qi = row3(q, ic);
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
     const float4 pi = sp[valid ? slot : N - 1];
     const int i = __float_as_int(pi.w);
     const size_t at = ((size_t)rep * T + frame) * N + i;
-    int32_t* lrow = A.nl_idx + at * LG_LIST;
+    uint16_t* lrow = A.nl_idx + at * LG_LIST;
     int cnt = 0;                                                     // candidates of the row's atom so far (row-uniform)
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
     // every lane runs this for every chunk (live = it holds a candidate): the row's ballot bits give the slots
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
         const unsigned rowmask = (unsigned)(__ballot(in) >> (16 * row)) & 0xffffu;
         if (in) {
             const int at_ = cnt + __popc(rowmask & ((1u << s) - 1u));
-            if (at_ < LG_LIST) lrow[at_] = j;
+            if (at_ < LG_LIST) lrow[at_] = (uint16_t)j;
             if (d2 != 0.f)                                                    // topology.py:67
                 pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx,
                                     gy, gz, th);
@@ -1142,10 +1143,11 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && bad) A.flags[5] = 1;
     const size_t at = ((size_t)rep * T + slot) * N + ic;
-    const int32_t* idx = A.nl_idx + at * LG_LIST;
+    // (entry s + 16 p of the row: two 16-bit entries per word, lanes 2t and 2t + 1 read the same word)
+    const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
     int jj[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) jj[p] = idx[s + 16 * p];
+    for (int p = 0; p < NP; ++p) jj[p] = (int)((idx[(s >> 1) + 8 * p] >> (16 * (s & 1))) & 0xffffu);
     const int n = (valid && !bad) ? min(A.nl_cnt[at], LG_LIST) : 0;
     const float* wl = A.wl + so;                                       // w = lam_v / m (NVE: lam_v), written by large_prep<2|3>
     const Row3 qi = row3(q, ic), li = row3(wl, ic);
@@ -1236,10 +1238,10 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
     w.binslot = take((size_t)R * N);
     // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
-    const long long lw = (long long)R * T * N * (LG_LIST + 1) + 2ll * R * T + 2ll * R;
+    const long long lw = (long long)R * T * N * (LG_LIST / 2 + 1) + 2ll * R * T + 2ll * R;
     w.keep_lists = T > 1 && lw <= LG_LIST_MAX_WORDS;
     if (w.keep_lists) {
-        w.nl_idx = take((size_t)R * T * N * LG_LIST); w.nl_cnt = take((size_t)R * T * N);
+        w.nl_idx = take((size_t)R * T * N * (LG_LIST / 2)); w.nl_cnt = take((size_t)R * T * N);
         w.nl_bad = take((size_t)R * T); w.nl_build = take((size_t)R * T); w.nl_state = take((size_t)2 * R);
     }
     w.total = o;
@@ -1313,7 +1315,7 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
     a.binslot = reinterpret_cast<int32_t*>(ws + L.binslot);                                          \
     a.ncell = 0;                                                                                     \
     if (L.keep_lists && prm->block != -1) {          /* (block = -1: search at every evaluation) */       \
-        a.nl_idx = reinterpret_cast<int32_t*>(ws + L.nl_idx); a.nl_cnt = reinterpret_cast<int32_t*>(ws + L.nl_cnt); \
+        a.nl_idx = reinterpret_cast<uint16_t*>(ws + L.nl_idx); a.nl_cnt = reinterpret_cast<int32_t*>(ws + L.nl_cnt); \
         a.nl_bad = reinterpret_cast<int32_t*>(ws + L.nl_bad);                                        \
         a.nl_build = reinterpret_cast<int32_t*>(ws + L.nl_build);                                    \
         a.nl_state = reinterpret_cast<int32_t*>(ws + L.nl_state);                                    \
