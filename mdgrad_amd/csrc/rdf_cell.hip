@@ -178,14 +178,15 @@ __device__ __forceinline__ void row_candidates(const float4* __restrict__ sp, co
 __global__ __launch_bounds__(RC_THREADS) void rdf_cell_fwd_kernel(const float4* __restrict__ spos,
                                                                   const int32_t* __restrict__ bstart, int N, int total,
                                                                   MdgCell cell, CellGrid g, const float* __restrict__ mu,
-                                                                  float reach, float inv_h, int nfine,
+                                                                  float reach, float inv_h, int nfine, float cutoff,
                                                                   uint32_t* __restrict__ ghist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
     const float tlo = -(mu[0] - reach) * inv_h;                        // fine bin of distance d: d inv_h + tlo
     for (int m = threadIdx.x; m < nfine; m += blockDim.x) hist[m] = 0u;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const uint32_t fmax_bits = __float_as_uint((float)nfine);
+    // (pairs beyond the list cutoff are not counted, as over a neighbour list: the stencil only reaches that far)
+    const uint32_t fmax_bits = __float_as_uint(fminf((float)nfine, fmaf(cutoff, inv_h, tlo)));
     for (int t0 = (blockIdx.x * nw + wid) * 4; t0 < total; t0 += gridDim.x * nw * 4) {
         const int t = t0 + (lane >> 4);
         const bool valid = t < total;
@@ -292,7 +293,7 @@ extern "C" int mdg_rdf_fwd_cell(const float* xyz, int n_frames, int n_atoms, con
     int grid = (total + 63) / 64;
     if (grid > 512) grid = 512;                                      // (persistent: one histogram flush per workgroup)
     hipLaunchKernelGGL(rdf_cell_fwd_kernel, dim3((unsigned)grid), dim3(RC_THREADS), sizeof(uint32_t) * (size_t)P.nfine, st,
-                       S.spos, S.bstart, n_atoms, total, *cell, g, mu, P.reach, 1.0f / P.h, (int)P.nfine, ghist);
+                       S.spos, S.bstart, n_atoms, total, *cell, g, mu, P.reach, 1.0f / P.h, (int)P.nfine, cutoff, ghist);
     const int rc = mdg_rdf_fine_finish(ghist, P, mu, nbins, raw, st);
     (void)hipFreeAsync(ghist, st);
     if (rc) return rc;
