@@ -615,9 +615,9 @@ def main():
             # tolerance: tests/test_gpu_config5.py) and reports the all-f32 rate beside it
             a16 = copy.copy(args)
             a16.bf16 = True
-            for name, fn, st, a_ in (("schnet4096", run_schnet4096, 3, a16), ("lj4096", run_lj4096, 5, args)):
+            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 3, 1, a16), ("lj4096", run_lj4096, 10, 2, args)):
                 try:
-                    sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=1)
+                    sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
                 except (Exception, SystemExit) as e:        # a secondary workload must not take the headline down
                     sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             if "error" not in sec["schnet4096"] and not args.bf16:
