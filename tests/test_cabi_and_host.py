@@ -204,3 +204,28 @@ def test_rdf_recognises_time_slices_of_a_fused_trajectory():
     spec.rdf_hint = hint
     q_t._mdg_traj = (spec, 1, hint, raw)
     assert other._fused_raw(q_t[:, ::2]) is None
+
+
+def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
+    """Host-only entry points (no kernel runs): which boxes the list-free RDF sweeps accept, their scratch size, loud
+    argument checks, and the large-path workspace that holds the stored candidate lists (16-bit indices, 128 per atom
+    and frame) until they would exceed the cap."""
+    from mdgrad_amd import _lib
+    lib = _lib.load()
+    box = _lib.make_cell([16.9, 16.9, 16.9])
+    assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(box), 2.62) == 1
+    assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(box), 6.0) == 0                 # fewer than 3 bins per side
+    assert lib.mdg_rdf_cell_supported(20000, ctypes.byref(box), 2.62) == 0               # above 16 384 atoms
+    tri = _lib.make_cell(torch.tensor([[16.9, 0, 0], [3.0, 16.9, 0], [0, 0, 16.9]]))
+    assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(tri), 2.62) == 0                # orthorhombic cells only
+    nb = int(16.9 // 2.62)
+    assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(box), 2.62) == 5 * 11 * 4096 + 11 * (nb ** 3 + 1)
+    assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(tri), 2.62) == -1
+    assert lib.mdg_rdf_fwd_cell(None, 11, 4096, ctypes.byref(box), 2.62, None, 0.0175, -1632.0, 100, None, None, None) == -1
+    assert b"rdf_fwd_cell" in lib.mdg_last_error()
+    # workspace: running state + per-frame candidate rows (N * 128 * 2 bytes = N * 64 words) while they fit
+    w10, w20 = lib.mdg_traj_large_workspace(1, 4096, 10, 2), lib.mdg_traj_large_workspace(1, 4096, 20, 2)
+    per_frame = (w20 - w10) / 10
+    assert 4096 * 64 <= per_frame <= 4096 * 64 + 4096 + 1024, per_frame
+    huge = lib.mdg_traj_large_workspace(64, 16384, 2000, 2)                              # lists would need > 32 GiB
+    assert huge < 64 * 16384 * 2000, "beyond the cap the lists are not kept (every evaluation searches)"
