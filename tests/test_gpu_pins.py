@@ -794,6 +794,29 @@ def test_list_based_rdf_for_large_systems_vs_oracle(direct):
     close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, cell-based")
 
 
+def test_cell_sweep_rdf_in_a_dilute_box_with_capped_bins_vs_oracle():
+    """A dilute gas in a large box: the bin count per side is capped at 16 (bins wider than the list cutoff), most
+    bins are empty, a few atoms sit in the same spot twice (d = 0 pairs are not counted, topology.py:67)."""
+    from mdgrad_amd.observable import rdf
+    rng = np.random.default_rng(12)
+    L = 60.0
+    cell = np.array([L, L, L], dtype=np.float32)
+    pos = rng.uniform(0, L, (2048, 3)).astype(np.float32)
+    pos[1::2] = np.mod(pos[0::2] + rng.normal(0, 0.9, (1024, 3)), L).astype(np.float32)      # pairs within reach
+    pos[100] = pos[7]                                                                        # a coincident pair
+    frames = np.stack([pos, np.mod(pos + rng.normal(0, 0.3, pos.shape), L).astype(np.float32)])
+    system = mk_system(pos, cell)
+    wgt = torch.linspace(1, 2, 100)
+    x = T(frames, DEV).requires_grad_(True)
+    count, bins, gr = rdf(system, nbins=100, r_range=(0.75, 2.5))(x)
+    (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    xo = T(frames).requires_grad_(True)
+    _, _, go = O.rdf_oracle(xo, T(cell), 100, (0.75, 2.5))
+    (gxo,) = torch.autograd.grad((go * wgt).sum(), xo)
+    close(gr, go, 2e-4, 2e-4 * float(go.detach().abs().max()), "g(r), dilute box")
+    close(gx, gxo, 2e-3, 2e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, dilute box")
+
+
 def test_cell_sweep_rdf_equals_list_rdf_and_is_reproducible():
     """The direct sweep and the list-based kernels count the same pairs on the same integer grid: the same raw
     histograms (4 096 atoms, 5 frames, one of them a dense cluster that makes bins longer than a wave), and two runs of
