@@ -12,6 +12,7 @@ with its own value / ms_per_step / roofline / cpu_baseline):
   lj4096       4 096-atom LJ liquid (BASELINE config #4), fused large-N kernels, 64 replicas / GPU
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus 8 --steps 10 --warmup 2         # spawns its own 8 ranks (torch.distributed.run, RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29511 bench.py --gpus 8 --steps 10 --warmup 2
     python bench.py --workload schnet4096      # one workload alone as the printed line
@@ -54,6 +55,14 @@ def _profile_json(name):
         return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
+
+
+def _dist_record(mdist, dev, params, el_rank, ms_rank):
+    """Evidence that the N ranks ran and met in the collective: backend, ranks counted by an
+    all-reduce of ones, the time of one all-reduce of the flat-gradient-sized buffer, every rank's ms per pass."""
+    rec = mdist.collective_evidence(dev, sum(p.numel() for p in params))
+    rec["per_rank_ms"] = mdist.gather_over_ranks(ms_rank, dev)
+    return rec
 
 
 # ====================================================================================== 108-atom LJ (headline)
@@ -165,7 +174,8 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
         loss = step()
     torch.cuda.synchronize()
     mdist.barrier()
-    el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    el_rank = time.perf_counter() - t0
+    el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(step.last_q) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     md_steps = R * (T - 1) * world * args.steps
@@ -178,6 +188,7 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
                                   "%d replicas/GPU per pass" % (T - 1, R),
                       "replicas_per_gpu": R, "md_steps_per_pass": R * (T - 1), "parallelism": "replica-dp%d" % world,
                       "loss": float(loss.detach())}}
+    out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / args.steps * 1e3)
     if rank != 0:
         return out
     # ---- roofline of the dominant kernel (adjoint sweep): HIP events on the launch stream over repeated launches
@@ -388,7 +399,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
         loss, q_last = step()
     torch.cuda.synchronize()
     mdist.barrier()
-    el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    el_rank = time.perf_counter() - t0
+    el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(q_last) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     N = base.get_number_of_atoms()
@@ -401,6 +413,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                                   "cutoff 6, NoseHooverChain(Q=50, 5 chains), %d steps fwd + RDF(60 bins) loss + analytic "
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
+    out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
     if rank != 0:
         return out
     # ---- roofline: (a) the dominant kernel of the step, the fused interaction block's forward + tangent sweep
@@ -543,7 +556,8 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
         loss, q_last = step()
     torch.cuda.synchronize()
     mdist.barrier()
-    el = mdist.max_over_ranks(time.perf_counter() - t0, dev)
+    el_rank = time.perf_counter() - t0
+    el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(q_last) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     md_steps = R * (T - 1) * world * steps
@@ -554,6 +568,7 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
                                   "steps fwd + RDF(100 bins, every 5th frame) loss + adjoint; %d replicas/GPU per pass, "
                                   "cell-binned neighbour search fused into every force evaluation" % (T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
+    out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
     if rank != 0:
         return out
     ell = ops.build_ell(pos[0], spec.cell_struct, 2.5)
@@ -596,6 +611,12 @@ def main():
     args = ap.parse_args()
 
     from mdgrad_amd import dist as mdist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: spawn the N ranks ourselves (one per GPU, rendezvous on
+        # 127.0.0.1 at a free port); rank 0 of the children prints the ONE JSON line on our stdout
+        if os.environ.get("MDG_SINGLE_DEVICE") != "1" and torch.cuda.device_count() < args.gpus:
+            raise SystemExit("--gpus %d but only %d HIP device(s) are visible" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(mdist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank, world, dev = mdist.init()
     if dev.type != "cuda":
         raise SystemExit("bench.py needs a HIP device (the hot path has no CPU implementation)")

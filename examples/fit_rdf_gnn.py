@@ -13,6 +13,7 @@ all-reduce of the parameter gradient per epoch precedes identical optimizer step
 the filter network of the fused interaction block on bf16 MFMA operands.
 
     python examples/fit_rdf_gnn.py --size 4 --replicas 8 --epochs 20
+    python examples/fit_rdf_gnn.py --gpus 8 --size 8 --replicas 8 --bf16     # spawns its own 8 ranks (RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29512 \
         examples/fit_rdf_gnn.py --size 8 --replicas 8 --bf16
     python examples/fit_rdf_gnn.py --target my_rdf.csv     # (r, g) columns instead of the synthetic target
@@ -47,7 +48,11 @@ def main(argv=None):
     ap.add_argument("--target", default=None)
     ap.add_argument("--filters", type=int, default=128, help="n_filters of the SchNet (config #5: 128)")
     ap.add_argument("--bf16", action="store_true", help="bf16 MFMA operands in the cfconv filter network")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks to spawn (one per GPU) when started without a launcher")
     args = ap.parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from mdgrad_amd import dist as mdist
+        sys.exit(mdist.self_launch(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus))
     from mdgrad_amd import fit, potentials as P, units
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
     from mdgrad_amd.md import NoseHooverChain, Simulations

@@ -62,6 +62,60 @@ def unflatten_to_grads(flat, params):
         pos += n
 
 
+class GradBucket:
+    """ONE persistent flat gradient buffer for a parameter list; every `p.grad` is a view into it.
+
+    The buffer is allocated once (7 MB for the SchNet of BASELINE config #5) and handed to the collective as is:
+    no `torch.cat`, no per-parameter clone per outer step.  A gradient that autograd (re)allocated since the last
+    step -- `zero_grad(set_to_none=True)` drops the views -- is copied into its slice once and `p.grad` re-pointed
+    at the view, so the optimizer reads the reduced values; gradients accumulated in place into the views (the
+    `zero_grad(set_to_none=False)` idiom) cost nothing."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.offsets = []
+        n = 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += p.numel()
+        ref = self.params[0]
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+
+    def matches(self, params):
+        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+
+    def gather(self):
+        """Bring every parameter's gradient into the flat buffer (no-op for those that already live there)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr() or g.shape != v.shape or not g.is_contiguous():
+                src.append(g.detach().to(v.dtype))
+                dst.append(v)
+            if g is None or g is not v:
+                p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        return self.flat
+
+
+_buckets = []
+
+
+def _bucket_for(params):
+    for b in _buckets:
+        if b.matches(params):
+            return b
+    b = GradBucket(params)
+    _buckets.append(b)
+    if len(_buckets) > 8:
+        _buckets.pop(0)
+    return b
+
+
 def _all_reduce(t, op):
     """all_reduce that also works when a CPU-only backend (gloo) is given a HIP tensor."""
     if t.is_cuda and dist.get_backend() == "gloo":
@@ -73,16 +127,16 @@ def _all_reduce(t, op):
 
 
 def all_reduce_grads(params, average=False):
-    """One collective per outer step: SUM (or mean) of the flat gradient over all ranks,
-    written back into p.grad.  No-op for world_size 1."""
+    """One collective per outer step: SUM (or mean) of the flat gradient over all ranks; afterwards every
+    `p.grad` is a view of the reduced persistent buffer (`GradBucket`).  No-op for world_size 1."""
     params = list(params)
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not params:
         return
-    flat = flatten_grads(params)
+    bucket = _bucket_for(params)
+    flat = bucket.gather()
     _all_reduce(flat, dist.ReduceOp.SUM)
     if average:
         flat /= dist.get_world_size()
-    unflatten_to_grads(flat, params)
 
 
 def barrier():
@@ -104,3 +158,65 @@ def sum_over_ranks(value, device):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     _all_reduce(t, dist.ReduceOp.SUM)
     return float(t.item())
+
+
+def gather_over_ranks(value, device):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one small all_gather)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    w = dist.get_world_size()
+    gloo_on_gpu = device.type == "cuda" and dist.get_backend() == "gloo"
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if gloo_on_gpu else device)
+    out = [torch.zeros_like(t) for _ in range(w)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
+
+
+def collective_evidence(device, n_elems, reps=20):
+    """What a record needs to show that the collective really ran over `world` ranks: the backend, the number of ranks
+    that contributed to a SUM of ones, and the time of one all-reduce of an `n_elems` fp32 buffer (the size of the
+    flat parameter gradient of the workload), measured on this rank around `reps` back-to-back collectives."""
+    import time
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return {"backend": None, "world": 1, "ranks_seen": 1, "allreduce_us": None, "allreduce_elems": int(n_elems)}
+    one = torch.ones(1, dtype=torch.float32, device=device)
+    _all_reduce(one, dist.ReduceOp.SUM)
+    buf = torch.zeros(max(1, int(n_elems)), dtype=torch.float32, device=device)
+    _all_reduce(buf, dist.ReduceOp.SUM)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _all_reduce(buf, dist.ReduceOp.SUM)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    return {"backend": dist.get_backend(), "world": dist.get_world_size(), "ranks_seen": int(round(float(one.item()))),
+            "allreduce_us": max_over_ranks(us, device), "allreduce_elems": int(n_elems)}
+
+
+def self_launch(script, argv, n_ranks):
+    """Start `n_ranks` ranks of `script` through torch.distributed.run (one per visible GPU, rendezvous on 127.0.0.1
+    at a free port) when the caller was started as a plain `python script --gpus N` without a launcher, and return the
+    launcher's exit code.  The children see RANK / LOCAL_RANK / WORLD_SIZE and take the normal path."""
+    import socket
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    rc = 1
+    for _ in range(3):                    # a probed port can be taken between the probe and the rendezvous
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+        r = subprocess.run(cmd, env=env, stderr=subprocess.PIPE, text=True)
+        sys.stderr.write(r.stderr)
+        rc = r.returncode
+        if rc == 0 or "address already in use" not in r.stderr.lower():
+            break
+    return rc

@@ -6,6 +6,8 @@ differentiable twice) that the reference's Python solvers call; `fused_spec(meth
 the same dynamics to the fused HIP trajectory kernels when that is possible.
 """
 import numpy as np
+import weakref
+
 import torch
 
 from . import units, ops
@@ -159,12 +161,19 @@ class _EOM(torch.nn.Module):
             # very same saved frame (the dL/dt call of sovlers.py:258, then the first augmented evaluation).  A
             # rebuild at the same tensor object (unchanged version, nobody else touched the model's topology in
             # between) returns the same list, so it is skipped; the counter still advances.
+            # (held through a weak reference: `q` is usually a view of the saved trajectory, which must not be kept
+            # alive past backward; inference-mode tensors have no version counter and always rebuild)
             m = self.model
-            same = (getattr(self, "_topo_q", None) is q and self._topo_ver == q._version
+            try:
+                ver = q._version
+            except RuntimeError:
+                ver = None
+            ref = getattr(self, "_topo_ref", None)
+            same = (ver is not None and ref is not None and ref() is q and self._topo_ver == ver
                     and getattr(m, "_topo_stamp", None) is self._topo_stamp)
             if not same:
                 m._reset_topology(q)
-                self._topo_q, self._topo_ver, self._topo_stamp = q, q._version, getattr(m, "_topo_stamp", None)
+                self._topo_ref, self._topo_ver, self._topo_stamp = weakref.ref(q), ver, getattr(m, "_topo_stamp", None)
         self.update_count += 1
 
     def attach_observable(self, obs, start=0, stride=1):

@@ -2,6 +2,8 @@
 :10-21, Observable :24-31, rdf :33-76, vacf :153-163.  The pair search + Gaussian smearing +
 histogram of rdf.forward is one HIP op (ops.RdfRawFn, csrc/rdf.hip); vacf is one fused reduction over the
 velocity trajectory (ops.VacfFn, csrc/observe.hip)."""
+import warnings
+
 import numpy as np
 import torch
 
@@ -54,6 +56,8 @@ class rdf(Observable):
         self.index_tuple = index_tuple
         self._cell_struct = _lib.make_cell(self.cell)      # diagonal of the cell, as the reference
         self._mask = ops.build_mask(self.natoms, index_tuple, None, self.device)
+        self._warned_fused = False
+        self.last_path = None           # "kernel" | "fused-trajectory": which path produced the last forward's histogram
 
     def _fused_raw(self, xyz):
         """The raw histogram of `xyz` if a fused trajectory launch already produced it (ops.fused_traj); otherwise
@@ -77,6 +81,14 @@ class rdf(Observable):
             if start >= base.shape[td] or xyz.shape[td] != (base.shape[td] - start + stride - 1) // stride:
                 return None
         if hint is not None and raw is not None and hint.matches(self, start, stride):
+            if not self._warned_fused:
+                self._warned_fused = True
+                warnings.warn("mdgrad_amd.rdf: the histogram of this trajectory was produced inside the fused trajectory "
+                              "launch; its dependence on the frames is routed through the adjoint launch (raw -> FusedTrajFn), "
+                              "not through q_t in the autograd graph (autograd.grad(loss, q_t) / hooks on q_t do not see the "
+                              "RDF term), and it is the fine-grid histogram (<= 2e-5 per bin from the exact kernel).  "
+                              "integrator.fuse_observables = False keeps the separate kernels; rdf.last_path tells which ran.",
+                              stacklevel=3)
             return raw
         new = ops.RdfFuse(self, start, stride)
         spec.rdf_hint = new
@@ -87,6 +99,7 @@ class rdf(Observable):
 
     def forward(self, xyz):
         count = self._fused_raw(xyz)
+        self.last_path = "fused-trajectory" if count is not None else "kernel"
         if count is None:
             if self.n_rep > 1 and xyz.shape[-2] == self.n_rep * self.natoms:
                 xyz = xyz.reshape(xyz.shape[:-2] + (self.n_rep, self.natoms, 3))

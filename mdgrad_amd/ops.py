@@ -198,6 +198,7 @@ class PairGradFn(torch.autograd.Function):
     def forward(ctx, xyz, theta, ell, term, cache):
         ctx.ell, ctx.term = ell, term
         ctx.save_for_backward(xyz, theta)
+        ctx.set_materialize_grads(False)        # an unused dU/dtheta output arrives as None, not as zeros: no device read
         if cache is not None:
             g, gth = cache
         else:
@@ -210,9 +211,11 @@ class PairGradFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, wg, wgth):
         xyz, theta = ctx.saved_tensors
-        if wgth is not None and wgth.numel() and (wgth.requires_grad or bool((wgth != 0).any())):
+        if wgth is not None and wgth.numel():
             raise NotImplementedError("mdgrad_amd: second derivatives of a pair energy w.r.t. its parameters alone "
                                       "(a cotangent on dU/dtheta) are not provided by the HIP pair kernels")
+        if wg is None:
+            return None, None, None, None, None
         w = wg.detach().contiguous()
         o = pair_eval(ctx.ell, xyz, ctx.term, theta, w=w, energy=False, grad=False)
         gthw = o["gtheta_w"] if o["gtheta_w"] is not None else None

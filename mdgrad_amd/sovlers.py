@@ -248,7 +248,9 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
                 w = func.nhv_work(lam[0], lam[2])
                 frames = [a.contiguous() for a in ans]
                 gout = [g.contiguous() for g in grad_output]
-                tc = t.contiguous()
+                # the mdg_nhv_adj_* kernels read the time grid as a float32 device array (a float64 or host grid handed
+                # straight to odeint_adjoint must not reach them as a raw pointer)
+                tc = t.to(device=lam[0].device, dtype=lam[0].dtype).contiguous()
                 idx = torch.full((1,), T - 1, dtype=torch.int64, device=lam[0].device)
                 for i in range(T - 1, 0, -1):
                     q, wv = w.adj_pre(frames, lam[0], idx)
@@ -260,7 +262,7 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
                     _, dwf1, th1 = func.model.force_vjp(qm, wh)
                     w.adj_end(lam, dwf1, tc, idx, gout)
                     if th1:
-                        gth = gth + _flatten(func.theta_in_parameter_order(th1)) * (t[i] - t[i - 1])   # :160
+                        gth = gth + _flatten(func.theta_in_parameter_order(th1)) * (tc[i] - tc[i - 1])   # :160
                     idx.sub_(1)
                 return lam, gth
             for i in range(T - 1, 0, -1):

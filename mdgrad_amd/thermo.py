@@ -14,12 +14,13 @@ class Temperature(Observable):
 
     def forward(self, velocities):
         """Instantaneous kinetic temperature (energy units), sum(m v^2) / N_dof: a scalar for one frame [N, 3] like
-        the reference, one value per frame for a trajectory [T, N, 3] (one fused launch, csrc/observe.hip)."""
-        v = velocities if velocities.dim() == 3 else velocities[None]
-        T_, n = v.shape[0], v.shape[1]
-        if n != self.natoms:                     # replica-stacked state [T, R N, 3]: one temperature per (frame, replica)
-            out = ops.TemperatureFn.apply(v.reshape(T_ * (n // self.natoms), self.natoms, 3), self.mass, self.dof)
-            out = out.reshape(T_, n // self.natoms)
-        else:
-            out = ops.TemperatureFn.apply(v, self.mass, self.dof)
-        return out if velocities.dim() == 3 else out[0]
+        the reference, one value per frame for a trajectory [T, N, 3] or a batched one [R, T, N, 3] (one fused launch,
+        csrc/observe.hip)."""
+        lead = velocities.shape[:-2]                      # any leading shape: [], [T], [R, T] (batched fused trajectories)
+        n = velocities.shape[-2]
+        if n % self.natoms:
+            raise ValueError("Temperature: %d atoms per frame is not a multiple of the system's %d" % (n, self.natoms))
+        k = n // self.natoms                              # replica-stacked state [..., R N, 3]: one value per replica
+        v = velocities.reshape(-1, self.natoms, 3)
+        out = ops.TemperatureFn.apply(v, self.mass, self.dof)
+        return out.reshape(*lead, k) if k > 1 else out.reshape(lead)

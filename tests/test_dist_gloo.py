@@ -85,3 +85,65 @@ def test_flatten_roundtrip_and_world1_noop():
     assert torch.equal(ps[0].grad.reshape(-1), flat[:6] * 2)
     mdist.all_reduce_grads(ps)                             # not initialised: no-op
     assert mdist.max_over_ranks(3.5, torch.device("cpu")) == 3.5
+
+
+def test_grad_bucket_keeps_one_flat_buffer_with_parameter_views():
+    """all_reduce_grads' persistent buffer (mdgrad_amd.dist.GradBucket): gradients that autograd re-allocated are
+    copied into their slice once and p.grad re-pointed at the view; in-place accumulation into the views is free;
+    missing gradients are zeros."""
+    from mdgrad_amd.dist import GradBucket
+    ps = [torch.nn.Parameter(torch.randn(3, 2)), torch.nn.Parameter(torch.randn(5)), torch.nn.Parameter(torch.randn(1))]
+    b = GradBucket(ps)
+    ps[0].grad = torch.arange(6.0).reshape(3, 2)
+    ps[2].grad = torch.tensor([7.0])
+    flat = b.gather()
+    assert flat.data_ptr() == b.flat.data_ptr()
+    assert torch.equal(flat, torch.tensor([0, 1, 2, 3, 4, 5, 0, 0, 0, 0, 0, 7.0]))
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(ps, b.views))
+    # autograd accumulates in place into the views (zero_grad(set_to_none=False) idiom): nothing to copy
+    (ps[0].sum() * 2 + ps[1].sum()).backward()
+    assert ps[0].grad.data_ptr() == b.views[0].data_ptr()
+    flat2 = b.gather()
+    assert torch.equal(flat2[:6], torch.arange(6.0) + 2) and torch.equal(flat2[6:11], torch.ones(5))
+    # set_to_none=True drops the views: the next gather restores them and zeroes the missing ones
+    for p in ps:
+        p.grad = None
+    ps[1].grad = torch.full((5,), 3.0)
+    flat3 = b.gather()
+    assert torch.equal(flat3, torch.tensor([0, 0, 0, 0, 0, 0, 3, 3, 3, 3, 3, 0.0]))
+    flat3 *= 2                                        # what the collective does: the parameters see it through the views
+    assert torch.equal(ps[1].grad, torch.full((5,), 6.0))
+
+
+_SELF_LAUNCH_SCRIPT = '''
+import argparse, os, sys
+sys.path.insert(0, %r)
+import torch
+from mdgrad_amd import dist as mdist
+ap = argparse.ArgumentParser(); ap.add_argument("--gpus", type=int, default=1); args = ap.parse_args()
+if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(mdist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+rank, world, dev = mdist.init(backend="gloo")
+p = torch.nn.Parameter(torch.zeros(3)); p.grad = torch.full((3,), float(rank + 1))
+mdist.all_reduce_grads([p])
+ev = mdist.collective_evidence(dev, 3, reps=2)
+ms = mdist.gather_over_ranks(10.0 + rank, dev)
+if rank == 0:
+    print("RESULT", world, float(p.grad[0]), ev["backend"], ev["world"], ev["ranks_seen"], ev["allreduce_us"] > 0, ms, flush=True)
+import torch.distributed as d
+d.destroy_process_group()
+'''
+
+
+def test_plain_command_spawns_its_own_ranks(tmp_path):
+    """`python script --gpus 2` without a launcher re-executes itself through torch.distributed.run (bench.py and
+    examples/fit_rdf_gnn.py use the same helper): rank 0's line arrives on the parent's stdout, the collective sees 2
+    ranks."""
+    import subprocess
+    script = tmp_path / "selflaunch.py"
+    script.write_text(_SELF_LAUNCH_SCRIPT % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+    assert lines == ["RESULT 2 3.0 gloo 2 2 True [10.0, 11.0]"], r.stdout[-1000:]

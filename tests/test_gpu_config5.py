@@ -133,3 +133,23 @@ def test_bench_two_ranks_on_one_device():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["parallelism"] == "replica-dp2"
     assert out["value"] > 0 and abs(out["value"] - 2 * 1024 * 49 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
     assert out["config"]["rdf_fused_into_trajectory_kernels"] is True and "roofline" in out
+
+
+def test_bench_plain_command_spawns_two_ranks_on_one_device():
+    """`python bench.py --gpus 2` as a plain command (what the driver runs): bench.py spawns its own ranks, rank 0 prints
+    ONE JSON line, and `config.dist` shows that the collective saw both ranks (here: both on cuda:0 over gloo; on an
+    N-GPU node the same path runs RCCL)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--replicas", "1024",
+           "--no-secondary", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    d = out["config"]["dist"]
+    assert out["n_gpus"] == 2 and d["backend"] == "gloo" and d["world"] == 2 and d["ranks_seen"] == 2
+    assert d["allreduce_us"] > 0 and len(d["per_rank_ms"]) == 2 and all(x > 0 for x in d["per_rank_ms"])
+    assert abs(max(d["per_rank_ms"]) - out["ms_per_step"]) < 1e-6 * out["ms_per_step"]

@@ -225,3 +225,25 @@ def test_fused_rdf_through_the_reference_api_with_stacked_replicas():
     close(res[True][0], gr, 2e-5, 2e-5, "g(r): fused vs separate, 4096 frames")
     close(res[True][1], mdl.sigma.grad, 1e-3, 1e-6, "dsigma")
     close(res[True][2], mdl.epsilon.grad, 1e-3, 1e-6, "depsilon")
+
+
+def test_fused_rdf_reports_its_path_and_does_not_pass_through_q_t():
+    """the automatic fusion changes the autograd graph -- from the second pass on the histogram is an output
+    of the trajectory launch, not a function of q_t.  The observable says which path ran (`last_path`), warns once
+    when it switches, and a derivative w.r.t. q_t that would silently lose the RDF term raises instead."""
+    import warnings
+    from mdgrad_amd import ops
+    g, mdl, integ, spec, pos, vel, t, obs, nhc = _setup(108, "nhc", R=2, nT=7)
+    paths = []
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        for rep in range(3):
+            v0, q0 = T(vel, DEV), T(pos, DEV)
+            pv0 = torch.zeros(2, 5, device=DEV)
+            v_t, q_t, pv_t = ops.fused_traj(v0, q0, pv0, t, spec.flat_params(), spec)
+            _, _, gr = obs(q_t)
+            paths.append(obs.last_path)
+    assert paths == ["kernel", "fused-trajectory", "fused-trajectory"]
+    assert sum("fused trajectory launch" in str(w.message) for w in rec) == 1          # once, not per pass
+    with pytest.raises(RuntimeError):                    # the RDF term does not reach q_t in the graph: no silent zero
+        torch.autograd.grad(gr.pow(2).sum(), q_t)
