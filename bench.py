@@ -91,8 +91,9 @@ def _oracle_lj108(pos, vel, frames, dt, O):
 
 def cpu_baseline_lj108(frames, dt, check=None, budget_s=12.0):
     """The CPU oracle (port of the reference algorithm, oracle/) on this host: the same 108-atom workload, one
-    replica at a time, forward + rdf loss + adjoint; bounded to ~budget_s.  `check` = (pos0, vel0, q_t0, g0, gth0)
-    of replica 0 of the timed batch geometry: its HIP results are compared with the oracle's on the same inputs."""
+    replica at a time, forward + rdf loss + adjoint; bounded to ~budget_s.  `check` = [(r, pos_r, vel_r, q_t_r, g_r,
+    gth_r, R)] for sampled replicas r of the timed launch: their HIP results are compared with the oracle's on the same
+    inputs."""
     import oracle as O
     nthreads = min(8, os.cpu_count() or 1)       # 108-atom tensors are far too small for one thread per core
     torch.set_num_threads(nthreads)
@@ -108,14 +109,18 @@ def cpu_baseline_lj108(frames, dt, check=None, budget_s=12.0):
     out = {"value": n * (frames - 1) / el, "unit": "MD steps/s", "cores": nthreads, "kind": "port",
            "sample": "%d trajectories x %d steps (fwd + rdf loss + adjoint), 108-atom LJ, oracle/ on %d torch threads, "
                      "%.1f s" % (n, frames - 1, nthreads, el)}
-    if check is not None:
-        p0, v0, q_hip, g_hip, gth_hip, n_rep = check
-        traj, g_o, gth_o = _oracle_lj108(p0, v0, frames, dt, O)
-        out["parity_replica0"] = {
-            "max_abs_dq": float((q_hip - traj[1]).abs().max()), "max_abs_dg": float((g_hip - g_o).abs().max()),
-            "rel_dtheta": float(((gth_hip - gth_o).abs() / gth_o.abs().max()).max()),
-            "note": "replica 0 of a %s-replica launch (the timed geometry) vs the oracle on the same inputs: "
-                    "positions over %d frames, g(r) of that replica, d(loss)/d(sigma, epsilon)" % (n_rep, frames)}
+    if check:
+        dq = dg = dth = 0.0
+        for (r, p0, v0, q_hip, g_hip, gth_hip, n_rep) in check:
+            traj, g_o, gth_o = _oracle_lj108(p0, v0, frames, dt, O)
+            dq = max(dq, float((q_hip - traj[1]).abs().max()))
+            dg = max(dg, float((g_hip - g_o).abs().max()))
+            dth = max(dth, float(((gth_hip - gth_o).abs() / gth_o.abs().max()).max()))
+        out["parity_sampled"] = {
+            "replicas": [c[0] for c in check], "max_abs_dq": dq, "max_abs_dg": dg, "rel_dtheta": dth,
+            "note": "first / middle / last replica of a %s-replica launch (the timed geometry) vs the oracle on the same "
+                    "inputs, worst of the three: positions over %d frames, g(r) of that replica, d(loss)/d(sigma, epsilon)"
+                    % (check[0][6], frames)}
     return out
 
 
@@ -144,14 +149,15 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
     opt = torch.optim.Adam(params, lr=1e-4)
 
     # ---- parity of the timed geometry (before any optimizer step): replica 0 alone feeds the loss
-    check = None
+    check = []
     if rank == 0 and with_cpu and world == 1:
-        v_t, q_t, pv_t = ops.fused_traj(vel, pos, pv0, t, spec.flat_params(), spec)
-        _, _, g0 = obs(q_t[:1])
-        (g0 - 1).pow(2).mean().backward()
-        check = (pos[0].cpu(), vel[0].cpu(), q_t[0].detach().cpu(), g0.detach().cpu(),
-                 torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())]).cpu(), R)
-        opt.zero_grad(set_to_none=True)
+        for r in sorted({0, R // 2, R - 1}):           # one replica at a time feeds the loss of the whole launch
+            v_t, q_t, pv_t = ops.fused_traj(vel, pos, pv0, t, spec.flat_params(), spec)
+            _, _, g0 = obs(q_t[r:r + 1])
+            (g0 - 1).pow(2).mean().backward()
+            check.append((r, pos[r].cpu(), vel[r].cpu(), q_t[r].detach().cpu(), g0.detach().cpu(),
+                          torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())]).cpu(), R))
+            opt.zero_grad(set_to_none=True)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -342,6 +348,76 @@ def cpu_baseline_schnet(budget_s=10.0):
                           n, nsteps, nthreads, el)}
 
 
+def parity_schnet_stacked(dev, bf16, R=8, size=2, T=11):
+    """The path the schnet4096 leg times (replica-stacked system, fused interaction block, analytic adjoint, graph replay)
+    on boxes the oracle finishes in seconds: 8 stacked replicas x 64 beads, 10 steps + per-replica RDF loss + adjoint,
+    first / middle / last replica against oracle/ (autograd double backward like the reference), and the summed
+    parameter gradient of the three."""
+    import oracle as O
+    from mdgrad_amd import potentials as P, units
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from mdgrad_amd.system import System, Diamond
+    rng = np.random.default_rng(99)
+    a = units.get_unit_len(0.997, 18.01528, 8)
+    atoms = Diamond("O", (size,) * 3, a)
+    atoms.masses[:] = 18.01528
+    base = System(atoms, device=dev)
+    N, L = base.get_number_of_atoms(), a * size
+    system = base.replicate(R)
+    lat = base.get_positions()
+    pos = np.stack([np.mod(lat + rng.normal(0, 0.05, lat.shape), L) for _ in range(R)]).astype(np.float32)
+    kT = 298.0 * units.kB
+    vel = (rng.normal(0, 1, pos.shape) * np.sqrt(kT / 18.01528)).astype(np.float32)
+    system.set_positions(pos.reshape(-1, 3))
+    system.set_velocities(vel.reshape(-1, 3))
+    torch.manual_seed(0)
+    net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2, "cutoff": 6.0})
+    net.filter_bf16 = bool(bf16)
+    with torch.no_grad():
+        net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
+    sd = {k: v.detach().clone().cpu() for k, v in net.state_dict().items()}
+    integ = NoseHooverChain(Stack({"gnn": GNNPotentials(system, net, cutoff=6.0),
+                                   "prior": PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)}),
+                            system, T=kT, num_chains=5, Q=50.0).to(dev)
+    t = torch.Tensor([units.fs * i for i in range(T)])
+    y0 = tuple(integ.get_inital_states(wrap=True))
+    v_t, q_t, pv_t = odeint_adjoint(integ, y0, t.to(dev), method="NH_verlet")
+    obs = rdf(base, nbins=60, r_range=(2.0, 6.0))
+    sample = sorted({0, R // 2, R - 1})
+    qr = q_t.reshape(T, R, N, 3)
+    gs = [obs(qr[::5, r])[2] for r in sample]
+    sum((g - 1).pow(2).mean() for g in gs).backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()]).cpu()
+    cellt = torch.tensor([L] * 3, dtype=torch.float32)
+    dq = dg = 0.0
+    gsum = None
+    for r, g in zip(sample, gs):
+        gnn = O.SchNetTerm(sd, np.full(N, 8), 6.0, cellt)
+        prior = O.PairTerm("lj", torch.tensor([2.6, 0.01]), 6.0, cellt, p=12, q=0, c=0)
+        eom = O.NHCOracle(O.ModelOracle([gnn, prior]), torch.full((N,), 18.01528), kT, 50.0, 5)
+        traj = O.odeint_oracle(eom, (torch.from_numpy(vel[r]), torch.from_numpy(pos[r]), torch.zeros(5)), t)
+        leaves = [x.clone().requires_grad_(True) for x in traj]
+        _, _, go = O.rdf_oracle(leaves[1][::5], cellt, 60, (2.0, 6.0))
+        (go - 1).pow(2).mean().backward()
+        _, gth = O.adjoint_oracle(eom, traj, [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves], t)
+        gsum = gth if gsum is None else gsum + gth
+        dq = max(dq, float((qr[:, r].detach().cpu() - traj[1]).abs().max()))
+        dg = max(dg, float((g.detach().cpu() - go.detach()).abs().max()))
+    cos = float((flat.double() * gsum.double()).sum() / (flat.double().norm() * gsum.double().norm()))
+    return {"replicas": sample, "max_abs_dq": dq, "max_abs_dg": dg,
+            "rel_dtheta": float((flat - gsum).abs().max() / gsum.abs().max()), "cos_dtheta": cos,
+            "filter": "bf16 MFMA operands" if bf16 else "f32",
+            "note": "%d stacked replicas x %d CG-water beads on the path of the timed launch, same SchNet widths, %d steps + "
+                    "per-replica RDF loss + analytic adjoint: first / middle / last replica vs oracle/ (positions in A over "
+                    "%d frames, g(r)), and the %d-entry parameter gradient summed over the three (largest deviation "
+                    "relative to the largest entry, cosine); 8 x 512 beads are pinned replica by replica in "
+                    "tests/test_gpu_secondary_pins.py" % (R, N, T - 1, T, flat.numel())}
+
+
 def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None):
     from mdgrad_amd import ops, potentials as P, units
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
@@ -466,6 +542,10 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                                  "construction" if args.bf16 else "")}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_schnet()
+        try:
+            out["cpu_baseline"]["parity_sampled"] = parity_schnet_stacked(dev, bool(args.bf16))
+        except Exception as e:
+            out["cpu_baseline"]["parity_sampled"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -507,6 +587,60 @@ def cpu_baseline_lj4096(budget_s=10.0):
             "sample": "%d trajectories x %d steps (fwd + adjoint) of a 1000-atom LJ liquid (dense N^2 neighbour search of "
                       "the reference algorithm; BASELINE.md: 0.34 steps/s at 4000 atoms for the reference), oracle/ on %d "
                       "torch threads, %.1f s" % (n, nsteps, nthreads, el)}
+
+
+def parity_lj_large(dev, R=64, n_side=10, T=11):
+    """The kernels the lj4096 leg times (csrc/traj_large.hip: 64 stacked replicas per launch, Verlet reuse with device-side
+    rebuild decisions, cell-sweep RDF) on a system the oracle finishes in seconds: 64 x 1 000 atoms, 10 steps + RDF loss +
+    adjoint, first / middle / last replica of the launch against oracle/ on the same inputs."""
+    import oracle as O
+    from mdgrad_amd import ops
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.system import System, Atoms
+    rng = np.random.default_rng(77)
+    pos1, L = lj_liquid(n_side, 0.845, rng)
+    N = len(pos1)
+    system = System(Atoms(positions=pos1, cell=[L, L, L], numbers=np.ones(N)), device=dev)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5,
+                            Q=50.0).to(dev)
+    integ.fused_large = True
+    integ.fuse_observables = False
+    spec = integ.fused_spec("NH_verlet")
+    assert spec is not None and spec.large
+    pos = np.stack([lj_liquid(n_side, 0.845, rng)[0] for _ in range(R)]).astype(np.float32)
+    vel = rng.normal(0, 1.0, (R, N, 3)).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(T)])
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    sample = sorted({0, R // 2, R - 1})
+    v_t, q_t, pv_t = ops.fused_traj(torch.from_numpy(vel).to(dev), torch.from_numpy(pos).to(dev),
+                                    torch.zeros(R, 5, device=dev), t.to(dev), spec.flat_params(), spec)
+    cell = torch.tensor([L] * 3, dtype=torch.float32)
+    mass = torch.full((N,), float(system.get_masses()[0]))
+    dq = dg = dth = 0.0
+    for r in sample:
+        mdl.zero_grad()
+        _, _, g = obs(q_t[r, ::5])
+        (g - 1).pow(2).mean().backward(retain_graph=True)
+        gth_hip = torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())]).cpu()
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, cell, p=12, q=6, c=1)
+        eom = O.NHCOracle(O.ModelOracle([term]), mass, 1.0, 50.0, 5)
+        traj = O.odeint_oracle(eom, (torch.from_numpy(vel[r]), torch.from_numpy(pos[r]), torch.zeros(5)), t)
+        leaves = [x.clone().requires_grad_(True) for x in traj]
+        _, _, go = O.rdf_oracle(leaves[1][::5], cell, 100, (0.75, 2.5))
+        (go - 1).pow(2).mean().backward()
+        _, gth = O.adjoint_oracle(eom, traj, [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves], t)
+        dq = max(dq, float((q_t[r].detach().cpu() - traj[1]).abs().max()))
+        dg = max(dg, float((g.detach().cpu() - go.detach()).abs().max()))
+        dth = max(dth, float(((gth_hip - gth).abs() / gth.abs().max()).max()))
+    return {"replicas": sample, "max_abs_dq": dq, "max_abs_dg": dg, "rel_dtheta": dth,
+            "note": "%d stacked replicas x %d atoms on the kernels of the timed launch (multi-launch path, stored candidate "
+                    "lists reused across steps, cell-sweep RDF on every 5th frame), %d steps + RDF loss + adjoint: first / "
+                    "middle / last replica vs oracle/ on the same inputs, worst of the three (the 64 x 4096 geometry itself "
+                    "is pinned for 2 steps in tests/test_gpu_secondary_pins.py)" % (R, N, T - 1)}
 
 
 def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None):
@@ -590,6 +724,10 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
                                "wave over the stored candidate lists) by VALU issue and gather latency (DESIGN.md section 4)" % Pn}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_lj4096()
+        try:
+            out["cpu_baseline"]["parity_sampled"] = parity_lj_large(dev)
+        except Exception as e:                     # (reported, never hidden: a failed check is part of the record)
+            out["cpu_baseline"]["parity_sampled"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 

@@ -794,6 +794,31 @@ def test_list_based_rdf_for_large_systems_vs_oracle(direct):
     close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, cell-based")
 
 
+@pytest.mark.parametrize("width_scale", [3.0, 8.0])
+def test_wide_gaussians_on_the_large_system_rdf_vs_oracle(width_scale):
+    """the pair search of the large-system RDF is trimmed to the reach of the observable's Gaussians
+    -- mu_last + 5.3 / s with s = sqrt(-coeff log2 e), where a term is below 2^-28 of its peak, never beyond the
+    reference's own `end + 0.5` -- so the trim follows the user's `width`.  2 744 atoms, `width` = 3 and 8 bin spacings
+    (at 8 the reach exceeds the reference's cutoff_boundary and the search runs to 3.0 like the reference's list),
+    forward and d/dxyz against the oracle; the deviation budget is the same as at the default width."""
+    from mdgrad_amd.observable import rdf
+    pos, cell = liquid(14, seed=19, jitter=0.08)
+    rng = np.random.default_rng(3)
+    frames = np.stack([np.mod(pos + rng.normal(0, 0.05, pos.shape), cell) for _ in range(2)]).astype(np.float32)
+    system = mk_system(pos, cell)
+    nbins, rr = 100, (0.75, 2.5)
+    width = width_scale * (rr[1] - rr[0]) / nbins
+    wgt = torch.linspace(-1, 1, nbins)
+    x = T(frames, DEV).requires_grad_(True)
+    _, _, gr = rdf(system, nbins=nbins, r_range=rr, width=width)(x)
+    (gx,) = torch.autograd.grad((gr * wgt.to(DEV)).sum(), x)
+    xo = T(frames).requires_grad_(True)
+    _, _, go = O.rdf_oracle(xo, T(cell), nbins, rr, width=width)
+    (gxo,) = torch.autograd.grad((go * wgt).sum(), xo)
+    close(gr, go, 1e-4, 1e-4, "g(r), width x%.0f" % width_scale)
+    close(gx, gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(g.w)/dxyz, width x%.0f" % width_scale)
+
+
 def test_cell_sweep_rdf_in_a_dilute_box_with_capped_bins_vs_oracle():
     """A dilute gas in a large box: the bin count per side is capped at 16 (bins wider than the list cutoff), most
     bins are empty, a few atoms sit in the same spot twice (d = 0 pairs are not counted, topology.py:67)."""
