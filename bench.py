@@ -466,6 +466,27 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
         opt.step()
         return loss, q_t
 
+    bf16_dev = None
+    if args.bf16 and rank == 0:
+        # deviation of the bf16-operand filter network from the all-f32 path ON THE TIMED WORKLOAD: one pass each from
+        # the same initial state, no optimizer step in between
+        def one_pass(flag):
+            net.filter_bf16 = flag
+            opt.zero_grad(set_to_none=True)
+            y0 = tuple(integ.get_inital_states(wrap=True))
+            v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+            g = obs(q_t[::5])[2]
+            (g - target).pow(2).mean().backward()
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+            return q_t.detach().clone(), g.detach().clone(), flat.double()
+        qa, ga, fa = one_pass(False)
+        qb, gb, fb = one_pass(True)
+        opt.zero_grad(set_to_none=True)
+        bf16_dev = {"max_abs_dq_A": float((qa - qb).abs().max()), "max_abs_dg": float((ga - gb).abs().max()),
+                    "dtheta_rel_to_largest": float((fa - fb).abs().max() / fa.abs().max()),
+                    "dtheta_cosine": float((fa * fb).sum() / (fa.norm() * fb.norm())),
+                    "note": "bf16 filter operands vs all-f32 on the timed workload itself (%d steps, same initial state): "
+                            "positions, g(r), the %d-entry parameter gradient" % (T - 1, fa.numel())}
     for _ in range(warmup):
         step()
     mdist.barrier()
@@ -490,6 +511,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach())}}
     out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
+    if bf16_dev is not None:
+        out["config"]["bf16_vs_f32"] = bf16_dev
     if rank != 0:
         return out
     # ---- roofline: (a) the dominant kernel of the step, the fused interaction block's forward + tangent sweep
@@ -770,18 +793,19 @@ def main():
         if args.workload == "all" and not args.no_secondary:
             sec = {}
             import copy
+            # (>= 1 s of GPU time per secondary workload: 16 x ~60 ms, 50 x ~20 ms)
             # BASELINE config #5 names the bf16 cfconv MFMA: the SchNet workload runs with bf16 filter operands (stated
             # tolerance: tests/test_gpu_config5.py) and reports the all-f32 rate beside it
             a16 = copy.copy(args)
             a16.bf16 = True
-            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 3, 1, a16), ("lj4096", run_lj4096, 10, 2, args)):
+            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 16, 2, a16), ("lj4096", run_lj4096, 50, 3, args)):
                 try:
                     sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
                 except (Exception, SystemExit) as e:        # a secondary workload must not take the headline down
                     sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             if "error" not in sec["schnet4096"] and not args.bf16:
                 try:
-                    f32 = run_schnet4096(args, rank, world, dev, mdist, False, steps=3, warmup=1)
+                    f32 = run_schnet4096(args, rank, world, dev, mdist, False, steps=8, warmup=1)
                     sec["schnet4096"]["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "dtype")}
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
