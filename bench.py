@@ -57,7 +57,7 @@ def _profile_json(name):
         return None
 
 
-def _dist_record(mdist, dev, params, el_rank, ms_rank):
+def _dist_record(mdist, dev, params, ms_rank):
     """Evidence that the N ranks ran and met in the collective: backend, ranks counted by an
     all-reduce of ones, the time of one all-reduce of the flat-gradient-sized buffer, every rank's ms per pass."""
     rec = mdist.collective_evidence(dev, sum(p.numel() for p in params))
@@ -639,6 +639,14 @@ def parity_lj_large(dev, R=64, n_side=10, T=11):
     t = torch.Tensor([0.005 * i for i in range(T)])
     obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
     sample = sorted({0, R // 2, R - 1})
+    was, ops.RDF_LIST_ATOMS = ops.RDF_LIST_ATOMS, 512          # the cell-sweep RDF of the timed leg (normally from 2 048 atoms)
+    try:
+        return _parity_lj_large_body(dev, O, ops, obs, spec, mdl, system, pos, vel, t, sample, R, N, L, T)
+    finally:
+        ops.RDF_LIST_ATOMS = was
+
+
+def _parity_lj_large_body(dev, O, ops, obs, spec, mdl, system, pos, vel, t, sample, R, N, L, T):
     v_t, q_t, pv_t = ops.fused_traj(torch.from_numpy(vel).to(dev), torch.from_numpy(pos).to(dev),
                                     torch.zeros(R, 5, device=dev), t.to(dev), spec.flat_params(), spec)
     cell = torch.tensor([L] * 3, dtype=torch.float32)

@@ -443,6 +443,11 @@ int mdg_ssp_dual_bwd(const float* sa, const float* xd, const float* sdb, const f
 /* the same with the tangent given as t_dot = sa * x_dot:  xdb = sa sdb ; xb = (1 - sa) t_dot sdb + sa sb */
 int mdg_ssp_dual_bwd_t(const float* sa, const float* td, const float* sdb, const float* sb, int64_t n, float* xdb,
                        float* xb, void* stream);
+/* head of the reverse sweeps through the readout U = sum_i L2 . ssp(y_i) + l2 (nff/nn/modules.py:761-809, schnet.py:155-158):
+ * ydb = sy * L2 ; yb = (1 - sy) * syd * L2, with sy = sigmoid(y) and syd = sy * y_dot [n_rows, n_cols], L2 [n_cols];
+ * syd = yb = NULL: first-order pass */
+int mdg_readout_head(const float* sy, const float* syd, const float* L2, int64_t n_rows, int n_cols, float* ydb, float* yb,
+                     void* stream);
 int mdg_smear_bwd(const float* gdb, const float* gb, const float* g, const float* phi, const float* dd,
                   const float* c, int64_t n_edges, int n_gauss, float* d_b, float* dd_b, void* stream);
 
@@ -457,6 +462,36 @@ int mdg_atb(const float* A, const float* B, int64_t n_rows, int m, int n, float*
 /* C = A^T B + A2^T B2 (same shapes; A2 = B2 = NULL: mdg_atb): primal + tangent halves of a weight gradient at once */
 int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, int64_t n_rows, int m, int n, float* C,
              float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * All parameter-gradient reductions of one SchNet adjoint evaluation in two launches (csrc/gradjobs.hip): what double
+ * autograd accumulates into the .grad of the Dense weights / biases and the embedding of nff/nn/modules.py:514-575 and
+ * nff/nn/models/schnet.py:113-171 while it differentiates w.F (torchmd/sovlers.py:229-233), times the interval weight of
+ * sovlers.py:160.  A job is one reduction over `rows` atoms:
+ *   MDG_GRAD_ATB     out[m,n] = A[rows,m]^T B[rows,n] (+ A2^T B2); row r of the result goes to destination row
+ *                    row_map[r] when row_map != NULL (rows of the embedding table), else r
+ *   MDG_GRAD_COLSUM  out[m]   = sum_rows A (.* B) (+ A2 (.* B2))            (B, B2 optional, together)
+ *   MDG_GRAD_AXPY    out[m]   = A (+ A2)                                     (already reduced: cfconv_bwd's gW1, gb1, gW2)
+ * and lands at flat[out_off ...]:  flat = (accumulate ? flat : 0) + alpha * (t ? t[*idx] - t[*idx - 1] : 1) * out, with the
+ * time grid t and the frame index idx on the device (a captured HIP graph advances idx itself).  Fixed-order sums, no
+ * atomics.  workspace: mdg_grad_jobs_workspace() floats.  At most MDG_GRAD_JOBS_MAX jobs per call.
+ */
+#define MDG_GRAD_JOBS_MAX 32
+enum { MDG_GRAD_ATB = 0, MDG_GRAD_COLSUM = 1, MDG_GRAD_AXPY = 2 };
+typedef struct {
+    const float* A;
+    const float* B;
+    const float* A2;
+    const float* B2;
+    const int64_t* row_map;
+    int64_t rows;
+    int32_t m, n;
+    int32_t kind, pad_;
+    int64_t out_off;
+} MdgGradJob;
+int64_t mdg_grad_jobs_workspace(const MdgGradJob* jobs, int n_jobs);
+int mdg_grad_jobs(const MdgGradJob* jobs, int n_jobs, float* flat, float alpha, const float* t, const int64_t* idx,
+                  int accumulate, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Nose-Hoover-chain algebra of the generic (non-fused) integrator path as single launches

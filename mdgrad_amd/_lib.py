@@ -49,6 +49,15 @@ class MdgFilterNet(C.Structure):
                 ("W2", C.c_void_p), ("b2", C.c_void_p), ("n_gauss", C.c_int32), ("n_filters", C.c_int32)]
 
 
+class MdgGradJob(C.Structure):
+    """One reduction of mdg_grad_jobs (include/mdgrad_hip.h)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("A2", C.c_void_p), ("B2", C.c_void_p), ("row_map", C.c_void_p),
+                ("rows", C.c_int64), ("m", C.c_int32), ("n", C.c_int32), ("kind", C.c_int32), ("pad_", C.c_int32),
+                ("out_off", C.c_int64)]
+
+
+GRAD_ATB, GRAD_COLSUM, GRAD_AXPY, GRAD_JOBS_MAX = 0, 1, 2, 32
+
 P = C.c_void_p
 _SIGNATURES = {
     "mdg_last_error": (C.c_char_p, []),
@@ -116,10 +125,13 @@ _SIGNATURES = {
     "mdg_mul_row": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P]),
     "mdg_ssp_dual_bwd": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
     "mdg_ssp_dual_bwd_t": (C.c_int, [P, P, P, P, C.c_int64, P, P, P]),
+    "mdg_readout_head": (C.c_int, [P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_smear_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int64, C.c_int, P, P, P]),
     "mdg_atb_workspace": (C.c_int64, [C.c_int64, C.c_int, C.c_int]),
     "mdg_atb": (C.c_int, [P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
     "mdg_atb2": (C.c_int, [P, P, P, P, C.c_int64, C.c_int, C.c_int, P, P, P]),
+    "mdg_grad_jobs_workspace": (C.c_int64, [P, C.c_int]),
+    "mdg_grad_jobs": (C.c_int, [P, C.c_int, P, C.c_float, P, P, C.c_int, P, P]),
     "mdg_vacf_workspace": (C.c_int64, [C.c_int]),
     "mdg_vacf_fwd": (C.c_int, [P, C.c_int, C.c_int64, C.c_int, P, P, P]),
     "mdg_vacf_bwd": (C.c_int, [P, P, C.c_int, C.c_int64, C.c_int, P, P]),

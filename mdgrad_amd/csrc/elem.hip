@@ -66,6 +66,18 @@ __global__ void ssp_dual_bwd_t_kernel(const float* __restrict__ sa, const float*
     xb[t] = (1.f - s) * td[t] * db + s * sb[t];
 }
 
+// head of the reverse sweeps through the readout  U = sum_i L2 . ssp(y_i) + l2  (nff/nn/modules.py:761-809):
+//   ydb = sy * L2  (the adjoint of y_dot, which is also dU/dy) ;  yb = (1 - sy) (sy y_dot) L2  (the adjoint of y in U_dot)
+// from sy = sigmoid(y) and sy * y_dot as the Dense epilogue leaves them; syd = NULL: first-order pass, ydb only
+__global__ void readout_head_kernel(const float* __restrict__ sy, const float* __restrict__ syd, const float* __restrict__ L2,
+                                    long long n, int cols, float* __restrict__ ydb, float* __restrict__ yb) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const float s = sy[t], l = L2[t % cols];
+    ydb[t] = s * l;
+    if (syd) yb[t] = (1.f - s) * syd[t] * l;
+}
+
 // reverse of the smearing (and its tangent), reduced over the G Gaussians of each edge:
 //   gb' = gb + gdb * phi * dd ;  d_b += sum_k gdb g 2c dd + gb' g phi ;  dd_b += sum_k gdb g phi
 // gdb may be NULL (first-order pass): d_b += sum_k gb g phi.   16 lanes per edge row.
@@ -156,6 +168,16 @@ extern "C" int mdg_ssp_dual_bwd_t(const float* sa, const float* td, const float*
     hipLaunchKernelGGL(ssp_dual_bwd_t_kernel, dim3(nblk(n)), dim3(256), 0, (hipStream_t)stream, sa, td, sdb, sb,
                        (long long)n, xdb, xb);
     MDG_CHECK_LAUNCH("ssp_dual_bwd_t_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_readout_head(const float* sy, const float* syd, const float* L2, int64_t n_rows, int n_cols, float* ydb,
+                                float* yb, void* stream) {
+    ELEM_CHECK(n_rows, "readout_head");
+    MDG_CHECK_ARG(sy && L2 && ydb && n_cols > 0 && (!syd || yb), "readout_head: bad arguments");
+    hipLaunchKernelGGL(readout_head_kernel, dim3(nblk(n_rows * n_cols)), dim3(256), 0, (hipStream_t)stream, sy, syd, L2,
+                       (long long)n_rows * n_cols, n_cols, ydb, yb);
+    MDG_CHECK_LAUNCH("readout_head_kernel");
     return MDG_OK;
 }
 

@@ -1,0 +1,276 @@
+// Batched parameter-gradient reductions of one SchNet adjoint evaluation (mdgrad_amd/nn/analytic.py).
+//
+// The reverse sweep of U_dot (what double autograd derives at torchmd/sovlers.py:229-233 for the parameters of
+// nff/nn/modules.py:514-575 and nff/nn/models/schnet.py:113-171) leaves ~25 small reductions over the atoms: the
+// weight gradients  x^T g (+ xd^T gd)  of every node-level Dense layer (tall-skinny [N,M]^T [N,K] products), the bias
+// gradients (column sums, some of an elementwise product), the rows of the embedding table, and the filter-network
+// gradients that cfconv_bwd already reduced.  Issued one by one they were ~50 launches per evaluation (split-K product +
+// reduce per weight, torch reductions / cat / neg / scale / add for the rest); here ALL of them are TWO launches:
+//
+//   grad_partial_kernel   every (job, unit, K-slab) on its own wave: products on v_mfma_f32_16x16x4_f32 with 16-byte
+//                         operand loads (a lane's float4 feeds four 16x16 tiles: the k index of an MFMA operand is the
+//                         row of the tall matrix, the 16 "column" lanes take 4 consecutive floats each), column sums by
+//                         row-strided float4 reads + an ordered LDS combine; partial results to a workspace;
+//   grad_reduce_kernel    fixed-order sum over the slabs and  flat[dst] (+)= alpha * (t[i] - t[i-1]) * value: the
+//                         interval weight of sovlers.py:160 is read on the device, the destination is the caller's flat
+//                         gradient buffer in nn.Module.parameters() order (tinydiffeq.py:106-108).
+//
+// No atomics; two launches with the same inputs give the same bits.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct JobTable {
+    MdgGradJob j[MDG_GRAD_JOBS_MAX];
+    long long ws_off[MDG_GRAD_JOBS_MAX];      // first float of the job's partial results in the workspace
+    long long slab[MDG_GRAD_JOBS_MAX];        // rows per K-slab
+    int first_block[MDG_GRAD_JOBS_MAX + 1];   // partial kernel: blocks [first_block[k], first_block[k+1]) belong to job k
+    int splits[MDG_GRAD_JOBS_MAX];
+    int first_out[MDG_GRAD_JOBS_MAX + 1];     // reduce kernel: output elements (padded to 64 per job), prefix sums
+    int n_jobs;
+};
+
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ p, long long row, int width, int col0, bool row_ok) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (!row_ok) return v;
+    const float* q = p + row * (long long)width + col0;
+    if ((width & 3) == 0 && col0 + 3 < width) {
+        v = *reinterpret_cast<const f32x4*>(q);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (col0 + c < width) v[c] = q[c];
+    }
+    return v;
+}
+
+// One wave: C[64 x 64 NJ] block of A^T B over rows [k0, k1).  Tile (c; j, c2): rows m = m0 + 4 i + c, columns
+// n = n0 + 64 j + 4 i2 + c2 (i, i2 = the MFMA's 16 row / column lanes).
+template <int NJ>
+__device__ __forceinline__ void atb_wave(const MdgGradJob& J, int m0, int n0, long long k0, long long k1, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    const int M = J.m, N = J.n;
+    f32x4 acc[4][NJ][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) acc[c][j][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < (J.A2 ? 2 : 1); ++pass) {
+        const float* __restrict__ Ap = pass ? J.A2 : J.A;
+        const float* __restrict__ Bp = pass ? J.B2 : J.B;
+        f32x4 a = load4(Ap, k0 + lk, M, m0 + 4 * li, k0 + lk < k1);
+        f32x4 b[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = load4(Bp, k0 + lk, N, n0 + 64 * j + 4 * li, k0 + lk < k1);
+        for (long long k = k0; k < k1; k += 4) {
+            const long long rn = k + 4 + lk;                     // next step's rows are in flight during the MFMAs
+            const f32x4 an = load4(Ap, rn, M, m0 + 4 * li, rn < k1);
+            f32x4 bn[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bn[j] = load4(Bp, rn, N, n0 + 64 * j + 4 * li, rn < k1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int c2 = 0; c2 < 4; ++c2)
+                        acc[c][j][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[j][c2], acc[c][j][c2], 0, 0, 0);
+            a = an;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+        }
+    }
+    // accumulator layout: column lane = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * (lk * 4 + r) + c;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
+                    const int n = n0 + 64 * j + 4 * li + c2;
+                    if (n < N) out[(size_t)m * N + n] = acc[c][j][c2][r];
+                }
+        }
+}
+
+__global__ __launch_bounds__(256) void grad_partial_kernel(const JobTable T, float* __restrict__ ws) {
+    __shared__ f32x4 red[256];
+    int k = 0;
+    while (k + 1 < T.n_jobs && (int)blockIdx.x >= T.first_block[k + 1]) ++k;
+    const MdgGradJob& J = T.j[k];
+    const int local = (int)blockIdx.x - T.first_block[k];
+    const int wid = threadIdx.x >> 6;
+    if (J.kind == MDG_GRAD_ATB) {
+        const int units_n = (J.n + 127) / 128, units = ((J.m + 63) / 64) * units_n;
+        const int wave = local * 4 + wid;
+        const int unit = wave % units, split = wave / units;
+        if (split >= T.splits[k]) return;
+        const long long k0 = (long long)split * T.slab[k], k1 = min(J.rows, k0 + T.slab[k]);
+        const int m0 = (unit / units_n) * 64, n0 = (unit % units_n) * 128;
+        float* out = ws + T.ws_off[k] + (size_t)split * J.m * J.n;
+        if (J.n - n0 > 64) atb_wave<2>(J, m0, n0, k0, k1, out);
+        else atb_wave<1>(J, m0, n0, k0, k1, out);
+        return;
+    }
+    // column sums of A (.* B) (+ A2 .* B2) over the block's row slab: a thread owns 4 consecutive columns, the block's
+    // 256 / (cols / 4) row lanes walk the slab with that stride; ordered combine through LDS
+    const int groups = (J.m + 3) / 4;                              // float4 column groups (<= 256: m <= 1024)
+    const int cg_per_blk = min(groups, 256), rl_n = 256 / cg_per_blk;
+    const int col_blocks = (groups + cg_per_blk - 1) / cg_per_blk;
+    const int split = local / col_blocks, cb = local % col_blocks;
+    const int cg = cb * cg_per_blk + (int)(threadIdx.x % cg_per_blk), rl = (int)(threadIdx.x / cg_per_blk);
+    const long long k0 = (long long)split * T.slab[k], k1 = min(J.rows, k0 + T.slab[k]);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (cg < groups && rl < rl_n) {
+        for (int pass = 0; pass < (J.A2 ? 2 : 1); ++pass) {
+            const float* __restrict__ Ap = pass ? J.A2 : J.A;
+            const float* __restrict__ Bp = pass ? J.B2 : J.B;
+            for (long long r = k0 + rl; r < k1; r += rl_n) {
+                f32x4 a = load4(Ap, r, J.m, 4 * cg, true);
+                if (Bp) a *= load4(Bp, r, J.m, 4 * cg, true);
+                s += a;
+            }
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rl == 0 && cg < groups) {
+        for (int q = 1; q < rl_n; ++q) s += red[q * cg_per_blk + (int)(threadIdx.x % cg_per_blk)];
+        float* out = ws + T.ws_off[k] + (size_t)split * J.m;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * cg + c < J.m) out[4 * cg + c] = s[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const JobTable T, const float* __restrict__ ws, float* __restrict__ flat,
+                                                          float alpha, const float* __restrict__ tgrid,
+                                                          const long long* __restrict__ idx, int accumulate) {
+    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, sub = threadIdx.x & 3;
+    // (every job's outputs are padded to a multiple of the 64 elements a block covers: k is uniform in the block)
+    const int g0 = (int)blockIdx.x * 64;
+    int k = 0;
+    while (k + 1 < T.n_jobs && g0 >= T.first_out[k + 1]) ++k;
+    const MdgGradJob& J = T.j[k];
+    const int e = g - T.first_out[k];
+    const int MN = J.kind == MDG_GRAD_ATB ? J.m * J.n : J.m;
+    const bool live = e < MN;
+    float s = 0.f;
+    if (live) {
+        if (J.kind == MDG_GRAD_AXPY) {
+            if (sub == 0) s = J.A[e] + (J.A2 ? J.A2[e] : 0.f);
+        } else {
+            const float* p = ws + T.ws_off[k] + e;
+            for (int q = sub; q < T.splits[k]; q += 4) s += p[(size_t)q * MN];
+        }
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (!live || sub != 0) return;
+    float f = alpha;
+    if (tgrid) { const long long i = idx[0]; f *= tgrid[i] - tgrid[i - 1]; }
+    long long dst = J.out_off + e;
+    if (J.kind == MDG_GRAD_ATB && J.row_map) dst = J.out_off + (long long)J.row_map[e / J.n] * J.n + (e % J.n);
+    flat[dst] = accumulate ? fmaf(f, s, flat[dst]) : f * s;
+}
+
+int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) {
+    if (n_jobs < 0 || n_jobs > MDG_GRAD_JOBS_MAX) { mdg_set_error("grad_jobs: at most %d jobs per call", MDG_GRAD_JOBS_MAX); return MDG_EINVAL; }
+    T.n_jobs = n_jobs;
+    long long ws = 0;
+    int blocks = 0, outs = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const MdgGradJob& J = jobs[k];
+        T.j[k] = J;
+        T.first_block[k] = blocks;
+        T.first_out[k] = outs;
+        T.ws_off[k] = ws;
+        const bool pair_ok = J.kind == MDG_GRAD_AXPY ? true
+                           : J.kind == MDG_GRAD_ATB ? (J.A2 == nullptr) == (J.B2 == nullptr)
+                                                    : (J.A2 == nullptr ? J.B2 == nullptr : (J.B2 == nullptr) == (J.B == nullptr));
+        if (J.m <= 0 || J.rows < 0 || !J.A || !pair_ok) {
+            mdg_set_error("grad_jobs: job %d has bad operands", k);
+            return MDG_EINVAL;
+        }
+        if (J.kind == MDG_GRAD_ATB) {
+            if (J.n <= 0 || !J.B) { mdg_set_error("grad_jobs: job %d: a product needs B and n > 0", k); return MDG_EINVAL; }
+            const int units = ((J.m + 63) / 64) * ((J.n + 127) / 128);
+            long long want = (2048 + units - 1) / units;                 // ~2048 waves in flight over all jobs' units
+            const long long maxs = (J.rows + 63) / 64;                   // at least 64 rows per slab
+            if (want > maxs) want = maxs;
+            if (want < 1) want = 1;
+            if (want > 512) want = 512;
+            long long slab = (J.rows + want - 1) / want;
+            slab = (slab + 3) / 4 * 4;
+            if (slab < 4) slab = 4;
+            const int splits = (int)((J.rows + slab - 1) / slab > 0 ? (J.rows + slab - 1) / slab : 1);
+            T.splits[k] = splits;
+            T.slab[k] = slab;
+            blocks += (units * splits + 3) / 4;
+            ws += (long long)splits * J.m * J.n;
+            outs += (J.m * J.n + 63) / 64 * 64;
+        } else if (J.kind == MDG_GRAD_COLSUM) {
+            if (J.m > 1024) { mdg_set_error("grad_jobs: job %d: column sums take at most 1024 columns", k); return MDG_EINVAL; }
+            const int groups = (J.m + 3) / 4, cg_per_blk = groups < 256 ? groups : 256;
+            const int col_blocks = (groups + cg_per_blk - 1) / cg_per_blk;
+            long long want = (J.rows + 511) / 512;                      // ~512 rows per block
+            if (want < 1) want = 1;
+            if (want > 256) want = 256;
+            const long long slab = (J.rows + want - 1) / want > 0 ? (J.rows + want - 1) / want : 1;
+            const int splits = (int)((J.rows + slab - 1) / slab > 0 ? (J.rows + slab - 1) / slab : 1);
+            T.splits[k] = splits;
+            T.slab[k] = slab;
+            blocks += splits * col_blocks;
+            ws += (long long)splits * J.m;
+            outs += (J.m + 63) / 64 * 64;
+        } else if (J.kind == MDG_GRAD_AXPY) {
+            T.splits[k] = 0;
+            T.slab[k] = 0;
+            outs += (J.m + 63) / 64 * 64;
+        } else {
+            mdg_set_error("grad_jobs: job %d: unknown kind %d", k, J.kind);
+            return MDG_EINVAL;
+        }
+    }
+    T.first_block[n_jobs] = blocks;
+    T.first_out[n_jobs] = outs;
+    ws_floats = ws;
+    return MDG_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t mdg_grad_jobs_workspace(const MdgGradJob* jobs, int n_jobs) {
+    JobTable T;
+    long long ws = 0;
+    if (plan(jobs, n_jobs, T, ws) != MDG_OK) return -1;
+    return ws > 0 ? ws : 1;
+}
+
+extern "C" int mdg_grad_jobs(const MdgGradJob* jobs, int n_jobs, float* flat, float alpha, const float* t, const int64_t* idx,
+                             int accumulate, float* workspace, void* stream) {
+    MDG_CHECK_ARG(flat && (n_jobs == 0 || jobs), "grad_jobs: null buffer");
+    MDG_CHECK_ARG((t == nullptr) == (idx == nullptr), "grad_jobs: the time grid and the frame index go together");
+    if (n_jobs == 0) return MDG_OK;
+    JobTable T;
+    long long ws = 0;
+    const int rc = plan(jobs, n_jobs, T, ws);
+    if (rc != MDG_OK) return rc;
+    MDG_CHECK_ARG(ws == 0 || workspace, "grad_jobs: null workspace");
+    hipStream_t st = (hipStream_t)stream;
+    if (T.first_block[n_jobs] > 0)
+        hipLaunchKernelGGL(grad_partial_kernel, dim3(T.first_block[n_jobs]), dim3(256), 0, st, T, workspace);
+    const int outs = T.first_out[n_jobs];
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3((outs * 4 + 255) / 256), dim3(256), 0, st, T, (const float*)workspace, flat, alpha, t,
+                       (const long long*)idx, accumulate);
+    MDG_CHECK_LAUNCH("grad_jobs kernels");
+    return MDG_OK;
+}

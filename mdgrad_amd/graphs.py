@@ -167,7 +167,14 @@ class _AdjointGraph:
             F, dwf, _ = func.model.force_vjp(q, wv, want_theta=False)
             qm, wh = w.adj_mid(lam, F, dwf, self.t, i)
             func.update_topology(qm)
-            _, dwf1, th1 = func.model.force_vjp(qm, wh)
+            if getattr(func.model, "accepts_accum", False):
+                # every piece of the parameter gradient is added into self.gth by the kernel that reduces it, weighted
+                # with t[i] - t[i-1] read on the device (sovlers.py:160)
+                from . import ops
+                acc = ops.ThetaAccum(func.parameters(), flat=self.gth, t=self.t, idx=i)
+                _, dwf1, th1 = func.model.force_vjp(qm, wh, accum=acc)
+            else:
+                _, dwf1, th1 = func.model.force_vjp(qm, wh)
             w.adj_end(lam, dwf1, self.t, i, self.gout)
             if th1:
                 self.gth.add_(_flatten(func.theta_in_parameter_order(th1)) * (self.t.index_select(0, i) - self.t.index_select(0, i - 1)))

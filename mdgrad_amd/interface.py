@@ -12,6 +12,15 @@ from .potentials import is_builtin_form
 from .topology import compute_dis, get_offsets
 
 
+def _accumulate_list(accum, params, grads):
+    """flat[offset(p)] += weight * g for a member that returned its parameter gradients as a list."""
+    jobs = ops.GradJobs()
+    for p, g in zip(params, grads):
+        if g is not None:
+            jobs.axpy(accum.off[id(p)], g.detach().to(torch.float32))
+    jobs.run(accum, alpha=1.0, accumulate=True)
+
+
 class GeneralInteraction(torch.nn.Module):
     def __init__(self, system):
         super().__init__()
@@ -163,10 +172,14 @@ class GNNPotentials(GeneralInteraction):
         from .nn import analytic
         return analytic.force(self.gnn, self._z(), xyz, self.inputs['_topo'], self.inputs['offsets'], want_energy=False)[1]
 
-    def force_vjp(self, xyz, w, want_theta=True):
+    accepts_accum = True
+
+    def force_vjp(self, xyz, w, want_theta=True, accum=None):
+        """`accum` (ops.ThetaAccum): the parameter gradients are added into its flat buffer (weighted on the device) and
+        None is returned in their place."""
         from .nn import analytic
         _, F, dq, gth = analytic.force_vjp(self.gnn, self._z(), xyz, w, self.inputs['_topo'], self.inputs['offsets'],
-                                           want_theta=want_theta, want_energy=False)
+                                           want_theta=want_theta, want_energy=False, accum=accum)
         return F, dq, gth
 
 
@@ -292,14 +305,33 @@ class PairPotentials(GeneralInteraction):
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True)
         return -o["grad"]
 
-    def force_vjp(self, xyz, w, want_theta=True):
+    accepts_accum = True
+
+    def force_vjp(self, xyz, w, want_theta=True, accum=None):
         """(F, d(w.F)/dx, [d(w.F)/dtheta_p for p in parameters()]) -- what double autograd yields at
-        torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term)."""
+        torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term).  `accum`
+        (ops.ThetaAccum): the parameter part is added into its flat buffer instead (None returned)."""
         if not self.builtin():
-            return self._module_force_vjp(xyz.detach().contiguous(), w.detach().contiguous(), want_theta)
+            out = self._module_force_vjp(xyz.detach().contiguous(), w.detach().contiguous(), want_theta)
+            if accum is None or out[2] is None:
+                return out
+            _accumulate_list(accum, self.parameters(), out[2])
+            return out[0], out[1], None
         theta, params = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, w=w.detach().contiguous(),
                           energy=False, grad=True)
+        if accum is not None and want_theta:
+            if params:
+                jobs, pos = ops.GradJobs(), 0
+                offs = [accum.off[id(p)] for p in params]
+                if all(offs[k + 1] == offs[k] + params[k].numel() for k in range(len(params) - 1)):
+                    jobs.axpy(offs[0], o["gtheta_w"])               # the term's parameters are adjacent in the flat buffer
+                else:
+                    for p, o_ in zip(params, offs):
+                        jobs.axpy(o_, o["gtheta_w"][pos:pos + p.numel()])
+                        pos += p.numel()
+                jobs.run(accum, alpha=-1.0, accumulate=True)
+            return -o["grad"], -o["hw"], None
         gth, pos = [], 0
         for p in params:
             n = p.numel()
@@ -401,20 +433,30 @@ class Stack(torch.nn.Module):
             out = f if out is None else out + f
         return out
 
-    def force_vjp(self, x, w, want_theta=True):
+    accepts_accum = True
+
+    def force_vjp(self, x, w, want_theta=True, accum=None):
         """Sum over members; the parameter gradients come back as a list aligned with self.parameters()
         (None when want_theta is False: the first augmented evaluation of an adjoint interval discards
-        them, sovlers.py:141-143)."""
+        them, sovlers.py:141-143) -- or are added into `accum` (ops.ThetaAccum) by the members themselves."""
         F = dq = None
         by_id = {}
         for m in self.models.values():
-            f, g, gth = m.force_vjp(x, w, want_theta=want_theta)
+            if accum is not None and want_theta:
+                if getattr(m, "accepts_accum", False):
+                    f, g, gth = m.force_vjp(x, w, want_theta=True, accum=accum)
+                else:
+                    f, g, gth = m.force_vjp(x, w, want_theta=True)
+                if gth is not None:
+                    _accumulate_list(accum, m.parameters(), gth)
+            else:
+                f, g, gth = m.force_vjp(x, w, want_theta=want_theta)
             F = f if F is None else F + f
             dq = g if dq is None else dq + g
-            if want_theta:
+            if want_theta and accum is None:
                 for p, gp in zip(m.parameters(), gth):
                     by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp
-        if not want_theta:
+        if not want_theta or accum is not None:
             return F, dq, None
         return F, dq, [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
 

@@ -279,16 +279,18 @@ def _forward_fused(net, z, x, topo, w=None, want_sums=False, want_energy=True):
         r, _, rd = _dense(P["U2"], t, bias=P["c2"], res=r, x1=td, res1=rd)       # residual (schnet.py:149-151)
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
-    y, _, yd = _dense(L1, r, bias=l1, x1=rd)
-    U = (_ssp(y).mm(L2.t()) + l2).sum() if want_energy else None    # (the integrators only ask for forces)
-    return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, y=y, yd=yd, L1=L1, L2=L2, U=U)
+    # readout layer with its activation in the epilogue: ssp(y), sy = sigmoid(y), syd = sy * y_dot -- all the reverse
+    # sweeps need of it
+    ty, sy, syd = _dense(L1, r, bias=l1, act=True, x1=rd, want_sig=True)
+    U = (ty.mm(L2.t()) + l2).sum() if want_energy else None         # (the integrators only ask for forces)
+    return dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=sy, syd=syd, L1=L1, L2=L2, U=U)
 
 
 @torch.no_grad()
 def _force_fused(net, z, x, topo, want_energy=True):
     fw = _forward_fused(net, z, x, topo, want_energy=want_energy)
     d = fw["d"]
-    rb = _dense(fw["L1"], torch.sigmoid(fw["y"]) * fw["L2"], trans=True)[0]
+    rb = _dense(fw["L1"], ops.readout_head(fw["sy"], None, fw["L2"])[0], trans=True)[0]
     dU_dd = torch.zeros_like(d)
     for idx in range(len(fw["layers"]) - 1, -1, -1):
         L = fw["layers"][idx]
@@ -304,21 +306,24 @@ def _force_fused(net, z, x, topo, want_energy=True):
 
 
 @torch.no_grad()
-def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
+def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accum=None):
+    """`accum` (ops.ThetaAccum): the parameter gradients are accumulated into its flat buffer -- every reduction of the
+    sweep in one batched launch pair (csrc/gradjobs.hip) -- and None is returned in their place; without it they come
+    back as a list aligned with net.parameters()."""
     fw = _forward_fused(net, z, x, topo, w, want_sums=want_theta, want_energy=want_energy)
     d, dd = fw["d"], fw["dd"]
-    L1, L2, y, yd, rd = fw["L1"], fw["L2"], fw["y"], fw["yd"], fw["rd"]
-    sy = torch.sigmoid(y)
+    L1, L2, rd = fw["L1"], fw["L2"], fw["rd"]
     # ---------------- reverse sweep of U_dot = sum_i L2 . (sig(y_i) * yd_i)
-    ydb = sy * L2
-    yb = sy * (1 - sy) * yd * L2
-    grads = {}
+    ydb, yb = ops.readout_head(fw["sy"], fw["syd"], L2)
     ro = net.atomwisereadout.readout["energy"]
+    jobs = acc = None
     if want_theta:
-        grads[id(ro[2].weight)] = (sy * yd).sum(0)[None]
-        grads[id(ro[2].bias)] = torch.zeros_like(ro[2].bias)
-        grads[id(ro[0].weight)] = _atb_sum(yb, fw["r"], ydb, rd)
-        grads[id(ro[0].bias)] = yb.sum(0)
+        acc = accum if accum is not None else ops.ThetaAccum(net.parameters())
+        off = lambda p: acc.off[id(p)]
+        jobs = ops.GradJobs()
+        jobs.colsum(off(ro[2].weight), fw["syd"])                                    # (ro[2].bias: U_dot does not see it)
+        jobs.atb(off(ro[0].weight), yb, fw["r"], ydb, rd)
+        jobs.colsum(off(ro[0].bias), yb)
     rdb, _, rb = _dense(L1, ydb, trans=True, x1=yb)
     d_b, dd_b = torch.zeros_like(d), torch.zeros_like(d)
     convs = list(net.convolutions)
@@ -327,45 +332,46 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True):
         P = L["P"]
         tdb, _, tb = _dense(P["U2"], rdb, trans=True, x1=rb)
         if want_theta:
-            grads[id(md_["update_function"][2].weight)] = _atb_sum(rb, L["t"], rdb, L["td"])
-            grads[id(md_["update_function"][2].bias)] = rb.sum(0)
+            jobs.atb(off(md_["update_function"][2].weight), rb, L["t"], rdb, L["td"])
+            jobs.colsum(off(md_["update_function"][2].bias), rb)
         udb, ub = ops.ssp_dual_bwd_t(L["su"], L["td"], tdb, tb)
         mdb, _, mb = _dense(P["U1"], udb, trans=True, x1=ub)
         if want_theta:
-            grads[id(md_["update_function"][0].weight)] = _atb_sum(udb, L["md"], ub, L["m"])
-            grads[id(md_["update_function"][0].bias)] = ub.sum(0)
+            jobs.atb(off(md_["update_function"][0].weight), udb, L["md"], ub, L["m"])
+            jobs.colsum(off(md_["update_function"][0].bias), ub)
         th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta)
         if want_theta:
-            gb2 = (mb * L["hsum"]).sum(0)                        # sum_e W_b[e] = sum_n mb_n (.) sum_{j in nbr(n)} h_j
+            jobs.axpy(off(md_["message_edge_filter"][1].weight), th[0])
+            jobs.axpy(off(md_["message_edge_filter"][1].bias), th[1])
+            jobs.axpy(off(md_["message_edge_filter"][3].weight), th[2])
+            # sum_e W_b[e] = sum_n mb_n (.) sum_{j in nbr(n)} h_j  (+ the tangent half)
             if L["hdsum"] is not None:
-                gb2 = gb2 + (mdb * L["hdsum"]).sum(0)
-            grads[id(md_["message_edge_filter"][1].weight)] = th[0]
-            grads[id(md_["message_edge_filter"][1].bias)] = th[1]
-            grads[id(md_["message_edge_filter"][3].weight)] = th[2]
-            grads[id(md_["message_edge_filter"][3].bias)] = gb2
+                jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"], mdb, L["hdsum"])
+            else:
+                jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"])
         if want_theta or idx > 0:
             # the aggregation is symmetric in the adjacency: fed (mdb, mb) the forward kernel returns the
             # adjoints (hdb, hb) of (hd, h)
             hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
             if want_theta:
-                grads[id(md_["message_node_filter"].weight)] = _atb_sum(hb, L["r"], hdb if L["rd"] is not None else None, L["rd"])
-                grads[id(md_["message_node_filter"].bias)] = hb.sum(0)
+                if L["rd"] is not None:
+                    jobs.atb(off(md_["message_node_filter"].weight), hb, L["r"], hdb, L["rd"])
+                else:
+                    jobs.atb(off(md_["message_node_filter"].weight), hb, L["r"])
+                jobs.colsum(off(md_["message_node_filter"].bias), hb)
             rdb, _, rb = _dense(P["Wn"], hdb, trans=True, res=rdb, x1=hb, res1=rb)
     # dd_b = dU/dd (see the module docstring): force and d(w.F)/dx from one scatter
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
     if not want_theta:
         return fw["U"], F, dwf, None
+    # embedding rows: one-hot(z)^T rb, row s of the product -> row uniq[s] of the table (no float atomics: index_add_ on a
+    # handful of species serialises and is not reproducible)
     uniq, onehot = _species_onehot(z)
-    emb = torch.zeros_like(net.atom_embed.weight)
-    emb[uniq] = _atb(onehot, rb)
-    grads[id(net.atom_embed.weight)] = emb
-    plist = list(net.parameters())
-    flat = torch.cat([grads[id(p)].reshape(-1) for p in plist]).neg_()          # w.F = -U_dot
-    out, pos = [], 0
-    for p in plist:
-        out.append(flat[pos:pos + p.numel()].reshape(p.shape))
-        pos += p.numel()
-    return fw["U"], F, dwf, out
+    jobs.atb(off(net.atom_embed.weight), onehot, rb, row_map=uniq)
+    jobs.run(acc, alpha=-1.0, accumulate=True)                   # w.F = -U_dot
+    if accum is not None:
+        return fw["U"], F, dwf, None
+    return fw["U"], F, dwf, acc.views()
 
 
 @torch.no_grad()
@@ -380,16 +386,25 @@ def force(net, z, x, topo, offsets=None, want_energy=True):
 
 
 @torch.no_grad()
-def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=True):
+def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=True, accum=None):
     """(U, F, d(w.F)/dx, [d(w.F)/dtheta_p for p in net.parameters()]); the parameter part is skipped
-    (None) when want_theta is False.  (`offsets` is the topology's own image-flag array; the argument is
-    kept for callers that pass it explicitly.)"""
+    (None) when want_theta is False, and accumulated into `accum` (ops.ThetaAccum: flat buffer, interval weight read on
+    the device) instead of being returned when that is given.  (`offsets` is the topology's own image-flag array; the
+    argument is kept for callers that pass it explicitly.)"""
     if fused_ok(net):
         with _node_blas():
-            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy)
+            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy,
+                                    accum)
     topo = _stable(topo)
     with _blas_for(topo):
-        return _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)
+        out = _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)
+    if accum is not None and out[3] is not None:
+        jobs = ops.GradJobs()
+        for p, g in zip(net.parameters(), out[3]):
+            jobs.axpy(accum.off[id(p)], g)
+        jobs.run(accum, alpha=1.0, accumulate=True)
+        return out[0], out[1], out[2], None
+    return out
 
 
 def _force_vjp_unfused(net, z, x, w, topo, offsets, want_theta=True):

@@ -1321,6 +1321,86 @@ def ssp_dual_bwd_t(sa, td, sdb, sb):
     return xdb, xb
 
 
+def readout_head(sy, syd, L2):
+    """(ydb, yb) = (sy * L2, (1 - sy) * syd * L2): the seeds of the reverse sweep through the readout, one launch
+    (csrc/elem.hip); syd None: first-order pass, yb None."""
+    lib = _lib.load()
+    require_gpu(sy, "sy")
+    sy = sy.contiguous()
+    syd = syd.contiguous() if syd is not None else None
+    l2 = L2.detach().reshape(-1).contiguous()
+    ydb = torch.empty_like(sy)
+    yb = torch.empty_like(sy) if syd is not None else None
+    check(lib.mdg_readout_head(ptr(sy), ptr(syd), ptr(l2), sy.shape[0], sy.shape[1], ptr(ydb), ptr(yb),
+                               stream_ptr(sy.device)), "mdg_readout_head")
+    return ydb, yb
+
+
+class ThetaAccum:
+    """A flat parameter-gradient buffer in `params` order (tinydiffeq.py:106-108) that kernels accumulate into directly:
+    `flat[offset(p) ...] += alpha * (t[idx] - t[idx - 1]) * value` with the time grid and the frame index on the device
+    (sovlers.py:160; t = idx = None: plain alpha)."""
+
+    def __init__(self, params, flat=None, t=None, idx=None):
+        self.params = list(params)
+        self.off, n = {}, 0
+        for p in self.params:
+            self.off[id(p)] = n
+            n += p.numel()
+        self.n = n
+        self.flat = flat if flat is not None else torch.zeros(n, device=self.params[0].device, dtype=torch.float32)
+        assert self.flat.numel() == n and self.flat.is_contiguous()
+        self.t, self.idx = t, idx
+
+    def views(self):
+        return [self.flat[self.off[id(p)]:self.off[id(p)] + p.numel()].view(p.shape) for p in self.params]
+
+
+class GradJobs:
+    """Collects the reductions of one adjoint evaluation and issues them as two launches per <= 32 jobs
+    (mdg_grad_jobs, csrc/gradjobs.hip)."""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def _add(self, kind, off, rows, m, n, A, B=None, A2=None, B2=None, row_map=None):
+        ts = [x.contiguous() if x is not None else None for x in (A, B, A2, B2)]
+        self.keep.extend(ts)
+        if row_map is not None:
+            self.keep.append(row_map)
+        self.jobs.append((kind, int(off), int(rows), int(m), int(n), ts, row_map))
+
+    def atb(self, off, A, B, A2=None, B2=None, row_map=None):
+        """flat[off ...] <- A^T B (+ A2^T B2), [m, n] row-major (rows re-mapped through row_map)."""
+        self._add(_lib.GRAD_ATB, off, A.shape[0], A.shape[1], B.shape[1], A, B, A2, B2, row_map)
+
+    def colsum(self, off, A, B=None, A2=None, B2=None):
+        """flat[off ...] <- sum over rows of A (.* B) (+ A2 (.* B2))."""
+        self._add(_lib.GRAD_COLSUM, off, A.shape[0], A.shape[1], 0, A, B, A2, B2)
+
+    def axpy(self, off, A):
+        """flat[off ...] <- A (already reduced)."""
+        self._add(_lib.GRAD_AXPY, off, 1, A.numel(), 0, A.reshape(-1))
+
+    def run(self, acc, alpha=1.0, accumulate=True):
+        lib = _lib.load()
+        dev = acc.flat.device
+        for c0 in range(0, len(self.jobs), _lib.GRAD_JOBS_MAX):
+            chunk = self.jobs[c0:c0 + _lib.GRAD_JOBS_MAX]
+            arr = (_lib.MdgGradJob * len(chunk))()
+            for j, (kind, off, rows, m, n, ts, row_map) in zip(arr, chunk):
+                j.A, j.B, j.A2, j.B2 = (x.data_ptr() if x is not None else None for x in ts)
+                j.row_map = row_map.data_ptr() if row_map is not None else None
+                j.rows, j.m, j.n, j.kind, j.out_off = rows, m, n, kind, off
+            need = int(lib.mdg_grad_jobs_workspace(arr, len(chunk)))
+            if need < 0:
+                check(1, "mdg_grad_jobs_workspace")
+            ws = torch.empty(max(1, need), device=dev, dtype=torch.float32)
+            self.keep.append(ws)
+            check(lib.mdg_grad_jobs(arr, len(chunk), ptr(acc.flat), float(alpha), ptr(acc.t), ptr(acc.idx), int(bool(accumulate)),
+                                    ptr(ws), stream_ptr(dev)), "mdg_grad_jobs")
+
+
 def smear_bwd(gdb, gb, g, phi, dd, c, d_b, dd_b):
     """Accumulates into d_b (and dd_b when gdb is given) in place."""
     lib = _lib.load()

@@ -252,6 +252,10 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
                 # straight to odeint_adjoint must not reach them as a raw pointer)
                 tc = t.to(device=lam[0].device, dtype=lam[0].dtype).contiguous()
                 idx = torch.full((1,), T - 1, dtype=torch.int64, device=lam[0].device)
+                # parameter gradients: every kernel that produces a piece adds  (t[i] - t[i-1]) * piece  straight into the
+                # flat buffer (:160), reading the interval from the device grid
+                accepts = getattr(func.model, "accepts_accum", False)
+                acc = ops.ThetaAccum(func.parameters(), flat=gth, t=tc, idx=idx) if accepts else None
                 for i in range(T - 1, 0, -1):
                     q, wv = w.adj_pre(frames, lam[0], idx)
                     func.update_topology(q)                               # :258 (dL/dt call: counter / rebuild only)
@@ -259,10 +263,13 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
                     F, dwf, _ = func.model.force_vjp(q, wv, want_theta=False)
                     qm, wh = w.adj_mid(lam, F, dwf, tc, idx)
                     func.update_topology(qm)
-                    _, dwf1, th1 = func.model.force_vjp(qm, wh)
+                    if accepts:
+                        _, dwf1, th1 = func.model.force_vjp(qm, wh, accum=acc)
+                    else:
+                        _, dwf1, th1 = func.model.force_vjp(qm, wh)
                     w.adj_end(lam, dwf1, tc, idx, gout)
                     if th1:
-                        gth = gth + _flatten(func.theta_in_parameter_order(th1)) * (tc[i] - tc[i - 1])   # :160
+                        gth += _flatten(func.theta_in_parameter_order(th1)) * (tc[i] - tc[i - 1])   # :160
                     idx.sub_(1)
                 return lam, gth
             for i in range(T - 1, 0, -1):

@@ -258,3 +258,95 @@ def test_atb2_kernel():
         ref = (A.double().t() @ B.double() + A2.double().t() @ B2.double()).float()
         _close(ops._atb2(A, B, A2, B2), ref, "atb2")
         assert torch.equal(ops._atb2(A, B, A2, B2), ops._atb2(A, B, A2, B2)), "bitwise reproducible"
+
+
+def test_grad_jobs_batched_parameter_gradient_reductions():
+    """mdg_grad_jobs (csrc/gradjobs.hip): tall-skinny products (one / two operand pairs, odd widths, a single-column
+    operand with re-mapped destination rows), column sums (plain, of a product, of two products), pre-reduced pieces --
+    35 jobs in two chunks -- accumulated into a flat buffer with the interval weight read from a device time grid;
+    against fp64 torch.  Two runs give the same bits."""
+    from mdgrad_amd import ops
+    torch.manual_seed(3)
+    N = 5000
+    rnd = lambda *s: torch.randn(*s, device=DEV)
+    shapes = [(64, 128), (32, 64), (128, 64), (64, 64), (30, 66), (100, 36), (3, 64), (256, 256)]
+    params = [torch.nn.Parameter(torch.zeros(m, n, device=DEV)) for m, n in shapes]
+    params += [torch.nn.Parameter(torch.zeros(c, device=DEV)) for c in (128, 64, 30, 1, 257)]
+    emb = torch.nn.Parameter(torch.zeros(100, 64, device=DEV))
+    pre = [torch.nn.Parameter(torch.zeros(30, 30, device=DEV)), torch.nn.Parameter(torch.zeros(30, device=DEV))]
+    allp = params + [emb] + pre
+    t = torch.tensor([0.0, 0.3, 0.7, 1.5], device=DEV)
+    idx = torch.tensor([2], dtype=torch.int64, device=DEV)
+    outs = []
+    for rep in range(2):
+        acc = ops.ThetaAccum(allp, t=t, idx=idx)
+        acc.flat.copy_(torch.arange(acc.n, device=DEV, dtype=torch.float32) * 1e-3)
+        base = acc.flat.double().clone()
+        torch.manual_seed(4)
+        jobs, want = ops.GradJobs(), {}
+        for k, (p, (m, n)) in enumerate(zip(params, shapes)):
+            A, B = rnd(N, m), rnd(N, n)
+            if k % 2 == 0:
+                A2, B2 = rnd(N, m), rnd(N, n)
+                jobs.atb(acc.off[id(p)], A, B, A2, B2)
+                want[id(p)] = A.double().t() @ B.double() + A2.double().t() @ B2.double()
+            else:
+                jobs.atb(acc.off[id(p)], A, B)
+                want[id(p)] = A.double().t() @ B.double()
+        for k, p in enumerate(params[len(shapes):]):
+            c = p.numel()
+            A, B, A2, B2 = rnd(N, c), rnd(N, c), rnd(N, c), rnd(N, c)
+            if k % 3 == 0:
+                jobs.colsum(acc.off[id(p)], A)
+                want[id(p)] = A.double().sum(0)
+            elif k % 3 == 1:
+                jobs.colsum(acc.off[id(p)], A, B)
+                want[id(p)] = (A.double() * B.double()).sum(0)
+            else:
+                jobs.colsum(acc.off[id(p)], A, B, A2, B2)
+                want[id(p)] = (A.double() * B.double() + A2.double() * B2.double()).sum(0)
+        uniq = torch.tensor([1, 8, 17], dtype=torch.int64, device=DEV)
+        onehot = torch.nn.functional.one_hot(torch.randint(0, 3, (N,), device=DEV), 3).float()
+        rb = rnd(N, 64)
+        jobs.atb(acc.off[id(emb)], onehot, rb, row_map=uniq)
+        w_emb = torch.zeros(100, 64, device=DEV, dtype=torch.float64)
+        w_emb[uniq] = onehot.double().t() @ rb.double()
+        want[id(emb)] = w_emb
+        for p in pre:
+            g = rnd(*p.shape)
+            jobs.axpy(acc.off[id(p)], g)
+            want[id(p)] = g.double()
+        for extra in range(20):                                   # second chunk (> 32 jobs per evaluation)
+            g = rnd(30)
+            jobs.axpy(acc.off[id(pre[1])], g)
+            want[id(pre[1])] = want[id(pre[1])] + g.double()
+        assert len(jobs.jobs) > 32
+        jobs.run(acc, alpha=-1.0, accumulate=True)
+        ref = base.clone()
+        dt = float(t[2] - t[1])
+        for p in allp:
+            o = acc.off[id(p)]
+            ref[o:o + p.numel()] += -dt * want[id(p)].reshape(-1)
+        scale = float(ref.abs().max())
+        err = float((acc.flat.double() - ref).abs().max())
+        assert err < 2e-5 * scale, "grad jobs vs fp64: %.3e (scale %.3e)" % (err, scale)
+        # without accumulation the destination is overwritten
+        acc2 = ops.ThetaAccum(pre[1:])
+        acc2.flat.fill_(7.0)
+        j2 = ops.GradJobs()
+        g = rnd(30)
+        j2.axpy(0, g)
+        j2.run(acc2, alpha=2.0, accumulate=False)
+        assert torch.allclose(acc2.flat, 2.0 * g)
+        outs.append(acc.flat.clone())
+    assert torch.equal(outs[0], outs[1]), "fixed-order reductions: two runs must give the same bits"
+
+
+def test_readout_head_kernel():
+    from mdgrad_amd import ops
+    torch.manual_seed(0)
+    sy, syd, L2 = torch.rand(777, 32, device=DEV), torch.randn(777, 32, device=DEV), torch.randn(1, 32, device=DEV)
+    ydb, yb = ops.readout_head(sy, syd, L2)
+    assert torch.allclose(ydb, sy * L2) and torch.allclose(yb, (1 - sy) * syd * L2, atol=1e-6)
+    ydb1, none = ops.readout_head(sy, None, L2)
+    assert none is None and torch.equal(ydb1, ydb)
