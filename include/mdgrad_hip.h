@@ -419,7 +419,8 @@ int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float
  *  transposed products of the hand-derived reverse sweeps):
  *     z0 = x0 B + bias0 ;  out0 = act(z0) * mul0 + res0 ;  sig0 = sigmoid(z0)            (act = 1: shifted softplus)
  *     z1 = x1 B          ;  out1 = act'(z0) z1 + res1                                     (x1 nullable)
- *  B[k][m] = W[m*k_dim + k] (trans = 0, torch.nn.Linear layout) or W[k*m_dim + m] (trans = 1).  k <= 256.
+ *  B[k][m] = W[m*k_dim + k] (trans = 0, torch.nn.Linear layout) or W[k*m_dim + m] (trans = 1).  Any k: layers wider than
+ *  256 inputs run as k-slabs of 256 that hand their partial sums on through out0 / out1.
  */
 int mdg_dense(const float* W, int trans, int act, int n_rows, int k, int m,
               const float* x0, const float* bias0, const float* mul0, const float* res0, float* out0, float* sig0,

@@ -84,6 +84,8 @@ __device__ __forceinline__ void xcd_sweep(int n, int unit, int& begin, int& end,
 struct FilterDev {
     const float *mu, *coef, *W1, *b1, *W2, *b2;
     int G, F;
+    int RS;       // floats per row of the node feature matrices (= n_filters of the whole layer; F is this launch's
+                  // chunk of <= 128 filters, W2 / b2 and the node pointers are offset to its first filter)
 };
 
 // ============================================================================================ forward
@@ -96,11 +98,11 @@ struct FwdArgs {
 };
 
 template <int FT>
-__device__ __forceinline__ void load_row(const float* __restrict__ base, long long row, int F, int li, bool ok,
+__device__ __forceinline__ void load_row(const float* __restrict__ base, long long row, int F, int RS, int li, bool ok,
                                          float (&out)[FT]) {
     // FT consecutive filters li*FT .. li*FT+FT-1 of one gathered row (zero outside the row / for an inert slot)
     if (ok && li * FT + FT <= F) {
-        const float4* p = reinterpret_cast<const float4*>(base + row * F + li * FT);
+        const float4* p = reinterpret_cast<const float4*>(base + row * RS + li * FT);
 #pragma unroll
         for (int v = 0; v < FT / 4; ++v) {
             const float4 x = p[v];
@@ -113,9 +115,9 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, long lo
 }
 
 template <int FT>
-__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int F, int li, const float (&v)[FT]) {
+__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int F, int RS, int li, const float (&v)[FT]) {
     if (li * FT + FT <= F) {
-        float4* p = reinterpret_cast<float4*>(base + row * F + li * FT);
+        float4* p = reinterpret_cast<float4*>(base + row * RS + li * FT);
 #pragma unroll
         for (int q = 0; q < FT / 4; ++q) p[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
     float* b2s = b1s + GP;
     float* h1s = b2s + FP;                  // [4 waves][16][SA]  (, [4][16][SA] tangent)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = A.net.G, F = A.net.F;
+    const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int k = t / GP, j = t % GP;
         w1s[k * S1 + j] = (k < G && j < G) ? A.net.W1[j * G + k] : 0.f;
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
                 const int s = t0 + 4 * lk + r;
                 const bool vc = s < cnt;
                 const int j = vc ? A.col[rowb + s] : 0;
-                load_row<FT>(A.h, j, F, li, vc, hreg[r]);
-                if (TANGENT) load_row<FT>(A.hd, j, F, li, vc && A.hd != nullptr, hdreg[r]);
+                load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
+                if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
             // ---- layer 1: Gaussians (and d/dd of them) in registers as A fragments
             float af[KS], adf[KS];
@@ -271,10 +273,10 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
             }
         }
         if (lk == 0) {
-            store_row<FT>(A.m, n, F, li, macc);
-            if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
-            if (SUMS) store_row<FT>(A.hsum, n, F, li, hs);
-            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+            store_row<FT>(A.m, n, F, RS, li, macc);
+            if (TANGENT) store_row<FT>(A.md, n, F, RS, li, mdacc);
+            if (SUMS) store_row<FT>(A.hsum, n, F, RS, li, hs);
+            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
         }
     }
 }
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     unsigned short* w2b = w1b + GP * KSB;                                    // [FP rows c][KSB]   W2[f(c)][k]
     unsigned short* h1s = w2b + FP * KSB;                                    // [4 (+4) waves][16][KSB]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = A.net.G, F = A.net.F;
+    const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int j = t / GP, k = t % GP;
         w1b[j * KSB + k] = (j < G && k < G) ? f2bf(A.net.W1[j * G + k]) : 0;
@@ -354,8 +356,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const int s = t0 + 4 * lk + r;
                 const bool vc = s < cnt;
                 const int j = vc ? A.col[rowb + s] : 0;
-                load_row<FT>(A.h, j, F, li, vc, hreg[r]);
-                if (TANGENT) load_row<FT>(A.hd, j, F, li, vc && A.hd != nullptr, hdreg[r]);
+                load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
+                if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
             bf16x8 af[KB], adf[KB];
 #pragma unroll
@@ -429,10 +431,10 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             }
         }
         if (lk == 0) {
-            store_row<FT>(A.m, n, F, li, macc);
-            if (TANGENT) store_row<FT>(A.md, n, F, li, mdacc);
-            if (SUMS) store_row<FT>(A.hsum, n, F, li, hs);
-            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, li, hds);
+            store_row<FT>(A.m, n, F, RS, li, macc);
+            if (TANGENT) store_row<FT>(A.md, n, F, RS, li, mdacc);
+            if (SUMS) store_row<FT>(A.hsum, n, F, RS, li, hs);
+            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
         }
     }
 }
@@ -486,7 +488,7 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
     float* b1s = c2s + GP;
     float* wsc = b1s + GP;                   // [4 waves][WSZ]
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int G = A.net.G, F = A.net.F;
+    const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int k = t / GP, j = t % GP;
         const bool in = k < G && j < G;
@@ -549,24 +551,24 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
             float4 hi = {0.f, 0.f, 0.f, 0.f}, hj = hi, pi = hi, pj = hi;
             const bool ok = va && f0 + 4 <= F;
             if (ok) {
-                hi = *reinterpret_cast<const float4*>(A.h + ia * F + f0);
-                hj = *reinterpret_cast<const float4*>(A.h + ja * F + f0);
-                pi = *reinterpret_cast<const float4*>(A.mdb + ia * F + f0);
-                pj = *reinterpret_cast<const float4*>(A.mdb + ja * F + f0);
+                hi = *reinterpret_cast<const float4*>(A.h + ia * RS + f0);
+                hj = *reinterpret_cast<const float4*>(A.h + ja * RS + f0);
+                pi = *reinterpret_cast<const float4*>(A.mdb + ia * RS + f0);
+                pj = *reinterpret_cast<const float4*>(A.mdb + ja * RS + f0);
             }
             wdb[4 * q] = pi.x * hj.x + pj.x * hi.x; wdb[4 * q + 1] = pi.y * hj.y + pj.y * hi.y;
             wdb[4 * q + 2] = pi.z * hj.z + pj.z * hi.z; wdb[4 * q + 3] = pi.w * hj.w + pj.w * hi.w;
             if (DUAL) {
                 float4 bi = {0.f, 0.f, 0.f, 0.f}, bj = bi;
                 if (ok) {
-                    bi = *reinterpret_cast<const float4*>(A.mb + ia * F + f0);
-                    bj = *reinterpret_cast<const float4*>(A.mb + ja * F + f0);
+                    bi = *reinterpret_cast<const float4*>(A.mb + ia * RS + f0);
+                    bj = *reinterpret_cast<const float4*>(A.mb + ja * RS + f0);
                 }
                 float4 w = {bi.x * hj.x + bj.x * hi.x, bi.y * hj.y + bj.y * hi.y, bi.z * hj.z + bj.z * hi.z,
                             bi.w * hj.w + bj.w * hi.w};
                 if (A.hd != nullptr && ok) {
-                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * F + f0);
-                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * F + f0);
+                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * RS + f0);
+                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * RS + f0);
                     w.x += pi.x * tj.x + pj.x * ti.x; w.y += pi.y * tj.y + pj.y * ti.y;
                     w.z += pi.z * tj.z + pj.z * ti.z; w.w += pi.w * tj.w + pj.w * ti.w;
                 }
@@ -782,7 +784,8 @@ size_t bwd_lds_bytes(bool theta) {
 
 // sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes
 __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nrec, int GP, int FP, int G, int F,
-                                         float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2) {
+                                         float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
+                                         int accumulate) {
     const int REC = GP * GP + GP + FP * GP;
     const int t = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     float s = 0.f;
@@ -793,10 +796,10 @@ __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nre
     if (t >= REC || sub) return;
     if (t < GP * GP) {
         const int j = t / GP, k = t % GP;
-        if (j < G && k < G) gW1[j * G + k] = s;
+        if (j < G && k < G) gW1[j * G + k] = accumulate ? gW1[j * G + k] + s : s;     // (later filter chunks add)
     } else if (t < GP * GP + GP) {
         const int j = t - GP * GP;
-        if (j < G) gb1[j] = s;
+        if (j < G) gb1[j] = accumulate ? gb1[j] + s : s;
     } else {
         const int u = t - GP * GP - GP, f = u / GP, k = u % GP;
         if (f < F && k < G) gW2[(size_t)f * G + k] = s;
@@ -892,16 +895,26 @@ int shape_ok(const MdgFilterNet* net, int& GP, int& FT) {
     MDG_CHECK_ARG(net && net->mu && net->coef && net->W1 && net->b1 && net->W2 && net->b2, "cfconv: null filter weights");
     const int G = net->n_gauss, F = net->n_filters;
     MDG_CHECK_ARG(G >= 1 && G <= 64, "cfconv: 1 <= n_gaussians <= 64 (got %d)", G);
-    MDG_CHECK_ARG(F >= 4 && F <= 128 && F % (F <= 64 ? 4 : 8) == 0,
-                  "cfconv: n_filters must be a multiple of 4 up to 64 or of 8 up to 128 (got %d)", F);
+    MDG_CHECK_ARG(mdg_cfconv_supported(G, F),
+                  "cfconv: n_filters must be a multiple of 4 up to 64, of 8 up to 128, or of 128 up to 512 (got %d)", F);
     GP = G <= 32 ? 32 : 64;
     FT = F <= 64 ? 4 : 8;
     return MDG_OK;
 }
 
-FilterDev dev_of(const MdgFilterNet* net) {
-    return FilterDev{net->mu, net->coef, net->W1, net->b1, net->W2, net->b2, net->n_gauss, net->n_filters};
+// Layers wider than 128 filters run as chunks of 128: W(d) is a per-filter function, so chunk c of the output
+// (columns 128 c ...) needs rows 128 c ... of W2 / b2 and the same columns of the node rows -- one launch per chunk with
+// offset pointers and the full row stride (layer 1 of the filter network is recomputed per chunk); the adjoints are linear
+// in the filter adjoint rows, so the reverse sweep adds the chunks up (d_b / dd_b in place, gW1 / gb1 in the reduce).
+constexpr int F_CHUNK = 128;
+
+FilterDev dev_of(const MdgFilterNet* net, int f0) {
+    const int F = net->n_filters, fc = F - f0 < F_CHUNK ? F - f0 : F_CHUNK;
+    return FilterDev{net->mu, net->coef, net->W1, net->b1, net->W2 + (size_t)f0 * net->n_gauss, net->b2 + f0, net->n_gauss, fc, F};
 }
+
+inline const float* at_col(const float* p, int f0) { return p ? p + f0 : nullptr; }
+inline float* at_col(float* p, int f0) { return p ? p + f0 : nullptr; }
 
 int bwd_blocks(long long n_edges, bool theta) {
     const long long tiles = (n_edges + 63) / 64;
@@ -912,8 +925,9 @@ int bwd_blocks(long long n_edges, bool theta) {
 }  // namespace
 
 extern "C" int mdg_cfconv_supported(int n_gauss, int n_filters) {
-    return n_gauss >= 1 && n_gauss <= 64 && n_filters >= 4 && n_filters <= 128 &&
-           n_filters % (n_filters <= 64 ? 4 : 8) == 0;
+    if (n_gauss < 1 || n_gauss > 64 || n_filters < 4) return 0;
+    if (n_filters <= 128) return n_filters % (n_filters <= 64 ? 4 : 8) == 0;
+    return n_filters <= 512 && n_filters % 128 == 0;          // chunks of 128 filters per launch (csrc/cfconv_fused.hip)
 }
 
 extern "C" int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
@@ -950,9 +964,11 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd: tangent buffers without dd");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd: node feature matrices must be 16-byte aligned");
-    FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
     const int most = (n_atoms + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
+    for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
+    FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
+              at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
 #define MDG_FWD1(GP_, FT_, T_, S_)                                                                                 \
     do {                                                                                                           \
         const size_t lds = fwd_lds_bytes<GP_, FT_>(T_);                                                            \
@@ -970,6 +986,7 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     else MDG_FWD(64, 8);
 #undef MDG_FWD
 #undef MDG_FWD1
+    }
     MDG_CHECK_LAUNCH("cfconv_fwd_kernel");
     return MDG_OK;
 }
@@ -987,9 +1004,11 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd_bf16: tangent buffers without dd");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd_bf16: node feature matrices must be 16-byte aligned");
-    FwdArgs a{dev_of(net), d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum};
     const int most = (n_atoms + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
+    for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
+    FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
+              at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
 #define MDG_FWDB1(GP_, FT_, T_, S_)                                                                                \
     do {                                                                                                           \
         const size_t lds = fwd_bf16_lds_bytes<GP_, FT_>(T_);                                                       \
@@ -1007,6 +1026,7 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     else MDG_FWDB(64, 8);
 #undef MDG_FWDB
 #undef MDG_FWDB1
+    }
     MDG_CHECK_LAUNCH("cfconv_fwd_bf16_kernel");
     return MDG_OK;
 }
@@ -1043,9 +1063,11 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(!theta || workspace, "cfconv_bwd: workspace missing");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb),
                   "cfconv_bwd: node feature matrices must be 16-byte aligned");
-    BwdArgs a{dev_of(net), d, dd, nbr, (long long)n_edges, h, hd, mb, mdb, d_b, dd_b, workspace, n_valid};
-    int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
     const long long tiles64 = (n_edges + 63) / 64;
+    for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
+    BwdArgs a{dev_of(net, f0), d, dd, nbr, (long long)n_edges, at_col(h, f0), at_col(hd, f0), at_col(mb, f0), at_col(mdb, f0),
+              d_b, dd_b, workspace, n_valid};
+    int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
 #define MDG_BWD(GP_, FT_)                                                                                          \
     do {                                                                                                           \
         if (theta) {                                                                                               \
@@ -1074,8 +1096,9 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     if (theta) {
         const int FP = 16 * FT, REC = GP * GP + GP + FP * GP;
         hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC * 4 + 255) / 256), dim3(256), 0, st, workspace, nb, GP, FP,
-                           net->n_gauss, net->n_filters, gW1, gb1, gW2);
+                           net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, f0 > 0 ? 1 : 0);
         MDG_CHECK_LAUNCH("cfconv_bwd_reduce_kernel");
+    }
     }
     return MDG_OK;
 }

@@ -9,7 +9,8 @@
 // One launch serves up to two inputs that share the weight (DUAL): the primal rows and their forward-mode tangent
 // (z1 = x1 B ; out1 = act'(z0) z1 (+ res1)), or the two adjoints of the dual reverse sweep -- one set of B
 // fragments from LDS feeds both accumulator sets.  v_mfma_f32_16x16x4_f32 (exact f32): persistent workgroups
-// stage one chunk of <= 128 output columns of the weight (all k <= 256) in LDS once and walk 64-row tiles (16 rows
+// stage one chunk of <= 128 output columns of the weight (k <= 256 per launch; wider layers run as k-slabs that
+// hand their partial sums on through the output buffer) in LDS once and walk 64-row tiles (16 rows
 // per wave); LDS rows are permuted so that the A operand is gathered as 16-byte vectors (k-step 4 q + c of a
 // 64-chunk <-> k = 16 q + 4 lk + c).
 #include "common.hpp"
@@ -30,6 +31,7 @@ struct DenseProb {
     const float* res;    // [N, M] or null
     float* out;          // [N, M]
     float* sig;          // [N, M] or null     (row 0, act == 1)
+    const float* pre;    // [N, M] or null: added to z before bias / activation (the partial sums of earlier k chunks)
 };
 
 struct DenseArgs {
@@ -37,19 +39,20 @@ struct DenseArgs {
     const float* W;
     int trans;           // 0: B[k][m] = W[m*K + k] ; 1: B[k][m] = W[k*M + m]
     int act;             // 0 identity, 1 shifted softplus: out0 = ssp(z0), sig0 = sigmoid(z0), out1 = sigmoid(z0) z1
-    int N, K, M;
+    int N, K, M;         // K: the k range of THIS launch (<= 256)
+    int ldx, ldw;        // floats per row of x and (trans = 0) of W: the layer's full k
 };
 
-__device__ __forceinline__ void load_a(const float* __restrict__ x, int arow, bool aok, int K, bool vec, int kc, int lk,
+__device__ __forceinline__ void load_a(const float* __restrict__ x, int arow, bool aok, int K, int ldx, bool vec, int kc, int lk,
                                        float (&af)[16]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int k0 = kc + 16 * q + 4 * lk;
         float4 v = {0.f, 0.f, 0.f, 0.f};
         if (aok) {
-            if (vec && k0 + 4 <= K) v = *reinterpret_cast<const float4*>(x + (size_t)arow * K + k0);
+            if (vec && k0 + 4 <= K) v = *reinterpret_cast<const float4*>(x + (size_t)arow * ldx + k0);
             else {
-                const float* px = x + (size_t)arow * K;
+                const float* px = x + (size_t)arow * ldx;
                 if (k0 < K) v.x = px[k0];
                 if (k0 + 1 < K) v.y = px[k0 + 1];
                 if (k0 + 2 < K) v.z = px[k0 + 2];
@@ -79,14 +82,14 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
         const int col = NT ? (m % NT) * 16 + m / NT : m;
         bs[prow * DN_SB + col] = v;
     };
-    if (!A.trans && (A.K & 3) == 0) {
+    if (!A.trans && (A.K & 3) == 0 && (A.ldw & 3) == 0) {
         // Linear layout W[m][k]: 16-byte loads along k, several in flight
         const int kq = Kpad >> 2;
 #pragma unroll 4
         for (int t = tid; t < kq * Mp; t += 256) {
             const int m = t / kq, k = (t % kq) * 4;
             float4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < A.K && m < Mc) v = *reinterpret_cast<const float4*>(A.W + (size_t)(m_lo + m) * A.K + k);
+            if (k < A.K && m < Mc) v = *reinterpret_cast<const float4*>(A.W + (size_t)(m_lo + m) * A.ldw + k);
             put(k, m, v.x); put(k + 1, m, v.y); put(k + 2, m, v.z); put(k + 3, m, v.w);
         }
     } else {
@@ -95,12 +98,12 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
             int k, m;
             if (A.trans) { k = t / Mp; m = t % Mp; } else { m = t / Kpad; k = t % Kpad; }
             float v = 0.f;
-            if (k < A.K && m < Mc) v = A.trans ? A.W[(size_t)k * A.M + m_lo + m] : A.W[(size_t)(m_lo + m) * A.K + k];
+            if (k < A.K && m < Mc) v = A.trans ? A.W[(size_t)k * A.M + m_lo + m] : A.W[(size_t)(m_lo + m) * A.ldw + k];
             put(k, m, v);
         }
     }
     __syncthreads();
-    const bool vec = (A.K & 3) == 0;
+    const bool vec = (A.K & 3) == 0 && (A.ldx & 3) == 0;
     const int row_tiles = (A.N + 63) >> 6;
     constexpr int TT = NT ? NT : DN_MC / 16;
     for (int tile = blockIdx.x; tile < row_tiles; tile += gridDim.x) {
@@ -115,8 +118,8 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
         }
         for (int kc = 0; kc < A.K; kc += DN_KC) {
             float a0[16], a1[16];
-            load_a(P0.x, arow, aok, A.K, vec, kc, lk, a0);
-            if (DUAL) load_a(P1.x, arow, aok, A.K, vec, kc, lk, a1);
+            load_a(P0.x, arow, aok, A.K, A.ldx, vec, kc, lk, a0);
+            if (DUAL) load_a(P1.x, arow, aok, A.K, A.ldx, vec, kc, lk, a1);
             const float* bk = bs + (size_t)kc * DN_SB;
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
@@ -142,10 +145,19 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
                 if (row >= A.N) continue;
                 const size_t o = (size_t)row * A.M + mb;
                 float z[NT], z1[NT], sg[NT];
+                float pz[NT], pz1[NT];
+#pragma unroll
+                for (int v = 0; v < NT / 4; ++v) {
+                    float4 q = {0.f, 0.f, 0.f, 0.f}, q1 = q;
+                    if (P0.pre) q = *reinterpret_cast<const float4*>(P0.pre + o + 4 * v);
+                    if (DUAL && P1.pre) q1 = *reinterpret_cast<const float4*>(P1.pre + o + 4 * v);
+                    pz[4 * v] = q.x; pz[4 * v + 1] = q.y; pz[4 * v + 2] = q.z; pz[4 * v + 3] = q.w;
+                    pz1[4 * v] = q1.x; pz1[4 * v + 1] = q1.y; pz1[4 * v + 2] = q1.z; pz1[4 * v + 3] = q1.w;
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    z[t] = acc0[t][r] + bv[t];
-                    z1[t] = DUAL ? acc1[t][r] : 0.f;
+                    z[t] = acc0[t][r] + pz[t] + bv[t];
+                    z1[t] = DUAL ? acc1[t][r] + pz1[t] : 0.f;
                     if (A.act == 1) {
                         const float ex = __builtin_amdgcn_exp2f(z[t] * LOG2E_D);
                         const bool big = z[t] > 20.f;
@@ -191,8 +203,8 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
                     const int row = row0 + 4 * lk + r;
                     if (row >= A.N) continue;
                     const size_t o = (size_t)row * A.M + m_lo + m;
-                    float z = acc0[t][r] + b0;
-                    float z1 = DUAL ? acc1[t][r] : 0.f;
+                    float z = acc0[t][r] + (P0.pre ? P0.pre[o] : 0.f) + b0;
+                    float z1 = DUAL ? acc1[t][r] + (P1.pre ? P1.pre[o] : 0.f) : 0.f;
                     if (A.act == 1) {
                         const float ex = __builtin_amdgcn_exp2f(z * LOG2E_D);
                         const bool big = z > 20.f;
@@ -220,26 +232,36 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
 extern "C" int mdg_dense(const float* W, int trans, int act, int n_rows, int k, int m,
                          const float* x0, const float* bias0, const float* mul0, const float* res0, float* out0,
                          float* sig0, const float* x1, const float* res1, float* out1, void* stream) {
-    MDG_CHECK_ARG(n_rows >= 0 && k > 0 && k <= 256 && m > 0, "dense: bad sizes (1 <= k <= 256)");
+    MDG_CHECK_ARG(n_rows >= 0 && k > 0 && m > 0, "dense: bad sizes");
     if (n_rows == 0) return MDG_OK;
     MDG_CHECK_ARG(W && x0 && out0 && (!x1 || out1), "dense: null buffer");
     MDG_CHECK_ARG(act == 0 || act == 1, "dense: act must be 0 (identity) or 1 (shifted softplus)");
     MDG_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, "dense: inputs must be 16-byte aligned");
-    DenseArgs a{};
-    a.p[0] = DenseProb{x0, bias0, mul0, res0, out0, sig0};
-    a.p[1] = DenseProb{x1, nullptr, nullptr, res1, out1, nullptr};
-    a.W = W; a.trans = trans; a.act = act; a.N = n_rows; a.K = k; a.M = m;
     const int row_tiles = (n_rows + 63) / 64;
     dim3 grid(row_tiles < 256 ? row_tiles : 256, (m + DN_MC - 1) / DN_MC);
-    const size_t lds = sizeof(float) * (size_t)((k + DN_KC - 1) / DN_KC * DN_KC) * DN_SB;
     // 16-byte epilogue when every column chunk is 64 or 128 wide and all row pointers are 16-byte aligned
     const uintptr_t al = (uintptr_t)mul0 | (uintptr_t)res0 | (uintptr_t)out0 | (uintptr_t)sig0 | (uintptr_t)res1 |
                          (uintptr_t)out1 | (uintptr_t)bias0;
     const int nt = ((al & 15) == 0 && m % 64 == 0 && (m <= DN_MC ? true : m % DN_MC == 0)) ? (m >= DN_MC ? 8 : 4) : 0;
     hipStream_t st = (hipStream_t)stream;
+    // The weight chunk of a launch (<= 128 output columns x all its k) lives in LDS, which holds k <= 256: wider layers
+    // (n_atom_basis / n_filters 512, demo/fit_rdf_gnn.py:16-19) run as k-slabs of 256 -- the earlier slabs leave their partial
+    // sums z in out0 / out1, the last one adds them before bias and activation (`pre`).
+    constexpr int DN_KMAX = 256;
+    for (int k0 = 0; k0 < k; k0 += DN_KMAX) {
+        const int kc = k - k0 < DN_KMAX ? k - k0 : DN_KMAX;
+        const bool first = k0 == 0, last = k0 + kc >= k;
+        DenseArgs a{};
+        a.p[0] = DenseProb{x0 + k0, last ? bias0 : nullptr, last ? mul0 : nullptr, last ? res0 : nullptr, out0, last ? sig0 : nullptr,
+                           first ? nullptr : out0};
+        a.p[1] = DenseProb{x1 ? x1 + k0 : nullptr, nullptr, nullptr, last ? res1 : nullptr, out1, nullptr, first ? nullptr : out1};
+        a.W = trans ? W + (size_t)k0 * m : W + k0;
+        a.trans = trans; a.act = last ? act : 0; a.N = n_rows; a.K = kc; a.M = m; a.ldx = k; a.ldw = k;
+        const size_t lds = sizeof(float) * (size_t)((kc + DN_KC - 1) / DN_KC * DN_KC) * DN_SB;
 #define MDG_DENSE(D_, N_) hipLaunchKernelGGL((dense_kernel<D_, N_>), grid, dim3(256), lds, st, a)
-    if (x1) { if (nt == 8) MDG_DENSE(true, 8); else if (nt == 4) MDG_DENSE(true, 4); else MDG_DENSE(true, 0); }
-    else { if (nt == 8) MDG_DENSE(false, 8); else if (nt == 4) MDG_DENSE(false, 4); else MDG_DENSE(false, 0); }
+        if (x1) { if (nt == 8) MDG_DENSE(true, 8); else if (nt == 4) MDG_DENSE(true, 4); else MDG_DENSE(true, 0); }
+        else { if (nt == 8) MDG_DENSE(false, 8); else if (nt == 4) MDG_DENSE(false, 4); else MDG_DENSE(false, 0); }
+    }
 #undef MDG_DENSE
     MDG_CHECK_LAUNCH("dense_kernel");
     return MDG_OK;

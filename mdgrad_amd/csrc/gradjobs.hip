@@ -7,10 +7,11 @@
 // gradients that cfconv_bwd already reduced.  Issued one by one they were ~50 launches per evaluation (split-K product +
 // reduce per weight, torch reductions / cat / neg / scale / add for the rest); here ALL of them are TWO launches:
 //
-//   grad_partial_kernel   every (job, unit, K-slab) on its own wave: products on v_mfma_f32_16x16x4_f32 with 16-byte
-//                         operand loads (a lane's float4 feeds four 16x16 tiles: the k index of an MFMA operand is the
-//                         row of the tall matrix, the 16 "column" lanes take 4 consecutive floats each), column sums by
-//                         row-strided float4 reads + an ordered LDS combine; partial results to a workspace;
+//   grad_partial_kernel   every (job, 64 x 64 unit, K-slab) on its own workgroup: products on v_mfma_f32_16x16x4_f32 with
+//                         16-byte operand loads (a lane's float4 feeds four 16x16 tiles: the k index of an MFMA operand
+//                         is the row of the tall matrix, the 16 "column" lanes take 4 consecutive floats each), the four
+//                         waves interleave the slab's rows and combine in LDS; column sums by row-strided float4 reads +
+//                         an ordered LDS combine; partial results to a workspace;
 //   grad_reduce_kernel    fixed-order sum over the slabs and  flat[dst] (+)= alpha * (t[i] - t[i-1]) * value: the
 //                         interval weight of sovlers.py:160 is read on the device, the destination is the caller's flat
 //                         gradient buffer in nn.Module.parameters() order (tinydiffeq.py:106-108).
@@ -46,78 +47,81 @@ __device__ __forceinline__ f32x4 load4(const float* __restrict__ p, long long ro
     return v;
 }
 
-// One wave: C[64 x 64 NJ] block of A^T B over rows [k0, k1).  Tile (c; j, c2): rows m = m0 + 4 i + c, columns
-// n = n0 + 64 j + 4 i2 + c2 (i, i2 = the MFMA's 16 row / column lanes).
-template <int NJ>
-__device__ __forceinline__ void atb_wave(const MdgGradJob& J, int m0, int n0, long long k0, long long k1, float* __restrict__ out) {
+// One wave: its share of C[64 x 64] = A[:, m0:m0+64]^T B[:, n0:n0+64] over the rows k0 + 4 (4 i + w) + {0..3}, i = 0, 1, ...
+// (the four waves of a workgroup interleave 4-row steps of the workgroup's K-slab).  Tile (c, c2): rows m = m0 + 4 i + c,
+// columns n = n0 + 4 i2 + c2 (i, i2 = the MFMA's 16 row / column lanes), so a lane's float4 loads feed four tiles each.
+// Two steps of loads are in flight while the 16 MFMAs of the current one run.
+__device__ __forceinline__ void atb_wave(const MdgGradJob& J, int m0, int n0, long long k0, long long k1, int w, f32x4 (&acc)[4][4]) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     const int M = J.m, N = J.n;
-    f32x4 acc[4][NJ][4];
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int c2 = 0; c2 < 4; ++c2) acc[c][j][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c2 = 0; c2 < 4; ++c2) acc[c][c2] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int pass = 0; pass < (J.A2 ? 2 : 1); ++pass) {
         const float* __restrict__ Ap = pass ? J.A2 : J.A;
         const float* __restrict__ Bp = pass ? J.B2 : J.B;
-        f32x4 a = load4(Ap, k0 + lk, M, m0 + 4 * li, k0 + lk < k1);
-        f32x4 b[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = load4(Bp, k0 + lk, N, n0 + 64 * j + 4 * li, k0 + lk < k1);
-        for (long long k = k0; k < k1; k += 4) {
-            const long long rn = k + 4 + lk;                     // next step's rows are in flight during the MFMAs
-            const f32x4 an = load4(Ap, rn, M, m0 + 4 * li, rn < k1);
-            f32x4 bn[NJ];
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) bn[j] = load4(Bp, rn, N, n0 + 64 * j + 4 * li, rn < k1);
+        const long long kw = k0 + 4 * w;                          // the wave's step 0 (uniform); this lane's row: + lk
+        f32x4 a0 = load4(Ap, kw + lk, M, m0 + 4 * li, kw + lk < k1), b0 = load4(Bp, kw + lk, N, n0 + 4 * li, kw + lk < k1);
+        f32x4 a1 = load4(Ap, kw + 16 + lk, M, m0 + 4 * li, kw + 16 + lk < k1);
+        f32x4 b1 = load4(Bp, kw + 16 + lk, N, n0 + 4 * li, kw + 16 + lk < k1);
+        for (long long kb = kw; kb < k1; kb += 16) {              // (uniform trip count over the wave: rows are masked)
+            const long long r2 = kb + 32 + lk;
+            const f32x4 a2 = load4(Ap, r2, M, m0 + 4 * li, r2 < k1), b2 = load4(Bp, r2, N, n0 + 4 * li, r2 < k1);
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                    for (int c2 = 0; c2 < 4; ++c2)
-                        acc[c][j][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b[j][c2], acc[c][j][c2], 0, 0, 0);
-            a = an;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) b[j] = bn[j];
+                for (int c2 = 0; c2 < 4; ++c2)
+                    acc[c][c2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[c], b0[c2], acc[c][c2], 0, 0, 0);
+            a0 = a1; b0 = b1; a1 = a2; b1 = b2;
         }
     }
-    // accumulator layout: column lane = lane & 15, row = (lane >> 4) * 4 + r
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + 4 * (lk * 4 + r) + c;
-            if (m >= M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int c2 = 0; c2 < 4; ++c2) {
-                    const int n = n0 + 64 * j + 4 * li + c2;
-                    if (n < N) out[(size_t)m * N + n] = acc[c][j][c2][r];
-                }
-        }
 }
 
 __global__ __launch_bounds__(256) void grad_partial_kernel(const JobTable T, float* __restrict__ ws) {
-    __shared__ f32x4 red[256];
+    __shared__ __attribute__((aligned(16))) float atb_red[3 * 16 * 64 * 4];        // 48 KB: three waves' accumulators
+    f32x4* red = reinterpret_cast<f32x4*>(atb_red);                                  // (column sums: 256 x float4)
     int k = 0;
     while (k + 1 < T.n_jobs && (int)blockIdx.x >= T.first_block[k + 1]) ++k;
     const MdgGradJob& J = T.j[k];
     const int local = (int)blockIdx.x - T.first_block[k];
     const int wid = threadIdx.x >> 6;
     if (J.kind == MDG_GRAD_ATB) {
-        const int units_n = (J.n + 127) / 128, units = ((J.m + 63) / 64) * units_n;
-        const int wave = local * 4 + wid;
-        const int unit = wave % units, split = wave / units;
-        if (split >= T.splits[k]) return;
+        // one workgroup = one (64 x 64 unit, K-slab): the four waves take interleaved 4-row steps of the slab, their
+        // accumulators are combined through LDS in wave order, wave 0 writes the partial block
+        const int units_n = (J.n + 63) / 64, units = ((J.m + 63) / 64) * units_n;
+        const int unit = local % units, split = local / units;
         const long long k0 = (long long)split * T.slab[k], k1 = min(J.rows, k0 + T.slab[k]);
-        const int m0 = (unit / units_n) * 64, n0 = (unit % units_n) * 128;
+        const int m0 = (unit / units_n) * 64, n0 = (unit % units_n) * 64;
+        f32x4 acc[4][4];
+        atb_wave(J, m0, n0, k0, k1, wid, acc);
+        const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+        f32x4* buf = reinterpret_cast<f32x4*>(atb_red);           // [3 waves][16 tiles][64 lanes]
+        if (wid > 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) buf[((wid - 1) * 16 + c * 4 + c2) * 64 + lane] = acc[c][c2];
+        }
+        __syncthreads();
+        if (wid != 0) return;
         float* out = ws + T.ws_off[k] + (size_t)split * J.m * J.n;
-        if (J.n - n0 > 64) atb_wave<2>(J, m0, n0, k0, k1, out);
-        else atb_wave<1>(J, m0, n0, k0, k1, out);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                f32x4 v = acc[c][c2];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v += buf[(q * 16 + c * 4 + c2) * 64 + lane];
+                const int n = n0 + 4 * li + c2;
+                if (n >= J.n) continue;
+                // accumulator layout: column lane = lane & 15, row = (lane >> 4) * 4 + r
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + 4 * (lk * 4 + r) + c;
+                    if (m < J.m) out[(size_t)m * J.n + n] = v[r];
+                }
+            }
         return;
     }
     // column sums of A (.* B) (+ A2 .* B2) over the block's row slab: a thread owns 4 consecutive columns, the block's
@@ -185,6 +189,9 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const JobTable T, cons
 int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) {
     if (n_jobs < 0 || n_jobs > MDG_GRAD_JOBS_MAX) { mdg_set_error("grad_jobs: at most %d jobs per call", MDG_GRAD_JOBS_MAX); return MDG_EINVAL; }
     T.n_jobs = n_jobs;
+    int n_atb = 0;
+    for (int k = 0; k < n_jobs; ++k) n_atb += jobs[k].kind == MDG_GRAD_ATB;
+    const int atb_budget = 1536 / (n_atb > 0 ? n_atb : 1);
     long long ws = 0;
     int blocks = 0, outs = 0;
     for (int k = 0; k < n_jobs; ++k) {
@@ -202,19 +209,19 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
         }
         if (J.kind == MDG_GRAD_ATB) {
             if (J.n <= 0 || !J.B) { mdg_set_error("grad_jobs: job %d: a product needs B and n > 0", k); return MDG_EINVAL; }
-            const int units = ((J.m + 63) / 64) * ((J.n + 127) / 128);
-            long long want = (2048 + units - 1) / units;                 // ~2048 waves in flight over all jobs' units
-            const long long maxs = (J.rows + 63) / 64;                   // at least 64 rows per slab
+            const int units = ((J.m + 63) / 64) * ((J.n + 63) / 64);
+            long long want = (atb_budget + units - 1) / units;            // workgroups of this job: its share of ~2 rounds of the chip
+            const long long maxs = (J.rows + 255) / 256;                 // at least 256 rows (16 steps per wave) per slab
             if (want > maxs) want = maxs;
             if (want < 1) want = 1;
             if (want > 512) want = 512;
             long long slab = (J.rows + want - 1) / want;
-            slab = (slab + 3) / 4 * 4;
-            if (slab < 4) slab = 4;
+            slab = (slab + 15) / 16 * 16;
+            if (slab < 16) slab = 16;
             const int splits = (int)((J.rows + slab - 1) / slab > 0 ? (J.rows + slab - 1) / slab : 1);
             T.splits[k] = splits;
             T.slab[k] = slab;
-            blocks += (units * splits + 3) / 4;
+            blocks += units * splits;
             ws += (long long)splits * J.m * J.n;
             outs += (J.m * J.n + 63) / 64 * 64;
         } else if (J.kind == MDG_GRAD_COLSUM) {

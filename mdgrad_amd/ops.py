@@ -1237,7 +1237,7 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
     return (gW1, gb1, gW2) if want_theta else None
 
 
-DENSE_MAX_K = 256
+DENSE_MAX_K = 4096       # (k > 256 runs as k-slabs of 256 inside mdg_dense)
 
 
 def dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None, res1=None, want_sig=False):

@@ -274,7 +274,8 @@ def test_grad_jobs_batched_parameter_gradient_reductions():
     params += [torch.nn.Parameter(torch.zeros(c, device=DEV)) for c in (128, 64, 30, 1, 257)]
     emb = torch.nn.Parameter(torch.zeros(100, 64, device=DEV))
     pre = [torch.nn.Parameter(torch.zeros(30, 30, device=DEV)), torch.nn.Parameter(torch.zeros(30, device=DEV))]
-    allp = params + [emb] + pre
+    more = [torch.nn.Parameter(torch.zeros(30, device=DEV)) for _ in range(20)]      # (a destination appears once per call)
+    allp = params + [emb] + pre + more
     t = torch.tensor([0.0, 0.3, 0.7, 1.5], device=DEV)
     idx = torch.tensor([2], dtype=torch.int64, device=DEV)
     outs = []
@@ -316,10 +317,10 @@ def test_grad_jobs_batched_parameter_gradient_reductions():
             g = rnd(*p.shape)
             jobs.axpy(acc.off[id(p)], g)
             want[id(p)] = g.double()
-        for extra in range(20):                                   # second chunk (> 32 jobs per evaluation)
+        for p in more:                                            # second chunk (> 32 jobs per evaluation)
             g = rnd(30)
-            jobs.axpy(acc.off[id(pre[1])], g)
-            want[id(pre[1])] = want[id(pre[1])] + g.double()
+            jobs.axpy(acc.off[id(p)], g)
+            want[id(p)] = g.double()
         assert len(jobs.jobs) > 32
         jobs.run(acc, alpha=-1.0, accumulate=True)
         ref = base.clone()
