@@ -57,6 +57,51 @@ def _profile_json(name):
         return None
 
 
+# which source files a kernel's code comes from: counters are refused when one of them changed since they were collected
+_KERNEL_SOURCES = (("traj_", ("traj_ring.hpp", "traj_small.hip", "common.hpp")), ("large_", ("traj_large.hip", "common.hpp")),
+                   ("rdf_cell", ("rdf_cell.hip", "common.hpp")), ("rdf_", ("rdf.hip", "common.hpp")),
+                   ("cfconv_", ("cfconv_fused.hip",)), ("dense_", ("dense.hip",)), ("grad_", ("gradjobs.hip",)),
+                   ("nbr_", ("nbr.hip", "common.hpp")))
+
+
+def _source_sha(fname):
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, "mdgrad_amd", "csrc", fname), "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def _counters(workload, kernel_prefix):
+    """The rocprofv3 counter record (profiles/pmc_<workload>.json, tools/pmc_collect.py) of the kernel whose name starts
+    with `kernel_prefix` -- the instance with the largest share of the pass -- or (None, reason): no record, or a record
+    collected from different kernel sources than the ones in the tree (stamped per file; VERDICT r2 weak #9)."""
+    pj = _profile_json("pmc_%s.json" % workload)
+    if not pj:
+        return None, "no profiles/pmc_%s.json" % workload
+    hit = [(k, r) for k, r in pj["kernels"].items() if k.startswith(kernel_prefix)]
+    if not hit:
+        return None, "kernel %s not in profiles/pmc_%s.json" % (kernel_prefix, workload)
+    name, rec = max(hit, key=lambda kr: kr[1]["share"])
+    for pre, files in _KERNEL_SOURCES:
+        if name.startswith(pre):
+            stale = [f for f in files if pj.get("sources", {}).get(f) != _source_sha(f)]
+            if stale:
+                return None, "stale counters: %s changed since profiles/pmc_%s.json was collected" % (", ".join(stale), workload)
+            break
+    rec = dict(rec, name=name)
+    return rec, None
+
+
+def _pass_traffic(workload, passes):
+    """HBM bytes per pass summed over every profiled kernel (calls x bytes per launch / passes of the profiled run)."""
+    pj = _profile_json("pmc_%s.json" % workload)
+    if not pj:
+        return None
+    tot = sum(r["calls"] * r["hbm_bytes_per_launch"] for r in pj["kernels"].values() if "hbm_bytes_per_launch" in r)
+    return tot / passes
+
+
 def _dist_record(mdist, dev, params, ms_rank):
     """Evidence that the N ranks ran and met in the collective (VERDICT r2 #1): backend, ranks counted by an
     all-reduce of ones, the time of one all-reduce of the flat-gradient-sized buffer, every rank's ms per pass."""
@@ -267,18 +312,17 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
     useful = FLOP_PER_PAIR_RING * Pn * 2.0 * intervals
     executed = FLOP_PER_PAIR_RING * ring_ops * 128.0 * 2.0 * intervals
     bytes_adj = (48 * Pn + 208 * N) * intervals                    # 2 B_H + B_A + 2 B_N per step
-    pj = _profile_json("pmc_traffic.json")
-    traffic = None
     kname = "traj_adj_ring_kernel"
-    if pj and pj.get(kname, {}).get("frames") == T:
-        traffic = pj[kname]["hbm_bytes_per_replica"] * R
-    issue = _profile_json("pmc_issue.json") or {}
+    # counters of the same launch (16 384 replicas, 50 frames, observable fused in), refused when the kernel source changed
+    cnt, why = _counters("lj108", "traj_adj_ring_kernel<true") if (R == 16384 and T == 50 and fused) else (None, "other geometry")
+    traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
     sec = adj_ms * 1e-3
     out["roofline"] = {
         "bound": "valu", "kernel": kname, "achieved": useful / sec / 1e12, "peak": VEC_F32_PEAK_TF,
         "unit": "TFLOP/s", "frac": useful / sec / 1e12 / VEC_F32_PEAK_TF, "traffic": traffic, "kernel_ms": adj_ms,
         "executed_tflops": executed / sec / 1e12, "executed_frac": executed / sec / 1e12 / VEC_F32_PEAK_TF,
-        "valu_busy": issue.get(kname, {}).get("valu_busy"),
+        "valu_busy": cnt.get("valu_busy") if cnt else None, "wait_frac": cnt.get("wait_frac") if cnt else None,
+        "counters": ("profiles/pmc_lj108.json: %s, %.1f us under rocprofv3" % (cnt["name"], cnt["avg_us"])) if cnt else why,
         "hbm_frac_measured": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None,
         "hbm_frac_algorithmic": bytes_adj / sec / 1e9 / HBM_PEAK_GBS,
         "algorithmic_bytes_per_launch": bytes_adj,
@@ -286,7 +330,7 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
                 "evaluations x %d intervals; executed_* = the %d packed pair operations x 128 slots the ring issues per "
                 "evaluation (N(N-1)/2 = %d pairs, 10 of 64 lanes own no atom).  hbm_frac_algorithmic prices SURVEY 8d's "
                 "bytes of the unfused op chain (48P+208N per step) against 8 TB/s; the state lives in registers, so the "
-                "measured HBM traffic (frame + frame-gradient loads, profiles/pmc_traffic.json) is ~40x lower" % (
+                "measured HBM traffic (frame + frame-gradient loads, profiles/pmc_lj108.json) is ~40x lower" % (
                     FLOP_PER_PAIR_RING, Pn, intervals, ring_ops, N * (N - 1) // 2)}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_lj108(T, args.dt, check)
@@ -742,17 +786,40 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     sec_per_step = el / md_steps * world
     # per MD step + adjoint interval: one force sweep (40 flop per directed pair) and two force + Hessian.w sweeps (70)
     useful = (40.0 + 2.0 * FLOP_PER_PAIR_ADJ) * 2.0 * Pn / sec_per_step
-    out["roofline"] = {"bound": "hbm", "kernel": "large_adj_listed / large_fwd_listed / large_force_step (whole step)",
+    # counters of the same workload (profiles/pmc_lj4096.json, 64 replicas x 51 frames): HBM bytes of a whole pass summed over
+    # its kernels, and the issue-side picture of the kernel with the largest share of the pass
+    std = R == 64 and T == 51
+    dom, why = _counters("lj4096", "large_adj_listed") if std else (None, "other geometry")
+    pj = _profile_json("pmc_lj4096.json") if std else None
+    traffic = _pass_traffic("lj4096", 3) if (dom is not None) else None     # (the profiled run: 1 warm-up + 2 timed passes)
+    B_H = (12.0 * Pn + 48.0 * N) * R                                        # fused force + Hessian.w sweep, per launch
+    dominant = None
+    if dom is not None:
+        sec_k = dom["avg_us"] * 1e-6
+        dominant = {"kernel": dom["name"], "share_of_pass": dom["share"], "avg_us_rocprof": dom["avg_us"],
+                    "algorithmic_bytes_per_launch": B_H, "algorithmic_gbs": B_H / sec_k / 1e9,
+                    "algorithmic_frac_of_hbm_peak": B_H / sec_k / 1e9 / HBM_PEAK_GBS,
+                    "hbm_bytes_per_launch_measured": dom.get("hbm_bytes_per_launch"), "hbm_gbs_measured": dom.get("hbm_gbs"),
+                    "valu_busy": dom.get("valu_busy"), "wait_frac": dom.get("wait_frac"), "vgpr": dom.get("vgpr"),
+                    "binding": "VALU issue: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x duration x 2.4 GHz) = %.2f; its measured HBM "
+                               "traffic is %.2f x the algorithmic bytes (no wasted re-reads) at %.0f GB/s" % (
+                                   dom.get("valu_busy", float("nan")), dom.get("hbm_bytes_per_launch", float("nan")) / B_H,
+                                   dom.get("hbm_gbs", float("nan")))}
+    out["roofline"] = {"bound": "hbm", "kernel": "whole MD step (large_prep / large_search_rows / large_fwd_listed / large_adj_listed "
+                                                 "+ cell-sweep RDF)",
                        "achieved": bytes_step / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                       "frac": bytes_step / sec_per_step / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "frac": bytes_step / sec_per_step / 1e9 / HBM_PEAK_GBS,
+                       "traffic": traffic, "algorithmic_bytes_per_pass": bytes_step * R * (T - 1),
+                       "traffic_over_algorithmic": (traffic / (bytes_step * R * (T - 1))) if traffic else None,
+                       "busy_over_span_profiled": pj.get("busy_over_span") if pj else None,
+                       "dominant_kernel": dominant if dominant is not None else why,
                        "useful_tflops": useful / 1e12, "useful_frac_of_vector_peak": useful / 1e12 / VEC_F32_PEAK_TF,
                        "note": "SURVEY 8d: B_step = 60 P + 316 N bytes per MD step (P = %d half-list pairs) over the measured "
-                               "time per MD step of the whole pass; the kernels keep positions in L2/LDS and never write a "
-                               "full neighbour list, so this is the algorithmic figure of the unfused chain.  Neither roof "
-                               "binds: a searching forward launch (one step in ~7, Verlet reuse with a device-side rebuild "
-                               "decision) is bound by the instruction issue of its wave-per-atom search (~1300 instructions "
-                               "per atom, most of them candidate tests and the sort); the listed launches (four atoms per "
-                               "wave over the stored candidate lists) by VALU issue and gather latency (DESIGN.md section 4)" % Pn}
+                               "time per MD step of the whole pass.  `traffic` = HBM bytes of one pass from the FETCH_SIZE / "
+                               "WRITE_SIZE counters of every kernel of the workload (profiles/pmc_lj4096.json, refused when the "
+                               "kernel sources changed).  The pass is not bandwidth-bound: the kernel with the largest share, the "
+                               "listed force + Hessian.w sweep of the adjoint, keeps the SIMDs' VALU issue slots busy (see "
+                               "dominant_kernel); searches run one step in ~7 (Verlet reuse, device-side decision)" % Pn}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_lj4096()
         try:

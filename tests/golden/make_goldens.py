@@ -23,6 +23,7 @@ Golden sets:
   G14 gnn_traj_water192  config #3: 192-atom water, SchNet A128/F128/G32/3 conv + prior, NHC + adjoint
   G15 schnet_cg64_wide   SchNet A64/F128/G30/2 conv (config #5 widths): U, F, H.w, d(w.F)/dtheta
   G16 vacf_temp          vacf / Temperature observables      torchmd/observable.py:153-163, thermo.py:57-66
+  G17 schnet_cg64_a256   SchNet A256/F256/G41/2 conv (wide search-space setting): U, F, H.w, d(w.F)/dtheta
   G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
                                              torchmd/potentials.py:163-217, interface.py:139-215
 """
@@ -618,9 +619,42 @@ def g13():
     save("exp_rdf", r=r.astype(F32), g=g.astype(F32), x=x.astype(F32), g_obs=g_obs)
 
 
+# ------------------------------------------------------------------ G17
+def g17():
+    """SchNet at the wide settings of the reference's search space (demo/fit_rdf_gnn.py:16-19, 127-134: n_atom_basis =
+    n_filters = 256, n_gaussians = int(cutoff // gaussian_width) = 41) on the 64-bead CG box: U, F, H.w, d(w.F)/dtheta."""
+    a = 6.2148
+    pos, cell = diamond(2, a)
+    rng = np.random.default_rng(17)
+    pos = np.mod(pos + rng.normal(0, 0.3, pos.shape), cell).astype(F32).astype(np.float64)
+    numbers = np.full(len(pos), 8)
+    masses = np.full(len(pos), 18.01528)
+    system = make_system(pos, cell, numbers=numbers, masses=masses)
+    params = {"n_atom_basis": 256, "n_filters": 256, "n_gaussians": 41, "n_convolutions": 2,
+              "cutoff": 6.0, "trainable_gauss": False}
+    torch.manual_seed(17)
+    net = SchNet(params)
+    gnn = GNNPotentials(system, net, cutoff=6.0)
+    q = torch.Tensor(pos).requires_grad_(True)
+    gnn._reset_topology(q.detach())
+    U = gnn(q)
+    (gq,) = torch.autograd.grad(U.sum(), q, create_graph=True)
+    w = torch.Tensor(rng.normal(0, 1, pos.shape))
+    plist = list(net.parameters())
+    grads = torch.autograd.grad((w * -gq).sum(), [q] + plist, allow_unused=True)
+    flat = torch.cat([(g_ if g_ is not None else torch.zeros_like(p_)).reshape(-1) for g_, p_ in zip(grads[1:], plist)])
+    # the embedding table has 100 rows of which one (Z = 8) is used: keep that row only (the others are never read and
+    # their gradient is zero -- the test rebuilds the table around it)
+    sd = {"sd__" + k: v for k, v in net.state_dict().items() if k != "atom_embed.weight"}
+    save("schnet_cg64_a256", pos=pos.astype(F32), cell=cell.astype(F32), numbers=numbers, masses=masses.astype(F32),
+         n_atom_basis=256, n_filters=256, n_gaussians=41, n_convolutions=2, cutoff=6.0,
+         nbr=gnn.inputs["nbr_list"], offsets=gnn.inputs["offsets"], U=U.detach().reshape(-1), F=-gq.detach(), w=w,
+         dwF_dq=grads[0], dwF_dtheta=flat, embed_row8=net.state_dict()["atom_embed.weight"][8], **sd)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13", "g1415", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13", "g1415", "g16", "g17"]
     table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11,
-             "g12": g12, "g13": g13, "g1415": g14_g15, "g16": g16}
+             "g12": g12, "g13": g13, "g1415": g14_g15, "g16": g16, "g17": g17}
     for w in which:
         table[w]()

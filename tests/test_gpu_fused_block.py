@@ -48,7 +48,7 @@ def _close(a, b, what):
 
 
 @pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (32, 64, 6), (41, 128, 6), (64, 32, 6), (12, 8, 6),
-                                        (30, 128, 16)])
+                                        (30, 128, 16), (30, 256, 6), (41, 512, 6), (25, 384, 6)])
 def test_fused_forward_kernel_primal_and_tangent(G, F, n_side):
     from mdgrad_amd import ops
     x, topo, net = _setup(G, F, seed=G + F, n_side=n_side)
@@ -78,7 +78,7 @@ def test_fused_forward_kernel_primal_and_tangent(G, F, n_side):
 
 
 @pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (32, 64, 6), (41, 128, 6), (64, 32, 6), (12, 8, 6),
-                                        (30, 128, 16)])
+                                        (30, 128, 16), (30, 256, 6), (41, 512, 6), (25, 384, 6)])
 def test_fused_backward_kernel_plain_dual_and_theta(G, F, n_side):
     from mdgrad_amd import ops
     x, topo, net = _setup(G, F, seed=3 * G + F, n_side=n_side)
@@ -158,7 +158,45 @@ def test_fused_kernels_on_a_padded_fixed_capacity_topology():
             _close(b, a, "padded topology theta %d" % k)
 
 
-@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide"])
+@pytest.mark.parametrize("A,F,G", [(512, 512, 41), (128, 384, 12)])
+def test_widest_search_space_settings_run_on_the_fused_kernels_vs_autograd(A, F, G):
+    """demo/fit_rdf_gnn.py:16-19: n_atom_basis / n_filters up to 512.  The fused block takes them (filters in chunks of
+    128, Dense layers in k-slabs of 256): force, d(w.F)/dx and the 1.9 M-entry d(w.F)/dtheta against the autograd path
+    (double backward through SchNet.forward) on a 64-bead box."""
+    from mdgrad_amd import ops
+    from mdgrad_amd.interface import GNNPotentials
+    from mdgrad_amd.nn import get_model, analytic
+    assert ops.FilterNet.supported(G, F)
+    g = load_golden("schnet_cg64_wide")
+    system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    torch.manual_seed(A + F)
+    net = get_model({"n_atom_basis": A, "n_filters": F, "n_gaussians": G, "n_convolutions": 2, "cutoff": 6.0})
+    gnn = GNNPotentials(system, net, cutoff=6.0)
+    q = T(g["pos"], DEV)
+    gnn._reset_topology(q)
+    assert analytic.fused_ok(net)
+    w = T(np.random.default_rng(2).normal(0, 1, g["pos"].shape).astype(np.float32), DEV)
+    U, F_, dq, gth = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+    qa = q.clone().requires_grad_(True)
+    Ua = gnn(qa).sum()
+    (gq,) = torch.autograd.grad(Ua, qa, create_graph=True)
+    plist = list(net.parameters())
+    ga = torch.autograd.grad((w * -gq).sum(), [qa] + plist, allow_unused=True)
+    close(U.reshape(1), Ua.detach().reshape(1), 1e-4, 1e-4, "U")
+    close(F_, -gq.detach(), 1e-3, 1e-4 * float(gq.abs().max()), "F")
+    close(dq, ga[0], 2e-3, 2e-4 * float(ga[0].abs().max()), "d(w.F)/dx")
+    flat = torch.cat([t.reshape(-1) for t in gth])
+    fa = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(ga[1:], plist)])
+    close(flat, fa, 2e-3, 2e-4 * float(fa.abs().max()), "d(w.F)/dtheta")
+    # bf16 filter operands at the same widths: within the stated bf16 tolerance of the f32 path
+    net.filter_bf16 = True
+    _, F16, dq16, g16 = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+    close(F16, F_, 0, 2e-2 * float(F_.abs().max()), "F (bf16 filter)")
+    f16 = torch.cat([t.reshape(-1) for t in g16])
+    assert float((f16.double() * flat.double()).sum() / (f16.double().norm() * flat.double().norm())) > 0.999
+
+
+@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide", "schnet_cg64_a256"])
 def test_fused_analytic_path_equals_unfused(name):
     from mdgrad_amd.interface import GNNPotentials
     from mdgrad_amd.nn import get_model, analytic
@@ -186,7 +224,8 @@ def test_fused_analytic_path_equals_unfused(name):
     close(res[0][1], g["F"], 1e-4, 1e-5 * np.abs(g["F"]).max(), "fused F vs golden")
 
 
-@pytest.mark.parametrize("N,K,M", [(1000, 64, 128), (4096, 128, 64), (37, 30, 30), (513, 200, 130), (64, 32, 1), (300, 64, 64)])
+@pytest.mark.parametrize("N,K,M", [(1000, 64, 128), (4096, 128, 64), (37, 30, 30), (513, 200, 130), (64, 32, 1), (300, 64, 64),
+                                   (700, 512, 256), (300, 512, 512), (129, 300, 512), (200, 770, 64)])
 def test_dense_node_kernel_epilogues(N, K, M):
     """csrc/dense.hip against torch: linear / transposed weight, bias, shifted softplus with its tangent row,
     elementwise product and residuals, single and dual inputs."""

@@ -11,7 +11,12 @@ pytestmark = pytest.mark.gpu
 
 
 def sd_of(g):
-    return {k[4:]: T(v) for k, v in g.items() if k.startswith("sd__")}
+    sd = {k[4:]: T(v) for k, v in g.items() if k.startswith("sd__")}
+    if "embed_row8" in g:              # (wide goldens keep the one embedding row in use: Z = 8; rows never read are zeros)
+        emb = torch.zeros(100, int(g["n_atom_basis"]))
+        emb[8] = T(g["embed_row8"])
+        sd = dict([("atom_embed.weight", emb)] + list(sd.items()))
+    return sd
 
 
 def params_of(g):
@@ -78,7 +83,7 @@ def test_mfma_filter_kernel_vs_torch_to_second_order(G, F, E):
         close(b, a, 2e-4, 2e-5 * float(a.abs().max()) + 1e-6, "filter output/derivative #%d" % k)
 
 
-@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide"])
+@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide", "schnet_cg64_a256"])
 def test_schnet_energy_force_vjp_golden(name):
     from mdgrad_amd.interface import GNNPotentials
     from mdgrad_amd.nn import get_model
@@ -250,7 +255,7 @@ def test_bf16_mfma_filter_variant(G, F, E):
         close(a, b, 1e-4, 1e-5 * float(b.abs().max()), "bf16 filter gradient (fp32 formulas)")
 
 
-@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide"])
+@pytest.mark.parametrize("name", ["schnet_cg64", "schnet_water192", "schnet_cg64_wide", "schnet_cg64_a256"])
 def test_analytic_schnet_passes_golden_and_autograd(name):
     """Hand-derived force / force-vjp (no autograd) against the reference goldens and the autograd path."""
     from mdgrad_amd.interface import GNNPotentials
