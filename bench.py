@@ -559,9 +559,10 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
         out["config"]["bf16_vs_f32"] = bf16_dev
     if rank != 0:
         return out
-    # ---- roofline: (a) the dominant kernel of the step, the fused interaction block's forward + tangent sweep
-    # (cfconv_fwd_kernel<32,8,true>), timed with HIP events on the launch stream on the step's own topology;
-    # (b) the whole step's MFMA-eligible flops (21 x forward) over the step time
+    # ---- roofline: (a) the kernel with the largest share of the pass (profiles/*schnet4096_kernel_stats.txt): the reverse
+    # sweep of the fused interaction block with parameter gradients, cfconv_bwd_kernel<32,8,true,true>, timed with HIP
+    # events on the launch stream on the step's own topology; the forward + tangent sweep beside it; (b) the whole step's
+    # MFMA-eligible flops (21 x forward) over the step time
     from mdgrad_amd.nn import analytic
     topo = gnn.inputs["_topo"]
     NN, E = topo.n_atoms, topo.n_edges
@@ -571,17 +572,29 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     x = torch.Tensor(system.get_positions()).to(dev)
     w = torch.randn(NN, 3, device=dev)
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
-    h, hd = torch.randn(NN, F_, device=dev), torch.randn(NN, F_, device=dev)
-    ops.cfconv_fwd(fn, d, dd, h, hd, topo)
-    e0, e1 = _events(2)
-    e0.record()
-    for _ in range(10):
-        ops.cfconv_fwd(fn, d, dd, h, hd, topo)
-    e1.record()
-    torch.cuda.synchronize()
-    k_ms = e0.elapsed_time(e1) / 10
+    h, hd, mb, mdb = [torch.randn(NN, F_, device=dev) for _ in range(4)]
+    d_b, dd_b = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
+
+    def timed(fn_, reps=10):
+        fn_()
+        e0, e1 = _events(2)
+        e0.record()
+        for _ in range(reps):
+            fn_()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    kb_ms = timed(lambda: ops.cfconv_bwd(fn, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, True))
+    k_ms = timed(lambda: ops.cfconv_fwd(fn, d, dd, h, hd, topo))
     tiles = int(((topo.ell.cnt + 15) // 16).sum())
     GP, FT = (32 if G_ <= 32 else 64), (4 if F_ <= 64 else 8)
+    NT_, KS_ = GP // 16, GP // 4
+    # cfconv_bwd<DUAL, THETA>, f32 MFMA per 16-edge tile: layer-1 recompute 2 NT KS, gW2 2 x 4 FT NT, s_db / s_b 2 x 4 FT NT,
+    # g_db / g_b 2 NT KS, gW1 2 x 4 NT NT  (352 at GP = 32, FT = 8)
+    mfma_bwd = 2 * NT_ * KS_ + 8 * FT * NT_ + 8 * FT * NT_ + 2 * NT_ * KS_ + 8 * NT_ * NT_
+    etiles = (E + 15) // 16
+    exec_bwd = etiles * mfma_bwd * 2048.0
     if args.bf16:                                   # v_mfma_f32_16x16x32_bf16: K = 32 per instruction, 16384 flop
         mfma_per_tile = 2 * (GP // 32) * (GP // 16) + 2 * (GP // 32) * FT
         executed, peak, insn = tiles * mfma_per_tile * 16384.0, MFMA_BF16_PEAK_TF, "v_mfma_f32_16x16x32_bf16 x 16384"
@@ -592,21 +605,31 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
         kname = "cfconv_fwd_kernel<32,8,true>"
     useful = 2.0 * (2 * E) * 2.0 * G_ * (G_ + F_)                            # directed slots x (primal + tangent)
     step_flops = 21.0 * schnet_flops_forward(N, E / R, A_, F_, G_, NC) * R * (T - 1)
+    std = R == 8 and T == 11 and bool(args.bf16)
+    cnt, why = _counters("schnet4096", "cfconv_bwd_kernel<32, 8, true, true>") if std else (None, "other geometry")
     out["roofline"] = {
-        "bound": "mfma", "kernel": kname + " (filter MLP + gather-multiply-sum, primal + tangent)",
-        "achieved": executed / (k_ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-        "frac": executed / (k_ms * 1e-3) / 1e12 / peak, "traffic": None, "kernel_ms": k_ms,
-        "useful_tflops": useful / (k_ms * 1e-3) / 1e12,
+        "bound": "mfma", "kernel": "cfconv_bwd_kernel<32,8,true,true> (reverse sweep of the filter network with parameter "
+                                   "gradients: the largest share of the pass)",
+        "achieved": exec_bwd / (kb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+        "frac": exec_bwd / (kb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "kernel_ms": kb_ms,
+        "traffic": cnt.get("hbm_bytes_per_launch") if cnt else None,
+        "share_of_pass": cnt.get("share") if cnt else None, "mfma_busy": cnt.get("mfma_busy") if cnt else None,
+        "valu_busy": cnt.get("valu_busy") if cnt else None, "wait_frac": cnt.get("wait_frac") if cnt else None,
+        "counters": ("profiles/pmc_schnet4096.json: %s, %.1f us under rocprofv3" % (cnt["name"], cnt["avg_us"])) if cnt else why,
+        "forward_kernel": {"kernel": kname + " (filter MLP + gather-multiply-sum, primal + tangent)", "kernel_ms": k_ms,
+                           "executed_tflops": executed / (k_ms * 1e-3) / 1e12, "peak": peak,
+                           "frac": executed / (k_ms * 1e-3) / 1e12 / peak, "useful_tflops": useful / (k_ms * 1e-3) / 1e12},
         "step_mfma_frac": step_flops / (el / steps) / 1e12 / MFMA_F32_PEAK_TF,
         "step_tflops": step_flops / (el / steps) / 1e12,
-        "note": "executed = %d 16-slot tiles x %d %s flop (G padded to %d; every undirected edge "
-                "is evaluated from both ends: no [E,F] tensor in HBM); useful = 2 x 2E x 2G(G+F), E = %d edges.  "
-                "step_* = SURVEY 8d's 21 x forward flops per MD step over the measured step time, priced against the f32 "
-                "MFMA peak%s" % (tiles, mfma_per_tile, insn, GP, E,
-                                 "; with bf16 operands the Dense layers shrink to 20 MFMAs per tile and the kernel is bound by "
-                                 "its f32 VALU work (2G exp2 per slot for the Gaussians and their tangents, the ssp activations, "
-                                 "the multiply with the gathered rows), so frac against the 2.5 PF bf16 peak is small by "
-                                 "construction" if args.bf16 else "")}
+        "note": "achieved = %d 16-edge tiles x %d v_mfma_f32_16x16x4_f32 x 2048 flop (the filter network is recomputed from d: "
+                "nothing edge-sized was saved) over the kernel time (HIP events); counters of the same kernel from "
+                "profiles/pmc_schnet4096.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz), FETCH / WRITE).  "
+                "forward_kernel: %d 16-slot tiles x %d %s flop (G padded to %d; every undirected edge is evaluated from both "
+                "ends), E = %d edges%s.  step_* = SURVEY 8d's 21 x forward flops per MD step over the measured step time, "
+                "priced against the f32 MFMA peak" % (
+                    etiles, mfma_bwd, tiles, mfma_per_tile, insn, GP, E,
+                    "; with bf16 operands its Dense layers shrink to 20 MFMAs per tile and it is bound by its f32 VALU work, so "
+                    "its fraction of the 2.5 PF bf16 peak is small by construction" if args.bf16 else "")}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_schnet()
         try:

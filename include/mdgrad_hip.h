@@ -411,6 +411,12 @@ int mdg_cfconv_bwd(const MdgFilterNet* net /*host*/, const float* d, const float
                    int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                    float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
                    const int32_t* n_valid /*device, nullable: real rows of a capacity-padded list*/, void* stream);
+/* bf16-operand MFMA variant of mdg_cfconv_bwd (v_mfma_f32_16x16x32_bf16 / v_mfma_f32_16x16x16_bf16; everything else fp32):
+ * the reverse half of BASELINE config #5's "bf16 cfconv MFMA, full fwd + adjoint".  Same arguments and workspace. */
+int mdg_cfconv_bwd_bf16(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
+                        int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                        float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                        const int32_t* n_valid, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K11/K12  node-level Dense layers with fused epilogues on the f32 MFMA

@@ -782,6 +782,365 @@ size_t bwd_lds_bytes(bool theta) {
     return sizeof(float) * ((size_t)2 * GP * S1 + (size_t)FP * S1 + 4 * GP + 4 * wsz);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16-operand variant of the reverse sweep (BASELINE config #5: "bf16 cfconv MFMA, full fwd + adjoint"): the same
+// sweep with every matrix product on bf16 operands and fp32 accumulation --
+//   a = g W1^T, g_b = a_b W1          v_mfma_f32_16x16x32_bf16 (K = G: one or two instructions per 16 x 16 tile)
+//   s_b = W_b W2                      v_mfma_f32_16x16x16_bf16: a lane's four consecutive filters 16 q + 4 lk + c ARE the
+//                                     instruction's k = 4 lk + c, so the float4 gathers feed it without a permutation
+//   gW2 += W_b^T s, gW1 += a_b^T g    v_mfma_f32_16x16x16_bf16 over the tile's 16 edges: the accumulator layout
+//                                     (edge = 4 lk + r) is exactly its operand layout -- one instruction where the f32
+//                                     kernel issues four
+// 70 MFMAs per 16-edge tile instead of 352 (dual + theta, G <= 32, F = 128); W1 / W2 live in LDS as bf16 (48 KB per
+// workgroup instead of 71: three resident workgroups per CU).  Gaussians, activations, the adjoint rows, every
+// accumulation and the contraction with the Gaussian derivatives stay fp32; operands are rounded to nearest even.
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k((a), (b), (c), 0, 0, 0)
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
+    bf16x4 v;
+    v[0] = (short)f2bf(a); v[1] = (short)f2bf(b); v[2] = (short)f2bf(c); v[3] = (short)f2bf(d);
+    return v;
+}
+
+template <int GP, int FT, bool DUAL, bool THETA>
+__global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int FP = 16 * FT;
+    constexpr int KSB = GP + 8;                                  // bf16 row stride of the W1 copies (16-B aligned rows)
+    constexpr int FS = FP + 8;                                   // bf16 row stride of the W2 copy
+    constexpr int SA = GP + 4;                                   // f32 scratch stride (rows 16-B aligned)
+    constexpr int SW = FP + 4;                                   // tile stride: 4 mod 32, rows 16-B aligned
+    constexpr int KB = GP / 32, NT = GP / 16;
+    constexpr int WSZ = THETA ? 16 * SW : 16 * SA;               // per-wave scratch (tile / transposes), floats
+    static_assert(!THETA || DUAL, "parameter gradients come from the dual sweep");
+    static_assert(!THETA || SW >= SA, "the tile scratch also serves the transposes");
+    float* mus = sm;
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    float* wsc = b1s + GP;                                       // [4 waves][WSZ]
+    unsigned short* w1b = reinterpret_cast<unsigned short*>(wsc + 4 * WSZ);   // [GP j][KSB]  W1[j][k]: B of a = g W1^T
+    unsigned short* w1nb = w1b + GP * KSB;                       // [GP n][KSB]  W1[j][n]: B of g_b = a_b W1  (k = j)
+    unsigned short* w2g = w1nb + GP * KSB;                       // [GP k][FS]   W2[f][k]: B of s_b = W_b W2  (k = f)
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int G = A.net.G, F = A.net.F, RS = A.net.RS;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int j = t / GP, c = t % GP;
+        w1b[j * KSB + c] = (j < G && c < G) ? f2bf(A.net.W1[j * G + c]) : 0;       // row j, column k = c
+        w1nb[j * KSB + c] = (j < G && c < G) ? f2bf(A.net.W1[c * G + j]) : 0;      // row n = j, column j' = c: W1[j'][n]
+    }
+    for (int t = tid; t < FP * GP; t += 256) {
+        const int f = t / GP, c = t % GP;                        // (consecutive threads: consecutive k of one W2 row)
+        w2g[c * FS + f] = (f < F && c < G) ? f2bf(A.net.W2[(size_t)f * G + c]) : 0;
+    }
+    for (int c = tid; c < GP; c += 256) {
+        const float cc = c < G ? A.net.coef[c] : 0.f;
+        mus[c] = c < G ? A.net.mu[c] : 0.f;
+        cfs[c] = cc * LOG2E;
+        c2s[c] = 2.f * cc;
+        b1s[c] = c < G ? A.net.b1[c] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    float* ws = wsc + wid * WSZ;
+    // persistent per-wave gradient accumulators (THETA)
+    f32x4 gW2[THETA ? FT : 1][THETA ? NT : 1], gW1[THETA ? NT : 1][THETA ? NT : 1];
+    float gb1[NT];
+    if (THETA) {
+#pragma unroll
+        for (int a = 0; a < FT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) gW2[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) gW1[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) gb1[c] = 0.f;
+
+    // 64 edges per workgroup step, 16 per wave; a fixed-capacity list is swept over its real rows only (the split over
+    // the XCDs then stays balanced)
+    const long long nrows = A.n_valid ? min((long long)*A.n_valid, A.E) : A.E;
+    const long long ntiles = (nrows + 63) / 64;
+    int t_begin, t_end, t_step;
+    xcd_sweep((int)ntiles, 1, t_begin, t_end, t_step);           // the half list is sorted by atom: same locality argument
+    for (long long tile = t_begin; tile < t_end; tile += t_step) {
+        const long long e0 = tile * 64 + wid * 16;
+        // ---- A-layout row: edge e0 + li
+        const long long ea = e0 + li;
+        long long ia = -1, ja = -1;
+        if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
+        const bool va = ia >= 0;                                  // (-1: padding row of a fixed-capacity list)
+        if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
+        const float da = va ? A.d[ea] : PAD_D;
+        float dda = 0.f;
+        if (DUAL) dda = va ? A.dd[ea] : 0.f;
+        // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
+        float wdb[4 * FT], wb[DUAL ? 4 * FT : 1];
+#pragma unroll
+        for (int q = 0; q < FT; ++q) {
+            const int f0 = 16 * q + 4 * lk;
+            float4 hi = {0.f, 0.f, 0.f, 0.f}, hj = hi, pi = hi, pj = hi;
+            const bool ok = va && f0 + 4 <= F;
+            if (ok) {
+                hi = *reinterpret_cast<const float4*>(A.h + ia * RS + f0);
+                hj = *reinterpret_cast<const float4*>(A.h + ja * RS + f0);
+                pi = *reinterpret_cast<const float4*>(A.mdb + ia * RS + f0);
+                pj = *reinterpret_cast<const float4*>(A.mdb + ja * RS + f0);
+            }
+            wdb[4 * q] = pi.x * hj.x + pj.x * hi.x; wdb[4 * q + 1] = pi.y * hj.y + pj.y * hi.y;
+            wdb[4 * q + 2] = pi.z * hj.z + pj.z * hi.z; wdb[4 * q + 3] = pi.w * hj.w + pj.w * hi.w;
+            if (DUAL) {
+                float4 bi = {0.f, 0.f, 0.f, 0.f}, bj = bi;
+                if (ok) {
+                    bi = *reinterpret_cast<const float4*>(A.mb + ia * RS + f0);
+                    bj = *reinterpret_cast<const float4*>(A.mb + ja * RS + f0);
+                }
+                float4 w = {bi.x * hj.x + bj.x * hi.x, bi.y * hj.y + bj.y * hi.y, bi.z * hj.z + bj.z * hi.z,
+                            bi.w * hj.w + bj.w * hi.w};
+                if (A.hd != nullptr && ok) {
+                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * RS + f0);
+                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * RS + f0);
+                    w.x += pi.x * tj.x + pj.x * ti.x; w.y += pi.y * tj.y + pj.y * ti.y;
+                    w.z += pi.z * tj.z + pj.z * ti.z; w.w += pi.w * tj.w + pj.w * ti.w;
+                }
+                wb[4 * q] = w.x; wb[4 * q + 1] = w.y; wb[4 * q + 2] = w.z; wb[4 * q + 3] = w.w;
+            }
+        }
+        // ---- recompute layer 1: a = g W1^T + b1 (and its tangent) in the accumulator layout
+        float sg[NT][4], qd[DUAL ? NT : 1][4], sc[THETA ? NT : 1][4], sdc[THETA ? NT : 1][4];
+        {
+            bf16x8 af[KB], adf[DUAL ? KB : 1];
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int kk = ks * 32 + lk * 8 + t;
+                    const float x = da - mus[kk];
+                    const float g = __builtin_amdgcn_exp2f(cfs[kk] * x * x);
+                    af[ks][t] = (short)f2bf(g);
+                    if (DUAL) adf[ks][t] = (short)f2bf(g * (c2s[kk] * x) * dda);
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&w1b[(nt * 16 + li) * KSB + ks * 32 + lk * 8]);
+                    acc = MFMA32(af[ks], bfr, acc);
+                    if (DUAL) accd = MFMA32(adf[ks], bfr, accd);
+                }
+                const float bias = b1s[nt * 16 + li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float s, g1;
+                    ssp_sig(acc[r] + bias, s, g1);
+                    sg[nt][r] = g1;
+                    if (DUAL) qd[nt][r] = g1 * (1.f - g1) * accd[r];
+                    if (THETA) { sc[nt][r] = s; sdc[nt][r] = g1 * accd[r]; }
+                }
+            }
+        }
+        // ---- THETA: gW2[f][k] += sum_e Wdb[e][f] sd[e][k] + Wb[e][f] s[e][k]  (contraction over the 16 edges,
+        //      edge = 4 lk + r: B operands are the accumulator-layout registers; A through the LDS tile)
+        if (THETA) {
+            bf16x4 sdp[NT], scp[NT];                                 // B[e = 4 lk + c][k]: the accumulator-layout registers, packed
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                sdp[nt] = pack4(sdc[nt][0], sdc[nt][1], sdc[nt][2], sdc[nt][3]);
+                scp[nt] = pack4(sc[nt][0], sc[nt][1], sc[nt][2], sc[nt][3]);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+                for (int q = 0; q < FT; ++q)
+                    *reinterpret_cast<float4*>(&ws[li * SW + 16 * q + 4 * lk]) =
+                        pass == 0 ? make_float4(wdb[4 * q], wdb[4 * q + 1], wdb[4 * q + 2], wdb[4 * q + 3])
+                                  : make_float4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+#pragma unroll
+                for (int mt = 0; mt < FT; ++mt) {
+                    float at[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) at[r] = ws[(4 * lk + r) * SW + mt * 16 + li];
+                    const bf16x4 ap = pack4(at[0], at[1], at[2], at[3]);     // A[f][e = 4 lk + c]
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        gW2[mt][nt] = MFMA16(ap, pass == 0 ? sdp[nt] : scp[nt], gW2[mt][nt]);
+                }
+            }
+        }
+        // ---- s_db = Wdb W2, s_b = Wb W2   ([16 x F] x [F x G])
+        bf16x4 wdbp[FT], wbp[DUAL ? FT : 1];
+#pragma unroll
+        for (int q = 0; q < FT; ++q) {
+            wdbp[q] = pack4(wdb[4 * q], wdb[4 * q + 1], wdb[4 * q + 2], wdb[4 * q + 3]);
+            if (DUAL) wbp[q] = pack4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+        }
+        f32x4 sdb[NT], sb[DUAL ? NT : 1];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < FT; ++q) {                         // k = filter 16 q + 4 lk + c on both operands
+                const bf16x4 bfr = *reinterpret_cast<const bf16x4*>(&w2g[(nt * 16 + li) * FS + 16 * q + 4 * lk]);
+                acc = MFMA16(wdbp[q], bfr, acc);
+                if (DUAL) acc2 = MFMA16(wbp[q], bfr, acc2);
+            }
+            sdb[nt] = acc;
+            if (DUAL) sb[nt] = acc2;
+        }
+        // ---- through the shifted softplus: a_db = s_db sig(a) ; a_b = s_b sig(a) + s_db sig'(a) a_dot
+        float adb[NT][4], ab[DUAL ? NT : 1][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                adb[nt][r] = sdb[nt][r] * sg[nt][r];
+                if (DUAL) {
+                    ab[nt][r] = sb[nt][r] * sg[nt][r] + sdb[nt][r] * qd[nt][r];
+                    gb1[nt] += ab[nt][r];
+                }
+            }
+        // ---- g_db = a_db W1, g_b = a_b W1: accumulator layout -> A layout through the wave's scratch
+        f32x4 gdb[NT], gb[DUAL ? NT : 1];
+#pragma unroll
+        for (int pass = 0; pass < (DUAL ? 2 : 1); ++pass) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ws[(4 * lk + r) * SA + nt * 16 + li] = pass == 0 ? adb[nt][r] : ab[DUAL ? nt : 0][r];
+            bf16x8 af[KB];
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+                const float4 u0 = *reinterpret_cast<const float4*>(&ws[li * SA + ks * 32 + lk * 8]);
+                const float4 u1 = *reinterpret_cast<const float4*>(&ws[li * SA + ks * 32 + lk * 8 + 4]);
+                af[ks][0] = (short)f2bf(u0.x); af[ks][1] = (short)f2bf(u0.y); af[ks][2] = (short)f2bf(u0.z); af[ks][3] = (short)f2bf(u0.w);
+                af[ks][4] = (short)f2bf(u1.x); af[ks][5] = (short)f2bf(u1.y); af[ks][6] = (short)f2bf(u1.z); af[ks][7] = (short)f2bf(u1.w);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks)
+                    acc = MFMA32(af[ks], *reinterpret_cast<const bf16x8*>(&w1nb[(nt * 16 + li) * KSB + ks * 32 + lk * 8]), acc);
+                if (pass == 0) gdb[nt] = acc; else gb[DUAL ? nt : 0] = acc;
+            }
+        }
+        // ---- contract with the Gaussian derivatives in the accumulator layout (rows 4 lk + r, Gaussian nt*16 + li)
+        float s_dd[4] = {0.f, 0.f, 0.f, 0.f}, s_d[4] = {0.f, 0.f, 0.f, 0.f};
+        float gc[THETA ? NT : 1][4], gdc[THETA ? NT : 1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float dr = __shfl(da, 4 * lk + r, 64);
+            const float ddr = DUAL ? __shfl(dda, 4 * lk + r, 64) : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int k = nt * 16 + li;
+                const float x = dr - mus[k];
+                const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                const float ph = c2s[k] * x;
+                const float gp = g * ph;
+                s_dd[r] = fmaf(gdb[nt][r], gp, s_dd[r]);
+                if (DUAL) {
+                    s_d[r] = fmaf(gb[nt][r], gp, s_d[r]);
+                    s_d[r] = fmaf(gdb[nt][r] * ddr, g * (ph * ph + c2s[k]), s_d[r]);
+                }
+                if (THETA) { gc[nt][r] = g; gdc[nt][r] = gp * ddr; }
+            }
+        }
+        // ---- THETA: gW1[j][k] += sum_e a_db[e][j] gd[e][k] + a_b[e][j] g[e][k]  (all operands already in the
+        //      accumulator layout: A = the adjoint of a, B = the Gaussians)
+        if (THETA) {
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                {
+                    gW1[mt][nt] = MFMA16(pack4(adb[mt][0], adb[mt][1], adb[mt][2], adb[mt][3]),
+                                         pack4(gdc[nt][0], gdc[nt][1], gdc[nt][2], gdc[nt][3]), gW1[mt][nt]);
+                    gW1[mt][nt] = MFMA16(pack4(ab[mt][0], ab[mt][1], ab[mt][2], ab[mt][3]),
+                                         pack4(gc[nt][0], gc[nt][1], gc[nt][2], gc[nt][3]), gW1[mt][nt]);
+                }
+        }
+        // ---- row sums over the 16 Gaussian lanes, then read-add-write of the edge's own entries
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                s_dd[r] += __shfl_xor(s_dd[r], o, 64);
+                if (DUAL) s_d[r] += __shfl_xor(s_d[r], o, 64);
+            }
+        }
+        if (li == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long e = e0 + 4 * lk + r;
+                if (e < A.E) {
+                    A.dd_b[e] += s_dd[r];
+                    if (DUAL) A.d_b[e] += s_d[r];
+                }
+            }
+        }
+    }
+
+    // ---- THETA: ordered cross-wave reduction through LDS, one partial record per workgroup
+    if (THETA) {
+        constexpr int REC = GP * GP + GP + FP * GP;              // [gW1 | gb1 | gW2], padded sizes
+        __syncthreads();                                         // everyone is done with the weights / scratch
+        float* buf = sm;                                         // REC floats: reuses the whole LDS block (bwd_bf16_lds_bytes reserves >= REC)
+#pragma unroll
+        for (int v = 0; v < NT; ++v) { gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64); }
+        for (int w = 0; w < 4; ++w) {
+            if (wid == w) {
+#pragma unroll
+                for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = (mt * 16 + 4 * lk + r) * GP + nt * 16 + li;       // gW1[j][k]
+                            buf[idx] = (w ? buf[idx] : 0.f) + gW1[mt][nt][r];
+                        }
+                if (lk == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int idx = GP * GP + nt * 16 + li;
+                        buf[idx] = (w ? buf[idx] : 0.f) + gb1[nt];
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < FT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = GP * GP + GP + (mt * 16 + 4 * lk + r) * GP + nt * 16 + li;   // gW2[f][k]
+                            buf[idx] = (w ? buf[idx] : 0.f) + gW2[mt][nt][r];
+                        }
+            }
+            __syncthreads();
+        }
+        float* out = A.part + (size_t)blockIdx.x * REC;
+        for (int t = tid; t < REC; t += 256) out[t] = buf[t];
+    }
+}
+
+template <int GP, int FT>
+size_t bwd_bf16_lds_bytes(bool theta) {
+    constexpr int FP = 16 * FT, KSB = GP + 8, FS = FP + 8, SA = GP + 4, SW = FP + 4;
+    const size_t wsz = theta ? 16 * SW : 16 * SA;
+    size_t b = sizeof(float) * (4 * GP + 4 * wsz) + sizeof(unsigned short) * ((size_t)2 * GP * KSB + (size_t)GP * FS);
+    const size_t rec = sizeof(float) * ((size_t)GP * GP + GP + (size_t)FP * GP);
+    if (theta && b < rec) b = rec;
+    return (b + 15) / 16 * 16;
+}
+
 // sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes
 __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nrec, int GP, int FP, int G, int F,
                                          float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
@@ -1037,10 +1396,12 @@ extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t 
     return (int64_t)bwd_blocks(n_edges, true) * (GP * GP + GP + FP * GP);
 }
 
-extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
-                              int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
-                              float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
-                              const int32_t* n_valid, void* stream) {
+namespace {
+
+int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                    int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                    float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                    const int32_t* n_valid, void* stream, bool bf16) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1068,30 +1429,36 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     BwdArgs a{dev_of(net, f0), d, dd, nbr, (long long)n_edges, at_col(h, f0), at_col(hd, f0), at_col(mb, f0), at_col(mdb, f0),
               d_b, dd_b, workspace, n_valid};
     int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
-#define MDG_BWD(GP_, FT_)                                                                                          \
+#define MDG_BWD_K(K_, L_, GP_, FT_)                                                                                \
     do {                                                                                                           \
         if (theta) {                                                                                               \
-            const size_t lds = bwd_lds_bytes<GP_, FT_>(true);                                                      \
-            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, true, true>, lds);                        \
+            const size_t lds = L_<GP_, FT_>(true);                                                                 \
+            const int want = resident_blocks(K_<GP_, FT_, true, true>, lds);                                       \
             if (want < nb) nb = want;                                                                              \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, true>), dim3(nb), dim3(256), lds, st, a);        \
+            hipLaunchKernelGGL((K_<GP_, FT_, true, true>), dim3(nb), dim3(256), lds, st, a);                       \
         } else if (dual) {                                                                                         \
-            const size_t lds = bwd_lds_bytes<GP_, FT_>(false);                                                     \
-            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, true, false>, lds);                       \
+            const size_t lds = L_<GP_, FT_>(false);                                                                \
+            const int want = resident_blocks(K_<GP_, FT_, true, false>, lds);                                      \
             nb = (int)(tiles64 < want ? tiles64 : want);                                                           \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, true, false>), dim3(nb), dim3(256), lds, st, a);       \
+            hipLaunchKernelGGL((K_<GP_, FT_, true, false>), dim3(nb), dim3(256), lds, st, a);                      \
         } else {                                                                                                   \
-            const size_t lds = bwd_lds_bytes<GP_, FT_>(false);                                                     \
-            const int want = resident_blocks(cfconv_bwd_kernel<GP_, FT_, false, false>, lds);                      \
+            const size_t lds = L_<GP_, FT_>(false);                                                                \
+            const int want = resident_blocks(K_<GP_, FT_, false, false>, lds);                                     \
             nb = (int)(tiles64 < want ? tiles64 : want);                                                           \
-            hipLaunchKernelGGL((cfconv_bwd_kernel<GP_, FT_, false, false>), dim3(nb), dim3(256), lds, st, a);      \
+            hipLaunchKernelGGL((K_<GP_, FT_, false, false>), dim3(nb), dim3(256), lds, st, a);                     \
         }                                                                                                          \
+    } while (0)
+#define MDG_BWD(GP_, FT_)                                                                                          \
+    do {                                                                                                           \
+        if (bf16) MDG_BWD_K(cfconv_bwd_bf16_kernel, bwd_bf16_lds_bytes, GP_, FT_);                                 \
+        else MDG_BWD_K(cfconv_bwd_kernel, bwd_lds_bytes, GP_, FT_);                                                \
     } while (0)
     if (GP == 32 && FT == 4) MDG_BWD(32, 4);
     else if (GP == 32) MDG_BWD(32, 8);
     else if (FT == 4) MDG_BWD(64, 4);
     else MDG_BWD(64, 8);
 #undef MDG_BWD
+#undef MDG_BWD_K
     MDG_CHECK_LAUNCH("cfconv_bwd_kernel");
     if (theta) {
         const int FP = 16 * FT, REC = GP * GP + GP + FP * GP;
@@ -1102,3 +1469,20 @@ extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const flo
     }
     return MDG_OK;
 }
+
+}  // namespace
+
+extern "C" int mdg_cfconv_bwd(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                              int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                              float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                              const int32_t* n_valid, void* stream) {
+    return cfconv_bwd_impl(net, d, dd, nbr, n_edges, h, hd, mb, mdb, d_b, dd_b, gW1, gb1, gW2, workspace, n_valid, stream, false);
+}
+
+extern "C" int mdg_cfconv_bwd_bf16(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                                   int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                                   float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
+                                   const int32_t* n_valid, void* stream) {
+    return cfconv_bwd_impl(net, d, dd, nbr, n_edges, h, hd, mb, mdb, d_b, dd_b, gW1, gb1, gW2, workspace, n_valid, stream, true);
+}
+

@@ -238,7 +238,13 @@ extern "C" int mdg_dense(const float* W, int trans, int act, int n_rows, int k, 
     MDG_CHECK_ARG(act == 0 || act == 1, "dense: act must be 0 (identity) or 1 (shifted softplus)");
     MDG_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)x1) & 15) == 0, "dense: inputs must be 16-byte aligned");
     const int row_tiles = (n_rows + 63) / 64;
-    dim3 grid(row_tiles < 256 ? row_tiles : 256, (m + DN_MC - 1) / DN_MC);
+    // persistent workgroups: as many per CU as the LDS-resident weight chunk allows (<= 4), so that several row tiles are in
+    // flight per CU -- with one workgroup per CU the kernel ran at ~2 TB/s on [32768 x 128] rows (latency-bound loads)
+    const size_t lds_max = sizeof(float) * (size_t)(((k < 256 ? k : 256) + DN_KC - 1) / DN_KC * DN_KC) * DN_SB;
+    int per_cu = (int)((size_t)(160 * 1024) / (lds_max + 1024));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
+    const int gx_max = 256 * per_cu;
+    dim3 grid(row_tiles < gx_max ? row_tiles : gx_max, (m + DN_MC - 1) / DN_MC);
     // 16-byte epilogue when every column chunk is 64 or 128 wide and all row pointers are 16-byte aligned
     const uintptr_t al = (uintptr_t)mul0 | (uintptr_t)res0 | (uintptr_t)out0 | (uintptr_t)sig0 | (uintptr_t)res1 |
                          (uintptr_t)out1 | (uintptr_t)bias0;

@@ -107,33 +107,34 @@ __global__ void bin_count_kernel(const float* __restrict__ pos, int N, int group
     atomicAdd(&bin_cnt[b], 1);
 }
 
-// single-block exclusive scan: out[k] = sum_{l<k} in[l], out[n] = total; also copies to cursor
-__global__ void scan_kernel(const int32_t* __restrict__ in, int n, int32_t* __restrict__ out,
-                            int32_t* __restrict__ cursor) {
+// single-block exclusive scan: out[k] = sum_{l<k} in[l], out[n] = total; also copies to cursor.  `out` may alias `in`.
+// Every wave owns one contiguous segment: pass 1 sums it (coalesced, independent loads), one barrier and a 16-entry prefix
+// give the segment offsets, pass 2 re-reads the segment in 64-item chunks (L2 hits) and writes the running wave scan --
+// two barriers whatever n (the chunk-by-chunk version it replaces took 3 block barriers per 1 024 items: 37 us for the
+// 32 768 row counts of eight stacked 4 096-bead replicas).
+__global__ void scan_kernel(const int32_t* in, int n, int32_t* out, int32_t* __restrict__ cursor) {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int k = base + threadIdx.x;
-        const int v = k < n ? in[k] : 0;
+    const int seg = ((n + nw - 1) / nw + 63) / 64 * 64;            // items per wave, a multiple of the chunk
+    const int b = min(n, wid * seg), e = min(n, b + seg);
+    int s = 0;
+    for (int k = b + lane; k < e; k += 64) s += in[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) wsum[wid] = s;
+    __syncthreads();                                             // (every read of pass 1 precedes every write of pass 2)
+    int run = 0;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int k0 = b; k0 < e; k0 += 64) {
+        const int k = k0 + lane;
+        const int v = k < e ? in[k] : 0;
         int x = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-        if (lane == 63) wsum[wid] = x;
-        __syncthreads();
-        int woff = 0;
-        for (int w = 0; w < wid; ++w) woff += wsum[w];
-        const int carry = carry_s;
-        const int excl = carry + woff + x - v;
-        if (k < n) { out[k] = excl; if (cursor) cursor[k] = excl; }
-        __syncthreads();
-        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + x;
-        __syncthreads();
-        (void)nw;
+        if (k < e) { out[k] = run + x - v; if (cursor) cursor[k] = run + x - v; }
+        run += __shfl(x, 63, 64);
     }
-    if (threadIdx.x == 0) out[n] = carry_s;
+    if (wid == nw - 1 && lane == 0) out[n] = run;                  // (segments past n are empty: run = the total)
 }
 
 __global__ void bin_fill_kernel(const int32_t* __restrict__ atom_bin, int N, int32_t* __restrict__ cursor,

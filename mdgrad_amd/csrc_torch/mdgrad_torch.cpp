@@ -12,7 +12,7 @@
 //   nhc_vv_adjoint   K7   sovlers.py:211-293                -> mdg_traj_adj_small
 //   rdf_fwd/rdf_bwd  K8   observable.py:62-76               -> mdg_rdf_fwd_uniform / mdg_rdf_bwd_uniform
 //   edge_geom(+_bwd) schnet.py:142                          -> mdg_edge_geom / mdg_edge_geom_bwd
-//   cfconv_fwd/_bwd  K9+K10 modules.py:531-571              -> mdg_cfconv_fwd(_bf16) / mdg_cfconv_bwd
+//   cfconv_fwd/_bwd  K9+K10 modules.py:531-571              -> mdg_cfconv_fwd(_bf16) / mdg_cfconv_bwd(_bf16)
 //   dense_ssp        K11/12 layers.py:86-134                -> mdg_dense
 //   ssp_dual_bwd_t, atb                                     -> mdg_ssp_dual_bwd_t / mdg_atb
 #include <ATen/ATen.h>
@@ -256,7 +256,7 @@ MdgFilterNet filter_net(const Tensor& mu, const Tensor& coef, const Tensor& W1, 
     n.n_gauss = (int32_t)mu.numel(); n.n_filters = (int32_t)W2.size(0);
     TORCH_CHECK(W1.dim() == 2 && W1.size(0) == n.n_gauss && W1.size(1) == n.n_gauss && W2.dim() == 2 && W2.size(1) == n.n_gauss,
                 "mdgrad: filter network shapes (W1 [G,G], W2 [F,G])");
-    TORCH_CHECK(mdg_cfconv_supported(n.n_gauss, n.n_filters), "mdgrad: fused cfconv needs G <= 64 and F <= 128 (a multiple of 4/8)");
+    TORCH_CHECK(mdg_cfconv_supported(n.n_gauss, n.n_filters), "mdgrad: fused cfconv needs G <= 64 and F a multiple of 4 up to 64, of 8 up to 128, or of 128 up to 512");
     return n;
 }
 
@@ -315,7 +315,7 @@ std::tuple<Tensor, Tensor, Tensor> cfconv_bwd(const Tensor& mu, const Tensor& co
                                               const Tensor& W2, const Tensor& b2, const Tensor& d, const OptTensor& dd,
                                               const Tensor& nbr, int64_t n_edges, const Tensor& h, const OptTensor& hd,
                                               const OptTensor& mb, const Tensor& mdb, const OptTensor& d_b, Tensor& dd_b,
-                                              const OptTensor& n_valid, bool want_theta) {
+                                              const OptTensor& n_valid, bool want_theta, bool bf16) {
     const MdgFilterNet net = filter_net(mu, coef, W1, b1, W2, b2);
     check_f32(d, "d"); check_f32(h, "h"); check_f32(mdb, "mdb"); check_f32(dd_b, "dd_b");
     TORCH_CHECK(nbr.is_cuda() && nbr.scalar_type() == at::kLong && nbr.is_contiguous(), "mdgrad: nbr must be int64 on the device");
@@ -325,9 +325,10 @@ std::tuple<Tensor, Tensor, Tensor> cfconv_bwd(const Tensor& mu, const Tensor& co
     Tensor ws = at::empty({want_theta ? std::max<int64_t>(1, mdg_cfconv_bwd_workspace((int)G, (int)F, n_edges)) : 0}, h.options());
     const int32_t* nv = nullptr;
     if (n_valid.has_value() && n_valid->defined()) { check_i32(*n_valid, "n_valid"); nv = n_valid->data_ptr<int32_t>(); }
-    ok(mdg_cfconv_bwd(&net, fptr(d), fptr(dd, "dd"), nbr.data_ptr<int64_t>(), n_edges, fptr(h), fptr(hd, "hd"), fptr(mb, "mb"),
-                      fptr(mdb), const_cast<float*>(fptr(d_b, "d_b")), mptr(dd_b), want_theta ? mptr(gW1) : nullptr, want_theta ? mptr(gb1) : nullptr,
-                      want_theta ? mptr(gW2) : nullptr, want_theta ? mptr(ws) : nullptr, nv, stream_of(h)));
+    auto fn = bf16 ? mdg_cfconv_bwd_bf16 : mdg_cfconv_bwd;
+    ok(fn(&net, fptr(d), fptr(dd, "dd"), nbr.data_ptr<int64_t>(), n_edges, fptr(h), fptr(hd, "hd"), fptr(mb, "mb"),
+          fptr(mdb), const_cast<float*>(fptr(d_b, "d_b")), mptr(dd_b), want_theta ? mptr(gW1) : nullptr, want_theta ? mptr(gb1) : nullptr,
+          want_theta ? mptr(gW2) : nullptr, want_theta ? mptr(ws) : nullptr, nv, stream_of(h)));
     return {gW1, gb1, gW2};
 }
 
@@ -388,7 +389,7 @@ TORCH_LIBRARY(mdgrad, m) {
           "Tensor? hd, Tensor col, Tensor eid, Tensor cnt, bool want_sums) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("cfconv_bwd(Tensor mu, Tensor coef, Tensor W1, Tensor b1, Tensor W2, Tensor b2, Tensor d, Tensor? dd, Tensor nbr, "
           "int n_edges, Tensor h, Tensor? hd, Tensor? mb, Tensor mdb, Tensor(a!)? d_b, Tensor(b!) dd_b, Tensor? n_valid, "
-          "bool want_theta) -> (Tensor, Tensor, Tensor)");
+          "bool want_theta, bool bf16=False) -> (Tensor, Tensor, Tensor)");
     m.def("dense_ssp(Tensor W, bool trans, bool act, Tensor x0, Tensor? bias, Tensor? mul, Tensor? res, Tensor? x1, Tensor? res1, "
           "bool want_sig) -> (Tensor, Tensor, Tensor)");
     m.def("ssp_dual_bwd_t(Tensor sa, Tensor td, Tensor sdb, Tensor sb) -> (Tensor, Tensor)");

@@ -1136,6 +1136,8 @@ class FilterNet:
     """Device-side description of one SchNetConv filter network for the fused kernels (csrc/cfconv_fused.hip):
     Gaussian centres / coefficients and the two Dense layers, as contiguous fp32 tensors kept alive here."""
 
+    bf16_reverse = True                          # ... and in the reverse sweep of the filter network (mdg_cfconv_bwd_bf16)
+
     def __init__(self, mu, coef, W1, b1, W2, b2, bf16=False):
         self.bf16 = bool(bf16)                   # bf16 MFMA operands in the forward / tangent / aggregation sweeps
         self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
@@ -1224,16 +1226,18 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
     tops = _torch_ops.get()
     if tops is not None:
         out = tops.cfconv_bwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, d, dd, topo.nbr, int(topo.n_edges), h, hd,
-                              mb, mdb, d_b, dd_b, getattr(topo, "n_valid", None), bool(want_theta))
+                              mb, mdb, d_b, dd_b, getattr(topo, "n_valid", None), bool(want_theta),
+                              bool(fnet.bf16 and fnet.bf16_reverse))
         return tuple(out) if want_theta else None
     gW1 = gb1 = gW2 = ws = None
     if want_theta:
         gW1, gb1 = torch.empty(fnet.G, fnet.G, device=dev), torch.empty(fnet.G, device=dev)
         gW2 = torch.empty(fnet.F, fnet.G, device=dev)
         ws = torch.empty(max(1, int(lib.mdg_cfconv_bwd_workspace(fnet.G, fnet.F, topo.n_edges))), device=dev)
-    check(lib.mdg_cfconv_bwd(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
-                             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws),
-                             ptr(getattr(topo, "n_valid", None)), stream_ptr(dev)), "mdg_cfconv_bwd")
+    fn = lib.mdg_cfconv_bwd_bf16 if (fnet.bf16 and fnet.bf16_reverse) else lib.mdg_cfconv_bwd
+    check(fn(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
+             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws),
+             ptr(getattr(topo, "n_valid", None)), stream_ptr(dev)), "mdg_cfconv_bwd")
     return (gW1, gb1, gW2) if want_theta else None
 
 

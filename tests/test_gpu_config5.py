@@ -45,6 +45,36 @@ def test_bf16_forward_kernel_vs_f32(G, F):
     assert torch.equal(prim[0], got[0]), "primal bits do not depend on the tangent riding along"
 
 
+@pytest.mark.parametrize("G,F", [(30, 128), (16, 48), (41, 64), (41, 128), (30, 256)])
+def test_bf16_backward_kernel_vs_f32(G, F):
+    """mdg_cfconv_bwd_bf16 (v_mfma_f32_16x16x32_bf16 / 16x16x16_bf16 operands, fp32 accumulation) against the f32 MFMA
+    kernel: plain reverse sweep, dual sweep, dual sweep with the parameter gradients; bitwise reproducible."""
+    from mdgrad_amd import ops
+    from test_gpu_fused_block import _setup
+    x, topo, net = _setup(G, F, seed=7 * G + F)
+    N, E = topo.n_atoms, topo.n_edges
+    w = torch.randn(N, 3, device=DEV)
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    h, hd, mb, mdb = [torch.randn(N, F, device=DEV) for _ in range(4)]
+    f32, b16 = ops.FilterNet(*net), ops.FilterNet(*net, bf16=True)
+    assert b16.bf16_reverse
+
+    def run(fn, dual, theta, with_hd=True):
+        d_b, dd_b = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        th = ops.cfconv_bwd(fn, d, dd if dual else None, topo, h, hd if (dual and with_hd) else None, mb if dual else None, mdb,
+                            d_b if dual else None, dd_b, want_theta=theta)
+        return [dd_b, d_b] + (list(th) if theta else [])
+
+    for dual, theta, with_hd in ((False, False, False), (True, False, True), (True, True, True), (True, True, False)):
+        ref, got = run(f32, dual, theta, with_hd), run(b16, dual, theta, with_hd)
+        for a, b, nm in zip(got, ref, ("dd_b", "d_b", "gW1", "gb1", "gW2")):
+            if nm == "d_b" and not dual:
+                continue
+            close(a, b, 0, 2e-2 * float(b.abs().max()) + 1e-6, "bf16 reverse %s (dual=%s theta=%s hd=%s)" % (nm, dual, theta, with_hd))
+        again = run(b16, dual, theta, with_hd)
+        assert all(torch.equal(p_, q_) for p_, q_ in zip(again, got)), "bitwise reproducible"
+
+
 def test_bf16_filter_trajectory_and_adjoint_vs_reference_golden():
     """Stack(SchNet + ExcludedVolume prior), NHC, 10 steps, RDF loss, adjoint -- the golden G9 of the fp32 reference,
     run with the filter network on bf16 MFMA operands."""
@@ -68,19 +98,21 @@ def test_bf16_filter_trajectory_and_adjoint_vs_reference_golden():
     y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
     t = torch.Tensor([float(g["dt"]) * i for i in range(11)]).to(DEV)
     v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
-    close(q_t, g["q_t"], 0, 2e-3, "q_t (bf16 filter)")
-    close(v_t, g["v_t"], 0, 2e-2 * np.abs(g["v_t"]).max(), "v_t (bf16 filter)")
+    # tolerances: ~10-20 x what this configuration shows on MI355X with bf16 operands in BOTH sweeps of the filter network
+    # (q 2.2e-5 A, g 2.8e-5, dL/dtheta 2.2e-5 of the largest entry, grad_q0 4e-5; tools: MDG_TEST_REPORT)
+    close(q_t, g["q_t"], 0, 3e-4, "q_t (bf16 filter)")
+    close(v_t, g["v_t"], 0, 1e-3 * np.abs(g["v_t"]).max(), "v_t (bf16 filter)")
     _, _, gr = rdf(system, nbins=40, r_range=(2.0, 5.5))(q_t[::2])
-    close(gr, g["g"], 0, 2e-2, "g(r) (bf16 filter)")
+    close(gr, g["g"], 0, 5e-4, "g(r) (bf16 filter)")
     loss = gr.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3
     loss.backward()
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
     ref = g["grad_flat"]
     assert torch.isfinite(flat).all()
     cos = float((flat.cpu().double() * torch.tensor(ref).double()).sum() / (flat.cpu().double().norm() * np.linalg.norm(ref)))
-    assert cos > 0.999, "dL/dtheta direction (cosine %.5f)" % cos
-    close(flat, ref, 0, 5e-2 * np.abs(ref).max(), "dL/dtheta (bf16 filter)")
-    close(y0[1].grad, g["grad_q0"], 0, 5e-2 * np.abs(g["grad_q0"]).max(), "grad_q0 (bf16 filter)")
+    assert cos > 0.99999, "dL/dtheta direction (cosine %.7f)" % cos
+    close(flat, ref, 0, 5e-4 * np.abs(ref).max(), "dL/dtheta (bf16 filter)")
+    close(y0[1].grad, g["grad_q0"], 0, 1e-3 * np.abs(g["grad_q0"]).max(), "grad_q0 (bf16 filter)")
 
 
 def test_fit_rdf_gnn_two_ranks_on_one_device():
