@@ -295,6 +295,22 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)(u >> 16);
 }
 
+// two f32 -> two bf16 in ONE instruction (v_cvt_pk_bf16_f32, round to nearest even: the same bits as f2bf for finite
+// values; the software rounding above costs four VALU operations per value and was a fifth of the bf16 kernels' issue
+// slots); lo half = a, hi half = b
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2hw __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned int cvt_pk_bf16(float a, float b) {
+    const f32x2v v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2hw));
+}
+__device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
+    const u32x4v u = {cvt_pk_bf16(f[0], f[1]), cvt_pk_bf16(f[2], f[3]), cvt_pk_bf16(f[4], f[5]), cvt_pk_bf16(f[6], f[7])};
+    return __builtin_bit_cast(bf16x8, u);
+}
+
 template <int GP, int FT, bool TANGENT, bool SUMS>          // GP in {32, 64}
 __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -362,14 +378,17 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             bf16x8 af[KB], adf[KB];
 #pragma unroll
             for (int ks = 0; ks < KB; ++ks) {
+                float gk[8], gdk[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int k = ks * 32 + lk * 8 + t;
                     const float x = da - mus[k];
                     const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
-                    af[ks][t] = (short)f2bf(g);
-                    if (TANGENT) adf[ks][t] = (short)f2bf(g * (c2s[k] * x) * dda);
+                    gk[t] = g;
+                    gdk[t] = TANGENT ? g * (c2s[k] * x) * dda : 0.f;
                 }
+                af[ks] = pack8(gk);
+                if (TANGENT) adf[ks] = pack8(gdk);
             }
 #pragma unroll
             for (int nt = 0; nt < GP / 16; ++nt) {
@@ -386,8 +405,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 for (int r = 0; r < 4; ++r) {
                     float s, sg;
                     ssp_sig(acc[r] + bias, s, sg);
-                    h1w[(lk * 4 + r) * KSB + c] = f2bf(s);
-                    if (TANGENT) h1dw[(lk * 4 + r) * KSB + c] = f2bf(sg * accd[r]);
+                    h1w[(lk * 4 + r) * KSB + c] = (unsigned short)cvt_pk_bf16(s, 0.f);
+                    if (TANGENT) h1dw[(lk * 4 + r) * KSB + c] = (unsigned short)cvt_pk_bf16(sg * accd[r], 0.f);
                 }
             }
 #pragma unroll
@@ -799,9 +818,8 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
-    bf16x4 v;
-    v[0] = (short)f2bf(a); v[1] = (short)f2bf(b); v[2] = (short)f2bf(c); v[3] = (short)f2bf(d);
-    return v;
+    const u32x2v u = {cvt_pk_bf16(a, b), cvt_pk_bf16(c, d)};
+    return __builtin_bit_cast(bf16x4, u);
 }
 
 template <int GP, int FT, bool DUAL, bool THETA>
@@ -917,14 +935,17 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
             bf16x8 af[KB], adf[DUAL ? KB : 1];
 #pragma unroll
             for (int ks = 0; ks < KB; ++ks) {
+                float gk[8], gdk[8];
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int kk = ks * 32 + lk * 8 + t;
                     const float x = da - mus[kk];
                     const float g = __builtin_amdgcn_exp2f(cfs[kk] * x * x);
-                    af[ks][t] = (short)f2bf(g);
-                    if (DUAL) adf[ks][t] = (short)f2bf(g * (c2s[kk] * x) * dda);
+                    gk[t] = g;
+                    gdk[t] = DUAL ? g * (c2s[kk] * x) * dda : 0.f;
                 }
+                af[ks] = pack8(gk);
+                if (DUAL) adf[ks] = pack8(gdk);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -1020,8 +1041,8 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
             for (int ks = 0; ks < KB; ++ks) {
                 const float4 u0 = *reinterpret_cast<const float4*>(&ws[li * SA + ks * 32 + lk * 8]);
                 const float4 u1 = *reinterpret_cast<const float4*>(&ws[li * SA + ks * 32 + lk * 8 + 4]);
-                af[ks][0] = (short)f2bf(u0.x); af[ks][1] = (short)f2bf(u0.y); af[ks][2] = (short)f2bf(u0.z); af[ks][3] = (short)f2bf(u0.w);
-                af[ks][4] = (short)f2bf(u1.x); af[ks][5] = (short)f2bf(u1.y); af[ks][6] = (short)f2bf(u1.z); af[ks][7] = (short)f2bf(u1.w);
+                const float uu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+                af[ks] = pack8(uu);
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
