@@ -151,6 +151,16 @@ int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* cell /*host*
                       float* energy, float* grad, float* gtheta,
                       float* hw, float* gtheta_w,
                       float* partial, void* stream);
+/* the same with the per-atom outputs scaled and (accumulate != 0) added onto existing values:
+ *   grad = (accumulate ? grad : 0) + out_scale * dU/dx ,  hw likewise -- the force sum of a Stack
+ *   (torchmd/interface.py:396-401) without extra launches: F += -dU/dx of this term */
+int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
+                      const int32_t* col, const int32_t* shift, const int32_t* cnt, int max_nbr,
+                      const MdgPairTerm* term /*host*/, const float* theta,
+                      const float* w,
+                      float* energy, float* grad, float* gtheta,
+                      float* hw, float* gtheta_w,
+                      float* partial, float out_scale, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K5-K7  fused trajectories for small systems (one workgroup per replica, state in LDS,

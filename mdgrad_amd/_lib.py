@@ -76,6 +76,8 @@ _SIGNATURES = {
     "mdg_pair_partial_size": (C.c_int64, [C.c_int]),
     "mdg_pair_eval_ell": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), P, P, P, C.c_int,
                                     C.POINTER(MdgPairTerm), P, P, P, P, P, P, P, P, P]),
+    "mdg_pair_eval_ell_into": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), P, P, P, C.c_int,
+                                         C.POINTER(MdgPairTerm), P, P, P, P, P, P, P, P, C.c_float, C.c_int, P]),
     "mdg_traj_fwd_small": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                      P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_traj_adj_small": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),

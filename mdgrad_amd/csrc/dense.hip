@@ -106,10 +106,18 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
     const bool vec = (A.K & 3) == 0 && (A.ldx & 3) == 0;
     const int row_tiles = (A.N + 63) >> 6;
     constexpr int TT = NT ? NT : DN_MC / 16;
+    // software pipeline over the (row tile, k chunk) sequence of this workgroup: the A fragments of the NEXT chunk -- the
+    // first chunk of the next row tile after the last one -- are requested before the MFMAs of the current chunk, so the
+    // global loads overlap the matrix work and the epilogue instead of heading every chunk with a round trip
+    float a0[16], a1[16];
+    {
+        const int arow = (int)blockIdx.x * 64 + wid * 16 + li;
+        const bool aok = (int)blockIdx.x < row_tiles && arow < A.N;
+        load_a(P0.x, arow, aok, A.K, A.ldx, vec, 0, lk, a0);
+        if (DUAL) load_a(P1.x, arow, aok, A.K, A.ldx, vec, 0, lk, a1);
+    }
     for (int tile = blockIdx.x; tile < row_tiles; tile += gridDim.x) {
         const int row0 = tile * 64 + wid * 16;
-        const int arow = row0 + li;
-        const bool aok = arow < A.N;
         f32x4 acc0[TT], acc1[DUAL ? TT : 1];
 #pragma unroll
         for (int t = 0; t < TT; ++t) {
@@ -117,9 +125,15 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
             if (DUAL) acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         for (int kc = 0; kc < A.K; kc += DN_KC) {
-            float a0[16], a1[16];
-            load_a(P0.x, arow, aok, A.K, A.ldx, vec, kc, lk, a0);
-            if (DUAL) load_a(P1.x, arow, aok, A.K, A.ldx, vec, kc, lk, a1);
+            float n0[16], n1[16];
+            {
+                const bool more_k = kc + DN_KC < A.K;
+                const int ntile = more_k ? tile : tile + (int)gridDim.x;
+                const int nrow = ntile * 64 + wid * 16 + li;
+                const bool nok = ntile < row_tiles && nrow < A.N;
+                load_a(P0.x, nrow, nok, A.K, A.ldx, vec, more_k ? kc + DN_KC : 0, lk, n0);
+                if (DUAL) load_a(P1.x, nrow, nok, A.K, A.ldx, vec, more_k ? kc + DN_KC : 0, lk, n1);
+            }
             const float* bk = bs + (size_t)kc * DN_SB;
 #pragma unroll
             for (int t = 0; t < TT; ++t) {
@@ -132,6 +146,8 @@ __global__ __launch_bounds__(256) void dense_kernel(const DenseArgs A) {
                     }
                 }
             }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { a0[q] = n0[q]; if (DUAL) a1[q] = n1[q]; }
         }
         if constexpr (NT != 0) {
             // lane: rows row0 + 4 lk + r, columns m_lo + li * NT + [0, NT)

@@ -19,6 +19,7 @@ struct EllArgs {
     const int32_t* col; const int32_t* shift; const int32_t* cnt; int max_nbr;
     MdgPairTerm term; const float* theta; const float* w;
     float* grad; float* hw; float* partial;
+    float oscale; int oacc;      // grad / hw outputs: out = (oacc ? out : 0) + oscale * value  (force sums of a Stack)
 };
 
 template <int LPA, int LEVEL>
@@ -68,8 +69,17 @@ __global__ void pair_ell_kernel(const EllArgs A) {
             gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
             if (LEVEL >= 2) { hx = group_sum<LPA>(hx); hy = group_sum<LPA>(hy); hz = group_sum<LPA>(hz); }
             if (sub == 0) {
-                if (A.grad) { A.grad[3 * i] = gx; A.grad[3 * i + 1] = gy; A.grad[3 * i + 2] = gz; }
-                if (LEVEL >= 2) { A.hw[3 * i] = hx; A.hw[3 * i + 1] = hy; A.hw[3 * i + 2] = hz; }
+                const float os = A.oscale;
+                if (A.grad) {
+                    if (A.oacc) { A.grad[3 * i] = fmaf(os, gx, A.grad[3 * i]); A.grad[3 * i + 1] = fmaf(os, gy, A.grad[3 * i + 1]);
+                                  A.grad[3 * i + 2] = fmaf(os, gz, A.grad[3 * i + 2]); }
+                    else { A.grad[3 * i] = os * gx; A.grad[3 * i + 1] = os * gy; A.grad[3 * i + 2] = os * gz; }
+                }
+                if (LEVEL >= 2) {
+                    if (A.oacc) { A.hw[3 * i] = fmaf(os, hx, A.hw[3 * i]); A.hw[3 * i + 1] = fmaf(os, hy, A.hw[3 * i + 1]);
+                                  A.hw[3 * i + 2] = fmaf(os, hz, A.hw[3 * i + 2]); }
+                    else { A.hw[3 * i] = os * hx; A.hw[3 * i + 1] = os * hy; A.hw[3 * i + 2] = os * hz; }
+                }
             }
         }
     }
@@ -114,11 +124,26 @@ extern "C" int64_t mdg_pair_partial_size(int n_atoms) {
         else hipLaunchKernelGGL((pair_ell_kernel<LPA_, 0>), grid, dim3(256), 0, st, a);            \
         break;
 
+extern "C" int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCell* cell, const int32_t* col,
+                                      const int32_t* shift, const int32_t* cnt, int max_nbr,
+                                      const MdgPairTerm* term, const float* theta, const float* w,
+                                      float* energy, float* grad, float* gtheta, float* hw, float* gtheta_w,
+                                      float* partial, float out_scale, int accumulate, void* stream);
+
 extern "C" int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* cell, const int32_t* col,
                                  const int32_t* shift, const int32_t* cnt, int max_nbr,
                                  const MdgPairTerm* term, const float* theta, const float* w,
                                  float* energy, float* grad, float* gtheta, float* hw, float* gtheta_w,
                                  float* partial, void* stream) {
+    return mdg_pair_eval_ell_into(pos, n_atoms, cell, col, shift, cnt, max_nbr, term, theta, w, energy, grad, gtheta, hw,
+                                  gtheta_w, partial, 1.0f, 0, stream);
+}
+
+extern "C" int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCell* cell, const int32_t* col,
+                                      const int32_t* shift, const int32_t* cnt, int max_nbr,
+                                      const MdgPairTerm* term, const float* theta, const float* w,
+                                      float* energy, float* grad, float* gtheta, float* hw, float* gtheta_w,
+                                      float* partial, float out_scale, int accumulate, void* stream) {
     MDG_CHECK_ARG(pos && cell && col && shift && cnt && term && partial, "pair_eval_ell: null buffer");
     MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0, "pair_eval_ell: bad sizes");
     // (MDG_PAIR_TABLE: theta is the table itself -- 2 p floats -- and carries no parameter gradient here)
@@ -128,7 +153,7 @@ extern "C" int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* c
     MDG_CHECK_ARG(term->n_theta == 0 || theta, "pair_eval_ell: theta is null");
     MDG_CHECK_ARG(!w || hw, "pair_eval_ell: w given without hw output");
     const int level = w ? 2 : ((grad || gtheta) ? 1 : 0);
-    EllArgs a{pos, n_atoms, *cell, col, shift, cnt, max_nbr, *term, theta, w, grad, hw, partial};
+    EllArgs a{pos, n_atoms, *cell, col, shift, cnt, max_nbr, *term, theta, w, grad, hw, partial, out_scale, accumulate};
     const int lpa = pick_lpa(n_atoms);
     const int apb = 256 / lpa;
     const int nblocks = (n_atoms + apb - 1) / apb;

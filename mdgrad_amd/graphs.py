@@ -127,6 +127,7 @@ class _ForwardGraph:
 
     def run(self, y0, t):
         func = self.func
+        getattr(func.model, "prepare_pass", lambda: None)()
         for s, x in zip(self.state, y0):
             s.copy_(x)
         self.t.copy_(t)
@@ -198,6 +199,7 @@ class _AdjointGraph:
 
     def run(self, t, ans, grad_output):
         T = ans[0].shape[0]
+        getattr(self.func.model, "prepare_pass", lambda: None)()
         for dst, src in zip(self.ans, ans):
             dst.copy_(src)
         for dst, src in zip(self.gout, grad_output):

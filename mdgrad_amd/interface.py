@@ -174,6 +174,13 @@ class GNNPotentials(GeneralInteraction):
 
     accepts_accum = True
 
+    def prepare_pass(self):
+        """Once per trajectory pass, before HIP-graph replays: state the captured steps read but do not recompute (the
+        embedding rows of the atoms, which change with every optimizer step)."""
+        from .nn import analytic
+        if self.supports_force_vjp():
+            analytic.refresh_embedding(self.gnn, self._z())
+
     def force_vjp(self, xyz, w, want_theta=True, accum=None):
         """`accum` (ops.ThetaAccum): the parameter gradients are added into its flat buffer (weighted on the device) and
         None is returned in their place."""
@@ -297,29 +304,37 @@ class PairPotentials(GeneralInteraction):
         params = self.model.mdg_params()
         return (torch.cat([p.detach().reshape(-1) for p in params]) if params else like.new_zeros(0)), params
 
-    def force(self, xyz):
-        """F = -dU/dx in one kernel launch."""
+    accepts_into = True
+
+    def force(self, xyz, into=None):
+        """F = -dU/dx in one kernel launch; `into` (a force buffer of another Stack member): added onto it in the same
+        launch and returned."""
         if not self.builtin():
-            return self._module_force(xyz.detach().contiguous())
+            f = self._module_force(xyz.detach().contiguous())
+            return f if into is None else into.add_(f)
         theta, _ = self._theta(xyz)
-        o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True)
-        return -o["grad"]
+        o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True,
+                          into=None if into is None else (into, None), scale=-1.0)
+        return o["grad"]
 
     accepts_accum = True
 
-    def force_vjp(self, xyz, w, want_theta=True, accum=None):
+    def force_vjp(self, xyz, w, want_theta=True, accum=None, into=None):
         """(F, d(w.F)/dx, [d(w.F)/dtheta_p for p in parameters()]) -- what double autograd yields at
         torchmd/sovlers.py:229-233 -- in one kernel launch (force + Hessian-vector product + mixed term).  `accum`
-        (ops.ThetaAccum): the parameter part is added into its flat buffer instead (None returned)."""
+        (ops.ThetaAccum): the parameter part is added into its flat buffer instead (None returned).  `into` = (F, dq)
+        buffers of another Stack member: this term's force and d(w.F)/dx are added onto them in the same launch."""
         if not self.builtin():
             out = self._module_force_vjp(xyz.detach().contiguous(), w.detach().contiguous(), want_theta)
+            if into is not None:
+                out = (into[0].add_(out[0]), into[1].add_(out[1]), out[2])
             if accum is None or out[2] is None:
                 return out
             _accumulate_list(accum, self.parameters(), out[2])
             return out[0], out[1], None
         theta, params = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, w=w.detach().contiguous(),
-                          energy=False, grad=True)
+                          energy=False, grad=True, into=into, scale=-1.0)
         if accum is not None and want_theta:
             if params:
                 jobs, pos = ops.GradJobs(), 0
@@ -331,13 +346,13 @@ class PairPotentials(GeneralInteraction):
                         jobs.axpy(o_, o["gtheta_w"][pos:pos + p.numel()])
                         pos += p.numel()
                 jobs.run(accum, alpha=-1.0, accumulate=True)
-            return -o["grad"], -o["hw"], None
+            return o["grad"], o["hw"], None
         gth, pos = [], 0
         for p in params:
             n = p.numel()
             gth.append(-o["gtheta_w"][pos:pos + n].reshape(p.shape))
             pos += n
-        return -o["grad"], -o["hw"], gth
+        return o["grad"], o["hw"], gth
 
     def forward(self, xyz):
         if self.builtin():
@@ -426,9 +441,21 @@ class Stack(torch.nn.Module):
     def supports_force_vjp(self):
         return all(getattr(m, "supports_force_vjp", lambda: False)() for m in self.models.values())
 
+    def prepare_pass(self):
+        for m in self.models.values():
+            getattr(m, "prepare_pass", lambda: None)()
+
+    def _ordered(self):
+        """Members that can add their result onto an existing buffer inside their own launch (pair terms) go last."""
+        ms = list(self.models.values())
+        return [m for m in ms if not getattr(m, "accepts_into", False)] + [m for m in ms if getattr(m, "accepts_into", False)]
+
     def force(self, x):
         out = None
-        for m in self.models.values():
+        for m in self._ordered():
+            if out is not None and getattr(m, "accepts_into", False):
+                out = m.force(x, into=out)
+                continue
             f = m.force(x)
             out = f if out is None else out + f
         return out
@@ -441,18 +468,24 @@ class Stack(torch.nn.Module):
         them, sovlers.py:141-143) -- or are added into `accum` (ops.ThetaAccum) by the members themselves."""
         F = dq = None
         by_id = {}
-        for m in self.models.values():
+        for m in self._ordered():
+            kw = {}
+            if F is not None and getattr(m, "accepts_into", False):
+                kw["into"] = (F, dq)                                   # this member's launch adds onto the running sums
             if accum is not None and want_theta:
                 if getattr(m, "accepts_accum", False):
-                    f, g, gth = m.force_vjp(x, w, want_theta=True, accum=accum)
+                    f, g, gth = m.force_vjp(x, w, want_theta=True, accum=accum, **kw)
                 else:
-                    f, g, gth = m.force_vjp(x, w, want_theta=True)
+                    f, g, gth = m.force_vjp(x, w, want_theta=True, **kw)
                 if gth is not None:
                     _accumulate_list(accum, m.parameters(), gth)
             else:
-                f, g, gth = m.force_vjp(x, w, want_theta=want_theta)
-            F = f if F is None else F + f
-            dq = g if dq is None else dq + g
+                f, g, gth = m.force_vjp(x, w, want_theta=want_theta, **kw)
+            if "into" in kw:
+                F, dq = f, g
+            else:
+                F = f if F is None else F + f
+                dq = g if dq is None else dq + g
             if want_theta and accum is None:
                 for p, gp in zip(m.parameters(), gth):
                     by_id[id(p)] = gp if id(p) not in by_id else by_id[id(p)] + gp

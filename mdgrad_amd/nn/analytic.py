@@ -17,7 +17,8 @@ of its primal (rdb = dU/dr, mdb = dU/dm, ..., dd_b = dU/dd) and the force -dU/dx
 Edge level (everything of size [E, .]): the fused interaction-block kernels of csrc/cfconv_fused.hip -- filter
 network on the MFMA, gather-multiply-sum per atom, and the adjoints with the filter recomputed -- so no
 [E,G] / [E,F] tensor exists.  Node level ([N, .]): GEMMs + small fused elementwise kernels.  Shapes the fused
-kernels do not take (n_filters > 128, n_gaussians > 64) run the unfused chain (`_force_vjp_unfused`): graph
+kernels do not take (n_gaussians > 64, n_filters not a multiple of 128 above 128 or above 512) run the unfused chain
+(`_force_vjp_unfused`): graph
 kernels of csrc/graph.hip, the split-K A^T B kernel and library GEMMs.
 
 Notation follows SURVEY A.9 / nff/nn/models/schnet.py:113-171 (reference parameter names in
@@ -250,16 +251,30 @@ def _dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None
 
 @torch.no_grad()
 def _embedded(net, z):
-    """atom_embed.weight[z], kept until the weights (an optimizer step bumps their version) or the species change: a
-    trajectory evaluates it three times per MD step on the same inputs."""
+    """atom_embed.weight[z] in a persistent buffer, refreshed in place when the weights (an optimizer step bumps their
+    version) or the species change: a trajectory evaluates it three times per MD step on the same inputs.  Inside a
+    HIP-graph capture the buffer is returned as it is -- the replaying pass refreshes it once before its first replay
+    (`refresh_embedding`, called through the interaction's `prepare_pass`), so the captured steps carry no gather."""
     wt = net.atom_embed.weight
+    buf = getattr(net, "_embed_buf", None)
+    shape = (z.shape[0], wt.shape[1])
+    if buf is None or tuple(buf.shape) != shape or buf.device != wt.device:
+        if wt.is_cuda and torch.cuda.is_current_stream_capturing():
+            return wt.detach()[z]                # (no buffer yet: the gather becomes part of this graph)
+        buf = net._embed_buf = torch.empty(shape, device=wt.device, dtype=wt.dtype)
+        net._embed_key = None
     if wt.is_cuda and torch.cuda.is_current_stream_capturing():
-        return wt.detach()[z]                    # (inside a HIP-graph capture the gather must be part of the graph)
+        return buf
     key = (wt.data_ptr(), wt._version, z.data_ptr(), z._version, tuple(z.shape))
-    c = getattr(net, "_embed_cache", None)
-    if c is None or c[0] != key:
-        c = net._embed_cache = (key, wt.detach()[z])
-    return c[1]
+    if getattr(net, "_embed_key", None) != key:
+        torch.index_select(wt.detach(), 0, z, out=buf)
+        net._embed_key = key
+    return buf
+
+
+def refresh_embedding(net, z):
+    """Bring the persistent embedding rows up to date (before the graph replays of a pass)."""
+    _embedded(net, z)
 
 
 def _forward_fused(net, z, x, topo, w=None, want_sums=False, want_energy=True):
@@ -325,7 +340,8 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accu
         jobs.atb(off(ro[0].weight), yb, fw["r"], ydb, rd)
         jobs.colsum(off(ro[0].bias), yb)
     rdb, _, rb = _dense(L1, ydb, trans=True, x1=yb)
-    d_b, dd_b = torch.zeros_like(d), torch.zeros_like(d)
+    both = torch.zeros(2, d.shape[0], device=d.device, dtype=d.dtype)        # (one fill for the two per-edge accumulators)
+    d_b, dd_b = both[0], both[1]
     convs = list(net.convolutions)
     for idx in range(len(convs) - 1, -1, -1):
         L, md_ = fw["layers"][idx], convs[idx].moduledict

@@ -162,8 +162,10 @@ def make_term(desc, cutoff, theta_off=0, n_theta=0, mask=None):
     return t
 
 
-def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True):
-    """One launch of mdg_pair_eval_ell.  Returns dict with the requested outputs."""
+def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True, into=None, scale=1.0):
+    """One launch of mdg_pair_eval_ell.  Returns dict with the requested outputs.  `into` = (grad_buffer, hw_buffer or
+    None): the per-atom outputs are ADDED onto those buffers, times `scale` (F += -dU/dx of a Stack member without extra
+    launches); without `into`, `scale` multiplies the fresh outputs."""
     lib = _lib.load()
     require_gpu(xyz, "xyz")
     if theta is not None and theta.numel():
@@ -176,15 +178,22 @@ def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True):
     N, K = ell.n_atoms, term.n_theta
     out = {}
     e = torch.empty(1, device=dev) if energy else None
-    g = torch.empty(N, 3, device=dev) if grad else None
+    acc = into is not None
+    g = (into[0] if acc else torch.empty(N, 3, device=dev)) if grad else None
     gth = torch.empty(K, device=dev) if (grad and K) else None
-    hw = torch.empty(N, 3, device=dev) if w is not None else None
+    hw = (into[1] if acc else torch.empty(N, 3, device=dev)) if w is not None else None
     gthw = torch.empty(K, device=dev) if (w is not None and K) else None
     partial = torch.empty(int(lib.mdg_pair_partial_size(N)), device=dev)
-    check(lib.mdg_pair_eval_ell(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
-                                ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
-                                ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), stream_ptr(dev)),
-          "mdg_pair_eval_ell")
+    if acc or scale != 1.0:
+        check(lib.mdg_pair_eval_ell_into(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
+                                         ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
+                                         ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), float(scale), int(acc),
+                                         stream_ptr(dev)), "mdg_pair_eval_ell_into")
+    else:
+        check(lib.mdg_pair_eval_ell(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
+                                    ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
+                                    ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), stream_ptr(dev)),
+              "mdg_pair_eval_ell")
     out.update(energy=e, grad=g, gtheta=gth, hw=hw, gtheta_w=gthw)
     return out
 
