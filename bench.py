@@ -606,12 +606,15 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     useful = 2.0 * (2 * E) * 2.0 * G_ * (G_ + F_)                            # directed slots x (primal + tangent)
     step_flops = 21.0 * schnet_flops_forward(N, E / R, A_, F_, G_, NC) * R * (T - 1)
     std = R == 8 and T == 11 and bool(args.bf16)
-    cnt, why = _counters("schnet4096", "cfconv_bwd_kernel<32, 8, true, true>") if std else (None, "other geometry")
+    bname = "cfconv_bwd_bf16_kernel<32, 8, true, true>" if args.bf16 else "cfconv_bwd_kernel<32, 8, true, true>"
+    cnt, why = _counters("schnet4096", bname) if std else (None, "other geometry")
+    bpeak = MFMA_BF16_PEAK_TF if args.bf16 else MFMA_F32_PEAK_TF
     out["roofline"] = {
-        "bound": "mfma", "kernel": "cfconv_bwd_kernel<32,8,true,true> (reverse sweep of the filter network with parameter "
-                                   "gradients: the largest share of the pass)",
-        "achieved": exec_bwd / (kb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-        "frac": exec_bwd / (kb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, "kernel_ms": kb_ms,
+        "bound": "mfma", "kernel": bname.replace(", ", ",") + " (reverse sweep of the filter network with parameter gradients: "
+                                   "with the forward + tangent sweep the largest share of the pass)",
+        "achieved": exec_bwd / (kb_ms * 1e-3) / 1e12, "peak": bpeak, "unit": "TFLOP/s",
+        "frac": exec_bwd / (kb_ms * 1e-3) / 1e12 / bpeak, "kernel_ms": kb_ms,
+        "frac_of_f32_mfma_peak": exec_bwd / (kb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
         "traffic": cnt.get("hbm_bytes_per_launch") if cnt else None,
         "share_of_pass": cnt.get("share") if cnt else None, "mfma_busy": cnt.get("mfma_busy") if cnt else None,
         "valu_busy": cnt.get("valu_busy") if cnt else None, "wait_frac": cnt.get("wait_frac") if cnt else None,
@@ -621,8 +624,11 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                            "frac": executed / (k_ms * 1e-3) / 1e12 / peak, "useful_tflops": useful / (k_ms * 1e-3) / 1e12},
         "step_mfma_frac": step_flops / (el / steps) / 1e12 / MFMA_F32_PEAK_TF,
         "step_tflops": step_flops / (el / steps) / 1e12,
-        "note": "achieved = %d 16-edge tiles x %d v_mfma_f32_16x16x4_f32 x 2048 flop (the filter network is recomputed from d: "
-                "nothing edge-sized was saved) over the kernel time (HIP events); counters of the same kernel from "
+        "note": "achieved = %d 16-edge tiles x %d x 2048 flop -- the arithmetic of the f32 kernel's v_mfma_f32_16x16x4_f32 count; the "
+                "bf16 kernel does the same products in 80 wider instructions, and its fraction of the 2.5 PF bf16 peak is small "
+                "by construction: the sweep is bound by its gathers (4-8 node rows per edge) and fp32 VALU work, see mfma_busy / "
+                "valu_busy / wait_frac (the filter network is recomputed from d: "
+                "nothing edge-sized was saved) -- over the kernel time (HIP events); counters of the same kernel from "
                 "profiles/pmc_schnet4096.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x duration x 2.4 GHz), FETCH / WRITE).  "
                 "forward_kernel: %d 16-slot tiles x %d %s flop (G padded to %d; every undirected edge is evaluated from both "
                 "ends), E = %d edges%s.  step_* = SURVEY 8d's 21 x forward flops per MD step over the measured step time, "

@@ -129,6 +129,20 @@ int mdg_nbr_half_fill_padded(const int32_t* col, const int32_t* shift, const int
                              float pad_offset, int64_t* nbr, float* offsets, int32_t* edge_id,
                              int32_t* n_valid, int32_t* need, void* stream);
 
+/* Verlet reuse of a fixed-capacity list (extension; the reference rebuilds at every call, torchmd/md.py:200-204).  One call per
+ * force evaluation, no host synchronisation: the list is searched with list_cutoff = cutoff + skin and kept while every atom
+ * stays within half_skin of where it was built -- decided on the device (state[0]); the builder launches return at their
+ * first instruction otherwise, so a captured HIP graph replays the same nodes either way.  Consumers re-apply the exact
+ * cutoff per pair with the builders' own arithmetic (mdg_edge_geom_masked, mdg_pair_eval_ell_into's recheck bit): the pair
+ * set of every evaluation is the one a fresh search at `cutoff` finds.  state int32[4], zero-initialised once (state[3]
+ * counts the builds); pos_build [N,3] initialised with NaN; need int32[2] as in the fixed-capacity builders; the remaining
+ * buffers are those of mdg_nbr_build_*_groups / mdg_nbr_half_count / mdg_nbr_half_fill_padded, all persistent. */
+int mdg_nbr_verlet_rebuild(const float* pos, int n_atoms, int group, const MdgCell* cell /*host*/, float list_cutoff,
+                           float half_skin, const uint8_t* mask, int use_cell_list, int32_t* col, int32_t* shift, int32_t* cnt,
+                           int max_nbr, int64_t capacity, float pad_offset, int64_t* nbr, float* offsets, int32_t* edge_id,
+                           int32_t* n_valid, int32_t* need, float* pos_build, int32_t* state, int32_t* row_base,
+                           int32_t* scratch, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K2-K4  pair energy / gradient / Hessian-vector product over an ELL list
  * (replaces compute_dis + pair form + .sum() and both autograd passes through them:
@@ -153,7 +167,9 @@ int mdg_pair_eval_ell(const float* pos, int n_atoms, const MdgCell* cell /*host*
                       float* partial, void* stream);
 /* the same with the per-atom outputs scaled and (accumulate != 0) added onto existing values:
  *   grad = (accumulate ? grad : 0) + out_scale * dU/dx ,  hw likewise -- the force sum of a Stack
- *   (torchmd/interface.py:396-401) without extra launches: F += -dU/dx of this term */
+ *   (torchmd/interface.py:396-401) without extra launches: F += -dU/dx of this term.  accumulate bit 1 (value 2): the list
+ *   was searched with a skin (mdg_nbr_verlet_rebuild); every pair is re-tested with the list builders' own arithmetic
+ *   (D = x_j - x_i, reference minimum image, un-contracted d^2 < cutoff^2) before it counts */
 int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCell* cell /*host*/,
                       const int32_t* col, const int32_t* shift, const int32_t* cnt, int max_nbr,
                       const MdgPairTerm* term /*host*/, const float* theta,
@@ -405,6 +421,10 @@ typedef struct {
 int mdg_cfconv_supported(int n_gauss, int n_filters);
 int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
                   float* d, float* uhat, float* dd, float* ddel, void* stream);
+/* mdg_edge_geom for a list searched with a skin: pairs that fail the builders' cutoff test at the current positions get
+ * d = -1 (and dd = 0) and are skipped by the cfconv kernels like padding */
+int mdg_edge_geom_masked(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                         const MdgCell* cell /*host*/, float cutoff, float* d, float* uhat, float* dd, float* ddel, void* stream);
 int mdg_edge_geom_bwd(const float* d_b, const float* dd_b, const float* d, const float* dd, const float* uhat,
                       const float* ddel, const int32_t* col, const int32_t* eid, const int32_t* cnt,
                       int n_atoms, int max_nbr, float* force, float* dwf, void* stream);

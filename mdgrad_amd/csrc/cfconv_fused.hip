@@ -181,9 +181,14 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
         for (int t0 = 0; t0 < cnt; t0 += 16) {
             // ---- A-layout row (slot t0 + li): distance (and its tangent)
-            const bool va = t0 + li < cnt;
-            const int ea = va ? A.eid[rowb + t0 + li] : 0;
-            const float da = va ? A.d[ea] : PAD_D;
+            const bool vin = t0 + li < cnt;
+            const int ea = vin ? A.eid[rowb + t0 + li] : 0;
+            const float draw = vin ? A.d[ea] : -1.f;
+            // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
+            // d = -1 and they are skipped like the slots past the row's end
+            const bool va = draw >= 0.f;
+            const unsigned long long live = __ballot(va);            // bit s (lanes 0..15): slot t0 + s is a real neighbour
+            const float da = va ? draw : PAD_D;
             float dda = 0.f;
             if (TANGENT) dda = va ? A.dd[ea] : 0.f;
             // ---- C-layout rows (slots t0 + 4 lk + r): gathered node rows, FT consecutive filters per lane
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
-                const bool vc = s < cnt;
+                const bool vc = (live >> (4 * lk + r)) & 1ull;
                 const int j = vc ? A.col[rowb + s] : 0;
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
@@ -361,16 +366,21 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
         for (int t0 = 0; t0 < cnt; t0 += 16) {
-            const bool va = t0 + li < cnt;
-            const int ea = va ? A.eid[rowb + t0 + li] : 0;
-            const float da = va ? A.d[ea] : PAD_D;
+            const bool vin = t0 + li < cnt;
+            const int ea = vin ? A.eid[rowb + t0 + li] : 0;
+            const float draw = vin ? A.d[ea] : -1.f;
+            // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
+            // d = -1 and they are skipped like the slots past the row's end
+            const bool va = draw >= 0.f;
+            const unsigned long long live = __ballot(va);            // bit s (lanes 0..15): slot t0 + s is a real neighbour
+            const float da = va ? draw : PAD_D;
             float dda = 0.f;
             if (TANGENT) dda = va ? A.dd[ea] : 0.f;
             float hreg[4][FT], hdreg[4][FT];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
-                const bool vc = s < cnt;
+                const bool vc = (live >> (4 * lk + r)) & 1ull;
                 const int j = vc ? A.col[rowb + s] : 0;
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
@@ -557,9 +567,10 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
         const long long ea = e0 + li;
         long long ia = -1, ja = -1;
         if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
-        const bool va = ia >= 0;                                  // (-1: padding row of a fixed-capacity list)
+        const float draw = ia >= 0 ? A.d[ea] : -1.f;             // (-1: padding row of a fixed-capacity list)
+        const bool va = draw >= 0.f;                              // (d = -1: a pair of a stored list that is beyond the cutoff now)
         if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
-        const float da = va ? A.d[ea] : PAD_D;
+        const float da = va ? draw : PAD_D;
         float dda = 0.f;
         if (DUAL) dda = va ? A.dd[ea] : 0.f;
         // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
@@ -892,9 +903,10 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
         const long long ea = e0 + li;
         long long ia = -1, ja = -1;
         if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
-        const bool va = ia >= 0;                                  // (-1: padding row of a fixed-capacity list)
+        const float draw = ia >= 0 ? A.d[ea] : -1.f;             // (-1: padding row of a fixed-capacity list)
+        const bool va = draw >= 0.f;                              // (d = -1: a pair of a stored list that is beyond the cutoff now)
         if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
-        const float da = va ? A.d[ea] : PAD_D;
+        const float da = va ? draw : PAD_D;
         float dda = 0.f;
         if (DUAL) dda = va ? A.dd[ea] : 0.f;
         // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
@@ -1189,13 +1201,24 @@ __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nre
 // ============================================================================================ geometry
 // d_e = |x_i - x_j - o_e| (nff/nn/models/schnet.py:142, raw image flags by default), unit vector, and for the
 // tangent sweep dd_e = uhat . (w_i - w_j).  Padding rows (i = -1): |delta| = |o| (= 1e4), tangent 0.
+// MASK: the list was searched with a skin (mdg_nbr_verlet_rebuild); a pair counts only while the builders' own test holds at
+// the current positions -- D = x_j - x_i, reference minimum image, un-contracted d^2 < rc^2 and != 0 (topology.py:59-67):
+// the same arithmetic, so the pair set is the one a fresh search at the cutoff finds.  Pairs outside get d = -1.
+template <bool MASK, bool DIAG>
 __global__ void edge_geom_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                  const int64_t* __restrict__ nbr, const float* __restrict__ off, long long E,
                                  float* __restrict__ d, float* __restrict__ uhat, float* __restrict__ dd,
-                                 float* __restrict__ ddel) {
+                                 float* __restrict__ ddel, MdgCell cell, float rc2) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     const long long i = nbr[2 * e], j = nbr[2 * e + 1];
+    bool masked = false;
+    if (MASK && i >= 0) {
+        float bx = x[3 * j] - x[3 * i], by = x[3 * j + 1] - x[3 * i + 1], bz = x[3 * j + 2] - x[3 * i + 2];
+        min_image<DIAG>(cell, bx, by, bz);
+        const float b2 = norm2_ref(bx, by, bz);
+        masked = !((b2 < rc2) && (b2 != 0.f));
+    }
     float dx = -off[3 * e], dy = -off[3 * e + 1], dz = -off[3 * e + 2];
     float wx = 0.f, wy = 0.f, wz = 0.f;
     if (i >= 0) {
@@ -1205,10 +1228,10 @@ __global__ void edge_geom_kernel(const float* __restrict__ x, const float* __res
     const float r = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ir = 1.0f / r;
     const float ux = dx * ir, uy = dy * ir, uz = dz * ir;
-    d[e] = r;
+    d[e] = masked ? -1.f : r;
     uhat[3 * e] = ux; uhat[3 * e + 1] = uy; uhat[3 * e + 2] = uz;
     if (w) {
-        dd[e] = ux * wx + uy * wy + uz * wz;
+        dd[e] = masked ? 0.f : ux * wx + uy * wy + uz * wz;
         ddel[3 * e] = wx; ddel[3 * e + 1] = wy; ddel[3 * e + 2] = wz;
     }
 }
@@ -1315,8 +1338,25 @@ extern "C" int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr,
     MDG_CHECK_ARG(n_edges >= 0, "edge_geom: bad size");
     if (n_edges == 0) return MDG_OK;
     MDG_CHECK_ARG(x && nbr && offsets && d && uhat && (!w || (dd && ddel)), "edge_geom: null buffer");
-    hipLaunchKernelGGL(edge_geom_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
-                       nbr, offsets, (long long)n_edges, d, uhat, dd, ddel);
+    hipLaunchKernelGGL((edge_geom_kernel<false, true>), dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                       nbr, offsets, (long long)n_edges, d, uhat, dd, ddel, MdgCell{}, 0.f);
+    MDG_CHECK_LAUNCH("edge_geom_kernel");
+    return MDG_OK;
+}
+
+extern "C" int mdg_edge_geom_masked(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                                    const MdgCell* cell, float cutoff, float* d, float* uhat, float* dd, float* ddel,
+                                    void* stream) {
+    MDG_CHECK_ARG(n_edges >= 0 && cell && cutoff > 0.f, "edge_geom_masked: bad arguments");
+    if (n_edges == 0) return MDG_OK;
+    MDG_CHECK_ARG(x && nbr && offsets && d && uhat && (!w || (dd && ddel)), "edge_geom_masked: null buffer");
+    const dim3 grid((unsigned)((n_edges + 255) / 256));
+    if (cell->diag)
+        hipLaunchKernelGGL((edge_geom_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w, nbr, offsets,
+                           (long long)n_edges, d, uhat, dd, ddel, *cell, cutoff * cutoff);
+    else
+        hipLaunchKernelGGL((edge_geom_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, nbr, offsets,
+                           (long long)n_edges, d, uhat, dd, ddel, *cell, cutoff * cutoff);
     MDG_CHECK_LAUNCH("edge_geom_kernel");
     return MDG_OK;
 }

@@ -46,11 +46,14 @@ template <bool DIAG>
 __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, float rc2,
                                  const uint8_t* __restrict__ mask, int32_t* __restrict__ col,
                                  int32_t* __restrict__ shift, int32_t* __restrict__ cnt, int max_nbr,
-                                 int32_t* __restrict__ overflow) {
+                                 int32_t* __restrict__ overflow, const int32_t* __restrict__ gate = nullptr,
+                                 float* __restrict__ pos_build = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int lane = threadIdx.x & 63;
     const int i = xcd_chunk(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // XCD-aware atom order
     if (i >= N) return;
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
+    if (pos_build && lane < 3) pos_build[3 * i + lane] = pos[3 * i + lane];      // where this list was built
     const int g0 = (i / group) * group, g1 = min(N, g0 + group);
     int base = 0;
     for (int j0 = g0; j0 < g1; j0 += 64) {
@@ -96,9 +99,12 @@ __device__ __forceinline__ int bin_coord(float x, float inv, int nb) {
 // (replica-stacked systems: every group of `group` consecutive atoms has its own set of bins, group g owning
 //  bins [g ncell, (g+1) ncell) -- pairs never cross groups)
 __global__ void bin_count_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, Bins bins,
-                                 int32_t* __restrict__ atom_bin, int32_t* __restrict__ bin_cnt) {
+                                 int32_t* __restrict__ atom_bin, int32_t* __restrict__ bin_cnt,
+                                 const int32_t* __restrict__ gate = nullptr, float* __restrict__ pos_build = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    if (pos_build) { pos_build[3 * i] = pos[3 * i]; pos_build[3 * i + 1] = pos[3 * i + 1]; pos_build[3 * i + 2] = pos[3 * i + 2]; }
     const int bx = bin_coord(pos[3 * i], cell.inv[0], bins.nb[0]);
     const int by = bin_coord(pos[3 * i + 1], cell.inv[4], bins.nb[1]);
     const int bz = bin_coord(pos[3 * i + 2], cell.inv[8], bins.nb[2]);
@@ -112,7 +118,9 @@ __global__ void bin_count_kernel(const float* __restrict__ pos, int N, int group
 // give the segment offsets, pass 2 re-reads the segment in 64-item chunks (L2 hits) and writes the running wave scan --
 // two barriers whatever n (the chunk-by-chunk version it replaces took 3 block barriers per 1 024 items: 37 us for the
 // 32 768 row counts of eight stacked 4 096-bead replicas).
-__global__ void scan_kernel(const int32_t* in, int n, int32_t* out, int32_t* __restrict__ cursor) {
+__global__ void scan_kernel(const int32_t* in, int n, int32_t* out, int32_t* __restrict__ cursor,
+                            const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     __shared__ int32_t wsum[16];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int seg = ((n + nw - 1) / nw + 63) / 64 * 64;            // items per wave, a multiple of the chunk
@@ -138,7 +146,8 @@ __global__ void scan_kernel(const int32_t* in, int n, int32_t* out, int32_t* __r
 }
 
 __global__ void bin_fill_kernel(const int32_t* __restrict__ atom_bin, int N, int32_t* __restrict__ cursor,
-                                int32_t* __restrict__ sorted_atoms) {
+                                int32_t* __restrict__ sorted_atoms, const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const int slot = atomicAdd(&cursor[atom_bin[i]], 1);
@@ -151,7 +160,9 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group,
                                 const uint8_t* __restrict__ mask, const int32_t* __restrict__ atom_bin,
                                 const int32_t* __restrict__ bin_start, const int32_t* __restrict__ sorted_atoms,
                                 int32_t* __restrict__ col, int32_t* __restrict__ shift,
-                                int32_t* __restrict__ cnt, int max_nbr, int32_t* __restrict__ overflow) {
+                                int32_t* __restrict__ cnt, int max_nbr, int32_t* __restrict__ overflow,
+                                const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     int32_t* bj = sm + wid * 2 * ROW_CAP;
@@ -218,7 +229,8 @@ __device__ __forceinline__ int first_greater(const int32_t* __restrict__ row, in
 }
 
 __global__ void half_count_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ cnt, int N,
-                                  int max_nbr, int32_t* __restrict__ row_half) {
+                                  int max_nbr, int32_t* __restrict__ row_half, const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     row_half[i] = cnt[i] - first_greater(col + (size_t)i * max_nbr, cnt[i], i);
@@ -227,7 +239,8 @@ __global__ void half_count_kernel(const int32_t* __restrict__ col, const int32_t
 __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ shift,
                                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ row_base,
                                  int N, int max_nbr, int64_t* __restrict__ nbr, float* __restrict__ offsets,
-                                 int32_t* __restrict__ edge_id, long long capacity) {
+                                 int32_t* __restrict__ edge_id, long long capacity, const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int i = blockIdx.x;
     const int32_t* row = col + (size_t)i * max_nbr;
     const int n = cnt[i];
@@ -265,7 +278,8 @@ __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t*
 // "distance" far outside any radial basis; P > capacity is reported through need[0] (atomic max).
 __global__ void half_pad_kernel(const int32_t* __restrict__ row_base, int N, long long capacity, float pad_offset,
                                 int64_t* __restrict__ nbr, float* __restrict__ offsets, int32_t* __restrict__ n_valid,
-                                int32_t* __restrict__ need) {
+                                int32_t* __restrict__ need, const int32_t* __restrict__ gate = nullptr) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const long long P = row_base[N];
     const long long e = P + (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -275,6 +289,40 @@ __global__ void half_pad_kernel(const int32_t* __restrict__ row_base, int N, lon
     if (e >= capacity) return;
     nbr[2 * e] = -1; nbr[2 * e + 1] = -1;
     offsets[3 * e] = pad_offset; offsets[3 * e + 1] = 0.f; offsets[3 * e + 2] = 0.f;
+}
+
+// ---------------------------------------------------------------------------- Verlet reuse of a stored list
+// state[0] <- 1 when some atom is farther than `thr` from where the stored list was built (or the list has never been
+// built: pos_build holds NaN), else 0; state[3] counts the builds.  state[1] / state[2] are the flag / ticket words of the
+// last-block pattern (left zero for the next call).  No float atomics; the result does not depend on block order.
+__global__ void verlet_check_kernel(const float* __restrict__ pos, const float* __restrict__ pos_build, int N, float thr2,
+                                    int32_t* __restrict__ state) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool far = false;
+    if (i < N) {
+        const float dx = pos[3 * i] - pos_build[3 * i], dy = pos[3 * i + 1] - pos_build[3 * i + 1],
+                    dz = pos[3 * i + 2] - pos_build[3 * i + 2];
+        far = !(dx * dx + dy * dy + dz * dz <= thr2);            // (NaN compares false: a list never built is rebuilt)
+    }
+    const int any = __syncthreads_or(far ? 1 : 0);
+    if (threadIdx.x != 0) return;
+    if (any) atomicOr(&state[1], 1);
+    __threadfence();
+    const int ticket = atomicAdd(&state[2], 1);
+    if (ticket == (int)gridDim.x - 1) {
+        const int all = atomicOr(&state[1], 0);
+        state[0] = all ? 1 : 0;
+        if (all) state[3] += 1;
+        state[1] = 0;
+        state[2] = 0;
+        __threadfence();
+    }
+}
+
+__global__ void zero_i32_kernel(int32_t* __restrict__ p, int n, const int32_t* __restrict__ gate) {
+    if (gate && gate[0] == 0) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
 }
 
 }  // namespace
@@ -402,5 +450,72 @@ extern "C" int mdg_nbr_half_fill_padded(const int32_t* col, const int32_t* shift
     hipLaunchKernelGGL(half_pad_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, row_base,
                        n_atoms, (long long)capacity, pad_offset, nbr, offsets, n_valid, need);
     MDG_CHECK_LAUNCH("nbr_half_fill_padded");
+    return MDG_OK;
+}
+
+// Fixed-capacity list (per-atom rows + padded half list) with Verlet reuse, one call per force evaluation and no host
+// synchronisation: the list is searched with `list_cutoff` = cutoff + skin and kept while every atom stays within
+// `half_skin` of where it was built (verlet_check_kernel decides on the device; the builder launches below return at
+// their first instruction otherwise -- a captured HIP graph replays the same nodes either way).  Consumers re-apply the
+// exact cutoff per pair (mdg_edge_geom_masked, mdg_pair_eval_ell_into's recheck bit), so the pair set of every evaluation
+// is the one a fresh search at `cutoff` finds.  state: int32[4] (zero-initialised once; state[3] counts the builds),
+// pos_build [N,3] initialised with NaN.  The other buffers are the ones mdg_nbr_build_*_groups / mdg_nbr_half_count /
+// mdg_nbr_half_fill_padded take, all persistent.
+extern "C" int mdg_nbr_verlet_rebuild(const float* pos, int n_atoms, int group, const MdgCell* cell, float list_cutoff,
+                                      float half_skin, const uint8_t* mask, int use_cell_list, int32_t* col, int32_t* shift,
+                                      int32_t* cnt, int max_nbr, int64_t capacity, float pad_offset, int64_t* nbr,
+                                      float* offsets, int32_t* edge_id, int32_t* n_valid, int32_t* need, float* pos_build,
+                                      int32_t* state, int32_t* row_base, int32_t* scratch, void* stream) {
+    MDG_CHECK_ARG(pos && cell && col && shift && cnt && nbr && offsets && edge_id && n_valid && need && pos_build && state &&
+                  row_base, "nbr_verlet_rebuild: null buffer");
+    MDG_CHECK_ARG(n_atoms > 0 && max_nbr > 0 && list_cutoff > 0.f && half_skin >= 0.f && capacity > 0, "nbr_verlet_rebuild: bad sizes");
+    MDG_CHECK_ARG(group > 0 && n_atoms % group == 0, "nbr_verlet_rebuild: n_atoms must be a multiple of the group size");
+    hipStream_t st = (hipStream_t)stream;
+    const int tb = 256;
+    hipLaunchKernelGGL(verlet_check_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, (const float*)pos_build, n_atoms,
+                       half_skin * half_skin, state);
+    const int32_t* gate = state;
+    const float rc2 = list_cutoff * list_cutoff;
+    if (use_cell_list) {
+        MDG_CHECK_ARG(scratch, "nbr_verlet_rebuild: the cell-list search needs its scratch");
+        MDG_CHECK_ARG(cell->diag, "nbr_verlet_rebuild: cell lists take orthorhombic cells only");
+        Bins bins = make_bins(*cell, list_cutoff);
+        const int nbins_total = bins.ncell * (n_atoms / group);
+        MDG_CHECK_ARG(bins.nb[0] >= 3 && bins.nb[1] >= 3 && bins.nb[2] >= 3, "nbr_verlet_rebuild: box shorter than 3 list cutoffs");
+        MDG_CHECK_ARG(max_nbr <= ROW_CAP, "nbr_verlet_rebuild: max_nbr > %d", ROW_CAP);
+        int32_t* atom_bin = scratch;
+        int32_t* sorted_atoms = atom_bin + n_atoms;
+        int32_t* bin_cnt = sorted_atoms + n_atoms;
+        int32_t* bin_start = bin_cnt + nbins_total + 1;
+        int32_t* cursor = bin_start + nbins_total + 1;
+        hipLaunchKernelGGL(zero_i32_kernel, dim3((nbins_total + 1 + tb - 1) / tb), dim3(tb), 0, st, bin_cnt, nbins_total + 1, gate);
+        hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, group, *cell, bins,
+                           atom_bin, bin_cnt, gate, pos_build);
+        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)bin_cnt, nbins_total, bin_start, cursor, gate);
+        hipLaunchKernelGGL(bin_fill_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, (const int32_t*)atom_bin, n_atoms, cursor,
+                           sorted_atoms, gate);
+        const int wpb = 4;
+        const size_t lds = sizeof(int32_t) * 2 * ROW_CAP * wpb;
+        hipLaunchKernelGGL(nbr_cell_kernel, dim3((n_atoms + wpb - 1) / wpb), dim3(64 * wpb), lds, st, pos, n_atoms, group, *cell,
+                           bins, rc2, mask, (const int32_t*)atom_bin, (const int32_t*)bin_start, (const int32_t*)sorted_atoms, col,
+                           shift, cnt, max_nbr, need, gate);
+    } else {
+        const int wpb = 4;
+        dim3 grid((n_atoms + wpb - 1) / wpb), block(64 * wpb);
+        if (cell->diag)
+            hipLaunchKernelGGL(nbr_dense_kernel<true>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col, shift, cnt,
+                               max_nbr, need, gate, pos_build);
+        else
+            hipLaunchKernelGGL(nbr_dense_kernel<false>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col, shift, cnt,
+                               max_nbr, need, gate, pos_build);
+    }
+    hipLaunchKernelGGL(half_count_kernel, dim3((n_atoms + 255) / 256), dim3(256), 0, st, (const int32_t*)col, (const int32_t*)cnt,
+                       n_atoms, max_nbr, row_base, gate);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)row_base, n_atoms, row_base, (int32_t*)nullptr, gate);
+    hipLaunchKernelGGL(half_fill_kernel, dim3(n_atoms), dim3(64), 0, st, (const int32_t*)col, (const int32_t*)shift,
+                       (const int32_t*)cnt, (const int32_t*)row_base, n_atoms, max_nbr, nbr, offsets, edge_id, (long long)capacity, gate);
+    hipLaunchKernelGGL(half_pad_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, (const int32_t*)row_base, n_atoms,
+                       (long long)capacity, pad_offset, nbr, offsets, n_valid, need + 1, gate);
+    MDG_CHECK_LAUNCH("nbr_verlet_rebuild kernels");
     return MDG_OK;
 }

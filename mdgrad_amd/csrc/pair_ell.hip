@@ -20,6 +20,7 @@ struct EllArgs {
     MdgPairTerm term; const float* theta; const float* w;
     float* grad; float* hw; float* partial;
     float oscale; int oacc;      // grad / hw outputs: out = (oacc ? out : 0) + oscale * value  (force sums of a Stack)
+    int recheck;                 // the list was searched with a skin: re-apply the builders' exact cutoff test per pair
 };
 
 template <int LPA, int LEVEL>
@@ -41,6 +42,14 @@ __global__ void pair_ell_kernel(const EllArgs A) {
         for (int k = sub; k < n; k += LPA) {
             const int j = A.col[row + k];
             float dx = xi - A.pos[3 * j], dy = yi - A.pos[3 * j + 1], dz = zi - A.pos[3 * j + 2];
+            if (A.recheck) {
+                // the test of the list builders at the current positions (D = x_j - x_i, reference minimum image,
+                // un-contracted d^2: csrc/nbr.hip pair_test), so the pair set is the one a fresh search at the cutoff finds
+                float bx = -dx, by = -dy, bz = -dz;
+                if (A.cell.diag) min_image<true>(A.cell, bx, by, bz); else min_image<false>(A.cell, bx, by, bz);
+                const float b2 = norm2_ref(bx, by, bz);
+                if (!((b2 < tc.rc2) && (b2 != 0.f))) continue;
+            }
             apply_shift(A.cell, A.shift[row + k], dx, dy, dz);      // d = x_i - x_j - o.h
             PairOut o;
             float r, ir;
@@ -153,7 +162,9 @@ extern "C" int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCe
     MDG_CHECK_ARG(term->n_theta == 0 || theta, "pair_eval_ell: theta is null");
     MDG_CHECK_ARG(!w || hw, "pair_eval_ell: w given without hw output");
     const int level = w ? 2 : ((grad || gtheta) ? 1 : 0);
-    EllArgs a{pos, n_atoms, *cell, col, shift, cnt, max_nbr, *term, theta, w, grad, hw, partial, out_scale, accumulate};
+    // accumulate: bit 0 = add onto grad / hw, bit 1 = re-apply the exact cutoff test (Verlet lists)
+    EllArgs a{pos, n_atoms, *cell, col, shift, cnt, max_nbr, *term, theta, w, grad, hw, partial, out_scale, accumulate & 1,
+              (accumulate >> 1) & 1};
     const int lpa = pick_lpa(n_atoms);
     const int apb = 256 / lpa;
     const int nblocks = (n_atoms + apb - 1) / apb;

@@ -58,6 +58,25 @@ class GeneralInteraction(torch.nn.Module):
             cache[key] = ell
         return ell
 
+    # Verlet reuse of the fixed-capacity lists (graph replay / sync-free eager passes only): the list is searched with
+    # cutoff * (1 + verlet_skin) and kept while no atom has moved more than half the skin; consumers re-apply the exact
+    # cutoff, so every evaluation sees the pair set of a fresh search (ops.VerletList).  0 switches it off.
+    verlet_skin = 0.02
+
+    def _verlet_list(self, xyz, cache, st):
+        key = ("verlet", float(self.cutoff), None if self._mask is None else self._mask.data_ptr(), self._group)
+        if cache is not None and key in cache:
+            return cache[key]
+        vl = st.get("verlet")
+        sig = (int(st["max_nbr"]), int(st["capacity"]))
+        if vl is None or vl.sig != sig or vl.n_atoms != xyz.shape[0]:
+            vl = st["verlet"] = ops.VerletList(xyz.shape[0], self._group, self._cell_struct, self.cutoff,
+                                               self.verlet_skin * float(self.cutoff), self._mask, sig[0], sig[1], xyz.device)
+        vl.rebuild(xyz, st["need"])
+        if cache is not None:
+            cache[key] = vl
+        return vl
+
     # -- fixed-capacity neighbour lists (HIP-graph capture of the integrator steps, mdgrad_amd/graphs.py) --
     def supports_static_topology(self):
         return False
@@ -131,7 +150,9 @@ class GNNPotentials(GeneralInteraction):
     def _reset_topology(self, xyz, _cache=None):
         self._topo_stamp = object()                  # identity of this rebuild (see md._EOM.update_topology)
         st = self._static if self._static_on else None
-        if st is not None:
+        if st is not None and self.verlet_skin > 0 and self.supports_force_vjp():
+            topo = self._verlet_list(xyz, _cache, st).topo               # (rebuilt only when an atom left its half-skin ball)
+        elif st is not None:
             topo = ops.StaticTopo(self._shared_static_ell(xyz, _cache, st), st["capacity"], st["need"])
         else:
             topo = ops.GraphTopo(self._shared_ell(xyz, _cache))
@@ -147,8 +168,9 @@ class GNNPotentials(GeneralInteraction):
         if on and self._static is None:
             topo = self.inputs['_topo']
             longest = int(topo.ell.cnt.max().item())
-            self._static = dict(max_nbr=min(self._group - 1, (int(longest * 1.25) + 15) // 8 * 8),
-                                capacity=(int(topo.n_edges * 1.25) + 1023) // 1024 * 1024,
+            grow = 1.25 * (1.0 + self.verlet_skin) ** 3              # head room, and the skin's extra candidates
+            self._static = dict(max_nbr=min(self._group - 1, (int(longest * grow) + 15) // 8 * 8),
+                                capacity=(int(topo.n_edges * grow) + 1023) // 1024 * 1024,
                                 need=torch.zeros(2, dtype=torch.int32, device=self.device), version=0)
 
     def forward(self, xyz):
@@ -233,7 +255,10 @@ class PairPotentials(GeneralInteraction):
     def _reset_topology(self, xyz, _cache=None):
         self._topo_stamp = object()
         st = self._static if self._static_on else None
-        if st is not None:
+        vkey = ("verlet", float(self.cutoff), None if self._mask is None else self._mask.data_ptr(), self._group)
+        if st is not None and _cache is not None and vkey in _cache and self.builtin():
+            self._ell = _cache[vkey].ell             # a Stack member's Verlet list (exact cutoff re-applied per pair)
+        elif st is not None:
             self._ell = self._shared_static_ell(xyz, _cache, st)
         else:
             self._ell = self._shared_ell(xyz, _cache)
@@ -496,7 +521,9 @@ class Stack(torch.nn.Module):
     def _reset_topology(self, x):
         self._topo_stamp = object()
         shared = {}                          # one neighbour search per distinct (cutoff, selection, grouping)
-        for key in self.models.keys():
+        # (members that own a stored Verlet list go first, so that pair terms with the same cutoff can use it)
+        keys = sorted(self.models.keys(), key=lambda k: 0 if isinstance(self.models[k], GNNPotentials) else 1)
+        for key in keys:
             m = self.models[key]
             if isinstance(m, GeneralInteraction):
                 m._reset_topology(x, _cache=shared)

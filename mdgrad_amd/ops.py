@@ -184,11 +184,12 @@ def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True, into=None, 
     hw = (into[1] if acc else torch.empty(N, 3, device=dev)) if w is not None else None
     gthw = torch.empty(K, device=dev) if (w is not None and K) else None
     partial = torch.empty(int(lib.mdg_pair_partial_size(N)), device=dev)
-    if acc or scale != 1.0:
+    recheck = bool(getattr(ell, "verlet", False))        # a list searched with a skin: exact cutoff test per pair
+    if acc or scale != 1.0 or recheck:
         check(lib.mdg_pair_eval_ell_into(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
                                          ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
-                                         ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), float(scale), int(acc),
-                                         stream_ptr(dev)), "mdg_pair_eval_ell_into")
+                                         ptr(g), ptr(gth), ptr(hw), ptr(gthw), ptr(partial), float(scale),
+                                         int(acc) | (2 if recheck else 0), stream_ptr(dev)), "mdg_pair_eval_ell_into")
     else:
         check(lib.mdg_pair_eval_ell(ptr(xyz), N, C.byref(ell.cell_struct), ptr(ell.col), ptr(ell.shift),
                                     ptr(ell.cnt), ell.max_nbr, C.byref(term), ptr(theta), ptr(w), ptr(e),
@@ -896,6 +897,65 @@ class StaticTopo:
         self.n_atoms, self.n_edges = ell.n_atoms, int(capacity)
 
 
+class VerletList:
+    """Persistent fixed-capacity neighbour list with Verlet reuse (mdg_nbr_verlet_rebuild, csrc/nbr.hip): searched with
+    cutoff + skin, kept while every atom stays within skin / 2 of where it was built (decided on the device, no host
+    sync), consumed through the exact per-pair cutoff test (`edge_geom` masks, `pair_eval` re-checks) -- so every
+    evaluation sees the pair set a fresh search at the cutoff would find.  All buffers live as long as the object: a
+    captured HIP graph replays the same addresses."""
+
+    def __init__(self, n_atoms, group, cell_struct, cutoff, skin, mask, max_nbr, capacity, device):
+        lib = _lib.load()
+        self.n_atoms, self.group, self.cell_struct = int(n_atoms), int(group), cell_struct
+        self.cutoff, self.skin, self.mask = float(cutoff), float(skin), mask
+        self.list_cutoff = self.cutoff + self.skin
+        self.max_nbr, self.capacity = int(max_nbr), int(capacity)
+        self.sig = (self.max_nbr, self.capacity)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.col, self.shift = torch.zeros(n_atoms, max_nbr, **i32), torch.zeros(n_atoms, max_nbr, **i32)
+        self.cnt = torch.zeros(n_atoms, **i32)
+        self.nbr = torch.full((capacity, 2), -1, dtype=torch.int64, device=device)
+        self.offsets = torch.zeros(capacity, 3, device=device)
+        self.offsets[:, 0] = StaticTopo.PAD_OFFSET
+        self.eid = torch.zeros(n_atoms, max_nbr, **i32)
+        self.n_valid = torch.zeros(1, **i32)
+        self.row_base = torch.zeros(n_atoms + 1, **i32)
+        self.pos_build = torch.full((n_atoms, 3), float("nan"), device=device)
+        self.state = torch.zeros(4, **i32)
+        self.use_cell = bool(_use_cell_list(group, cell_struct, self.list_cutoff) and max_nbr <= 512)
+        ns = int(lib.mdg_nbr_cell_scratch_groups(n_atoms, group, C.byref(cell_struct), self.list_cutoff)) if self.use_cell else 1
+        self.scratch = torch.zeros(max(1, ns), **i32)
+        self.ell = EllList(n_atoms, max_nbr, self.col, self.shift, self.cnt, cell_struct, self.cutoff, mask)
+        self.ell.verlet = True
+        self.topo = _VerletTopo(self)
+
+    def rebuild(self, xyz, need):
+        """Decide on the device whether the stored list still serves `xyz`; search again if not."""
+        lib = _lib.load()
+        x = xyz.detach().contiguous()
+        check(lib.mdg_nbr_verlet_rebuild(ptr(x), self.n_atoms, self.group, C.byref(self.cell_struct), self.list_cutoff,
+                                         0.5 * self.skin, ptr(self.mask), int(self.use_cell), ptr(self.col), ptr(self.shift),
+                                         ptr(self.cnt), self.max_nbr, self.capacity, float(StaticTopo.PAD_OFFSET), ptr(self.nbr),
+                                         ptr(self.offsets), ptr(self.eid), ptr(self.n_valid), ptr(need), ptr(self.pos_build),
+                                         ptr(self.state), ptr(self.row_base), ptr(self.scratch), stream_ptr(x.device)),
+              "mdg_nbr_verlet_rebuild")
+
+    def builds(self):
+        """Searches so far (one host sync; diagnostics and tests)."""
+        return int(self.state[3].item())
+
+
+class _VerletTopo:
+    """The StaticTopo view of a VerletList (same attributes; `verlet` tells the geometry kernel to mask)."""
+
+    padded = True
+
+    def __init__(self, vl):
+        self.ell, self.nbr, self.offsets, self.eid, self.n_valid = vl.ell, vl.nbr, vl.offsets, vl.eid, vl.n_valid
+        self.n_atoms, self.n_edges = vl.n_atoms, vl.capacity
+        self.verlet = (vl.cell_struct, vl.cutoff)
+
+
 def _edge_diff(x, topo):
     lib = _lib.load()
     require_gpu(x, "x")
@@ -1167,8 +1227,9 @@ def edge_geom(x, topo, w=None):
     lib = _lib.load()
     require_gpu(x, "x")
     x = x.contiguous()
+    verlet = getattr(topo, "verlet", None)       # a list searched with a skin: pairs beyond the cutoff get d = -1
     tops = _torch_ops.get()
-    if tops is not None:
+    if tops is not None and verlet is None:
         d, uhat, dd, ddel = tops.edge_geom(x, w.contiguous() if w is not None else None, topo.nbr, topo.offsets)
         return (d, uhat, dd, ddel) if w is not None else (d, uhat, None, None)
     E, dev = topo.n_edges, x.device
@@ -1177,6 +1238,10 @@ def edge_geom(x, topo, w=None):
     if w is not None:
         w = w.contiguous()
         dd, ddel = torch.empty(E, device=dev), torch.empty(E, 3, device=dev)
+    if verlet is not None:
+        check(lib.mdg_edge_geom_masked(ptr(x), ptr(w), ptr(topo.nbr), ptr(topo.offsets), E, C.byref(verlet[0]), float(verlet[1]),
+                                       ptr(d), ptr(uhat), ptr(dd), ptr(ddel), stream_ptr(dev)), "mdg_edge_geom_masked")
+        return d, uhat, dd, ddel
     check(lib.mdg_edge_geom(ptr(x), ptr(w), ptr(topo.nbr), ptr(topo.offsets), E, ptr(d), ptr(uhat), ptr(dd), ptr(ddel),
                             stream_ptr(dev)), "mdg_edge_geom")
     return d, uhat, dd, ddel
