@@ -533,6 +533,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                             "positions, g(r), the %d-entry parameter gradient" % (T - 1, fa.numel())}
     for _ in range(warmup):
         step()
+    vl0 = (gnn._static or {}).get("verlet")
+    builds0 = vl0.builds() if vl0 is not None else None
     mdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -544,6 +546,13 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(q_last) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
+    vl1 = (gnn._static or {}).get("verlet")
+    nbr_info = None
+    if vl1 is not None and vl1 is vl0:
+        nbr_info = {"skin_A": vl1.skin, "searches_per_pass": (vl1.builds() - builds0) / float(steps),
+                    "force_evaluations_per_pass": 3 * (T - 1) + 1,
+                    "note": "stored list searched with cutoff + skin, kept while no bead has moved more than skin / 2 (device-side "
+                            "decision); every evaluation re-applies the exact cutoff per pair (tests/test_gpu_verlet.py)"}
     N = base.get_number_of_atoms()
     md_steps = R * (T - 1) * world * steps
     out = {"metric": "MD steps/sec (fwd+adjoint), 4096-bead SchNet CG water NHC", "value": md_steps / el,
@@ -557,6 +566,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
     if bf16_dev is not None:
         out["config"]["bf16_vs_f32"] = bf16_dev
+    if nbr_info is not None:
+        out["config"]["neighbour_list"] = nbr_info
     if rank != 0:
         return out
     # ---- roofline: (a) the kernel with the largest share of the pass (profiles/*schnet4096_kernel_stats.txt): the reverse

@@ -3,6 +3,7 @@ GeneralInteraction :33-57, PairPotentials :217-300, Stack :364-403 (GNNPotential
 mdgrad_amd.nn).  forward(xyz) -> energy; _reset_topology(xyz) rebuilds the neighbour list.
 """
 import inspect
+import os
 
 import torch
 from torch.nn import ModuleDict
@@ -61,7 +62,7 @@ class GeneralInteraction(torch.nn.Module):
     # Verlet reuse of the fixed-capacity lists (graph replay / sync-free eager passes only): the list is searched with
     # cutoff * (1 + verlet_skin) and kept while no atom has moved more than half the skin; consumers re-apply the exact
     # cutoff, so every evaluation sees the pair set of a fresh search (ops.VerletList).  0 switches it off.
-    verlet_skin = 0.02
+    verlet_skin = float(os.environ.get("MDG_VERLET_SKIN", "0.02"))
 
     def _verlet_list(self, xyz, cache, st):
         key = ("verlet", float(self.cutoff), None if self._mask is None else self._mask.data_ptr(), self._group)

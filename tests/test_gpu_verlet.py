@@ -95,6 +95,8 @@ def test_gnn_trajectory_reuses_its_list_and_matches_the_exact_list_path():
     assert graphs.enabled(integ)
     gnn = integ.model.models["gnn"]
     assert gnn.verlet_skin > 0
+    for m in integ.model.models.values():        # (this box moves ~0.05 A per evaluation under its random-init forces: a 1 A skin)
+        m.verlet_skin = 0.2
     out = _traj_and_grads(integ, system, t)
     vl = gnn._static["verlet"]
     evaluations = 3 * 12 + 4
