@@ -123,8 +123,11 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, long long ro
     }
 }
 
+// (occupancy: the register allocator is asked for three waves per SIMD where round 2's build had them -- 168 registers for
+//  the primal + tangent sweep; left alone it drifted to 224 = two waves after small edits, 253 -> 293 us at E = 459 k)
 template <int GP, int FT, bool TANGENT, bool SUMS>
-__global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? 2 : 3) : 4) : 1)))
+void cfconv_fwd_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;          // s16m32(GP) for GP in {16,32,48,64}
     constexpr int FP = 16 * FT;
@@ -187,7 +190,11 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
             const bool va = draw >= 0.f;
-            const unsigned long long live = __ballot(va);            // bit s (lanes 0..15): slot t0 + s is a real neighbour
+            // bit s (lanes 0..15) of the ballot: slot t0 + s is a real neighbour; mr[r] = 1 / 0 for the lane's four C-layout rows
+            const unsigned nib = ((unsigned)__ballot(va) >> (4 * lk)) & 0xFu;
+            float mr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) ? 1.f : 0.f;
             const float da = va ? draw : PAD_D;
             float dda = 0.f;
             if (TANGENT) dda = va ? A.dd[ea] : 0.f;
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
-                const bool vc = (live >> (4 * lk + r)) & 1ull;
-                const int j = vc ? A.col[rowb + s] : 0;
+                const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
+                const int j = vc ? A.col[rowb + s] : 0;           //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
@@ -233,10 +240,12 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
                 }
             }
             // (h1w / h1dw are private to the wave: program order + the LDS counter suffice, no barrier)
+            // a masked slot's row of the second layer is zeroed at its A fragment (the lane's own row li) and its bias below:
+            // W = 0 for it, whatever was gathered
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                af[ks] = h1w[li * SA + ks * 4 + lk];
-                if (TANGENT) adf[ks] = h1dw[li * SA + ks * 4 + lk];
+                af[ks] = va ? h1w[li * SA + ks * 4 + lk] : 0.f;
+                if (TANGENT) adf[ks] = va ? h1dw[li * SA + ks * 4 + lk] : 0.f;
             }
             // ---- layer 2 + multiply with the gathered rows + sum over the 4 rows of the lane
 #pragma unroll
@@ -253,13 +262,13 @@ __global__ __launch_bounds__(256) void cfconv_fwd_kernel(const FwdArgs A) {
                 const float bias = b2s[nt * 16 + li];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float W = acc[r] + bias;
+                    const float W = fmaf(bias, mr[r], acc[r]);
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    if (SUMS) hs[nt] += hreg[r][nt];
+                    if (SUMS) hs[nt] = fmaf(hreg[r][nt], mr[r], hs[nt]);
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS) hds[nt] += hdreg[r][nt];
+                        if (SUMS) hds[nt] = fmaf(hdreg[r][nt], mr[r], hds[nt]);
                     }
                 }
             }
@@ -372,7 +381,11 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
             const bool va = draw >= 0.f;
-            const unsigned long long live = __ballot(va);            // bit s (lanes 0..15): slot t0 + s is a real neighbour
+            // bit s (lanes 0..15) of the ballot: slot t0 + s is a real neighbour; mr[r] = 1 / 0 for the lane's four C-layout rows
+            const unsigned nib = ((unsigned)__ballot(va) >> (4 * lk)) & 0xFu;
+            float mr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) ? 1.f : 0.f;
             const float da = va ? draw : PAD_D;
             float dda = 0.f;
             if (TANGENT) dda = va ? A.dd[ea] : 0.f;
@@ -380,8 +393,8 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
-                const bool vc = (live >> (4 * lk + r)) & 1ull;
-                const int j = vc ? A.col[rowb + s] : 0;
+                const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
+                const int j = vc ? A.col[rowb + s] : 0;           //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
@@ -421,8 +434,9 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             }
 #pragma unroll
             for (int ks = 0; ks < KB; ++ks) {
-                af[ks] = *reinterpret_cast<const bf16x8*>(&h1w[li * KSB + ks * 32 + lk * 8]);
-                if (TANGENT) adf[ks] = *reinterpret_cast<const bf16x8*>(&h1dw[li * KSB + ks * 32 + lk * 8]);
+                const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};      // (masked slot: see cfconv_fwd_kernel)
+                af[ks] = va ? *reinterpret_cast<const bf16x8*>(&h1w[li * KSB + ks * 32 + lk * 8]) : zero8;
+                if (TANGENT) adf[ks] = va ? *reinterpret_cast<const bf16x8*>(&h1dw[li * KSB + ks * 32 + lk * 8]) : zero8;
             }
 #pragma unroll
             for (int nt = 0; nt < FT; ++nt) {
@@ -436,13 +450,13 @@ __global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const float bias = b2s[nt * 16 + li];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float W = acc[r] + bias;
+                    const float W = fmaf(bias, mr[r], acc[r]);
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    if (SUMS) hs[nt] += hreg[r][nt];
+                    if (SUMS) hs[nt] = fmaf(hreg[r][nt], mr[r], hs[nt]);
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS) hds[nt] += hdreg[r][nt];
+                        if (SUMS) hds[nt] = fmaf(hdreg[r][nt], mr[r], hds[nt]);
                     }
                 }
             }
