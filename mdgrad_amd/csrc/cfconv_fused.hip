@@ -325,8 +325,11 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
+// (three waves per SIMD for the primal + tangent sweep: 168 registers + 11 spilled dwords instead of 188 registers at two
+//  waves -- the sweep waits on its gathers, not on issue slots: 155 -> 126 us at E = 459 k)
 template <int GP, int FT, bool TANGENT, bool SUMS>          // GP in {32, 64}
-__global__ __launch_bounds__(256) void cfconv_fwd_bf16_kernel(const FwdArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? 2 : 3) : 4) : 1)))
+void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                    // bf16 row stride (elements): 16-B aligned rows, conflict-free b128 reads
@@ -848,6 +851,8 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
 }
 
 template <int GP, int FT, bool DUAL, bool THETA>
+// (asking the allocator for more waves per SIMD was measured and dropped here: 3 waves for the dual sweep spills 38 dwords and
+//  runs 164 -> 240 us; 2 waves for dual + theta spills 45 and changes nothing)
 __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
