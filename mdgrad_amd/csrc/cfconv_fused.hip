@@ -176,16 +176,41 @@ void cfconv_fwd_kernel(const FwdArgs A) {
     // 8 MB of rows in flight, measured gather-bound)
     int n_begin, n_end, n_step;
     xcd_sweep(A.N, 4, n_begin, n_end, n_step);
+    // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
+    // the first tile of the wave's next atom after an atom's last one -- are requested before the current tile is worked
+    // on: the distance and node-row gathers of a tile then start at once instead of behind a second round trip.
+    int pf_cnt = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
+    if (n_begin + wid < n_end) {
+        const size_t rb = (size_t)(n_begin + wid) * A.max_nbr;
+        pf_cnt = A.cnt[n_begin + wid];
+        pf_e = A.eid[rb + min(li, A.max_nbr - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(4 * lk + r, A.max_nbr - 1)];
+    }
     for (int n = n_begin + wid; n < n_end; n += n_step) {
-        const int cnt = A.cnt[n];
-        const size_t rowb = (size_t)n * A.max_nbr;
+        const int cnt = pf_cnt;
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
-        for (int t0 = 0; t0 < cnt; t0 += 16) {
+        for (int t0 = 0; t0 < cnt || t0 == 0; t0 += 16) {         // (an atom without neighbours still hands the prefetch on)
+            const int ea_raw = pf_e;
+            int j_raw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) j_raw[r] = pf_j[r];
+            {
+                const bool last = t0 + 16 >= cnt;
+                const int n2 = last ? n + n_step : n, t2 = last ? 0 : t0 + 16;
+                if (n2 < n_end) {
+                    const size_t rb2 = (size_t)n2 * A.max_nbr;
+                    pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb2 + min(t2 + 4 * lk + r, A.max_nbr - 1)];
+                    if (last) pf_cnt = A.cnt[n2];
+                }
+            }
             // ---- A-layout row (slot t0 + li): distance (and its tangent)
             const bool vin = t0 + li < cnt;
-            const int ea = vin ? A.eid[rowb + t0 + li] : 0;
+            const int ea = vin ? ea_raw : 0;
             const float draw = vin ? A.d[ea] : -1.f;
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
@@ -204,7 +229,7 @@ void cfconv_fwd_kernel(const FwdArgs A) {
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
                 const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
-                const int j = vc ? A.col[rowb + s] : 0;           //  zeroed through the filter below)
+                const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
@@ -371,15 +396,40 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
     int n_begin, n_end, n_step;
     xcd_sweep(A.N, 4, n_begin, n_end, n_step);              // (see cfconv_fwd_kernel)
+    // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
+    // the first tile of the wave's next atom after an atom's last one -- are requested before the current tile is worked
+    // on: the distance and node-row gathers of a tile then start at once instead of behind a second round trip.
+    int pf_cnt = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
+    if (n_begin + wid < n_end) {
+        const size_t rb = (size_t)(n_begin + wid) * A.max_nbr;
+        pf_cnt = A.cnt[n_begin + wid];
+        pf_e = A.eid[rb + min(li, A.max_nbr - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(4 * lk + r, A.max_nbr - 1)];
+    }
     for (int n = n_begin + wid; n < n_end; n += n_step) {
-        const int cnt = A.cnt[n];
-        const size_t rowb = (size_t)n * A.max_nbr;
+        const int cnt = pf_cnt;
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
-        for (int t0 = 0; t0 < cnt; t0 += 16) {
+        for (int t0 = 0; t0 < cnt || t0 == 0; t0 += 16) {         // (an atom without neighbours still hands the prefetch on)
+            const int ea_raw = pf_e;
+            int j_raw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) j_raw[r] = pf_j[r];
+            {
+                const bool last = t0 + 16 >= cnt;
+                const int n2 = last ? n + n_step : n, t2 = last ? 0 : t0 + 16;
+                if (n2 < n_end) {
+                    const size_t rb2 = (size_t)n2 * A.max_nbr;
+                    pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb2 + min(t2 + 4 * lk + r, A.max_nbr - 1)];
+                    if (last) pf_cnt = A.cnt[n2];
+                }
+            }
             const bool vin = t0 + li < cnt;
-            const int ea = vin ? A.eid[rowb + t0 + li] : 0;
+            const int ea = vin ? ea_raw : 0;
             const float draw = vin ? A.d[ea] : -1.f;
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
@@ -397,7 +447,7 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
                 const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
-                const int j = vc ? A.col[rowb + s] : 0;           //  zeroed through the filter below)
+                const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
                 if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
             }
