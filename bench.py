@@ -908,19 +908,19 @@ def main():
         if args.workload == "all" and not args.no_secondary:
             sec = {}
             import copy
-            # (>= 1 s of GPU time per secondary workload: 16 x ~60 ms, 50 x ~20 ms)
+            # (>= 1 s of GPU time per secondary workload: 28 x ~41 ms (bf16) / 18 x ~56 ms (f32), 50 x ~20 ms)
             # BASELINE config #5 names the bf16 cfconv MFMA: the SchNet workload runs with bf16 filter operands (stated
             # tolerance: tests/test_gpu_config5.py) and reports the all-f32 rate beside it
             a16 = copy.copy(args)
             a16.bf16 = True
-            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 16, 2, a16), ("lj4096", run_lj4096, 50, 3, args)):
+            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 28, 2, a16), ("lj4096", run_lj4096, 50, 3, args)):
                 try:
                     sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
                 except (Exception, SystemExit) as e:        # a secondary workload must not take the headline down
                     sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             if "error" not in sec["schnet4096"] and not args.bf16:
                 try:
-                    f32 = run_schnet4096(args, rank, world, dev, mdist, False, steps=8, warmup=1)
+                    f32 = run_schnet4096(args, rank, world, dev, mdist, False, steps=18, warmup=1)
                     sec["schnet4096"]["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "dtype")}
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
