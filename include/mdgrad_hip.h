@@ -447,6 +447,13 @@ int mdg_cfconv_bwd_bf16(const MdgFilterNet* net /*host*/, const float* d, const 
                         int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                         float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
                         const int32_t* n_valid, void* stream);
+/* either of the two with the gradients of the radial basis as well (GaussianSmearing(trainable=True), nff/nn/layers.py:34-83:
+ * `offsets` and `width` are parameters): gmu[G] = d/d(mu_k), gcoef[G] = d/d(coef_k) of the same scalar; the caller chains
+ * coef = -0.5 / width^2.  bf16 != 0: bf16 MFMA operands. */
+int mdg_cfconv_bwd_smear(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
+                         int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                         float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu, float* gcoef,
+                         float* workspace, const int32_t* n_valid, int bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K11/K12  node-level Dense layers with fused epilogues on the f32 MFMA

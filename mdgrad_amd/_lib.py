@@ -149,6 +149,8 @@ _SIGNATURES = {
     "mdg_cfconv_bwd_workspace": (C.c_int64, [C.c_int, C.c_int, C.c_int64]),
     "mdg_cfconv_bwd": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_bwd_bf16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mdg_cfconv_bwd_smear": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                                       C.c_int, P]),
     "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),

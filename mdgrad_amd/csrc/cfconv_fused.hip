@@ -609,7 +609,10 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
     // persistent per-wave gradient accumulators (THETA)
     f32x4 gW2[THETA ? FT : 1][THETA ? NT : 1], gW1[THETA ? NT : 1][THETA ? NT : 1];
     float gb1[NT];
+    float gmu[THETA ? NT : 1], gcf[THETA ? NT : 1];      // THETA: gradients of the Gaussian centres and coefficients (trainable smearing)
     if (THETA) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) gmu[c] = gcf[c] = 0.f;
 #pragma unroll
         for (int a = 0; a < FT; ++a)
 #pragma unroll
@@ -792,7 +795,13 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
                     s_d[r] = fmaf(gb[nt][r], gp, s_d[r]);
                     s_d[r] = fmaf(gdb[nt][r] * ddr, g * (ph * ph + c2s[k]), s_d[r]);
                 }
-                if (THETA) { gc[nt][r] = g; gdc[nt][r] = gp * ddr; }
+                if (THETA) {
+                    gc[nt][r] = g; gdc[nt][r] = gp * ddr;
+                    // g_k = exp(c_k x^2), x = d - mu_k:  dg/dmu = -dg/dd,  dg/dc = g x^2;  the tangent gd = g 2c x dd likewise
+                    const float td_ = gdb[nt][r] * ddr;
+                    gmu[nt] -= gb[nt][r] * gp + td_ * g * (ph * ph + c2s[k]);
+                    gcf[nt] += gb[nt][r] * g * x * x + td_ * g * x * (x * ph + 2.f);
+                }
             }
         }
         // ---- THETA: gW1[j][k] += sum_e a_db[e][j] gd[e][k] + a_b[e][j] g[e][k]  (all operands already in the
@@ -831,11 +840,16 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
 
     // ---- THETA: ordered cross-wave reduction through LDS, one partial record per workgroup
     if (THETA) {
-        constexpr int REC = GP * GP + GP + FP * GP;              // [gW1 | gb1 | gW2], padded sizes
+        constexpr int REC0 = GP * GP + GP + FP * GP;             // [gW1 | gb1 | gW2 | gmu | gcoef], padded sizes
+        constexpr int REC = REC0 + 2 * GP;
         __syncthreads();                                         // everyone is done with the weights / scratch
         float* buf = sm;                                         // REC floats: reuses the weight area (GP*S1*2 + FP*S1 >= REC)
 #pragma unroll
-        for (int v = 0; v < NT; ++v) { gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64); }
+        for (int v = 0; v < NT; ++v) {
+            gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64);
+            gmu[v] += __shfl_xor(gmu[v], 16, 64); gmu[v] += __shfl_xor(gmu[v], 32, 64);
+            gcf[v] += __shfl_xor(gcf[v], 16, 64); gcf[v] += __shfl_xor(gcf[v], 32, 64);
+        }
         for (int w = 0; w < 4; ++w) {
             if (wid == w) {
 #pragma unroll
@@ -852,6 +866,9 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
                     for (int nt = 0; nt < NT; ++nt) {
                         const int idx = GP * GP + nt * 16 + li;
                         buf[idx] = (w ? buf[idx] : 0.f) + gb1[nt];
+                        const int im = REC0 + nt * 16 + li, ic = REC0 + GP + nt * 16 + li;
+                        buf[im] = (w ? buf[im] : 0.f) + gmu[nt];
+                        buf[ic] = (w ? buf[ic] : 0.f) + gcf[nt];
                     }
                 }
 #pragma unroll
@@ -947,7 +964,10 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     // persistent per-wave gradient accumulators (THETA)
     f32x4 gW2[THETA ? FT : 1][THETA ? NT : 1], gW1[THETA ? NT : 1][THETA ? NT : 1];
     float gb1[NT];
+    float gmu[THETA ? NT : 1], gcf[THETA ? NT : 1];      // THETA: gradients of the Gaussian centres and coefficients (trainable smearing)
     if (THETA) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) gmu[c] = gcf[c] = 0.f;
 #pragma unroll
         for (int a = 0; a < FT; ++a)
 #pragma unroll
@@ -1153,7 +1173,13 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
                     s_d[r] = fmaf(gb[nt][r], gp, s_d[r]);
                     s_d[r] = fmaf(gdb[nt][r] * ddr, g * (ph * ph + c2s[k]), s_d[r]);
                 }
-                if (THETA) { gc[nt][r] = g; gdc[nt][r] = gp * ddr; }
+                if (THETA) {
+                    gc[nt][r] = g; gdc[nt][r] = gp * ddr;
+                    // g_k = exp(c_k x^2), x = d - mu_k:  dg/dmu = -dg/dd,  dg/dc = g x^2;  the tangent gd = g 2c x dd likewise
+                    const float td_ = gdb[nt][r] * ddr;
+                    gmu[nt] -= gb[nt][r] * gp + td_ * g * (ph * ph + c2s[k]);
+                    gcf[nt] += gb[nt][r] * g * x * x + td_ * g * x * (x * ph + 2.f);
+                }
             }
         }
         // ---- THETA: gW1[j][k] += sum_e a_db[e][j] gd[e][k] + a_b[e][j] g[e][k]  (all operands already in the
@@ -1193,11 +1219,16 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
 
     // ---- THETA: ordered cross-wave reduction through LDS, one partial record per workgroup
     if (THETA) {
-        constexpr int REC = GP * GP + GP + FP * GP;              // [gW1 | gb1 | gW2], padded sizes
+        constexpr int REC0 = GP * GP + GP + FP * GP;             // [gW1 | gb1 | gW2 | gmu | gcoef], padded sizes
+        constexpr int REC = REC0 + 2 * GP;
         __syncthreads();                                         // everyone is done with the weights / scratch
         float* buf = sm;                                         // REC floats: reuses the whole LDS block (bwd_bf16_lds_bytes reserves >= REC)
 #pragma unroll
-        for (int v = 0; v < NT; ++v) { gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64); }
+        for (int v = 0; v < NT; ++v) {
+            gb1[v] += __shfl_xor(gb1[v], 16, 64); gb1[v] += __shfl_xor(gb1[v], 32, 64);
+            gmu[v] += __shfl_xor(gmu[v], 16, 64); gmu[v] += __shfl_xor(gmu[v], 32, 64);
+            gcf[v] += __shfl_xor(gcf[v], 16, 64); gcf[v] += __shfl_xor(gcf[v], 32, 64);
+        }
         for (int w = 0; w < 4; ++w) {
             if (wid == w) {
 #pragma unroll
@@ -1214,6 +1245,9 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
                     for (int nt = 0; nt < NT; ++nt) {
                         const int idx = GP * GP + nt * 16 + li;
                         buf[idx] = (w ? buf[idx] : 0.f) + gb1[nt];
+                        const int im = REC0 + nt * 16 + li, ic = REC0 + GP + nt * 16 + li;
+                        buf[im] = (w ? buf[im] : 0.f) + gmu[nt];
+                        buf[ic] = (w ? buf[ic] : 0.f) + gcf[nt];
                     }
                 }
 #pragma unroll
@@ -1238,7 +1272,7 @@ size_t bwd_bf16_lds_bytes(bool theta) {
     constexpr int FP = 16 * FT, KSB = GP + 8, FS = FP + 8, SA = GP + 4, SW = FP + 4;
     const size_t wsz = theta ? 16 * SW : 16 * SA;
     size_t b = sizeof(float) * (4 * GP + 4 * wsz) + sizeof(unsigned short) * ((size_t)2 * GP * KSB + (size_t)GP * FS);
-    const size_t rec = sizeof(float) * ((size_t)GP * GP + GP + (size_t)FP * GP);
+    const size_t rec = sizeof(float) * ((size_t)GP * GP + 3 * GP + (size_t)FP * GP);
     if (theta && b < rec) b = rec;
     return (b + 15) / 16 * 16;
 }
@@ -1246,8 +1280,8 @@ size_t bwd_bf16_lds_bytes(bool theta) {
 // sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes
 __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nrec, int GP, int FP, int G, int F,
                                          float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
-                                         int accumulate) {
-    const int REC = GP * GP + GP + FP * GP;
+                                         float* __restrict__ gmu, float* __restrict__ gcoef, int accumulate) {
+    const int REC0 = GP * GP + GP + FP * GP, REC = REC0 + 2 * GP;
     const int t = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
     float s = 0.f;
     if (t < REC)
@@ -1261,9 +1295,13 @@ __global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nre
     } else if (t < GP * GP + GP) {
         const int j = t - GP * GP;
         if (j < G) gb1[j] = accumulate ? gb1[j] + s : s;
-    } else {
+    } else if (t < REC0) {
         const int u = t - GP * GP - GP, f = u / GP, k = u % GP;
         if (f < F && k < G) gW2[(size_t)f * G + k] = s;
+    } else {
+        const int k = (t - REC0) % GP;
+        float* out = t - REC0 < GP ? gmu : gcoef;                 // (nullable: asked for only with trainable smearing)
+        if (out && k < G) out[k] = accumulate ? out[k] + s : s;
     }
 }
 
@@ -1523,7 +1561,7 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
 extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges) {
     if (!mdg_cfconv_supported(n_gauss, n_filters) || n_edges <= 0) return 0;
     const int GP = n_gauss <= 32 ? 32 : 64, FP = n_filters <= 64 ? 64 : 128;
-    return (int64_t)bwd_blocks(n_edges, true) * (GP * GP + GP + FP * GP);
+    return (int64_t)bwd_blocks(n_edges, true) * (GP * GP + 3 * GP + FP * GP);
 }
 
 namespace {
@@ -1531,7 +1569,7 @@ namespace {
 int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
                     int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                     float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
-                    const int32_t* n_valid, void* stream, bool bf16) {
+                    const int32_t* n_valid, void* stream, bool bf16, float* gmu = nullptr, float* gcoef = nullptr) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1545,6 +1583,8 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
             MDG_HIP(hipMemsetAsync(gW1, 0, sizeof(float) * G * G, st));
             MDG_HIP(hipMemsetAsync(gb1, 0, sizeof(float) * G, st));
             MDG_HIP(hipMemsetAsync(gW2, 0, sizeof(float) * F * G, st));
+            if (gmu) MDG_HIP(hipMemsetAsync(gmu, 0, sizeof(float) * G, st));
+            if (gcoef) MDG_HIP(hipMemsetAsync(gcoef, 0, sizeof(float) * G, st));
         }
         return MDG_OK;
     }
@@ -1591,9 +1631,9 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
 #undef MDG_BWD_K
     MDG_CHECK_LAUNCH("cfconv_bwd_kernel");
     if (theta) {
-        const int FP = 16 * FT, REC = GP * GP + GP + FP * GP;
+        const int FP = 16 * FT, REC = GP * GP + 3 * GP + FP * GP;
         hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC * 4 + 255) / 256), dim3(256), 0, st, workspace, nb, GP, FP,
-                           net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, f0 > 0 ? 1 : 0);
+                           net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, gmu, gcoef, f0 > 0 ? 1 : 0);
         MDG_CHECK_LAUNCH("cfconv_bwd_reduce_kernel");
     }
     }
@@ -1616,3 +1656,15 @@ extern "C" int mdg_cfconv_bwd_bf16(const MdgFilterNet* net, const float* d, cons
     return cfconv_bwd_impl(net, d, dd, nbr, n_edges, h, hd, mb, mdb, d_b, dd_b, gW1, gb1, gW2, workspace, n_valid, stream, true);
 }
 
+
+// mdg_cfconv_bwd / mdg_cfconv_bwd_bf16 (bf16 != 0) with the gradients of the Gaussian basis as well: gmu[G] = d/d(mu_k),
+// gcoef[G] = d/d(coef_k) of the same scalar (nff/nn/layers.py:34-83 with trainable = True: `offsets` and `width` are
+// parameters; coef = -0.5 / width^2 is chained by the caller).
+extern "C" int mdg_cfconv_bwd_smear(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                                    int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
+                                    float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu, float* gcoef,
+                                    float* workspace, const int32_t* n_valid, int bf16, void* stream) {
+    MDG_CHECK_ARG(gW1 && gmu && gcoef, "cfconv_bwd_smear: the basis gradients come with the parameter gradients");
+    return cfconv_bwd_impl(net, d, dd, nbr, n_edges, h, hd, mb, mdb, d_b, dd_b, gW1, gb1, gW2, workspace, n_valid, stream,
+                           bf16 != 0, gmu, gcoef);
+}

@@ -18,7 +18,8 @@ Edge level (everything of size [E, .]): the fused interaction-block kernels of c
 network on the MFMA, gather-multiply-sum per atom, and the adjoints with the filter recomputed -- so no
 [E,G] / [E,F] tensor exists.  Node level ([N, .]): GEMMs + small fused elementwise kernels.  Shapes the fused
 kernels do not take (n_gaussians > 64, n_filters not a multiple of 128 above 128 or above 512) run the unfused chain
-(`_force_vjp_unfused`): graph
+(`_force_vjp_unfused`); a trainable radial basis (GaussianSmearing(trainable=True)) stays on the fused kernels, which then
+also return the gradients of its centres and widths: graph
 kernels of csrc/graph.hip, the split-K A^T B kernel and library GEMMs.
 
 Notation follows SURVEY A.9 / nff/nn/models/schnet.py:113-171 (reference parameter names in
@@ -87,9 +88,17 @@ def supported(net):
         return False
     for conv in net.convolutions:
         seq = conv.moduledict["message_edge_filter"]
-        if isinstance(seq[0].width, torch.nn.Parameter) or seq[0].centered:
-            return False                        # trainable / centred Gaussians: autograd path
+        if seq[0].centered:
+            return False                        # origin-centred Gaussians (not reachable through SchNetConv): autograd path
+        if isinstance(seq[0].width, torch.nn.Parameter) and not (
+                getattr(net, "fused_block", True) is not False
+                and ops.FilterNet.supported(seq[0].offsets.shape[0], seq[3].weight.shape[0])):
+            return False                        # a trainable basis is differentiated by the fused kernels only
     return True
+
+
+def _trainable_smear(conv):
+    return isinstance(conv.moduledict["message_edge_filter"][0].width, torch.nn.Parameter)
 
 
 def _gauss_coeff(smear):
@@ -355,7 +364,13 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accu
         if want_theta:
             jobs.atb(off(md_["update_function"][0].weight), udb, L["md"], ub, L["m"])
             jobs.colsum(off(md_["update_function"][0].bias), ub)
-        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta)
+        smear_t = want_theta and _trainable_smear(convs[idx])
+        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta, want_smear=smear_t)
+        if smear_t:
+            # GaussianSmearing(trainable=True), layers.py:34-83: offsets = the centres; coef = -0.5 / width^2 per Gaussian
+            sm = md_["message_edge_filter"][0]
+            jobs.axpy(off(sm.offsets), th[3])
+            jobs.axpy(off(sm.width), th[4] * sm.width.detach().pow(-3))
         if want_theta:
             jobs.axpy(off(md_["message_edge_filter"][1].weight), th[0])
             jobs.axpy(off(md_["message_edge_filter"][1].bias), th[1])

@@ -1289,29 +1289,37 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     return m, md, hsum, hdsum
 
 
-def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False):
+def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, want_smear=False):
     """Adjoint of the filter network (see include/mdgrad_hip.h): accumulates into d_b / dd_b in place and returns
-    (gW1, gb1, gW2) when want_theta."""
+    (gW1, gb1, gW2) when want_theta -- plus (gmu, gcoef), the gradients of the Gaussian centres and coefficients, when
+    want_smear (trainable radial basis)."""
     lib = _lib.load()
     dev = h.device
     h, mdb = h.contiguous(), mdb.contiguous()
     hd = hd.contiguous() if hd is not None else None
     mb = mb.contiguous() if mb is not None else None
+    bf16 = bool(fnet.bf16 and fnet.bf16_reverse)
     tops = _torch_ops.get()
-    if tops is not None:
+    if tops is not None and not want_smear:
         out = tops.cfconv_bwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, d, dd, topo.nbr, int(topo.n_edges), h, hd,
-                              mb, mdb, d_b, dd_b, getattr(topo, "n_valid", None), bool(want_theta),
-                              bool(fnet.bf16 and fnet.bf16_reverse))
+                              mb, mdb, d_b, dd_b, getattr(topo, "n_valid", None), bool(want_theta), bf16)
         return tuple(out) if want_theta else None
-    gW1 = gb1 = gW2 = ws = None
+    gW1 = gb1 = gW2 = gmu = gcf = ws = None
     if want_theta:
         gW1, gb1 = torch.empty(fnet.G, fnet.G, device=dev), torch.empty(fnet.G, device=dev)
         gW2 = torch.empty(fnet.F, fnet.G, device=dev)
         ws = torch.empty(max(1, int(lib.mdg_cfconv_bwd_workspace(fnet.G, fnet.F, topo.n_edges))), device=dev)
-    fn = lib.mdg_cfconv_bwd_bf16 if (fnet.bf16 and fnet.bf16_reverse) else lib.mdg_cfconv_bwd
+    nv = ptr(getattr(topo, "n_valid", None))
+    if want_smear:
+        assert want_theta, "the basis gradients come with the parameter gradients"
+        gmu, gcf = torch.empty(fnet.G, device=dev), torch.empty(fnet.G, device=dev)
+        check(lib.mdg_cfconv_bwd_smear(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
+                                       ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gmu), ptr(gcf), ptr(ws), nv,
+                                       int(bf16), stream_ptr(dev)), "mdg_cfconv_bwd_smear")
+        return gW1, gb1, gW2, gmu, gcf
+    fn = lib.mdg_cfconv_bwd_bf16 if bf16 else lib.mdg_cfconv_bwd
     check(fn(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
-             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws),
-             ptr(getattr(topo, "n_valid", None)), stream_ptr(dev)), "mdg_cfconv_bwd")
+             ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(ws), nv, stream_ptr(dev)), "mdg_cfconv_bwd")
     return (gW1, gb1, gW2) if want_theta else None
 
 

@@ -390,3 +390,48 @@ def test_readout_head_kernel():
     assert torch.allclose(ydb, sy * L2) and torch.allclose(yb, (1 - sy) * syd * L2, atol=1e-6)
     ydb1, none = ops.readout_head(sy, None, L2)
     assert none is None and torch.equal(ydb1, ydb)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
+    """GaussianSmearing(trainable=True) (nff/nn/layers.py:34-83; `trainable_gauss` of demo/fit_rdf_gnn.py): `offsets` and `width`
+    are parameters.  The fused reverse sweep returns their gradients too (mdg_cfconv_bwd_smear): force, d(w.F)/dx and every
+    d(w.F)/dtheta -- the 2 x 30 basis parameters of each layer included -- against the autograd path (double backward through
+    SchNet.forward); a trajectory through the analytic adjoint then matches the generic autograd adjoint."""
+    from mdgrad_amd.interface import GNNPotentials
+    from mdgrad_amd.nn import get_model, analytic
+    g = load_golden("schnet_cg64_wide")
+    system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    torch.manual_seed(21)
+    net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2, "cutoff": 6.0,
+                     "trainable_gauss": True})
+    with torch.no_grad():                       # (move the basis off its initial grid so that nothing is symmetric by accident)
+        for conv in net.convolutions:
+            sm = conv.moduledict["message_edge_filter"][0]
+            sm.offsets.add_(torch.randn_like(sm.offsets) * 0.03)
+            sm.width.mul_(1.0 + 0.1 * torch.rand_like(sm.width))
+    names = [n for n, _ in net.named_parameters()]
+    assert any(n.endswith("message_edge_filter.0.width") for n in names) and any(n.endswith("message_edge_filter.0.offsets") for n in names)
+    gnn = GNNPotentials(system, net, cutoff=6.0)
+    assert analytic.supported(net) and analytic.fused_ok(net) and gnn.supports_force_vjp()
+    q = T(g["pos"], DEV)
+    gnn._reset_topology(q)
+    w = T(np.random.default_rng(4).normal(0, 1, g["pos"].shape).astype(np.float32), DEV)
+    qa = q.clone().requires_grad_(True)
+    Ua = gnn(qa).sum()
+    (gq,) = torch.autograd.grad(Ua, qa, create_graph=True)
+    plist = list(net.parameters())
+    ga = torch.autograd.grad((w * -gq).sum(), [qa] + plist, allow_unused=True)
+    net.filter_bf16 = bf16
+    U, F_, dq, gth = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+    tol = 2e-4 if not bf16 else 2e-2
+    close(F_, -gq.detach(), 0, tol * float(gq.abs().max()), "F")
+    close(dq, ga[0], 0, tol * float(ga[0].abs().max()), "d(w.F)/dx")
+    for (n, p), got, ref in zip(net.named_parameters(), gth, ga[1:]):
+        ref = ref if ref is not None else torch.zeros_like(p)
+        if n.endswith(".0.width") or n.endswith(".0.offsets") or not bf16:
+            close(got, ref, 0, (5e-4 if not bf16 else 3e-2) * float(ref.abs().max()) + 1e-7, "d(w.F)/d " + n)
+    fa = torch.cat([(x if x is not None else torch.zeros_like(p)).reshape(-1) for x, p in zip(ga[1:], plist)])
+    flat = torch.cat([t.reshape(-1) for t in gth])
+    cos = float((flat.double() * fa.double()).sum() / (flat.double().norm() * fa.double().norm()))
+    assert cos > (0.999999 if not bf16 else 0.9999), cos
