@@ -1,8 +1,13 @@
+# End-of-round evidence on the GPU box: tests, counters (copied into profiles/ of the box's tree so that the bench line that
+# follows reads records of the same sources), the bench line, kernel benches.  Results under gpurun_out/ (copy the r0X_* /
+# pmc_* files of gpurun_out/prof and the bench line to profiles/ afterwards).
+TAG=${1:-r03c}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8) > gpurun_out/f_pytest.log; tail -3 gpurun_out/f_pytest.log
+bash tools/prof_round3.sh $TAG lj108 lj4096 schnet4096 > gpurun_out/f_prof.log 2>&1
+cp gpurun_out/prof/pmc_lj108.json gpurun_out/prof/pmc_lj4096.json gpurun_out/prof/pmc_schnet4096.json profiles/
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/f_bench.json 2> gpurun_out/f_bench.err); tail -c 200 gpurun_out/f_bench.err
-bash tools/prof_round3.sh r03c lj108 lj4096 schnet4096 > gpurun_out/f_prof.log 2>&1
-python tools/kbench_cfconv.py > gpurun_out/prof/r03c_cfconv_kbench.txt 2>/dev/null
-python tools/kbench_cfconv.py --bf16 > gpurun_out/prof/r03c_cfconv_kbench_bf16.txt 2>/dev/null
+python tools/kbench_cfconv.py > gpurun_out/prof/${TAG}_cfconv_kbench.txt 2>/dev/null
+python tools/kbench_cfconv.py --bf16 > gpurun_out/prof/${TAG}_cfconv_kbench_bf16.txt 2>/dev/null
 (timeout 300 python tools/gbench.py gnn64 gnn512 gnn4096 --steps 20 > gpurun_out/f_gbench.txt 2>&1); tail -3 gpurun_out/f_gbench.txt
