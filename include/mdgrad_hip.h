@@ -560,25 +560,30 @@ int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, const float* l
  *   mdg_nhv_finish   v += dv_h + 1/2 a1 dt, pv += dp_h + 1/2 b1 dt, q = qn, f = fn ; frame k+1 stored
  *   mdg_nhv_adj_pre  (v, q, pv) <- frame i ;  w = lam_v / m
  *   mdg_nhv_adj_mid  vh = v - a hh, qm = q + vh h, pm = pv - b hh, lam_h = lam + G0 hh, wh = lam_h_v / m
- *   mdg_nhv_adj_end  lam += G1 h + dL/dy_{i-1} */
+ *   mdg_nhv_adj_end  lam += G1 h + dL/dy_{i-1}
+ * A replica's elements are cut over several workgroups; `scratch` (mdg_nhv_scratch_floats(n_rep, n_atoms) floats,
+ * zeroed ONCE by the caller, reusable by every launch of the same shape on one stream) carries the per-workgroup
+ * partial sums of the kinetic energy / <lam_v, v> and a ticket per replica; the result does not depend on the order
+ * the workgroups finish in. */
+int64_t mdg_nhv_scratch_floats(int n_rep, int n_atoms);
 int mdg_nhv_kick(const float* v, const float* q, const float* pv, const float* f, const float* mass, const float* Q,
                  const float* T, float n_dof, const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains,
-                 float* dv_h, float* dp_h, float* qn, void* stream);
+                 float* dv_h, float* dp_h, float* qn, float* scratch, void* stream);
 int mdg_nhv_finish(float* v, float* q, float* pv, float* f, const float* dv_h, const float* dp_h, const float* qn,
                    const float* fn, const float* mass, const float* Q, const float* T, float n_dof, const float* t,
                    const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* out_v, float* out_q, float* out_pv,
-                   void* stream);
+                   float* scratch, void* stream);
 int mdg_nhv_adj_pre(const float* v_t, const float* q_t, const float* pv_t, const float* lv, const float* mass,
                     const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* v, float* q, float* pv, float* w,
                     void* stream);
 int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, const float* lv, const float* lq, const float* lp,
                     const float* f, const float* dwf, const float* mass, const float* Q, const float* T, float n_dof,
                     const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* vh, float* qm, float* pm,
-                    float* lvh, float* lqh, float* lph, float* wh, void* stream);
+                    float* lvh, float* lqh, float* lph, float* wh, float* scratch, void* stream);
 int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const float* lqh, const float* lph, const float* dwf,
                     const float* mass, const float* Q, const float* t, const int64_t* idx, const float* g_v,
                     const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains, float* lv, float* lq,
-                    float* lp, void* stream);
+                    float* lp, float* scratch, void* stream);
 
 
 #ifdef __cplusplus

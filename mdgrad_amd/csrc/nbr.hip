@@ -47,7 +47,7 @@ __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group
                                  const uint8_t* __restrict__ mask, int32_t* __restrict__ col,
                                  int32_t* __restrict__ shift, int32_t* __restrict__ cnt, int max_nbr,
                                  int32_t* __restrict__ overflow, const int32_t* __restrict__ gate = nullptr,
-                                 float* __restrict__ pos_build = nullptr) {
+                                 float* __restrict__ pos_build = nullptr, int32_t* __restrict__ row_half = nullptr) {
     if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     const int lane = threadIdx.x & 63;
     const int i = xcd_chunk(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);   // XCD-aware atom order
@@ -55,7 +55,7 @@ __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group
     const float xi = pos[3 * i], yi = pos[3 * i + 1], zi = pos[3 * i + 2];
     if (pos_build && lane < 3) pos_build[3 * i + lane] = pos[3 * i + lane];      // where this list was built
     const int g0 = (i / group) * group, g1 = min(N, g0 + group);
-    int base = 0;
+    int base = 0, half = 0;
     for (int j0 = g0; j0 < g1; j0 += 64) {
         const int j = j0 + lane;
         int code = -1;
@@ -64,14 +64,17 @@ __global__ void nbr_dense_kernel(const float* __restrict__ pos, int N, int group
             if (code >= 0 && mask && !mask[(size_t)(i - g0) * group + (j - g0)]) code = -1;
         }
         const unsigned long long b = __ballot(code >= 0);
+        bool upper = false;
         if (code >= 0) {
             const int k = base + __popcll(b & lanemask_lt());
-            if (k < max_nbr) { col[(size_t)i * max_nbr + k] = j; shift[(size_t)i * max_nbr + k] = code; }
+            if (k < max_nbr) { col[(size_t)i * max_nbr + k] = j; shift[(size_t)i * max_nbr + k] = code; upper = j > i; }
         }
+        half += __popcll(__ballot(upper));
         base += __popcll(b);
     }
     if (lane == 0) {
         cnt[i] = base < max_nbr ? base : max_nbr;
+        if (row_half) row_half[i] = half;                        // stored entries with j > i (what half_count_kernel finds)
         if (base > max_nbr) atomicMax(overflow, base);
     }
 }
@@ -154,6 +157,59 @@ __global__ void bin_fill_kernel(const int32_t* __restrict__ atom_bin, int N, int
     sorted_atoms[slot] = i;
 }
 
+// Counting sort of one group's atoms into its bins by ONE workgroup (counts, scan and cursors in LDS): what
+// zero + bin_count_kernel + scan_kernel + bin_fill_kernel do in four launches, for groups whose bins fit LDS_BINS.
+// A group owns atoms [g group, (g+1) group) of sorted_atoms, so bin_start needs no scan across groups.  The order of the
+// atoms inside a bin depends on the LDS atomics; the rows built from it are rank-sorted, so the list does not.
+constexpr int LDS_BINS = 8192;
+constexpr int SORT_BLOCK = 1024;
+constexpr int SORT_MAX_GROUP = 1 << 16;
+__global__ __launch_bounds__(SORT_BLOCK) void bin_sort_group_kernel(
+    const float* __restrict__ pos, int N, int group, MdgCell cell, Bins bins, int32_t* __restrict__ atom_bin,
+    int32_t* __restrict__ bin_start, int32_t* __restrict__ sorted_atoms, const int32_t* __restrict__ gate,
+    float* __restrict__ pos_build) {
+    if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
+    extern __shared__ __attribute__((aligned(16))) int32_t sm[];
+    __shared__ int32_t wsum[SORT_BLOCK / 64];
+    const int nc = bins.ncell, g = blockIdx.x, g0 = g * group;
+    int32_t* c = sm;                                             // counts, then cursors
+    int32_t* st = sm + nc;                                       // exclusive starts (local to the group)
+    for (int b = threadIdx.x; b < nc; b += SORT_BLOCK) c[b] = 0;
+    __syncthreads();
+    for (int a = threadIdx.x; a < group; a += SORT_BLOCK) {
+        const int i = g0 + a;
+        const float x = pos[3 * i], y = pos[3 * i + 1], z = pos[3 * i + 2];
+        if (pos_build) { pos_build[3 * i] = x; pos_build[3 * i + 1] = y; pos_build[3 * i + 2] = z; }
+        const int b = (bin_coord(x, cell.inv[0], bins.nb[0]) * bins.nb[1] + bin_coord(y, cell.inv[4], bins.nb[1])) * bins.nb[2] +
+                      bin_coord(z, cell.inv[8], bins.nb[2]);
+        atom_bin[i] = g * nc + b;
+        atomicAdd(&c[b], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the counts: every thread owns `per` consecutive bins
+    const int per = (nc + SORT_BLOCK - 1) / SORT_BLOCK, b0 = min(nc, (int)threadIdx.x * per), b1 = min(nc, b0 + per);
+    int mine = 0;
+    for (int b = b0; b < b1; ++b) mine += c[b];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int x = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int run = x - mine;
+    for (int w = 0; w < wid; ++w) run += wsum[w];
+    for (int b = b0; b < b1; ++b) { const int n = c[b]; st[b] = run; run += n; }
+    __syncthreads();
+    for (int b = threadIdx.x; b < nc; b += SORT_BLOCK) { c[b] = st[b]; bin_start[g * nc + b] = g0 + st[b]; }
+    if (g == (int)gridDim.x - 1 && threadIdx.x == 0) bin_start[(size_t)gridDim.x * nc] = N;
+    __syncthreads();
+    for (int a = threadIdx.x; a < group; a += SORT_BLOCK) {
+        const int i = g0 + a;
+        const int slot = atomicAdd(&c[atom_bin[i] - g * nc], 1);
+        sorted_atoms[g0 + slot] = i;
+    }
+}
+
 constexpr int ROW_CAP = 512;   // LDS row buffer per wave (entries)
 
 __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group, MdgCell cell, Bins bins, float rc2,
@@ -161,7 +217,7 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group,
                                 const int32_t* __restrict__ bin_start, const int32_t* __restrict__ sorted_atoms,
                                 int32_t* __restrict__ col, int32_t* __restrict__ shift,
                                 int32_t* __restrict__ cnt, int max_nbr, int32_t* __restrict__ overflow,
-                                const int32_t* __restrict__ gate = nullptr) {
+                                const int32_t* __restrict__ gate = nullptr, int32_t* __restrict__ row_half = nullptr) {
     if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
     extern __shared__ __attribute__((aligned(16))) int32_t sm[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -209,14 +265,20 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group,
     }
     const int n = base < ROW_CAP ? base : ROW_CAP;
     // rank sort by neighbour index (entries are distinct)
+    int half = 0;
     for (int k = lane; k < n; k += 64) {
         const int jk = bj[k];
         int rank = 0;
         for (int l = 0; l < n; ++l) rank += bj[l] < jk;
-        if (rank < max_nbr) { col[(size_t)i * max_nbr + rank] = jk; shift[(size_t)i * max_nbr + rank] = bc[k]; }
+        if (rank < max_nbr) { col[(size_t)i * max_nbr + rank] = jk; shift[(size_t)i * max_nbr + rank] = bc[k]; half += jk > i; }
+    }
+    if (row_half) {                                              // stored entries with j > i (what half_count_kernel finds)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) half += __shfl_xor(half, o, 64);
     }
     if (lane == 0) {
         cnt[i] = base < max_nbr ? base : max_nbr;
+        if (row_half) row_half[i] = half;
         if (base > max_nbr) atomicMax(overflow, base);
     }
 }
@@ -239,8 +301,21 @@ __global__ void half_count_kernel(const int32_t* __restrict__ col, const int32_t
 __global__ void half_fill_kernel(const int32_t* __restrict__ col, const int32_t* __restrict__ shift,
                                  const int32_t* __restrict__ cnt, const int32_t* __restrict__ row_base,
                                  int N, int max_nbr, int64_t* __restrict__ nbr, float* __restrict__ offsets,
-                                 int32_t* __restrict__ edge_id, long long capacity, const int32_t* __restrict__ gate = nullptr) {
+                                 int32_t* __restrict__ edge_id, long long capacity, const int32_t* __restrict__ gate = nullptr,
+                                 int pad = 0, float pad_offset = 0.f, int32_t* __restrict__ n_valid = nullptr,
+                                 int32_t* __restrict__ need = nullptr) {
     if (gate && gate[0] == 0) return;                            // (Verlet reuse: the stored list still holds)
+    if (pad) {                                                   // half_pad_kernel's sweep, spread over this grid
+        const long long P = row_base[N];
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            if (n_valid) *n_valid = (int32_t)(P < capacity ? P : capacity);
+            if (P > capacity && need) atomicMax(need, (int32_t)P);
+        }
+        for (long long e = P + (long long)blockIdx.x * blockDim.x + threadIdx.x; e < capacity; e += (long long)gridDim.x * blockDim.x) {
+            nbr[2 * e] = -1; nbr[2 * e + 1] = -1;
+            offsets[3 * e] = pad_offset; offsets[3 * e + 1] = 0.f; offsets[3 * e + 2] = 0.f;
+        }
+    }
     const int i = blockIdx.x;
     const int32_t* row = col + (size_t)i * max_nbr;
     const int n = cnt[i];
@@ -488,34 +563,37 @@ extern "C" int mdg_nbr_verlet_rebuild(const float* pos, int n_atoms, int group, 
         int32_t* bin_cnt = sorted_atoms + n_atoms;
         int32_t* bin_start = bin_cnt + nbins_total + 1;
         int32_t* cursor = bin_start + nbins_total + 1;
-        hipLaunchKernelGGL(zero_i32_kernel, dim3((nbins_total + 1 + tb - 1) / tb), dim3(tb), 0, st, bin_cnt, nbins_total + 1, gate);
-        hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, group, *cell, bins,
-                           atom_bin, bin_cnt, gate, pos_build);
-        hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)bin_cnt, nbins_total, bin_start, cursor, gate);
-        hipLaunchKernelGGL(bin_fill_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, (const int32_t*)atom_bin, n_atoms, cursor,
-                           sorted_atoms, gate);
+        if (bins.ncell <= LDS_BINS && group <= SORT_MAX_GROUP) {
+            hipLaunchKernelGGL(bin_sort_group_kernel, dim3(n_atoms / group), dim3(SORT_BLOCK), sizeof(int32_t) * 2 * bins.ncell, st,
+                               pos, n_atoms, group, *cell, bins, atom_bin, bin_start, sorted_atoms, gate, pos_build);
+        } else {
+            hipLaunchKernelGGL(zero_i32_kernel, dim3((nbins_total + 1 + tb - 1) / tb), dim3(tb), 0, st, bin_cnt, nbins_total + 1, gate);
+            hipLaunchKernelGGL(bin_count_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, pos, n_atoms, group, *cell, bins,
+                               atom_bin, bin_cnt, gate, pos_build);
+            hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)bin_cnt, nbins_total, bin_start, cursor, gate);
+            hipLaunchKernelGGL(bin_fill_kernel, dim3((n_atoms + tb - 1) / tb), dim3(tb), 0, st, (const int32_t*)atom_bin, n_atoms,
+                               cursor, sorted_atoms, gate);
+        }
         const int wpb = 4;
         const size_t lds = sizeof(int32_t) * 2 * ROW_CAP * wpb;
         hipLaunchKernelGGL(nbr_cell_kernel, dim3((n_atoms + wpb - 1) / wpb), dim3(64 * wpb), lds, st, pos, n_atoms, group, *cell,
                            bins, rc2, mask, (const int32_t*)atom_bin, (const int32_t*)bin_start, (const int32_t*)sorted_atoms, col,
-                           shift, cnt, max_nbr, need, gate);
+                           shift, cnt, max_nbr, need, gate, row_base);
     } else {
         const int wpb = 4;
         dim3 grid((n_atoms + wpb - 1) / wpb), block(64 * wpb);
         if (cell->diag)
             hipLaunchKernelGGL(nbr_dense_kernel<true>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col, shift, cnt,
-                               max_nbr, need, gate, pos_build);
+                               max_nbr, need, gate, pos_build, row_base);
         else
             hipLaunchKernelGGL(nbr_dense_kernel<false>, grid, block, 0, st, pos, n_atoms, group, *cell, rc2, mask, col, shift, cnt,
-                               max_nbr, need, gate, pos_build);
+                               max_nbr, need, gate, pos_build, row_base);
     }
-    hipLaunchKernelGGL(half_count_kernel, dim3((n_atoms + 255) / 256), dim3(256), 0, st, (const int32_t*)col, (const int32_t*)cnt,
-                       n_atoms, max_nbr, row_base, gate);
+    // (the searches leave the per-row half counts in row_base; the fill launch also pads [P, capacity))
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, st, (const int32_t*)row_base, n_atoms, row_base, (int32_t*)nullptr, gate);
     hipLaunchKernelGGL(half_fill_kernel, dim3(n_atoms), dim3(64), 0, st, (const int32_t*)col, (const int32_t*)shift,
-                       (const int32_t*)cnt, (const int32_t*)row_base, n_atoms, max_nbr, nbr, offsets, edge_id, (long long)capacity, gate);
-    hipLaunchKernelGGL(half_pad_kernel, dim3((unsigned)((capacity + 255) / 256)), dim3(256), 0, st, (const int32_t*)row_base, n_atoms,
-                       (long long)capacity, pad_offset, nbr, offsets, n_valid, need + 1, gate);
+                       (const int32_t*)cnt, (const int32_t*)row_base, n_atoms, max_nbr, nbr, offsets, edge_id, (long long)capacity, gate,
+                       1, pad_offset, n_valid, need + 1);
     MDG_CHECK_LAUNCH("nbr_verlet_rebuild kernels");
     return MDG_OK;
 }

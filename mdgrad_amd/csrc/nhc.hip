@@ -82,31 +82,74 @@ __device__ __forceinline__ float nhc_bath_vjp(const float* pr, const float* lr, 
     return -lr[k - 1] * pr[k - 1] / Q[k] - lr[k] * pr[k + 1] / Q[k + 1] + 2.f * pr[k] * lr[k + 1] / Q[k];
 }
 
+// A replica's 3n elements are cut into NHV_CHUNK-element chunks, one workgroup each (grid = chunks x replicas): at
+// 4 096 beads a single 256-thread workgroup per replica left the launch latency-bound (~16 us; 12 workgroups ~5 us).
+// The kinetic-energy / <lam_v, v> sums cross workgroups through `scratch` (per-chunk partials + one ticket per
+// replica): the workgroup that draws the last ticket adds the partials IN CHUNK ORDER (so the result does not depend on
+// which workgroup finished last) and does the chain update; it also hands the ticket back at zero for the next launch.
+constexpr int NHV_CHUNK = 1024;
+__host__ __device__ inline int nhv_chunks(int n) { return (3 * n + NHV_CHUNK - 1) / NHV_CHUNK; }
+
+template <int NV>
+__device__ __forceinline__ bool replica_sum(float (&val)[NV], float* red, float* scratch, int R, int r) {
+    const int nb = gridDim.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) val[i] = block_sum(val[i], red);
+    if (nb == 1) return true;
+    __shared__ int last;
+    float* part = scratch + (size_t)r * nb * 2;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            __hip_atomic_store(part + blockIdx.x * 2 + i, val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)R * nb * 2) + r;
+        const unsigned tk = atomicAdd(ticket, 1u);
+        last = tk == (unsigned)(nb - 1);
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!last) return false;
+    __threadfence();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+        for (int b = 0; b < nb; ++b) s += __hip_atomic_load(part + b * 2 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        val[i] = s;
+    }
+    return true;
+}
+
+#define NHV_RANGE                                                                                   \
+    const int r = blockIdx.y;                                                                       \
+    const size_t o = (size_t)r * n * 3;                                                             \
+    const int e0 = blockIdx.x * NHV_CHUNK, e1 = min(e0 + NHV_CHUNK, 3 * n)
+
 // forward, first half (sovlers.py:111-118): rhs at (v, q, pv) with the cached force ->
 //   dv_h = 1/2 a dt, dp_h = 1/2 b dt, qn = q + (v + dv_h) dt
 __global__ __launch_bounds__(NHC_BLOCK) void nhv_kick_kernel(
     const float* __restrict__ v, const float* __restrict__ q, const float* __restrict__ pv, const float* __restrict__ f,
     const float* __restrict__ mass, const float* __restrict__ Q, const float* __restrict__ Tp, float n_dof,
-    const float* __restrict__ t, const long long* __restrict__ idx, int n, int C, float* __restrict__ dv_h,
-    float* __restrict__ dp_h, float* __restrict__ qn) {
+    const float* __restrict__ t, const long long* __restrict__ idx, int R, int n, int C, float* __restrict__ dv_h,
+    float* __restrict__ dp_h, float* __restrict__ qn, float* __restrict__ scratch) {
     __shared__ float red[32];
     __shared__ float ps[MDG_MAX_CHAINS];
-    const int r = blockIdx.x;
-    const size_t o = (size_t)r * n * 3;
+    NHV_RANGE;
     const long long k = idx[0];
     const float dt = t[k + 1] - t[k], T = Tp[0];
     const float* pr = pv + (size_t)r * C;
     const float pv0 = pr[0], q0 = Q[0];
-    float part = 0.f;
-    for (int e = threadIdx.x; e < 3 * n; e += NHC_BLOCK) {
+    float s[1] = {0.f};
+    for (int e = e0 + threadIdx.x; e < e1; e += NHC_BLOCK) {
         const float m = mass[(size_t)r * n + e / 3], ve = v[o + e], p = ve * m;
-        part += p * p / m;
+        s[0] += p * p / m;
         const float a = (f[o + e] - pv0 * p / q0) / m;
         const float h = 1.f / 2.f * a * dt;
         dv_h[o + e] = h;
         qn[o + e] = q[o + e] + (ve + h) * dt;
     }
-    const float ke = 0.5f * block_sum(part, red);
+    if (!replica_sum(s, red, scratch, R, r)) return;
+    const float ke = 0.5f * s[0];
     if (threadIdx.x < C) ps[threadIdx.x] = pr[threadIdx.x];
     __syncthreads();
     if (threadIdx.x < C) dp_h[(size_t)r * C + threadIdx.x] = 1.f / 2.f * nhc_bath(ps, Q, T, n_dof, ke, C, threadIdx.x) * dt;
@@ -114,16 +157,16 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_kick_kernel(
 
 // forward, second half (sovlers.py:121-125): rhs at (v + dv_h, qn, pv + dp_h) with the new force ->
 //   v += dv_h + 1/2 a1 dt, pv += dp_h + 1/2 b1 dt, q = qn, f = fn; frame k+1 stored
+// (pv is written by the last workgroup only, after every workgroup of the replica has read it)
 __global__ __launch_bounds__(NHC_BLOCK) void nhv_finish_kernel(
     float* __restrict__ v, float* __restrict__ q, float* __restrict__ pv, float* __restrict__ f,
     const float* __restrict__ dv_h, const float* __restrict__ dp_h, const float* __restrict__ qn,
     const float* __restrict__ fn, const float* __restrict__ mass, const float* __restrict__ Q,
     const float* __restrict__ Tp, float n_dof, const float* __restrict__ t, const long long* __restrict__ idx, int R, int n,
-    int C, float* __restrict__ out_v, float* __restrict__ out_q, float* __restrict__ out_pv) {
+    int C, float* __restrict__ out_v, float* __restrict__ out_q, float* __restrict__ out_pv, float* __restrict__ scratch) {
     __shared__ float red[32];
     __shared__ float ps[MDG_MAX_CHAINS];
-    const int r = blockIdx.x;
-    const size_t o = (size_t)r * n * 3;
+    NHV_RANGE;
     const long long k = idx[0];
     const float dt = t[k + 1] - t[k], T = Tp[0];
     float* pr = pv + (size_t)r * C;
@@ -131,17 +174,18 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_finish_kernel(
     __syncthreads();
     const float pv0 = ps[0], q0 = Q[0];
     const size_t fo = (size_t)(k + 1) * R * n * 3 + o;              // frames are time-major: [T, R*n, 3]
-    float part = 0.f;
-    for (int e = threadIdx.x; e < 3 * n; e += NHC_BLOCK) {
+    float s[1] = {0.f};
+    for (int e = e0 + threadIdx.x; e < e1; e += NHC_BLOCK) {
         const float m = mass[(size_t)r * n + e / 3], h = dv_h[o + e], ve = v[o + e] + h, p = ve * m;
-        part += p * p / m;
+        s[0] += p * p / m;
         const float a1 = (fn[o + e] - pv0 * p / q0) / m;
         const float vn = v[o + e] + (h + 1.f / 2.f * a1 * dt);
         const float qe = qn[o + e];
         v[o + e] = vn; q[o + e] = qe; f[o + e] = fn[o + e];
         out_v[fo + e] = vn; out_q[fo + e] = qe;
     }
-    const float ke = 0.5f * block_sum(part, red);
+    if (!replica_sum(s, red, scratch, R, r)) return;
+    const float ke = 0.5f * s[0];
     if (threadIdx.x < C) {
         const float pn = pr[threadIdx.x] + (dp_h[(size_t)r * C + threadIdx.x] + 1.f / 2.f * nhc_bath(ps, Q, T, n_dof, ke, C, threadIdx.x) * dt);
         pr[threadIdx.x] = pn;
@@ -155,13 +199,13 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_pre_kernel(
     const float* __restrict__ v_t, const float* __restrict__ q_t, const float* __restrict__ pv_t,
     const float* __restrict__ lv, const float* __restrict__ mass, const long long* __restrict__ idx, int R, int n, int C,
     float* __restrict__ v, float* __restrict__ q, float* __restrict__ pv, float* __restrict__ w) {
-    const int r = blockIdx.x;
-    const size_t o = (size_t)r * n * 3, fo = (size_t)idx[0] * R * n * 3 + o;
-    for (int e = threadIdx.x; e < 3 * n; e += NHC_BLOCK) {
+    NHV_RANGE;
+    const size_t fo = (size_t)idx[0] * R * n * 3 + o;
+    for (int e = e0 + threadIdx.x; e < e1; e += NHC_BLOCK) {
         v[o + e] = v_t[fo + e]; q[o + e] = q_t[fo + e];
         w[o + e] = lv[o + e] / mass[(size_t)r * n + e / 3];
     }
-    if (threadIdx.x < C) pv[(size_t)r * C + threadIdx.x] = pv_t[((size_t)idx[0] * R + r) * C + threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < C) pv[(size_t)r * C + threadIdx.x] = pv_t[((size_t)idx[0] * R + r) * C + threadIdx.x];
 }
 
 // adjoint, after the first evaluation (F, dwF_dq at frame i): midpoint state and half-step adjoint
@@ -170,22 +214,21 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_mid_kernel(
     const float* __restrict__ v, const float* __restrict__ q, const float* __restrict__ pv, const float* __restrict__ lv,
     const float* __restrict__ lq, const float* __restrict__ lp, const float* __restrict__ f, const float* __restrict__ dwf,
     const float* __restrict__ mass, const float* __restrict__ Q, const float* __restrict__ Tp, float n_dof,
-    const float* __restrict__ t, const long long* __restrict__ idx, int n, int C, float* __restrict__ vh,
+    const float* __restrict__ t, const long long* __restrict__ idx, int R, int n, int C, float* __restrict__ vh,
     float* __restrict__ qm, float* __restrict__ pm, float* __restrict__ lvh, float* __restrict__ lqh,
-    float* __restrict__ lph, float* __restrict__ wh) {
+    float* __restrict__ lph, float* __restrict__ wh, float* __restrict__ scratch) {
     __shared__ float red[32];
     __shared__ float ps[MDG_MAX_CHAINS], ls[MDG_MAX_CHAINS];
-    const int r = blockIdx.x;
-    const size_t o = (size_t)r * n * 3;
+    NHV_RANGE;
     const long long i = idx[0];
     const float h = t[i] - t[i - 1], hh = 0.5f * h, T = Tp[0];
     if (threadIdx.x < C) { ps[threadIdx.x] = pv[(size_t)r * C + threadIdx.x]; ls[threadIdx.x] = lp[(size_t)r * C + threadIdx.x]; }
     __syncthreads();
     const float pv0 = ps[0], lp0 = ls[0], q0 = Q[0];
-    float p1 = 0.f, p2 = 0.f;
-    for (int e = threadIdx.x; e < 3 * n; e += NHC_BLOCK) {
+    float s[2] = {0.f, 0.f};
+    for (int e = e0 + threadIdx.x; e < e1; e += NHC_BLOCK) {
         const float m = mass[(size_t)r * n + e / 3], ve = v[o + e], p = ve * m, le = lv[o + e];
-        p1 += p * p / m; p2 += le * ve;
+        s[0] += p * p / m; s[1] += le * ve;
         const float a = (f[o + e] - pv0 * p / q0) / m;
         const float Gv = -(pv0 / q0) * le + lq[o + e] + 2.f * m * ve * lp0;
         const float vhe = ve - a * hh;                                          // :132
@@ -196,7 +239,8 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_mid_kernel(
         lqh[o + e] = lq[o + e] + dwf[o + e] * hh;                               // :142
         wh[o + e] = lvhe / m;
     }
-    const float ke = 0.5f * block_sum(p1, red), slv = block_sum(p2, red);
+    if (!replica_sum(s, red, scratch, R, r)) return;
+    const float ke = 0.5f * s[0], slv = s[1];
     if (threadIdx.x < C) {
         pm[(size_t)r * C + threadIdx.x] = ps[threadIdx.x] - nhc_bath(ps, Q, T, n_dof, ke, C, threadIdx.x) * hh;      // :135
         lph[(size_t)r * C + threadIdx.x] = ls[threadIdx.x] + nhc_bath_vjp(ps, ls, Q, slv, C, threadIdx.x) * hh;     // :143
@@ -209,30 +253,31 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_end_kernel(
     const float* __restrict__ lph, const float* __restrict__ dwf, const float* __restrict__ mass,
     const float* __restrict__ Q, const float* __restrict__ t, const long long* __restrict__ idx,
     const float* __restrict__ g_v, const float* __restrict__ g_q, const float* __restrict__ g_pv, int R, int n, int C,
-    float* __restrict__ lv, float* __restrict__ lq, float* __restrict__ lp) {
+    float* __restrict__ lv, float* __restrict__ lq, float* __restrict__ lp, float* __restrict__ scratch) {
     __shared__ float red[32];
     __shared__ float ps[MDG_MAX_CHAINS], ls[MDG_MAX_CHAINS];
-    const int r = blockIdx.x;
-    const size_t o = (size_t)r * n * 3;
+    NHV_RANGE;
     const long long i = idx[0];
     const float h = t[i] - t[i - 1];
     const size_t go = (size_t)(i - 1) * R * n * 3 + o;
     if (threadIdx.x < C) { ps[threadIdx.x] = pm[(size_t)r * C + threadIdx.x]; ls[threadIdx.x] = lph[(size_t)r * C + threadIdx.x]; }
     __syncthreads();
     const float pv0 = ps[0], lp0 = ls[0], q0 = Q[0];
-    float part = 0.f;
-    for (int e = threadIdx.x; e < 3 * n; e += NHC_BLOCK) {
+    float s[1] = {0.f};
+    for (int e = e0 + threadIdx.x; e < e1; e += NHC_BLOCK) {
         const float m = mass[(size_t)r * n + e / 3], ve = vh[o + e], le = lvh[o + e];
-        part += le * ve;
+        s[0] += le * ve;
         const float Gv = -(pv0 / q0) * le + lqh[o + e] + 2.f * m * ve * lp0;
         lv[o + e] = lv[o + e] + Gv * h + g_v[go + e];
         lq[o + e] = lq[o + e] + dwf[o + e] * h + g_q[go + e];
     }
-    const float slv = block_sum(part, red);
+    if (!replica_sum(s, red, scratch, R, r)) return;
+    const float slv = s[0];
     if (threadIdx.x < C)
         lp[(size_t)r * C + threadIdx.x] = lp[(size_t)r * C + threadIdx.x] + nhc_bath_vjp(ps, ls, Q, slv, C, threadIdx.x) * h +
                                           g_pv[((size_t)(i - 1) * R + r) * C + threadIdx.x];
 }
+#undef NHV_RANGE
 
 }  // namespace
 
@@ -258,13 +303,20 @@ extern "C" int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, con
     return MDG_OK;
 }
 
+// floats of the cross-workgroup scratch the mdg_nhv_* launches of one (n_rep, n_atoms) share; ZERO it once
+extern "C" int64_t mdg_nhv_scratch_floats(int n_rep, int n_atoms) {
+    if (n_rep <= 0 || n_atoms <= 0) return 0;
+    return (int64_t)n_rep * nhv_chunks(n_atoms) * 2 + n_rep;
+}
+
 extern "C" int mdg_nhv_kick(const float* v, const float* q, const float* pv, const float* f, const float* mass, const float* Q,
                             const float* T, float n_dof, const float* t, const int64_t* idx, int n_rep, int n_atoms,
-                            int n_chains, float* dv_h, float* dp_h, float* qn, void* stream) {
-    MDG_CHECK_ARG(v && q && pv && f && mass && Q && T && t && idx && dv_h && dp_h && qn, "nhv_kick: null buffer");
+                            int n_chains, float* dv_h, float* dp_h, float* qn, float* scratch, void* stream) {
+    MDG_CHECK_ARG(v && q && pv && f && mass && Q && T && t && idx && dv_h && dp_h && qn && scratch, "nhv_kick: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_kick: bad sizes");
-    hipLaunchKernelGGL(nhv_kick_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv, f, mass, Q, T, n_dof, t,
-                       reinterpret_cast<const long long*>(idx), n_atoms, n_chains, dv_h, dp_h, qn);
+    hipLaunchKernelGGL(nhv_kick_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv, f,
+                       mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_rep, n_atoms, n_chains, dv_h, dp_h, qn,
+                       scratch);
     MDG_CHECK_LAUNCH("nhv_kick_kernel");
     return MDG_OK;
 }
@@ -272,13 +324,13 @@ extern "C" int mdg_nhv_kick(const float* v, const float* q, const float* pv, con
 extern "C" int mdg_nhv_finish(float* v, float* q, float* pv, float* f, const float* dv_h, const float* dp_h, const float* qn,
                               const float* fn, const float* mass, const float* Q, const float* T, float n_dof,
                               const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* out_v,
-                              float* out_q, float* out_pv, void* stream) {
-    MDG_CHECK_ARG(v && q && pv && f && dv_h && dp_h && qn && fn && mass && Q && T && t && idx && out_v && out_q && out_pv,
-                  "nhv_finish: null buffer");
+                              float* out_q, float* out_pv, float* scratch, void* stream) {
+    MDG_CHECK_ARG(v && q && pv && f && dv_h && dp_h && qn && fn && mass && Q && T && t && idx && out_v && out_q && out_pv &&
+                  scratch, "nhv_finish: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_finish: bad sizes");
-    hipLaunchKernelGGL(nhv_finish_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv, f, dv_h, dp_h, qn, fn,
-                       mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_rep, n_atoms, n_chains, out_v, out_q,
-                       out_pv);
+    hipLaunchKernelGGL(nhv_finish_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv,
+                       f, dv_h, dp_h, qn, fn, mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_rep, n_atoms,
+                       n_chains, out_v, out_q, out_pv, scratch);
     MDG_CHECK_LAUNCH("nhv_finish_kernel");
     return MDG_OK;
 }
@@ -287,8 +339,9 @@ extern "C" int mdg_nhv_adj_pre(const float* v_t, const float* q_t, const float* 
                                const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* v, float* q, float* pv,
                                float* w, void* stream) {
     MDG_CHECK_ARG(v_t && q_t && pv_t && lv && mass && idx && v && q && pv && w, "nhv_adj_pre: null buffer");
-    hipLaunchKernelGGL(nhv_adj_pre_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v_t, q_t, pv_t, lv, mass,
-                       reinterpret_cast<const long long*>(idx), n_rep, n_atoms, n_chains, v, q, pv, w);
+    MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0, "nhv_adj_pre: bad sizes");
+    hipLaunchKernelGGL(nhv_adj_pre_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v_t, q_t,
+                       pv_t, lv, mass, reinterpret_cast<const long long*>(idx), n_rep, n_atoms, n_chains, v, q, pv, w);
     MDG_CHECK_LAUNCH("nhv_adj_pre_kernel");
     return MDG_OK;
 }
@@ -297,13 +350,13 @@ extern "C" int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, 
                                const float* lp, const float* f, const float* dwf, const float* mass, const float* Q,
                                const float* T, float n_dof, const float* t, const int64_t* idx, int n_rep, int n_atoms,
                                int n_chains, float* vh, float* qm, float* pm, float* lvh, float* lqh, float* lph, float* wh,
-                               void* stream) {
+                               float* scratch, void* stream) {
     MDG_CHECK_ARG(v && q && pv && lv && lq && lp && f && dwf && mass && Q && T && t && idx && vh && qm && pm && lvh && lqh &&
-                  lph && wh, "nhv_adj_mid: null buffer");
+                  lph && wh && scratch, "nhv_adj_mid: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_adj_mid: bad sizes");
-    hipLaunchKernelGGL(nhv_adj_mid_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv, lv, lq, lp, f, dwf,
-                       mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_atoms, n_chains, vh, qm, pm, lvh, lqh,
-                       lph, wh);
+    hipLaunchKernelGGL(nhv_adj_mid_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv,
+                       lv, lq, lp, f, dwf, mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_rep, n_atoms,
+                       n_chains, vh, qm, pm, lvh, lqh, lph, wh, scratch);
     MDG_CHECK_LAUNCH("nhv_adj_mid_kernel");
     return MDG_OK;
 }
@@ -311,12 +364,13 @@ extern "C" int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, 
 extern "C" int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const float* lqh, const float* lph,
                                const float* dwf, const float* mass, const float* Q, const float* t, const int64_t* idx,
                                const float* g_v, const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains,
-                               float* lv, float* lq, float* lp, void* stream) {
-    MDG_CHECK_ARG(vh && pm && lvh && lqh && lph && dwf && mass && Q && t && idx && g_v && g_q && g_pv && lv && lq && lp,
-                  "nhv_adj_end: null buffer");
+                               float* lv, float* lq, float* lp, float* scratch, void* stream) {
+    MDG_CHECK_ARG(vh && pm && lvh && lqh && lph && dwf && mass && Q && t && idx && g_v && g_q && g_pv && lv && lq && lp &&
+                  scratch, "nhv_adj_end: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_adj_end: bad sizes");
-    hipLaunchKernelGGL(nhv_adj_end_kernel, dim3(n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, vh, pm, lvh, lqh, lph, dwf, mass,
-                       Q, t, reinterpret_cast<const long long*>(idx), g_v, g_q, g_pv, n_rep, n_atoms, n_chains, lv, lq, lp);
+    hipLaunchKernelGGL(nhv_adj_end_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, vh, pm,
+                       lvh, lqh, lph, dwf, mass, Q, t, reinterpret_cast<const long long*>(idx), g_v, g_q, g_pv, n_rep, n_atoms,
+                       n_chains, lv, lq, lp, scratch);
     MDG_CHECK_LAUNCH("nhv_adj_end_kernel");
     return MDG_OK;
 }

@@ -171,8 +171,9 @@ extern "C" int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCe
     dim3 grid(nblocks);
     hipStream_t st = (hipStream_t)stream;
     switch (lpa) { MDG_ELL_LAUNCH(8) MDG_ELL_LAUNCH(16) MDG_ELL_LAUNCH(32) MDG_ELL_LAUNCH(64) }
-    hipLaunchKernelGGL(pair_ell_finish, dim3(NSCAL), dim3(64), 0, st, partial, nblocks, term->n_theta, energy,
-                       gtheta, gtheta_w);
+    if (energy || gtheta || gtheta_w)            // (a force-only evaluation has no scalar to finish)
+        hipLaunchKernelGGL(pair_ell_finish, dim3(NSCAL), dim3(64), 0, st, partial, nblocks, term->n_theta, energy,
+                           gtheta, gtheta_w);
     MDG_CHECK_LAUNCH("pair_ell_kernel");
     return MDG_OK;
 }

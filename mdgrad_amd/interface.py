@@ -327,8 +327,30 @@ class PairPotentials(GeneralInteraction):
         return F, -ops._edge_scatter(hv, topo), gth
 
     def _theta(self, like):
+        """(flat parameter vector of the pair form, its parameters).  The vector lives in a persistent buffer that is
+        refreshed when a parameter changed (version counters); inside a HIP-graph capture it is returned as it is -- the
+        replaying pass refreshes it once before its first replay (`prepare_pass`), so the captured steps carry no `cat`."""
         params = self.model.mdg_params()
-        return (torch.cat([p.detach().reshape(-1) for p in params]) if params else like.new_zeros(0)), params
+        if not params:
+            return like.new_zeros(0), params
+        n = sum(p.numel() for p in params)
+        buf = getattr(self, "_theta_buf", None)
+        if buf is None or buf.numel() != n or buf.device != params[0].device:
+            if params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+                return torch.cat([p.detach().reshape(-1) for p in params]), params
+            buf = self._theta_buf = torch.empty(n, device=params[0].device, dtype=torch.float32)
+            self._theta_key = None
+        if params[0].is_cuda and torch.cuda.is_current_stream_capturing():
+            return buf, params
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        if self._theta_key != key:
+            torch.cat([p.detach().reshape(-1).to(torch.float32) for p in params], out=buf)
+            self._theta_key = key
+        return buf, params
+
+    def prepare_pass(self):
+        if self.builtin():
+            self._theta(self.cell)
 
     accepts_into = True
 
@@ -340,7 +362,7 @@ class PairPotentials(GeneralInteraction):
             return f if into is None else into.add_(f)
         theta, _ = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, energy=False, grad=True,
-                          into=None if into is None else (into, None), scale=-1.0)
+                          into=None if into is None else (into, None), scale=-1.0, theta_grads=False)
         return o["grad"]
 
     accepts_accum = True
@@ -360,7 +382,7 @@ class PairPotentials(GeneralInteraction):
             return out[0], out[1], None
         theta, params = self._theta(xyz)
         o = ops.pair_eval(self._ell, xyz.detach().contiguous(), self.mdg_term(0), theta, w=w.detach().contiguous(),
-                          energy=False, grad=True, into=into, scale=-1.0)
+                          energy=False, grad=True, into=into, scale=-1.0, theta_grads=bool(want_theta))
         if accum is not None and want_theta:
             if params:
                 jobs, pos = ops.GradJobs(), 0
@@ -372,6 +394,8 @@ class PairPotentials(GeneralInteraction):
                         jobs.axpy(o_, o["gtheta_w"][pos:pos + p.numel()])
                         pos += p.numel()
                 jobs.run(accum, alpha=-1.0, accumulate=True)
+            return o["grad"], o["hw"], None
+        if not want_theta:
             return o["grad"], o["hw"], None
         gth, pos = [], 0
         for p in params:

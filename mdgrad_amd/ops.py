@@ -162,10 +162,11 @@ def make_term(desc, cutoff, theta_off=0, n_theta=0, mask=None):
     return t
 
 
-def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True, into=None, scale=1.0):
+def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True, into=None, scale=1.0, theta_grads=True):
     """One launch of mdg_pair_eval_ell.  Returns dict with the requested outputs.  `into` = (grad_buffer, hw_buffer or
     None): the per-atom outputs are ADDED onto those buffers, times `scale` (F += -dU/dx of a Stack member without extra
-    launches); without `into`, `scale` multiplies the fresh outputs."""
+    launches); without `into`, `scale` multiplies the fresh outputs.  theta_grads=False: dU/dtheta and d(w.dU/dx)/dtheta are
+    not wanted (a force-only evaluation then skips the scalar reduction launch)."""
     lib = _lib.load()
     require_gpu(xyz, "xyz")
     if theta is not None and theta.numel():
@@ -180,9 +181,9 @@ def pair_eval(ell, xyz, term, theta, w=None, energy=True, grad=True, into=None, 
     e = torch.empty(1, device=dev) if energy else None
     acc = into is not None
     g = (into[0] if acc else torch.empty(N, 3, device=dev)) if grad else None
-    gth = torch.empty(K, device=dev) if (grad and K) else None
+    gth = torch.empty(K, device=dev) if (grad and K and theta_grads) else None
     hw = (into[1] if acc else torch.empty(N, 3, device=dev)) if w is not None else None
-    gthw = torch.empty(K, device=dev) if (w is not None and K) else None
+    gthw = torch.empty(K, device=dev) if (w is not None and K and theta_grads) else None
     partial = torch.empty(int(lib.mdg_pair_partial_size(N)), device=dev)
     recheck = bool(getattr(ell, "verlet", False))        # a list searched with a skin: exact cutoff test per pair
     if acc or scale != 1.0 or recheck:
@@ -805,6 +806,9 @@ class NhvWork:
         self.vh, self.qm, self.pm = z(like_v), z(like_v), z(like_pv)
         self.lvh, self.lqh, self.lph, self.wh = z(like_v), z(like_v), z(like_pv), z(like_v)
         self._T = integ._T_device
+        # cross-workgroup partial sums + tickets of the multi-workgroup launches (zeroed once; the kernels hand the
+        # tickets back at zero)
+        self.scratch = torch.zeros(int(_lib.load().mdg_nhv_scratch_floats(self.R, self.n)), device=like_v.device)
 
     def _a(self):
         return ptr(self.mass), ptr(self.Q), ptr(self._T()), self.n_dof
@@ -813,7 +817,8 @@ class NhvWork:
         lib = _lib.load()
         m, Q, T, nd = self._a()
         check(lib.mdg_nhv_kick(ptr(v), ptr(q), ptr(pv), ptr(f), m, Q, T, nd, ptr(t), ptr(k), self.R, self.n, self.C,
-                               ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn), stream_ptr(v.device)), "mdg_nhv_kick")
+                               ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn), ptr(self.scratch), stream_ptr(v.device)),
+              "mdg_nhv_kick")
         _touched(self.qn)
         return self.qn
 
@@ -822,7 +827,7 @@ class NhvWork:
         m, Q, T, nd = self._a()
         check(lib.mdg_nhv_finish(ptr(v), ptr(q), ptr(pv), ptr(f), ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn),
                                  ptr(fn.contiguous()), m, Q, T, nd, ptr(t), ptr(k), self.R, self.n, self.C, ptr(out[0]),
-                                 ptr(out[1]), ptr(out[2]), stream_ptr(v.device)), "mdg_nhv_finish")
+                                 ptr(out[1]), ptr(out[2]), ptr(self.scratch), stream_ptr(v.device)), "mdg_nhv_finish")
         _touched(v, q, pv, f, *out)
 
     def adj_pre(self, ans, lv, i):
@@ -839,7 +844,7 @@ class NhvWork:
         check(lib.mdg_nhv_adj_mid(ptr(self.v), ptr(self.q), ptr(self.pv), ptr(lam[0]), ptr(lam[1]), ptr(lam[2]),
                                   ptr(f.contiguous()), ptr(dwf.contiguous()), m, Q, T, nd, ptr(t), ptr(i), self.R, self.n,
                                   self.C, ptr(self.vh), ptr(self.qm), ptr(self.pm), ptr(self.lvh), ptr(self.lqh),
-                                  ptr(self.lph), ptr(self.wh), stream_ptr(f.device)), "mdg_nhv_adj_mid")
+                                  ptr(self.lph), ptr(self.wh), ptr(self.scratch), stream_ptr(f.device)), "mdg_nhv_adj_mid")
         _touched(self.qm, self.wh)
         return self.qm, self.wh
 
@@ -848,7 +853,7 @@ class NhvWork:
         check(lib.mdg_nhv_adj_end(ptr(self.vh), ptr(self.pm), ptr(self.lvh), ptr(self.lqh), ptr(self.lph),
                                   ptr(dwf.contiguous()), ptr(self.mass), ptr(self.Q), ptr(t), ptr(i), ptr(gout[0]),
                                   ptr(gout[1]), ptr(gout[2]), self.R, self.n, self.C, ptr(lam[0]), ptr(lam[1]), ptr(lam[2]),
-                                  stream_ptr(dwf.device)), "mdg_nhv_adj_end")
+                                  ptr(self.scratch), stream_ptr(dwf.device)), "mdg_nhv_adj_end")
         _touched(*lam)
 
 

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--replicas", type=int, default=1, help="stack R replicas (System.replicate) in one trajectory")
     ap.add_argument("--table-nodes", type=int, default=0, help="mlp108: nodes of the tabulated pair energy (0 = default)")
+    ap.add_argument("--bf16", action="store_true", help="gnn*: bf16 MFMA operands in the filter network (both sweeps)")
     args = ap.parse_args()
     from mdgrad_amd import potentials as P, units
     from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
@@ -131,6 +132,7 @@ def main():
                              "cutoff": 6.0})
             with torch.no_grad():   # tame the random-init network so the synthetic dynamics stay finite
                 net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
+            net.filter_bf16 = bool(args.bf16)
             gnn = GNNPotentials(system, net, cutoff=6.0)
             prior = PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)
             integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=kT, num_chains=5, Q=50.0).to(dev)
