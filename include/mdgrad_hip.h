@@ -508,6 +508,44 @@ int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, i
              float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K13  a CHAIN of such Dense layers in one launch (csrc/rowchain.hip): between two continuous-filter convolutions every
+ * operation of a SchNet block is local to one atom's feature row -- update MLP + residual (nff/nn/modules.py:543-547,
+ * nff/nn/models/schnet.py:149-151), the next block's message_node_filter, the readout (nff/nn/modules.py:761-809) -- and so
+ * is the stretch of the hand-derived reverse sweeps from the readout head back to the adjoint of the last aggregation.  A
+ * workgroup owns 16 rows and walks the stages; a stage's outputs stay on chip as the next stage's input and are copied to
+ * the global buffers the caller names.  Per stage (x = in0 / in1 when given, else the previous stage's outputs):
+ *     z0 = x0 B + bias ; z1 = x1 B                        B[k][m] = W[m*K + k] (trans = 0) or W[k*M + m] (trans = 1)
+ *     act = 1:          out0 = ssp(z0), sig = sigmoid(z0), out1 = sig z1
+ *     MDG_CHAIN_MUL     out0 *= aux0[row, m]
+ *     MDG_CHAIN_HEAD    (act = 1) pre0 = out0, pre1 = out1 ; out0 = sig aux0[m] ; out1 = (1 - sig) pre1 aux0[m]
+ *     MDG_CHAIN_SSP_BWD out0 = s z0 ; out1 = (1 - s) td z0 + s z1         (s = aux0[row, m], td = aux1[row, m])
+ *     then out0 += res0[row, m], out1 += res1[row, m]
+ * dual = 0: only the "0" operands are touched.  aux0 / aux1 / res may be buffers an EARLIER stage of the same call wrote
+ * with the same width M (same owner thread); any other aliasing between a stage's outputs and a later stage's inputs is
+ * not allowed.  Widths 1..MDG_CHAIN_MAX_WIDTH, 1..MDG_CHAIN_MAX_STAGES stages.
+ */
+#define MDG_CHAIN_MAX_STAGES 8
+#define MDG_CHAIN_MAX_WIDTH 512
+enum { MDG_CHAIN_NONE = 0, MDG_CHAIN_MUL = 1, MDG_CHAIN_HEAD = 2, MDG_CHAIN_SSP_BWD = 3 };
+typedef struct {
+    const float* W;
+    const float* bias;
+    const float* in0;
+    const float* in1;
+    const float* res0;
+    const float* res1;
+    const float* aux0;
+    const float* aux1;
+    float* out0;
+    float* out1;
+    float* sig;
+    float* pre0;
+    float* pre1;
+    int32_t K, M, trans, act, mode, pad_;
+} MdgChainStage;
+int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * All parameter-gradient reductions of one SchNet adjoint evaluation in two launches (csrc/gradjobs.hip): what double
  * autograd accumulates into the .grad of the Dense weights / biases and the embedding of nff/nn/modules.py:514-575 and
  * nff/nn/models/schnet.py:113-171 while it differentiates w.F (torchmd/sovlers.py:229-233), times the interval weight of

@@ -58,6 +58,16 @@ class MdgGradJob(C.Structure):
 
 GRAD_ATB, GRAD_COLSUM, GRAD_AXPY, GRAD_JOBS_MAX = 0, 1, 2, 32
 
+
+class MdgChainStage(C.Structure):
+    """One Dense stage of mdg_row_chain (include/mdgrad_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("W", "bias", "in0", "in1", "res0", "res1", "aux0", "aux1", "out0", "out1", "sig",
+                                          "pre0", "pre1")] + \
+               [(n, C.c_int32) for n in ("K", "M", "trans", "act", "mode", "pad_")]
+
+
+CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512
+
 P = C.c_void_p
 _SIGNATURES = {
     "mdg_last_error": (C.c_char_p, []),
@@ -115,6 +125,7 @@ _SIGNATURES = {
                                       C.c_int, P, P, P]),
     "mdg_nhc_rhs": (C.c_int, [P, P, P, P, P, P, C.c_float, C.c_int, C.c_int, C.c_int, P, P, P]),
     "mdg_nhc_vjp": (C.c_int, [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P]),
+    "mdg_row_chain": (C.c_int, [C.POINTER(MdgChainStage), C.c_int, C.c_int, C.c_int, P]),
     "mdg_nhv_scratch_floats": (C.c_int64, [C.c_int, C.c_int]),
     "mdg_nhv_kick": (C.c_int, [P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
     "mdg_nhv_finish": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),

@@ -31,7 +31,7 @@ import math
 
 import torch
 
-from .. import ops
+from .. import ops, _lib as C_
 
 _LN2 = math.log(2.0)
 
@@ -405,11 +405,166 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accu
     return fw["U"], F, dwf, acc.views()
 
 
+# ------------------------------------------------------------------------------------------------ row chains
+# Between two aggregations every layer is local to an atom's feature row: the launches of _force_fused /
+# _force_vjp_fused that are not cfconv kernels collapse into one mdg_row_chain launch per stretch (csrc/rowchain.hip):
+#   forward   [m -> update MLP -> residual -> next block's message_node_filter]                      per inner block
+#   turn      [m -> update MLP -> residual -> readout -> head -> readout^T -> U2^T -> ssp' -> U1^T] last block
+#   reverse   [hb -> message_node_filter^T + residual -> U2^T -> ssp' -> U1^T]                     per inner block
+def chain_ok(net):
+    """The row-chain kernel takes every node-level layer of this network (and is not switched off)."""
+    if getattr(net, "row_chain", True) is False or not fused_ok(net):
+        return False
+    ws = []
+    for conv in net.convolutions:
+        P = _layer_params(conv)
+        ws += list(P["Wn"].shape) + list(P["U1"].shape) + list(P["U2"].shape)
+    ws += list(net.atomwisereadout.readout["energy"][0].weight.shape)
+    return ops.RowChain.supported(*ws)
+
+
+def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
+    """Primal (+ tangent along w) sweep and the turn at the readout: -> (fw, adjoints entering the last block's
+    aggregation).  With w = None: first order (the force), one row per atom instead of a dual pair."""
+    dual = w is not None
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    convs = list(net.convolutions)
+    Ps = [_layer_params(c) for c in convs]
+    fns = [ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"],
+                         bf16=getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False)) for c, P in zip(convs, Ps)]
+    ro = net.atomwisereadout.readout["energy"]
+    L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
+    N, dev = z.shape[0], x.device
+    r, rd = _embedded(net, z), None                               # r_dot^0 = 0
+    h, _, hd = _dense(Ps[0]["Wn"], r, bias=Ps[0]["bn"])           # message_node_filter of the first block
+    layers, turn = [], None
+    for i, P in enumerate(Ps):
+        m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, h, hd, topo, want_sums)
+        ch = ops.RowChain(N, dual, dev)
+        a = ch.stage(P["U1"], bias=P["c1"], act=True, in0=m, in1=md, want_sig=True)         # t, su, td
+        b = ch.stage(P["U2"], bias=P["c2"], res0=r, res1=rd)                                # residual (schnet.py:149-151)
+        layers.append(dict(P=P, fn=fns[i], r=r, rd=rd, h=h, hd=hd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=a.out0, su=a.sig,
+                           td=a.out1))
+        r, rd = b.out0, b.out1
+        if i + 1 < len(Ps):
+            c = ch.stage(Ps[i + 1]["Wn"], bias=Ps[i + 1]["bn"])
+            h, hd = c.out0, c.out1
+        else:
+            y = ch.stage(L1, bias=l1, act=True, mode=C_.CHAIN_HEAD, aux0=L2, want_sig=True, want_pre=(want_energy, True))
+            g = ch.stage(L1, trans=True)                                                    # rdb, rb
+            if dual:
+                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)   # udb, ub
+            else:
+                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=a.sig)
+            f = ch.stage(P["U1"], trans=True)                                               # mdb, mb
+            turn = dict(y=y, g=g, e=e, f=f)
+        ch.run()
+    y = turn["y"]
+    U = (y.pre0.mm(L2.t()) + l2).sum() if want_energy else None     # (the integrators only ask for forces)
+    fw = dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=y.sig, syd=y.pre1, L1=L1, L2=L2, U=U)
+    return fw, turn
+
+
+@torch.no_grad()
+def _force_chain(net, z, x, topo, want_energy=True):
+    fw, turn = _chain_forward(net, z, x, topo, None, False, want_energy)
+    d, layers = fw["d"], fw["layers"]
+    rb, mb = turn["g"].out0, turn["f"].out0
+    dU_dd = torch.zeros_like(d)
+    for idx in range(len(layers) - 1, -1, -1):
+        L = layers[idx]
+        ops.cfconv_bwd(L["fn"], d, None, topo, L["h"], None, None, mb, None, dU_dd)
+        if idx > 0:                                               # (the embedding below layer 0 is not needed)
+            hb = ops.cfconv_fwd(L["fn"], d, None, mb, None, topo)[0]
+            Lp = layers[idx - 1]
+            ch = ops.RowChain(z.shape[0], False, x.device)
+            g = ch.stage(L["P"]["Wn"], trans=True, in0=hb, res0=rb)
+            ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
+            f = ch.stage(Lp["P"]["U1"], trans=True)
+            ch.run()
+            rb, mb = g.out0, f.out0
+    F, _ = ops.edge_geom_bwd(None, dU_dd, None, None, fw["uhat"], None, topo)
+    return fw["U"], F
+
+
+@torch.no_grad()
+def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accum=None):
+    """_force_vjp_fused with the node-level layers chained (same results, same argument meaning)."""
+    fw, turn = _chain_forward(net, z, x, topo, w, want_theta, want_energy)
+    d, dd, layers = fw["d"], fw["dd"], fw["layers"]
+    ro = net.atomwisereadout.readout["energy"]
+    ydb, yb = turn["y"].out0, turn["y"].out1
+    rdb, rb = turn["g"].out0, turn["g"].out1
+    udb, ub = turn["e"].out0, turn["e"].out1
+    mdb, mb = turn["f"].out0, turn["f"].out1
+    jobs = acc = None
+    if want_theta:
+        acc = accum if accum is not None else ops.ThetaAccum(net.parameters())
+        off = lambda p: acc.off[id(p)]
+        jobs = ops.GradJobs()
+        jobs.colsum(off(ro[2].weight), fw["syd"])                                    # (ro[2].bias: U_dot does not see it)
+        jobs.atb(off(ro[0].weight), yb, fw["r"], ydb, fw["rd"])
+        jobs.colsum(off(ro[0].bias), yb)
+    both = torch.zeros(2, d.shape[0], device=d.device, dtype=d.dtype)        # (one fill for the two per-edge accumulators)
+    d_b, dd_b = both[0], both[1]
+    convs = list(net.convolutions)
+    for idx in range(len(convs) - 1, -1, -1):
+        L, md_ = layers[idx], convs[idx].moduledict
+        P = L["P"]
+        if want_theta:
+            jobs.atb(off(md_["update_function"][2].weight), rb, L["t"], rdb, L["td"])
+            jobs.colsum(off(md_["update_function"][2].bias), rb)
+            jobs.atb(off(md_["update_function"][0].weight), udb, L["md"], ub, L["m"])
+            jobs.colsum(off(md_["update_function"][0].bias), ub)
+        smear_t = want_theta and _trainable_smear(convs[idx])
+        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta, want_smear=smear_t)
+        if smear_t:
+            sm = md_["message_edge_filter"][0]
+            jobs.axpy(off(sm.offsets), th[3])
+            jobs.axpy(off(sm.width), th[4] * sm.width.detach().pow(-3))
+        if want_theta:
+            jobs.axpy(off(md_["message_edge_filter"][1].weight), th[0])
+            jobs.axpy(off(md_["message_edge_filter"][1].bias), th[1])
+            jobs.axpy(off(md_["message_edge_filter"][3].weight), th[2])
+            if L["hdsum"] is not None:
+                jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"], mdb, L["hdsum"])
+            else:
+                jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"])
+        if want_theta or idx > 0:
+            hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
+            if want_theta:
+                if L["rd"] is not None:
+                    jobs.atb(off(md_["message_node_filter"].weight), hb, L["r"], hdb, L["rd"])
+                else:
+                    jobs.atb(off(md_["message_node_filter"].weight), hb, L["r"])
+                jobs.colsum(off(md_["message_node_filter"].bias), hb)
+            if idx > 0:
+                Lp = layers[idx - 1]
+                ch = ops.RowChain(z.shape[0], True, x.device)
+                g = ch.stage(P["Wn"], trans=True, in0=hdb, in1=hb, res0=rdb, res1=rb)
+                e = ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
+                f = ch.stage(Lp["P"]["U1"], trans=True)
+                ch.run()
+                rdb, rb, udb, ub, mdb, mb = g.out0, g.out1, e.out0, e.out1, f.out0, f.out1
+            else:
+                rdb, _, rb = _dense(P["Wn"], hdb, trans=True, res=rdb, x1=hb, res1=rb)
+    F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
+    if not want_theta:
+        return fw["U"], F, dwf, None
+    uniq, onehot = _species_onehot(z)
+    jobs.atb(off(net.atom_embed.weight), onehot, rb, row_map=uniq)
+    jobs.run(acc, alpha=-1.0, accumulate=True)                   # w.F = -U_dot
+    if accum is not None:
+        return fw["U"], F, dwf, None
+    return fw["U"], F, dwf, acc.views()
+
+
 @torch.no_grad()
 def force(net, z, x, topo, offsets=None, want_energy=True):
     if fused_ok(net):
         with _node_blas():
-            return _force_fused(net, z, x.detach().contiguous(), topo, want_energy)
+            fn = _force_chain if chain_ok(net) else _force_fused
+            return fn(net, z, x.detach().contiguous(), topo, want_energy)
     topo = _stable(topo)
     with _blas_for(topo):
         fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
@@ -424,8 +579,8 @@ def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=Tru
     argument is kept for callers that pass it explicitly.)"""
     if fused_ok(net):
         with _node_blas():
-            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy,
-                                    accum)
+            fn = _force_vjp_chain if chain_ok(net) else _force_vjp_fused
+            return fn(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
     topo = _stable(topo)
     with _blas_for(topo):
         out = _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)

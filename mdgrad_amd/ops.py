@@ -1492,6 +1492,53 @@ class GradJobs:
                                     ptr(ws), stream_ptr(dev)), "mdg_grad_jobs")
 
 
+class _ChainOut:
+    __slots__ = ("out0", "out1", "sig", "pre0", "pre1")
+
+
+class RowChain:
+    """A chain of node-level Dense layers as ONE launch (mdg_row_chain, csrc/rowchain.hip): every stage reads the
+    previous stage's outputs from on-chip memory (or `in0` / `in1`) and leaves global copies of its outputs in fresh
+    [n_rows, M] tensors.  `dual`: primal + tangent rows (or the two adjoints) share the weights."""
+
+    def __init__(self, n_rows, dual, device):
+        self.N, self.dual, self.dev = int(n_rows), bool(dual), device
+        self.stages, self.keep = [], []
+
+    @staticmethod
+    def supported(*widths):
+        return all(1 <= int(w) <= _lib.CHAIN_MAX_WIDTH for w in widths)
+
+    def stage(self, W, trans=False, bias=None, act=False, mode=0, in0=None, in1=None, res0=None, res1=None, aux0=None,
+              aux1=None, want_sig=False, want_pre=(False, False), store=True):
+        """-> the stage's output tensors (out0, out1, sig, pre0, pre1; None where not produced)."""
+        assert len(self.stages) < _lib.CHAIN_MAX_STAGES, "row chain: too many stages"
+        W = W.detach().contiguous()
+        K, M = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
+        cont = lambda t: t.detach().contiguous() if t is not None else None
+        ins = [cont(t) for t in (bias, in0, in1, res0, res1, aux0, aux1)]
+        new = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.float32) if on else None
+        o = _ChainOut()
+        o.out0, o.out1 = new(store), new(store and self.dual)
+        o.sig = new(act and want_sig)
+        o.pre0 = new(mode == _lib.CHAIN_HEAD and want_pre[0])
+        o.pre1 = new(mode == _lib.CHAIN_HEAD and want_pre[1] and self.dual)
+        self.keep.extend([W] + ins)
+        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode)))
+        return o
+
+    def run(self):
+        lib = _lib.load()
+        arr = (_lib.MdgChainStage * len(self.stages))()
+        p = lambda t: t.data_ptr() if t is not None else None
+        for st, (W, ins, o, K, M, trans, act, mode) in zip(arr, self.stages):
+            st.W = W.data_ptr()
+            st.bias, st.in0, st.in1, st.res0, st.res1, st.aux0, st.aux1 = (p(t) for t in ins)
+            st.out0, st.out1, st.sig, st.pre0, st.pre1 = p(o.out0), p(o.out1), p(o.sig), p(o.pre0), p(o.pre1)
+            st.K, st.M, st.trans, st.act, st.mode = K, M, trans, act, mode
+        check(lib.mdg_row_chain(arr, len(self.stages), self.N, int(self.dual), stream_ptr(self.dev)), "mdg_row_chain")
+
+
 def smear_bwd(gdb, gb, g, phi, dd, c, d_b, dd_b):
     """Accumulates into d_b (and dd_b when gdb is given) in place."""
     lib = _lib.load()

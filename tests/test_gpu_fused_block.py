@@ -435,3 +435,95 @@ def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
     flat = torch.cat([t.reshape(-1) for t in gth])
     cos = float((flat.double() * fa.double()).sum() / (flat.double().norm() * fa.double().norm()))
     assert cos > (0.999999 if not bf16 else 0.9999), cos
+
+
+@pytest.mark.parametrize("N,K,M1,M2,M3", [(1000, 128, 64, 64, 32), (4096, 64, 128, 128, 64), (37, 50, 25, 25, 12),
+                                          (530, 512, 512, 512, 256), (129, 384, 130, 130, 65), (16, 8, 8, 8, 4)])
+def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3):
+    """csrc/rowchain.hip: the stretch of the SchNet sweeps around the readout as ONE launch -- update MLP (activation,
+    sigmoid, tangent), residual, readout with the head transform, then the three transposed layers with the reverse of the
+    (ssp, tangent) pair -- every saved tensor against the same sequence in torch, dual and single rows, widths that are
+    not multiples of 16 / 4 and a row count that is not a multiple of the 16-row tile."""
+    from mdgrad_amd import ops, _lib
+    torch.manual_seed(N + K + M1)
+    rn = lambda *s: torch.randn(*s, device=DEV)
+    W1, W2, W3 = rn(M1, K) / K ** 0.5, rn(M2, M1) / M1 ** 0.5, rn(M3, M2) / M2 ** 0.5
+    b1, b2, b3, l = rn(M1), rn(M2), rn(M3), rn(1, M3)
+    x0, x1, r0, r1 = rn(N, K), rn(N, K), rn(N, M2), rn(N, M2)
+    ln2 = float(np.log(2.0))
+    ssp = lambda z: torch.nn.functional.softplus(z) - ln2
+    for dual in (True, False):
+        ch = ops.RowChain(N, dual, x0.device)
+        a = ch.stage(W1, bias=b1, act=True, in0=x0, in1=x1 if dual else None, want_sig=True)
+        b = ch.stage(W2, bias=b2, res0=r0, res1=r1 if dual else None)
+        y = ch.stage(W3, bias=b3, act=True, mode=_lib.CHAIN_HEAD, aux0=l, want_sig=True, want_pre=(True, True))
+        g = ch.stage(W3, trans=True)
+        if dual:
+            e = ch.stage(W2, trans=True, mode=_lib.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)
+        else:
+            e = ch.stage(W2, trans=True, mode=_lib.CHAIN_MUL, aux0=a.sig)
+        f = ch.stage(W1, trans=True)
+        ch.run()
+        z1 = x0 @ W1.t() + b1
+        t, su = ssp(z1), torch.sigmoid(z1)
+        r = t @ W2.t() + b2 + r0
+        z3 = r @ W3.t() + b3
+        sy = torch.sigmoid(z3)
+        ydb = sy * l
+        rdb = ydb @ W3
+        tdb = rdb @ W2
+        _close(a.out0, t, "t"); _close(a.sig, su, "su"); _close(b.out0, r, "r"); _close(y.sig, sy, "sy")
+        _close(y.pre0, ssp(z3), "ty"); _close(y.out0, ydb, "ydb"); _close(g.out0, rdb, "rdb")
+        _close(e.out0, su * tdb, "udb"); _close(f.out0, (su * tdb) @ W1, "mdb")
+        if dual:
+            td = su * (x1 @ W1.t())
+            rd = td @ W2.t() + r1
+            syd = sy * (rd @ W3.t())
+            yb = (1 - sy) * syd * l
+            rb = yb @ W3
+            tb = rb @ W2
+            ub = (1 - su) * td * tdb + su * tb
+            _close(a.out1, td, "td"); _close(b.out1, rd, "rd"); _close(y.pre1, syd, "syd"); _close(y.out1, yb, "yb")
+            _close(g.out1, rb, "rb"); _close(e.out1, ub, "ub"); _close(f.out1, ub @ W1, "mb")
+        else:
+            assert a.out1 is None and y.pre1 is None and f.out1 is None
+    # a stage whose copy is not asked for leaves no tensor, and the chain still feeds the next stage
+    ch = ops.RowChain(N, False, x0.device)
+    ch.stage(W1, bias=b1, in0=x0, store=False)
+    o = ch.stage(W2, bias=b2)
+    ch.run()
+    _close(o.out0, (x0 @ W1.t() + b1) @ W2.t() + b2, "two plain stages, first one not stored")
+    with pytest.raises(RuntimeError):
+        bad = ops.RowChain(N, False, x0.device)
+        bad.stage(W1, in0=x0)
+        bad.stage(rn(5, M1 + 1))                                   # k = M1 + 1 does not match the previous width M1
+        bad.run()
+
+
+@pytest.mark.parametrize("A,F,G,convs", [(64, 128, 30, 2), (48, 64, 16, 3), (100, 96, 25, 1)])
+def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs):
+    """analytic.force / force_vjp with the node-level layers chained (one launch per stretch between aggregations) against
+    the layer-by-layer launches of csrc/dense.hip: energy, force, d(w.F)/dx, d(w.F)/dtheta -- 1, 2 and 3 interaction
+    blocks (the inner forward / reverse chains only exist from 2 blocks on), widths that are not multiples of 16."""
+    from mdgrad_amd.interface import GNNPotentials
+    from mdgrad_amd.nn import get_model, analytic
+    g = load_golden("schnet_cg64")
+    system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    torch.manual_seed(A + convs)
+    net = get_model({"n_atom_basis": A, "n_filters": F, "n_gaussians": G, "n_convolutions": convs, "cutoff": 6.0})
+    gnn = GNNPotentials(system, net, cutoff=6.0)
+    q = T(g["pos"], DEV)
+    gnn._reset_topology(q)
+    assert analytic.chain_ok(net)
+    w = T(np.random.default_rng(3).normal(0, 1, g["pos"].shape).astype(np.float32), DEV)
+    res = []
+    for chain in (True, False):
+        net.row_chain = chain
+        assert analytic.chain_ok(net) == chain
+        U, F_ = analytic.force(net, gnn._z(), q, gnn.inputs["_topo"])
+        U2, F2, dq, gth = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+        Un, F3, dq3, none = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"], want_theta=False, want_energy=False)
+        assert none is None and Un is None
+        res.append([U.reshape(1), F_, U2.reshape(1), F2, dq, F3, dq3, torch.cat([t.reshape(-1) for t in gth])])
+    for k, (a, b) in enumerate(zip(*res)):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "chained vs layer-by-layer #%d" % k)
