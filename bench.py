@@ -462,6 +462,64 @@ def parity_schnet_stacked(dev, bf16, R=8, size=2, T=11):
                     "tests/test_gpu_secondary_pins.py" % (R, N, T - 1, T, flat.numel())}
 
 
+def schnet_single_system(dev, bf16, T=21, passes=4):
+    """The same model and loss on ONE 4 096-bead system (no replica stacking): the launch-bound end of the SchNet path --
+    each MD step is ~100 graph nodes of 5-50 us.  -> MD steps/s over `passes` timed passes of T - 1 steps (forward +
+    adjoint + RDF loss + optimizer step), after two warm-up passes."""
+    from mdgrad_amd import potentials as P, units
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    from mdgrad_amd.system import System, Diamond
+    rng = np.random.default_rng(77)
+    a = units.get_unit_len(0.997, 18.01528, 8)
+    atoms = Diamond("O", (8,) * 3, a)
+    atoms.masses[:] = 18.01528
+    system = System(atoms, device=dev)
+    system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.05, (len(system), 3)), a * 8))
+    kT = 298.0 * units.kB
+    system.set_temperature(kT, rng=rng)
+    torch.manual_seed(0)
+    net = get_model({"n_atom_basis": 64, "n_filters": 128, "n_gaussians": 30, "n_convolutions": 2, "cutoff": 6.0})
+    net.filter_bf16 = bool(bf16)
+    with torch.no_grad():
+        net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
+    integ = NoseHooverChain(Stack({"gnn": GNNPotentials(system, net, cutoff=6.0),
+                                   "prior": PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)}),
+                            system, T=kT, num_chains=5, Q=50.0).to(dev)
+    obs = rdf(system, nbins=60, r_range=(2.0, 6.0))
+    target = torch.ones(60, device=dev)
+    t = torch.Tensor([units.fs * i for i in range(T)]).to(dev)
+    params = list(integ.parameters())
+    opt = torch.optim.Adam(params, lr=1e-5)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y0 = tuple(integ.get_inital_states(wrap=True))
+        v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        (obs(q_t[::5])[2] - target).pow(2).mean().backward()
+        opt.step()
+        return q_t
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        q_t = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if not _finite(q_t):
+        return {"error": "non-finite trajectory"}
+    return {"md_steps_per_s": passes * (T - 1) / el, "us_per_md_step": el / (passes * (T - 1)) * 1e6, "beads": len(system),
+            "filter": "bf16 MFMA operands" if bf16 else "f32",
+            "note": "ONE 4096-bead system, %d passes x %d steps fwd + RDF loss + analytic adjoint + Adam step (HIP-graph replay "
+                    "of the per-step launches; node-level layers as row chains, csrc/rowchain.hip); tools/gbench.py gnn4096 "
+                    "times the same without the optimizer" % (passes, T - 1)}
+
+
 def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None):
     from mdgrad_amd import ops, potentials as P, units
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
@@ -647,6 +705,11 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                     etiles, mfma_bwd, tiles, mfma_per_tile, insn, GP, E,
                     "; with bf16 operands its Dense layers shrink to 20 MFMAs per tile and it is bound by its f32 VALU work, so "
                     "its fraction of the 2.5 PF bf16 peak is small by construction" if args.bf16 else "")}
+    if world == 1:
+        try:
+            out["config"]["single_system"] = schnet_single_system(dev, bool(args.bf16))
+        except Exception as e:
+            out["config"]["single_system"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if with_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_schnet()
         try:

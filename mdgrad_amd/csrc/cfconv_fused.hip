@@ -1277,18 +1277,34 @@ size_t bwd_bf16_lds_bytes(bool theta) {
     return (b + 15) / 16 * 16;
 }
 
-// sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes
-__global__ void cfconv_bwd_reduce_kernel(const float* __restrict__ part, int nrec, int GP, int FP, int G, int F,
-                                         float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
-                                         float* __restrict__ gmu, float* __restrict__ gcoef, int accumulate) {
+// sum of the per-workgroup partial records in a fixed order; un-pads [GP x GP | GP | FP x GP] to the true sizes.
+// A workgroup owns 64 consecutive entries of the record (coalesced rows of `part`); its 16 waves take the records
+// p = wave, wave + 16, ... with the loads of a wave independent of one another, then add up across waves in wave order.
+constexpr int RED_WAVES = 16;
+__global__ __launch_bounds__(64 * RED_WAVES) void cfconv_bwd_reduce_kernel(
+    const float* __restrict__ part, int nrec, int GP, int FP, int G, int F, float* __restrict__ gW1, float* __restrict__ gb1,
+    float* __restrict__ gW2, float* __restrict__ gmu, float* __restrict__ gcoef, int accumulate) {
+    __shared__ float red[RED_WAVES][64];
     const int REC0 = GP * GP + GP + FP * GP, REC = REC0 + 2 * GP;
-    const int t = blockIdx.x * (blockDim.x >> 2) + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (t < REC) {
+        int p = wid;
+        for (; p + 3 * RED_WAVES < nrec; p += 4 * RED_WAVES) {
+            s0 += part[(size_t)p * REC + t];
+            s1 += part[(size_t)(p + RED_WAVES) * REC + t];
+            s2 += part[(size_t)(p + 2 * RED_WAVES) * REC + t];
+            s3 += part[(size_t)(p + 3 * RED_WAVES) * REC + t];
+        }
+        for (; p < nrec; p += RED_WAVES) s0 += part[(size_t)p * REC + t];
+    }
+    red[wid][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wid || t >= REC) return;
     float s = 0.f;
-    if (t < REC)
-        for (int p = sub; p < nrec; p += 4) s += part[(size_t)p * REC + t];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (t >= REC || sub) return;
+#pragma unroll
+    for (int w = 0; w < RED_WAVES; ++w) s += red[w][lane];
     if (t < GP * GP) {
         const int j = t / GP, k = t % GP;
         if (j < G && k < G) gW1[j * G + k] = accumulate ? gW1[j * G + k] + s : s;     // (later filter chunks add)
@@ -1632,7 +1648,7 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
     MDG_CHECK_LAUNCH("cfconv_bwd_kernel");
     if (theta) {
         const int FP = 16 * FT, REC = GP * GP + 3 * GP + FP * GP;
-        hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC * 4 + 255) / 256), dim3(256), 0, st, workspace, nb, GP, FP,
+        hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC + 63) / 64), dim3(64 * RED_WAVES), 0, st, workspace, nb, GP, FP,
                            net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, gmu, gcoef, f0 > 0 ? 1 : 0);
         MDG_CHECK_LAUNCH("cfconv_bwd_reduce_kernel");
     }

@@ -34,6 +34,85 @@ struct ChainArgs {
     int n_stages, N, ldt;
 };
 
+// Weight fragments of column tile t, k chunk kc of a stage: lane (li, lk) gets B[k = kc + 16 q + 4 lk + c][m = 16 t + li] in
+// b[4 q + c] (the k order of the activation operand).  Linear layout: four 16-byte loads along k; transposed: 16 loads,
+// each coalesced over li.
+__device__ __forceinline__ void load_b(const MdgChainStage& S, int kc, int t, int li, int lk, float (&b)[16]) {
+    const int K = S.K, M = S.M, m = t * 16 + li;
+    const bool vecb = !S.trans && (K & 3) == 0 && ((uintptr_t)S.W & 15) == 0;
+    if (vecb) {
+        const float* w = S.W + (unsigned)(m * K + kc + 4 * lk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m < M && kc + 16 * q + 4 * lk < K) v = *reinterpret_cast<const float4*>(w + 16 * q);
+            b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = kc + 16 * q + 4 * lk + c;
+                float v = 0.f;
+                if (m < M && k < K) v = S.trans ? S.W[(unsigned)(k * M + m)] : S.W[(unsigned)(m * K + k)];
+                b[4 * q + c] = v;
+            }
+    }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+
+// operands of the epilogue for the 4 consecutive columns a lane owns in a tile
+struct EpiOps { float4 b, l, x0, x1, r0, r1; };
+
+template <bool DUAL>
+__device__ __forceinline__ void epi_load(const MdgChainStage& S, bool mok, bool ok, unsigned m, unsigned o, EpiOps& e) {
+    const float4 z = {0.f, 0.f, 0.f, 0.f};
+    e.b = (mok && S.bias) ? ld4(S.bias + m) : z;
+    e.l = (mok && S.mode == MDG_CHAIN_HEAD) ? ld4(S.aux0 + m) : z;
+    const bool ax = ok && (S.mode == MDG_CHAIN_MUL || S.mode == MDG_CHAIN_SSP_BWD);
+    e.x0 = ax ? ld4(S.aux0 + o) : z;
+    e.x1 = (ax && DUAL && S.mode == MDG_CHAIN_SSP_BWD) ? ld4(S.aux1 + o) : z;
+    e.r0 = (ok && S.res0) ? ld4(S.res0 + o) : z;
+    e.r1 = (ok && DUAL && S.res1) ? ld4(S.res1 + o) : z;
+}
+
+// act / mode / residual on one element; the global copies of sig / pre are written by the caller
+template <bool DUAL>
+__device__ __forceinline__ void epi_math(int act, int mode, float bv, float lv, float x0, float x1, float q0, float q1, float& z0,
+                                         float& z1, float& sg, float& p0, float& p1) {
+    z0 += bv;
+    sg = 0.f;
+    if (act == 1) {
+        const float ex = __builtin_amdgcn_exp2f(z0 * LOG2E_C);
+        const bool big = z0 > 20.f;
+        const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_C;
+        sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
+        z0 = (big ? z0 : sp) - LN2_C;
+        z1 *= sg;
+    }
+    p0 = z0; p1 = z1;
+    if (mode == MDG_CHAIN_MUL) {
+        z0 *= x0;
+    } else if (mode == MDG_CHAIN_HEAD) {
+        z0 = sg * lv;
+        z1 = (1.f - sg) * z1 * lv;
+    } else if (mode == MDG_CHAIN_SSP_BWD) {
+        const float n0 = x0 * z0;
+        z1 = (1.f - x0) * x1 * z0 + x0 * z1;
+        z0 = n0;
+    }
+    z0 += q0;
+    z1 += q1;
+}
+
+// The MFMA takes the WEIGHT fragment as its first operand and the activations as its second: the accumulator of lane
+// (li, lk) then holds columns 16 t + 4 lk + [0, 4) of row li -- 16 consecutive bytes of every row-major buffer the epilogue
+// touches.  With one wave per SIMD the launch is bound by the instructions a wave issues, not by the matrix pipe: the
+// epilogue moves 16-byte vectors (widths that are multiples of 4, aligned buffers; anything else takes the element-wise
+// path), offsets are 32-bit, and the operands of the epilogue are requested before the matrix loop.
 template <bool DUAL, int TPW>          // TPW: column tiles per wave (2: layers up to 128 wide, 8: up to 512)
 __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -42,6 +121,10 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
     float* X1 = sm + RC_ROWS * ldt;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.x * RC_ROWS;
+    const int row = row0 + li;                                       // the row whose outputs this lane owns
+    constexpr bool PRE = TPW <= 2;                                   // epilogue operands requested before the matrix loop
+    float bc[16];
+    if (wid < ((A.s[0].M + 15) >> 4)) load_b(A.s[0], 0, wid, li, lk, bc);
     for (int si = 0; si < A.n_stages; ++si) {
         const MdgChainStage& S = A.s[si];
         const int K = S.K, M = S.M;
@@ -51,27 +134,41 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
             if ((K & 3) == 0 && (((uintptr_t)S.in0 | (uintptr_t)S.in1) & 15) == 0) {
                 const int kq = K >> 2;
                 for (int t = tid; t < RC_ROWS * kq; t += 256) {
-                    const int r = t / kq, k = (t % kq) * 4, row = row0 + r;
+                    const int r = t / kq, k = (t % kq) * 4, rw = row0 + r;
                     float4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
-                    if (row < N) {
-                        v0 = *reinterpret_cast<const float4*>(S.in0 + (size_t)row * K + k);
-                        if (DUAL && S.in1) v1 = *reinterpret_cast<const float4*>(S.in1 + (size_t)row * K + k);
+                    if (rw < N) {
+                        v0 = ld4(S.in0 + (unsigned)(rw * K + k));
+                        if (DUAL && S.in1) v1 = ld4(S.in1 + (unsigned)(rw * K + k));
                     }
                     *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0;
                     if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1;
                 }
             } else {
                 for (int t = tid; t < RC_ROWS * K4; t += 256) {
-                    const int r = t / K4, k = t % K4, row = row0 + r;
-                    const bool ok = row < N && k < K;
-                    X0[r * ldt + k] = ok ? S.in0[(size_t)row * K + k] : 0.f;
-                    if (DUAL) X1[r * ldt + k] = (ok && S.in1) ? S.in1[(size_t)row * K + k] : 0.f;
+                    const int r = t / K4, k = t % K4, rw = row0 + r;
+                    const bool ok = rw < N && k < K;
+                    X0[r * ldt + k] = ok ? S.in0[(unsigned)(rw * K + k)] : 0.f;
+                    if (DUAL) X1[r * ldt + k] = (ok && S.in1) ? S.in1[(unsigned)(rw * K + k)] : 0.f;
                 }
             }
             __syncthreads();
         }
         const int ntile = (M + 15) >> 4;
-        const bool vecb = !S.trans && (K & 3) == 0 && ((uintptr_t)S.W & 15) == 0;
+        const int ntt = wid < ntile ? (ntile - wid + 3) >> 2 : 0;     // tiles of this wave: t = wid + 4 tt, tt < ntt
+        const uintptr_t al = (uintptr_t)S.bias | (uintptr_t)S.aux0 | (uintptr_t)S.aux1 | (uintptr_t)S.res0 | (uintptr_t)S.res1 |
+                             (uintptr_t)S.out0 | (uintptr_t)S.out1 | (uintptr_t)S.sig | (uintptr_t)S.pre0 | (uintptr_t)S.pre1;
+        const bool fast = (M & 3) == 0 && (al & 15) == 0;
+        EpiOps eo[PRE ? TPW : 1];
+        if constexpr (PRE) {
+            if (fast) {
+#pragma unroll
+                for (int tt = 0; tt < TPW; ++tt) {
+                    const int m = (wid + 4 * tt) * 16 + 4 * lk;
+                    const bool mok = tt < ntt && m < M;
+                    epi_load<DUAL>(S, mok, mok && row < N, m, row * M + m, eo[tt]);
+                }
+            }
+        }
         f32x4 acc0[TPW], acc1[DUAL ? TPW : 1];
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
@@ -93,80 +190,85 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
             }
 #pragma unroll
             for (int tt = 0; tt < TPW; ++tt) {
-                const int t = wid + 4 * tt;
-                if (t >= ntile) continue;
-                const int m = t * 16 + li;
-                float b[16];
-                if (vecb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int k0 = kc + 16 * q + 4 * lk;
-                        float4 v = {0.f, 0.f, 0.f, 0.f};
-                        if (m < M && k0 < K) v = *reinterpret_cast<const float4*>(S.W + (size_t)m * K + k0);
-                        b[4 * q] = v.x; b[4 * q + 1] = v.y; b[4 * q + 2] = v.z; b[4 * q + 3] = v.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const int k = kc + 16 * q + 4 * lk + c;
-                            float v = 0.f;
-                            if (m < M && k < K) v = S.trans ? S.W[(size_t)k * M + m] : S.W[(size_t)m * K + k];
-                            b[4 * q + c] = v;
-                        }
-                }
+                if (tt >= ntt) continue;
+                // the fragments of the next step of this wave: next tile of this chunk, first tile of the next chunk, or
+                // the first step of the next stage
+                float bn[16];
+                if (tt + 1 < ntt) load_b(S, kc, wid + 4 * (tt + 1), li, lk, bn);
+                else if (kc + 64 < K) load_b(S, kc + 64, wid, li, lk, bn);
+                else if (si + 1 < A.n_stages && wid < ((A.s[si + 1].M + 15) >> 4)) load_b(A.s[si + 1], 0, wid, li, lk, bn);
 #pragma unroll
                 for (int ks = 0; ks < 16; ++ks) {
-                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[ks], b[ks], acc0[tt], 0, 0, 0);
-                    if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[ks], b[ks], acc1[tt], 0, 0, 0);
+                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[ks], a0[ks], acc0[tt], 0, 0, 0);
+                    if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[ks], a1[ks], acc1[tt], 0, 0, 0);
                 }
+#pragma unroll
+                for (int ks = 0; ks < 16; ++ks) bc[ks] = bn[ks];
             }
         }
-        __syncthreads();                                             // every wave has read its A operand: X may be overwritten
+        // (a wave without a tile in this stage still has to fetch its first fragments of the next one)
+        if (ntt == 0 && si + 1 < A.n_stages && wid < ((A.s[si + 1].M + 15) >> 4)) load_b(A.s[si + 1], 0, wid, li, lk, bc);
+        __syncthreads();                                             // every wave has read its activations: X may be overwritten
+        const int act = S.act, mode = S.mode;
 #pragma unroll
         for (int tt = 0; tt < TPW; ++tt) {
-            const int t = wid + 4 * tt;
-            if (t >= ntile) continue;
-            const int m = t * 16 + li;
-            const bool mok = m < M;
-            const float bv = (mok && S.bias) ? S.bias[m] : 0.f;
-            const float lv = (mok && S.mode == MDG_CHAIN_HEAD) ? S.aux0[m] : 0.f;
+            if (tt >= ntt) continue;
+            const int m = (wid + 4 * tt) * 16 + 4 * lk;               // first of the lane's 4 columns
+            if (fast) {
+                const bool mok = m < M, ok = mok && row < N;
+                const unsigned o = row * M + m;
+                EpiOps e;
+                if constexpr (PRE) e = eo[tt];
+                else epi_load<DUAL>(S, mok, ok, m, o, e);
+                const float bv[4] = {e.b.x, e.b.y, e.b.z, e.b.w}, lv[4] = {e.l.x, e.l.y, e.l.z, e.l.w};
+                const float x0[4] = {e.x0.x, e.x0.y, e.x0.z, e.x0.w}, x1[4] = {e.x1.x, e.x1.y, e.x1.z, e.x1.w};
+                const float q0[4] = {e.r0.x, e.r0.y, e.r0.z, e.r0.w}, q1[4] = {e.r1.x, e.r1.y, e.r1.z, e.r1.w};
+                float z0[4], z1[4], sg[4], p0[4], p1[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 4 * lk + r, row = row0 + rr;
-                const bool ok = mok && row < N;
-                const size_t o = (size_t)row * M + m;
-                float z0 = acc0[tt][r] + bv, z1 = DUAL ? acc1[tt][r] : 0.f, sg = 0.f;
-                if (S.act == 1) {
-                    const float ex = __builtin_amdgcn_exp2f(z0 * LOG2E_C);
-                    const bool big = z0 > 20.f;
-                    const float sp = __builtin_amdgcn_logf(1.0f + ex) * LN2_C;
-                    sg = big ? 1.0f : ex * __builtin_amdgcn_rcpf(1.0f + ex);
-                    z0 = (big ? z0 : sp) - LN2_C;
-                    z1 *= sg;
-                    if (ok && S.sig) S.sig[o] = sg;
+                for (int r = 0; r < 4; ++r) {
+                    z0[r] = acc0[tt][r]; z1[r] = DUAL ? acc1[tt][r] : 0.f;
+                    epi_math<DUAL>(act, mode, bv[r], lv[r], x0[r], x1[r], q0[r], q1[r], z0[r], z1[r], sg[r], p0[r], p1[r]);
+                    if (!ok) { z0[r] = 0.f; z1[r] = 0.f; }
                 }
-                if (S.mode == MDG_CHAIN_MUL) {
-                    if (ok) z0 *= S.aux0[o];
-                } else if (S.mode == MDG_CHAIN_HEAD) {
-                    if (ok && S.pre0) S.pre0[o] = z0;
-                    if (ok && DUAL && S.pre1) S.pre1[o] = z1;
-                    z0 = sg * lv;
-                    z1 = (1.f - sg) * z1 * lv;
-                } else if (S.mode == MDG_CHAIN_SSP_BWD) {
-                    const float s = ok ? S.aux0[o] : 0.f, td = (ok && DUAL) ? S.aux1[o] : 0.f;
-                    const float n0 = s * z0;
-                    z1 = (1.f - s) * td * z0 + s * z1;
-                    z0 = n0;
+                if (ok) {
+                    if (act == 1 && S.sig) st4(S.sig + o, sg);
+                    if (mode == MDG_CHAIN_HEAD) {
+                        if (S.pre0) st4(S.pre0 + o, p0);
+                        if (DUAL && S.pre1) st4(S.pre1 + o, p1);
+                    }
+                    if (S.out0) st4(S.out0 + o, z0);
+                    if (DUAL && S.out1) st4(S.out1 + o, z1);
                 }
-                if (ok && S.res0) z0 += S.res0[o];
-                if (ok && DUAL && S.res1) z1 += S.res1[o];
-                if (!ok) { z0 = 0.f; z1 = 0.f; }
-                if (ok && S.out0) S.out0[o] = z0;
-                if (ok && DUAL && S.out1) S.out1[o] = z1;
-                X0[rr * ldt + m] = z0;
-                if (DUAL) X1[rr * ldt + m] = z1;
+                if (mok) {
+                    st4(X0 + li * ldt + m, z0);
+                    if (DUAL) st4(X1 + li * ldt + m, z1);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mm = m + r;
+                    const bool mok = mm < M, ok = mok && row < N;
+                    const unsigned o = row * M + mm;
+                    const float bv = (mok && S.bias) ? S.bias[mm] : 0.f;
+                    const float lv = (mok && mode == MDG_CHAIN_HEAD) ? S.aux0[mm] : 0.f;
+                    const bool ax = ok && (mode == MDG_CHAIN_MUL || mode == MDG_CHAIN_SSP_BWD);
+                    const float x0 = ax ? S.aux0[o] : 0.f, x1 = (ax && DUAL && mode == MDG_CHAIN_SSP_BWD) ? S.aux1[o] : 0.f;
+                    const float q0 = (ok && S.res0) ? S.res0[o] : 0.f, q1 = (ok && DUAL && S.res1) ? S.res1[o] : 0.f;
+                    float z0 = acc0[tt][r], z1 = DUAL ? acc1[tt][r] : 0.f, sg, p0, p1;
+                    epi_math<DUAL>(act, mode, bv, lv, x0, x1, q0, q1, z0, z1, sg, p0, p1);
+                    if (!ok) { z0 = 0.f; z1 = 0.f; }
+                    if (ok) {
+                        if (act == 1 && S.sig) S.sig[o] = sg;
+                        if (mode == MDG_CHAIN_HEAD) {
+                            if (S.pre0) S.pre0[o] = p0;
+                            if (DUAL && S.pre1) S.pre1[o] = p1;
+                        }
+                        if (S.out0) S.out0[o] = z0;
+                        if (DUAL && S.out1) S.out1[o] = z1;
+                    }
+                    X0[li * ldt + mm] = z0;                           // (columns [M, 16 ntile) are left at zero)
+                    if (DUAL) X1[li * ldt + mm] = z1;
+                }
             }
         }
         __syncthreads();
@@ -177,7 +279,7 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
 
 extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream) {
     MDG_CHECK_ARG(stages && n_stages >= 1 && n_stages <= MDG_CHAIN_MAX_STAGES, "row_chain: 1..%d stages", MDG_CHAIN_MAX_STAGES);
-    MDG_CHECK_ARG(n_rows >= 0, "row_chain: bad row count");
+    MDG_CHECK_ARG(n_rows >= 0 && (int64_t)n_rows * MDG_CHAIN_MAX_WIDTH < ((int64_t)1 << 31), "row_chain: bad row count");
     if (n_rows == 0) return MDG_OK;
     ChainArgs a{};
     int wmax = 0, tiles = 0;

@@ -28,6 +28,7 @@ brackets): per layer  g = smear(d) -> a = W1 g + b1 [edge_filter.1] -> s = ssp(a
 t = ssp(u);  r <- r + U2 t + c2 [update.2];  readout y = L1 r + l1, U = sum L2 ssp(y) + l2.
 """
 import math
+import os
 
 import torch
 
@@ -281,9 +282,39 @@ def _embedded(net, z):
     return buf
 
 
+@torch.no_grad()
+def _first_filter(net, z, P0):
+    """(r, h) of the first interaction block: the embedding rows and h = message_node_filter(r) = Wn r + bn
+    (nff/nn/modules.py:514-533).  Neither depends on the positions, so h lives in a persistent buffer like the embedding
+    rows and is recomputed when a weight it reads changes; inside a HIP-graph capture the buffer is returned as it is and
+    the replaying pass refreshes it first (`refresh_embedding`)."""
+    r = _embedded(net, z)
+    Wn, bn = P0["Wn"], P0["bn"]
+    buf = getattr(net, "_h0_buf", None)
+    shape = (z.shape[0], Wn.shape[0])
+    capturing = r.is_cuda and torch.cuda.is_current_stream_capturing()
+    if buf is None or tuple(buf.shape) != shape or buf.device != r.device:
+        if capturing:
+            return r, _dense(Wn, r, bias=bn)[0]      # (no buffer yet: the layer becomes part of this graph)
+        buf = net._h0_buf = torch.empty(shape, device=r.device, dtype=r.dtype)
+        net._h0_key = None
+    if capturing:
+        return r, buf
+    key = (getattr(net, "_embed_key", None), Wn.data_ptr(), Wn._version, bn.data_ptr() if bn is not None else 0,
+           bn._version if bn is not None else 0)
+    if getattr(net, "_h0_key", None) != key:
+        buf.copy_(_dense(Wn, r, bias=bn)[0])
+        net._h0_key = key
+    return r, buf
+
+
 def refresh_embedding(net, z):
-    """Bring the persistent embedding rows up to date (before the graph replays of a pass)."""
-    _embedded(net, z)
+    """Bring the persistent embedding rows (and the first block's filtered rows) up to date, before the graph replays
+    of a pass."""
+    if fused_ok(net) and chain_ok(net):
+        _first_filter(net, z, _layer_params(net.convolutions[0]))
+    else:
+        _embedded(net, z)
 
 
 def _forward_fused(net, z, x, topo, w=None, want_sums=False, want_energy=True):
@@ -413,7 +444,7 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accu
 #   reverse   [hb -> message_node_filter^T + residual -> U2^T -> ssp' -> U1^T]                     per inner block
 def chain_ok(net):
     """The row-chain kernel takes every node-level layer of this network (and is not switched off)."""
-    if getattr(net, "row_chain", True) is False or not fused_ok(net):
+    if getattr(net, "row_chain", True) is False or os.environ.get("MDG_ROW_CHAIN", "1") == "0" or not fused_ok(net):
         return False
     ws = []
     for conv in net.convolutions:
@@ -435,8 +466,7 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     N, dev = z.shape[0], x.device
-    r, rd = _embedded(net, z), None                               # r_dot^0 = 0
-    h, _, hd = _dense(Ps[0]["Wn"], r, bias=Ps[0]["bn"])           # message_node_filter of the first block
+    (r, h), rd, hd = _first_filter(net, z, Ps[0]), None, None      # r_dot^0 = 0; message_node_filter of the first block
     layers, turn = [], None
     for i, P in enumerate(Ps):
         m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, h, hd, topo, want_sums)
@@ -547,7 +577,10 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
                 ch.run()
                 rdb, rb, udb, ub, mdb, mb = g.out0, g.out1, e.out0, e.out1, f.out0, f.out1
             else:
-                rdb, _, rb = _dense(P["Wn"], hdb, trans=True, res=rdb, x1=hb, res1=rb)
+                # below the first block only the embedding rows' adjoint in U_dot is left (r_dot^0 = 0)
+                ch = ops.RowChain(z.shape[0], False, x.device)
+                rb = ch.stage(P["Wn"], trans=True, in0=hb, res0=rb).out0
+                ch.run()
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
     if not want_theta:
         return fw["U"], F, dwf, None
