@@ -137,11 +137,24 @@ __global__ __launch_bounds__(256) void grad_partial_kernel(const JobTable T, flo
         for (int pass = 0; pass < (J.A2 ? 2 : 1); ++pass) {
             const float* __restrict__ Ap = pass ? J.A2 : J.A;
             const float* __restrict__ Bp = pass ? J.B2 : J.B;
-            for (long long r = k0 + rl; r < k1; r += rl_n) {
+            // four rows in flight per thread (the loads of one row are a dependent round trip otherwise)
+            long long r = k0 + rl;
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1, s3 = s1;
+            for (; r + 3 * rl_n < k1; r += 4 * rl_n) {
+                f32x4 a0 = load4(Ap, r, J.m, 4 * cg, true), a1 = load4(Ap, r + rl_n, J.m, 4 * cg, true);
+                f32x4 a2 = load4(Ap, r + 2 * rl_n, J.m, 4 * cg, true), a3 = load4(Ap, r + 3 * rl_n, J.m, 4 * cg, true);
+                if (Bp) {
+                    a0 *= load4(Bp, r, J.m, 4 * cg, true); a1 *= load4(Bp, r + rl_n, J.m, 4 * cg, true);
+                    a2 *= load4(Bp, r + 2 * rl_n, J.m, 4 * cg, true); a3 *= load4(Bp, r + 3 * rl_n, J.m, 4 * cg, true);
+                }
+                s += a0; s1 += a1; s2 += a2; s3 += a3;
+            }
+            for (; r < k1; r += rl_n) {
                 f32x4 a = load4(Ap, r, J.m, 4 * cg, true);
                 if (Bp) a *= load4(Bp, r, J.m, 4 * cg, true);
                 s += a;
             }
+            s += (s1 + s2) + s3;
         }
     }
     red[threadIdx.x] = s;
@@ -158,9 +171,12 @@ __global__ __launch_bounds__(256) void grad_partial_kernel(const JobTable T, flo
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const JobTable T, const float* __restrict__ ws, float* __restrict__ flat,
                                                           float alpha, const float* __restrict__ tgrid,
                                                           const long long* __restrict__ idx, int accumulate) {
-    const int g = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, sub = threadIdx.x & 3;
-    // (every job's outputs are padded to a multiple of the 64 elements a block covers: k is uniform in the block)
-    const int g0 = (int)blockIdx.x * 64;
+    // a block covers 64 consecutive output elements of ONE job (every job's outputs are padded to a multiple of 64); its
+    // four waves take the slabs q = wave, wave + 4, ... -- rows of the workspace, read coalesced and four at a time -- and
+    // add up in wave order
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int g0 = (int)blockIdx.x * 64, g = g0 + lane;
     int k = 0;
     while (k + 1 < T.n_jobs && g0 >= T.first_out[k + 1]) ++k;
     const MdgGradJob& J = T.j[k];
@@ -173,12 +189,20 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const JobTable T, cons
             if (sub == 0) s = J.A[e] + (J.A2 ? J.A2[e] : 0.f);
         } else {
             const float* p = ws + T.ws_off[k] + e;
-            for (int q = sub; q < T.splits[k]; q += 4) s += p[(size_t)q * MN];
+            const int ns = T.splits[k];
+            float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int q = sub;
+            for (; q + 12 < ns; q += 16) {
+                s += p[(size_t)q * MN]; s1 += p[(size_t)(q + 4) * MN]; s2 += p[(size_t)(q + 8) * MN]; s3 += p[(size_t)(q + 12) * MN];
+            }
+            for (; q < ns; q += 4) s += p[(size_t)q * MN];
+            s = (s + s1) + (s2 + s3);
         }
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
+    red[sub][lane] = s;
+    __syncthreads();
     if (!live || sub != 0) return;
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     float f = alpha;
     if (tgrid) { const long long i = idx[0]; f *= tgrid[i] - tgrid[i - 1]; }
     long long dst = J.out_off + e;
@@ -191,7 +215,7 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
     T.n_jobs = n_jobs;
     int n_atb = 0;
     for (int k = 0; k < n_jobs; ++k) n_atb += jobs[k].kind == MDG_GRAD_ATB;
-    const int atb_budget = 1536 / (n_atb > 0 ? n_atb : 1);
+    const int atb_budget = 4096 / (n_atb > 0 ? n_atb : 1);
     long long ws = 0;
     int blocks = 0, outs = 0;
     for (int k = 0; k < n_jobs; ++k) {
@@ -211,8 +235,12 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
             if (J.n <= 0 || !J.B) { mdg_set_error("grad_jobs: job %d: a product needs B and n > 0", k); return MDG_EINVAL; }
             const int units = ((J.m + 63) / 64) * ((J.n + 63) / 64);
             long long want = (atb_budget + units - 1) / units;            // workgroups of this job: its share of ~2 rounds of the chip
-            const long long maxs = (J.rows + 255) / 256;                 // at least 256 rows (16 steps per wave) per slab
+            // at least 64 rows (4 steps per wave) per slab: the product is bound by the latency of its row loads (two steps in
+            // flight per wave), so short slabs on many workgroups beat long ones -- 4 096 rows: 50 us at 256 rows per slab
+            const long long maxs = (J.rows + 63) / 64;
             if (want > maxs) want = maxs;
+            const long long cap = ((long long)1 << 20) / ((long long)J.m * J.n);      // <= 4 MB of partial blocks per job
+            if (want > cap && cap >= 16) want = cap;
             if (want < 1) want = 1;
             if (want > 512) want = 512;
             long long slab = (J.rows + want - 1) / want;
@@ -228,7 +256,7 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
             if (J.m > 1024) { mdg_set_error("grad_jobs: job %d: column sums take at most 1024 columns", k); return MDG_EINVAL; }
             const int groups = (J.m + 3) / 4, cg_per_blk = groups < 256 ? groups : 256;
             const int col_blocks = (groups + cg_per_blk - 1) / cg_per_blk;
-            long long want = (J.rows + 511) / 512;                      // ~512 rows per block
+            long long want = (J.rows + 127) / 128;                      // ~128 rows per block
             if (want < 1) want = 1;
             if (want > 256) want = 256;
             const long long slab = (J.rows + want - 1) / want > 0 ? (J.rows + want - 1) / want : 1;
@@ -276,7 +304,7 @@ extern "C" int mdg_grad_jobs(const MdgGradJob* jobs, int n_jobs, float* flat, fl
     if (T.first_block[n_jobs] > 0)
         hipLaunchKernelGGL(grad_partial_kernel, dim3(T.first_block[n_jobs]), dim3(256), 0, st, T, workspace);
     const int outs = T.first_out[n_jobs];
-    hipLaunchKernelGGL(grad_reduce_kernel, dim3((outs * 4 + 255) / 256), dim3(256), 0, st, T, (const float*)workspace, flat, alpha, t,
+    hipLaunchKernelGGL(grad_reduce_kernel, dim3(outs / 64), dim3(256), 0, st, T, (const float*)workspace, flat, alpha, t,
                        (const long long*)idx, accumulate);
     MDG_CHECK_LAUNCH("grad_jobs kernels");
     return MDG_OK;
