@@ -602,14 +602,15 @@ int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, const float* l
  * A replica's elements are cut over several workgroups; `scratch` (mdg_nhv_scratch_floats(n_rep, n_atoms) floats,
  * zeroed ONCE by the caller, reusable by every launch of the same shape on one stream) carries the per-workgroup
  * partial sums of the kinetic energy / <lam_v, v> and a ticket per replica; the result does not depend on the order
- * the workgroups finish in. */
+ * the workgroups finish in.  advance != 0 (mdg_nhv_finish / mdg_nhv_adj_end): the launch also moves the counter, idx[0] <- k + 1
+ * resp. i - 1, once every workgroup has read the old value -- no separate increment launch per step. */
 int64_t mdg_nhv_scratch_floats(int n_rep, int n_atoms);
 int mdg_nhv_kick(const float* v, const float* q, const float* pv, const float* f, const float* mass, const float* Q,
                  const float* T, float n_dof, const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains,
                  float* dv_h, float* dp_h, float* qn, float* scratch, void* stream);
 int mdg_nhv_finish(float* v, float* q, float* pv, float* f, const float* dv_h, const float* dp_h, const float* qn,
                    const float* fn, const float* mass, const float* Q, const float* T, float n_dof, const float* t,
-                   const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* out_v, float* out_q, float* out_pv,
+                   int64_t* idx, int advance, int n_rep, int n_atoms, int n_chains, float* out_v, float* out_q, float* out_pv,
                    float* scratch, void* stream);
 int mdg_nhv_adj_pre(const float* v_t, const float* q_t, const float* pv_t, const float* lv, const float* mass,
                     const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* v, float* q, float* pv, float* w,
@@ -619,7 +620,7 @@ int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, const float
                     const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* vh, float* qm, float* pm,
                     float* lvh, float* lqh, float* lph, float* wh, float* scratch, void* stream);
 int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const float* lqh, const float* lph, const float* dwf,
-                    const float* mass, const float* Q, const float* t, const int64_t* idx, const float* g_v,
+                    const float* mass, const float* Q, const float* t, int64_t* idx, int advance, const float* g_v,
                     const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains, float* lv, float* lq,
                     float* lp, float* scratch, void* stream);
 

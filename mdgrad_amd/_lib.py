@@ -128,11 +128,12 @@ _SIGNATURES = {
     "mdg_row_chain": (C.c_int, [C.POINTER(MdgChainStage), C.c_int, C.c_int, C.c_int, P]),
     "mdg_nhv_scratch_floats": (C.c_int64, [C.c_int, C.c_int]),
     "mdg_nhv_kick": (C.c_int, [P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
-    "mdg_nhv_finish": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
+    "mdg_nhv_finish": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P,
+                                 P]),
     "mdg_nhv_adj_pre": (C.c_int, [P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
     "mdg_nhv_adj_mid": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int,
                                   P, P, P, P, P, P, P, P, P]),
-    "mdg_nhv_adj_end": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
+    "mdg_nhv_adj_end": (C.c_int, [P, P, P, P, P, P, P, P, P, P, C.c_int, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
     "mdg_edge_diff": (C.c_int, [P, P, C.c_int64, C.c_int, P, P]),
     "mdg_edge_scatter": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),
     "mdg_cfconv_agg": (C.c_int, [P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P]),

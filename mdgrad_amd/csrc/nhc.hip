@@ -90,26 +90,42 @@ __device__ __forceinline__ float nhc_bath_vjp(const float* pr, const float* lr, 
 constexpr int NHV_CHUNK = 1024;
 __host__ __device__ inline int nhv_chunks(int n) { return (3 * n + NHV_CHUNK - 1) / NHV_CHUNK; }
 
+// `idx` (nullable): the launch also moves the device-side step / frame counter to `new_idx` -- by the workgroup that draws
+// the last ticket of the WHOLE grid, i.e. after every workgroup has read the old value (each reads it before its loop).
 template <int NV>
-__device__ __forceinline__ bool replica_sum(float (&val)[NV], float* red, float* scratch, int R, int r) {
+__device__ __forceinline__ bool replica_sum(float (&val)[NV], float* red, float* scratch, int R, int r, long long* idx = nullptr,
+                                            long long new_idx = 0) {
     const int nb = gridDim.x;
 #pragma unroll
     for (int i = 0; i < NV; ++i) val[i] = block_sum(val[i], red);
-    if (nb == 1) return true;
     __shared__ int last;
     float* part = scratch + (size_t)r * nb * 2;
+    unsigned* tickets = reinterpret_cast<unsigned*>(scratch + (size_t)R * nb * 2);
     if (threadIdx.x == 0) {
+        int mine = 1;
+        if (nb > 1) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i)
-            __hip_atomic_store(part + blockIdx.x * 2 + i, val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)R * nb * 2) + r;
-        const unsigned tk = atomicAdd(ticket, 1u);
-        last = tk == (unsigned)(nb - 1);
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int i = 0; i < NV; ++i)
+                __hip_atomic_store(part + blockIdx.x * 2 + i, val[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            const unsigned tk = atomicAdd(tickets + r, 1u);
+            mine = tk == (unsigned)(nb - 1);
+            if (mine) __hip_atomic_store(tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        last = mine;
+        if (idx) {
+            const unsigned all = gridDim.x * gridDim.y;
+            if (all == 1) idx[0] = new_idx;
+            else if (atomicAdd(tickets + R, 1u) == all - 1) {
+                __hip_atomic_store(tickets + R, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                idx[0] = new_idx;
+            }
+        }
     }
+    if (nb == 1 && !idx) return true;
     __syncthreads();
     if (!last) return false;
+    if (nb == 1) return true;
     __threadfence();
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_finish_kernel(
     float* __restrict__ v, float* __restrict__ q, float* __restrict__ pv, float* __restrict__ f,
     const float* __restrict__ dv_h, const float* __restrict__ dp_h, const float* __restrict__ qn,
     const float* __restrict__ fn, const float* __restrict__ mass, const float* __restrict__ Q,
-    const float* __restrict__ Tp, float n_dof, const float* __restrict__ t, const long long* __restrict__ idx, int R, int n,
+    const float* __restrict__ Tp, float n_dof, const float* __restrict__ t, long long* idx, int advance, int R, int n,
     int C, float* __restrict__ out_v, float* __restrict__ out_q, float* __restrict__ out_pv, float* __restrict__ scratch) {
     __shared__ float red[32];
     __shared__ float ps[MDG_MAX_CHAINS];
@@ -184,7 +200,7 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_finish_kernel(
         v[o + e] = vn; q[o + e] = qe; f[o + e] = fn[o + e];
         out_v[fo + e] = vn; out_q[fo + e] = qe;
     }
-    if (!replica_sum(s, red, scratch, R, r)) return;
+    if (!replica_sum(s, red, scratch, R, r, advance ? idx : nullptr, k + 1)) return;
     const float ke = 0.5f * s[0];
     if (threadIdx.x < C) {
         const float pn = pr[threadIdx.x] + (dp_h[(size_t)r * C + threadIdx.x] + 1.f / 2.f * nhc_bath(ps, Q, T, n_dof, ke, C, threadIdx.x) * dt);
@@ -251,7 +267,7 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_mid_kernel(
 __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_end_kernel(
     const float* __restrict__ vh, const float* __restrict__ pm, const float* __restrict__ lvh, const float* __restrict__ lqh,
     const float* __restrict__ lph, const float* __restrict__ dwf, const float* __restrict__ mass,
-    const float* __restrict__ Q, const float* __restrict__ t, const long long* __restrict__ idx,
+    const float* __restrict__ Q, const float* __restrict__ t, long long* idx, int advance,
     const float* __restrict__ g_v, const float* __restrict__ g_q, const float* __restrict__ g_pv, int R, int n, int C,
     float* __restrict__ lv, float* __restrict__ lq, float* __restrict__ lp, float* __restrict__ scratch) {
     __shared__ float red[32];
@@ -271,7 +287,7 @@ __global__ __launch_bounds__(NHC_BLOCK) void nhv_adj_end_kernel(
         lv[o + e] = lv[o + e] + Gv * h + g_v[go + e];
         lq[o + e] = lq[o + e] + dwf[o + e] * h + g_q[go + e];
     }
-    if (!replica_sum(s, red, scratch, R, r)) return;
+    if (!replica_sum(s, red, scratch, R, r, advance ? idx : nullptr, i - 1)) return;
     const float slv = s[0];
     if (threadIdx.x < C)
         lp[(size_t)r * C + threadIdx.x] = lp[(size_t)r * C + threadIdx.x] + nhc_bath_vjp(ps, ls, Q, slv, C, threadIdx.x) * h +
@@ -306,7 +322,7 @@ extern "C" int mdg_nhc_vjp(const float* v, const float* pv, const float* lv, con
 // floats of the cross-workgroup scratch the mdg_nhv_* launches of one (n_rep, n_atoms) share; ZERO it once
 extern "C" int64_t mdg_nhv_scratch_floats(int n_rep, int n_atoms) {
     if (n_rep <= 0 || n_atoms <= 0) return 0;
-    return (int64_t)n_rep * nhv_chunks(n_atoms) * 2 + n_rep;
+    return (int64_t)n_rep * nhv_chunks(n_atoms) * 2 + n_rep + 1;
 }
 
 extern "C" int mdg_nhv_kick(const float* v, const float* q, const float* pv, const float* f, const float* mass, const float* Q,
@@ -323,13 +339,13 @@ extern "C" int mdg_nhv_kick(const float* v, const float* q, const float* pv, con
 
 extern "C" int mdg_nhv_finish(float* v, float* q, float* pv, float* f, const float* dv_h, const float* dp_h, const float* qn,
                               const float* fn, const float* mass, const float* Q, const float* T, float n_dof,
-                              const float* t, const int64_t* idx, int n_rep, int n_atoms, int n_chains, float* out_v,
+                              const float* t, int64_t* idx, int advance, int n_rep, int n_atoms, int n_chains, float* out_v,
                               float* out_q, float* out_pv, float* scratch, void* stream) {
     MDG_CHECK_ARG(v && q && pv && f && dv_h && dp_h && qn && fn && mass && Q && T && t && idx && out_v && out_q && out_pv &&
                   scratch, "nhv_finish: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_finish: bad sizes");
     hipLaunchKernelGGL(nhv_finish_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, v, q, pv,
-                       f, dv_h, dp_h, qn, fn, mass, Q, T, n_dof, t, reinterpret_cast<const long long*>(idx), n_rep, n_atoms,
+                       f, dv_h, dp_h, qn, fn, mass, Q, T, n_dof, t, reinterpret_cast<long long*>(idx), advance, n_rep, n_atoms,
                        n_chains, out_v, out_q, out_pv, scratch);
     MDG_CHECK_LAUNCH("nhv_finish_kernel");
     return MDG_OK;
@@ -362,14 +378,14 @@ extern "C" int mdg_nhv_adj_mid(const float* v, const float* q, const float* pv, 
 }
 
 extern "C" int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const float* lqh, const float* lph,
-                               const float* dwf, const float* mass, const float* Q, const float* t, const int64_t* idx,
+                               const float* dwf, const float* mass, const float* Q, const float* t, int64_t* idx, int advance,
                                const float* g_v, const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains,
                                float* lv, float* lq, float* lp, float* scratch, void* stream) {
     MDG_CHECK_ARG(vh && pm && lvh && lqh && lph && dwf && mass && Q && t && idx && g_v && g_q && g_pv && lv && lq && lp &&
                   scratch, "nhv_adj_end: null buffer");
     MDG_CHECK_ARG(n_rep > 0 && n_atoms > 0 && n_chains >= 2 && n_chains <= MDG_MAX_CHAINS, "nhv_adj_end: bad sizes");
     hipLaunchKernelGGL(nhv_adj_end_kernel, dim3(nhv_chunks(n_atoms), n_rep), dim3(NHC_BLOCK), 0, (hipStream_t)stream, vh, pm,
-                       lvh, lqh, lph, dwf, mass, Q, t, reinterpret_cast<const long long*>(idx), g_v, g_q, g_pv, n_rep, n_atoms,
+                       lvh, lqh, lph, dwf, mass, Q, t, reinterpret_cast<long long*>(idx), advance, g_v, g_q, g_pv, n_rep, n_atoms,
                        n_chains, lv, lq, lp, scratch);
     MDG_CHECK_LAUNCH("nhv_adj_end_kernel");
     return MDG_OK;

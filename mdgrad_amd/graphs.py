@@ -108,8 +108,7 @@ class _ForwardGraph:
             # + frame store
             w = func.nhv_work(v, pv)
             qn = w.kick(v, q, pv, F, self.t, k)
-            w.finish(v, q, pv, F, func.force(qn), self.t, k, self.out)
-            k.add_(1)
+            w.finish(v, q, pv, F, func.force(qn), self.t, k, self.out, advance=True)    # (k <- k + 1 inside)
             return
         dt = self.t.index_select(0, k + 1) - self.t.index_select(0, k)
         a0, _, b0 = func.rhs_from_force((v, q, pv), F)
@@ -176,10 +175,10 @@ class _AdjointGraph:
                 _, dwf1, th1 = func.model.force_vjp(qm, wh, accum=acc)
             else:
                 _, dwf1, th1 = func.model.force_vjp(qm, wh)
-            w.adj_end(lam, dwf1, self.t, i, self.gout)
+            w.adj_end(lam, dwf1, self.t, i, self.gout, advance=not th1)                 # (i <- i - 1 inside)
             if th1:
                 self.gth.add_(_flatten(func.theta_in_parameter_order(th1)) * (self.t.index_select(0, i) - self.t.index_select(0, i - 1)))
-            i.sub_(1)
+                i.sub_(1)
             return
         h = self.t.index_select(0, i) - self.t.index_select(0, i - 1)
         v, q, pv = (a.index_select(0, i)[0] for a in self.ans)

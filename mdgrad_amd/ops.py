@@ -822,13 +822,16 @@ class NhvWork:
         _touched(self.qn)
         return self.qn
 
-    def finish(self, v, q, pv, f, fn, t, k, out):
+    def finish(self, v, q, pv, f, fn, t, k, out, advance=False):
+        """advance: the launch also sets k <- k + 1 (no separate increment)."""
         lib = _lib.load()
         m, Q, T, nd = self._a()
         check(lib.mdg_nhv_finish(ptr(v), ptr(q), ptr(pv), ptr(f), ptr(self.dv_h), ptr(self.dp_h), ptr(self.qn),
-                                 ptr(fn.contiguous()), m, Q, T, nd, ptr(t), ptr(k), self.R, self.n, self.C, ptr(out[0]),
+                                 ptr(fn.contiguous()), m, Q, T, nd, ptr(t), ptr(k), int(bool(advance)), self.R, self.n, self.C, ptr(out[0]),
                                  ptr(out[1]), ptr(out[2]), ptr(self.scratch), stream_ptr(v.device)), "mdg_nhv_finish")
         _touched(v, q, pv, f, *out)
+        if advance:
+            _touched(k)
 
     def adj_pre(self, ans, lv, i):
         lib = _lib.load()
@@ -848,13 +851,16 @@ class NhvWork:
         _touched(self.qm, self.wh)
         return self.qm, self.wh
 
-    def adj_end(self, lam, dwf, t, i, gout):
+    def adj_end(self, lam, dwf, t, i, gout, advance=False):
+        """advance: the launch also sets i <- i - 1."""
         lib = _lib.load()
         check(lib.mdg_nhv_adj_end(ptr(self.vh), ptr(self.pm), ptr(self.lvh), ptr(self.lqh), ptr(self.lph),
-                                  ptr(dwf.contiguous()), ptr(self.mass), ptr(self.Q), ptr(t), ptr(i), ptr(gout[0]),
+                                  ptr(dwf.contiguous()), ptr(self.mass), ptr(self.Q), ptr(t), ptr(i), int(bool(advance)), ptr(gout[0]),
                                   ptr(gout[1]), ptr(gout[2]), self.R, self.n, self.C, ptr(lam[0]), ptr(lam[1]), ptr(lam[2]),
                                   ptr(self.scratch), stream_ptr(dwf.device)), "mdg_nhv_adj_end")
         _touched(*lam)
+        if advance:
+            _touched(i)
 
 
 # ----------------------------------------------------------------------------- graph ops (SchNet)

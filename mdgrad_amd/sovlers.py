@@ -126,8 +126,7 @@ def _nhv_forward(func, y0, t):
     t = t.contiguous()
     for _ in range(T - 1):
         qn = w.kick(v, q, pv, F, t, k)
-        w.finish(v, q, pv, F, func.force(qn), t, k, out)
-        k.add_(1)
+        w.finish(v, q, pv, F, func.force(qn), t, k, out, advance=True)          # (k <- k + 1 inside the launch)
     return tuple(out)
 
 
@@ -267,10 +266,9 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
                         _, dwf1, th1 = func.model.force_vjp(qm, wh, accum=acc)
                     else:
                         _, dwf1, th1 = func.model.force_vjp(qm, wh)
-                    w.adj_end(lam, dwf1, tc, idx, gout)
+                    w.adj_end(lam, dwf1, tc, idx, gout, advance=True)             # (idx <- idx - 1 inside the launch)
                     if th1:
                         gth += _flatten(func.theta_in_parameter_order(th1)) * (tc[i] - tc[i - 1])   # :160
-                    idx.sub_(1)
                 return lam, gth
             for i in range(T - 1, 0, -1):
                 h = t[i] - t[i - 1]
