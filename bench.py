@@ -61,7 +61,7 @@ def _profile_json(name):
 _KERNEL_SOURCES = (("traj_", ("traj_ring.hpp", "traj_small.hip", "common.hpp")), ("large_", ("traj_large.hip", "common.hpp")),
                    ("rdf_cell", ("rdf_cell.hip", "common.hpp")), ("rdf_", ("rdf.hip", "common.hpp")),
                    ("cfconv_", ("cfconv_fused.hip",)), ("dense_", ("dense.hip",)), ("grad_", ("gradjobs.hip",)),
-                   ("nbr_", ("nbr.hip", "common.hpp")))
+                   ("nbr_", ("nbr.hip", "common.hpp")), ("row_chain", ("rowchain.hip",)), ("nhv_", ("nhc.hip", "common.hpp")))
 
 
 def _source_sha(fname):

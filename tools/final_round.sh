@@ -10,4 +10,6 @@ cp gpurun_out/prof/pmc_lj108.json gpurun_out/prof/pmc_lj4096.json gpurun_out/pro
 (timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/f_bench.json 2> gpurun_out/f_bench.err); tail -c 200 gpurun_out/f_bench.err
 python tools/kbench_cfconv.py > gpurun_out/prof/${TAG}_cfconv_kbench.txt 2>/dev/null
 python tools/kbench_cfconv.py --bf16 > gpurun_out/prof/${TAG}_cfconv_kbench_bf16.txt 2>/dev/null
-(timeout 300 python tools/gbench.py gnn64 gnn512 gnn4096 --steps 20 > gpurun_out/f_gbench.txt 2>&1); tail -3 gpurun_out/f_gbench.txt
+(timeout 300 python tools/gbench.py gnn64 gnn512 gnn4096 --steps 20 > gpurun_out/f_gbench.txt 2>&1; timeout 300 python tools/gbench.py gnn64 gnn512 gnn4096 --steps 20 --bf16 >> gpurun_out/f_gbench.txt 2>&1; timeout 300 python tools/gbench.py gnn4096 --steps 10 --replicas 8 --bf16 >> gpurun_out/f_gbench.txt 2>&1); grep "steps/s" gpurun_out/f_gbench.txt
+bash tools/prof_gnn_single.sh > /dev/null 2>&1
+python tools/kbench_chain.py > gpurun_out/prof/${TAG}_chain_kbench.txt 2>/dev/null; python tools/kbench_gradjobs.py > gpurun_out/prof/${TAG}_gradjobs_kbench.txt 2>/dev/null
