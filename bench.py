@@ -705,7 +705,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
                     etiles, mfma_bwd, tiles, mfma_per_tile, insn, GP, E,
                     "; with bf16 operands its Dense layers shrink to 20 MFMAs per tile and it is bound by its f32 VALU work, so "
                     "its fraction of the 2.5 PF bf16 peak is small by construction" if args.bf16 else "")}
-    if world == 1:
+    if with_cpu and world == 1:               # (not under the profiler: tools/prof_round3.sh passes --no-cpu-baseline)
         try:
             out["config"]["single_system"] = schnet_single_system(dev, bool(args.bf16))
         except Exception as e:

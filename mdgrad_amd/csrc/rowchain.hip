@@ -113,8 +113,12 @@ __device__ __forceinline__ void epi_math(int act, int mode, float bv, float lv, 
 // touches.  With one wave per SIMD the launch is bound by the instructions a wave issues, not by the matrix pipe: the
 // epilogue moves 16-byte vectors (widths that are multiples of 4, aligned buffers; anything else takes the element-wise
 // path), offsets are 32-bit, and the operands of the epilogue are requested before the matrix loop.
-template <bool DUAL, int TPW>          // TPW: column tiles per wave (2: layers up to 128 wide, 8: up to 512)
-__global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
+// LAT: the few-workgroup variant (<= 2 workgroups per CU anyway): epilogue operands requested before the matrix loop, registers
+// spent freely.  !LAT: many rows -- what counts is how many workgroups a CU holds, so the operand prefetch goes and the
+// register budget is that of four waves per SIMD (8 x 4 096 beads: 6-stage dual chain 114 -> see profiles/r03e_chain_kbench.txt).
+template <bool DUAL, int TPW, bool LAT>          // TPW: column tiles per wave (2: layers up to 128 wide, 8: up to 512)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (TPW <= 2 ? 4 : 2))))
+void row_chain_kernel(const ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldt = A.ldt, N = A.N;
     float* X0 = sm;
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(256) void row_chain_kernel(const ChainArgs A) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int row0 = blockIdx.x * RC_ROWS;
     const int row = row0 + li;                                       // the row whose outputs this lane owns
-    constexpr bool PRE = TPW <= 2;                                   // epilogue operands requested before the matrix loop
+    constexpr bool PRE = LAT && TPW <= 2;                            // epilogue operands requested before the matrix loop
     float bc[16];
     if (wid < ((A.s[0].M + 15) >> 4)) load_b(A.s[0], 0, wid, li, lk, bc);
     for (int si = 0; si < A.n_stages; ++si) {
@@ -305,13 +309,12 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
     const size_t lds = sizeof(float) * RC_ROWS * a.ldt * (dual ? 2 : 1);
     dim3 grid((n_rows + RC_ROWS - 1) / RC_ROWS), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dual) {
-        if (tiles <= 2) hipLaunchKernelGGL((row_chain_kernel<true, 2>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((row_chain_kernel<true, 8>), grid, block, lds, st, a);
-    } else {
-        if (tiles <= 2) hipLaunchKernelGGL((row_chain_kernel<false, 2>), grid, block, lds, st, a);
-        else hipLaunchKernelGGL((row_chain_kernel<false, 8>), grid, block, lds, st, a);
-    }
+    const bool lat = n_rows <= 8192;
+#define MDG_RC(D_, T_) do { if (lat) hipLaunchKernelGGL((row_chain_kernel<D_, T_, true>), grid, block, lds, st, a); \
+                            else hipLaunchKernelGGL((row_chain_kernel<D_, T_, false>), grid, block, lds, st, a); } while (0)
+    if (dual) { if (tiles <= 2) MDG_RC(true, 2); else MDG_RC(true, 8); }
+    else { if (tiles <= 2) MDG_RC(false, 2); else MDG_RC(false, 8); }
+#undef MDG_RC
     MDG_CHECK_LAUNCH("row_chain_kernel");
     return MDG_OK;
 }
