@@ -229,3 +229,33 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     assert 4096 * 64 <= per_frame <= 4096 * 64 + 4096 + 1024, per_frame
     huge = lib.mdg_traj_large_workspace(64, 16384, 2000, 2)                              # lists would need > 32 GiB
     assert huge < 64 * 16384 * 2000, "beyond the cap the lists are not kept (every evaluation searches)"
+
+
+def test_host_side_of_the_row_chain_and_the_nh_half_step_scratch():
+    """mdg_row_chain / mdg_nhv_scratch_floats without a GPU: struct layout, argument validation (every refusal happens before
+    a launch), the empty call, and the size of the cross-workgroup scratch (partials of 1 024-element chunks, a ticket per
+    replica, one ticket for the whole grid)."""
+    from mdgrad_amd import _lib
+    lib = _lib.load()
+    assert ctypes.sizeof(_lib.MdgChainStage) == 13 * 8 + 6 * 4
+    dummy = ctypes.c_void_p(0x1000)                      # never dereferenced: every call below returns before its launch
+    st = (_lib.MdgChainStage * 2)()
+    st[0].W, st[0].in0, st[0].K, st[0].M = dummy, dummy, 64, 32
+    st[1].W, st[1].K, st[1].M = dummy, 32, 16
+    assert lib.mdg_row_chain(st, 2, 0, 1, None) == 0                       # no rows: nothing to do
+    assert lib.mdg_row_chain(st, 0, 16, 0, None) != 0 and b"stages" in lib.mdg_last_error()
+    assert lib.mdg_row_chain(st, _lib.CHAIN_MAX_STAGES + 1, 16, 0, None) != 0
+    st[1].K = 48                                                           # does not continue the previous stage's 32 outputs
+    assert lib.mdg_row_chain(st, 2, 16, 0, None) != 0 and b"previous stage" in lib.mdg_last_error()
+    st[1].K, st[1].mode = 32, _lib.CHAIN_HEAD                              # HEAD needs an activation and the readout row
+    assert lib.mdg_row_chain(st, 2, 16, 0, None) != 0 and b"HEAD" in lib.mdg_last_error()
+    st[1].mode, st[1].M = _lib.CHAIN_NONE, _lib.CHAIN_MAX_WIDTH + 1
+    assert lib.mdg_row_chain(st, 2, 16, 0, None) != 0 and b"width" in lib.mdg_last_error()
+    st[1].M = 16
+    st[0].in0 = None                                                       # the first stage reads global memory
+    assert lib.mdg_row_chain(st, 2, 16, 0, None) != 0
+    # scratch of the mdg_nhv_* launches: 2 floats per (replica, chunk) + a ticket per replica + the grid's ticket
+    assert lib.mdg_nhv_scratch_floats(1, 64) == 1 * 1 * 2 + 1 + 1
+    assert lib.mdg_nhv_scratch_floats(8, 512) == 8 * 2 * 2 + 8 + 1         # 1 536 elements: two chunks
+    assert lib.mdg_nhv_scratch_floats(1, 4096) == 12 * 2 + 1 + 1
+    assert lib.mdg_nhv_scratch_floats(0, 64) == 0
