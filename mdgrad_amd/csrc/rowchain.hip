@@ -115,9 +115,9 @@ __device__ __forceinline__ void epi_math(int act, int mode, float bv, float lv, 
 // path), offsets are 32-bit, and the operands of the epilogue are requested before the matrix loop.
 // LAT: the few-workgroup variant (<= 2 workgroups per CU anyway): epilogue operands requested before the matrix loop, registers
 // spent freely.  !LAT: many rows -- what counts is how many workgroups a CU holds, so the operand prefetch goes and the
-// register budget is that of four waves per SIMD (8 x 4 096 beads: 6-stage dual chain 114 -> see profiles/r03e_chain_kbench.txt).
+// register budget is that of three (dual) or four waves per SIMD, no spills (32 768 rows: 6-stage dual chain 114 -> 89 us).
 template <bool DUAL, int TPW, bool LAT>          // TPW: column tiles per wave (2: layers up to 128 wide, 8: up to 512)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (TPW <= 2 ? 4 : 2))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LAT ? 1 : (TPW <= 2 ? (DUAL ? 3 : 4) : 2))))
 void row_chain_kernel(const ChainArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int ldt = A.ldt, N = A.N;
