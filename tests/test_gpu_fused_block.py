@@ -438,7 +438,10 @@ def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
 
 
 @pytest.mark.parametrize("N,K,M1,M2,M3", [(1000, 128, 64, 64, 32), (4096, 64, 128, 128, 64), (37, 50, 25, 25, 12),
-                                          (530, 512, 512, 512, 256), (129, 384, 130, 130, 65), (16, 8, 8, 8, 4)])
+                                          (530, 512, 512, 512, 256), (129, 384, 130, 130, 65), (16, 8, 8, 8, 4),
+                                          # more than 8 192 rows: the many-row variants of the kernel (no operand prefetch,
+                                          # three / four waves per SIMD), which the stacked 8 x 4 096-bead workload runs on
+                                          (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64)])
 def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3):
     """csrc/rowchain.hip: the stretch of the SchNet sweeps around the readout as ONE launch -- update MLP (activation,
     sigmoid, tangent), residual, readout with the head transform, then the three transposed layers with the reverse of the
