@@ -503,8 +503,8 @@ def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3):
         bad.run()
 
 
-@pytest.mark.parametrize("A,F,G,convs", [(64, 128, 30, 2), (48, 64, 16, 3), (100, 96, 25, 1)])
-def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs):
+@pytest.mark.parametrize("A,F,G,convs,R", [(64, 128, 30, 2, 1), (48, 64, 16, 3, 1), (100, 96, 25, 1, 1), (64, 128, 30, 2, 160)])
+def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs, R):
     """analytic.force / force_vjp with the node-level layers chained (one launch per stretch between aggregations) against
     the layer-by-layer launches of csrc/dense.hip: energy, force, d(w.F)/dx, d(w.F)/dtheta -- 1, 2 and 3 interaction
     blocks (the inner forward / reverse chains only exist from 2 blocks on), widths that are not multiples of 16."""
@@ -512,13 +512,19 @@ def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs):
     from mdgrad_amd.nn import get_model, analytic
     g = load_golden("schnet_cg64")
     system = mk_system(g["pos"], g["cell"], mass=g["masses"], numbers=g["numbers"])
+    pos = g["pos"]
+    if R > 1:            # R stacked replicas (10 240 rows at R = 160: the many-row variants of the chain kernel)
+        system = system.replicate(R)
+        rng = np.random.default_rng(17)
+        pos = np.concatenate([np.mod(g["pos"] + rng.normal(0, 0.03, g["pos"].shape), g["cell"]) for _ in range(R)]).astype(np.float32)
+        system.set_positions(pos)
     torch.manual_seed(A + convs)
     net = get_model({"n_atom_basis": A, "n_filters": F, "n_gaussians": G, "n_convolutions": convs, "cutoff": 6.0})
     gnn = GNNPotentials(system, net, cutoff=6.0)
-    q = T(g["pos"], DEV)
+    q = T(pos, DEV)
     gnn._reset_topology(q)
     assert analytic.chain_ok(net)
-    w = T(np.random.default_rng(3).normal(0, 1, g["pos"].shape).astype(np.float32), DEV)
+    w = T(np.random.default_rng(3).normal(0, 1, pos.shape).astype(np.float32), DEV)
     res = []
     for chain in (True, False):
         net.row_chain = chain
