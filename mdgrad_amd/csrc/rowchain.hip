@@ -20,6 +20,7 @@
 // loads along k for the Linear layout with the k permutation dense.hip uses for its A operand (k-step 4 q + c <-> k = 16 q
 // + 4 lk + c).  v_mfma_f32_16x16x4_f32, exact f32.  A value another stage of the same launch wrote to global memory
 // (sig / t_dot of the update MLP, read back by SSP_BWD) is read by the thread that wrote it: same (row, column) owner.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace {
@@ -279,6 +280,305 @@ void row_chain_kernel(const ChainArgs A) {
     }
 }
 
+// ======================================================================================= specialised chains
+// The walker above reads a stage's shape, flags and pointers at run time; with one wave per SIMD that interpretation is
+// most of what a stage costs (a chain of plain 64 -> 64 stages: 2.15 us per stage through the walker, 0.32 us with
+// everything known at compile time, same MFMAs).  The three stretches the SchNet sweeps consist of are therefore ALSO
+// compiled with their shapes and epilogues fixed -- mdg_row_chain recognises them in the descriptor list and takes the
+// compiled version when the widths are among the instantiated ones; every other list goes through the walker.
+//   FWD    [F -> A, ssp] [A -> A, + residual] [A -> F]                                   update MLP, residual, next node filter
+//   TURN   [F -> A, ssp] [A -> A, + residual] [A -> A/2, ssp, head] [A/2 -> A]^T [A -> A]^T ssp' [A -> F]^T
+//   REV    [F -> A]^T + residual, [A -> A]^T ssp', [A -> F]^T
+// All weight fragments of the launch (<= 120 registers per lane for TURN at A = 64, F = 128) are requested at kernel start,
+// in one round trip, together with the first input rows; sigmoid / tangent rows a later stage of the same launch needs stay
+// in registers (TURN).
+template <int M> constexpr int spec_tp() { return (M / 16 + 3) / 4; }          // column tiles per wave
+
+template <int K, int M, bool TRANS>
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, float (&b)[spec_tp<M>()][K / 4]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+        const int t = wid + 4 * tt;
+        if (t * 16 >= M) continue;
+        const int m = t * 16 + li;
+#pragma unroll
+        for (int q = 0; q < K / 16; ++q) {
+            if constexpr (!TRANS) {
+                const float4 v = ld4(W + m * K + 16 * q + 4 * lk);
+                b[tt][4 * q] = v.x; b[tt][4 * q + 1] = v.y; b[tt][4 * q + 2] = v.z; b[tt][4 * q + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b[tt][4 * q + c] = W[(16 * q + 4 * lk + c) * M + m];
+            }
+        }
+    }
+}
+
+template <bool DUAL, int K>
+__device__ __forceinline__ void spec_load_x(const float* __restrict__ in0, const float* __restrict__ in1, float* X0, float* X1,
+                                            int ldt, int row0, int N, int tid) {
+    constexpr int KQ = K / 4;
+#pragma unroll
+    for (int t0 = 0; t0 < RC_ROWS * KQ; t0 += 256) {
+        const int t = t0 + tid;
+        if (RC_ROWS * KQ % 256 != 0 && t >= RC_ROWS * KQ) break;
+        const int r = t / KQ, k = (t % KQ) * 4, rw = row0 + r;
+        float4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (rw < N) {
+            v0 = ld4(in0 + (unsigned)(rw * K + k));
+            if (DUAL && in1) v1 = ld4(in1 + (unsigned)(rw * K + k));
+        }
+        *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0;
+        if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1;
+    }
+}
+
+// matrix part of a stage: acc[tt] (+)= rows of X (LDS) x the wave's weight fragments; lane (li, lk) ends up with columns
+// 16 t + 4 lk + [0, 4) of row li
+template <bool DUAL, int K, int M>
+__device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk,
+                                         const float (&b)[spec_tp<M>()][K / 4], f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) { acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[tt] = acc0[tt]; }
+#pragma unroll
+    for (int q = 0; q < K / 16; ++q) {
+        const float4 v0 = *reinterpret_cast<const float4*>(X0 + li * ldt + 16 * q + 4 * lk);
+        float4 v1 = v0;
+        if (DUAL) v1 = *reinterpret_cast<const float4*>(X1 + li * ldt + 16 * q + 4 * lk);
+        const float a0[4] = {v0.x, v0.y, v0.z, v0.w}, a1[4] = {v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+            if ((wid + 4 * tt) * 16 >= M) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tt][4 * q + c], a0[c], acc0[tt], 0, 0, 0);
+                if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tt][4 * q + c], a1[c], acc1[tt], 0, 0, 0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void st4v(float* p, unsigned o, const float (&v)[4]) {
+    if (p) *reinterpret_cast<float4*>(p + o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float (&v)[4]) {
+    float4 q = {0.f, 0.f, 0.f, 0.f};
+    if (ok && p) q = ld4(p + o);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+
+// epilogue of a stage on the lane's 4 columns of each of its tiles; x0 / x1: operands of MUL / SSP_BWD (registers), q0 / q1:
+// residuals (registers); sg / kd receive sigmoid and the tangent row of an activation stage
+template <bool DUAL, int M, int ACT, int MODE>
+__device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()],
+                                              const float (&x0)[spec_tp<M>()][4], const float (&x1)[spec_tp<M>()][4],
+                                              const float (&q0)[spec_tp<M>()][4], const float (&q1)[spec_tp<M>()][4],
+                                              float (&sgk)[spec_tp<M>()][4], float (&tdk)[spec_tp<M>()][4], float* X0, float* X1, int ldt,
+                                              int row, int N, int wid, int li, int lk) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+        const int m = (wid + 4 * tt) * 16 + 4 * lk;
+        if ((wid + 4 * tt) * 16 >= M) continue;
+        const bool ok = row < N;
+        const unsigned o = (unsigned)(row * M + m);
+        float bv[4], lv[4];
+        ld4v(S.bias, m, true, bv);
+        if (MODE == MDG_CHAIN_HEAD) ld4v(S.aux0, m, true, lv);
+        float z0[4], z1[4], sg[4], p0[4], p1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z0[r] = acc0[tt][r]; z1[r] = DUAL ? acc1[tt][r] : 0.f;
+            epi_math<DUAL>(ACT, MODE, bv[r], MODE == MDG_CHAIN_HEAD ? lv[r] : 0.f, x0[tt][r], x1[tt][r], q0[tt][r], q1[tt][r], z0[r], z1[r],
+                           sg[r], p0[r], p1[r]);
+            if (ACT == 1) { sgk[tt][r] = sg[r]; tdk[tt][r] = p1[r]; }
+            if (!ok) { z0[r] = 0.f; z1[r] = 0.f; }
+        }
+        if (ok) {
+            if (ACT == 1) st4v(S.sig, o, sg);
+            if (MODE == MDG_CHAIN_HEAD) { st4v(S.pre0, o, p0); if (DUAL) st4v(S.pre1, o, p1); }
+            st4v(S.out0, o, z0);
+            if (DUAL) st4v(S.out1, o, z1);
+        }
+        *reinterpret_cast<float4*>(X0 + li * ldt + m) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        if (DUAL) *reinterpret_cast<float4*>(X1 + li * ldt + m) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+    }
+}
+
+template <int M>
+__device__ __forceinline__ void spec_zero(float (&v)[spec_tp<M>()][4]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[tt][r] = 0.f;
+}
+
+// residual / operand rows of a stage, requested early
+template <int M>
+__device__ __forceinline__ void spec_load_rows(const float* p, int row, int N, int wid, int lk, float (&v)[spec_tp<M>()][4]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+        const int m = (wid + 4 * tt) * 16 + 4 * lk;
+        ld4v(p, (unsigned)(row * M + m), (wid + 4 * tt) * 16 < M && row < N, v[tt]);
+    }
+}
+
+enum { SPEC_FWD = 0, SPEC_TURN = 1, SPEC_REV = 2 };
+
+template <int A_, int F_, bool DUAL, int KIND>
+__global__ __launch_bounds__(256) void chain_spec_kernel(const ChainArgs A) {
+    constexpr int H_ = A_ / 2;                                                      // readout hidden width
+    constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + 4;
+    __shared__ __attribute__((aligned(16))) float Xs[(DUAL ? 2 : 1) * RC_ROWS * ldt];
+    float* X0 = Xs;
+    float* X1 = Xs + (DUAL ? RC_ROWS * ldt : 0);
+    const int N = A.N, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int row0 = blockIdx.x * RC_ROWS, row = row0 + li;
+    float sgA[spec_tp<A_>()][4], tdA[spec_tp<A_>()][4], zA[spec_tp<A_>()][4], zF[spec_tp<F_>()][4], zH[spec_tp<H_>()][4];
+    float dF[spec_tp<F_>()][4], dH[spec_tp<H_>()][4];                              // (sigmoid / tangent sinks of stages that keep none)
+    spec_zero<A_>(zA); spec_zero<F_>(zF); spec_zero<H_>(zH);
+    if constexpr (KIND == SPEC_FWD || KIND == SPEC_TURN) {
+        // ---- weights of the whole launch + the input rows: one round trip
+        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
+        spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
+        spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
+        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+        spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+        spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+        __syncthreads();
+        // stage 0: t = ssp(U1 m + c1), su, td
+        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+        __syncthreads();
+        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk);
+        __syncthreads();
+        // stage 1: r' = U2 t + c2 + r
+        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+        __syncthreads();
+        {
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
+        }
+        __syncthreads();
+        if constexpr (KIND == SPEC_FWD) {
+            // stage 2: h' = Wn' r' + bn'
+            float w2[spec_tp<F_>()][A_ / 4];
+            spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
+            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
+            __syncthreads();
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+        } else {
+            float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
+            spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
+            spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
+            spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
+            spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
+            // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
+            f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
+            spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
+            __syncthreads();
+            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk);
+            __syncthreads();
+            // stage 3: (rdb, rb) = (ydb, yb) L1
+            spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
+            }
+            __syncthreads();
+            // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w4, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
+                                                                                    N, wid, li, lk);
+            }
+            __syncthreads();
+            // stage 5: (mdb, mb) = (udb, ub) U1
+            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
+            __syncthreads();
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+        }
+    } else {
+        // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
+        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
+        spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
+        spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
+        spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
+        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+        spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
+        spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
+        spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
+        spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, row, N, wid, lk, tdA);
+        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+        float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+        __syncthreads();
+        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+        __syncthreads();
+        spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
+        __syncthreads();
+        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+        __syncthreads();
+        spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
+                                                                            li, lk);
+        __syncthreads();
+        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
+        __syncthreads();
+        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+    }
+}
+
+// does the descriptor list have the shape of one of the compiled chains (widths A, F)?  -1: no
+int spec_kind(const MdgChainStage* s, int n, int dual, int A_, int F_) {
+    const int H_ = A_ / 2;
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    for (int i = 0; i < n; ++i) {
+        const MdgChainStage& t = s[i];
+        if (!al(t.W) || !al(t.bias) || !al(t.in0) || !al(t.in1) || !al(t.res0) || !al(t.res1) || !al(t.aux0) || !al(t.aux1) ||
+            !al(t.out0) || !al(t.out1) || !al(t.sig) || !al(t.pre0) || !al(t.pre1))
+            return -1;
+        if (i > 0 && t.in0) return -1;
+    }
+    auto plain = [](const MdgChainStage& t) { return t.mode == MDG_CHAIN_NONE && !t.aux0 && !t.aux1; };
+    auto st = [](const MdgChainStage& t, int K, int M, int trans, int act) { return t.K == K && t.M == M && t.trans == trans && t.act == act; };
+    const int bmode = dual ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL;
+    if (n == 3 && st(s[0], F_, A_, 0, 1) && plain(s[0]) && !s[0].res0 && !s[0].res1 && st(s[1], A_, A_, 0, 0) && plain(s[1]) &&
+        st(s[2], A_, F_, 0, 0) && plain(s[2]) && !s[2].res0 && !s[2].res1)
+        return SPEC_FWD;
+    if (n == 6 && st(s[0], F_, A_, 0, 1) && plain(s[0]) && !s[0].res0 && !s[0].res1 && st(s[1], A_, A_, 0, 0) && plain(s[1]) &&
+        st(s[2], A_, H_, 0, 1) && s[2].mode == MDG_CHAIN_HEAD && !s[2].res0 && !s[2].res1 && st(s[3], H_, A_, 1, 0) && plain(s[3]) &&
+        !s[3].bias && !s[3].res0 && !s[3].res1 && st(s[4], A_, A_, 1, 0) && s[4].mode == bmode && s[4].aux0 == s[0].sig && s[0].sig &&
+        (!dual || (s[4].aux1 == s[0].out1 && s[0].out1)) && !s[4].bias && !s[4].res0 && !s[4].res1 && st(s[5], A_, F_, 1, 0) &&
+        plain(s[5]) && !s[5].bias && !s[5].res0 && !s[5].res1)
+        return SPEC_TURN;
+    if (n == 3 && st(s[0], F_, A_, 1, 0) && plain(s[0]) && !s[0].bias && st(s[1], A_, A_, 1, 0) && s[1].mode == bmode && s[1].aux0 &&
+        (!dual || s[1].aux1) && !s[1].bias && !s[1].res0 && !s[1].res1 && st(s[2], A_, F_, 1, 0) && plain(s[2]) && !s[2].bias &&
+        !s[2].res0 && !s[2].res1)
+        return SPEC_REV;
+    return -1;
+}
+
+template <int A_, int F_>
+bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, hipStream_t st) {
+    const int kind = spec_kind(s, n, dual, A_, F_);
+    if (kind < 0) return false;
+    dim3 grid((n_rows + RC_ROWS - 1) / RC_ROWS), block(256);
+#define MDG_SPEC(K_)                                                                                         \
+    do {                                                                                                     \
+        if (dual) hipLaunchKernelGGL((chain_spec_kernel<A_, F_, true, K_>), grid, block, 0, st, a);          \
+        else hipLaunchKernelGGL((chain_spec_kernel<A_, F_, false, K_>), grid, block, 0, st, a);              \
+    } while (0)
+    if (kind == SPEC_FWD) MDG_SPEC(SPEC_FWD); else if (kind == SPEC_TURN) MDG_SPEC(SPEC_TURN); else MDG_SPEC(SPEC_REV);
+#undef MDG_SPEC
+    return true;
+}
+
 }  // namespace
 
 extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream) {
@@ -309,6 +609,13 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
     const size_t lds = sizeof(float) * RC_ROWS * a.ldt * (dual ? 2 : 1);
     dim3 grid((n_rows + RC_ROWS - 1) / RC_ROWS), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (!getenv("MDG_CHAIN_WALKER")) {                                  // (MDG_CHAIN_WALKER=1: always the descriptor walker)
+        if (spec_launch<64, 128>(a, stages, n_stages, n_rows, dual, st) || spec_launch<128, 128>(a, stages, n_stages, n_rows, dual, st) ||
+            spec_launch<64, 64>(a, stages, n_stages, n_rows, dual, st)) {
+            MDG_CHECK_LAUNCH("chain_spec_kernel");
+            return MDG_OK;
+        }
+    }
     const bool lat = n_rows <= 8192;
 #define MDG_RC(D_, T_) do { if (lat) hipLaunchKernelGGL((row_chain_kernel<D_, T_, true>), grid, block, lds, st, a); \
                             else hipLaunchKernelGGL((row_chain_kernel<D_, T_, false>), grid, block, lds, st, a); } while (0)

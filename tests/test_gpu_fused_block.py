@@ -441,13 +441,23 @@ def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
                                           (530, 512, 512, 512, 256), (129, 384, 130, 130, 65), (16, 8, 8, 8, 4),
                                           # more than 8 192 rows: the many-row variants of the kernel (no operand prefetch,
                                           # three / four waves per SIMD), which the stacked 8 x 4 096-bead workload runs on
-                                          (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64)])
-def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3):
+                                          (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64),
+                                          # the other widths the compiled chains exist for (A = F = 128, A = F = 64)
+                                          (777, 128, 128, 128, 64), (555, 64, 64, 64, 32)])
+@pytest.mark.parametrize("walker", [False, True])
+def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3, walker, monkeypatch):
     """csrc/rowchain.hip: the stretch of the SchNet sweeps around the readout as ONE launch -- update MLP (activation,
     sigmoid, tangent), residual, readout with the head transform, then the three transposed layers with the reverse of the
     (ssp, tangent) pair -- every saved tensor against the same sequence in torch, dual and single rows, widths that are
     not multiples of 16 / 4 and a row count that is not a multiple of the 16-row tile."""
     from mdgrad_amd import ops, _lib
+    # (F, A, A, A / 2) = (128, 64, 64, 32), (128, 128, 128, 64) and (64, 64, 64, 32) have the shape of the SchNet turn chain: the
+    # library runs its compiled version of it (csrc/rowchain.hip, "specialised chains"); walker = True forces the
+    # descriptor walker on the same lists, so both are pinned to the same torch sequence
+    if walker:
+        monkeypatch.setenv("MDG_CHAIN_WALKER", "1")
+    else:
+        monkeypatch.delenv("MDG_CHAIN_WALKER", raising=False)
     torch.manual_seed(N + K + M1)
     rn = lambda *s: torch.randn(*s, device=DEV)
     W1, W2, W3 = rn(M1, K) / K ** 0.5, rn(M2, M1) / M1 ** 0.5, rn(M3, M2) / M2 ** 0.5
