@@ -28,6 +28,14 @@ def compute_grad(inputs, output, create_graph=True, retain_graph=True):
     return g
 
 
+
+def _to_device_f32(var, device):
+    """torch.Tensor(var).to(device) -- the same float32 rounding -- through numpy: torch.Tensor(float64 ndarray) converts
+    element by element (20 ms for the 32 768 x 3 positions of eight stacked 4 096-bead systems; this is 0.03 ms), and the call
+    sits inside every pass of a training loop (demo/fit_rdf_gnn.py:405-408)."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(var, dtype=np.float64).astype(np.float32))).to(device)
+
+
 class Simulations():
     """torchmd/md.py:14-96: runs `steps // frequency` epochs of `frequency` time points each,
     logs the last frame of every epoch on the host, restarts each epoch from the (wrapped)
@@ -285,7 +293,7 @@ class NVE(_EOM):
 
     def get_inital_states(self, wrap=True):
         states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap)]
-        return [torch.Tensor(var).to(self.system.device) for var in states]
+        return [_to_device_f32(var, self.system.device) for var in states]
 
 
 class NoseHooverChain(_EOM):
@@ -467,4 +475,4 @@ class NoseHooverChain(_EOM):
     def get_inital_states(self, wrap=True):
         baths = [0.0] * self.num_chains if self.n_rep == 1 else np.zeros((self.n_rep, self.num_chains))
         states = [self.system.get_velocities(), self.system.get_positions(wrap=wrap), baths]
-        return [torch.Tensor(var).to(self.system.device) for var in states]
+        return [_to_device_f32(var, self.system.device) for var in states]
