@@ -216,6 +216,24 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
     int n_atb = 0;
     for (int k = 0; k < n_jobs; ++k) n_atb += jobs[k].kind == MDG_GRAD_ATB;
     const int atb_budget = 4096 / (n_atb > 0 ? n_atb : 1);
+    // Small calls (one system of a few thousand atoms): every workgroup of the launch holds the 48 KB of the product's LDS
+    // combine, i.e. three are resident per CU -- 768 on the device.  When the column-sum workgroups leave room, the products
+    // share what is left of that ONE resident round (same number of k-slabs each) instead of spilling into a second one
+    // (4 096 rows: 848 workgroups -> 764, 22.7 -> see tools/kbench_gradjobs.py).
+    long long cs_blocks = 0, atb_units = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const MdgGradJob& J = jobs[k];
+        if (J.kind == MDG_GRAD_COLSUM && J.m > 0) {
+            const int groups = (J.m + 3) / 4, cgb = groups < 256 ? groups : 256;
+            long long want = (J.rows + 127) / 128;
+            want = want < 1 ? 1 : (want > 256 ? 256 : want);
+            cs_blocks += want * ((groups + cgb - 1) / cgb);
+        } else if (J.kind == MDG_GRAD_ATB && J.m > 0 && J.n > 0) {
+            atb_units += (long long)((J.m + 63) / 64) * ((J.n + 63) / 64);
+        }
+    }
+    const long long one_round = 768;
+    const long long splits_one_round = atb_units > 0 && cs_blocks < one_round ? (one_round - cs_blocks) / atb_units : 0;
     long long ws = 0;
     int blocks = 0, outs = 0;
     for (int k = 0; k < n_jobs; ++k) {
@@ -239,6 +257,7 @@ int plan(const MdgGradJob* jobs, int n_jobs, JobTable& T, long long& ws_floats) 
             // flight per wave), so short slabs on many workgroups beat long ones -- 4 096 rows: 50 us at 256 rows per slab
             const long long maxs = (J.rows + 63) / 64;
             if (want > maxs) want = maxs;
+            if (splits_one_round >= 8 && want > splits_one_round) want = splits_one_round;
             const long long cap = ((long long)1 << 20) / ((long long)J.m * J.n);      // <= 4 MB of partial blocks per job
             if (want > cap && cap >= 16) want = cap;
             if (want < 1) want = 1;
