@@ -285,7 +285,8 @@ void row_chain_kernel(const ChainArgs A) {
 // most of what a stage costs (a chain of plain 64 -> 64 stages: 2.15 us per stage through the walker, 0.32 us with
 // everything known at compile time, same MFMAs).  The three stretches the SchNet sweeps consist of are therefore ALSO
 // compiled with their shapes and epilogues fixed -- mdg_row_chain recognises them in the descriptor list and takes the
-// compiled version when the widths are among the instantiated ones; every other list goes through the walker.
+// compiled version when the widths are among the instantiated ones -- (A, F) in {64, 128}^2, the lower half of the reference's
+// search space (demo/fit_rdf_gnn.py:16-19); every other list goes through the walker.
 //   FWD    [F -> A, ssp] [A -> A, + residual] [A -> F]                                   update MLP, residual, next node filter
 //   TURN   [F -> A, ssp] [A -> A, + residual] [A -> A/2, ssp, head] [A/2 -> A]^T [A -> A]^T ssp' [A -> F]^T
 //   REV    [F -> A]^T + residual, [A -> A]^T ssp', [A -> F]^T
@@ -611,7 +612,7 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
     hipStream_t st = (hipStream_t)stream;
     if (!getenv("MDG_CHAIN_WALKER")) {                                  // (MDG_CHAIN_WALKER=1: always the descriptor walker)
         if (spec_launch<64, 128>(a, stages, n_stages, n_rows, dual, st) || spec_launch<128, 128>(a, stages, n_stages, n_rows, dual, st) ||
-            spec_launch<64, 64>(a, stages, n_stages, n_rows, dual, st)) {
+            spec_launch<64, 64>(a, stages, n_stages, n_rows, dual, st) || spec_launch<128, 64>(a, stages, n_stages, n_rows, dual, st)) {
             MDG_CHECK_LAUNCH("chain_spec_kernel");
             return MDG_OK;
         }

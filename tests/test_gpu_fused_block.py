@@ -442,8 +442,8 @@ def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
                                           # more than 8 192 rows: the many-row variants of the kernel (no operand prefetch,
                                           # three / four waves per SIMD), which the stacked 8 x 4 096-bead workload runs on
                                           (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64),
-                                          # the other widths the compiled chains exist for (A = F = 128, A = F = 64)
-                                          (777, 128, 128, 128, 64), (555, 64, 64, 64, 32)])
+                                          # the other widths the compiled chains exist for (A = F = 128, A = F = 64, A = 128 / F = 64)
+                                          (777, 128, 128, 128, 64), (555, 64, 64, 64, 32), (640, 64, 128, 128, 64)])
 @pytest.mark.parametrize("walker", [False, True])
 def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3, walker, monkeypatch):
     """csrc/rowchain.hip: the stretch of the SchNet sweeps around the readout as ONE launch -- update MLP (activation,
