@@ -546,3 +546,43 @@ def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs, R):
         res.append([U.reshape(1), F_, U2.reshape(1), F2, dq, F3, dq3, torch.cat([t.reshape(-1) for t in gth])])
     for k, (a, b) in enumerate(zip(*res)):
         close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "chained vs layer-by-layer #%d" % k)
+
+
+@pytest.mark.parametrize("walker", [False, True])
+def test_row_chain_zero_tangent_input_and_a_fresh_input_in_the_middle(walker, monkeypatch):
+    """Two corners of mdg_row_chain's contract: a dual chain whose first stage has no tangent rows (in1 = NULL: x_dot = 0, as
+    below the first interaction block) -- on the compiled forward chain and on the walker --, and a later stage that takes
+    its input from global memory again instead of the previous stage's outputs."""
+    from mdgrad_amd import ops
+    if walker:
+        monkeypatch.setenv("MDG_CHAIN_WALKER", "1")
+    else:
+        monkeypatch.delenv("MDG_CHAIN_WALKER", raising=False)
+    torch.manual_seed(5)
+    N, F, A = 333, 128, 64
+    rn = lambda *s: torch.randn(*s, device=DEV)
+    U1, U2, Wn = rn(A, F) / F ** 0.5, rn(A, A) / A ** 0.5, rn(F, A) / A ** 0.5
+    c1, c2, bn = rn(A), rn(A), rn(F)
+    m, r, rd = rn(N, F), rn(N, A), rn(N, A)
+    ln2 = float(np.log(2.0))
+    ch = ops.RowChain(N, True, m.device)
+    a = ch.stage(U1, bias=c1, act=True, in0=m, in1=None, want_sig=True)
+    b = ch.stage(U2, bias=c2, res0=r, res1=rd)
+    c = ch.stage(Wn, bias=bn)
+    ch.run()
+    z = m @ U1.t() + c1
+    t = torch.nn.functional.softplus(z) - ln2
+    rr = t @ U2.t() + c2 + r
+    _close(a.out0, t, "t"); _close(a.sig, torch.sigmoid(z), "su")
+    assert float(a.out1.abs().max()) == 0.0, "zero tangent in, zero tangent row out of the activation stage"
+    _close(b.out0, rr, "r'"); _close(b.out1, rd, "rd' = residual only")
+    _close(c.out0, rr @ Wn.t() + bn, "h'"); _close(c.out1, rd @ Wn.t(), "hd'")
+    # a stage in the middle with its own global input
+    y = rn(N, A)
+    ch = ops.RowChain(N, False, m.device)
+    ch.stage(U1, bias=c1, in0=m, store=False)
+    s2 = ch.stage(U2, bias=c2, in0=y)
+    s3 = ch.stage(Wn)
+    ch.run()
+    _close(s2.out0, y @ U2.t() + c2, "second stage reads its own input")
+    _close(s3.out0, (y @ U2.t() + c2) @ Wn.t(), "third stage continues from the second")
