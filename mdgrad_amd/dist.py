@@ -8,6 +8,7 @@ step (RCCL over xGMI; backend "nccl" on ROCm), after which every rank applies th
 optimizer step.  The same code runs on CPU tensors with the gloo backend (tests).
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -79,6 +80,9 @@ class GradBucket:
             self.offsets.append(n)
             n += p.numel()
         ref = self.params[0]
+        if any(p.dtype != ref.dtype or p.device != ref.device for p in self.params):
+            raise ValueError("GradBucket needs parameters of one dtype on one device (got %s)"
+                             % sorted({(str(p.dtype), str(p.device)) for p in self.params}))
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
         self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
 
@@ -102,17 +106,19 @@ class GradBucket:
         return self.flat
 
 
-_buckets = []
+_buckets = weakref.WeakValueDictionary()          # id(first parameter) -> bucket; the bucket itself hangs on that parameter
 
 
 def _bucket_for(params):
-    for b in _buckets:
-        if b.matches(params):
-            return b
+    """The bucket of this parameter list.  It is owned by the list's first parameter (an attribute on the tensor), so a
+    model that goes away takes its flat buffer with it: nothing here keeps parameters or buffers of earlier runs alive."""
+    params = list(params)
+    b = _buckets.get(id(params[0]))
+    if b is not None and b.matches(params):
+        return b
     b = GradBucket(params)
-    _buckets.append(b)
-    if len(_buckets) > 8:
-        _buckets.pop(0)
+    params[0]._mdg_grad_bucket = b
+    _buckets[id(params[0])] = b
     return b
 
 

@@ -69,10 +69,14 @@ class GeneralInteraction(torch.nn.Module):
         if cache is not None and key in cache:
             return cache[key]
         vl = st.get("verlet")
-        sig = (int(st["max_nbr"]), int(st["capacity"]))
+        skin = self.verlet_skin * float(self.cutoff)
+        # everything the stored list was searched with: a changed cutoff / skin / selection / cell / grouping rebuilds it
+        sig = (int(st["max_nbr"]), int(st["capacity"]), float(self.cutoff), float(skin),
+               None if self._mask is None else self._mask.data_ptr(), bytes(self._cell_struct), int(self._group))
         if vl is None or vl.sig != sig or vl.n_atoms != xyz.shape[0]:
             vl = st["verlet"] = ops.VerletList(xyz.shape[0], self._group, self._cell_struct, self.cutoff,
-                                               self.verlet_skin * float(self.cutoff), self._mask, sig[0], sig[1], xyz.device)
+                                               skin, self._mask, sig[0], sig[1], xyz.device)
+            vl.sig = sig
         vl.rebuild(xyz, st["need"])
         if cache is not None:
             cache[key] = vl
@@ -151,7 +155,7 @@ class GNNPotentials(GeneralInteraction):
     def _reset_topology(self, xyz, _cache=None):
         self._topo_stamp = object()                  # identity of this rebuild (see md._EOM.update_topology)
         st = self._static if self._static_on else None
-        if st is not None and self.verlet_skin > 0 and self.supports_force_vjp():
+        if st is not None and self.verlet_skin > 0 and self._verlet_consumers_ok():
             topo = self._verlet_list(xyz, _cache, st).topo               # (rebuilt only when an atom left its half-skin ball)
         elif st is not None:
             topo = ops.StaticTopo(self._shared_static_ell(xyz, _cache, st), st["capacity"], st["need"])
@@ -162,6 +166,15 @@ class GNNPotentials(GeneralInteraction):
 
     def supports_static_topology(self):
         return self.supports_force_vjp()
+
+    def _verlet_consumers_ok(self):
+        """A list searched with a skin is only handed to consumers that re-apply the exact cutoff per pair: the fused
+        interaction-block kernels (`ops.edge_geom` -> mdg_edge_geom_masked marks pairs beyond the cutoff, the cfconv
+        kernels skip them).  The unfused chain (`analytic._primal`: n_gaussians > 64, `fused_block = False`, filter
+        counts the fused kernels do not take) reads every listed pair at full weight -- the filter has no cutoff
+        envelope -- so it gets the exact fixed-capacity list."""
+        from .nn import analytic
+        return self.supports_force_vjp() and analytic.fused_ok(self.gnn)
 
     def set_static_topology(self, on=True):
         """Fixed capacities (neighbours per atom, edges) sized from the current list with ~25 % head room."""

@@ -103,17 +103,26 @@ def _trainable_smear(conv):
 
 
 def _gauss_coeff(smear):
-    """-0.5 / width^2 of a (non-trainable, `supported`) GaussianSmearing, computed once: three tiny launches per
-    layer and evaluation otherwise."""
+    """-0.5 / width^2 of a (`supported`) GaussianSmearing in a PERSISTENT buffer, refreshed in place when the width
+    changed (three tiny launches per layer and evaluation otherwise).  A captured HIP graph holds the buffer's address:
+    inside a capture the buffer is returned as it is, and the replaying pass refreshes every layer's buffer before its
+    first replay (`refresh_embedding` through the interaction's `prepare_pass`), so an optimizer step on a trainable
+    width reaches the replayed steps -- the same scheme as `_embedded` / `PairPotentials._theta`."""
     w = smear.width
+    capturing = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    buf = getattr(smear, "_mdg_coeff_buf", None)
+    if buf is None or buf.shape != w.shape or buf.device != w.device:
+        if capturing:
+            return (-0.5 / w.detach().pow(2)).contiguous()   # (no buffer yet: computed from the live width inside this graph)
+        buf = smear._mdg_coeff_buf = torch.empty(w.shape, device=w.device, dtype=torch.float32)
+        smear._mdg_coeff_key = None
+    if capturing:
+        return buf
     key = (w.data_ptr(), w._version)
-    c = getattr(smear, "_mdg_coeff", None)
-    if c is None or c[0] != key:
-        val = (-0.5 / w.detach().pow(2)).contiguous()
-        if w.is_cuda and torch.cuda.is_current_stream_capturing():
-            return val                           # (memory of a graph's private pool must not outlive the capture)
-        c = smear._mdg_coeff = (key, val)
-    return c[1]
+    if smear._mdg_coeff_key != key:
+        buf.copy_(-0.5 / w.detach().to(torch.float32).pow(2))
+        smear._mdg_coeff_key = key
+    return buf
 
 
 def _layer_params(conv):
@@ -311,6 +320,8 @@ def _first_filter(net, z, P0):
 def refresh_embedding(net, z):
     """Bring the persistent embedding rows (and the first block's filtered rows) up to date, before the graph replays
     of a pass."""
+    for conv in net.convolutions:                                 # Gaussian coefficients of every layer (trainable widths)
+        _gauss_coeff(conv.moduledict["message_edge_filter"][0])
     if fused_ok(net) and chain_ok(net):
         _first_filter(net, z, _layer_params(net.convolutions[0]))
     else:

@@ -459,3 +459,15 @@ def test_trainable_gaussian_basis_trajectory_graph_replay_equals_eager_and_moves
     close(moved[1], moved_ref[1], 1e-4, 2e-5 * float(moved_ref[1].abs().max()), "after moving the centres: q_t")
     close(moved[3], moved_ref[3], 1e-4, 2e-5 * float(moved_ref[3].abs().max()) + 1e-7, "after moving the centres: dL/dtheta")
     assert float((moved[1] - out[1]).abs().max()) > 0
+    # ... and the new WIDTHS: the kernels read -0.5 / width^2 from a derived buffer (analytic._gauss_coeff), which a replayed
+    # graph must see refreshed (it used to bake in a cached tensor of the capture's warm-up runs)
+    integ.use_graphs = True
+    with torch.no_grad():
+        for conv in net.convolutions:
+            conv.moduledict["message_edge_filter"][0].width.mul_(1.3)
+    wide = _traj_and_grads(integ, system, t)
+    integ.use_graphs = False
+    wide_ref = _traj_and_grads(integ, system, t)
+    close(wide[1], wide_ref[1], 1e-4, 2e-5 * float(wide_ref[1].abs().max()), "after widening the Gaussians: q_t")
+    close(wide[3], wide_ref[3], 1e-4, 2e-5 * float(wide_ref[3].abs().max()) + 1e-7, "after widening the Gaussians: dL/dtheta")
+    assert float((wide[1] - moved[1]).abs().max()) > 1e-6 * float(moved[1].abs().max()), "the replayed steps ignored the new widths"

@@ -112,3 +112,41 @@ def test_gnn_trajectory_reuses_its_list_and_matches_the_exact_list_path():
     assert integ2.model.models["gnn"]._static.get("verlet") is None
     for a, b, name in zip(out, off, ("v_t", "q_t", "pv_t", "dL/dtheta")):
         close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "reuse on vs off: " + name)
+
+
+@pytest.mark.parametrize("how", ["fused_block_off", "wide_basis"])
+def test_unfused_chain_never_sees_a_skin_list(how):
+    """the unfused SchNet chain (`fused_block = False`, or n_gaussians > 64 -- the reference's search space
+    reaches 320) reads every listed pair at full weight, so a list searched with cutoff + skin must not reach it: graph
+    replay / sync-free passes give it the exact fixed-capacity list, and the trajectory + adjoint equal the eager pass on
+    exact lists."""
+    from mdgrad_amd import graphs, potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model, analytic
+    from test_gpu_schnet import _traj_and_grads, params_of
+    g = load_golden("gnn_traj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    torch.manual_seed(5)
+    prm = dict(params_of(g))
+    if how == "wide_basis":
+        prm["n_gaussians"] = 80
+    net = get_model(prm)
+    if how == "fused_block_off":
+        net.fused_block = False
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12), cutoff=float(g["cutoff"]))
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=float(g["T"]), num_chains=int(g["chains"]),
+                            Q=float(g["Q"]), adjoint=True).to(DEV)
+    assert gnn.supports_force_vjp() and not analytic.fused_ok(net)
+    for m in integ.model.models.values():        # a skin wide enough that pairs in (rc, rc + skin] certainly exist
+        m.verlet_skin = 0.2
+    t = torch.Tensor([float(g["dt"]) * i for i in range(6)]).to(DEV)
+    out = _traj_and_grads(integ, system, t)
+    assert gnn._static is None or gnn._static.get("verlet") is None, "a skin list reached the unfused chain"
+    integ.use_graphs = False
+    for m in integ.model.models.values():
+        m.verlet_skin = 0.0
+    ref = _traj_and_grads(integ, system, t)
+    for a, b, name in zip(out, ref, ("v_t", "q_t", "pv_t", "dL/dtheta")):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "unfused chain, static lists vs exact lists: " + name)
