@@ -158,3 +158,148 @@ def test_stacked_schnet_replicas_trajectory_and_adjoint_vs_oracle(size, R, frame
         close(gv0[r], lam[0], 5e-3, 2e-3 * float(lam[0].abs().max()), "adj v0 replica %d" % r)
     assert flat.shape == gth_sum.shape
     close(flat, gth_sum, 5e-3, 5e-4 * float(gth_sum.abs().max()), "sum over replicas of dL/dtheta (SchNet + prior)")
+
+
+# ------------------------------------------------------------------ north_star's 4 096-bead SchNet geometry
+# Built through bench.build_schnet_workload -- the function bench.py's schnet4096 leg (and its single-system figure) builds its
+# systems with -- so the tests take the code paths the timed runs take: ONE 4 096-bead system (57 k edges: HIP-graph replay,
+# the specialised row chains at 4 096 rows, grouped cell lists) and the 8 x 4 096-bead stack (459 k edges > graphs.MAX_EDGES:
+# `graphs.eager_static` on stored Verlet lists, the many-row chain variants, 65 536-slot cfconv grids, cell lists at 32 768
+# atoms).  Reference behaviour: nff/nn/models/schnet.py:113-171 under torchmd/sovlers.py:211-293.
+_ORACLE_4096 = {}
+
+
+def _rdf_plus(cellt, stride, N):
+    """Per-replica loss: RDF(60 bins, 2..6 A) of every `stride`-th frame against 1 -- bench.py's loss -- plus small terms in
+    the last velocities / thermostat momenta so that every adjoint input is non-zero."""
+    def oracle_loss(L):
+        g = O.rdf_oracle(L[1][::stride], cellt, 60, (2.0, 6.0))[2]
+        return (g - 1).pow(2).mean() + L[0][-1].pow(2).sum() / (N * 3) * 10.0 + L[2][-1].sum() * 1e-2
+    return oracle_loss
+
+
+def _oracle_4096(key, wl, sd, pos, vel, t, stride):
+    if key not in _ORACLE_4096:
+        import bench
+        torch.set_num_threads(min(32, bench._host_cpus()[1]))
+        cellt = torch.tensor([wl["L"]] * 3, dtype=torch.float32)
+        traj, lam, gth = bench.schnet_oracle_replica(wl, sd, pos, vel, t, _rdf_plus(cellt, stride, wl["N"]))
+        g = O.rdf_oracle(traj[1][::stride], cellt, 60, (2.0, 6.0))[2]
+        _ORACLE_4096[key] = (traj, lam, gth, g)
+    return _ORACLE_4096[key]
+
+
+def _run_schnet_workload(wl, t, stride, replicas=None):
+    """Trajectory + adjoint of a bench workload under the per-replica loss of `_rdf_plus` summed over `replicas`."""
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    integ, R, N = wl["integ"], wl["R"], wl["N"]
+    replicas = range(R) if replicas is None else replicas
+    for p in integ.parameters():
+        p.grad = None
+    vl = (wl["gnn"]._static or {}).get("verlet")
+    if vl is not None:
+        vl.pos_build.fill_(float("nan"))           # every pass starts from a search at its own first positions
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="NH_verlet")
+    F = t.shape[0]
+    qr, vr, pr = q_t.reshape(F, R, N, 3), v_t.reshape(F, R, N, 3), pv_t.reshape(F, R, -1)
+    obs = rdf(wl["base"], nbins=60, r_range=(2.0, 6.0))
+    gs = {r: obs(qr[::stride, r])[2] for r in replicas}
+    sum((gs[r] - 1).pow(2).mean() + vr[-1, r].pow(2).sum() / (N * 3) * 10.0 + pr[-1, r].sum() * 1e-2 for r in replicas).backward()
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in integ.parameters()])
+    return dict(q=qr.detach(), v=vr.detach(), pv=pr.detach(), g={r: g.detach() for r, g in gs.items()},
+                gq0=y0[1].grad.reshape(R, N, 3), gv0=y0[0].grad.reshape(R, N, 3), gpv0=y0[2].grad.reshape(R, -1), flat=flat)
+
+
+def _tols(bf16):
+    # f32: the tolerances of the 8 x 512-bead test above.  bf16 filter operands (BASELINE config #5): the stated tolerances of
+    # tests/test_gpu_config5.py (positions 3e-4 A, g 5e-4, gradients 5e-4 .. 1e-3 of the largest entry + cosine)
+    if bf16:
+        return dict(q=3e-4, v=(1e-2, 2e-3), pv=(2e-2, 1e-4), g=5e-4, adj=(0.0, 2e-2), th=(0.0, 5e-3), cos=0.9999)
+    return dict(q=2e-5, v=(1e-3, 1e-4), pv=(2e-3, 1e-5), g=1e-4, adj=(5e-3, 2e-3), th=(5e-3, 5e-4), cos=0.999999)
+
+
+def _check_replica(out, r, ref, tol, tag):
+    traj, lam, gth, g = ref
+    close(out["q"][:, r], traj[1], 0, tol["q"], tag + " q_t")
+    close(out["v"][:, r], traj[0], tol["v"][0], tol["v"][1] * float(traj[0].abs().max()), tag + " v_t")
+    close(out["pv"][:, r], traj[2], tol["pv"][0], tol["pv"][1], tag + " pv_t")
+    close(out["g"][r], g, 0, tol["g"], tag + " g(r)")
+    close(out["gq0"][r], lam[1], tol["adj"][0], tol["adj"][1] * float(lam[1].abs().max()), tag + " adj q0")
+    close(out["gv0"][r], lam[0], tol["adj"][0], tol["adj"][1] * float(lam[0].abs().max()), tag + " adj v0")
+
+
+def _check_theta(flat, gth, tol, tag):
+    assert flat.shape == gth.shape
+    close(flat, gth, tol["th"][0], tol["th"][1] * float(gth.abs().max()), tag + " dL/dtheta")
+    a, b = flat.double().cpu(), gth.double()
+    assert float((a * b).sum() / (a.norm() * b.norm())) > tol["cos"], tag + " dL/dtheta cosine"
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_schnet_one_4096_bead_system_vs_oracle(bf16):
+    """north_star / BASELINE config #5 at full size, one replica per GPU: ONE 4 096-bead CG-water system, SchNet A64/F128/G30/2
+    conv + prior, 3 NH-Verlet steps + RDF loss + analytic adjoint through HIP-graph replay -- trajectory, g(r), adjoints of
+    the initial state and the 14 337-entry parameter gradient against oracle/ (autograd double backward like the reference);
+    f32 and with bf16 filter operands (same oracle run)."""
+    import bench
+    from mdgrad_amd import graphs, units
+    wl = bench.build_schnet_workload(DEV, 1, bf16, 77)
+    N = wl["N"]
+    assert N == 4096 and wl["gnn"].inputs["_topo"].n_edges > 50000
+    assert graphs.enabled(wl["integ"])
+    sd = {k: v.detach().clone().cpu() for k, v in wl["net"].state_dict().items()}
+    pos = wl["system"].get_positions().astype(np.float32)
+    vel = wl["system"].get_velocities().astype(np.float32)
+    t = torch.Tensor([units.fs * i for i in range(4)])
+    out = _run_schnet_workload(wl, t, 3)
+    ref = _oracle_4096(("single", 77), wl, sd, pos, vel, t, 3)
+    tol = _tols(bf16)
+    _check_replica(out, 0, ref, tol, "one 4096-bead system (%s)" % ("bf16" if bf16 else "f32"))
+    _check_theta(out["flat"], ref[2], tol, "one 4096-bead system")
+
+
+@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
+    """The launch geometry bench.py's schnet4096 leg times, built by the same function: 8 stacked replicas x 4 096 beads
+    (32 768 atoms, 459 k edges), 2 steps + per-replica RDF loss + adjoint.  First and last replica against their own oracle
+    runs; the parameter gradient of those two against the oracle's sum; a second pass is bitwise the first (determinism over
+    all eight); and replica 3 of the stack equals the same replica run as a system of its own (a stacking / grouping bug would
+    show there)."""
+    import bench
+    from mdgrad_amd import graphs, units
+    R = 8
+    wl = bench.build_schnet_workload(DEV, R, bf16, 2000)
+    N = wl["N"]
+    topo = wl["gnn"].inputs["_topo"]
+    assert N == 4096 and topo.n_edges > graphs.MAX_EDGES, "the timed stack must take the eager pass on stored lists"
+    sd = {k: v.detach().clone().cpu() for k, v in wl["net"].state_dict().items()}
+    pos = wl["system"].get_positions().reshape(R, N, 3).astype(np.float32)
+    vel = wl["system"].get_velocities().reshape(R, N, 3).astype(np.float32)
+    t = torch.Tensor([units.fs * i for i in range(3)])
+    tol = _tols(bf16)
+    tag = "8 x 4096 stack (%s)" % ("bf16" if bf16 else "f32")
+    out = _run_schnet_workload(wl, t, 2, replicas=(0, R - 1))
+    gsum = None
+    for r in (0, R - 1):
+        ref = _oracle_4096(("stack", 2000, r), wl, sd, pos[r], vel[r], t, 2)
+        _check_replica(out, r, ref, tol, "%s replica %d" % (tag, r))
+        gsum = ref[2] if gsum is None else gsum + ref[2]
+    _check_theta(out["flat"], gsum, tol, tag + " replicas 0 + 7")
+    # all eight: finite, and a second pass reproduces the first bit for bit
+    again = _run_schnet_workload(wl, t, 2, replicas=(0, R - 1))
+    for k in ("q", "v", "pv", "gq0", "gv0", "flat"):
+        assert bool(torch.isfinite(out[k]).all()), k
+        assert torch.equal(out[k], again[k]), "second pass differs from the first: " + k
+    # replica 3 alone == replica 3 inside the stack (same kernels, different launch geometry: graph replay at 57 k edges)
+    one = bench.build_schnet_workload(DEV, 1, bf16, 1)
+    one["system"].set_positions(pos[3])
+    one["system"].set_velocities(vel[3])
+    alone = _run_schnet_workload(one, t, 2)
+    full = _run_schnet_workload(wl, t, 2, replicas=(3,))
+    sc = 10.0 if bf16 else 1.0          # (bf16: the operand rounding sees tile groupings that differ between the launches)
+    close(full["q"][:, 3], alone["q"][:, 0], 0, 1e-5 * sc, tag + " replica 3: stacked vs alone, q_t")
+    close(full["v"][:, 3], alone["v"][:, 0], 0, 2e-5 * sc * float(alone["v"].abs().max()), tag + " replica 3: stacked vs alone, v_t")
+    close(full["gq0"][3], alone["gq0"][0], 0, 2e-4 * sc * float(alone["gq0"].abs().max()), tag + " replica 3: stacked vs alone, adj q0")
+    close(full["flat"], alone["flat"], 0, 2e-4 * sc * float(alone["flat"].abs().max()), tag + " replica 3: stacked vs alone, dL/dtheta")
