@@ -98,26 +98,26 @@ struct FwdArgs {
 };
 
 template <int FT>
-__device__ __forceinline__ void load_row(const float* __restrict__ base, long long row, int F, int RS, int li, bool ok,
+__device__ __forceinline__ void load_row(const float* __restrict__ base, int row, int F, int RS, int li, bool ok,
                                          float (&out)[FT]) {
-    // FT consecutive filters li*FT .. li*FT+FT-1 of one gathered row (zero outside the row / for an inert slot)
-    if (ok && li * FT + FT <= F) {
-        const float4* p = reinterpret_cast<const float4*>(base + row * RS + li * FT);
+    // FT consecutive filters li*FT .. li*FT+FT-1 of one gathered row.  The load is UNCONDITIONAL: an inert slot reads row 0 and
+    // a lane past the last filter column 0 -- valid, finite memory whose values meet a zero filter value / a zero mask in
+    // every product they enter (masked slots: W = 0 and mr = 0; padded columns: zero weights, never stored) -- so a tile's
+    // gathers are straight-line code that is in flight while the filter network is evaluated.  32-bit element offset from
+    // the uniform base (the launcher checks n_atoms * row stride < 2^30).
+    const unsigned off = (unsigned)(ok ? row : 0) * (unsigned)RS + (unsigned)(li * FT + FT <= F ? li * FT : 0);
+    const float4* p = reinterpret_cast<const float4*>(base + off);
 #pragma unroll
-        for (int v = 0; v < FT / 4; ++v) {
-            const float4 x = p[v];
-            out[4 * v] = x.x; out[4 * v + 1] = x.y; out[4 * v + 2] = x.z; out[4 * v + 3] = x.w;
-        }
-    } else {
-#pragma unroll
-        for (int v = 0; v < FT; ++v) out[v] = 0.f;
+    for (int v = 0; v < FT / 4; ++v) {
+        const float4 x = p[v];
+        out[4 * v] = x.x; out[4 * v + 1] = x.y; out[4 * v + 2] = x.z; out[4 * v + 3] = x.w;
     }
 }
 
 template <int FT>
-__device__ __forceinline__ void store_row(float* __restrict__ base, long long row, int F, int RS, int li, const float (&v)[FT]) {
+__device__ __forceinline__ void store_row(float* __restrict__ base, int row, int F, int RS, int li, const float (&v)[FT]) {
     if (li * FT + FT <= F) {
-        float4* p = reinterpret_cast<float4*>(base + row * RS + li * FT);
+        float4* p = reinterpret_cast<float4*>(base + ((unsigned)row * (unsigned)RS + (unsigned)(li * FT)));
 #pragma unroll
         for (int q = 0; q < FT / 4; ++q) p[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
@@ -142,7 +142,7 @@ void cfconv_fwd_kernel(const FwdArgs A) {
     float* b1s = c2s + GP;
     float* b2s = b1s + GP;
     float* h1s = b2s + FP;                  // [4 waves][16][SA]  (, [4][16][SA] tangent)
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index: uniform)
     const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int k = t / GP, j = t % GP;
@@ -174,21 +174,30 @@ void cfconv_fwd_kernel(const FwdArgs A) {
     // at any time the XCD works on a window of consecutive -- i.e. spatially close -- atoms, so the node rows their
     // neighbours gather stay in its 4 MB L2 (a contiguous chunk per workgroup spreads the XCD over the whole replica:
     // 8 MB of rows in flight, measured gather-bound)
+    const bool has_hd = A.hd != nullptr;
     int n_begin, n_end, n_step;
     xcd_sweep(A.N, 4, n_begin, n_end, n_step);
     // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
     // the first tile of the wave's next atom after an atom's last one -- are requested before the current tile is worked
     // on: the distance and node-row gathers of a tile then start at once instead of behind a second round trip.
-    int pf_cnt = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
+    // (the neighbour counts of the wave's next 64 atoms come in ONE vector load, lane k <-> the k-th atom ahead, and are read
+    //  out with v_readlane: a count fetched per atom sat, as a loop-carried scalar, behind a round trip of its own per atom)
+    int cnt_vec = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
     if (n_begin + wid < n_end) {
         const size_t rb = (size_t)(n_begin + wid) * A.max_nbr;
-        pf_cnt = A.cnt[n_begin + wid];
         pf_e = A.eid[rb + min(li, A.max_nbr - 1)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(4 * lk + r, A.max_nbr - 1)];
     }
-    for (int n = n_begin + wid; n < n_end; n += n_step) {
-        const int cnt = pf_cnt;
+    int kat = 0;
+    for (int n = n_begin + wid; n < n_end; n += n_step, ++kat) {
+        if ((kat & 63) == 0) {
+            int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane id, recomputed here:
+            asm volatile("" : "+v"(ln));                          // nothing of this rare load's address arithmetic lives across the loops
+            const long long na = (long long)n + (long long)ln * n_step;
+            cnt_vec = na < n_end ? A.cnt[na] : 0;
+        }
+        const int cnt = __builtin_amdgcn_readlane(cnt_vec, kat & 63);
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
@@ -205,24 +214,26 @@ void cfconv_fwd_kernel(const FwdArgs A) {
                     pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb2 + min(t2 + 4 * lk + r, A.max_nbr - 1)];
-                    if (last) pf_cnt = A.cnt[n2];
                 }
             }
-            // ---- A-layout row (slot t0 + li): distance (and its tangent)
+            // ---- A-layout row (slot t0 + li): distance (and its tangent).  Both loads are unconditional (slot past the row's
+            // end: entry 0) and independent of one another, so they leave together with the row gathers below -- guarded by
+            // the validity of the distance, the tangent's load sat behind a full round trip of the distance's
             const bool vin = t0 + li < cnt;
             const int ea = vin ? ea_raw : 0;
-            const float draw = vin ? A.d[ea] : -1.f;
+            const float dload = A.d[ea];
+            const float ddload = TANGENT ? A.dd[ea] : 0.f;
+            const float draw = vin ? dload : -1.f;
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
             const bool va = draw >= 0.f;
             // bit s (lanes 0..15) of the ballot: slot t0 + s is a real neighbour; mr[r] = 1 / 0 for the lane's four C-layout rows
             const unsigned nib = ((unsigned)__ballot(va) >> (4 * lk)) & 0xFu;
-            float mr[4];
+            bool mr[4];                                           // (lane masks: they live in scalar registers)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) ? 1.f : 0.f;
+            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) != 0u;
             const float da = va ? draw : PAD_D;
-            float dda = 0.f;
-            if (TANGENT) dda = va ? A.dd[ea] : 0.f;
+            const float dda = (TANGENT && va) ? ddload : 0.f;
             // ---- C-layout rows (slots t0 + 4 lk + r): gathered node rows, FT consecutive filters per lane
             float hreg[4][FT], hdreg[4][FT];
 #pragma unroll
@@ -231,7 +242,17 @@ void cfconv_fwd_kernel(const FwdArgs A) {
                 const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
                 const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
-                if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
+            }
+            if (TANGENT) {
+                if (has_hd) {                                     // (wave-uniform: the first block's node rows have no tangent)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int v = 0; v < FT; ++v) hdreg[r][v] = 0.f;
+                }
             }
             // ---- layer 1: Gaussians (and d/dd of them) in registers as A fragments
             float af[KS], adf[KS];
@@ -287,13 +308,13 @@ void cfconv_fwd_kernel(const FwdArgs A) {
                 const float bias = b2s[nt * 16 + li];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float W = fmaf(bias, mr[r], acc[r]);
+                    const float W = acc[r] + (mr[r] ? bias : 0.f);
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    if (SUMS) hs[nt] = fmaf(hreg[r][nt], mr[r], hs[nt]);
+                    if (SUMS) hs[nt] += mr[r] ? hreg[r][nt] : 0.f;
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS) hds[nt] = fmaf(hdreg[r][nt], mr[r], hds[nt]);
+                        if (SUMS) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
                     }
                 }
             }
@@ -367,7 +388,7 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     unsigned short* w1b = reinterpret_cast<unsigned short*>(b2s + FP);      // [GP rows j][KSB]   W1[j][k]
     unsigned short* w2b = w1b + GP * KSB;                                    // [FP rows c][KSB]   W2[f(c)][k]
     unsigned short* h1s = w2b + FP * KSB;                                    // [4 (+4) waves][16][KSB]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index: uniform)
     const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int j = t / GP, k = t % GP;
@@ -394,21 +415,30 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     const int li = lane & 15, lk = lane >> 4;
     unsigned short* h1w = h1s + wid * 16 * KSB;
     unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
+    const bool has_hd = A.hd != nullptr;
     int n_begin, n_end, n_step;
     xcd_sweep(A.N, 4, n_begin, n_end, n_step);              // (see cfconv_fwd_kernel)
     // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
     // the first tile of the wave's next atom after an atom's last one -- are requested before the current tile is worked
     // on: the distance and node-row gathers of a tile then start at once instead of behind a second round trip.
-    int pf_cnt = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
+    // (the neighbour counts of the wave's next 64 atoms come in ONE vector load, lane k <-> the k-th atom ahead, and are read
+    //  out with v_readlane: a count fetched per atom sat, as a loop-carried scalar, behind a round trip of its own per atom)
+    int cnt_vec = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
     if (n_begin + wid < n_end) {
         const size_t rb = (size_t)(n_begin + wid) * A.max_nbr;
-        pf_cnt = A.cnt[n_begin + wid];
         pf_e = A.eid[rb + min(li, A.max_nbr - 1)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(4 * lk + r, A.max_nbr - 1)];
     }
-    for (int n = n_begin + wid; n < n_end; n += n_step) {
-        const int cnt = pf_cnt;
+    int kat = 0;
+    for (int n = n_begin + wid; n < n_end; n += n_step, ++kat) {
+        if ((kat & 63) == 0) {
+            int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane id, recomputed here:
+            asm volatile("" : "+v"(ln));                          // nothing of this rare load's address arithmetic lives across the loops
+            const long long na = (long long)n + (long long)ln * n_step;
+            cnt_vec = na < n_end ? A.cnt[na] : 0;
+        }
+        const int cnt = __builtin_amdgcn_readlane(cnt_vec, kat & 63);
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
@@ -425,23 +455,23 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                     pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb2 + min(t2 + 4 * lk + r, A.max_nbr - 1)];
-                    if (last) pf_cnt = A.cnt[n2];
                 }
             }
             const bool vin = t0 + li < cnt;
             const int ea = vin ? ea_raw : 0;
-            const float draw = vin ? A.d[ea] : -1.f;
+            const float dload = A.d[ea];                          // (unconditional, with the tangent's: see cfconv_fwd_kernel)
+            const float ddload = TANGENT ? A.dd[ea] : 0.f;
+            const float draw = vin ? dload : -1.f;
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
             const bool va = draw >= 0.f;
             // bit s (lanes 0..15) of the ballot: slot t0 + s is a real neighbour; mr[r] = 1 / 0 for the lane's four C-layout rows
             const unsigned nib = ((unsigned)__ballot(va) >> (4 * lk)) & 0xFu;
-            float mr[4];
+            bool mr[4];                                           // (lane masks: they live in scalar registers)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) ? 1.f : 0.f;
+            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) != 0u;
             const float da = va ? draw : PAD_D;
-            float dda = 0.f;
-            if (TANGENT) dda = va ? A.dd[ea] : 0.f;
+            const float dda = (TANGENT && va) ? ddload : 0.f;
             float hreg[4][FT], hdreg[4][FT];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -449,7 +479,17 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
                 const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
-                if (TANGENT) load_row<FT>(A.hd, j, F, RS, li, vc && A.hd != nullptr, hdreg[r]);
+            }
+            if (TANGENT) {
+                if (has_hd) {                                     // (wave-uniform: the first block's node rows have no tangent)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int v = 0; v < FT; ++v) hdreg[r][v] = 0.f;
+                }
             }
             bf16x8 af[KB], adf[KB];
 #pragma unroll
@@ -503,13 +543,13 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const float bias = b2s[nt * 16 + li];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float W = fmaf(bias, mr[r], acc[r]);
+                    const float W = acc[r] + (mr[r] ? bias : 0.f);
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    if (SUMS) hs[nt] = fmaf(hreg[r][nt], mr[r], hs[nt]);
+                    if (SUMS) hs[nt] += mr[r] ? hreg[r][nt] : 0.f;
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
                         mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS) hds[nt] = fmaf(hdreg[r][nt], mr[r], hds[nt]);
+                        if (SUMS) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
                     }
                 }
             }
@@ -561,12 +601,98 @@ struct BwdArgs {
     const int32_t* n_valid;   // fixed-capacity lists: device count of real rows (rows beyond are padding), or null
 };
 
+// ---- the gathers of one 16-edge tile, shared by the f32 and the bf16 sweep ------------------------------------------
+// Lane (li, lk) owns edge e0 + li and, per k-block q, filters 16 q + 4 lk + [0, 4) of it.
+struct EdgeIdx {
+    int i, j;            // atoms of the lane's edge (-1: padding row / past the end)
+    float d, dd;         // its distance (-1: padding, or a pair of a stored list that is beyond the cutoff now) and tangent
+};
+
+// nbr, d and dd are indexed by the edge itself, so the three loads are independent: ONE round trip, requested a tile ahead
+template <bool DUAL>
+__device__ __forceinline__ EdgeIdx load_edge_idx(const BwdArgs& A, long long e) {
+    EdgeIdx x{-1, -1, -1.f, 0.f};
+    if (e < A.E) {
+        const longlong2 ij = *reinterpret_cast<const longlong2*>(A.nbr + 2 * e);
+        x.i = (int)ij.x; x.j = (int)ij.y;
+        x.d = A.d[e];
+        if (DUAL) x.dd = A.dd[e];
+    }
+    if (x.i < 0) x.d = -1.f;
+    return x;
+}
+
+// Adjoint rows of the filter output:  Wdb = mdb_i h_j + mdb_j h_i,   Wb = mb_i h_j + mb_j h_i (+ mdb_i hd_j + mdb_j hd_i).
+// Every load is UNCONDITIONAL -- the rows of an inert edge and the columns past F are clamped to row 0 / column 0 and the
+// products selected to 0 afterwards -- and the k-blocks are gathered in batches of QB: all loads of a batch are issued back to
+// back (a scheduling fence keeps the products behind them), so a tile costs FT / QB round trips with QB x 4..8 rows in flight
+// per lane.  (Round 3 guarded each k-block's loads with the lane's validity: the divergent branches pinned every block's
+// products behind its own loads, 8-16 dependent round trips per tile -- the sweep waited on memory 65 % of the time with one
+// wave per SIMD; profiles/pmc_schnet4096.json.)
+template <int FT, int QB, bool DUAL, bool HASHD>
+__device__ __forceinline__ void gather_adjoint_rows(const BwdArgs& A, int ia, int ja, bool va, int lk, int F, int RS,
+                                                    float (&wdb)[4 * FT], float (&wb)[DUAL ? 4 * FT : 1]) {
+    const long long ri = (long long)(va ? ia : 0) * RS + 4 * lk, rj = (long long)(va ? ja : 0) * RS + 4 * lk;
+    const float* __restrict__ hI = A.h + ri;
+    const float* __restrict__ hJ = A.h + rj;
+    const float* __restrict__ pI = A.mdb + ri;
+    const float* __restrict__ pJ = A.mdb + rj;
+    const float* __restrict__ bI = DUAL ? A.mb + ri : nullptr;
+    const float* __restrict__ bJ = DUAL ? A.mb + rj : nullptr;
+    const float* __restrict__ tI = HASHD ? A.hd + ri : nullptr;
+    const float* __restrict__ tJ = HASHD ? A.hd + rj : nullptr;
+#pragma unroll
+    for (int q0 = 0; q0 < FT; q0 += QB) {
+        float4 hi[QB], hj[QB], pi[QB], pj[QB], bi[DUAL ? QB : 1], bj[DUAL ? QB : 1], ti[HASHD ? QB : 1], tj[HASHD ? QB : 1];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int fc = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
+            hi[u] = *reinterpret_cast<const float4*>(hI + fc);
+            hj[u] = *reinterpret_cast<const float4*>(hJ + fc);
+            pi[u] = *reinterpret_cast<const float4*>(pI + fc);
+            pj[u] = *reinterpret_cast<const float4*>(pJ + fc);
+            if (DUAL) {
+                bi[u] = *reinterpret_cast<const float4*>(bI + fc);
+                bj[u] = *reinterpret_cast<const float4*>(bJ + fc);
+            }
+            if (HASHD) {
+                ti[u] = *reinterpret_cast<const float4*>(tI + fc);
+                tj[u] = *reinterpret_cast<const float4*>(tJ + fc);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // the batch's loads stay together, ahead of its products
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int q = q0 + u;
+            const bool ok = va && 16 * q + 4 * lk + 4 <= F;
+            wdb[4 * q] = ok ? pi[u].x * hj[u].x + pj[u].x * hi[u].x : 0.f;
+            wdb[4 * q + 1] = ok ? pi[u].y * hj[u].y + pj[u].y * hi[u].y : 0.f;
+            wdb[4 * q + 2] = ok ? pi[u].z * hj[u].z + pj[u].z * hi[u].z : 0.f;
+            wdb[4 * q + 3] = ok ? pi[u].w * hj[u].w + pj[u].w * hi[u].w : 0.f;
+            if (DUAL) {
+                float4 w = {bi[u].x * hj[u].x + bj[u].x * hi[u].x, bi[u].y * hj[u].y + bj[u].y * hi[u].y,
+                            bi[u].z * hj[u].z + bj[u].z * hi[u].z, bi[u].w * hj[u].w + bj[u].w * hi[u].w};
+                if (HASHD) {
+                    w.x += pi[u].x * tj[u].x + pj[u].x * ti[u].x; w.y += pi[u].y * tj[u].y + pj[u].y * ti[u].y;
+                    w.z += pi[u].z * tj[u].z + pj[u].z * ti[u].z; w.w += pi[u].w * tj[u].w + pj[u].w * ti[u].w;
+                }
+                wb[4 * q] = ok ? w.x : 0.f; wb[4 * q + 1] = ok ? w.y : 0.f;
+                wb[4 * q + 2] = ok ? w.z : 0.f; wb[4 * q + 3] = ok ? w.w : 0.f;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // physical row of filter f in the LDS copy of W2 used as the B operand of  [16 x F] x [F x G]:
 // k-step ks = 4 (f / 16) + f % 4, k-lane lk = (f % 16) / 4
 __host__ __device__ inline int w2_row(int f) { return (4 * (f >> 4) + (f & 3)) * 4 + ((f & 15) >> 2); }
 
 template <int GP, int FT, bool DUAL, bool THETA>
-__global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
+// (f32 operands: the 64 adjoint-row registers stay live as MFMA operands and the weights take 71 KB of LDS, so the sweep with
+//  parameter gradients keeps one wave per SIMD -- with four k-blocks in flight per round trip -- and the others two)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (THETA ? 1 : 2) : 1)))
+void cfconv_bwd_kernel(const BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int S1 = GP % 32 == 16 ? GP : GP + 16;
     constexpr int FP = 16 * FT;
@@ -583,7 +709,7 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
     float* c2s = cfs + GP;
     float* b1s = c2s + GP;
     float* wsc = b1s + GP;                   // [4 waves][WSZ]
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index: uniform)
     const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int k = t / GP, j = t % GP;
@@ -631,50 +757,23 @@ __global__ __launch_bounds__(256) void cfconv_bwd_kernel(const BwdArgs A) {
     const long long ntiles = (nrows + 63) / 64;
     int t_begin, t_end, t_step;
     xcd_sweep((int)ntiles, 1, t_begin, t_end, t_step);           // the half list is sorted by atom: same locality argument
+    const bool has_hd = A.hd != nullptr;                          // (wave-uniform: the first block's node rows have no tangent)
+    EdgeIdx nx = load_edge_idx<DUAL>(A, (long long)t_begin * 64 + wid * 16 + li);
     for (long long tile = t_begin; tile < t_end; tile += t_step) {
         const long long e0 = tile * 64 + wid * 16;
-        // ---- A-layout row: edge e0 + li
-        const long long ea = e0 + li;
-        long long ia = -1, ja = -1;
-        if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
-        const float draw = ia >= 0 ? A.d[ea] : -1.f;             // (-1: padding row of a fixed-capacity list)
-        const bool va = draw >= 0.f;                              // (d = -1: a pair of a stored list that is beyond the cutoff now)
+        // ---- A-layout row: edge e0 + li (indices, distance and tangent were requested a tile ahead)
+        const EdgeIdx cur = nx;
+        if (tile + t_step < t_end) nx = load_edge_idx<DUAL>(A, (tile + t_step) * 64 + wid * 16 + li);
+        const int ia = cur.i, ja = cur.j;
+        const bool va = cur.d >= 0.f;                             // (-1: padding row, or a pair of a stored list beyond the cutoff now)
         if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
-        const float da = va ? draw : PAD_D;
-        float dda = 0.f;
-        if (DUAL) dda = va ? A.dd[ea] : 0.f;
+        const float da = va ? cur.d : PAD_D;
+        const float dda = (DUAL && va) ? cur.dd : 0.f;
         // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
         float wdb[4 * FT], wb[DUAL ? 4 * FT : 1];
-#pragma unroll
-        for (int q = 0; q < FT; ++q) {
-            const int f0 = 16 * q + 4 * lk;
-            float4 hi = {0.f, 0.f, 0.f, 0.f}, hj = hi, pi = hi, pj = hi;
-            const bool ok = va && f0 + 4 <= F;
-            if (ok) {
-                hi = *reinterpret_cast<const float4*>(A.h + ia * RS + f0);
-                hj = *reinterpret_cast<const float4*>(A.h + ja * RS + f0);
-                pi = *reinterpret_cast<const float4*>(A.mdb + ia * RS + f0);
-                pj = *reinterpret_cast<const float4*>(A.mdb + ja * RS + f0);
-            }
-            wdb[4 * q] = pi.x * hj.x + pj.x * hi.x; wdb[4 * q + 1] = pi.y * hj.y + pj.y * hi.y;
-            wdb[4 * q + 2] = pi.z * hj.z + pj.z * hi.z; wdb[4 * q + 3] = pi.w * hj.w + pj.w * hi.w;
-            if (DUAL) {
-                float4 bi = {0.f, 0.f, 0.f, 0.f}, bj = bi;
-                if (ok) {
-                    bi = *reinterpret_cast<const float4*>(A.mb + ia * RS + f0);
-                    bj = *reinterpret_cast<const float4*>(A.mb + ja * RS + f0);
-                }
-                float4 w = {bi.x * hj.x + bj.x * hi.x, bi.y * hj.y + bj.y * hi.y, bi.z * hj.z + bj.z * hi.z,
-                            bi.w * hj.w + bj.w * hi.w};
-                if (A.hd != nullptr && ok) {
-                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * RS + f0);
-                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * RS + f0);
-                    w.x += pi.x * tj.x + pj.x * ti.x; w.y += pi.y * tj.y + pj.y * ti.y;
-                    w.z += pi.z * tj.z + pj.z * ti.z; w.w += pi.w * tj.w + pj.w * ti.w;
-                }
-                wb[4 * q] = w.x; wb[4 * q + 1] = w.y; wb[4 * q + 2] = w.z; wb[4 * q + 3] = w.w;
-            }
-        }
+        constexpr int QB = (GP == 64 && THETA) ? 2 : 4;   // k-blocks gathered per round trip (registers in flight)
+        if (DUAL && has_hd) gather_adjoint_rows<FT, QB, DUAL, true>(A, ia, ja, va, lk, F, RS, wdb, wb);
+        else gather_adjoint_rows<FT, QB, DUAL, false>(A, ia, ja, va, lk, F, RS, wdb, wb);
         // ---- recompute layer 1: a = g W1^T + b1 (and its tangent) in the accumulator layout
         float sg[NT][4], qd[DUAL ? NT : 1][4], sc[THETA ? NT : 1][4], sdc[THETA ? NT : 1][4];
         {
@@ -917,20 +1016,85 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
     return __builtin_bit_cast(bf16x4, u);
 }
 
+// gather_adjoint_rows for the bf16 sweep: the products leave the gather as packed bf16 MFMA operands (2 registers per
+// k-block and matrix instead of 4 + 4 floats kept for the whole tile) and, for the parameter gradients, go straight into
+// the wave's two bf16 LDS tiles  tdb / tb [16 edges][SWB]  that the transposed operand of gW2 is read from.
+template <int FT, int QB, int SWB, bool DUAL, bool HASHD, bool TILE>
+__device__ __forceinline__ void gather_adjoint_rows_bf16(const BwdArgs& A, int ia, int ja, bool va, int li, int lk, int F,
+                                                         int RS, bf16x4 (&wdbp)[FT], bf16x4 (&wbp)[DUAL ? FT : 1],
+                                                         unsigned short* tdb, unsigned short* tb) {
+    const long long ri = (long long)(va ? ia : 0) * RS + 4 * lk, rj = (long long)(va ? ja : 0) * RS + 4 * lk;
+    const float* __restrict__ hI = A.h + ri;
+    const float* __restrict__ hJ = A.h + rj;
+    const float* __restrict__ pI = A.mdb + ri;
+    const float* __restrict__ pJ = A.mdb + rj;
+    const float* __restrict__ bI = DUAL ? A.mb + ri : nullptr;
+    const float* __restrict__ bJ = DUAL ? A.mb + rj : nullptr;
+    const float* __restrict__ tI = HASHD ? A.hd + ri : nullptr;
+    const float* __restrict__ tJ = HASHD ? A.hd + rj : nullptr;
+#pragma unroll
+    for (int q0 = 0; q0 < FT; q0 += QB) {
+        float4 hi[QB], hj[QB], pi[QB], pj[QB], bi[DUAL ? QB : 1], bj[DUAL ? QB : 1], ti[HASHD ? QB : 1], tj[HASHD ? QB : 1];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int fc = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
+            hi[u] = *reinterpret_cast<const float4*>(hI + fc);
+            hj[u] = *reinterpret_cast<const float4*>(hJ + fc);
+            pi[u] = *reinterpret_cast<const float4*>(pI + fc);
+            pj[u] = *reinterpret_cast<const float4*>(pJ + fc);
+            if (DUAL) {
+                bi[u] = *reinterpret_cast<const float4*>(bI + fc);
+                bj[u] = *reinterpret_cast<const float4*>(bJ + fc);
+            }
+            if (HASHD) {
+                ti[u] = *reinterpret_cast<const float4*>(tI + fc);
+                tj[u] = *reinterpret_cast<const float4*>(tJ + fc);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // the batch's loads stay together, ahead of its products
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int q = q0 + u;
+            const bool ok = va && 16 * q + 4 * lk + 4 <= F;
+            const bf16x4 zero4 = {0, 0, 0, 0};
+            const bf16x4 a = pack4(pi[u].x * hj[u].x + pj[u].x * hi[u].x, pi[u].y * hj[u].y + pj[u].y * hi[u].y,
+                                   pi[u].z * hj[u].z + pj[u].z * hi[u].z, pi[u].w * hj[u].w + pj[u].w * hi[u].w);
+            wdbp[q] = ok ? a : zero4;
+            if (TILE) *reinterpret_cast<bf16x4*>(&tdb[li * SWB + 16 * q + 4 * lk]) = wdbp[q];
+            if (DUAL) {
+                float4 w = {bi[u].x * hj[u].x + bj[u].x * hi[u].x, bi[u].y * hj[u].y + bj[u].y * hi[u].y,
+                            bi[u].z * hj[u].z + bj[u].z * hi[u].z, bi[u].w * hj[u].w + bj[u].w * hi[u].w};
+                if (HASHD) {
+                    w.x += pi[u].x * tj[u].x + pj[u].x * ti[u].x; w.y += pi[u].y * tj[u].y + pj[u].y * ti[u].y;
+                    w.z += pi[u].z * tj[u].z + pj[u].z * ti[u].z; w.w += pi[u].w * tj[u].w + pj[u].w * ti[u].w;
+                }
+                const bf16x4 b = pack4(w.x, w.y, w.z, w.w);
+                wbp[q] = ok ? b : zero4;
+                if (TILE) *reinterpret_cast<bf16x4*>(&tb[li * SWB + 16 * q + 4 * lk]) = wbp[q];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 template <int GP, int FT, bool DUAL, bool THETA>
-// (asking the allocator for more waves per SIMD was measured and dropped here: 3 waves for the dual sweep spills 38 dwords and
-//  runs 164 -> 240 us; 2 waves for dual + theta spills 45 and changes nothing)
-__global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
+// (waves per SIMD: round 3 measured more waves as a loss -- with each k-block's gathers behind a divergent branch the sweep
+//  made 8-16 dependent round trips per tile whatever the occupancy, and the registers a second wave needed were spilled.  With
+//  the batched unconditional gathers of gather_adjoint_rows_bf16 the state fits two waves: LDS allows three workgroups per CU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (THETA ? 2 : (DUAL ? 2 : 3)) : 1)))
+void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                                  // bf16 row stride of the W1 copies (16-B aligned rows)
     constexpr int FS = FP + 8;                                   // bf16 row stride of the W2 copy
     constexpr int SA = GP + 4;                                   // f32 scratch stride (rows 16-B aligned)
-    constexpr int SW = FP + 4;                                   // tile stride: 4 mod 32, rows 16-B aligned
+    constexpr int SW = FP + 4;                                   // f32 words of the per-wave scratch per tile row (THETA)
+    constexpr int SWB = FP + 4;                                  // bf16 tile stride (elements): rows 8-B aligned, 4 rows = 32 B mod 128
     constexpr int KB = GP / 32, NT = GP / 16;
-    constexpr int WSZ = THETA ? 16 * SW : 16 * SA;               // per-wave scratch (tile / transposes), floats
+    constexpr int WSZ = THETA ? 16 * SW : 16 * SA;               // per-wave scratch (two bf16 tiles / transposes), floats
     static_assert(!THETA || DUAL, "parameter gradients come from the dual sweep");
     static_assert(!THETA || SW >= SA, "the tile scratch also serves the transposes");
+    static_assert(2 * SWB * 2 <= SW * 4, "two bf16 tiles fit the scratch of one f32 tile");
     float* mus = sm;
     float* cfs = mus + GP;
     float* c2s = cfs + GP;
@@ -939,7 +1103,7 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     unsigned short* w1b = reinterpret_cast<unsigned short*>(wsc + 4 * WSZ);   // [GP j][KSB]  W1[j][k]: B of a = g W1^T
     unsigned short* w1nb = w1b + GP * KSB;                       // [GP n][KSB]  W1[j][n]: B of g_b = a_b W1  (k = j)
     unsigned short* w2g = w1nb + GP * KSB;                       // [GP k][FS]   W2[f][k]: B of s_b = W_b W2  (k = f)
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index: uniform)
     const int G = A.net.G, F = A.net.F, RS = A.net.RS;
     for (int t = tid; t < GP * GP; t += 256) {
         const int j = t / GP, c = t % GP;
@@ -986,50 +1150,25 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     const long long ntiles = (nrows + 63) / 64;
     int t_begin, t_end, t_step;
     xcd_sweep((int)ntiles, 1, t_begin, t_end, t_step);           // the half list is sorted by atom: same locality argument
+    const bool has_hd = A.hd != nullptr;                          // (wave-uniform: the first block's node rows have no tangent)
+    EdgeIdx nx = load_edge_idx<DUAL>(A, (long long)t_begin * 64 + wid * 16 + li);
     for (long long tile = t_begin; tile < t_end; tile += t_step) {
         const long long e0 = tile * 64 + wid * 16;
-        // ---- A-layout row: edge e0 + li
-        const long long ea = e0 + li;
-        long long ia = -1, ja = -1;
-        if (ea < A.E) { ia = A.nbr[2 * ea]; ja = A.nbr[2 * ea + 1]; }
-        const float draw = ia >= 0 ? A.d[ea] : -1.f;             // (-1: padding row of a fixed-capacity list)
-        const bool va = draw >= 0.f;                              // (d = -1: a pair of a stored list that is beyond the cutoff now)
+        // ---- A-layout row: edge e0 + li (indices, distance and tangent were requested a tile ahead)
+        const EdgeIdx cur = nx;
+        if (tile + t_step < t_end) nx = load_edge_idx<DUAL>(A, (tile + t_step) * 64 + wid * 16 + li);
+        const int ia = cur.i, ja = cur.j;
+        const bool va = cur.d >= 0.f;                             // (-1: padding row, or a pair of a stored list beyond the cutoff now)
         if (__ballot(va) == 0ull) continue;                       // a wave's 16 rows all padding / past the end: nothing to add
-        const float da = va ? draw : PAD_D;
-        float dda = 0.f;
-        if (DUAL) dda = va ? A.dd[ea] : 0.f;
+        const float da = va ? cur.d : PAD_D;
+        const float dda = (DUAL && va) ? cur.dd : 0.f;
         // ---- adjoint rows of the filter output as A fragments (k-step 4 q + c <-> filter 16 q + 4 lk + c)
-        float wdb[4 * FT], wb[DUAL ? 4 * FT : 1];
-#pragma unroll
-        for (int q = 0; q < FT; ++q) {
-            const int f0 = 16 * q + 4 * lk;
-            float4 hi = {0.f, 0.f, 0.f, 0.f}, hj = hi, pi = hi, pj = hi;
-            const bool ok = va && f0 + 4 <= F;
-            if (ok) {
-                hi = *reinterpret_cast<const float4*>(A.h + ia * RS + f0);
-                hj = *reinterpret_cast<const float4*>(A.h + ja * RS + f0);
-                pi = *reinterpret_cast<const float4*>(A.mdb + ia * RS + f0);
-                pj = *reinterpret_cast<const float4*>(A.mdb + ja * RS + f0);
-            }
-            wdb[4 * q] = pi.x * hj.x + pj.x * hi.x; wdb[4 * q + 1] = pi.y * hj.y + pj.y * hi.y;
-            wdb[4 * q + 2] = pi.z * hj.z + pj.z * hi.z; wdb[4 * q + 3] = pi.w * hj.w + pj.w * hi.w;
-            if (DUAL) {
-                float4 bi = {0.f, 0.f, 0.f, 0.f}, bj = bi;
-                if (ok) {
-                    bi = *reinterpret_cast<const float4*>(A.mb + ia * RS + f0);
-                    bj = *reinterpret_cast<const float4*>(A.mb + ja * RS + f0);
-                }
-                float4 w = {bi.x * hj.x + bj.x * hi.x, bi.y * hj.y + bj.y * hi.y, bi.z * hj.z + bj.z * hi.z,
-                            bi.w * hj.w + bj.w * hi.w};
-                if (A.hd != nullptr && ok) {
-                    const float4 ti = *reinterpret_cast<const float4*>(A.hd + ia * RS + f0);
-                    const float4 tj = *reinterpret_cast<const float4*>(A.hd + ja * RS + f0);
-                    w.x += pi.x * tj.x + pj.x * ti.x; w.y += pi.y * tj.y + pj.y * ti.y;
-                    w.z += pi.z * tj.z + pj.z * ti.z; w.w += pi.w * tj.w + pj.w * ti.w;
-                }
-                wb[4 * q] = w.x; wb[4 * q + 1] = w.y; wb[4 * q + 2] = w.z; wb[4 * q + 3] = w.w;
-            }
-        }
+        bf16x4 wdbp[FT], wbp[DUAL ? FT : 1];
+        unsigned short* tdb = reinterpret_cast<unsigned short*>(ws);      // THETA: [16 edges][SWB] Wdb and, behind it, Wb
+        unsigned short* tb = tdb + 16 * SWB;
+        constexpr int QB = DUAL ? (THETA ? 2 : 4) : FT;          // k-blocks gathered per round trip (registers in flight)
+        if (DUAL && has_hd) gather_adjoint_rows_bf16<FT, QB, SWB, DUAL, true, THETA>(A, ia, ja, va, li, lk, F, RS, wdbp, wbp, tdb, tb);
+        else gather_adjoint_rows_bf16<FT, QB, SWB, DUAL, false, THETA>(A, ia, ja, va, li, lk, F, RS, wdbp, wbp, tdb, tb);
         // ---- recompute layer 1: a = g W1^T + b1 (and its tangent) in the accumulator layout
         float sg[NT][4], qd[DUAL ? NT : 1][4], sc[THETA ? NT : 1][4], sdc[THETA ? NT : 1][4];
         {
@@ -1079,17 +1218,14 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
             }
 #pragma unroll
             for (int pass = 0; pass < 2; ++pass) {
-#pragma unroll
-                for (int q = 0; q < FT; ++q)
-                    *reinterpret_cast<float4*>(&ws[li * SW + 16 * q + 4 * lk]) =
-                        pass == 0 ? make_float4(wdb[4 * q], wdb[4 * q + 1], wdb[4 * q + 2], wdb[4 * q + 3])
-                                  : make_float4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+                const unsigned short* tl = pass == 0 ? tdb : tb;            // (written by the gather; same wave: program order)
 #pragma unroll
                 for (int mt = 0; mt < FT; ++mt) {
-                    float at[4];
+                    unsigned int at[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) at[r] = ws[(4 * lk + r) * SW + mt * 16 + li];
-                    const bf16x4 ap = pack4(at[0], at[1], at[2], at[3]);     // A[f][e = 4 lk + c]
+                    for (int r = 0; r < 4; ++r) at[r] = tl[(4 * lk + r) * SWB + mt * 16 + li];
+                    const u32x2v apu = {at[0] | (at[1] << 16), at[2] | (at[3] << 16)};
+                    const bf16x4 ap = __builtin_bit_cast(bf16x4, apu);      // A[f][e = 4 lk + c]
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
                         gW2[mt][nt] = MFMA16(ap, pass == 0 ? sdp[nt] : scp[nt], gW2[mt][nt]);
@@ -1097,12 +1233,6 @@ __global__ __launch_bounds__(256) void cfconv_bwd_bf16_kernel(const BwdArgs A) {
             }
         }
         // ---- s_db = Wdb W2, s_b = Wb W2   ([16 x F] x [F x G])
-        bf16x4 wdbp[FT], wbp[DUAL ? FT : 1];
-#pragma unroll
-        for (int q = 0; q < FT; ++q) {
-            wdbp[q] = pack4(wdb[4 * q], wdb[4 * q + 1], wdb[4 * q + 2], wdb[4 * q + 3]);
-            if (DUAL) wbp[q] = pack4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
-        }
         f32x4 sdb[NT], sb[DUAL ? NT : 1];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -1504,6 +1634,7 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(d && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd: bad arguments");
     const bool tangent = dd != nullptr;
     MDG_CHECK_ARG(!tangent || md, "cfconv_fwd: the tangent sweep needs md");
+    MDG_CHECK_ARG((long long)n_atoms * net->n_filters < (1LL << 30), "cfconv_fwd: n_atoms x n_filters must stay below 2^30");
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd: tangent buffers without dd");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd: node feature matrices must be 16-byte aligned");
@@ -1544,6 +1675,7 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     MDG_CHECK_ARG(d && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd_bf16: bad arguments");
     const bool tangent = dd != nullptr;
     MDG_CHECK_ARG(!tangent || md, "cfconv_fwd_bf16: the tangent sweep needs md");
+    MDG_CHECK_ARG((long long)n_atoms * net->n_filters < (1LL << 30), "cfconv_fwd_bf16: n_atoms x n_filters must stay below 2^30");
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd_bf16: tangent buffers without dd");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd_bf16: node feature matrices must be 16-byte aligned");
@@ -1608,8 +1740,8 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
     MDG_CHECK_ARG(!dual || (dd && d_b), "cfconv_bwd: the dual sweep needs dd and d_b");
     MDG_CHECK_ARG(dual || !hd, "cfconv_bwd: hd without the dual sweep");
     MDG_CHECK_ARG(!theta || workspace, "cfconv_bwd: workspace missing");
-    MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb),
-                  "cfconv_bwd: node feature matrices must be 16-byte aligned");
+    MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb) && aligned16(nbr),
+                  "cfconv_bwd: node feature matrices and the pair list must be 16-byte aligned");
     const long long tiles64 = (n_edges + 63) / 64;
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
     BwdArgs a{dev_of(net, f0), d, dd, nbr, (long long)n_edges, at_col(h, f0), at_col(hd, f0), at_col(mb, f0), at_col(mdb, f0),

@@ -56,6 +56,9 @@ def main():
         ("cfconv_bwd plain", lambda: ops.cfconv_bwd(fn, d, None, topo, h, None, None, mdb, None, dd_b), ((E + 15) // 16) * 96),
         ("cfconv_bwd dual", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, hd, mb, mdb, d_b, dd_b), ((E + 15) // 16) * 192),
         ("cfconv_bwd dual+theta", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, True), ((E + 15) // 16) * 352),
+        ("cfconv_fwd primal+tangent (no hd)", lambda: ops.cfconv_fwd(fn, d, dd, h, None, topo), tiles * 160),
+        ("cfconv_bwd dual (no hd)", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, None, mb, mdb, d_b, dd_b), ((E + 15) // 16) * 192),
+        ("cfconv_bwd dual+theta (no hd)", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, None, mb, mdb, d_b, dd_b, True), ((E + 15) // 16) * 352),
         ("dense A->F dual", lambda: ops.dense(Wn, r, bias=bn, x1=rd), 0),
         ("dense F->A ssp dual", lambda: ops.dense(U1, h, bias=c1, act=True, x1=hd, want_sig=True), 0),
         ("edge_geom (tangent)", lambda: ops.edge_geom(x, topo, w), 0),
@@ -75,7 +78,7 @@ def main():
         if mfma and not args.bf16:
             tf = mfma * 2048.0 / (ms * 1e-3) / 1e12
             extra = "  %6.1f TFLOP/s executed MFMA = %.0f%% of 157.3" % (tf, 100 * tf / 157.3)
-        print("%-28s %8.1f us%s" % (name, ms * 1e3, extra), flush=True)
+        print("%-34s %8.1f us%s" % (name, ms * 1e3, extra), flush=True)
 
 
 if __name__ == "__main__":
