@@ -624,6 +624,28 @@ int mdg_nhv_adj_end(const float* vh, const float* pm, const float* lvh, const fl
                     const float* g_q, const float* g_pv, int n_rep, int n_atoms, int n_chains, float* lv, float* lq,
                     float* lp, float* scratch, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * f4  bonded terms over a static topology table (csrc/bonded.hip).
+ * Replaces torchmd/interface.py:447-455 (BondPotentials.forward: harmonic in the SQUARED bond length,
+ * 1/2 k (|b|^2 - ro)^2) and :496-508 (AnglePotentials.forward: 1/2 k (theta - theta0)^2 over triples (i, j, k) centred on
+ * j), their image flags topology.get_offsets (topology.py:75-80: -[b >= L/2] + [b < -L/2], L = cell.diag()), the autograd
+ * force behind them (torchmd/md.py:228-230) and the double-backward Hessian-vector product of the adjoint
+ * (torchmd/sovlers.py:229-233) -- one launch, no atomics.
+ *   kind      MDG_BONDED_BOND: top = int32 [n_terms, 2], x0 = ro ;  MDG_BONDED_ANGLE: top = int32 [n_terms, 3], x0 = theta0
+ *   cell_len  host float[3], the diagonal of the cell
+ *   inc_ptr   int32 [n_atoms + 1], inc int32 [sum of roles]: the incidence list of every atom, entries 4 * term + role
+ *             (role = the atom's column in `top`), ascending per atom -- the order the per-atom sums run in
+ *   w         nullable [n_atoms, 3]; required for hw
+ *   e_atom    nullable [n_atoms]: energy of the terms whose FIRST atom this is (sum = U)
+ *   grad, hw  nullable [n_atoms, 3]:  grad = (accumulate ? grad : 0) + out_scale * dU/dx ,  hw likewise with H w
+ *             (out_scale = -1: the force and d(w.F)/dx, added onto another Stack member's buffers when accumulate != 0)
+ */
+#define MDG_BONDED_BOND 0
+#define MDG_BONDED_ANGLE 1
+int mdg_bonded_eval(const float* pos, int n_atoms, const float* cell_len /*host*/, int kind, const int32_t* top, int n_terms,
+                    float k, float x0, const int32_t* inc_ptr, const int32_t* inc, const float* w, float* e_atom,
+                    float* grad, float* hw, float out_scale, int accumulate, void* stream);
+
 
 #ifdef __cplusplus
 }

@@ -167,6 +167,8 @@ _SIGNATURES = {
     "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
+    "mdg_bonded_eval": (C.c_int, [P, C.c_int, C.POINTER(C.c_float), C.c_int, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P,
+                                  C.c_float, C.c_int, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

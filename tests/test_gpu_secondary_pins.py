@@ -215,9 +215,11 @@ def _run_schnet_workload(wl, t, stride, replicas=None):
 def _tols(bf16):
     # f32: the tolerances of the 8 x 512-bead test above.  bf16 filter operands (BASELINE config #5): the stated tolerances of
     # tests/test_gpu_config5.py (positions 3e-4 A, g 5e-4, gradients 5e-4 .. 1e-3 of the largest entry + cosine)
+    # g(r): relative to its peak (6.4 here) -- the observable's fine-grid histogram is within 2e-5 per bin of the exact kernel
+    # (observed on MI355X: 1.5e-5 of the peak in f32 and bf16 alike; positions 4e-6 A = one ulp at 50 A)
     if bf16:
-        return dict(q=3e-4, v=(1e-2, 2e-3), pv=(2e-2, 1e-4), g=5e-4, adj=(0.0, 2e-2), th=(0.0, 5e-3), cos=0.9999)
-    return dict(q=2e-5, v=(1e-3, 1e-4), pv=(2e-3, 1e-5), g=1e-4, adj=(5e-3, 2e-3), th=(5e-3, 5e-4), cos=0.999999)
+        return dict(q=3e-4, v=(1e-2, 2e-3), pv=(2e-2, 1e-4), g=1e-4, adj=(0.0, 2e-2), th=(0.0, 5e-3), cos=0.9999)
+    return dict(q=2e-5, v=(1e-3, 1e-4), pv=(2e-3, 1e-5), g=5e-5, adj=(5e-3, 2e-3), th=(5e-3, 5e-4), cos=0.999999)
 
 
 def _check_replica(out, r, ref, tol, tag):
@@ -225,7 +227,7 @@ def _check_replica(out, r, ref, tol, tag):
     close(out["q"][:, r], traj[1], 0, tol["q"], tag + " q_t")
     close(out["v"][:, r], traj[0], tol["v"][0], tol["v"][1] * float(traj[0].abs().max()), tag + " v_t")
     close(out["pv"][:, r], traj[2], tol["pv"][0], tol["pv"][1], tag + " pv_t")
-    close(out["g"][r], g, 0, tol["g"], tag + " g(r)")
+    close(out["g"][r], g, 0, tol["g"] * float(g.abs().max()), tag + " g(r)")
     close(out["gq0"][r], lam[1], tol["adj"][0], tol["adj"][1] * float(lam[1].abs().max()), tag + " adj q0")
     close(out["gv0"][r], lam[0], tol["adj"][0], tol["adj"][1] * float(lam[0].abs().max()), tag + " adj v0")
 
