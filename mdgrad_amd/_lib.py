@@ -67,6 +67,7 @@ class MdgChainStage(C.Structure):
 
 
 CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512
+BONDED_BOND, BONDED_ANGLE = 0, 1                 # include/mdgrad_hip.h MDG_BONDED_*
 
 P = C.c_void_p
 _SIGNATURES = {

@@ -449,42 +449,114 @@ class TPairPotentials(PairPotentials):
         return self._phi(compute_dis(xyz, nbr, off, self.cell)).sum()            # interface.py:207-215
 
 
-class BondPotentials(torch.nn.Module):
-    """Harmonic term in the SQUARED bond length, 1/2 k (|b|^2 - ro)^2 (torchmd/interface.py:406-456; the
-    polymer demo's bonded term).  `top` = [n_bonds, 2] atom indices; orthorhombic minimum image with the
-    non-strict test of topology.get_offsets.  A few torch ops on the device (outside the pair hot path)."""
+class _BondedTerm(torch.nn.Module):
+    """Common part of BondPotentials / AnglePotentials: the static topology table on the device and the analytic-adjoint
+    protocol (force / force_vjp) on mdg_bonded_eval (csrc/bonded.hip) -- one launch for energy, force and the
+    Hessian-vector product, so a polymer Stack(pair + bond [+ angle] [+ GNN]) (demo/fold.py:131-161) keeps the analytic
+    adjoint and HIP-graph replay instead of the reference's double backward.  No trainable parameters (k, ro / thetao are
+    plain numbers in the reference); given as tensors that require grad they switch the term to the reference's torch
+    ops so that autograd reaches them."""
 
-    def __init__(self, system, top, k, ro):
+    _kind = None
+    accepts_into = True
+    accepts_accum = True
+    analytic = True
+
+    def __init__(self, system, top):
         super().__init__()
+        self.system = system
         self.device = system.device
-        self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)
-        self.k, self.ro = k, ro
+        self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)      # interface.py:429-431
         self.top = top.to(self.device)
+        self._n_atoms = system.get_number_of_atoms()
+        self._table = None
 
-    def _reset_topology(self, xyz):
-        pass
+    def _consts(self):
+        raise NotImplementedError
+
+    def _hip_ok(self):
+        return self.analytic and not any(torch.is_tensor(c) and c.requires_grad for c in self._consts())
+
+    def table(self):
+        k, x0 = [float(c) for c in self._consts()]
+        t = self._table
+        if t is None or t.k != k or t.x0 != x0:
+            t = self._table = ops.BondedTable(self._kind, self.top, self._n_atoms, self.cell.detach().cpu().tolist(), k, x0,
+                                              self.device)
+        return t
+
+    def _reset_topology(self, xyz):          # (static table; absent for AnglePotentials in the reference, which therefore
+        pass                                 #  cannot be a member of a Stack there)
+
+    def _torch_energy(self, xyz):
+        raise NotImplementedError
 
     def forward(self, xyz):
+        if self._hip_ok():
+            return ops.BondedEnergyFn.apply(xyz.contiguous(), self.table())
+        return self._torch_energy(xyz)
+
+    # -- analytic-adjoint protocol (md._EOM.rhs_vjp, Stack.force / force_vjp) -------------------------------------
+    def supports_force_vjp(self):
+        return self._hip_ok()
+
+    def force(self, xyz, into=None):
+        o = ops.bonded_eval(self.table(), xyz.detach(), into=None if into is None else (into, None), scale=-1.0)
+        return o["grad"]
+
+    def force_vjp(self, xyz, w, want_theta=True, accum=None, into=None):
+        """(F, d(w.F)/dx, []) -- the term has no parameters."""
+        o = ops.bonded_eval(self.table(), xyz.detach(), w=w.detach(), into=into, scale=-1.0)
+        return o["grad"], o["hw"], ([] if (want_theta and accum is None) else None)
+
+    # -- fixed-capacity topology (HIP-graph capture): the table is static, nothing can overflow ------------------
+    def supports_static_topology(self):
+        return self._hip_ok()
+
+    def set_static_topology(self, on=True):
+        self.table()
+
+    def static_overflow(self):
+        return False
+
+    def static_version(self):
+        return 0
+
+
+class BondPotentials(_BondedTerm):
+    """Harmonic term in the SQUARED bond length, 1/2 k (|b|^2 - ro)^2 (torchmd/interface.py:406-456; the polymer demo's
+    bonded term, demo/fold.py:131).  `top` = [n_bonds, 2] atom indices; orthorhombic minimum image with the non-strict
+    test of topology.get_offsets (topology.py:75-80)."""
+
+    _kind = _lib.BONDED_BOND
+
+    def __init__(self, system, top, k, ro):
+        super().__init__(system, top)
+        self.k, self.ro = k, ro
+
+    def _consts(self):
+        return self.k, self.ro
+
+    def _torch_energy(self, xyz):
         b = xyz[self.top[:, 0]] - xyz[self.top[:, 1]]
         b = b + get_offsets(b, self.cell, self.device) * self.cell
         return 0.5 * self.k * (b.pow(2).sum(-1) - self.ro).pow(2).sum(-1)
 
 
-class AnglePotentials(torch.nn.Module):
+class AnglePotentials(_BondedTerm):
     """Harmonic angle term 1/2 k (theta - theta0)^2 over triples (i, j, k) centred on j
     (torchmd/interface.py:457-510)."""
 
+    _kind = _lib.BONDED_ANGLE
+
     def __init__(self, system, top, k, thetao):
-        super().__init__()
-        self.device = system.device
-        self.cell = torch.Tensor(system.get_cell()).diag().to(self.device)
+        super().__init__(system, top)
         self.k, self.thetao = k, thetao
-        self.top = top.to(self.device)
 
-    def _reset_topology(self, xyz):          # (absent in the reference, which therefore cannot Stack it)
-        pass
+    def _consts(self):
+        return self.k, self.thetao
 
-    def forward(self, xyz):
+    def _torch_energy(self, xyz):
         b1 = xyz[self.top[:, 0]] - xyz[self.top[:, 1]]
         b2 = xyz[self.top[:, 2]] - xyz[self.top[:, 1]]
         b1 = b1 + get_offsets(b1, self.cell, self.device) * self.cell

@@ -252,6 +252,87 @@ class PairEnergyFn(torch.autograd.Function):
         return gU * g, gtheta, None, None
 
 
+# ----------------------------------------------------------------------------- bonded terms (f4)
+class BondedTable:
+    """Static topology table of a bonded term for mdg_bonded_eval (csrc/bonded.hip): `top` [n_terms, 2 | 3] atom indices
+    (torchmd/interface.py:406-510) as int32 on the device, plus the incidence list of every atom -- entries
+    4 * term + role, ascending per atom -- built once on the host."""
+
+    def __init__(self, kind, top, n_atoms, cell_len, k, x0, device):
+        import numpy as np
+        width = 2 if kind == _lib.BONDED_BOND else 3
+        t = torch.as_tensor(top).detach().cpu().numpy().astype(np.int64).reshape(-1, width)
+        if t.size and (t.min() < 0 or t.max() >= n_atoms):
+            raise ValueError("mdgrad_amd: bonded topology refers to atoms outside [0, %d)" % n_atoms)
+        self.kind, self.n_atoms, self.n_terms = int(kind), int(n_atoms), int(t.shape[0])
+        atoms = t.reshape(-1)
+        codes = (4 * np.repeat(np.arange(self.n_terms), width) + np.tile(np.arange(width), self.n_terms)).astype(np.int64)
+        order = np.lexsort((codes, atoms))                       # by atom, then by (term, role)
+        ptr_ = np.zeros(n_atoms + 1, dtype=np.int64)
+        np.add.at(ptr_, atoms + 1, 1)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.top = torch.as_tensor(t.astype(np.int32).copy(), **i32).contiguous()
+        self.inc_ptr = torch.as_tensor(np.cumsum(ptr_).astype(np.int32), **i32)
+        self.inc = torch.as_tensor(codes[order].astype(np.int32), **i32)
+        self.cell_len = (C.c_float * 3)(*[float(x) for x in cell_len])
+        self.k, self.x0 = float(k), float(x0)
+
+
+def bonded_eval(tab, xyz, w=None, energy=False, grad=True, into=None, scale=1.0):
+    """One launch of mdg_bonded_eval -> dict(e_atom, grad, hw).  `into` = (grad buffer, hw buffer or None): the per-atom
+    outputs are ADDED onto them, times `scale` (a Stack member's force without extra launches)."""
+    lib = _lib.load()
+    require_gpu(xyz, "xyz")
+    if xyz.shape != (tab.n_atoms, 3):
+        raise ValueError("mdgrad_amd: xyz must be [%d, 3] (got %s)" % (tab.n_atoms, tuple(xyz.shape)))
+    xyz = xyz.contiguous()
+    dev, N = xyz.device, tab.n_atoms
+    acc = into is not None
+    e = torch.empty(N, device=dev) if energy else None
+    g = (into[0] if acc else torch.empty(N, 3, device=dev)) if grad else None
+    hw = None
+    if w is not None:
+        require_gpu(w, "w")
+        w = w.contiguous()
+        hw = into[1] if acc else torch.empty(N, 3, device=dev)
+    check(lib.mdg_bonded_eval(ptr(xyz), N, tab.cell_len, tab.kind, ptr(tab.top), tab.n_terms, tab.k, tab.x0, ptr(tab.inc_ptr),
+                              ptr(tab.inc), ptr(w), ptr(e), ptr(g), ptr(hw), float(scale), int(acc), stream_ptr(dev)),
+          "mdg_bonded_eval")
+    return dict(e_atom=e, grad=g, hw=hw)
+
+
+class BondedGradFn(torch.autograd.Function):
+    """dU/dx of a bonded term as a differentiable op; backward = the Hessian-vector product (the second autograd pass of
+    torchmd/sovlers.py:229-233)."""
+
+    @staticmethod
+    def forward(ctx, xyz, tab, cache):
+        ctx.tab = tab
+        ctx.save_for_backward(xyz)
+        return cache if cache is not None else bonded_eval(tab, xyz)["grad"]
+
+    @staticmethod
+    def backward(ctx, wg):
+        (xyz,) = ctx.saved_tensors
+        return bonded_eval(ctx.tab, xyz, w=wg.detach().contiguous(), grad=False)["hw"], None, None
+
+
+class BondedEnergyFn(torch.autograd.Function):
+    """U(x) of a bonded term (torchmd/interface.py:447-455, 496-508), differentiable twice."""
+
+    @staticmethod
+    def forward(ctx, xyz, tab):
+        o = bonded_eval(tab, xyz, energy=True, grad=True)
+        ctx.tab, ctx.cache = tab, o["grad"]
+        ctx.save_for_backward(xyz)
+        return o["e_atom"].sum()
+
+    @staticmethod
+    def backward(ctx, gU):
+        (xyz,) = ctx.saved_tensors
+        return gU * BondedGradFn.apply(xyz, ctx.tab, ctx.cache), None
+
+
 # ----------------------------------------------------------------------------- fused trajectories
 class FusedSpec:
     """Host-side descriptor of a fusable integrator (NoseHooverChain / NVE over built-in pair

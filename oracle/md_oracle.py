@@ -12,7 +12,8 @@ import numpy as np
 import torch
 
 __all__ = [
-    "cell_matrix", "nbr_list", "compute_dis", "pair_phi", "PairTerm", "ModelOracle",
+    "cell_matrix", "nbr_list", "compute_dis", "pair_phi", "PairTerm", "ModelOracle", "BondTerm", "AngleTerm",
+    "get_offsets_oracle",
     "NHCOracle", "NVEOracle", "odeint_oracle", "adjoint_oracle", "rdf_oracle", "rdf_raw_oracle",
     "rdf_normalise_oracle", "vacf_oracle", "temperature_oracle",
     "vol_bins_oracle", "wrap_positions_oracle", "fcc_lattice", "diamond_lattice",
@@ -205,6 +206,64 @@ class PairTerm:
         dth = (torch.stack([-(x * a).sum() for x in ddu_dth]) if ddu_dth
                else torch.zeros(0, dtype=q.dtype))
         return F, dq, dth
+
+
+def get_offsets_oracle(vecs, cell_len):
+    """topology.get_offsets (torchmd/topology.py:75-80): -[b >= L/2] + [b < -L/2] -- NON-strict on the upper side,
+    unlike the neighbour list's test (:60-61)."""
+    return -(vecs >= 0.5 * cell_len).to(vecs) + (vecs < -0.5 * cell_len).to(vecs)
+
+
+class _BondedTerm:
+    """A bonded term over a static topology table as an oracle term: no neighbour list, no parameters; force and the
+    vjp d(w.F)/dq by autograd on the restated energy (double backward, like the reference at sovlers.py:229-233)."""
+
+    n_theta = 0
+
+    def __init__(self, top, k, x0, cell):
+        self.top = torch.as_tensor(top, dtype=torch.long)
+        self.k, self.x0 = float(k), float(x0)
+        c = torch.as_tensor(cell, dtype=torch.float32)
+        self.cell_len = torch.diag(c) if c.dim() == 2 else c        # interface.py:429-431: cell.diag()
+
+    def reset(self, q):                                             # interface.py:439-440: pass
+        pass
+
+    def force(self, q):
+        with torch.enable_grad():
+            x = q.detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(self.energy(x), x)
+        return -g
+
+    def force_vjp(self, q, w):
+        with torch.enable_grad():
+            x = q.detach().requires_grad_(True)
+            (g,) = torch.autograd.grad(self.energy(x), x, create_graph=True)
+            (dq,) = torch.autograd.grad((w.detach() * (-g)).sum(), x)
+        return (-g).detach(), dq.detach(), torch.zeros(0, dtype=q.dtype)
+
+
+class BondTerm(_BondedTerm):
+    """BondPotentials (torchmd/interface.py:406-456): 1/2 k (|b|^2 - ro)^2 -- harmonic in the SQUARED length."""
+
+    def energy(self, q):
+        L = self.cell_len.to(q)
+        b = q[self.top[:, 0]] - q[self.top[:, 1]]                   # :447
+        b = b + get_offsets_oracle(b, L) * L                        # :448-449
+        return 0.5 * self.k * (b.pow(2).sum(-1) - self.x0).pow(2).sum(-1)   # :450-453
+
+
+class AngleTerm(_BondedTerm):
+    """AnglePotentials (torchmd/interface.py:457-510): 1/2 k (theta - theta0)^2, triples (i, j, k) centred on j."""
+
+    def energy(self, q):
+        L = self.cell_len.to(q)
+        b1 = q[self.top[:, 0]] - q[self.top[:, 1]]                  # :496
+        b2 = q[self.top[:, 2]] - q[self.top[:, 1]]                  # :497
+        b1 = b1 + get_offsets_oracle(b1, L) * L
+        b2 = b2 + get_offsets_oracle(b2, L) * L
+        cos = (b1 * b2).sum(-1) / (b1.pow(2).sum(-1) * b2.pow(2).sum(-1)).sqrt()   # :500-503
+        return 0.5 * self.k * (torch.acos(cos) - self.x0).pow(2).sum(-1)           # :505-507
 
 
 class ModelOracle:

@@ -24,6 +24,9 @@ Golden sets:
   G15 schnet_cg64_wide   SchNet A64/F128/G30/2 conv (config #5 widths): U, F, H.w, d(w.F)/dtheta
   G16 vacf_temp          vacf / Temperature observables      torchmd/observable.py:153-163, thermo.py:57-66
   G17 schnet_cg64_a256   SchNet A256/F256/G41/2 conv (wide search-space setting): U, F, H.w, d(w.F)/dtheta
+  G18 bonded_hvp, fold_traj   f4 in the adjoint: H.w of the bonded terms; the polymer Stack of demo/fold.py:131-161
+                                             (GNN + BondPotentials + ExcludedVolume with the bonded pairs excluded) and
+                                             Stack(pair + bond): NHC trajectory + adjoint      torchmd/interface.py:406-510
   G11 pair_mlp  pairMLP / TpairMLP energies, forces, Stack(pairMLP + LJFamily) NHC trajectory + adjoint
                                              torchmd/potentials.py:163-217, interface.py:139-215
 """
@@ -601,6 +604,86 @@ def g12():
     save("bonded", **out)
 
 
+# ------------------------------------------------------------------ G18
+def g18():
+    """f4 in the adjoint.  (a) bonded_hvp: H.w of BondPotentials / AnglePotentials by double autograd --
+    what the reference's adjoint derives at sovlers.py:229-233 -- on the chain of G12.  (b) fold_traj: the polymer Stack of
+    demo/fold.py:131-161 -- {'gnn': GNNPotentials, 'prior': BondPotentials, 'pair': ExcludedVolume(power 10, cutoff 2.5) with the
+    bonded pairs excluded} -- and the same without the GNN, NoseHooverChain(Q = 50, 5 chains) trajectory + adjoint.
+    (AnglePotentials has no _reset_topology in the reference and cannot be a Stack member there: its golden is (a).)"""
+    rng = np.random.default_rng(7)
+    n, L = 24, 6.0
+    steps = rng.normal(0, 1, (n, 3))
+    steps = 1.1 * steps / np.linalg.norm(steps, axis=1)[:, None]
+    pos = np.mod(np.cumsum(steps, 0) + 2.5, L).astype(F32).astype(np.float64)
+    cell = np.array([L, L, L])
+    bonds = torch.LongTensor([[i, i + 1] for i in range(n - 1)])
+    angles = torch.LongTensor([[i, i + 1, i + 2] for i in range(n - 2)])
+    system = make_system(pos, cell)
+    rng = np.random.default_rng(18)
+    w = rng.normal(0, 1, pos.shape).astype(F32)
+    out = dict(pos=pos.astype(F32), cell=cell.astype(F32), bonds=bonds.numpy(), angles=angles.numpy(), w=w,
+               k_bond=3.0, ro=1.21, k_angle=2.0, theta0=1.9)
+    for tag, mod in [("bond", BondPotentials(system, bonds, 3.0, 1.21)), ("angle", AnglePotentials(system, angles, 2.0, 1.9))]:
+        q = torch.Tensor(pos).requires_grad_(True)
+        u = mod(q)
+        (gq,) = torch.autograd.grad(u, q, create_graph=True)
+        (hw,) = torch.autograd.grad((gq * torch.Tensor(w)).sum(), q)
+        out[tag + "_energy"], out[tag + "_force"], out[tag + "_hw"] = u.detach().reshape(1), -gq.detach(), hw
+    save("bonded_hvp", **out)
+
+    # (b) a self-avoiding chain across the periodic boundary: no non-bonded pair closer than 1.0 (the random walk above has
+    # beads on top of each other, fine for the bonded terms alone but not under an excluded-volume term)
+    def min_dist(p, others):
+        d = others - p
+        d -= L * np.round(d / L)
+        return np.sqrt((d ** 2).sum(1)).min()
+    chain = [np.array([2.5, 2.5, 2.5])]
+    while len(chain) < n:
+        st = rng.normal(0, 1, 3)
+        cand = chain[-1] + 1.1 * st / np.linalg.norm(st)
+        if len(chain) < 2 or min_dist(cand, np.array(chain[:-1])) > 1.0:
+            chain.append(cand)
+    pos = np.mod(np.array(chain), L).astype(F32).astype(np.float64)
+    T_, dt, nsteps = 0.5, 0.005, 12
+    masses = np.full(n, 1.008)
+    vel = rng.normal(0, np.sqrt(T_ / 1.008), pos.shape).astype(F32).astype(np.float64)
+    params = {"n_atom_basis": 32, "n_filters": 48, "n_gaussians": 16, "n_convolutions": 2, "cutoff": 2.5,
+              "trainable_gauss": False}
+    out = dict(pos=pos.astype(F32), cell=cell.astype(F32), vel=vel.astype(F32), masses=masses.astype(F32),
+               numbers=np.ones(n, dtype=np.int64), bonds=bonds.numpy(), k_bond=3.0, ro=1.21, T=T_, Q=50.0, chains=5, dt=dt,
+               pair_cutoff=2.5, pair_sigma=0.9, pair_epsilon=0.5, pair_power=10,
+               **{k: v for k, v in params.items() if k != "trainable_gauss"})
+    for tag in ("fold", "pairbond"):
+        system = make_system(pos, cell, numbers=np.ones(n, dtype=np.int64), masses=masses, vel=vel)
+        bond = BondPotentials(system, bonds, 3.0, 1.21)
+        pair_model = P.ExcludedVolume(sigma=0.9, epsilon=0.5, power=10)
+        pair = PairPotentials(system, pair_model, cutoff=2.5, ex_pairs=bonds)        # demo/fold.py:150-155
+        if tag == "fold":
+            torch.manual_seed(18)
+            net = SchNet(params)
+            with torch.no_grad():                      # (random-init SchNet forces are O(100): keep the 12 steps gentle)
+                net.atomwisereadout.readout["energy"][2].weight.mul_(0.05)
+            out.update({"sd__" + k: v.detach().clone() for k, v in net.state_dict().items()})
+            gnn = GNNPotentials(system, net, cutoff=2.5)
+            stack = Stack({"gnn": gnn, "prior": bond, "pair": pair})                 # demo/fold.py:157-161
+        else:
+            stack = Stack({"pair": pair, "bond": bond})
+        integ = NoseHooverChain(stack, system, T=T_, num_chains=5, Q=50.0, adjoint=True)
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        t = torch.Tensor([dt * i for i in range(nsteps + 1)])
+        v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+        loss = q_t[::3].pow(2).mean() * 1e-2 + v_t[-1].pow(2).mean() + pv_t[-1].sum() * 1e-2
+        loss.backward()
+        plist = list(integ.parameters())
+        flatg = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in plist])
+        out.update({tag + "_v_t": v_t.detach(), tag + "_q_t": q_t.detach(), tag + "_pv_t": pv_t.detach(),
+                    tag + "_loss": loss.detach().reshape(1), tag + "_grad_flat": flatg,
+                    tag + "_param_names": np.array([nm for nm, _ in integ.named_parameters()]),
+                    tag + "_grad_q0": y0[1].grad, tag + "_grad_v0": y0[0].grad, tag + "_grad_pv0": y0[2].grad})
+    save("fold_traj", **out)
+
+
 # ------------------------------------------------------------------ G13
 def g13():
     """get_exp_rdf (scripts/data.py:11-31): target g(r) on the observable's grid from tabulated data.
@@ -653,8 +736,8 @@ def g17():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13", "g1415", "g16", "g17"]
+    which = sys.argv[1:] or ["g1", "g2", "g345", "g6", "g7", "g89", "g10", "g11", "g12", "g13", "g1415", "g16", "g17", "g18"]
     table = {"g1": g1, "g2": g2, "g345": g3_g4_g5, "g6": g6, "g7": g7, "g89": g8_g9, "g10": g10, "g11": g11,
-             "g12": g12, "g13": g13, "g1415": g14_g15, "g16": g16, "g17": g17}
+             "g12": g12, "g13": g13, "g1415": g14_g15, "g16": g16, "g17": g17, "g18": g18}
     for w in which:
         table[w]()

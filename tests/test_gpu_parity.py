@@ -952,7 +952,7 @@ def test_bonded_terms_golden():
     q = T(g["pos"], DEV).requires_grad_(True)
     stack._reset_topology(q.detach())
     (gq,) = torch.autograd.grad(stack(q).sum(), q)
-    assert torch.isfinite(gq).all() and not stack.supports_force_vjp()
+    assert torch.isfinite(gq).all() and stack.supports_force_vjp()      # (f4 as kernels: tests/test_gpu_bonded.py)
 
 
 @pytest.mark.parametrize("n_side,large", [(10, False), (25, True)])
