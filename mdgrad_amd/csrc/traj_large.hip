@@ -795,6 +795,7 @@ struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };      // one 
 __device__ __forceinline__ Row3 row3(const float* __restrict__ a, int j) { return *reinterpret_cast<const Row3*>(a + 3 * (size_t)j); }
 
 constexpr int LG_ROW_ATOMS = 16;                 // atoms per workgroup of the listed kernels (4 waves x 4 rows)
+constexpr int LG_ADJ_GROUPS = 4;                 // ... large_adj_listed: groups of four atoms a wave takes one after the other
 
 template <bool DIAG, int KIND>
 __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
@@ -848,6 +849,35 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     const int n = valid ? min(A.nl_cnt[at], LG_LIST) : 0;
     const Row3 qi = row3(q, ic);
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+    if constexpr (KIND == KIND_LJ126 && DIAG) {
+        // two candidates per lane and iteration in packed fp32 (see large_adj_listed)
+        const TermConst& t0 = tc[0];
+        const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
+        const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;
+        const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+        const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+        f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2;
+        int jA = s < n ? jj[0] : ic, jB = s + 16 < n ? jj[1] : ic;
+        Row3 qA = row3(q, jA), qB = row3(q, jB);
+#pragma unroll
+        for (int p = 0; p < NP; p += 2) {
+            if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+            f32x2 dx = f32x2{qA.x, qB.x} - qi.x, dy = f32x2{qA.y, qB.y} - qi.y, dz = f32x2{qA.z, qB.z} - qi.z;
+            if (p + 2 < NP) {
+                jA = s + 16 * (p + 2) < n ? jj[p + 2] : ic; jB = s + 16 * (p + 3) < n ? jj[p + 3] : ic;
+                qA = row3(q, jA); qB = row3(q, jB);
+            }
+            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            const bool ok0 = (d2.x != 0.f) && (d2.x < rc2), ok1 = (d2.y != 0.f) && (d2.y < rc2);
+            const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+            const f32x2 s2 = sig2 * i2;
+            const f32x2 s6 = s2 * s2 * s2;
+            const f32x2 c1 = (m1a * s6 - m1b * (s6 * s6)) * i2;
+            fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;
+        }
+        fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
+    } else {
     int jn = s < n ? jj[0] : ic;
     Row3 qn = row3(q, jn);
 #pragma unroll
@@ -863,6 +893,7 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
         const float d2 = norm2_ref(dx, dy, dz);
         if (d2 == 0.f) continue;
         pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx, gy, gz, th);
+    }
     }
     fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
     float kepart = 0.f;
@@ -1105,7 +1136,7 @@ void large_adj_force(const LargeArgs A, const int second) {
 // The candidates are the stored indices of the build that serves frame A.step; a build that overflowed, or a midpoint
 // that moved past the skin (flagged by large_prep<3>), raises flags[5]: the caller repeats the adjoint with searches
 // (MdgTrajParams.block = -1).
-// Launch: 256 threads = 16 atoms per workgroup, grid (ceil(N / 16), R); A.nbF = ceil(N / 16) rows of partN.
+// Launch: 256 threads = 16 LG_ADJ_GROUPS atoms per workgroup, grid (ceil(N / (16 LG_ADJ_GROUPS)), R) = A.nbF rows of partN.
 template <bool DIAG, int KIND>
 __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const int second) {
     constexpr int NP = LG_LIST / 16;                                   // passes a full row takes
@@ -1121,9 +1152,6 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
     else prepare_terms(A, tc);
     const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
-    const int i = (blockIdx.x * 4 + wid) * 4 + (lane >> 4);
-    const bool valid = i < N;
-    const int ic = valid ? i : N - 1;                                  // (rows past the end read the last atom, count 0)
     const bool nhc = A.prm.ensemble == 0;
     const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
     const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
@@ -1142,6 +1170,19 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
         A.nl_state[2 * rep] = 0; A.nl_state[2 * rep + 1] = 0;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && bad) A.flags[5] = 1;
+    const float* wl = A.wl + so;                                       // w = lam_v / m (NVE: lam_v), written by large_prep<2|3>
+    // A wave takes LG_ADJ_GROUPS consecutive groups of four atoms: the launch-constant part of a wave (term constants, list
+    // selection) and the wave- and workgroup-level reductions of the parameter / kinetic partial sums -- half of the
+    // instructions of a wave that handled ONE group -- are paid once per 16 atoms
+    float vals[NTH + 2];
+#pragma unroll
+    for (int p = 0; p < NTH + 2; ++p) vals[p] = 0.f;
+#pragma unroll 1
+    for (int grp = 0; grp < LG_ADJ_GROUPS; ++grp) {
+    const int i = ((blockIdx.x * 4 + wid) * LG_ADJ_GROUPS + grp) * 4 + (lane >> 4);
+    if (__ballot(i < N) == 0ull) break;                                // (wave-uniform: this wave's groups are through)
+    const bool valid = i < N;
+    const int ic = valid ? i : N - 1;                                  // (rows past the end read the last atom, count 0)
     const size_t at = ((size_t)rep * T + slot) * N + ic;
     // (entry s + 16 p of the row: two 16-bit entries per word, lanes 2t and 2t + 1 read the same word)
     const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
@@ -1149,7 +1190,6 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
 #pragma unroll
     for (int p = 0; p < NP; ++p) jj[p] = (int)((idx[(s >> 1) + 8 * p] >> (16 * (s & 1))) & 0xffffu);
     const int n = (valid && !bad) ? min(A.nl_cnt[at], LG_LIST) : 0;
-    const float* wl = A.wl + so;                                       // w = lam_v / m (NVE: lam_v), written by large_prep<2|3>
     const Row3 qi = row3(q, ic), li = row3(wl, ic);
     const float xi = qi.x, yi = qi.y, zi = qi.z;
     const float mi = A.mass[ic];
@@ -1157,6 +1197,56 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
 #pragma unroll
     for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
+    if constexpr (KIND == KIND_LJ126 && DIAG) {
+        // LJ 12-6 in an orthorhombic cell (BASELINE config #4): TWO candidates per lane and iteration -- entries s + 16 p and
+        // s + 16 (p + 1) of the row -- as the halves of packed fp32 registers (v_pk_fma / mul / add_f32), the arithmetic of
+        // the wave-per-replica kernels (csrc/traj_small.hip force_lj126_packed, traj_ring.hpp): even powers of 1/r from one
+        // v_rcp_f32 per pair, no square root, branch-free (the 1/d^2 of a rejected candidate is selected to 0, so every
+        // term below is exactly 0 for it), the parameter gradients carried as the two sums they are linear in.  The scalar
+        // loop it replaces issued ~180 lane-instructions per accepted pair with the VALU 99 % busy
+        // (profiles/pmc_lj4096.json, round 3).
+        const TermConst& t0 = tc[0];
+        const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
+        const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;                    // phi'/r  = (m1a s6 - m1b s12) / d2
+        const float ka = 48.f * e4 * cq, kb = 168.f * e4;                    // phi'' - phi'/r = (kb s12 - ka s6) / d2
+        const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+        const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+        f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2, gx2 = fx2, gy2 = fx2, gz2 = fx2, S6 = fx2, S12 = fx2;
+        int jA = s < n ? jj[0] : ic, jB = s + 16 < n ? jj[1] : ic;
+        Row3 qA = row3(q, jA), qB = row3(q, jB), lA = row3(wl, jA), lB = row3(wl, jB);
+#pragma unroll
+        for (int p = 0; p < NP; p += 2) {
+            if (p > 0 && __ballot(s + 16 * p < n) == 0) break;        // (wave-uniform: every row is through)
+            f32x2 dx = f32x2{qA.x, qB.x} - xi, dy = f32x2{qA.y, qB.y} - yi, dz = f32x2{qA.z, qB.z} - zi;   // D = x_j - x_i
+            const f32x2 ax = wxi - f32x2{lA.x, lB.x}, ay = wyi - f32x2{lA.y, lB.y}, az = wzi - f32x2{lA.z, lB.z};
+            if (p + 2 < NP) {
+                jA = s + 16 * (p + 2) < n ? jj[p + 2] : ic; jB = s + 16 * (p + 3) < n ? jj[p + 3] : ic;
+                qA = row3(q, jA); qB = row3(q, jB); lA = row3(wl, jA); lB = row3(wl, jB);
+            }
+            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+            const f32x2 d2 = norm2_ref2(dx, dy, dz);
+            const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);             // (idle lanes gathered the atom itself: D = 0)
+            const bool ok1 = (d2.y != 0.f) && (d2.y < rc2);             // topology.py:67
+            const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+            const f32x2 s2 = sig2 * i2;
+            const f32x2 s6 = s2 * s2 * s2;
+            const f32x2 s12 = s6 * s6;
+            const f32x2 c1 = (m1a * s6 - m1b * s12) * i2;
+            fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;           // F_i += (phi'/r) D
+            const f32x2 b = dx * ax + dy * ay + dz * az;
+            const f32x2 bi = b * i2;                                    // (w_ij . D) / d2
+            const f32x2 k2 = (kb * s12 - ka * s6) * (bi * i2);          // (phi'' - phi'/r) (w_ij . D) / d2
+            gx2 += k2 * dx; gx2 += c1 * ax;                             // (opposite sign: negated once below)
+            gy2 += k2 * dy; gy2 += c1 * ay;
+            gz2 += k2 * dz; gz2 += c1 * az;
+            S6 += s6 * bi; S12 += s12 * bi;
+        }
+        fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
+        gx = -(gx2.x + gx2.y); gy = -(gy2.x + gy2.y); gz = -(gz2.x + gz2.y);
+        const float a6 = S6.x + S6.y, a12 = S12.x + S12.y;
+        th[0] = e4 * t0.k2 * (18.f * cq * a6 - 72.f * a12);             // 1/2 d(w.F)/dsigma, this atom's end of its pairs
+        th[1] = 12.f * cq * a6 - 24.f * a12;                            // ... d/depsilon
+    } else {
     // software pipeline over the passes: (position, direction) of pass p + 1 in flight while pass p is evaluated
     int jn = s < n ? jj[0] : ic;
     Row3 qn = row3(q, jn), ln = row3(wl, jn);
@@ -1175,21 +1265,20 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
         if (d2 == 0.f) continue;                                        // the atom itself (idle lanes) -- topology.py:67
         pair_terms<2, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, wxi, wyi, wzi, ax, ay, az, gw, rep, fx, fy, fz, gx, gy, gz, th);
     }
+    }
     fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
     gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);
-    float vals[NTH + 2];
 #pragma unroll
-    for (int p = 0; p < NTH; ++p) vals[p] = th[p];
-    float p1 = 0.f, p2 = 0.f;
+    for (int p = 0; p < NTH; ++p) vals[p] += th[p];
     if (valid && s < 3) {
         const int e = 3 * i + s;
         A.f[so + e] = s == 0 ? fx : (s == 1 ? fy : fz);
         A.dq[so + e] = s == 0 ? gx : (s == 1 ? gy : gz);
         const float pp = vs[e] * mi;
-        p1 = pp * pp / mi;
-        p2 = lam[e] * vs[e];
+        vals[NTH] += pp * pp / mi;
+        vals[NTH + 1] += lam[e] * vs[e];
     }
-    vals[NTH] = p1; vals[NTH + 1] = p2;
+    }                                                                  // groups of this wave
 #pragma unroll
     for (int p = 0; p < NTH + 2; ++p) vals[p] = wave_sum_rows(vals[p]);
     if (lane == 0) {
@@ -1422,15 +1511,16 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
     }
     dim3 gF(nbF, R);
-    if (a.nl_idx) a.nbF = (int)gL.x;                   // (rows of partN the listed launches write, the prep launches sum)
+    const dim3 gLA((N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS), R);
+    if (a.nl_idx) a.nbF = (int)gLA.x;                  // (rows of partN the listed launches write, the prep launches sum)
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
         if (a.nl_idx) {                                                                                             \
-            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gL, dim3(256), 0, st, a, SECOND_);       \
-            else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gL, dim3(256), 0, st, a, SECOND_);            \
-            else hipLaunchKernelGGL((large_adj_listed<false, -1>), gL, dim3(256), 0, st, a, SECOND_);                     \
+            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, st, a, SECOND_);      \
+            else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gLA, dim3(256), 0, st, a, SECOND_);           \
+            else hipLaunchKernelGGL((large_adj_listed<false, -1>), gLA, dim3(256), 0, st, a, SECOND_);                    \
         } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
         else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);    \
         else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);            \
