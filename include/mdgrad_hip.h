@@ -217,6 +217,29 @@ int mdg_traj_adj_small(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
                        const float* g_v, const float* g_q, const float* g_pv,
                        float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
                        void* stream);
+/* The same two launches for integrators with topology_update_freq > 1 (torchmd/md.py:200-204: the lists are rebuilt only
+ * at the calls whose running count is a multiple of the frequency -- the counter advances on EVERY right-hand-side call,
+ * the adjoint's included -- and are stale in between: pair set and image flags frozen at the rebuild positions, no cutoff
+ * re-test, i.e. PairPotentials.forward over self.nbr_list / self.offsets, interface.py:298-300).
+ *   freq     topology_update_freq;  count0 = the integrator's update_count at the launch's first call.  The forward launch
+ *            makes 2 (n_frames - 1) calls (sovlers.py:110-127); the adjoint 3 (n_frames - 1): per interval the dL/dt evaluation
+ *            (sovlers.py:258), the first augmented evaluation at the same state, the midpoint evaluation
+ *   code     uint16 [n_rep][n_atoms][n_atoms] (mdg_traj_stale_words words), persistent across launches like the reference's
+ *            nbr_list / offsets attributes: 0 = no pair, else (term bits << 5) | image code; written at rebuilds
+ * Built-in pair forms (any number of terms, masks, any cell) on the generic one-workgroup-per-replica kernels. */
+int64_t mdg_traj_stale_words(int n_rep, int n_atoms);
+int mdg_traj_fwd_small_stale(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/, const MdgTerms* terms /*host*/,
+                             const float* theta, const float* mass, const float* t_grid,
+                             const float* v0, const float* q0, const float* pv0,
+                             float* v_t, float* q_t, float* pv_t, int32_t* nonfinite,
+                             int freq, int64_t count0, uint16_t* code, void* stream);
+int mdg_traj_adj_small_stale(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/, const MdgTerms* terms /*host*/,
+                             const float* theta, const float* mass, const float* t_grid,
+                             const float* v_t, const float* q_t, const float* pv_t,
+                             const float* g_v, const float* g_q, const float* g_pv,
+                             float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                             int freq, int64_t count0, uint16_t* code, void* stream);
+
 
 /* Fused observable (extension): the radial distribution function of torchmd/observable.py:62-76 evaluated on frames
  * of the trajectory INSIDE the trajectory kernels -- the force sweep already holds every pair distance of a frame, so

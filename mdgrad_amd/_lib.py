@@ -168,6 +168,11 @@ _SIGNATURES = {
     "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
+    "mdg_traj_stale_words": (C.c_int64, [C.c_int, C.c_int]),
+    "mdg_traj_fwd_small_stale": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms), P, P, P, P, P, P,
+                                           P, P, P, P, C.c_int, C.c_int64, P, P]),
+    "mdg_traj_adj_small_stale": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms), P, P, P, P, P, P,
+                                           P, P, P, P, P, P, P, C.c_int, C.c_int64, P, P]),
     "mdg_bonded_eval": (C.c_int, [P, C.c_int, C.POINTER(C.c_float), C.c_int, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P,
                                   C.c_float, C.c_int, P]),
 }

@@ -796,6 +796,7 @@ __device__ __forceinline__ Row3 row3(const float* __restrict__ a, int j) { retur
 
 constexpr int LG_ROW_ATOMS = 16;                 // atoms per workgroup of the listed kernels (4 waves x 4 rows)
 constexpr int LG_ADJ_GROUPS = 4;                 // ... large_adj_listed: groups of four atoms a wave takes one after the other
+constexpr int LG_FWD_GROUPS = 4;                 // ... large_fwd_listed
 
 template <bool DIAG, int KIND>
 __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
@@ -837,7 +838,12 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
     else prepare_terms(A, tc);
     const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
-    const int i = (blockIdx.x * 4 + wid) * 4 + (lane >> 4);
+    // (a wave takes LG_FWD_GROUPS consecutive groups of four atoms: see large_adj_listed)
+    float kepart = 0.f;
+#pragma unroll 1
+    for (int grp = 0; grp < LG_FWD_GROUPS; ++grp) {
+    const int i = ((blockIdx.x * 4 + wid) * LG_FWD_GROUPS + grp) * 4 + (lane >> 4);
+    if (__ballot(i < N) == 0ull) break;
     const bool valid = i < N;
     const int ic = valid ? i : N - 1;
     const size_t at = ((size_t)rep * T + slot) * N + ic;
@@ -857,16 +863,9 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
         const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
         const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
         f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2;
-        int jA = s < n ? jj[0] : ic, jB = s + 16 < n ? jj[1] : ic;
-        Row3 qA = row3(q, jA), qB = row3(q, jB);
-#pragma unroll
-        for (int p = 0; p < NP; p += 2) {
-            if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+        constexpr int NPF = 6;                                         // rows requested up front (see large_adj_listed)
+        auto pair2 = [&](const Row3 qA, const Row3 qB) {
             f32x2 dx = f32x2{qA.x, qB.x} - qi.x, dy = f32x2{qA.y, qB.y} - qi.y, dz = f32x2{qA.z, qB.z} - qi.z;
-            if (p + 2 < NP) {
-                jA = s + 16 * (p + 2) < n ? jj[p + 2] : ic; jB = s + 16 * (p + 3) < n ? jj[p + 3] : ic;
-                qA = row3(q, jA); qB = row3(q, jB);
-            }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
             const bool ok0 = (d2.x != 0.f) && (d2.x < rc2), ok1 = (d2.y != 0.f) && (d2.y < rc2);
@@ -875,6 +874,23 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
             const f32x2 s6 = s2 * s2 * s2;
             const f32x2 c1 = (m1a * s6 - m1b * (s6 * s6)) * i2;
             fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;
+        };
+        {
+            Row3 qv[NPF];
+#pragma unroll
+            for (int p = 0; p < NPF; ++p) qv[p] = row3(q, s + 16 * p < n ? jj[p] : ic);
+#pragma unroll
+            for (int p = 0; p < NPF; p += 2) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+                pair2(qv[p], qv[p + 1]);
+            }
+        }
+        if (__ballot(s + 16 * NPF < n) != 0) {
+            Row3 qv[NP - NPF];
+#pragma unroll
+            for (int p = NPF; p < NP; ++p) qv[p - NPF] = row3(q, s + 16 * p < n ? jj[p] : ic);
+#pragma unroll
+            for (int p = 0; p < NP - NPF; p += 2) pair2(qv[p], qv[p + 1]);
         }
         fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
     } else {
@@ -896,7 +912,6 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     }
     }
     fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
-    float kepart = 0.f;
     if (valid && s < 3) {
         const float F = s == 0 ? fx : (s == 1 ? fy : fz);
         const int e = 3 * i + s;
@@ -911,13 +926,19 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
         A.q_t[fr] = q[e];
         A.v_t[fr] = vn;
         const float pn = vn * m;
-        kepart = pn * pn / m;
+        kepart += pn * pn / m;
         if (!(isfinite(vn) && isfinite(F))) A.flags[1] = 1;
     }
+    }                                                                  // groups of this wave
     kepart = wave_sum_rows(kepart);
     if (lane == 0) red[wid] = kepart;
     __syncthreads();
-    if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    // partA holds A.nbL rows for the listed launches (large_search_rows writes one per 16 atoms): this workgroup's sum goes to
+    // its first row, its other rows are cleared
+    if (threadIdx.x < LG_FWD_GROUPS) {
+        const int row = blockIdx.x * LG_FWD_GROUPS + threadIdx.x;
+        if (row < A.nbL) A.partA[(size_t)rep * A.nbF + row] = threadIdx.x == 0 ? (red[0] + red[1]) + (red[2] + red[3]) : 0.f;
+    }
 }
 
 // The forward force launch that SEARCHES (first frame, and every Verlet rebuild) in a binned box with kept lists: the
@@ -1212,17 +1233,14 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
         const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
         const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
         f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2, gx2 = fx2, gy2 = fx2, gz2 = fx2, S6 = fx2, S12 = fx2;
-        int jA = s < n ? jj[0] : ic, jB = s + 16 < n ? jj[1] : ic;
-        Row3 qA = row3(q, jA), qB = row3(q, jB), lA = row3(wl, jA), lB = row3(wl, jB);
-#pragma unroll
-        for (int p = 0; p < NP; p += 2) {
-            if (p > 0 && __ballot(s + 16 * p < n) == 0) break;        // (wave-uniform: every row is through)
+        // One double pass is ~90 VALU instructions, a gather round trip ten times that: with the next pass's rows requested
+        // one pass ahead a wave still waited out every round trip (VALU 63 % busy after the packing).  So ALL rows of the
+        // first NPF passes (96 candidates: a liquid's rows hold ~78) are requested up front -- one exposed round trip per
+        // group of atoms -- and the rare longer rows take a second batch.
+        constexpr int NPF = 6;
+        auto pair2 = [&](const Row3 qA, const Row3 qB, const Row3 lA, const Row3 lB) {
             f32x2 dx = f32x2{qA.x, qB.x} - xi, dy = f32x2{qA.y, qB.y} - yi, dz = f32x2{qA.z, qB.z} - zi;   // D = x_j - x_i
             const f32x2 ax = wxi - f32x2{lA.x, lB.x}, ay = wyi - f32x2{lA.y, lB.y}, az = wzi - f32x2{lA.z, lB.z};
-            if (p + 2 < NP) {
-                jA = s + 16 * (p + 2) < n ? jj[p + 2] : ic; jB = s + 16 * (p + 3) < n ? jj[p + 3] : ic;
-                qA = row3(q, jA); qB = row3(q, jB); lA = row3(wl, jA); lB = row3(wl, jB);
-            }
             dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
             const f32x2 d2 = norm2_ref2(dx, dy, dz);
             const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);             // (idle lanes gathered the atom itself: D = 0)
@@ -1240,6 +1258,29 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
             gy2 += k2 * dy; gy2 += c1 * ay;
             gz2 += k2 * dz; gz2 += c1 * az;
             S6 += s6 * bi; S12 += s12 * bi;
+        };
+        {
+            Row3 qv[NPF], lv_[NPF];
+#pragma unroll
+            for (int p = 0; p < NPF; ++p) {
+                const int j = s + 16 * p < n ? jj[p] : ic;
+                qv[p] = row3(q, j); lv_[p] = row3(wl, j);
+            }
+#pragma unroll
+            for (int p = 0; p < NPF; p += 2) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;    // (wave-uniform: every row is through)
+                pair2(qv[p], qv[p + 1], lv_[p], lv_[p + 1]);
+            }
+        }
+        if (__ballot(s + 16 * NPF < n) != 0) {                         // rows beyond 96 candidates (dense / hot spots)
+            Row3 qv[NP - NPF], lv_[NP - NPF];
+#pragma unroll
+            for (int p = NPF; p < NP; ++p) {
+                const int j = s + 16 * p < n ? jj[p] : ic;
+                qv[p - NPF] = row3(q, j); lv_[p - NPF] = row3(wl, j);
+            }
+#pragma unroll
+            for (int p = 0; p < NP - NPF; p += 2) pair2(qv[p], qv[p + 1], lv_[p], lv_[p + 1]);
         }
         fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
         gx = -(gx2.x + gx2.y); gy = -(gy2.x + gy2.y); gz = -(gz2.x + gz2.y);
@@ -1468,9 +1509,10 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
         LG_PREP_LAUNCH(1);                                  // kick + drift + bath half step; search needed? then binning
         LG_FORCE_STEP(1);                                   // (returns at once while the current list serves)
         if (a.nl_idx) {                                     // (returns at once when the step searched)
-            if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gL, dim3(256), 0, st, a);
-            else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gL, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((large_fwd_listed<false, -1>), gL, dim3(256), 0, st, a);
+            const dim3 gLF((N + LG_ROW_ATOMS * LG_FWD_GROUPS - 1) / (LG_ROW_ATOMS * LG_FWD_GROUPS), R);
+            if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gLF, dim3(256), 0, st, a);
+            else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gLF, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((large_fwd_listed<false, -1>), gLF, dim3(256), 0, st, a);
         }
     }
 #undef LG_FORCE_STEP

@@ -27,6 +27,13 @@ struct TrajArgs {
     int32_t* nonfinite;
     int ld;                 // leading dimension of the SoA [3][ld] LDS arrays: 128 for N <= 128 (compile-time
                             // offsets, 8-byte pair loads in the packed loops), N rounded up to even otherwise
+    // topology_update_freq > 1 (torchmd/md.py:200-204): the neighbour lists are rebuilt only at the calls whose running
+    // count is a multiple of `freq` and are STALE in between -- pair set and image flags frozen at the rebuild positions,
+    // no cutoff re-test (compute_dis over the stored list, topology.py:5-12).  code[rep][i][j] = 0 (no pair) or
+    // (term bits << 5) | image code; persistent across launches, like the reference's nbr_list / offsets attributes.
+    uint16_t* code;
+    int freq;
+    long long count0;       // value of the integrator's update_count at the first force call of this launch
 };
 
 constexpr int KMAX_ALL = MDG_MAX_TERMS * MDG_MAX_THETA;
@@ -383,6 +390,94 @@ __device__ __forceinline__ void force_all_pairs(const TrajArgs& A, int tpa_log2,
     }
 }
 
+// force_all_pairs for stale neighbour lists (topology_update_freq > 1; generic multi-term kernels only).  `rebuild`
+// (workgroup-uniform): this call's count is a multiple of the frequency -- the lists of every term are searched at the
+// current positions exactly as generate_nbr_list does (minimum image, un-contracted d^2 < rc^2, != 0, selection mask) and
+// written to the replica's code matrix; otherwise the stored pairs are evaluated with their frozen image flags, whatever
+// their distance is now (the reference's PairPotentials.forward over self.nbr_list / self.offsets, interface.py:298-300).
+template <bool DIAG, int NT, int LEVEL>
+__device__ __forceinline__ void force_pairs_stale(const TrajArgs& A, int tpa_log2, const float* __restrict__ q,
+                                                  const float* __restrict__ w, float* __restrict__ f,
+                                                  float* __restrict__ dq, float (&dth)[KMAX], bool rebuild) {
+    const int N = A.prm.n_atoms, LD = A.ld;
+    const int TPA = 1 << tpa_log2;
+    const int slots = blockDim.x >> tpa_log2;
+    const int slot = threadIdx.x >> tpa_log2, sub = threadIdx.x & (TPA - 1);
+    const int nt = NT == 1 ? 1 : A.terms.n_terms;
+    uint16_t* code = A.code + (size_t)blockIdx.x * N * N;
+    TermConst tc[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+        if (m < nt) tc[m] = term_prepare(A.terms.t[m], A.theta);
+    for (int i = slot; i < N; i += slots) {
+        const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
+        float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+        if (LEVEL >= 2) { wxi = w[i]; wyi = w[LD + i]; wzi = w[2 * LD + i]; }
+        float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int j = sub; j < N; j += TPA) {
+            float dx = q[j] - xi, dy = q[LD + j] - yi, dz = q[2 * LD + j] - zi;   // D = x_j - x_i
+            unsigned c;
+            if (rebuild) {
+                const int img = min_image<DIAG>(A.cell, dx, dy, dz);
+                const float d2n = norm2_ref(dx, dy, dz);
+                unsigned bits = 0;
+                if (d2n != 0.f) {                                               // topology.py:67
+#pragma unroll
+                    for (int m = 0; m < NT; ++m) {
+                        if (m >= nt) break;
+                        const uint8_t* mk = A.terms.t[m].mask;
+                        if (d2n < tc[m].rc2 && (!mk || mk[(size_t)i * N + j])) bits |= 1u << m;
+                    }
+                }
+                c = bits ? ((bits << 5) | (unsigned)img) : 0u;
+                code[(size_t)i * N + j] = (uint16_t)c;
+            } else {
+                c = code[(size_t)i * N + j];
+                if (c) {                                                        // D += o . h with the stored flags
+                    const int img = (int)(c & 31u);
+                    const float ox = (float)(img % 3 - 1), oy = (float)((img / 3) % 3 - 1), oz = (float)(img / 9 - 1);
+                    dx += fmaf(oz, A.cell.h[6], fmaf(oy, A.cell.h[3], ox * A.cell.h[0]));
+                    dy += fmaf(oz, A.cell.h[7], fmaf(oy, A.cell.h[4], ox * A.cell.h[1]));
+                    dz += fmaf(oz, A.cell.h[8], fmaf(oy, A.cell.h[5], ox * A.cell.h[2]));
+                }
+            }
+            if (!c) continue;
+            const float d2 = norm2_ref(dx, dy, dz);
+#pragma unroll
+            for (int m = 0; m < NT; ++m) {
+                if (m >= nt) break;
+                if (!((c >> (5 + m)) & 1u)) continue;
+                PairOut o;
+                float r, ir;
+                pair_eval<LEVEL, -1>(tc[m], d2, r, ir, o);
+                const float c1 = o.du * ir;
+                fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+                if (LEVEL >= 2) {
+                    const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+                    const float ax = wxi - w[j], ay = wyi - w[LD + j], az = wzi - w[2 * LD + j];
+                    const float a = rx * ax + ry * ay + rz * az;
+                    const float c2 = o.d2u * a - c1 * a, c3 = c1;
+                    gx -= c2 * rx + c3 * ax;
+                    gy -= c2 * ry + c3 * ay;
+                    gz -= c2 * rz + c3 * az;
+#pragma unroll
+                    for (int k = 0; k < MDG_MAX_THETA; ++k)
+                        if (k < A.terms.t[m].n_theta) dth[m * MDG_MAX_THETA + k] -= 0.5f * o.ddu_dth[k] * a;
+                }
+            }
+        }
+        fx = group_sum_rt(fx, TPA); fy = group_sum_rt(fy, TPA); fz = group_sum_rt(fz, TPA);
+        if (LEVEL >= 2) { gx = group_sum_rt(gx, TPA); gy = group_sum_rt(gy, TPA); gz = group_sum_rt(gz, TPA); }
+        if (sub == 0) {
+            f[i] = fx; f[LD + i] = fy; f[2 * LD + i] = fz;
+            if (LEVEL >= 2) { dq[i] = gx; dq[LD + i] = gy; dq[2 * LD + i] = gz; }
+        }
+    }
+}
+
+// the call with running index `e` of this launch rebuilds the lists (md.py:200-204: update_count % freq == 0)
+__device__ __forceinline__ bool stale_due(const TrajArgs& A, long long e) { return (A.count0 + e) % (long long)A.freq == 0; }
+
 // Nose-Hoover chain bath right-hand side, entry k (md.py:234-236)
 // (Q is an LDS copy of prm.Q: indexing the by-value kernel argument with a run-time index
 //  would force the whole argument struct into scratch)
@@ -452,11 +547,24 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     store_aos(A.v_t + ((size_t)rep * T) * N * 3, v, N, LD);
     if (nhc && threadIdx.x < C) A.pv_t[((size_t)rep * T) * C + threadIdx.x] = pv[threadIdx.x];
 
-    force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
+    bool stale = false;
+    if constexpr (KIND < 0) stale = A.code != nullptr;
+    if constexpr (KIND < 0) {
+        if (stale) force_pairs_stale<DIAG, NT, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, stale_due(A, 0));
+    }
+    if (!stale) force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
     __syncthreads();
 
     for (int k = 0; k + 1 < T; ++k) {
         const float dt = A.t[k + 1] - A.t[k];
+        if constexpr (KIND < 0) {
+            // stale lists: the first right-hand side of step k is call 2 k.  It sees the positions of call 2 k - 1, so the
+            // cached force is this call's force unless the lists are rebuilt now
+            if (stale && k > 0 && stale_due(A, 2ll * k)) {
+                force_pairs_stale<DIAG, NT, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, true);
+                __syncthreads();
+            }
+        }
         // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
         float ke = 0.f;
         if (nhc) {
@@ -485,7 +593,10 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
         }
         __syncthreads();
         // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-        force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
+        if constexpr (KIND < 0) {
+            if (stale) force_pairs_stale<DIAG, NT, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, stale_due(A, 2ll * k + 1));
+        }
+        if (!stale) force_all_pairs<DIAG, NT, KIND, 1>(A, tpa_log2, q, nullptr, f, nullptr, dth_unused, TB, vmax_unused);
         float pvh0 = 0.f;
         if (nhc) {
             float part = 0.f;
@@ -530,13 +641,18 @@ template <bool DIAG, int NT, int KIND>
 __device__ __forceinline__ void aug_eval(const TrajArgs& A, int tpa_log2, bool nhc, const float* q, const float* v,
                                          const float* lv, const float* ms, float* w, float* f,
                                          float* dq, float* red, float (&th)[KMAX], float& ke,
-                                         float& slv, const TableRef& TB, float& vmax, bool th_on = true) {
+                                         float& slv, const TableRef& TB, float& vmax, bool th_on = true,
+                                         int stale_mode = 0 /* 0: no stale lists, 1: stored lists, 2: rebuild */) {
     const int N = A.prm.n_atoms, LD = A.ld;
     MDG_FOR_DOF(e, ia, ca) w[e] = nhc ? lv[e] * __builtin_amdgcn_rcpf(ms[ia]) : lv[e];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) th[k] = 0.f;
-    force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th, TB, vmax, th_on);
+    bool done = false;
+    if constexpr (KIND < 0) {
+        if (stale_mode) { force_pairs_stale<DIAG, NT, 2>(A, tpa_log2, q, w, f, dq, th, stale_mode == 2); done = true; }
+    }
+    if (!done) force_all_pairs<DIAG, NT, KIND, 2>(A, tpa_log2, q, w, f, dq, th, TB, vmax, th_on);
     // one fused block reduction: th[0..K), sum p^2/m, sum lv.v
     float vals[KMAX + 2];
 #pragma unroll
@@ -627,8 +743,19 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
         // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC,
         //  sovlers.py:160, and from this first one for NVE, :82,101 -- both with total weight h)
         TBacc.gw = 0.5f * h * A.terms.t[0].c;
+        // stale lists (topology_update_freq > 1): an interval makes three calls -- the dL/dt evaluation at y_i (sovlers.py:258;
+        // result unused, but it advances the counter and may rebuild), the first augmented evaluation at the same
+        // positions, the midpoint evaluation -- with running counts c0, c0 + 1, c0 + 2
+        int sm1 = 0, sm2 = 0;
+        if constexpr (KIND < 0) {
+            if (A.code != nullptr) {
+                const long long c0 = 3ll * (T - 1 - i);
+                sm1 = (stale_due(A, c0) || stale_due(A, c0 + 1)) ? 2 : 1;
+                sm2 = stale_due(A, c0 + 2) ? 2 : 1;
+            }
+        }
         aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lv, ms, w, f, dq, red, th, ke, slv, nhc ? TB : TBacc, vmax,
-                                 /*th_on=*/!nhc);
+                                 /*th_on=*/!nhc, sm1);
         if (nhc) {
             const float pv0 = pv[0], lp0 = lp[0];
             if (tid < C) { pb[tid] = bath_rhs(A, Qs, pv, ke, tid); gp[tid] = bath_vjp(A, Qs, pv, lp, slv, tid); }
@@ -650,7 +777,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
             if (tid < C) pv[tid] = pv[tid] + 0.5f * (-pb[tid]) * h;   // :135
             __syncthreads();
             // ---------------- midpoint evaluation                    :147-150
-            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TBacc, vmax);
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TBacc, vmax, true, sm2);
             const float pvm0 = pv[0], lpm0 = lph[0];
             if (tid < C) gp[tid] = bath_vjp(A, Qs, pv, lph, slv, tid);
             __syncthreads();
@@ -685,7 +812,7 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 #pragma unroll
             for (int k = 0; k < KMAX; ++k) gth[k] += (th[k] * 0.5f * h) * 2.f;   // :82,101
             __syncthreads();
-            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TB, vmax);
+            aug_eval<DIAG, NT, KIND>(A, tpa_log2, nhc, q, v, lvh, ms, w, f, dq, red, th, ke, slv, TB, vmax, true, sm2);
             MDG_FOR_DOF(e, ia, ca) {
                 float nlv = lvh[e];                                   // lv + dvad
                 float nlq = lqh[e] + dq[e] * h * 0.5f;                // :100
@@ -914,6 +1041,73 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     hipStream_t st = (hipStream_t)stream;
     MDG_TRAJ_DISPATCH(traj_adj_kernel);
     MDG_CHECK_LAUNCH("traj_adj_kernel");
+    return MDG_OK;
+}
+
+// ------------------------------------------------------------------------------------ stale neighbour lists
+// mdg_traj_fwd_small / mdg_traj_adj_small for integrators with topology_update_freq > 1 (torchmd/md.py:200-204): see
+// TrajArgs::code.  Always the generic multi-term kernels (built-in pair forms, masks, any cell); a tabulated pair model
+// is not taken.
+extern "C" int64_t mdg_traj_stale_words(int n_rep, int n_atoms) { return (int64_t)n_rep * n_atoms * n_atoms; }
+
+extern "C" int mdg_traj_fwd_small_stale(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                        const float* theta, const float* mass, const float* t_grid,
+                                        const float* v0, const float* q0, const float* pv0,
+                                        float* v_t, float* q_t, float* pv_t, int32_t* nonfinite,
+                                        int freq, int64_t count0, uint16_t* code, void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v0 && q0 && v_t && q_t, "traj_fwd_stale: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd_stale: NHC needs pv0/pv_t");
+    MDG_CHECK_ARG(freq >= 1 && count0 >= 0 && code, "traj_fwd_stale: bad frequency / counter / list buffer");
+    MDG_CHECK_ARG(terms->t[0].kind != MDG_PAIR_TABLE, "traj_fwd_stale: a tabulated pair model is not supported");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v0 = v0; a.q0 = q0; a.pv0 = pv0; a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t; a.nonfinite = nonfinite;
+    a.code = code; a.freq = freq; a.count0 = count0;
+    const int N = prm->n_atoms;
+    const int block = pick_block(*prm, false);
+    a.ld = N <= 128 ? 128 : (N + 1) & ~1;
+    const size_t lds = sizeof(float) * (13 * (size_t)a.ld + 5 * MDG_MAX_CHAINS + RED_FLOATS);
+    MDG_CHECK_ARG(lds <= 160 * 1024, "traj_fwd_stale: N=%d does not fit the LDS-resident kernel", N);
+    const int tl = pick_tpa_log2(N, block);
+    dim3 grid(prm->n_rep);
+    hipStream_t st = (hipStream_t)stream;
+    if (cell->diag) hipLaunchKernelGGL((traj_fwd_kernel<true, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl);
+    else hipLaunchKernelGGL((traj_fwd_kernel<false, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl);
+    MDG_CHECK_LAUNCH("traj_fwd_kernel (stale lists)");
+    return MDG_OK;
+}
+
+extern "C" int mdg_traj_adj_small_stale(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                        const float* theta, const float* mass, const float* t_grid,
+                                        const float* v_t, const float* q_t, const float* pv_t,
+                                        const float* g_v, const float* g_q, const float* g_pv,
+                                        float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                        int freq, int64_t count0, uint16_t* code, void* stream) {
+    int rc = validate(prm, cell, terms);
+    if (rc) return rc;
+    MDG_CHECK_ARG(mass && t_grid && v_t && q_t && adj_v0 && adj_q0, "traj_adj_stale: null buffer");
+    MDG_CHECK_ARG(prm->ensemble == 1 || pv_t, "traj_adj_stale: NHC needs pv_t");
+    MDG_CHECK_ARG(freq >= 1 && count0 >= 0 && code, "traj_adj_stale: bad frequency / counter / list buffer");
+    MDG_CHECK_ARG(terms->t[0].kind != MDG_PAIR_TABLE, "traj_adj_stale: a tabulated pair model is not supported");
+    TrajArgs a{};
+    a.prm = *prm; a.cell = *cell; a.terms = *terms; a.theta = theta; a.mass = mass; a.t = t_grid;
+    a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
+    a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
+    a.adj_v0 = adj_v0; a.adj_q0 = adj_q0; a.adj_pv0 = adj_pv0; a.adj_theta = adj_theta;
+    a.code = code; a.freq = freq; a.count0 = count0;
+    const int N = prm->n_atoms;
+    const int block = pick_block(*prm, false);
+    a.ld = N <= 128 ? 128 : (N + 1) & ~1;
+    const size_t lds = sizeof(float) * (28 * (size_t)a.ld + 6 * MDG_MAX_CHAINS + RED_FLOATS);
+    MDG_CHECK_ARG(lds <= 160 * 1024, "traj_adj_stale: N=%d does not fit the LDS-resident kernel", N);
+    const int tl = pick_tpa_log2(N, block);
+    dim3 grid(prm->n_rep);
+    hipStream_t st = (hipStream_t)stream;
+    if (cell->diag) hipLaunchKernelGGL((traj_adj_kernel<true, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl);
+    else hipLaunchKernelGGL((traj_adj_kernel<false, MDG_MAX_TERMS, -1>), grid, dim3(block), lds, st, a, tl);
+    MDG_CHECK_LAUNCH("traj_adj_kernel (stale lists)");
     return MDG_OK;
 }
 

@@ -193,10 +193,20 @@ class _EOM(torch.nn.Module):
 
     def fused_spec(self, method):
         """FusedSpec when the whole trajectory can run in the fused HIP kernels, else None."""
-        if method != self._method or self.topology_update_freq != 1 or self.dim != 3:
+        if method != self._method or self.dim != 3:
             return None
+        freq = int(self.topology_update_freq)
         mods = _pair_terms_of(self.model)
         N = getattr(self.system, "group_size", self.mass.shape[0])      # atoms per replica
+        if freq != 1:
+            # stale neighbour lists (md.py:200-204): the one-workgroup-per-replica kernels keep the lists of the last rebuild
+            # and follow the reference's call counter (mdg_traj_*_small_stale); built-in pair forms, N <= FUSED_MAX_ATOMS, and
+            # only from a call count at which the reference rebuilds too or with the lists of an earlier fused pass at hand
+            if (freq < 1 or mods is None or not self.adjoint or N > FUSED_MAX_ATOMS or self.fused_large
+                    or getattr(self, "fused_stale", True) is False):
+                return None
+            if self.update_count % freq != 0 and getattr(self, "_stale_code", None) is None:
+                return None
         table_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if (mods is None and self.adjoint and self.fused_table
                 and (N <= FUSED_MAX_ATOMS_LARGE if table_large else N <= FUSED_MAX_ATOMS)):
@@ -215,6 +225,8 @@ class _EOM(torch.nn.Module):
             return None
         large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if large and N > FUSED_MAX_ATOMS_LARGE:
+            return None
+        if freq != 1 and large:
             return None
         plist = list(self.parameters())
         offs, pos = {}, 0
@@ -239,10 +251,23 @@ class _EOM(torch.nn.Module):
         spec = _FusedSpec(self, self._ensemble, N, self.mass[:N].contiguous(), cs, ops.make_terms(terms, pos), pos,
                           masks, large=large, **kw)
         spec.n_rep = getattr(self.system, "n_replicas", 1)
+        spec.stale_freq = freq if freq != 1 else 0
         # an rdf observable that was evaluated on an earlier trajectory of this integrator (observable.py) is
         # computed inside the next fused launch; `fuse_observables = False` on the integrator switches that off
-        spec.rdf_hint = getattr(self, "_rdf_hint", None) if getattr(self, "fuse_observables", True) else None
+        spec.rdf_hint = (getattr(self, "_rdf_hint", None) if (getattr(self, "fuse_observables", True) and freq == 1)
+                         else None)
         return spec
+
+    def stale_lists(self, n_rep, n_atoms, device):
+        """Persistent neighbour-list buffer of the stale-list kernels ([R][N][N] uint16 words: pair set + image flags of
+        every term as of the last rebuild) -- the fused counterpart of the reference's nbr_list / offsets attributes."""
+        code = getattr(self, "_stale_code", None)
+        if code is None or code.shape != (n_rep, n_atoms, n_atoms) or code.device != device:
+            if code is not None or self.update_count % int(self.topology_update_freq) != 0:
+                raise RuntimeError("mdgrad_amd: stale neighbour lists of another launch geometry are in use (the call "
+                                   "counter is between two rebuilds); set integrator.fused_stale = False")
+            code = self._stale_code = torch.zeros(n_rep, n_atoms, n_atoms, dtype=torch.int16, device=device)
+        return code
 
 
 class NVE(_EOM):

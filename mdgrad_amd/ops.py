@@ -496,6 +496,17 @@ class FusedTrajFn(torch.autograd.Function):
             spec._last_large = (weakref.ref(ws), (R, N, T, spec.n_theta_total))    # (ops.large_list_builds)
             ctx.lists_ok = not fl[4]               # every frame's candidate list was stored: the adjoint re-tests them
             LARGE_STATS["lists_incomplete"] += int(bool(fl[4]))
+        elif getattr(spec, "stale_freq", 0):
+            # topology_update_freq > 1: stale lists, rebuilt at the calls whose running count is a multiple of the frequency
+            # (md.py:200-204); the forward pass makes 2 (T - 1) calls
+            integ = spec._integrator
+            code = integ.stale_lists(R, N, dev)
+            bad = torch.zeros(R, dtype=torch.int32, device=dev)
+            check(lib.mdg_traj_fwd_small_stale(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                               ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t), ptr(q_t),
+                                               ptr(pv_t), ptr(bad), int(spec.stale_freq), int(integ.update_count), ptr(code),
+                                               stream_ptr(dev)), "mdg_traj_fwd_small_stale")
+            integ.update_count += 2 * (T - 1)
         else:
             bad = torch.zeros(R, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
@@ -596,6 +607,17 @@ class FusedTrajFn(torch.autograd.Function):
                         break
                     LARGE_STATS["adjoint_redone_with_searches"] += 1
                 return flags
+            if getattr(spec, "stale_freq", 0):
+                # the adjoint makes 3 calls per interval (the dL/dt evaluation and two augmented ones, sovlers.py:258-266)
+                integ = spec._integrator
+                code = integ.stale_lists(R, N, dev)
+                check(lib.mdg_traj_adj_small_stale(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                                   ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                                   ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),
+                                                   int(spec.stale_freq), int(integ.update_count), ptr(code),
+                                                   stream_ptr(dev)), "mdg_traj_adj_small_stale")
+                integ.update_count += 3 * (T - 1)
+                return None
             check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
                                          ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th),

@@ -216,22 +216,77 @@ def test_fused_traj_and_adjoint_golden(kind):
         close(y.grad, ga[k], 5e-3, 2e-3 * np.abs(ga[k]).max(), k)
 
 
-def test_generic_adjoint_stale_topology_golden():
-    """topology_update_freq=3 runs the generic (reference control flow) path on HIP ops."""
+@pytest.mark.parametrize("path", ["fused", "generic"])
+def test_adjoint_stale_topology_golden(path):
+    """topology_update_freq = 3 (torchmd/md.py:200-204: the list is rebuilt at every third right-hand-side call, the
+    adjoint's calls included, and is stale in between) against the reference: through the fused stale-list kernels
+    (mdg_traj_fwd_small_stale / mdg_traj_adj_small_stale: the call counter lives on the device) and, forced, through the
+    generic path (the reference's Python control flow on the HIP pair ops)."""
+    from mdgrad_amd import ops
     from mdgrad_amd.sovlers import odeint_adjoint
     g = load_golden("nhc_adj_freq3")
     system, mdl, integ = lj_setup(g, freq=3)
-    assert integ.fused_spec("NH_verlet") is None
+    if path == "generic":
+        integ.fused_stale = False
+        assert integ.fused_spec("NH_verlet") is None
+    else:
+        spec = integ.fused_spec("NH_verlet")
+        assert spec is not None and spec.stale_freq == 3 and not spec.large
     y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
     t = torch.Tensor([float(g["dt"]) * i for i in range(12)]).to(DEV)
     v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
+    assert integ.update_count == 22, "two right-hand-side calls per step"
+    assert (v_t.grad_fn is not None and type(v_t.grad_fn).__name__.startswith("FusedTrajFn")) == (path == "fused")
     for x, k in zip((v_t, q_t, pv_t), ["v_t", "q_t", "pv_t"]):
         close(x, g[k], 1e-4, 1e-4, k)
     (q_t[::3].pow(2).mean() + v_t[-1].pow(2).mean()).backward()
+    assert integ.update_count == 22 + 33, "three calls per adjoint interval"
     close(mdl.sigma.grad, g["grad_sigma"], 2e-3, 1e-4 * abs(float(g["grad_sigma"][0])), "dsigma")
     close(mdl.epsilon.grad, g["grad_epsilon"], 2e-3, 1e-4 * abs(float(g["grad_sigma"][0])), "depsilon")
     for y, k in zip(y0, ["grad_v0", "grad_q0", "grad_pv0"]):
         close(y.grad, g[k], 5e-3, 2e-3 * np.abs(g[k]).max(), k)
+
+
+@pytest.mark.parametrize("freq,two_terms", [(3, False), (2, True), (5, False)])
+def test_stale_lists_persist_across_passes_fused_equals_generic(freq, two_terms):
+    """The call counter and the lists survive from one pass to the next (epochs of Simulations): two forward + adjoint
+    passes in a row on ONE integrator, the second starting between two rebuilds, through the fused stale-list kernels and
+    through the generic path -- same trajectories and gradients in both passes; also with two pair terms of different
+    cutoffs, one of them masked (their lists are separate in the reference, interface.py:228-260)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("nhc_adj_freq3")
+    res = {}
+    for path in ("fused", "generic"):
+        system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+        terms = {"a": PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=2.5)}
+        if two_terms:
+            idx = (list(range(0, 108, 2)), list(range(1, 108, 2)))
+            terms["b"] = PairPotentials(system, P.ExcludedVolume(1.1, 0.7, 12), cutoff=1.9, index_tuple=idx)
+        integ = NoseHooverChain(Stack(terms), system, T=1.0, num_chains=5, Q=50.0, adjoint=True,
+                                topology_update_freq=freq).to(DEV)
+        if path == "generic":
+            integ.fused_stale = False
+        out = []
+        t = torch.Tensor([0.006 * i for i in range(9)]).to(DEV)          # 8 steps: 16 + 24 calls per pass
+        y0 = [s.clone() for s in integ.get_inital_states(wrap=True)]
+        for rep in range(2):
+            for p_ in integ.parameters():
+                p_.grad = None
+            ys = [s.clone().requires_grad_(True) for s in y0]
+            v_t, q_t, pv_t = odeint_adjoint(integ, tuple(ys), t, method="NH_verlet")
+            assert (type(v_t.grad_fn).__name__.startswith("FusedTrajFn")) == (path == "fused"), (path, rep)
+            (q_t[::2].pow(2).mean() + v_t[-1].pow(2).mean() + pv_t[-1].sum() * 1e-2).backward()
+            out.append([v_t.detach(), q_t.detach(), pv_t.detach()] + [y.grad for y in ys]
+                       + [torch.cat([p_.grad.reshape(-1) for p_ in integ.parameters()])])
+            y0 = [v_t[-1].detach(), q_t[-1].detach(), pv_t[-1].detach()]
+        assert integ.update_count == 2 * 40
+        res[path] = out
+    for rep in range(2):
+        for a, b, nm in zip(res["fused"][rep], res["generic"][rep], ("v_t", "q_t", "pv_t", "adj v0", "adj q0", "adj pv0", "dtheta")):
+            close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-7, "pass %d, fused vs generic (freq %d): %s" % (rep, freq, nm))
 
 
 def test_generic_equals_fused():
