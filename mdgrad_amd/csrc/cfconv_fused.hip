@@ -373,9 +373,16 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
 
 // (three waves per SIMD for the primal + tangent sweep: 168 registers + 11 spilled dwords instead of 188 registers at two
 //  waves -- the sweep waits on its gathers, not on issue slots: 155 -> 126 us at E = 459 k)
-template <int GP, int FT, bool TANGENT, bool SUMS>          // GP in {32, 64}
+// HASHD: the node rows carry a tangent (false for the first interaction block, whose input rows do not depend on the
+// positions: no loads, no products, no zero-filled registers for it).  BIASK: n_gaussians <= GP - 2, so the second Dense
+// layer's bias rides in the two unused k columns of the product -- the shifted softplus is made to return exactly 1 there (a
+// pseudo-bias of ln(2 e - 1) on zero weights) and W2's columns hold the bias split into a bf16 head and a bf16 remainder
+// (2^-17 relative) -- instead of a masked add per filter value: the bias of a masked slot vanishes with the slot's zeroed
+// operand row, and the epilogue is the three fused multiply-adds of the aggregation alone.
+template <int GP, int FT, bool TANGENT, bool SUMS, bool HASHD, bool BIASK>          // GP in {32, 64}
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? 2 : 3) : 4) : 1)))
 void cfconv_fwd_bf16_kernel(const FwdArgs A) {
+    static_assert(TANGENT || !HASHD, "node tangents come with the tangent sweep");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                    // bf16 row stride (elements): 16-B aligned rows, conflict-free b128 reads
@@ -397,25 +404,30 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     for (int t = tid; t < FP * GP; t += 256) {
         const int c = t / GP, k = t % GP;
         const int f = (c & 15) * FT + (c >> 4);
-        w2b[c * KSB + k] = (f < F && k < G) ? f2bf(A.net.W2[(size_t)f * G + k]) : 0;
+        unsigned short wv = (f < F && k < G) ? f2bf(A.net.W2[(size_t)f * G + k]) : 0;
+        if (BIASK && k >= GP - 2 && f < F) {                     // bias columns: head and remainder of b2[f]
+            const float b = A.net.b2[f];
+            const unsigned short hi = f2bf(b);
+            wv = k == GP - 2 ? hi : f2bf(b - __uint_as_float((unsigned)hi << 16));
+        }
+        w2b[c * KSB + k] = wv;
     }
     for (int k = tid; k < GP; k += 256) {
         const float c = k < G ? A.net.coef[k] : 0.f;
         mus[k] = k < G ? A.net.mu[k] : 0.f;
         cfs[k] = c * LOG2E;
         c2s[k] = 2.f * c;
-        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+        b1s[k] = k < G ? A.net.b1[k] : ((BIASK && k >= GP - 2) ? 1.4899244f : 0.f);    // ssp(ln(2 e - 1)) = 1
     }
     for (int c = tid; c < FP; c += 256) {
         const int f = (c & 15) * FT + (c >> 4);
-        b2s[c] = f < F ? A.net.b2[f] : 0.f;
+        b2s[c] = (!BIASK && f < F) ? A.net.b2[f] : 0.f;
     }
     __syncthreads();
 
     const int li = lane & 15, lk = lane >> 4;
     unsigned short* h1w = h1s + wid * 16 * KSB;
     unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
-    const bool has_hd = A.hd != nullptr;
     int n_begin, n_end, n_step;
     xcd_sweep(A.N, 4, n_begin, n_end, n_step);              // (see cfconv_fwd_kernel)
     // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
@@ -480,16 +492,9 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
                 load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
             }
-            if (TANGENT) {
-                if (has_hd) {                                     // (wave-uniform: the first block's node rows have no tangent)
+            if (HASHD) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int v = 0; v < FT; ++v) hdreg[r][v] = 0.f;
-                }
+                for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
             }
             bf16x8 af[KB], adf[KB];
 #pragma unroll
@@ -540,16 +545,16 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr, acc, 0, 0, 0);
                     if (TANGENT) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adf[ks], bfr, accd, 0, 0, 0);
                 }
-                const float bias = b2s[nt * 16 + li];
+                const float bias = BIASK ? 0.f : b2s[nt * 16 + li];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float W = acc[r] + (mr[r] ? bias : 0.f);
+                    const float W = BIASK ? acc[r] : acc[r] + (mr[r] ? bias : 0.f);
                     macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
                     if (SUMS) hs[nt] += mr[r] ? hreg[r][nt] : 0.f;
                     if (TANGENT) {
                         mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
-                        mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
+                        if (HASHD) mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
+                        if (SUMS && HASHD) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
                     }
                 }
             }
@@ -563,14 +568,14 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
 #pragma unroll
             for (int v = 0; v < FT; ++v) {
                 hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
-                if (TANGENT) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
+                if (HASHD) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
             }
         }
         if (lk == 0) {
             store_row<FT>(A.m, n, F, RS, li, macc);
             if (TANGENT) store_row<FT>(A.md, n, F, RS, li, mdacc);
             if (SUMS) store_row<FT>(A.hsum, n, F, RS, li, hs);
-            if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
+            if (SUMS && HASHD && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
         }
     }
 }
@@ -644,21 +649,34 @@ __device__ __forceinline__ void gather_adjoint_rows(const BwdArgs& A, int ia, in
 #pragma unroll
     for (int q0 = 0; q0 < FT; q0 += QB) {
         float4 hi[QB], hj[QB], pi[QB], pj[QB], bi[DUAL ? QB : 1], bj[DUAL ? QB : 1], ti[HASHD ? QB : 1], tj[HASHD ? QB : 1];
+        // (array by array: the 64-byte pieces two neighbouring k-blocks take of a row are the halves of one 128-byte line --
+        //  requested back to back, the second is served by the fill the first started)
+        int fc[QB];
 #pragma unroll
-        for (int u = 0; u < QB; ++u) {
-            const int fc = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
-            hi[u] = *reinterpret_cast<const float4*>(hI + fc);
-            hj[u] = *reinterpret_cast<const float4*>(hJ + fc);
-            pi[u] = *reinterpret_cast<const float4*>(pI + fc);
-            pj[u] = *reinterpret_cast<const float4*>(pJ + fc);
-            if (DUAL) {
-                bi[u] = *reinterpret_cast<const float4*>(bI + fc);
-                bj[u] = *reinterpret_cast<const float4*>(bJ + fc);
-            }
-            if (HASHD) {
-                ti[u] = *reinterpret_cast<const float4*>(tI + fc);
-                tj[u] = *reinterpret_cast<const float4*>(tJ + fc);
-            }
+        for (int u = 0; u < QB; ++u) fc[u] = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) hj[u] = *reinterpret_cast<const float4*>(hJ + fc[u]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) pj[u] = *reinterpret_cast<const float4*>(pJ + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) bj[u] = *reinterpret_cast<const float4*>(bJ + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) tj[u] = *reinterpret_cast<const float4*>(tJ + fc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) hi[u] = *reinterpret_cast<const float4*>(hI + fc[u]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) pi[u] = *reinterpret_cast<const float4*>(pI + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) bi[u] = *reinterpret_cast<const float4*>(bI + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) ti[u] = *reinterpret_cast<const float4*>(tI + fc[u]);
         }
         __builtin_amdgcn_sched_barrier(0);                        // the batch's loads stay together, ahead of its products
 #pragma unroll
@@ -1035,21 +1053,34 @@ __device__ __forceinline__ void gather_adjoint_rows_bf16(const BwdArgs& A, int i
 #pragma unroll
     for (int q0 = 0; q0 < FT; q0 += QB) {
         float4 hi[QB], hj[QB], pi[QB], pj[QB], bi[DUAL ? QB : 1], bj[DUAL ? QB : 1], ti[HASHD ? QB : 1], tj[HASHD ? QB : 1];
+        // (array by array: the 64-byte pieces two neighbouring k-blocks take of a row are the halves of one 128-byte line --
+        //  requested back to back, the second is served by the fill the first started)
+        int fc[QB];
 #pragma unroll
-        for (int u = 0; u < QB; ++u) {
-            const int fc = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
-            hi[u] = *reinterpret_cast<const float4*>(hI + fc);
-            hj[u] = *reinterpret_cast<const float4*>(hJ + fc);
-            pi[u] = *reinterpret_cast<const float4*>(pI + fc);
-            pj[u] = *reinterpret_cast<const float4*>(pJ + fc);
-            if (DUAL) {
-                bi[u] = *reinterpret_cast<const float4*>(bI + fc);
-                bj[u] = *reinterpret_cast<const float4*>(bJ + fc);
-            }
-            if (HASHD) {
-                ti[u] = *reinterpret_cast<const float4*>(tI + fc);
-                tj[u] = *reinterpret_cast<const float4*>(tJ + fc);
-            }
+        for (int u = 0; u < QB; ++u) fc[u] = 16 * (q0 + u) + 4 * lk + 4 <= F ? 16 * (q0 + u) : 0;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) hj[u] = *reinterpret_cast<const float4*>(hJ + fc[u]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) pj[u] = *reinterpret_cast<const float4*>(pJ + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) bj[u] = *reinterpret_cast<const float4*>(bJ + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) tj[u] = *reinterpret_cast<const float4*>(tJ + fc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) hi[u] = *reinterpret_cast<const float4*>(hI + fc[u]);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) pi[u] = *reinterpret_cast<const float4*>(pI + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) bi[u] = *reinterpret_cast<const float4*>(bI + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) ti[u] = *reinterpret_cast<const float4*>(tI + fc[u]);
         }
         __builtin_amdgcn_sched_barrier(0);                        // the batch's loads stay together, ahead of its products
 #pragma unroll
@@ -1684,21 +1715,25 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
     FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
               at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
-#define MDG_FWDB1(GP_, FT_, T_, S_)                                                                                \
+#define MDG_FWDB2(GP_, FT_, T_, S_, H_, B_)                                                                        \
     do {                                                                                                           \
         const size_t lds = fwd_bf16_lds_bytes<GP_, FT_>(T_);                                                       \
-        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_>, lds);                           \
-        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_>, lds);                   \
+        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
     } while (0)
+#define MDG_FWDB1(GP_, FT_, T_, S_, H_)                                                                            \
+    do { if (net->n_gauss + 2 <= GP_) MDG_FWDB2(GP_, FT_, T_, S_, H_, true); else MDG_FWDB2(GP_, FT_, T_, S_, H_, false); } while (0)
 #define MDG_FWDB(GP_, FT_)                                                                                         \
     do {                                                                                                           \
-        if (tangent) { if (hsum) MDG_FWDB1(GP_, FT_, true, true); else MDG_FWDB1(GP_, FT_, true, false); }         \
-        else { if (hsum) MDG_FWDB1(GP_, FT_, false, true); else MDG_FWDB1(GP_, FT_, false, false); }               \
+        if (tangent && hd) { if (hsum) MDG_FWDB1(GP_, FT_, true, true, true); else MDG_FWDB1(GP_, FT_, true, false, true); }   \
+        else if (tangent) { if (hsum) MDG_FWDB1(GP_, FT_, true, true, false); else MDG_FWDB1(GP_, FT_, true, false, false); } \
+        else { if (hsum) MDG_FWDB1(GP_, FT_, false, true, false); else MDG_FWDB1(GP_, FT_, false, false, false); }             \
     } while (0)
     if (GP == 32 && FT == 4) MDG_FWDB(32, 4);
     else if (GP == 32) MDG_FWDB(32, 8);
     else if (FT == 4) MDG_FWDB(64, 4);
     else MDG_FWDB(64, 8);
+#undef MDG_FWDB2
 #undef MDG_FWDB
 #undef MDG_FWDB1
     }
