@@ -21,7 +21,6 @@
 // O(N^2) pair tests per evaluation: meant for N <= ~16k (launch-bound regime); above that the
 // generic path with the cell list applies.
 #include "common.hpp"
-#include <stdlib.h>
 #pragma clang diagnostic ignored "-Wunused-result"
 
 namespace {
@@ -1234,10 +1233,12 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
         const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
         const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
         f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2, gx2 = fx2, gy2 = fx2, gz2 = fx2, S6 = fx2, S12 = fx2;
-        // One double pass is ~90 VALU instructions, a gather round trip ten times that: with the next pass's rows requested
-        // one pass ahead a wave still waited out every round trip (VALU 63 % busy after the packing).  So ALL rows of the
-        // first NPF passes (96 candidates: a liquid's rows hold ~78) are requested up front -- one exposed round trip per
-        // group of atoms -- and the rare longer rows take a second batch.
+        // ALL rows of the first NPF passes (96 candidates: a liquid's rows hold ~78) are requested up front -- one round trip
+        // per group of atoms instead of one per pass -- and the rare longer rows take a second batch.  (What bounds the
+        // sweep after the packing is neither the arithmetic nor that latency: ~48 fully divergent 12-byte gathers per wave
+        // at ~64 cache lines each keep the CU's address / L1 path busy for the kernel's whole duration -- packing, up-front
+        // requests and a version software-pipelined across the groups all measured 66 us +- 1 at 64 replicas with the
+        // VALU 63-65 % busy, where the scalar loop measured 68 us at 99 %; profiles/pmc_lj4096.json.)
         constexpr int NPF = 6;
         auto pair2 = [&](const Row3 qA, const Row3 qB, const Row3 lA, const Row3 lB) {
             f32x2 dx = f32x2{qA.x, qB.x} - xi, dy = f32x2{qA.y, qB.y} - yi, dz = f32x2{qA.z, qB.z} - zi;   // D = x_j - x_i
@@ -1321,151 +1322,6 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
         vals[NTH + 1] += lam[e] * vs[e];
     }
     }                                                                  // groups of this wave
-#pragma unroll
-    for (int p = 0; p < NTH + 2; ++p) vals[p] = wave_sum_rows(vals[p]);
-    if (lane == 0) {
-#pragma unroll
-        for (int p = 0; p < NTH + 2; ++p) red[wid * (NTH + 2) + p] = vals[p];
-    }
-    __syncthreads();
-    if (threadIdx.x < LG_NV) {
-        const int p = threadIdx.x;
-        const int c = p < LG_KMAX ? (p < NTH ? p : -1) : NTH + (p - LG_KMAX);
-        float t_ = 0.f;
-        if (c >= 0) t_ = (red[c] + red[(NTH + 2) + c]) + (red[2 * (NTH + 2) + c] + red[3 * (NTH + 2) + c]);
-        A.partN[((size_t)rep * A.nbF + blockIdx.x) * LG_NV + p] = t_;
-    }
-}
-
-// large_adj_listed<true, KIND_LJ126> as a SOFTWARE PIPELINE over the wave's groups of four atoms.  The packed loop
-// (above) left the sweep latency-bound: a group is index words -> rows -> ~300 VALU instructions, two dependent round
-// trips for half a microsecond of arithmetic, and four waves per SIMD all sit in the same phase (VALU 65 % busy at the old
-// duration).  Here the index words are requested two groups ahead and the rows one group ahead, so what a group waits
-// for was issued a whole group earlier; the loop over the groups is unrolled and the buffers are named by group.
-template <int WAVES>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES))) void large_adj_listed_lj(const LargeArgs A, const int second) {
-    constexpr int NP = LG_LIST / 16, NPF = 6, NTH = MDG_MAX_THETA, G = LG_ADJ_GROUPS;
-    __shared__ float red[4 * (NTH + 2)];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), s = lane & 15;
-    const size_t so = (size_t)rep * N * 3;
-    const float* q = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
-    const float* vs = second ? A.vm + so : A.v_t + ((size_t)rep * T + i_fr) * N * 3;
-    const float* lam = second ? A.lvh + so : A.lv + so;
-    const float* wl = A.wl + so;                                       // w = lam_v / m (NVE: lam_v), written by large_prep<2|3>
-    // (list selection: as large_adj_listed)
-    int slot = A.nl_build[(size_t)rep * T + i_fr];
-    bool bad = A.nl_bad[(size_t)rep * T + slot] != 0;
-    if (second) {
-        const int slotB = i_fr + 1 < T ? A.nl_build[(size_t)rep * T + i_fr + 1] : slot;
-        const bool okA = !bad && !A.nl_state[2 * rep];
-        const bool okB = !A.nl_bad[(size_t)rep * T + slotB] && !A.nl_state[2 * rep + 1];
-        if (okB) slot = slotB;
-        bad = !(okA || okB);
-    } else if (blockIdx.x == 0 && threadIdx.x == 0) {
-        A.nl_state[2 * rep] = 0; A.nl_state[2 * rep + 1] = 0;
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && bad) A.flags[5] = 1;
-    const float sig = A.theta[A.terms.t[0].theta_off], eps = A.theta[A.terms.t[0].theta_off + 1];
-    const float cq = A.terms.t[0].c, rc2 = A.terms.t[0].cutoff * A.terms.t[0].cutoff;
-    const float sig2 = sig * sig, e4 = 4.f * eps, isig = 1.0f / sig;
-    const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;                    // phi'/r  = (m1a s6 - m1b s12) / d2
-    const float ka = 48.f * e4 * cq, kb = 168.f * e4;                    // phi'' - phi'/r = (kb s12 - ka s6) / d2
-    const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
-    const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
-    const int i0 = (blockIdx.x * 4 + wid) * G * 4 + (lane >> 4);       // the lane's atom of group 0; group g: + 4 g
-
-    uint32_t iw[G][NP];                                                // index words of the lane's row, per group
-    int cnt[G];
-    Row3 qv[G][NPF], wv[G][NPF], qi[G], wi[G];
-    float mi[G], vse[G], lame[G];                                      // (vs / lam entries of lanes s < 3: requested with the indices)
-    auto atom = [&](int g, bool& valid) { const int i = i0 + 4 * g; valid = i < N; return valid ? i : N - 1; };
-    auto load_idx = [&](int g) {
-        bool valid;
-        const int ic = atom(g, valid);
-        const size_t at = ((size_t)rep * T + slot) * N + ic;
-        const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) iw[g][p] = idx[(s >> 1) + 8 * p];
-        cnt[g] = A.nl_cnt[at];
-        qi[g] = row3(q, ic); wi[g] = row3(wl, ic); mi[g] = A.mass[ic];
-        const int e = 3 * ic + (s < 3 ? s : 0);
-        vse[g] = vs[e]; lame[g] = lam[e];
-    };
-    auto count = [&](int g) { bool valid; atom(g, valid); return (valid && !bad) ? min(cnt[g], LG_LIST) : 0; };
-    auto entry = [&](int g, int p) { return (int)((iw[g][p] >> (16 * (s & 1))) & 0xffffu); };
-    auto gather = [&](int g) {
-        bool valid;
-        const int ic = atom(g, valid), n = count(g);
-#pragma unroll
-        for (int p = 0; p < NPF; ++p) {
-            const int j = s + 16 * p < n ? entry(g, p) : ic;           // (idle lanes gather the atom itself: D = 0 is skipped)
-            qv[g][p] = row3(q, j); wv[g][p] = row3(wl, j);
-        }
-    };
-    float vals[NTH + 2];
-#pragma unroll
-    for (int p = 0; p < NTH + 2; ++p) vals[p] = 0.f;
-    load_idx(0);
-    if (G > 1) load_idx(1);
-    gather(0);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (g + 2 < G) load_idx(g + 2);
-        if (g + 1 < G) gather(g + 1);
-        bool valid;
-        const int ic = atom(g, valid), n = count(g), i = i0 + 4 * g;
-        const float xi = qi[g].x, yi = qi[g].y, zi = qi[g].z, wxi = wi[g].x, wyi = wi[g].y, wzi = wi[g].z;
-        f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2, gx2 = fx2, gy2 = fx2, gz2 = fx2, S6 = fx2, S12 = fx2;
-        auto pair2 = [&](const Row3 qA, const Row3 qB, const Row3 lA, const Row3 lB) {
-            f32x2 dx = f32x2{qA.x, qB.x} - xi, dy = f32x2{qA.y, qB.y} - yi, dz = f32x2{qA.z, qB.z} - zi;   // D = x_j - x_i
-            const f32x2 ax = wxi - f32x2{lA.x, lB.x}, ay = wyi - f32x2{lA.y, lB.y}, az = wzi - f32x2{lA.z, lB.z};
-            dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
-            const f32x2 d2 = norm2_ref2(dx, dy, dz);
-            const bool ok0 = (d2.x != 0.f) && (d2.x < rc2), ok1 = (d2.y != 0.f) && (d2.y < rc2);       // topology.py:67
-            const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
-            const f32x2 s2 = sig2 * i2;
-            const f32x2 s6 = s2 * s2 * s2;
-            const f32x2 s12 = s6 * s6;
-            const f32x2 c1 = (m1a * s6 - m1b * s12) * i2;
-            fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;           // F_i += (phi'/r) D
-            const f32x2 b = dx * ax + dy * ay + dz * az;
-            const f32x2 bi = b * i2;                                    // (w_ij . D) / d2
-            const f32x2 k2 = (kb * s12 - ka * s6) * (bi * i2);          // (phi'' - phi'/r) (w_ij . D) / d2
-            gx2 += k2 * dx; gx2 += c1 * ax;                             // (opposite sign: negated once below)
-            gy2 += k2 * dy; gy2 += c1 * ay;
-            gz2 += k2 * dz; gz2 += c1 * az;
-            S6 += s6 * bi; S12 += s12 * bi;
-        };
-#pragma unroll
-        for (int p = 0; p < NPF; p += 2) {
-            if (p > 0 && __ballot(s + 16 * p < n) == 0) break;        // (wave-uniform: every row is through)
-            pair2(qv[g][p], qv[g][p + 1], wv[g][p], wv[g][p + 1]);
-        }
-        if (__ballot(s + 16 * NPF < n) != 0) {                         // rows beyond 96 candidates (dense spots): a second batch
-            Row3 q2[NP - NPF], w2[NP - NPF];
-#pragma unroll
-            for (int p = NPF; p < NP; ++p) {
-                const int j = s + 16 * p < n ? entry(g, p) : ic;
-                q2[p - NPF] = row3(q, j); w2[p - NPF] = row3(wl, j);
-            }
-#pragma unroll
-            for (int p = 0; p < NP - NPF; p += 2) pair2(q2[p], q2[p + 1], w2[p], w2[p + 1]);
-        }
-        const float fx = row16_sum(fx2.x + fx2.y), fy = row16_sum(fy2.x + fy2.y), fz = row16_sum(fz2.x + fz2.y);
-        const float gx = row16_sum(-(gx2.x + gx2.y)), gy = row16_sum(-(gy2.x + gy2.y)), gz = row16_sum(-(gz2.x + gz2.y));
-        const float a6 = S6.x + S6.y, a12 = S12.x + S12.y;
-        vals[0] += e4 * isig * (18.f * cq * a6 - 72.f * a12);           // 1/2 d(w.F)/dsigma, this atom's end of its pairs
-        vals[1] += 12.f * cq * a6 - 24.f * a12;                         // ... d/depsilon
-        if (valid && s < 3) {
-            const int e = 3 * i + s;
-            A.f[so + e] = s == 0 ? fx : (s == 1 ? fy : fz);
-            A.dq[so + e] = s == 0 ? gx : (s == 1 ? gy : gz);
-            const float pp = vse[g] * mi[g];
-            vals[NTH] += pp * pp / mi[g];
-            vals[NTH + 1] += lame[g] * vse[g];
-        }
-    }
 #pragma unroll
     for (int p = 0; p < NTH + 2; ++p) vals[p] = wave_sum_rows(vals[p]);
     if (lane == 0) {
@@ -1700,17 +1556,13 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     }
     dim3 gF(nbF, R);
     const dim3 gLA((N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS), R);
-    // (MDG_LARGE_ADJ: 2 / 3 = the pipelined LJ sweep at two / three waves per SIMD, 1 = the plain loop over the groups)
-    static const int adj_variant = [] { const char* e = getenv("MDG_LARGE_ADJ"); return e ? atoi(e) : 2; }();
     if (a.nl_idx) a.nbF = (int)gLA.x;                  // (rows of partN the listed launches write, the prep launches sum)
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
         if (a.nl_idx) {                                                                                             \
-            if (lj126 && adj_variant == 2) hipLaunchKernelGGL(large_adj_listed_lj<2>, gLA, dim3(256), 0, st, a, SECOND_); \
-            else if (lj126 && adj_variant == 3) hipLaunchKernelGGL(large_adj_listed_lj<3>, gLA, dim3(256), 0, st, a, SECOND_); \
-            else if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, st, a, SECOND_); \
+            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, st, a, SECOND_);      \
             else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gLA, dim3(256), 0, st, a, SECOND_);           \
             else hipLaunchKernelGGL((large_adj_listed<false, -1>), gLA, dim3(256), 0, st, a, SECOND_);                    \
         } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
