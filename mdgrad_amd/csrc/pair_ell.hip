@@ -51,28 +51,48 @@ __global__ void pair_ell_kernel(const EllArgs A) {
                 if (!((b2 < tc.rc2) && (b2 != 0.f))) continue;
             }
             apply_shift(A.cell, A.shift[row + k], dx, dy, dz);      // d = x_i - x_j - o.h
-            PairOut o;
-            float r, ir;
-            pair_eval<LEVEL>(tc, dx * dx + dy * dy + dz * dz, r, ir, o);
-            vals[0] += 0.5f * o.u;
-            if (LEVEL >= 1) {
-                const float rx = dx * ir, ry = dy * ir, rz = dz * ir;
-                gx = fmaf(o.du, rx, gx); gy = fmaf(o.du, ry, gy); gz = fmaf(o.du, rz, gz);
-#pragma unroll
-                for (int t = 0; t < MDG_MAX_THETA; ++t)
-                    if (t < A.term.n_theta) vals[1 + t] += 0.5f * o.du_dth[t];
-                if (LEVEL >= 2) {
-                    const float ax = wxi - A.w[3 * j], ay = wyi - A.w[3 * j + 1], az = wzi - A.w[3 * j + 2];
-                    const float a = rx * ax + ry * ay + rz * az;
-                    const float c2 = o.d2u * a, c3 = o.du * ir;
-                    hx += c2 * rx + c3 * (ax - a * rx);
-                    hy += c2 * ry + c3 * (ay - a * ry);
-                    hz += c2 * rz + c3 * (az - a * rz);
+            // (the functional form is dispatched HERE, around evaluation AND accumulation: with one run-time switch inside
+            //  pair_eval the parameter-derivative slots of PairOut -- filled differently by every form -- merged after the
+            //  switch as a private-memory array: 16-20 bytes of scratch per lane in every instantiation)
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            auto accumulate = [&](const PairOut& o, float ir) {
+                vals[0] += 0.5f * o.u;
+                if (LEVEL >= 1) {
+                    const float rx = dx * ir, ry = dy * ir, rz = dz * ir;
+                    gx = fmaf(o.du, rx, gx); gy = fmaf(o.du, ry, gy); gz = fmaf(o.du, rz, gz);
 #pragma unroll
                     for (int t = 0; t < MDG_MAX_THETA; ++t)
-                        if (t < A.term.n_theta) vals[1 + MDG_MAX_THETA + t] += 0.5f * o.ddu_dth[t] * a;
+                        if (t < A.term.n_theta) vals[1 + t] += 0.5f * o.du_dth[t];
+                    if (LEVEL >= 2) {
+                        const float ax = wxi - A.w[3 * j], ay = wyi - A.w[3 * j + 1], az = wzi - A.w[3 * j + 2];
+                        const float a = rx * ax + ry * ay + rz * az;
+                        const float c2 = o.d2u * a, c3 = o.du * ir;
+                        hx += c2 * rx + c3 * (ax - a * rx);
+                        hy += c2 * ry + c3 * (ay - a * ry);
+                        hz += c2 * rz + c3 * (az - a * rz);
+#pragma unroll
+                        for (int t = 0; t < MDG_MAX_THETA; ++t)
+                            if (t < A.term.n_theta) vals[1 + MDG_MAX_THETA + t] += 0.5f * o.ddu_dth[t] * a;
+                    }
                 }
+            };
+#define MDG_ELL_FORM(KIND_)                                                        \
+            case KIND_: {                                                          \
+                PairOut o{};                                                       \
+                float r, ir;                                                       \
+                pair_eval<LEVEL, KIND_>(tc, d2, r, ir, o);                         \
+                accumulate(o, ir);                                                 \
+            } break;
+            switch (tc.kind) {
+                MDG_ELL_FORM(MDG_PAIR_LJ) MDG_ELL_FORM(MDG_PAIR_MORSE) MDG_ELL_FORM(MDG_PAIR_BUCK) MDG_ELL_FORM(MDG_PAIR_TABLE)
+                default: {
+                    PairOut o{};
+                    float r, ir;
+                    pair_eval<LEVEL, MDG_PAIR_YUKAWA>(tc, d2, r, ir, o);
+                    accumulate(o, ir);
+                } break;
             }
+#undef MDG_ELL_FORM
         }
         if (LEVEL >= 1) {
             gx = group_sum<LPA>(gx); gy = group_sum<LPA>(gy); gz = group_sum<LPA>(gz);
