@@ -200,8 +200,35 @@ __device__ __forceinline__ void ring_lds_fence() {
 // The ring has nl = ceil(N/2) lanes (the lanes that own atoms).  The visitors' positions and w do not move at all:
 // they sit in LDS ([6][64] f32x2, written once per evaluation) and lane l reads entry (l - k) mod nl at step k;
 // only the visitors' accumulators travel, through ds_bpermute_b32 (the LDS crossbar: no VALU slot, no memory).
-template <int LEVEL, bool NEAR, int RDF, int KIND>
-__device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, int N, int lane, const Vec3x2& q,
+// MASK: the term carries a selection mask (index_tuple / ex_pairs, topology.py:37-53).  mk[0..3] / mk[4..7] = the 128-bit
+// rows of the lane's two atoms (bit j: the pair with atom j is selected); the visitors of lane m are atoms 2m, 2m + 1, i.e.
+// bits 2 (m & 15), + 1 of word m >> 4 -- a select chain over four registers and a shift per ring step.  The fused
+// observable's flags stay unmasked (its own selection is the host's concern: only unmasked observables are fused).
+struct RingMask { uint32_t w[8]; };
+__device__ __forceinline__ uint32_t ring_mask_word(const uint32_t* w4, int q) {
+    return q == 0 ? w4[0] : (q == 1 ? w4[1] : (q == 2 ? w4[2] : w4[3]));
+}
+__device__ __forceinline__ RingMask ring_mask_load(const uint8_t* __restrict__ mask, int N, int lane) {
+    RingMask M;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int i = 2 * lane + a;
+#pragma unroll
+        for (int wd = 0; wd < 4; ++wd) {
+            uint32_t acc = 0u;
+            if (i < N)
+                for (int b = 0; b < 32; ++b) {
+                    const int j = 32 * wd + b;
+                    if (j < N && mask[(size_t)i * N + j]) acc |= 1u << b;
+                }
+            M.w[4 * a + wd] = acc;
+        }
+    }
+    return M;
+}
+
+template <int LEVEL, bool NEAR, int RDF, int KIND, bool MASK>
+__device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, const RingMask& M, int N, int lane, const Vec3x2& q,
                                            const Vec3x2& w, Vec3x2& f, Vec3x2& g, float (&th)[MDG_MAX_THETA], Vec3x2& rq,
                                            f32x2* __restrict__ lds) {
     const int nl = (N + 1) >> 1;
@@ -219,7 +246,9 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
     // step 0: the pair inside the lane, both directions (one copy for the histogram)
     {
         const bool v = vi0 && vi1;
-        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, q, w, v, v, v, RDF == 2 && v, fi, gi, fj, gj, D, ri, rj);
+        bool vm = v;
+        if constexpr (MASK) vm = v && ((ring_mask_word(M.w, lane >> 4) >> (2 * (lane & 15) + 1)) & 1u);   // (i0, i1)
+        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, q, w, vm, vm, v, RDF == 2 && v, fi, gi, fj, gj, D, ri, rj);
     }
     const int prev = lane < nl ? ((lane == 0 ? nl : lane) - 1) * 4 : lane * 4;     // bpermute address of lane l-1
     const int nsteps = (nl - 1) >> 1;
@@ -234,8 +263,13 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
         if constexpr (RDF == 2) rj = ring_move(rj, prev);
         const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
         const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
-        ring_pair<LEVEL, NEAR, false, true, RDF, KIND>(K, X, q, w, qj, wj, s0, s1, s0, s1, fi, gi, fj, gj, S, ri, rj);
-        ring_pair<LEVEL, NEAR, true, true, RDF, KIND>(K, X, q, w, qj, wj, c0, c1, c0, c1, fi, gi, fj, gj, S, ri, rj);
+        bool ms0 = s0, ms1 = s1, mc0 = c0, mc1 = c1;
+        if constexpr (MASK) {
+            const uint32_t b0 = ring_mask_word(M.w, idx >> 4) >> (2 * (idx & 15)), b1 = ring_mask_word(M.w + 4, idx >> 4) >> (2 * (idx & 15));
+            ms0 = s0 && (b0 & 1u); mc0 = c0 && (b0 & 2u); mc1 = c1 && (b1 & 1u); ms1 = s1 && (b1 & 2u);
+        }
+        ring_pair<LEVEL, NEAR, false, true, RDF, KIND>(K, X, q, w, qj, wj, ms0, ms1, s0, s1, fi, gi, fj, gj, S, ri, rj);
+        ring_pair<LEVEL, NEAR, true, true, RDF, KIND>(K, X, q, w, qj, wj, mc0, mc1, c0, c1, fi, gi, fj, gj, S, ri, rj);
     }
     if (!(nl & 1)) {
         // antipodal lanes (k = nl/2) see each other from both sides -> directed evaluation, visitors not updated
@@ -245,10 +279,15 @@ __device__ __forceinline__ void ring_sweep(const RingLJ& K, const RingRdf& X, in
         if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; }
         const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
         const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
+        bool ms0 = s0, ms1 = s1, mc0 = c0, mc1 = c1;
+        if constexpr (MASK) {
+            const uint32_t b0 = ring_mask_word(M.w, idx >> 4) >> (2 * (idx & 15)), b1 = ring_mask_word(M.w + 4, idx >> 4) >> (2 * (idx & 15));
+            ms0 = s0 && (b0 & 1u); mc0 = c0 && (b0 & 2u); mc1 = c1 && (b1 & 1u); ms1 = s1 && (b1 & 2u);
+        }
         const bool once = RDF == 2 || 2 * lane < nl;
         Vec3x2 fu = vzero(), gu = vzero(), ru = vzero();
-        ring_pair<LEVEL, NEAR, false, false, RDF, KIND>(K, X, q, w, qj, wj, s0, s1, s0 && once, s1 && once, fi, gi, fu, gu, D, ri, ru);
-        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, qj, wj, c0, c1, c0 && once, c1 && once, fi, gi, fu, gu, D, ri, ru);
+        ring_pair<LEVEL, NEAR, false, false, RDF, KIND>(K, X, q, w, qj, wj, ms0, ms1, s0 && once, s1 && once, fi, gi, fu, gu, D, ri, ru);
+        ring_pair<LEVEL, NEAR, true, false, RDF, KIND>(K, X, q, w, qj, wj, mc0, mc1, c0 && once, c1 && once, fi, gi, fu, gu, D, ri, ru);
     }
     // the travelling accumulators are nsteps lanes ahead of their owners
     int home = lane + nsteps; home = home >= nl ? home - nl : home;
@@ -281,21 +320,21 @@ __device__ __forceinline__ bool ring_near(const RingLJ& K, const Vec3x2& q) {
 }
 
 // RDF: compile-time mode of the kernel; with_rdf: this frame is one of the observable's frames (wave-uniform)
-template <int LEVEL, int RDF, int KIND>
-__device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, bool with_rdf, int N, int lane,
+template <int LEVEL, int RDF, int KIND, bool MASK>
+__device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, const RingMask& M, bool with_rdf, int N, int lane,
                                            const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g, float (&th)[MDG_MAX_THETA],
                                            Vec3x2& rq, f32x2* __restrict__ lds) {
     const bool near = ring_near(K, q);
     if constexpr (RDF != 0) {
         if (with_rdf) {
-            if (near) ring_sweep<LEVEL, true, RDF, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
-            else ring_sweep<LEVEL, false, RDF, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
+            if (near) ring_sweep<LEVEL, true, RDF, KIND, MASK>(K, X, M, N, lane, q, w, f, g, th, rq, lds);
+            else ring_sweep<LEVEL, false, RDF, KIND, MASK>(K, X, M, N, lane, q, w, f, g, th, rq, lds);
             return;
         }
     }
     if constexpr (LEVEL >= 1) {
-        if (near) ring_sweep<LEVEL, true, 0, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
-        else ring_sweep<LEVEL, false, 0, KIND>(K, X, N, lane, q, w, f, g, th, rq, lds);
+        if (near) ring_sweep<LEVEL, true, 0, KIND, MASK>(K, X, M, N, lane, q, w, f, g, th, rq, lds);
+        else ring_sweep<LEVEL, false, 0, KIND, MASK>(K, X, M, N, lane, q, w, f, g, th, rq, lds);
     }
 }
 
@@ -375,13 +414,15 @@ __device__ __forceinline__ bool ring_frame_selected(const RingRdfArgs& F, int k)
 // RDF = false: one wave (= one replica) per workgroup.  RDF = true: sixteen waves share the workgroup's fine
 // histogram in LDS and stride over the replicas (persistent grid: the histogram is merged into HBM once per
 // workgroup); the waves are otherwise independent.
-template <bool RDF, int KIND>
+template <bool RDF, int KIND, bool MASK = false>
 __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, N3 = 3 * N;
     const RingLJ K = ring_constants(A);
+    RingMask M{};
+    if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
     const int nf2 = RDF ? (F.nfine + 1) & ~1 : 0;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smr);
     f32x2* lds = reinterpret_cast<f32x2*>(smr + nf2) + wid * 3 * 64;
@@ -411,7 +452,7 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
         Vec3x2 f, gu, ru, wu = vzero();
         float tu[MDG_MAX_THETA];
         // (every force evaluation of the forward pass is at the positions of a stored frame: the RDF rides along)
-        ring_force<1, RDF ? 1 : 0, KIND>(K, X, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, tu, ru, lds);
+        ring_force<1, RDF ? 1 : 0, KIND, MASK>(K, X, M, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, tu, ru, lds);
         for (int k = 0; k + 1 < T; ++k) {
             const float dt = A.t[k + 1] - A.t[k];
             // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
@@ -432,7 +473,7 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
             q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
             const float ph = 0.5f * pb * dt, pvh = pv + ph;
             // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-            ring_force<1, RDF ? 1 : 0, KIND>(K, X, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, tu, ru, lds);
+            ring_force<1, RDF ? 1 : 0, KIND, MASK>(K, X, M, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, tu, ru, lds);
             const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
             if (nhc) {
                 const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
@@ -487,13 +528,15 @@ __device__ __forceinline__ void ring_theta(const RingLJ& K, const float (&th)[MD
 // RDF = true: the frame gradients of the fused observable are produced here -- in the first augmented evaluation
 // of interval i (which sits at frame i) for frames T-1 .. 1, and in one geometry-only sweep for frame 0 -- and
 // added to lam_q where the adjoint adds the incoming g_q (sovlers.py:249, :286).
-template <bool RDF, int KIND>
+template <bool RDF, int KIND, bool MASK = false>
 __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
     const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
     const RingLJ K = ring_constants(A);
+    RingMask M{};
+    if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
     RingRdf X{};
     int ncell = 0;
     if constexpr (RDF) {
@@ -530,7 +573,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         // ---------------- first augmented evaluation at (y_i, lam)
         if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
         const bool with_rdf = RDF && ring_frame_selected(F, i);
-        ring_force<2, RDF ? 2 : 0, KIND>(K, X, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
+        ring_force<2, RDF ? 2 : 0, KIND, MASK>(K, X, M, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
         if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
         if (nhc) {
@@ -555,7 +598,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             pv = pv + 0.5f * (-pb) * h;                               // :135
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
-            ring_force<2, 0, KIND>(K, X, false, N, lane, q, w, f, dq, th, ru, lds);
+            ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, w, f, dq, th, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
             const float gpm = ring_bath_vjp(A, lane, Qk, pv, lph, slm);
@@ -587,7 +630,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             }
             MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
 #undef MDG_RING_NVE
-            ring_force<2, 0, KIND>(K, X, false, N, lane, q, lvh, f, dq, th, ru, lds);
+            ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, lvh, f, dq, th, ru, lds);
             const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
             const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
             lv.x = lvh.x + gv.x; lv.y = lvh.y + gv.y; lv.z = lvh.z + gv.z;
@@ -601,7 +644,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             const Vec3x2 q = ring_load(A.q_t + fr * N3, N, lane), wu = vzero();
             Vec3x2 fu, gu, rq = vzero();
             float tu[MDG_MAX_THETA];
-            ring_force<0, 2, KIND>(K, X, true, N, lane, q, wu, fu, gu, tu, rq, lds);
+            ring_force<0, 2, KIND, MASK>(K, X, M, true, N, lane, q, wu, fu, gu, tu, rq, lds);
             lq.x += rq.x; lq.y += rq.y; lq.z += rq.z;
         }
     }

@@ -860,7 +860,9 @@ bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& term
     const MdgPairTerm& t = terms.t[0];
     // one unmasked built-in pair form (LJ 12-6 / ExcludedVolume(12) on the even-power polynomial, the others through
     // pair_eval) in an orthorhombic cell
-    return terms.n_terms == 1 && cell.diag && !t.mask && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA && p.n_atoms <= 128;
+    // (a selection mask -- index_tuple / ex_pairs -- is taken for the LJ family: MDG_RING_LAUNCH)
+    return terms.n_terms == 1 && cell.diag && (!t.mask || t.kind == MDG_PAIR_LJ) && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA &&
+           p.n_atoms <= 128;
 }
 bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     return ring_form(p, cell, terms) && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
@@ -871,9 +873,16 @@ int ring_kind(const MdgPairTerm& t) {
 // launch of a ring kernel specialised on the pair form
 #define MDG_RING_LAUNCH(KERNEL, RDF_, grid, block, lds, st, ...)                                              \
     do {                                                                                                      \
+        const bool masked_ = terms->t[0].mask != nullptr;                                                     \
         switch (ring_kind(terms->t[0])) {                                                                     \
-        case KIND_LJ126: hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126>), grid, block, lds, st, __VA_ARGS__); break;        \
-        case MDG_PAIR_LJ: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ>), grid, block, lds, st, __VA_ARGS__); break;      \
+        case KIND_LJ126:                                                                                      \
+            if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126, true>), grid, block, lds, st, __VA_ARGS__);         \
+            else hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126>), grid, block, lds, st, __VA_ARGS__);                       \
+            break;                                                                                            \
+        case MDG_PAIR_LJ:                                                                                     \
+            if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ, true>), grid, block, lds, st, __VA_ARGS__);        \
+            else hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ>), grid, block, lds, st, __VA_ARGS__);                      \
+            break;                                                                                            \
         case MDG_PAIR_MORSE: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_MORSE>), grid, block, lds, st, __VA_ARGS__); break; \
         case MDG_PAIR_BUCK: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_BUCK>), grid, block, lds, st, __VA_ARGS__); break;  \
         default: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_YUKAWA>), grid, block, lds, st, __VA_ARGS__); break;          \

@@ -871,3 +871,108 @@ def test_cell_sweep_rdf_equals_list_rdf_and_is_reproducible():
     #  distance can move a pair across a fine-bin edge)
     close(out[0][0], out[2][0], 1e-5, 1e-8, "histogram: sweep vs list")
     close(out[0][1], out[2][1], 1e-4, 1e-6 * float(out[2][1].abs().max()), "gradient: sweep vs list")
+
+
+@pytest.mark.parametrize("case", ["two_species_lj126", "excluded_pairs_ljfam", "two_species_nve", "odd_atoms"])
+def test_ring_kernels_with_a_selection_mask_vs_oracle(case):
+    """The wave-per-replica kernels with a masked term (first half): index_tuple = (A, B) of a two-species
+    mixture (only A-B pairs interact, torchmd/topology.py:37-42) and ex_pairs (:44-53) -- the mask rides as two 128-bit rows per
+    lane.  Trajectory, adjoints and parameter gradients of 4 replicas against the oracle, and the same launch on the
+    one-workgroup-per-replica kernels (block = 128: the generic masked path)."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE, NoseHooverChain
+    g = load_golden("nhc_traj_lj")
+    pos0, vel0, mass = g["pos"], g["vel"], g["mass"]
+    if case == "odd_atoms":
+        pos0, vel0, mass = pos0[:107], vel0[:107], mass[:107]
+    n_atoms = len(pos0)
+    R, nT = 4, 7
+    rng = np.random.default_rng(len(case))
+    system = mk_system(pos0, g["cell"], vel0, mass)
+    A_, B_ = list(range(0, n_atoms, 2)), list(range(1, n_atoms, 2))
+    if case == "excluded_pairs_ljfam":
+        ex = np.array([[i, i + 1] for i in range(0, n_atoms - 1, 3)] + [[0, 5], [7, 100]])
+        mdl, okw = P.LJFamily(epsilon=1.1, sigma=0.95, rep_pow=8, attr_pow=4), dict(p=8, q=4, c=1)
+        kw, okw_sel = dict(ex_pairs=torch.as_tensor(ex)), dict(ex_pairs=ex)
+        theta = [0.95, 1.1]
+    else:
+        mdl, okw, theta = P.LennardJones(1.0, 1.0), dict(p=12, q=6, c=1), [1.0, 1.0]
+        kw, okw_sel = dict(index_tuple=(A_, B_)), dict(index_tuple=(A_, B_))
+    stack = Stack({"pair": PairPotentials(system, mdl, cutoff=2.5, **kw)})
+    nhc = case != "two_species_nve"
+    integ = (NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0) if nhc else NVE(stack, system)).to(DEV)
+    pos = np.mod(pos0[None] + rng.normal(0, 0.02, (R,) + pos0.shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 0.5, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.004 * i for i in range(nT)])
+    nrm = n_atoms * 3
+    outs = {}
+    for block in (64, 128):
+        spec = integ.fused_spec("NH_verlet" if nhc else "verlet")
+        assert spec is not None and not spec.large
+        spec.block = block                                   # 64: wave per replica (ring); 128: workgroup per replica
+        v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+        pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True) if nhc else None
+        out = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+        mdl.zero_grad()
+        loss = (out[1][:, ::2].pow(2).sum((1, 2, 3)) / (4 * nrm) + out[0][:, -1].pow(2).sum((1, 2)) / nrm).sum()
+        if nhc:
+            loss = loss + out[2][:, -1].sum()
+        loss.backward()
+        outs[block] = [out[0].detach(), out[1].detach(), v0.grad, q0.grad,
+                       torch.cat([p.grad.reshape(-1) for p in mdl.parameters()])]
+    for a, b, nm in zip(outs[64], outs[128], ("v_t", "q_t", "adj v0", "adj q0", "dtheta")):
+        close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-7, "ring vs workgroup kernels, masked term: " + nm)
+    v_t, q_t, gv0, gq0, gth_hip = outs[64]
+    gth_sum = np.zeros(2)
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor(theta), 2.5, T(g["cell"]), **okw_sel, **okw)
+        traj, lam, gth = oracle_run(
+            pos[r], g["cell"], vel[r], mass, [term], 1.0, 50.0, 5, t,
+            lambda L: L[1][::2].pow(2).sum() / (4 * nrm) + L[0][-1].pow(2).sum() / nrm + (L[2][-1].sum() if nhc else 0.0),
+            ensemble="nhc" if nhc else "nve")
+        close(q_t[r], traj[1], 0, 3e-5, "q_t[%d]" % r)
+        close(v_t[r], traj[0], 0, 3e-4, "v_t[%d]" % r)
+        close(gv0[r], lam[0], 2e-3, 3e-4 * float(lam[0].abs().max()), "adj v0[%d]" % r)
+        close(gq0[r], lam[1], 2e-3, 3e-4 * float(lam[1].abs().max()), "adj q0[%d]" % r)
+        gth_sum += gth.numpy()
+    close(gth_hip, gth_sum, 2e-3, 3e-4 * np.abs(gth_sum).max(), "dL/dtheta")
+
+
+def test_masked_ring_kernels_with_the_fused_rdf_observable():
+    """A masked potential under the fused observable: the force sweep honours the mask, the RDF rides along unmasked -- the
+    second launch (observable fused into the ring kernels) against the first (separate observable kernels) on 3 replicas."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.observable import rdf
+    g = load_golden("nhc_traj_lj")
+    R, nT = 3, 9
+    rng = np.random.default_rng(8)
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    A_, B_ = list(range(0, 108, 2)), list(range(1, 108, 2))
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5, index_tuple=(A_, B_))}), system, T=1.0,
+                            num_chains=5, Q=50.0).to(DEV)
+    spec = integ.fused_spec("NH_verlet")
+    spec.block = 64
+    pos = np.mod(g["pos"][None] + rng.normal(0, 0.03, (R,) + g["pos"].shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(nT)]).to(DEV)
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    res = []
+    for launch in range(2):
+        v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+        pv0 = torch.zeros(R, 5, device=DEV, requires_grad=True)
+        out = ops.fused_traj(v0, q0, pv0, t, spec.flat_params(), spec)
+        fused = out[1]._mdg_traj[3] is not None
+        gr = obs(out[1])[2]
+        mdl.zero_grad()
+        ((gr * torch.linspace(0.5, 1.5, 100, device=DEV)).pow(2).sum() + out[0][:, -1].pow(2).sum() / 50.0).backward()
+        res.append((fused, out[1].detach(), gr.detach(), q0.grad.clone(), v0.grad.clone(),
+                    torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])))
+    assert not res[0][0] and res[1][0], "the second launch must carry the observable"
+    assert torch.equal(res[0][1], res[1][1]), "the trajectory itself does not change"
+    close(res[1][2], res[0][2], 2e-4, 1e-4, "g(r)")
+    for k, nm in ((3, "adj q0"), (4, "adj v0"), (5, "dtheta")):
+        close(res[1][k], res[0][k], 1e-3, 1e-3 * float(res[0][k].abs().max()) + 1e-7, nm)
