@@ -425,8 +425,13 @@ __device__ __forceinline__ void spec_load_rows(const float* p, int row, int N, i
 
 enum { SPEC_FWD = 0, SPEC_TURN = 1, SPEC_REV = 2 };
 
+// (a workgroup's life is one round trip for its inputs, a few small matrix products between barriers, and its stores: the
+//  launch is as fast as there are workgroups in flight -- the register budget is that of four waves per SIMD where it costs no
+//  scratch (n_atom_basis = 64): the turn chain 136 -> 116 registers, the forward chain 104 -> 90; the reverse chain would spill
+//  two dwords and the 128-wide chains hundreds of bytes: they keep the compiler's own budget)
 template <int A_, int F_, bool DUAL, int KIND>
-__global__ __launch_bounds__(256) void chain_spec_kernel(const ChainArgs A) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A_ == 64 && KIND != 2) ? 4 : 1)))
+void chain_spec_kernel(const ChainArgs A) {
     constexpr int H_ = A_ / 2;                                                      // readout hidden width
     constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + 4;
     __shared__ __attribute__((aligned(16))) float Xs[(DUAL ? 2 : 1) * RC_ROWS * ldt];
