@@ -426,12 +426,13 @@ def cpu_baseline_schnet(budget_s=10.0):
     return out
 
 
-def build_schnet_workload(dev, R, bf16, seed, size=8, widths=(64, 128, 30, 2)):
+def build_schnet_workload(dev, R, bf16, seed, size=8, widths=(64, 128, 30, 2), rows16=False):
     """The SchNet workload of BASELINE config #5 as every leg of this script (and tests/test_gpu_secondary_pins.py) builds it:
     CG water on a Diamond size^3 lattice (8 size^3 beads, rho = 0.997 g/cm3), jittered and thermalised at 298 K with
     default_rng(seed), R replicas stacked into one system, SchNet(A, F, G, n_conv) with torch.manual_seed(0) weights (readout
     scaled by 0.02 so that the synthetic dynamics stay stable) + ExcludedVolume(2.6, 0.01, 12) prior, cutoff 6,
-    NoseHooverChain(Q = 50, 5 chains)."""
+    NoseHooverChain(Q = 50, 5 chains).  bf16: bf16 MFMA operands in the filter network; rows16 (with bf16): the convolution
+    kernels gather bf16 mirrors of the node matrices as well (SchNet.node_rows_bf16)."""
     from mdgrad_amd import potentials as P, units
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
     from mdgrad_amd.md import NoseHooverChain
@@ -451,6 +452,7 @@ def build_schnet_workload(dev, R, bf16, seed, size=8, widths=(64, 128, 30, 2)):
     torch.manual_seed(0)
     net = get_model({"n_atom_basis": A_, "n_filters": F_, "n_gaussians": G_, "n_convolutions": NC, "cutoff": 6.0})
     net.filter_bf16 = bool(bf16)
+    net.node_rows_bf16 = bool(bf16 and rows16)
     with torch.no_grad():        # random-init SchNet forces are O(100 eV/A): scale the readout so the synthetic
         net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)   # dynamics stay stable (checked by the callers)
     gnn = GNNPotentials(system, net, cutoff=6.0)
@@ -577,7 +579,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     R = 8 if args.replicas is None or args.workload != "schnet4096" else args.replicas
     T = 11 if args.frames is None or args.workload != "schnet4096" else args.frames
     A_, F_, G_, NC = 64, 128, 30, 2
-    wl = build_schnet_workload(dev, R, args.bf16, 2000 + rank, widths=(A_, F_, G_, NC))
+    rows16 = bool(args.bf16 and getattr(args, "bf16_rows", False))
+    wl = build_schnet_workload(dev, R, args.bf16, 2000 + rank, widths=(A_, F_, G_, NC), rows16=rows16)
     base, system, net, gnn, integ = wl["base"], wl["system"], wl["net"], wl["gnn"], wl["integ"]
     obs = rdf(system, nbins=60, r_range=(2.0, 6.0))
     target = torch.ones(60, device=dev)
@@ -614,8 +617,9 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
         bf16_dev = {"max_abs_dq_A": float((qa - qb).abs().max()), "max_abs_dg": float((ga - gb).abs().max()),
                     "dtheta_rel_to_largest": float((fa - fb).abs().max() / fa.abs().max()),
                     "dtheta_cosine": float((fa * fb).sum() / (fa.norm() * fb.norm())),
-                    "note": "bf16 filter operands vs all-f32 on the timed workload itself (%d steps, same initial state): "
-                            "positions, g(r), the %d-entry parameter gradient" % (T - 1, fa.numel())}
+                    "note": "bf16 filter operands%s vs all-f32 on the timed workload itself (%d steps, same initial state): "
+                            "positions, g(r), the %d-entry parameter gradient" % (
+                                " + bf16 mirrors of the gathered node rows" if rows16 else "", T - 1, fa.numel())}
     for _ in range(warmup):
         step()
     vl0 = (gnn._static or {}).get("verlet")
@@ -643,7 +647,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     out = {"metric": "MD steps/sec (fwd+adjoint), 4096-bead SchNet CG water NHC", "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16 filter MFMA operands, f32 accumulate" if args.bf16 else "f32", "data": "synthetic",
+           "dtype": ("bf16 filter MFMA operands + bf16 mirrors of the gathered node rows, f32 products and accumulate" if rows16
+                     else "bf16 filter MFMA operands, f32 accumulate") if args.bf16 else "f32", "data": "synthetic",
            "config": {"workload": "CG water Diamond 8^3 (%d beads), SchNet A64 F128 G30 2 conv + ExcludedVolume prior, "
                                   "cutoff 6, NoseHooverChain(Q=50, 5 chains), %d steps fwd + RDF(60 bins) loss + analytic "
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
@@ -664,11 +669,13 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     NN, E = topo.n_atoms, topo.n_edges
     conv = net.convolutions[0]
     Pm = analytic._layer_params(conv)
-    fn = ops.FilterNet(Pm["mu"], Pm["c"], Pm["W1"], Pm["b1"], Pm["W2"], Pm["b2"], bf16=bool(args.bf16))
+    fn = ops.FilterNet(Pm["mu"], Pm["c"], Pm["W1"], Pm["b1"], Pm["W2"], Pm["b2"], bf16=bool(args.bf16), rows16=rows16)
     x = torch.Tensor(system.get_positions()).to(dev)
     w = torch.randn(NN, 3, device=dev)
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
     h, hd, mb, mdb = [torch.randn(NN, F_, device=dev) for _ in range(4)]
+    if fn.rows16:                                   # (the kernels of this run gather bf16 mirrors)
+        h, hd, mb, mdb = [ops.rows_to_bf16(v) for v in (h, hd, mb, mdb)]
     d_b, dd_b = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
 
     def timed(fn_, reps=10):
@@ -708,7 +715,10 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     t_min = filt_flops / (filt_peak * 1e12) + (step_flops - filt_flops) / (MFMA_F32_PEAK_TF * 1e12)
     std = R == 8 and T == 11 and bool(args.bf16)
     bname = "cfconv_bwd_bf16_kernel<32, 8, true, true>" if args.bf16 else "cfconv_bwd_kernel<32, 8, true, true>"
-    cnt, why = _counters("schnet4096", bname) if std else (None, "other geometry")
+    if rows16:
+        bname = "cfconv_bwd_bf16_kernel<32, 8, true, true, true>"
+    cnt, why = _counters("schnet4096", bname) if (std and not rows16) else (None, "other geometry" if not rows16 else
+                                                                            "no counter pass for the rows16 kernels")
     bpeak = MFMA_BF16_PEAK_TF if args.bf16 else MFMA_F32_PEAK_TF
     out["roofline"] = {
         "bound": "mfma", "kernel": bname.replace(", ", ",") + " (reverse sweep of the filter network with parameter gradients: "
@@ -1008,9 +1018,14 @@ def main():
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--bf16", action="store_true", help="schnet4096: bf16 MFMA operands in the filter network")
+    ap.add_argument("--bf16-rows", action="store_true",
+                    help="schnet4096: --bf16 and bf16 mirrors of the node rows the convolution kernels gather (a further precision "
+                         "option, SchNet.node_rows_bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     args = ap.parse_args()
+    if args.bf16_rows:
+        args.bf16 = True
 
     from mdgrad_amd import dist as mdist
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1039,6 +1054,7 @@ def main():
             # tolerance: tests/test_gpu_config5.py) and reports the all-f32 rate beside it
             a16 = copy.copy(args)
             a16.bf16 = True
+            a16.bf16_rows = False
             for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 28, 2, a16), ("lj4096", run_lj4096, 50, 3, args)):
                 try:
                     sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
@@ -1052,6 +1068,18 @@ def main():
                     sec["schnet4096"]["f32"]["kernel_frac_of_f32_mfma_peak"] = f32["roofline"]["frac"]
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                # ... and the explicit precision option on top of bf16 operands: bf16 mirrors of the gathered node rows
+                try:
+                    a16r = copy.copy(a16)
+                    a16r.bf16_rows = True
+                    r16 = run_schnet4096(a16r, rank, world, dev, mdist, False, steps=28, warmup=2)
+                    sec["schnet4096"]["bf16_rows"] = {k: r16[k] for k in ("value", "ms_per_step", "dtype")}
+                    sec["schnet4096"]["bf16_rows"]["step_roof_frac"] = r16["roofline"]["step_roof"]["frac"]
+                    sec["schnet4096"]["bf16_rows"]["vs_f32"] = r16["config"].get("bf16_vs_f32")
+                    sec["schnet4096"]["bf16_rows"]["kernel_ms"] = {"bwd_dual_theta": r16["roofline"]["kernel_ms"],
+                                                                   "fwd_tangent": r16["roofline"]["forward_kernel"]["kernel_ms"]}
+                except (Exception, SystemExit) as e:
+                    sec["schnet4096"]["bf16_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["secondary"] = sec
             # the two other north-star workloads, in keys the driver's parser keeps: value, time per pass,
             # the roofline fraction that binds each, and the CPU figure
@@ -1070,6 +1098,8 @@ def main():
                             "parity_sampled": {k: v for k, v in (cb.get("parity_sampled") or {}).items() if k != "note"}}
                 if "f32" in rec:
                     ns[name]["f32"] = rec["f32"]
+                if "bf16_rows" in rec:
+                    ns[name]["bf16_rows"] = rec["bf16_rows"]
             out["config"]["north_star_workloads"] = ns
     if rank == 0:
         print(json.dumps(out))

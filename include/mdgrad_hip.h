@@ -478,6 +478,26 @@ int mdg_cfconv_bwd_smear(const MdgFilterNet* net /*host*/, const float* d, const
                          float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu, float* gcoef,
                          float* workspace, const int32_t* n_valid, int bf16, void* stream);
 
+/* "rows16": the bf16 variants over bf16 MIRRORS of the node matrices the kernels GATHER per edge (h, hd and, in the reverse
+ * sweep, mb, mdb): [n_atoms, n_filters] bf16, dense rows, round-to-nearest-even copies of the f32 matrices (mdg_row_chain
+ * writes them next to its f32 outputs, mdg_rows_to_bf16 makes one of any f32 matrix).  A gathered row is then one 16-byte
+ * load per lane instead of two and half the cache lines; it widens exactly and every product, sum and output stays f32.
+ * This is a PRECISION OPTION of its own on top of the bf16 MFMA operands (the gathered features carry 8 significant bits
+ * into the products; nff/nn/modules.py:564-571 multiplies f32 features) -- callers opt in explicitly
+ * (SchNet.node_rows_bf16, bench.py --bf16-rows) and tests/test_gpu_schnet_rows16.py states its tolerance.
+ * Layers of more than 64 filters (mdg_cfconv_rows16_supported).  Outputs, workspace and the other arguments as in
+ * mdg_cfconv_fwd_bf16 / mdg_cfconv_bwd_smear (gmu = gcoef = NULL: no basis gradients). */
+int mdg_cfconv_rows16_supported(int n_gauss, int n_filters);
+int mdg_cfconv_fwd_rows16(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const uint16_t* h16,
+                          const uint16_t* hd16, const int32_t* col, const int32_t* eid, const int32_t* cnt, int n_atoms,
+                          int max_nbr, float* m, float* md, float* hsum, float* hdsum, void* stream);
+int mdg_cfconv_bwd_rows16(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
+                          int64_t n_edges, int n_atoms, const uint16_t* h16, const uint16_t* hd16, const uint16_t* mb16,
+                          const uint16_t* mdb16, float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu,
+                          float* gcoef, float* workspace, const int32_t* n_valid, void* stream);
+/* dst[r, c] = bf16(src[r * src_stride + c]), dense [n_rows, n_cols] bf16 (n_cols, src_stride multiples of 4) */
+int mdg_rows_to_bf16(const float* src, int64_t n_rows, int n_cols, int src_stride, uint16_t* dst, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * K11/K12  node-level Dense layers with fused epilogues on the f32 MFMA
  * (replaces nff/nn/layers.py:86-134 Dense + nff/nn/activations.py:5-11 on [N, .] node features: message_node_filter,
@@ -542,7 +562,7 @@ int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, i
  *     MDG_CHAIN_MUL     out0 *= aux0[row, m]
  *     MDG_CHAIN_HEAD    (act = 1) pre0 = out0, pre1 = out1 ; out0 = sig aux0[m] ; out1 = (1 - sig) pre1 aux0[m]
  *     MDG_CHAIN_SSP_BWD out0 = s z0 ; out1 = (1 - s) td z0 + s z1         (s = aux0[row, m], td = aux1[row, m])
- *     then out0 += res0[row, m], out1 += res1[row, m]
+ *     then out0 += res0[row, m], out1 += res1[row, m]; out0_h / out1_h (when given) receive the same values rounded to bf16
  * dual = 0: only the "0" operands are touched.  aux0 / aux1 / res may be buffers an EARLIER stage of the same call wrote
  * with the same width M (same owner thread); any other aliasing between a stage's outputs and a later stage's inputs is
  * not allowed.  Widths 1..MDG_CHAIN_MAX_WIDTH, 1..MDG_CHAIN_MAX_STAGES stages.
@@ -564,6 +584,10 @@ typedef struct {
     float* sig;
     float* pre0;
     float* pre1;
+    uint16_t* out0_h;   /* nullable: bf16 mirrors [n_rows, M] of out0 / out1 (the rows16 kernels' inputs), written with them */
+    uint16_t* out1_h;
+    const float* Wt;    /* nullable, trans = 1 only: the [M][K] copy of W (Wt[m*K + k] = W[k*M + m]) -- the compiled chain shapes
+                           then load a lane's weight fragment as 16-byte vectors along k instead of dword by dword */
     int32_t K, M, trans, act, mode, pad_;
 } MdgChainStage;
 int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream);

@@ -62,7 +62,7 @@ GRAD_ATB, GRAD_COLSUM, GRAD_AXPY, GRAD_JOBS_MAX = 0, 1, 2, 32
 class MdgChainStage(C.Structure):
     """One Dense stage of mdg_row_chain (include/mdgrad_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("W", "bias", "in0", "in1", "res0", "res1", "aux0", "aux1", "out0", "out1", "sig",
-                                          "pre0", "pre1")] + \
+                                          "pre0", "pre1", "out0_h", "out1_h", "Wt")] + \
                [(n, C.c_int32) for n in ("K", "M", "trans", "act", "mode", "pad_")]
 
 
@@ -165,6 +165,11 @@ _SIGNATURES = {
     "mdg_cfconv_bwd_bf16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_bwd_smear": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                        C.c_int, P]),
+    "mdg_cfconv_rows16_supported": (C.c_int, [C.c_int, C.c_int]),
+    "mdg_cfconv_fwd_rows16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, P, P, P]),
+    "mdg_cfconv_bwd_rows16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                        P, P]),
+    "mdg_rows_to_bf16": (C.c_int, [P, C.c_int64, C.c_int, C.c_int, P, P]),
     "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),

@@ -86,6 +86,7 @@ struct FilterDev {
     int G, F;
     int RS;       // floats per row of the node feature matrices (= n_filters of the whole layer; F is this launch's
                   // chunk of <= 128 filters, W2 / b2 and the node pointers are offset to its first filter)
+    int RS16;     // rows16 variants: bf16 elements per row of the GATHERED node matrices (h, hd, mb, mdb point at bf16 mirrors)
 };
 
 // ============================================================================================ forward
@@ -112,6 +113,18 @@ __device__ __forceinline__ void load_row(const float* __restrict__ base, int row
         const float4 x = p[v];
         out[4 * v] = x.x; out[4 * v + 1] = x.y; out[4 * v + 2] = x.z; out[4 * v + 3] = x.w;
     }
+}
+
+// The same row out of a bf16 mirror (rows16 variants, FT = 8): ONE 16-byte load per gathered row instead of two, half the
+// lines, and the row stays packed in four registers until its values are used; they widen exactly (bf16 -> f32 is a shift),
+// every product and sum downstream is the f32 arithmetic of the f32-row kernels.
+__device__ __forceinline__ uint4 load_row16(const unsigned short* __restrict__ base, int row, int F, int RS16, int li, bool ok) {
+    const unsigned off = (unsigned)(ok ? row : 0) * (unsigned)RS16 + (unsigned)(li * 8 + 8 <= F ? li * 8 : 0);
+    return *reinterpret_cast<const uint4*>(base + off);
+}
+__device__ __forceinline__ float row16_elem(const uint4& x, int e) {        // e: a compile-time constant after unrolling
+    const unsigned w = (e >> 1) == 0 ? x.x : (e >> 1) == 1 ? x.y : (e >> 1) == 2 ? x.z : x.w;
+    return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
 }
 
 template <int FT>
@@ -379,10 +392,13 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
 // pseudo-bias of ln(2 e - 1) on zero weights) and W2's columns hold the bias split into a bf16 head and a bf16 remainder
 // (2^-17 relative) -- instead of a masked add per filter value: the bias of a masked slot vanishes with the slot's zeroed
 // operand row, and the epilogue is the three fused multiply-adds of the aggregation alone.
-template <int GP, int FT, bool TANGENT, bool SUMS, bool HASHD, bool BIASK>          // GP in {32, 64}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? 2 : 3) : 4) : 1)))
+// (packed bf16 node rows leave room for one more wave per SIMD where the kernel carries no node tangent or the neighbour sums)
+template <int GP, int FT, bool TANGENT, bool SUMS, bool HASHD, bool BIASK, bool R16 = false>          // GP in {32, 64}
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? (R16 ? 3 : 2) : ((R16 && !HASHD) ? 4 : 3)) : 4) : 1)))
 void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     static_assert(TANGENT || !HASHD, "node tangents come with the tangent sweep");
+    static_assert(!R16 || FT == 8, "bf16 node rows: layers of more than 64 filters");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                    // bf16 row stride (elements): 16-B aligned rows, conflict-free b128 reads
@@ -484,17 +500,23 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) != 0u;
             const float da = va ? draw : PAD_D;
             const float dda = (TANGENT && va) ? ddload : 0.f;
-            float hreg[4][FT], hdreg[4][FT];
+            float hreg[R16 ? 1 : 4][FT], hdreg[R16 ? 1 : 4][FT];
+            uint4 hraw[R16 ? 4 : 1], hdraw[R16 ? 4 : 1];          // R16: the packed rows
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int s = t0 + 4 * lk + r;
                 const bool vc = s < cnt;                          // (the gathers do not wait for the distances: masked rows are
                 const int j = vc ? j_raw[r] : 0;                  //  zeroed through the filter below)
-                load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
+                if constexpr (R16) hraw[r] = load_row16(reinterpret_cast<const unsigned short*>(A.h), j, F, A.net.RS16, li, vc);
+                else load_row<FT>(A.h, j, F, RS, li, vc, hreg[r]);
             }
             if (HASHD) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
+                for (int r = 0; r < 4; ++r) {
+                    if constexpr (R16)
+                        hdraw[r] = load_row16(reinterpret_cast<const unsigned short*>(A.hd), j_raw[r], F, A.net.RS16, li, t0 + 4 * lk + r < cnt);
+                    else load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
+                }
             }
             bf16x8 af[KB], adf[KB];
 #pragma unroll
@@ -549,12 +571,15 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float W = BIASK ? acc[r] : acc[r] + (mr[r] ? bias : 0.f);
-                    macc[nt] = fmaf(hreg[r][nt], W, macc[nt]);
-                    if (SUMS) hs[nt] += mr[r] ? hreg[r][nt] : 0.f;
+                    float hv, hdv = 0.f;
+                    if constexpr (R16) { hv = row16_elem(hraw[r], nt); if (HASHD) hdv = row16_elem(hdraw[r], nt); }
+                    else { hv = hreg[r][nt]; if (HASHD) hdv = hdreg[r][nt]; }
+                    macc[nt] = fmaf(hv, W, macc[nt]);
+                    if (SUMS) hs[nt] += mr[r] ? hv : 0.f;
                     if (TANGENT) {
-                        mdacc[nt] = fmaf(hreg[r][nt], accd[r], mdacc[nt]);
-                        if (HASHD) mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
-                        if (SUMS && HASHD) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
+                        mdacc[nt] = fmaf(hv, accd[r], mdacc[nt]);
+                        if (HASHD) mdacc[nt] = fmaf(hdv, W, mdacc[nt]);
+                        if (SUMS && HASHD) hds[nt] += mr[r] ? hdv : 0.f;
                     }
                 }
             }
@@ -1108,12 +1133,102 @@ __device__ __forceinline__ void gather_adjoint_rows_bf16(const BwdArgs& A, int i
     }
 }
 
-template <int GP, int FT, bool DUAL, bool THETA>
+// Filter owned by (k-block q, k-lane lk, component c) is  fbase + c.  With f32 rows a lane's 16-byte load is ONE k-block's four
+// filters (16 q + 4 lk); with bf16 rows (R16) a 16-byte load carries EIGHT filters, the pieces of k-blocks 2 Q and 2 Q + 1, so
+// the contraction index is permuted to  32 Q + 8 lk + 4 (q & 1) + c  -- on the adjoint rows, on the W2 operand read from LDS
+// and on the columns of the gW2 tiles alike (any permutation of a contraction index is as good as another).
+template <bool R16>
+__device__ __forceinline__ int fbase(int q, int lk) { return R16 ? 32 * (q >> 1) + 8 * lk + 4 * (q & 1) : 16 * q + 4 * lk; }
+
+__device__ __forceinline__ float4 widen4(const uint4& x, int half) {       // filters 4 half .. 4 half + 3 of a lane's eight
+    const unsigned a = half ? x.z : x.x, b = half ? x.w : x.y;
+    return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xffff0000u), __uint_as_float(b << 16),
+                       __uint_as_float(b & 0xffff0000u));
+}
+
+// gather_adjoint_rows_bf16 over bf16 MIRRORS of the node matrices (mdg_cfconv_bwd_rows16): half the loads, half the lines.
+// QB k-blocks per batch = QB / 2 loads per matrix; the widened values enter the same f32 products.
+template <int FT, int QB, int SWB, bool DUAL, bool HASHD, bool TILE>
+__device__ __forceinline__ void gather_adjoint_rows_r16(const BwdArgs& A, int ia, int ja, bool va, int li, int lk, int F,
+                                                        int RS16, bf16x4 (&wdbp)[FT], bf16x4 (&wbp)[DUAL ? FT : 1],
+                                                        unsigned short* tdb, unsigned short* tb) {
+    static_assert(QB % 2 == 0 && FT % QB == 0, "k-blocks come in pairs");
+    constexpr int NL = QB / 2;
+    const unsigned ri = (unsigned)(va ? ia : 0) * (unsigned)RS16 + 8u * lk, rj = (unsigned)(va ? ja : 0) * (unsigned)RS16 + 8u * lk;
+    const unsigned short* __restrict__ hI = reinterpret_cast<const unsigned short*>(A.h) + ri;
+    const unsigned short* __restrict__ hJ = reinterpret_cast<const unsigned short*>(A.h) + rj;
+    const unsigned short* __restrict__ pI = reinterpret_cast<const unsigned short*>(A.mdb) + ri;
+    const unsigned short* __restrict__ pJ = reinterpret_cast<const unsigned short*>(A.mdb) + rj;
+    const unsigned short* __restrict__ bI = DUAL ? reinterpret_cast<const unsigned short*>(A.mb) + ri : nullptr;
+    const unsigned short* __restrict__ bJ = DUAL ? reinterpret_cast<const unsigned short*>(A.mb) + rj : nullptr;
+    const unsigned short* __restrict__ tI = HASHD ? reinterpret_cast<const unsigned short*>(A.hd) + ri : nullptr;
+    const unsigned short* __restrict__ tJ = HASHD ? reinterpret_cast<const unsigned short*>(A.hd) + rj : nullptr;
+#pragma unroll
+    for (int q0 = 0; q0 < FT; q0 += QB) {
+        uint4 hi[NL], hj[NL], pi[NL], pj[NL], bi[DUAL ? NL : 1], bj[DUAL ? NL : 1], ti[HASHD ? NL : 1], tj[HASHD ? NL : 1];
+        int fc[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) fc[u] = 32 * (q0 / 2 + u) + 8 * lk + 8 <= F ? 32 * (q0 / 2 + u) : 0;
+#pragma unroll
+        for (int u = 0; u < NL; ++u) hj[u] = *reinterpret_cast<const uint4*>(hJ + fc[u]);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) pj[u] = *reinterpret_cast<const uint4*>(pJ + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) bj[u] = *reinterpret_cast<const uint4*>(bJ + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) tj[u] = *reinterpret_cast<const uint4*>(tJ + fc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NL; ++u) hi[u] = *reinterpret_cast<const uint4*>(hI + fc[u]);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) pi[u] = *reinterpret_cast<const uint4*>(pI + fc[u]);
+        if (DUAL) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) bi[u] = *reinterpret_cast<const uint4*>(bI + fc[u]);
+        }
+        if (HASHD) {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) ti[u] = *reinterpret_cast<const uint4*>(tI + fc[u]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                        // the batch's loads stay together, ahead of its products
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            const int q = q0 + u, fb = fbase<true>(q, lk);
+            const bool ok = va && fb + 4 <= F;
+            const bf16x4 zero4 = {0, 0, 0, 0};
+            const float4 Hi = widen4(hi[u >> 1], u & 1), Hj = widen4(hj[u >> 1], u & 1);
+            const float4 Pi = widen4(pi[u >> 1], u & 1), Pj = widen4(pj[u >> 1], u & 1);
+            const bf16x4 a = pack4(Pi.x * Hj.x + Pj.x * Hi.x, Pi.y * Hj.y + Pj.y * Hi.y, Pi.z * Hj.z + Pj.z * Hi.z,
+                                   Pi.w * Hj.w + Pj.w * Hi.w);
+            wdbp[q] = ok ? a : zero4;
+            if (TILE) *reinterpret_cast<bf16x4*>(&tdb[li * SWB + fb]) = wdbp[q];
+            if (DUAL) {
+                const float4 Bi = widen4(bi[u >> 1], u & 1), Bj = widen4(bj[u >> 1], u & 1);
+                float4 w = {Bi.x * Hj.x + Bj.x * Hi.x, Bi.y * Hj.y + Bj.y * Hi.y, Bi.z * Hj.z + Bj.z * Hi.z, Bi.w * Hj.w + Bj.w * Hi.w};
+                if (HASHD) {
+                    const float4 Ti = widen4(ti[u >> 1], u & 1), Tj = widen4(tj[u >> 1], u & 1);
+                    w.x += Pi.x * Tj.x + Pj.x * Ti.x; w.y += Pi.y * Tj.y + Pj.y * Ti.y;
+                    w.z += Pi.z * Tj.z + Pj.z * Ti.z; w.w += Pi.w * Tj.w + Pj.w * Ti.w;
+                }
+                const bf16x4 b = pack4(w.x, w.y, w.z, w.w);
+                wbp[q] = ok ? b : zero4;
+                if (TILE) *reinterpret_cast<bf16x4*>(&tb[li * SWB + fb]) = wbp[q];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int GP, int FT, bool DUAL, bool THETA, bool R16 = false>
 // (waves per SIMD: round 3 measured more waves as a loss -- with each k-block's gathers behind a divergent branch the sweep
 //  made 8-16 dependent round trips per tile whatever the occupancy, and the registers a second wave needed were spilled.  With
 //  the batched unconditional gathers of gather_adjoint_rows_bf16 the state fits two waves: LDS allows three workgroups per CU)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (THETA ? 2 : (DUAL ? 2 : 3)) : 1)))
 void cfconv_bwd_bf16_kernel(const BwdArgs A) {
+    static_assert(!R16 || FT == 8, "bf16 node rows: layers of more than 64 filters");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                                  // bf16 row stride of the W1 copies (16-B aligned rows)
@@ -1198,8 +1313,14 @@ void cfconv_bwd_bf16_kernel(const BwdArgs A) {
         unsigned short* tdb = reinterpret_cast<unsigned short*>(ws);      // THETA: [16 edges][SWB] Wdb and, behind it, Wb
         unsigned short* tb = tdb + 16 * SWB;
         constexpr int QB = DUAL ? (THETA ? 2 : 4) : FT;          // k-blocks gathered per round trip (registers in flight)
+        if constexpr (R16) {
+            constexpr int QR = DUAL ? (THETA ? 4 : 8) : FT;      // (a 16-byte load carries two k-blocks: the same registers in flight)
+            if (DUAL && has_hd) gather_adjoint_rows_r16<FT, QR, SWB, DUAL, true, THETA>(A, ia, ja, va, li, lk, F, A.net.RS16, wdbp, wbp, tdb, tb);
+            else gather_adjoint_rows_r16<FT, QR, SWB, DUAL, false, THETA>(A, ia, ja, va, li, lk, F, A.net.RS16, wdbp, wbp, tdb, tb);
+        } else {
         if (DUAL && has_hd) gather_adjoint_rows_bf16<FT, QB, SWB, DUAL, true, THETA>(A, ia, ja, va, li, lk, F, RS, wdbp, wbp, tdb, tb);
         else gather_adjoint_rows_bf16<FT, QB, SWB, DUAL, false, THETA>(A, ia, ja, va, li, lk, F, RS, wdbp, wbp, tdb, tb);
+        }
         // ---- recompute layer 1: a = g W1^T + b1 (and its tangent) in the accumulator layout
         float sg[NT][4], qd[DUAL ? NT : 1][4], sc[THETA ? NT : 1][4], sdc[THETA ? NT : 1][4];
         {
@@ -1269,8 +1390,8 @@ void cfconv_bwd_bf16_kernel(const BwdArgs A) {
         for (int nt = 0; nt < NT; ++nt) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < FT; ++q) {                         // k = filter 16 q + 4 lk + c on both operands
-                const bf16x4 bfr = *reinterpret_cast<const bf16x4*>(&w2g[(nt * 16 + li) * FS + 16 * q + 4 * lk]);
+            for (int q = 0; q < FT; ++q) {                         // k = filter fbase(q, lk) + c on both operands
+                const bf16x4 bfr = *reinterpret_cast<const bf16x4*>(&w2g[(nt * 16 + li) * FS + fbase<R16>(q, lk)]);
                 acc = MFMA16(wdbp[q], bfr, acc);
                 if (DUAL) acc2 = MFMA16(wbp[q], bfr, acc2);
             }
@@ -1597,11 +1718,16 @@ constexpr int F_CHUNK = 128;
 
 FilterDev dev_of(const MdgFilterNet* net, int f0) {
     const int F = net->n_filters, fc = F - f0 < F_CHUNK ? F - f0 : F_CHUNK;
-    return FilterDev{net->mu, net->coef, net->W1, net->b1, net->W2 + (size_t)f0 * net->n_gauss, net->b2 + f0, net->n_gauss, fc, F};
+    return FilterDev{net->mu, net->coef, net->W1, net->b1, net->W2 + (size_t)f0 * net->n_gauss, net->b2 + f0, net->n_gauss, fc, F, F};
 }
 
 inline const float* at_col(const float* p, int f0) { return p ? p + f0 : nullptr; }
 inline float* at_col(float* p, int f0) { return p ? p + f0 : nullptr; }
+// column f0 of a bf16 mirror that travels through the kernels' `const float*` argument slots
+inline const float* at_col16(const float* p, int f0) {
+    return p ? reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(p) + f0) : nullptr;
+}
+inline bool rows16_ok(const MdgFilterNet* net) { return net->n_filters > 64 && net->n_filters % 8 == 0; }
 
 int bwd_blocks(long long n_edges, bool theta) {
     const long long tiles = (n_edges + 63) / 64;
@@ -1696,10 +1822,11 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     return MDG_OK;
 }
 
-extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, const float* dd, const float* h,
-                                   const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
-                                   int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
-                                   void* stream) {
+namespace {
+int cfconv_fwd_bf16_impl(const MdgFilterNet* net, const float* d, const float* dd, const float* h,
+                         const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                         int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
+                         void* stream, bool rows16) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1710,16 +1837,23 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd_bf16: tangent buffers without dd");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd_bf16: node feature matrices must be 16-byte aligned");
+    MDG_CHECK_ARG(!rows16 || rows16_ok(net), "cfconv_fwd_rows16: bf16 node rows need n_filters > 64, a multiple of 8 (got %d)",
+                  net->n_filters);
     const int most = (n_atoms + 3) / 4;
     hipStream_t st = (hipStream_t)stream;
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
-    FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
-              at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
-#define MDG_FWDB2(GP_, FT_, T_, S_, H_, B_)                                                                        \
+    FwdArgs a{dev_of(net, f0), d, dd, rows16 ? at_col16(h, f0) : at_col(h, f0), rows16 ? at_col16(hd, f0) : at_col(hd, f0), col,
+              eid, cnt, n_atoms, max_nbr, at_col(m, f0), at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
+#define MDG_FWDB3(GP_, FT_, T_, S_, H_, B_, R_)                                                                    \
     do {                                                                                                           \
         const size_t lds = fwd_bf16_lds_bytes<GP_, FT_>(T_);                                                       \
-        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_>, lds);                   \
-        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_>, lds);               \
+        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+    } while (0)
+#define MDG_FWDB2(GP_, FT_, T_, S_, H_, B_)                                                                        \
+    do {                                                                                                           \
+        if (rows16) MDG_FWDB3(GP_, FT_, T_, S_, H_, B_, (FT_ == 8));   /* (FT = 4 never gets here: rows16_ok) */   \
+        else MDG_FWDB3(GP_, FT_, T_, S_, H_, B_, false);                                                           \
     } while (0)
 #define MDG_FWDB1(GP_, FT_, T_, S_, H_)                                                                            \
     do { if (net->n_gauss + 2 <= GP_) MDG_FWDB2(GP_, FT_, T_, S_, H_, true); else MDG_FWDB2(GP_, FT_, T_, S_, H_, false); } while (0)
@@ -1733,12 +1867,36 @@ extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, cons
     else if (GP == 32) MDG_FWDB(32, 8);
     else if (FT == 4) MDG_FWDB(64, 4);
     else MDG_FWDB(64, 8);
+#undef MDG_FWDB3
 #undef MDG_FWDB2
 #undef MDG_FWDB
 #undef MDG_FWDB1
     }
     MDG_CHECK_LAUNCH("cfconv_fwd_bf16_kernel");
     return MDG_OK;
+}
+}  // namespace
+
+extern "C" int mdg_cfconv_fwd_bf16(const MdgFilterNet* net, const float* d, const float* dd, const float* h,
+                                   const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                                   int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
+                                   void* stream) {
+    return cfconv_fwd_bf16_impl(net, d, dd, h, hd, col, eid, cnt, n_atoms, max_nbr, m, md, hsum, hdsum, stream, false);
+}
+
+// mdg_cfconv_fwd_bf16 over bf16 MIRRORS of the gathered node matrices: h16 / hd16 are [n_atoms, n_filters] bf16 (dense rows);
+// the outputs stay f32.  A precision option of its own (the node rows lose 16 mantissa bits before they are multiplied), see
+// include/mdgrad_hip.h.
+extern "C" int mdg_cfconv_fwd_rows16(const MdgFilterNet* net, const float* d, const float* dd, const uint16_t* h16,
+                                     const uint16_t* hd16, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                                     int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
+                                     void* stream) {
+    return cfconv_fwd_bf16_impl(net, d, dd, reinterpret_cast<const float*>(h16), reinterpret_cast<const float*>(hd16), col, eid,
+                                cnt, n_atoms, max_nbr, m, md, hsum, hdsum, stream, true);
+}
+
+extern "C" int mdg_cfconv_rows16_supported(int n_gauss, int n_filters) {
+    return mdg_cfconv_supported(n_gauss, n_filters) && n_filters > 64 && n_filters % 8 == 0;
 }
 
 extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t n_edges) {
@@ -1749,10 +1907,15 @@ extern "C" int64_t mdg_cfconv_bwd_workspace(int n_gauss, int n_filters, int64_t 
 
 namespace {
 
+// the rows16 instantiation behind the launch macro's four-parameter kernel name (FT = 4 never gets here: rows16_ok)
+template <int GP, int FT, bool DUAL, bool THETA>
+constexpr auto bwd_r16_kernel = cfconv_bwd_bf16_kernel<GP, FT, DUAL, THETA, (FT == 8)>;
+
 int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
                     int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                     float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
-                    const int32_t* n_valid, void* stream, bool bf16, float* gmu = nullptr, float* gcoef = nullptr) {
+                    const int32_t* n_valid, void* stream, bool bf16, float* gmu = nullptr, float* gcoef = nullptr,
+                    bool rows16 = false) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1777,10 +1940,13 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
     MDG_CHECK_ARG(!theta || workspace, "cfconv_bwd: workspace missing");
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(mb) && aligned16(mdb) && aligned16(nbr),
                   "cfconv_bwd: node feature matrices and the pair list must be 16-byte aligned");
+    MDG_CHECK_ARG(!rows16 || (bf16 && rows16_ok(net)),
+                  "cfconv_bwd_rows16: bf16 node rows need n_filters > 64, a multiple of 8 (got %d)", net->n_filters);
     const long long tiles64 = (n_edges + 63) / 64;
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
-    BwdArgs a{dev_of(net, f0), d, dd, nbr, (long long)n_edges, at_col(h, f0), at_col(hd, f0), at_col(mb, f0), at_col(mdb, f0),
-              d_b, dd_b, workspace, n_valid};
+    BwdArgs a{dev_of(net, f0), d, dd, nbr, (long long)n_edges, rows16 ? at_col16(h, f0) : at_col(h, f0),
+              rows16 ? at_col16(hd, f0) : at_col(hd, f0), rows16 ? at_col16(mb, f0) : at_col(mb, f0),
+              rows16 ? at_col16(mdb, f0) : at_col(mdb, f0), d_b, dd_b, workspace, n_valid};
     int nb = bwd_blocks(n_edges, theta);             // (theta: the workspace holds one record per workgroup, <= 512)
 #define MDG_BWD_K(K_, L_, GP_, FT_)                                                                                \
     do {                                                                                                           \
@@ -1803,7 +1969,8 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
     } while (0)
 #define MDG_BWD(GP_, FT_)                                                                                          \
     do {                                                                                                           \
-        if (bf16) MDG_BWD_K(cfconv_bwd_bf16_kernel, bwd_bf16_lds_bytes, GP_, FT_);                                 \
+        if (rows16) MDG_BWD_K(bwd_r16_kernel, bwd_bf16_lds_bytes, GP_, FT_);                                       \
+        else if (bf16) MDG_BWD_K(cfconv_bwd_bf16_kernel, bwd_bf16_lds_bytes, GP_, FT_);                            \
         else MDG_BWD_K(cfconv_bwd_kernel, bwd_lds_bytes, GP_, FT_);                                                \
     } while (0)
     if (GP == 32 && FT == 4) MDG_BWD(32, 4);
@@ -1850,4 +2017,47 @@ extern "C" int mdg_cfconv_bwd_smear(const MdgFilterNet* net, const float* d, con
     MDG_CHECK_ARG(gW1 && gmu && gcoef, "cfconv_bwd_smear: the basis gradients come with the parameter gradients");
     return cfconv_bwd_impl(net, d, dd, nbr, n_edges, h, hd, mb, mdb, d_b, dd_b, gW1, gb1, gW2, workspace, n_valid, stream,
                            bf16 != 0, gmu, gcoef);
+}
+
+// mdg_cfconv_bwd_bf16 / mdg_cfconv_bwd_smear over bf16 MIRRORS of the four gathered node matrices ([n_atoms, n_filters] bf16,
+// dense rows; hd16 may be null as hd may).  gmu / gcoef null: no basis gradients.  See mdg_cfconv_fwd_rows16.
+extern "C" int mdg_cfconv_bwd_rows16(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                                     int64_t n_edges, int n_atoms, const uint16_t* h16, const uint16_t* hd16,
+                                     const uint16_t* mb16, const uint16_t* mdb16, float* d_b, float* dd_b, float* gW1,
+                                     float* gb1, float* gW2, float* gmu, float* gcoef, float* workspace,
+                                     const int32_t* n_valid, void* stream) {
+    MDG_CHECK_ARG(net && n_atoms > 0 && (long long)n_atoms * net->n_filters < (1LL << 30),
+                  "cfconv_bwd_rows16: n_atoms x n_filters must stay below 2^30");
+    MDG_CHECK_ARG((gmu == nullptr) == (gcoef == nullptr) && (!gmu || gW1), "cfconv_bwd_rows16: the basis gradients come together");
+    return cfconv_bwd_impl(net, d, dd, nbr, n_edges, reinterpret_cast<const float*>(h16), reinterpret_cast<const float*>(hd16),
+                           reinterpret_cast<const float*>(mb16), reinterpret_cast<const float*>(mdb16), d_b, dd_b, gW1, gb1,
+                           gW2, workspace, n_valid, stream, true, gmu, gcoef, true);
+}
+
+// [n_rows, n_cols] f32 rows (row stride src_stride floats) -> dense bf16 rows, round to nearest even: the mirror of a node
+// matrix that was not produced by mdg_row_chain (which writes its mirrors itself).
+namespace {
+__global__ __launch_bounds__(256) void rows_to_bf16_kernel(const float* __restrict__ src, long long n_rows, int n_cols,
+                                                           int src_stride, unsigned short* __restrict__ dst) {
+    const int per = n_cols / 4;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_rows * per) return;
+    const long long r = t / per;
+    const int c = (int)(t % per) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src + r * src_stride + c);
+    const u32x2v o = {cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w)};
+    *reinterpret_cast<u32x2v*>(dst + r * n_cols + c) = o;
+}
+}  // namespace
+
+extern "C" int mdg_rows_to_bf16(const float* src, int64_t n_rows, int n_cols, int src_stride, uint16_t* dst, void* stream) {
+    MDG_CHECK_ARG(src && dst && n_rows >= 0 && n_cols > 0 && n_cols % 4 == 0 && src_stride >= n_cols && src_stride % 4 == 0,
+                  "rows_to_bf16: bad arguments (columns and stride in multiples of 4)");
+    MDG_CHECK_ARG(aligned16(src) && (((uintptr_t)dst) & 7) == 0, "rows_to_bf16: unaligned buffers");
+    if (n_rows == 0) return MDG_OK;
+    const long long work = n_rows * (n_cols / 4);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       (long long)n_rows, n_cols, src_stride, dst);
+    MDG_CHECK_LAUNCH("rows_to_bf16_kernel");
+    return MDG_OK;
 }

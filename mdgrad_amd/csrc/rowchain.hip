@@ -63,6 +63,14 @@ __device__ __forceinline__ void load_b(const MdgChainStage& S, int kc, int t, in
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// two f32 -> two bf16, round to nearest even (v_cvt_pk_bf16_f32): lo half = a
+typedef float rc_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int rc_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int rc_pk_bf16(float a, float b) {
+    const rc_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, rc_bf16x2));
+}
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
 
 // operands of the epilogue for the 4 consecutive columns a lane owns in a tile
@@ -243,6 +251,8 @@ void row_chain_kernel(const ChainArgs A) {
                     }
                     if (S.out0) st4(S.out0 + o, z0);
                     if (DUAL && S.out1) st4(S.out1 + o, z1);
+                    if (S.out0_h) *reinterpret_cast<rc_u32x2*>(S.out0_h + o) = rc_u32x2{rc_pk_bf16(z0[0], z0[1]), rc_pk_bf16(z0[2], z0[3])};
+                    if (DUAL && S.out1_h) *reinterpret_cast<rc_u32x2*>(S.out1_h + o) = rc_u32x2{rc_pk_bf16(z1[0], z1[1]), rc_pk_bf16(z1[2], z1[3])};
                 }
                 if (mok) {
                     st4(X0 + li * ldt + m, z0);
@@ -270,6 +280,8 @@ void row_chain_kernel(const ChainArgs A) {
                         }
                         if (S.out0) S.out0[o] = z0;
                         if (DUAL && S.out1) S.out1[o] = z1;
+                        if (S.out0_h) S.out0_h[o] = (uint16_t)rc_pk_bf16(z0, 0.f);
+                        if (DUAL && S.out1_h) S.out1_h[o] = (uint16_t)rc_pk_bf16(z1, 0.f);
                     }
                     X0[li * ldt + mm] = z0;                           // (columns [M, 16 ntile) are left at zero)
                     if (DUAL) X1[li * ldt + mm] = z1;
@@ -295,23 +307,58 @@ void row_chain_kernel(const ChainArgs A) {
 // in registers (TURN).
 template <int M> constexpr int spec_tp() { return (M / 16 + 3) / 4; }          // column tiles per wave
 
+__device__ __forceinline__ void st4v(float* p, unsigned o, const float (&v)[4]) {
+    if (p) *reinterpret_cast<float4*>(p + o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+// the bf16 mirror of an output row piece (MdgChainStage::out0_h / out1_h): what the rows16 cfconv kernels gather
+__device__ __forceinline__ void st4h(uint16_t* p, unsigned o, const float (&v)[4]) {
+    if (p) *reinterpret_cast<rc_u32x2*>(p + o) = rc_u32x2{rc_pk_bf16(v[0], v[1]), rc_pk_bf16(v[2], v[3])};
+}
+__device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float (&v)[4]) {
+    float4 q = {0.f, 0.f, 0.f, 0.f};
+    if (ok && p) q = ld4(p + o);
+    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+}
+
+// TRANS: B[k][m] = W[k * M + m] (the reverse sweeps multiply with the transposed layer).  Wt, when the caller has one
+// (MdgChainStage::Wt), is the [M][K] copy of the same matrix: a lane's fragment is then K / 16 16-byte loads along k like a
+// Linear-layout stage instead of K / 4 dword loads -- 14 load instructions instead of 56 for the three transposed layers of the
+// turn chain at A = 64, F = 128.
 template <int K, int M, bool TRANS>
-__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, float (&b)[spec_tp<M>()][K / 4]) {
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, const float* __restrict__ Wt, int wid, int li, int lk,
+                                            float (&b)[spec_tp<M>()][K / 4]) {
+    const bool lin = !TRANS || Wt != nullptr;                       // (uniform)
+    const float* __restrict__ L = TRANS ? Wt : W;
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
         const int t = wid + 4 * tt;
         if (t * 16 >= M) continue;
         const int m = t * 16 + li;
+        if (lin) {
 #pragma unroll
-        for (int q = 0; q < K / 16; ++q) {
-            if constexpr (!TRANS) {
-                const float4 v = ld4(W + m * K + 16 * q + 4 * lk);
+            for (int q = 0; q < K / 16; ++q) {
+                const float4 v = ld4(L + m * K + 16 * q + 4 * lk);
                 b[tt][4 * q] = v.x; b[tt][4 * q + 1] = v.y; b[tt][4 * q + 2] = v.z; b[tt][4 * q + 3] = v.w;
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < K / 16; ++q)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) b[tt][4 * q + c] = W[(16 * q + 4 * lk + c) * M + m];
-            }
         }
+    }
+}
+
+// bias (and the head vector of a HEAD stage) of the lane's 4 columns per tile: requested BEFORE the stage's matrix products,
+// so the epilogue behind the barrier does not start with a round trip of its own
+template <int M, int MODE>
+__device__ __forceinline__ void spec_load_bias(const MdgChainStage& S, int wid, int lk, float (&bv)[spec_tp<M>()][4], float (&lv)[spec_tp<M>()][4]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+        const int m = (wid + 4 * tt) * 16 + 4 * lk;
+        const bool on = (wid + 4 * tt) * 16 < M;
+        ld4v(S.bias, m, on, bv[tt]);
+        ld4v(MODE == MDG_CHAIN_HEAD ? S.aux0 : nullptr, m, on, lv[tt]);
     }
 }
 
@@ -359,14 +406,6 @@ __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int l
     }
 }
 
-__device__ __forceinline__ void st4v(float* p, unsigned o, const float (&v)[4]) {
-    if (p) *reinterpret_cast<float4*>(p + o) = make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float (&v)[4]) {
-    float4 q = {0.f, 0.f, 0.f, 0.f};
-    if (ok && p) q = ld4(p + o);
-    v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
-}
 
 // epilogue of a stage on the lane's 4 columns of each of its tiles; x0 / x1: operands of MUL / SSP_BWD (registers), q0 / q1:
 // residuals (registers); sg / kd receive sigmoid and the tangent row of an activation stage
@@ -375,21 +414,19 @@ __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&ac
                                               const float (&x0)[spec_tp<M>()][4], const float (&x1)[spec_tp<M>()][4],
                                               const float (&q0)[spec_tp<M>()][4], const float (&q1)[spec_tp<M>()][4],
                                               float (&sgk)[spec_tp<M>()][4], float (&tdk)[spec_tp<M>()][4], float* X0, float* X1, int ldt,
-                                              int row, int N, int wid, int li, int lk) {
+                                              int row, int N, int wid, int li, int lk, const float (&bvs)[spec_tp<M>()][4],
+                                              const float (&lvs)[spec_tp<M>()][4]) {
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
         const int m = (wid + 4 * tt) * 16 + 4 * lk;
         if ((wid + 4 * tt) * 16 >= M) continue;
         const bool ok = row < N;
         const unsigned o = (unsigned)(row * M + m);
-        float bv[4], lv[4];
-        ld4v(S.bias, m, true, bv);
-        if (MODE == MDG_CHAIN_HEAD) ld4v(S.aux0, m, true, lv);
         float z0[4], z1[4], sg[4], p0[4], p1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z0[r] = acc0[tt][r]; z1[r] = DUAL ? acc1[tt][r] : 0.f;
-            epi_math<DUAL>(ACT, MODE, bv[r], MODE == MDG_CHAIN_HEAD ? lv[r] : 0.f, x0[tt][r], x1[tt][r], q0[tt][r], q1[tt][r], z0[r], z1[r],
+            epi_math<DUAL>(ACT, MODE, bvs[tt][r], MODE == MDG_CHAIN_HEAD ? lvs[tt][r] : 0.f, x0[tt][r], x1[tt][r], q0[tt][r], q1[tt][r], z0[r], z1[r],
                            sg[r], p0[r], p1[r]);
             if (ACT == 1) { sgk[tt][r] = sg[r]; tdk[tt][r] = p1[r]; }
             if (!ok) { z0[r] = 0.f; z1[r] = 0.f; }
@@ -399,6 +436,10 @@ __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&ac
             if (MODE == MDG_CHAIN_HEAD) { st4v(S.pre0, o, p0); if (DUAL) st4v(S.pre1, o, p1); }
             st4v(S.out0, o, z0);
             if (DUAL) st4v(S.out1, o, z1);
+            if (S.out0_h) {                                       // (uniform, rare)
+                st4h(S.out0_h, o, z0);
+                if (DUAL) st4h(S.out1_h, o, z1);
+            }
         }
         *reinterpret_cast<float4*>(X0 + li * ldt + m) = make_float4(z0[0], z0[1], z0[2], z0[3]);
         if (DUAL) *reinterpret_cast<float4*>(X1 + li * ldt + m) = make_float4(z1[0], z1[1], z1[2], z1[3]);
@@ -443,55 +484,74 @@ void chain_spec_kernel(const ChainArgs A) {
     float dF[spec_tp<F_>()][4], dH[spec_tp<H_>()][4];                              // (sigmoid / tangent sinks of stages that keep none)
     spec_zero<A_>(zA); spec_zero<F_>(zF); spec_zero<H_>(zH);
     if constexpr (KIND == SPEC_FWD || KIND == SPEC_TURN) {
-        // ---- weights of the whole launch + the input rows: one round trip
+        // ---- first round trip: the weights of the first two stages, the input rows, the residual rows, the biases.  The
+        //      weights of a later stage are requested while the stage two before it multiplies (its own fragments are dead by
+        //      then), the bias of a stage before the stage's products: no epilogue starts with a round trip of its own.
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
-        spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
-        spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
+        spec_load_w<F_, A_, false>(A.s[0].W, nullptr, wid, li, lk, w0);
+        spec_load_w<A_, A_, false>(A.s[1].W, nullptr, wid, li, lk, w1);
         spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
         float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
         spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
         spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+        float b0[spec_tp<A_>()][4], b1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4];
+        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
+        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
         f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
         __syncthreads();
         // stage 0: t = ssp(U1 m + c1), su, td
         spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        __syncthreads();
-        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk);
-        __syncthreads();
-        // stage 1: r' = U2 t + c2 + r
-        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-        __syncthreads();
-        {
-            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
-        }
-        __syncthreads();
         if constexpr (KIND == SPEC_FWD) {
+            float w2[spec_tp<F_>()][A_ / 4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
+            spec_load_w<A_, F_, false>(A.s[2].W, nullptr, wid, li, lk, w2);
+            spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
+            __syncthreads();
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+            __syncthreads();
+            // stage 1: r' = U2 t + c2 + r
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+            }
+            __syncthreads();
             // stage 2: h' = Wn' r' + bn'
-            float w2[spec_tp<F_>()][A_ / 4];
-            spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
         } else {
-            float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
-            spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
-            spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
-            spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
-            spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
+            float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], b2[spec_tp<H_>()][4], l2[spec_tp<H_>()][4];
+            spec_load_w<A_, H_, false>(A.s[2].W, nullptr, wid, li, lk, w2);
+            spec_load_w<H_, A_, true>(A.s[3].W, A.s[3].Wt, wid, li, lk, w3);
+            spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, b2, l2);
+            __syncthreads();
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+            __syncthreads();
+            // stage 1: r' = U2 t + c2 + r
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+            float w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
+            spec_load_w<A_, A_, true>(A.s[4].W, A.s[4].Wt, wid, li, lk, w4);
+            spec_load_w<A_, F_, true>(A.s[5].W, A.s[5].Wt, wid, li, lk, w5);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+            }
+            __syncthreads();
             // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
             f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
             spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
             __syncthreads();
-            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk);
+            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, b2, l2);
             __syncthreads();
             // stage 3: (rdb, rb) = (ydb, yb) L1
             spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
             }
             __syncthreads();
             // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
@@ -500,21 +560,20 @@ void chain_spec_kernel(const ChainArgs A) {
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
                 spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
-                                                                                    N, wid, li, lk);
+                                                                                    N, wid, li, lk, zA, zA);
             }
             __syncthreads();
             // stage 5: (mdb, mb) = (udb, ub) U1
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
         }
     } else {
         // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
-        spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
-        spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
-        spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
+        spec_load_w<F_, A_, true>(A.s[0].W, A.s[0].Wt, wid, li, lk, w0);
+        spec_load_w<A_, A_, true>(A.s[1].W, A.s[1].Wt, wid, li, lk, w1);
         spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
         float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
         spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
@@ -525,18 +584,19 @@ void chain_spec_kernel(const ChainArgs A) {
         float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
         __syncthreads();
         spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+        spec_load_w<A_, F_, true>(A.s[2].W, A.s[2].Wt, wid, li, lk, w2);      // (requested while the first stage multiplies)
         __syncthreads();
-        spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk);
+        spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
         __syncthreads();
         spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
         __syncthreads();
         spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
-                                                                            li, lk);
+                                                                            li, lk, zA, zA);
         __syncthreads();
         f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
         spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
         __syncthreads();
-        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk);
+        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
     }
 }
 
@@ -547,7 +607,7 @@ int spec_kind(const MdgChainStage* s, int n, int dual, int A_, int F_) {
     for (int i = 0; i < n; ++i) {
         const MdgChainStage& t = s[i];
         if (!al(t.W) || !al(t.bias) || !al(t.in0) || !al(t.in1) || !al(t.res0) || !al(t.res1) || !al(t.aux0) || !al(t.aux1) ||
-            !al(t.out0) || !al(t.out1) || !al(t.sig) || !al(t.pre0) || !al(t.pre1))
+            !al(t.out0) || !al(t.out1) || !al(t.sig) || !al(t.pre0) || !al(t.pre1) || !al(t.Wt))
             return -1;
         if (i > 0 && t.in0) return -1;
     }
@@ -604,6 +664,9 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_HEAD || (s.act == 1 && s.aux0), "row_chain: stage %d: HEAD needs act = 1 and aux0", i);
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_MUL || s.aux0, "row_chain: stage %d: MUL needs aux0", i);
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_SSP_BWD || (s.aux0 && (!dual || s.aux1)), "row_chain: stage %d: SSP_BWD needs aux0 (and aux1)", i);
+        MDG_CHECK_ARG(!s.Wt || s.trans, "row_chain: stage %d: Wt is the transposed copy of a trans = 1 stage's weights", i);
+        MDG_CHECK_ARG((!s.out0_h && !s.out1_h) || (s.out0_h && s.M % 4 == 0 && (!dual || s.out1_h) && (((uintptr_t)s.out0_h | (uintptr_t)s.out1_h) & 7) == 0),
+                      "row_chain: stage %d: bf16 mirrors come for both outputs, 8-byte aligned, widths in multiples of 4", i);
         wmax = s.K > wmax ? s.K : wmax;
         wmax = s.M > wmax ? s.M : wmax;
         const int t = ((s.M + 15) / 16 + 3) / 4;

@@ -52,6 +52,13 @@ const float* fptr(const OptTensor& t, const char* name) {
 float* mptr(Tensor& t) { return t.data_ptr<float>(); }
 float* mptr(OptTensor& t) { return (t.has_value() && t->defined()) ? t->data_ptr<float>() : nullptr; }
 void ok(int rc) { TORCH_CHECK(rc == 0, "mdgrad: ", mdg_last_error()); }
+// bf16 mirrors of node matrices (the rows16 kernels, include/mdgrad_hip.h)
+bool is_bf16(const Tensor& t) { return t.scalar_type() == at::kBFloat16; }
+const uint16_t* hptr(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda() && is_bf16(t) && t.is_contiguous(), "mdgrad: ", name, " must be a contiguous bfloat16 tensor on a HIP device");
+    return reinterpret_cast<const uint16_t*>(t.data_ptr());
+}
+const uint16_t* hptr(const OptTensor& t, const char* name) { return (t.has_value() && t->defined()) ? hptr(*t, name) : nullptr; }
 
 // cell = the 9 row-major entries of h followed by the 9 of its inverse (the Python side computes the inverse the way
 // the reference does, topology.py:59) and a diagonal flag
@@ -296,13 +303,24 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> cfconv_fwd(const Tensor& mu, const Te
                                                       const OptTensor& dd, const Tensor& h, const OptTensor& hd,
                                                       const Tensor& col, const Tensor& eid, const Tensor& cnt, bool want_sums) {
     const MdgFilterNet net = filter_net(mu, coef, W1, b1, W2, b2);
-    check_f32(d, "d"); check_f32(h, "h");
+    const bool r16 = is_bf16(h);                 // bf16 mirrors of the node rows: mdg_cfconv_fwd_rows16
+    check_f32(d, "d");
+    if (!r16) check_f32(h, "h");
     check_i32(col, "col"); check_i32(eid, "eid"); check_i32(cnt, "cnt");
     const int64_t N = cnt.numel(), F = net.n_filters;
     TORCH_CHECK(h.dim() == 2 && h.size(0) == N && h.size(1) == F, "mdgrad: h must be [N,F]");
     const bool tan = dd.has_value() && dd->defined(), htan = hd.has_value() && hd->defined();
-    Tensor m = at::empty({N, F}, h.options()), md = at::empty({tan ? N : 0, F}, h.options());
-    Tensor hs = at::empty({want_sums ? N : 0, F}, h.options()), hds = at::empty({want_sums && htan ? N : 0, F}, h.options());
+    const auto fo = h.options().dtype(at::kFloat);
+    Tensor m = at::empty({N, F}, fo), md = at::empty({tan ? N : 0, F}, fo);
+    Tensor hs = at::empty({want_sums ? N : 0, F}, fo), hds = at::empty({want_sums && htan ? N : 0, F}, fo);
+    if (r16) {
+        TORCH_CHECK(bf16, "mdgrad: bf16 node rows go with the bf16 filter kernels");
+        ok(mdg_cfconv_fwd_rows16(&net, fptr(d), fptr(dd, "dd"), hptr(h, "h"), hptr(hd, "hd"), col.data_ptr<int32_t>(),
+                                 eid.data_ptr<int32_t>(), cnt.data_ptr<int32_t>(), (int)N, (int)col.size(1), mptr(m),
+                                 tan ? mptr(md) : nullptr, want_sums ? mptr(hs) : nullptr, want_sums && htan ? mptr(hds) : nullptr,
+                                 stream_of(h)));
+        return {m, md, hs, hds};
+    }
     auto fn = bf16 ? mdg_cfconv_fwd_bf16 : mdg_cfconv_fwd;
     ok(fn(&net, fptr(d), fptr(dd, "dd"), fptr(h), fptr(hd, "hd"), col.data_ptr<int32_t>(), eid.data_ptr<int32_t>(),
           cnt.data_ptr<int32_t>(), (int)N, (int)col.size(1), mptr(m), tan ? mptr(md) : nullptr, want_sums ? mptr(hs) : nullptr,
@@ -317,14 +335,25 @@ std::tuple<Tensor, Tensor, Tensor> cfconv_bwd(const Tensor& mu, const Tensor& co
                                               const OptTensor& mb, const Tensor& mdb, const OptTensor& d_b, Tensor& dd_b,
                                               const OptTensor& n_valid, bool want_theta, bool bf16) {
     const MdgFilterNet net = filter_net(mu, coef, W1, b1, W2, b2);
-    check_f32(d, "d"); check_f32(h, "h"); check_f32(mdb, "mdb"); check_f32(dd_b, "dd_b");
+    const bool r16 = is_bf16(h);                 // bf16 mirrors of the four gathered matrices: mdg_cfconv_bwd_rows16
+    check_f32(d, "d"); check_f32(dd_b, "dd_b");
+    if (!r16) { check_f32(h, "h"); check_f32(mdb, "mdb"); }
     TORCH_CHECK(nbr.is_cuda() && nbr.scalar_type() == at::kLong && nbr.is_contiguous(), "mdgrad: nbr must be int64 on the device");
     const int64_t G = net.n_gauss, F = net.n_filters;
-    Tensor gW1 = at::empty({want_theta ? G : 0, G}, h.options()), gb1 = at::empty({want_theta ? G : 0}, h.options());
-    Tensor gW2 = at::empty({want_theta ? F : 0, G}, h.options());
-    Tensor ws = at::empty({want_theta ? std::max<int64_t>(1, mdg_cfconv_bwd_workspace((int)G, (int)F, n_edges)) : 0}, h.options());
+    const auto fo = h.options().dtype(at::kFloat);
+    Tensor gW1 = at::empty({want_theta ? G : 0, G}, fo), gb1 = at::empty({want_theta ? G : 0}, fo);
+    Tensor gW2 = at::empty({want_theta ? F : 0, G}, fo);
+    Tensor ws = at::empty({want_theta ? std::max<int64_t>(1, mdg_cfconv_bwd_workspace((int)G, (int)F, n_edges)) : 0}, fo);
     const int32_t* nv = nullptr;
     if (n_valid.has_value() && n_valid->defined()) { check_i32(*n_valid, "n_valid"); nv = n_valid->data_ptr<int32_t>(); }
+    if (r16) {
+        TORCH_CHECK(bf16, "mdgrad: bf16 node rows go with the bf16 filter kernels");
+        ok(mdg_cfconv_bwd_rows16(&net, fptr(d), fptr(dd, "dd"), nbr.data_ptr<int64_t>(), n_edges, (int)h.size(0), hptr(h, "h"),
+                                 hptr(hd, "hd"), hptr(mb, "mb"), hptr(mdb, "mdb"), const_cast<float*>(fptr(d_b, "d_b")), mptr(dd_b),
+                                 want_theta ? mptr(gW1) : nullptr, want_theta ? mptr(gb1) : nullptr, want_theta ? mptr(gW2) : nullptr,
+                                 nullptr, nullptr, want_theta ? mptr(ws) : nullptr, nv, stream_of(h)));
+        return {gW1, gb1, gW2};
+    }
     auto fn = bf16 ? mdg_cfconv_bwd_bf16 : mdg_cfconv_bwd;
     ok(fn(&net, fptr(d), fptr(dd, "dd"), nbr.data_ptr<int64_t>(), n_edges, fptr(h), fptr(hd, "hd"), fptr(mb, "mb"),
           fptr(mdb), const_cast<float*>(fptr(d_b, "d_b")), mptr(dd_b), want_theta ? mptr(gW1) : nullptr, want_theta ? mptr(gb1) : nullptr,

@@ -317,13 +317,69 @@ def _first_filter(net, z, P0):
     return r, buf
 
 
+def _wt(W):
+    """Contiguous copy of W.t() for the transposed stages of the row chains (MdgChainStage::Wt), in a persistent buffer on
+    the parameter: refreshed when the weights change (an optimizer step bumps their version); inside a HIP-graph capture
+    the buffer is returned as it is (the replaying pass refreshes it first, `refresh_embedding`) -- or None when there is
+    none yet, and the kernels read W itself."""
+    buf = getattr(W, "_mdg_wt", None)
+    capturing = W.is_cuda and torch.cuda.is_current_stream_capturing()
+    if buf is None or tuple(buf.shape) != (W.shape[1], W.shape[0]) or buf.device != W.device:
+        if capturing:
+            return None
+        buf = W._mdg_wt = torch.empty(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
+        W._mdg_wt_key = None
+    if capturing:
+        return buf
+    key = (W.data_ptr(), W._version)
+    if getattr(W, "_mdg_wt_key", None) != key:
+        buf.copy_(W.detach().t())
+        W._mdg_wt_key = key
+    return buf
+
+
+def _rows16(net, conv):
+    """Does this block's convolution read bf16 mirrors of its gathered node matrices (SchNet.node_rows_bf16)?"""
+    if not getattr(net, "node_rows_bf16", False):
+        return False
+    if not (getattr(conv, "filter_bf16", False) or getattr(net, "filter_bf16", False)):
+        return False
+    P = _layer_params(conv)
+    return bool(C_.load().mdg_cfconv_rows16_supported(int(P["mu"].shape[0]), int(P["W2"].shape[0])))
+
+
+def _h0_mirror(net, h):
+    """bf16 mirror of the first block's filtered rows (`_first_filter`): persistent like them, refreshed with them."""
+    buf = getattr(net, "_h0_buf16", None)
+    capturing = h.is_cuda and torch.cuda.is_current_stream_capturing()
+    if buf is None or buf.shape != h.shape or buf.device != h.device:
+        if capturing or h is not getattr(net, "_h0_buf", None):
+            return ops.rows_to_bf16(h)               # (no buffer yet: the conversion becomes part of this graph)
+        buf = net._h0_buf16 = torch.empty(h.shape, device=h.device, dtype=torch.bfloat16)
+        net._h0_key16 = None
+    if capturing:
+        return buf
+    if h is not getattr(net, "_h0_buf", None):
+        return ops.rows_to_bf16(h)
+    if getattr(net, "_h0_key16", None) != net._h0_key:
+        buf.copy_(h)                                 # (round to nearest even, as mdg_rows_to_bf16)
+        net._h0_key16 = net._h0_key
+    return buf
+
+
 def refresh_embedding(net, z):
     """Bring the persistent embedding rows (and the first block's filtered rows) up to date, before the graph replays
     of a pass."""
     for conv in net.convolutions:                                 # Gaussian coefficients of every layer (trainable widths)
         _gauss_coeff(conv.moduledict["message_edge_filter"][0])
     if fused_ok(net) and chain_ok(net):
-        _first_filter(net, z, _layer_params(net.convolutions[0]))
+        _, h0 = _first_filter(net, z, _layer_params(net.convolutions[0]))
+        if _rows16(net, net.convolutions[0]):
+            _h0_mirror(net, h0)
+        for conv in net.convolutions:                             # transposed copies for the reverse stages of the row chains
+            P = _layer_params(conv)
+            _wt(P["Wn"]); _wt(P["U1"]); _wt(P["U2"])
+        _wt(net.atomwisereadout.readout["energy"][0].weight)
     else:
         _embedded(net, z)
 
@@ -473,31 +529,36 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     convs = list(net.convolutions)
     Ps = [_layer_params(c) for c in convs]
     fns = [ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"],
-                         bf16=getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False)) for c, P in zip(convs, Ps)]
+                         bf16=getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False),
+                         rows16=getattr(net, "node_rows_bf16", False)) for c, P in zip(convs, Ps)]
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     N, dev = z.shape[0], x.device
     (r, h), rd, hd = _first_filter(net, z, Ps[0]), None, None      # r_dot^0 = 0; message_node_filter of the first block
+    # rows16 blocks gather bf16 mirrors (hg, hgd) of (h, hd); the chain stage that produces a block's rows writes them
+    hg, hgd = (_h0_mirror(net, h) if fns[0].rows16 else h), None
     layers, turn = [], None
     for i, P in enumerate(Ps):
-        m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, h, hd, topo, want_sums)
+        m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, hg, hgd, topo, want_sums)
         ch = ops.RowChain(N, dual, dev)
         a = ch.stage(P["U1"], bias=P["c1"], act=True, in0=m, in1=md, want_sig=True)         # t, su, td
         b = ch.stage(P["U2"], bias=P["c2"], res0=r, res1=rd)                                # residual (schnet.py:149-151)
-        layers.append(dict(P=P, fn=fns[i], r=r, rd=rd, h=h, hd=hd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=a.out0, su=a.sig,
-                           td=a.out1))
+        layers.append(dict(P=P, fn=fns[i], r=r, rd=rd, h=hg, hd=hgd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=a.out0, su=a.sig,
+                           td=a.out1))                            # (h / hd: what this block's kernels gather)
         r, rd = b.out0, b.out1
         if i + 1 < len(Ps):
-            c = ch.stage(Ps[i + 1]["Wn"], bias=Ps[i + 1]["bn"])
+            # (a rows16 block reads its filtered rows through the mirrors only: the f32 copies are not written)
+            c = ch.stage(Ps[i + 1]["Wn"], bias=Ps[i + 1]["bn"], mirror=fns[i + 1].rows16, store=not fns[i + 1].rows16)
             h, hd = c.out0, c.out1
+            hg, hgd = (c.out0_h, c.out1_h) if fns[i + 1].rows16 else (h, hd)
         else:
             y = ch.stage(L1, bias=l1, act=True, mode=C_.CHAIN_HEAD, aux0=L2, want_sig=True, want_pre=(want_energy, True))
-            g = ch.stage(L1, trans=True)                                                    # rdb, rb
+            g = ch.stage(L1, trans=True, Wt=_wt(L1))                                                    # rdb, rb
             if dual:
-                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)   # udb, ub
+                e = ch.stage(P["U2"], trans=True, Wt=_wt(P["U2"]), mode=C_.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)   # udb, ub
             else:
-                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=a.sig)
-            f = ch.stage(P["U1"], trans=True)                                               # mdb, mb
+                e = ch.stage(P["U2"], trans=True, Wt=_wt(P["U2"]), mode=C_.CHAIN_MUL, aux0=a.sig)
+            f = ch.stage(P["U1"], trans=True, Wt=_wt(P["U1"]), mirror=fns[i].rows16)                         # mdb, mb
             turn = dict(y=y, g=g, e=e, f=f)
         ch.run()
     y = turn["y"]
@@ -511,19 +572,21 @@ def _force_chain(net, z, x, topo, want_energy=True):
     fw, turn = _chain_forward(net, z, x, topo, None, False, want_energy)
     d, layers = fw["d"], fw["layers"]
     rb, mb = turn["g"].out0, turn["f"].out0
+    mg = turn["f"].out0_h if layers[-1]["fn"].rows16 else mb     # (what the block's kernels gather: the bf16 mirror or mb itself)
     dU_dd = torch.zeros_like(d)
     for idx in range(len(layers) - 1, -1, -1):
         L = layers[idx]
-        ops.cfconv_bwd(L["fn"], d, None, topo, L["h"], None, None, mb, None, dU_dd)
+        ops.cfconv_bwd(L["fn"], d, None, topo, L["h"], None, None, mg, None, dU_dd)
         if idx > 0:                                               # (the embedding below layer 0 is not needed)
-            hb = ops.cfconv_fwd(L["fn"], d, None, mb, None, topo)[0]
+            hb = ops.cfconv_fwd(L["fn"], d, None, mg, None, topo)[0]
             Lp = layers[idx - 1]
             ch = ops.RowChain(z.shape[0], False, x.device)
-            g = ch.stage(L["P"]["Wn"], trans=True, in0=hb, res0=rb)
-            ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
-            f = ch.stage(Lp["P"]["U1"], trans=True)
+            g = ch.stage(L["P"]["Wn"], trans=True, Wt=_wt(L["P"]["Wn"]), in0=hb, res0=rb)
+            ch.stage(Lp["P"]["U2"], trans=True, Wt=_wt(Lp["P"]["U2"]), mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
+            f = ch.stage(Lp["P"]["U1"], trans=True, Wt=_wt(Lp["P"]["U1"]), mirror=Lp["fn"].rows16)
             ch.run()
             rb, mb = g.out0, f.out0
+            mg = f.out0_h if Lp["fn"].rows16 else mb
     F, _ = ops.edge_geom_bwd(None, dU_dd, None, None, fw["uhat"], None, topo)
     return fw["U"], F
 
@@ -538,6 +601,8 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
     rdb, rb = turn["g"].out0, turn["g"].out1
     udb, ub = turn["e"].out0, turn["e"].out1
     mdb, mb = turn["f"].out0, turn["f"].out1
+    r16 = layers[-1]["fn"].rows16                                 # (mdg, mg: what the block's kernels gather -- bf16 mirrors or the rows)
+    mdg, mg = (turn["f"].out0_h, turn["f"].out1_h) if r16 else (mdb, mb)
     jobs = acc = None
     if want_theta:
         acc = accum if accum is not None else ops.ThetaAccum(net.parameters())
@@ -558,7 +623,7 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             jobs.atb(off(md_["update_function"][0].weight), udb, L["md"], ub, L["m"])
             jobs.colsum(off(md_["update_function"][0].bias), ub)
         smear_t = want_theta and _trainable_smear(convs[idx])
-        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mb, mdb, d_b, dd_b, want_theta, want_smear=smear_t)
+        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mg, mdg, d_b, dd_b, want_theta, want_smear=smear_t)
         if smear_t:
             sm = md_["message_edge_filter"][0]
             jobs.axpy(off(sm.offsets), th[3])
@@ -572,7 +637,7 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             else:
                 jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"])
         if want_theta or idx > 0:
-            hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdb, mb, topo)
+            hdb, hb, _, _ = ops.cfconv_fwd(L["fn"], d, dd, mdg, mg, topo)
             if want_theta:
                 if L["rd"] is not None:
                     jobs.atb(off(md_["message_node_filter"].weight), hb, L["r"], hdb, L["rd"])
@@ -582,15 +647,16 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             if idx > 0:
                 Lp = layers[idx - 1]
                 ch = ops.RowChain(z.shape[0], True, x.device)
-                g = ch.stage(P["Wn"], trans=True, in0=hdb, in1=hb, res0=rdb, res1=rb)
-                e = ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
-                f = ch.stage(Lp["P"]["U1"], trans=True)
+                g = ch.stage(P["Wn"], trans=True, Wt=_wt(P["Wn"]), in0=hdb, in1=hb, res0=rdb, res1=rb)
+                e = ch.stage(Lp["P"]["U2"], trans=True, Wt=_wt(Lp["P"]["U2"]), mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
+                f = ch.stage(Lp["P"]["U1"], trans=True, Wt=_wt(Lp["P"]["U1"]), mirror=Lp["fn"].rows16)
                 ch.run()
                 rdb, rb, udb, ub, mdb, mb = g.out0, g.out1, e.out0, e.out1, f.out0, f.out1
+                mdg, mg = (f.out0_h, f.out1_h) if Lp["fn"].rows16 else (mdb, mb)
             else:
                 # below the first block only the embedding rows' adjoint in U_dot is left (r_dot^0 = 0)
                 ch = ops.RowChain(z.shape[0], False, x.device)
-                rb = ch.stage(P["Wn"], trans=True, in0=hb, res0=rb).out0
+                rb = ch.stage(P["Wn"], trans=True, Wt=_wt(P["Wn"]), in0=hb, res0=rb).out0
                 ch.run()
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
     if not want_theta:

@@ -94,6 +94,12 @@ class SchNetConv(nn.Module):
 class SchNet(nn.Module):
     """nff/nn/models/schnet.py:23-171."""
 
+    # Analytic path (mdgrad_amd/nn/analytic.py), with filter_bf16 on the row-chain kernels: the node matrices the convolution
+    # kernels GATHER per edge are read from bf16 mirrors (mdg_cfconv_*_rows16, include/mdgrad_hip.h).  A precision option of
+    # its own on top of the bf16 MFMA operands -- the gathered features carry 8 significant bits into f32 products -- and off
+    # unless asked for; tests/test_gpu_schnet_rows16.py holds its tolerance.
+    node_rows_bf16 = False
+
     def __init__(self, modelparams):
         super().__init__()
         n_atom_basis = modelparams['n_atom_basis']

@@ -1321,8 +1321,12 @@ class FilterNet:
 
     bf16_reverse = True                          # ... and in the reverse sweep of the filter network (mdg_cfconv_bwd_bf16)
 
-    def __init__(self, mu, coef, W1, b1, W2, b2, bf16=False):
+    def __init__(self, mu, coef, W1, b1, W2, b2, bf16=False, rows16=False):
         self.bf16 = bool(bf16)                   # bf16 MFMA operands in the forward / tangent / aggregation sweeps
+        # ... and bf16 MIRRORS of the gathered node matrices (mdg_cfconv_*_rows16: a precision option of its own, see
+        # include/mdgrad_hip.h); the callers hand cfconv_fwd / cfconv_bwd torch.bfloat16 matrices then
+        self.rows16 = bool(rows16 and bf16 and self.bf16_reverse and
+                           _lib.load().mdg_cfconv_rows16_supported(int(mu.shape[0]), int(W2.shape[0])))
         self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
         self.G, self.F = int(self.t[0].shape[0]), int(self.t[4].shape[0])
         self.mu, self.coef, self.W1, self.b1, self.W2, self.b2 = self.t
@@ -1382,11 +1386,16 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     """(m, md, hsum, hdsum): filter generation + gather-multiply + per-atom sum in one kernel; with dd the
     forward-mode tangent rides along (hd may be None: no node tangent yet)."""
     lib = _lib.load()
-    require_gpu(h, "h")
+    require_gpu(h, "h", dtype=None)
+    if h.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("mdgrad_amd: h must be float32 (or a bfloat16 mirror for the rows16 kernels), got %s" % h.dtype)
     h = h.contiguous()
     hd = hd.contiguous() if hd is not None else None
     e = topo.ell
     N, dev = topo.n_atoms, h.device
+    r16 = h.dtype == torch.bfloat16               # bf16 mirrors of the node rows: the rows16 kernels
+    if r16:
+        assert fnet.bf16 and (hd is None or hd.dtype == torch.bfloat16), "cfconv_fwd: bf16 node rows go with the bf16 filter kernels"
     tops = _torch_ops.get()
     if tops is not None:
         m, md, hsum, hdsum = tops.cfconv_fwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, bool(fnet.bf16), d, dd,
@@ -1397,7 +1406,7 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     md = torch.empty(N, fnet.F, device=dev) if dd is not None else None
     hsum = torch.empty(N, fnet.F, device=dev) if want_sums else None
     hdsum = torch.empty(N, fnet.F, device=dev) if (want_sums and hd is not None) else None
-    fn = lib.mdg_cfconv_fwd_bf16 if fnet.bf16 else lib.mdg_cfconv_fwd
+    fn = lib.mdg_cfconv_fwd_rows16 if r16 else (lib.mdg_cfconv_fwd_bf16 if fnet.bf16 else lib.mdg_cfconv_fwd)
     check(fn(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(h), ptr(hd), ptr(e.col), ptr(topo.eid), ptr(e.cnt),
              N, e.max_nbr, ptr(m), ptr(md), ptr(hsum), ptr(hdsum), stream_ptr(dev)), "mdg_cfconv_fwd")
     return m, md, hsum, hdsum
@@ -1413,6 +1422,10 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, w
     hd = hd.contiguous() if hd is not None else None
     mb = mb.contiguous() if mb is not None else None
     bf16 = bool(fnet.bf16 and fnet.bf16_reverse)
+    r16 = h.dtype == torch.bfloat16               # bf16 mirrors of the four gathered matrices: mdg_cfconv_bwd_rows16
+    if r16:
+        assert bf16 and all(t is None or t.dtype == torch.bfloat16 for t in (hd, mb, mdb)), \
+            "cfconv_bwd: bf16 node rows come for all gathered matrices, with the bf16 filter kernels"
     tops = _torch_ops.get()
     if tops is not None and not want_smear:
         out = tops.cfconv_bwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, d, dd, topo.nbr, int(topo.n_edges), h, hd,
@@ -1427,6 +1440,12 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, w
     if want_smear:
         assert want_theta, "the basis gradients come with the parameter gradients"
         gmu, gcf = torch.empty(fnet.G, device=dev), torch.empty(fnet.G, device=dev)
+    if r16:
+        check(lib.mdg_cfconv_bwd_rows16(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, int(h.shape[0]), ptr(h),
+                                        ptr(hd), ptr(mb), ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gmu),
+                                        ptr(gcf), ptr(ws), nv, stream_ptr(dev)), "mdg_cfconv_bwd_rows16")
+        return ((gW1, gb1, gW2, gmu, gcf) if want_smear else (gW1, gb1, gW2)) if want_theta else None
+    if want_smear:
         check(lib.mdg_cfconv_bwd_smear(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, ptr(h), ptr(hd), ptr(mb),
                                        ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gmu), ptr(gcf), ptr(ws), nv,
                                        int(bf16), stream_ptr(dev)), "mdg_cfconv_bwd_smear")
@@ -1602,7 +1621,7 @@ class GradJobs:
 
 
 class _ChainOut:
-    __slots__ = ("out0", "out1", "sig", "pre0", "pre1")
+    __slots__ = ("out0", "out1", "sig", "pre0", "pre1", "out0_h", "out1_h")
 
 
 class RowChain:
@@ -1619,33 +1638,50 @@ class RowChain:
         return all(1 <= int(w) <= _lib.CHAIN_MAX_WIDTH for w in widths)
 
     def stage(self, W, trans=False, bias=None, act=False, mode=0, in0=None, in1=None, res0=None, res1=None, aux0=None,
-              aux1=None, want_sig=False, want_pre=(False, False), store=True):
-        """-> the stage's output tensors (out0, out1, sig, pre0, pre1; None where not produced)."""
+              aux1=None, want_sig=False, want_pre=(False, False), store=True, mirror=False, Wt=None):
+        """-> the stage's output tensors (out0, out1, sig, pre0, pre1; None where not produced).  mirror: bf16 copies
+        out0_h / out1_h of the outputs as well (what the rows16 cfconv kernels gather); with store=False only they are
+        written.  Wt (trans stages): a contiguous copy of W.t() -- the compiled chain shapes then load the weights as vectors."""
         assert len(self.stages) < _lib.CHAIN_MAX_STAGES, "row chain: too many stages"
         W = W.detach().contiguous()
         K, M = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
         cont = lambda t: t.detach().contiguous() if t is not None else None
         ins = [cont(t) for t in (bias, in0, in1, res0, res1, aux0, aux1)]
+        if Wt is not None:
+            assert trans and tuple(Wt.shape) == (M, K) and Wt.is_contiguous() and Wt.dtype == torch.float32, "row chain: Wt is W.t()"
         new = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.float32) if on else None
         o = _ChainOut()
         o.out0, o.out1 = new(store), new(store and self.dual)
         o.sig = new(act and want_sig)
         o.pre0 = new(mode == _lib.CHAIN_HEAD and want_pre[0])
         o.pre1 = new(mode == _lib.CHAIN_HEAD and want_pre[1] and self.dual)
-        self.keep.extend([W] + ins)
-        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode)))
+        new_h = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.bfloat16) if on else None
+        o.out0_h, o.out1_h = new_h(mirror), new_h(mirror and self.dual)
+        self.keep.extend([W, Wt] + ins)
+        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode), Wt))
         return o
 
     def run(self):
         lib = _lib.load()
         arr = (_lib.MdgChainStage * len(self.stages))()
         p = lambda t: t.data_ptr() if t is not None else None
-        for st, (W, ins, o, K, M, trans, act, mode) in zip(arr, self.stages):
-            st.W = W.data_ptr()
+        for st, (W, ins, o, K, M, trans, act, mode, Wt) in zip(arr, self.stages):
+            st.W, st.Wt = W.data_ptr(), p(Wt)
             st.bias, st.in0, st.in1, st.res0, st.res1, st.aux0, st.aux1 = (p(t) for t in ins)
             st.out0, st.out1, st.sig, st.pre0, st.pre1 = p(o.out0), p(o.out1), p(o.sig), p(o.pre0), p(o.pre1)
+            st.out0_h, st.out1_h = p(o.out0_h), p(o.out1_h)
             st.K, st.M, st.trans, st.act, st.mode = K, M, trans, act, mode
         check(lib.mdg_row_chain(arr, len(self.stages), self.N, int(self.dual), stream_ptr(self.dev)), "mdg_row_chain")
+
+
+def rows_to_bf16(x):
+    """Round-to-nearest-even bf16 copy of an f32 node matrix [N, M] (M a multiple of 4): mdg_rows_to_bf16."""
+    lib = _lib.load()
+    require_gpu(x, "x")
+    x = x.contiguous()
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(lib.mdg_rows_to_bf16(ptr(x), x.shape[0], x.shape[1], x.shape[1], ptr(out), stream_ptr(x.device)), "mdg_rows_to_bf16")
+    return out
 
 
 def smear_bwd(gdb, gb, g, phi, dd, c, d_b, dd_b):

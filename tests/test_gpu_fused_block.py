@@ -546,6 +546,19 @@ def test_row_chain_path_equals_layer_by_layer_path(A, F, G, convs, R):
         res.append([U.reshape(1), F_, U2.reshape(1), F2, dq, F3, dq3, torch.cat([t.reshape(-1) for t in gth])])
     for k, (a, b) in enumerate(zip(*res)):
         close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "chained vs layer-by-layer #%d" % k)
+    # the transposed weight copies the reverse stages read (analytic._wt) follow an in-place update of the weights
+    with torch.no_grad():
+        for conv in net.convolutions:
+            conv.moduledict["update_function"][2].weight.mul_(1.25)
+            conv.moduledict["message_node_filter"].weight.add_(0.01)
+        net.atomwisereadout.readout["energy"][0].weight.mul_(0.8)
+    res = []
+    for chain in (True, False):
+        net.row_chain = chain
+        U2, F2, dq, gth = analytic.force_vjp(net, gnn._z(), q, w, gnn.inputs["_topo"])
+        res.append([F2, dq, torch.cat([t.reshape(-1) for t in gth])])
+    for k, (a, b) in enumerate(zip(*res)):
+        close(a, b, 1e-4, 2e-5 * float(b.abs().max()) + 1e-7, "chained vs layer-by-layer after a weight update #%d" % k)
 
 
 @pytest.mark.parametrize("walker", [False, True])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Timings of the fused SchNet interaction-block kernels and the node-level Dense kernel on the topology of
 bench.py --workload schnet4096 (4096 CG-water beads x R stacked replicas, cutoff 6, A64 / F128 / G30):
-    python tools/kbench_cfconv.py [--replicas 8] [--reps 20] [--bf16]
+    python tools/kbench_cfconv.py [--replicas 8] [--reps 20] [--bf16 | --rows16]
 HIP events on the launch stream; also the vehicle for rocprofv3 --pmc passes (tools/pmc_cfconv.sh)."""
 import argparse
 import os
@@ -18,7 +18,9 @@ def main():
     ap.add_argument("--replicas", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--rows16", action="store_true", help="--bf16 with bf16 mirrors of the gathered node rows (mdg_cfconv_*_rows16)")
     args = ap.parse_args()
+    args.bf16 = args.bf16 or args.rows16
     from mdgrad_amd import ops, units, _lib
     from mdgrad_amd.system import System, Diamond
     dev = "cuda:0"
@@ -39,10 +41,14 @@ def main():
     coef = torch.full((G,), -0.5 / float(mu[1] - mu[0]) ** 2, device=dev)
     net = (mu, coef, torch.randn(G, G, device=dev) / G ** 0.5, torch.randn(G, device=dev) * 0.1,
            torch.randn(F, G, device=dev) / G ** 0.5, torch.randn(F, device=dev) * 0.1)
-    fn = ops.FilterNet(*net, bf16=args.bf16)
+    fn = ops.FilterNet(*net, bf16=args.bf16, rows16=args.rows16)
     w = torch.randn(N, 3, device=dev)
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
     h, hd, mb, mdb = [torch.randn(N, F, device=dev) for _ in range(4)]
+    hf, hdf = h, hd                               # (f32 rows for the Dense case below)
+    if args.rows16:
+        assert fn.rows16
+        h, hd, mb, mdb = [ops.rows_to_bf16(v) for v in (h, hd, mb, mdb)]
     d_b, dd_b = torch.zeros(E, device=dev), torch.zeros(E, device=dev)
     r, rd = torch.randn(N, A, device=dev), torch.randn(N, A, device=dev)
     Wn, bn = torch.randn(F, A, device=dev) / 8, torch.randn(F, device=dev)
@@ -60,7 +66,8 @@ def main():
         ("cfconv_bwd dual (no hd)", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, None, mb, mdb, d_b, dd_b), ((E + 15) // 16) * 192),
         ("cfconv_bwd dual+theta (no hd)", lambda: ops.cfconv_bwd(fn, d, dd, topo, h, None, mb, mdb, d_b, dd_b, True), ((E + 15) // 16) * 352),
         ("dense A->F dual", lambda: ops.dense(Wn, r, bias=bn, x1=rd), 0),
-        ("dense F->A ssp dual", lambda: ops.dense(U1, h, bias=c1, act=True, x1=hd, want_sig=True), 0),
+        ("dense F->A ssp dual", lambda: ops.dense(U1, hf, bias=c1, act=True, x1=hdf, want_sig=True), 0),
+        ("rows_to_bf16 [N,F]", lambda: ops.rows_to_bf16(hf), 0),
         ("edge_geom (tangent)", lambda: ops.edge_geom(x, topo, w), 0),
         ("edge_geom_bwd", lambda: ops.edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, topo), 0),
         ("nbr build (cell, grouped)", lambda: ops.build_ell(x, cs, 6.0, group=len(atoms), max_nbr=ell.max_nbr), 0),
