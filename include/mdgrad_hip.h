@@ -586,8 +586,6 @@ typedef struct {
     float* pre1;
     uint16_t* out0_h;   /* nullable: bf16 mirrors [n_rows, M] of out0 / out1 (the rows16 kernels' inputs), written with them */
     uint16_t* out1_h;
-    const float* Wt;    /* nullable, trans = 1 only: the [M][K] copy of W (Wt[m*K + k] = W[k*M + m]) -- the compiled chain shapes
-                           then load a lane's weight fragment as 16-byte vectors along k instead of dword by dword */
     int32_t K, M, trans, act, mode, pad_;
 } MdgChainStage;
 int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream);

@@ -62,7 +62,7 @@ GRAD_ATB, GRAD_COLSUM, GRAD_AXPY, GRAD_JOBS_MAX = 0, 1, 2, 32
 class MdgChainStage(C.Structure):
     """One Dense stage of mdg_row_chain (include/mdgrad_hip.h)."""
     _fields_ = [(n, C.c_void_p) for n in ("W", "bias", "in0", "in1", "res0", "res1", "aux0", "aux1", "out0", "out1", "sig",
-                                          "pre0", "pre1", "out0_h", "out1_h", "Wt")] + \
+                                          "pre0", "pre1", "out0_h", "out1_h")] + \
                [(n, C.c_int32) for n in ("K", "M", "trans", "act", "mode", "pad_")]
 
 

@@ -320,37 +320,30 @@ __device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float 
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
 
-// TRANS: B[k][m] = W[k * M + m] (the reverse sweeps multiply with the transposed layer).  Wt, when the caller has one
-// (MdgChainStage::Wt), is the [M][K] copy of the same matrix: a lane's fragment is then K / 16 16-byte loads along k like a
-// Linear-layout stage instead of K / 4 dword loads -- 14 load instructions instead of 56 for the three transposed layers of the
-// turn chain at A = 64, F = 128.
 template <int K, int M, bool TRANS>
-__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, const float* __restrict__ Wt, int wid, int li, int lk,
-                                            float (&b)[spec_tp<M>()][K / 4]) {
-    const bool lin = !TRANS || Wt != nullptr;                       // (uniform)
-    const float* __restrict__ L = TRANS ? Wt : W;
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, float (&b)[spec_tp<M>()][K / 4]) {
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
         const int t = wid + 4 * tt;
         if (t * 16 >= M) continue;
         const int m = t * 16 + li;
-        if (lin) {
 #pragma unroll
-            for (int q = 0; q < K / 16; ++q) {
-                const float4 v = ld4(L + m * K + 16 * q + 4 * lk);
+        for (int q = 0; q < K / 16; ++q) {
+            if constexpr (!TRANS) {
+                const float4 v = ld4(W + m * K + 16 * q + 4 * lk);
                 b[tt][4 * q] = v.x; b[tt][4 * q + 1] = v.y; b[tt][4 * q + 2] = v.z; b[tt][4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int q = 0; q < K / 16; ++q)
+            } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) b[tt][4 * q + c] = W[(16 * q + 4 * lk + c) * M + m];
+            }
         }
     }
 }
 
-// bias (and the head vector of a HEAD stage) of the lane's 4 columns per tile: requested BEFORE the stage's matrix products,
-// so the epilogue behind the barrier does not start with a round trip of its own
+// bias (and the head vector of a HEAD stage) of the lane's 4 columns per tile.  The forward chain requests them BEFORE the
+// stage's matrix products, so that the epilogue behind the barrier does not start with a round trip of its own (dual forward
+// chain at 32 768 rows: 45.1 -> 41.9 us); the turn / reverse chains -- more weights in flight, no biases on their transposed
+// stages -- measured no gain from the same reordering and keep the loads where the values are used.
 template <int M, int MODE>
 __device__ __forceinline__ void spec_load_bias(const MdgChainStage& S, int wid, int lk, float (&bv)[spec_tp<M>()][4], float (&lv)[spec_tp<M>()][4]) {
 #pragma unroll
@@ -483,13 +476,12 @@ void chain_spec_kernel(const ChainArgs A) {
     float sgA[spec_tp<A_>()][4], tdA[spec_tp<A_>()][4], zA[spec_tp<A_>()][4], zF[spec_tp<F_>()][4], zH[spec_tp<H_>()][4];
     float dF[spec_tp<F_>()][4], dH[spec_tp<H_>()][4];                              // (sigmoid / tangent sinks of stages that keep none)
     spec_zero<A_>(zA); spec_zero<F_>(zF); spec_zero<H_>(zH);
-    if constexpr (KIND == SPEC_FWD || KIND == SPEC_TURN) {
+    if constexpr (KIND == SPEC_FWD) {
         // ---- first round trip: the weights of the first two stages, the input rows, the residual rows, the biases.  The
-        //      weights of a later stage are requested while the stage two before it multiplies (its own fragments are dead by
-        //      then), the bias of a stage before the stage's products: no epilogue starts with a round trip of its own.
+        //      weights of the third stage are requested while the first multiplies, each bias before its stage's products.
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
-        spec_load_w<F_, A_, false>(A.s[0].W, nullptr, wid, li, lk, w0);
-        spec_load_w<A_, A_, false>(A.s[1].W, nullptr, wid, li, lk, w1);
+        spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
+        spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
         spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
         float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
         spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
@@ -501,79 +493,94 @@ void chain_spec_kernel(const ChainArgs A) {
         __syncthreads();
         // stage 0: t = ssp(U1 m + c1), su, td
         spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        if constexpr (KIND == SPEC_FWD) {
-            float w2[spec_tp<F_>()][A_ / 4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
-            spec_load_w<A_, F_, false>(A.s[2].W, nullptr, wid, li, lk, w2);
-            spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
-            __syncthreads();
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
-            __syncthreads();
-            // stage 1: r' = U2 t + c2 + r
-            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-            __syncthreads();
-            {
-                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
-            }
-            __syncthreads();
-            // stage 2: h' = Wn' r' + bn'
-            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
-            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
-            __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
-        } else {
-            float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], b2[spec_tp<H_>()][4], l2[spec_tp<H_>()][4];
-            spec_load_w<A_, H_, false>(A.s[2].W, nullptr, wid, li, lk, w2);
-            spec_load_w<H_, A_, true>(A.s[3].W, A.s[3].Wt, wid, li, lk, w3);
-            spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, b2, l2);
-            __syncthreads();
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
-            __syncthreads();
-            // stage 1: r' = U2 t + c2 + r
-            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-            float w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
-            spec_load_w<A_, A_, true>(A.s[4].W, A.s[4].Wt, wid, li, lk, w4);
-            spec_load_w<A_, F_, true>(A.s[5].W, A.s[5].Wt, wid, li, lk, w5);
-            __syncthreads();
-            {
-                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
-            }
-            __syncthreads();
-            // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
-            f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
-            spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
-            __syncthreads();
-            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, b2, l2);
-            __syncthreads();
-            // stage 3: (rdb, rb) = (ydb, yb) L1
-            spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
-            __syncthreads();
-            {
-                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
-            }
-            __syncthreads();
-            // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
-            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w4, a0, a1);
-            __syncthreads();
-            {
-                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
-                                                                                    N, wid, li, lk, zA, zA);
-            }
-            __syncthreads();
-            // stage 5: (mdb, mb) = (udb, ub) U1
-            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
-            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
-            __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+        float w2[spec_tp<F_>()][A_ / 4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
+        spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
+        spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
+        __syncthreads();
+        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+        __syncthreads();
+        // stage 1: r' = U2 t + c2 + r
+        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+        __syncthreads();
+        {
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
         }
+        __syncthreads();
+        // stage 2: h' = Wn' r' + bn'
+        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
+        __syncthreads();
+        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
+    } else if constexpr (KIND == SPEC_TURN) {
+        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
+        spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
+        spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
+        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+        spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+        spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+        float bA[spec_tp<A_>()][4], lA[spec_tp<A_>()][4];
+        __syncthreads();
+        // stage 0: t = ssp(U1 m + c1), su, td
+        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+        __syncthreads();
+        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA, lA);
+        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA, zA);
+        __syncthreads();
+        // stage 1: r' = U2 t + c2 + r
+        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+        __syncthreads();
+        {
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA, lA);
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA, zA);
+        }
+        __syncthreads();
+        float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
+        spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
+        spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
+        spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
+        spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
+        // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
+        f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
+        spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
+        __syncthreads();
+        {
+            float bH[spec_tp<H_>()][4], lH[spec_tp<H_>()][4];
+            spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
+            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
+        }
+        __syncthreads();
+        // stage 3: (rdb, rb) = (ydb, yb) L1
+        spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
+        __syncthreads();
+        {
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+        }
+        __syncthreads();
+        // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
+        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w4, a0, a1);
+        __syncthreads();
+        {
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
+                                                                                N, wid, li, lk, zA, zA);
+        }
+        __syncthreads();
+        // stage 5: (mdb, mb) = (udb, ub) U1
+        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
+        __syncthreads();
+        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
     } else {
         // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
-        spec_load_w<F_, A_, true>(A.s[0].W, A.s[0].Wt, wid, li, lk, w0);
-        spec_load_w<A_, A_, true>(A.s[1].W, A.s[1].Wt, wid, li, lk, w1);
+        spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
+        spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
+        spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
         spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
         float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
         spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
@@ -584,7 +591,6 @@ void chain_spec_kernel(const ChainArgs A) {
         float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
         __syncthreads();
         spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        spec_load_w<A_, F_, true>(A.s[2].W, A.s[2].Wt, wid, li, lk, w2);      // (requested while the first stage multiplies)
         __syncthreads();
         spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
         __syncthreads();
@@ -607,7 +613,7 @@ int spec_kind(const MdgChainStage* s, int n, int dual, int A_, int F_) {
     for (int i = 0; i < n; ++i) {
         const MdgChainStage& t = s[i];
         if (!al(t.W) || !al(t.bias) || !al(t.in0) || !al(t.in1) || !al(t.res0) || !al(t.res1) || !al(t.aux0) || !al(t.aux1) ||
-            !al(t.out0) || !al(t.out1) || !al(t.sig) || !al(t.pre0) || !al(t.pre1) || !al(t.Wt))
+            !al(t.out0) || !al(t.out1) || !al(t.sig) || !al(t.pre0) || !al(t.pre1))
             return -1;
         if (i > 0 && t.in0) return -1;
     }
@@ -664,7 +670,6 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_HEAD || (s.act == 1 && s.aux0), "row_chain: stage %d: HEAD needs act = 1 and aux0", i);
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_MUL || s.aux0, "row_chain: stage %d: MUL needs aux0", i);
         MDG_CHECK_ARG(s.mode != MDG_CHAIN_SSP_BWD || (s.aux0 && (!dual || s.aux1)), "row_chain: stage %d: SSP_BWD needs aux0 (and aux1)", i);
-        MDG_CHECK_ARG(!s.Wt || s.trans, "row_chain: stage %d: Wt is the transposed copy of a trans = 1 stage's weights", i);
         MDG_CHECK_ARG((!s.out0_h && !s.out1_h) || (s.out0_h && s.M % 4 == 0 && (!dual || s.out1_h) && (((uintptr_t)s.out0_h | (uintptr_t)s.out1_h) & 7) == 0),
                       "row_chain: stage %d: bf16 mirrors come for both outputs, 8-byte aligned, widths in multiples of 4", i);
         wmax = s.K > wmax ? s.K : wmax;

@@ -317,27 +317,6 @@ def _first_filter(net, z, P0):
     return r, buf
 
 
-def _wt(W):
-    """Contiguous copy of W.t() for the transposed stages of the row chains (MdgChainStage::Wt), in a persistent buffer on
-    the parameter: refreshed when the weights change (an optimizer step bumps their version); inside a HIP-graph capture
-    the buffer is returned as it is (the replaying pass refreshes it first, `refresh_embedding`) -- or None when there is
-    none yet, and the kernels read W itself."""
-    buf = getattr(W, "_mdg_wt", None)
-    capturing = W.is_cuda and torch.cuda.is_current_stream_capturing()
-    if buf is None or tuple(buf.shape) != (W.shape[1], W.shape[0]) or buf.device != W.device:
-        if capturing:
-            return None
-        buf = W._mdg_wt = torch.empty(W.shape[1], W.shape[0], device=W.device, dtype=torch.float32)
-        W._mdg_wt_key = None
-    if capturing:
-        return buf
-    key = (W.data_ptr(), W._version)
-    if getattr(W, "_mdg_wt_key", None) != key:
-        buf.copy_(W.detach().t())
-        W._mdg_wt_key = key
-    return buf
-
-
 def _rows16(net, conv):
     """Does this block's convolution read bf16 mirrors of its gathered node matrices (SchNet.node_rows_bf16)?"""
     if not getattr(net, "node_rows_bf16", False):
@@ -376,10 +355,6 @@ def refresh_embedding(net, z):
         _, h0 = _first_filter(net, z, _layer_params(net.convolutions[0]))
         if _rows16(net, net.convolutions[0]):
             _h0_mirror(net, h0)
-        for conv in net.convolutions:                             # transposed copies for the reverse stages of the row chains
-            P = _layer_params(conv)
-            _wt(P["Wn"]); _wt(P["U1"]); _wt(P["U2"])
-        _wt(net.atomwisereadout.readout["energy"][0].weight)
     else:
         _embedded(net, z)
 
@@ -553,12 +528,12 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
             hg, hgd = (c.out0_h, c.out1_h) if fns[i + 1].rows16 else (h, hd)
         else:
             y = ch.stage(L1, bias=l1, act=True, mode=C_.CHAIN_HEAD, aux0=L2, want_sig=True, want_pre=(want_energy, True))
-            g = ch.stage(L1, trans=True, Wt=_wt(L1))                                                    # rdb, rb
+            g = ch.stage(L1, trans=True)                                                    # rdb, rb
             if dual:
-                e = ch.stage(P["U2"], trans=True, Wt=_wt(P["U2"]), mode=C_.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)   # udb, ub
+                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=a.sig, aux1=a.out1)   # udb, ub
             else:
-                e = ch.stage(P["U2"], trans=True, Wt=_wt(P["U2"]), mode=C_.CHAIN_MUL, aux0=a.sig)
-            f = ch.stage(P["U1"], trans=True, Wt=_wt(P["U1"]), mirror=fns[i].rows16)                         # mdb, mb
+                e = ch.stage(P["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=a.sig)
+            f = ch.stage(P["U1"], trans=True, mirror=fns[i].rows16)                         # mdb, mb
             turn = dict(y=y, g=g, e=e, f=f)
         ch.run()
     y = turn["y"]
@@ -581,9 +556,9 @@ def _force_chain(net, z, x, topo, want_energy=True):
             hb = ops.cfconv_fwd(L["fn"], d, None, mg, None, topo)[0]
             Lp = layers[idx - 1]
             ch = ops.RowChain(z.shape[0], False, x.device)
-            g = ch.stage(L["P"]["Wn"], trans=True, Wt=_wt(L["P"]["Wn"]), in0=hb, res0=rb)
-            ch.stage(Lp["P"]["U2"], trans=True, Wt=_wt(Lp["P"]["U2"]), mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
-            f = ch.stage(Lp["P"]["U1"], trans=True, Wt=_wt(Lp["P"]["U1"]), mirror=Lp["fn"].rows16)
+            g = ch.stage(L["P"]["Wn"], trans=True, in0=hb, res0=rb)
+            ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
+            f = ch.stage(Lp["P"]["U1"], trans=True, mirror=Lp["fn"].rows16)
             ch.run()
             rb, mb = g.out0, f.out0
             mg = f.out0_h if Lp["fn"].rows16 else mb
@@ -647,16 +622,16 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             if idx > 0:
                 Lp = layers[idx - 1]
                 ch = ops.RowChain(z.shape[0], True, x.device)
-                g = ch.stage(P["Wn"], trans=True, Wt=_wt(P["Wn"]), in0=hdb, in1=hb, res0=rdb, res1=rb)
-                e = ch.stage(Lp["P"]["U2"], trans=True, Wt=_wt(Lp["P"]["U2"]), mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
-                f = ch.stage(Lp["P"]["U1"], trans=True, Wt=_wt(Lp["P"]["U1"]), mirror=Lp["fn"].rows16)
+                g = ch.stage(P["Wn"], trans=True, in0=hdb, in1=hb, res0=rdb, res1=rb)
+                e = ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
+                f = ch.stage(Lp["P"]["U1"], trans=True, mirror=Lp["fn"].rows16)
                 ch.run()
                 rdb, rb, udb, ub, mdb, mb = g.out0, g.out1, e.out0, e.out1, f.out0, f.out1
                 mdg, mg = (f.out0_h, f.out1_h) if Lp["fn"].rows16 else (mdb, mb)
             else:
                 # below the first block only the embedding rows' adjoint in U_dot is left (r_dot^0 = 0)
                 ch = ops.RowChain(z.shape[0], False, x.device)
-                rb = ch.stage(P["Wn"], trans=True, Wt=_wt(P["Wn"]), in0=hb, res0=rb).out0
+                rb = ch.stage(P["Wn"], trans=True, in0=hb, res0=rb).out0
                 ch.run()
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)
     if not want_theta:

@@ -1638,17 +1638,15 @@ class RowChain:
         return all(1 <= int(w) <= _lib.CHAIN_MAX_WIDTH for w in widths)
 
     def stage(self, W, trans=False, bias=None, act=False, mode=0, in0=None, in1=None, res0=None, res1=None, aux0=None,
-              aux1=None, want_sig=False, want_pre=(False, False), store=True, mirror=False, Wt=None):
+              aux1=None, want_sig=False, want_pre=(False, False), store=True, mirror=False):
         """-> the stage's output tensors (out0, out1, sig, pre0, pre1; None where not produced).  mirror: bf16 copies
         out0_h / out1_h of the outputs as well (what the rows16 cfconv kernels gather); with store=False only they are
-        written.  Wt (trans stages): a contiguous copy of W.t() -- the compiled chain shapes then load the weights as vectors."""
+        written."""
         assert len(self.stages) < _lib.CHAIN_MAX_STAGES, "row chain: too many stages"
         W = W.detach().contiguous()
         K, M = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
         cont = lambda t: t.detach().contiguous() if t is not None else None
         ins = [cont(t) for t in (bias, in0, in1, res0, res1, aux0, aux1)]
-        if Wt is not None:
-            assert trans and tuple(Wt.shape) == (M, K) and Wt.is_contiguous() and Wt.dtype == torch.float32, "row chain: Wt is W.t()"
         new = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.float32) if on else None
         o = _ChainOut()
         o.out0, o.out1 = new(store), new(store and self.dual)
@@ -1657,16 +1655,16 @@ class RowChain:
         o.pre1 = new(mode == _lib.CHAIN_HEAD and want_pre[1] and self.dual)
         new_h = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.bfloat16) if on else None
         o.out0_h, o.out1_h = new_h(mirror), new_h(mirror and self.dual)
-        self.keep.extend([W, Wt] + ins)
-        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode), Wt))
+        self.keep.extend([W] + ins)
+        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode)))
         return o
 
     def run(self):
         lib = _lib.load()
         arr = (_lib.MdgChainStage * len(self.stages))()
         p = lambda t: t.data_ptr() if t is not None else None
-        for st, (W, ins, o, K, M, trans, act, mode, Wt) in zip(arr, self.stages):
-            st.W, st.Wt = W.data_ptr(), p(Wt)
+        for st, (W, ins, o, K, M, trans, act, mode) in zip(arr, self.stages):
+            st.W = W.data_ptr()
             st.bias, st.in0, st.in1, st.res0, st.res1, st.aux0, st.aux1 = (p(t) for t in ins)
             st.out0, st.out1, st.sig, st.pre0, st.pre1 = p(o.out0), p(o.out1), p(o.sig), p(o.pre0), p(o.pre1)
             st.out0_h, st.out1_h = p(o.out0_h), p(o.out1_h)

@@ -237,7 +237,7 @@ def test_host_side_of_the_row_chain_and_the_nh_half_step_scratch():
     replica, one ticket for the whole grid)."""
     from mdgrad_amd import _lib
     lib = _lib.load()
-    assert ctypes.sizeof(_lib.MdgChainStage) == 16 * 8 + 6 * 4      # (13 f32 pointers, 2 bf16 mirrors, Wt, 6 ints)
+    assert ctypes.sizeof(_lib.MdgChainStage) == 15 * 8 + 6 * 4      # (13 f32 pointers, 2 bf16 mirrors, 6 ints)
     dummy = ctypes.c_void_p(0x1000)                      # never dereferenced: every call below returns before its launch
     st = (_lib.MdgChainStage * 2)()
     st[0].W, st[0].in0, st[0].K, st[0].M = dummy, dummy, 64, 32

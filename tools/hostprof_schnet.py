@@ -1,0 +1,67 @@
+#!/usr/bin/env python
+"""Where the HOST spends its time in one eager pass of bench.py's stacked SchNet workload (8 x 4096 beads: more pairs than
+graphs.MAX_EDGES, so every launch is issued from Python):  python tools/hostprof_schnet.py [--bf16-rows] [--passes 3]
+Prints the pass time with the GPU running asynchronously, the host-only time of the same pass (kernel launches are
+asynchronous: the time until the last launch is issued), and the cProfile top of the host side."""
+import argparse
+import cProfile
+import io
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bf16-rows", action="store_true")
+    ap.add_argument("--passes", type=int, default=3)
+    args = ap.parse_args()
+    import bench
+    from mdgrad_amd import units
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    dev = torch.device("cuda:0")
+    wl = bench.build_schnet_workload(dev, 8, True, 2000, rows16=args.bf16_rows)
+    integ, system = wl["integ"], wl["system"]
+    obs = rdf(system, nbins=60, r_range=(2.0, 6.0))
+    target = torch.ones(60, device=dev)
+    t = torch.Tensor([units.fs * i for i in range(11)]).to(dev)
+    params = list(integ.parameters())
+
+    def one():
+        for p in params:
+            p.grad = None
+        y0 = tuple(integ.get_inital_states(wrap=True))
+        v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        loss = (obs(q_t[::5])[2] - target).pow(2).mean()
+        loss.backward()
+        return loss
+
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    for _ in range(args.passes):
+        t0 = time.perf_counter()
+        one()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("pass: host issued everything after %.2f ms, GPU done after %.2f ms" % ((t1 - t0) * 1e3, (t2 - t0) * 1e3), flush=True)
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(args.passes):
+        one()
+    pr.disable()
+    torch.cuda.synchronize()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(35)
+    print(out.getvalue())
+
+
+if __name__ == "__main__":
+    main()
