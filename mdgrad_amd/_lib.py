@@ -126,7 +126,7 @@ _SIGNATURES = {
                                       C.c_int, P, P, P]),
     "mdg_nhc_rhs": (C.c_int, [P, P, P, P, P, P, C.c_float, C.c_int, C.c_int, C.c_int, P, P, P]),
     "mdg_nhc_vjp": (C.c_int, [P, P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, P, P, P]),
-    "mdg_row_chain": (C.c_int, [C.POINTER(MdgChainStage), C.c_int, C.c_int, C.c_int, P]),
+    "mdg_row_chain": (C.c_int, [P, C.c_int, C.c_int, C.c_int, P]),      # (MdgChainStage*: an array object or a raw address)
     "mdg_nhv_scratch_floats": (C.c_int64, [C.c_int, C.c_int]),
     "mdg_nhv_kick": (C.c_int, [P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, P, P, P, P, P]),
     "mdg_nhv_finish": (C.c_int, [P, P, P, P, P, P, P, P, P, P, P, C.c_float, P, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P,
@@ -224,7 +224,17 @@ def ptr(t):
 
 
 def stream_ptr(device=None):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """The current HIP stream of `device` (torch.device / index / None) as a void*: one call into torch's C layer
+    (torch.cuda.current_stream() builds a Stream object per call -- ~5 us, several hundred times per MD pass)."""
+    if device is None:
+        idx = torch.cuda.current_device()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = device.index if isinstance(device, torch.device) else torch.device(device).index
+        if idx is None:
+            idx = torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))
 
 
 def require_gpu(t, name="tensor", dtype=torch.float32):

@@ -80,7 +80,36 @@ def _species_onehot(z):
     return hit[1], hit[2]
 
 
+# The answers of supported / fused_ok / chain_ok depend on the network's STRUCTURE (module types, layer widths, a few
+# switches), not on its weights; an MD pass asks them several times per force evaluation, and walking the module tree costs
+# more host time than the launches it decides about (tools/hostprof_schnet.py).  They are cached on the network under a key
+# that names everything they read: the switches, the conv modules' identities and their layer shapes.
+def _structure_key(net):
+    convs = getattr(net, "convolutions", None)
+    if convs is None:
+        return None
+    return (getattr(net, "fused_block", True), getattr(net, "row_chain", True), os.environ.get("MDG_ROW_CHAIN", "1"),
+            tuple(id(c) for c in convs), id(net.atomwisereadout))
+
+
+def _cached(net, name, compute):
+    key = _structure_key(net)
+    if key is None:
+        return compute(net)
+    c = net.__dict__.get("_mdg_structure")
+    if c is None or c[0] != key:
+        c = (key, {})
+        net.__dict__["_mdg_structure"] = c
+    if name not in c[1]:
+        c[1][name] = compute(net)
+    return c[1][name]
+
+
 def supported(net):
+    return _cached(net, "supported", _supported)
+
+
+def _supported(net):
     from .schnet import SchNet
     if not isinstance(net, SchNet) or list(net.atomwisereadout.readout.keys()) != ["energy"]:
         return False
@@ -126,10 +155,21 @@ def _gauss_coeff(smear):
 
 
 def _layer_params(conv):
-    md = conv.moduledict
+    """The tensors of one interaction block by role.  The parameter OBJECTS are looked up once per conv module (the module
+    tree is walked ~25 times per block otherwise, per force evaluation); the cache is dropped when the block's submodules or
+    one of their parameters were replaced.  `c` (the Gaussian coefficients) is refreshed on every call."""
+    md = conv._modules["moduledict"]._modules
     f, n, u = md["message_edge_filter"], md["message_node_filter"], md["update_function"]
-    return dict(mu=f[0].offsets, c=_gauss_coeff(f[0]), W1=f[1].weight, b1=f[1].bias, W2=f[3].weight,
-                b2=f[3].bias, Wn=n.weight, bn=n.bias, U1=u[0].weight, c1=u[0].bias, U2=u[2].weight, c2=u[2].bias)
+    c = conv.__dict__.get("_mdg_P")
+    if c is None or c[0] is not f or c[1] is not n or c[2] is not u or c[3]["Wn"] is not n._parameters.get("weight") \
+            or c[3]["W2"] is not f[3]._parameters.get("weight") or c[3]["U2"] is not u[2]._parameters.get("weight"):
+        P = dict(mu=f[0].offsets, W1=f[1].weight, b1=f[1].bias, W2=f[3].weight, b2=f[3].bias, Wn=n.weight, bn=n.bias,
+                 U1=u[0].weight, c1=u[0].bias, U2=u[2].weight, c2=u[2].bias)
+        c = (f, n, u, P, f[0])
+        conv.__dict__["_mdg_P"] = c
+    P = dict(c[3])
+    P["c"] = _gauss_coeff(c[4])
+    return P
 
 
 @torch.no_grad()
@@ -214,6 +254,10 @@ class _blas_for:
 
 def fused_ok(net):
     """The fused interaction-block kernels take every layer of this network (and are not switched off)."""
+    return _cached(net, "fused_ok", _fused_ok)
+
+
+def _fused_ok(net):
     if getattr(net, "fused_block", True) is False:
         return False
     for conv in net.convolutions:
@@ -315,6 +359,21 @@ def _first_filter(net, z, P0):
         buf.copy_(_dense(Wn, r, bias=bn)[0])
         net._h0_key = key
     return r, buf
+
+
+def _filter_net(conv, P, bf16, rows16):
+    """ops.FilterNet of one block, rebuilt only when a tensor it points at was reallocated (its constructor is six
+    detach / contiguous calls and a ctypes struct: ~15 us, twice per force evaluation)."""
+    ts = [P[k] for k in ("mu", "c", "W1", "b1", "W2", "b2")]
+    if not all(t.dtype == torch.float32 and t.is_contiguous() for t in ts):
+        # (FilterNet would hold converted COPIES of these tensors: nothing to key a cache on)
+        return ops.FilterNet(*ts, bf16=bf16, rows16=rows16)
+    key = (bool(bf16), bool(rows16), bool(ops.FilterNet.bf16_reverse)) + tuple(t.data_ptr() for t in ts)
+    c = conv.__dict__.get("_mdg_fn")
+    if c is None or c[0] != key:
+        c = (key, ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"], bf16=bf16, rows16=rows16))
+        conv.__dict__["_mdg_fn"] = c
+    return c[1]
 
 
 def _rows16(net, conv):
@@ -486,6 +545,10 @@ def _force_vjp_fused(net, z, x, w, topo, want_theta=True, want_energy=True, accu
 #   reverse   [hb -> message_node_filter^T + residual -> U2^T -> ssp' -> U1^T]                     per inner block
 def chain_ok(net):
     """The row-chain kernel takes every node-level layer of this network (and is not switched off)."""
+    return _cached(net, "chain_ok", _chain_ok)
+
+
+def _chain_ok(net):
     if getattr(net, "row_chain", True) is False or os.environ.get("MDG_ROW_CHAIN", "1") == "0" or not fused_ok(net):
         return False
     ws = []
@@ -503,9 +566,8 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
     convs = list(net.convolutions)
     Ps = [_layer_params(c) for c in convs]
-    fns = [ops.FilterNet(P["mu"], P["c"], P["W1"], P["b1"], P["W2"], P["b2"],
-                         bf16=getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False),
-                         rows16=getattr(net, "node_rows_bf16", False)) for c, P in zip(convs, Ps)]
+    fns = [_filter_net(c, P, getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False),
+                       getattr(net, "node_rows_bf16", False)) for c, P in zip(convs, Ps)]
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     N, dev = z.shape[0], x.device
@@ -537,7 +599,10 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
             turn = dict(y=y, g=g, e=e, f=f)
         ch.run()
     y = turn["y"]
-    U = (y.pre0.mm(L2.t()) + l2).sum() if want_energy else None     # (the integrators only ask for forces)
+    U = None                                                        # (the integrators only ask for forces)
+    if want_energy:
+        with _node_blas():                                          # (the one library GEMM of this path)
+            U = (y.pre0.mm(L2.t()) + l2).sum()
     fw = dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=y.sig, syd=y.pre1, L1=L1, L2=L2, U=U)
     return fw, turn
 
@@ -647,9 +712,10 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
 @torch.no_grad()
 def force(net, z, x, topo, offsets=None, want_energy=True):
     if fused_ok(net):
+        if chain_ok(net):                                         # (no library GEMM on this path: nothing to switch)
+            return _force_chain(net, z, x.detach().contiguous(), topo, want_energy)
         with _node_blas():
-            fn = _force_chain if chain_ok(net) else _force_fused
-            return fn(net, z, x.detach().contiguous(), topo, want_energy)
+            return _force_fused(net, z, x.detach().contiguous(), topo, want_energy)
     topo = _stable(topo)
     with _blas_for(topo):
         fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
@@ -663,9 +729,10 @@ def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=Tru
     the device) instead of being returned when that is given.  (`offsets` is the topology's own image-flag array; the
     argument is kept for callers that pass it explicitly.)"""
     if fused_ok(net):
+        if chain_ok(net):                                         # (no library GEMM on this path: nothing to switch)
+            return _force_vjp_chain(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
         with _node_blas():
-            fn = _force_vjp_chain if chain_ok(net) else _force_vjp_fused
-            return fn(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
+            return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
     topo = _stable(topo)
     with _blas_for(topo):
         out = _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)

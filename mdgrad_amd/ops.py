@@ -12,6 +12,7 @@ import math
 import weakref
 
 import torch
+from array import array as _array
 
 from . import _lib
 from . import _torch_ops
@@ -1631,7 +1632,7 @@ class RowChain:
 
     def __init__(self, n_rows, dual, device):
         self.N, self.dual, self.dev = int(n_rows), bool(dual), device
-        self.stages, self.keep = [], []
+        self.stages, self.keep, self.words = [], [], []
 
     @staticmethod
     def supported(*widths):
@@ -1642,34 +1643,47 @@ class RowChain:
         """-> the stage's output tensors (out0, out1, sig, pre0, pre1; None where not produced).  mirror: bf16 copies
         out0_h / out1_h of the outputs as well (what the rows16 cfconv kernels gather); with store=False only they are
         written."""
+        # (host cost matters: a stacked SchNet pass builds ~70 chains, and below ~1 ms of GPU work per MD step the launch
+        #  thread is what the GPU waits for -- the descriptors are packed as plain integers, MdgChainStage's layout)
         assert len(self.stages) < _lib.CHAIN_MAX_STAGES, "row chain: too many stages"
-        W = W.detach().contiguous()
+        if not W.is_contiguous():
+            W = W.contiguous()
         K, M = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
-        cont = lambda t: t.detach().contiguous() if t is not None else None
-        ins = [cont(t) for t in (bias, in0, in1, res0, res1, aux0, aux1)]
-        new = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.float32) if on else None
+        N, dev, dual = self.N, self.dev, self.dual
         o = _ChainOut()
-        o.out0, o.out1 = new(store), new(store and self.dual)
-        o.sig = new(act and want_sig)
-        o.pre0 = new(mode == _lib.CHAIN_HEAD and want_pre[0])
-        o.pre1 = new(mode == _lib.CHAIN_HEAD and want_pre[1] and self.dual)
-        new_h = lambda on: torch.empty(self.N, M, device=self.dev, dtype=torch.bfloat16) if on else None
-        o.out0_h, o.out1_h = new_h(mirror), new_h(mirror and self.dual)
-        self.keep.extend([W] + ins)
-        self.stages.append((W, ins, o, int(K), int(M), int(bool(trans)), int(bool(act)), int(mode)))
+        f32, head = torch.float32, mode == _lib.CHAIN_HEAD
+        o.out0 = torch.empty(N, M, device=dev, dtype=f32) if store else None
+        o.out1 = torch.empty(N, M, device=dev, dtype=f32) if (store and dual) else None
+        o.sig = torch.empty(N, M, device=dev, dtype=f32) if (act and want_sig) else None
+        o.pre0 = torch.empty(N, M, device=dev, dtype=f32) if (head and want_pre[0]) else None
+        o.pre1 = torch.empty(N, M, device=dev, dtype=f32) if (head and want_pre[1] and dual) else None
+        o.out0_h = torch.empty(N, M, device=dev, dtype=torch.bfloat16) if mirror else None
+        o.out1_h = torch.empty(N, M, device=dev, dtype=torch.bfloat16) if (mirror and dual) else None
+        words, keep = self.words, self.keep
+        words.append(W.data_ptr())
+        keep.append(W)
+        for t in (bias, in0, in1, res0, res1, aux0, aux1):
+            if t is None:
+                words.append(0)
+            else:
+                if not t.is_contiguous():
+                    t = t.contiguous()
+                keep.append(t)
+                words.append(t.data_ptr())
+        for t in (o.out0, o.out1, o.sig, o.pre0, o.pre1, o.out0_h, o.out1_h):
+            words.append(0 if t is None else t.data_ptr())
+        words.append(int(K) | (int(M) << 32))                       # int32 K, M
+        words.append((1 if trans else 0) | ((1 if act else 0) << 32))   # int32 trans, act
+        words.append(int(mode))                                     # int32 mode, pad_
+        self.stages.append(o)
         return o
 
     def run(self):
         lib = _lib.load()
-        arr = (_lib.MdgChainStage * len(self.stages))()
-        p = lambda t: t.data_ptr() if t is not None else None
-        for st, (W, ins, o, K, M, trans, act, mode) in zip(arr, self.stages):
-            st.W = W.data_ptr()
-            st.bias, st.in0, st.in1, st.res0, st.res1, st.aux0, st.aux1 = (p(t) for t in ins)
-            st.out0, st.out1, st.sig, st.pre0, st.pre1 = p(o.out0), p(o.out1), p(o.sig), p(o.pre0), p(o.pre1)
-            st.out0_h, st.out1_h = p(o.out0_h), p(o.out1_h)
-            st.K, st.M, st.trans, st.act, st.mode = K, M, trans, act, mode
-        check(lib.mdg_row_chain(arr, len(self.stages), self.N, int(self.dual), stream_ptr(self.dev)), "mdg_row_chain")
+        buf = _array("Q", self.words)                               # [n_stages] MdgChainStage, 18 x 8 bytes each
+        assert len(self.words) == 18 * len(self.stages) and C.sizeof(_lib.MdgChainStage) == 144
+        check(lib.mdg_row_chain(buf.buffer_info()[0], len(self.stages), self.N, int(self.dual), stream_ptr(self.dev)),
+              "mdg_row_chain")
 
 
 def rows_to_bf16(x):
