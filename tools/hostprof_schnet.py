@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Where the HOST spends its time in one eager pass of bench.py's stacked SchNet workload (8 x 4096 beads: more pairs than
-graphs.MAX_EDGES, so every launch is issued from Python):  python tools/hostprof_schnet.py [--bf16-rows] [--passes 3]
+graphs.MAX_EDGES, so every launch is issued from Python):  python tools/hostprof_schnet.py [--bf16-rows | --f32] [--passes 3]
 Prints the pass time with the GPU running asynchronously, the host-only time of the same pass (kernel launches are
 asynchronous: the time until the last launch is issued), and the cProfile top of the host side."""
 import argparse
@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16-rows", action="store_true")
+    ap.add_argument("--f32", action="store_true")
     ap.add_argument("--passes", type=int, default=3)
     args = ap.parse_args()
     import bench
@@ -26,7 +27,7 @@ def main():
     from mdgrad_amd.observable import rdf
     from mdgrad_amd.sovlers import odeint_adjoint
     dev = torch.device("cuda:0")
-    wl = bench.build_schnet_workload(dev, 8, True, 2000, rows16=args.bf16_rows)
+    wl = bench.build_schnet_workload(dev, 8, not args.f32, 2000, rows16=args.bf16_rows)
     integ, system = wl["integ"], wl["system"]
     obs = rdf(system, nbins=60, r_range=(2.0, 6.0))
     target = torch.ones(60, device=dev)

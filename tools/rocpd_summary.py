@@ -2,6 +2,9 @@
 """Summarise rocprofv3 (ROCm 7.2 rocpd sqlite) outputs as text:
   python tools/rocpd_summary.py stats <results.db>          per-kernel time table (--kernel-trace --stats)
   python tools/rocpd_summary.py pmc   <results.db> [...]    per-kernel mean counter values (--pmc passes)
+  python tools/rocpd_summary.py gaps  <results.db> [n [last_ms]]   the n longest idle stretches between two kernels, with the
+                                                            kernels on either side, and the idle time by the kernel that
+                                                            follows; last_ms: only the last so many ms of the trace
 """
 import sqlite3
 import sys
@@ -34,6 +37,34 @@ def stats(path):
             100.0 * sum(v) / total, wg, grid, vg, sg, lds, scr))
 
 
+def gaps(path, n=25, last_ms=None):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    if last_ms is not None:
+        t_end = max(r[2] for r in rows)
+        rows = [r for r in rows if r[1] >= t_end - last_ms * 1e6]
+        busy = sum(r[2] - r[1] for r in rows)
+        print("# last %.1f ms of the trace: %d launches, busy %.3f ms" % (last_ms, len(rows), busy / 1e6))
+    out, by_next = [], defaultdict(lambda: [0, 0.0])
+    last_end, last_name = None, None
+    for name, st, en in rows:
+        if last_end is not None and st > last_end:
+            g = (st - last_end) / 1e3
+            out.append((g, last_name, name, (st - rows[0][1]) / 1e6))
+            by_next[name][0] += 1
+            by_next[name][1] += g
+        if last_end is None or en > last_end:
+            last_end, last_name = en, name
+    total = sum(g for g, _, _, _ in out)
+    print("# %d launches, idle between kernels %.3f ms in %d gaps" % (len(rows), total / 1e3, len(out)))
+    print("# longest gaps: us | at ms | after kernel -> before kernel")
+    for g, a, b, at in sorted(out, key=lambda x: -x[0])[:n]:
+        print("%10.1f | %9.2f | %s -> %s" % (g, at, short(a, 50), short(b, 50)))
+    print("# idle time by the kernel that follows: total us | gaps | mean us | kernel")
+    for name, (c, t) in sorted(by_next.items(), key=lambda kv: -kv[1][1])[:n]:
+        print("%10.1f | %5d | %8.1f | %s" % (t, c, t / c, short(name, 70)))
+
+
 def pmc(paths):
     for path in paths:
         cur = sqlite3.connect(path).cursor()
@@ -51,5 +82,7 @@ def pmc(paths):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25, float(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:
         pmc(sys.argv[2:])
