@@ -495,6 +495,19 @@ int mdg_cfconv_bwd_rows16(const MdgFilterNet* net /*host*/, const float* d, cons
                           int64_t n_edges, int n_atoms, const uint16_t* h16, const uint16_t* hd16, const uint16_t* mb16,
                           const uint16_t* mdb16, float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu,
                           float* gcoef, float* workspace, const int32_t* n_valid, void* stream);
+/* The reverse sweep with parameter gradients, every option in one entry.  flags: MDG_CFCONV_BF16 (bf16 MFMA operands as
+ * mdg_cfconv_bwd_bf16) | MDG_CFCONV_ROWS16 (with BF16: h, hd, mb, mdb are bf16 mirrors, n_atoms rows each).  gb2[n_filters]
+ * (nullable; needs mdg_cfconv_bias_column(n_gauss)): d/d b2 of the same scalar, sum over the edges of the filter output's
+ * adjoint rows -- it falls out of a spare padded column of the first filter layer whose activation is pinned to 1
+ * (csrc/cfconv_fused.hip: B2COL_BIAS), so the caller needs neither the neighbour sums of mdg_cfconv_fwd (hsum / hdsum) nor a
+ * reduction over atoms for it (nff/nn/modules.py:531-541: the bias of Dense(n_gaussians -> n_filters)' second layer).
+ * gmu / gcoef (nullable, together) as in mdg_cfconv_bwd_smear. */
+enum { MDG_CFCONV_BF16 = 1, MDG_CFCONV_ROWS16 = 2 };
+int mdg_cfconv_bias_column(int n_gauss);
+int mdg_cfconv_bwd_theta(const MdgFilterNet* net /*host*/, const float* d, const float* dd, const int64_t* nbr,
+                         int64_t n_edges, int n_atoms, const void* h, const void* hd, const void* mb, const void* mdb,
+                         float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gb2, float* gmu, float* gcoef,
+                         float* workspace, const int32_t* n_valid, int flags, void* stream);
 /* dst[r, c] = bf16(src[r * src_stride + c]), dense [n_rows, n_cols] bf16 (n_cols, src_stride multiples of 4) */
 int mdg_rows_to_bf16(const float* src, int64_t n_rows, int n_cols, int src_stride, uint16_t* dst, void* stream);
 

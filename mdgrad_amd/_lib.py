@@ -68,6 +68,7 @@ class MdgChainStage(C.Structure):
 
 CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512
 BONDED_BOND, BONDED_ANGLE = 0, 1                 # include/mdgrad_hip.h MDG_BONDED_*
+CFCONV_BF16, CFCONV_ROWS16 = 1, 2                # include/mdgrad_hip.h MDG_CFCONV_*
 
 P = C.c_void_p
 _SIGNATURES = {
@@ -170,6 +171,9 @@ _SIGNATURES = {
     "mdg_cfconv_bwd_rows16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                                         P, P]),
     "mdg_rows_to_bf16": (C.c_int, [P, C.c_int64, C.c_int, C.c_int, P, P]),
+    "mdg_cfconv_bias_column": (C.c_int, [C.c_int]),
+    "mdg_cfconv_bwd_theta": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P,
+                                       P, P, C.c_int, P]),
     "mdg_dense": (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, P, P, P, P, P, P, P, P, P]),
     "mdg_cfconv_filter": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),
     "mdg_cfconv_filter_bf16": (C.c_int, [P, C.c_int64, P, P, C.c_int, P, P, P, P, C.c_int, P, P]),

@@ -44,6 +44,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.69314718055994531f;
 constexpr float PAD_D = 1.0e4f;         // distance of an inert row: every Gaussian is exactly 0 there
+// The gradient of the second filter layer's BIAS for free (reverse sweeps with parameter gradients, n_gaussians below the
+// padded width GP): the padded column GP - 1 of the first layer has zero weights, so its pre-activation is its bias alone;
+// with the bias ln(2 e - 1) its activation ssp(.) is exactly 1 on every edge, and  gW2[f][GP - 1] = sum_e Wb[e][f] * 1  is
+// d/d b2[f] -- accumulated by the products that are there anyway.  Nothing else sees the column: W2, the transposed W1 and
+// the tangent operand are zero there, so its adjoints and tangents vanish (s_b, a_b, g_b and the gW1 / gb1 / basis terms).
+// (Without it the caller needs the neighbour sums of the node rows from the forward sweep and one more reduction over atoms.)
+constexpr float B2COL_BIAS = 1.4899244f;
 
 __host__ __device__ inline int s16m32(int n) {   // smallest s >= n with s % 32 == 16 (conflict-free B fetches)
     int s = (n + 31) / 32 * 32 - 16;
@@ -769,7 +776,7 @@ void cfconv_bwd_kernel(const BwdArgs A) {
         mus[k] = k < G ? A.net.mu[k] : 0.f;
         cfs[k] = c * LOG2E;
         c2s[k] = 2.f * c;
-        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+        b1s[k] = k < G ? A.net.b1[k] : ((THETA && k == GP - 1) ? B2COL_BIAS : 0.f);     // (see B2COL_BIAS)
     }
     __syncthreads();
 
@@ -1265,7 +1272,7 @@ void cfconv_bwd_bf16_kernel(const BwdArgs A) {
         mus[c] = c < G ? A.net.mu[c] : 0.f;
         cfs[c] = cc * LOG2E;
         c2s[c] = 2.f * cc;
-        b1s[c] = c < G ? A.net.b1[c] : 0.f;
+        b1s[c] = c < G ? A.net.b1[c] : ((THETA && c == GP - 1) ? B2COL_BIAS : 0.f);     // (see B2COL_BIAS)
     }
     __syncthreads();
 
@@ -1565,7 +1572,7 @@ size_t bwd_bf16_lds_bytes(bool theta) {
 constexpr int RED_WAVES = 16;
 __global__ __launch_bounds__(64 * RED_WAVES) void cfconv_bwd_reduce_kernel(
     const float* __restrict__ part, int nrec, int GP, int FP, int G, int F, float* __restrict__ gW1, float* __restrict__ gb1,
-    float* __restrict__ gW2, float* __restrict__ gmu, float* __restrict__ gcoef, int accumulate) {
+    float* __restrict__ gW2, float* __restrict__ gmu, float* __restrict__ gcoef, int accumulate, float* __restrict__ gb2) {
     __shared__ float red[RED_WAVES][64];
     const int REC0 = GP * GP + GP + FP * GP, REC = REC0 + 2 * GP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -1596,6 +1603,7 @@ __global__ __launch_bounds__(64 * RED_WAVES) void cfconv_bwd_reduce_kernel(
     } else if (t < REC0) {
         const int u = t - GP * GP - GP, f = u / GP, k = u % GP;
         if (f < F && k < G) gW2[(size_t)f * G + k] = s;
+        if (gb2 && f < F && k == GP - 1 && G < GP) gb2[f] = s;      // the bias column (B2COL_BIAS)
     } else {
         const int k = (t - REC0) % GP;
         float* out = t - REC0 < GP ? gmu : gcoef;                 // (nullable: asked for only with trainable smearing)
@@ -1736,6 +1744,10 @@ int bwd_blocks(long long n_edges, bool theta) {
 }
 
 }  // namespace
+
+extern "C" int mdg_cfconv_bias_column(int n_gauss) {
+    return n_gauss >= 1 && n_gauss <= 64 && n_gauss != 32 && n_gauss != 64;       // a spare padded column (B2COL_BIAS)
+}
 
 extern "C" int mdg_cfconv_supported(int n_gauss, int n_filters) {
     if (n_gauss < 1 || n_gauss > 64 || n_filters < 4) return 0;
@@ -1915,7 +1927,7 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
                     int64_t n_edges, const float* h, const float* hd, const float* mb, const float* mdb,
                     float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* workspace,
                     const int32_t* n_valid, void* stream, bool bf16, float* gmu = nullptr, float* gcoef = nullptr,
-                    bool rows16 = false) {
+                    bool rows16 = false, float* gb2 = nullptr) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
@@ -1931,9 +1943,13 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
             MDG_HIP(hipMemsetAsync(gW2, 0, sizeof(float) * F * G, st));
             if (gmu) MDG_HIP(hipMemsetAsync(gmu, 0, sizeof(float) * G, st));
             if (gcoef) MDG_HIP(hipMemsetAsync(gcoef, 0, sizeof(float) * G, st));
+            if (gb2) MDG_HIP(hipMemsetAsync(gb2, 0, sizeof(float) * F, st));
         }
         return MDG_OK;
     }
+    MDG_CHECK_ARG(!gb2 || (theta && mdg_cfconv_bias_column(net->n_gauss)),
+                  "cfconv_bwd: the bias-column gradient needs the parameter gradients and n_gaussians below the padded width (got %d)",
+                  net->n_gauss);
     MDG_CHECK_ARG(d && nbr && h && mdb && dd_b, "cfconv_bwd: null buffer");
     MDG_CHECK_ARG(!dual || (dd && d_b), "cfconv_bwd: the dual sweep needs dd and d_b");
     MDG_CHECK_ARG(dual || !hd, "cfconv_bwd: hd without the dual sweep");
@@ -1983,7 +1999,8 @@ int cfconv_bwd_impl(const MdgFilterNet* net, const float* d, const float* dd, co
     if (theta) {
         const int FP = 16 * FT, REC = GP * GP + 3 * GP + FP * GP;
         hipLaunchKernelGGL(cfconv_bwd_reduce_kernel, dim3((REC + 63) / 64), dim3(64 * RED_WAVES), 0, st, workspace, nb, GP, FP,
-                           net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, gmu, gcoef, f0 > 0 ? 1 : 0);
+                           net->n_gauss, a.net.F, gW1, gb1, gW2 + (size_t)f0 * net->n_gauss, gmu, gcoef, f0 > 0 ? 1 : 0,
+                           gb2 ? gb2 + f0 : nullptr);
         MDG_CHECK_LAUNCH("cfconv_bwd_reduce_kernel");
     }
     }
@@ -2060,4 +2077,23 @@ extern "C" int mdg_rows_to_bf16(const float* src, int64_t n_rows, int n_cols, in
                        (long long)n_rows, n_cols, src_stride, dst);
     MDG_CHECK_LAUNCH("rows_to_bf16_kernel");
     return MDG_OK;
+}
+
+// The reverse sweep with parameter gradients, every option in one entry: flags = MDG_CFCONV_BF16 (bf16 MFMA operands) |
+// MDG_CFCONV_ROWS16 (with BF16: h, hd, mb, mdb point at bf16 mirrors, see mdg_cfconv_fwd_rows16).  gb2[n_filters] (nullable,
+// mdg_cfconv_bias_column(n_gauss) != 0): the gradient of the second filter layer's bias, sum_e Wb[e][f].  gmu / gcoef
+// (nullable, together): the gradients of the Gaussian basis as in mdg_cfconv_bwd_smear.
+extern "C" int mdg_cfconv_bwd_theta(const MdgFilterNet* net, const float* d, const float* dd, const int64_t* nbr,
+                                    int64_t n_edges, int n_atoms, const void* h, const void* hd, const void* mb,
+                                    const void* mdb, float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gb2,
+                                    float* gmu, float* gcoef, float* workspace, const int32_t* n_valid, int flags,
+                                    void* stream) {
+    const bool bf16 = (flags & MDG_CFCONV_BF16) != 0, rows16 = (flags & MDG_CFCONV_ROWS16) != 0;
+    MDG_CHECK_ARG(net && gW1 && gb1 && gW2, "cfconv_bwd_theta: the parameter-gradient outputs are required");
+    MDG_CHECK_ARG(!rows16 || (bf16 && n_atoms > 0 && (long long)n_atoms * net->n_filters < (1LL << 30)),
+                  "cfconv_bwd_theta: bf16 node rows go with the bf16 kernels, n_atoms x n_filters below 2^30");
+    MDG_CHECK_ARG((gmu == nullptr) == (gcoef == nullptr), "cfconv_bwd_theta: the basis gradients come together");
+    return cfconv_bwd_impl(net, d, dd, nbr, n_edges, static_cast<const float*>(h), static_cast<const float*>(hd),
+                           static_cast<const float*>(mb), static_cast<const float*>(mdb), d_b, dd_b, gW1, gb1, gW2, workspace,
+                           n_valid, stream, bf16, gmu, gcoef, rows16, gb2);
 }

@@ -576,7 +576,9 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     hg, hgd = (_h0_mirror(net, h) if fns[0].rows16 else h), None
     layers, turn = [], None
     for i, P in enumerate(Ps):
-        m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, hg, hgd, topo, want_sums)
+        # (want_sums: the neighbour sums of the node rows, which the gradient of the second filter layer's bias is made of --
+        #  not needed where the reverse sweep hands that gradient out itself, FilterNet.b2col)
+        m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, hg, hgd, topo, want_sums and not fns[i].b2col)
         ch = ops.RowChain(N, dual, dev)
         a = ch.stage(P["U1"], bias=P["c1"], act=True, in0=m, in1=md, want_sig=True)         # t, su, td
         b = ch.stage(P["U2"], bias=P["c2"], res0=r, res1=rd)                                # residual (schnet.py:149-151)
@@ -663,7 +665,8 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             jobs.atb(off(md_["update_function"][0].weight), udb, L["md"], ub, L["m"])
             jobs.colsum(off(md_["update_function"][0].bias), ub)
         smear_t = want_theta and _trainable_smear(convs[idx])
-        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mg, mdg, d_b, dd_b, want_theta, want_smear=smear_t)
+        b2col = want_theta and L["fn"].b2col
+        th = ops.cfconv_bwd(L["fn"], d, dd, topo, L["h"], L["hd"], mg, mdg, d_b, dd_b, want_theta, want_smear=smear_t, want_b2=b2col)
         if smear_t:
             sm = md_["message_edge_filter"][0]
             jobs.axpy(off(sm.offsets), th[3])
@@ -672,7 +675,9 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
             jobs.axpy(off(md_["message_edge_filter"][1].weight), th[0])
             jobs.axpy(off(md_["message_edge_filter"][1].bias), th[1])
             jobs.axpy(off(md_["message_edge_filter"][3].weight), th[2])
-            if L["hdsum"] is not None:
+            if b2col:
+                jobs.axpy(off(md_["message_edge_filter"][3].bias), th[-1])
+            elif L["hdsum"] is not None:
                 jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"], mdb, L["hdsum"])
             else:
                 jobs.colsum(off(md_["message_edge_filter"][3].bias), mb, L["hsum"])

@@ -1328,6 +1328,8 @@ class FilterNet:
         # include/mdgrad_hip.h); the callers hand cfconv_fwd / cfconv_bwd torch.bfloat16 matrices then
         self.rows16 = bool(rows16 and bf16 and self.bf16_reverse and
                            _lib.load().mdg_cfconv_rows16_supported(int(mu.shape[0]), int(W2.shape[0])))
+        # the reverse sweep with parameter gradients can hand out d/d b2 as well (a spare padded column, mdg_cfconv_bwd_theta)
+        self.b2col = bool(_lib.load().mdg_cfconv_bias_column(int(mu.shape[0])))
         self.t = [x.detach().to(torch.float32).contiguous() for x in (mu, coef, W1, b1, W2, b2)]
         self.G, self.F = int(self.t[0].shape[0]), int(self.t[4].shape[0])
         self.mu, self.coef, self.W1, self.b1, self.W2, self.b2 = self.t
@@ -1413,10 +1415,11 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     return m, md, hsum, hdsum
 
 
-def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, want_smear=False):
+def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, want_smear=False, want_b2=False):
     """Adjoint of the filter network (see include/mdgrad_hip.h): accumulates into d_b / dd_b in place and returns
     (gW1, gb1, gW2) when want_theta -- plus (gmu, gcoef), the gradients of the Gaussian centres and coefficients, when
-    want_smear (trainable radial basis)."""
+    want_smear (trainable radial basis) -- plus gb2, the gradient of the second layer's bias, LAST when want_b2
+    (`fnet.b2col`: mdg_cfconv_bwd_theta)."""
     lib = _lib.load()
     dev = h.device
     h, mdb = h.contiguous(), mdb.contiguous()
@@ -1427,6 +1430,20 @@ def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, w
     if r16:
         assert bf16 and all(t is None or t.dtype == torch.bfloat16 for t in (hd, mb, mdb)), \
             "cfconv_bwd: bf16 node rows come for all gathered matrices, with the bf16 filter kernels"
+    if want_b2:
+        assert want_theta and fnet.b2col, "cfconv_bwd: the bias gradient comes with the parameter gradients (FilterNet.b2col)"
+        gW1, gb1 = torch.empty(fnet.G, fnet.G, device=dev), torch.empty(fnet.G, device=dev)
+        gW2, gb2 = torch.empty(fnet.F, fnet.G, device=dev), torch.empty(fnet.F, device=dev)
+        gmu = gcf = None
+        if want_smear:
+            gmu, gcf = torch.empty(fnet.G, device=dev), torch.empty(fnet.G, device=dev)
+        ws = torch.empty(max(1, int(lib.mdg_cfconv_bwd_workspace(fnet.G, fnet.F, topo.n_edges))), device=dev)
+        flags = (_lib.CFCONV_BF16 if bf16 else 0) | (_lib.CFCONV_ROWS16 if r16 else 0)
+        check(lib.mdg_cfconv_bwd_theta(C.byref(fnet.struct), ptr(d), ptr(dd), ptr(topo.nbr), topo.n_edges, int(h.shape[0]), ptr(h),
+                                       ptr(hd), ptr(mb), ptr(mdb), ptr(d_b), ptr(dd_b), ptr(gW1), ptr(gb1), ptr(gW2), ptr(gb2),
+                                       ptr(gmu), ptr(gcf), ptr(ws), ptr(getattr(topo, "n_valid", None)), flags, stream_ptr(dev)),
+              "mdg_cfconv_bwd_theta")
+        return (gW1, gb1, gW2, gmu, gcf, gb2) if want_smear else (gW1, gb1, gW2, gb2)
     tops = _torch_ops.get()
     if tops is not None and not want_smear:
         out = tops.cfconv_bwd(fnet.mu, fnet.coef, fnet.W1, fnet.b1, fnet.W2, fnet.b2, d, dd, topo.nbr, int(topo.n_edges), h, hd,

@@ -129,6 +129,46 @@ def test_fused_backward_kernel_plain_dual_and_theta(G, F, n_side):
     assert none is None and torch.equal(F2, F_)
 
 
+@pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (41, 128, 6), (30, 256, 6), (30, 128, 16), (25, 384, 6)])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "rows16"])
+def test_bias_gradient_from_the_spare_filter_column(G, F, n_side, mode):
+    """mdg_cfconv_bwd_theta's gb2 = d/d b2 of  sum_e Wdb_e . Wd_e + Wb_e . W_e  =  sum_e Wb_e  (W = s W2 + b2, Wd has no bias):
+    the padded column of the first filter layer with its activation pinned to 1.  Against the sum formed in torch, with the
+    other gradients unchanged by the column (f32: to rounding; bf16 operands: Wb is rounded to bf16 before it is summed)."""
+    from mdgrad_amd import ops
+    x, topo, net = _setup(G, F, seed=5 * G + F, n_side=n_side)
+    N, E = topo.n_atoms, topo.n_edges
+    w = torch.randn(N, 3, device=DEV)
+    d, uhat, dd, ddel = ops.edge_geom(x, topo, w)
+    fn = ops.FilterNet(*net, bf16=mode != "f32", rows16=mode == "rows16")
+    if mode == "rows16" and not fn.rows16:
+        pytest.skip("bf16 node rows need more than 64 filters")
+    assert fn.b2col
+    h, hd, mb, mdb = [torch.randn(N, F, device=DEV) for _ in range(4)]
+    if mode == "rows16":
+        h16, hd16, mb16, mdb16 = [ops.rows_to_bf16(v) for v in (h, hd, mb, mdb)]
+        h, hd, mb, mdb = [v.float() for v in (h16, hd16, mb16, mdb16)]
+    i, j = topo.nbr[:, 0], topo.nbr[:, 1]
+    for with_hd in (True, False):
+        Wb = mb[i] * h[j] + mb[j] * h[i]
+        if with_hd:
+            Wb = Wb + mdb[i] * hd[j] + mdb[j] * hd[i]
+        ref = Wb.double().sum(0).float()
+        args = (h16, hd16 if with_hd else None, mb16, mdb16) if mode == "rows16" else (h, hd if with_hd else None, mb, mdb)
+        d_b, dd_b = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        th = ops.cfconv_bwd(fn, d, dd, topo, *args, d_b, dd_b, want_theta=True, want_b2=True)
+        d_b2, dd_b2 = torch.zeros(E, device=DEV), torch.zeros(E, device=DEV)
+        th0 = ops.cfconv_bwd(fn, d, dd, topo, *args, d_b2, dd_b2, want_theta=True)
+        assert len(th) == 4 and len(th0) == 3
+        scale = float(Wb.abs().sum(0).max())                        # (a sum of E signed terms: errors relative to its terms)
+        close(th[3], ref, 0, (2e-6 if mode == "f32" else 3e-3) * scale, "gb2 (%s, hd=%s)" % (mode, with_hd))
+        for a, b in zip(th[:3], th0):
+            assert torch.equal(a, b), "the other parameter gradients do not see the column"
+        assert torch.equal(d_b, d_b2) and torch.equal(dd_b, dd_b2)
+    full = _setup(32, F, seed=2, n_side=n_side)[2]
+    assert not ops.FilterNet(*full).b2col, "no spare column at n_gaussians = 32"
+
+
 def test_fused_kernels_on_a_padded_fixed_capacity_topology():
     """StaticTopo (HIP-graph capture): padding rows (-1, -1) are inert in the edge-centric kernel."""
     from mdgrad_amd import ops
