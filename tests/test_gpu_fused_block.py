@@ -161,7 +161,8 @@ def test_bias_gradient_from_the_spare_filter_column(G, F, n_side, mode):
         th0 = ops.cfconv_bwd(fn, d, dd, topo, *args, d_b2, dd_b2, want_theta=True)
         assert len(th) == 4 and len(th0) == 3
         scale = float(Wb.abs().sum(0).max())                        # (a sum of E signed terms: errors relative to its terms)
-        close(th[3], ref, 0, (2e-6 if mode == "f32" else 3e-3) * scale, "gb2 (%s, hd=%s)" % (mode, with_hd))
+        # (f32: the partial sums of ~10^3..10^5 terms in f32, observed 2.4e-6; bf16 operands: 2^-9 per rounded term)
+        close(th[3], ref, 0, (1e-5 if mode == "f32" else 3e-3) * scale, "gb2 (%s, hd=%s)" % (mode, with_hd))
         for a, b in zip(th[:3], th0):
             assert torch.equal(a, b), "the other parameter gradients do not see the column"
         assert torch.equal(d_b, d_b2) and torch.equal(dd_b, dd_b2)

@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bf16-rows", action="store_true")
     ap.add_argument("--f32", action="store_true")
+    ap.add_argument("--opt", type=int, default=0, help="instead of the profile: N passes WITH an Adam step each, time per pass")
     ap.add_argument("--passes", type=int, default=3)
     args = ap.parse_args()
     import bench
@@ -48,6 +49,38 @@ def main():
     for _ in range(2):
         one()
     torch.cuda.synchronize()
+    if args.opt:
+        import gc
+        gcs = []
+
+        def on_gc(phase, info, _t=[0.0]):                      # how long every collection of the cyclic collector takes
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gcs.append((info["generation"], (time.perf_counter() - _t[0]) * 1e3, info["collected"]))
+        gc.callbacks.append(on_gc)
+        if os.environ.get("MDG_NO_GC") == "1":
+            gc.collect()
+            gc.disable()
+        opt = torch.optim.Adam(params, lr=1e-5)
+        vl = (wl["gnn"]._static or {}).get("verlet")
+        for k in range(args.opt):
+            b0 = vl.builds() if vl is not None else 0
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            opt.zero_grad(set_to_none=True)
+            one()
+            t1 = time.perf_counter()
+            opt.step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            print("pass %2d: fwd + adjoint %.2f ms, + Adam step %.2f ms, searches %d, capacity %s" % (
+                k, (t1 - t0) * 1e3, (t2 - t0) * 1e3, (vl.builds() - b0) if vl is not None else -1,
+                {kk: vv for kk, vv in (wl["gnn"]._static or {}).items() if kk in ("max_nbr", "capacity", "version")}), flush=True)
+            if gcs:
+                print("         collections during this pass (generation, ms, objects freed): %s" % [(g, round(ms, 2), c) for g, ms, c in gcs], flush=True)
+                del gcs[:]
+        return
     for _ in range(args.passes):
         t0 = time.perf_counter()
         one()
