@@ -1233,7 +1233,7 @@ template <int GP, int FT, bool DUAL, bool THETA, bool R16 = false>
 // (waves per SIMD: round 3 measured more waves as a loss -- with each k-block's gathers behind a divergent branch the sweep
 //  made 8-16 dependent round trips per tile whatever the occupancy, and the registers a second wave needed were spilled.  With
 //  the batched unconditional gathers of gather_adjoint_rows_bf16 the state fits two waves: LDS allows three workgroups per CU)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (THETA ? 2 : (DUAL ? 2 : 3)) : 1)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (THETA ? 2 : (DUAL ? (R16 ? 3 : 2) : (R16 ? 4 : 3))) : 1)))
 void cfconv_bwd_bf16_kernel(const BwdArgs A) {
     static_assert(!R16 || FT == 8, "bf16 node rows: layers of more than 64 filters");
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1321,7 +1321,8 @@ void cfconv_bwd_bf16_kernel(const BwdArgs A) {
         unsigned short* tb = tdb + 16 * SWB;
         constexpr int QB = DUAL ? (THETA ? 2 : 4) : FT;          // k-blocks gathered per round trip (registers in flight)
         if constexpr (R16) {
-            constexpr int QR = DUAL ? (THETA ? 4 : 8) : FT;      // (a 16-byte load carries two k-blocks: the same registers in flight)
+            constexpr int QR = DUAL ? 4 : FT;                    // (a 16-byte load carries two k-blocks; the dual sweep without
+                                                                 //  parameter gradients then fits three waves per SIMD: 196 -> 156 registers)
             if (DUAL && has_hd) gather_adjoint_rows_r16<FT, QR, SWB, DUAL, true, THETA>(A, ia, ja, va, li, lk, F, A.net.RS16, wdbp, wbp, tdb, tb);
             else gather_adjoint_rows_r16<FT, QR, SWB, DUAL, false, THETA>(A, ia, ja, va, li, lk, F, A.net.RS16, wdbp, wbp, tdb, tb);
         } else {
