@@ -722,11 +722,10 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     filt_peak = MFMA_BF16_PEAK_TF if args.bf16 else MFMA_F32_PEAK_TF
     t_min = filt_flops / (filt_peak * 1e12) + (step_flops - filt_flops) / (MFMA_F32_PEAK_TF * 1e12)
     std = R == 8 and T == 11 and bool(args.bf16)
-    bname = "cfconv_bwd_bf16_kernel<32, 8, true, true>" if args.bf16 else "cfconv_bwd_kernel<32, 8, true, true>"
+    bname = "cfconv_bwd_bf16_kernel<32, 8, true, true, false>" if args.bf16 else "cfconv_bwd_kernel<32, 8, true, true>"
     if rows16:
         bname = "cfconv_bwd_bf16_kernel<32, 8, true, true, true>"
-    cnt, why = _counters("schnet4096", bname) if (std and not rows16) else (None, "other geometry" if not rows16 else
-                                                                            "no counter pass for the rows16 kernels")
+    cnt, why = _counters("schnet4096rows" if rows16 else "schnet4096", bname) if std else (None, "other geometry")
     bpeak = MFMA_BF16_PEAK_TF if args.bf16 else MFMA_F32_PEAK_TF
     out["roofline"] = {
         "bound": "mfma", "kernel": bname.replace(", ", ",") + " (reverse sweep of the filter network with parameter gradients: "

@@ -3,5 +3,5 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/q0
 rocprofv3 --kernel-trace --stats -d /tmp/q0 -o run -- python $R/tools/gbench.py gnn4096 --steps 20 --bf16 > /dev/null 2>&1
 DB0=$(find /tmp/q0 -name "*results.db" | head -1)
-python $R/tools/rocpd_summary.py stats $DB0 2>/dev/null | head -60 > $O/r03e_gnn4096_single_kernel_stats.txt
-cat $O/r03e_gnn4096_single_kernel_stats.txt | cut -c1-170
+python $R/tools/rocpd_summary.py stats $DB0 2>/dev/null | head -60 > $O/r04_gnn4096_single_kernel_stats.txt
+cat $O/r04_gnn4096_single_kernel_stats.txt | cut -c1-170

@@ -8,8 +8,9 @@ O=$R/gpurun_out/prof
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for W in $WL; do
-  EXTRA=""; [ "$W" = "schnet4096" ] && EXTRA="--bf16"
-  BENCH="python $R/bench.py --workload $W --steps 2 --warmup 1 --no-cpu-baseline $EXTRA"
+  EXTRA=""; WW=$W; [ "$W" = "schnet4096" ] && EXTRA="--bf16"
+  [ "$W" = "schnet4096rows" ] && { EXTRA="--bf16-rows"; WW=schnet4096; }      # (the rows16 precision option: records of its own)
+  BENCH="python $R/bench.py --workload $WW --steps 2 --warmup 1 --no-cpu-baseline $EXTRA"
   rm -rf /tmp/q0 /tmp/q1 /tmp/q2 /tmp/q3 /tmp/q4
   rocprofv3 --kernel-trace --stats -d /tmp/q0 -o run -- $BENCH > /dev/null 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/q1 -o run -- $BENCH > /dev/null 2>&1
