@@ -110,6 +110,54 @@ def _dist_record(mdist, dev, params, ms_rank):
     return rec
 
 
+# CPU legs (oracle baselines, parity of the timed geometry against the oracle) of a run over all workloads are collected here
+# and executed AFTER the last timed GPU leg: measured in round 4 -- with the oracle's 16-thread CPU work between the legs the
+# stacked SchNet pass took 27.6 ms instead of 26.3 and the lj4096 pass 22.9 instead of 20.9 (the same kernels, a slower host
+# / device right after the CPU burst); nothing about the legs themselves depends on the order.
+_DEFERRED = None
+
+
+def _later(fn):
+    if _DEFERRED is not None:
+        _DEFERRED.append(fn)
+    else:
+        fn()
+
+
+class _PassTrace:
+    """MDG_BENCH_TRACE=1: host time of every timed pass (the launches stay asynchronous: a pass that ends in a host sync, as
+    the SchNet passes do, shows its full time) and every collection of the cyclic collector, on stderr.  Diagnostics only."""
+
+    def __init__(self, name):
+        self.on = os.environ.get("MDG_BENCH_TRACE") == "1"
+        self.name, self.t, self.gcs, self._t0 = name, [], [], 0.0
+        if self.on:
+            import gc
+            gc.callbacks.append(self._gc)
+
+    def _gc(self, phase, info):
+        if phase == "start":
+            self._g0 = time.perf_counter()
+        else:
+            self.gcs.append((len(self.t), info["generation"], round((time.perf_counter() - self._g0) * 1e3, 2)))
+
+    def tick(self):
+        if self.on:
+            now = time.perf_counter()
+            self.t.append(round((now - self._t0) * 1e3, 2))
+            self._t0 = now
+
+    def start(self):
+        self._t0 = time.perf_counter()
+
+    def done(self):
+        if self.on:
+            import gc
+            gc.callbacks.remove(self._gc)
+            print("[trace %s] ms per pass: %s\n[trace %s] collections (pass, generation, ms): %s" % (
+                self.name, self.t, self.name, [g for g in self.gcs if g[2] >= 1.0]), file=sys.stderr, flush=True)
+
+
 def _host_cpus():
     """(os.cpu_count(), CPUs this process may actually use: the cgroup quota / affinity mask when one is set)."""
     total = os.cpu_count() or 1
@@ -377,7 +425,9 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
                 "frame-gradient loads, profiles/pmc_lj108.json) is ~40x below SURVEY 8d's unfused-chain bytes" % (
                     FLOP_PER_PAIR_RING, Pn, intervals, ring_ops, N * (N - 1) // 2)}
     if with_cpu and world == 1:
-        out["cpu_baseline"] = cpu_baseline_lj108(T, args.dt, check)
+        def cpu_part():
+            out["cpu_baseline"] = cpu_baseline_lj108(T, args.dt, check)
+        _later(cpu_part)
     return out
 
 
@@ -634,12 +684,16 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     builds0 = vl0.builds() if vl0 is not None else None
     mdist.barrier()
     torch.cuda.synchronize()
+    tr = _PassTrace("schnet4096")
     t0 = time.perf_counter()
+    tr.start()
     for _ in range(steps):
         loss, q_last = step()
+        tr.tick()
     torch.cuda.synchronize()
     mdist.barrier()
     el_rank = time.perf_counter() - t0
+    tr.done()
     el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(q_last) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
@@ -762,7 +816,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
             out["config"]["single_system"] = schnet_single_system(dev, bool(args.bf16))
         except Exception as e:
             out["config"]["single_system"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if with_cpu and world == 1:
+
+    def cpu_part():
         small = cpu_baseline_schnet()
         try:
             # THE TIMED GEOMETRY (8 x 4096 beads, 459 k edges: the eager pass on stored lists, many-row chains, 65 536-slot
@@ -782,6 +837,8 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
             out["cpu_baseline"]["parity_small_boxes"] = parity_schnet_stacked(dev, bool(args.bf16))
         except Exception as e:
             out["cpu_baseline"]["parity_small_boxes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if with_cpu and world == 1:
+        _later(cpu_part)
     return out
 
 
@@ -927,12 +984,16 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
         step()
     mdist.barrier()
     torch.cuda.synchronize()
+    tr = _PassTrace("lj4096")
     t0 = time.perf_counter()
+    tr.start()
     for _ in range(steps):
         loss, q_last = step()
+        tr.tick()
     torch.cuda.synchronize()
     mdist.barrier()
     el_rank = time.perf_counter() - t0
+    tr.done()
     el = mdist.max_over_ranks(el_rank, dev)
     if not (_finite(q_last) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
@@ -987,7 +1048,7 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
                                "kernel sources changed).  The pass is not bandwidth-bound: the kernel with the largest share, the "
                                "listed force + Hessian.w sweep of the adjoint, keeps the SIMDs' VALU issue slots busy (see "
                                "dominant_kernel); searches run one step in ~7 (Verlet reuse, device-side decision)" % Pn}
-    if with_cpu and world == 1:
+    def cpu_part():
         small = cpu_baseline_lj4096()
         try:
             # THE TIMED GEOMETRY: the last replica of the 64 x 4096-atom launch itself, 2 steps + RDF loss + adjoint, against
@@ -1009,6 +1070,8 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
             out["cpu_baseline"]["parity_small_boxes"] = parity_lj_large(dev)
         except Exception as e:
             out["cpu_baseline"]["parity_small_boxes"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if with_cpu and world == 1:
+        _later(cpu_part)
     return out
 
 
@@ -1052,6 +1115,9 @@ def main():
     elif args.workload == "lj4096":
         out = run_lj4096(args, rank, world, dev, mdist, cpu)
     else:
+        global _DEFERRED
+        if args.workload == "all" and not args.no_secondary:
+            _DEFERRED = []                      # (every timed GPU leg first, the CPU legs afterwards: see _DEFERRED)
         out = run_lj108(args, rank, world, dev, mdist, cpu)
         if args.workload == "all" and not args.no_secondary:
             sec = {}
@@ -1064,8 +1130,10 @@ def main():
             a16.bf16_rows = False
             # (warm-up passes: the first Adam step builds its state, and one of the first half-dozen passes of a process has
             #  been seen to take ~100 ms longer than the rest (tools/hostprof_schnet.py --opt: pass 4 or 6 of 12, once, not a
-            #  collection of the cyclic collector) -- six warm-up passes keep that out of the 28 timed ones)
-            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 28, 6, a16), ("lj4096", run_lj4096, 50, 3, args)):
+            #  collection of the cyclic collector; the lj4096 leg showed the same once: pass 5 of a fresh leg, 112 ms instead of
+            #  20.5 -- consistent with the caching allocator taking a multi-GB block from the driver for the first time) -- six /
+            #  eight warm-up passes keep that out of the timed ones)
+            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 28, 6, a16), ("lj4096", run_lj4096, 50, 8, args)):
                 try:
                     sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
                 except (Exception, SystemExit) as e:        # a secondary workload must not take the headline down
@@ -1091,6 +1159,12 @@ def main():
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["bf16_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["secondary"] = sec
+            pending, _DEFERRED = _DEFERRED, None
+            for fn in pending:
+                try:
+                    fn()
+                except (Exception, SystemExit) as e:        # (a CPU leg must not take the measured lines down)
+                    out.setdefault("cpu_leg_errors", []).append("%s: %s" % (type(e).__name__, e))
             # the two other north-star workloads, in keys the driver's parser keeps: value, time per pass,
             # the roofline fraction that binds each, and the CPU figure
             ns = {}
