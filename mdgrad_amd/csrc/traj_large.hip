@@ -133,6 +133,15 @@ __device__ __forceinline__ void sum_partial_rows(const float* __restrict__ part,
     block_sum_n<LG_NV>(tot, red);
 }
 
+struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };      // one [3] row of a [N][3] array: global_load_dwordx3
+__device__ __forceinline__ Row3 row3(const float* __restrict__ a, int j) { return *reinterpret_cast<const Row3*>(a + 3 * (size_t)j); }
+// the same at an element offset / as a store: the element-wise updates of large_prep request ALL rows of an atom in one
+// round trip (twelve-byte loads back to back, no store between them) and write its results afterwards -- taken component
+// by component through the state arrays, every store could alias the next component's loads and the three components
+// became three dependent round trips (18-26 us per launch at 2-3 TB/s)
+__device__ __forceinline__ Row3 ld3(const float* a, size_t e) { return *reinterpret_cast<const Row3*>(a + e); }
+__device__ __forceinline__ void st3(float* a, size_t e, float x, float y, float z) { *reinterpret_cast<Row3*>(a + e) = Row3{x, y, z}; }
+
 // ------------------------------------------------------------------------------------ per-replica preparation
 // Everything between two force launches runs in ONE launch of one 1 024-thread workgroup per replica: the
 // elementwise update of the integrator / adjoint (which ends in the positions of the next force evaluation), the
@@ -207,20 +216,25 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
-                float qn[3], mv2 = 0.f;
+                const size_t e3 = so + 3 * (size_t)a;
+                const Row3 vr = ld3(A.v, e3), fr = ld3(A.f, e3), qr = ld3(A.q, e3);
+                const Row3 qbr = lists ? ld3(qb, 3 * (size_t)a) : Row3{0.f, 0.f, 0.f};
+                const float vv[3] = {vr.x, vr.y, vr.z}, ff[3] = {fr.x, fr.y, fr.z}, qq[3] = {qr.x, qr.y, qr.z};
+                const float qbv[3] = {qbr.x, qbr.y, qbr.z};
+                float qn[3], hv[3], mv2 = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const size_t e = so + 3 * a + c;
-                    const float ve = A.v[e], p = ve * m;
-                    const float acc = nhc ? (A.f[e] - pv0 * p / A.prm.Q[0]) / m : A.f[e];     // (NVE: md.py:145-148)
+                    const float ve = vv[c], p = ve * m;
+                    const float acc = nhc ? (ff[c] - pv0 * p / A.prm.Q[0]) / m : ff[c];     // (NVE: md.py:145-148)
                     const float h = 0.5f * acc * dt;
-                    A.vh[e] = h;
-                    qn[c] = A.q[e] + (ve + h) * dt;
-                    A.q[e] = qn[c];
+                    hv[c] = h;
+                    qn[c] = qq[c] + (ve + h) * dt;
                     const float ph2 = (ve + h) * m;
                     part += ph2 * ph2 / m;
-                    if (lists) { const float mv = qn[c] - qb[3 * a + c]; mv2 = fmaf(mv, mv, mv2); }
+                    if (lists) { const float mv = qn[c] - qbv[c]; mv2 = fmaf(mv, mv, mv2); }
                 }
+                st3(A.vh, e3, hv[0], hv[1], hv[2]);
+                st3(A.q, e3, qn[0], qn[1], qn[2]);
                 far2 = fmaxf(far2, mv2);
                 px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
             }
@@ -268,16 +282,32 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                     lp[threadIdx.x] = nlp;
                 }
 #pragma unroll
-                for (int u = 0; u < 3 * NA; ++u) {
-                    const int e = tid + u * stride;
-                    if (e >= 3 * N) break;
-                    const float m = A.mass[e / 3];
-                    const float Gv = -(pvm0 / A.prm.Q[0]) * A.lvh[so + e] + A.lqh[so + e] + 2.f * m * A.vm[so + e] * lpm0;
-                    float nlv = A.lv[so + e] + Gv * h;                                  // :156
-                    float nlq = A.lq[so + e] + A.dq[so + e] * h;                        // :157
-                    if (A.g_v) nlv += A.g_v[go + e];                                    // :286
-                    if (A.g_q) nlq += A.g_q[go + e];
-                    A.lv[so + e] = nlv; A.lq[so + e] = nlq;
+                for (int u = 0; u < NA; ++u) {
+                    const int a = tid + u * stride;
+                    if (a >= N) break;
+                    const float m = A.mass[a];
+                    const size_t e3 = so + 3 * (size_t)a, g3 = go + 3 * (size_t)a;
+                    const Row3 lvhr = ld3(A.lvh, e3), lqhr = ld3(A.lqh, e3), vmr = ld3(A.vm, e3), lvr = ld3(A.lv, e3),
+                               lqr = ld3(A.lq, e3), dqr = ld3(A.dq, e3);
+                    const Row3 gvr = A.g_v ? ld3(A.g_v, g3) : Row3{0.f, 0.f, 0.f}, gqr = A.g_q ? ld3(A.g_q, g3) : Row3{0.f, 0.f, 0.f};
+                    const float lvh_[3] = {lvhr.x, lvhr.y, lvhr.z}, lqh_[3] = {lqhr.x, lqhr.y, lqhr.z}, vm_[3] = {vmr.x, vmr.y, vmr.z};
+                    const float lv_[3] = {lvr.x, lvr.y, lvr.z}, lq_[3] = {lqr.x, lqr.y, lqr.z}, dq_[3] = {dqr.x, dqr.y, dqr.z};
+                    const float gv_[3] = {gvr.x, gvr.y, gvr.z}, gq_[3] = {gqr.x, gqr.y, gqr.z};
+                    float nlv[3], nlq[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float Gv = -(pvm0 / A.prm.Q[0]) * lvh_[c] + lqh_[c] + 2.f * m * vm_[c] * lpm0;
+                        nlv[c] = lv_[c] + Gv * h;                                       // :156
+                        nlq[c] = lq_[c] + dq_[c] * h;                                   // :157
+                        if (A.g_v) nlv[c] += gv_[c];                                    // :286
+                        if (A.g_q) nlq[c] += gq_[c];
+                    }
+                    st3(A.lv, e3, nlv[0], nlv[1], nlv[2]);
+                    st3(A.lq, e3, nlq[0], nlq[1], nlq[2]);
+                    if (PHASE == 2 && A.nl_idx) {                                       // (w = lam_v / m of the coming listed evaluation)
+                        const float im = 1.0f / m;
+                        st3(A.wl, e3, nlv[0] * im, nlv[1] * im, nlv[2] * im);
+                    }
                 }
             } else {
                 // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
@@ -296,12 +326,16 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         if constexpr (PHASE == 2) {
             if (A.nl_idx) {
                 // the stored candidates of frame i serve; the listed evaluation gathers w = lam_v / m (NVE: lam_v) of
-                // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic)
+                // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic).
+                // (NHC intervals that were finished above wrote it with their update; this loop serves the last frame's
+                //  first interval -- nothing to finish -- and NVE)
+                if (!(nhc && i_fr <= T - 1)) {
 #pragma unroll
-                for (int u = 0; u < 3 * NA; ++u) {
-                    const int e = tid + u * stride;
-                    if (e >= 3 * N) break;
-                    A.wl[so + e] = nhc ? A.lv[so + e] * (1.0f / A.mass[e / 3]) : A.lv[so + e];
+                    for (int u = 0; u < 3 * NA; ++u) {
+                        const int e = tid + u * stride;
+                        if (e >= 3 * N) break;
+                        A.wl[so + e] = nhc ? A.lv[so + e] * (1.0f / A.mass[e / 3]) : A.lv[so + e];
+                    }
                 }
                 return;
             }
@@ -357,37 +391,47 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const int a = tid + u * stride;
             if (a < N) {
                 const float m = A.mass[a];
-                float qn[3], mv2 = 0.f, mv2B = 0.f;
+                const size_t e3 = so + 3 * (size_t)a, f3 = fo + 3 * (size_t)a;
+                // (all rows of the atom in one round trip: see ld3)
+                const Row3 ver = ld3(A.v_t, f3), qtr = ld3(A.q_t, f3), fr = ld3(A.f, e3), lvr = ld3(A.lv, e3), lqr = ld3(A.lq, e3),
+                           dqr = ld3(A.dq, e3), qar = ld3(qbA, 3 * (size_t)a), qbr = ld3(qbB, 3 * (size_t)a);
+                const float ve_[3] = {ver.x, ver.y, ver.z}, qt_[3] = {qtr.x, qtr.y, qtr.z}, f_[3] = {fr.x, fr.y, fr.z};
+                const float lv_[3] = {lvr.x, lvr.y, lvr.z}, lq_[3] = {lqr.x, lqr.y, lqr.z}, dq_[3] = {dqr.x, dqr.y, dqr.z};
+                const float qa_[3] = {qar.x, qar.y, qar.z}, qb_[3] = {qbr.x, qbr.y, qbr.z};
+                float qn[3], vmo[3], lvho[3], wlo[3], lqho[3], mv2 = 0.f, mv2B = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const size_t e = so + 3 * a + c, ef = fo + 3 * a + c;
-                    const float ve = A.v_t[ef];
+                    const float ve = ve_[c];
                     if (nhc) {
                         const float p = ve * m;
-                        const float acc = (A.f[e] - pv0 * p / A.prm.Q[0]) / m;
-                        const float Gv = -(pv0 / A.prm.Q[0]) * A.lv[e] + A.lq[e] + 2.f * m * ve * lp0;
+                        const float acc = (f_[c] - pv0 * p / A.prm.Q[0]) / m;
+                        const float Gv = -(pv0 / A.prm.Q[0]) * lv_[c] + lq_[c] + 2.f * m * ve * lp0;
                         const float vhalf = 0.5f * (-acc) * h;                           // :132
-                        qn[c] = A.q_t[ef] + (ve + vhalf) * h;                            // :138 (forward-time sign)
-                        A.vm[e] = ve + vhalf;
-                        const float lvh_ = A.lv[e] + Gv * 0.5f * h;                      // :141
-                        A.lvh[e] = lvh_;
-                        if (A.nl_idx) A.wl[e] = lvh_ * (1.0f / m);                       // (the listed midpoint evaluation's w)
-                        A.lqh[e] = A.lq[e] + A.dq[e] * 0.5f * h;                         // :142
+                        qn[c] = qt_[c] + (ve + vhalf) * h;                               // :138 (forward-time sign)
+                        vmo[c] = ve + vhalf;
+                        const float lvh_ = lv_[c] + Gv * 0.5f * h;                       // :141
+                        lvho[c] = lvh_;
+                        wlo[c] = lvh_ * (1.0f / m);                                      // (the listed midpoint evaluation's w)
+                        lqho[c] = lq_[c] + dq_[c] * 0.5f * h;                            // :142
                     } else {
-                        const float vhalf = ve - 0.5f * (-A.f[e]) * h;                   // :49-50
-                        qn[c] = A.q_t[ef] - vhalf * h;                                   // :51-52
-                        A.vm[e] = vhalf;
-                        const float dx = A.dq[e] * h * 0.5f;                             // :71
-                        const float lvh_ = A.lv[e] + (A.lq[e] + dx) * h;                 // :72
-                        A.lvh[e] = lvh_;
-                        if (A.nl_idx) A.wl[e] = lvh_;
-                        A.lqh[e] = A.lq[e] + dx;
+                        const float vhalf = ve - 0.5f * (-f_[c]) * h;                    // :49-50
+                        qn[c] = qt_[c] - vhalf * h;                                      // :51-52
+                        vmo[c] = vhalf;
+                        const float dx = dq_[c] * h * 0.5f;                              // :71
+                        const float lvh_ = lv_[c] + (lq_[c] + dx) * h;                   // :72
+                        lvho[c] = lvh_;
+                        wlo[c] = lvh_;
+                        lqho[c] = lq_[c] + dx;
                     }
-                    A.qm[e] = qn[c];
-                    const float mv = qn[c] - qbA[3 * a + c], mvB = qn[c] - qbB[3 * a + c];
+                    const float mv = qn[c] - qa_[c], mvB = qn[c] - qb_[c];
                     mv2 = fmaf(mv, mv, mv2);
                     mv2B = fmaf(mvB, mvB, mv2B);
                 }
+                st3(A.vm, e3, vmo[0], vmo[1], vmo[2]);
+                st3(A.lvh, e3, lvho[0], lvho[1], lvho[2]);
+                if (A.nl_idx) st3(A.wl, e3, wlo[0], wlo[1], wlo[2]);
+                st3(A.lqh, e3, lqho[0], lqho[1], lqho[2]);
+                st3(A.qm, e3, qn[0], qn[1], qn[2]);
                 far2 = fmaxf(far2, mv2);
                 far2B = fmaxf(far2B, mv2B);
                 px[u] = qn[0]; py[u] = qn[1]; pz[u] = qn[2];
@@ -791,8 +835,6 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
 // Second half of step k over the CURRENT list (large_prep<1> found every atom inside its reuse ball): the same four-
 // atoms-per-wave rows as large_adj_listed below, force only, then large_force_step<1>'s epilogue.  Exits at once when
 // this step searched instead.
-struct __attribute__((packed, aligned(4))) Row3 { float x, y, z; };      // one [3] row of a [N][3] array: global_load_dwordx3
-__device__ __forceinline__ Row3 row3(const float* __restrict__ a, int j) { return *reinterpret_cast<const Row3*>(a + 3 * (size_t)j); }
 
 constexpr int LG_ROW_ATOMS = 16;                 // atoms per workgroup of the listed kernels (4 waves x 4 rows)
 constexpr int LG_ADJ_GROUPS = 4;                 // ... large_adj_listed: groups of four atoms a wave takes one after the other
@@ -1345,6 +1387,19 @@ __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t*
     if (k < n) out[k] = (float)(((double)ghi[k] * 1048576.0 + (double)glo[k]) / (double)scale);
 }
 
+// lam(T-1) = dL/dy_{T-1} of every replica: the last frame's rows of the incoming gradients (zeros where none came)
+__global__ void large_adj_init(const float* __restrict__ g_v, const float* __restrict__ g_q, const float* __restrict__ g_pv, int N,
+                               int T, int C, float* __restrict__ lv, float* __restrict__ lq, float* __restrict__ lp) {
+    const int r = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t src = ((size_t)r * T + T - 1) * N * 3, dst = (size_t)r * N * 3;
+    if (e < 3 * N) {
+        lv[dst + e] = g_v ? g_v[src + e] : 0.f;
+        lq[dst + e] = g_q ? g_q[src + e] : 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < MDG_MAX_CHAINS)
+        lp[r * MDG_MAX_CHAINS + threadIdx.x] = (g_pv && (int)threadIdx.x < C) ? g_pv[((size_t)r * T + T - 1) * C + threadIdx.x] : 0.f;
+}
+
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, wl, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
         spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
@@ -1537,18 +1592,10 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
     const int C = prm->n_chains, T = prm->n_frames, KT = terms->n_theta_total;
     const size_t fr = sizeof(float) * (size_t)N * 3;
-    // lam = dL/dy_{T-1}
-    for (int r = 0; r < R; ++r) {
-        float* lv = a.lv + (size_t)r * N * 3;
-        float* lq = a.lq + (size_t)r * N * 3;
-        if (g_v) MDG_HIP(hipMemcpyAsync(lv, g_v + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st));
-        else MDG_HIP(hipMemsetAsync(lv, 0, fr, st));
-        if (g_q) MDG_HIP(hipMemcpyAsync(lq, g_q + ((size_t)r * T + T - 1) * N * 3, fr, hipMemcpyDeviceToDevice, st));
-        else MDG_HIP(hipMemsetAsync(lq, 0, fr, st));
-        if (g_pv) MDG_HIP(hipMemcpyAsync(a.lp + r * MDG_MAX_CHAINS, g_pv + ((size_t)r * T + T - 1) * C, sizeof(float) * C,
-                                 hipMemcpyDeviceToDevice, st));
-        else MDG_HIP(hipMemsetAsync(a.lp + r * MDG_MAX_CHAINS, 0, sizeof(float) * MDG_MAX_CHAINS, st));
-    }
+    // lam = dL/dy_{T-1}: ONE launch for all replicas (three copies per replica in a host loop were 192 serialised 3-5 us copies
+    // per 64-replica adjoint: 0.5-1 ms of a 20 ms pass)
+    (void)fr;
+    hipLaunchKernelGGL(large_adj_init, dim3((3 * N + 255) / 256, R), dim3(256), 0, st, g_v, g_q, g_pv, N, T, C, a.lv, a.lq, a.lp);
     MDG_HIP(hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st));
     if (table) {
         MDG_HIP(hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st));
