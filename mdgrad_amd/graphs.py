@@ -102,6 +102,19 @@ class _ForwardGraph:
         self.graph = _capture(self._step, self.k.zero_)
 
     def _step(self):
+        if len(self.state) == 2:                  # NVE (velocity Verlet, sovlers.py:25-33; dv/dt = F)
+            func, (v, q), F, k = self.func, self.state, self.F, self.k
+            dt = self.t.index_select(0, k + 1) - self.t.index_select(0, k)
+            dv_h = 0.5 * F * dt
+            dq = (v + dv_h) * dt
+            qn = q + dq
+            Fn = func.force(qn)
+            vn = v + (dv_h + 0.5 * Fn * dt)
+            v.copy_(vn), q.copy_(qn), F.copy_(Fn)
+            for o, x in zip(self.out, (v, q)):
+                o.index_copy_(0, k + 1, x[None])
+            k.add_(1)
+            return
         func, (v, q, pv), F, k = self.func, self.state, self.F, self.k
         if getattr(func, "fused_steps_ok", lambda *a: False)(v, q, pv):
             # both halves of the step as one launch each (csrc/nhc.hip): rhs + half kick + drift, force, rhs + finish
@@ -158,6 +171,17 @@ class _AdjointGraph:
 
     def _interval(self):
         func, lam, i = self.func, self.lam, self.i
+        if len(lam) == 2:                         # NVE: sovlers.nve_adjoint_interval on the frame the device index names
+            from .sovlers import nve_adjoint_interval
+            h = self.t.index_select(0, i) - self.t.index_select(0, i - 1)
+            v, x = (a.index_select(0, i)[0] for a in self.ans)
+            g_prev = tuple(g.index_select(0, i - 1)[0] for g in self.gout)
+            new, th0 = nve_adjoint_interval(func, v, x, (lam[0], lam[1]), h, g_prev)
+            lam[0].copy_(new[0]), lam[1].copy_(new[1])
+            if th0:
+                self.gth.add_(_flatten(th0) * 0.5 * h * 2)
+            i.sub_(1)
+            return
         if getattr(func, "fused_steps_ok", lambda *a: False)(*lam):
             # sovlers.py:258 (counter / rebuild only), two force-vjp evaluations, three launches of algebra around them
             w = func.nhv_work(lam[0], lam[2])

@@ -184,6 +184,20 @@ class _EOM(torch.nn.Module):
                 self._topo_ref, self._topo_ver, self._topo_stamp = weakref.ref(q), ver, getattr(m, "_topo_stamp", None)
         self.update_count += 1
 
+    def force(self, q):
+        """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to
+        reuse the force between the second evaluation of step k and the first of step k+1 -- same q,
+        bit-identical result, SURVEY 0.6; only when topology_update_freq == 1)."""
+        if getattr(self.model, "supports_force_vjp", lambda: False)():
+            self.update_topology(q)
+            return self.model.force(q)
+        with torch.set_grad_enabled(True):
+            q = q.detach().requires_grad_(True)
+            self.update_topology(q)
+            u = self.model(q)
+            (g,) = torch.autograd.grad(u.sum(), q)
+        return -g
+
     def attach_observable(self, obs, start=0, stride=1):
         """Ask the fused trajectory launches of this integrator to evaluate `obs` (an `observable.rdf`) on the frames
         start, start + stride, ... of every trajectory from now on -- what the observable otherwise arranges itself
@@ -437,20 +451,6 @@ class NoseHooverChain(_EOM):
         """force_vjp's parameter gradients (model.parameters() order) as a list in self.parameters() order."""
         by_id = {id(p): g for p, g in zip(self.model.parameters(), gth)}
         return [by_id[id(p)] if id(p) in by_id else torch.zeros_like(p) for p in self.parameters()]
-
-    def force(self, q):
-        """F(q) = -dU/dq with the topology update of md.py:225-228 (used by the generic solver to
-        reuse the force between the second evaluation of step k and the first of step k+1 -- same q,
-        bit-identical result, SURVEY 0.6; only when topology_update_freq == 1)."""
-        if getattr(self.model, "supports_force_vjp", lambda: False)():
-            self.update_topology(q)
-            return self.model.force(q)
-        with torch.set_grad_enabled(True):
-            q = q.detach().requires_grad_(True)
-            self.update_topology(q)
-            u = self.model(q)
-            (g,) = torch.autograd.grad(u.sum(), q)
-        return -g
 
     def _hip_algebra(self, *tensors):
         """The single-launch thermostat kernels (csrc/nhc.hip) apply to fp32 device states outside

@@ -134,6 +134,38 @@ class Verlet(FixedGridODESolver):
     def step_func(self, func, t, dt, y):
         return verlet_update(func, t, dt, y)
 
+    def integrate(self, t):
+        """Graph-free forward integration of an NVE integrator whose model has analytic forces: the force at q_{k+1} is
+        evaluated once and reused by the next step (the reference's two calls per step, sovlers.py:25-33, see the same q),
+        and the steps are replayed from a HIP graph where that applies -- NHVerlet.integrate for the 2-state system."""
+        func = self.func
+        if (torch.is_grad_enabled() or len(self.y0) != 2 or not hasattr(func, "force")
+                or not getattr(func, "supports_rhs_vjp", lambda: False)()
+                or getattr(func, "topology_update_freq", 0) != 1 or getattr(func, "analytic_verlet", True) is False):
+            return super().integrate(t)
+        t = t.type_as(self.y0[0]).to(self.y0[0].device)
+
+        def eager():
+            v, q = self.y0
+            frames = [(v, q)]
+            F = func.force(q)                                     # (NVE: dv/dt = F, no 1/m -- md.py:145-148)
+            for k in range(t.shape[0] - 1):
+                dt = t[k + 1] - t[k]
+                dv_h = 0.5 * F * dt
+                dq = (v + dv_h) * dt
+                F = func.force(q + dq)
+                v, q = v + (dv_h + 0.5 * F * dt), q + dq
+                frames.append((v, q))
+            return tuple(torch.stack([f[i] for f in frames]) for i in range(2))
+
+        if graphs.enabled(func) and t.shape[0] > 3:
+            out = graphs.forward(func, tuple(self.y0), t)
+            if out is None:
+                out = graphs.eager_static(func, eager, lambda o: o[1][-1])
+            if out is not None:
+                return out
+        return eager()
+
 
 SOLVERS = {'rk4': RK4, 'NH_verlet': NHVerlet, 'verlet': Verlet}
 
@@ -204,6 +236,8 @@ class OdeintAdjointMethod(torch.autograd.Function):
         closed_form = (not wants_time) and getattr(func, "supports_rhs_vjp", lambda: False)()
         if closed_form and solver["method"] == 'NH_verlet' and n == 3:
             return _analytic_nhc_adjoint(func, t, frames, cotangents, flat_params)
+        if closed_form and solver["method"] == 'verlet' and n == 2 and getattr(func, "analytic_verlet", True) is not False:
+            return _analytic_nve_adjoint(func, t, frames, cotangents, flat_params)
         system = _BackwardSystem(func, n, closed_form)
         with torch.no_grad():
             costate = tuple(c[-1] for c in cotangents)                     # lam(t_last) = dL/dy_last   (:249)
@@ -291,6 +325,54 @@ def _analytic_nhc_adjoint(func, t, ans, grad_output, flat_params):
         if graphs.enabled(func) and T > 3:
             out = graphs.adjoint(func, t, ans, grad_output, flat_params.numel())   # one graph launch per interval
             if out is None:                                               # too large for replay: sync-free lists
+                out = graphs.eager_static(func, eager, lambda o: ans[1][0])
+        if out is None:
+            out = eager()
+        return (*out[0], None, None, out[1], None, None, None, None, None)
+
+
+def nve_adjoint_interval(func, v, x, lam, h, g_prev):
+    """One interval of OdeintAdjointMethod.backward over the backward branch of verlet_update (sovlers.py:42-101, :253-288)
+    for an integrator with rhs_vjp: (new costate, parameter term).  h = t[i] - t[i-1] > 0: the generic path integrates the
+    interval in s = -t with the NEGATED augmented right-hand side (tinydiffeq.py:132-135), i.e. the solver sees
+    (-F, -v, +lam_q, +d(lam_v.F)/dq, 0, +d(lam_v.F)/dtheta) and reads the first, fourth and sixth entry of it, twice: at
+    (x, lam) with the parameter term and at the half-updated point without."""
+    lv, lx = lam
+    func.update_topology(x)                                       # :258 (the dL/dt call: counter / rebuild only)
+    (F0, _), (_, X0), th0 = func.rhs_vjp((v, x), (lv, lx))
+    dv_h = 1 / 2 * (-F0) * h
+    v_half = v - dv_h                                             # :49-50
+    dx = v_half * h
+    x0 = x - dx                                                   # :51-52
+    dlx = X0 * h * 0.5                                            # :71
+    dlv = (lx + dlx) * h                                          # :72
+    _, (_, X1), _ = func.rhs_vjp((v_half, x0), (lv + dlv, lx + dlx), want_theta=False)
+    lam_new = (lv + dlv + g_prev[0], lx + (X1 * h * 0.5 + dlx) + g_prev[1])       # :100, :286
+    return lam_new, th0
+
+
+def _analytic_nve_adjoint(func, t, ans, grad_output, flat_params):
+    """OdeintAdjointMethod.backward for `verlet` over an integrator with rhs_vjp, without the 6-tuple solver algebra: per
+    interval the counter-only call and two analytic force-vjp evaluations (`nve_adjoint_interval`); replayed from a HIP
+    graph where that applies.  The parameter term of an interval is  theta_vjp(x_i; lam_v) * h  (sovlers.py:82, :101: the half
+    step taken twice)."""
+    with torch.no_grad():
+        T = ans[0].shape[0]
+
+        def eager():
+            lam = tuple(g[-1].clone() for g in grad_output)
+            gth = torch.zeros_like(flat_params)
+            for i in range(T - 1, 0, -1):
+                h = t[i] - t[i - 1]
+                lam, th0 = nve_adjoint_interval(func, ans[0][i], ans[1][i], lam, h, (grad_output[0][i - 1], grad_output[1][i - 1]))
+                if th0:
+                    gth = gth + _flatten(th0) * 0.5 * h * 2        # :82, :101 (the half step taken twice)
+            return list(lam), gth
+
+        out = None
+        if graphs.enabled(func) and T > 3:
+            out = graphs.adjoint(func, t, ans, grad_output, flat_params.numel())
+            if out is None:
                 out = graphs.eager_static(func, eager, lambda o: ans[1][0])
         if out is None:
             out = eager()

@@ -403,6 +403,51 @@ def test_nve_generic_analytic_adjoint_equals_autograd():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames", [3, 7])
+def test_nve_analytic_verlet_paths_equal_the_generic_solver(frames):
+    """NVE over GNN + prior: the cached-force forward integration and the analytic adjoint of `verlet` (Verlet.integrate,
+    sovlers._analytic_nve_adjoint: two force-vjp evaluations per interval) -- eagerly (3 frames) and replayed from HIP graphs
+    (7 frames; once more with graphs switched off) -- against the reference's own control flow on the same kernels: the
+    two-call step and the 6-state backward branch of verlet_update through the generic solver (sovlers.py:21-104, :196-293)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NVE
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("gnn_traj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["masses"], g["numbers"])
+    net = get_model(params_of(g))
+    net.load_state_dict(sd_of(g))
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12),
+                           cutoff=float(g["cutoff"]))
+    integ = NVE(Stack({"gnn": gnn, "prior": prior}), system).to(DEV)
+    t = torch.Tensor([float(g["dt"]) * i for i in range(frames)]).to(DEV)
+    params = list(integ.parameters())
+
+    def run(analytic, graphs_on=True):
+        integ.analytic_verlet, integ.use_graphs = analytic, graphs_on
+        for p_ in params:
+            p_.grad = None
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        v_t, q_t = odeint_adjoint(integ, tuple(y0), t, method="verlet")
+        (q_t[-1].pow(2).mean() + v_t[::2].pow(2).mean() + q_t[1].sum() * 1e-3).backward()
+        gth = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in params])
+        return v_t.detach(), q_t.detach(), y0[0].grad, y0[1].grad, gth
+
+    ref = run(False)
+    assert not getattr(integ, "_graph_cache", None), "the generic solver captures nothing"
+    outs = [run(True)]
+    if frames > 3:
+        assert len(integ._graph_cache) == 2, "forward and adjoint graphs of the verlet steps"
+        outs.append(run(True))                                     # replay of the cached graphs
+        outs.append(run(True, graphs_on=False))
+    for o in outs:
+        for a, b, name in zip(o, ref, ("v_t", "q_t", "dL/dv0", "dL/dq0", "dL/dtheta")):
+            close(a, b, 1e-5, 1e-6 * float(b.abs().max()) + 1e-9, "analytic verlet vs generic solver: " + name)
+
+
+@pytest.mark.gpu
 def test_fit_rdf_gnn_example_runs():
     """examples/fit_rdf_gnn.py (the loop of demo/fit_rdf_gnn.py:380-461: annealing through update_T,
     Simulations epochs, JS / compute_D losses, Adam + ReduceLROnPlateau) on a small stacked system."""
