@@ -221,10 +221,11 @@ def make_inputs(R, seed, dev):
     return atoms, torch.from_numpy(pos).to(dev), torch.from_numpy(vel).to(dev)
 
 
-def _oracle_lj108(pos, vel, frames, dt, O):
+def _oracle_lj108(pos, vel, frames, dt, O, form="lj"):
     cell = torch.tensor([4.8] * 3)
     t = torch.Tensor([dt * i for i in range(frames)])
-    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, cell, p=12, q=6, c=1)
+    term = (O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, cell, p=12, q=6, c=1) if form == "lj" else
+            O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, cell, p=12, q=0, c=0))       # ExcludedVolume(sigma 1, epsilon 1, power 12)
     eom = O.NHCOracle(O.ModelOracle([term]), torch.full((108,), 1.008), 1.0, 50.0, 5)
     traj = O.odeint_oracle(eom, (vel, pos, torch.zeros(5)), t)
     leaves = [x.clone().requires_grad_(True) for x in traj]
@@ -234,19 +235,20 @@ def _oracle_lj108(pos, vel, frames, dt, O):
     return traj, g.detach(), gth
 
 
-def cpu_baseline_lj108(frames, dt, check=None, budget_s=12.0):
+def cpu_baseline_lj108(frames, dt, check=None, budget_s=12.0, form="lj", timed=True):
     """The CPU oracle (port of the reference algorithm, oracle/) on this host: the same 108-atom workload, one
     replica at a time, forward + rdf loss + adjoint; bounded to ~budget_s.  `check` = [(r, pos_r, vel_r, q_t_r, g_r,
     gth_r, R)] for sampled replicas r of the timed launch: their HIP results are compared with the oracle's on the same
     inputs."""
     import oracle as O
     _, pos, vel = make_inputs(1, 123, "cpu")
-    out = _cpu_timed(lambda: _oracle_lj108(pos[0], vel[0], frames, dt, O), frames - 1,
-                     "the timed workload itself (108-atom LJ, fwd + rdf loss + adjoint, one replica at a time)")
+    out = _cpu_timed(lambda: _oracle_lj108(pos[0], vel[0], frames, dt, O, form), frames - 1,
+                     "the timed workload itself (108-atom %s, fwd + rdf loss + adjoint, one replica at a time)" % form,
+                     batch_s=2.5 if timed else 0.6)
     if check:
         dq = dg = dth = 0.0
         for (r, p0, v0, q_hip, g_hip, gth_hip, n_rep) in check:
-            traj, g_o, gth_o = _oracle_lj108(p0, v0, frames, dt, O)
+            traj, g_o, gth_o = _oracle_lj108(p0, v0, frames, dt, O, form)
             dq = max(dq, float((q_hip - traj[1]).abs().max()))
             dg = max(dg, float((g_hip - g_o).abs().max()))
             dth = max(dth, float(((gth_hip - gth_o).abs() / gth_o.abs().max()).max()))
@@ -258,7 +260,18 @@ def cpu_baseline_lj108(frames, dt, check=None, budget_s=12.0):
     return out
 
 
-def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
+def run_lj108(args, rank, world, dev, mdist, with_cpu=True, form="lj", dt=None, steps=None, warmup=None):
+    """form "lj": LennardJones(1, 1), the headline.  form "exvol": the reference README's own demo model,
+    ExcludedVolume(sigma 1, epsilon 1, power 12) at its dt = 0.01 (README.md:70-85): the same ring kernels -- the even-power
+    polynomial with the attractive coefficient 0."""
+    import copy
+    args = copy.copy(args)
+    if dt is not None:
+        args.dt = dt
+    if steps is not None:
+        args.steps = steps
+    if warmup is not None:
+        args.warmup = warmup
     import ctypes as C
     from mdgrad_amd import ops, _lib
     from mdgrad_amd import potentials as P
@@ -270,7 +283,7 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
     T = 50 if args.frames is None else args.frames
     atoms, pos, vel = make_inputs(R, 1000 + rank, dev)
     system = System(atoms, device=dev)
-    mdl = P.LennardJones(1.0, 1.0)
+    mdl = P.LennardJones(1.0, 1.0) if form == "lj" else P.ExcludedVolume(1.0, 1.0, 12)
     integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0,
                             num_chains=5, Q=50.0).to(dev)
     obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
@@ -319,13 +332,14 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
     if not (_finite(step.last_q) and all(_finite(p) for p in params)):
         raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
     md_steps = R * (T - 1) * world * args.steps
-    out = {"metric": "MD steps/sec (fwd+adjoint), 108-atom LJ NHC", "value": md_steps / el,
+    label = "LJ(1,1)" if form == "lj" else "ExcludedVolume(sigma 1, eps 1, power 12)"
+    out = {"metric": "MD steps/sec (fwd+adjoint), 108-atom %s NHC" % ("LJ" if form == "lj" else "ExcludedVolume"), "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": {"workload": "FCC 3x3x3 LJ(1,1) 108 atoms, cutoff 2.5, NoseHooverChain(Q=50, 5 chains) "
-                                  "velocity-Verlet, %d steps fwd + RDF(100 bins) loss + adjoint; "
-                                  "%d replicas/GPU per pass" % (T - 1, R),
+           "config": {"workload": "FCC 3x3x3 %s 108 atoms, cutoff 2.5, NoseHooverChain(Q=50, 5 chains) "
+                                  "velocity-Verlet dt %g, %d steps fwd + RDF(100 bins) loss + adjoint; "
+                                  "%d replicas/GPU per pass" % (label, args.dt, T - 1, R),
                       "replicas_per_gpu": R, "md_steps_per_pass": R * (T - 1), "parallelism": "replica-dp%d" % world,
                       "loss": float(loss.detach())}}
     out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / args.steps * 1e3)
@@ -403,7 +417,8 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
     bytes_adj = (48 * Pn + 208 * N) * intervals                    # 2 B_H + B_A + 2 B_N per step
     kname = "traj_adj_ring_kernel"
     # counters of the same launch (16 384 replicas, 50 frames, observable fused in), refused when the kernel source changed
-    cnt, why = _counters("lj108", "traj_adj_ring_kernel<true") if (R == 16384 and T == 50 and fused) else (None, "other geometry")
+    cnt, why = (_counters("lj108", "traj_adj_ring_kernel<true") if (R == 16384 and T == 50 and fused and form == "lj")
+                else (None, "other geometry / pair form"))
     traffic = cnt.get("hbm_bytes_per_launch") if cnt else None
     sec = adj_ms * 1e-3
     out["roofline"] = {
@@ -426,7 +441,7 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True):
                     FLOP_PER_PAIR_RING, Pn, intervals, ring_ops, N * (N - 1) // 2)}
     if with_cpu and world == 1:
         def cpu_part():
-            out["cpu_baseline"] = cpu_baseline_lj108(T, args.dt, check)
+            out["cpu_baseline"] = cpu_baseline_lj108(T, args.dt, check, form=form, timed=form == "lj")
         _later(cpu_part)
     return out
 
@@ -628,6 +643,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     warmup = args.warmup if warmup is None else warmup
     R = 8 if args.replicas is None or args.workload != "schnet4096" else args.replicas
     T = 11 if args.frames is None or args.workload != "schnet4096" else args.frames
+    T = getattr(args, "frames_override", None) or T
     A_, F_, G_, NC = 64, 128, 30, 2
     rows16 = bool(args.bf16 and getattr(args, "bf16_rows", False))
     wl = build_schnet_workload(dev, R, args.bf16, 2000 + rank, widths=(A_, F_, G_, NC), rows16=rows16)
@@ -775,7 +791,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     filt_flops = 21.0 * NC * 2.0 * (E / R) * G_ * (G_ + F_) * R * (T - 1)
     filt_peak = MFMA_BF16_PEAK_TF if args.bf16 else MFMA_F32_PEAK_TF
     t_min = filt_flops / (filt_peak * 1e12) + (step_flops - filt_flops) / (MFMA_F32_PEAK_TF * 1e12)
-    std = R == 8 and T == 11 and bool(args.bf16)
+    std = R == 8 and bool(args.bf16)
     bname = "cfconv_bwd_bf16_kernel<32, 8, true, true, false>" if args.bf16 else "cfconv_bwd_kernel<32, 8, true, true>"
     if rows16:
         bname = "cfconv_bwd_bf16_kernel<32, 8, true, true, true>"
@@ -840,6 +856,159 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
     if with_cpu and world == 1:
         _later(cpu_part)
     return out
+
+
+# ====================================================================================== config #3: 192-atom water, SchNet
+def _golden_water192():
+    """tests/golden/gnn_traj_water192.npz (G14): the 64-molecule water box of the reference's data/water_init_64.xyz, the
+    reference's own SchNet(A128, F128, G32, 3 conv) weights from torch.manual_seed(0), velocities, and what the REFERENCE
+    computed from them on CPU (8 NH-Verlet steps, O-H g(r), parameter gradients) -- data, generated by
+    tests/golden/make_goldens.py in the build container."""
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "gnn_traj_water192.npz"), allow_pickle=False))
+    sd = {k[4:]: torch.from_numpy(np.asarray(v)) for k, v in g.items() if k.startswith("sd__")}
+    prm = {"n_atom_basis": int(g["n_atom_basis"]), "n_filters": int(g["n_filters"]), "n_gaussians": int(g["n_gaussians"]),
+           "n_convolutions": int(g["n_convolutions"]), "cutoff": float(g["cutoff"])}
+    return g, sd, prm
+
+
+def build_water192(dev):
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.nn import get_model
+    from mdgrad_amd.system import System
+    g, sd, prm = _golden_water192()
+    system = System(positions=np.asarray(g["pos"], dtype=np.float64), cell=np.asarray(g["cell"], dtype=np.float64),
+                    numbers=g["numbers"], masses=np.asarray(g["masses"], dtype=np.float64), device=dev)
+    system.set_velocities(np.asarray(g["vel"], dtype=np.float64))
+    net = get_model(prm)
+    net.load_state_dict(sd)
+    gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
+    prior = PairPotentials(system, P.ExcludedVolume(float(g["prior_sigma"]), float(g["prior_epsilon"]), 12), cutoff=float(g["cutoff"]))
+    integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=float(g["T"]), num_chains=int(g["chains"]),
+                            Q=float(g["Q"]), adjoint=True).to(dev)
+    return g, sd, prm, system, net, gnn, integ
+
+
+def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None):
+    """BASELINE config #3 / SURVEY 8d M3: SchNet A128/F128/G32/3 conv + ExcludedVolume prior on the 64-molecule water box,
+    cutoff 5, NoseHooverChain, dt = 0.25 fs (the golden's), 20 steps forward + O-H RDF loss + analytic adjoint + Adam, one
+    system per GPU (HIP-graph replay of the per-step launches), f32."""
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    g, sd, prm, system, net, gnn, integ = build_water192(dev)
+    T = 21 if args.frames is None or args.workload != "water192" else args.frames
+    dt = float(g["dt"])
+    obs = rdf(system, nbins=40, r_range=(0.6, 5.0), index_tuple=(g["idx_O"].tolist(), g["idx_H"].tolist()))
+    target = torch.ones(40, device=dev)
+    params = list(integ.parameters())
+    opt = torch.optim.Adam(params, lr=1e-6)
+    y0_dev = tuple(x.clone() for x in integ.get_inital_states(wrap=True))
+    # ---- parity against the REFERENCE's own output (before any optimizer step): the golden's 8 steps
+    par = None
+    if rank == 0:
+        nf = g["q_t"].shape[0]
+        t9 = torch.Tensor([dt * i for i in range(nf)]).to(dev)
+        v_t, q_t, pv_t = odeint_adjoint(integ, tuple(x.clone() for x in y0_dev), t9, method="NH_verlet")
+        gr = obs(q_t[::2])[2]
+        loss = gr.pow(2).mean() + q_t[-1].pow(2).mean() * 1e-3 + v_t[-1].pow(2).sum() * 1e-2
+        loss.backward()
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).cpu().numpy()
+        ref = g["grad_flat"]
+        par = {"vs": "the reference's CPU run (golden G14, tests/golden/gnn_traj_water192.npz)", "steps": int(nf - 1),
+               "max_abs_dq": float(np.abs(q_t.detach().cpu().numpy() - g["q_t"]).max()),
+               "max_abs_dg": float(np.abs(gr.detach().cpu().numpy() - g["g"]).max()),
+               "rel_dtheta": float(np.abs(flat - ref).max() / np.abs(ref).max()),
+               "cos_dtheta": float((flat.astype(np.float64) * ref).sum() / (np.linalg.norm(flat.astype(np.float64)) * np.linalg.norm(ref)))}
+        opt.zero_grad(set_to_none=True)
+    t = torch.Tensor([dt * i for i in range(T)]).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y0 = tuple(x.clone() for x in y0_dev)
+        v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        loss = (obs(q_t[::2])[2] - target).pow(2).mean()
+        loss.backward()
+        mdist.all_reduce_grads(params)
+        opt.step()
+        return loss, q_t
+
+    for _ in range(warmup):
+        step()
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, q_last = step()
+    torch.cuda.synchronize()
+    mdist.barrier()
+    el_rank = time.perf_counter() - t0
+    el = mdist.max_over_ranks(el_rank, dev)
+    if not (_finite(q_last) and all(_finite(p) for p in params)):
+        raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
+    N = len(system)
+    md_steps = (T - 1) * world * steps
+    topo = gnn.inputs["_topo"]
+    E = int(topo.n_edges)
+    A_, F_, G_, NC = prm["n_atom_basis"], prm["n_filters"], prm["n_gaussians"], prm["n_convolutions"]
+    step_flops = 21.0 * schnet_flops_forward(N, E, A_, F_, G_, NC)
+    sec_per_step = el / (steps * (T - 1))
+    out = {"metric": "MD steps/sec (fwd+adjoint), 192-atom water SchNet NHC (BASELINE config #3)", "value": md_steps / el,
+           "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "64-molecule water box (192 atoms, golden G14 geometry), SchNet A%d F%d G%d %d conv + "
+                                  "ExcludedVolume prior, cutoff 5, NoseHooverChain(Q=50, 5 chains), %d steps fwd + O-H RDF(40 "
+                                  "bins) loss + analytic adjoint + Adam; one system per GPU, HIP-graph replay" % (A_, F_, G_, NC, T - 1),
+                      "replicas_per_gpu": 1, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach()), "edges": E,
+                      "us_per_md_step": sec_per_step * 1e6}}
+    out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
+    if rank != 0:
+        return out
+    out["config"]["parity_reference_golden"] = par
+    out["roofline"] = {"bound": "mfma", "kernel": "whole MD step (launch-bound: one 192-atom system, E = %d edges)" % E,
+                       "achieved": step_flops / sec_per_step / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                       "frac": step_flops / sec_per_step / 1e12 / MFMA_F32_PEAK_TF, "traffic": None,
+                       "note": "SURVEY 8d: 21 x the flops of one forward energy evaluation per MD step (1 force + 2 force-vjp "
+                               "evaluations) over the measured time per step; at 192 atoms the step is a chain of ~70 graph "
+                               "nodes of 5-15 us each: bound by launch latency, not by the matrix cores"}
+    if with_cpu and world == 1:
+        def cpu_part():
+            import oracle as O
+            total, usable = _host_cpus()
+            threads = max(1, min(usable, 16))
+            torch.set_num_threads(threads)
+            cell = torch.from_numpy(np.asarray(g["cell"], dtype=np.float32))
+            nf = g["q_t"].shape[0]
+            tt = torch.Tensor([dt * i for i in range(nf)])
+
+            def one():
+                gnn_o = O.SchNetTerm(sd, g["numbers"], float(g["cutoff"]), cell)
+                prior_o = O.PairTerm("lj", torch.tensor([float(g["prior_sigma"]), float(g["prior_epsilon"])]), float(g["cutoff"]),
+                                     cell, p=12, q=0, c=0)
+                eom = O.NHCOracle(O.ModelOracle([gnn_o, prior_o]), torch.from_numpy(g["masses"]), float(g["T"]), float(g["Q"]),
+                                  int(g["chains"]))
+                traj = O.odeint_oracle(eom, (torch.from_numpy(g["vel"]), torch.from_numpy(g["pos"]), torch.zeros(5)), tt)
+                leaves = [x.clone().requires_grad_(True) for x in traj]
+                gr = O.rdf_oracle(leaves[1][::2], cell, 40, (0.6, 5.0), (g["idx_O"].tolist(), g["idx_H"].tolist()))[2]
+                (gr - 1).pow(2).mean().backward()
+                O.adjoint_oracle(eom, traj, [x.grad if x.grad is not None else torch.zeros_like(x) for x in leaves], tt)
+            one()
+            ts = []
+            for _ in range(3):
+                t0_ = time.perf_counter()
+                one()
+                ts.append(time.perf_counter() - t0_)
+            med = sorted(ts)[1]
+            out["cpu_baseline"] = {"value": (nf - 1) / med, "unit": "MD steps/s", "cores": threads, "threads": threads,
+                                   "host_cores": total, "usable_cores": usable, "kind": "port",
+                                   "sample": "1 warm-up + median of 3 runs of %d steps (fwd + O-H rdf loss + adjoint) of the timed "
+                                             "system itself, oracle/ (autograd double backward like the reference) on %d torch "
+                                             "threads; median %.2f s" % (nf - 1, threads, med)}
+        _later(cpu_part)
+    return out
+
 
 
 # ====================================================================================== 4096-atom LJ liquid
@@ -1075,16 +1244,87 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     return out
 
 
+# ====================================================================================== output
+# What the driver keeps of a run is (a) the LAST JSON line, of which it stores the scalar keys of `config` and the scalar
+# entries of `roofline` / `cpu_baseline` (strings cut at ~140 characters), and (b) the last ~8 KB of stdout.  So: every
+# secondary workload is printed as its own compact line BEFORE the headline, the headline carries the secondaries' figures
+# as flat scalars in `config`, and everything long (notes, nested records) goes to the detail file only
+# (gpurun_out/bench_full.json, or $MDG_BENCH_DETAIL).
+_DROP = {"note", "hbm_algorithmic_model", "protocol", "batch_s", "threads_tried", "counters", "model", "parity_small_boxes",
+         "small_box", "cpu_baseline_sample", "binding"}
+
+
+def _compact(o, depth=0, cut=150):
+    if isinstance(o, dict):
+        return {k: _compact(v, depth + 1, cut) for k, v in o.items() if k not in _DROP and not (depth >= 3 and isinstance(v, (dict, list)))}
+    if isinstance(o, (list, tuple)):
+        return [_compact(v, depth + 1, cut) for v in o][:16]
+    if isinstance(o, str) and len(o) > cut:
+        return o[:cut - 3] + "..."
+    if isinstance(o, float):
+        return float("%.6g" % o)
+    return o
+
+
+def _flat(name, rec):
+    """The figures of a secondary workload as flat scalar keys for the headline's `config`."""
+    if not isinstance(rec, dict) or "error" in rec:
+        return {name + "_error": str((rec or {}).get("error"))[:140]}
+    rl, cb = rec.get("roofline") or {}, rec.get("cpu_baseline") or {}
+    par = cb.get("parity_sampled") or rec.get("config", {}).get("parity_reference_golden") or {}
+    f = {name + "_md_steps_per_s": rec.get("value"), name + "_ms_per_pass": rec.get("ms_per_step"), name + "_dtype": rec.get("dtype"),
+         name + "_passes": rec.get("steps"), name + "_roofline_bound": rl.get("bound"), name + "_kernel_frac": rl.get("frac"),
+         name + "_step_roof_frac": (rl.get("step_roof") or {}).get("frac"), name + "_cpu_steps_per_s": cb.get("value"),
+         name + "_cpu_cores": cb.get("cores"), name + "_parity_max_abs_dq": par.get("max_abs_dq"),
+         name + "_parity_max_abs_dg": par.get("max_abs_dg"), name + "_parity_rel_dtheta": par.get("rel_dtheta")}
+    return {k: (float("%.6g" % v) if isinstance(v, float) else v) for k, v in f.items() if v is not None}
+
+
+def _line(name, rec):
+    """One compact JSON line of a secondary workload (< ~1.5 KB)."""
+    if not isinstance(rec, dict) or "error" in rec:
+        return json.dumps({"workload": name, "error": str((rec or {}).get("error"))[:300]})
+    c = rec.get("config", {})
+    o = {"workload": name, "metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "n_gpus": rec["n_gpus"],
+         "steps": rec["steps"], "warmup": rec["warmup"], "ms_per_step": rec["ms_per_step"], "dtype": rec["dtype"],
+         "replicas_per_gpu": c.get("replicas_per_gpu"), "per_rank_ms": (c.get("dist") or {}).get("per_rank_ms")}
+    rl = rec.get("roofline") or {}
+    o["roofline"] = {k: rl.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms") if k in rl}
+    if "step_roof" in rl:
+        o["roofline"]["step_roof_frac"] = rl["step_roof"].get("frac")
+    cb = rec.get("cpu_baseline") or {}
+    o["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+    par = cb.get("parity_sampled") or c.get("parity_reference_golden")
+    if par:
+        o["parity"] = {k: v for k, v in par.items() if k in ("max_abs_dq", "max_abs_dg", "rel_dtheta", "cos_dtheta", "replicas", "steps", "vs")}
+    for k in ("f32", "bf16_rows", "steps52", "single_system", "neighbour_list", "md_steps_per_s_traj_only_per_gpu"):
+        if k in rec:
+            o[k] = rec[k]
+        elif k in c:
+            o[k] = c[k]
+    return json.dumps(_compact(o, cut=120))
+
+
+def _write_detail(out):
+    path = os.environ.get("MDG_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_full.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as fh:
+            json.dump(out, fh)
+    except OSError:
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="all", choices=["all", "lj108", "schnet4096", "lj4096"])
+    ap.add_argument("--workload", default="all", choices=["all", "lj108", "exvol108", "schnet4096", "lj4096", "water192"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
                     help="timed passes (default: ~4.5 s of GPU time on the headline workload, so that a coarse utilisation "
                          "sampler sees the device busy)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU (default 16384 / 8 / 64)")
-    ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11 / 51")
+    ap.add_argument("--frames", type=int, default=None, help="saved frames T (T-1 MD steps); default 50 / 11 / 51 / 21")
     ap.add_argument("--dt", type=float, default=0.005)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--bf16", action="store_true", help="schnet4096: bf16 MFMA operands in the filter network")
@@ -1093,6 +1333,8 @@ def main():
                          "option, SchNet.node_rows_bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--full-line", action="store_true", help="print the un-compacted record as the last line (default: compact "
+                                                              "line; the full record goes to gpurun_out/bench_full.json)")
     args = ap.parse_args()
     if args.bf16_rows:
         args.bf16 = True
@@ -1110,10 +1352,15 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     cpu = not args.no_cpu_baseline
+    lines = []
     if args.workload == "schnet4096":
         out = run_schnet4096(args, rank, world, dev, mdist, cpu)
     elif args.workload == "lj4096":
         out = run_lj4096(args, rank, world, dev, mdist, cpu)
+    elif args.workload == "water192":
+        out = run_water192(args, rank, world, dev, mdist, cpu)
+    elif args.workload == "exvol108":
+        out = run_lj108(args, rank, world, dev, mdist, cpu, form="exvol", dt=0.01)
     else:
         global _DEFERRED
         if args.workload == "all" and not args.no_secondary:
@@ -1122,23 +1369,35 @@ def main():
         if args.workload == "all" and not args.no_secondary:
             sec = {}
             import copy
-            # (>= 1 s of GPU time per secondary workload: 28 x ~41 ms (bf16) / 18 x ~56 ms (f32), 50 x ~20 ms)
+            # (>= 1 s of GPU time per secondary workload)
             # BASELINE config #5 names the bf16 cfconv MFMA: the SchNet workload runs with bf16 filter operands (stated
             # tolerance: tests/test_gpu_config5.py) and reports the all-f32 rate beside it
             a16 = copy.copy(args)
             a16.bf16 = True
             a16.bf16_rows = False
             # (warm-up passes: the first Adam step builds its state, and one of the first half-dozen passes of a process has
-            #  been seen to take ~100 ms longer than the rest (tools/hostprof_schnet.py --opt: pass 4 or 6 of 12, once, not a
-            #  collection of the cyclic collector; the lj4096 leg showed the same once: pass 5 of a fresh leg, 112 ms instead of
-            #  20.5 -- consistent with the caching allocator taking a multi-GB block from the driver for the first time) -- six /
-            #  eight warm-up passes keep that out of the timed ones)
-            for name, fn, st, wu, a_ in (("schnet4096", run_schnet4096, 28, 6, a16), ("lj4096", run_lj4096, 50, 8, args)):
+            #  been seen to take ~100 ms longer than the rest (the caching allocator taking a multi-GB block from the driver for
+            #  the first time) -- six / eight warm-up passes keep that out of the timed ones)
+            legs = (("exvol108", lambda: run_lj108(args, rank, world, dev, mdist, cpu, form="exvol", dt=0.01, steps=20, warmup=3)),
+                    ("schnet4096", lambda: run_schnet4096(a16, rank, world, dev, mdist, cpu, steps=28, warmup=6)),
+                    ("lj4096", lambda: run_lj4096(args, rank, world, dev, mdist, cpu, steps=50, warmup=8)),
+                    ("water192", lambda: run_water192(args, rank, world, dev, mdist, cpu, steps=20, warmup=4)))
+            for name, fn in legs:
                 try:
-                    sec[name] = fn(a_, rank, world, dev, mdist, cpu, steps=st, warmup=wu)
+                    sec[name] = fn()
                 except (Exception, SystemExit) as e:        # a secondary workload must not take the headline down
                     sec[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             if "error" not in sec["schnet4096"] and not args.bf16:
+                try:
+                    # SURVEY 8d M4 names opt_freq = 52 steps per pass (demo/fit_rdf_gnn.py): the same workload at that horizon
+                    a52 = copy.copy(a16)
+                    a52.frames_override = 53
+                    r52 = run_schnet4096(a52, rank, world, dev, mdist, False, steps=8, warmup=3)
+                    sec["schnet4096"]["steps52"] = {"value": r52["value"], "ms_per_step": r52["ms_per_step"], "md_steps_per_pass": 52 * 8,
+                                                    "searches_per_pass": (r52["config"].get("neighbour_list") or {}).get("searches_per_pass"),
+                                                    "step_roof_frac": r52["roofline"]["step_roof"]["frac"]}
+                except (Exception, SystemExit) as e:
+                    sec["schnet4096"]["steps52"] = {"error": "%s: %s" % (type(e).__name__, e)}
                 try:
                     f32 = run_schnet4096(args, rank, world, dev, mdist, False, steps=18, warmup=5)
                     sec["schnet4096"]["f32"] = {k: f32[k] for k in ("value", "ms_per_step", "dtype")}
@@ -1151,11 +1410,9 @@ def main():
                     a16r = copy.copy(a16)
                     a16r.bf16_rows = True
                     r16 = run_schnet4096(a16r, rank, world, dev, mdist, False, steps=28, warmup=5)
-                    sec["schnet4096"]["bf16_rows"] = {k: r16[k] for k in ("value", "ms_per_step", "dtype")}
+                    sec["schnet4096"]["bf16_rows"] = {k: r16[k] for k in ("value", "ms_per_step")}
                     sec["schnet4096"]["bf16_rows"]["step_roof_frac"] = r16["roofline"]["step_roof"]["frac"]
-                    sec["schnet4096"]["bf16_rows"]["vs_f32"] = r16["config"].get("bf16_vs_f32")
-                    sec["schnet4096"]["bf16_rows"]["kernel_ms"] = {"bwd_dual_theta": r16["roofline"]["kernel_ms"],
-                                                                   "fwd_tangent": r16["roofline"]["forward_kernel"]["kernel_ms"]}
+                    sec["schnet4096"]["bf16_rows"]["vs_f32"] = {k: v for k, v in (r16["config"].get("bf16_vs_f32") or {}).items() if k != "note"}
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["bf16_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["secondary"] = sec
@@ -1165,28 +1422,32 @@ def main():
                     fn()
                 except (Exception, SystemExit) as e:        # (a CPU leg must not take the measured lines down)
                     out.setdefault("cpu_leg_errors", []).append("%s: %s" % (type(e).__name__, e))
-            # the two other north-star workloads, in keys the driver's parser keeps: value, time per pass,
-            # the roofline fraction that binds each, and the CPU figure
-            ns = {}
+            # the other north-star workloads as flat scalars the driver's parser keeps, and one line each
             for name, rec in sec.items():
-                if "error" in rec:
-                    ns[name] = {"error": rec["error"]}
-                    continue
-                rl, cb = rec.get("roofline", {}), rec.get("cpu_baseline", {})
-                ns[name] = {"metric": rec["metric"], "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"],
-                            "steps": rec["steps"], "dtype": rec["dtype"], "replicas_per_gpu": rec["config"]["replicas_per_gpu"],
-                            "roofline_bound": rl.get("bound"), "roofline_frac": rl.get("frac"),
-                            "roofline_kernel": rl.get("kernel"),
-                            "step_roof_frac": (rl.get("step_roof") or {}).get("frac"),
-                            "cpu_baseline_value": cb.get("value"), "cpu_baseline_sample": cb.get("sample"),
-                            "parity_sampled": {k: v for k, v in (cb.get("parity_sampled") or {}).items() if k != "note"}}
-                if "f32" in rec:
-                    ns[name]["f32"] = rec["f32"]
-                if "bf16_rows" in rec:
-                    ns[name]["bf16_rows"] = rec["bf16_rows"]
-            out["config"]["north_star_workloads"] = ns
+                out["config"].update(_flat(name, rec))
+                lines.append(_line(name, rec))
+            s4 = sec.get("schnet4096") or {}
+            if "error" not in s4:
+                for k, tag in (("f32", "schnet4096_f32"), ("bf16_rows", "schnet4096_bf16rows"), ("steps52", "schnet4096_52step")):
+                    if isinstance(s4.get(k), dict) and "value" in s4[k]:
+                        out["config"][tag + "_md_steps_per_s"] = float("%.6g" % s4[k]["value"])
+                        out["config"][tag + "_step_roof_frac"] = s4[k].get("step_roof_frac")
+                ss = (s4.get("config") or {}).get("single_system") or {}
+                if "md_steps_per_s" in ss:
+                    out["config"]["single_system_md_steps_per_s"] = float("%.6g" % ss["md_steps_per_s"])
+                    out["config"]["single_system_us_per_md_step"] = float("%.6g" % ss["us_per_md_step"])
+                    for k in ("launches_per_md_step", "busy_us_per_md_step"):
+                        if k in ss:
+                            out["config"]["single_system_" + k] = ss[k]
     if rank == 0:
-        print(json.dumps(out))
+        _write_detail(out)
+        for ln in lines:
+            print(ln, flush=True)
+        if args.full_line:
+            print(json.dumps(out), flush=True)
+        else:
+            head = {k: v for k, v in out.items() if k != "secondary"}
+            print(json.dumps(_compact(head)), flush=True)
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
         mdist.barrier()

@@ -14,6 +14,14 @@
 //                           table (MDG_PAIR_TABLE, built by the caller from dL/d raw): dL/dx_i = sum_j phi'(d) D/d,
 //                           every pair from both ends, no atomics
 // Pair geometry as everywhere: reference minimum image (topology.py:59-64) and un-contracted d^2.
+//
+// Round 5: COLUMN TILES in LDS (rdf_cell_fwd_tile_kernel / rdf_cell_bwd_tile_kernel).  The row sweeps above read every
+// candidate of every atom from L2 (27 bins x ~19 atoms x 16 B per atom: 24 GB per backward call at 704 frames x 4 096 atoms --
+// the kernels ran at the L2 -> L1 rate, 4x above their arithmetic).  A workgroup now owns one (bx, by) column of bins of one
+// frame -- a contiguous range of the sorted array -- and stages the 3 x 3 columns around it (nine contiguous ranges, ~1 000
+// atoms = 16 KB) in LDS once; every row then reads its candidates with conflict-free ds_read_b128 (16 consecutive float4 per
+// row and pass).  Same candidates in the same per-lane order as the row sweeps: the backward sums are bit for bit the same,
+// the forward counts are integers.  A tile whose nine columns exceed the staged capacity takes the row sweep from L2.
 #include "common.hpp"
 
 namespace {
@@ -238,6 +246,196 @@ __global__ __launch_bounds__(256) void rdf_cell_bwd_kernel(const float4* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// column tiles (see the header): the staged neighbourhood of one (bx, by) column of one frame
+constexpr int RC_MAX_NB = 16;                // bins per dimension (RC_MAX_CELLS = 16^3)
+constexpr int RC_TILE_MAX = 4096;            // staged atoms at most (64 KB of float4)
+
+struct TileMeta {
+    int cbase[10];                           // first staged slot of stencil column c (c = 3 (dx + 1) + (dy + 1)); [9] = staged atoms
+    int gstart[9];                           // ... its first slot in the frame's sorted array
+    int zst[9][RC_MAX_NB + 1];               // staged slot of the first atom of z-bin z of column c
+    unsigned above;                          // bit c: column c's linear index is above the own column's (half stencil)
+    int fits;
+};
+
+// header + staging by the whole workgroup (blockDim threads).  Ends with a barrier.
+__device__ __forceinline__ void tile_stage(const float4* __restrict__ sp, const int32_t* __restrict__ bs, const CellGrid& g,
+                                           int cx, int cy, int cap, TileMeta& M, float4* tile) {
+    const int nbz = g.nb[2];
+    __syncthreads();                                                   // (the previous tile's rows are through)
+    if (threadIdx.x < 9) {
+        const int c = threadIdx.x;
+        const int col = (wrap_bin(cx + c / 3 - 1, g.nb[0]) * g.nb[1] + wrap_bin(cy + c % 3 - 1, g.nb[1])) * nbz;
+        M.gstart[c] = bs[col];
+        M.cbase[c + 1] = bs[col + nbz] - bs[col];                       // (length; prefix below)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        unsigned above = 0u;
+        const int own = (cx * g.nb[1] + cy) * nbz;
+        for (int c = 0; c < 9; ++c) {
+            const int len = M.cbase[c + 1];
+            M.cbase[c] = run;
+            run += len;
+            const int col = (wrap_bin(cx + c / 3 - 1, g.nb[0]) * g.nb[1] + wrap_bin(cy + c % 3 - 1, g.nb[1])) * nbz;
+            if (col > own) above |= 1u << c;
+        }
+        M.cbase[9] = run;
+        M.above = above;
+        M.fits = run <= cap;
+    }
+    __syncthreads();
+    if (!M.fits) return;
+    for (int t = threadIdx.x; t < 9 * (nbz + 1); t += blockDim.x) {
+        const int c = t / (nbz + 1), z = t - c * (nbz + 1);
+        const int col = (wrap_bin(cx + c / 3 - 1, g.nb[0]) * g.nb[1] + wrap_bin(cy + c % 3 - 1, g.nb[1])) * nbz;
+        M.zst[c][z] = M.cbase[c] + (bs[col + z] - M.gstart[c]);
+    }
+    const int total = M.cbase[9];
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        int c = 0;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) c += t >= M.cbase[k];
+        tile[t] = sp[M.gstart[c] + (t - M.cbase[c])];
+    }
+    __syncthreads();
+}
+
+// The row sweep of row_candidates over the staged tile: the same candidates in the same per-lane order (part, column,
+// entry s + 16 k), read from LDS.  slot_i = the row atom's staged slot (inside column 4).
+template <bool HALF, class Fn>
+__device__ __forceinline__ void tile_row_candidates(const float4* tile, const TileMeta& M, const MdgCell& cell, const CellGrid& g,
+                                                    const float4 pi, int slot_i, bool valid, int s, Fn&& fn) {
+    const int nbz = g.nb[2];
+    const int bz = bin_coord_c(pi.z, cell.inv[8], nbz);
+    const int wrapped = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);
+#pragma unroll 1
+    for (int part = 0; part < 2; ++part) {
+        const bool on = valid && (part == 0 || wrapped >= 0);
+        if (part == 1 && !__any(on)) break;
+        const int zlo = part ? max(wrapped, 0) : max(bz - 1, 0), zhi = part ? max(wrapped, 0) : min(bz + 1, nbz - 1);
+#pragma unroll 1
+        for (int c = 0; c < 9; ++c) {
+            int a0 = M.zst[c][zlo], a1 = M.zst[c][zhi + 1];
+            if (HALF && part == 0 && c == 4) a0 = slot_i + 1;
+            bool use = on;
+            if (HALF) use = use && (c == 4 ? (part == 0 || wrapped > bz) : ((M.above >> c) & 1u) != 0u);
+            if (!use) a1 = 0;
+            for (int a = a0 + s; a < a1; a += 16) fn(tile[a]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RC_THREADS) void rdf_cell_fwd_tile_kernel(const float4* __restrict__ spos,
+                                                                       const int32_t* __restrict__ bstart, int N, int n_frames,
+                                                                       MdgCell cell, CellGrid g, const float* __restrict__ mu,
+                                                                       float reach, float inv_h, int nfine, int nfine_pad,
+                                                                       float cutoff, int cap, uint32_t* __restrict__ ghist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t hist[];
+    float4* tile = reinterpret_cast<float4*>(hist + nfine_pad);
+    __shared__ TileMeta M;
+    const float tlo = -(mu[0] - reach) * inv_h;
+    for (int m = threadIdx.x; m < nfine; m += blockDim.x) hist[m] = 0u;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, s = lane & 15;
+    const uint32_t fmax_bits = __float_as_uint(fminf((float)nfine, fmaf(cutoff, inv_h, tlo)));
+    const int ncol = g.nb[0] * g.nb[1];
+    const long long ntiles = (long long)n_frames * ncol;
+    auto count = [&](const float4 pi, const float4 pj) {
+        float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;
+        min_image<true>(cell, dx, dy, dz);
+        const float tt = fmaf(__builtin_amdgcn_sqrtf(norm2_ref(dx, dy, dz)), inv_h, tlo);
+        if (__float_as_uint(tt) < fmax_bits) atomicAdd(&hist[(int)tt], 1u);
+    };
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int f = (int)(tl / ncol), colid = (int)(tl - (long long)f * ncol);
+        const float4* sp = spos + (size_t)f * N;
+        const int32_t* bs = bstart + (size_t)f * (g.ncell + 1);
+        tile_stage(sp, bs, g, colid / g.nb[1], colid % g.nb[1], cap, M, tile);
+        const int own0 = M.cbase[4], nown = M.cbase[5] - M.cbase[4], g0 = M.gstart[4];
+        for (int r0 = wid * 4; r0 < nown; r0 += nw * 4) {
+            const int r = r0 + (lane >> 4);
+            const bool valid = r < nown;
+            const int rc_ = valid ? r : nown - 1;
+            if (M.fits) {
+                const float4 pi = tile[own0 + rc_];
+                tile_row_candidates<true>(tile, M, cell, g, pi, own0 + rc_, valid, s, [&](const float4 pj) { count(pi, pj); });
+            } else {
+                const float4 pi = sp[g0 + rc_];
+                row_candidates<true>(sp, bs, cell, g, pi, g0 + rc_, valid, s, [&](const float4 pj) { count(pi, pj); });
+            }
+        }
+    }
+    __syncthreads();
+    for (int m = threadIdx.x; m < nfine; m += blockDim.x) {
+        const uint32_t v = hist[m];
+        if (v) atomicAdd(&ghist[m], v);
+    }
+}
+
+__global__ __launch_bounds__(256) void rdf_cell_bwd_tile_kernel(const float4* __restrict__ spos, const int32_t* __restrict__ bstart,
+                                                                int N, int n_frames, MdgCell cell, CellGrid g, MdgPairTerm term,
+                                                                const float* __restrict__ theta, int cap, float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) float4 tile_b[];
+    __shared__ TileMeta M;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, s = lane & 15;
+    const TermConst tc = term_prepare(term, theta);
+    const int ncol = g.nb[0] * g.nb[1];
+    const long long ntiles = (long long)n_frames * ncol;
+    for (long long tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int f = (int)(tl / ncol), colid = (int)(tl - (long long)f * ncol);
+        const float4* sp = spos + (size_t)f * N;
+        const int32_t* bs = bstart + (size_t)f * (g.ncell + 1);
+        tile_stage(sp, bs, g, colid / g.nb[1], colid % g.nb[1], cap, M, tile_b);
+        const int own0 = M.cbase[4], nown = M.cbase[5] - M.cbase[4], g0 = M.gstart[4];
+        for (int r0 = wid * 4; r0 < nown; r0 += nw * 4) {
+            const int r = r0 + (lane >> 4);
+            const bool valid = r < nown;
+            const int rc_ = valid ? r : nown - 1;
+            const float4 pi = M.fits ? tile_b[own0 + rc_] : sp[g0 + rc_];
+            const int idx_i = __float_as_int(pi.w);
+            float gx = 0.f, gy = 0.f, gz = 0.f;
+            auto force = [&](const float4 pj) {
+                if (__float_as_int(pj.w) == idx_i) return;
+                float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;             // D = x_j - x_i
+                min_image<true>(cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                if (!(d2 < tc.rc2) || d2 == 0.f) return;
+                PairOut o;
+                float rr, ir;
+                pair_eval<1, MDG_PAIR_TABLE>(tc, d2, rr, ir, o);
+                const float c1 = -o.du * ir;
+                gx = fmaf(c1, dx, gx); gy = fmaf(c1, dy, gy); gz = fmaf(c1, dz, gz);
+            };
+            if (M.fits) tile_row_candidates<false>(tile_b, M, cell, g, pi, own0 + rc_, valid, s, force);
+            else row_candidates<false>(sp, bs, cell, g, pi, g0 + rc_, valid, s, force);
+            gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);                  // (fixed order: reproducible)
+            if (valid && s < 3) grad[((size_t)f * N + idx_i) * 3 + s] = s == 0 ? gx : (s == 1 ? gy : gz);
+        }
+    }
+}
+
+constexpr size_t RC_LDS_BYTES = 160 * 1024;   // LDS of a gfx950 CU (one 1 024-thread forward workgroup per CU)
+
+// MDG_RDF_CELL_TILES=0 keeps the row sweeps from L2 (A/B measurements, tests of the two against each other)
+bool tiles_enabled() {
+    const char* e = getenv("MDG_RDF_CELL_TILES");      // (read per call: a test flips it between two calls)
+    return !(e && e[0] == '0');
+}
+
+// staged capacity of a launch: 1.5 x the nine columns of a uniform frame (+ slack), at most RC_TILE_MAX and what `lds_left`
+// bytes hold; tiles beyond it take the row sweep from L2
+int tile_capacity(int n_atoms, const CellGrid& g, size_t lds_left) {
+    long long est = (long long)(9.0 * 1.5 * n_atoms / (double)(g.nb[0] * g.nb[1])) + 64;
+    if (est > n_atoms) est = n_atoms;
+    if (est > RC_TILE_MAX) est = RC_TILE_MAX;
+    const long long room = (long long)(lds_left / sizeof(float4));
+    if (est > room) est = room;
+    return est < 64 ? 0 : (int)est;
+}
+
 struct Scratch { int32_t* bstart; int32_t* tmp; float4* spos; };
 
 Scratch carve(int32_t* scratch, int F, int N, const CellGrid& g) {
@@ -292,6 +490,16 @@ extern "C" int mdg_rdf_fwd_cell(const float* xyz, int n_frames, int n_atoms, con
     const int total = n_frames * n_atoms;
     int grid = (total + 63) / 64;
     if (grid > 512) grid = 512;                                      // (persistent: one histogram flush per workgroup)
+    const int nfine_pad = ((int)P.nfine + 3) & ~3;
+    const size_t hist_bytes = sizeof(uint32_t) * (size_t)nfine_pad;
+    const int cap = (tiles_enabled() && hist_bytes + 4096 < RC_LDS_BYTES) ? tile_capacity(n_atoms, g, RC_LDS_BYTES - 4096 - hist_bytes) : 0;
+    if (cap > 0) {
+        const long long ntiles = (long long)n_frames * g.nb[0] * g.nb[1];
+        const int gt = ntiles < 512 ? (int)ntiles : 512;
+        hipLaunchKernelGGL(rdf_cell_fwd_tile_kernel, dim3((unsigned)gt), dim3(RC_THREADS), hist_bytes + sizeof(float4) * (size_t)cap,
+                           st, S.spos, S.bstart, n_atoms, n_frames, *cell, g, mu, P.reach, 1.0f / P.h, (int)P.nfine, nfine_pad,
+                           cutoff, cap, ghist);
+    } else
     hipLaunchKernelGGL(rdf_cell_fwd_kernel, dim3((unsigned)grid), dim3(RC_THREADS), sizeof(uint32_t) * (size_t)P.nfine, st,
                        S.spos, S.bstart, n_atoms, total, *cell, g, mu, P.reach, 1.0f / P.h, (int)P.nfine, cutoff, ghist);
     const int rc = mdg_rdf_fine_finish(ghist, P, mu, nbins, raw, st);
@@ -313,6 +521,13 @@ extern "C" int mdg_rdf_bwd_cell(int n_frames, int n_atoms, const MdgCell* cell, 
     const int total = n_frames * n_atoms;
     int grid = (total + 15) / 16;
     if (grid > 4096) grid = 4096;
+    const int cap = tiles_enabled() ? tile_capacity(n_atoms, g, sizeof(float4) * (size_t)RC_TILE_MAX) : 0;
+    if (cap > 0) {
+        const long long ntiles = (long long)n_frames * g.nb[0] * g.nb[1];
+        const int gt = ntiles < (1 << 20) ? (int)ntiles : (1 << 20);
+        hipLaunchKernelGGL(rdf_cell_bwd_tile_kernel, dim3((unsigned)gt), dim3(256), sizeof(float4) * (size_t)cap, st, S.spos, S.bstart,
+                           n_atoms, n_frames, *cell, g, *term, theta, cap, g_xyz);
+    } else
     hipLaunchKernelGGL(rdf_cell_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, st, S.spos, S.bstart, n_atoms, total, *cell, g,
                        *term, theta, g_xyz);
     MDG_CHECK_LAUNCH("rdf_bwd_cell");

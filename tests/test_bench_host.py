@@ -32,3 +32,49 @@ def test_pass_trace_is_off_unless_asked_for(monkeypatch, capsys):
     tr.start(); tr.tick(); tr.tick(); tr.done()
     err = capsys.readouterr().err
     assert len(tr.t) == 2 and "[trace leg] ms per pass" in err and "collections" in err
+
+
+def _fake_secondary():
+    return {"metric": "MD steps/sec (fwd+adjoint), 4096-bead SchNet CG water NHC", "value": 3019.123456789, "unit": "MD steps/s",
+            "n_gpus": 1, "steps": 28, "warmup": 6, "ms_per_step": 26.5, "dtype": "bf16 filter MFMA operands, f32 accumulate",
+            "config": {"replicas_per_gpu": 8, "dist": {"per_rank_ms": [26.5]}, "single_system": {"md_steps_per_s": 1233.0,
+                                                                                                 "us_per_md_step": 811.0}},
+            "roofline": {"bound": "mfma", "kernel": "k" * 400, "achieved": 117.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.047,
+                         "traffic": 1.0e8, "kernel_ms": 0.176, "note": "n" * 2000, "step_roof": {"frac": 0.19, "model": "m" * 500}},
+            "cpu_baseline": {"value": 0.1, "unit": "MD steps/s", "cores": 16, "kind": "port", "sample": "s" * 600,
+                             "parity_sampled": {"max_abs_dq": 1e-6, "max_abs_dg": 2e-5, "rel_dtheta": 4e-4, "note": "x" * 900}}}
+
+
+def test_secondary_workloads_become_flat_scalars_and_short_lines():
+    """the driver keeps the scalar keys of `config` and the tail of stdout -- every secondary workload must
+    survive both: flat scalar keys on the headline, one compact JSON line each before it."""
+    import json
+    bench = importlib.import_module("bench")
+    rec = _fake_secondary()
+    flat = bench._flat("schnet4096", rec)
+    assert flat["schnet4096_md_steps_per_s"] == 3019.12 and flat["schnet4096_ms_per_pass"] == 26.5
+    assert flat["schnet4096_step_roof_frac"] == 0.19 and flat["schnet4096_kernel_frac"] == 0.047
+    assert flat["schnet4096_cpu_steps_per_s"] == 0.1 and flat["schnet4096_parity_max_abs_dq"] == 1e-6
+    assert all(isinstance(v, (int, float, str)) for v in flat.values()), "scalars only: nested values are dropped by the driver"
+    line = bench._line("schnet4096", rec)
+    assert len(line) < 1500 and "\n" not in line
+    back = json.loads(line)
+    assert back["workload"] == "schnet4096" and back["roofline"]["step_roof_frac"] == 0.19 and back["parity"]["rel_dtheta"] == 4e-4
+    assert "error" in json.loads(bench._line("lj4096", {"error": "RuntimeError: x"}))
+    assert bench._flat("lj4096", {"error": "boom"}) == {"lj4096_error": "boom"}
+
+
+def test_compact_headline_drops_notes_and_keeps_every_contract_key():
+    bench = importlib.import_module("bench")
+    head = {"metric": "m", "value": 1.23456789e7, "unit": "u", "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 22.3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "w" * 300, "dist": {"backend": "nccl", "per_rank_ms": [1.0]}},
+            "roofline": {"bound": "valu", "achieved": 26.1, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.166, "traffic": None,
+                         "note": "n" * 3000},
+            "cpu_baseline": {"value": 124.0, "unit": "MD steps/s", "cores": 16, "kind": "port", "sample": "s" * 700}}
+    c = bench._compact(head)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c
+    assert "note" not in c["roofline"] and len(c["cpu_baseline"]["sample"]) <= 150 and c["value"] == 1.23457e7
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"])

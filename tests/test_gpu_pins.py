@@ -873,6 +873,48 @@ def test_cell_sweep_rdf_equals_list_rdf_and_is_reproducible():
     close(out[0][1], out[2][1], 1e-4, 1e-6 * float(out[2][1].abs().max()), "gradient: sweep vs list")
 
 
+@pytest.mark.parametrize("case", ["liquid4096", "crowded", "dilute", "tall_box"])
+def test_cell_sweep_rdf_column_tiles_equal_the_row_sweep_bitwise(case, monkeypatch):
+    """Round 5: the cell-sweep RDF stages the 3 x 3 bin columns around a workgroup's column in LDS (csrc/rdf_cell.hip
+    rdf_cell_*_tile_kernel) instead of reading every candidate from L2.  Same candidates in the same per-lane order: the
+    histogram AND the gradient are bitwise the ones of the row sweep (MDG_RDF_CELL_TILES=0).  crowded: a 600-atom cluster
+    makes one column overflow the staged capacity, so its tiles take the row sweep inside the tile kernel; dilute: 16 capped
+    bins per side, mostly empty columns; tall_box: nb = (3, 4, 9) -- every x column is a neighbour of every other."""
+    from mdgrad_amd.observable import rdf
+    rng = np.random.default_rng(21)
+    if case == "dilute":
+        L = 60.0
+        cell = np.array([L, L, L], dtype=np.float32)
+        pos = rng.uniform(0, L, (2048, 3)).astype(np.float32)
+        pos[1::2] = np.mod(pos[0::2] + rng.normal(0, 0.9, (1024, 3)), L).astype(np.float32)
+        frames = np.stack([pos, np.mod(pos + rng.normal(0, 0.3, pos.shape), L).astype(np.float32)])
+    elif case == "tall_box":
+        cell = np.array([8.0, 10.6, 24.0], dtype=np.float32)
+        n = 2048
+        pos = (rng.uniform(0, 1, (n, 3)) * cell).astype(np.float32)
+        frames = np.stack([pos, np.mod(pos + rng.normal(0, 0.2, pos.shape), cell).astype(np.float32),
+                           (pos + np.array([8.0, -10.6, 24.0], dtype=np.float32)).astype(np.float32)])
+    else:
+        pos, cell = liquid(16, seed=5, jitter=0.08)
+        frames = np.stack([np.mod(pos + rng.normal(0, 0.06, pos.shape), cell) for _ in range(4)]).astype(np.float32)
+        if case == "crowded":
+            frames[2, :600] = (np.asarray(cell) * 0.5 + rng.normal(0, 0.5, (600, 3))).astype(np.float32)
+    system = mk_system(frames[0], cell)
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    wgt = torch.linspace(1, -1, 100, device=DEV)
+    out = {}
+    for tiles in ("1", "0", "1"):
+        monkeypatch.setenv("MDG_RDF_CELL_TILES", tiles)
+        x = T(frames, DEV).requires_grad_(True)
+        count, _, gr = obs(x)
+        (gx,) = torch.autograd.grad((gr * wgt).sum(), x)
+        out.setdefault(tiles, []).append((count.clone(), gx.clone()))
+    assert float(out["1"][0][0].sum()) > 0
+    assert torch.equal(out["1"][0][0], out["0"][0][0]), "histogram: tiles vs row sweep"
+    assert torch.equal(out["1"][0][1], out["0"][0][1]), "gradient: tiles vs row sweep (bitwise)"
+    assert torch.equal(out["1"][0][1], out["1"][1][1]), "two runs of the tile kernels differ"
+
+
 @pytest.mark.parametrize("case", ["two_species_lj126", "excluded_pairs_ljfam", "two_species_nve", "odd_atoms"])
 def test_ring_kernels_with_a_selection_mask_vs_oracle(case):
     """The wave-per-replica kernels with a masked term (first half): index_tuple = (A, B) of a two-species
