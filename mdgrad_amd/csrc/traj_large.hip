@@ -35,6 +35,9 @@ constexpr float LG_SKIN = 0.12f;             // skin of the stored lists, as a f
 constexpr float LG_REUSE = 0.45f;            // the forward pass searches again once an atom has moved this fraction of the skin
                                              // (< 1/2: room for the adjoint's midpoint states between two frames)
 constexpr long long LG_LIST_MAX_WORDS = 1ll << 33;   // at most 32 GiB of stored lists (of 288); beyond that every evaluation searches
+constexpr int LG_TILE_THREADS = 512;          // workgroup of the column-tile kernels (32 rows of 16 lanes)
+constexpr int LG_TILE_MAX = 4096;            // staged atoms of a column tile at most
+constexpr int LG_MAX_COLS = 1366;            // bin columns (nbx nby) at most: LG_MAX_CELLS / 3
 constexpr int LG_KMAX = MDG_MAX_TERMS * MDG_MAX_THETA;
 constexpr int LG_NV = LG_KMAX + 2;           // theta partials, sum p^2/m, sum lambda_v.v
 
@@ -81,6 +84,20 @@ struct LargeArgs {
     int32_t* nl_state;                       // [R][2]  {the coming force launch searches, frame of the current list}
     int nbL;                                 // workgroups (partial rows) of the listed force launches
     float skin;                              // absolute skin (0: lists not kept)
+    // COLUMN TILES (round 5; binned boxes with kept lists).  The listed launches gathered every candidate's position and
+    // adjoint direction from L2 by atom index -- ~48 fully divergent 12-byte gathers per wave, bound by the CU's address /
+    // L1 path at 66 us per adjoint evaluation of 64 x 4 096 atoms.  Now a workgroup owns one (bx, by) column of bins of
+    // the list's BUILD (a contiguous range of the build's sorted order), stages the 3 x 3 columns around it -- nine
+    // contiguous ranges of a copy of the state kept in that sorted order -- in LDS once, and a stored row holds 16-bit
+    // slots INTO THE STAGED TILE: every candidate is an LDS read (ds_read_b96).  The order is fixed for the life of a
+    // build (atoms stay within skin / 2 of where they were binned), so the permutation is applied once per build to the
+    // rows and once per evaluation to the state copy (written by the prep launch that produces that state anyway).
+    int32_t* nl_rank;                        // [R][T][N]  sorted slot of atom a in the build of frame b
+    int32_t* nl_bst;                         // [R][T][LG_MAX_COLS + 1]  first sorted slot of bin column c of that build
+    float4* spk;                             // [R][N]  forward: (x, y, z, index) of the current positions in the current build's order
+    float4* apk;                             // [R][2 builds][pos | w][N]  adjoint: the evaluation's state in the order of build A / B
+    int tile_cap;                            // staged atoms of a tile at most (0: no tiles)
+    int ncol;                                // bin columns nb[0] nb[1]
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -248,98 +265,118 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const float lim = (k + 2 >= T ? 0.5f * LG_REUSE : LG_REUSE) * A.skin;
             const int search = __syncthreads_or(!(far2 <= lim * lim)) || A.nl_bad[(size_t)rep * T + bfr] != 0;
             if (threadIdx.x == 0) A.nl_state[2 * rep] = search;
-            if (!search) return;
-        }
-    }
-    if constexpr (PHASE == 2 || PHASE == 4) {
-        const int i_fr = A.step + 1;                                   // the interval being finished
-        if (i_fr <= T - 1) {
-            const size_t go = ((size_t)rep * T + i_fr - 1) * N * 3;
-            const float h = A.t[i_fr] - A.t[i_fr - 1];
-            if (nhc) {
-                const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
-                const float* lph = A.lph + rep * MDG_MAX_CHAINS;
-                float* lp = A.lp + rep * MDG_MAX_CHAINS;
-                const float pvm0 = pvm[0], lpm0 = lph[0];
-                float tot[LG_NV];
-                sum_partial_rows(A.partN + (size_t)rep * A.nbF * LG_NV, A.nbF, tot, redN);
-                const float slv = tot[LG_KMAX + 1];
-                const int KT = A.terms.n_theta_total;
-                if (first && threadIdx.x == 0) {
+            if (!search) {
+                if (A.tile_cap) {                                          // the listed launch stages from the build's order
+                    const int32_t* rk = A.nl_rank + ((size_t)rep * T + bfr) * N;
+                    float4* pk = A.spk + (size_t)rep * N;
 #pragma unroll
-                    for (int m = 0; m < MDG_MAX_TERMS; ++m)
-#pragma unroll
-                        for (int p = 0; p < MDG_MAX_THETA; ++p)
-                            if (m < A.terms.n_terms && p < A.terms.t[m].n_theta)
-                                A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += tot[m * MDG_MAX_THETA + p] * h;   // :160
-                }
-                if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
-                __syncthreads();
-                if (first && threadIdx.x < C) {
-                    const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
-                    float nlp = lp[threadIdx.x] + gp * h;                               // :158
-                    if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
-                    lp[threadIdx.x] = nlp;
-                }
-#pragma unroll
-                for (int u = 0; u < NA; ++u) {
-                    const int a = tid + u * stride;
-                    if (a >= N) break;
-                    const float m = A.mass[a];
-                    const size_t e3 = so + 3 * (size_t)a, g3 = go + 3 * (size_t)a;
-                    const Row3 lvhr = ld3(A.lvh, e3), lqhr = ld3(A.lqh, e3), vmr = ld3(A.vm, e3), lvr = ld3(A.lv, e3),
-                               lqr = ld3(A.lq, e3), dqr = ld3(A.dq, e3);
-                    const Row3 gvr = A.g_v ? ld3(A.g_v, g3) : Row3{0.f, 0.f, 0.f}, gqr = A.g_q ? ld3(A.g_q, g3) : Row3{0.f, 0.f, 0.f};
-                    const float lvh_[3] = {lvhr.x, lvhr.y, lvhr.z}, lqh_[3] = {lqhr.x, lqhr.y, lqhr.z}, vm_[3] = {vmr.x, vmr.y, vmr.z};
-                    const float lv_[3] = {lvr.x, lvr.y, lvr.z}, lq_[3] = {lqr.x, lqr.y, lqr.z}, dq_[3] = {dqr.x, dqr.y, dqr.z};
-                    const float gv_[3] = {gvr.x, gvr.y, gvr.z}, gq_[3] = {gqr.x, gqr.y, gqr.z};
-                    float nlv[3], nlq[3];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float Gv = -(pvm0 / A.prm.Q[0]) * lvh_[c] + lqh_[c] + 2.f * m * vm_[c] * lpm0;
-                        nlv[c] = lv_[c] + Gv * h;                                       // :156
-                        nlq[c] = lq_[c] + dq_[c] * h;                                   // :157
-                        if (A.g_v) nlv[c] += gv_[c];                                    // :286
-                        if (A.g_q) nlq[c] += gq_[c];
-                    }
-                    st3(A.lv, e3, nlv[0], nlv[1], nlv[2]);
-                    st3(A.lq, e3, nlq[0], nlq[1], nlq[2]);
-                    if (PHASE == 2 && A.nl_idx) {                                       // (w = lam_v / m of the coming listed evaluation)
-                        const float im = 1.0f / m;
-                        st3(A.wl, e3, nlv[0] * im, nlv[1] * im, nlv[2] * im);
-                    }
-                }
-            } else {
-                // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
-#pragma unroll
-                for (int u = 0; u < 3 * NA; ++u) {
-                    const int e = tid + u * stride;
-                    if (e >= 3 * N) break;
-                    float nlv = A.lvh[so + e];
-                    float nlq = A.lqh[so + e] + A.dq[so + e] * h * 0.5f;
-                    if (A.g_v) nlv += A.g_v[go + e];
-                    if (A.g_q) nlq += A.g_q[go + e];
-                    A.lv[so + e] = nlv; A.lq[so + e] = nlq;
-                }
-            }
-        }
-        if constexpr (PHASE == 2) {
-            if (A.nl_idx) {
-                // the stored candidates of frame i serve; the listed evaluation gathers w = lam_v / m (NVE: lam_v) of
-                // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic).
-                // (NHC intervals that were finished above wrote it with their update; this loop serves the last frame's
-                //  first interval -- nothing to finish -- and NVE)
-                if (!(nhc && i_fr <= T - 1)) {
-#pragma unroll
-                    for (int u = 0; u < 3 * NA; ++u) {
-                        const int e = tid + u * stride;
-                        if (e >= 3 * N) break;
-                        A.wl[so + e] = nhc ? A.lv[so + e] * (1.0f / A.mass[e / 3]) : A.lv[so + e];
+                    for (int u = 0; u < NA; ++u) {
+                        const int a = tid + u * stride;
+                        if (a < N) pk[rk[a]] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
                     }
                 }
                 return;
             }
-            const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
+        }
+    }
+    if constexpr (PHASE == 2 || PHASE == 4) {
+        const int i_fr = A.step + 1;                                   // the interval being finished
+        const bool fin = i_fr <= T - 1;
+        const size_t go = ((size_t)rep * T + (fin ? i_fr - 1 : 0)) * N * 3;
+        const float h = fin ? A.t[i_fr] - A.t[i_fr - 1] : 0.f;
+        float pvm0 = 0.f, lpm0 = 0.f;
+        if (fin && nhc) {
+            const float* pvm = A.pvm + rep * MDG_MAX_CHAINS;
+            const float* lph = A.lph + rep * MDG_MAX_CHAINS;
+            float* lp = A.lp + rep * MDG_MAX_CHAINS;
+            pvm0 = pvm[0]; lpm0 = lph[0];
+            float tot[LG_NV];
+            sum_partial_rows(A.partN + (size_t)rep * A.nbF * LG_NV, A.nbF, tot, redN);
+            const float slv = tot[LG_KMAX + 1];
+            const int KT = A.terms.n_theta_total;
+            if (first && threadIdx.x == 0) {
+#pragma unroll
+                for (int m = 0; m < MDG_MAX_TERMS; ++m)
+#pragma unroll
+                    for (int p = 0; p < MDG_MAX_THETA; ++p)
+                        if (m < A.terms.n_terms && p < A.terms.t[m].n_theta)
+                            A.gth[(size_t)rep * KT + A.terms.t[m].theta_off + p] += tot[m * MDG_MAX_THETA + p] * h;   // :160
+            }
+            if (threadIdx.x < C) { pvs[threadIdx.x] = pvm[threadIdx.x]; lps[threadIdx.x] = lph[threadIdx.x]; }
+            __syncthreads();
+            if (first && threadIdx.x < C) {
+                const float gp = bath_vjp_l(A.prm, Qs, pvs, lps, slv, threadIdx.x);
+                float nlp = lp[threadIdx.x] + gp * h;                               // :158
+                if (A.g_pv) nlp += A.g_pv[((size_t)rep * T + i_fr - 1) * C + threadIdx.x];
+                lp[threadIdx.x] = nlp;
+            }
+        }
+        // the coming listed evaluation (PHASE 2, first evaluation of interval A.step) gathers w = lam_v / m (NVE: lam_v) of
+        // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic); with column
+        // tiles it stages (q_t[A.step], w) from a copy in the order of the build that serves frame A.step
+        const bool want_w = PHASE == 2 && A.nl_idx != nullptr;
+        const bool pack = want_w && A.tile_cap > 0;
+        const int bA = pack ? A.nl_build[(size_t)rep * T + A.step] : 0;
+        const int32_t* rk = A.nl_rank + ((size_t)rep * T + bA) * N;
+        const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
+        float4* pkq = A.apk + (size_t)rep * 4 * N;
+        float4* pkw = pkq + N;
+        if (fin || want_w) {
+#pragma unroll
+            for (int u = 0; u < NA; ++u) {
+                const int a = tid + u * stride;
+                if (a >= N) break;
+                const float m = A.mass[a];
+                const size_t e3 = so + 3 * (size_t)a, g3 = go + 3 * (size_t)a;
+                float nlv[3];
+                if (fin) {
+                    const Row3 lvhr = ld3(A.lvh, e3), lqhr = ld3(A.lqh, e3), dqr = ld3(A.dq, e3);
+                    const Row3 gvr = A.g_v ? ld3(A.g_v, g3) : Row3{0.f, 0.f, 0.f}, gqr = A.g_q ? ld3(A.g_q, g3) : Row3{0.f, 0.f, 0.f};
+                    const float lvh_[3] = {lvhr.x, lvhr.y, lvhr.z}, lqh_[3] = {lqhr.x, lqhr.y, lqhr.z}, dq_[3] = {dqr.x, dqr.y, dqr.z};
+                    const float gv_[3] = {gvr.x, gvr.y, gvr.z}, gq_[3] = {gqr.x, gqr.y, gqr.z};
+                    float nlq[3];
+                    if (nhc) {
+                        const Row3 vmr = ld3(A.vm, e3), lvr = ld3(A.lv, e3), lqr = ld3(A.lq, e3);
+                        const float vm_[3] = {vmr.x, vmr.y, vmr.z}, lv_[3] = {lvr.x, lvr.y, lvr.z}, lq_[3] = {lqr.x, lqr.y, lqr.z};
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float Gv = -(pvm0 / A.prm.Q[0]) * lvh_[c] + lqh_[c] + 2.f * m * vm_[c] * lpm0;
+                            nlv[c] = lv_[c] + Gv * h;                                       // :156
+                            nlq[c] = lq_[c] + dq_[c] * h;                                   // :157
+                            if (A.g_v) nlv[c] += gv_[c];                                    // :286
+                            if (A.g_q) nlq[c] += gq_[c];
+                        }
+                    } else {
+                        // verlet_update backward branch, second half (sovlers.py:100) + dL/dy_{i-1} (:286)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            nlv[c] = lvh_[c];
+                            nlq[c] = lqh_[c] + dq_[c] * h * 0.5f;
+                            if (A.g_v) nlv[c] += gv_[c];
+                            if (A.g_q) nlq[c] += gq_[c];
+                        }
+                    }
+                    st3(A.lv, e3, nlv[0], nlv[1], nlv[2]);
+                    st3(A.lq, e3, nlq[0], nlq[1], nlq[2]);
+                } else {
+                    const Row3 lvr = ld3(A.lv, e3);                                         // (the last frame: nothing to finish)
+                    nlv[0] = lvr.x; nlv[1] = lvr.y; nlv[2] = lvr.z;
+                }
+                if (want_w) {
+                    const float im = nhc ? 1.0f / m : 1.0f;
+                    const float wx = nlv[0] * im, wy = nlv[1] * im, wz = nlv[2] * im;
+                    st3(A.wl, e3, wx, wy, wz);
+                    if (pack) {
+                        const Row3 qr = ld3(qf, 3 * (size_t)a);
+                        const int sl = rk[a];
+                        pkq[sl] = make_float4(qr.x, qr.y, qr.z, __int_as_float(a));
+                        pkw[sl] = make_float4(wx, wy, wz, 0.f);
+                    }
+                }
+            }
+        }
+        if constexpr (PHASE == 2) {
+            if (A.nl_idx) return;                                      // (the stored candidates of frame i serve)
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
                 const int a = tid + u * stride;
@@ -430,6 +467,19 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 st3(A.vm, e3, vmo[0], vmo[1], vmo[2]);
                 st3(A.lvh, e3, lvho[0], lvho[1], lvho[2]);
                 if (A.nl_idx) st3(A.wl, e3, wlo[0], wlo[1], wlo[2]);
+                if (A.tile_cap) {
+                    // (which build serves the midpoint is known only after every workgroup has measured its atoms: the
+                    //  state goes out in the order of both candidates -- one copy when they are the same build)
+                    float4* pk = A.apk + (size_t)rep * 4 * N;
+                    const int sA = A.nl_rank[((size_t)rep * T + slotA) * N + a];
+                    pk[sA] = make_float4(qn[0], qn[1], qn[2], __int_as_float(a));
+                    pk[N + sA] = make_float4(wlo[0], wlo[1], wlo[2], 0.f);
+                    if (slotB != slotA) {
+                        const int sB = A.nl_rank[((size_t)rep * T + slotB) * N + a];
+                        pk[2 * N + sB] = make_float4(qn[0], qn[1], qn[2], __int_as_float(a));
+                        pk[3 * N + sB] = make_float4(wlo[0], wlo[1], wlo[2], 0.f);
+                    }
+                }
                 st3(A.lqh, e3, lqho[0], lqho[1], lqho[2]);
                 st3(A.qm, e3, qn[0], qn[1], qn[2]);
                 far2 = fmaxf(far2, mv2);
@@ -1013,6 +1063,11 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
             A.nl_state[2 * rep + 1] = frame;
             if (MODE == 0) A.nl_state[2 * rep] = 1;
         }
+        {                                                            // the build's bin columns, for the tiles of its consumers
+            const int32_t* bs0 = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
+            int32_t* dst = A.nl_bst + ((size_t)rep * T + frame) * (LG_MAX_COLS + 1);
+            for (int c = threadIdx.x; c <= A.ncol; c += blockDim.x) dst[c] = bs0[c * A.nb[2]];
+        }
         if (MODE == 1 && nhc) {                                      // finish the bath with KE(v + vh), as large_force_step<1>
             if (threadIdx.x < MDG_MAX_CHAINS) {
                 float qv = 0.f;
@@ -1045,12 +1100,13 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
     const int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
     const float4 pi = sp[valid ? slot : N - 1];
     const int i = __float_as_int(pi.w);
-    const size_t at = ((size_t)rep * T + frame) * N + i;
+    // (column tiles: the row lives at the atom's SORTED SLOT and holds staged-tile slots; see LargeArgs)
+    const size_t at = ((size_t)rep * T + frame) * N + (valid ? slot : N - 1);
     uint16_t* lrow = A.nl_idx + at * LG_LIST;
     int cnt = 0;                                                     // candidates of the row's atom so far (row-uniform)
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
     // every lane runs this for every chunk (live = it holds a candidate): the row's ballot bits give the slots
-    auto take = [&](const float4 pj, bool live) {
+    auto take = [&](const float4 pj, bool live, int loc) {
         const int j = __float_as_int(pj.w);
         float dx = pj.x - pi.x, dy = pj.y - pi.y, dz = pj.z - pi.z;            // D = x_j - x_i
         min_image<true>(A.cell, dx, dy, dz);
@@ -1059,7 +1115,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
         const unsigned rowmask = (unsigned)(__ballot(in) >> (16 * row)) & 0xffffu;
         if (in) {
             const int at_ = cnt + __popc(rowmask & ((1u << s) - 1u));
-            if (at_ < LG_LIST) lrow[at_] = (uint16_t)j;
+            if (at_ < LG_LIST) lrow[at_] = (uint16_t)loc;
             if (d2 != 0.f)                                                    // topology.py:67
                 pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx,
                                     gy, gz, th);
@@ -1078,6 +1134,22 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
             cx = cx < 0 ? cx + nbx : (cx >= nbx ? cx - nbx : cx);
             cy = cy < 0 ? cy + nby : (cy >= nby ? cy - nby : cy);
             col[c] = (cx * nby + cy) * nbz;
+        }
+        // the row's column tile: the nine stencil columns in stencil order, each the contiguous range [bs[col], bs[col + nbz])
+        // of the sorted array; staged slot of sorted slot a of column c = cb[c] + (a - bs[col[c]])
+        int shift[9];
+        {
+            int run = 0;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const int g0 = bs[col[c]], g1 = bs[col[c] + nbz];
+                shift[c] = run - g0;
+                run += g1 - g0;
+            }
+            if (valid && s == 0 && (run > A.tile_cap || run > 65535)) {       // the tile does not fit the staged capacity
+                A.nl_bad[(size_t)rep * T + frame] = 1; A.flags[4] = 1;
+            }
+            if (valid && s == 0) A.nl_rank[((size_t)rep * T + frame) * N + i] = slot;
         }
 #pragma unroll 1
         for (int part = 0; part < 2; ++part) {
@@ -1100,8 +1172,8 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    if (__any(a0[c] + 16 * u < a1[c])) take(P[u], a0[c] + 16 * u < a1[c]);
-                for (int a = a0[c] + 64; __any(a < a1[c]); a += 16) take(sp[a < a1[c] ? a : 0], a < a1[c]);   // (dense bins)
+                    if (__any(a0[c] + 16 * u < a1[c])) take(P[u], a0[c] + 16 * u < a1[c], a0[c] + 16 * u + shift[c]);
+                for (int a = a0[c] + 64; __any(a < a1[c]); a += 16) take(sp[a < a1[c] ? a : 0], a < a1[c], a + shift[c]);   // (dense bins)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) P[u] = Q[u];
             }
