@@ -290,6 +290,7 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True, form="lj", dt=None, 
     target = torch.ones(100, device=dev)
     t = torch.Tensor([args.dt * i for i in range(T)]).to(dev)
     pv0 = torch.zeros(R, 5, device=dev)
+    integ.fuse_observables = True        # opt-in: the RDF of the selected frames is evaluated inside the trajectory launches
     spec = integ.fused_spec("NH_verlet")
     spec.block = args.block
     params = list(integ.parameters())

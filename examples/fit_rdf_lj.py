@@ -37,6 +37,7 @@ def trajectories(system, integ, R, frames, dt, seed, dev):
     pos = np.mod(lat[None] + rng.uniform(-0.05, 0.05, (R,) + lat.shape), 4.8).astype(np.float32)
     vel = rng.normal(0, np.sqrt(1.0 / 1.008), pos.shape).astype(np.float32)
     t = torch.Tensor([dt * i for i in range(frames)]).to(dev)
+    integ.fuse_observables = True            # opt-in: the loss only reads g(r), nothing differentiates w.r.t. q_t itself
     spec = integ.fused_spec("NH_verlet")
     # (fused_traj = FusedTrajFn + the bookkeeping that lets `rdf` ride inside the trajectory kernels from the second
     #  epoch on when there are >= 1 024 replicas: the observable registers itself the first time it sees q_t)

@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
             A.nl_state[2 * rep + 1] = frame;
             if (MODE == 0) A.nl_state[2 * rep] = 1;
         }
-        {                                                            // the build's bin columns, for the tiles of its consumers
+        if (A.tile_cap) {                                            // the build's bin columns, for the tiles of its consumers
             const int32_t* bs0 = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
             int32_t* dst = A.nl_bst + ((size_t)rep * T + frame) * (LG_MAX_COLS + 1);
             for (int c = threadIdx.x; c <= A.ncol; c += blockDim.x) dst[c] = bs0[c * A.nb[2]];
@@ -1101,7 +1101,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
     const float4 pi = sp[valid ? slot : N - 1];
     const int i = __float_as_int(pi.w);
     // (column tiles: the row lives at the atom's SORTED SLOT and holds staged-tile slots; see LargeArgs)
-    const size_t at = ((size_t)rep * T + frame) * N + (valid ? slot : N - 1);
+    const size_t at = ((size_t)rep * T + frame) * N + (A.tile_cap ? (valid ? slot : N - 1) : i);
     uint16_t* lrow = A.nl_idx + at * LG_LIST;
     int cnt = 0;                                                     // candidates of the row's atom so far (row-uniform)
     float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
         const unsigned rowmask = (unsigned)(__ballot(in) >> (16 * row)) & 0xffffu;
         if (in) {
             const int at_ = cnt + __popc(rowmask & ((1u << s) - 1u));
-            if (at_ < LG_LIST) lrow[at_] = (uint16_t)loc;
+            if (at_ < LG_LIST) lrow[at_] = (uint16_t)(A.tile_cap ? loc : j);
             if (d2 != 0.f)                                                    // topology.py:67
                 pair_terms<1, KIND>(A, tc, ntl, N, i, j, dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx,
                                     gy, gz, th);
@@ -1146,10 +1146,12 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
                 shift[c] = run - g0;
                 run += g1 - g0;
             }
-            if (valid && s == 0 && (run > A.tile_cap || run > 65535)) {       // the tile does not fit the staged capacity
-                A.nl_bad[(size_t)rep * T + frame] = 1; A.flags[4] = 1;
+            if (A.tile_cap && valid && s == 0) {
+                if (run > A.tile_cap || run > 65535) {                        // the tile does not fit the staged capacity
+                    A.nl_bad[(size_t)rep * T + frame] = 1; A.flags[4] = 1;
+                }
+                A.nl_rank[((size_t)rep * T + frame) * N + i] = slot;
             }
-            if (valid && s == 0) A.nl_rank[((size_t)rep * T + frame) * N + i] = slot;
         }
 #pragma unroll 1
         for (int part = 0; part < 2; ++part) {
@@ -1210,6 +1212,8 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
     if (lane == 0) red[wid] = kepart;
     __syncthreads();
     if (threadIdx.x == 0) A.partA[(size_t)rep * A.nbF + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    // (the rows the column-tile launches write beyond this grid: cleared, large_prep<1> sums A.nbL of them)
+    if (blockIdx.x == 0) for (int row = gridDim.x + threadIdx.x; row < A.nbL; row += blockDim.x) A.partA[(size_t)rep * A.nbF + row] = 0.f;
 }
 
 // ------------------------------------------------------------------------------------ adjoint
@@ -1452,6 +1456,335 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// COLUMN-TILE versions of the two listed launches (see LargeArgs): a workgroup = one (bx, by) column of bins of the
+// serving build = a contiguous range of that build's sorted order; the 3 x 3 columns around it staged in LDS once.
+struct LTile {
+    int cbase[10];                           // first staged slot of stencil column c; [9] = staged atoms
+    int gstart[9];                           // ... its first slot in the build's sorted order
+    int ok;
+};
+
+// header + staging by the whole workgroup; pk_w == nullptr: positions only.  Ends with a barrier.
+__device__ __forceinline__ void large_stage(const LargeArgs& A, const int32_t* __restrict__ bst, int tile,
+                                            const float4* __restrict__ pk_pos, const float4* __restrict__ pk_w, LTile& M,
+                                            Row3* tp, Row3* tw, int32_t* tidx) {
+    const int nbx = A.nb[0], nby = A.nb[1];
+    const int cx = tile / nby, cy = tile - cx * nby;
+    if (threadIdx.x < 9) {
+        const int c = threadIdx.x;
+        int x = cx + c / 3 - 1, y = cy + c % 3 - 1;
+        x = x < 0 ? x + nbx : (x >= nbx ? x - nbx : x);
+        y = y < 0 ? y + nby : (y >= nby ? y - nby : y);
+        const int col = x * nby + y;
+        M.gstart[c] = bst[col];
+        M.cbase[c + 1] = bst[col + 1] - bst[col];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int c = 0; c < 9; ++c) { const int len = M.cbase[c + 1]; M.cbase[c] = run; run += len; }
+        M.cbase[9] = run;
+        M.ok = run <= A.tile_cap;
+    }
+    __syncthreads();
+    const int total = M.ok ? M.cbase[9] : 0;
+    for (int t = threadIdx.x; t < total; t += blockDim.x) {
+        int c = 0;
+#pragma unroll
+        for (int k = 1; k < 9; ++k) c += t >= M.cbase[k];
+        const int src = M.gstart[c] + (t - M.cbase[c]);
+        const float4 p = pk_pos[src];
+        tp[t] = Row3{p.x, p.y, p.z};
+        tidx[t] = __float_as_int(p.w);
+        if (pk_w) { const float4 w = pk_w[src]; tw[t] = Row3{w.x, w.y, w.z}; }
+    }
+    __syncthreads();
+}
+
+// Second half of step k over the CURRENT list, column tiles.  grid (R, ncol): consecutive workgroups = consecutive
+// replicas, so the tiles of a replica run on one XCD (its L2 holds the replica's state copy and rows).
+template <int KIND>
+__global__ __launch_bounds__(LG_TILE_THREADS) void large_fwd_tiled(const LargeArgs A) {
+    constexpr int NP = LG_LIST / 16;
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    __shared__ LTile M;
+    __shared__ float red[32];
+    __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.x, tile = blockIdx.y, k = A.step;
+    if (A.nl_state[2 * rep]) return;                                   // this step searched (large_search_rows<1>)
+    const int slot = A.nl_state[2 * rep + 1];
+    Row3* tp = reinterpret_cast<Row3*>(lds_f);
+    int32_t* tidx = reinterpret_cast<int32_t*>(lds_f + 3 * (size_t)A.tile_cap);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, s = lane & 15;
+    const size_t so = (size_t)rep * N * 3;
+    float* q = A.q + so; float* v = A.v + so; float* vh = A.vh + so; float* f = A.f + so;
+    float* pv = A.pv + rep * MDG_MAX_CHAINS; float* ph = A.ph + rep * MDG_MAX_CHAINS;
+    float* pvh = A.pvh + rep * MDG_MAX_CHAINS;
+    const bool nhc = A.prm.ensemble == 0;
+    const float dt = A.t[k + 1] - A.t[k];
+    if (tile == 0) {
+        if (threadIdx.x == 0) A.nl_build[(size_t)rep * T + k + 1] = slot;
+        if (nhc) {                                                      // finish the bath with KE(v + vh), as large_force_step<1>
+            if (threadIdx.x < MDG_MAX_CHAINS) {
+                float qv = 0.f;
+#pragma unroll
+                for (int c = 0; c < MDG_MAX_CHAINS; ++c) if (threadIdx.x == c) qv = A.prm.Q[c];
+                Qs[threadIdx.x] = qv;
+            }
+            const float ke = 0.5f * reduce_partials(A.partB + (size_t)rep * A.nbE, A.nbE, 1, 0, red);
+            if (threadIdx.x < C) pvs[threadIdx.x] = pvh[threadIdx.x];
+            __syncthreads();
+            if (threadIdx.x < C) {
+                const float b1 = bath_rhs_l(A.prm, Qs, pvs, ke, threadIdx.x);
+                const float np = pv[threadIdx.x] + (ph[threadIdx.x] + 0.5f * b1 * dt);
+                pv[threadIdx.x] = np;
+                A.pv_t[((size_t)rep * T + k + 1) * C + threadIdx.x] = np;
+            }
+            __syncthreads();
+        }
+    }
+    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), tile, A.spk + (size_t)rep * N, nullptr, M, tp, nullptr, tidx);
+    TermConst tc[MDG_MAX_TERMS];
+    if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
+    else prepare_terms(A, tc);
+    const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
+    const int own0 = M.cbase[4], nown = M.ok ? M.cbase[5] - M.cbase[4] : 0, g0 = M.gstart[4];
+    float kepart = 0.f;
+#pragma unroll 1
+    for (int r0 = wid * 4; r0 < nown; r0 += nw * 4) {
+        const int r = r0 + (lane >> 4);
+        const bool valid = r < nown;
+        const int rc = valid ? r : nown - 1;
+        const int ls = own0 + rc;                                      // the row atom's staged slot
+        const size_t at = ((size_t)rep * T + slot) * N + g0 + rc;
+        const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
+        int jj[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) jj[p] = (int)((idx[(s >> 1) + 8 * p] >> (16 * (s & 1))) & 0xffffu);
+        const int n = valid ? min(A.nl_cnt[at], LG_LIST) : 0;
+        const Row3 qi = tp[ls];
+        const int i = tidx[ls];
+        float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+        if constexpr (KIND == KIND_LJ126) {
+            const TermConst& t0 = tc[0];
+            const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
+            const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;
+            const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+            const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+            f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2;
+#pragma unroll
+            for (int p = 0; p < NP; p += 2) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;    // (wave-uniform: every row is through)
+                const Row3 qA = tp[s + 16 * p < n ? jj[p] : ls], qB = tp[s + 16 * (p + 1) < n ? jj[p + 1] : ls];
+                f32x2 dx = f32x2{qA.x, qB.x} - qi.x, dy = f32x2{qA.y, qB.y} - qi.y, dz = f32x2{qA.z, qB.z} - qi.z;
+                dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+                const f32x2 d2 = norm2_ref2(dx, dy, dz);
+                const bool ok0 = (d2.x != 0.f) && (d2.x < rc2), ok1 = (d2.y != 0.f) && (d2.y < rc2);
+                const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+                const f32x2 s2 = sig2 * i2;
+                const f32x2 s6 = s2 * s2 * s2;
+                const f32x2 c1 = (m1a * s6 - m1b * (s6 * s6)) * i2;
+                fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;
+            }
+            fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
+        } else {
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+                if (!(s + 16 * p < n)) continue;
+                const int l = jj[p];
+                const Row3 qn = tp[l];
+                float dx = qn.x - qi.x, dy = qn.y - qi.y, dz = qn.z - qi.z;
+                min_image<true>(A.cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                if (d2 == 0.f) continue;
+                pair_terms<1, KIND>(A, tc, ntl, N, i, tidx[l], dx, dy, dz, d2, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, rep, fx, fy, fz, gx, gy,
+                                    gz, th);
+            }
+        }
+        fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
+        if (valid && s < 3) {
+            const float F = s == 0 ? fx : (s == 1 ? fy : fz);
+            const int e = 3 * i + s;
+            const float m = A.mass[i];
+            const float vv = v[e] + vh[e];
+            const float p = vv * m;
+            const float a = nhc ? (F - pvh[0] * p / A.prm.Q[0]) / m : F;          // (NVE: md.py:145-148, no 1/m)
+            const float vn = v[e] + (vh[e] + 0.5f * a * dt);
+            v[e] = vn;
+            f[e] = F;
+            const size_t fr = ((size_t)rep * T + k + 1) * N * 3 + e;
+            A.q_t[fr] = q[e];
+            A.v_t[fr] = vn;
+            const float pn = vn * m;
+            kepart += pn * pn / m;
+            if (!(isfinite(vn) && isfinite(F))) A.flags[1] = 1;
+        }
+    }
+    kepart = wave_sum_rows(kepart);
+    if (lane == 0) red[wid] = kepart;
+    __syncthreads();
+    // partA holds A.nbL rows for the listed launches (large_search_rows writes one per 16 atoms): this tile's sum goes to row
+    // `tile`, and the tiles clear the rows beyond ncol between them
+    if (threadIdx.x == 0) {
+        float t_ = 0.f;
+        for (int w = 0; w < nw; ++w) t_ += red[w];
+        A.partA[(size_t)rep * A.nbF + tile] = t_;
+        for (int row = tile + A.ncol; row < A.nbL; row += A.ncol) A.partA[(size_t)rep * A.nbF + row] = 0.f;
+    }
+}
+
+// The adjoint's evaluation over the stored candidates, column tiles: (position, w) staged per tile, every candidate two
+// ds_read_b96.  Build selection and the flags as large_adj_listed.  grid (R, ncol), partN rows = ncol per replica.
+template <int KIND>
+__global__ __launch_bounds__(LG_TILE_THREADS) void large_adj_tiled(const LargeArgs A, const int second) {
+    constexpr int NP = LG_LIST / 16;
+    constexpr int NTH = KIND >= 0 ? MDG_MAX_THETA : LG_KMAX;
+    constexpr int NWV = LG_TILE_THREADS / 64;
+    extern __shared__ __attribute__((aligned(16))) float lds_a[];
+    __shared__ LTile M;
+    __shared__ float red[NWV * (NTH + 2)];
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.x, tile = blockIdx.y, i_fr = A.step;
+    Row3* tp = reinterpret_cast<Row3*>(lds_a);
+    Row3* tw = reinterpret_cast<Row3*>(lds_a + 3 * (size_t)A.tile_cap);
+    int32_t* tidx = reinterpret_cast<int32_t*>(lds_a + 6 * (size_t)A.tile_cap);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, s = lane & 15;
+    const size_t so = (size_t)rep * N * 3;
+    const float* vs = second ? A.vm + so : A.v_t + ((size_t)rep * T + i_fr) * N * 3;
+    const float* lam = second ? A.lvh + so : A.lv + so;
+    TermConst tc[MDG_MAX_TERMS];
+    if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
+    else prepare_terms(A, tc);
+    const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
+    const bool nhc = A.prm.ensemble == 0;
+    const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
+    const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    const int slotA = A.nl_build[(size_t)rep * T + i_fr];
+    int slot = slotA;
+    bool bad = A.nl_bad[(size_t)rep * T + slot] != 0;
+    bool copyB = false;
+    if (second) {
+        const int slotB = i_fr + 1 < T ? A.nl_build[(size_t)rep * T + i_fr + 1] : slot;
+        const bool okA = !bad && !A.nl_state[2 * rep];
+        const bool okB = !A.nl_bad[(size_t)rep * T + slotB] && !A.nl_state[2 * rep + 1];
+        if (okB) { slot = slotB; copyB = slotB != slotA; }
+        bad = !(okA || okB);
+    }
+    const float4* pk = A.apk + (size_t)rep * 4 * N + (copyB ? 2 * (size_t)N : 0);
+    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), tile, pk, pk + N, M, tp, tw, tidx);
+    // (the first evaluation clears the midpoint flags: only after every workgroup of the previous midpoint launch -- an
+    //  earlier kernel of the stream -- has read them)
+    if (!second && tile == 0 && threadIdx.x == 0) { A.nl_state[2 * rep] = 0; A.nl_state[2 * rep + 1] = 0; }
+    if (tile == 0 && threadIdx.x == 0 && (bad || !M.ok)) A.flags[5] = 1;
+    const int own0 = M.cbase[4], nown = (M.ok && !bad) ? M.cbase[5] - M.cbase[4] : 0, g0 = M.gstart[4];
+    float vals[NTH + 2];
+#pragma unroll
+    for (int p = 0; p < NTH + 2; ++p) vals[p] = 0.f;
+#pragma unroll 1
+    for (int r0 = wid * 4; r0 < nown; r0 += nw * 4) {
+        const int r = r0 + (lane >> 4);
+        const bool valid = r < nown;
+        const int rc = valid ? r : nown - 1;
+        const int ls = own0 + rc;
+        const size_t at = ((size_t)rep * T + slot) * N + g0 + rc;
+        const uint32_t* idx = reinterpret_cast<const uint32_t*>(A.nl_idx + at * LG_LIST);
+        int jj[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) jj[p] = (int)((idx[(s >> 1) + 8 * p] >> (16 * (s & 1))) & 0xffffu);
+        const int n = valid ? min(A.nl_cnt[at], LG_LIST) : 0;
+        const Row3 qi = tp[ls], li = tw[ls];
+        const int i = tidx[ls];
+        const float xi = qi.x, yi = qi.y, zi = qi.z, wxi = li.x, wyi = li.y, wzi = li.z;
+        float fx = 0.f, fy = 0.f, fz = 0.f, gx = 0.f, gy = 0.f, gz = 0.f, th[LG_KMAX];
+#pragma unroll
+        for (int p = 0; p < LG_KMAX; ++p) th[p] = 0.f;
+        if constexpr (KIND == KIND_LJ126) {
+            // the packed arithmetic of large_adj_listed: two candidates per lane and iteration, even powers of 1/r from one
+            // v_rcp_f32 per pair, branch-free, the parameter gradients as the two sums they are linear in
+            const TermConst& t0 = tc[0];
+            const float sig2 = t0.k0 * t0.k0, e4 = 4.f * t0.k1, cq = t0.c, rc2 = t0.rc2;
+            const float m1a = 6.f * e4 * cq, m1b = 12.f * e4;                    // phi'/r  = (m1a s6 - m1b s12) / d2
+            const float ka = 48.f * e4 * cq, kb = 168.f * e4;                    // phi'' - phi'/r = (kb s12 - ka s6) / d2
+            const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
+            const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
+            f32x2 fx2 = {0.f, 0.f}, fy2 = fx2, fz2 = fx2, gx2 = fx2, gy2 = fx2, gz2 = fx2, S6 = fx2, S12 = fx2;
+#pragma unroll
+            for (int p = 0; p < NP; p += 2) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;    // (wave-uniform: every row is through)
+                const int lA = s + 16 * p < n ? jj[p] : ls, lB = s + 16 * (p + 1) < n ? jj[p + 1] : ls;
+                const Row3 qA = tp[lA], qB = tp[lB], wA = tw[lA], wB = tw[lB];
+                f32x2 dx = f32x2{qA.x, qB.x} - xi, dy = f32x2{qA.y, qB.y} - yi, dz = f32x2{qA.z, qB.z} - zi;   // D = x_j - x_i
+                const f32x2 ax = wxi - f32x2{wA.x, wB.x}, ay = wyi - f32x2{wA.y, wB.y}, az = wzi - f32x2{wA.z, wB.z};
+                dx = min_image_diag2(dx, ivx, hx); dy = min_image_diag2(dy, ivy, hy); dz = min_image_diag2(dz, ivz, hz);
+                const f32x2 d2 = norm2_ref2(dx, dy, dz);
+                const bool ok0 = (d2.x != 0.f) && (d2.x < rc2);             // (idle lanes read the atom itself: D = 0)
+                const bool ok1 = (d2.y != 0.f) && (d2.y < rc2);             // topology.py:67
+                const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+                const f32x2 s2 = sig2 * i2;
+                const f32x2 s6 = s2 * s2 * s2;
+                const f32x2 s12 = s6 * s6;
+                const f32x2 c1 = (m1a * s6 - m1b * s12) * i2;
+                fx2 += c1 * dx; fy2 += c1 * dy; fz2 += c1 * dz;           // F_i += (phi'/r) D
+                const f32x2 b = dx * ax + dy * ay + dz * az;
+                const f32x2 bi = b * i2;                                    // (w_ij . D) / d2
+                const f32x2 k2 = (kb * s12 - ka * s6) * (bi * i2);          // (phi'' - phi'/r) (w_ij . D) / d2
+                gx2 += k2 * dx; gx2 += c1 * ax;                             // (opposite sign: negated once below)
+                gy2 += k2 * dy; gy2 += c1 * ay;
+                gz2 += k2 * dz; gz2 += c1 * az;
+                S6 += s6 * bi; S12 += s12 * bi;
+            }
+            fx = fx2.x + fx2.y; fy = fy2.x + fy2.y; fz = fz2.x + fz2.y;
+            gx = -(gx2.x + gx2.y); gy = -(gy2.x + gy2.y); gz = -(gz2.x + gz2.y);
+            const float a6 = S6.x + S6.y, a12 = S12.x + S12.y;
+            th[0] = e4 * t0.k2 * (18.f * cq * a6 - 72.f * a12);             // 1/2 d(w.F)/dsigma, this atom's end of its pairs
+            th[1] = 12.f * cq * a6 - 24.f * a12;                            // ... d/depsilon
+        } else {
+#pragma unroll 1
+            for (int p = 0; p < NP; ++p) {
+                if (p > 0 && __ballot(s + 16 * p < n) == 0) break;
+                if (!(s + 16 * p < n)) continue;
+                const int l = jj[p];
+                const Row3 qn = tp[l], ln = tw[l];
+                float dx = qn.x - xi, dy = qn.y - yi, dz = qn.z - zi;       // D = x_j - x_i
+                min_image<true>(A.cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                if (d2 == 0.f) continue;                                    // topology.py:67
+                pair_terms<2, KIND>(A, tc, ntl, N, i, tidx[l], dx, dy, dz, d2, wxi, wyi, wzi, ln.x, ln.y, ln.z, gw, rep, fx, fy, fz,
+                                    gx, gy, gz, th);
+            }
+        }
+        fx = row16_sum(fx); fy = row16_sum(fy); fz = row16_sum(fz);
+        gx = row16_sum(gx); gy = row16_sum(gy); gz = row16_sum(gz);
+#pragma unroll
+        for (int p = 0; p < NTH; ++p) vals[p] += th[p];
+        if (valid && s < 3) {
+            const int e = 3 * i + s;
+            A.f[so + e] = s == 0 ? fx : (s == 1 ? fy : fz);
+            A.dq[so + e] = s == 0 ? gx : (s == 1 ? gy : gz);
+            const float mi = A.mass[i];
+            const float pp = vs[e] * mi;
+            vals[NTH] += pp * pp / mi;
+            vals[NTH + 1] += lam[e] * vs[e];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NTH + 2; ++p) vals[p] = wave_sum_rows(vals[p]);
+    if (lane == 0) {
+#pragma unroll
+        for (int p = 0; p < NTH + 2; ++p) red[wid * (NTH + 2) + p] = vals[p];
+    }
+    __syncthreads();
+    if (threadIdx.x < LG_NV) {
+        const int p = threadIdx.x;
+        const int c = p < LG_KMAX ? (p < NTH ? p : -1) : NTH + (p - LG_KMAX);
+        float t_ = 0.f;
+        if (c >= 0)
+            for (int w = 0; w < nw; ++w) t_ += red[w * (NTH + 2) + c];
+        A.partN[((size_t)rep * A.nbF + tile) * LG_NV + p] = t_;
+    }
+}
+
 // fixed point -> float table gradient
 __global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t* __restrict__ glo, size_t n, float scale,
                                  float* __restrict__ out) {
@@ -1474,7 +1807,7 @@ __global__ void large_adj_init(const float* __restrict__ g_v, const float* __res
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, wl, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, total;
+        spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, nl_rank, nl_bst, spk, apk, total;
     bool keep_lists;
 };
 
@@ -1497,14 +1830,23 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
     w.binslot = take((size_t)R * N);
     // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
-    const long long lw = (long long)R * T * N * (LG_LIST / 2 + 1) + 2ll * R * T + 2ll * R;
+    const long long lw = (long long)R * T * N * (LG_LIST / 2 + 2) + (long long)R * T * (LG_MAX_COLS + 3) + 2ll * R + 20ll * R * N;
     w.keep_lists = T > 1 && lw <= LG_LIST_MAX_WORDS;
     if (w.keep_lists) {
         w.nl_idx = take((size_t)R * T * N * (LG_LIST / 2)); w.nl_cnt = take((size_t)R * T * N);
         w.nl_bad = take((size_t)R * T); w.nl_build = take((size_t)R * T); w.nl_state = take((size_t)2 * R);
+        // column tiles: per build the atoms' sorted slots and the bin columns' first slots; the state copies in build order
+        w.nl_rank = take((size_t)R * T * N); w.nl_bst = take((size_t)R * T * (LG_MAX_COLS + 1));
+        w.spk = take((size_t)R * N * 4); w.apk = take((size_t)R * N * 16);
     }
     w.total = o;
     return w;
+}
+
+// MDG_LARGE_TILES=0: the listed launches gather by atom index from L2 (A/B measurements; the pre-round-5 kernels)
+bool large_tiles_enabled() {
+    const char* e = getenv("MDG_LARGE_TILES");
+    return !(e && e[0] == '0');
 }
 
 int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
@@ -1592,11 +1934,26 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
             a.nb[0] = nbx[0]; a.nb[1] = nbx[1]; a.nb[2] = nbx[2]; a.ncell = nbx[0] * nbx[1] * nbx[2]; \
         }                                                                                            \
     }                                                                                                \
+    if (a.ncell && a.nl_idx) {                                                                       \
+        /* column tiles: staged capacity = 1.35 x the nine columns of a uniform box (+ slack); a box whose tiles cannot */ \
+        /* be staged keeps the L2-gather launches */                                                 \
+        a.ncol = a.nb[0] * a.nb[1];                                                                  \
+        long long cap = (long long)(9.0 * 1.35 * N / (double)a.ncol) + 64;                           \
+        if (cap > N) cap = N;                                                                        \
+        cap = (cap + 63) / 64 * 64;                                                                  \
+        if (large_tiles_enabled() && cap <= LG_TILE_MAX && a.ncol <= LG_MAX_COLS && a.ncol <= (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL) { \
+            a.tile_cap = (int)cap;                                                                   \
+            a.nl_rank = reinterpret_cast<int32_t*>(ws + L.nl_rank);                                  \
+            a.nl_bst = reinterpret_cast<int32_t*>(ws + L.nl_bst);                                    \
+            a.spk = reinterpret_cast<float4*>(ws + L.spk);                                           \
+            a.apk = reinterpret_cast<float4*>(ws + L.apk);                                           \
+        }          /* (otherwise the rows hold atom indices and the listed launches gather from L2, as in unbinned boxes) */ \
+    }                                                                                                \
     const int wpb = a.ncell ? LG_WAVES_CELL : LG_WAVES;                                              \
     const int nbF = (N + wpb - 1) / wpb;                                                             \
     a.nbF = nbF;                                                                                     \
     const dim3 gL((N + LG_ROW_ATOMS - 1) / LG_ROW_ATOMS, R);       /* the listed kernels: 16 atoms per workgroup */ \
-    a.nbL = (int)gL.x;                                                                               \
+    a.nbL = (int)gL.x > a.ncol || !a.tile_cap ? (int)gL.x : a.ncol;   /* partA rows of the listed / searching launches */ \
     const size_t tile_lds = sizeof(float4) * (size_t)wpb * LG_CAP + (a.ncell ? 0 : sizeof(float) * 3 * LG_TILE); \
     const bool lj126 = terms->n_terms == 1 && diag && !terms->t[0].mask && terms->t[0].kind == MDG_PAIR_LJ && \
                        terms->t[0].p == 12 && (terms->t[0].q == 6 || terms->t[0].c == 0.f);          \
@@ -1637,7 +1994,12 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
         a.step = k;
         LG_PREP_LAUNCH(1);                                  // kick + drift + bath half step; search needed? then binning
         LG_FORCE_STEP(1);                                   // (returns at once while the current list serves)
-        if (a.nl_idx) {                                     // (returns at once when the step searched)
+        if (a.tile_cap) {                                   // (returns at once when the step searched)
+            const dim3 gT(R, a.ncol);
+            const size_t lds = sizeof(float) * 4 * (size_t)a.tile_cap;
+            if (lj126) hipLaunchKernelGGL((large_fwd_tiled<KIND_LJ126>), gT, dim3(LG_TILE_THREADS), lds, st, a);
+            else hipLaunchKernelGGL((large_fwd_tiled<-1>), gT, dim3(LG_TILE_THREADS), lds, st, a);
+        } else if (a.nl_idx) {
             const dim3 gLF((N + LG_ROW_ATOMS * LG_FWD_GROUPS - 1) / (LG_ROW_ATOMS * LG_FWD_GROUPS), R);
             if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gLF, dim3(256), 0, st, a);
             else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gLF, dim3(256), 0, st, a);
@@ -1675,12 +2037,16 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     }
     dim3 gF(nbF, R);
     const dim3 gLA((N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS), R);
-    if (a.nl_idx) a.nbF = (int)gLA.x;                  // (rows of partN the listed launches write, the prep launches sum)
+    if (a.nl_idx) a.nbF = a.tile_cap ? a.ncol : (int)gLA.x;   // (rows of partN the listed launches write, the prep launches sum)
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
-        if (a.nl_idx) {                                                                                             \
+        if (a.tile_cap) {                                                                                           \
+            const size_t lds_ = sizeof(float) * 7 * (size_t)a.tile_cap;                                             \
+            if (lj126) hipLaunchKernelGGL((large_adj_tiled<KIND_LJ126>), dim3(R, a.ncol), dim3(LG_TILE_THREADS), lds_, st, a, SECOND_); \
+            else hipLaunchKernelGGL((large_adj_tiled<-1>), dim3(R, a.ncol), dim3(LG_TILE_THREADS), lds_, st, a, SECOND_); \
+        } else if (a.nl_idx) {                                                                                      \
             if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, st, a, SECOND_);      \
             else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gLA, dim3(256), 0, st, a, SECOND_);           \
             else hipLaunchKernelGGL((large_adj_listed<false, -1>), gLA, dim3(256), 0, st, a, SECOND_);                    \

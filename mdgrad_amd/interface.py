@@ -474,7 +474,12 @@ class _BondedTerm(torch.nn.Module):
     def _consts(self):
         raise NotImplementedError
 
-    def _hip_ok(self):
+    def _hip_ok(self, xyz=None):
+        """The HIP kernel serves float32 device positions with plain-number constants.  Constants that require grad, and
+        float64 device positions, take the reference's torch ops on the device instead; host tensors are refused
+        by the kernel entry as everywhere (no CPU path)."""
+        if xyz is not None and xyz.is_cuda and xyz.dtype != torch.float32:
+            return False
         return self.analytic and not any(torch.is_tensor(c) and c.requires_grad for c in self._consts())
 
     def table(self):
@@ -492,7 +497,7 @@ class _BondedTerm(torch.nn.Module):
         raise NotImplementedError
 
     def forward(self, xyz):
-        if self._hip_ok():
+        if self._hip_ok(xyz):
             return ops.BondedEnergyFn.apply(xyz.contiguous(), self.table())
         return self._torch_energy(xyz)
 

@@ -160,11 +160,27 @@ class _EOM(torch.nn.Module):
     _method = None
     fused_large = None      # None = by size; True/False forces the multi-launch / one-workgroup kernels
     fused_table = True      # tabulate user pair modules for the fused kernels (N <= 1024); False: generic path
+    fuse_observables = False   # True (or attach_observable): an rdf called on a fused trajectory is evaluated INSIDE the next
+    #                            trajectory launches (its histogram is then an output of the launch, not a function of q_t in
+    #                            the autograd graph: autograd.grad(loss, q_t) / hooks on q_t do not see the RDF term).  Off by
+    #                            default: the reference's callers may rely on q_t carrying that term.
     table_nodes = 1024      # nodes of the u = r^2 grid on [ (table_rmin * cutoff)^2 , cutoff^2 ]
     table_rmin = 0.2
 
     def update_topology(self, q):                               # md.py:200-204
-        if self.update_count % self.topology_update_freq == 0:
+        freq = self.topology_update_freq
+        if freq != 1:
+            #  the fused stale-list kernels keep their lists in _stale_code, this path in the model's own
+            # nbr_list: a pass of one kind between two rebuilds must not leave the other evaluating with older lists.  A
+            # generic call drops the fused lists (the next fused pass waits for a rebuild count, fused_spec); the first
+            # generic call after fused passes rebuilds here at once -- the reference's lists of that moment were built
+            # inside the fused launch and exist only in its encoding.
+            self._stale_code = None
+            if getattr(self, "_stale_fused_dirty", False):
+                self._stale_fused_dirty = False
+                self.model._reset_topology(q)
+                self._topo_ref = None
+        if self.update_count % freq == 0:
             # The reference rebuilds here unconditionally; its adjoint asks twice in a row for the list at the
             # very same saved frame (the dL/dt call of sovlers.py:258, then the first augmented evaluation).  A
             # rebuild at the same tensor object (unchanged version, nobody else touched the model's topology in
@@ -202,8 +218,11 @@ class _EOM(torch.nn.Module):
         """Ask the fused trajectory launches of this integrator to evaluate `obs` (an `observable.rdf`) on the frames
         start, start + stride, ... of every trajectory from now on -- what the observable otherwise arranges itself
         the first time it is called on (a time slice of) a fused trajectory.  `attach_observable(None)` detaches;
-        `fuse_observables = False` switches the mechanism off."""
+        `fuse_observables = False` switches the mechanism off.  Attaching IS the opt-in: by default
+        (`fuse_observables = False`) an rdf stays a function of q_t in the autograd graph, exactly as in the reference."""
         self._rdf_hint = None if obs is None else ops.RdfFuse(obs, start, stride)
+        if obs is not None:
+            self.fuse_observables = True
 
     def fused_spec(self, method):
         """FusedSpec when the whole trajectory can run in the fused HIP kernels, else None."""
@@ -219,8 +238,9 @@ class _EOM(torch.nn.Module):
             if (freq < 1 or mods is None or not self.adjoint or N > FUSED_MAX_ATOMS or self.fused_large
                     or getattr(self, "fused_stale", True) is False):
                 return None
-            if self.update_count % freq != 0 and getattr(self, "_stale_code", None) is None:
-                return None
+            code = getattr(self, "_stale_code", None)
+            if self.update_count % freq != 0 and (code is None or tuple(code.shape[:2]) != (getattr(self.system, "n_replicas", 1), N)):
+                return None                 # (between two rebuilds without the lists of this geometry: the generic path)
         table_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if (mods is None and self.adjoint and self.fused_table
                 and (N <= FUSED_MAX_ATOMS_LARGE if table_large else N <= FUSED_MAX_ATOMS)):
@@ -267,8 +287,8 @@ class _EOM(torch.nn.Module):
         spec.n_rep = getattr(self.system, "n_replicas", 1)
         spec.stale_freq = freq if freq != 1 else 0
         # an rdf observable that was evaluated on an earlier trajectory of this integrator (observable.py) is
-        # computed inside the next fused launch; `fuse_observables = False` on the integrator switches that off
-        spec.rdf_hint = (getattr(self, "_rdf_hint", None) if (getattr(self, "fuse_observables", True) and freq == 1)
+        # computed inside the next fused launch when the caller opted in (`fuse_observables = True` / attach_observable)
+        spec.rdf_hint = (getattr(self, "_rdf_hint", None) if (getattr(self, "fuse_observables", False) and freq == 1)
                          else None)
         return spec
 

@@ -84,12 +84,28 @@ def _species_onehot(z):
 # switches), not on its weights; an MD pass asks them several times per force evaluation, and walking the module tree costs
 # more host time than the launches it decides about (tools/hostprof_schnet.py).  They are cached on the network under a key
 # that names everything they read: the switches, the conv modules' identities and their layer shapes.
+def _conv_shape_key(conv):
+    """What supported / fused_ok / chain_ok read of one interaction block beyond its identity: the layer shapes,
+    whether the Gaussian basis is origin-centred and whether its width is trainable (a Parameter)."""
+    md = conv._modules["moduledict"]._modules
+    f, n, u = md["message_edge_filter"], md["message_node_filter"], md["update_function"]
+    sm = f[0]
+    return (id(conv), tuple(f[1].weight.shape), tuple(f[3].weight.shape), tuple(n.weight.shape), tuple(u[0].weight.shape),
+            tuple(u[2].weight.shape), bool(getattr(sm, "centered", False)), isinstance(sm.width, torch.nn.Parameter))
+
+
 def _structure_key(net):
     convs = getattr(net, "convolutions", None)
     if convs is None:
         return None
+    ro = net.atomwisereadout
+    try:
+        ro_key = (id(ro), tuple(ro.readout.keys()), tuple(tuple(m.weight.shape) for m in ro.readout["energy"] if hasattr(m, "weight")),
+                  ro.post_readout is None)
+    except (AttributeError, KeyError, TypeError):
+        ro_key = (id(ro),)
     return (getattr(net, "fused_block", True), getattr(net, "row_chain", True), os.environ.get("MDG_ROW_CHAIN", "1"),
-            tuple(id(c) for c in convs), id(net.atomwisereadout))
+            tuple(_conv_shape_key(c) for c in convs), ro_key)
 
 
 def _cached(net, name, compute):
@@ -161,11 +177,20 @@ def _layer_params(conv):
     md = conv._modules["moduledict"]._modules
     f, n, u = md["message_edge_filter"], md["message_node_filter"], md["update_function"]
     c = conv.__dict__.get("_mdg_P")
-    if c is None or c[0] is not f or c[1] is not n or c[2] is not u or c[3]["Wn"] is not n._parameters.get("weight") \
-            or c[3]["W2"] is not f[3]._parameters.get("weight") or c[3]["U2"] is not u[2]._parameters.get("weight"):
-        P = dict(mu=f[0].offsets, W1=f[1].weight, b1=f[1].bias, W2=f[3].weight, b2=f[3].bias, Wn=n.weight, bn=n.bias,
-                 U1=u[0].weight, c1=u[0].bias, U2=u[2].weight, c2=u[2].bias)
-        c = (f, n, u, P, f[0])
+    ok = c is not None and c[0] is f and c[1] is n and c[2] is u
+    if ok:
+        # every cached tensor is checked by identity against the module that owns it (a Parameter replaced by
+        # assignment, parametrize or prune must reach the kernels AND keep its gradient slot) -- ten dictionary lookups
+        for mod, attr, role in c[5]:
+            if c[3][role] is not (mod._parameters.get(attr) if attr in mod._parameters else getattr(mod, attr)):
+                ok = False
+                break
+    if not ok:
+        slots = ((f[1], "weight", "W1"), (f[1], "bias", "b1"), (f[3], "weight", "W2"), (f[3], "bias", "b2"), (n, "weight", "Wn"),
+                 (n, "bias", "bn"), (u[0], "weight", "U1"), (u[0], "bias", "c1"), (u[2], "weight", "U2"), (u[2], "bias", "c2"),
+                 (f[0], "offsets", "mu"))
+        P = {role: getattr(mod, attr) for mod, attr, role in slots}
+        c = (f, n, u, P, f[0], slots)
         conv.__dict__["_mdg_P"] = c
     P = dict(c[3])
     P["c"] = _gauss_coeff(c[4])

@@ -87,13 +87,16 @@ class rdf(Observable):
                               "launch; its dependence on the frames is routed through the adjoint launch (raw -> FusedTrajFn), "
                               "not through q_t in the autograd graph (autograd.grad(loss, q_t) / hooks on q_t do not see the "
                               "RDF term), and it is the fine-grid histogram (<= 2e-5 per bin from the exact kernel).  "
-                              "integrator.fuse_observables = False keeps the separate kernels; rdf.last_path tells which ran.",
+                              "(opted into with integrator.fuse_observables = True; rdf.last_path tells which path ran).",
                               stacklevel=3)
             return raw
-        new = ops.RdfFuse(self, start, stride)
-        spec.rdf_hint = new
+        # OPT-IN (integrator.fuse_observables = True, or integrator.attach_observable): the fused histogram is an output of
+        # the trajectory launch, not a function of q_t in the autograd graph -- a reference caller that differentiates
+        # w.r.t. q_t or hooks it would lose the RDF term, so nothing is fused unless asked for
         integ = getattr(spec, "_integrator", None)
-        if integ is not None and getattr(integ, "fuse_observables", True):
+        if integ is not None and getattr(integ, "fuse_observables", False):
+            new = ops.RdfFuse(self, start, stride)
+            spec.rdf_hint = new
             integ._rdf_hint = new
         return None
 

@@ -263,6 +263,7 @@ class BondedTable:
         import numpy as np
         width = 2 if kind == _lib.BONDED_BOND else 3
         t = torch.as_tensor(top).detach().cpu().numpy().astype(np.int64).reshape(-1, width)
+        t = np.where(t < 0, t + n_atoms, t)                      # (the reference's xyz[top] accepts negative indices)
         if t.size and (t.min() < 0 or t.max() >= n_atoms):
             raise ValueError("mdgrad_amd: bonded topology refers to atoms outside [0, %d)" % n_atoms)
         self.kind, self.n_atoms, self.n_terms = int(kind), int(n_atoms), int(t.shape[0])
@@ -508,6 +509,7 @@ class FusedTrajFn(torch.autograd.Function):
                                                ptr(pv_t), ptr(bad), int(spec.stale_freq), int(integ.update_count), ptr(code),
                                                stream_ptr(dev)), "mdg_traj_fwd_small_stale")
             integ.update_count += 2 * (T - 1)
+            integ._stale_fused_dirty = True        # (the generic path's own lists are older than these now: md.update_topology)
         else:
             bad = torch.zeros(R, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
@@ -618,6 +620,7 @@ class FusedTrajFn(torch.autograd.Function):
                                                    int(spec.stale_freq), int(integ.update_count), ptr(code),
                                                    stream_ptr(dev)), "mdg_traj_adj_small_stale")
                 integ.update_count += 3 * (T - 1)
+                integ._stale_fused_dirty = True
                 return None
             check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                          ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),

@@ -86,6 +86,15 @@ class NHVerlet(FixedGridODESolver):
         t = t.type_as(self.y0[0]).to(self.y0[0].device)
 
         def eager():
+            out = eager_()
+            # the call counter as the reference leaves it: two right-hand-side calls per step (sovlers.py:111,121), whatever
+            # the number of force evaluations made here (the counter decides rebuilds once the frequency changes)
+            func.update_count = c0 + 2 * (t.shape[0] - 1)
+            return out
+
+        c0 = getattr(func, "update_count", 0)
+
+        def eager_():
             v, q, pv = self.y0
             if getattr(func, "fused_steps_ok", lambda *a: False)(v, q, pv):
                 return _nhv_forward(func, self.y0, t)
@@ -146,6 +155,13 @@ class Verlet(FixedGridODESolver):
         t = t.type_as(self.y0[0]).to(self.y0[0].device)
 
         def eager():
+            out = eager_()
+            func.update_count = c0 + 2 * (t.shape[0] - 1)          # (as NHVerlet.integrate: the reference's count)
+            return out
+
+        c0 = getattr(func, "update_count", 0)
+
+        def eager_():
             v, q = self.y0
             frames = [(v, q)]
             F = func.force(q)                                     # (NVE: dv/dt = F, no 1/m -- md.py:145-148)

@@ -226,7 +226,8 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     # workspace: running state + per-frame candidate rows (N * 128 * 2 bytes = N * 64 words) while they fit
     w10, w20 = lib.mdg_traj_large_workspace(1, 4096, 10, 2), lib.mdg_traj_large_workspace(1, 4096, 20, 2)
     per_frame = (w20 - w10) / 10
-    assert 4096 * 64 <= per_frame <= 4096 * 64 + 4096 + 1024, per_frame
+    # (+ per frame: the row counts, the atoms' sorted slots and the bin columns' first slots of a build -- the column tiles)
+    assert 4096 * 64 <= per_frame <= 4096 * 66 + 2048, per_frame
     huge = lib.mdg_traj_large_workspace(64, 16384, 2000, 2)                              # lists would need > 32 GiB
     assert huge < 64 * 16384 * 2000, "beyond the cap the lists are not kept (every evaluation searches)"
 
@@ -259,3 +260,30 @@ def test_host_side_of_the_row_chain_and_the_nh_half_step_scratch():
     assert lib.mdg_nhv_scratch_floats(8, 512) == 8 * 2 * 2 + 8 + 1         # 1 536 elements: two chunks
     assert lib.mdg_nhv_scratch_floats(1, 4096) == 12 * 2 + 1 + 1
     assert lib.mdg_nhv_scratch_floats(0, 64) == 0
+
+
+def test_layer_parameter_cache_follows_replaced_parameters_and_shapes():
+    """the per-block tensor cache of the analytic SchNet path is validated tensor by tensor (a replaced W1 / bias /
+    U1 must reach the kernels and keep its own gradient slot), and the structure key names the layer shapes and whether the
+    Gaussian width is trainable."""
+    from mdgrad_amd.nn import analytic, get_model
+    net = get_model({"n_atom_basis": 16, "n_filters": 32, "n_gaussians": 8, "n_convolutions": 2, "cutoff": 4.0})
+    conv = net.convolutions[0]
+    P0 = analytic._layer_params(conv)
+    f = conv.moduledict["message_edge_filter"]
+    assert P0["W1"] is f[1].weight and P0["c1"] is conv.moduledict["update_function"][0].bias
+    assert analytic._layer_params(conv)["W1"] is P0["W1"], "unchanged modules: the cached objects"
+    for mod, attr, role in ((f[1], "weight", "W1"), (f[1], "bias", "b1"), (conv.moduledict["update_function"][0], "weight", "U1"),
+                            (conv.moduledict["message_node_filter"], "bias", "bn")):
+        new = torch.nn.Parameter(getattr(mod, attr).detach().clone() * 2)
+        setattr(mod, attr, new)
+        assert analytic._layer_params(conv)[role] is new, role
+    k0 = analytic._structure_key(net)
+    assert analytic._structure_key(net) == k0
+    f[0].width = torch.nn.Parameter(f[0].width.detach().clone())          # a trainable basis changes what `supported` reads
+    assert analytic._structure_key(net) != k0
+    k1 = analytic._structure_key(net)
+    f[1].weight = torch.nn.Parameter(torch.zeros(8, 8))
+    assert analytic._structure_key(net) == k1, "same shapes: same structure"
+    f[3].weight = torch.nn.Parameter(torch.zeros(64, 8))
+    assert analytic._structure_key(net) != k1, "a layer shape is part of the key"

@@ -3,8 +3,8 @@ mdg_traj_fwd_small_rdf / mdg_traj_adj_small_rdf) against the separate observable
 (ops.RdfRawFn on the stored frames, themselves pinned to the oracle in tests/test_gpu_pins.py) and against the CPU
 oracle directly: histogram, g(r), and every gradient that flows through it -- d/d(sigma, epsilon), d/d(v0, q0, pv0).
 
-The fusion is transparent: `rdf.forward` called on a fused trajectory registers itself with the integrator, the NEXT
-launch produces the histogram; a slice along time that runs to the last frame (q_t[::k], q_t[s:]) is recognised."""
+The fusion is opt-in (`integrator.fuse_observables = True` or `attach_observable`): `rdf.forward` called on a fused
+trajectory then registers itself with the integrator, the NEXT launch produces the histogram; a slice along time that runs to the last frame (q_t[::k], q_t[s:]) is recognised."""
 import numpy as np
 import pytest
 import torch
@@ -28,6 +28,7 @@ def _setup(n_atoms=108, ensemble="nhc", R=3, seed=0, nT=9):
     stack = Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)})
     nhc = ensemble == "nhc"
     integ = (NoseHooverChain(stack, system, T=1.0, num_chains=5, Q=50.0) if nhc else NVE(stack, system)).to(DEV)
+    integ.fuse_observables = True                        # (opt-in since round 5; the default is tested at the end of this file)
     spec = integ.fused_spec("NH_verlet" if nhc else "verlet")
     spec.block = 64
     rng = np.random.default_rng(seed)
@@ -247,3 +248,36 @@ def test_fused_rdf_reports_its_path_and_does_not_pass_through_q_t():
     assert sum("fused trajectory launch" in str(w.message) for w in rec) == 1          # once, not per pass
     with pytest.raises(RuntimeError):                    # the RDF term does not reach q_t in the graph: no silent zero
         torch.autograd.grad(gr.pow(2).sum(), q_t)
+
+
+def test_fusion_is_off_by_default_and_q_t_carries_the_rdf_term():
+    """without the opt-in nothing is fused, however often the observable is called on fused
+    trajectories -- the histogram stays a function of q_t in the autograd graph, so d(loss)/d(q_t) is the RDF term (as
+    for a reference caller) and equals the oracle's."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.observable import rdf
+    g = load_golden("nhc_traj_lj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=5, Q=50.0).to(DEV)
+    assert integ.fuse_observables is False
+    spec = integ.fused_spec("NH_verlet")
+    spec.block = 64
+    obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
+    rng = np.random.default_rng(3)
+    pos = np.mod(g["pos"][None] + rng.normal(0, 0.03, (2,) + g["pos"].shape), g["cell"]).astype(np.float32)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    t = torch.Tensor([0.005 * i for i in range(6)]).to(DEV)
+    for rep in range(3):
+        v_t, q_t, pv_t = ops.fused_traj(T(vel, DEV), T(pos, DEV), torch.zeros(2, 5, device=DEV), t, spec.flat_params(), spec)
+        _, _, gr = obs(q_t)
+        assert obs.last_path == "kernel" and q_t._mdg_traj[3] is None and spec.rdf_hint is None
+    (gq,) = torch.autograd.grad(gr.pow(2).sum(), q_t)
+    xo = q_t.detach().cpu().reshape(-1, 108, 3).clone().requires_grad_(True)
+    _, _, go = O.rdf_oracle(xo, T(g["cell"]), 100, (0.75, 2.5))
+    (gxo,) = torch.autograd.grad(go.pow(2).sum(), xo)
+    close(gq.reshape(-1, 108, 3), gxo, 1e-3, 1e-4 * float(gxo.abs().max()), "d(loss)/d(q_t) through the observable")
+    integ.attach_observable(obs)                          # the explicit opt-in
+    assert integ.fuse_observables is True and integ.fused_spec("NH_verlet").rdf_hint is not None
