@@ -90,12 +90,11 @@ struct LargeArgs {
     // the list's BUILD (a contiguous range of the build's sorted order), stages the 3 x 3 columns around it -- nine
     // contiguous ranges of a copy of the state kept in that sorted order -- in LDS once, and a stored row holds 16-bit
     // slots INTO THE STAGED TILE: every candidate is an LDS read (ds_read_b96).  The order is fixed for the life of a
-    // build (atoms stay within skin / 2 of where they were binned), so the permutation is applied once per build to the
-    // rows and once per evaluation to the state copy (written by the prep launch that produces that state anyway).
-    int32_t* nl_rank;                        // [R][T][N]  sorted slot of atom a in the build of frame b
+    // build (atoms stay within skin / 2 of where they were binned); staging gathers the state rows through the build's
+    // permutation -- ~9 gathered rows per atom of the tile instead of ~78 per atom (a first version kept copies of the state
+    // in build order, written by the prep launches: their scattered 16-byte stores cost more than these gathers save).
+    int32_t* nl_perm;                        // [R][T][N]  atom at sorted slot s of the build of frame b
     int32_t* nl_bst;                         // [R][T][LG_MAX_COLS + 1]  first sorted slot of bin column c of that build
-    float4* spk;                             // [R][N]  forward: (x, y, z, index) of the current positions in the current build's order
-    float4* apk;                             // [R][2 builds][pos | w][N]  adjoint: the evaluation's state in the order of build A / B
     int tile_cap;                            // staged atoms of a tile at most (0: no tiles)
     int ncol;                                // bin columns nb[0] nb[1]
 };
@@ -265,18 +264,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             const float lim = (k + 2 >= T ? 0.5f * LG_REUSE : LG_REUSE) * A.skin;
             const int search = __syncthreads_or(!(far2 <= lim * lim)) || A.nl_bad[(size_t)rep * T + bfr] != 0;
             if (threadIdx.x == 0) A.nl_state[2 * rep] = search;
-            if (!search) {
-                if (A.tile_cap) {                                          // the listed launch stages from the build's order
-                    const int32_t* rk = A.nl_rank + ((size_t)rep * T + bfr) * N;
-                    float4* pk = A.spk + (size_t)rep * N;
-#pragma unroll
-                    for (int u = 0; u < NA; ++u) {
-                        const int a = tid + u * stride;
-                        if (a < N) pk[rk[a]] = make_float4(px[u], py[u], pz[u], __int_as_float(a));
-                    }
-                }
-                return;
-            }
+            if (!search) return;
         }
     }
     if constexpr (PHASE == 2 || PHASE == 4) {
@@ -312,15 +300,9 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
             }
         }
         // the coming listed evaluation (PHASE 2, first evaluation of interval A.step) gathers w = lam_v / m (NVE: lam_v) of
-        // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic); with column
-        // tiles it stages (q_t[A.step], w) from a copy in the order of the build that serves frame A.step
+        // its candidates from ONE array (each gather stream of that kernel costs as much as its arithmetic)
         const bool want_w = PHASE == 2 && A.nl_idx != nullptr;
-        const bool pack = want_w && A.tile_cap > 0;
-        const int bA = pack ? A.nl_build[(size_t)rep * T + A.step] : 0;
-        const int32_t* rk = A.nl_rank + ((size_t)rep * T + bA) * N;
         const float* qf = A.q_t + ((size_t)rep * T + A.step) * N * 3;
-        float4* pkq = A.apk + (size_t)rep * 4 * N;
-        float4* pkw = pkq + N;
         if (fin || want_w) {
 #pragma unroll
             for (int u = 0; u < NA; ++u) {
@@ -366,12 +348,6 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                     const float im = nhc ? 1.0f / m : 1.0f;
                     const float wx = nlv[0] * im, wy = nlv[1] * im, wz = nlv[2] * im;
                     st3(A.wl, e3, wx, wy, wz);
-                    if (pack) {
-                        const Row3 qr = ld3(qf, 3 * (size_t)a);
-                        const int sl = rk[a];
-                        pkq[sl] = make_float4(qr.x, qr.y, qr.z, __int_as_float(a));
-                        pkw[sl] = make_float4(wx, wy, wz, 0.f);
-                    }
                 }
             }
         }
@@ -467,19 +443,6 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
                 st3(A.vm, e3, vmo[0], vmo[1], vmo[2]);
                 st3(A.lvh, e3, lvho[0], lvho[1], lvho[2]);
                 if (A.nl_idx) st3(A.wl, e3, wlo[0], wlo[1], wlo[2]);
-                if (A.tile_cap) {
-                    // (which build serves the midpoint is known only after every workgroup has measured its atoms: the
-                    //  state goes out in the order of both candidates -- one copy when they are the same build)
-                    float4* pk = A.apk + (size_t)rep * 4 * N;
-                    const int sA = A.nl_rank[((size_t)rep * T + slotA) * N + a];
-                    pk[sA] = make_float4(qn[0], qn[1], qn[2], __int_as_float(a));
-                    pk[N + sA] = make_float4(wlo[0], wlo[1], wlo[2], 0.f);
-                    if (slotB != slotA) {
-                        const int sB = A.nl_rank[((size_t)rep * T + slotB) * N + a];
-                        pk[2 * N + sB] = make_float4(qn[0], qn[1], qn[2], __int_as_float(a));
-                        pk[3 * N + sB] = make_float4(wlo[0], wlo[1], wlo[2], 0.f);
-                    }
-                }
                 st3(A.lqh, e3, lqho[0], lqho[1], lqho[2]);
                 st3(A.qm, e3, qn[0], qn[1], qn[2]);
                 far2 = fmaxf(far2, mv2);
@@ -1150,7 +1113,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
                 if (run > A.tile_cap || run > 65535) {                        // the tile does not fit the staged capacity
                     A.nl_bad[(size_t)rep * T + frame] = 1; A.flags[4] = 1;
                 }
-                A.nl_rank[((size_t)rep * T + frame) * N + i] = slot;
+                A.nl_perm[((size_t)rep * T + frame) * N + slot] = i;
             }
         }
 #pragma unroll 1
@@ -1465,9 +1428,10 @@ struct LTile {
     int ok;
 };
 
-// header + staging by the whole workgroup; pk_w == nullptr: positions only.  Ends with a barrier.
-__device__ __forceinline__ void large_stage(const LargeArgs& A, const int32_t* __restrict__ bst, int tile,
-                                            const float4* __restrict__ pk_pos, const float4* __restrict__ pk_w, LTile& M,
+// header + staging by the whole workgroup: the rows of `q` (and `w`, unless nullptr) of the atoms at the tile's sorted slots,
+// gathered through the build's permutation.  Ends with a barrier.
+__device__ __forceinline__ void large_stage(const LargeArgs& A, const int32_t* __restrict__ bst, const int32_t* __restrict__ perm,
+                                            int tile, const float* __restrict__ q, const float* __restrict__ w, LTile& M,
                                             Row3* tp, Row3* tw, int32_t* tidx) {
     const int nbx = A.nb[0], nby = A.nb[1];
     const int cx = tile / nby, cy = tile - cx * nby;
@@ -1493,11 +1457,10 @@ __device__ __forceinline__ void large_stage(const LargeArgs& A, const int32_t* _
         int c = 0;
 #pragma unroll
         for (int k = 1; k < 9; ++k) c += t >= M.cbase[k];
-        const int src = M.gstart[c] + (t - M.cbase[c]);
-        const float4 p = pk_pos[src];
-        tp[t] = Row3{p.x, p.y, p.z};
-        tidx[t] = __float_as_int(p.w);
-        if (pk_w) { const float4 w = pk_w[src]; tw[t] = Row3{w.x, w.y, w.z}; }
+        const int a = perm[M.gstart[c] + (t - M.cbase[c])];
+        tp[t] = row3(q, a);
+        tidx[t] = a;
+        if (w) tw[t] = row3(w, a);
     }
     __syncthreads();
 }
@@ -1544,7 +1507,8 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_fwd_tiled(const LargeAr
             __syncthreads();
         }
     }
-    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), tile, A.spk + (size_t)rep * N, nullptr, M, tp, nullptr, tidx);
+    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), A.nl_perm + ((size_t)rep * T + slot) * N, tile, q, nullptr, M,
+                tp, nullptr, tidx);
     TermConst tc[MDG_MAX_TERMS];
     if (KIND >= 0) tc[0] = term_prepare(A.terms.t[0], A.theta);
     else prepare_terms(A, tc);
@@ -1660,19 +1624,18 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_adj_tiled(const LargeAr
     const bool nhc = A.prm.ensemble == 0;
     const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
     const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
-    const int slotA = A.nl_build[(size_t)rep * T + i_fr];
-    int slot = slotA;
+    int slot = A.nl_build[(size_t)rep * T + i_fr];
     bool bad = A.nl_bad[(size_t)rep * T + slot] != 0;
-    bool copyB = false;
     if (second) {
         const int slotB = i_fr + 1 < T ? A.nl_build[(size_t)rep * T + i_fr + 1] : slot;
         const bool okA = !bad && !A.nl_state[2 * rep];
         const bool okB = !A.nl_bad[(size_t)rep * T + slotB] && !A.nl_state[2 * rep + 1];
-        if (okB) { slot = slotB; copyB = slotB != slotA; }
+        if (okB) slot = slotB;
         bad = !(okA || okB);
     }
-    const float4* pk = A.apk + (size_t)rep * 4 * N + (copyB ? 2 * (size_t)N : 0);
-    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), tile, pk, pk + N, M, tp, tw, tidx);
+    const float* q = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
+    large_stage(A, A.nl_bst + ((size_t)rep * T + slot) * (LG_MAX_COLS + 1), A.nl_perm + ((size_t)rep * T + slot) * N, tile, q, A.wl + so, M,
+                tp, tw, tidx);
     // (the first evaluation clears the midpoint flags: only after every workgroup of the previous midpoint launch -- an
     //  earlier kernel of the stream -- has read them)
     if (!second && tile == 0 && threadIdx.x == 0) { A.nl_state[2 * rep] = 0; A.nl_state[2 * rep + 1] = 0; }
@@ -1807,7 +1770,7 @@ __global__ void large_adj_init(const float* __restrict__ g_v, const float* __res
 
 struct WsLayout {
     size_t q, v, vh, f, lv, lq, lvh, lqh, dq, qm, vm, wl, pv, ph, pvh, lp, lph, pvm, partA, partB, partN, gth, ghi, glo, flags,
-        spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, nl_rank, nl_bst, spk, apk, total;
+        spos, bstart, binslot, nl_idx, nl_cnt, nl_bad, nl_build, nl_state, nl_perm, nl_bst, total;
     bool keep_lists;
 };
 
@@ -1830,14 +1793,13 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
     w.binslot = take((size_t)R * N);
     // neighbour lists of every frame, kept for the adjoint (when they fit the budget)
-    const long long lw = (long long)R * T * N * (LG_LIST / 2 + 2) + (long long)R * T * (LG_MAX_COLS + 3) + 2ll * R + 20ll * R * N;
+    const long long lw = (long long)R * T * N * (LG_LIST / 2 + 2) + (long long)R * T * (LG_MAX_COLS + 3) + 2ll * R;
     w.keep_lists = T > 1 && lw <= LG_LIST_MAX_WORDS;
     if (w.keep_lists) {
         w.nl_idx = take((size_t)R * T * N * (LG_LIST / 2)); w.nl_cnt = take((size_t)R * T * N);
         w.nl_bad = take((size_t)R * T); w.nl_build = take((size_t)R * T); w.nl_state = take((size_t)2 * R);
-        // column tiles: per build the atoms' sorted slots and the bin columns' first slots; the state copies in build order
-        w.nl_rank = take((size_t)R * T * N); w.nl_bst = take((size_t)R * T * (LG_MAX_COLS + 1));
-        w.spk = take((size_t)R * N * 4); w.apk = take((size_t)R * N * 16);
+        // column tiles: per build the permutation (sorted slot -> atom) and the bin columns' first slots
+        w.nl_perm = take((size_t)R * T * N); w.nl_bst = take((size_t)R * T * (LG_MAX_COLS + 1));
     }
     w.total = o;
     return w;
@@ -1943,10 +1905,8 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
         cap = (cap + 63) / 64 * 64;                                                                  \
         if (large_tiles_enabled() && cap <= LG_TILE_MAX && a.ncol <= LG_MAX_COLS && a.ncol <= (N + LG_WAVES_CELL - 1) / LG_WAVES_CELL) { \
             a.tile_cap = (int)cap;                                                                   \
-            a.nl_rank = reinterpret_cast<int32_t*>(ws + L.nl_rank);                                  \
+            a.nl_perm = reinterpret_cast<int32_t*>(ws + L.nl_perm);                                  \
             a.nl_bst = reinterpret_cast<int32_t*>(ws + L.nl_bst);                                    \
-            a.spk = reinterpret_cast<float4*>(ws + L.spk);                                           \
-            a.apk = reinterpret_cast<float4*>(ws + L.apk);                                           \
         }          /* (otherwise the rows hold atom indices and the listed launches gather from L2, as in unbinned boxes) */ \
     }                                                                                                \
     const int wpb = a.ncell ? LG_WAVES_CELL : LG_WAVES;                                              \

@@ -37,56 +37,56 @@ def _to_device_f32(var, device):
 
 
 class Simulations():
-    """torchmd/md.py:14-96: runs `steps // frequency` epochs of `frequency` time points each,
-    logs the last frame of every epoch on the host, restarts each epoch from the (wrapped)
-    checkpoint and returns the trajectories of the LAST epoch (only they carry gradient)."""
+    """Epoch driver with the reference's interface and bookkeeping (torchmd/md.py:14-96).  One call of `simulate` runs
+    steps // frequency epochs; an epoch integrates `frequency` time points (so frequency - 1 steps, SURVEY A.10), appends
+    its LAST frame of every state variable to `log` (host numpy, keyed by the integrator's `state_keys`), pushes positions
+    and velocities back into the System, and the next epoch starts from that frame -- positions wrapped into the cell when
+    `wrap` is set.  Only the final epoch's trajectories are returned, so only they carry gradient."""
 
     def __init__(self, system, integrator, wrap=True, method="NH_verlet"):
-        self.system = system
+        self.system, self.integrator = system, integrator
         self.device = system.device
-        self.integrator = integrator
-        self.solvemethod = method
-        self.wrap = wrap
-        self.keys = self.integrator.state_keys
+        self.solvemethod, self.wrap = method, wrap
+        self.keys = integrator.state_keys
         self.initialize_log()
 
+    # ---- the log: one list of last frames per state variable
     def initialize_log(self):
-        self.log = {key: [] for key in self.keys}
+        self.log = dict((name, []) for name in self.keys)
 
     def update_log(self, trajs):
-        for i, key in enumerate(self.keys):
-            self.log[key].append(trajs[i][-1].detach().cpu().numpy())
+        for name, traj in zip(self.keys, trajs):
+            self.log[name].append(traj[-1].detach().cpu().numpy())
 
     def update_states(self):
-        if "positions" in self.log:
-            self.system.set_positions(self.log['positions'][-1])
-        if "velocities" in self.log:
-            self.system.set_velocities(self.log['velocities'][-1])
+        for name, setter in (("positions", self.system.set_positions), ("velocities", self.system.set_velocities)):
+            if name in self.log:
+                setter(self.log[name][-1])
 
     def get_check_point(self):
-        if not hasattr(self, 'log'):
+        """Device tensors of the newest logged frame, in `keys` order; index 1 (the positions) wrapped when `wrap`."""
+        log = getattr(self, "log", None)
+        if log is None:
             raise ValueError("No log available")
-        states = [torch.Tensor(self.log[key][-1]).to(self.device) for key in self.log]
+        newest = [torch.Tensor(frames[-1]).to(self.device) for frames in log.values()]
         if self.wrap:
-            wrapped_xyz = wrap_positions(self.log['positions'][-1], self.system.get_cell())
-            states[1] = torch.Tensor(wrapped_xyz).to(self.device)
-        return states
+            newest[1] = torch.Tensor(wrap_positions(log["positions"][-1], self.system.get_cell())).to(self.device)
+        return newest
+
+    def _integrate(self, states, t):
+        if self.integrator.adjoint:
+            return odeint_adjoint(self.integrator, states, t, method=self.solvemethod)
+        for x in states:                                    # (the reference's plain-autograd branch, md.py:88-91)
+            x.requires_grad = True
+        return odeint(self.integrator, tuple(states), t, method=self.solvemethod)
 
     def simulate(self, steps=1, dt=1.0 * units.fs, frequency=1):
-        if self.log['positions'] == []:
-            states = self.integrator.get_inital_states(self.wrap)
-        else:
-            states = self.get_check_point()
-        sim_epochs = int(steps // frequency)
-        t = torch.Tensor([dt * i for i in range(frequency)]).to(self.device)
+        fresh = len(self.log["positions"]) == 0
+        states = self.integrator.get_inital_states(self.wrap) if fresh else self.get_check_point()
+        t = torch.Tensor([dt * k for k in range(frequency)]).to(self.device)
         trajs = None
-        for epoch in range(sim_epochs):
-            if self.integrator.adjoint:
-                trajs = odeint_adjoint(self.integrator, states, t, method=self.solvemethod)
-            else:
-                for var in states:
-                    var.requires_grad = True
-                trajs = odeint(self.integrator, tuple(states), t, method=self.solvemethod)
+        for _ in range(int(steps // frequency)):
+            trajs = self._integrate(states, t)
             self.update_log(trajs)
             self.update_states()
             states = self.get_check_point()

@@ -158,9 +158,15 @@ def test_rdf_recognises_time_slices_of_a_fused_trajectory():
     from mdgrad_amd.observable import rdf
     from mdgrad_amd.system import System, FaceCenteredCubic
 
+    class Integ:                                  # (opted in: registration is off by default since round 5)
+        fuse_observables = True
+        _rdf_hint = None
+
     class Spec:                                   # what the observable touches on a FusedSpec
         rdf_hint = None
-        _integrator = None
+
+        def __init__(self):
+            self._integrator = Integ()
 
     system = System(FaceCenteredCubic("H", (3, 3, 3), 1.6), device="cpu")
     obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
@@ -173,6 +179,9 @@ def test_rdf_recognises_time_slices_of_a_fused_trajectory():
         return None if spec.rdf_hint is None else (spec.rdf_hint.start, spec.rdf_hint.stride)
 
     batched, single = (4, 12, 108, 3), (12, 108, 3)
+    Integ.fuse_observables = False
+    assert hint_after(lambda q: q, 1, batched) is None, "no opt-in: nothing is registered, the rdf stays a function of q_t"
+    Integ.fuse_observables = True
     assert hint_after(lambda q: q, 1, batched) == (0, 1)
     assert hint_after(lambda q: q[:, ::3], 1, batched) == (0, 3)
     assert hint_after(lambda q: q[:, 2:], 1, batched) == (2, 1)
@@ -226,7 +235,7 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     # workspace: running state + per-frame candidate rows (N * 128 * 2 bytes = N * 64 words) while they fit
     w10, w20 = lib.mdg_traj_large_workspace(1, 4096, 10, 2), lib.mdg_traj_large_workspace(1, 4096, 20, 2)
     per_frame = (w20 - w10) / 10
-    # (+ per frame: the row counts, the atoms' sorted slots and the bin columns' first slots of a build -- the column tiles)
+    # (+ per frame: the row counts, the build's permutation and its bin columns' first slots -- the column tiles)
     assert 4096 * 64 <= per_frame <= 4096 * 66 + 2048, per_frame
     huge = lib.mdg_traj_large_workspace(64, 16384, 2000, 2)                              # lists would need > 32 GiB
     assert huge < 64 * 16384 * 2000, "beyond the cap the lists are not kept (every evaluation searches)"
