@@ -42,6 +42,19 @@ FLOP_PER_PAIR_ADJ = 70.0
 FLOP_PER_PAIR_RING = 79.0
 
 
+def _measured_vector_peak():
+    """TFLOP/s of back-to-back v_pk_fma_f32 on this chip as tools/micro/valu_rate.hip measured it (profiles/r05_valu_rate.txt):
+    a packed fma issues in ~5.3 cycles per SIMD against ~2.9 for a plain v_fma_f32, so the 157.3 TF of the data sheet (one
+    packed fma per SIMD every 4 cycles) is not reachable by any instruction stream; 118 TF is."""
+    try:
+        for ln in open(os.path.join(ROOT, "profiles", "r05_valu_rate.txt")):
+            if ln.startswith("v_pk_fma_f32"):
+                return float(ln.split()[-2])
+    except (OSError, ValueError, IndexError):
+        pass
+    return None
+
+
 def _events(n):
     return [torch.cuda.Event(enable_timing=True) for _ in range(n)]
 
@@ -426,6 +439,8 @@ def run_lj108(args, rank, world, dev, mdist, with_cpu=True, form="lj", dt=None, 
         "bound": "valu", "kernel": kname, "achieved": useful / sec / 1e12, "peak": VEC_F32_PEAK_TF,
         "unit": "TFLOP/s", "frac": useful / sec / 1e12 / VEC_F32_PEAK_TF, "traffic": traffic, "kernel_ms": adj_ms,
         "executed_tflops": executed / sec / 1e12, "executed_frac": executed / sec / 1e12 / VEC_F32_PEAK_TF,
+        "peak_measured": _measured_vector_peak(),
+        "executed_frac_of_measured_peak": (executed / sec / 1e12 / _measured_vector_peak()) if _measured_vector_peak() else None,
         "valu_busy": cnt.get("valu_busy") if cnt else None, "wait_frac": cnt.get("wait_frac") if cnt else None,
         "counters": ("profiles/pmc_lj108.json: %s, %.1f us under rocprofv3" % (cnt["name"], cnt["avg_us"])) if cnt else why,
         "hbm_frac_measured": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None,

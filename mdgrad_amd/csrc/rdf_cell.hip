@@ -375,6 +375,10 @@ __global__ __launch_bounds__(RC_THREADS) void rdf_cell_fwd_tile_kernel(const flo
     }
 }
 
+// (Measured and dropped in round 5: a TEST / EVALUATE split of this sweep -- rows only test their candidates and append the
+//  accepted ones, one in eight, to an LDS queue, the table force then runs with full lanes.  3.29 ms against 2.66 ms for 704
+//  frames of 4 096 atoms: the ballot / queue-write chain serialises every 16-candidate step behind its LDS read, and the
+//  straight loop below, which the compiler unrolls and overlaps freely, hides that latency better than the split saves work.)
 __global__ __launch_bounds__(256) void rdf_cell_bwd_tile_kernel(const float4* __restrict__ spos, const int32_t* __restrict__ bstart,
                                                                 int N, int n_frames, MdgCell cell, CellGrid g, MdgPairTerm term,
                                                                 const float* __restrict__ theta, int cap, float* __restrict__ grad) {

@@ -172,6 +172,7 @@ __device__ __forceinline__ void st3(float* a, size_t e, float x, float y, float 
 //            :42-82); bin the midpoint positions
 //   PHASE 4  adjoint, after the last interval: finish interval 1 (A.step = 0), no binning
 constexpr int LG_PREP = 1024;
+constexpr int LG_PREP_SMALL = 256;           // ... of the phases that bin nothing (the adjoint over stored lists): more, smaller workgroups
 constexpr int LG_PREP_ATOMS = 16;            // atoms per thread: N <= 16 384
 
 // NA = atoms per thread (compile-time: their positions stay in registers between the update and the binning)
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, nc = A.ncell;
     // gridDim.x workgroups share a replica's atoms when nothing has to be binned (the adjoint over stored lists); the
     // scalar work (partial sums, thermostat chain) is repeated by each, written by the first
-    const int tid = blockIdx.x * LG_PREP + threadIdx.x, stride = gridDim.x * LG_PREP;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     const bool first = blockIdx.x == 0;
     const bool nhc = A.prm.ensemble == 0;
     const size_t so = (size_t)rep * N * 3;
@@ -1851,7 +1852,7 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
 #define LG_PREP_LAUNCH(PH_)                                                                          \
     do {                                                                                             \
         if ((PH_) >= 2 && a.nl_idx)                                                                  \
-            hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP - 1) / LG_PREP, R), dim3(LG_PREP), 0, st, a); \
+            hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP_SMALL - 1) / LG_PREP_SMALL, R), dim3(LG_PREP_SMALL), 0, st, a); \
         else if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(1, R), dim3(LG_PREP), 0, st, a); \
         else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, R), dim3(LG_PREP), 0, st, a);  \
     } while (0)
