@@ -95,6 +95,7 @@ struct LargeArgs {
     // in build order, written by the prep launches: their scattered 16-byte stores cost more than these gathers save).
     int32_t* nl_perm;                        // [R][T][N]  atom at sorted slot s of the build of frame b
     int32_t* nl_bst;                         // [R][T][LG_MAX_COLS + 1]  first sorted slot of bin column c of that build
+    int rep0;                                // first replica of this launch (replica groups on concurrent streams, see lg_streams)
     int tile_cap;                            // staged atoms of a tile at most (0: no tiles)
     int ncol;                                // bin columns nb[0] nb[1]
 };
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
     __shared__ float red[32];
     __shared__ float redN[16 * LG_NV];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS], lps[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, nc = A.ncell;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y + A.rep0, nc = A.ncell;
     // gridDim.x workgroups share a replica's atoms when nothing has to be binned (the adjoint over stored lists); the
     // scalar work (partial sums, thermostat chain) is repeated by each, written by the first
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     float* tile = reinterpret_cast<float*>(nbuf + (blockDim.x >> 6) * LG_CAP);
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y + A.rep0;
     if (MODE == 1 && A.nl_idx && !A.nl_state[2 * rep]) return;      // the current list serves this step (large_fwd_listed)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t so = (size_t)rep * N * 3;
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(256) void large_fwd_listed(const LargeArgs A) {
     constexpr int NP = LG_LIST / 16;
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y + A.rep0, k = A.step;
     if (A.nl_state[2 * rep]) return;                                   // this step searched (large_force_step<1>)
     const int slot = A.nl_state[2 * rep + 1];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15;
@@ -1010,7 +1011,7 @@ template <int MODE, int KIND>
 __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y, k = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.y + A.rep0, k = A.step;
     if (MODE == 1 && !A.nl_state[2 * rep]) return;                  // the current list serves this step (large_fwd_listed)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15, row = lane >> 4;
     const size_t so = (size_t)rep * N * 3;
@@ -1190,7 +1191,7 @@ void large_adj_force(const LargeArgs A, const int second) {
     extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
     float* tile = reinterpret_cast<float*>(nbuf + (blockDim.x >> 6) * LG_CAP);
     __shared__ float red[16 * LG_NV];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y + A.rep0, i_fr = A.step;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const size_t so = (size_t)rep * N * 3;
     const float* qs = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
@@ -1245,7 +1246,7 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     constexpr int NP = LG_LIST / 16;                                   // passes a full row takes
     constexpr int NTH = KIND >= 0 ? MDG_MAX_THETA : LG_KMAX;           // live parameter partials
     __shared__ float red[4 * (NTH + 2)];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y, i_fr = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.y + A.rep0, i_fr = A.step;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, s = lane & 15;
     const size_t so = (size_t)rep * N * 3;
     const float* q = second ? A.qm + so : A.q_t + ((size_t)rep * T + i_fr) * N * 3;
@@ -1475,7 +1476,7 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_fwd_tiled(const LargeAr
     __shared__ LTile M;
     __shared__ float red[32];
     __shared__ float Qs[MDG_MAX_CHAINS], pvs[MDG_MAX_CHAINS];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.x, tile = blockIdx.y, k = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains, rep = blockIdx.x + A.rep0, tile = blockIdx.y, k = A.step;
     if (A.nl_state[2 * rep]) return;                                   // this step searched (large_search_rows<1>)
     const int slot = A.nl_state[2 * rep + 1];
     Row3* tp = reinterpret_cast<Row3*>(lds_f);
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_adj_tiled(const LargeAr
     extern __shared__ __attribute__((aligned(16))) float lds_a[];
     __shared__ LTile M;
     __shared__ float red[NWV * (NTH + 2)];
-    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.x, tile = blockIdx.y, i_fr = A.step;
+    const int N = A.prm.n_atoms, T = A.prm.n_frames, rep = blockIdx.x + A.rep0, tile = blockIdx.y, i_fr = A.step;
     Row3* tp = reinterpret_cast<Row3*>(lds_a);
     Row3* tw = reinterpret_cast<Row3*>(lds_a + 3 * (size_t)A.tile_cap);
     int32_t* tidx = reinterpret_cast<int32_t*>(lds_a + 6 * (size_t)A.tile_cap);
@@ -1806,6 +1807,49 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     return w;
 }
 
+// REPLICA GROUPS ON CONCURRENT STREAMS (round 5).  Between two force launches a trajectory runs a `prep` launch that is pure
+// latency: one or four workgroups per replica, a chain of dependent loads, 17-20 us during which most of the chip idles
+// (valu_busy 0.08-0.2; 14 % of the 64 x 4 096-atom pass), and every force launch ends in a tail of half-empty CUs.  Replicas
+// never interact, so the launches of a trajectory are issued for two halves of the replicas on two side streams (forked from /
+// joined into the caller's stream by events): one half's prep and tails overlap the other half's force sweep.  The kernels and
+// every number they produce are unchanged -- a replica's launches run in the same order on the same data.
+constexpr int LG_MAX_GROUPS = 4;
+struct LgStreams {
+    int device = -1;
+    hipStream_t s[LG_MAX_GROUPS] = {};
+    hipEvent_t fork = nullptr, join[LG_MAX_GROUPS] = {};
+};
+
+// number of groups for R replicas on stream `st` (MDG_LARGE_STREAMS = 1..4 overrides; 1 while `st` is being captured)
+int lg_group_count(int R, hipStream_t st) {
+    // (64 x 4 096 atoms, MI355X: 170.3 k steps/s on one stream, 193.4 k with two groups, 195.6 k with three -- about one round
+    //  of workgroups per launch --, 173.8 k with four: launches too small to fill the chip)
+    int want = R >= 48 ? 3 : (R >= 8 ? 2 : 1);
+    if (const char* e = getenv("MDG_LARGE_STREAMS")) want = atoi(e);
+    if (want < 1) want = 1;
+    if (want > LG_MAX_GROUPS) want = LG_MAX_GROUPS;
+    if (want > R) want = R;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) want = 1;
+    return want;
+}
+
+LgStreams* lg_streams() {
+    static thread_local LgStreams pool[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    LgStreams& P = pool[dev];
+    if (P.device != dev) {
+        for (int g = 0; g < LG_MAX_GROUPS; ++g) {
+            if (hipStreamCreateWithFlags(&P.s[g], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&P.join[g], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&P.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        P.device = dev;
+    }
+    return &P;
+}
+
 // MDG_LARGE_TILES=0: the listed launches gather by atom index from L2 (A/B measurements; the pre-round-5 kernels)
 bool large_tiles_enabled() {
     const char* e = getenv("MDG_LARGE_TILES");
@@ -1852,10 +1896,35 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
 #define LG_PREP_LAUNCH(PH_)                                                                          \
     do {                                                                                             \
         if ((PH_) >= 2 && a.nl_idx)                                                                  \
-            hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP_SMALL - 1) / LG_PREP_SMALL, R), dim3(LG_PREP_SMALL), 0, st, a); \
-        else if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(1, R), dim3(LG_PREP), 0, st, a); \
-        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, R), dim3(LG_PREP), 0, st, a);  \
+            hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP_SMALL - 1) / LG_PREP_SMALL, Rg), dim3(LG_PREP_SMALL), 0, sg, a); \
+        else if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a); \
+        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a);  \
     } while (0)
+
+// the replica groups of a trajectory: G, their streams (the caller's when G == 1), fork / join around the launch loops
+#define LG_GROUPS_BEGIN()                                                                            \
+    int G = lg_group_count(R, st);                                                                   \
+    LgStreams* LS = G > 1 ? lg_streams() : nullptr;                                                  \
+    if (!LS) G = 1;                                                                                  \
+    if (G > 1) {                                                                                     \
+        MDG_HIP(hipEventRecord(LS->fork, st));                                                       \
+        for (int g = 0; g < G; ++g) MDG_HIP(hipStreamWaitEvent(LS->s[g], LS->fork, 0));              \
+    }                                                                                                \
+    (void)0
+#define LG_GROUP(g_)                                                                                 \
+    const int r0_ = (int)((long long)R * (g_) / G), Rg = (int)((long long)R * ((g_) + 1) / G) - r0_; \
+    hipStream_t sg = G > 1 ? LS->s[g_] : st;                                                         \
+    a.rep0 = r0_;                                                                                    \
+    (void)0
+#define LG_GROUPS_END()                                                                              \
+    if (G > 1) {                                                                                     \
+        for (int g = 0; g < G; ++g) {                                                                \
+            MDG_HIP(hipEventRecord(LS->join[g], LS->s[g]));                                          \
+            MDG_HIP(hipStreamWaitEvent(st, LS->join[g], 0));                                         \
+        }                                                                                            \
+    }                                                                                                \
+    a.rep0 = 0;                                                                                      \
+    (void)0
 
 #define LG_SETUP()                                                                                   \
     const int R = prm->n_rep, N = prm->n_atoms;                                                      \
@@ -1936,37 +2005,45 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
     if (prm->ensemble == 0)
         MDG_HIP(hipMemcpy2DAsync(a.pv, sizeof(float) * MDG_MAX_CHAINS, pv0, sizeof(float) * C, sizeof(float) * C, R,
                                  hipMemcpyDeviceToDevice, st));
-    dim3 gF(nbF, R);
     a.step = 0;
     if (a.nl_idx) MDG_HIP(hipMemsetAsync(a.nl_bad, 0, sizeof(int32_t) * (size_t)R * T, st));
 #define LG_FORCE_STEP(MODE_)                                                                                    \
     do {                                                                                                        \
+        const dim3 gF(nbF, Rg), gLg(gL.x, Rg);                                                                  \
         if (a.nl_idx && a.ncell) {         /* binned box, lists kept: the row-based search (one sweep) */      \
-            if (lj126) hipLaunchKernelGGL((large_search_rows<MODE_, KIND_LJ126>), gL, dim3(256), 0, st, a);   \
-            else hipLaunchKernelGGL((large_search_rows<MODE_, -1>), gL, dim3(256), 0, st, a);                  \
+            if (lj126) hipLaunchKernelGGL((large_search_rows<MODE_, KIND_LJ126>), gLg, dim3(256), 0, sg, a);  \
+            else hipLaunchKernelGGL((large_search_rows<MODE_, -1>), gLg, dim3(256), 0, sg, a);                 \
         } else                                                                                                  \
-        if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a); \
-        else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);    \
-        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, st, a);            \
+        if (lj126) hipLaunchKernelGGL((large_force_step<true, MODE_, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, sg, a); \
+        else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, sg, a);    \
+        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, sg, a);            \
     } while (0)
-    if (a.ncell) LG_PREP_LAUNCH(0);
-    LG_FORCE_STEP(0);
+    LG_GROUPS_BEGIN();
+    for (int g = 0; g < G; ++g) {
+        LG_GROUP(g);
+        if (a.ncell) LG_PREP_LAUNCH(0);
+        LG_FORCE_STEP(0);
+    }
     for (int k = 0; k + 1 < T; ++k) {
         a.step = k;
-        LG_PREP_LAUNCH(1);                                  // kick + drift + bath half step; search needed? then binning
-        LG_FORCE_STEP(1);                                   // (returns at once while the current list serves)
-        if (a.tile_cap) {                                   // (returns at once when the step searched)
-            const dim3 gT(R, a.ncol);
-            const size_t lds = sizeof(float) * 4 * (size_t)a.tile_cap;
-            if (lj126) hipLaunchKernelGGL((large_fwd_tiled<KIND_LJ126>), gT, dim3(LG_TILE_THREADS), lds, st, a);
-            else hipLaunchKernelGGL((large_fwd_tiled<-1>), gT, dim3(LG_TILE_THREADS), lds, st, a);
-        } else if (a.nl_idx) {
-            const dim3 gLF((N + LG_ROW_ATOMS * LG_FWD_GROUPS - 1) / (LG_ROW_ATOMS * LG_FWD_GROUPS), R);
-            if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gLF, dim3(256), 0, st, a);
-            else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gLF, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((large_fwd_listed<false, -1>), gLF, dim3(256), 0, st, a);
+        for (int g = 0; g < G; ++g) {
+            LG_GROUP(g);
+            LG_PREP_LAUNCH(1);                                  // kick + drift + bath half step; search needed? then binning
+            LG_FORCE_STEP(1);                                   // (returns at once while the current list serves)
+            if (a.tile_cap) {                                   // (returns at once when the step searched)
+                const dim3 gT(Rg, a.ncol);
+                const size_t lds = sizeof(float) * 4 * (size_t)a.tile_cap;
+                if (lj126) hipLaunchKernelGGL((large_fwd_tiled<KIND_LJ126>), gT, dim3(LG_TILE_THREADS), lds, sg, a);
+                else hipLaunchKernelGGL((large_fwd_tiled<-1>), gT, dim3(LG_TILE_THREADS), lds, sg, a);
+            } else if (a.nl_idx) {
+                const dim3 gLF((N + LG_ROW_ATOMS * LG_FWD_GROUPS - 1) / (LG_ROW_ATOMS * LG_FWD_GROUPS), Rg);
+                if (lj126) hipLaunchKernelGGL((large_fwd_listed<true, KIND_LJ126>), gLF, dim3(256), 0, sg, a);
+                else if (diag) hipLaunchKernelGGL((large_fwd_listed<true, -1>), gLF, dim3(256), 0, sg, a);
+                else hipLaunchKernelGGL((large_fwd_listed<false, -1>), gLF, dim3(256), 0, sg, a);
+            }
         }
     }
+    LG_GROUPS_END();
 #undef LG_FORCE_STEP
     MDG_CHECK_LAUNCH("traj_fwd_large");
     return MDG_OK;
@@ -1996,33 +2073,41 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         MDG_HIP(hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st));
         MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
     }
-    dim3 gF(nbF, R);
-    const dim3 gLA((N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS), R);
-    if (a.nl_idx) a.nbF = a.tile_cap ? a.ncol : (int)gLA.x;   // (rows of partN the listed launches write, the prep launches sum)
-    for (int i = T - 1; i >= 1; --i) {
-        a.step = i;
+    const int gLAx = (N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS);
+    if (a.nl_idx) a.nbF = a.tile_cap ? a.ncol : gLAx;         // (rows of partN the listed launches write, the prep launches sum)
 #define LG_ADJ_FORCE(SECOND_)                                                                                       \
     do {                                                                                                            \
+        const dim3 gF(nbF, Rg), gLA(gLAx, Rg);                                                                      \
         if (a.tile_cap) {                                                                                           \
             const size_t lds_ = sizeof(float) * 7 * (size_t)a.tile_cap;                                             \
-            if (lj126) hipLaunchKernelGGL((large_adj_tiled<KIND_LJ126>), dim3(R, a.ncol), dim3(LG_TILE_THREADS), lds_, st, a, SECOND_); \
-            else hipLaunchKernelGGL((large_adj_tiled<-1>), dim3(R, a.ncol), dim3(LG_TILE_THREADS), lds_, st, a, SECOND_); \
+            if (lj126) hipLaunchKernelGGL((large_adj_tiled<KIND_LJ126>), dim3(Rg, a.ncol), dim3(LG_TILE_THREADS), lds_, sg, a, SECOND_); \
+            else hipLaunchKernelGGL((large_adj_tiled<-1>), dim3(Rg, a.ncol), dim3(LG_TILE_THREADS), lds_, sg, a, SECOND_); \
         } else if (a.nl_idx) {                                                                                      \
-            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, st, a, SECOND_);      \
-            else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gLA, dim3(256), 0, st, a, SECOND_);           \
-            else hipLaunchKernelGGL((large_adj_listed<false, -1>), gLA, dim3(256), 0, st, a, SECOND_);                    \
-        } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_); \
-        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);    \
-        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, st, a, SECOND_);            \
+            if (lj126) hipLaunchKernelGGL((large_adj_listed<true, KIND_LJ126>), gLA, dim3(256), 0, sg, a, SECOND_);      \
+            else if (diag) hipLaunchKernelGGL((large_adj_listed<true, -1>), gLA, dim3(256), 0, sg, a, SECOND_);           \
+            else hipLaunchKernelGGL((large_adj_listed<false, -1>), gLA, dim3(256), 0, sg, a, SECOND_);                    \
+        } else if (lj126) hipLaunchKernelGGL((large_adj_force<true, KIND_LJ126>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_); \
+        else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);    \
+        else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);            \
     } while (0)
-        LG_PREP_LAUNCH(2);                                                          // finish interval i + 1, bin frame i
-        LG_ADJ_FORCE(0);
-        LG_PREP_LAUNCH(3);                                                          // midpoint state, bin it
-        LG_ADJ_FORCE(1);
-#undef LG_ADJ_FORCE
+    LG_GROUPS_BEGIN();
+    for (int i = T - 1; i >= 1; --i) {
+        a.step = i;
+        for (int g = 0; g < G; ++g) {
+            LG_GROUP(g);
+            LG_PREP_LAUNCH(2);                                                      // finish interval i + 1, bin frame i
+            LG_ADJ_FORCE(0);
+            LG_PREP_LAUNCH(3);                                                      // midpoint state, bin it
+            LG_ADJ_FORCE(1);
+        }
     }
+#undef LG_ADJ_FORCE
     a.step = 0;
-    LG_PREP_LAUNCH(4);                                                              // finish interval 1
+    for (int g = 0; g < G; ++g) {
+        LG_GROUP(g);
+        LG_PREP_LAUNCH(4);                                                          // finish interval 1
+    }
+    LG_GROUPS_END();
     MDG_HIP(hipMemcpyAsync(adj_v0, a.lv, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     MDG_HIP(hipMemcpyAsync(adj_q0, a.lq, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
     if (prm->ensemble == 0)

@@ -873,6 +873,42 @@ def test_cell_sweep_rdf_equals_list_rdf_and_is_reproducible():
     close(out[0][1], out[2][1], 1e-4, 1e-6 * float(out[2][1].abs().max()), "gradient: sweep vs list")
 
 
+def test_large_path_replica_groups_on_concurrent_streams_are_bitwise_the_single_stream_run(monkeypatch):
+    """Round 5: the launches of a large-system trajectory are issued for halves of the replicas on two side streams, so
+    that one half's latency-bound prep launches overlap the other half's force sweeps (csrc/traj_large.hip lg_streams).  A
+    replica's launches run in the same order on the same data: trajectories, adjoints and parameter gradients of 5 stacked
+    1 000-atom replicas (odd count: uneven groups; different velocities: the replicas search at different steps) with 1, 2
+    and 3 groups are bitwise equal."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    pos, cell = liquid(10, seed=51, jitter=0.05)
+    rng = np.random.default_rng(151)
+    N, R = len(pos), 5
+    system = mk_system(pos, cell, rng.normal(0, 1.0, pos.shape).astype(np.float32), np.full(N, 1.008, dtype=np.float32))
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3, Q=30.0).to(DEV)
+    integ.fused_large = True
+    t = torch.Tensor([0.005 * i for i in range(13)]).to(DEV)
+    q0 = T(np.stack([np.mod(pos + rng.normal(0, 0.02, pos.shape), cell) for _ in range(R)]).astype(np.float32), DEV)
+    v0 = T(np.stack([rng.normal(0, 0.6 + 0.3 * r, pos.shape) for r in range(R)]).astype(np.float32), DEV)
+    res = []
+    for groups in ("1", "2", "3"):
+        monkeypatch.setenv("MDG_LARGE_STREAMS", groups)
+        spec = integ.fused_spec("NH_verlet")
+        assert spec.large
+        v, q = v0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
+        pv = torch.zeros(R, 3, device=DEV, requires_grad=True)
+        v_t, q_t, pv_t = ops.FusedTrajFn.apply(v, q, pv, t, spec.flat_params(), spec)
+        mdl.zero_grad()
+        (q_t[:, ::4].pow(2).mean() + v_t[:, -1].pow(2).mean() + pv_t[:, -1].sum() * 1e-3).backward()
+        res.append([q_t.detach().clone(), v_t.detach().clone(), pv_t.detach().clone(), v.grad.clone(), q.grad.clone(), pv.grad.clone(),
+                    torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())]).clone()])
+    for other in res[1:]:
+        for a, b, nm in zip(res[0], other, ("q_t", "v_t", "pv_t", "adj v0", "adj q0", "adj pv0", "dL/dtheta")):
+            assert torch.equal(a, b), nm
+
+
 @pytest.mark.parametrize("case", ["liquid4096", "crowded", "dilute", "tall_box"])
 def test_cell_sweep_rdf_column_tiles_equal_the_row_sweep_bitwise(case, monkeypatch):
     """Round 5: the cell-sweep RDF stages the 3 x 3 bin columns around a workgroup's column in LDS (csrc/rdf_cell.hip
