@@ -1202,10 +1202,12 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
     # counters of the same workload (profiles/pmc_lj4096.json, 64 replicas x 51 frames): HBM bytes of a whole pass summed over
     # its kernels, and the issue-side picture of the kernel with the largest share of the pass
     std = R == 64 and T == 51
-    dom, why = _counters("lj4096", "large_adj_listed") if std else (None, "other geometry")
+    dom, why = _counters("lj4096", "large_adj_") if std else (None, "other geometry")      # (large_adj_tiled / large_adj_listed)
+    # the launches of a trajectory are issued for groups of replicas on concurrent streams (csrc/traj_large.hip lg_group_count)
+    groups = int(os.environ.get("MDG_LARGE_STREAMS", "0")) or (3 if R >= 48 else (2 if R >= 8 else 1))
     pj = _profile_json("pmc_lj4096.json") if std else None
     traffic = _pass_traffic("lj4096", 3) if (dom is not None) else None     # (the profiled run: 1 warm-up + 2 timed passes)
-    B_H = (12.0 * Pn + 48.0 * N) * R                                        # fused force + Hessian.w sweep, per launch
+    B_H = (12.0 * Pn + 48.0 * N) * R / groups                               # fused force + Hessian.w sweep, per launch
     dominant = None
     if dom is not None:
         sec_k = dom["avg_us"] * 1e-6
@@ -1214,11 +1216,14 @@ def run_lj4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=
                     "algorithmic_frac_of_hbm_peak": B_H / sec_k / 1e9 / HBM_PEAK_GBS,
                     "hbm_bytes_per_launch_measured": dom.get("hbm_bytes_per_launch"), "hbm_gbs_measured": dom.get("hbm_gbs"),
                     "valu_busy": dom.get("valu_busy"), "wait_frac": dom.get("wait_frac"), "vgpr": dom.get("vgpr"),
-                    "binding": "VALU issue: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x duration x 2.4 GHz) = %.2f; its measured HBM "
-                               "traffic is %.2f x the algorithmic bytes (no wasted re-reads) at %.0f GB/s" % (
+                    "replica_groups_on_concurrent_streams": groups,
+                    "binding": "VALU issue (0.70 when the launch runs alone, profiles/r05c_lj4096_kernel_stats.txt; under the "
+                               "profiler the groups' launches overlap and each sees a share of the chip): SQ_ACTIVE_INST_VALU x 4 / "
+                               "(1024 SIMDs x duration x 2.4 GHz) = %.2f; its measured HBM traffic is %.2f x the algorithmic bytes "
+                               "at %.0f GB/s" % (
                                    dom.get("valu_busy", float("nan")), dom.get("hbm_bytes_per_launch", float("nan")) / B_H,
                                    dom.get("hbm_gbs", float("nan")))}
-    out["roofline"] = {"bound": "hbm", "kernel": "whole MD step (large_prep / large_search_rows / large_fwd_listed / large_adj_listed "
+    out["roofline"] = {"bound": "hbm", "kernel": "whole MD step (large_prep / large_search_rows / large_fwd_tiled / large_adj_tiled "
                                                  "+ cell-sweep RDF)",
                        "achieved": bytes_step / sec_per_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": bytes_step / sec_per_step / 1e9 / HBM_PEAK_GBS,

@@ -73,21 +73,29 @@ class GradBucket:
     `zero_grad(set_to_none=False)` idiom) cost nothing."""
 
     def __init__(self, params):
-        self.params = list(params)
-        self.offsets = []
+        params = list(params)
+        self._refs = [weakref.ref(p) for p in params]     # (weak: the bucket must not keep a model alive, nor form a cycle
+        self.offsets = []                                 #  parameter -> bucket -> parameter -- ADVICE r4)
         n = 0
-        for p in self.params:
+        for p in params:
             self.offsets.append(n)
             n += p.numel()
-        ref = self.params[0]
-        if any(p.dtype != ref.dtype or p.device != ref.device for p in self.params):
+        ref = params[0]
+        if any(p.dtype != ref.dtype or p.device != ref.device for p in params):
             raise ValueError("GradBucket needs parameters of one dtype on one device (got %s)"
-                             % sorted({(str(p.dtype), str(p.device)) for p in self.params}))
+                             % sorted({(str(p.dtype), str(p.device)) for p in params}))
         self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, self.params)]
+        self.views = [self.flat[o:o + p.numel()].view(p.shape) for o, p in zip(self.offsets, params)]
+
+    @property
+    def params(self):
+        ps = [r() for r in self._refs]
+        if any(p is None for p in ps):
+            raise RuntimeError("GradBucket: a parameter of this bucket no longer exists")
+        return ps
 
     def matches(self, params):
-        return len(params) == len(self.params) and all(a is b for a, b in zip(params, self.params))
+        return len(params) == len(self._refs) and all(r() is b for r, b in zip(self._refs, params))
 
     def gather(self):
         """Bring every parameter's gradient into the flat buffer (no-op for those that already live there)."""
@@ -106,19 +114,22 @@ class GradBucket:
         return self.flat
 
 
-_buckets = weakref.WeakValueDictionary()          # id(first parameter) -> bucket; the bucket itself hangs on that parameter
+_buckets = {}          # id(first parameter) -> bucket, dropped by a finalizer when that parameter is collected
 
 
 def _bucket_for(params):
-    """The bucket of this parameter list.  It is owned by the list's first parameter (an attribute on the tensor), so a
-    model that goes away takes its flat buffer with it: nothing here keeps parameters or buffers of earlier runs alive."""
+    """The bucket of this parameter list, kept in a module-level table under the identity of the list's first parameter and
+    removed when that parameter dies (weakref.finalize) -- nothing is attached to the Parameter itself, so torch.save /
+    copy.deepcopy of a model do not drag the flat buffer along, and the bucket holds its parameters weakly."""
     params = list(params)
-    b = _buckets.get(id(params[0]))
+    key = id(params[0])
+    b = _buckets.get(key)
     if b is not None and b.matches(params):
         return b
     b = GradBucket(params)
-    params[0]._mdg_grad_bucket = b
-    _buckets[id(params[0])] = b
+    if key not in _buckets:
+        weakref.finalize(params[0], _buckets.pop, key, None)
+    _buckets[key] = b
     return b
 
 

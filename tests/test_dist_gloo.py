@@ -147,3 +147,24 @@ def test_plain_command_spawns_its_own_ranks(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
     assert lines == ["RESULT 2 3.0 gloo 2 2 True [10.0, 11.0]"], r.stdout[-1000:]
+
+
+def test_grad_bucket_does_not_hang_on_the_parameter_nor_keep_the_model_alive():
+    """the flat gradient buffer is not an attribute of a Parameter (deepcopy / pickling of a model stay small), holds
+    its parameters weakly, and its table entry goes when the model does."""
+    import copy
+    import gc
+    import weakref
+    import torch
+    from mdgrad_amd import dist as mdist
+    model = torch.nn.Linear(4, 3)
+    params = list(model.parameters())
+    b = mdist._bucket_for(params)
+    assert mdist._bucket_for(params) is b
+    assert not any(isinstance(v, mdist.GradBucket) for v in vars(params[0]).values())
+    clone = copy.deepcopy(model)
+    assert not any(isinstance(v, mdist.GradBucket) for p in clone.parameters() for v in vars(p).values())
+    key, ref = id(params[0]), weakref.ref(params[0])
+    del model, params, clone
+    gc.collect()
+    assert ref() is None and key not in mdist._buckets, "the bucket must not keep the parameters alive"
