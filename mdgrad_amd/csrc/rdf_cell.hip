@@ -375,6 +375,10 @@ __global__ __launch_bounds__(RC_THREADS) void rdf_cell_fwd_tile_kernel(const flo
     }
 }
 
+// (Also measured and dropped in round 5: bins of HALF the cutoff with a 5 x 5 x 5 stencil -- 42 % fewer candidates for the same
+//  pairs -- as tiles of 2 x 2 columns staging 6 x 6: histogram identical, forward 3.7 ms against 1.5 ms, backward 3.4 against
+//  2.7 for 704 frames of 4 096 atoms.  Twenty-five z-ranges of ~12 atoms per row instead of nine of ~57: the per-column
+//  bookkeeping and the 75 %-full 16-lane passes cost more than the candidates saved.)
 // (Measured and dropped in round 5: a TEST / EVALUATE split of this sweep -- rows only test their candidates and append the
 //  accepted ones, one in eight, to an LDS queue, the table force then runs with full lanes.  3.29 ms against 2.66 ms for 704
 //  frames of 4 096 atoms: the ballot / queue-write chain serialises every 16-candidate step behind its LDS read, and the
