@@ -273,7 +273,7 @@ int mdg_traj_adj_small_rdf(const MdgTrajParams* prm /*host*/, const MdgCell* cel
                            const MdgRdfFuse* rdf /*host*/, const float* g_raw /*[nbins]*/, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * K5-K7 for systems beyond one workgroup (N <= 16384, NoseHooverChain or NVE): same contract as
+ * K5-K7 for systems beyond one workgroup (N <= 32768, NoseHooverChain or NVE): same contract as
  * mdg_traj_fwd_small / mdg_traj_adj_small, three launches per step (forward) / four per adjoint
  * interval, enqueued by a host loop; the neighbour search is fused into the force kernel (per-wave LDS list).
  * Verlet reuse: a search uses the cutoff rc + skin (skin = 12 % of the largest cutoff) and keeps the candidate
@@ -342,7 +342,7 @@ int mdg_rdf_fwd_ell(const float* pos, int64_t n_atoms_total, const MdgCell* cell
  * than the histogram): per frame, positions sorted by (bin, atom index); a wave per atom walks the 27-bin stencil and
  * counts every pair once on the fine integer grid (forward), or sums the tabulated pair force of
  * phi(d) = sum_k g_k exp(coeff (d - mu_k)^2) (backward: term/theta = the MDG_PAIR_TABLE built from dL/d raw, as for
- * mdg_pair_eval_ell; g_xyz [F][N][3] = dL/dxyz).  Orthorhombic cells of >= 3 `cutoff` per side, N <= 16 384
+ * mdg_pair_eval_ell; g_xyz [F][N][3] = dL/dxyz).  Orthorhombic cells of >= 3 `cutoff` per side, N <= 32 768
  * (mdg_rdf_cell_supported); cutoff = the list cutoff (>= the reach of the fine grid).  scratch: int32 words of
  * mdg_rdf_cell_scratch(), 16-byte aligned, filled by the forward call and read by the backward call of the same frames.
  * Replaces torchmd/observable.py:62-76 (generate_nbr_list + GaussianSmearing(...).sum(0)) and its autograd transpose. */

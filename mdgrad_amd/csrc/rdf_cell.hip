@@ -28,7 +28,7 @@ namespace {
 
 constexpr int RC_MAX_CELLS = 4096;           // bins per frame (LDS scan)
 constexpr int RC_THREADS = 1024;
-constexpr int RC_MAX_ATOMS = RC_THREADS * 16;
+constexpr int RC_MAX_ATOMS = RC_THREADS * 32;
 
 struct CellGrid { int nb[3]; int ncell; };
 
@@ -488,8 +488,11 @@ extern "C" int mdg_rdf_fwd_cell(const float* xyz, int n_frames, int n_atoms, con
     if (n_atoms <= 4 * RC_THREADS)
         hipLaunchKernelGGL((rdf_cell_bin_kernel<4>), dim3(n_frames), dim3(RC_THREADS), 0, st, xyz, n_atoms, *cell, g, S.bstart,
                            S.tmp, S.spos);
-    else
+    else if (n_atoms <= 16 * RC_THREADS)
         hipLaunchKernelGGL((rdf_cell_bin_kernel<16>), dim3(n_frames), dim3(RC_THREADS), 0, st, xyz, n_atoms, *cell, g, S.bstart,
+                           S.tmp, S.spos);
+    else
+        hipLaunchKernelGGL((rdf_cell_bin_kernel<32>), dim3(n_frames), dim3(RC_THREADS), 0, st, xyz, n_atoms, *cell, g, S.bstart,
                            S.tmp, S.spos);
     uint32_t* ghist = nullptr;
     MDG_HIP(hipMallocAsync((void**)&ghist, sizeof(uint32_t) * (size_t)P.nfine, st));

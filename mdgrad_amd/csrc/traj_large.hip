@@ -174,7 +174,8 @@ __device__ __forceinline__ void st3(float* a, size_t e, float x, float y, float 
 //   PHASE 4  adjoint, after the last interval: finish interval 1 (A.step = 0), no binning
 constexpr int LG_PREP = 1024;
 constexpr int LG_PREP_SMALL = 256;           // ... of the phases that bin nothing (the adjoint over stored lists): more, smaller workgroups
-constexpr int LG_PREP_ATOMS = 16;            // atoms per thread: N <= 16 384
+constexpr int LG_PREP_ATOMS = 16;            // atoms per thread of the binning workgroup: N <= 16 384 ...
+constexpr int LG_PREP_ATOMS_MAX = 32;        // ... and <= 32 768 (round 5: the positions of 32 atoms per thread in registers)
 
 // NA = atoms per thread (compile-time: their positions stay in registers between the update and the binning)
 template <int PHASE, int NA>
@@ -1859,7 +1860,7 @@ bool large_tiles_enabled() {
 int validate_large(const MdgTrajParams* p, const MdgCell* cell, const MdgTerms* terms) {
     MDG_CHECK_ARG(p && cell && terms, "traj_large: null descriptor");
     MDG_CHECK_ARG(p->n_rep > 0 && p->n_atoms > 1 && p->n_frames >= 1, "traj_large: bad sizes");
-    MDG_CHECK_ARG(p->n_atoms <= LG_PREP * LG_PREP_ATOMS, "traj_large: at most %d atoms", LG_PREP * LG_PREP_ATOMS);
+    MDG_CHECK_ARG(p->n_atoms <= LG_PREP * LG_PREP_ATOMS_MAX, "traj_large: at most %d atoms", LG_PREP * LG_PREP_ATOMS_MAX);
     MDG_CHECK_ARG(p->ensemble == 0 || p->ensemble == 1, "traj_large: ensemble must be 0 (NHC) or 1 (NVE)");
     MDG_CHECK_ARG(p->ensemble == 1 || (p->n_chains >= 2 && p->n_chains <= MDG_MAX_CHAINS),
                   "traj_large: 2 <= num_chains <= %d", MDG_MAX_CHAINS);
@@ -1898,7 +1899,8 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
         if ((PH_) >= 2 && a.nl_idx)                                                                  \
             hipLaunchKernelGGL((large_prep<PH_, 1>), dim3((N + LG_PREP_SMALL - 1) / LG_PREP_SMALL, Rg), dim3(LG_PREP_SMALL), 0, sg, a); \
         else if (N <= 4 * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, 4>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a); \
-        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a);  \
+        else if (N <= LG_PREP_ATOMS * LG_PREP) hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a); \
+        else hipLaunchKernelGGL((large_prep<PH_, LG_PREP_ATOMS_MAX>), dim3(1, Rg), dim3(LG_PREP), 0, sg, a); \
     } while (0)
 
 // the replica groups of a trajectory: G, their streams (the caller's when G == 1), fork / join around the launch loops

@@ -17,7 +17,7 @@ from .system import wrap_positions
 from .tinydiffeq import _flatten
 
 FUSED_MAX_ATOMS = 1024          # one workgroup per replica (csrc/traj_small.hip)
-FUSED_MAX_ATOMS_LARGE = 16384   # multi-launch kernels (csrc/traj_large.hip), NoseHooverChain and NVE
+FUSED_MAX_ATOMS_LARGE = 32768   # multi-launch kernels (csrc/traj_large.hip), NoseHooverChain and NVE
 
 
 def compute_grad(inputs, output, create_graph=True, retain_graph=True):

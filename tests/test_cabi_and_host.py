@@ -224,7 +224,7 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     box = _lib.make_cell([16.9, 16.9, 16.9])
     assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(box), 2.62) == 1
     assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(box), 6.0) == 0                 # fewer than 3 bins per side
-    assert lib.mdg_rdf_cell_supported(20000, ctypes.byref(box), 2.62) == 0               # above 16 384 atoms
+    assert lib.mdg_rdf_cell_supported(40000, ctypes.byref(box), 2.62) == 0               # above 32 768 atoms
     tri = _lib.make_cell(torch.tensor([[16.9, 0, 0], [3.0, 16.9, 0], [0, 0, 16.9]]))
     assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(tri), 2.62) == 0                # orthorhombic cells only
     nb = int(16.9 // 2.62)
