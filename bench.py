@@ -1284,7 +1284,7 @@ def _compact(o, depth=0, cut=150):
     if isinstance(o, str) and len(o) > cut:
         return o[:cut - 3] + "..."
     if isinstance(o, float):
-        return float("%.6g" % o)
+        return o if depth <= 1 else float("%.9g" % o)     # (top-level figures exact: value = units / time to the last digit)
     return o
 
 

@@ -76,5 +76,5 @@ def test_compact_headline_drops_notes_and_keeps_every_contract_key():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in c
-    assert "note" not in c["roofline"] and len(c["cpu_baseline"]["sample"]) <= 150 and c["value"] == 1.23457e7
+    assert "note" not in c["roofline"] and len(c["cpu_baseline"]["sample"]) <= 150 and c["value"] == 1.23456789e7
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"])
