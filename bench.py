@@ -907,7 +907,7 @@ def build_water192(dev):
     return g, sd, prm, system, net, gnn, integ
 
 
-def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None):
+def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmup=None, bf16=False):
     """BASELINE config #3 / SURVEY 8d M3: SchNet A128/F128/G32/3 conv + ExcludedVolume prior on the 64-molecule water box,
     cutoff 5, NoseHooverChain, dt = 0.25 fs (the golden's), 20 steps forward + O-H RDF loss + analytic adjoint + Adam, one
     system per GPU (HIP-graph replay of the per-step launches), f32."""
@@ -916,6 +916,7 @@ def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmu
     steps = args.steps if steps is None else steps
     warmup = args.warmup if warmup is None else warmup
     g, sd, prm, system, net, gnn, integ = build_water192(dev)
+    net.filter_bf16 = bool(bf16)                          # (bf16 MFMA operands in the filter network: a reported variant)
     T = 21 if args.frames is None or args.workload != "water192" else args.frames
     dt = float(g["dt"])
     obs = rdf(system, nbins=40, r_range=(0.6, 5.0), index_tuple=(g["idx_O"].tolist(), g["idx_H"].tolist()))
@@ -974,7 +975,8 @@ def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmu
     sec_per_step = el / (steps * (T - 1))
     out = {"metric": "MD steps/sec (fwd+adjoint), 192-atom water SchNet NHC (BASELINE config #3)", "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 filter MFMA operands, f32 accumulate" if bf16 else "f32", "data": "synthetic",
            "config": {"workload": "64-molecule water box (192 atoms, golden G14 geometry), SchNet A%d F%d G%d %d conv + "
                                   "ExcludedVolume prior, cutoff 5, NoseHooverChain(Q=50, 5 chains), %d steps fwd + O-H RDF(40 "
                                   "bins) loss + analytic adjoint + Adam; one system per GPU, HIP-graph replay" % (A_, F_, G_, NC, T - 1),
@@ -1284,7 +1286,7 @@ def _compact(o, depth=0, cut=150):
     if isinstance(o, str) and len(o) > cut:
         return o[:cut - 3] + "..."
     if isinstance(o, float):
-        return o if depth <= 1 else float("%.9g" % o)     # (top-level figures exact: value = units / time to the last digit)
+        return o if depth <= 1 else float("%.7g" % o)     # (top-level figures exact: value = units / time to the last digit)
     return o
 
 
@@ -1294,11 +1296,11 @@ def _flat(name, rec):
         return {name + "_error": str((rec or {}).get("error"))[:140]}
     rl, cb = rec.get("roofline") or {}, rec.get("cpu_baseline") or {}
     par = cb.get("parity_sampled") or rec.get("config", {}).get("parity_reference_golden") or {}
+    # (the keys VERDICT r4 #1 names, + the parameter-gradient parity; the rest of a leg is in its own line)
     f = {name + "_md_steps_per_s": rec.get("value"), name + "_ms_per_pass": rec.get("ms_per_step"), name + "_dtype": rec.get("dtype"),
-         name + "_passes": rec.get("steps"), name + "_roofline_bound": rl.get("bound"), name + "_kernel_frac": rl.get("frac"),
-         name + "_step_roof_frac": (rl.get("step_roof") or {}).get("frac"), name + "_cpu_steps_per_s": cb.get("value"),
-         name + "_cpu_cores": cb.get("cores"), name + "_parity_max_abs_dq": par.get("max_abs_dq"),
-         name + "_parity_max_abs_dg": par.get("max_abs_dg"), name + "_parity_rel_dtheta": par.get("rel_dtheta")}
+         name + "_kernel_frac": rl.get("frac"), name + "_step_roof_frac": (rl.get("step_roof") or {}).get("frac"),
+         name + "_cpu_steps_per_s": cb.get("value"), name + "_parity_max_abs_dq": par.get("max_abs_dq"),
+         name + "_parity_rel_dtheta": par.get("rel_dtheta")}
     return {k: (float("%.6g" % v) if isinstance(v, float) else v) for k, v in f.items() if v is not None}
 
 
@@ -1319,12 +1321,12 @@ def _line(name, rec):
     par = cb.get("parity_sampled") or c.get("parity_reference_golden")
     if par:
         o["parity"] = {k: v for k, v in par.items() if k in ("max_abs_dq", "max_abs_dg", "rel_dtheta", "cos_dtheta", "replicas", "steps", "vs")}
-    for k in ("f32", "bf16_rows", "steps10", "single_system", "neighbour_list", "md_steps_per_s_traj_only_per_gpu"):
+    for k in ("f32", "bf16", "bf16_rows", "steps10", "single_system", "neighbour_list", "md_steps_per_s_traj_only_per_gpu"):
         if k in rec:
             o[k] = rec[k]
         elif k in c:
             o[k] = c[k]
-    return json.dumps(_compact(o, cut=120))
+    return json.dumps(_compact(o, cut=90))
 
 
 def _write_detail(out):
@@ -1441,6 +1443,13 @@ def main():
                     sec["schnet4096"]["bf16_rows"]["vs_f32"] = {k: v for k, v in (r16["config"].get("bf16_vs_f32") or {}).items() if k != "note"}
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["bf16_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if "error" not in sec["water192"]:
+                try:
+                    wb = run_water192(args, rank, world, dev, mdist, False, steps=20, warmup=4, bf16=True)
+                    sec["water192"]["bf16"] = {"value": wb["value"], "ms_per_step": wb["ms_per_step"],
+                                               "parity_reference_golden": {k: v for k, v in (wb["config"].get("parity_reference_golden") or {}).items() if k != "vs"}}
+                except (Exception, SystemExit) as e:
+                    sec["water192"]["bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
             out["secondary"] = sec
             pending, _DEFERRED = _DEFERRED, None
             for fn in pending:
@@ -1452,6 +1461,10 @@ def main():
             for name, rec in sec.items():
                 out["config"].update(_flat(name, rec))
                 lines.append(_line(name, rec))
+            wbf = (sec.get("water192") or {}).get("bf16") or {}
+            if "value" in wbf:
+                out["config"]["water192_bf16_md_steps_per_s"] = float("%.6g" % wbf["value"])
+                out["config"]["water192_bf16_parity_max_abs_dq"] = (wbf.get("parity_reference_golden") or {}).get("max_abs_dq")
             s4 = sec.get("schnet4096") or {}
             if "error" not in s4:
                 for k, tag in (("f32", "schnet4096_f32"), ("bf16_rows", "schnet4096_bf16rows"), ("steps10", "schnet4096_10step")):
@@ -1473,7 +1486,7 @@ def main():
             print(json.dumps(out), flush=True)
         else:
             head = {k: v for k, v in out.items() if k != "secondary"}
-            print(json.dumps(_compact(head)), flush=True)
+            print(json.dumps(_compact(head, cut=110)), flush=True)
     import torch.distributed as tdist
     if tdist.is_available() and tdist.is_initialized():
         mdist.barrier()

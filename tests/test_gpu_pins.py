@@ -909,6 +909,54 @@ def test_large_path_replica_groups_on_concurrent_streams_are_bitwise_the_single_
             assert torch.equal(a, b), nm
 
 
+def test_large_path_column_tiles_with_a_two_term_masked_stack_equal_fresh_searches_and_oracle():
+    """The generic (multi-term) instantiation of the column-tile launches (csrc/traj_large.hip large_fwd_tiled<-1> /
+    large_adj_tiled<-1>): a two-species LJ mixture -- an A-A term with cutoff 2.5 and an A-B LJ 9-6 term with cutoff 2.0, both
+    with selection masks (index_tuple, torchmd/topology.py:37-42) -- on 1 000 atoms in a binned box.  Stored lists reused
+    across steps (tiles, staged atom indices feed the masks) == a search at every evaluation (block = -1) == the oracle."""
+    from mdgrad_amd import ops, potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    pos, cell = liquid(10, seed=61, jitter=0.05)
+    rng = np.random.default_rng(161)
+    N = len(pos)
+    vel = rng.normal(0, 1.0, pos.shape).astype(np.float32)
+    mass = np.full(N, 1.008, dtype=np.float32)
+    A_, B_ = list(range(0, N, 2)), list(range(1, N, 2))
+    t = torch.Tensor([0.004 * i for i in range(9)])
+    system = mk_system(pos, cell, vel, mass)
+    m_aa, m_ab = P.LennardJones(1.0, 1.0), P.LennardJones69(0.9, 0.7)
+    stack = Stack({"aa": PairPotentials(system, m_aa, cutoff=2.5, index_tuple=(A_, A_)),
+                   "ab": PairPotentials(system, m_ab, cutoff=2.0, index_tuple=(A_, B_))})
+    integ = NoseHooverChain(stack, system, T=1.0, num_chains=3, Q=30.0).to(DEV)
+    integ.fused_large = True
+
+    def loss_fn(L):
+        return L[1][::4].pow(2).sum() / L[1][::4].numel() + L[0][-1].pow(2).sum() / (N * 3) + L[2][-1].sum() * 1e-3
+
+    res = []
+    for block in (0, -1):
+        spec = integ.fused_spec("NH_verlet")
+        assert spec is not None and spec.large
+        spec.block = block
+        y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
+        v_t, q_t, pv_t = ops.FusedTrajFn.apply(y0[0], y0[1], y0[2], t.to(DEV), spec.flat_params(), spec)
+        for m in (m_aa, m_ab):
+            m.zero_grad()
+        loss_fn((v_t, q_t, pv_t)).backward()
+        res.append([q_t.detach(), v_t.detach(), pv_t.detach(), y0[0].grad.clone(), y0[1].grad.clone(),
+                    torch.stack([p.grad.reshape(()) for m in (m_aa, m_ab) for p in m.parameters()])])
+    for a, b, nm in zip(res[0], res[1], ("q_t", "v_t", "pv_t", "adj v0", "adj q0", "dL/dtheta")):
+        close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-12, "%s (tiles vs searches, two masked terms)" % nm)
+    it_aa, it_ab = (A_, A_), (A_, B_)
+    terms = [O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1, index_tuple=it_aa),
+             O.PairTerm("lj", torch.tensor([0.9, 0.7]), 2.0, T(cell), p=9, q=6, c=1, index_tuple=it_ab)]
+    traj, lam, gth = oracle_run(pos, cell, vel, mass, terms, 1.0, 30.0, 3, t, loss_fn)
+    close(res[0][0], traj[1], 0, 1e-4, "q_t vs oracle")
+    close(res[0][5], gth, 5e-3, 5e-4 * float(gth.abs().max()), "dL/dtheta vs oracle")
+    close(res[0][4], lam[1], 5e-3, 1e-3 * float(lam[1].abs().max()) + 1e-9, "adj q0 vs oracle")
+
+
 @pytest.mark.parametrize("case", ["liquid4096", "crowded", "dilute", "tall_box"])
 def test_cell_sweep_rdf_column_tiles_equal_the_row_sweep_bitwise(case, monkeypatch):
     """Round 5: the cell-sweep RDF stages the 3 x 3 bin columns around a workgroup's column in LDS (csrc/rdf_cell.hip
