@@ -1,25 +1,22 @@
 // Fused trajectories for systems too large for one workgroup (BASELINE config #4: 4 096-atom
-// LJ liquid).  Same semantics as traj_small.hip (NoseHooverChain + NH-Verlet forward,
+// LJ liquid; 1 024 < N <= 32 768).  Same semantics as traj_small.hip (NoseHooverChain + NH-Verlet forward,
 // torchmd/sovlers.py:110-127 with RHS torchmd/md.py:210-240; adjoint sovlers.py:211-293 with the
-// backward branch :129-164), but the state lives in HBM/L2 and every step is TWO launches
+// backward branch :129-164), but the state lives in HBM/L2 and every step is a few launches
 // enqueued from a C++ host loop (no Python, no host sync):
 //
-//   prep       : one 1 024-thread workgroup per replica: first RHS (cached force) -> half kick, drift, bath half
-//                step; sums the per-block partials of the previous force launch; bins the new positions
-//   force_step : neighbour search + force (+HVP) + second half kick + frame store, fused:
-//                one wave per atom walks the 3 x 3 stencil columns of the bin-sorted positions (or, for cells the
-//                binning does not take, scans LDS-staged tiles of all positions) with the reference's
-//                minimum-image test, compacts the accepted neighbours into a per-wave LDS
-//                list (ordered ballot compaction -- the neighbour list never exists in HBM),
-//                then all 64 lanes evaluate the compact list and combine with wave shuffles.
-// The adjoint interval is FOUR launches (prep, force + HVP, prep, force + HVP), NHC or NVE.
-//
-// This reproduces topology_update_freq == 1 (pair set re-derived at every force evaluation).
-// Scalars that couple workgroups (kinetic energy, sum(lambda_v . v), parameter gradients)
-// travel as per-block partials and are summed in a fixed order by block 0 of the NEXT launch
-// ("launch-boundary reduce"): deterministic, no atomics, no grid barrier.
-// O(N^2) pair tests per evaluation: meant for N <= ~16k (launch-bound regime); above that the
-// generic path with the cell list applies.
+//   large_prep        between two force launches: the element-wise update of the integrator / adjoint that ends in the
+//                     positions of the next force evaluation, the cross-workgroup scalars of the previous force launch
+//                     (summed in a fixed order: "launch-boundary reduce" -- deterministic, no atomics, no grid barrier),
+//                     the thermostat chain, the Verlet-reuse decision and, when a search is due, the cell binning
+//   large_search_rows the force launch that SEARCHES (cell-binned, candidates at cutoff + skin stored per atom)
+//   large_fwd_tiled / large_adj_tiled     the force (+ Hessian.w + parameter vjp) launches over the STORED candidates,
+//                     exact cutoff re-applied (topology_update_freq = 1 semantics with a search every ~7 steps): a
+//                     workgroup owns one column of bins of the list's build and stages the 3 x 3 columns' state rows in
+//                     LDS (column tiles, round 5; large_*_listed: the same from L2 by atom index, for unbinned boxes)
+//   large_force_step / large_adj_force    search + evaluate at every call (boxes that cannot be binned, block = -1)
+// Forward step: three launches; adjoint interval: four, NHC or NVE.  The launches of a trajectory are issued for groups
+// of replicas on concurrent side streams (lg_streams, round 5): one group's latency-bound prep launches and tails overlap
+// another group's force sweep.
 #include "common.hpp"
 #pragma clang diagnostic ignored "-Wunused-result"
 
@@ -1469,7 +1466,7 @@ __device__ __forceinline__ void large_stage(const LargeArgs& A, const int32_t* _
 }
 
 // Second half of step k over the CURRENT list, column tiles.  grid (R, ncol): consecutive workgroups = consecutive
-// replicas, so the tiles of a replica run on one XCD (its L2 holds the replica's state copy and rows).
+// replicas, so the tiles of a replica run on one XCD (its L2 holds the replica's state rows and candidate rows).
 template <int KIND>
 __global__ __launch_bounds__(LG_TILE_THREADS) void large_fwd_tiled(const LargeArgs A) {
     constexpr int NP = LG_LIST / 16;
