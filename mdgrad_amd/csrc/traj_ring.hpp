@@ -80,7 +80,21 @@ struct RingRdf {
     uint32_t* hist; float inv_h, tlo, fmax;                 // RDF = 1: fine histogram [nfine], t = d inv_h + tlo < fmax
     const float4* tab; float ulo, inv_hu, tmax;             // RDF = 2: cell cubics of (dL/dd)/d in u = d^2, t = (d2 - ulo) inv_hu < tmax
                                                             // (fmax / tmax: end of the grid or the observable's cutoff)
+    // KIND_TABLE (round 5; the tabulated pair model of traj_small.hip force_table_packed -- pairMLP + prior stacks,
+    // scripts/fit_rdf_pair.py:355-368 -- register-resident): the nodes (c1_g, du dc1/du_g) of c1(u) = phi'(r)/r in LDS; the
+    // fixed-point planes of this replica's table gradient (value = HI 2^20 + LO, integer LDS atomics: order-independent) and
+    // the weight of the current evaluation's contributions (0: the evaluation does not accumulate, sovlers.py:160 / :82,101);
+    // tflag: LDS word, bit 1 = a live pair below the first node (forward), bit 2 = a contribution beyond 2^45 (adjoint)
+    const float2* ttab; int32_t* tghi; int32_t* tglo; int32_t* tflag; float tgw, tu0, tinv_du, ttmax;
 };
+
+__device__ __forceinline__ void ring_table_scatter(const RingRdf& X, int idx, float val) {
+    if (fabsf(val) >= 3.5e13f) *X.tflag = 4;                             // 2^45: out of the fixed-point range
+    const float hi = rintf(val * (1.f / 1048576.f));
+    const float lo = fmaf(hi, -1048576.f, val);
+    atomicAdd(X.tghi + idx, (int)hi);
+    atomicAdd(X.tglo + idx, (int)rintf(lo));
+}
 
 // One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
 // v0 / v1: both atoms of the pair in .x / .y exist.  JSIDE: also update the visitors' accumulators.
@@ -135,8 +149,30 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
         // per pair: c1 = phi'/r, kk = (phi'' - phi'/r)/r^2 and the parameter factors tk (dth_k += tk (w.D) per directed
         // pair) -- from the even-power polynomial for LJ 12-6, from pair_eval for every other form
         f32x2 c1, kk, tk[MDG_MAX_THETA];
-        constexpr int NTH = KIND == KIND_LJ126 ? 2 : kind_ntheta(KIND);
-        if constexpr (KIND == KIND_LJ126) {
+        constexpr int NTH = KIND == KIND_LJ126 ? 2 : (KIND == KIND_TABLE ? 0 : kind_ntheta(KIND));
+        f32x2 h00 = {0.f, 0.f}, h10 = h00, h01 = h00, h11 = h00;                      // (KIND_TABLE: Hermite basis of the pair's cell)
+        int g0 = 0, g1 = 0;
+        if constexpr (KIND == KIND_TABLE) {
+            // cubic Hermite in u = d^2 on the LDS-resident nodes: c1 = phi'/r, and (phi'' - phi'/r)/r^2 = 2 dc1/du from the
+            // derivative of the SAME interpolant (force and Hessian.w stay consistent) -- force_table_packed's arithmetic
+            const f32x2 sel = {ok0 ? 1.f : 0.f, ok1 ? 1.f : 0.f};
+            if constexpr (LEVEL == 1) {
+                if ((ok0 && d2.x < X.tu0) || (ok1 && d2.y < X.tu0)) *X.tflag = 2;  // below the first node: the host raises
+            }
+            f32x2 tt = (d2 - X.tu0) * X.tinv_du;
+            tt.x = fminf(fmaxf(ok0 ? tt.x : 0.f, 0.f), X.ttmax); tt.y = fminf(fmaxf(ok1 ? tt.y : 0.f, 0.f), X.ttmax);
+            g0 = (int)tt.x; g1 = (int)tt.y;
+            const f32x2 fr = {tt.x - (float)g0, tt.y - (float)g1};
+            const float2 a0 = X.ttab[g0], b0 = X.ttab[g0 + 1], a1 = X.ttab[g1], b1 = X.ttab[g1 + 1];
+            const f32x2 v0 = {a0.x, a1.x}, s0 = {a0.y, a1.y}, v1 = {b0.x, b1.x}, s1 = {b0.y, b1.y};
+            const f32x2 om = 1.f - fr, fr2 = fr * fr, om2 = om * om;
+            h00 = (1.f + 2.f * fr) * om2; h10 = fr * om2; h01 = fr2 * (3.f - 2.f * fr); h11 = fr2 * (fr - 1.f);
+            c1 = (h00 * v0 + h10 * s0 + h01 * v1 + h11 * s1) * sel;
+            if constexpr (LEVEL >= 2) {
+                const f32x2 e00 = 6.f * fr * (fr - 1.f), e10 = (3.f * fr - 4.f) * fr + 1.f, e11 = (3.f * fr - 2.f) * fr;
+                kk = (2.f * (e00 * (v0 - v1) + e10 * s0 + e11 * s1)) * (X.tinv_du * sel);
+            }
+        } else if constexpr (KIND == KIND_LJ126) {
             // 1/d2 selected to 0 for a rejected pair: s6, s12 and everything below are then exactly zero
             const f32x2 i2 = {ok0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, ok1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
             const f32x2 s2 = K.sig2 * i2;
@@ -183,6 +219,21 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
             }
 #pragma unroll
             for (int k = 0; k < NTH; ++k) TH[k] += tk[k] * b;
+            if constexpr (KIND == KIND_TABLE) {
+                // table gradient: d(w.F)/dnode += 1/2 (D.w_ij) basis per DIRECTED pair (tgw carries 1/2 h 2^S); a ring step
+                // meets an undirected pair once and stands for both directions
+                if (X.tgw != 0.f) {
+                    const f32x2 x = (X.tgw * (JSIDE ? 2.f : 1.f)) * b;
+                    if (ok0) {
+                        ring_table_scatter(X, 2 * g0, x.x * h00.x); ring_table_scatter(X, 2 * g0 + 1, x.x * h10.x);
+                        ring_table_scatter(X, 2 * g0 + 2, x.x * h01.x); ring_table_scatter(X, 2 * g0 + 3, x.x * h11.x);
+                    }
+                    if (ok1) {
+                        ring_table_scatter(X, 2 * g1, x.y * h00.y); ring_table_scatter(X, 2 * g1 + 1, x.y * h10.y);
+                        ring_table_scatter(X, 2 * g1 + 2, x.y * h01.y); ring_table_scatter(X, 2 * g1 + 3, x.y * h11.y);
+                    }
+                }
+            }
         }
     }
 }
@@ -427,6 +478,17 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
     uint32_t* hist = reinterpret_cast<uint32_t*>(smr);
     f32x2* lds = reinterpret_cast<f32x2*>(smr + nf2) + wid * 3 * 64;
     RingRdf X{};
+    if constexpr (KIND == KIND_TABLE) {
+        // (one wave per workgroup: the unfused launch) the nodes of the tabulated pair model, behind the wave's ring buffers
+        const MdgPairTerm& t0 = A.terms.t[0];
+        float2* ttab = reinterpret_cast<float2*>(smr + nf2 + nw * 3 * 64 * 2);
+        int32_t* tflag = reinterpret_cast<int32_t*>(ttab + t0.p);
+        const float* thp = A.theta + t0.theta_off;
+        for (int g = threadIdx.x; g < t0.p; g += blockDim.x) ttab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
+        if (threadIdx.x == 0) *tflag = 0;
+        X.ttab = ttab; X.tflag = tflag; X.tu0 = t0.a; X.tinv_du = 1.f / t0.phi; X.ttmax = (float)(t0.p - 1) - 1e-3f;
+        __syncthreads();
+    }
     if constexpr (RDF) {
         for (int m = threadIdx.x; m < F.nfine; m += blockDim.x) hist[m] = 0u;
         __syncthreads();
@@ -493,7 +555,15 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
         }
         if (A.nonfinite) {
             const bool bad = !(isfinite(hsum(q.x + q.y + q.z)) && isfinite(hsum(v.x + v.y + v.z)));
-            if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) A.nonfinite[rep] = 1;
+            int below = 0;
+            if constexpr (KIND == KIND_TABLE) {                           // (bit 1: a live pair below the table's first node)
+                ring_lds_fence();
+                below = *X.tflag;
+                ring_lds_fence();
+                if (lane == 0) *X.tflag = 0;
+            }
+            const int nf = __builtin_amdgcn_ballot_w64(bad) != 0 ? 1 : 0;
+            if ((nf | below) && lane == 0) A.nonfinite[rep] = nf | below;
         }
     }
     if constexpr (RDF) {
@@ -510,7 +580,9 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
 template <int KIND>
 __device__ __forceinline__ void ring_theta(const RingLJ& K, const float (&th)[MDG_MAX_THETA], float (&gth)[MDG_MAX_THETA],
                                            float h, bool nve) {
-    if constexpr (KIND == KIND_LJ126) {
+    if constexpr (KIND == KIND_TABLE) {
+        // (the table gradient is scattered by the sweep itself)
+    } else if constexpr (KIND == KIND_LJ126) {
         const float t6 = wave_sum(th[0]), t12 = wave_sum(th[1]);
         const float gs = K.tsa * t6 - K.tsb * t12, ge = K.tea * t6 - K.teb * t12;
         gth[0] += nve ? (gs * 0.5f * h) * 2.f : gs * h;
@@ -550,6 +622,21 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         __syncthreads();
     }
     f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell);
+    if constexpr (KIND == KIND_TABLE) {
+        // the nodes and this replica's two gradient planes behind the ring buffers (6 x 64 f32x2)
+        const MdgPairTerm& t0 = A.terms.t[0];
+        float2* ttab = reinterpret_cast<float2*>(smr + 4 * ncell + 6 * 64 * 2);
+        int32_t* thi = reinterpret_cast<int32_t*>(ttab + t0.p);
+        int32_t* tlo = thi + 2 * t0.p;
+        int32_t* tflag = tlo + 2 * t0.p;
+        const float* thp = A.theta + t0.theta_off;
+        for (int g = lane; g < t0.p; g += 64) ttab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
+        for (int g = lane; g < 2 * t0.p; g += 64) { thi[g] = 0; tlo[g] = 0; }
+        if (lane == 0) *tflag = 0;
+        X.ttab = ttab; X.tghi = thi; X.tglo = tlo; X.tflag = tflag; X.tgw = 0.f;
+        X.tu0 = t0.a; X.tinv_du = 1.f / t0.phi; X.ttmax = (float)(t0.p - 1) - 1e-3f;
+        __syncthreads();
+    }
     const size_t fr = (size_t)rep * T;
     f32x2 ms = {1.f, 1.f};
     if (2 * lane < N) ms.x = A.mass[2 * lane];
@@ -573,6 +660,9 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         // ---------------- first augmented evaluation at (y_i, lam)
         if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
         const bool with_rdf = RDF && ring_frame_selected(F, i);
+        // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC, sovlers.py:160, and
+        //  from this first one for NVE, :82,101 -- both with total weight h)
+        if constexpr (KIND == KIND_TABLE) X.tgw = nhc ? 0.f : 0.5f * h * A.terms.t[0].c;
         ring_force<2, RDF ? 2 : 0, KIND, MASK>(K, X, M, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
         if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
@@ -598,6 +688,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             pv = pv + 0.5f * (-pb) * h;                               // :135
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
+            if constexpr (KIND == KIND_TABLE) X.tgw = 0.5f * h * A.terms.t[0].c;
             ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, w, f, dq, th, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
@@ -630,6 +721,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             }
             MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
 #undef MDG_RING_NVE
+            if constexpr (KIND == KIND_TABLE) X.tgw = 0.f;
             ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, lvh, f, dq, th, ru, lds);
             const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
             const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
@@ -651,6 +743,20 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
     ring_store(A.adj_v0 + (size_t)rep * N3, lv, N, lane);
     ring_store(A.adj_q0 + (size_t)rep * N3, lq, N, lane);
     if (nhc && lane < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + lane] = lp;
+    if constexpr (KIND == KIND_TABLE) {
+        // table gradient: fixed point -> float; an out-of-range contribution poisons the output (the host re-scales and
+        // reports it), as in traj_adj_kernel
+        ring_lds_fence();
+        if (A.adj_theta) {
+            const int M2 = 2 * A.terms.t[0].p;
+            const bool worst = (*X.tflag & 4) != 0;
+            const double inv = 1.0 / (double)A.terms.t[0].c;
+            float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
+            for (int g = lane; g < M2; g += 64)
+                out[g] = worst ? __builtin_inff() : (float)(((double)X.tghi[g] * 1048576.0 + (double)X.tglo[g]) * inv);
+        }
+        return;
+    }
     if (lane == 0 && A.adj_theta) {
         float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
 #pragma unroll

@@ -856,11 +856,19 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 // ------------------------------------------------------------------------------------ launch
 // wave-per-replica kernels (traj_ring.hpp): one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and either
 // asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
+constexpr int RING_TABLE_MAX_NODES = 2048;     // 6 x 2048 x 4 B = 48 KB of LDS per adjoint wave: three waves per CU
+
 bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
     // one unmasked built-in pair form (LJ 12-6 / ExcludedVolume(12) on the even-power polynomial, the others through
     // pair_eval) in an orthorhombic cell
     // (a selection mask -- index_tuple / ex_pairs -- is taken for the LJ family: MDG_RING_LAUNCH)
+    // (round 5: the tabulated pair model -- pairMLP + prior stacks -- up to RING_TABLE_MAX_NODES nodes: the nodes and the
+    //  replica's gradient planes sit in LDS beside the wave's ring buffers)
+    if (t.kind == MDG_PAIR_TABLE) {
+        const char* e = getenv("MDG_RING_TABLE");                        // (=0: the one-workgroup-per-replica kernels; A/B)
+        return !(e && e[0] == '0') && terms.n_terms == 1 && cell.diag && !t.mask && t.p <= RING_TABLE_MAX_NODES && p.n_atoms <= 128;
+    }
     return terms.n_terms == 1 && cell.diag && (!t.mask || t.kind == MDG_PAIR_LJ) && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA &&
            p.n_atoms <= 128;
 }
@@ -868,7 +876,13 @@ bool use_ring(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms
     return ring_form(p, cell, terms) && (p.block == 64 || (p.block == 0 && p.n_rep >= 1024));
 }
 int ring_kind(const MdgPairTerm& t) {
+    if (t.kind == MDG_PAIR_TABLE) return KIND_TABLE;
     return (t.kind == MDG_PAIR_LJ && t.p == 12 && (t.q == 6 || t.c == 0.f)) ? KIND_LJ126 : t.kind;
+}
+// LDS of the tabulated kind behind a wave's ring buffers: the nodes (forward) + two int32 gradient planes (adjoint) + a flag word
+size_t ring_table_lds(const MdgTerms& terms, bool adjoint) {
+    if (terms.t[0].kind != MDG_PAIR_TABLE) return 0;
+    return sizeof(float) * (size_t)(adjoint ? 6 : 2) * terms.t[0].p + 16;
 }
 // launch of a ring kernel specialised on the pair form
 #define MDG_RING_LAUNCH(KERNEL, RDF_, grid, block, lds, st, ...)                                              \
@@ -883,6 +897,7 @@ int ring_kind(const MdgPairTerm& t) {
             if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ, true>), grid, block, lds, st, __VA_ARGS__);        \
             else hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ>), grid, block, lds, st, __VA_ARGS__);                      \
             break;                                                                                            \
+        case KIND_TABLE: hipLaunchKernelGGL((KERNEL<false, KIND_TABLE>), grid, block, lds, st, __VA_ARGS__); break;     \
         case MDG_PAIR_MORSE: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_MORSE>), grid, block, lds, st, __VA_ARGS__); break; \
         case MDG_PAIR_BUCK: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_BUCK>), grid, block, lds, st, __VA_ARGS__); break;  \
         default: hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_YUKAWA>), grid, block, lds, st, __VA_ARGS__); break;          \
@@ -897,6 +912,7 @@ constexpr int RING_RDF_MAX_CELLS = 1088;                     // derivative table
 // the fused RDF observable: fine-grid plan (csrc/rdf.hip) + what fits beside the kernels' own LDS
 bool ring_rdf_plan(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms, const MdgRdfFuse* rdf, RdfFinePlan* plan) {
     if (!rdf || !rdf->mu || !use_ring(p, cell, terms)) return false;     // (only where the ring kernels run anyway)
+    if (terms.t[0].kind == MDG_PAIR_TABLE) return false;                 // (the tabulated kind keeps the separate observable kernels)
     if (rdf->frame_stride < 1 || rdf->frame_start < 0 || !(rdf->cutoff > 0.f)) return false;
     const RdfFinePlan P = mdg_rdf_fine_plan(rdf->spacing, rdf->coeff, rdf->nbins);
     if (P.nfine <= 0 || P.ncell <= 0 || P.ncell > RING_RDF_MAX_CELLS) return false;
@@ -997,7 +1013,8 @@ extern "C" int mdg_traj_fwd_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
         MDG_CHECK_ARG(theta || terms->n_theta_total == 0, "traj_fwd: null theta");
-        MDG_RING_LAUNCH(traj_fwd_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_FWD, (hipStream_t)stream, a, RingRdfArgs{});
+        MDG_RING_LAUNCH(traj_fwd_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_FWD + ring_table_lds(*terms, false),
+                        (hipStream_t)stream, a, RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_fwd_ring_kernel");
         return MDG_OK;
     }
@@ -1034,7 +1051,8 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
         MDG_CHECK_ARG(theta || terms->n_theta_total == 0, "traj_adj: null theta");
-        MDG_RING_LAUNCH(traj_adj_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ, (hipStream_t)stream, a, RingRdfArgs{});
+        MDG_RING_LAUNCH(traj_adj_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ + ring_table_lds(*terms, true),
+                        (hipStream_t)stream, a, RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_adj_ring_kernel");
         return MDG_OK;
     }
