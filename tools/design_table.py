@@ -22,7 +22,7 @@ rows = [
        c["schnet4096_bf16rows_md_steps_per_s"], c["schnet4096_ms_per_pass"], c["schnet4096_step_roof_frac"],
        c["schnet4096_f32_step_roof_frac"], c["schnet4096_kernel_frac"], c["schnet4096_cpu_steps_per_s"],
        c["schnet4096_parity_max_abs_dq"], c["schnet4096_parity_rel_dtheta"]),
-    "| `lj4096`: 64 × 4 096-atom LJ liquid, 50 steps + RDF every 5th frame + adjoint (config #4) | 154.9 k (driver) | **%.1f k steps/s** (187–196 k from box to box) | %.2f ms | B_step over the step time: %.3f of HBM — the pass is VALU-issue bound, see below | %.2f | last replica of the timed launch, 2 steps: \\|Δq\\| %.1e, Δθ %.1e |"
+    "| `lj4096`: 64 × 4 096-atom LJ liquid, 50 steps + RDF every 5th frame + adjoint (config #4) | 154.9 k (driver) | **%.1f k steps/s** (182–196 k from box to box) | %.2f ms | B_step over the step time: %.3f of HBM — the pass is VALU-issue bound, see below | %.2f | last replica of the timed launch, 2 steps: \\|Δq\\| %.1e, Δθ %.1e |"
     % (c["lj4096_md_steps_per_s"] / 1e3, c["lj4096_ms_per_pass"], c["lj4096_kernel_frac"], c["lj4096_cpu_steps_per_s"],
        c["lj4096_parity_max_abs_dq"], c["lj4096_parity_rel_dtheta"]),
     "| `water192`: config #3, SchNet A128 F128 G32 3 conv + prior, one system, f32, graph replay | — (no leg) | **%.0f steps/s** | %.1f ms (20 steps) | %.3f of f32 MFMA (launch floor) | %.1f | vs the REFERENCE's own run (golden G14): \\|Δq\\| %.1e Å, Δθ %.1e |"
