@@ -193,7 +193,8 @@ int mdg_pair_eval_ell_into(const float* pos, int n_atoms, const MdgCell* cell /*
  * adjoint  (replaces OdeintAdjointMethod.backward: torchmd/sovlers.py:211-293 with the
  *           backward branches :129-164 / :42-101)
  *   g_* are dL/d(frames) (any may be NULL = zeros); outputs adj_v0,adj_q0 [R,N,3],
- *   adj_pv0 [R,C], adj_theta [R,K] (sum over R on the caller's side).
+ *   adj_pv0 [R,C], adj_theta [R,K] (sum over R on the caller's side; for an MDG_PAIR_TABLE term only that sum is
+ *   defined: the wave-per-replica kernels hand the table gradient of eight replicas to the first one's row).
  * nonfinite (optional int32[R]): set to 1 for replicas whose state became non-finite.
  */
 typedef struct MdgTrajParams {

@@ -88,12 +88,25 @@ struct RingRdf {
     const float2* ttab; int32_t* tghi; int32_t* tglo; int32_t* tflag; float tgw, tu0, tinv_du, ttmax;
 };
 
-__device__ __forceinline__ void ring_table_scatter(const RingRdf& X, int idx, float val) {
-    if (fabsf(val) >= 3.5e13f) *X.tflag = 4;                             // 2^45: out of the fixed-point range
-    const float hi = rintf(val * (1.f / 1048576.f));
-    const float lo = fmaf(hi, -1048576.f, val);
-    atomicAdd(X.tghi + idx, (int)hi);
-    atomicAdd(X.tglo + idx, (int)rintf(lo));
+// Two ADJACENT plane words (idx even: a node's value and slope entries) in ONE 64-bit LDS atomic per plane: the sum of
+// (a + b 2^32) over the contributions is (sum a) + (sum b) 2^32 as a 64-bit integer, and as long as sum a stays inside int32 --
+// the range every plane word has to stay in anyway -- the two sums are read back exactly (low word signed; the rest / 2^32).
+// Halves the atomic instructions of the scatter: the LDS atomic unit, shared by the waves of a CU, bounds the accumulating
+// evaluation of the tabulated kind.
+__device__ __forceinline__ void ring_table_scatter2(const RingRdf& X, int idx, float va, float vb) {
+    if (fmaxf(fabsf(va), fabsf(vb)) >= 3.5e13f) *X.tflag = 4;             // 2^45: out of the fixed-point range
+    const float ha = rintf(va * (1.f / 1048576.f)), hb = rintf(vb * (1.f / 1048576.f));
+    const int la = (int)rintf(fmaf(ha, -1048576.f, va)), lb = (int)rintf(fmaf(hb, -1048576.f, vb));
+    const unsigned long long ph = (unsigned long long)(long long)(int)ha + ((unsigned long long)(long long)(int)hb << 32);
+    const unsigned long long pl = (unsigned long long)(long long)la + ((unsigned long long)(long long)lb << 32);
+    atomicAdd(reinterpret_cast<unsigned long long*>(X.tghi + idx), ph);
+    atomicAdd(reinterpret_cast<unsigned long long*>(X.tglo + idx), pl);
+}
+// (read-back of the word pair at even idx: -> the two int32 sums)
+__device__ __forceinline__ void ring_table_unpack(const int32_t* plane, int idx, int& a, int& b) {
+    const long long w = *reinterpret_cast<const long long*>(plane + idx);
+    a = (int)(w & 0xffffffffll);
+    b = (int)((w - (long long)a) >> 32);
 }
 
 // One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
@@ -225,12 +238,12 @@ __device__ __forceinline__ void ring_pair(const RingLJ& K, const RingRdf& X, con
                 if (X.tgw != 0.f) {
                     const f32x2 x = (X.tgw * (JSIDE ? 2.f : 1.f)) * b;
                     if (ok0) {
-                        ring_table_scatter(X, 2 * g0, x.x * h00.x); ring_table_scatter(X, 2 * g0 + 1, x.x * h10.x);
-                        ring_table_scatter(X, 2 * g0 + 2, x.x * h01.x); ring_table_scatter(X, 2 * g0 + 3, x.x * h11.x);
+                        ring_table_scatter2(X, 2 * g0, x.x * h00.x, x.x * h10.x);
+                        ring_table_scatter2(X, 2 * g0 + 2, x.x * h01.x, x.x * h11.x);
                     }
                     if (ok1) {
-                        ring_table_scatter(X, 2 * g1, x.y * h00.y); ring_table_scatter(X, 2 * g1 + 1, x.y * h10.y);
-                        ring_table_scatter(X, 2 * g1 + 2, x.y * h01.y); ring_table_scatter(X, 2 * g1 + 3, x.y * h11.y);
+                        ring_table_scatter2(X, 2 * g1, x.y * h00.y, x.y * h10.y);
+                        ring_table_scatter2(X, 2 * g1 + 2, x.y * h01.y, x.y * h11.y);
                     }
                 }
             }
@@ -600,12 +613,22 @@ __device__ __forceinline__ void ring_theta(const RingLJ& K, const float (&th)[MD
 // RDF = true: the frame gradients of the fused observable are produced here -- in the first augmented evaluation
 // of interval i (which sits at frame i) for frames T-1 .. 1, and in one geometry-only sweep for frame 0 -- and
 // added to lam_q where the adjoint adds the incoming g_q (sovlers.py:249, :286).
+// KIND_TABLE: RING_TABLE_WAVES replicas (one wave each) per workgroup share the nodes AND one pair of gradient planes --
+// per-wave planes (24 KB at 1 024 nodes) would leave five waves per CU where the registers allow eight.  The workgroup's
+// table gradient goes to the adj_theta row of its first replica, the rows of its other replicas are zero: only the sum over
+// replicas of a tabulated kind's rows is defined (what the caller forms, ops.FusedTrajFn.backward).
+constexpr int RING_TABLE_WAVES = 8;
+
 template <bool RDF, int KIND, bool MASK = false>
-__global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
+__global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
-    const int rep = blockIdx.x, lane = threadIdx.x, N3 = 3 * N;
+    constexpr int NWV = KIND == KIND_TABLE ? RING_TABLE_WAVES : 1;
+    const int wid = KIND == KIND_TABLE ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & 63, N3 = 3 * N;
+    // (a wave beyond the last replica of the last workgroup repeats the last replica without accumulating or storing)
+    const bool live = blockIdx.x * NWV + wid < A.prm.n_rep;
+    const int rep = live ? blockIdx.x * NWV + wid : A.prm.n_rep - 1;
     const RingLJ K = ring_constants(A);
     RingMask M{};
     if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
@@ -621,18 +644,18 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         X.tmax = fminf((float)ncell, (F.rc * F.rc - X.ulo) * X.inv_hu);
         __syncthreads();
     }
-    f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell);
+    f32x2* lds = reinterpret_cast<f32x2*>(smr + 4 * ncell) + wid * 6 * 64;
     if constexpr (KIND == KIND_TABLE) {
-        // the nodes and this replica's two gradient planes behind the ring buffers (6 x 64 f32x2)
+        // the nodes and the workgroup's two gradient planes behind the waves' ring buffers (6 x 64 f32x2 each)
         const MdgPairTerm& t0 = A.terms.t[0];
-        float2* ttab = reinterpret_cast<float2*>(smr + 4 * ncell + 6 * 64 * 2);
+        float2* ttab = reinterpret_cast<float2*>(smr + 4 * ncell + NWV * 6 * 64 * 2);
         int32_t* thi = reinterpret_cast<int32_t*>(ttab + t0.p);
         int32_t* tlo = thi + 2 * t0.p;
         int32_t* tflag = tlo + 2 * t0.p;
         const float* thp = A.theta + t0.theta_off;
-        for (int g = lane; g < t0.p; g += 64) ttab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
-        for (int g = lane; g < 2 * t0.p; g += 64) { thi[g] = 0; tlo[g] = 0; }
-        if (lane == 0) *tflag = 0;
+        for (int g = threadIdx.x; g < t0.p; g += blockDim.x) ttab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
+        for (int g = threadIdx.x; g < 2 * t0.p; g += blockDim.x) { thi[g] = 0; tlo[g] = 0; }
+        if (threadIdx.x == 0) *tflag = 0;
         X.ttab = ttab; X.tghi = thi; X.tglo = tlo; X.tflag = tflag; X.tgw = 0.f;
         X.tu0 = t0.a; X.tinv_du = 1.f / t0.phi; X.ttmax = (float)(t0.p - 1) - 1e-3f;
         __syncthreads();
@@ -662,7 +685,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
         const bool with_rdf = RDF && ring_frame_selected(F, i);
         // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC, sovlers.py:160, and
         //  from this first one for NVE, :82,101 -- both with total weight h)
-        if constexpr (KIND == KIND_TABLE) X.tgw = nhc ? 0.f : 0.5f * h * A.terms.t[0].c;
+        if constexpr (KIND == KIND_TABLE) X.tgw = (nhc || !live) ? 0.f : 0.5f * h * A.terms.t[0].c;
         ring_force<2, RDF ? 2 : 0, KIND, MASK>(K, X, M, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
         if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
@@ -688,7 +711,7 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             pv = pv + 0.5f * (-pb) * h;                               // :135
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
-            if constexpr (KIND == KIND_TABLE) X.tgw = 0.5f * h * A.terms.t[0].c;
+            if constexpr (KIND == KIND_TABLE) X.tgw = live ? 0.5f * h * A.terms.t[0].c : 0.f;
             ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, w, f, dq, th, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
@@ -740,20 +763,32 @@ __global__ __launch_bounds__(64) void traj_adj_ring_kernel(const TrajArgs A, con
             lq.x += rq.x; lq.y += rq.y; lq.z += rq.z;
         }
     }
-    ring_store(A.adj_v0 + (size_t)rep * N3, lv, N, lane);
-    ring_store(A.adj_q0 + (size_t)rep * N3, lq, N, lane);
-    if (nhc && lane < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + lane] = lp;
+    if (live) {
+        ring_store(A.adj_v0 + (size_t)rep * N3, lv, N, lane);
+        ring_store(A.adj_q0 + (size_t)rep * N3, lq, N, lane);
+        if (nhc && lane < C && A.adj_pv0) A.adj_pv0[(size_t)rep * C + lane] = lp;
+    }
     if constexpr (KIND == KIND_TABLE) {
-        // table gradient: fixed point -> float; an out-of-range contribution poisons the output (the host re-scales and
-        // reports it), as in traj_adj_kernel
-        ring_lds_fence();
+        // table gradient of the workgroup's replicas: fixed point -> float into the row of its first replica (zeros into
+        // the others'); an out-of-range contribution poisons the output (the host re-scales and reports it), as in
+        // traj_adj_kernel
+        __syncthreads();
         if (A.adj_theta) {
-            const int M2 = 2 * A.terms.t[0].p;
+            const int M2 = 2 * A.terms.t[0].p, KT = A.terms.n_theta_total;
             const bool worst = (*X.tflag & 4) != 0;
             const double inv = 1.0 / (double)A.terms.t[0].c;
-            float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
-            for (int g = lane; g < M2; g += 64)
-                out[g] = worst ? __builtin_inff() : (float)(((double)X.tghi[g] * 1048576.0 + (double)X.tglo[g]) * inv);
+            float* out = A.adj_theta + (size_t)(blockIdx.x * NWV) * KT + A.terms.t[0].theta_off;
+            for (int g = 2 * threadIdx.x; g < M2; g += 2 * blockDim.x) {
+                int ha, hb, la, lb;
+                ring_table_unpack(X.tghi, g, ha, hb);
+                ring_table_unpack(X.tglo, g, la, lb);
+                out[g] = worst ? __builtin_inff() : (float)(((double)ha * 1048576.0 + (double)la) * inv);
+                out[g + 1] = worst ? __builtin_inff() : (float)(((double)hb * 1048576.0 + (double)lb) * inv);
+            }
+            if (wid > 0 && live) {
+                float* mine = A.adj_theta + (size_t)rep * KT + A.terms.t[0].theta_off;
+                for (int g = lane; g < M2; g += 64) mine[g] = 0.f;
+            }
         }
         return;
     }

@@ -1051,8 +1051,11 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
     const int N = prm->n_atoms;
     if (use_ring(*prm, *cell, *terms)) {
         MDG_CHECK_ARG(theta || terms->n_theta_total == 0, "traj_adj: null theta");
-        MDG_RING_LAUNCH(traj_adj_ring_kernel, false, dim3(prm->n_rep), dim3(64), RING_LDS_ADJ + ring_table_lds(*terms, true),
-                        (hipStream_t)stream, a, RingRdfArgs{});
+        // (tabulated kind: RING_TABLE_WAVES replicas per workgroup share the nodes and one pair of gradient planes)
+        const bool rt = terms->t[0].kind == MDG_PAIR_TABLE;
+        const int wpw = rt ? RING_TABLE_WAVES : 1;
+        MDG_RING_LAUNCH(traj_adj_ring_kernel, false, dim3((prm->n_rep + wpw - 1) / wpw), dim3(64 * wpw),
+                        wpw * RING_LDS_ADJ + ring_table_lds(*terms, true), (hipStream_t)stream, a, RingRdfArgs{});
         MDG_CHECK_LAUNCH("traj_adj_ring_kernel");
         return MDG_OK;
     }
