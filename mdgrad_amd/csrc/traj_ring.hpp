@@ -627,8 +627,9 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
     constexpr int NWV = KIND == KIND_TABLE ? RING_TABLE_WAVES : 1;
     const int wid = KIND == KIND_TABLE ? (int)(threadIdx.x >> 6) : 0, lane = threadIdx.x & 63, N3 = 3 * N;
     // (a wave beyond the last replica of the last workgroup repeats the last replica without accumulating or storing)
-    const bool live = blockIdx.x * NWV + wid < A.prm.n_rep;
-    const int rep = live ? blockIdx.x * NWV + wid : A.prm.n_rep - 1;
+    // (the other kinds launch one wave per replica: `live` is a compile-time true there, the code of round 4)
+    const bool live = KIND != KIND_TABLE || (int)(blockIdx.x * NWV + wid) < A.prm.n_rep;
+    const int rep = KIND != KIND_TABLE ? (int)blockIdx.x : (live ? (int)(blockIdx.x * NWV + wid) : A.prm.n_rep - 1);
     const RingLJ K = ring_constants(A);
     RingMask M{};
     if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
