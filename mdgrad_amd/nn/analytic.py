@@ -41,6 +41,18 @@ def _ssp(x):
     return torch.nn.functional.softplus(x) - _LN2
 
 
+_warned = set()
+
+
+def _warn_once(key, msg):
+    """The library-GEMM fallbacks announce themselves once per process: nobody should time them as the
+    product's hand-written path by accident."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn("mdgrad_amd.nn.analytic: " + msg, RuntimeWarning, stacklevel=3)
+
+
 def _addmm(bias, x, wt):
     """x @ wt + bias without the hipBLASLt epilogue path (see _blas_for)."""
     return x.mm(wt).add_(bias)
@@ -318,6 +330,8 @@ def _dense(W, x0, trans=False, bias=None, act=False, mul=None, res=None, x1=None
     weight chunk (k > 256) go through the library GEMM with the same epilogue in torch ops."""
     if x0.shape[1] <= ops.DENSE_MAX_K and x0.is_cuda:
         return ops.dense(W, x0, trans, bias, act, mul, res, x1, res1, want_sig)
+    _warn_once("dense_k", "a node-level layer with %d input features (> %d) runs on the library GEMM (rocBLAS / hipBLASLt) with "
+               "torch epilogues, not on the MFMA node kernel of csrc/dense.hip" % (x0.shape[1], ops.DENSE_MAX_K))
     B = W if trans else W.t()
     z0 = x0.mm(B)
     if bias is not None:
@@ -584,6 +598,23 @@ def _chain_ok(net):
     return ops.RowChain.supported(*ws)
 
 
+class _FlatAcc:
+    """What mdg_grad_jobs needs of an accumulator: a flat f32 buffer, no interval weights."""
+
+    def __init__(self, n, dev):
+        self.flat, self.t, self.idx = torch.empty(n, device=dev, dtype=torch.float32), None, None
+
+
+def _head_energy(act, L2, l2):
+    """sum over atoms of (L2 . act_n + l2) for the readout's last layer (nff/nn/utils.py:56-75, one output)."""
+    acc = _FlatAcc(act.shape[1], act.device)
+    jobs = ops.GradJobs()
+    jobs.colsum(0, act)
+    jobs.run(acc, alpha=1.0, accumulate=False)
+    U = (L2.detach() * acc.flat).sum()                              # ([out, A / 2] * [A / 2]: every output row, as .sum() of the layer)
+    return U + act.shape[0] * l2.detach().sum() if l2 is not None else U
+
+
 def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     """Primal (+ tangent along w) sweep and the turn at the readout: -> (fw, adjoints entering the last block's
     aggregation).  With w = None: first order (the force), one row per atom instead of a dual pair."""
@@ -628,8 +659,9 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     y = turn["y"]
     U = None                                                        # (the integrators only ask for forces)
     if want_energy:
-        with _node_blas():                                          # (the one library GEMM of this path)
-            U = (y.pre0.mm(L2.t()) + l2).sum()
+        # U = sum_n (L2 . ssp(y_n) + l2): the column sums of the head stage's activations on the reduction kernel of
+        # csrc/gradjobs.hip (fixed order), then a dot product over A / 2 numbers -- no library GEMM on the chained path
+        U = _head_energy(y.pre0, L2, l2)
     fw = dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=y.sig, syd=y.pre1, L1=L1, L2=L2, U=U)
     return fw, turn
 
@@ -739,6 +771,12 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
     return fw["U"], F, dwf, acc.views()
 
 
+_UNFUSED_MSG = ("this network's shapes are outside the fused interaction-block kernels (n_gaussians > 64, or n_filters above 128 "
+                "that is not a multiple of 128 / above 512, or SchNet.fused_block = False): the filter network and the edge-level "
+                "products run as library GEMMs (rocBLAS / hipBLASLt) on [E, G] / [E, F] tensors in HBM -- correct, several "
+                "times slower than csrc/cfconv_fused.hip")
+
+
 @torch.no_grad()
 def force(net, z, x, topo, offsets=None, want_energy=True):
     if fused_ok(net):
@@ -746,6 +784,7 @@ def force(net, z, x, topo, offsets=None, want_energy=True):
             return _force_chain(net, z, x.detach().contiguous(), topo, want_energy)
         with _node_blas():
             return _force_fused(net, z, x.detach().contiguous(), topo, want_energy)
+    _warn_once("unfused", _UNFUSED_MSG)
     topo = _stable(topo)
     with _blas_for(topo):
         fw = _primal(net, z, x.detach().contiguous(), topo, topo.offsets)
@@ -763,6 +802,7 @@ def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=Tru
             return _force_vjp_chain(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
         with _node_blas():
             return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
+    _warn_once("unfused", _UNFUSED_MSG)
     topo = _stable(topo)
     with _blas_for(topo):
         out = _force_vjp_unfused(net, z, x, w, topo, topo.offsets, want_theta)

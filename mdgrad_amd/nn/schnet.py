@@ -16,6 +16,8 @@ import torch.nn as nn
 from torch.nn import ModuleDict, Sequential
 
 from .. import ops
+from .graphconv import MessagePassingModule
+from .graphop import batch_and_sum
 from .layers import Dense, GaussianSmearing, shifted_softplus
 
 _LAYER_TYPES = {"linear": torch.nn.Linear, "Tanh": torch.nn.Tanh, "ReLU": torch.nn.ReLU, "Dense": Dense,
@@ -48,8 +50,10 @@ class NodeMultiTaskReadOut(nn.Module):                       # nff/nn/modules.py
         return out
 
 
-class SchNetConv(nn.Module):
-    """nff/nn/modules.py:514-575 (+ MessagePassingModule.forward, graphconv.py:43-53)."""
+class SchNetConv(MessagePassingModule):
+    """nff/nn/modules.py:514-575 on MessagePassingModule (graphconv.py:11-53): `message` = filter network x filtered node rows
+    at both ends of a pair, `aggregate` = scatter-add, `update` = the update MLP.  With the topology GNNPotentials attaches,
+    `forward` replaces message + aggregate by one atom-centric HIP gather."""
 
     def __init__(self, n_atom_basis, n_filters, n_gaussians, cutoff, trainable_gauss):
         super().__init__()
@@ -79,16 +83,24 @@ class SchNetConv(nn.Module):
                                             d2.weight, d2.bias, self.filter_bf16)
         return seq(e)
 
-    def forward(self, r, e, a, aggr_wgt=None, topo=None):
+    def message(self, r, e, a, aggr_wgt=None):               # modules.py:547-568
         W = self.edge_filter(e)                              # [E,F] continuous filter
         h = self.moduledict['message_node_filter'](r)        # [N,F]
         if aggr_wgt is not None:
             h = h * aggr_wgt
-        if topo is not None:
-            m = ops.CfconvAggFn.apply(h, W, topo)
-        else:                                                # explicit list without topology: torch ops
-            m = torch.zeros_like(h).index_add(0, a[:, 1], h[a[:, 0]] * W).index_add(0, a[:, 0], h[a[:, 1]] * W)
-        return self.moduledict['update_function'](m)
+        return h[a[:, 0]] * W, h[a[:, 1]] * W
+
+    def update(self, r):                                     # modules.py:570-571
+        return self.moduledict['update_function'](r)
+
+    def forward(self, r, e, a, aggr_wgt=None, topo=None):
+        if topo is None:                                     # explicit list without topology: the reference's own three steps
+            return MessagePassingModule.forward(self, r, e, a, aggr_wgt)
+        W = self.edge_filter(e)
+        h = self.moduledict['message_node_filter'](r)
+        if aggr_wgt is not None:
+            h = h * aggr_wgt
+        return self.update(ops.CfconvAggFn.apply(h, W, topo))
 
 
 class SchNet(nn.Module):
@@ -142,11 +154,7 @@ class SchNet(nn.Module):
     def forward(self, batch, xyz=None):
         r, N, xyz = self.convolve(batch, xyz)
         r = self.atomwisereadout(r)
-        results = {}
-        for key, val in r.items():                            # batch_and_sum, nff/nn/graphop.py:32-63
-            if key in batch:
-                results[key] = torch.stack([c.sum(0) for c in torch.split(val, N)])
-        return results
+        return batch_and_sum(r, N, list(batch.keys()), xyz)  # schnet.py:167-169
 
 
 _PARAMS_TYPE = {'n_atom_basis': int, 'n_filters': int, 'n_gaussians': int, 'n_convolutions': int,

@@ -41,8 +41,7 @@ def NHverlet_update(func, t, dt, y):
                   tuple(y[i] + half[i - 3] for i in range(3, 8)))
         return (dv_h + 1 / 2 * k1[0] * dt, dq, dp_h + 1 / 2 * k1[2] * dt) + \
             tuple(k1[i] * dt for i in range(3, 8))
-    raise ValueError("received {} argumets integration, but should be {} for the forward call or {} "
-                     "for the backward call".format(len(y), 3, 8))
+    raise ValueError("NHverlet_update takes 3 state tensors (forward) or 8 (augmented adjoint state), got %d" % len(y))
 
 
 def verlet_update(func, t, dt, y):
@@ -67,8 +66,7 @@ def verlet_update(func, t, dt, y):
         dv2, _, _, X1, vjp_t2, _ = func(t, (v_half, x0, lv + dlv, lx + dlx, y[4] + vjp_t * dt,
                                             y[5] + dth_half))
         return (dv_h - dv2 * dt * 0.5, dx, dlv, X1 * dt * 0.5 + dlx, vjp_t2 * dt, dth_half * 2)
-    raise ValueError("received {} argumets integration, but should be {} for the forward call or {} "
-                     "for the backward call".format(len(y), 2, 6))
+    raise ValueError("verlet_update takes 2 state tensors (forward) or 6 (augmented adjoint state), got %d" % len(y))
 
 
 class NHVerlet(FixedGridODESolver):

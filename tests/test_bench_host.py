@@ -78,3 +78,40 @@ def test_compact_headline_drops_notes_and_keeps_every_contract_key():
         assert k in c
     assert "note" not in c["roofline"] and len(c["cpu_baseline"]["sample"]) <= 150 and c["value"] == 1.23456789e7
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"])
+
+
+def test_headline_config_puts_every_baseline_config_first_and_keeps_the_workload_short():
+    """the driver's parser keeps the first ~20 scalar keys of `config` and cuts strings at 100
+    characters -- the rate, time per pass and dominant-kernel fraction of configs #3 / #4 / #5 and the one-system-per-GPU leg
+    come right after the workload string, parity / dtype scalars after them."""
+    bench = importlib.import_module("bench")
+    cfg = {"workload": "w" * 140, "replicas_per_gpu": 16384, "md_steps_per_pass": 1, "parallelism": "replica-dp1", "loss": 0.9,
+           "dist": {"backend": "nccl"}, "rdf_fused_into_trajectory_kernels": True, "rdf_fused": "fine-grid histogram",
+           "exvol108_md_steps_per_s": 3.4e7, "exvol108_dtype": "f32"}
+    for name in ("schnet4096", "lj4096", "water192"):
+        cfg.update({name + "_md_steps_per_s": 1.0, name + "_ms_per_pass": 2.0, name + "_dtype": "f32", name + "_kernel_frac": 0.1,
+                    name + "_parity_max_abs_dq": 1e-6})
+    cfg.update({"single_system_md_steps_per_s": 1200.0, "single_system_us_per_md_step": 800.0, "single_system_ms_per_pass": 16.0})
+    out = bench._ordered_config(cfg)
+    keys = list(out)
+    assert keys[0] == "workload" and len(out["workload"]) <= 100 and out["workload_full"] == "w" * 140
+    head = keys[:20]
+    for name in ("lj4096", "water192", "schnet4096"):
+        for suffix in ("_md_steps_per_s", "_ms_per_pass", "_kernel_frac"):
+            assert name + suffix in head, (name + suffix, head)
+    assert "single_system_md_steps_per_s" in head and "single_system_ms_per_pass" in head and "rdf_fused" in head
+    assert keys.index("lj4096_kernel_frac") < keys.index("lj4096_parity_max_abs_dq") and keys.index("rdf_fused") < keys.index("loss")
+    assert set(out) == set(cfg) | {"workload_full"}, "nothing is dropped"
+    # the real headline's workload string fits the parser's cut without the fallback
+    import inspect
+    src = inspect.getsource(bench.run_lj108)
+    assert "rep/GPU" in src
+    assert len("FCC 3^3 %s 108 atoms rc 2.5 NHC(Q50,5) dt %g, %d steps+RDF loss+adjoint, %d rep/GPU"
+               % ("ExVol(1,1,12)", 0.005, 49, 16384)) <= 100
+
+
+def test_compulsory_bytes_of_the_fused_adjoint_launch():
+    bench = importlib.import_module("bench")
+    b = bench._lj108_compulsory_bytes(108, 16384, 50, 2)
+    per_step_replica = b / (16384 * 49.0)
+    assert 2500 < per_step_replica < 2800, "one (v, q, pv) frame of 108 atoms per step-replica: ~2.6 KB"
