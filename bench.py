@@ -120,6 +120,10 @@ def _dist_record(mdist, dev, params, ms_rank):
     all-reduce of ones, the time of one all-reduce of the flat-gradient-sized buffer, every rank's ms per pass."""
     rec = mdist.collective_evidence(dev, sum(p.numel() for p in params))
     rec["per_rank_ms"] = mdist.gather_over_ranks(ms_rank, dev)
+    # every rank applied the same reduced gradient in the same optimizer: its parameters are bit-identical to rank 0's
+    sums = mdist.gather_over_ranks(float(sum(p.detach().double().sum() for p in params)), dev)
+    rec["param_checksum"] = sums[0]
+    rec["params_identical_on_all_ranks"] = all(x == sums[0] for x in sums)
     return rec
 
 

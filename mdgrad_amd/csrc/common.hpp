@@ -23,6 +23,22 @@ void mdg_set_error(const char* fmt, ...);
          if (e_ != hipSuccess) { mdg_set_error("%s: %s", name, hipGetErrorString(e_)); \
                                  return MDG_ELAUNCH; } } while (0)
 
+// Fixed-point accumulation of float contributions (the table-gradient scatter of the tabulated pair model, csrc/traj_small.hip,
+// traj_ring.hpp, traj_large.hip): ONE signed 64-bit word per value, integer atomics -- order-independent, so bitwise
+// reproducible.  fx64(v) = round(v) exactly for |v| < 2^51 (two float roundings: the part above 2^20 and the rest).
+// Range: a launch flags a single contribution at or above  fx64_limit(n) = 2^62 / n,  n = the largest number of
+// contributions one word can receive, so no sum can leave int64 unflagged (two int32 planes wrapped silently once
+// the adjoint had grown by ~2^10); the host re-runs a flagged launch with a coarser scale.
+__device__ __forceinline__ unsigned long long fx64(float v) {
+    const float hi = rintf(v * (1.f / 1048576.f));
+    const int lo = (int)rintf(fmaf(hi, -1048576.f, v));
+    return (unsigned long long)(((long long)(int)hi << 20) + (long long)lo);
+}
+__host__ __device__ inline float fx64_limit(double n_contrib) {
+    const double lim = 4611686018427387904.0 / (n_contrib < 1.0 ? 1.0 : n_contrib);      // 2^62 / n
+    return (float)(lim < 1125899906842624.0 ? lim : 1125899906842624.0);                 // (<= 2^50: fx64's own range)
+}
+
 // internal: the fine grids of the many-frame RDF kernels (csrc/rdf.hip), shared with the fused observable of the
 // trajectory kernels (csrc/traj_small.hip).  Not part of the C ABI.
 struct RdfFinePlan {

@@ -54,7 +54,8 @@ struct LargeArgs {
     float *lp, *lph, *pvm;                   // [R][16]
     float *partN;                            // [R][nb][LG_NV]
     float *gth;                              // [R][K_total]
-    int32_t *ghi, *glo;                      // MDG_PAIR_TABLE: fixed-point table gradient, two planes [R][K_total]
+    unsigned long long* g64;                 // MDG_PAIR_TABLE: fixed-point table gradient, int64 words [R][K_total] (fx64, common.hpp)
+    float glim;                              //   a single contribution at or beyond this raises flags[2] (fx64_limit)
     float *adj_v0, *adj_q0, *adj_pv0, *adj_theta;
     int nbF, nbE;                            // workgroups of the per-atom / per-element kernels
     int step;                                // forward: step index k; adjoint: frame index i
@@ -550,19 +551,16 @@ __device__ __forceinline__ void pair_terms(const LargeArgs& A, const TermConst (
             const float c2 = o.d2u * a - c1 * a;
             gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
             if (KIND < 0 && tc[m].kind == MDG_PAIR_TABLE) {
-                // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (two int32
-                // planes, see traj_small.hip) with integer global atomics: order-independent
+                // table gradient: d(w.F)/dnode = 1/2 (D.w_ij) basis, scattered in fixed point (one int64 word per
+                // entry, see traj_small.hip) with integer global atomics: order-independent
                 if (gw != 0.f) {
                     const float x = -gw * a * r;                         // D . w_ij = -a r
-                    int32_t* hi = A.ghi + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
-                    int32_t* lo = A.glo + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
+                    unsigned long long* g = A.g64 + (size_t)rep * A.terms.n_theta_total + 2 * o.tg;
 #pragma unroll
                     for (int b_ = 0; b_ < 4; ++b_) {
                         const float val = x * o.tb[b_];
-                        if (fabsf(val) >= 3.5e13f) atomicOr(&A.flags[2], 1);          // 2^45: out of range
-                        const float vh_ = rintf(val * (1.f / 1048576.f));
-                        atomicAdd(hi + b_, (int)vh_);
-                        atomicAdd(lo + b_, (int)rintf(fmaf(vh_, -1048576.f, val)));
+                        if (!(fabsf(val) < A.glim)) atomicOr(&A.flags[2], 1);         // out of range (or not a number)
+                        atomicAdd(g + b_, fx64(val));
                     }
                 }
             } else {
@@ -1205,7 +1203,7 @@ void large_adj_force(const LargeArgs A, const int second) {
     // (table kind: the parameter term of an interval comes from the midpoint evaluation with weight h, :160)
     // (NVE: from the first evaluation, sovlers.py:82,101 -- both with total weight h)
     const bool tab_eval = (A.prm.ensemble == 0) == (second != 0);
-    const float gw = (tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    const float gw = (tab_eval && A.g64) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
     wave_neighbours_and_force<DIAG, 2, KIND, 0>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
                                                 tc, rc2max, gw, rep);
     float vals[LG_NV];
@@ -1256,7 +1254,7 @@ __global__ __launch_bounds__(256) void large_adj_listed(const LargeArgs A, const
     const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
     const bool nhc = A.prm.ensemble == 0;
     const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
-    const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    const float gw = (KIND < 0 && tab_eval && A.g64) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
     // first evaluation: the build that serves frame i_fr (valid there by the forward pass's construction).  Midpoint:
     // that one or frame i_fr + 1's, whichever large_prep<3> found within skin / 2 of the midpoint positions
     // (nl_state[2 rep + {0, 1}] = {first, second} candidate is too far; cleared by the first evaluation's launch).
@@ -1623,7 +1621,7 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_adj_tiled(const LargeAr
     const int ntl = KIND >= 0 ? 1 : A.terms.n_terms;
     const bool nhc = A.prm.ensemble == 0;
     const bool tab_eval = nhc == (second != 0);                        // (as large_adj_force)
-    const float gw = (KIND < 0 && tab_eval && A.ghi) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    const float gw = (KIND < 0 && tab_eval && A.g64) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
     int slot = A.nl_build[(size_t)rep * T + i_fr];
     bool bad = A.nl_bad[(size_t)rep * T + slot] != 0;
     if (second) {
@@ -1749,10 +1747,9 @@ __global__ __launch_bounds__(LG_TILE_THREADS) void large_adj_tiled(const LargeAr
 }
 
 // fixed point -> float table gradient
-__global__ void large_table_grad(const int32_t* __restrict__ ghi, const int32_t* __restrict__ glo, size_t n, float scale,
-                                 float* __restrict__ out) {
+__global__ void large_table_grad(const unsigned long long* __restrict__ g64, size_t n, float scale, float* __restrict__ out) {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) out[k] = (float)(((double)ghi[k] * 1048576.0 + (double)glo[k]) / (double)scale);
+    if (k < n) out[k] = (float)((double)(long long)g64[k] / (double)scale);
 }
 
 // lam(T-1) = dL/dy_{T-1} of every replica: the last frame's rows of the incoming gradients (zeros where none came)
@@ -1786,8 +1783,8 @@ WsLayout ws_layout(int R, int N, int nb, int KT, int T) {
     w.partA = take((size_t)R * nbmax); w.partB = take((size_t)R * nbmax);
     w.partN = take((size_t)R * nbmax * LG_NV);
     w.gth = take((size_t)R * (KT > 0 ? KT : 1));
-    w.ghi = take((size_t)R * (KT > 0 ? KT : 1));        // (int32 planes of the table kind; a few words otherwise)
-    w.glo = take((size_t)R * (KT > 0 ? KT : 1));
+    w.ghi = take((size_t)2 * R * (KT > 0 ? KT : 1));    // (int64 words of the table kind -- offsets are multiples of 256 B --; a few words otherwise)
+    w.glo = w.ghi;
     w.flags = take(16);
     w.spos = take((size_t)R * N * 4);
     w.bstart = take((size_t)R * (LG_MAX_CELLS + 1));
@@ -1938,8 +1935,8 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
     a.pvm = ws + L.pvm; a.partA = ws + L.partA; a.partB = ws + L.partB; a.partN = ws + L.partN;      \
     a.gth = ws + L.gth; a.flags = flags; a.nbE = nbE;                                                \
     const bool table = terms->t[0].kind == MDG_PAIR_TABLE;                                           \
-    a.ghi = table ? reinterpret_cast<int32_t*>(ws + L.ghi) : nullptr;                                \
-    a.glo = table ? reinterpret_cast<int32_t*>(ws + L.glo) : nullptr;                                \
+    a.g64 = table ? reinterpret_cast<unsigned long long*>(ws + L.ghi) : nullptr;                     \
+    a.glim = fx64_limit((double)(prm->n_frames > 1 ? prm->n_frames - 1 : 1) * (double)prm->n_atoms * (double)LG_CAP); \
     hipStream_t st = (hipStream_t)stream;                                                            \
     const bool diag = cell->diag != 0;                                                               \
     a.spos = reinterpret_cast<float4*>(ws + L.spos);                                                 \
@@ -2069,8 +2066,7 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
     hipLaunchKernelGGL(large_adj_init, dim3((3 * N + 255) / 256, R), dim3(256), 0, st, g_v, g_q, g_pv, N, T, C, a.lv, a.lq, a.lp);
     MDG_HIP(hipMemsetAsync(a.gth, 0, sizeof(float) * (size_t)R * (KT > 0 ? KT : 1), st));
     if (table) {
-        MDG_HIP(hipMemsetAsync(a.ghi, 0, sizeof(int32_t) * (size_t)R * KT, st));
-        MDG_HIP(hipMemsetAsync(a.glo, 0, sizeof(int32_t) * (size_t)R * KT, st));
+        MDG_HIP(hipMemsetAsync(a.g64, 0, sizeof(unsigned long long) * (size_t)R * KT, st));
     }
     const int gLAx = (N + LG_ROW_ATOMS * LG_ADJ_GROUPS - 1) / (LG_ROW_ATOMS * LG_ADJ_GROUPS);
     if (a.nl_idx) a.nbF = a.tile_cap ? a.ncol : gLAx;         // (rows of partN the listed launches write, the prep launches sum)
@@ -2114,8 +2110,7 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
                                  hipMemcpyDeviceToDevice, st));
     if (adj_theta && table) {
         const size_t n = (size_t)R * KT;
-        hipLaunchKernelGGL(large_table_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.ghi, a.glo, n,
-                           terms->t[0].c, adj_theta);
+        hipLaunchKernelGGL(large_table_grad, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.g64, n, terms->t[0].c, adj_theta);
     } else if (adj_theta && KT > 0)
         MDG_HIP(hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st));
     MDG_CHECK_LAUNCH("traj_adj_large");

@@ -82,31 +82,19 @@ struct RingRdf {
                                                             // (fmax / tmax: end of the grid or the observable's cutoff)
     // KIND_TABLE (round 5; the tabulated pair model of traj_small.hip force_table_packed -- pairMLP + prior stacks,
     // scripts/fit_rdf_pair.py:355-368 -- register-resident): the nodes (c1_g, du dc1/du_g) of c1(u) = phi'(r)/r in LDS; the
-    // fixed-point planes of this replica's table gradient (value = HI 2^20 + LO, integer LDS atomics: order-independent) and
-    // the weight of the current evaluation's contributions (0: the evaluation does not accumulate, sovlers.py:160 / :82,101);
-    // tflag: LDS word, bit 1 = a live pair below the first node (forward), bit 2 = a contribution beyond 2^45 (adjoint)
-    const float2* ttab; int32_t* tghi; int32_t* tglo; int32_t* tflag; float tgw, tu0, tinv_du, ttmax;
+    // fixed-point words of this workgroup's table gradient (fx64, common.hpp: one int64 per entry, integer LDS atomics:
+    // order-independent) and the weight of the current evaluation's contributions (0: the evaluation does not accumulate,
+    // sovlers.py:160 / :82,101); tlim: the largest single contribution the words can take without any sum leaving int64;
+    // tflag: LDS word, bit 1 = a live pair below the first node (forward), bit 2 = a contribution at or beyond tlim (adjoint)
+    const float2* ttab; unsigned long long* tg64; int32_t* tflag; float tgw, tu0, tinv_du, ttmax, tlim;
 };
 
-// Two ADJACENT plane words (idx even: a node's value and slope entries) in ONE 64-bit LDS atomic per plane: the sum of
-// (a + b 2^32) over the contributions is (sum a) + (sum b) 2^32 as a 64-bit integer, and as long as sum a stays inside int32 --
-// the range every plane word has to stay in anyway -- the two sums are read back exactly (low word signed; the rest / 2^32).
-// Halves the atomic instructions of the scatter: the LDS atomic unit, shared by the waves of a CU, bounds the accumulating
-// evaluation of the tabulated kind.
+// A node's value and slope entries (idx even, idx + 1): one 64-bit LDS atomic each -- as many atomic instructions as the
+// two packed int32 planes of round 5 took for the pair, and no carry between neighbours to go wrong.
 __device__ __forceinline__ void ring_table_scatter2(const RingRdf& X, int idx, float va, float vb) {
-    if (fmaxf(fabsf(va), fabsf(vb)) >= 3.5e13f) *X.tflag = 4;             // 2^45: out of the fixed-point range
-    const float ha = rintf(va * (1.f / 1048576.f)), hb = rintf(vb * (1.f / 1048576.f));
-    const int la = (int)rintf(fmaf(ha, -1048576.f, va)), lb = (int)rintf(fmaf(hb, -1048576.f, vb));
-    const unsigned long long ph = (unsigned long long)(long long)(int)ha + ((unsigned long long)(long long)(int)hb << 32);
-    const unsigned long long pl = (unsigned long long)(long long)la + ((unsigned long long)(long long)lb << 32);
-    atomicAdd(reinterpret_cast<unsigned long long*>(X.tghi + idx), ph);
-    atomicAdd(reinterpret_cast<unsigned long long*>(X.tglo + idx), pl);
-}
-// (read-back of the word pair at even idx: -> the two int32 sums)
-__device__ __forceinline__ void ring_table_unpack(const int32_t* plane, int idx, int& a, int& b) {
-    const long long w = *reinterpret_cast<const long long*>(plane + idx);
-    a = (int)(w & 0xffffffffll);
-    b = (int)((w - (long long)a) >> 32);
+    if (!(fmaxf(fabsf(va), fabsf(vb)) < X.tlim)) *X.tflag = 4;            // out of range (or not a number): the host re-scales
+    atomicAdd(X.tg64 + idx, fx64(va));
+    atomicAdd(X.tg64 + idx + 1, fx64(vb));
 }
 
 // One packed pair operation: lane atoms (i0, i1) against visitors (j0, j1) [CROSS: (j1, j0)].
@@ -650,14 +638,16 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
         // the nodes and the workgroup's two gradient planes behind the waves' ring buffers (6 x 64 f32x2 each)
         const MdgPairTerm& t0 = A.terms.t[0];
         float2* ttab = reinterpret_cast<float2*>(smr + 4 * ncell + NWV * 6 * 64 * 2);
-        int32_t* thi = reinterpret_cast<int32_t*>(ttab + t0.p);
-        int32_t* tlo = thi + 2 * t0.p;
-        int32_t* tflag = tlo + 2 * t0.p;
+        unsigned long long* tg = reinterpret_cast<unsigned long long*>(ttab + t0.p);        // [2 p] int64 words
+        int32_t* tflag = reinterpret_cast<int32_t*>(tg + 2 * t0.p);
         const float* thp = A.theta + t0.theta_off;
         for (int g = threadIdx.x; g < t0.p; g += blockDim.x) ttab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
-        for (int g = threadIdx.x; g < 2 * t0.p; g += blockDim.x) { thi[g] = 0; tlo[g] = 0; }
+        for (int g = threadIdx.x; g < 2 * t0.p; g += blockDim.x) tg[g] = 0ull;
         if (threadIdx.x == 0) *tflag = 0;
-        X.ttab = ttab; X.tghi = thi; X.tglo = tlo; X.tflag = tflag; X.tgw = 0.f;
+        X.ttab = ttab; X.tg64 = tg; X.tflag = tflag; X.tgw = 0.f;
+        // one word can receive a contribution from every pair evaluation of the workgroup's replicas: one accumulating
+        // evaluation per interval, N (N - 1) / 2 pairs, two ends each
+        X.tlim = fx64_limit((double)NWV * (double)(T > 1 ? T - 1 : 1) * (double)N * (double)N);
         X.tu0 = t0.a; X.tinv_du = 1.f / t0.phi; X.ttmax = (float)(t0.p - 1) - 1e-3f;
         __syncthreads();
     }
@@ -779,13 +769,8 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
             const bool worst = (*X.tflag & 4) != 0;
             const double inv = 1.0 / (double)A.terms.t[0].c;
             float* out = A.adj_theta + (size_t)(blockIdx.x * NWV) * KT + A.terms.t[0].theta_off;
-            for (int g = 2 * threadIdx.x; g < M2; g += 2 * blockDim.x) {
-                int ha, hb, la, lb;
-                ring_table_unpack(X.tghi, g, ha, hb);
-                ring_table_unpack(X.tglo, g, la, lb);
-                out[g] = worst ? __builtin_inff() : (float)(((double)ha * 1048576.0 + (double)la) * inv);
-                out[g + 1] = worst ? __builtin_inff() : (float)(((double)hb * 1048576.0 + (double)lb) * inv);
-            }
+            for (int g = threadIdx.x; g < M2; g += blockDim.x)
+                out[g] = worst ? __builtin_inff() : (float)((double)(long long)X.tg64[g] * inv);
             if (wid > 0 && live) {
                 float* mine = A.adj_theta + (size_t)rep * KT + A.terms.t[0].theta_off;
                 for (int g = lane; g < M2; g += 64) mine[g] = 0.f;

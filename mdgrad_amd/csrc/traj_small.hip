@@ -144,21 +144,18 @@ __device__ __forceinline__ void force_lj126_packed(const TrajArgs& A, int tpa_lo
 // the derivative of the SAME interpolant, so force and Hessian-vector product stay consistent.
 // The parameter vjp is the gradient w.r.t. the table nodes: d(w.F)/dnode += 1/2 (D.w_ij) basis_node(u) per
 // directed pair, scattered into LDS.  Float LDS atomics are ~13x slower than integer ones on gfx950
-// (tools/micro/lds_atomics.hip), so the scatter is fixed point, split into two int32 planes
-// (value = HI * 2^20 + LO): order-independent => bitwise reproducible, like every other reduction here.
+// (tools/micro/lds_atomics.hip), so the scatter is fixed point in one int64 word per entry (fx64, common.hpp; round 6 --
+// two int32 planes before, whose sums could wrap unnoticed): order-independent => bitwise reproducible, like every
+// other reduction here.
 struct TableRef {
     const float2* tab;      // [M] (c1_g, du * dc1/du_g)
-    int32_t* ghi;           // [2M] or nullptr (no accumulation in this evaluation)
-    int32_t* glo;
+    unsigned long long* g64;   // [2M] or nullptr (no accumulation in this evaluation)
     float gw;               // weight of this evaluation's contributions: 1/2 * h * 2^S
 };
 
 __device__ __forceinline__ void table_scatter(const TableRef& T, int idx, float val, float& vmax) {
-    vmax = fmaxf(vmax, fabsf(val));
-    const float hi = rintf(val * (1.f / 1048576.f));
-    const float lo = fmaf(hi, -1048576.f, val);
-    atomicAdd(T.ghi + idx, (int)hi);
-    atomicAdd(T.glo + idx, (int)rintf(lo));
+    vmax = val == val ? fmaxf(vmax, fabsf(val)) : __builtin_inff();       // (a NaN contribution counts as out of range)
+    atomicAdd(T.g64 + idx, fx64(val));
 }
 
 template <int LEVEL, int LDC, bool NEAR>
@@ -174,7 +171,7 @@ __device__ __forceinline__ void force_table_packed(const TrajArgs& A, int tpa_lo
     const float tmax = (float)(t0.p - 1) - 1e-3f;
     const float ivx = A.cell.inv[0], ivy = A.cell.inv[4], ivz = A.cell.inv[8];
     const float hx = A.cell.h[0], hy = A.cell.h[4], hz = A.cell.h[8];
-    const bool acc = LEVEL >= 2 && T.ghi != nullptr;
+    const bool acc = LEVEL >= 2 && T.g64 != nullptr;
     for (int i = slot; i < N; i += slots) {
         const float xi = q[i], yi = q[LD + i], zi = q[2 * LD + i];
         float wxi = 0.f, wyi = 0.f, wzi = 0.f;
@@ -524,7 +521,7 @@ __global__ __launch_bounds__(1024) void traj_fwd_kernel(const TrajArgs A, const 
     float* red = Qs + MDG_MAX_CHAINS;   // [RED_FLOATS]
     float dth_unused[KMAX];
     float vmax_unused = 0.f;
-    TableRef TB{nullptr, nullptr, nullptr, 0.f};
+    TableRef TB{nullptr, nullptr, 0.f};
     if constexpr (KIND == KIND_TABLE) {                    // table nodes resident in LDS for the whole trajectory
         float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS);       // (13 LD + chains + RED_FLOATS is even)
         const float* th = A.theta + A.terms.t[0].theta_off;
@@ -710,17 +707,16 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) gth[k] = 0.f;
     float vmax = 0.f;
-    TableRef TB{nullptr, nullptr, nullptr, 0.f}, TBacc = TB;
+    TableRef TB{nullptr, nullptr, 0.f}, TBacc = TB;
     if constexpr (KIND == KIND_TABLE) {
         const int M = A.terms.t[0].p;
         float2* tab = reinterpret_cast<float2*>(red + RED_FLOATS);
-        int32_t* ghi = reinterpret_cast<int32_t*>(tab + M);
-        int32_t* glo = ghi + 2 * M;
+        unsigned long long* g64 = reinterpret_cast<unsigned long long*>(tab + M);      // [2 M] int64 words (8-byte aligned: tab is)
         const float* thp = A.theta + A.terms.t[0].theta_off;
         for (int g = threadIdx.x; g < M; g += blockDim.x) tab[g] = make_float2(thp[2 * g], thp[2 * g + 1]);
-        for (int g = threadIdx.x; g < 2 * M; g += blockDim.x) { ghi[g] = 0; glo[g] = 0; }
+        for (int g = threadIdx.x; g < 2 * M; g += blockDim.x) g64[g] = 0ull;
         TB.tab = tab;
-        TBacc = TableRef{tab, ghi, glo, 0.f};
+        TBacc = TableRef{tab, g64, 0.f};
     }
     const size_t fr = (size_t)rep * T;
     const int tid = threadIdx.x;
@@ -829,14 +825,15 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
     if constexpr (KIND == KIND_TABLE) {
         // table gradient: fixed point -> float; an out-of-range contribution poisons the output (the
         // host re-scales and reports it)
-        const float worst = block_sum(vmax >= 3.5e13f ? 1.f : 0.f, red);          // 2^45
+        // (one word can receive a contribution from every directed pair of the accumulating evaluation of every interval)
+        const float worst = block_sum(vmax >= fx64_limit((double)(T > 1 ? T - 1 : 1) * (double)N * (double)N) ? 1.f : 0.f, red);
         if (A.adj_theta) {
             const int KT = A.terms.n_theta_total, M2 = 2 * A.terms.t[0].p;
             const double inv = 1.0 / (double)A.terms.t[0].c;
             float* out = A.adj_theta + (size_t)rep * KT + A.terms.t[0].theta_off;
             for (int g = tid; g < M2; g += blockDim.x)
                 out[g] = worst > 0.f ? __builtin_inff()
-                                     : (float)(((double)TBacc.ghi[g] * 1048576.0 + (double)TBacc.glo[g]) * inv);
+                                     : (float)((double)(long long)TBacc.g64[g] * inv);
         }
         return;
     }
@@ -856,7 +853,22 @@ __global__ __launch_bounds__(1024) void traj_adj_kernel(const TrajArgs A, const 
 // ------------------------------------------------------------------------------------ launch
 // wave-per-replica kernels (traj_ring.hpp): one unmasked LJ 12-6 term, orthorhombic cell, N <= 128, and either
 // asked for (block = 64) or a many-replica launch, where throughput matters and not the latency of one replica
-constexpr int RING_TABLE_MAX_NODES = 2048;     // 6 x 2048 x 4 B = 48 KB of LDS per adjoint wave: three waves per CU
+// Tabulated kind on the ring kernels: up to 2 048 nodes.  The adjoint workgroup (RING_TABLE_WAVES = 8 replicas sharing the nodes
+// and one set of int64 gradient words) asks for 8 x 3 KB of ring buffers + 24 B per node + 16 B = 73.7 KB at 2 048 nodes: above
+// the 64 KB a workgroup gets on older parts, inside gfx950's 160 KB -- ring_form() checks the request against the device's
+// own limit and hands a launch that does not fit to the one-workgroup-per-replica kernels.
+constexpr int RING_TABLE_MAX_NODES = 2048;
+size_t ring_table_adj_lds(int nodes);          // (below, with the launch geometry)
+size_t device_lds_per_block() {
+    static size_t cached = 0;
+    if (!cached) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0)
+            v = 64 * 1024;
+        cached = (size_t)v;
+    }
+    return cached;
+}
 
 bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
@@ -867,7 +879,8 @@ bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& term
     //  replica's gradient planes sit in LDS beside the wave's ring buffers)
     if (t.kind == MDG_PAIR_TABLE) {
         const char* e = getenv("MDG_RING_TABLE");                        // (=0: the one-workgroup-per-replica kernels; A/B)
-        return !(e && e[0] == '0') && terms.n_terms == 1 && cell.diag && !t.mask && t.p <= RING_TABLE_MAX_NODES && p.n_atoms <= 128;
+        return !(e && e[0] == '0') && terms.n_terms == 1 && cell.diag && !t.mask && t.p <= RING_TABLE_MAX_NODES && p.n_atoms <= 128 &&
+               ring_table_adj_lds(t.p) <= device_lds_per_block();
     }
     return terms.n_terms == 1 && cell.diag && (!t.mask || t.kind == MDG_PAIR_LJ) && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA &&
            p.n_atoms <= 128;
@@ -879,7 +892,7 @@ int ring_kind(const MdgPairTerm& t) {
     if (t.kind == MDG_PAIR_TABLE) return KIND_TABLE;
     return (t.kind == MDG_PAIR_LJ && t.p == 12 && (t.q == 6 || t.c == 0.f)) ? KIND_LJ126 : t.kind;
 }
-// LDS of the tabulated kind behind a wave's ring buffers: the nodes (forward) + two int32 gradient planes (adjoint) + a flag word
+// LDS of the tabulated kind behind a wave's ring buffers: the nodes (forward) + the int64 gradient words (adjoint) + a flag word
 size_t ring_table_lds(const MdgTerms& terms, bool adjoint) {
     if (terms.t[0].kind != MDG_PAIR_TABLE) return 0;
     return sizeof(float) * (size_t)(adjoint ? 6 : 2) * terms.t[0].p + 16;
@@ -906,6 +919,7 @@ size_t ring_table_lds(const MdgTerms& terms, bool adjoint) {
 
 constexpr size_t RING_LDS_FWD = sizeof(f32x2) * 3 * 64;      // per wave: the visitors' positions
 constexpr size_t RING_LDS_ADJ = sizeof(f32x2) * 6 * 64;      //           ... and adjoint directions
+size_t ring_table_adj_lds(int nodes) { return RING_TABLE_WAVES * RING_LDS_ADJ + sizeof(float) * 6 * (size_t)nodes + 16; }
 constexpr int RING_RDF_WAVES = 16;                           // waves sharing the fine histogram of the fused RDF
 constexpr int RING_RDF_MAX_CELLS = 1088;                     // derivative table <= 17 KB: eight adjoint waves per CU
 
@@ -1060,7 +1074,7 @@ extern "C" int mdg_traj_adj_small(const MdgTrajParams* prm, const MdgCell* cell,
         return MDG_OK;
     }
     const int block = pick_block(*prm, terms->t[0].kind == MDG_PAIR_TABLE);
-    const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + two int32 planes
+    const size_t tab = terms->t[0].kind == MDG_PAIR_TABLE ? 6 * (size_t)terms->t[0].p : 0;   // nodes + the int64 gradient words
     MDG_CHECK_ARG(!tab || theta, "traj_adj: the table is passed through theta");
     a.ld = N <= 128 ? 128 : (N + 1) & ~1;
     const size_t lds = sizeof(float) * (28 * (size_t)a.ld + 6 * MDG_MAX_CHAINS + RED_FLOATS + tab);

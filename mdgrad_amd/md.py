@@ -298,8 +298,11 @@ class _EOM(torch.nn.Module):
         code = getattr(self, "_stale_code", None)
         if code is None or code.shape != (n_rep, n_atoms, n_atoms) or code.device != device:
             if code is not None or self.update_count % int(self.topology_update_freq) != 0:
-                raise RuntimeError("mdgrad_amd: stale neighbour lists of another launch geometry are in use (the call "
-                                   "counter is between two rebuilds); set integrator.fused_stale = False")
+                raise RuntimeError("mdgrad_amd: the fused stale-list kernels have no lists for this launch (%s) while the call "
+                                   "counter (%d, topology_update_freq %d) is between two rebuilds; set integrator.fused_stale = "
+                                   "False" % ("another launch geometry holds them" if code is not None else
+                                              "a generic force / odeint call on this integrator dropped them",
+                                              self.update_count, int(self.topology_update_freq)))
             code = self._stale_code = torch.zeros(n_rep, n_atoms, n_atoms, dtype=torch.int16, device=device)
         return code
 

@@ -510,6 +510,7 @@ class FusedTrajFn(torch.autograd.Function):
                                                stream_ptr(dev)), "mdg_traj_fwd_small_stale")
             integ.update_count += 2 * (T - 1)
             integ._stale_fused_dirty = True        # (the generic path's own lists are older than these now: md.update_topology)
+            ctx.stale_code = code                  # (the lists this pass ended with: what its backward continues from)
         else:
             bad = torch.zeros(R, dtype=torch.int32, device=dev)
             check(lib.mdg_traj_fwd_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
@@ -613,6 +614,12 @@ class FusedTrajFn(torch.autograd.Function):
             if getattr(spec, "stale_freq", 0):
                 # the adjoint makes 3 calls per interval (the dL/dt evaluation and two augmented ones, sovlers.py:258-266)
                 integ = spec._integrator
+                if getattr(integ, "_stale_code", None) is None and getattr(ctx, "stale_code", None) is not None:
+                    # a generic force / odeint call on this integrator between the fused forward and this backward (logging,
+                    # an observable) dropped the fused lists (md.update_topology): the forward's own lists -- held on ctx --
+                    # are the ones its saved frames were integrated with; the call counter keeps what the calls in between
+                    # made of it, as the reference's would
+                    integ._stale_code = ctx.stale_code
                 code = integ.stale_lists(R, N, dev)
                 check(lib.mdg_traj_adj_small_stale(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
                                                    ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
@@ -641,7 +648,9 @@ class FusedTrajFn(torch.autograd.Function):
 
         if table:
             # fixed-point scale of the in-kernel table-gradient scatter: the largest single contribution
-            # 1/2 h (D . w_ij) is put near 2^30 (the kernels accept up to 2^45); one host sync
+            # 1/2 h (D . w_ij) is put near 2^30; the kernels accumulate int64 words and flag a single contribution at or
+            # beyond 2^62 / (the contributions one word can receive) -- ~2^40 at 50 frames of 108 atoms --, so a sum cannot
+            # leave the word unflagged however far the adjoint grows along the trajectory; one host sync
             lam = max([float(g.abs().max()) for g in (gv, gq) if g is not None] + [1e-30])
             h = float((tc[1:] - tc[:-1]).abs().max())
             est = max(0.5 * h * 2.0 * spec.terms.t[0].cutoff * lam / float(spec.mass.min()), 1e-30)
@@ -656,7 +665,7 @@ class FusedTrajFn(torch.autograd.Function):
                 S -= 14                                    # adjoint grew past the range: coarser fixed point
             else:
                 raise RuntimeError("mdgrad_amd: the table-gradient accumulation overflowed (adjoint magnitudes "
-                                   "above 2^%d of the incoming gradients)" % (45 - S))
+                                   "above ~2^%d of the incoming gradients)" % (40 - S))
         else:
             flags = launch(spec.terms)
             if flags is not None:

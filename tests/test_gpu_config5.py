@@ -185,3 +185,48 @@ def test_bench_plain_command_spawns_two_ranks_on_one_device():
     assert out["n_gpus"] == 2 and d["backend"] == "gloo" and d["world"] == 2 and d["ranks_seen"] == 2
     assert d["allreduce_us"] > 0 and len(d["per_rank_ms"]) == 2 and all(x > 0 for x in d["per_rank_ms"])
     assert abs(max(d["per_rank_ms"]) - out["ms_per_step"]) < 1e-6 * out["ms_per_step"]
+
+
+def test_bench_plain_command_with_eight_ranks_on_one_device():
+    """the command the driver issues for its 8-GPU scaling point -- `python bench.py --gpus 8` -- spawns
+    eight ranks (here all on cuda:0 over gloo; on an 8-GPU node the same path runs RCCL over xGMI): the collective sees 8
+    ranks, every rank ends with bit-identical parameters, rank 0 prints ONE JSON line with the whole-job rate, and the run
+    stays far inside the driver's time limit."""
+    import json
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "lj108", "--steps", "3", "--warmup", "2",
+           "--replicas", "2048", "--no-cpu-baseline"]
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    d = out["config"]["dist"]
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["parallelism"] == "replica-dp8"
+    assert d["world"] == 8 and d["ranks_seen"] == 8 and len(d["per_rank_ms"]) == 8 and all(x > 0 for x in d["per_rank_ms"])
+    assert d["params_identical_on_all_ranks"] is True
+    assert abs(out["value"] - 8 * 2048 * 49 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    assert wall < 600, "eight ranks on ONE device took %.0f s" % wall
+
+
+def test_bench_default_leg_set_for_more_than_one_rank_is_lean():
+    """... and the default leg set of an N > 1 run: headline + lj4096 + schnet4096, no precision variants (two ranks on one
+    device; small pass counts so the test stays short)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MDG_DIST_BACKEND="gloo", MDG_SINGLE_DEVICE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--replicas", "1024",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    names = [ln.get("workload") for ln in lines[:-1]]
+    assert sorted(names) == ["lj4096", "schnet4096"], names
+    cfg = lines[-1]["config"]
+    assert cfg["lj4096_md_steps_per_s"] > 0 and cfg["schnet4096_md_steps_per_s"] > 0
+    assert not any(k.startswith(("water192", "exvol108", "schnet4096_f32", "schnet4096_bf16rows")) for k in cfg), sorted(cfg)
+    assert list(cfg)[0] == "workload" and len(cfg["workload"]) <= 100
