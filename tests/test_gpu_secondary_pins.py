@@ -105,7 +105,9 @@ def test_large_path_timed_geometry_16_steps_with_device_side_rebuilds_vs_oracle(
     16 steps, stored candidate lists reused with the exact cutoff re-applied, and at least one search decided on the device
     between two frames (torchmd/md.py:200-204 with topology_update_freq = 1: the pair set of EVERY evaluation is the exact
     one) -- the hottest replica of the launch, forward and adjoint, against its own oracle run."""
-    scales = tuple(0.8 + 0.4 * (r % 3) for r in range(63)) + (2.0,)
+    # (velocity scales near the thermostat's temperature: with 12 288 degrees of freedom on Q = 30 a replica started at 3.6 kT
+    #  is driven unstable by the chain itself within 7 steps -- in the reference's arithmetic as here)
+    scales = tuple((0.9, 1.0, 1.1, 1.2)[r % 4] for r in range(64))
     _stacked_large_vs_oracle(16, 64, 17, 0.005, scales, (63,), seed=38, tol_q=1e-4, expect_reuse="some")
 
 
@@ -336,7 +338,7 @@ def test_schnet_timed_stack_8x4096_beads_6_steps_with_stored_list_reuse_vs_oracl
         sd = {k: v.detach().clone().cpu() for k, v in wl["net"].state_dict().items()}
         pos = wl["system"].get_positions().reshape(R, N, 3).astype(np.float32)
         vel = wl["system"].get_velocities().reshape(R, N, 3).astype(np.float32)
-        _run_schnet_workload(wl, t[:2], 1, replicas=(R - 1,))          # (builds the stored lists)
+        _run_schnet_workload(wl, t[:4], 1, replicas=(R - 1,))          # (builds the stored lists: passes of more than 3 frames run on them)
         vl = (wl["gnn"]._static or {}).get("verlet")
         assert vl is not None, "the timed stack runs on stored Verlet lists"
         b0 = vl.builds()
