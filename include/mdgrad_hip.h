@@ -635,6 +635,67 @@ int mdg_grad_jobs(const MdgGradJob* jobs, int n_jobs, float* flat, float alpha, 
                   int accumulate, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * One SchNet evaluation per call (csrc/schnet_eval.hip, round 6): what GNNPotentials.forward + compute_grad
+ * (torchmd/interface.py:86-136, torchmd/md.py:23-31: F = -dU/dx by autograd through nff/nn/models/schnet.py:113-171) and the
+ * adjoint's vector-Jacobian product of it (torchmd/sovlers.py:229-233: d(w.F)/dx, d(w.F)/dtheta by double autograd) compute,
+ * as the hand-derived sweeps of mdgrad_amd/nn/analytic.py -- primal (+ tangent along w), turn at the readout, reverse -- with
+ * every launch of the evaluation (edge geometry, the fused interaction-block kernels, the row chains of the node-level layers,
+ * the batched parameter-gradient reductions) enqueued by one C++ loop on `stream`.  The caller describes the network and the
+ * topology with DEVICE pointers and hands over one workspace of mdg_schnet_workspace() floats; nothing is allocated inside.
+ *
+ *   layer[i]   one interaction block (nff/nn/modules.py:514-575): Gaussian basis + filter network (`filt`), message_node_filter
+ *              (Wn [F, A], bn), update MLP (U1 [A, F], c1; U2 [A, A], c2), torch.nn.Linear layout.  bf16 / bf16_rev: bf16 MFMA
+ *              operands in the forward-type / reverse sweeps of the filter network; rows16: the block's kernels gather bf16
+ *              mirrors of the node rows (mdg_cfconv_*_rows16); b2col: d/d b2 from the spare filter column (mdg_cfconv_bwd_theta).
+ *              off_*: offset of each parameter in the flat parameter-gradient vector (tinydiffeq.py:106-108 order).
+ *   readout    L1 [H, A], l1 [H], L2 [H] (nff/nn/utils.py:56-75: Linear, shifted_softplus, Linear(H -> 1)).
+ *   r0, h0     embedding rows atom_embed.weight[z] [N, A] and the first block's filtered rows Wn r0 + bn [N, F] (neither depends
+ *              on the positions: persistent buffers of the caller); h0_16: bf16 mirror of h0 (first block rows16).
+ *   onehot, uniq, n_species    [N, S] one-hot of the species and the S embedding rows in use (gradient of atom_embed.weight).
+ *   topology   half list nbr [E, 2] + image offsets [E, 3] and the per-atom rows col / eid / cnt of the same list
+ *              (mdg_nbr_*; capacity-padded lists: n_valid = device count of real rows).  masked: the list was searched with a
+ *              skin -- pairs beyond `cutoff` in `cell` at the current positions are skipped (mdg_edge_geom_masked).
+ * Results are bitwise those of the launch-by-launch sequence (tests/test_gpu_schnet_plan.py).
+ */
+#define MDG_SCHNET_MAX_LAYERS 8
+typedef struct {
+    MdgFilterNet filt;
+    const float *Wn, *bn, *U1, *c1, *U2, *c2;
+    int64_t off_W1, off_b1, off_W2, off_b2, off_Wn, off_bn, off_U1, off_c1, off_U2, off_c2;
+    int32_t bf16, bf16_rev, rows16, b2col;
+} MdgSchnetLayer;
+typedef struct {
+    int32_t n_atoms, n_layers, n_atom_basis, n_readout;
+    MdgSchnetLayer layer[MDG_SCHNET_MAX_LAYERS];
+    const float *L1, *l1, *L2;
+    int64_t off_L1, off_l1, off_L2, off_embed;
+    const float *r0, *h0;
+    const uint16_t* h0_16;
+    const float* onehot;
+    const int64_t* uniq;
+    int32_t n_species, masked;
+    const int64_t* nbr;
+    const float* offsets;
+    int64_t n_edges;
+    const int32_t *col, *eid, *cnt;
+    const int32_t* n_valid;
+    int32_t max_nbr;
+    float cutoff;
+    MdgCell cell;
+    float* ws;
+    int64_t ws_floats;
+} MdgSchnetPlan;              /* host struct of DEVICE pointers */
+int64_t mdg_schnet_plan_sizeof(void);      /* sizeof(MdgSchnetPlan): bindings in other languages check their layout against it */
+/* floats of workspace: dual = 0 for mdg_schnet_force, dual = 1 for mdg_schnet_force_vjp (theta != 0: with parameter gradients) */
+int64_t mdg_schnet_workspace(const MdgSchnetPlan* plan /*host*/, int dual, int theta);
+/* force [N, 3] = -dU/dx.  energy_colsum [H] (nullable): column sums of the readout's activations; U = L2 . colsum + N l2 */
+int mdg_schnet_force(const MdgSchnetPlan* plan /*host*/, const float* x, float* force, float* energy_colsum, void* stream);
+/* force, dwf [N, 3] = d(w.F)/dx and, theta_flat != NULL, theta_flat += alpha * (t ? t[*idx] - t[*idx - 1] : 1) * dU_dot/dtheta
+ * (callers pass alpha = -1: w.F = -U_dot; t / idx: the device-side interval weight of sovlers.py:160, together or NULL) */
+int mdg_schnet_force_vjp(const MdgSchnetPlan* plan /*host*/, const float* x, const float* w, float* force, float* dwf,
+                         float* theta_flat, float alpha, const float* t, const int64_t* idx, float* energy_colsum, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Nose-Hoover-chain algebra of the generic (non-fused) integrator path as single launches
  * (replaces the elementwise/reduction ops of NoseHooverChain.forward after the force,
  *  torchmd/md.py:221-240, and the thermostat part of its vjp).

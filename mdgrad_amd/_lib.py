@@ -66,6 +66,27 @@ class MdgChainStage(C.Structure):
                [(n, C.c_int32) for n in ("K", "M", "trans", "act", "mode", "pad_")]
 
 
+SCHNET_MAX_LAYERS = 8
+
+
+class MdgSchnetLayer(C.Structure):
+    """One interaction block of MdgSchnetPlan (include/mdgrad_hip.h)."""
+    _fields_ = [("filt", MdgFilterNet)] + [(n, C.c_void_p) for n in ("Wn", "bn", "U1", "c1", "U2", "c2")] + \
+               [("off_" + n, C.c_int64) for n in ("W1", "b1", "W2", "b2", "Wn", "bn", "U1", "c1", "U2", "c2")] + \
+               [(n, C.c_int32) for n in ("bf16", "bf16_rev", "rows16", "b2col")]
+
+
+class MdgSchnetPlan(C.Structure):
+    """A SchNet network + topology + workspace for mdg_schnet_force / mdg_schnet_force_vjp (include/mdgrad_hip.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("n_atoms", "n_layers", "n_atom_basis", "n_readout")] + \
+               [("layer", MdgSchnetLayer * SCHNET_MAX_LAYERS)] + [(n, C.c_void_p) for n in ("L1", "l1", "L2")] + \
+               [(n, C.c_int64) for n in ("off_L1", "off_l1", "off_L2", "off_embed")] + \
+               [(n, C.c_void_p) for n in ("r0", "h0", "h0_16", "onehot", "uniq")] + [("n_species", C.c_int32), ("masked", C.c_int32)] + \
+               [("nbr", C.c_void_p), ("offsets", C.c_void_p), ("n_edges", C.c_int64)] + \
+               [(n, C.c_void_p) for n in ("col", "eid", "cnt", "n_valid")] + [("max_nbr", C.c_int32), ("cutoff", C.c_float)] + \
+               [("cell", MdgCell), ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+
+
 CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512
 BONDED_BOND, BONDED_ANGLE = 0, 1                 # include/mdgrad_hip.h MDG_BONDED_*
 CFCONV_BF16, CFCONV_ROWS16 = 1, 2                # include/mdgrad_hip.h MDG_CFCONV_*
@@ -182,6 +203,10 @@ _SIGNATURES = {
                                            P, P, P, P, C.c_int, C.c_int64, P, P]),
     "mdg_traj_adj_small_stale": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms), P, P, P, P, P, P,
                                            P, P, P, P, P, P, P, C.c_int, C.c_int64, P, P]),
+    "mdg_schnet_plan_sizeof": (C.c_int64, []),
+    "mdg_schnet_workspace": (C.c_int64, [C.POINTER(MdgSchnetPlan), C.c_int, C.c_int]),
+    "mdg_schnet_force": (C.c_int, [C.POINTER(MdgSchnetPlan), P, P, P, P]),
+    "mdg_schnet_force_vjp": (C.c_int, [C.POINTER(MdgSchnetPlan), P, P, P, P, P, C.c_float, P, P, P, P]),
     "mdg_bonded_eval": (C.c_int, [P, C.c_int, C.POINTER(C.c_float), C.c_int, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P,
                                   C.c_float, C.c_int, P]),
 }

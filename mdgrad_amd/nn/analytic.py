@@ -777,11 +777,29 @@ _UNFUSED_MSG = ("this network's shapes are outside the fused interaction-block k
                 "times slower than csrc/cfconv_fused.hip")
 
 
+def _plan_inputs(net, z):
+    """(plan, (r0, h0, h0 mirror)) for the one-call evaluation of csrc/schnet_eval.hip, or (None, None)."""
+    from . import plan as _plan
+    convs = list(net.convolutions)
+    Ps = [_layer_params(c) for c in convs]
+    fns = [_filter_net(c, P, getattr(c, "filter_bf16", False) or getattr(net, "filter_bf16", False),
+                       getattr(net, "node_rows_bf16", False)) for c, P in zip(convs, Ps)]
+    pl = _plan.get(net, Ps, fns)
+    if pl is None:
+        return None, None
+    r0, h0 = _first_filter(net, z, Ps[0])
+    return pl, (r0, h0, _h0_mirror(net, h0) if fns[0].rows16 else None)
+
+
 @torch.no_grad()
 def force(net, z, x, topo, offsets=None, want_energy=True):
     if fused_ok(net):
         if chain_ok(net):                                         # (no library GEMM on this path: nothing to switch)
-            return _force_chain(net, z, x.detach().contiguous(), topo, want_energy)
+            x = x.detach().contiguous()
+            pl, rows = _plan_inputs(net, z) if x.is_cuda else (None, None)
+            if pl is not None:                                    # the whole evaluation as ONE C-ABI call (nn/plan.py)
+                return pl.force(x, topo, rows, want_energy)
+            return _force_chain(net, z, x, topo, want_energy)
         with _node_blas():
             return _force_fused(net, z, x.detach().contiguous(), topo, want_energy)
     _warn_once("unfused", _UNFUSED_MSG)
@@ -799,7 +817,13 @@ def force_vjp(net, z, x, w, topo, offsets=None, want_theta=True, want_energy=Tru
     argument is kept for callers that pass it explicitly.)"""
     if fused_ok(net):
         if chain_ok(net):                                         # (no library GEMM on this path: nothing to switch)
-            return _force_vjp_chain(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
+            x, w = x.detach().contiguous(), w.detach().contiguous()
+            pl, rows = _plan_inputs(net, z) if x.is_cuda else (None, None)
+            if pl is not None:                                    # the whole evaluation as ONE C-ABI call (nn/plan.py)
+                acc = (accum if accum is not None else ops.ThetaAccum(net.parameters())) if want_theta else None
+                U, F, dwf = pl.force_vjp(x, w, topo, rows, z, acc, want_energy)
+                return U, F, dwf, (acc.views() if (want_theta and accum is None) else None)
+            return _force_vjp_chain(net, z, x, w, topo, want_theta, want_energy, accum)
         with _node_blas():
             return _force_vjp_fused(net, z, x.detach().contiguous(), w.detach().contiguous(), topo, want_theta, want_energy, accum)
     _warn_once("unfused", _UNFUSED_MSG)
