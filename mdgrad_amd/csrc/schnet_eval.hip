@@ -16,6 +16,20 @@
 
 namespace {
 
+// (a kernel, not hipMemsetAsync: the evaluation is captured into HIP graphs, and a memset NODE between kernel nodes was seen to
+//  race with its neighbours on ROCm 7.2 -- flaky non-finite replays; torch's zeros_ is a kernel too)
+__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+int zero_fill(float* p, size_t n, hipStream_t st) {              // n floats, p 16-byte aligned; rounds up to whole float4s (arena slack)
+    const size_t n4 = (n + 3) / 4;
+    if (n4 == 0) return MDG_OK;
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4);
+    MDG_CHECK_LAUNCH("zero_kernel");
+    return MDG_OK;
+}
+
 struct Arena {
     float* base;
     size_t off;
@@ -276,7 +290,7 @@ int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, flo
         J.atb(P.off_L1, N, H, A, yb, r_fin, ydb, rd_fin);
         J.colsum(P.off_l1, N, H, yb);
     }
-    if (!dry) MDG_HIP(hipMemsetAsync(B.both, 0, sizeof(float) * 2 * (size_t)P.n_edges, st));   // (one fill for the two per-edge accumulators)
+    MDG_RUN(zero_fill(B.both, 2 * (size_t)P.n_edges, st));            // (one fill for the two per-edge accumulators)
     float *d_b = B.both, *dd_b = B.both + P.n_edges;
     for (int idx = nl - 1; idx >= 0; --idx) {
         const MdgSchnetLayer& S = P.layer[idx];
@@ -387,7 +401,7 @@ extern "C" int mdg_schnet_force(const MdgSchnetPlan* plan, const float* x, float
     MDG_TRY(forward_and_turn(P, B, x, nullptr, false, energy_colsum != nullptr, stream, dry));
     const int N = P.n_atoms, A = P.n_atom_basis;
     float* dU_dd = B.both;
-    MDG_HIP(hipMemsetAsync(dU_dd, 0, sizeof(float) * (size_t)P.n_edges, st));
+    MDG_TRY(zero_fill(dU_dd, (size_t)P.n_edges, st));
     const float* rb = B.g0;
     const void* mg = P.layer[P.n_layers - 1].rows16 ? (const void*)B.f016 : (const void*)B.f0;
     for (int idx = P.n_layers - 1; idx >= 0; --idx) {
