@@ -930,7 +930,9 @@ def _golden_water192():
     return g, sd, prm
 
 
-def build_water192(dev):
+def build_water192(dev, R=1):
+    """R = 1: the golden's box.  R > 1: R copies of it stacked into one System (System.replicate: replicas never interact,
+    one thermostat chain each) -- what the reference's sim_list loop (demo/fit_rdf_gnn.py:386-399) runs one after the other."""
     from mdgrad_amd import potentials as P
     from mdgrad_amd.interface import GNNPotentials, PairPotentials, Stack
     from mdgrad_amd.md import NoseHooverChain
@@ -940,6 +942,8 @@ def build_water192(dev):
     system = System(positions=np.asarray(g["pos"], dtype=np.float64), cell=np.asarray(g["cell"], dtype=np.float64),
                     numbers=g["numbers"], masses=np.asarray(g["masses"], dtype=np.float64), device=dev)
     system.set_velocities(np.asarray(g["vel"], dtype=np.float64))
+    if R > 1:
+        system = system.replicate(R)
     net = get_model(prm)
     net.load_state_dict(sd)
     gnn = GNNPotentials(system, net, cutoff=float(g["cutoff"]))
@@ -1070,6 +1074,93 @@ def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmu
         _later(cpu_part)
     return out
 
+
+
+def run_water192_stacked(args, rank, world, dev, mdist, R=64, steps=10, warmup=3):
+    """config #3's system the many-replica way -- R = 64 copies of the 192-atom water box stacked into ONE
+    trajectory (12 288 atoms; per-replica thermostats and neighbour lists), the way the 108-atom LJ headline runs 16 384
+    replicas: one system per GPU leaves the chip idle between 5-15 us launches, R systems fill the same launches.  Parity:
+    replicas 0 and R - 1 start from the golden's state, so the first 8 steps of each must be the REFERENCE's own run (G14)
+    and the summed parameter gradient R x the reference's."""
+    from mdgrad_amd.observable import rdf
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g, sd, prm, system, net, gnn, integ = build_water192(dev, R)
+    base = build_water192(dev, 1)[3]
+    N = len(base)
+    T = 21
+    dt = float(g["dt"])
+    obs = rdf(base, nbins=40, r_range=(0.6, 5.0), index_tuple=(g["idx_O"].tolist(), g["idx_H"].tolist()))
+    target = torch.ones(40, device=dev)
+    params = list(integ.parameters())
+    opt = torch.optim.Adam(params, lr=1e-6)
+    y0_dev = tuple(x.clone() for x in integ.get_inital_states(wrap=True))
+    par = None
+    if rank == 0:
+        nf = g["q_t"].shape[0]
+        t9 = torch.Tensor([dt * i for i in range(nf)]).to(dev)
+        v_t, q_t, pv_t = odeint_adjoint(integ, tuple(x.clone() for x in y0_dev), t9, method="NH_verlet")
+        qr, vr = q_t.reshape(nf, R, N, 3), v_t.reshape(nf, R, N, 3)
+        loss = 0.0
+        for r in range(R):                                    # the golden's loss, per replica
+            gr = obs(qr[::2, r])[2]
+            loss = loss + gr.pow(2).mean() + qr[-1, r].pow(2).mean() * 1e-3 + vr[-1, r].pow(2).sum() * 1e-2
+        loss.backward()
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params]).cpu().numpy() / R
+        ref = g["grad_flat"]
+        qn = qr.detach().cpu().numpy()
+        par = {"vs": "the reference's CPU run (golden G14) on replicas 0 and %d of the stack" % (R - 1), "steps": int(nf - 1),
+               "max_abs_dq": float(max(np.abs(qn[:, 0] - g["q_t"]).max(), np.abs(qn[:, R - 1] - g["q_t"]).max())),
+               "max_abs_dq_any_replica": float(np.abs(qn - g["q_t"][:, None]).max()),
+               "rel_dtheta": float(np.abs(flat - ref).max() / np.abs(ref).max()),
+               "cos_dtheta": float((flat.astype(np.float64) * ref).sum() / (np.linalg.norm(flat.astype(np.float64)) * np.linalg.norm(ref)))}
+        opt.zero_grad(set_to_none=True)
+    # timed passes: every replica its own velocities (a scaled copy of the golden's: 0.9 .. 1.1)
+    v0 = y0_dev[0].reshape(R, N, 3) * torch.linspace(0.9, 1.1, R, device=dev)[:, None, None]
+    y0_dev = (v0.reshape(-1, 3).contiguous(),) + tuple(y0_dev[1:])
+    t = torch.Tensor([dt * i for i in range(T)]).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y0 = tuple(x.clone() for x in y0_dev)
+        v_t, q_t, pv_t = odeint_adjoint(integ, y0, t, method="NH_verlet")
+        loss = (obs(q_t[::2].reshape(-1, N, 3))[2] - target).pow(2).mean()       # (replicas as further frames of the same box)
+        loss.backward()
+        mdist.all_reduce_grads(params)
+        opt.step()
+        return loss, q_t
+
+    for _ in range(warmup):
+        step()
+    mdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, q_last = step()
+    torch.cuda.synchronize()
+    mdist.barrier()
+    el_rank = time.perf_counter() - t0
+    el = mdist.max_over_ranks(el_rank, dev)
+    if not (_finite(q_last) and all(_finite(p) for p in params)):
+        raise SystemExit("bench: non-finite trajectory or parameters -- the measurement would be invalid")
+    md_steps = R * (T - 1) * world * steps
+    E = int(gnn.inputs["_topo"].n_edges)
+    A_, F_, G_, NC = prm["n_atom_basis"], prm["n_filters"], prm["n_gaussians"], prm["n_convolutions"]
+    step_flops = 21.0 * schnet_flops_forward(N * R, E, A_, F_, G_, NC)
+    sec_per_step = el / (steps * (T - 1))
+    out = {"metric": "MD steps/sec (fwd+adjoint), 192-atom water SchNet NHC, %d stacked replicas" % R, "value": md_steps / el,
+           "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "%d stacked 64-molecule water boxes (192 atoms each), SchNet A%d F%d G%d %d conv + prior, %d steps "
+                                  "fwd + O-H RDF loss + adjoint + Adam" % (R, A_, F_, G_, NC, T - 1),
+                      "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach()), "edges": E,
+                      "us_per_stacked_md_step": sec_per_step * 1e6}}
+    out["config"]["dist"] = _dist_record(mdist, dev, params, el_rank / steps * 1e3)
+    if rank == 0:
+        out["config"]["parity_reference_golden"] = par
+        out["roofline"] = {"bound": "mfma", "kernel": "whole MD step of the stack (%d atoms, E = %d edges)" % (N * R, E),
+                           "achieved": step_flops / sec_per_step / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                           "frac": step_flops / sec_per_step / 1e12 / MFMA_F32_PEAK_TF, "traffic": None}
+    return out
 
 
 # ====================================================================================== 4096-atom LJ liquid
@@ -1383,7 +1474,7 @@ def _write_detail(out):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="all", choices=["all", "lj108", "exvol108", "schnet4096", "lj4096", "water192"])
+    ap.add_argument("--workload", default="all", choices=["all", "lj108", "exvol108", "schnet4096", "lj4096", "water192", "water192x64"])
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200,
                     help="timed passes (default: ~4.5 s of GPU time on the headline workload, so that a coarse utilisation "
@@ -1427,6 +1518,8 @@ def main():
         out = run_lj4096(args, rank, world, dev, mdist, cpu)
     elif args.workload == "water192":
         out = run_water192(args, rank, world, dev, mdist, cpu)
+    elif args.workload == "water192x64":
+        out = run_water192_stacked(args, rank, world, dev, mdist, R=args.replicas or 64, steps=args.steps, warmup=args.warmup)
     elif args.workload == "exvol108":
         out = run_lj108(args, rank, world, dev, mdist, cpu, form="exvol", dt=0.01)
     else:
@@ -1493,6 +1586,11 @@ def main():
                     sec["schnet4096"]["bf16_rows"]["vs_f32"] = {k: v for k, v in (r16["config"].get("bf16_vs_f32") or {}).items() if k != "note"}
                 except (Exception, SystemExit) as e:
                     sec["schnet4096"]["bf16_rows"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            if "water192" in sec and "error" not in sec["water192"]:
+                try:                       # config #3's box the many-replica way
+                    sec["water192x64"] = run_water192_stacked(args, rank, world, dev, mdist, R=64, steps=10, warmup=3)
+                except (Exception, SystemExit) as e:
+                    sec["water192x64"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if "water192" in sec and "error" not in sec["water192"]:
                 try:
                     wb = run_water192(args, rank, world, dev, mdist, False, steps=20, warmup=4, bf16=True)
