@@ -496,6 +496,20 @@ int mdg_cfconv_bwd_rows16(const MdgFilterNet* net /*host*/, const float* d, cons
                           int64_t n_edges, int n_atoms, const uint16_t* h16, const uint16_t* hd16, const uint16_t* mb16,
                           const uint16_t* mdb16, float* d_b, float* dd_b, float* gW1, float* gb1, float* gW2, float* gmu,
                           float* gcoef, float* workspace, const int32_t* n_valid, void* stream);
+/* The G-wide stash of the filter network (round 6): its first Dense layer -- Gaussians, a = g W1^T + b1, s = ssp(a) and, with
+ * dd, the tangent sd = sigmoid(a) a_dot (nff/nn/modules.py:531-541, layers 0-2 of message_edge_filter) -- ONCE per undirected
+ * edge and evaluation, as [n_edges][W] bf16 rows (W = mdg_cfconv_stash_width(n_gauss): 32 or 64; 64 bytes per edge and
+ * quantity at W = 32), zero rows for pairs beyond the cutoff (d = -1) and padding.  mdg_cfconv_fwd_stashed is
+ * mdg_cfconv_fwd_bf16 / _rows16 reading the second layer's operands from it instead of recomputing them per directed slot
+ * (every edge from both ends, in each of the sweeps of an evaluation): the same bf16 operands, so bitwise the same outputs.
+ * d may be NULL when n_gauss + 2 <= W (the second layer's bias then rides in two spare k columns). */
+int mdg_cfconv_stash_width(int n_gauss);
+int mdg_cfconv_filter_stash(const MdgFilterNet* net /*host*/, const float* d, const float* dd /*nullable*/, int64_t n_edges,
+                            const int32_t* n_valid /*device, nullable*/, uint16_t* st_s, uint16_t* st_sd /*with dd*/, void* stream);
+int mdg_cfconv_fwd_stashed(const MdgFilterNet* net /*host*/, const uint16_t* st_s, const uint16_t* st_sd /*nullable: no tangent*/,
+                           const float* d /*see above*/, const void* h, const void* hd /*nullable*/, const int32_t* col,
+                           const int32_t* eid, const int32_t* cnt, int n_atoms, int max_nbr, float* m, float* md /*with st_sd*/,
+                           int rows16, void* stream);
 /* The reverse sweep with parameter gradients, every option in one entry.  flags: MDG_CFCONV_BF16 (bf16 MFMA operands as
  * mdg_cfconv_bwd_bf16) | MDG_CFCONV_ROWS16 (with BF16: h, hd, mb, mdb are bf16 mirrors, n_atoms rows each).  gb2[n_filters]
  * (nullable; needs mdg_cfconv_bias_column(n_gauss)): d/d b2 of the same scalar, sum over the edges of the filter output's
@@ -684,6 +698,8 @@ typedef struct {
     MdgCell cell;
     float* ws;
     int64_t ws_floats;
+    int32_t stash, pad_;      /* stash != 0: blocks with bf16 operands run mdg_cfconv_filter_stash once per evaluation and the
+                                 stashed forward-type sweeps (mdg_cfconv_fwd_stashed): same results, fewer instructions */
 } MdgSchnetPlan;              /* host struct of DEVICE pointers */
 int64_t mdg_schnet_plan_sizeof(void);      /* sizeof(MdgSchnetPlan): bindings in other languages check their layout against it */
 /* floats of workspace: dual = 0 for mdg_schnet_force, dual = 1 for mdg_schnet_force_vjp (theta != 0: with parameter gradients) */

@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmdgrad_hip.so")
+# (MDG_LIB: another build of the same library, e.g. a compile-time variant of one kernel file for an A/B run -- tools/variants.sh)
+LIB_PATH = os.environ.get("MDG_LIB") or os.path.join(_HERE, "lib", "libmdgrad_hip.so")
 
 MAX_TERMS, MAX_THETA, MAX_CHAINS = 4, 3, 16
 PAIR_LJ, PAIR_MORSE, PAIR_BUCK, PAIR_YUKAWA = 0, 1, 2, 3
@@ -84,7 +85,7 @@ class MdgSchnetPlan(C.Structure):
                [(n, C.c_void_p) for n in ("r0", "h0", "h0_16", "onehot", "uniq")] + [("n_species", C.c_int32), ("masked", C.c_int32)] + \
                [("nbr", C.c_void_p), ("offsets", C.c_void_p), ("n_edges", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("col", "eid", "cnt", "n_valid")] + [("max_nbr", C.c_int32), ("cutoff", C.c_float)] + \
-               [("cell", MdgCell), ("ws", C.c_void_p), ("ws_floats", C.c_int64)]
+               [("cell", MdgCell), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("stash", C.c_int32), ("pad_", C.c_int32)]
 
 
 CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512
@@ -192,6 +193,9 @@ _SIGNATURES = {
     "mdg_cfconv_bwd_rows16": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                                         P, P]),
     "mdg_rows_to_bf16": (C.c_int, [P, C.c_int64, C.c_int, C.c_int, P, P]),
+    "mdg_cfconv_stash_width": (C.c_int, [C.c_int]),
+    "mdg_cfconv_filter_stash": (C.c_int, [C.POINTER(MdgFilterNet), P, P, C.c_int64, P, P, P, P]),
+    "mdg_cfconv_fwd_stashed": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, P, P, P, P, P, C.c_int, C.c_int, P, P, C.c_int, P]),
     "mdg_cfconv_bias_column": (C.c_int, [C.c_int]),
     "mdg_cfconv_bwd_theta": (C.c_int, [C.POINTER(MdgFilterNet), P, P, P, C.c_int64, C.c_int, P, P, P, P, P, P, P, P, P, P, P, P,
                                        P, P, C.c_int, P]),

@@ -103,6 +103,10 @@ struct FwdArgs {
     const int32_t *col, *eid, *cnt;
     int N, max_nbr;
     float *m, *md, *hsum, *hdsum;
+    // STASH variants (round 6): the filter network's hidden activations per undirected edge, [E][GP] bf16 each, written once per
+    // evaluation by filter_stash_kernel -- s = ssp(a) and its tangent sd = sigmoid(a) a_dot, exactly the bf16 operands the
+    // recomputing kernel feeds its second Dense layer (zero rows for pairs beyond the cutoff)
+    const unsigned short *st_s, *st_sd;
 };
 
 template <int FT>
@@ -400,12 +404,18 @@ __device__ __forceinline__ bf16x8 pack8(const float (&f)[8]) {
 // (2^-17 relative) -- instead of a masked add per filter value: the bias of a masked slot vanishes with the slot's zeroed
 // operand row, and the epilogue is the three fused multiply-adds of the aggregation alone.
 // (packed bf16 node rows leave room for one more wave per SIMD where the kernel carries no node tangent or the neighbour sums)
-template <int GP, int FT, bool TANGENT, bool SUMS, bool HASHD, bool BIASK, bool R16 = false>          // GP in {32, 64}
+// STASH (round 6): the A operands of the second Dense layer come from the per-edge stash instead of being
+// recomputed per directed slot -- no Gaussians, no first layer, no softplus (30 exp + 30 log + 30 rcp per slot and sweep, and
+// every undirected edge from both ends): the sweep keeps the G -> F product on the MFMA and the multiply-sum epilogue.  The
+// stash holds exactly the bf16 operands this kernel would have computed, so the results are bitwise the recomputing kernel's.
+template <int GP, int FT, bool TANGENT, bool SUMS, bool HASHD, bool BIASK, bool R16 = false, bool STASH = false>          // GP in {32, 64}
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? (R16 ? 3 : 2) : ((R16 && !HASHD) ? 4 : 3)) : 4) : 1)))
+__attribute__((amdgpu_waves_per_eu(GP == 32 ? (STASH ? (TANGENT ? 4 : 5)
+                                                     : (TANGENT ? (SUMS ? (R16 ? 3 : 2) : ((R16 && !HASHD) ? 4 : 3)) : 4)) : 1)))
 void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     static_assert(TANGENT || !HASHD, "node tangents come with the tangent sweep");
     static_assert(!R16 || FT == 8, "bf16 node rows: layers of more than 64 filters");
+    static_assert(!STASH || !SUMS, "the neighbour sums ride on the recomputing kernels");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int FP = 16 * FT;
     constexpr int KSB = GP + 8;                    // bf16 row stride (elements): 16-B aligned rows, conflict-free b128 reads
@@ -420,9 +430,11 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
     unsigned short* h1s = w2b + FP * KSB;                                    // [4 (+4) waves][16][KSB]
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave index: uniform)
     const int G = A.net.G, F = A.net.F, RS = A.net.RS;
+    if constexpr (!STASH) {
     for (int t = tid; t < GP * GP; t += 256) {
         const int j = t / GP, k = t % GP;
         w1b[j * KSB + k] = (j < G && k < G) ? f2bf(A.net.W1[j * G + k]) : 0;
+    }
     }
     for (int t = tid; t < FP * GP; t += 256) {
         const int c = t / GP, k = t % GP;
@@ -494,9 +506,24 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
             }
             const bool vin = t0 + li < cnt;
             const int ea = vin ? ea_raw : 0;
-            const float dload = A.d[ea];                          // (unconditional, with the tangent's: see cfconv_fwd_kernel)
-            const float ddload = TANGENT ? A.dd[ea] : 0.f;
-            const float draw = vin ? dload : -1.f;
+            // (STASH with the bias in the k columns: the stash row of a pair beyond the cutoff is zero -- bias columns included --
+            //  so the sweep needs neither the distance nor its tangent; the slots past the row's end are zeroed by `vin`)
+            constexpr bool NEED_D = !(STASH && BIASK);
+            float dload = 0.f, ddload = 0.f;
+            if constexpr (NEED_D) {
+                dload = A.d[ea];                                  // (unconditional, with the tangent's: see cfconv_fwd_kernel)
+                if constexpr (!STASH) ddload = TANGENT ? A.dd[ea] : 0.f;
+            }
+            bf16x8 sfr[STASH ? KB : 1], sdfr[(STASH && TANGENT) ? KB : 1];
+            if constexpr (STASH) {                                // 16 bytes per lane and k-block: 64 contiguous bytes per edge and quantity
+                const unsigned so = (unsigned)ea * (unsigned)GP + (unsigned)(lk * 8);
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    sfr[ks] = *reinterpret_cast<const bf16x8*>(A.st_s + so + ks * 32);
+                    if constexpr (TANGENT) sdfr[ks] = *reinterpret_cast<const bf16x8*>(A.st_sd + so + ks * 32);
+                }
+            }
+            const float draw = NEED_D ? (vin ? dload : -1.f) : (vin ? 0.f : -1.f);
             // a stored (Verlet) list may hold pairs that are beyond the cutoff now: mdg_edge_geom_masked marks them
             // d = -1 and they are skipped like the slots past the row's end
             const bool va = draw >= 0.f;
@@ -526,6 +553,14 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 }
             }
             bf16x8 af[KB], adf[KB];
+            if constexpr (STASH) {
+#pragma unroll
+                for (int ks = 0; ks < KB; ++ks) {
+                    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+                    af[ks] = va ? sfr[ks] : zero8;
+                    if (TANGENT) adf[ks] = va ? sdfr[ks] : zero8;
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < KB; ++ks) {
                 float gk[8], gdk[8];
@@ -564,6 +599,7 @@ void cfconv_fwd_bf16_kernel(const FwdArgs A) {
                 const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};      // (masked slot: see cfconv_fwd_kernel)
                 af[ks] = va ? *reinterpret_cast<const bf16x8*>(&h1w[li * KSB + ks * 32 + lk * 8]) : zero8;
                 if (TANGENT) adf[ks] = va ? *reinterpret_cast<const bf16x8*>(&h1dw[li * KSB + ks * 32 + lk * 8]) : zero8;
+            }
             }
 #pragma unroll
             for (int nt = 0; nt < FT; ++nt) {
@@ -616,6 +652,112 @@ template <int GP, int FT>
 size_t fwd_bf16_lds_bytes(bool tangent) {
     constexpr int FP = 16 * FT, KSB = GP + 8;
     return sizeof(float) * (4 * GP + FP) + sizeof(unsigned short) * ((size_t)GP * KSB + (size_t)FP * KSB + (tangent ? 8 : 4) * 16 * KSB);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The stash producer (round 6): the first Dense layer of the filter network once per undirected edge and evaluation --
+// Gaussians, a = g W1^T + b1, s = ssp(a), sd = sigmoid(a) a_dot -- with the ARITHMETIC OF cfconv_fwd_bf16_kernel (same bf16
+// operands, same MFMA, same rounding of the outputs), written as [E][GP] bf16 rows in the A-operand order of the second
+// layer's MFMA: 64 contiguous bytes per edge and quantity at GP = 32.  Pairs a stored list holds beyond the cutoff
+// (d = -1) and padding rows get zero rows: a consumer then needs no distance.  nff/nn/modules.py:531-541 (layers 0-2 of
+// message_edge_filter).
+struct StashArgs {
+    FilterDev net;
+    const float *d, *dd;
+    long long E;
+    const int32_t* n_valid;
+    unsigned short *st_s, *st_sd;
+};
+
+template <int GP, bool TANGENT, bool BIASK>
+__global__ __launch_bounds__(256) void filter_stash_kernel(const StashArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int KSB = GP + 8, KB = GP / 32;
+    float* mus = sm;
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    unsigned short* w1b = reinterpret_cast<unsigned short*>(b1s + GP);        // [GP rows j][KSB]   W1[j][k]
+    unsigned short* h1s = w1b + GP * KSB;                                      // [4 (+4) waves][16][KSB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = A.net.G;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int j = t / GP, k = t % GP;
+        w1b[j * KSB + k] = (j < G && k < G) ? f2bf(A.net.W1[j * G + k]) : 0;
+    }
+    for (int k = tid; k < GP; k += 256) {
+        const float c = k < G ? A.net.coef[k] : 0.f;
+        mus[k] = k < G ? A.net.mu[k] : 0.f;
+        cfs[k] = c * LOG2E;
+        c2s[k] = 2.f * c;
+        b1s[k] = k < G ? A.net.b1[k] : ((BIASK && k >= GP - 2) ? 1.4899244f : 0.f);    // ssp(ln(2 e - 1)) = 1: the bias columns
+    }
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    unsigned short* h1w = h1s + wid * 16 * KSB;
+    unsigned short* h1dw = h1s + (4 + wid) * 16 * KSB;
+    const long long nrows = A.n_valid ? min((long long)*A.n_valid, A.E) : A.E;
+    const long long ntiles = (A.E + 63) / 64;                    // (every row of the stash is written: padding rows as zeros)
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long e = tile * 64 + wid * 16 + li;
+        const bool in = e < nrows;
+        const float dload = in ? A.d[e] : -1.f;
+        const float ddload = (TANGENT && in) ? A.dd[e] : 0.f;
+        const bool va = dload >= 0.f;
+        const float da = va ? dload : PAD_D;
+        const float dda = (TANGENT && va) ? ddload : 0.f;
+        bf16x8 af[KB], adf[KB];
+#pragma unroll
+        for (int ks = 0; ks < KB; ++ks) {
+            float gk[8], gdk[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int k = ks * 32 + lk * 8 + t;
+                const float x = da - mus[k];
+                const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                gk[t] = g;
+                gdk[t] = TANGENT ? g * (c2s[k] * x) * dda : 0.f;
+            }
+            af[ks] = pack8(gk);
+            if (TANGENT) adf[ks] = pack8(gdk);
+        }
+#pragma unroll
+        for (int nt = 0; nt < GP / 16; ++nt) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accd = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+                const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&w1b[(nt * 16 + li) * KSB + ks * 32 + lk * 8]);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], bfr, acc, 0, 0, 0);
+                if (TANGENT) accd = __builtin_amdgcn_mfma_f32_16x16x32_bf16(adf[ks], bfr, accd, 0, 0, 0);
+            }
+            const int c = nt * 16 + li;
+            const float bias = b1s[c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sv, sg;
+                ssp_sig(acc[r] + bias, sv, sg);
+                h1w[(lk * 4 + r) * KSB + c] = (unsigned short)cvt_pk_bf16(sv, 0.f);
+                if (TANGENT) h1dw[(lk * 4 + r) * KSB + c] = (unsigned short)cvt_pk_bf16(sg * accd[r], 0.f);
+            }
+        }
+        // (h1w / h1dw are private to the wave: program order + the LDS counter suffice, no barrier)
+        if (e < A.E) {
+            const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < KB; ++ks) {
+                const size_t o = (size_t)e * GP + ks * 32 + lk * 8;
+                *reinterpret_cast<bf16x8*>(A.st_s + o) = va ? *reinterpret_cast<const bf16x8*>(&h1w[li * KSB + ks * 32 + lk * 8]) : zero8;
+                if (TANGENT)
+                    *reinterpret_cast<bf16x8*>(A.st_sd + o) = va ? *reinterpret_cast<const bf16x8*>(&h1dw[li * KSB + ks * 32 + lk * 8]) : zero8;
+            }
+        }
+    }
+}
+
+template <int GP>
+size_t stash_lds_bytes(bool tangent) {
+    constexpr int KSB = GP + 8;
+    return sizeof(float) * 4 * GP + sizeof(unsigned short) * ((size_t)GP * KSB + (tangent ? 8 : 4) * 16 * KSB);
 }
 
 template <int GP, int FT>
@@ -1618,13 +1760,13 @@ __global__ __launch_bounds__(64 * RED_WAVES) void cfconv_bwd_reduce_kernel(
 // MASK: the list was searched with a skin (mdg_nbr_verlet_rebuild); a pair counts only while the builders' own test holds at
 // the current positions -- D = x_j - x_i, reference minimum image, un-contracted d^2 < rc^2 and != 0 (topology.py:59-67):
 // the same arithmetic, so the pair set is the one a fresh search at the cutoff finds.  Pairs outside get d = -1.
+// (the geometry of one edge; products and sums are kept un-contracted so that the bits do not depend on the surrounding code)
+struct EdgeGeo { float d, dd, ux, uy, uz, wx, wy, wz; };
 template <bool MASK, bool DIAG>
-__global__ void edge_geom_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                 const int64_t* __restrict__ nbr, const float* __restrict__ off, long long E,
-                                 float* __restrict__ d, float* __restrict__ uhat, float* __restrict__ dd,
-                                 float* __restrict__ ddel, MdgCell cell, float rc2) {
-    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= E) return;
+__device__ __forceinline__ EdgeGeo edge_geometry(const float* __restrict__ x, const float* __restrict__ w,
+                                                 const int64_t* __restrict__ nbr, const float* __restrict__ off, long long e,
+                                                 const MdgCell& cell, float rc2) {
+#pragma clang fp contract(off)
     const long long i = nbr[2 * e], j = nbr[2 * e + 1];
     bool masked = false;
     if (MASK && i >= 0) {
@@ -1634,19 +1776,32 @@ __global__ void edge_geom_kernel(const float* __restrict__ x, const float* __res
         masked = !((b2 < rc2) && (b2 != 0.f));
     }
     float dx = -off[3 * e], dy = -off[3 * e + 1], dz = -off[3 * e + 2];
-    float wx = 0.f, wy = 0.f, wz = 0.f;
+    EdgeGeo g{};
     if (i >= 0) {
         dx += x[3 * i] - x[3 * j]; dy += x[3 * i + 1] - x[3 * j + 1]; dz += x[3 * i + 2] - x[3 * j + 2];
-        if (w) { wx = w[3 * i] - w[3 * j]; wy = w[3 * i + 1] - w[3 * j + 1]; wz = w[3 * i + 2] - w[3 * j + 2]; }
+        if (w) { g.wx = w[3 * i] - w[3 * j]; g.wy = w[3 * i + 1] - w[3 * j + 1]; g.wz = w[3 * i + 2] - w[3 * j + 2]; }
     }
     const float r = sqrtf(dx * dx + dy * dy + dz * dz);
     const float ir = 1.0f / r;
-    const float ux = dx * ir, uy = dy * ir, uz = dz * ir;
-    d[e] = masked ? -1.f : r;
-    uhat[3 * e] = ux; uhat[3 * e + 1] = uy; uhat[3 * e + 2] = uz;
+    g.ux = dx * ir; g.uy = dy * ir; g.uz = dz * ir;
+    g.d = masked ? -1.f : r;
+    g.dd = (masked || !w) ? 0.f : g.ux * g.wx + g.uy * g.wy + g.uz * g.wz;
+    return g;
+}
+
+template <bool MASK, bool DIAG>
+__global__ void edge_geom_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                 const int64_t* __restrict__ nbr, const float* __restrict__ off, long long E,
+                                 float* __restrict__ d, float* __restrict__ uhat, float* __restrict__ dd,
+                                 float* __restrict__ ddel, MdgCell cell, float rc2) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E) return;
+    const EdgeGeo g = edge_geometry<MASK, DIAG>(x, w, nbr, off, e, cell, rc2);
+    d[e] = g.d;
+    uhat[3 * e] = g.ux; uhat[3 * e + 1] = g.uy; uhat[3 * e + 2] = g.uz;
     if (w) {
-        dd[e] = masked ? 0.f : ux * wx + uy * wy + uz * wz;
-        ddel[3 * e] = wx; ddel[3 * e + 1] = wy; ddel[3 * e + 2] = wz;
+        dd[e] = g.dd;
+        ddel[3 * e] = g.wx; ddel[3 * e + 1] = g.wy; ddel[3 * e + 2] = g.wz;
     }
 }
 
@@ -1691,9 +1846,9 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // this instantiation) times the CU count.  (768 workgroups on 256 CUs at 2 resident per CU ran as a full round
 // plus a half-empty one: -25 %.)  Cached per kernel instantiation and LDS size.
 template <typename K>
-int resident_blocks(K kernel, size_t lds) {
+int resident_blocks(K kernel, size_t lds, int cap = 4) {
     struct Entry { const void* k; size_t l; int n; };
-    static thread_local Entry cache[48];
+    static thread_local Entry cache[192];
     static thread_local int used = 0;
     for (int i = 0; i < used; ++i)
         if (cache[i].k == (const void*)kernel && cache[i].l == lds) return cache[i].n;
@@ -1702,9 +1857,9 @@ int resident_blocks(K kernel, size_t lds) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
         cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
-    if (per_cu > 4) per_cu = 4;
+    if (per_cu > cap) per_cu = cap;
     const int n = per_cu * cus;
-    if (used < 48) cache[used++] = Entry{(const void*)kernel, lds, n};
+    if (used < 192) cache[used++] = Entry{(const void*)kernel, lds, n};
     return n;
 }
 
@@ -1740,7 +1895,10 @@ inline bool rows16_ok(const MdgFilterNet* net) { return net->n_filters > 64 && n
 
 int bwd_blocks(long long n_edges, bool theta) {
     const long long tiles = (n_edges + 63) / 64;
-    const long long want = theta ? 512 : 768;
+#ifndef MDG_BWD_THETA_BLOCKS
+#define MDG_BWD_THETA_BLOCKS 512
+#endif
+    const long long want = theta ? MDG_BWD_THETA_BLOCKS : 768;
     return (int)(tiles < want ? (tiles > 0 ? tiles : 1) : want);
 }
 
@@ -1839,12 +1997,15 @@ namespace {
 int cfconv_fwd_bf16_impl(const MdgFilterNet* net, const float* d, const float* dd, const float* h,
                          const float* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
                          int n_atoms, int max_nbr, float* m, float* md, float* hsum, float* hdsum,
-                         void* stream, bool rows16) {
+                         void* stream, bool rows16, const uint16_t* st_s = nullptr, const uint16_t* st_sd = nullptr) {
     int GP, FT;
     int rc = shape_ok(net, GP, FT);
     if (rc) return rc;
-    MDG_CHECK_ARG(d && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd_bf16: bad arguments");
-    const bool tangent = dd != nullptr;
+    const bool stash = st_s != nullptr;
+    MDG_CHECK_ARG((d || stash) && h && col && eid && cnt && m && n_atoms > 0 && max_nbr > 0, "cfconv_fwd_bf16: bad arguments");
+    const bool tangent = stash ? st_sd != nullptr : dd != nullptr;
+    MDG_CHECK_ARG(!stash || (!hsum && !hdsum && (d || net->n_gauss + 2 <= GP)),
+                  "cfconv_fwd_stashed: no neighbour sums; the distances are needed when the bias does not ride in the k columns");
     MDG_CHECK_ARG(!tangent || md, "cfconv_fwd_bf16: the tangent sweep needs md");
     MDG_CHECK_ARG((long long)n_atoms * net->n_filters < (1LL << 30), "cfconv_fwd_bf16: n_atoms x n_filters must stay below 2^30");
     MDG_CHECK_ARG(tangent || (!hd && !md && !hdsum), "cfconv_fwd_bf16: tangent buffers without dd");
@@ -1856,12 +2017,17 @@ int cfconv_fwd_bf16_impl(const MdgFilterNet* net, const float* d, const float* d
     hipStream_t st = (hipStream_t)stream;
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
     FwdArgs a{dev_of(net, f0), d, dd, rows16 ? at_col16(h, f0) : at_col(h, f0), rows16 ? at_col16(hd, f0) : at_col(hd, f0), col,
-              eid, cnt, n_atoms, max_nbr, at_col(m, f0), at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
-#define MDG_FWDB3(GP_, FT_, T_, S_, H_, B_, R_)                                                                    \
+              eid, cnt, n_atoms, max_nbr, at_col(m, f0), at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0), st_s, st_sd};
+#define MDG_FWDB4(GP_, FT_, T_, S_, H_, B_, R_, X_)                                                                \
     do {                                                                                                           \
         const size_t lds = fwd_bf16_lds_bytes<GP_, FT_>(T_);                                                       \
-        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_>, lds);               \
-        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+        const int want = resident_blocks(cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_, X_>, lds, X_ ? 6 : 4); \
+        hipLaunchKernelGGL((cfconv_fwd_bf16_kernel<GP_, FT_, T_, S_, H_, B_, R_, X_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+    } while (0)
+#define MDG_FWDB3(GP_, FT_, T_, S_, H_, B_, R_)                                                                    \
+    do {                                                                                                           \
+        if (stash) MDG_FWDB4(GP_, FT_, T_, false, H_, B_, R_, (!(S_)));   /* (S_ = true never comes with a stash) */ \
+        else MDG_FWDB4(GP_, FT_, T_, S_, H_, B_, R_, false);                                                       \
     } while (0)
 #define MDG_FWDB2(GP_, FT_, T_, S_, H_, B_)                                                                        \
     do {                                                                                                           \
@@ -1880,6 +2046,7 @@ int cfconv_fwd_bf16_impl(const MdgFilterNet* net, const float* d, const float* d
     else if (GP == 32) MDG_FWDB(32, 8);
     else if (FT == 4) MDG_FWDB(64, 4);
     else MDG_FWDB(64, 8);
+#undef MDG_FWDB4
 #undef MDG_FWDB3
 #undef MDG_FWDB2
 #undef MDG_FWDB
@@ -1906,6 +2073,50 @@ extern "C" int mdg_cfconv_fwd_rows16(const MdgFilterNet* net, const float* d, co
                                      void* stream) {
     return cfconv_fwd_bf16_impl(net, d, dd, reinterpret_cast<const float*>(h16), reinterpret_cast<const float*>(hd16), col, eid,
                                 cnt, n_atoms, max_nbr, m, md, hsum, hdsum, stream, true);
+}
+
+// The first Dense layer of the filter network once per undirected edge: st_s (and, with dd, st_sd) [n_edges][GP] bf16,
+// GP = 32 for n_gaussians <= 32, else 64 (mdg_cfconv_stash_width).  See filter_stash_kernel.
+extern "C" int mdg_cfconv_stash_width(int n_gauss) { return n_gauss <= 32 ? 32 : 64; }
+
+extern "C" int mdg_cfconv_filter_stash(const MdgFilterNet* net, const float* d, const float* dd, int64_t n_edges,
+                                       const int32_t* n_valid, uint16_t* st_s, uint16_t* st_sd, void* stream) {
+    int GP, FT;
+    int rc = shape_ok(net, GP, FT);
+    if (rc) return rc;
+    MDG_CHECK_ARG(d && st_s && n_edges >= 0 && (dd == nullptr) == (st_sd == nullptr), "cfconv_filter_stash: bad arguments");
+    MDG_CHECK_ARG(aligned16(st_s) && aligned16(st_sd), "cfconv_filter_stash: the stash must be 16-byte aligned");
+    MDG_CHECK_ARG(n_edges * (long long)GP < (1LL << 32), "cfconv_filter_stash: n_edges x %d must stay below 2^32", GP);
+    if (n_edges == 0) return MDG_OK;
+    const bool tangent = dd != nullptr, biask = net->n_gauss + 2 <= GP;
+    StashArgs a{dev_of(net, 0), d, dd, (long long)n_edges, n_valid, st_s, st_sd};
+    const long long tiles = (n_edges + 63) / 64;
+    const int nb = (int)(tiles < 2048 ? tiles : 2048);
+    hipStream_t st = (hipStream_t)stream;
+#define MDG_STASH(GP_)                                                                                             \
+    do {                                                                                                           \
+        const size_t lds = stash_lds_bytes<GP_>(tangent);                                                          \
+        if (tangent) { if (biask) hipLaunchKernelGGL((filter_stash_kernel<GP_, true, true>), dim3(nb), dim3(256), lds, st, a);   \
+                       else hipLaunchKernelGGL((filter_stash_kernel<GP_, true, false>), dim3(nb), dim3(256), lds, st, a); }      \
+        else { if (biask) hipLaunchKernelGGL((filter_stash_kernel<GP_, false, true>), dim3(nb), dim3(256), lds, st, a);          \
+               else hipLaunchKernelGGL((filter_stash_kernel<GP_, false, false>), dim3(nb), dim3(256), lds, st, a); }             \
+    } while (0)
+    if (GP == 32) MDG_STASH(32); else MDG_STASH(64);
+#undef MDG_STASH
+    MDG_CHECK_LAUNCH("filter_stash_kernel");
+    return MDG_OK;
+}
+
+// mdg_cfconv_fwd_bf16 / mdg_cfconv_fwd_rows16 (rows16 != 0: h, hd are bf16 mirrors) with the second layer's operands read
+// from the stash of mdg_cfconv_filter_stash: tangent sweep iff st_sd (and md) are given.  d: the edge distances, needed only
+// when the bias does not ride in the k columns (n_gaussians + 2 > stash width); NULL otherwise.  Bitwise the outputs of the
+// recomputing entry points.
+extern "C" int mdg_cfconv_fwd_stashed(const MdgFilterNet* net, const uint16_t* st_s, const uint16_t* st_sd, const float* d,
+                                      const void* h, const void* hd, const int32_t* col, const int32_t* eid, const int32_t* cnt,
+                                      int n_atoms, int max_nbr, float* m, float* md, int rows16, void* stream) {
+    MDG_CHECK_ARG(st_s && (st_sd != nullptr) == (md != nullptr) && (st_sd || !hd), "cfconv_fwd_stashed: the tangent operands come together");
+    return cfconv_fwd_bf16_impl(net, d, nullptr, static_cast<const float*>(h), static_cast<const float*>(hd), col, eid, cnt, n_atoms,
+                                max_nbr, m, md, nullptr, nullptr, stream, rows16 != 0, st_s, st_sd);
 }
 
 extern "C" int mdg_cfconv_rows16_supported(int n_gauss, int n_filters) {

@@ -50,6 +50,7 @@ struct Bufs {
         float *hdb, *hb;                                    // reverse: adjoints of (hd, h)
         float *g0, *g1, *e0, *e1, *f0, *f1; uint16_t *f016, *f116;   // reverse chain below this block (idx > 0) / rb of block 0 in g0
         float *gW1, *gb1, *gW2, *gb2;
+        uint16_t *st_s, *st_sd;                             // the block's filter stash of this evaluation (null: recompute)
     } L[MDG_SCHNET_MAX_LAYERS];
     float *y0, *y1, *ysig, *ypre0, *ypre1, *g0, *g1, *e0, *e1, *f0, *f1; uint16_t *f016, *f116;   // the turn
     float *cf_ws, *en_ws, *gj_ws;
@@ -69,6 +70,14 @@ size_t carve(const MdgSchnetPlan& P, bool dual, bool theta, float* base, Bufs& B
         const size_t F = (size_t)S.filt.n_filters, G = (size_t)S.filt.n_gauss;
         Bufs::Layer& L = B.L[i];
         const bool sums = theta && !S.b2col;
+        // (measured, profiles/r06_cfconv_kbench_stash.txt: with bf16 node rows the stashed sweeps take 38 / 48 / 55 us against
+        //  53 / 76 / 88 recomputing; with f32 rows the sweeps are gather-bound either way and the producer is a net loss --
+        //  so the stash goes with rows16.  The neighbour sums ride on the recomputing kernels.)
+        if (P.stash && S.bf16 && S.rows16 && !sums) {
+            const size_t W = (size_t)mdg_cfconv_stash_width((int)G);
+            L.st_s = a.take16(E * W);
+            if (dual) L.st_sd = a.take16(E * W);
+        }
         L.m = a.take(N * F);
         if (dual) L.md = a.take(N * F);
         if (sums) { L.hsum = a.take(N * F); if (dual && i > 0) L.hdsum = a.take(N * F); }
@@ -182,7 +191,10 @@ int geom(const MdgSchnetPlan& P, const Bufs& B, const float* x, const float* w, 
 }
 
 int conv_fwd(const MdgSchnetPlan& P, const MdgSchnetLayer& S, const float* d, const float* dd, const void* h, const void* hd,
-             float* m, float* md, float* hsum, float* hdsum, void* st) {
+             float* m, float* md, float* hsum, float* hdsum, void* st, const Bufs::Layer* stl = nullptr) {
+    if (stl && stl->st_s && !hsum)                              // second filter layer's operands from this evaluation's stash
+        return mdg_cfconv_fwd_stashed(&S.filt, stl->st_s, dd ? stl->st_sd : nullptr, d, h, hd, P.col, P.eid, P.cnt, P.n_atoms, P.max_nbr,
+                                      m, md, S.rows16, st);
     if (S.rows16)
         return mdg_cfconv_fwd_rows16(&S.filt, d, dd, (const uint16_t*)h, (const uint16_t*)hd, P.col, P.eid, P.cnt, P.n_atoms, P.max_nbr,
                                      m, md, hsum, hdsum, st);
@@ -208,9 +220,14 @@ int conv_bwd(const MdgSchnetPlan& P, const MdgSchnetLayer& S, const Bufs& B, con
 }
 
 // Primal (+ tangent along w) sweep and the turn at the readout: analytic._chain_forward.
-int forward_and_turn(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, bool dual, bool want_pre0, void* st, bool dry) {
+int forward_and_turn(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, bool dual, bool want_pre0, void* st, bool dry,
+                     size_t zero_n) {                            // zero_n: floats of B.both the reverse sweeps accumulate into
     const int N = P.n_atoms, A = P.n_atom_basis, H = P.n_readout;
+    // (tried and dropped, round 6: geometry + accumulator fill + every block's stash in ONE launch -- 3 599 MD steps/s on the
+    //  stacked pass against 3 657 with the separate launches: one wave of four doing the latency-bound geometry of a 64-edge
+    //  tile serialises what edge_geom_kernel does with the whole chip)
     MDG_RUN(geom(P, B, x, w, st));
+    MDG_RUN(zero_fill(B.both, zero_n, (hipStream_t)st));
     const float *r = P.r0, *rd = nullptr;
     const void* hg = P.layer[0].rows16 ? (const void*)P.h0_16 : (const void*)P.h0;
     const void* hgd = nullptr;
@@ -218,7 +235,9 @@ int forward_and_turn(const MdgSchnetPlan& P, Bufs& B, const float* x, const floa
         const MdgSchnetLayer& S = P.layer[i];
         Bufs::Layer& L = B.L[i];
         const int F = S.filt.n_filters;
-        MDG_RUN(conv_fwd(P, S, B.d, dual ? B.dd : nullptr, hg, hgd, L.m, dual ? L.md : nullptr, L.hsum, hgd ? L.hdsum : nullptr, st));
+        if (L.st_s)
+            MDG_RUN(mdg_cfconv_filter_stash(&S.filt, B.d, dual ? B.dd : nullptr, P.n_edges, P.n_valid, L.st_s, dual ? L.st_sd : nullptr, st));
+        MDG_RUN(conv_fwd(P, S, B.d, dual ? B.dd : nullptr, hg, hgd, L.m, dual ? L.md : nullptr, L.hsum, hgd ? L.hdsum : nullptr, st, &L));
         Chain c;
         {   // update MLP: t = ssp(U1 m + c1), su = sigmoid(.), td = su (U1 md)
             MdgChainStage& s = c.add(S.U1, F, A, 0, 1, MDG_CHAIN_NONE);
@@ -275,7 +294,7 @@ void gathered_rows(const MdgSchnetPlan& P, const Bufs& B, int i, bool dual, cons
 int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, float* force, float* dwf, float* theta_flat, bool theta,
             float alpha, const float* t, const int64_t* idx_dev, float* energy_colsum, void* stream, bool dry, long long* gj_need) {
     hipStream_t st = (hipStream_t)stream;
-    MDG_TRY(forward_and_turn(P, B, x, w, true, energy_colsum != nullptr, stream, dry));
+    MDG_TRY(forward_and_turn(P, B, x, w, true, energy_colsum != nullptr, stream, dry, 2 * (size_t)P.n_edges));
     const int N = P.n_atoms, A = P.n_atom_basis, H = P.n_readout;
     const int nl = P.n_layers;
     Jobs J;
@@ -290,7 +309,6 @@ int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, flo
         J.atb(P.off_L1, N, H, A, yb, r_fin, ydb, rd_fin);
         J.colsum(P.off_l1, N, H, yb);
     }
-    MDG_RUN(zero_fill(B.both, 2 * (size_t)P.n_edges, st));            // (one fill for the two per-edge accumulators)
     float *d_b = B.both, *dd_b = B.both + P.n_edges;
     for (int idx = nl - 1; idx >= 0; --idx) {
         const MdgSchnetLayer& S = P.layer[idx];
@@ -317,7 +335,7 @@ int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, flo
         }
         if (theta || idx > 0) {
             // the aggregation is symmetric in the adjacency: fed (mdb, mb) the forward kernel returns the adjoints (hdb, hb) of (hd, h)
-            MDG_RUN(conv_fwd(P, S, B.d, B.dd, mdg, mg, L.hdb, L.hb, nullptr, nullptr, stream));
+            MDG_RUN(conv_fwd(P, S, B.d, B.dd, mdg, mg, L.hdb, L.hb, nullptr, nullptr, stream, &L));
             if (theta) {
                 if (rd_in) J.atb(S.off_Wn, N, F, A, L.hb, r_in, L.hdb, rd_in);
                 else J.atb(S.off_Wn, N, F, A, L.hb, r_in);
@@ -398,10 +416,9 @@ extern "C" int mdg_schnet_force(const MdgSchnetPlan* plan, const float* x, float
     const size_t need = carve(P, false, false, P.ws, B);
     MDG_CHECK_ARG((int64_t)need <= P.ws_floats, "schnet_force: workspace of %lld floats, %zu needed", (long long)P.ws_floats, need);
     hipStream_t st = (hipStream_t)stream;
-    MDG_TRY(forward_and_turn(P, B, x, nullptr, false, energy_colsum != nullptr, stream, dry));
+    MDG_TRY(forward_and_turn(P, B, x, nullptr, false, energy_colsum != nullptr, stream, dry, (size_t)P.n_edges));
     const int N = P.n_atoms, A = P.n_atom_basis;
     float* dU_dd = B.both;
-    MDG_TRY(zero_fill(dU_dd, (size_t)P.n_edges, st));
     const float* rb = B.g0;
     const void* mg = P.layer[P.n_layers - 1].rows16 ? (const void*)B.f016 : (const void*)B.f0;
     for (int idx = P.n_layers - 1; idx >= 0; --idx) {
@@ -411,7 +428,7 @@ extern "C" int mdg_schnet_force(const MdgSchnetPlan* plan, const float* x, float
         gathered_rows(P, B, idx, false, h, hd);
         MDG_TRY(conv_bwd(P, S, B, nullptr, h, nullptr, nullptr, mg, nullptr, dU_dd, nullptr, stream));
         if (idx > 0) {                                           // (the embedding below block 0 is not needed)
-            MDG_TRY(conv_fwd(P, S, B.d, nullptr, mg, nullptr, L.hb, nullptr, nullptr, nullptr, stream));
+            MDG_TRY(conv_fwd(P, S, B.d, nullptr, mg, nullptr, L.hb, nullptr, nullptr, nullptr, stream, &L));
             const MdgSchnetLayer& Sp = P.layer[idx - 1];
             const Bufs::Layer& Lp = B.L[idx - 1];
             Chain c;

@@ -55,8 +55,8 @@ struct RingLJ {
     TermConst t0;                                               // any other single-term form goes through pair_eval
 };
 
-__device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A) {
-    const TermConst t0 = term_prepare(A.terms.t[0], A.theta);
+__device__ __forceinline__ RingLJ ring_constants(const TrajArgs& A, int m = 0) {
+    const TermConst t0 = term_prepare(A.terms.t[m], A.theta);
     const float e4 = 4.f * t0.k1, cq = t0.c;
     RingLJ K;
     K.sig2 = t0.k0 * t0.k0; K.rc2 = t0.rc2;
@@ -271,7 +271,7 @@ __device__ __forceinline__ RingMask ring_mask_load(const uint8_t* __restrict__ m
             if (i < N)
                 for (int b = 0; b < 32; ++b) {
                     const int j = 32 * wd + b;
-                    if (j < N && mask[(size_t)i * N + j]) acc |= 1u << b;
+                    if (j < N && (!mask || mask[(size_t)i * N + j])) acc |= 1u << b;     // (no mask: an unmasked term of a two-term launch)
                 }
             M.w[4 * a + wd] = acc;
         }
@@ -390,6 +390,25 @@ __device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, co
     }
 }
 
+// NT terms of one pair form (round 6: the species mixtures of scripts/fit_mix.py -- index_tuple stacks, torchmd/interface.py:
+// 228-260): one ring sweep per term with the term's constants and its 128-bit mask rows, forces and Hessian.w added up, the
+// parameter sums kept per term.  The fused observable rides on the first term's sweep only (its flags are unmasked).
+template <int LEVEL, int RDF, int KIND, bool MASK, int NT>
+__device__ __forceinline__ void ring_force_terms(const RingLJ (&K)[NT], const RingRdf& X, const RingMask (&M)[NT], bool with_rdf, int N,
+                                                 int lane, const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g,
+                                                 float (&th)[NT][MDG_MAX_THETA], Vec3x2& rq, f32x2* __restrict__ lds) {
+    ring_force<LEVEL, RDF, KIND, MASK>(K[0], X, M[0], with_rdf, N, lane, q, w, f, g, th[0], rq, lds);
+    if constexpr (NT > 1 && LEVEL >= 1) {
+#pragma unroll
+        for (int m = 1; m < NT; ++m) {
+            Vec3x2 f2 = vzero(), g2 = vzero(), r2 = vzero();
+            ring_force<LEVEL, 0, KIND, MASK>(K[m], X, M[m], false, N, lane, q, w, f2, g2, th[m], r2, lds);
+            f.x += f2.x; f.y += f2.y; f.z += f2.z;
+            if constexpr (LEVEL >= 2) { g.x += g2.x; g.y += g2.y; g.z += g2.z; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ frame I/O
 // AoS [N,3] frames in HBM: lane l reads / writes the six consecutive floats of its two atoms.
 __device__ __forceinline__ Vec3x2 ring_load(const float* __restrict__ src, int N, int lane) {
@@ -466,15 +485,21 @@ __device__ __forceinline__ bool ring_frame_selected(const RingRdfArgs& F, int k)
 // RDF = false: one wave (= one replica) per workgroup.  RDF = true: sixteen waves share the workgroup's fine
 // histogram in LDS and stride over the replicas (persistent grid: the histogram is merged into HBM once per
 // workgroup); the waves are otherwise independent.
-template <bool RDF, int KIND, bool MASK = false>
+template <bool RDF, int KIND, bool MASK = false, int NT = 1>
 __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
+    static_assert(NT == 1 || (MASK && KIND != KIND_TABLE), "several terms: masked built-in forms");
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6, N3 = 3 * N;
-    const RingLJ K = ring_constants(A);
-    RingMask M{};
-    if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
+    RingLJ K[NT];
+    RingMask M[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        K[m] = ring_constants(A, m);
+        M[m] = RingMask{};
+        if constexpr (MASK) M[m] = ring_mask_load(A.terms.t[m].mask, N, lane);
+    }
     const int nf2 = RDF ? (F.nfine + 1) & ~1 : 0;
     uint32_t* hist = reinterpret_cast<uint32_t*>(smr);
     f32x2* lds = reinterpret_cast<f32x2*>(smr + nf2) + wid * 3 * 64;
@@ -513,9 +538,9 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
         ring_store(A.v_t + fr * N3, v, N, lane);
         if (nhc && lane < C) A.pv_t[fr * C + lane] = pv;
         Vec3x2 f, gu, ru, wu = vzero();
-        float tu[MDG_MAX_THETA];
+        float tu[NT][MDG_MAX_THETA];
         // (every force evaluation of the forward pass is at the positions of a stored frame: the RDF rides along)
-        ring_force<1, RDF ? 1 : 0, KIND, MASK>(K, X, M, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, tu, ru, lds);
+        ring_force_terms<1, RDF ? 1 : 0, KIND, MASK, NT>(K, X, M, RDF && ring_frame_selected(F, 0), N, lane, q, wu, f, gu, tu, ru, lds);
         for (int k = 0; k + 1 < T; ++k) {
             const float dt = A.t[k + 1] - A.t[k];
             // ---- first RHS at y_k (force cached), half kick + drift       sovlers.py:111-118
@@ -536,7 +561,7 @@ __global__ __launch_bounds__(RDF ? 1024 : 64) void traj_fwd_ring_kernel(const Tr
             q.x = q.x + (v.x + vh.x) * dt; q.y = q.y + (v.y + vh.y) * dt; q.z = q.z + (v.z + vh.z) * dt;
             const float ph = 0.5f * pb * dt, pvh = pv + ph;
             // ---- second RHS at (v + vh, q1, pv + ph)                      sovlers.py:121-125
-            ring_force<1, RDF ? 1 : 0, KIND, MASK>(K, X, M, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, tu, ru, lds);
+            ring_force_terms<1, RDF ? 1 : 0, KIND, MASK, NT>(K, X, M, RDF && ring_frame_selected(F, k + 1), N, lane, q, wu, f, gu, tu, ru, lds);
             const Vec3x2 vv{v.x + vh.x, v.y + vh.y, v.z + vh.z};
             if (nhc) {
                 const Vec3x2 p{vv.x * ms, vv.y * ms, vv.z * ms};
@@ -607,8 +632,9 @@ __device__ __forceinline__ void ring_theta(const RingLJ& K, const float (&th)[MD
 // replicas of a tabulated kind's rows is defined (what the caller forms, ops.FusedTrajFn.backward).
 constexpr int RING_TABLE_WAVES = 8;
 
-template <bool RDF, int KIND, bool MASK = false>
+template <bool RDF, int KIND, bool MASK = false, int NT = 1>
 __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) void traj_adj_ring_kernel(const TrajArgs A, const RingRdfArgs F) {
+    static_assert(NT == 1 || (MASK && KIND != KIND_TABLE), "several terms: masked built-in forms");
     extern __shared__ __attribute__((aligned(16))) float smr[];
     const int N = A.prm.n_atoms, T = A.prm.n_frames, C = A.prm.n_chains;
     const bool nhc = A.prm.ensemble == 0;
@@ -618,9 +644,14 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
     // (the other kinds launch one wave per replica: `live` is a compile-time true there, the code of round 4)
     const bool live = KIND != KIND_TABLE || (int)(blockIdx.x * NWV + wid) < A.prm.n_rep;
     const int rep = KIND != KIND_TABLE ? (int)blockIdx.x : (live ? (int)(blockIdx.x * NWV + wid) : A.prm.n_rep - 1);
-    const RingLJ K = ring_constants(A);
-    RingMask M{};
-    if constexpr (MASK) M = ring_mask_load(A.terms.t[0].mask, N, lane);
+    RingLJ K[NT];
+    RingMask M[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        K[m] = ring_constants(A, m);
+        M[m] = RingMask{};
+        if constexpr (MASK) M[m] = ring_mask_load(A.terms.t[m].mask, N, lane);
+    }
     RingRdf X{};
     int ncell = 0;
     if constexpr (RDF) {
@@ -662,22 +693,24 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
     Vec3x2 lv = A.g_v ? ring_load(A.g_v + (fr + T - 1) * N3, N, lane) : vzero();
     Vec3x2 lq = A.g_q ? ring_load(A.g_q + (fr + T - 1) * N3, N, lane) : vzero();
     float lp = (nhc && lane < C && A.g_pv) ? A.g_pv[(fr + T - 1) * C + lane] : 0.f;
-    float gth[MDG_MAX_THETA];
+    float gth[NT][MDG_MAX_THETA];
 #pragma unroll
-    for (int k = 0; k < MDG_MAX_THETA; ++k) gth[k] = 0.f;
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int k = 0; k < MDG_MAX_THETA; ++k) gth[m][k] = 0.f;
     for (int i = T - 1; i >= 1; --i) {
         const float h = A.t[i] - A.t[i - 1];
         Vec3x2 q = ring_load(A.q_t + (fr + i) * N3, N, lane), v = ring_load(A.v_t + (fr + i) * N3, N, lane);
         float pv = (nhc && lane < C) ? A.pv_t[(fr + i) * C + lane] : 0.f;
         Vec3x2 w, f, dq, rq = vzero(), ru;
-        float th[MDG_MAX_THETA];
+        float th[NT][MDG_MAX_THETA];
         // ---------------- first augmented evaluation at (y_i, lam)
         if (nhc) { w.x = lv.x * ims; w.y = lv.y * ims; w.z = lv.z * ims; } else w = lv;
         const bool with_rdf = RDF && ring_frame_selected(F, i);
         // (table kind: the parameter term of an interval comes from the midpoint evaluation for NHC, sovlers.py:160, and
         //  from this first one for NVE, :82,101 -- both with total weight h)
         if constexpr (KIND == KIND_TABLE) X.tgw = (nhc || !live) ? 0.f : 0.5f * h * A.terms.t[0].c;
-        ring_force<2, RDF ? 2 : 0, KIND, MASK>(K, X, M, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
+        ring_force_terms<2, RDF ? 2 : 0, KIND, MASK, NT>(K, X, M, with_rdf, N, lane, q, w, f, dq, th, rq, lds);
         if (with_rdf) { lq.x += rq.x; lq.y += rq.y; lq.z += rq.z; }       // dL/dq_t[i] of the fused observable
         Vec3x2 lvh, lqh;
         if (nhc) {
@@ -703,7 +736,7 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
             // ---------------- midpoint evaluation                    :147-150
             w.x = lvh.x * ims; w.y = lvh.y * ims; w.z = lvh.z * ims;
             if constexpr (KIND == KIND_TABLE) X.tgw = live ? 0.5f * h * A.terms.t[0].c : 0.f;
-            ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, w, f, dq, th, ru, lds);
+            ring_force_terms<2, 0, KIND, MASK, NT>(K, X, M, false, N, lane, q, w, f, dq, th, ru, lds);
             const float slm = wave_sum(ring_dot(lvh, v));
             const float cm = lane0(pv) * iQ0, lpm0 = lane0(lph);
             const float gpm = ring_bath_vjp(A, lane, Qk, pv, lph, slm);
@@ -720,10 +753,12 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
             float nlp = lp + gpm * h;                                 // :158
             if (lane < C && A.g_pv) nlp += A.g_pv[(fr + i - 1) * C + lane];
             lp = nlp;
-            ring_theta<KIND>(K, th, gth, h, false);                   // :160
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ring_theta<KIND>(K[m], th[m], gth[m], h, false);     // :160
         } else {
             // verlet_update backward branch                          sovlers.py:42-101
-            ring_theta<KIND>(K, th, gth, h, true);                    // :82,101
+#pragma unroll
+            for (int m = 0; m < NT; ++m) ring_theta<KIND>(K[m], th[m], gth[m], h, true);      // :82,101
 #define MDG_RING_NVE(c)                                                                      \
             {                                                                                \
                 const f32x2 vhalf = v.c - 0.5f * (-f.c) * h;          /* :49-50 */           \
@@ -736,7 +771,7 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
             MDG_RING_NVE(x) MDG_RING_NVE(y) MDG_RING_NVE(z)
 #undef MDG_RING_NVE
             if constexpr (KIND == KIND_TABLE) X.tgw = 0.f;
-            ring_force<2, 0, KIND, MASK>(K, X, M, false, N, lane, q, lvh, f, dq, th, ru, lds);
+            ring_force_terms<2, 0, KIND, MASK, NT>(K, X, M, false, N, lane, q, lvh, f, dq, th, ru, lds);
             const Vec3x2 gv = A.g_v ? ring_load(A.g_v + (fr + i - 1) * N3, N, lane) : vzero();
             const Vec3x2 gq = A.g_q ? ring_load(A.g_q + (fr + i - 1) * N3, N, lane) : vzero();
             lv.x = lvh.x + gv.x; lv.y = lvh.y + gv.y; lv.z = lvh.z + gv.z;
@@ -750,7 +785,7 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
             const Vec3x2 q = ring_load(A.q_t + fr * N3, N, lane), wu = vzero();
             Vec3x2 fu, gu, rq = vzero();
             float tu[MDG_MAX_THETA];
-            ring_force<0, 2, KIND, MASK>(K, X, M, true, N, lane, q, wu, fu, gu, tu, rq, lds);
+            ring_force<0, 2, KIND, MASK>(K[0], X, M[0], true, N, lane, q, wu, fu, gu, tu, rq, lds);
             lq.x += rq.x; lq.y += rq.y; lq.z += rq.z;
         }
     }
@@ -779,9 +814,12 @@ __global__ __launch_bounds__(KIND == KIND_TABLE ? 64 * RING_TABLE_WAVES : 64) vo
         return;
     }
     if (lane == 0 && A.adj_theta) {
-        float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[0].theta_off;
 #pragma unroll
-        for (int k = 0; k < MDG_MAX_THETA; ++k)
-            if (k < A.terms.t[0].n_theta) out[k] = gth[k];
+        for (int m = 0; m < NT; ++m) {
+            float* out = A.adj_theta + (size_t)rep * A.terms.n_theta_total + A.terms.t[m].theta_off;
+#pragma unroll
+            for (int k = 0; k < MDG_MAX_THETA; ++k)
+                if (k < A.terms.t[m].n_theta) out[k] = gth[m][k];
+        }
     }
 }

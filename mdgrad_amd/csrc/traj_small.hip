@@ -870,6 +870,7 @@ size_t device_lds_per_block() {
     return cached;
 }
 
+int ring_kind(const MdgPairTerm& t);
 bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms) {
     const MdgPairTerm& t = terms.t[0];
     // one unmasked built-in pair form (LJ 12-6 / ExcludedVolume(12) on the even-power polynomial, the others through
@@ -881,6 +882,18 @@ bool ring_form(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& term
         const char* e = getenv("MDG_RING_TABLE");                        // (=0: the one-workgroup-per-replica kernels; A/B)
         return !(e && e[0] == '0') && terms.n_terms == 1 && cell.diag && !t.mask && t.p <= RING_TABLE_MAX_NODES && p.n_atoms <= 128 &&
                ring_table_adj_lds(t.p) <= device_lds_per_block();
+    }
+    if (terms.n_terms == 2 || terms.n_terms == 3) {
+        // round 6: two or three terms of the LJ family with selection masks (species mixtures -- A-A / A-B / B-B index_tuple
+        // stacks, interface.py:228-260, scripts/fit_mix.py:101-117) -- one ring sweep per term (ring_force_terms); a term
+        // without a mask selects every pair
+        bool any_mask = false;
+        for (int m = 0; m < terms.n_terms; ++m) {
+            const MdgPairTerm& u = terms.t[m];
+            if (u.kind != MDG_PAIR_LJ || ring_kind(u) != ring_kind(t)) return false;
+            any_mask = any_mask || u.mask != nullptr;
+        }
+        return cell.diag && p.n_atoms <= 128 && any_mask;
     }
     return terms.n_terms == 1 && cell.diag && (!t.mask || t.kind == MDG_PAIR_LJ) && t.kind >= 0 && t.kind <= MDG_PAIR_YUKAWA &&
            p.n_atoms <= 128;
@@ -901,13 +914,18 @@ size_t ring_table_lds(const MdgTerms& terms, bool adjoint) {
 #define MDG_RING_LAUNCH(KERNEL, RDF_, grid, block, lds, st, ...)                                              \
     do {                                                                                                      \
         const bool masked_ = terms->t[0].mask != nullptr;                                                     \
+        const int nt_ = terms->n_terms;              /* (ring_form: > 1 only for the LJ family, unfused observable) */ \
         switch (ring_kind(terms->t[0])) {                                                                     \
         case KIND_LJ126:                                                                                      \
-            if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126, true>), grid, block, lds, st, __VA_ARGS__);         \
+            if (nt_ == 2) hipLaunchKernelGGL((KERNEL<false, KIND_LJ126, true, 2>), grid, block, lds, st, __VA_ARGS__);    \
+            else if (nt_ == 3) hipLaunchKernelGGL((KERNEL<false, KIND_LJ126, true, 3>), grid, block, lds, st, __VA_ARGS__); \
+            else if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126, true>), grid, block, lds, st, __VA_ARGS__);    \
             else hipLaunchKernelGGL((KERNEL<RDF_, KIND_LJ126>), grid, block, lds, st, __VA_ARGS__);                       \
             break;                                                                                            \
         case MDG_PAIR_LJ:                                                                                     \
-            if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ, true>), grid, block, lds, st, __VA_ARGS__);        \
+            if (nt_ == 2) hipLaunchKernelGGL((KERNEL<false, MDG_PAIR_LJ, true, 2>), grid, block, lds, st, __VA_ARGS__);   \
+            else if (nt_ == 3) hipLaunchKernelGGL((KERNEL<false, MDG_PAIR_LJ, true, 3>), grid, block, lds, st, __VA_ARGS__);  \
+            else if (masked_) hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ, true>), grid, block, lds, st, __VA_ARGS__);   \
             else hipLaunchKernelGGL((KERNEL<RDF_, MDG_PAIR_LJ>), grid, block, lds, st, __VA_ARGS__);                      \
             break;                                                                                            \
         case KIND_TABLE: hipLaunchKernelGGL((KERNEL<false, KIND_TABLE>), grid, block, lds, st, __VA_ARGS__); break;     \
@@ -926,7 +944,7 @@ constexpr int RING_RDF_MAX_CELLS = 1088;                     // derivative table
 // the fused RDF observable: fine-grid plan (csrc/rdf.hip) + what fits beside the kernels' own LDS
 bool ring_rdf_plan(const MdgTrajParams& p, const MdgCell& cell, const MdgTerms& terms, const MdgRdfFuse* rdf, RdfFinePlan* plan) {
     if (!rdf || !rdf->mu || !use_ring(p, cell, terms)) return false;     // (only where the ring kernels run anyway)
-    if (terms.t[0].kind == MDG_PAIR_TABLE) return false;                 // (the tabulated kind keeps the separate observable kernels)
+    if (terms.t[0].kind == MDG_PAIR_TABLE || terms.n_terms != 1) return false;   // (the tabulated kind and two-term stacks keep the separate observable kernels)
     if (rdf->frame_stride < 1 || rdf->frame_start < 0 || !(rdf->cutoff > 0.f)) return false;
     const RdfFinePlan P = mdg_rdf_fine_plan(rdf->spacing, rdf->coeff, rdf->nbins);
     if (P.nfine <= 0 || P.ncell <= 0 || P.ncell > RING_RDF_MAX_CELLS) return false;

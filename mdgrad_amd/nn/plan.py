@@ -50,6 +50,8 @@ class SchnetPlan:
             L.rows16, L.b2col = int(bool(fn.rows16)), int(bool(fn.b2col))
             self.keep.append(fn)
         s.L1, s.l1, s.L2 = self.L1.data_ptr(), self.l1.data_ptr(), self.L2.data_ptr()
+        # the G-wide filter stash (mdg_cfconv_filter_stash): same results as recomputing; MDG_SCHNET_STASH=0 for the A/B
+        s.stash = int(getattr(net, "filter_stash", True) is not False and os.environ.get("MDG_SCHNET_STASH", "1") != "0")
         self.struct = s
         self.key = self._key(Ps, fns)
         self.ws = {}                 # one workspace per evaluation kind (dual, theta): a captured HIP graph of one kind keeps

@@ -1427,6 +1427,35 @@ def cfconv_fwd(fnet, d, dd, h, hd, topo, want_sums=False):
     return m, md, hsum, hdsum
 
 
+def cfconv_filter_stash(fnet, d, dd, topo):
+    """(st_s, st_sd): the first Dense layer of the filter network once per undirected edge (mdg_cfconv_filter_stash) --
+    [E, W] bf16 rows of s = ssp(a) and, with dd, of the tangent sd = sigmoid(a) a_dot; st_sd is None without dd."""
+    lib = _lib.load()
+    assert fnet.bf16, "the stash holds the bf16 operands of the bf16 kernels"
+    E, dev = topo.n_edges, d.device
+    W = int(lib.mdg_cfconv_stash_width(fnet.G))
+    st_s = torch.empty(E, W, device=dev, dtype=torch.bfloat16)
+    st_sd = torch.empty(E, W, device=dev, dtype=torch.bfloat16) if dd is not None else None
+    check(lib.mdg_cfconv_filter_stash(C.byref(fnet.struct), ptr(d), ptr(dd), E, ptr(getattr(topo, "n_valid", None)), ptr(st_s),
+                                      ptr(st_sd), stream_ptr(dev)), "mdg_cfconv_filter_stash")
+    return st_s, st_sd
+
+
+def cfconv_fwd_stashed(fnet, st_s, st_sd, d, h, hd, topo):
+    """(m, md) of cfconv_fwd with the second filter layer's operands read from the stash (bitwise the same outputs); the
+    tangent sweep iff st_sd is given."""
+    lib = _lib.load()
+    e = topo.ell
+    N, dev = topo.n_atoms, h.device
+    r16 = h.dtype == torch.bfloat16
+    m = torch.empty(N, fnet.F, device=dev)
+    md = torch.empty(N, fnet.F, device=dev) if st_sd is not None else None
+    check(lib.mdg_cfconv_fwd_stashed(C.byref(fnet.struct), ptr(st_s), ptr(st_sd), ptr(d), ptr(h.contiguous()),
+                                     ptr(hd.contiguous()) if hd is not None else None, ptr(e.col), ptr(topo.eid), ptr(e.cnt), N,
+                                     e.max_nbr, ptr(m), ptr(md), int(r16), stream_ptr(dev)), "mdg_cfconv_fwd_stashed")
+    return m, md
+
+
 def cfconv_bwd(fnet, d, dd, topo, h, hd, mb, mdb, d_b, dd_b, want_theta=False, want_smear=False, want_b2=False):
     """Adjoint of the filter network (see include/mdgrad_hip.h): accumulates into d_b / dd_b in place and returns
     (gW1, gb1, gW2) when want_theta -- plus (gmu, gcoef), the gradients of the Gaussian centres and coefficients, when

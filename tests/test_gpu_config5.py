@@ -228,5 +228,5 @@ def test_bench_default_leg_set_for_more_than_one_rank_is_lean():
     assert sorted(names) == ["lj4096", "schnet4096"], names
     cfg = lines[-1]["config"]
     assert cfg["lj4096_md_steps_per_s"] > 0 and cfg["schnet4096_md_steps_per_s"] > 0
-    assert not any(k.startswith(("water192", "exvol108", "schnet4096_f32", "schnet4096_bf16rows")) for k in cfg), sorted(cfg)
+    assert not any(k.startswith(("water192", "exvol108", "schnet4096_f32", "schnet4096_bf16_f32rows")) for k in cfg), sorted(cfg)
     assert list(cfg)[0] == "workload" and len(cfg["workload"]) <= 100

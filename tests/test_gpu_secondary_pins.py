@@ -278,7 +278,7 @@ def test_schnet_one_4096_bead_system_vs_oracle(bf16):
     _check_theta(out["flat"], ref[2], tol, "one 4096-bead system")
 
 
-@pytest.mark.parametrize("bf16", [False, True], ids=["f32", "bf16"])
+@pytest.mark.parametrize("bf16", [False, True, "rows16"], ids=["f32", "bf16", "rows16"])
 def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
     """The launch geometry bench.py's schnet4096 leg times, built by the same function: 8 stacked replicas x 4 096 beads
     (32 768 atoms, 459 k edges), 2 steps + per-replica RDF loss + adjoint.  First and last replica against their own oracle
@@ -288,7 +288,9 @@ def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
     import bench
     from mdgrad_amd import graphs, units
     R = 8
-    wl = bench.build_schnet_workload(DEV, R, bf16, 2000)
+    rows16 = bf16 == "rows16"            # (round 6: what bench.py's schnet4096 leg runs -- bf16 operands AND bf16 gathered node rows)
+    bf16 = bool(bf16)
+    wl = bench.build_schnet_workload(DEV, R, bf16, 2000, rows16=rows16)
     N = wl["N"]
     topo = wl["gnn"].inputs["_topo"]
     assert N == 4096 and topo.n_edges > graphs.MAX_EDGES, "the timed stack must take the eager pass on stored lists"
@@ -297,7 +299,7 @@ def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
     vel = wl["system"].get_velocities().reshape(R, N, 3).astype(np.float32)
     t = torch.Tensor([units.fs * i for i in range(3)])
     tol = _tols(bf16)
-    tag = "8 x 4096 stack (%s)" % ("bf16" if bf16 else "f32")
+    tag = "8 x 4096 stack (%s)" % ("rows16" if rows16 else "bf16" if bf16 else "f32")
     out = _run_schnet_workload(wl, t, 2, replicas=(0, R - 1))
     gsum = None
     for r in (0, R - 1):
@@ -311,7 +313,7 @@ def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
         assert bool(torch.isfinite(out[k]).all()), k
         assert torch.equal(out[k], again[k]), "second pass differs from the first: " + k
     # replica 3 alone == replica 3 inside the stack (same kernels, different launch geometry: graph replay at 57 k edges)
-    one = bench.build_schnet_workload(DEV, 1, bf16, 1)
+    one = bench.build_schnet_workload(DEV, 1, bf16, 1, rows16=rows16)
     one["system"].set_positions(pos[3])
     one["system"].set_velocities(vel[3])
     alone = _run_schnet_workload(one, t, 2)
@@ -326,14 +328,14 @@ def test_schnet_timed_stack_8x4096_beads_vs_oracle(bf16):
 def test_schnet_timed_stack_8x4096_beads_6_steps_with_stored_list_reuse_vs_oracle():
     """the 8 x 4 096-bead stack over 6 steps (19 force evaluations: 6 forward, 12 + 1 in the adjoint) on
     ONE search of the stored Verlet list -- every later evaluation re-applies the exact cutoff to the stored pairs
-    (tests/test_gpu_verlet.py) --, last replica of the stack against its own oracle run, bf16 filter operands (the
-    configuration bench.py times) and f32 on the same oracle run."""
+    (tests/test_gpu_verlet.py) --, last replica of the stack against its own oracle run: bf16 filter operands + bf16 gathered
+    node rows (the configuration bench.py times since round 6), bf16 operands alone and f32, on the same oracle run."""
     import bench
     from mdgrad_amd import units
     R = 8
     t = torch.Tensor([units.fs * i for i in range(7)])
-    for bf16 in (True, False):
-        wl = bench.build_schnet_workload(DEV, R, bf16, 2000)
+    for bf16, rows16 in ((True, True), (True, False), (False, False)):
+        wl = bench.build_schnet_workload(DEV, R, bf16, 2000, rows16=rows16)
         N = wl["N"]
         sd = {k: v.detach().clone().cpu() for k, v in wl["net"].state_dict().items()}
         pos = wl["system"].get_positions().reshape(R, N, 3).astype(np.float32)
@@ -347,7 +349,7 @@ def test_schnet_timed_stack_8x4096_beads_6_steps_with_stored_list_reuse_vs_oracl
         assert 1 <= searches < 6, "6 steps of 1 fs stay inside the skin: stored lists must have been reused (%d searches)" % searches
         ref = _oracle_4096(("stack6", 2000, R - 1), wl, sd, pos[R - 1], vel[R - 1], t, 3)
         tol = _tols(bf16)
-        tag = "8 x 4096 stack, 6 steps (%s)" % ("bf16" if bf16 else "f32")
+        tag = "8 x 4096 stack, 6 steps (%s)" % ("bf16 operands + bf16 node rows" if rows16 else "bf16" if bf16 else "f32")
         _check_replica(out, R - 1, ref, tol, tag + " replica 7")
         _check_theta(out["flat"], ref[2], tol, tag + " replica 7")
 

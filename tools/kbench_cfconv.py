@@ -72,6 +72,20 @@ def main():
         ("edge_geom_bwd", lambda: ops.edge_geom_bwd(d_b, dd_b, d, dd, uhat, ddel, topo), 0),
         ("nbr build (cell, grouped)", lambda: ops.build_ell(x, cs, 6.0, group=len(atoms), max_nbr=ell.max_nbr), 0),
     ]
+    if args.bf16:
+        st_s, st_sd = ops.cfconv_filter_stash(fn, d, dd, topo)
+        for tag, a, b in (("primal", ops.cfconv_fwd(fn, d, None, h, None, topo)[0], ops.cfconv_fwd_stashed(fn, st_s, None, d, h, None, topo)[0]),
+                          ("tangent m", ops.cfconv_fwd(fn, d, dd, h, hd, topo)[0], ops.cfconv_fwd_stashed(fn, st_s, st_sd, d, h, hd, topo)[0]),
+                          ("tangent md", ops.cfconv_fwd(fn, d, dd, h, hd, topo)[1], ops.cfconv_fwd_stashed(fn, st_s, st_sd, d, h, hd, topo)[1]),
+                          ("tangent md (no hd)", ops.cfconv_fwd(fn, d, dd, h, None, topo)[1], ops.cfconv_fwd_stashed(fn, st_s, st_sd, d, h, None, topo)[1])):
+            print("stashed == recomputed, %-18s: %s (max |d| %.3e)" % (tag, bool(torch.equal(a, b)), float((a - b).abs().max())))
+        cases += [
+            ("filter_stash (s)", lambda: ops.cfconv_filter_stash(fn, d, None, topo), 0),
+            ("filter_stash (s, sd)", lambda: ops.cfconv_filter_stash(fn, d, dd, topo), 0),
+            ("cfconv_fwd STASHED primal", lambda: ops.cfconv_fwd_stashed(fn, st_s, None, None, h, None, topo), 0),
+            ("cfconv_fwd STASHED primal+tangent", lambda: ops.cfconv_fwd_stashed(fn, st_s, st_sd, None, h, hd, topo), 0),
+            ("cfconv_fwd STASHED tangent (no hd)", lambda: ops.cfconv_fwd_stashed(fn, st_s, st_sd, None, h, None, topo), 0),
+        ]
     for name, fnc, mfma in cases:
         fnc()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
