@@ -449,6 +449,10 @@ int mdg_edge_geom(const float* x, const float* w, const int64_t* nbr, const floa
  * d = -1 (and dd = 0) and are skipped by the cfconv kernels like padding */
 int mdg_edge_geom_masked(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
                          const MdgCell* cell /*host*/, float cutoff, float* d, float* uhat, float* dd, float* ddel, void* stream);
+/* mdg_edge_geom (cell == NULL) / mdg_edge_geom_masked and the zero fill of zero_n floats at `zero` (nullable) in one launch */
+int mdg_edge_geom_prepare(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                          const MdgCell* cell /*host, nullable*/, float cutoff, float* d, float* uhat, float* dd, float* ddel,
+                          float* zero, int64_t zero_n, void* stream);
 int mdg_edge_geom_bwd(const float* d_b, const float* dd_b, const float* d, const float* dd, const float* uhat,
                       const float* ddel, const int32_t* col, const int32_t* eid, const int32_t* cnt,
                       int n_atoms, int max_nbr, float* force, float* dwf, void* stream);

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "mdg_nbr_half_fill_padded": (C.c_int, [P, P, P, P, C.c_int, C.c_int, C.c_int64, C.c_float, P, P, P, P, P, P]),
     "mdg_nbr_verlet_rebuild": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, C.c_float, P, C.c_int, P, P, P,
                                          C.c_int, C.c_int64, C.c_float, P, P, P, P, P, P, P, P, P, P]),
+    "mdg_edge_geom_prepare": (C.c_int, [P, P, P, P, C.c_int64, C.POINTER(MdgCell), C.c_float, P, P, P, P, P, C.c_int64, P]),
     "mdg_edge_geom_masked": (C.c_int, [P, P, P, P, C.c_int64, C.POINTER(MdgCell), C.c_float, P, P, P, P, P]),
     "mdg_pair_partial_size": (C.c_int64, [C.c_int]),
     "mdg_pair_eval_ell": (C.c_int, [P, C.c_int, C.POINTER(MdgCell), P, P, P, C.c_int,

@@ -1793,8 +1793,11 @@ template <bool MASK, bool DIAG>
 __global__ void edge_geom_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                  const int64_t* __restrict__ nbr, const float* __restrict__ off, long long E,
                                  float* __restrict__ d, float* __restrict__ uhat, float* __restrict__ dd,
-                                 float* __restrict__ ddel, MdgCell cell, float rc2) {
+                                 float* __restrict__ ddel, MdgCell cell, float rc2, float* __restrict__ zero = nullptr,
+                                 long long zero_n = 0) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    // (mdg_edge_geom_prepare: the per-edge accumulators of the reverse sweeps are cleared by the same launch)
+    for (long long z = e; z < zero_n; z += (long long)gridDim.x * blockDim.x) zero[z] = 0.f;
     if (e >= E) return;
     const EdgeGeo g = edge_geometry<MASK, DIAG>(x, w, nbr, off, e, cell, rc2);
     d[e] = g.d;
@@ -1938,6 +1941,31 @@ extern "C" int mdg_edge_geom_masked(const float* x, const float* w, const int64_
     else
         hipLaunchKernelGGL((edge_geom_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, nbr, offsets,
                            (long long)n_edges, d, uhat, dd, ddel, *cell, cutoff * cutoff);
+    MDG_CHECK_LAUNCH("edge_geom_kernel");
+    return MDG_OK;
+}
+
+// mdg_edge_geom (cell == NULL) / mdg_edge_geom_masked in one launch with the zero fill of `zero_n` floats at `zero` (the per-edge
+// accumulators d_b / dd_b the reverse sweeps of the same evaluation add into): one launch less per evaluation.
+extern "C" int mdg_edge_geom_prepare(const float* x, const float* w, const int64_t* nbr, const float* offsets, int64_t n_edges,
+                                     const MdgCell* cell, float cutoff, float* d, float* uhat, float* dd, float* ddel,
+                                     float* zero, int64_t zero_n, void* stream) {
+    MDG_CHECK_ARG(n_edges >= 0 && zero_n >= 0 && (!cell || cutoff > 0.f), "edge_geom_prepare: bad arguments");
+    if (n_edges == 0 && zero_n == 0) return MDG_OK;
+    MDG_CHECK_ARG((n_edges == 0 || (x && nbr && offsets && d && uhat)) && (!w || (dd && ddel)) && (zero_n == 0 || zero),
+                  "edge_geom_prepare: null buffer");
+    const long long work = n_edges > 0 ? n_edges : 256;
+    const dim3 grid((unsigned)((work + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (!cell)
+        hipLaunchKernelGGL((edge_geom_kernel<false, true>), grid, dim3(256), 0, st, x, w, nbr, offsets, (long long)n_edges, d, uhat,
+                           dd, ddel, MdgCell{}, 0.f, zero, (long long)zero_n);
+    else if (cell->diag)
+        hipLaunchKernelGGL((edge_geom_kernel<true, true>), grid, dim3(256), 0, st, x, w, nbr, offsets, (long long)n_edges, d, uhat,
+                           dd, ddel, *cell, cutoff * cutoff, zero, (long long)zero_n);
+    else
+        hipLaunchKernelGGL((edge_geom_kernel<true, false>), grid, dim3(256), 0, st, x, w, nbr, offsets, (long long)n_edges, d, uhat,
+                           dd, ddel, *cell, cutoff * cutoff, zero, (long long)zero_n);
     MDG_CHECK_LAUNCH("edge_geom_kernel");
     return MDG_OK;
 }

@@ -16,20 +16,8 @@
 
 namespace {
 
-// (a kernel, not hipMemsetAsync: the evaluation is captured into HIP graphs, and a memset NODE between kernel nodes was seen to
-//  race with its neighbours on ROCm 7.2 -- flaky non-finite replays; torch's zeros_ is a kernel too)
-__global__ __launch_bounds__(256) void zero_kernel(float4* __restrict__ p, size_t n4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-}
-int zero_fill(float* p, size_t n, hipStream_t st) {              // n floats, p 16-byte aligned; rounds up to whole float4s (arena slack)
-    const size_t n4 = (n + 3) / 4;
-    if (n4 == 0) return MDG_OK;
-    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<float4*>(p), n4);
-    MDG_CHECK_LAUNCH("zero_kernel");
-    return MDG_OK;
-}
-
+// (the per-edge accumulators are cleared by the geometry kernel, not by hipMemsetAsync: the evaluation is captured into HIP
+//  graphs, and a memset NODE between kernel nodes was seen to race with its neighbours on ROCm 7.2 -- flaky non-finite replays)
 struct Arena {
     float* base;
     size_t off;
@@ -183,11 +171,10 @@ int check_plan(const MdgSchnetPlan* P) {
 //  gradjobs.hip sizes from the shapes alone)
 #define MDG_RUN(call) do { if (!dry) MDG_TRY(call); } while (0)
 
-int geom(const MdgSchnetPlan& P, const Bufs& B, const float* x, const float* w, void* st) {
-    if (P.masked)
-        return mdg_edge_geom_masked(x, w, P.nbr, P.offsets, P.n_edges, &P.cell, P.cutoff, B.d, B.uhat, w ? B.dd : nullptr,
-                                    w ? B.ddel : nullptr, st);
-    return mdg_edge_geom(x, w, P.nbr, P.offsets, P.n_edges, B.d, B.uhat, w ? B.dd : nullptr, w ? B.ddel : nullptr, st);
+// geometry of the half list + the zero fill of the per-edge accumulators, one launch
+int geom(const MdgSchnetPlan& P, const Bufs& B, const float* x, const float* w, size_t zero_n, void* st) {
+    return mdg_edge_geom_prepare(x, w, P.nbr, P.offsets, P.n_edges, P.masked ? &P.cell : nullptr, P.cutoff, B.d, B.uhat,
+                                 w ? B.dd : nullptr, w ? B.ddel : nullptr, B.both, (int64_t)zero_n, st);
 }
 
 int conv_fwd(const MdgSchnetPlan& P, const MdgSchnetLayer& S, const float* d, const float* dd, const void* h, const void* hd,
@@ -226,8 +213,7 @@ int forward_and_turn(const MdgSchnetPlan& P, Bufs& B, const float* x, const floa
     // (tried and dropped, round 6: geometry + accumulator fill + every block's stash in ONE launch -- 3 599 MD steps/s on the
     //  stacked pass against 3 657 with the separate launches: one wave of four doing the latency-bound geometry of a 64-edge
     //  tile serialises what edge_geom_kernel does with the whole chip)
-    MDG_RUN(geom(P, B, x, w, st));
-    MDG_RUN(zero_fill(B.both, zero_n, (hipStream_t)st));
+    MDG_RUN(geom(P, B, x, dual ? w : nullptr, zero_n, st));
     const float *r = P.r0, *rd = nullptr;
     const void* hg = P.layer[0].rows16 ? (const void*)P.h0_16 : (const void*)P.h0;
     const void* hgd = nullptr;

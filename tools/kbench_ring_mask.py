@@ -31,12 +31,16 @@ def main():
     vel = torch.from_numpy(rng.normal(0, 1.0, pos.shape).astype(np.float32)).to(dev)
     t = torch.Tensor([0.005 * i for i in range(T)]).to(dev)
     A_, B_ = list(range(0, 108, 2)), list(range(1, 108, 2))
-    for name, kw in (("unmasked LJ 12-6", {}), ("two species, index_tuple (A, B)", dict(index_tuple=(A_, B_)))):
-        mdl = P.LennardJones(1.0, 1.0)
-        integ = NoseHooverChain(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5, **kw)}), system, T=1.0, num_chains=5,
-                                Q=50.0).to(dev)
+    mix = [dict(index_tuple=(A_, A_)), dict(index_tuple=(B_, B_)), dict(index_tuple=(A_, B_))]
+    for name, kws, block in (("unmasked LJ 12-6", [{}], 0), ("two species, index_tuple (A, B)", [dict(index_tuple=(A_, B_))], 0),
+                             ("mixture A-A + B-B + A-B, ring (one sweep per term)", mix, 0),
+                             ("mixture A-A + B-B + A-B, workgroup kernels", mix, 128)):
+        mdls = [P.LennardJones(1.0 - 0.05 * k, 1.0 + 0.1 * k) for k in range(len(kws))]
+        integ = NoseHooverChain(Stack({"t%d" % k: PairPotentials(system, m, cutoff=2.5, **kw) for k, (m, kw) in enumerate(zip(mdls, kws))}),
+                                system, T=1.0, num_chains=5, Q=50.0).to(dev)
         integ.fuse_observables = False
         spec = integ.fused_spec("NH_verlet")
+        spec.block = block
         pv0 = torch.zeros(R, 5, device=dev)
 
         def one():
@@ -50,7 +54,7 @@ def main():
             one()
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / args.reps
-        print("%-34s %8.2f ms per pass  %6.2f M MD steps/s (fwd + adjoint, %d replicas)" % (name, el * 1e3, R * (T - 1) / el / 1e6, R))
+        print("%-52s %8.2f ms per pass  %6.2f M MD steps/s (fwd + adjoint, %d replicas)" % (name, el * 1e3, R * (T - 1) / el / 1e6, R))
 
 
 if __name__ == "__main__":
