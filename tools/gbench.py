@@ -51,7 +51,9 @@ def main():
     ap.add_argument("--replicas", type=int, default=1, help="stack R replicas (System.replicate) in one trajectory")
     ap.add_argument("--table-nodes", type=int, default=0, help="mlp108: nodes of the tabulated pair energy (0 = default)")
     ap.add_argument("--bf16", action="store_true", help="gnn*: bf16 MFMA operands in the filter network (both sweeps)")
+    ap.add_argument("--bf16-rows", action="store_true", help="gnn*: --bf16 and bf16 mirrors of the gathered node rows (SchNet.node_rows_bf16)")
     args = ap.parse_args()
+    args.bf16 = args.bf16 or args.bf16_rows
     from mdgrad_amd import potentials as P, units
     from mdgrad_amd.interface import PairPotentials, GNNPotentials, Stack
     from mdgrad_amd.md import NoseHooverChain
@@ -133,6 +135,7 @@ def main():
             with torch.no_grad():   # tame the random-init network so the synthetic dynamics stay finite
                 net.atomwisereadout.readout["energy"][2].weight.mul_(0.02)
             net.filter_bf16 = bool(args.bf16)
+            net.node_rows_bf16 = bool(args.bf16_rows)
             gnn = GNNPotentials(system, net, cutoff=6.0)
             prior = PairPotentials(system, P.ExcludedVolume(2.6, 0.01, 12), cutoff=6.0)
             integ = NoseHooverChain(Stack({"gnn": gnn, "prior": prior}), system, T=kT, num_chains=5, Q=50.0).to(dev)
