@@ -39,8 +39,9 @@ class GaussianSmearing(nn.Module):
 
 class Dense(nn.Linear):
     """Linear layer with optional activation, Xavier-uniform weight and zero bias by default
-    (layers.py:86-134).  2-D HIP inputs with many rows route their weight gradient to the split-K MFMA
-    kernel (ops.linear); everything else is the library GEMM."""
+    (layers.py:86-134).  2-D f32 HIP inputs run on the hand-written kernels -- the product on the MFMA node kernel
+    (mdg_dense), the weight gradient on the split-K kernel -- closed under differentiation (ops.linear); CPU / other inputs
+    take torch's own."""
 
     def __init__(self, in_features, out_features, bias=True, activation=None,
                  weight_init=nn.init.xavier_uniform_, bias_init=None):
@@ -55,10 +56,9 @@ class Dense(nn.Linear):
             self.bias_init(self.bias)
 
     def forward(self, inputs):
-        tall = inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32 and inputs.shape[0] >= 8192
-        if tall:
+        if inputs.is_cuda and inputs.dim() == 2 and inputs.dtype == torch.float32:
             from .. import ops
-            y = ops.linear(inputs, self.weight, self.bias)
+            y = ops.linear(inputs, self.weight, self.bias)       # (MFMA node kernel + split-K weight gradient: no library GEMM)
         else:
             y = F.linear(inputs, self.weight, self.bias)
         return self.activation(y) if self.activation else y

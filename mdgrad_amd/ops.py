@@ -1215,14 +1215,26 @@ def _atb2(A, B, A2, B2):
     return out
 
 
+def _mm(A, W):
+    """A[E,K] @ W[K,N] on the hand-written MFMA node kernel (mdg_dense, csrc/dense.hip) -- round 6: no library GEMM behind
+    `Dense` on the autograd path either (nff/nn/layers.py:86-134) -- for 2-D f32 HIP operands with K a multiple of 4; W may be
+    the transposed view of a Linear weight (read in place, Linear layout) or a contiguous [K,N] matrix.  Anything else: matmul."""
+    if (A.is_cuda and A.dim() == 2 and W.dim() == 2 and A.dtype == torch.float32 and W.dtype == torch.float32
+            and A.shape[0] > 0 and A.shape[1] % 4 == 0 and A.shape[1] <= DENSE_MAX_K and A.is_contiguous()):
+        if W.t().is_contiguous():
+            return dense(W.t(), A)[0]
+        return dense(W.contiguous(), A, trans=True)[0]
+    return A.matmul(W)
+
+
 class MMFn(torch.autograd.Function):
-    """A[E,K] @ W[K,N] on the library GEMM (tall A: fine there); its weight gradient is the tall-skinny
+    """A[E,K] @ W[K,N] on the MFMA node kernel (`_mm`); its weight gradient is the tall-skinny
     A^T g, which goes to AtBFn.  {MMFn, AtBFn} is closed under differentiation."""
 
     @staticmethod
     def forward(ctx, A, W):
         ctx.save_for_backward(A, W)
-        return A.detach().matmul(W.detach())
+        return _mm(A.detach(), W.detach())
 
     @staticmethod
     def backward(ctx, g):
@@ -1250,12 +1262,15 @@ class AtBFn(torch.autograd.Function):
         return gA, gB
 
 
-TALL_ROWS = 8192      # below this the library GEMM is launch-bound anyway and native autograd is cheaper
+TALL_ROWS = 8192      # (analytic.py: from here on a^T b goes to the split-K kernel)
 
 
 def linear(x, weight, bias=None):
-    """F.linear for 2-D x; for tall x the weight gradient (x^T g, tall-skinny) runs on AtBFn."""
-    if x.shape[0] < TALL_ROWS:
+    """F.linear for 2-D f32 HIP x on the hand-written kernels: the product on the MFMA node kernel (`_mm`), the weight
+    gradient x^T g on the split-K kernel (AtBFn); other inputs (CPU, other dtypes, widths that are no multiple of 4) take
+    torch's own."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.shape[1] % 4 == 0
+            and x.shape[0] > 0):
         return torch.nn.functional.linear(x, weight, bias)
     y = MMFn.apply(x, weight.t())
     return y if bias is None else y + bias
