@@ -390,13 +390,160 @@ __device__ __forceinline__ void ring_force(const RingLJ& K, const RingRdf& X, co
     }
 }
 
+// ---- several LJ 12-6 terms in ONE sweep (round 6): the geometry of a pair -- minimum image, d^2, 1/d^2: two thirds of a pair
+// operation -- is shared by the terms; each term adds its own polynomial where its mask selects the pair and the pair is
+// inside ITS cutoff, and keeps its own parameter sums.  Overlapping selections (a masked term over an unmasked one) simply add.
+template <int LEVEL, bool NEAR, bool CROSS, bool JSIDE, int NT>
+__device__ __forceinline__ void ring_pair_lj_multi(const RingLJ (&K)[NT], const Vec3x2& qi, const Vec3x2& wi, const Vec3x2& qj,
+                                                   const Vec3x2& wj, const bool (&v0)[NT], const bool (&v1)[NT], Vec3x2& fi,
+                                                   Vec3x2& gi, Vec3x2& fj, Vec3x2& gj, f32x2 (&TH)[NT][MDG_MAX_THETA]) {
+    f32x2 dx = (CROSS ? qj.x.yx : qj.x) - qi.x, dy = (CROSS ? qj.y.yx : qj.y) - qi.y,
+          dz = (CROSS ? qj.z.yx : qj.z) - qi.z;                                       // D = x_j - x_i
+    if constexpr (NEAR) {
+        dx = min_image_diag2_near(dx, K[0].ivx, K[0].hx); dy = min_image_diag2_near(dy, K[0].ivy, K[0].hy);
+        dz = min_image_diag2_near(dz, K[0].ivz, K[0].hz);
+    } else {
+        dx = min_image_diag2(dx, K[0].ivx, K[0].hx); dy = min_image_diag2(dy, K[0].ivy, K[0].hy);
+        dz = min_image_diag2(dz, K[0].ivz, K[0].hz);
+    }
+    const f32x2 d2 = norm2_ref2(dx, dy, dz);
+    const bool nz0 = d2.x != 0.f, nz1 = d2.y != 0.f;                                  // topology.py:67
+    const f32x2 r2 = {nz0 ? __builtin_amdgcn_rcpf(d2.x) : 0.f, nz1 ? __builtin_amdgcn_rcpf(d2.y) : 0.f};
+    f32x2 c1 = {0.f, 0.f}, kk = {0.f, 0.f}, t6[NT], t12[NT];
+#pragma unroll
+    for (int m = 0; m < NT; ++m) {
+        const bool ok0 = v0[m] && (d2.x < K[m].rc2), ok1 = v1[m] && (d2.y < K[m].rc2);
+        const f32x2 i2 = {ok0 ? r2.x : 0.f, ok1 ? r2.y : 0.f};                        // (0 for a rejected pair: every term below vanishes)
+        const f32x2 s2 = K[m].sig2 * i2;
+        const f32x2 s6 = s2 * s2 * s2;
+        const f32x2 s12 = s6 * s6;
+        c1 += (K[m].m1a * s6 - K[m].m1b * s12) * i2;
+        if constexpr (LEVEL >= 2) {
+            kk += (K[m].kb * s12 - K[m].ka * s6) * (i2 * i2);
+            t6[m] = s6 * i2; t12[m] = s12 * i2;
+        }
+    }
+    fi.x += c1 * dx; fi.y += c1 * dy; fi.z += c1 * dz;                                // F_i += (phi'/r) D
+    if constexpr (JSIDE) {
+        if constexpr (CROSS) {
+            fj.x = __builtin_elementwise_fma(-c1.yx, dx.yx, fj.x); fj.y = __builtin_elementwise_fma(-c1.yx, dy.yx, fj.y);
+            fj.z = __builtin_elementwise_fma(-c1.yx, dz.yx, fj.z);
+        } else {
+            fj.x -= c1 * dx; fj.y -= c1 * dy; fj.z -= c1 * dz;
+        }
+    }
+    if constexpr (LEVEL >= 2) {
+        const f32x2 ax = wi.x - (CROSS ? wj.x.yx : wj.x), ay = wi.y - (CROSS ? wj.y.yx : wj.y),
+                    az = wi.z - (CROSS ? wj.z.yx : wj.z);
+        const f32x2 b = dx * ax + dy * ay + dz * az;                                  // w_ij . D
+        const f32x2 k2 = kk * b;
+        const f32x2 tx = __builtin_elementwise_fma(k2, dx, c1 * ax), ty = __builtin_elementwise_fma(k2, dy, c1 * ay),
+                    tz = __builtin_elementwise_fma(k2, dz, c1 * az);                  // -(H w) contribution
+        gi.x += tx; gi.y += ty; gi.z += tz;
+        if constexpr (JSIDE) {
+            gj.x -= CROSS ? tx.yx : tx; gj.y -= CROSS ? ty.yx : ty; gj.z -= CROSS ? tz.yx : tz;
+        }
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {                    // (a directed pair counts half of an undirected one: ONE set of sums, th = 2 S)
+            const f32x2 bw = JSIDE ? b : 0.5f * b;
+            TH[m][0] += t6[m] * bw; TH[m][1] += t12[m] * bw;
+        }
+    }
+}
+
+// ring_sweep for NT LJ 12-6 terms at once (no fused observable): the ring of ring_sweep, per-term mask bits and sums
+template <int LEVEL, bool NEAR, int NT>
+__device__ __forceinline__ void ring_sweep_lj_multi(const RingLJ (&K)[NT], const RingMask (&M)[NT], int N, int lane, const Vec3x2& q,
+                                                    const Vec3x2& w, Vec3x2& f, Vec3x2& g, float (&th)[NT][MDG_MAX_THETA],
+                                                    f32x2* __restrict__ lds) {
+    const int nl = (N + 1) >> 1;
+    const bool vi0 = 2 * lane < N, vi1 = 2 * lane + 1 < N;
+    f32x2* sqx = lds; f32x2* sqy = lds + 64; f32x2* sqz = lds + 128;
+    f32x2* swx = lds + 192; f32x2* swy = lds + 256; f32x2* swz = lds + 320;
+    ring_lds_fence();
+    sqx[lane] = q.x; sqy[lane] = q.y; sqz[lane] = q.z;
+    if constexpr (LEVEL >= 2) { swx[lane] = w.x; swy[lane] = w.y; swz[lane] = w.z; }
+    ring_lds_fence();
+    Vec3x2 fi = vzero(), gi = vzero(), fj = vzero(), gj = vzero();
+    f32x2 S[NT][MDG_MAX_THETA];
+#pragma unroll
+    for (int m = 0; m < NT; ++m)
+#pragma unroll
+        for (int k = 0; k < MDG_MAX_THETA; ++k) S[m][k] = f32x2{0.f, 0.f};
+    {   // step 0: the pair inside the lane, both directions
+        const bool v = vi0 && vi1;
+        bool vm[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) vm[m] = v && ((ring_mask_word(M[m].w, lane >> 4) >> (2 * (lane & 15) + 1)) & 1u);
+        ring_pair_lj_multi<LEVEL, NEAR, true, false, NT>(K, q, w, q, w, vm, vm, fi, gi, fj, gj, S);
+    }
+    const int prev = lane < nl ? ((lane == 0 ? nl : lane) - 1) * 4 : lane * 4;
+    const int nsteps = (nl - 1) >> 1;
+    int idx = lane;
+    Vec3x2 qj, wj = vzero();
+#pragma unroll 1
+    for (int k = 1; k <= nsteps; ++k) {
+        idx -= 1; idx = idx < 0 ? idx + nl : idx;
+        qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
+        fj = ring_move(fj, prev);
+        if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; gj = ring_move(gj, prev); }
+        const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
+        const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
+        bool ms0[NT], ms1[NT], mc0[NT], mc1[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const uint32_t b0 = ring_mask_word(M[m].w, idx >> 4) >> (2 * (idx & 15)), b1 = ring_mask_word(M[m].w + 4, idx >> 4) >> (2 * (idx & 15));
+            ms0[m] = s0 && (b0 & 1u); mc0[m] = c0 && (b0 & 2u); mc1[m] = c1 && (b1 & 1u); ms1[m] = s1 && (b1 & 2u);
+        }
+        ring_pair_lj_multi<LEVEL, NEAR, false, true, NT>(K, q, w, qj, wj, ms0, ms1, fi, gi, fj, gj, S);
+        ring_pair_lj_multi<LEVEL, NEAR, true, true, NT>(K, q, w, qj, wj, mc0, mc1, fi, gi, fj, gj, S);
+    }
+    if (!(nl & 1)) {                                                  // antipodal lanes: directed evaluation, visitors not updated
+        idx -= 1; idx = idx < 0 ? idx + nl : idx;
+        qj.x = sqx[idx]; qj.y = sqy[idx]; qj.z = sqz[idx];
+        if constexpr (LEVEL >= 2) { wj.x = swx[idx]; wj.y = swy[idx]; wj.z = swz[idx]; }
+        const bool vj0 = 2 * idx < N, vj1 = 2 * idx + 1 < N;
+        const bool s0 = vi0 && vj0, s1 = vi1 && vj1, c0 = vi0 && vj1, c1 = vi1 && vj0;
+        bool ms0[NT], ms1[NT], mc0[NT], mc1[NT];
+#pragma unroll
+        for (int m = 0; m < NT; ++m) {
+            const uint32_t b0 = ring_mask_word(M[m].w, idx >> 4) >> (2 * (idx & 15)), b1 = ring_mask_word(M[m].w + 4, idx >> 4) >> (2 * (idx & 15));
+            ms0[m] = s0 && (b0 & 1u); mc0[m] = c0 && (b0 & 2u); mc1[m] = c1 && (b1 & 1u); ms1[m] = s1 && (b1 & 2u);
+        }
+        Vec3x2 fu = vzero(), gu = vzero();
+        ring_pair_lj_multi<LEVEL, NEAR, false, false, NT>(K, q, w, qj, wj, ms0, ms1, fi, gi, fu, gu, S);
+        ring_pair_lj_multi<LEVEL, NEAR, true, false, NT>(K, q, w, qj, wj, mc0, mc1, fi, gi, fu, gu, S);
+    }
+    int home = lane + nsteps; home = home >= nl ? home - nl : home;
+    home = (lane < nl ? home : lane) * 4;
+    fj = ring_move(fj, home);
+    f.x = fi.x + fj.x; f.y = fi.y + fj.y; f.z = fi.z + fj.z;
+    if constexpr (LEVEL >= 2) {
+        gj = ring_move(gj, home);
+        g.x = -(gi.x + gj.x); g.y = -(gi.y + gj.y); g.z = -(gi.z + gj.z);
+#pragma unroll
+        for (int m = 0; m < NT; ++m)
+#pragma unroll
+            for (int k = 0; k < MDG_MAX_THETA; ++k) th[m][k] = 2.f * hsum(S[m][k]);
+    }
+}
+
 // NT terms of one pair form (round 6: the species mixtures of scripts/fit_mix.py -- index_tuple stacks, torchmd/interface.py:
-// 228-260): one ring sweep per term with the term's constants and its 128-bit mask rows, forces and Hessian.w added up, the
-// parameter sums kept per term.  The fused observable rides on the first term's sweep only (its flags are unmasked).
+// 228-260): LJ 12-6 terms share ONE sweep (ring_sweep_lj_multi); other LJ-family powers take one ring sweep per term with the
+// term's constants and its 128-bit mask rows, forces and Hessian.w added up, the parameter sums kept per term.  The fused
+// observable rides on the first term's sweep only (its flags are unmasked).
 template <int LEVEL, int RDF, int KIND, bool MASK, int NT>
 __device__ __forceinline__ void ring_force_terms(const RingLJ (&K)[NT], const RingRdf& X, const RingMask (&M)[NT], bool with_rdf, int N,
                                                  int lane, const Vec3x2& q, const Vec3x2& w, Vec3x2& f, Vec3x2& g,
                                                  float (&th)[NT][MDG_MAX_THETA], Vec3x2& rq, f32x2* __restrict__ lds) {
+    if constexpr (NT > 1 && KIND == KIND_LJ126 && RDF == 0) {
+        // LJ 12-6 terms: ONE sweep, the pair geometry shared (ring_sweep_lj_multi)
+        if constexpr (LEVEL >= 1) {
+            if (ring_near(K[0], q)) ring_sweep_lj_multi<LEVEL, true, NT>(K, M, N, lane, q, w, f, g, th, lds);
+            else ring_sweep_lj_multi<LEVEL, false, NT>(K, M, N, lane, q, w, f, g, th, lds);
+        }
+        return;
+    }
     ring_force<LEVEL, RDF, KIND, MASK>(K[0], X, M[0], with_rdf, N, lane, q, w, f, g, th[0], rq, lds);
     if constexpr (NT > 1 && LEVEL >= 1) {
 #pragma unroll

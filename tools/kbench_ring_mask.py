@@ -33,7 +33,7 @@ def main():
     A_, B_ = list(range(0, 108, 2)), list(range(1, 108, 2))
     mix = [dict(index_tuple=(A_, A_)), dict(index_tuple=(B_, B_)), dict(index_tuple=(A_, B_))]
     for name, kws, block in (("unmasked LJ 12-6", [{}], 0), ("two species, index_tuple (A, B)", [dict(index_tuple=(A_, B_))], 0),
-                             ("mixture A-A + B-B + A-B, ring (one sweep per term)", mix, 0),
+                             ("mixture A-A + B-B + A-B, ring (one shared sweep)", mix, 0),
                              ("mixture A-A + B-B + A-B, workgroup kernels", mix, 128)):
         mdls = [P.LennardJones(1.0 - 0.05 * k, 1.0 + 0.1 * k) for k in range(len(kws))]
         integ = NoseHooverChain(Stack({"t%d" % k: PairPotentials(system, m, cutoff=2.5, **kw) for k, (m, kw) in enumerate(zip(mdls, kws))}),
