@@ -13,6 +13,12 @@ OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmdgrad_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# The SLP vectoriser pairs adjacent scalar f32 multiply-adds into v_pk_fma_f32 plus the v_mov's that line their operands up; on
+# gfx950 a packed f32 instruction costs 1.5-1.8 x a scalar one (profiles/r05_valu_rate.txt), so beside MFMAs the pairing is a loss:
+# the stashed cfconv sweeps 55.9 -> 50.3 us and no spill, the stacked SchNet pass + 2 % (profiles/r06_noslp_ab.txt).  The ring /
+# workgroup trajectory kernels keep it (their packed forms are written by hand, and the headline measured 0.6 % lower without).
+NO_SLP = ["-fno-slp-vectorize"]
+SLP_SOURCES = {"traj_small.hip"}
 
 
 def _newer(src, dst, deps):
@@ -24,9 +30,10 @@ def _newer(src, dst, deps):
 
 def _compile(src):
     obj = os.path.join(OBJDIR, os.path.basename(src) + ".o")
-    deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    deps = glob.glob(os.path.join(CSRC, "*.hpp")) + glob.glob(os.path.join(HERE, "..", "include", "*.h")) + [os.path.abspath(__file__)]
     if _newer(src, obj, deps):
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        extra = [] if os.path.basename(src) in SLP_SOURCES else NO_SLP
+        cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))

@@ -463,8 +463,13 @@ enum { SPEC_FWD = 0, SPEC_TURN = 1, SPEC_REV = 2 };
 //  launch is as fast as there are workgroups in flight -- the register budget is that of four waves per SIMD where it costs no
 //  scratch (n_atom_basis = 64): the turn chain 136 -> 116 registers, the forward chain 104 -> 90; the reverse chain would spill
 //  two dwords and the 128-wide chains hundreds of bytes: they keep the compiler's own budget)
-template <int A_, int F_, bool DUAL, int KIND>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((A_ == 64 && KIND != 2) ? 4 : 1)))
+// LOOP (round 6): many rows -- a stack of replicas, 2 048 row tiles -- as ONE round of workgroups has every workgroup of the
+// chip in the same phase at the same time (all loading, then all multiplying, then all storing) and re-reads the chain's
+// weights from L2 once per 16 rows (80 KB per workgroup: 164 MB per launch beside ~110 MB of rows).  The LOOP instantiation is
+// launched with a few workgroups per CU; each keeps ALL weight fragments and biases of the chain in registers and walks row
+// tiles blockIdx.x, + gridDim.x, ...: the weights are read once per workgroup and the workgroups of a CU drift out of phase.
+template <int A_, int F_, bool DUAL, int KIND, bool LOOP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LOOP ? 2 : ((A_ == 64 && KIND != 2) ? 4 : 1))))
 void chain_spec_kernel(const ChainArgs A) {
     constexpr int H_ = A_ / 2;                                                      // readout hidden width
     constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + 4;
@@ -472,137 +477,166 @@ void chain_spec_kernel(const ChainArgs A) {
     float* X0 = Xs;
     float* X1 = Xs + (DUAL ? RC_ROWS * ldt : 0);
     const int N = A.N, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int row0 = blockIdx.x * RC_ROWS, row = row0 + li;
+    const int n_tiles = (N + RC_ROWS - 1) / RC_ROWS, t_step = LOOP ? (int)gridDim.x : n_tiles;
     float sgA[spec_tp<A_>()][4], tdA[spec_tp<A_>()][4], zA[spec_tp<A_>()][4], zF[spec_tp<F_>()][4], zH[spec_tp<H_>()][4];
     float dF[spec_tp<F_>()][4], dH[spec_tp<H_>()][4];                              // (sigmoid / tangent sinks of stages that keep none)
     spec_zero<A_>(zA); spec_zero<F_>(zF); spec_zero<H_>(zH);
     if constexpr (KIND == SPEC_FWD) {
         // ---- first round trip: the weights of the first two stages, the input rows, the residual rows, the biases.  The
         //      weights of the third stage are requested while the first multiplies, each bias before its stage's products.
-        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
+        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
+        float b0[spec_tp<A_>()][4], b1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
-        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
-        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-        spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
-        spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
-        float b0[spec_tp<A_>()][4], b1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4];
-        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
-        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
-        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
-        __syncthreads();
-        // stage 0: t = ssp(U1 m + c1), su, td
-        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        float w2[spec_tp<F_>()][A_ / 4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
-        spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
-        spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
-        __syncthreads();
-        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
-        __syncthreads();
-        // stage 1: r' = U2 t + c2 + r
-        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-        __syncthreads();
-        {
-            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+        if constexpr (LOOP) {
+            spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
+            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
+            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
+            spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
         }
-        __syncthreads();
-        // stage 2: h' = Wn' r' + bn'
-        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
-        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
-        __syncthreads();
-        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
+        for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
+            const int row0 = tile * RC_ROWS, row = row0 + li;
+            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+            float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+            spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+            if constexpr (!LOOP) {
+                spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
+                spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
+            }
+            f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+            __syncthreads();
+            // stage 0: t = ssp(U1 m + c1), su, td
+            spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+            if constexpr (!LOOP) {
+                spec_load_w<A_, F_, false>(A.s[2].W, wid, li, lk, w2);
+                spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
+            }
+            __syncthreads();
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+            __syncthreads();
+            // stage 1: r' = U2 t + c2 + r
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+            }
+            __syncthreads();
+            // stage 2: h' = Wn' r' + bn'
+            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
+            __syncthreads();
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
+            if constexpr (LOOP) __syncthreads();                                   // (the next tile's rows overwrite X)
+        }
     } else if constexpr (KIND == SPEC_TURN) {
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
+        float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
+        float bA0[spec_tp<A_>()][4], bA1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], bH[spec_tp<H_>()][4], lH[spec_tp<H_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
-        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
-        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-        spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
-        spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
-        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
-        float bA[spec_tp<A_>()][4], lA[spec_tp<A_>()][4];
-        __syncthreads();
-        // stage 0: t = ssp(U1 m + c1), su, td
-        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        __syncthreads();
-        spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA, lA);
-        spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA, zA);
-        __syncthreads();
-        // stage 1: r' = U2 t + c2 + r
-        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-        __syncthreads();
-        {
-            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA, lA);
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA, zA);
-        }
-        __syncthreads();
-        float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
-        spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
-        spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
-        spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
-        spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
-        // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
-        f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
-        spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
-        __syncthreads();
-        {
-            float bH[spec_tp<H_>()][4], lH[spec_tp<H_>()][4];
+        if constexpr (LOOP) {
+            spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
+            spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
+            spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
+            spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
+            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA0, lA);
+            spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA1, lA);
             spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
+        }
+        for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
+            const int row0 = tile * RC_ROWS, row = row0 + li;
+            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+            float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+            spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+            f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+            __syncthreads();
+            // stage 0: t = ssp(U1 m + c1), su, td
+            spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+            __syncthreads();
+            if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA0, lA);
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA0, zA);
+            __syncthreads();
+            // stage 1: r' = U2 t + c2 + r
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA1, lA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA1, zA);
+            }
+            __syncthreads();
+            if constexpr (!LOOP) {
+                spec_load_w<A_, H_, false>(A.s[2].W, wid, li, lk, w2);
+                spec_load_w<H_, A_, true>(A.s[3].W, wid, li, lk, w3);
+                spec_load_w<A_, A_, true>(A.s[4].W, wid, li, lk, w4);
+                spec_load_w<A_, F_, true>(A.s[5].W, wid, li, lk, w5);
+            }
+            // stage 2: readout + head: sy, syd kept in global; out = (ydb, yb)
+            f32x4 h0[spec_tp<H_>()], h1[spec_tp<H_>()];
+            spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
+            __syncthreads();
+            if constexpr (!LOOP) spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
             spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
+            __syncthreads();
+            // stage 3: (rdb, rb) = (ydb, yb) L1
+            spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+            }
+            __syncthreads();
+            // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w4, a0, a1);
+            __syncthreads();
+            {
+                float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
+                                                                                    N, wid, li, lk, zA, zA);
+            }
+            __syncthreads();
+            // stage 5: (mdb, mb) = (udb, ub) U1
+            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
+            __syncthreads();
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            if constexpr (LOOP) __syncthreads();
         }
-        __syncthreads();
-        // stage 3: (rdb, rb) = (ydb, yb) L1
-        spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
-        __syncthreads();
-        {
-            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
-        }
-        __syncthreads();
-        // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
-        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w4, a0, a1);
-        __syncthreads();
-        {
-            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
-                                                                                N, wid, li, lk, zA, zA);
-        }
-        __syncthreads();
-        // stage 5: (mdb, mb) = (udb, ub) U1
-        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
-        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
-        __syncthreads();
-        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
     } else {
         // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
         float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
         spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
         spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
-        spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
-        float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-        spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
-        spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
-        spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
-        spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, row, N, wid, lk, tdA);
-        f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
-        float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-        __syncthreads();
-        spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
-        __syncthreads();
-        spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
-        __syncthreads();
-        spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
-        __syncthreads();
-        spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
-                                                                            li, lk, zA, zA);
-        __syncthreads();
-        f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
-        spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
-        __syncthreads();
-        spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+        for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
+            const int row0 = tile * RC_ROWS, row = row0 + li;
+            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+            float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
+            spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
+            spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
+            spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
+            spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, row, N, wid, lk, tdA);
+            f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
+            float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
+            __syncthreads();
+            spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
+            __syncthreads();
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+            __syncthreads();
+            spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
+            __syncthreads();
+            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
+                                                                                li, lk, zA, zA);
+            __syncthreads();
+            f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
+            spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
+            __syncthreads();
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            if constexpr (LOOP) __syncthreads();
+        }
     }
 }
 
@@ -636,16 +670,42 @@ int spec_kind(const MdgChainStage* s, int n, int dual, int A_, int F_) {
     return -1;
 }
 
+// workgroups of the LOOP instantiation: as many as are resident at once (the kernel's occupancy), trimmed so that every
+// workgroup walks the same number of tiles where that is possible; 0: one round of workgroups, no loop (fewer than two
+// tiles per resident workgroup, or MDG_CHAIN_LOOP_WGS=0; MDG_CHAIN_LOOP_WGS=n: n workgroups per CU)
+template <typename K>
+int loop_grid(K kernel, int n_tiles) {
+    static int per_cu = -1, cus = 0;                                 // (per instantiation)
+    if (per_cu < 0) {
+        const char* e = getenv("MDG_CHAIN_LOOP_WGS");
+        int occ = 0, dev = 0;
+        hipDeviceProp_t p;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
+        if (e) occ = atoi(e);
+        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess) occ = 0;
+        per_cu = occ < 0 ? 0 : occ;
+    }
+    if (per_cu <= 0 || n_tiles < 2 * per_cu * cus) return 0;
+    const int rounds = (n_tiles + per_cu * cus - 1) / (per_cu * cus);
+    return (n_tiles + rounds - 1) / rounds;
+}
+
+template <int A_, int F_, bool DUAL, int KIND>
+void spec_launch_kind(const ChainArgs& a, int n_tiles, hipStream_t st) {
+    int lg = 0;
+    if constexpr (A_ == 64) lg = loop_grid(chain_spec_kernel<A_, F_, DUAL, KIND, true>, n_tiles);   // (A = 128: the weights do not fit)
+    if constexpr (A_ == 64) {
+        if (lg) { hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, true>), dim3(lg), dim3(256), 0, st, a); return; }
+    }
+    hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, false>), dim3(n_tiles), dim3(256), 0, st, a);
+}
+
 template <int A_, int F_>
 bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, hipStream_t st) {
     const int kind = spec_kind(s, n, dual, A_, F_);
     if (kind < 0) return false;
-    dim3 grid((n_rows + RC_ROWS - 1) / RC_ROWS), block(256);
-#define MDG_SPEC(K_)                                                                                         \
-    do {                                                                                                     \
-        if (dual) hipLaunchKernelGGL((chain_spec_kernel<A_, F_, true, K_>), grid, block, 0, st, a);          \
-        else hipLaunchKernelGGL((chain_spec_kernel<A_, F_, false, K_>), grid, block, 0, st, a);              \
-    } while (0)
+    const int n_tiles = (n_rows + RC_ROWS - 1) / RC_ROWS;
+#define MDG_SPEC(K_) do { if (dual) spec_launch_kind<A_, F_, true, K_>(a, n_tiles, st); else spec_launch_kind<A_, F_, false, K_>(a, n_tiles, st); } while (0)
     if (kind == SPEC_FWD) MDG_SPEC(SPEC_FWD); else if (kind == SPEC_TURN) MDG_SPEC(SPEC_TURN); else MDG_SPEC(SPEC_REV);
 #undef MDG_SPEC
     return true;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Summarise rocprofv3 (ROCm 7.2 rocpd sqlite) outputs as text:
-  python tools/rocpd_summary.py stats <results.db>          per-kernel time table (--kernel-trace --stats)
+  python tools/rocpd_summary.py stats <results.db> [last_ms] per-kernel time table (--kernel-trace --stats)
   python tools/rocpd_summary.py pmc   <results.db> [...]    per-kernel mean counter values (--pmc passes)
   python tools/rocpd_summary.py gaps  <results.db> [n [last_ms]]   the n longest idle stretches between two kernels, with the
                                                             kernels on either side, and the idle time by the kernel that
@@ -16,17 +16,20 @@ def short(name, n=70):
     return name if len(name) <= n else name[:n - 3] + "..."
 
 
-def stats(path):
+def stats(path, last_ms=None):
     cur = sqlite3.connect(path).cursor()
+    where = ""
+    if last_ms is not None:                                  # only the launches of the last so many ms of the trace
+        where = " where start >= %d" % (cur.execute("select max(end) from kernels").fetchone()[0] - int(last_ms * 1e6))
     rows = cur.execute("select name, duration, workgroup_x, grid_x, vgpr_count, sgpr_count, lds_size, scratch_size "
-                       "from kernels").fetchall()
+                       "from kernels" + where).fetchall()
     agg = defaultdict(list)
     meta = {}
     for name, dur, wg, grid, vg, sg, lds, scr in rows:
         agg[name].append(dur)
         meta[name] = (wg, grid, vg, sg, lds, scr)
     total = sum(sum(v) for v in agg.values())
-    n, t0, t1 = cur.execute("select count(*), min(start), max(end) from kernels").fetchone()
+    n, t0, t1 = cur.execute("select count(*), min(start), max(end) from kernels" + where).fetchone()
     print("# %d kernel launches, GPU busy %.3f ms, first-start to last-end span %.3f ms" % (n, total / 1e6, (t1 - t0) / 1e6))
     print("%-72s %6s %12s %12s %12s %12s %6s | %5s %8s %5s %5s %7s %5s" % (
         "kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%", "wg", "grid", "vgpr", "sgpr", "lds", "scr"))
@@ -81,7 +84,7 @@ def pmc(paths):
 
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
-        stats(sys.argv[2])
+        stats(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else None)
     elif sys.argv[1] == "gaps":
         gaps(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 25, float(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:
