@@ -598,10 +598,15 @@ int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, i
  * dual = 0: only the "0" operands are touched.  aux0 / aux1 / res may be buffers an EARLIER stage of the same call wrote
  * with the same width M (same owner thread); any other aliasing between a stage's outputs and a later stage's inputs is
  * not allowed.  Widths 1..MDG_CHAIN_MAX_WIDTH, 1..MDG_CHAIN_MAX_STAGES stages.
+ * flags: MDG_CHAIN_DUAL (= the former `dual` argument: 0 / 1) | MDG_CHAIN_X3: the stage products as three bf16 MFMAs on
+ * operands split into bf16 head + bf16 remainder (x_h w_h + x_h w_l + x_l w_h, f32 accumulate: ~1e-5 relative per product
+ * instead of 6e-8, 3/16 of the matrix time) -- the companion of the rows16 precision option, honoured by the compiled
+ * n_atom_basis = 64 chains and ignored (f32 products) by every other list.
  */
 #define MDG_CHAIN_MAX_STAGES 8
 #define MDG_CHAIN_MAX_WIDTH 512
 enum { MDG_CHAIN_NONE = 0, MDG_CHAIN_MUL = 1, MDG_CHAIN_HEAD = 2, MDG_CHAIN_SSP_BWD = 3 };
+enum { MDG_CHAIN_DUAL = 1, MDG_CHAIN_X3 = 2 };
 typedef struct {
     const float* W;
     const float* bias;
@@ -620,7 +625,7 @@ typedef struct {
     uint16_t* out1_h;
     int32_t K, M, trans, act, mode, pad_;
 } MdgChainStage;
-int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream);
+int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int flags, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * All parameter-gradient reductions of one SchNet adjoint evaluation in two launches (csrc/gradjobs.hip): what double
@@ -702,7 +707,7 @@ typedef struct {
     MdgCell cell;
     float* ws;
     int64_t ws_floats;
-    int32_t stash, pad_;      /* stash != 0: blocks with bf16 operands run mdg_cfconv_filter_stash once per evaluation and the
+    int32_t stash, chain_x3;  /* chain_x3 != 0: the node-level chains run with MDG_CHAIN_X3 (split-bf16 products).  stash != 0: blocks with bf16 operands run mdg_cfconv_filter_stash once per evaluation and the
                                  stashed forward-type sweeps (mdg_cfconv_fwd_stashed): same results, fewer instructions */
 } MdgSchnetPlan;              /* host struct of DEVICE pointers */
 int64_t mdg_schnet_plan_sizeof(void);      /* sizeof(MdgSchnetPlan): bindings in other languages check their layout against it */

@@ -85,7 +85,7 @@ class MdgSchnetPlan(C.Structure):
                [(n, C.c_void_p) for n in ("r0", "h0", "h0_16", "onehot", "uniq")] + [("n_species", C.c_int32), ("masked", C.c_int32)] + \
                [("nbr", C.c_void_p), ("offsets", C.c_void_p), ("n_edges", C.c_int64)] + \
                [(n, C.c_void_p) for n in ("col", "eid", "cnt", "n_valid")] + [("max_nbr", C.c_int32), ("cutoff", C.c_float)] + \
-               [("cell", MdgCell), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("stash", C.c_int32), ("pad_", C.c_int32)]
+               [("cell", MdgCell), ("ws", C.c_void_p), ("ws_floats", C.c_int64), ("stash", C.c_int32), ("chain_x3", C.c_int32)]
 
 
 CHAIN_NONE, CHAIN_MUL, CHAIN_HEAD, CHAIN_SSP_BWD, CHAIN_MAX_STAGES, CHAIN_MAX_WIDTH = 0, 1, 2, 3, 8, 512

@@ -320,8 +320,93 @@ __device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float 
     v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
 }
 
+// X3 (round 6): the stage products as THREE bf16 MFMAs on operands split into a bf16 head and a bf16 remainder,
+//     x w  ~  x_h w_h + x_h w_l + x_l w_h                          (dropped: x_l w_l, 2^-18 of the product; heads round to nearest)
+// -- 3 v_mfma_f32_16x16x32_bf16 (3 x 16 cycles for 32 k) where the f32 form issues 8 v_mfma_f32_16x16x4_f32 (8 x 32 cycles): the
+// matrix time of a chain drops to 3/16.  The launches of the stacked trajectories are bound by exactly that time (dual forward
+// chain at 32 768 rows: 39.8 us, 26 us with the matrix instructions cut to a quarter).  ~1e-5 relative per product against
+// 6e-8: taken only where the caller says so (flag MDG_CHAIN_X3: the rows16 precision option, whose gathered rows are bf16).
+// LDS holds the stage inputs as two bf16 planes [16][ldt] (head, remainder) per row set; accumulation and epilogues are f32.
+typedef short rc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int rc_u32x4 __attribute__((ext_vector_type(4)));
+template <bool X3, int K, int M> struct WFrag { float b[spec_tp<M>()][K / 4]; };
+template <int K, int M> struct WFrag<true, K, M> { rc_bf16x8 h[spec_tp<M>()][K / 32], l[spec_tp<M>()][K / 32]; };
+
+// head / remainder of two floats, packed (low half = a)
+__device__ __forceinline__ void rc_split2(float a, float b, unsigned int& h, unsigned int& l) {
+    h = rc_pk_bf16(a, b);
+    l = rc_pk_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
+}
+__device__ __forceinline__ void rc_split8(const float (&f)[8], rc_bf16x8& h, rc_bf16x8& l) {
+    rc_u32x4 uh, ul;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned int a, b; rc_split2(f[2 * i], f[2 * i + 1], a, b); uh[i] = a; ul[i] = b; }
+    h = __builtin_bit_cast(rc_bf16x8, uh);
+    l = __builtin_bit_cast(rc_bf16x8, ul);
+}
+
+// lane (li, lk): W_eff[m = 16 t + li][k = 32 kc + 8 lk + 0..7], split
 template <int K, int M, bool TRANS>
-__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, float (&b)[spec_tp<M>()][K / 4]) {
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<true, K, M>& w) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+        const int t = wid + 4 * tt;
+        if (t * 16 >= M) continue;
+        const int m = t * 16 + li;
+#pragma unroll
+        for (int kc = 0; kc < K / 32; ++kc) {
+            float f[8];
+            if constexpr (!TRANS) {
+                const float4 u = ld4(W + m * K + 32 * kc + 8 * lk), v = ld4(W + m * K + 32 * kc + 8 * lk + 4);
+                f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) f[c] = W[(32 * kc + 8 * lk + c) * M + m];
+            }
+            rc_split8(f, w.h[tt][kc], w.l[tt][kc]);
+        }
+    }
+}
+
+// the X3 image of a row set: plane 0 = heads, plane 1 = remainders, [RC_ROWS][ldt] bf16 each (ldt elements = 2 ldt bytes per row)
+__device__ __forceinline__ void rc_put4(float* X, int ldt, int r, int k, float a, float b, float c, float d) {
+    unsigned short* P = reinterpret_cast<unsigned short*>(X);
+    unsigned int h0, l0, h1, l1;
+    rc_split2(a, b, h0, l0);
+    rc_split2(c, d, h1, l1);
+    *reinterpret_cast<rc_u32x2*>(P + r * ldt + k) = rc_u32x2{h0, h1};
+    *reinterpret_cast<rc_u32x2*>(P + (RC_ROWS + r) * ldt + k) = rc_u32x2{l0, l1};
+}
+
+template <bool DUAL, int K, int M>
+__device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk, const WFrag<true, K, M>& w,
+                                         f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
+    const unsigned short* P0 = reinterpret_cast<const unsigned short*>(X0);
+    const unsigned short* P1 = reinterpret_cast<const unsigned short*>(X1);
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt) { acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[tt] = acc0[tt]; }
+#pragma unroll
+    for (int kc = 0; kc < K / 32; ++kc) {
+        const int o = li * ldt + 32 * kc + 8 * lk;
+        const rc_bf16x8 xh = *reinterpret_cast<const rc_bf16x8*>(P0 + o), xl = *reinterpret_cast<const rc_bf16x8*>(P0 + RC_ROWS * ldt + o);
+        rc_bf16x8 yh = xh, yl = xl;
+        if (DUAL) { yh = *reinterpret_cast<const rc_bf16x8*>(P1 + o); yl = *reinterpret_cast<const rc_bf16x8*>(P1 + RC_ROWS * ldt + o); }
+#pragma unroll
+        for (int tt = 0; tt < spec_tp<M>(); ++tt) {
+            if ((wid + 4 * tt) * 16 >= M) continue;
+            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[tt][kc], xh, acc0[tt], 0, 0, 0);
+            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[tt][kc], yh, acc1[tt], 0, 0, 0);
+            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], xl, acc0[tt], 0, 0, 0);
+            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], yl, acc1[tt], 0, 0, 0);
+            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], xh, acc0[tt], 0, 0, 0);
+            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], yh, acc1[tt], 0, 0, 0);
+        }
+    }
+}
+
+template <int K, int M, bool TRANS>
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<false, K, M>& w) {
+    float (&b)[spec_tp<M>()][K / 4] = w.b;
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
         const int t = wid + 4 * tt;
@@ -355,7 +440,7 @@ __device__ __forceinline__ void spec_load_bias(const MdgChainStage& S, int wid, 
     }
 }
 
-template <bool DUAL, int K>
+template <bool DUAL, int K, bool X3 = false>
 __device__ __forceinline__ void spec_load_x(const float* __restrict__ in0, const float* __restrict__ in1, float* X0, float* X1,
                                             int ldt, int row0, int N, int tid) {
     constexpr int KQ = K / 4;
@@ -369,16 +454,64 @@ __device__ __forceinline__ void spec_load_x(const float* __restrict__ in0, const
             v0 = ld4(in0 + (unsigned)(rw * K + k));
             if (DUAL && in1) v1 = ld4(in1 + (unsigned)(rw * K + k));
         }
-        *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0;
-        if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1;
+        if constexpr (X3) {
+            rc_put4(X0, ldt, r, k, v0.x, v0.y, v0.z, v0.w);
+            if (DUAL) rc_put4(X1, ldt, r, k, v1.x, v1.y, v1.z, v1.w);
+        } else {
+            *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0;
+            if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1;
+        }
     }
+}
+
+// the same in two halves for the LOOP kernels: the next tile's rows are requested into registers while the current tile is
+// worked on, and written to LDS when its turn comes
+template <int K> constexpr int spec_xq() { return (RC_ROWS * (K / 4) + 255) / 256; }
+template <bool DUAL, int K>
+__device__ __forceinline__ void spec_fetch_x(const float* __restrict__ in0, const float* __restrict__ in1, int row0, int N, int tid,
+                                             float4 (&v0)[spec_xq<K>()], float4 (&v1)[spec_xq<K>()]) {
+    constexpr int KQ = K / 4;
+#pragma unroll
+    for (int i = 0; i < spec_xq<K>(); ++i) {
+        const int t = i * 256 + tid, r = t / KQ, k = (t % KQ) * 4, rw = row0 + r;
+        v0[i] = make_float4(0.f, 0.f, 0.f, 0.f); v1[i] = v0[i];
+        if (t < RC_ROWS * KQ && rw < N) {
+            v0[i] = ld4(in0 + (unsigned)(rw * K + k));
+            if (DUAL && in1) v1[i] = ld4(in1 + (unsigned)(rw * K + k));
+        }
+    }
+}
+template <bool DUAL, int K, bool X3 = false>
+__device__ __forceinline__ void spec_put_x(float* X0, float* X1, int ldt, int tid, const float4 (&v0)[spec_xq<K>()],
+                                           const float4 (&v1)[spec_xq<K>()]) {
+    constexpr int KQ = K / 4;
+#pragma unroll
+    for (int i = 0; i < spec_xq<K>(); ++i) {
+        const int t = i * 256 + tid, r = t / KQ, k = (t % KQ) * 4;
+        if (RC_ROWS * KQ % 256 != 0 && t >= RC_ROWS * KQ) break;
+        if constexpr (X3) {
+            rc_put4(X0, ldt, r, k, v0[i].x, v0[i].y, v0[i].z, v0[i].w);
+            if (DUAL) rc_put4(X1, ldt, r, k, v1[i].x, v1[i].y, v1[i].z, v1[i].w);
+        } else {
+            *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0[i];
+            if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1[i];
+        }
+    }
+}
+template <int M>
+__device__ __forceinline__ void spec_copy(float (&d)[spec_tp<M>()][4], const float (&s)[spec_tp<M>()][4]) {
+#pragma unroll
+    for (int tt = 0; tt < spec_tp<M>(); ++tt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[tt][r] = s[tt][r];
 }
 
 // matrix part of a stage: acc[tt] (+)= rows of X (LDS) x the wave's weight fragments; lane (li, lk) ends up with columns
 // 16 t + 4 lk + [0, 4) of row li
 template <bool DUAL, int K, int M>
 __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk,
-                                         const float (&b)[spec_tp<M>()][K / 4], f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
+                                         const WFrag<false, K, M>& w, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
+    const float (&b)[spec_tp<M>()][K / 4] = w.b;
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) { acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[tt] = acc0[tt]; }
 #pragma unroll
@@ -392,6 +525,9 @@ __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int l
             if ((wid + 4 * tt) * 16 >= M) continue;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
+#ifdef MDG_CHAIN_FAKE
+                if (c) continue;
+#endif
                 acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tt][4 * q + c], a0[c], acc0[tt], 0, 0, 0);
                 if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[tt][4 * q + c], a1[c], acc1[tt], 0, 0, 0);
             }
@@ -402,7 +538,7 @@ __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int l
 
 // epilogue of a stage on the lane's 4 columns of each of its tiles; x0 / x1: operands of MUL / SSP_BWD (registers), q0 / q1:
 // residuals (registers); sg / kd receive sigmoid and the tangent row of an activation stage
-template <bool DUAL, int M, int ACT, int MODE>
+template <bool DUAL, int M, int ACT, int MODE, bool X3 = false>
 __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()],
                                               const float (&x0)[spec_tp<M>()][4], const float (&x1)[spec_tp<M>()][4],
                                               const float (&q0)[spec_tp<M>()][4], const float (&q1)[spec_tp<M>()][4],
@@ -434,8 +570,13 @@ __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&ac
                 if (DUAL) st4h(S.out1_h, o, z1);
             }
         }
-        *reinterpret_cast<float4*>(X0 + li * ldt + m) = make_float4(z0[0], z0[1], z0[2], z0[3]);
-        if (DUAL) *reinterpret_cast<float4*>(X1 + li * ldt + m) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+        if constexpr (X3) {
+            rc_put4(X0, ldt, li, m, z0[0], z0[1], z0[2], z0[3]);
+            if (DUAL) rc_put4(X1, ldt, li, m, z1[0], z1[1], z1[2], z1[3]);
+        } else {
+            *reinterpret_cast<float4*>(X0 + li * ldt + m) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+            if (DUAL) *reinterpret_cast<float4*>(X1 + li * ldt + m) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+        }
     }
 }
 
@@ -468,11 +609,11 @@ enum { SPEC_FWD = 0, SPEC_TURN = 1, SPEC_REV = 2 };
 // weights from L2 once per 16 rows (80 KB per workgroup: 164 MB per launch beside ~110 MB of rows).  The LOOP instantiation is
 // launched with a few workgroups per CU; each keeps ALL weight fragments and biases of the chain in registers and walks row
 // tiles blockIdx.x, + gridDim.x, ...: the weights are read once per workgroup and the workgroups of a CU drift out of phase.
-template <int A_, int F_, bool DUAL, int KIND, bool LOOP>
+template <int A_, int F_, bool DUAL, int KIND, bool LOOP, bool X3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LOOP ? 2 : ((A_ == 64 && KIND != 2) ? 4 : 1))))
 void chain_spec_kernel(const ChainArgs A) {
     constexpr int H_ = A_ / 2;                                                      // readout hidden width
-    constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + 4;
+    constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + (X3 ? 8 : 4);       // (X3: bf16 elements per plane row)
     __shared__ __attribute__((aligned(16))) float Xs[(DUAL ? 2 : 1) * RC_ROWS * ldt];
     float* X0 = Xs;
     float* X1 = Xs + (DUAL ? RC_ROWS * ldt : 0);
@@ -484,7 +625,7 @@ void chain_spec_kernel(const ChainArgs A) {
     if constexpr (KIND == SPEC_FWD) {
         // ---- first round trip: the weights of the first two stages, the input rows, the residual rows, the biases.  The
         //      weights of the third stage are requested while the first multiplies, each bias before its stage's products.
-        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
+        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1; WFrag<X3, A_, F_> w2;
         float b0[spec_tp<A_>()][4], b1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
@@ -494,13 +635,27 @@ void chain_spec_kernel(const ChainArgs A) {
             spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
             spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
         }
+        float4 px0[spec_xq<F_>()], px1[spec_xq<F_>()];                            // LOOP: the next tile's rows and residuals
+        float pq0[spec_tp<A_>()][4], pq1[spec_tp<A_>()][4];
+        if constexpr (LOOP) {
+            spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, blockIdx.x * RC_ROWS, N, tid, px0, px1);
+            spec_load_rows<A_>(A.s[1].res0, blockIdx.x * RC_ROWS + li, N, wid, lk, pq0);
+            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, blockIdx.x * RC_ROWS + li, N, wid, lk, pq1);
+        }
         for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
-            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-            spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
-            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
-            if constexpr (!LOOP) {
+            if constexpr (LOOP) {
+                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1);
+                const int nrow0 = (tile + t_step) * RC_ROWS;                        // (past the end: nothing is loaded)
+                spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
+                spec_load_rows<A_>(A.s[1].res0, nrow0 + li, N, wid, lk, pq0);
+                spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, nrow0 + li, N, wid, lk, pq1);
+            } else {
+                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+                spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
                 spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
                 spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, b1, lA);
             }
@@ -513,26 +668,26 @@ void chain_spec_kernel(const ChainArgs A) {
                 spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
             }
             __syncthreads();
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
             __syncthreads();
             // stage 1: r' = U2 t + c2 + r
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
             }
             __syncthreads();
             // stage 2: h' = Wn' r' + bn'
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
             if constexpr (LOOP) __syncthreads();                                   // (the next tile's rows overwrite X)
         }
     } else if constexpr (KIND == SPEC_TURN) {
-        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4];
-        float w2[spec_tp<H_>()][A_ / 4], w3[spec_tp<A_>()][H_ / 4], w4[spec_tp<A_>()][A_ / 4], w5[spec_tp<F_>()][A_ / 4];
+        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1;
+        WFrag<X3, A_, H_> w2; WFrag<X3, H_, A_> w3; WFrag<X3, A_, A_> w4; WFrag<X3, A_, F_> w5;
         float bA0[spec_tp<A_>()][4], bA1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], bH[spec_tp<H_>()][4], lH[spec_tp<H_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
@@ -545,19 +700,35 @@ void chain_spec_kernel(const ChainArgs A) {
             spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA1, lA);
             spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
         }
+        float4 px0[spec_xq<F_>()], px1[spec_xq<F_>()];
+        float pq0[spec_tp<A_>()][4], pq1[spec_tp<A_>()][4];
+        if constexpr (LOOP) {
+            spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, blockIdx.x * RC_ROWS, N, tid, px0, px1);
+            spec_load_rows<A_>(A.s[1].res0, blockIdx.x * RC_ROWS + li, N, wid, lk, pq0);
+            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, blockIdx.x * RC_ROWS + li, N, wid, lk, pq1);
+        }
         for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
-            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-            spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
-            spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+            if constexpr (LOOP) {
+                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1);
+                const int nrow0 = (tile + t_step) * RC_ROWS;
+                spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
+                spec_load_rows<A_>(A.s[1].res0, nrow0 + li, N, wid, lk, pq0);
+                spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, nrow0 + li, N, wid, lk, pq1);
+            } else {
+                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
+                spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
+            }
             f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
             __syncthreads();
             // stage 0: t = ssp(U1 m + c1), su, td
             spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
             __syncthreads();
             if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA0, lA);
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA0, zA);
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA0, zA);
             __syncthreads();
             // stage 1: r' = U2 t + c2 + r
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
@@ -565,7 +736,7 @@ void chain_spec_kernel(const ChainArgs A) {
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
                 if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA1, lA);
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA1, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA1, zA);
             }
             __syncthreads();
             if constexpr (!LOOP) {
@@ -579,14 +750,14 @@ void chain_spec_kernel(const ChainArgs A) {
             spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
             __syncthreads();
             if constexpr (!LOOP) spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
-            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
+            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD, X3>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
             __syncthreads();
             // stage 3: (rdb, rb) = (ydb, yb) L1
             spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
             }
             __syncthreads();
             // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
@@ -594,7 +765,7 @@ void chain_spec_kernel(const ChainArgs A) {
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
+                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, X3>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
                                                                                     N, wid, li, lk, zA, zA);
             }
             __syncthreads();
@@ -602,39 +773,60 @@ void chain_spec_kernel(const ChainArgs A) {
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
             if constexpr (LOOP) __syncthreads();
         }
     } else {
         // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
-        float w0[spec_tp<A_>()][F_ / 4], w1[spec_tp<A_>()][A_ / 4], w2[spec_tp<F_>()][A_ / 4];
+        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1; WFrag<X3, A_, F_> w2;
         spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
         spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
+        float4 px0[spec_xq<F_>()], px1[spec_xq<F_>()];
+        float pq0[spec_tp<A_>()][4], pq1[spec_tp<A_>()][4], psg[spec_tp<A_>()][4], ptd[spec_tp<A_>()][4];
+        if constexpr (LOOP) {
+            const int frow = blockIdx.x * RC_ROWS + li;
+            spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, blockIdx.x * RC_ROWS, N, tid, px0, px1);
+            spec_load_rows<A_>(A.s[0].res0, frow, N, wid, lk, pq0);
+            spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, frow, N, wid, lk, pq1);
+            spec_load_rows<A_>(A.s[1].aux0, frow, N, wid, lk, psg);
+            spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, frow, N, wid, lk, ptd);
+        }
         for (int tile = blockIdx.x, it = 0; LOOP ? tile < n_tiles : it < 1; tile += t_step, ++it) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
-            spec_load_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
-            spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
-            spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
-            spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
-            spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, row, N, wid, lk, tdA);
+            if constexpr (LOOP) {
+                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1); spec_copy<A_>(sgA, psg); spec_copy<A_>(tdA, ptd);
+                const int nrow0 = (tile + t_step) * RC_ROWS, nrow = nrow0 + li;
+                spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
+                spec_load_rows<A_>(A.s[0].res0, nrow, N, wid, lk, pq0);
+                spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, nrow, N, wid, lk, pq1);
+                spec_load_rows<A_>(A.s[1].aux0, nrow, N, wid, lk, psg);
+                spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, nrow, N, wid, lk, ptd);
+            } else {
+                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
+                spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
+                spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
+                spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, row, N, wid, lk, tdA);
+            }
             f32x4 a0[spec_tp<A_>()], a1[spec_tp<A_>()];
             float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
             __syncthreads();
             spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
             __syncthreads();
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
             __syncthreads();
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
             __syncthreads();
-            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
+            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, X3>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
                                                                                 li, lk, zA, zA);
             __syncthreads();
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
             if constexpr (LOOP) __syncthreads();
         }
     }
@@ -670,42 +862,52 @@ int spec_kind(const MdgChainStage* s, int n, int dual, int A_, int F_) {
     return -1;
 }
 
-// workgroups of the LOOP instantiation: as many as are resident at once (the kernel's occupancy), trimmed so that every
-// workgroup walks the same number of tiles where that is possible; 0: one round of workgroups, no loop (fewer than two
-// tiles per resident workgroup, or MDG_CHAIN_LOOP_WGS=0; MDG_CHAIN_LOOP_WGS=n: n workgroups per CU)
-template <typename K>
-int loop_grid(K kernel, int n_tiles) {
-    static int per_cu = -1, cus = 0;                                 // (per instantiation)
+// workgroups of the LOOP instantiation: two per CU -- what the hoisted weight fragments leave room for (148 - 219 registers) --
+// trimmed so that every workgroup walks the same number of tiles where that is possible; 0: one round of workgroups, no loop
+// (fewer than two tiles per looping workgroup, or MDG_CHAIN_LOOP_WGS=0; MDG_CHAIN_LOOP_WGS=n: n workgroups per CU).
+// Measured at 32 768 rows (tools/kbench_chain.py): dual forward chain 42.3 -> 38.4 us, dual turn chain 60.9 -> 53.4 us; three
+// per CU leaves a third of the CUs with one workgroup more than the rest (40.4 / 61.2 us).
+int loop_grid(int n_tiles) {
+    static int per_cu = -1, cus = 0;
     if (per_cu < 0) {
         const char* e = getenv("MDG_CHAIN_LOOP_WGS");
-        int occ = 0, dev = 0;
+        int dev = 0;
         hipDeviceProp_t p;
         cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) ? p.multiProcessorCount : 256;
-        if (e) occ = atoi(e);
-        else if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, 256, 0) != hipSuccess) occ = 0;
-        per_cu = occ < 0 ? 0 : occ;
+        per_cu = e ? atoi(e) : 2;
     }
     if (per_cu <= 0 || n_tiles < 2 * per_cu * cus) return 0;
     const int rounds = (n_tiles + per_cu * cus - 1) / (per_cu * cus);
     return (n_tiles + rounds - 1) / rounds;
 }
 
-template <int A_, int F_, bool DUAL, int KIND>
+template <int A_, int F_, bool DUAL, int KIND, bool X3>
 void spec_launch_kind(const ChainArgs& a, int n_tiles, hipStream_t st) {
     int lg = 0;
-    if constexpr (A_ == 64) lg = loop_grid(chain_spec_kernel<A_, F_, DUAL, KIND, true>, n_tiles);   // (A = 128: the weights do not fit)
+    if constexpr (A_ == 64) lg = loop_grid(n_tiles);   // (A = 128: the weights do not fit)
     if constexpr (A_ == 64) {
-        if (lg) { hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, true>), dim3(lg), dim3(256), 0, st, a); return; }
+        if (lg) { hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, true, X3>), dim3(lg), dim3(256), 0, st, a); return; }
     }
-    hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, false>), dim3(n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, false, X3>), dim3(n_tiles), dim3(256), 0, st, a);
 }
 
 template <int A_, int F_>
-bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, hipStream_t st) {
+bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, bool x3, hipStream_t st) {
     const int kind = spec_kind(s, n, dual, A_, F_);
     if (kind < 0) return false;
     const int n_tiles = (n_rows + RC_ROWS - 1) / RC_ROWS;
-#define MDG_SPEC(K_) do { if (dual) spec_launch_kind<A_, F_, true, K_>(a, n_tiles, st); else spec_launch_kind<A_, F_, false, K_>(a, n_tiles, st); } while (0)
+#define MDG_SPEC(K_)                                                                                                   \
+    do {                                                                                                               \
+        if constexpr (A_ == 64) {                          /* X3 is compiled for the n_atom_basis = 64 chains */        \
+            if (x3) {                                                                                                  \
+                if (dual) spec_launch_kind<A_, F_, true, K_, true>(a, n_tiles, st);                                    \
+                else spec_launch_kind<A_, F_, false, K_, true>(a, n_tiles, st);                                        \
+                break;                                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        if (dual) spec_launch_kind<A_, F_, true, K_, false>(a, n_tiles, st);                                           \
+        else spec_launch_kind<A_, F_, false, K_, false>(a, n_tiles, st);                                               \
+    } while (0)
     if (kind == SPEC_FWD) MDG_SPEC(SPEC_FWD); else if (kind == SPEC_TURN) MDG_SPEC(SPEC_TURN); else MDG_SPEC(SPEC_REV);
 #undef MDG_SPEC
     return true;
@@ -713,7 +915,10 @@ bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, 
 
 }  // namespace
 
-extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int dual, void* stream) {
+extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int flags, void* stream) {
+    MDG_CHECK_ARG(flags >= 0 && flags <= (MDG_CHAIN_DUAL | MDG_CHAIN_X3), "row_chain: flags: MDG_CHAIN_DUAL | MDG_CHAIN_X3");
+    const int dual = flags & MDG_CHAIN_DUAL;
+    const bool x3 = (flags & MDG_CHAIN_X3) != 0;       // (honoured by the compiled n_atom_basis = 64 chains; f32 products elsewhere)
     MDG_CHECK_ARG(stages && n_stages >= 1 && n_stages <= MDG_CHAIN_MAX_STAGES, "row_chain: 1..%d stages", MDG_CHAIN_MAX_STAGES);
     MDG_CHECK_ARG(n_rows >= 0 && (int64_t)n_rows * MDG_CHAIN_MAX_WIDTH < ((int64_t)1 << 31), "row_chain: bad row count");
     if (n_rows == 0) return MDG_OK;
@@ -744,8 +949,8 @@ extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_ro
     dim3 grid((n_rows + RC_ROWS - 1) / RC_ROWS), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (!getenv("MDG_CHAIN_WALKER")) {                                  // (MDG_CHAIN_WALKER=1: always the descriptor walker)
-        if (spec_launch<64, 128>(a, stages, n_stages, n_rows, dual, st) || spec_launch<128, 128>(a, stages, n_stages, n_rows, dual, st) ||
-            spec_launch<64, 64>(a, stages, n_stages, n_rows, dual, st) || spec_launch<128, 64>(a, stages, n_stages, n_rows, dual, st)) {
+        if (spec_launch<64, 128>(a, stages, n_stages, n_rows, dual, x3, st) || spec_launch<128, 128>(a, stages, n_stages, n_rows, dual, x3, st) ||
+            spec_launch<64, 64>(a, stages, n_stages, n_rows, dual, x3, st) || spec_launch<128, 64>(a, stages, n_stages, n_rows, dual, x3, st)) {
             MDG_CHECK_LAUNCH("chain_spec_kernel");
             return MDG_OK;
         }

@@ -415,6 +415,16 @@ def _filter_net(conv, P, bf16, rows16):
     return c[1]
 
 
+def _chain_x3(net, fns):
+    """Do the node-level chains of this network run with MDG_CHAIN_X3 -- the Dense products as three bf16 MFMAs on operands
+    split into a bf16 head and remainder (csrc/rowchain.hip; ~1e-5 relative per product, 3/16 of the f32 matrix time)?  It comes
+    with the rows16 precision option (every block gathering bf16 node rows: their rounding is 2^-9), `SchNet.chain_x3 = False`
+    or MDG_CHAIN_X3=0 keeps f32 products."""
+    import os
+    return (all(fn.rows16 for fn in fns) and getattr(net, "chain_x3", True) is not False
+            and os.environ.get("MDG_CHAIN_X3", "1") != "0")
+
+
 def _rows16(net, conv):
     """Does this block's convolution read bf16 mirrors of its gathered node matrices (SchNet.node_rows_bf16)?"""
     if not getattr(net, "node_rows_bf16", False):
@@ -627,6 +637,7 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
     ro = net.atomwisereadout.readout["energy"]
     L1, l1, L2, l2 = ro[0].weight, ro[0].bias, ro[2].weight, ro[2].bias
     N, dev = z.shape[0], x.device
+    x3 = _chain_x3(net, fns)
     (r, h), rd, hd = _first_filter(net, z, Ps[0]), None, None      # r_dot^0 = 0; message_node_filter of the first block
     # rows16 blocks gather bf16 mirrors (hg, hgd) of (h, hd); the chain stage that produces a block's rows writes them
     hg, hgd = (_h0_mirror(net, h) if fns[0].rows16 else h), None
@@ -635,7 +646,7 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
         # (want_sums: the neighbour sums of the node rows, which the gradient of the second filter layer's bias is made of --
         #  not needed where the reverse sweep hands that gradient out itself, FilterNet.b2col)
         m, md, hsum, hdsum = ops.cfconv_fwd(fns[i], d, dd if dual else None, hg, hgd, topo, want_sums and not fns[i].b2col)
-        ch = ops.RowChain(N, dual, dev)
+        ch = ops.RowChain(N, dual, dev, x3)
         a = ch.stage(P["U1"], bias=P["c1"], act=True, in0=m, in1=md, want_sig=True)         # t, su, td
         b = ch.stage(P["U2"], bias=P["c2"], res0=r, res1=rd)                                # residual (schnet.py:149-151)
         layers.append(dict(P=P, fn=fns[i], r=r, rd=rd, h=hg, hd=hgd, m=m, md=md, hsum=hsum, hdsum=hdsum, t=a.out0, su=a.sig,
@@ -662,7 +673,7 @@ def _chain_forward(net, z, x, topo, w, want_sums, want_energy):
         # U = sum_n (L2 . ssp(y_n) + l2): the column sums of the head stage's activations on the reduction kernel of
         # csrc/gradjobs.hip (fixed order), then a dot product over A / 2 numbers -- no library GEMM on the chained path
         U = _head_energy(y.pre0, L2, l2)
-    fw = dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=y.sig, syd=y.pre1, L1=L1, L2=L2, U=U)
+    fw = dict(d=d, uhat=uhat, dd=dd, ddel=ddel, layers=layers, r=r, rd=rd, sy=y.sig, syd=y.pre1, L1=L1, L2=L2, U=U, x3=x3)
     return fw, turn
 
 
@@ -679,7 +690,7 @@ def _force_chain(net, z, x, topo, want_energy=True):
         if idx > 0:                                               # (the embedding below layer 0 is not needed)
             hb = ops.cfconv_fwd(L["fn"], d, None, mg, None, topo)[0]
             Lp = layers[idx - 1]
-            ch = ops.RowChain(z.shape[0], False, x.device)
+            ch = ops.RowChain(z.shape[0], False, x.device, fw["x3"])
             g = ch.stage(L["P"]["Wn"], trans=True, in0=hb, res0=rb)
             ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_MUL, aux0=Lp["su"], store=False)
             f = ch.stage(Lp["P"]["U1"], trans=True, mirror=Lp["fn"].rows16)
@@ -748,7 +759,7 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
                 jobs.colsum(off(md_["message_node_filter"].bias), hb)
             if idx > 0:
                 Lp = layers[idx - 1]
-                ch = ops.RowChain(z.shape[0], True, x.device)
+                ch = ops.RowChain(z.shape[0], True, x.device, fw["x3"])
                 g = ch.stage(P["Wn"], trans=True, in0=hdb, in1=hb, res0=rdb, res1=rb)
                 e = ch.stage(Lp["P"]["U2"], trans=True, mode=C_.CHAIN_SSP_BWD, aux0=Lp["su"], aux1=Lp["td"])
                 f = ch.stage(Lp["P"]["U1"], trans=True, mirror=Lp["fn"].rows16)
@@ -757,7 +768,7 @@ def _force_vjp_chain(net, z, x, w, topo, want_theta=True, want_energy=True, accu
                 mdg, mg = (f.out0_h, f.out1_h) if Lp["fn"].rows16 else (mdb, mb)
             else:
                 # below the first block only the embedding rows' adjoint in U_dot is left (r_dot^0 = 0)
-                ch = ops.RowChain(z.shape[0], False, x.device)
+                ch = ops.RowChain(z.shape[0], False, x.device, fw["x3"])
                 rb = ch.stage(P["Wn"], trans=True, in0=hb, res0=rb).out0
                 ch.run()
     F, dwf = ops.edge_geom_bwd(d_b, dd_b, d, dd, fw["uhat"], fw["ddel"], topo)

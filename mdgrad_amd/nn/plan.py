@@ -52,6 +52,8 @@ class SchnetPlan:
         s.L1, s.l1, s.L2 = self.L1.data_ptr(), self.l1.data_ptr(), self.L2.data_ptr()
         # the G-wide filter stash (mdg_cfconv_filter_stash): same results as recomputing; MDG_SCHNET_STASH=0 for the A/B
         s.stash = int(getattr(net, "filter_stash", True) is not False and os.environ.get("MDG_SCHNET_STASH", "1") != "0")
+        from . import analytic
+        s.chain_x3 = int(analytic._chain_x3(net, fns))       # (the launch-by-launch path asks the same question: same kernels)
         self.struct = s
         self.key = self._key(Ps, fns)
         self.ws = {}                 # one workspace per evaluation kind (dual, theta): a captured HIP graph of one kind keeps
@@ -66,8 +68,9 @@ class SchnetPlan:
         return tuple(k)
 
     def matches(self, Ps, fns):
+        from . import analytic
         ro = self.net.atomwisereadout.readout["energy"]
-        return (self.key == self._key(Ps, fns) and ro[0].weight is self.L1 and ro[0].bias is self.l1 and ro[2].weight is self.L2
+        return (self.key == self._key(Ps, fns) and int(analytic._chain_x3(self.net, fns)) == int(self.struct.chain_x3) and ro[0].weight is self.L1 and ro[0].bias is self.l1 and ro[2].weight is self.L2
                 and self.struct.L1 == self.L1.data_ptr() and self.struct.L2 == self.L2.data_ptr())
 
     # -- per call ---------------------------------------------------------------------------------

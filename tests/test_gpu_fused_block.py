@@ -482,7 +482,7 @@ def test_trainable_gaussian_basis_on_the_fused_kernels_vs_autograd(bf16):
                                           (530, 512, 512, 512, 256), (129, 384, 130, 130, 65), (16, 8, 8, 8, 4),
                                           # more than 8 192 rows: the many-row variants of the kernel (no operand prefetch,
                                           # three / four waves per SIMD), which the stacked 8 x 4 096-bead workload runs on
-                                          (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64),
+                                          (9001, 128, 64, 64, 32), (8200, 384, 130, 130, 65), (32768, 64, 128, 128, 64), (16400, 128, 64, 64, 32),
                                           # the other widths the compiled chains exist for (A = F = 128, A = F = 64, A = 128 / F = 64)
                                           (777, 128, 128, 128, 64), (555, 64, 64, 64, 32), (640, 64, 128, 128, 64)])
 @pytest.mark.parametrize("walker", [False, True])
@@ -552,6 +552,90 @@ def test_row_chain_kernel_every_stage_vs_torch(N, K, M1, M2, M3, walker, monkeyp
         bad.stage(W1, in0=x0)
         bad.stage(rn(5, M1 + 1))                                   # k = M1 + 1 does not match the previous width M1
         bad.run()
+
+
+@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("N", [1000, 16400 + 7, 32768])
+@pytest.mark.parametrize("A,F", [(64, 128), (64, 64)])
+def test_row_chain_looping_and_split_bf16_variants_vs_torch(A, F, N, x3):
+    """The three compiled chains of an n_atom_basis = 64 network (forward: update MLP + residual + next node filter with its
+    bf16 mirrors; turn; reverse) in the variants round 6 added: LOOP (>= 1 024 row tiles: two workgroups per CU keep the
+    weight fragments in registers and walk the tiles, the next tile's rows prefetched; the last tile ragged) and
+    MDG_CHAIN_X3 (products as three bf16 MFMAs on split operands: ~1e-5 relative) -- every output against torch in float64."""
+    from mdgrad_amd import ops, _lib
+    torch.manual_seed(N + A + F + int(x3))
+    rn = lambda *s: torch.randn(*s, device=DEV)
+    H = A // 2
+    U1, c1, U2, c2 = rn(A, F) / F ** 0.5, rn(A), rn(A, A) / A ** 0.5, rn(A)
+    Wn, bn, L1, l1, L2 = rn(F, A) / A ** 0.5, rn(F), rn(H, A) / A ** 0.5, rn(H), rn(1, H)
+    m, md, r, rd = rn(N, F), rn(N, F), rn(N, A), rn(N, A)
+    D = lambda t: t.double()
+    ln2 = float(np.log(2.0))
+    ssp = lambda z: torch.nn.functional.softplus(z) - ln2
+    tol = 3e-4 if x3 else 2e-5
+
+    def near(a, b, what):
+        b = b.float()
+        err = float((a.float() - b).abs().max())
+        assert err <= tol * float(b.abs().max()) + 1e-6, (what, err, float(b.abs().max()))
+
+    for dual in (True, False):
+        # forward chain
+        ch = ops.RowChain(N, dual, DEV, x3)
+        a = ch.stage(U1, bias=c1, act=True, in0=m, in1=md if dual else None, want_sig=True)
+        b = ch.stage(U2, bias=c2, res0=r, res1=rd if dual else None)
+        c = ch.stage(Wn, bias=bn, mirror=True)
+        ch.run()
+        z1 = D(m) @ D(U1).t() + D(c1)
+        t, su = ssp(z1), torch.sigmoid(z1)
+        rn_ = t @ D(U2).t() + D(c2) + D(r)
+        hn = rn_ @ D(Wn).t() + D(bn)
+        near(a.out0, t, "t"); near(a.sig, su, "su"); near(b.out0, rn_, "r'"); near(c.out0, hn, "h'")
+        assert torch.equal(c.out0_h, c.out0.to(torch.bfloat16)), "mirror of h'"
+        if dual:
+            td = su * (D(md) @ D(U1).t())
+            rdn = td @ D(U2).t() + D(rd)
+            near(a.out1, td, "td"); near(b.out1, rdn, "rd'"); near(c.out1, rdn @ D(Wn).t(), "hd'")
+            assert torch.equal(c.out1_h, c.out1.to(torch.bfloat16))
+        # turn chain
+        ch = ops.RowChain(N, dual, DEV, x3)
+        a = ch.stage(U1, bias=c1, act=True, in0=m, in1=md if dual else None, want_sig=True)
+        b = ch.stage(U2, bias=c2, res0=r, res1=rd if dual else None)
+        y = ch.stage(L1, bias=l1, act=True, mode=_lib.CHAIN_HEAD, aux0=L2, want_sig=True, want_pre=(True, True))
+        g = ch.stage(L1, trans=True)
+        e = ch.stage(U2, trans=True, mode=_lib.CHAIN_SSP_BWD if dual else _lib.CHAIN_MUL, aux0=a.sig, aux1=a.out1 if dual else None)
+        f = ch.stage(U1, trans=True, mirror=True)
+        ch.run()
+        z3 = rn_ @ D(L1).t() + D(l1)
+        sy = torch.sigmoid(z3)
+        ydb = sy * D(L2)
+        rdb = ydb @ D(L1)
+        tdb = rdb @ D(U2)
+        near(y.pre0, ssp(z3), "ty"); near(y.sig, sy, "sy"); near(g.out0, rdb, "rdb"); near(e.out0, su * tdb, "udb")
+        near(f.out0, (su * tdb) @ D(U1), "mdb")
+        assert torch.equal(f.out0_h, f.out0.to(torch.bfloat16))
+        if dual:
+            syd = sy * (rdn @ D(L1).t())
+            yb = (1 - sy) * syd * D(L2)
+            rb = yb @ D(L1)
+            ub = (1 - su) * td * tdb + su * (rb @ D(U2))
+            near(y.pre1, syd, "syd"); near(g.out1, rb, "rb"); near(e.out1, ub, "ub"); near(f.out1, ub @ D(U1), "mb")
+        # reverse chain (adjoint rows hb / hdb of the next block's filtered rows coming in)
+        hb, hdb, gb, gdb = rn(N, F), rn(N, F), rn(N, A), rn(N, A)
+        ch = ops.RowChain(N, dual, DEV, x3)
+        g2 = ch.stage(Wn, trans=True, in0=hb, in1=hdb if dual else None, res0=gb, res1=gdb if dual else None)
+        e2 = ch.stage(U2, trans=True, mode=_lib.CHAIN_SSP_BWD if dual else _lib.CHAIN_MUL, aux0=a.sig, aux1=a.out1 if dual else None)
+        f2 = ch.stage(U1, trans=True)
+        ch.run()
+        # (the saved activation rows a.sig / a.out1 are the kernel's own: the reference uses them as they are)
+        su_k, td_k = D(a.sig), (D(a.out1) if dual else None)
+        q0 = D(hb) @ D(Wn) + D(gb)
+        t0 = q0 @ D(U2)
+        near(g2.out0, q0, "rev r"); near(e2.out0, su_k * t0, "rev u"); near(f2.out0, (su_k * t0) @ D(U1), "rev m")
+        if dual:
+            q1 = D(hdb) @ D(Wn) + D(gdb)
+            u1 = (1 - su_k) * td_k * t0 + su_k * (q1 @ D(U2))
+            near(g2.out1, q1, "rev rd"); near(e2.out1, u1, "rev ud"); near(f2.out1, u1 @ D(U1), "rev md")
 
 
 @pytest.mark.parametrize("A,F,G,convs,R", [(64, 128, 30, 2, 1), (48, 64, 16, 3, 1), (100, 96, 25, 1, 1), (64, 128, 30, 2, 160)])
