@@ -232,36 +232,58 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group,
     int base = 0;
     // the three z-neighbours of a stencil column are consecutive bins, i.e. ONE contiguous range of the sorted atom
     // array (two when the column wraps around the cell): 9-11 ranges of ~3 bins instead of 27 single bins -- the
-    // rows are rank-sorted below, so the visiting order does not matter
+    // rows are rank-sorted below, so the visiting order does not matter.  The ranges are laid end to end and the wave walks
+    // the concatenation 64 candidates at a time (round 6): a range of ~24 atoms per pass left 60 % of the lanes idle (ten
+    // passes of the pair test per atom where four cover the ~220 candidates: 91 -> see profiles/r06_nbr_kbench.txt).
+    // Lane s < 18 holds range s: start, length; their running sum comes from a wave scan.
     const int nbz = bins.nb[2];
-    for (int s = 0; s < 18; ++s) {
-        const int col = s >> 1, part = s & 1;
-        const int cx = (bx + col / 3 - 1 + bins.nb[0]) % bins.nb[0];
-        const int cy = (by + col % 3 - 1 + bins.nb[1]) % bins.nb[1];
+    int r_a0 = 0, r_len = 0;
+    if (lane < 18) {
+        const int s = lane, colm = s >> 1, part = s & 1;
+        const int cx = (bx + colm / 3 - 1 + bins.nb[0]) % bins.nb[0];
+        const int cy = (by + colm % 3 - 1 + bins.nb[1]) % bins.nb[1];
         const int cb = gbin + (cx * bins.nb[1] + cy) * nbz;
         int zlo = bz - 1, zhi = bz + 1;                       // inclusive, before wrapping
+        bool on = true;
         if (part == 0) { zlo = max(zlo, 0); zhi = min(zhi, nbz - 1); }
         else if (bz == 0) { zlo = zhi = nbz - 1; }            // wrapped remainder
         else if (bz == nbz - 1) { zlo = zhi = 0; }
-        else continue;
-        const int a0 = bin_start[cb + zlo], a1 = bin_start[cb + zhi + 1];
-        for (int a = a0; a < a1; a += 64) {
-            const int idx = a + lane;
-            int code = -1, j = -1;
-            if (idx < a1) {
-                j = sorted_atoms[idx];
-                if (j != i) {
-                    code = pair_test<true>(cell, pos, i, j, xi, yi, zi, rc2, nullptr, N);
-                    if (code >= 0 && mask && !mask[(size_t)(i - g0) * group + (j - g0)]) code = -1;
-                }
+        else on = false;
+        if (on) { r_a0 = bin_start[cb + zlo]; r_len = bin_start[cb + zhi + 1] - r_a0; }
+    }
+    int r_end = r_len;                                         // inclusive scan over lanes 0..17 (lanes >= 18 hold zeros)
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int v = __shfl_up(r_end, o, 64);
+        if (lane >= o) r_end += v;
+    }
+    const int r_shift = r_a0 - (r_end - r_len);                // flat position q of range s sits at sorted index q + shift[s]
+    int ends[18], shifts[18];                                  // (wave-uniform: scalar registers)
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {
+        ends[s] = __builtin_amdgcn_readlane(r_end, s);
+        shifts[s] = __builtin_amdgcn_readlane(r_shift, s);
+    }
+    const int total = ends[17];
+    for (int q0 = 0; q0 < total; q0 += 64) {
+        const int q = q0 + lane;
+        int sh = shifts[0];
+#pragma unroll
+        for (int s = 0; s < 17; ++s) sh = q >= ends[s] ? shifts[s + 1] : sh;      // (an empty range: end[s] = end[s - 1], passed over)
+        int code = -1, j = -1;
+        if (q < total) {
+            j = sorted_atoms[q + sh];
+            if (j != i) {
+                code = pair_test<true>(cell, pos, i, j, xi, yi, zi, rc2, nullptr, N);
+                if (code >= 0 && mask && !mask[(size_t)(i - g0) * group + (j - g0)]) code = -1;
             }
-            const unsigned long long bal = __ballot(code >= 0);
-            if (code >= 0) {
-                const int k = base + __popcll(bal & lanemask_lt());
-                if (k < ROW_CAP) { bj[k] = j; bc[k] = code; }
-            }
-            base += __popcll(bal);
         }
+        const unsigned long long bal = __ballot(code >= 0);
+        if (code >= 0) {
+            const int k = base + __popcll(bal & lanemask_lt());
+            if (k < ROW_CAP) { bj[k] = j; bc[k] = code; }
+        }
+        base += __popcll(bal);
     }
     const int n = base < ROW_CAP ? base : ROW_CAP;
     // rank sort by neighbour index (entries are distinct)
