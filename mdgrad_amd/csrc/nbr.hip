@@ -234,7 +234,8 @@ __global__ void nbr_cell_kernel(const float* __restrict__ pos, int N, int group,
     // array (two when the column wraps around the cell): 9-11 ranges of ~3 bins instead of 27 single bins -- the
     // rows are rank-sorted below, so the visiting order does not matter.  The ranges are laid end to end and the wave walks
     // the concatenation 64 candidates at a time (round 6): a range of ~24 atoms per pass left 60 % of the lanes idle (ten
-    // passes of the pair test per atom where four cover the ~220 candidates: 91 -> see profiles/r06_nbr_kbench.txt).
+    // passes of the pair test per atom where four cover the ~220 candidates; list build at 8 x 4 096 beads 137 -> 81 us,
+    // profiles/r06_nbr_kbench.txt).
     // Lane s < 18 holds range s: start, length; their running sum comes from a wave scan.
     const int nbz = bins.nb[2];
     int r_a0 = 0, r_len = 0;
