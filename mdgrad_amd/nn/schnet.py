@@ -111,6 +111,15 @@ class SchNet(nn.Module):
     # its own on top of the bf16 MFMA operands -- the gathered features carry 8 significant bits into f32 products -- and off
     # unless asked for; tests/test_gpu_schnet_rows16.py holds its tolerance.
     node_rows_bf16 = False
+    # With node_rows_bf16 (every block gathering bf16 rows): the node-level Dense chains form each product as three bf16 MFMAs on
+    # operands split into a bf16 head and remainder (MDG_CHAIN_X3, csrc/rowchain.hip: ~1e-5 per product, f32 accumulate).
+    # False: exact f32 products there.
+    chain_x3 = True
+    # One C-ABI call per force / force-vjp evaluation (nn/plan.py, csrc/schnet_eval.hip) and, inside it, the per-edge stash of
+    # the filter network's first layer for the rows16 sweeps -- same kernels and results as the launch-by-launch path / the
+    # recomputing sweeps; False selects those (A/B and debugging).
+    eval_plan = True
+    filter_stash = True
 
     def __init__(self, modelparams):
         super().__init__()
