@@ -149,7 +149,12 @@ __device__ __forceinline__ void store_row(float* __restrict__ base, int row, int
 
 // (occupancy: the register allocator is asked for three waves per SIMD where round 2's build had them -- 168 registers for
 //  the primal + tangent sweep; left alone it drifted to 224 = two waves after small edits, 253 -> 293 us at E = 459 k)
-template <int GP, int FT, bool TANGENT, bool SUMS>
+// SPLIT (round 6): few atoms -- a 192-atom water box is 48 workgroups of four atoms, each wave walking its atom's ~6 tiles of 16
+// slots one after the other at ~190 dependent f32 MFMAs per tile (26 us per sweep on a chip that is 80 % idle).  Here a
+// workgroup owns ONE atom and deals its tiles to the four waves (wave w: slots 16 w, 16 w + 64, ...); the four partial rows meet
+// in LDS and are added in wave order, so the result does not depend on timing (it differs from the unsplit kernel's by the order
+// of the f32 sums).  Chosen by the launcher from the atom count alone.
+template <int GP, int FT, bool TANGENT, bool SUMS, bool SPLIT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GP == 32 ? (TANGENT ? (SUMS ? 2 : 3) : 4) : 1)))
 void cfconv_fwd_kernel(const FwdArgs A) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -200,21 +205,24 @@ void cfconv_fwd_kernel(const FwdArgs A) {
     // 8 MB of rows in flight, measured gather-bound)
     const bool has_hd = A.hd != nullptr;
     int n_begin, n_end, n_step;
-    xcd_sweep(A.N, 4, n_begin, n_end, n_step);
+    if constexpr (SPLIT) { n_begin = blockIdx.x; n_end = A.N; n_step = gridDim.x; }
+    else xcd_sweep(A.N, 4, n_begin, n_end, n_step);
+    const int aw = SPLIT ? 0 : wid;                            // the wave's atom within the workgroup's unit
+    const int tw0 = SPLIT ? 16 * wid : 0, tstep = SPLIT ? 64 : 16;   // its first tile and the distance to its next one
     // The slot indices (edge id of the lane's A-layout slot, neighbour ids of its four C-layout slots) of the NEXT tile --
     // the first tile of the wave's next atom after an atom's last one -- are requested before the current tile is worked
     // on: the distance and node-row gathers of a tile then start at once instead of behind a second round trip.
     // (the neighbour counts of the wave's next 64 atoms come in ONE vector load, lane k <-> the k-th atom ahead, and are read
     //  out with v_readlane: a count fetched per atom sat, as a loop-carried scalar, behind a round trip of its own per atom)
     int cnt_vec = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
-    if (n_begin + wid < n_end) {
-        const size_t rb = (size_t)(n_begin + wid) * A.max_nbr;
-        pf_e = A.eid[rb + min(li, A.max_nbr - 1)];
+    if (n_begin + aw < n_end) {
+        const size_t rb = (size_t)(n_begin + aw) * A.max_nbr;
+        pf_e = A.eid[rb + min(tw0 + li, A.max_nbr - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(4 * lk + r, A.max_nbr - 1)];
+        for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(tw0 + 4 * lk + r, A.max_nbr - 1)];
     }
     int kat = 0;
-    for (int n = n_begin + wid; n < n_end; n += n_step, ++kat) {
+    for (int n = n_begin + aw; n < n_end; n += n_step, ++kat) {
         if ((kat & 63) == 0) {
             int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // the lane id, recomputed here:
             asm volatile("" : "+v"(ln));                          // nothing of this rare load's address arithmetic lives across the loops
@@ -225,14 +233,14 @@ void cfconv_fwd_kernel(const FwdArgs A) {
         float macc[FT], mdacc[FT], hs[FT], hds[FT];
 #pragma unroll
         for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
-        for (int t0 = 0; t0 < cnt || t0 == 0; t0 += 16) {         // (an atom without neighbours still hands the prefetch on)
+        for (int t0 = tw0; t0 < cnt || t0 == tw0; t0 += tstep) {  // (a wave without a tile of this atom still hands the prefetch on)
             const int ea_raw = pf_e;
             int j_raw[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) j_raw[r] = pf_j[r];
             {
-                const bool last = t0 + 16 >= cnt;
-                const int n2 = last ? n + n_step : n, t2 = last ? 0 : t0 + 16;
+                const bool last = t0 + tstep >= cnt;
+                const int n2 = last ? n + n_step : n, t2 = last ? tw0 : t0 + tstep;
                 if (n2 < n_end) {
                     const size_t rb2 = (size_t)n2 * A.max_nbr;
                     pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
@@ -356,12 +364,45 @@ void cfconv_fwd_kernel(const FwdArgs A) {
                 if (TANGENT) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
             }
         }
-        if (lk == 0) {
+        if constexpr (SPLIT) {
+            // the waves' partial rows through their own (now idle) h1 areas: [quantity][filter v][li], 4 FT 16 <= 16 SA floats
+            static_assert(4 * FT * 16 <= 16 * SA, "the partial rows fit the wave's layer-1 buffer");
+            if (lk == 0) {
+#pragma unroll
+                for (int v = 0; v < FT; ++v) {
+                    h1w[v * 16 + li] = macc[v];
+                    if (TANGENT) h1w[(FT + v) * 16 + li] = mdacc[v];
+                    if (SUMS) h1w[(2 * FT + v) * 16 + li] = hs[v];
+                    if (SUMS && TANGENT) h1w[(3 * FT + v) * 16 + li] = hds[v];
+                }
+            }
+            __syncthreads();
+            if (wid == 0 && lk == 0) {
+#pragma unroll
+                for (int v = 0; v < FT; ++v) {
+                    macc[v] = ((h1s[v * 16 + li] + h1s[16 * SA + v * 16 + li]) + h1s[2 * 16 * SA + v * 16 + li]) + h1s[3 * 16 * SA + v * 16 + li];
+                    if (TANGENT) {
+                        const int o = (FT + v) * 16 + li;
+                        mdacc[v] = ((h1s[o] + h1s[16 * SA + o]) + h1s[2 * 16 * SA + o]) + h1s[3 * 16 * SA + o];
+                    }
+                    if (SUMS) {
+                        const int o = (2 * FT + v) * 16 + li;
+                        hs[v] = ((h1s[o] + h1s[16 * SA + o]) + h1s[2 * 16 * SA + o]) + h1s[3 * 16 * SA + o];
+                    }
+                    if (SUMS && TANGENT) {
+                        const int o = (3 * FT + v) * 16 + li;
+                        hds[v] = ((h1s[o] + h1s[16 * SA + o]) + h1s[2 * 16 * SA + o]) + h1s[3 * 16 * SA + o];
+                    }
+                }
+            }
+        }
+        if (lk == 0 && (!SPLIT || wid == 0)) {
             store_row<FT>(A.m, n, F, RS, li, macc);
             if (TANGENT) store_row<FT>(A.md, n, F, RS, li, mdacc);
             if (SUMS) store_row<FT>(A.hsum, n, F, RS, li, hs);
             if (SUMS && TANGENT && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
         }
+        if constexpr (SPLIT) __syncthreads();                    // (the next atom's tiles overwrite the h1 areas)
     }
 }
 
@@ -1848,6 +1889,14 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // Persistent grids are sized to ONE resident round: workgroups per CU from the occupancy API (registers + LDS of
 // this instantiation) times the CU count.  (768 workgroups on 256 CUs at 2 resident per CU ran as a full round
 // plus a half-empty one: -25 %.)  Cached per kernel instantiation and LDS size.
+// the SPLIT forward sweep (one atom per workgroup): systems whose four-atom workgroups would leave most CUs idle
+// (MDG_FWD_SPLIT_ATOMS: the largest such system; 0: never)
+bool fwd_split(int n_atoms) {
+    static int lim = -1;
+    if (lim < 0) { const char* e = getenv("MDG_FWD_SPLIT_ATOMS"); lim = e ? atoi(e) : 512; }
+    return n_atoms <= lim;
+}
+
 template <typename K>
 int resident_blocks(K kernel, size_t lds, int cap = 4) {
     struct Entry { const void* k; size_t l; int n; };
@@ -1995,6 +2044,7 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     MDG_CHECK_ARG(aligned16(h) && aligned16(hd) && aligned16(m) && aligned16(md) && aligned16(hsum) && aligned16(hdsum),
                   "cfconv_fwd: node feature matrices must be 16-byte aligned");
     const int most = (n_atoms + 3) / 4;
+    const bool split = fwd_split(n_atoms);
     hipStream_t st = (hipStream_t)stream;
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
     FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
@@ -2002,6 +2052,10 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
 #define MDG_FWD1(GP_, FT_, T_, S_)                                                                                 \
     do {                                                                                                           \
         const size_t lds = fwd_lds_bytes<GP_, FT_>(T_);                                                            \
+        if (split) {            /* few atoms: one atom per workgroup, its tiles dealt to the four waves */          \
+            hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, T_, S_, true>), dim3(n_atoms), dim3(256), lds, st, a); \
+            break;                                                                                                 \
+        }                                                                                                          \
         const int want = resident_blocks(cfconv_fwd_kernel<GP_, FT_, T_, S_>, lds);                                \
         hipLaunchKernelGGL((cfconv_fwd_kernel<GP_, FT_, T_, S_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
     } while (0)

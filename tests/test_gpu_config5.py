@@ -37,7 +37,9 @@ def test_bf16_forward_kernel_vs_f32(G, F):
     ref = ops.cfconv_fwd(ops.FilterNet(*net), d, dd, h, hd, topo, want_sums=True)
     got = ops.cfconv_fwd(ops.FilterNet(*net, bf16=True), d, dd, h, hd, topo, want_sums=True)
     for a, b, nm in zip(got, ref, ("m", "md", "hsum", "hdsum")):
-        tol = 0.0 if nm.startswith("h") else 2e-2 * float(b.abs().max())     # the plain neighbour sums are fp32 in both
+        # the plain neighbour sums are fp32 in both; at this size the f32 sweep deals an atom's tiles to four waves (SPLIT) and
+        # adds the partial rows in wave order: the same numbers in another order of f32 additions
+        tol = 4e-6 * float(b.abs().max()) if nm.startswith("h") else 2e-2 * float(b.abs().max())
         close(a, b, 0, tol + 1e-6, "bf16 " + nm)
     again = ops.cfconv_fwd(ops.FilterNet(*net, bf16=True), d, dd, h, hd, topo)
     assert torch.equal(again[0], got[0]) and torch.equal(again[1], got[1]), "bitwise reproducible"
