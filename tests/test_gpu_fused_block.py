@@ -77,6 +77,50 @@ def test_fused_forward_kernel_primal_and_tangent(G, F, n_side):
     assert torch.equal(ops.cfconv_fwd(fn, d, dd, h, hd, topo)[1], md2), "bitwise reproducible"
 
 
+def test_split_forward_sweep_equals_the_unsplit_one_to_rounding(tmp_path):
+    """Up to 512 atoms the f32 forward sweep runs one atom per workgroup with its tiles dealt to the four waves (SPLIT,
+    csrc/cfconv_fused.hip); MDG_FWD_SPLIT_ATOMS=0 keeps the four-atoms-per-workgroup sweep.  Same inputs in a second process
+    with the variable set: every output agrees to f32 rounding (the partial rows are added in another order), and each of the
+    two is reproducible bit for bit."""
+    import os, subprocess, sys
+    script = tmp_path / "fwd.py"
+    script.write_text(
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_gpu_fused_block import _setup\n"
+        "from test_gpu_parity import DEV\n"
+        "from mdgrad_amd import ops\n"
+        "x, topo, net = _setup(30, 128, seed=5)\n"
+        "N = topo.n_atoms\n"
+        "torch.manual_seed(1)\n"
+        "w = torch.randn(N, 3, device=DEV); h = torch.randn(N, 128, device=DEV); hd = torch.randn(N, 128, device=DEV)\n"
+        "d, uhat, dd, ddel = ops.edge_geom(x, topo, w)\n"
+        "fn = ops.FilterNet(*net)\n"
+        "a = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums=True)\n"
+        "b = ops.cfconv_fwd(fn, d, dd, h, hd, topo, want_sums=True)\n"
+        "assert all(torch.equal(p, q) for p, q in zip(a, b))\n"
+        "c = ops.cfconv_fwd(fn, d, None, h, None, topo)\n"
+        "assert torch.equal(c[0], a[0])\n"
+        "np.savez(sys.argv[1], *[t.cpu().numpy() for t in a])\n"
+        % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    outs = {}
+    for tag, val in (("split", None), ("unsplit", "0")):
+        env = dict(os.environ)
+        env.pop("MDG_FWD_SPLIT_ATOMS", None)
+        if val is not None:
+            env["MDG_FWD_SPLIT_ATOMS"] = val
+        out = tmp_path / (tag + ".npz")
+        r = subprocess.run([sys.executable, str(script), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[tag] = np.load(out)
+    worst = 0.0
+    for k in outs["split"].files:
+        a, b = outs["split"][k], outs["unsplit"][k]
+        assert np.abs(a - b).max() <= 4e-6 * np.abs(b).max() + 1e-7, k
+        worst = max(worst, float(np.abs(a - b).max()))
+    assert worst > 0.0, "216 atoms: the two sweeps are expected to differ in the order of their sums (is SPLIT being taken?)"
+
+
 @pytest.mark.parametrize("G,F,n_side", [(30, 128, 6), (16, 48, 6), (32, 64, 6), (41, 128, 6), (64, 32, 6), (12, 8, 6),
                                         (30, 128, 16), (30, 256, 6), (41, 512, 6), (25, 384, 6)])
 def test_fused_backward_kernel_plain_dual_and_theta(G, F, n_side):
