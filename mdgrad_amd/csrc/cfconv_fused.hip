@@ -696,6 +696,301 @@ size_t fwd_bf16_lds_bytes(bool tangent) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// X6 (round 6): the f32 sweep on the bf16 matrix pipe at f32 accuracy.  Every operand of the two Dense layers -- Gaussians,
+// W1, the softplus output, W2 -- is cut into THREE bf16 pieces (8 + 8 + 8 significant bits: the pieces add up to the f32 value
+// exactly) and a product is the six piece products that matter,
+//     a w  =  a1 w1 + (a1 w2 + a2 w1) + (a2 w2 + a1 w3 + a3 w1)  (+ terms below 2^-25 of it),
+// each exact in the f32 accumulator.  tools/micro/split_mfma.hip: max error 1.8e-7 of sum |terms| at K = 128 (rms 1.8e-8)
+// against 1.9e-7 (2.4e-8) for v_mfma_f32_16x16x4_f32 -- and 6 x 16 cycles per 32 k instead of 8 x 32.  The f32 sweep is bound
+// by exactly that issue time (mfma_busy 0.50-0.58; ~190 dependent matrix instructions per 16-slot tile).  Layout and slot
+// logic are cfconv_fwd_kernel's (f32 node rows, lane li owns FT consecutive filters, biases added in f32); operand layout is
+// the bf16 kernel's (lane (li, lk): k = 8 lk + [0, 8)).  n_gaussians <= 32.  SPLIT as in cfconv_fwd_kernel.
+__device__ __forceinline__ float bf_up(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split3(float w, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
+    p1 = f2bf(w);
+    const float r1 = w - bf_up(p1);
+    p2 = f2bf(r1);
+    p3 = f2bf(r1 - bf_up(p2));
+}
+// the three pieces of two values, packed (low half = a)
+__device__ __forceinline__ void split2x3(float a, float b, unsigned& u1, unsigned& u2, unsigned& u3) {
+    u1 = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(u1 << 16), rb = b - __uint_as_float(u1 & 0xffff0000u);
+    u2 = cvt_pk_bf16(ra, rb);
+    u3 = cvt_pk_bf16(ra - __uint_as_float(u2 << 16), rb - __uint_as_float(u2 & 0xffff0000u));
+}
+__device__ __forceinline__ void split8x3(const float (&f)[8], bf16x8 (&p)[3]) {
+    u32x4v u1, u2, u3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = f[2 * i], b = f[2 * i + 1];
+        const unsigned h = cvt_pk_bf16(a, b);
+        const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+        const unsigned m = cvt_pk_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(m << 16), sb = rb - __uint_as_float(m & 0xffff0000u);
+        u1[i] = h; u2[i] = m; u3[i] = cvt_pk_bf16(sa, sb);
+    }
+    p[0] = __builtin_bit_cast(bf16x8, u1); p[1] = __builtin_bit_cast(bf16x8, u2); p[2] = __builtin_bit_cast(bf16x8, u3);
+}
+// smallest pieces first
+__device__ __forceinline__ f32x4 six(const bf16x8 (&a)[3], const bf16x8 (&b)[3]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int FT>
+size_t fwd_x6_lds_bytes(bool tangent) {
+    constexpr int GP = 32, FP = 16 * FT, KSB = GP + 8;
+    return sizeof(float) * (4 * GP + FP) + sizeof(unsigned short) * 3 * ((size_t)GP * KSB + (size_t)FP * KSB + (tangent ? 8 : 4) * 16 * KSB);
+}
+
+template <int FT, bool TANGENT, bool SUMS, bool HASHD, bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+void cfconv_fwd_x6_kernel(const FwdArgs A) {
+    static_assert(TANGENT || !HASHD, "node tangents come with the tangent sweep");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int GP = 32, FP = 16 * FT, KSB = GP + 8, PL = 16 * KSB;      // PL: elements of one [16][KSB] piece plane
+    float* mus = sm;                               // [GP] centres, [GP] c log2e, [GP] 2c, [GP] b1, [FP] b2 (permuted)
+    float* cfs = mus + GP;
+    float* c2s = cfs + GP;
+    float* b1s = c2s + GP;
+    float* b2s = b1s + GP;
+    unsigned short* w1b = reinterpret_cast<unsigned short*>(b2s + FP);      // [3 pieces][GP rows j][KSB]   W1[j][k]
+    unsigned short* w2b = w1b + 3 * GP * KSB;                               // [3][FP rows c][KSB]          W2[f(c)][k]
+    unsigned short* h1s = w2b + 3 * FP * KSB;                               // [4 (+4) waves][3][16][KSB]
+    const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = A.net.G, F = A.net.F, RS = A.net.RS;
+    for (int t = tid; t < GP * GP; t += 256) {
+        const int j = t / GP, k = t % GP;
+        unsigned short p1, p2, p3;
+        split3((j < G && k < G) ? A.net.W1[j * G + k] : 0.f, p1, p2, p3);
+        w1b[j * KSB + k] = p1; w1b[GP * KSB + j * KSB + k] = p2; w1b[2 * GP * KSB + j * KSB + k] = p3;
+    }
+    for (int t = tid; t < FP * GP; t += 256) {
+        const int c = t / GP, k = t % GP;
+        const int f = (c & 15) * FT + (c >> 4);
+        unsigned short p1, p2, p3;
+        split3((f < F && k < G) ? A.net.W2[(size_t)f * G + k] : 0.f, p1, p2, p3);
+        w2b[c * KSB + k] = p1; w2b[FP * KSB + c * KSB + k] = p2; w2b[2 * FP * KSB + c * KSB + k] = p3;
+    }
+    for (int k = tid; k < GP; k += 256) {
+        const float c = k < G ? A.net.coef[k] : 0.f;
+        mus[k] = k < G ? A.net.mu[k] : 0.f;
+        cfs[k] = c * LOG2E;
+        c2s[k] = 2.f * c;
+        b1s[k] = k < G ? A.net.b1[k] : 0.f;
+    }
+    for (int c = tid; c < FP; c += 256) {
+        const int f = (c & 15) * FT + (c >> 4);
+        b2s[c] = f < F ? A.net.b2[f] : 0.f;
+    }
+    __syncthreads();
+
+    const int li = lane & 15, lk = lane >> 4;
+    unsigned short* h1w = h1s + wid * 3 * PL;
+    unsigned short* h1dw = h1s + (4 + wid) * 3 * PL;
+    int n_begin, n_end, n_step;
+    if constexpr (SPLIT) { n_begin = blockIdx.x; n_end = A.N; n_step = gridDim.x; }
+    else xcd_sweep(A.N, 4, n_begin, n_end, n_step);            // (see cfconv_fwd_kernel)
+    const int aw = SPLIT ? 0 : wid;
+    const int tw0 = SPLIT ? 16 * wid : 0, tstep = SPLIT ? 64 : 16;
+    int cnt_vec = 0, pf_e = 0, pf_j[4] = {0, 0, 0, 0};
+    if (n_begin + aw < n_end) {
+        const size_t rb = (size_t)(n_begin + aw) * A.max_nbr;
+        pf_e = A.eid[rb + min(tw0 + li, A.max_nbr - 1)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb + min(tw0 + 4 * lk + r, A.max_nbr - 1)];
+    }
+    int kat = 0;
+    for (int n = n_begin + aw; n < n_end; n += n_step, ++kat) {
+        if ((kat & 63) == 0) {
+            int ln = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            asm volatile("" : "+v"(ln));
+            const long long na = (long long)n + (long long)ln * n_step;
+            cnt_vec = na < n_end ? A.cnt[na] : 0;
+        }
+        const int cnt = __builtin_amdgcn_readlane(cnt_vec, kat & 63);
+        float macc[FT], mdacc[FT], hs[FT], hds[FT];
+#pragma unroll
+        for (int v = 0; v < FT; ++v) macc[v] = mdacc[v] = hs[v] = hds[v] = 0.f;
+        for (int t0 = tw0; t0 < cnt || t0 == tw0; t0 += tstep) {
+            const int ea_raw = pf_e;
+            int j_raw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) j_raw[r] = pf_j[r];
+            {
+                const bool last = t0 + tstep >= cnt;
+                const int n2 = last ? n + n_step : n, t2 = last ? tw0 : t0 + tstep;
+                if (n2 < n_end) {
+                    const size_t rb2 = (size_t)n2 * A.max_nbr;
+                    pf_e = A.eid[rb2 + min(t2 + li, A.max_nbr - 1)];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pf_j[r] = A.col[rb2 + min(t2 + 4 * lk + r, A.max_nbr - 1)];
+                }
+            }
+            const bool vin = t0 + li < cnt;
+            const int ea = vin ? ea_raw : 0;
+            const float dload = A.d[ea];
+            const float ddload = TANGENT ? A.dd[ea] : 0.f;
+            const float draw = vin ? dload : -1.f;
+            const bool va = draw >= 0.f;                          // (a stored list's pairs beyond the cutoff carry d = -1)
+            const unsigned nib = ((unsigned)__ballot(va) >> (4 * lk)) & 0xFu;
+            bool mr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mr[r] = ((nib >> r) & 1u) != 0u;
+            const float da = va ? draw : PAD_D;
+            const float dda = (TANGENT && va) ? ddload : 0.f;
+            float hreg[4][FT], hdreg[HASHD ? 4 : 1][FT];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool vc = t0 + 4 * lk + r < cnt;
+                load_row<FT>(A.h, vc ? j_raw[r] : 0, F, RS, li, vc, hreg[r]);
+            }
+            if constexpr (HASHD) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) load_row<FT>(A.hd, j_raw[r], F, RS, li, t0 + 4 * lk + r < cnt, hdreg[r]);
+            }
+            // ---- layer 1: Gaussians (and d/dd of them), three pieces each
+            bf16x8 ga[3], gda[3];
+            {
+                float gk[8], gdk[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int k = lk * 8 + t;
+                    const float x = da - mus[k];
+                    const float g = __builtin_amdgcn_exp2f(cfs[k] * x * x);
+                    gk[t] = g;
+                    gdk[t] = TANGENT ? g * (c2s[k] * x) * dda : 0.f;
+                }
+                split8x3(gk, ga);
+                if (TANGENT) split8x3(gdk, gda);
+            }
+#pragma unroll
+            for (int nt = 0; nt < GP / 16; ++nt) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&w1b[p * GP * KSB + (nt * 16 + li) * KSB + lk * 8]);
+                const f32x4 acc = six(ga, b);
+                f32x4 accd = {0.f, 0.f, 0.f, 0.f};
+                if (TANGENT) accd = six(gda, b);
+                const int c = nt * 16 + li;
+                const float bias = b1s[c];
+                float sv[4], sdv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float sg;
+                    ssp_sig(acc[r] + bias, sv[r], sg);
+                    sdv[r] = TANGENT ? sg * accd[r] : 0.f;
+                }
+                // three pieces of two values at a time (v_cvt_pk_bf16_f32: the rounding of f2bf in one instruction)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const int o0 = (lk * 4 + r) * KSB + c, o1 = o0 + KSB;
+                    unsigned u1, u2, u3;
+                    split2x3(sv[r], sv[r + 1], u1, u2, u3);
+                    h1w[o0] = (unsigned short)u1; h1w[o1] = (unsigned short)(u1 >> 16);
+                    h1w[PL + o0] = (unsigned short)u2; h1w[PL + o1] = (unsigned short)(u2 >> 16);
+                    h1w[2 * PL + o0] = (unsigned short)u3; h1w[2 * PL + o1] = (unsigned short)(u3 >> 16);
+                    if (TANGENT) {
+                        split2x3(sdv[r], sdv[r + 1], u1, u2, u3);
+                        h1dw[o0] = (unsigned short)u1; h1dw[o1] = (unsigned short)(u1 >> 16);
+                        h1dw[PL + o0] = (unsigned short)u2; h1dw[PL + o1] = (unsigned short)(u2 >> 16);
+                        h1dw[2 * PL + o0] = (unsigned short)u3; h1dw[2 * PL + o1] = (unsigned short)(u3 >> 16);
+                    }
+                }
+            }
+            // (h1w / h1dw are private to the wave: program order + the LDS counter suffice, no barrier)
+            bf16x8 sa[3], sda[3];
+            {
+                const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    sa[p] = va ? *reinterpret_cast<const bf16x8*>(&h1w[p * PL + li * KSB + lk * 8]) : zero8;
+                    if (TANGENT) sda[p] = va ? *reinterpret_cast<const bf16x8*>(&h1dw[p * PL + li * KSB + lk * 8]) : zero8;
+                }
+            }
+            // ---- layer 2 + multiply with the gathered rows + sum over the 4 rows of the lane
+#pragma unroll
+            for (int nt = 0; nt < FT; ++nt) {
+                bf16x8 b[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(&w2b[p * FP * KSB + (nt * 16 + li) * KSB + lk * 8]);
+                const f32x4 acc = six(sa, b);
+                f32x4 accd = {0.f, 0.f, 0.f, 0.f};
+                if (TANGENT) accd = six(sda, b);
+                const float bias = b2s[nt * 16 + li];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float W = acc[r] + (mr[r] ? bias : 0.f);
+                    const float hv = hreg[r][nt];
+                    macc[nt] = fmaf(hv, W, macc[nt]);
+                    if (SUMS) hs[nt] += mr[r] ? hv : 0.f;
+                    if (TANGENT) {
+                        mdacc[nt] = fmaf(hv, accd[r], mdacc[nt]);
+                        if constexpr (HASHD) {
+                            mdacc[nt] = fmaf(hdreg[r][nt], W, mdacc[nt]);
+                            if (SUMS) hds[nt] += mr[r] ? hdreg[r][nt] : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < FT; ++v) {
+            macc[v] += __shfl_xor(macc[v], 16, 64); macc[v] += __shfl_xor(macc[v], 32, 64);
+            if (TANGENT) { mdacc[v] += __shfl_xor(mdacc[v], 16, 64); mdacc[v] += __shfl_xor(mdacc[v], 32, 64); }
+        }
+        if (SUMS) {
+#pragma unroll
+            for (int v = 0; v < FT; ++v) {
+                hs[v] += __shfl_xor(hs[v], 16, 64); hs[v] += __shfl_xor(hs[v], 32, 64);
+                if (HASHD) { hds[v] += __shfl_xor(hds[v], 16, 64); hds[v] += __shfl_xor(hds[v], 32, 64); }
+            }
+        }
+        if constexpr (SPLIT) {
+            // the waves' partial rows through their own (now idle) piece planes: [quantity][filter v][li] floats
+            static_assert(4 * FT * 16 * sizeof(float) <= 3 * PL * sizeof(unsigned short), "the partial rows fit the wave's planes");
+            constexpr int WS = 3 * PL / 2;                        // a wave's planes, in floats
+            float* part = reinterpret_cast<float*>(h1s);
+            if (lk == 0) {
+#pragma unroll
+                for (int v = 0; v < FT; ++v) {
+                    part[wid * WS + v * 16 + li] = macc[v];
+                    if (TANGENT) part[wid * WS + (FT + v) * 16 + li] = mdacc[v];
+                    if (SUMS) part[wid * WS + (2 * FT + v) * 16 + li] = hs[v];
+                    if (SUMS && HASHD) part[wid * WS + (3 * FT + v) * 16 + li] = hds[v];
+                }
+            }
+            __syncthreads();
+            if (wid == 0 && lk == 0) {
+#pragma unroll
+                for (int v = 0; v < FT; ++v) {
+                    const int o0 = v * 16 + li, o1 = (FT + v) * 16 + li, o2 = (2 * FT + v) * 16 + li, o3 = (3 * FT + v) * 16 + li;
+                    macc[v] = ((part[o0] + part[WS + o0]) + part[2 * WS + o0]) + part[3 * WS + o0];
+                    if (TANGENT) mdacc[v] = ((part[o1] + part[WS + o1]) + part[2 * WS + o1]) + part[3 * WS + o1];
+                    if (SUMS) hs[v] = ((part[o2] + part[WS + o2]) + part[2 * WS + o2]) + part[3 * WS + o2];
+                    if (SUMS && HASHD) hds[v] = ((part[o3] + part[WS + o3]) + part[2 * WS + o3]) + part[3 * WS + o3];
+                }
+            }
+        }
+        if (lk == 0 && (!SPLIT || wid == 0)) {
+            store_row<FT>(A.m, n, F, RS, li, macc);
+            if (TANGENT) store_row<FT>(A.md, n, F, RS, li, mdacc);
+            if (SUMS) store_row<FT>(A.hsum, n, F, RS, li, hs);
+            if (SUMS && HASHD && A.hdsum) store_row<FT>(A.hdsum, n, F, RS, li, hds);
+        }
+        if constexpr (SPLIT) __syncthreads();
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // The stash producer (round 6): the first Dense layer of the filter network once per undirected edge and evaluation --
 // Gaussians, a = g W1^T + b1, s = ssp(a), sd = sigmoid(a) a_dot -- with the ARITHMETIC OF cfconv_fwd_bf16_kernel (same bf16
 // operands, same MFMA, same rounding of the outputs), written as [E][GP] bf16 rows in the A-operand order of the second
@@ -1889,6 +2184,14 @@ bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // Persistent grids are sized to ONE resident round: workgroups per CU from the occupancy API (registers + LDS of
 // this instantiation) times the CU count.  (768 workgroups on 256 CUs at 2 resident per CU ran as a full round
 // plus a half-empty one: -25 %.)  Cached per kernel instantiation and LDS size.
+// the f32 filter sweeps as six bf16 piece products per operand pair (cfconv_fwd_x6_kernel): MDG_F32_X6=0 keeps the
+// v_mfma_f32_16x16x4_f32 kernels
+bool fwd_x6() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MDG_F32_X6"); on = !(e && e[0] == '0'); }
+    return on != 0;
+}
+
 // the SPLIT forward sweep (one atom per workgroup): systems whose four-atom workgroups would leave most CUs idle
 // (MDG_FWD_SPLIT_ATOMS: the largest such system; 0: never)
 bool fwd_split(int n_atoms) {
@@ -2049,6 +2352,28 @@ extern "C" int mdg_cfconv_fwd(const MdgFilterNet* net, const float* d, const flo
     for (int f0 = 0; f0 < net->n_filters; f0 += F_CHUNK) {
     FwdArgs a{dev_of(net, f0), d, dd, at_col(h, f0), at_col(hd, f0), col, eid, cnt, n_atoms, max_nbr, at_col(m, f0),
               at_col(md, f0), at_col(hsum, f0), at_col(hdsum, f0)};
+    if (GP == 32 && fwd_x6()) {
+        // n_gaussians <= 32: the f32-accurate sweep on the bf16 matrix pipe (cfconv_fwd_x6_kernel)
+#define MDG_X6_3(FT_, T_, S_, H_, P_)                                                                              \
+    do {                                                                                                           \
+        const size_t lds = fwd_x6_lds_bytes<FT_>(T_);                                                              \
+        if (P_) { hipLaunchKernelGGL((cfconv_fwd_x6_kernel<FT_, T_, S_, H_, P_>), dim3(n_atoms), dim3(256), lds, st, a); break; } \
+        const int want = resident_blocks(cfconv_fwd_x6_kernel<FT_, T_, S_, H_, P_>, lds);                          \
+        hipLaunchKernelGGL((cfconv_fwd_x6_kernel<FT_, T_, S_, H_, P_>), dim3(most < want ? most : want), dim3(256), lds, st, a); \
+    } while (0)
+#define MDG_X6_2(FT_, T_, S_, H_) do { if (split) MDG_X6_3(FT_, T_, S_, H_, true); else MDG_X6_3(FT_, T_, S_, H_, false); } while (0)
+#define MDG_X6_1(FT_)                                                                                              \
+    do {                                                                                                           \
+        if (tangent && hd) { if (hsum) MDG_X6_2(FT_, true, true, true); else MDG_X6_2(FT_, true, false, true); }   \
+        else if (tangent) { if (hsum) MDG_X6_2(FT_, true, true, false); else MDG_X6_2(FT_, true, false, false); }  \
+        else { if (hsum) MDG_X6_2(FT_, false, true, false); else MDG_X6_2(FT_, false, false, false); }             \
+    } while (0)
+        if (FT == 4) MDG_X6_1(4); else MDG_X6_1(8);
+#undef MDG_X6_1
+#undef MDG_X6_2
+#undef MDG_X6_3
+        continue;
+    }
 #define MDG_FWD1(GP_, FT_, T_, S_)                                                                                 \
     do {                                                                                                           \
         const size_t lds = fwd_lds_bytes<GP_, FT_>(T_);                                                            \
