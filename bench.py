@@ -42,6 +42,12 @@ FLOP_PER_PAIR_ADJ = 70.0
 FLOP_PER_PAIR_RING = 79.0
 
 
+# the f32 SchNet legs: every sum, activation and product is f32; the FORWARD filter sweeps (n_gaussians <= 32) form each product
+# of their two Dense layers from three exact bf16 pieces per operand on the bf16 matrix pipe -- six piece products, error
+# 1.8e-7 of sum |terms| against 1.9e-7 for v_mfma_f32_16x16x4_f32 (profiles/r06_split_mfma_accuracy.txt; MDG_F32_X6=0: the f32
+# matrix instruction)
+F32_SCHNET = "f32 (forward filter products as six exact-bf16-piece products: f32-accurate)"
+
 def _measured_vector_peak():
     """TFLOP/s of back-to-back v_pk_fma_f32 on this chip as tools/micro/valu_rate.hip measured it (profiles/r05_valu_rate.txt):
     a packed fma issues in ~5.3 cycles per SIMD against ~2.9 for a plain v_fma_f32, so the 157.3 TF of the data sheet (one
@@ -785,7 +791,7 @@ def run_schnet4096(args, rank, world, dev, mdist, with_cpu=True, steps=None, war
            "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": ("bf16 filter MFMA operands + bf16 mirrors of the gathered node rows, f32 products and accumulate" if rows16
-                     else "bf16 filter MFMA operands, f32 accumulate") if args.bf16 else "f32", "data": "synthetic",
+                     else "bf16 filter MFMA operands, f32 accumulate") if args.bf16 else F32_SCHNET, "data": "synthetic",
            "config": {"workload": "CG water Diamond 8^3 (%d beads), SchNet A64 F128 G30 2 conv + ExcludedVolume prior, "
                                   "cutoff 6, NoseHooverChain(Q=50, 5 chains), %d steps fwd + RDF(60 bins) loss + analytic "
                                   "adjoint; %d stacked replicas/GPU" % (N, T - 1, R),
@@ -1022,7 +1028,7 @@ def run_water192(args, rank, world, dev, mdist, with_cpu=True, steps=None, warmu
     out = {"metric": "MD steps/sec (fwd+adjoint), 192-atom water SchNet NHC (BASELINE config #3)", "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16 filter MFMA operands, f32 accumulate" if bf16 else "f32", "data": "synthetic",
+           "dtype": "bf16 filter MFMA operands, f32 accumulate" if bf16 else F32_SCHNET, "data": "synthetic",
            "config": {"workload": "64-molecule water box (192 atoms, golden G14 geometry), SchNet A%d F%d G%d %d conv + "
                                   "ExcludedVolume prior, cutoff 5, NoseHooverChain(Q=50, 5 chains), %d steps fwd + O-H RDF(40 "
                                   "bins) loss + analytic adjoint + Adam; one system per GPU, HIP-graph replay" % (A_, F_, G_, NC, T - 1),
@@ -1149,7 +1155,7 @@ def run_water192_stacked(args, rank, world, dev, mdist, R=64, steps=10, warmup=3
     sec_per_step = el / (steps * (T - 1))
     out = {"metric": "MD steps/sec (fwd+adjoint), 192-atom water SchNet NHC, %d stacked replicas" % R, "value": md_steps / el,
            "unit": "MD steps/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": el / steps * 1e3,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": F32_SCHNET, "data": "synthetic",
            "config": {"workload": "%d stacked 64-molecule water boxes (192 atoms each), SchNet A%d F%d G%d %d conv + prior, %d steps "
                                   "fwd + O-H RDF loss + adjoint + Adam" % (R, A_, F_, G_, NC, T - 1),
                       "replicas_per_gpu": R, "parallelism": "replica-dp%d" % world, "loss": float(loss.detach()), "edges": E,
