@@ -26,13 +26,13 @@ rows = [
     "| `lj4096`: 64 x 4 096-atom LJ liquid, 50 steps + RDF every 5th frame + adjoint (config #4) | 188.7 k | **%.1f k steps/s** | %.2f ms | B_step over the step time: %.3f of HBM -- the pass is VALU-issue bound (section 5) | %.2f | last replica of the timed launch, 2 steps: \\|dq\\| %.1e, dtheta %.1e; 16 steps with device-side rebuilds: `tests/test_gpu_secondary_pins.py` |"
     % (c["lj4096_md_steps_per_s"] / 1e3, c["lj4096_ms_per_pass"], c["lj4096_kernel_frac"], c["lj4096_cpu_steps_per_s"],
        c["lj4096_parity_max_abs_dq"], c["lj4096_parity_rel_dtheta"]),
-    "| `water192`: config #3, SchNet A128 F128 G32 3 conv + prior, one system, f32, graph replay | 898 | **%.0f steps/s** | %.1f ms (20 steps) | %.3f of f32 MFMA (≈ 100 graph nodes per step, 94 % GPU-busy: kernels of one round of workgroups each) | %.1f | vs the REFERENCE's own run (golden G14): \\|dq\\| %.1e A, dtheta %.1e |"
+    "| `water192`: config #3, SchNet A128 F128 G32 3 conv + prior, one system, f32, graph replay | 898 | **%.0f steps/s** | %.1f ms (20 steps) | %.3f of f32 MFMA (≈ 100 graph nodes per step, 94 %% GPU-busy: kernels of one round of workgroups each) | %.1f | vs the REFERENCE's own run (golden G14): \\|dq\\| %.1e A, dtheta %.1e |"
     % (c["water192_md_steps_per_s"], c["water192_ms_per_pass"], c["water192_kernel_frac"], c["water192_cpu_steps_per_s"],
        c["water192_parity_max_abs_dq"], c["water192_parity_rel_dtheta"]),
     "| `water192x64` (round 6): 64 copies of config #3's box stacked in ONE trajectory (12 288 atoms, 325 k edges), f32 | -- | **%.0f steps/s** (%.1f x one system) | %.1f ms (64 x 20 steps) | %.3f of f32 MFMA | -- | replicas 0 and 63 (all 64) on the REFERENCE's own run (G14): \\|dq\\| %.1e A, dtheta %.1e |"
     % (c["water192x64_md_steps_per_s"], c["water192x64_md_steps_per_s"] / c["water192_md_steps_per_s"], c["water192x64_ms_per_pass"],
        c["water192x64_kernel_frac"], c["water192x64_parity_max_abs_dq"], c["water192x64_parity_rel_dtheta"]),
-    "| one 4 096-bead SchNet system per GPU (config #5 as written) | 1 249 | %.0f steps/s | %.0f us per step | ~70 graph nodes per step, 90 % GPU-busy: 5–35 µs kernels of one round of workgroups each | -- | pinned in `tests/test_gpu_secondary_pins.py` |"
+    "| one 4 096-bead SchNet system per GPU (config #5 as written) | 1 249 | %.0f steps/s | %.0f us per step | ~70 graph nodes per step, 90 %% GPU-busy: 5–35 µs kernels of one round of workgroups each | -- | pinned in `tests/test_gpu_secondary_pins.py` |"
     % (c["single_system_md_steps_per_s"], c["single_system_us_per_md_step"]),
 ]
 table = "\n".join(rows)
