@@ -601,12 +601,14 @@ int mdg_atb2(const float* A, const float* B, const float* A2, const float* B2, i
  * flags: MDG_CHAIN_DUAL (= the former `dual` argument: 0 / 1) | MDG_CHAIN_X3: the stage products as three bf16 MFMAs on
  * operands split into bf16 head + bf16 remainder (x_h w_h + x_h w_l + x_l w_h, f32 accumulate: ~1e-5 relative per product
  * instead of 6e-8, 3/16 of the matrix time) -- the companion of the rows16 precision option, honoured by the compiled
- * n_atom_basis = 64 chains and ignored (f32 products) by every other list.
+ * n_atom_basis = 64 chains and ignored (f32 products) by every other list.  MDG_CHAIN_X6 (instead): THREE exact bf16 pieces
+ * per operand and the six piece products that matter -- the accuracy of the f32 matrix instruction (1.8e-7 of sum |terms|,
+ * tools/micro/split_mfma.hip) at 3/8 of its issue time; honoured by every compiled chain.
  */
 #define MDG_CHAIN_MAX_STAGES 8
 #define MDG_CHAIN_MAX_WIDTH 512
 enum { MDG_CHAIN_NONE = 0, MDG_CHAIN_MUL = 1, MDG_CHAIN_HEAD = 2, MDG_CHAIN_SSP_BWD = 3 };
-enum { MDG_CHAIN_DUAL = 1, MDG_CHAIN_X3 = 2 };
+enum { MDG_CHAIN_DUAL = 1, MDG_CHAIN_X3 = 2, MDG_CHAIN_X6 = 4 };
 typedef struct {
     const float* W;
     const float* bias;
@@ -707,7 +709,7 @@ typedef struct {
     MdgCell cell;
     float* ws;
     int64_t ws_floats;
-    int32_t stash, chain_x3;  /* chain_x3 != 0: the node-level chains run with MDG_CHAIN_X3 (split-bf16 products).  stash != 0: blocks with bf16 operands run mdg_cfconv_filter_stash once per evaluation and the
+    int32_t stash, chain_x3;  /* chain_x3: MDG_CHAIN_X3 or MDG_CHAIN_X6 (or 0), handed to mdg_row_chain with every node-level chain.  stash != 0: blocks with bf16 operands run mdg_cfconv_filter_stash once per evaluation and the
                                  stashed forward-type sweeps (mdg_cfconv_fwd_stashed): same results, fewer instructions */
 } MdgSchnetPlan;              /* host struct of DEVICE pointers */
 int64_t mdg_schnet_plan_sizeof(void);      /* sizeof(MdgSchnetPlan): bindings in other languages check their layout against it */

@@ -329,25 +329,40 @@ __device__ __forceinline__ void ld4v(const float* p, unsigned o, bool ok, float 
 // LDS holds the stage inputs as two bf16 planes [16][ldt] (head, remainder) per row set; accumulation and epilogues are f32.
 typedef short rc_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int rc_u32x4 __attribute__((ext_vector_type(4)));
-template <bool X3, int K, int M> struct WFrag { float b[spec_tp<M>()][K / 4]; };
-template <int K, int M> struct WFrag<true, K, M> { rc_bf16x8 h[spec_tp<M>()][K / 32], l[spec_tp<M>()][K / 32]; };
+// X6 (round 6, the f32 chains): THREE bf16 pieces per operand (8 + 8 + 8 bits: they add up to the f32 value exactly) and the six
+// piece products that matter, smallest first -- error 1.8e-7 of sum |terms| against 1.9e-7 for v_mfma_f32_16x16x4_f32
+// (tools/micro/split_mfma.hip) at 6 x 16 instead of 8 x 32 cycles per 32 k: f32 accuracy on the bf16 matrix pipe.  Flag
+// MDG_CHAIN_X6; the compiled chains honour it.  NP below: planes per operand (0: f32 matrix instruction, 2: X3, 3: X6).
+template <int NP, int K, int M> struct WFrag { rc_bf16x8 p[NP][spec_tp<M>()][K / 32]; };
+template <int K, int M> struct WFrag<0, K, M> { float b[spec_tp<M>()][K / 4]; };
 
-// head / remainder of two floats, packed (low half = a)
-__device__ __forceinline__ void rc_split2(float a, float b, unsigned int& h, unsigned int& l) {
-    h = rc_pk_bf16(a, b);
-    l = rc_pk_bf16(a - __uint_as_float(h << 16), b - __uint_as_float(h & 0xffff0000u));
-}
-__device__ __forceinline__ void rc_split8(const float (&f)[8], rc_bf16x8& h, rc_bf16x8& l) {
-    rc_u32x4 uh, ul;
+// NP pieces of two floats, packed (low half = a): head, (middle,) remainder -- each the bf16 nearest to what is left
+template <int NP>
+__device__ __forceinline__ void rc_split2(float a, float b, unsigned int (&u)[NP]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { unsigned int a, b; rc_split2(f[2 * i], f[2 * i + 1], a, b); uh[i] = a; ul[i] = b; }
-    h = __builtin_bit_cast(rc_bf16x8, uh);
-    l = __builtin_bit_cast(rc_bf16x8, ul);
+    for (int p = 0; p < NP; ++p) {
+        u[p] = rc_pk_bf16(a, b);
+        a -= __uint_as_float(u[p] << 16);
+        b -= __uint_as_float(u[p] & 0xffff0000u);
+    }
+}
+template <int NP>
+__device__ __forceinline__ void rc_split8(const float (&f)[8], rc_bf16x8 (&out)[NP]) {
+    rc_u32x4 v[NP];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned int u[NP];
+        rc_split2<NP>(f[2 * i], f[2 * i + 1], u);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p][i] = u[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) out[p] = __builtin_bit_cast(rc_bf16x8, v[p]);
 }
 
 // lane (li, lk): W_eff[m = 16 t + li][k = 32 kc + 8 lk + 0..7], split
-template <int K, int M, bool TRANS>
-__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<true, K, M>& w) {
+template <int K, int M, bool TRANS, int NP>
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<NP, K, M>& w) {
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
         const int t = wid + 4 * tt;
@@ -363,23 +378,28 @@ __device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid
 #pragma unroll
                 for (int c = 0; c < 8; ++c) f[c] = W[(32 * kc + 8 * lk + c) * M + m];
             }
-            rc_split8(f, w.h[tt][kc], w.l[tt][kc]);
+            rc_bf16x8 pc[NP];
+            rc_split8<NP>(f, pc);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) w.p[p][tt][kc] = pc[p];
         }
     }
 }
 
-// the X3 image of a row set: plane 0 = heads, plane 1 = remainders, [RC_ROWS][ldt] bf16 each (ldt elements = 2 ldt bytes per row)
+// the split image of a row set: NP planes [RC_ROWS][ldt] bf16 (ldt elements = 2 ldt bytes per row), plane 0 = heads
+template <int NP>
 __device__ __forceinline__ void rc_put4(float* X, int ldt, int r, int k, float a, float b, float c, float d) {
     unsigned short* P = reinterpret_cast<unsigned short*>(X);
-    unsigned int h0, l0, h1, l1;
-    rc_split2(a, b, h0, l0);
-    rc_split2(c, d, h1, l1);
-    *reinterpret_cast<rc_u32x2*>(P + r * ldt + k) = rc_u32x2{h0, h1};
-    *reinterpret_cast<rc_u32x2*>(P + (RC_ROWS + r) * ldt + k) = rc_u32x2{l0, l1};
+    unsigned int u0[NP], u1[NP];
+    rc_split2<NP>(a, b, u0);
+    rc_split2<NP>(c, d, u1);
+#pragma unroll
+    for (int p = 0; p < NP; ++p) *reinterpret_cast<rc_u32x2*>(P + (p * RC_ROWS + r) * ldt + k) = rc_u32x2{u0[p], u1[p]};
 }
 
-template <bool DUAL, int K, int M>
-__device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk, const WFrag<true, K, M>& w,
+// piece products, smallest first: (weight piece, row piece) with piece index sum <= NP - 1
+template <bool DUAL, int K, int M, int NP>
+__device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk, const WFrag<NP, K, M>& w,
                                          f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
     const unsigned short* P0 = reinterpret_cast<const unsigned short*>(X0);
     const unsigned short* P1 = reinterpret_cast<const unsigned short*>(X1);
@@ -388,24 +408,30 @@ __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int l
 #pragma unroll
     for (int kc = 0; kc < K / 32; ++kc) {
         const int o = li * ldt + 32 * kc + 8 * lk;
-        const rc_bf16x8 xh = *reinterpret_cast<const rc_bf16x8*>(P0 + o), xl = *reinterpret_cast<const rc_bf16x8*>(P0 + RC_ROWS * ldt + o);
-        rc_bf16x8 yh = xh, yl = xl;
-        if (DUAL) { yh = *reinterpret_cast<const rc_bf16x8*>(P1 + o); yl = *reinterpret_cast<const rc_bf16x8*>(P1 + RC_ROWS * ldt + o); }
+        rc_bf16x8 x[NP], y[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            x[p] = *reinterpret_cast<const rc_bf16x8*>(P0 + p * RC_ROWS * ldt + o);
+            y[p] = x[p];
+            if (DUAL) y[p] = *reinterpret_cast<const rc_bf16x8*>(P1 + p * RC_ROWS * ldt + o);
+        }
 #pragma unroll
         for (int tt = 0; tt < spec_tp<M>(); ++tt) {
             if ((wid + 4 * tt) * 16 >= M) continue;
-            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[tt][kc], xh, acc0[tt], 0, 0, 0);
-            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[tt][kc], yh, acc1[tt], 0, 0, 0);
-            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], xl, acc0[tt], 0, 0, 0);
-            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], yl, acc1[tt], 0, 0, 0);
-            acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], xh, acc0[tt], 0, 0, 0);
-            if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[tt][kc], yh, acc1[tt], 0, 0, 0);
+#pragma unroll
+            for (int lvl = NP - 1; lvl >= 0; --lvl)
+#pragma unroll
+                for (int pw = lvl; pw >= 0; --pw) {
+                    const int px = lvl - pw;
+                    acc0[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[pw][tt][kc], x[px], acc0[tt], 0, 0, 0);
+                    if (DUAL) acc1[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.p[pw][tt][kc], y[px], acc1[tt], 0, 0, 0);
+                }
         }
     }
 }
 
 template <int K, int M, bool TRANS>
-__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<false, K, M>& w) {
+__device__ __forceinline__ void spec_load_w(const float* __restrict__ W, int wid, int li, int lk, WFrag<0, K, M>& w) {
     float (&b)[spec_tp<M>()][K / 4] = w.b;
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) {
@@ -440,7 +466,7 @@ __device__ __forceinline__ void spec_load_bias(const MdgChainStage& S, int wid, 
     }
 }
 
-template <bool DUAL, int K, bool X3 = false>
+template <bool DUAL, int K, int NP = 0>
 __device__ __forceinline__ void spec_load_x(const float* __restrict__ in0, const float* __restrict__ in1, float* X0, float* X1,
                                             int ldt, int row0, int N, int tid) {
     constexpr int KQ = K / 4;
@@ -454,9 +480,9 @@ __device__ __forceinline__ void spec_load_x(const float* __restrict__ in0, const
             v0 = ld4(in0 + (unsigned)(rw * K + k));
             if (DUAL && in1) v1 = ld4(in1 + (unsigned)(rw * K + k));
         }
-        if constexpr (X3) {
-            rc_put4(X0, ldt, r, k, v0.x, v0.y, v0.z, v0.w);
-            if (DUAL) rc_put4(X1, ldt, r, k, v1.x, v1.y, v1.z, v1.w);
+        if constexpr (NP > 0) {
+            rc_put4<NP>(X0, ldt, r, k, v0.x, v0.y, v0.z, v0.w);
+            if (DUAL) rc_put4<NP>(X1, ldt, r, k, v1.x, v1.y, v1.z, v1.w);
         } else {
             *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0;
             if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1;
@@ -481,7 +507,7 @@ __device__ __forceinline__ void spec_fetch_x(const float* __restrict__ in0, cons
         }
     }
 }
-template <bool DUAL, int K, bool X3 = false>
+template <bool DUAL, int K, int NP = 0>
 __device__ __forceinline__ void spec_put_x(float* X0, float* X1, int ldt, int tid, const float4 (&v0)[spec_xq<K>()],
                                            const float4 (&v1)[spec_xq<K>()]) {
     constexpr int KQ = K / 4;
@@ -489,9 +515,9 @@ __device__ __forceinline__ void spec_put_x(float* X0, float* X1, int ldt, int ti
     for (int i = 0; i < spec_xq<K>(); ++i) {
         const int t = i * 256 + tid, r = t / KQ, k = (t % KQ) * 4;
         if (RC_ROWS * KQ % 256 != 0 && t >= RC_ROWS * KQ) break;
-        if constexpr (X3) {
-            rc_put4(X0, ldt, r, k, v0[i].x, v0[i].y, v0[i].z, v0[i].w);
-            if (DUAL) rc_put4(X1, ldt, r, k, v1[i].x, v1[i].y, v1[i].z, v1[i].w);
+        if constexpr (NP > 0) {
+            rc_put4<NP>(X0, ldt, r, k, v0[i].x, v0[i].y, v0[i].z, v0[i].w);
+            if (DUAL) rc_put4<NP>(X1, ldt, r, k, v1[i].x, v1[i].y, v1[i].z, v1[i].w);
         } else {
             *reinterpret_cast<float4*>(X0 + r * ldt + k) = v0[i];
             if (DUAL) *reinterpret_cast<float4*>(X1 + r * ldt + k) = v1[i];
@@ -510,7 +536,7 @@ __device__ __forceinline__ void spec_copy(float (&d)[spec_tp<M>()][4], const flo
 // 16 t + 4 lk + [0, 4) of row li
 template <bool DUAL, int K, int M>
 __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int ldt, int wid, int li, int lk,
-                                         const WFrag<false, K, M>& w, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
+                                         const WFrag<0, K, M>& w, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()]) {
     const float (&b)[spec_tp<M>()][K / 4] = w.b;
 #pragma unroll
     for (int tt = 0; tt < spec_tp<M>(); ++tt) { acc0[tt] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[tt] = acc0[tt]; }
@@ -538,7 +564,7 @@ __device__ __forceinline__ void spec_mma(const float* X0, const float* X1, int l
 
 // epilogue of a stage on the lane's 4 columns of each of its tiles; x0 / x1: operands of MUL / SSP_BWD (registers), q0 / q1:
 // residuals (registers); sg / kd receive sigmoid and the tangent row of an activation stage
-template <bool DUAL, int M, int ACT, int MODE, bool X3 = false>
+template <bool DUAL, int M, int ACT, int MODE, int NP = 0>
 __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&acc0)[spec_tp<M>()], f32x4 (&acc1)[spec_tp<M>()],
                                               const float (&x0)[spec_tp<M>()][4], const float (&x1)[spec_tp<M>()][4],
                                               const float (&q0)[spec_tp<M>()][4], const float (&q1)[spec_tp<M>()][4],
@@ -570,9 +596,9 @@ __device__ __forceinline__ void spec_epilogue(const MdgChainStage& S, f32x4 (&ac
                 if (DUAL) st4h(S.out1_h, o, z1);
             }
         }
-        if constexpr (X3) {
-            rc_put4(X0, ldt, li, m, z0[0], z0[1], z0[2], z0[3]);
-            if (DUAL) rc_put4(X1, ldt, li, m, z1[0], z1[1], z1[2], z1[3]);
+        if constexpr (NP > 0) {
+            rc_put4<NP>(X0, ldt, li, m, z0[0], z0[1], z0[2], z0[3]);
+            if (DUAL) rc_put4<NP>(X1, ldt, li, m, z1[0], z1[1], z1[2], z1[3]);
         } else {
             *reinterpret_cast<float4*>(X0 + li * ldt + m) = make_float4(z0[0], z0[1], z0[2], z0[3]);
             if (DUAL) *reinterpret_cast<float4*>(X1 + li * ldt + m) = make_float4(z1[0], z1[1], z1[2], z1[3]);
@@ -609,14 +635,16 @@ enum { SPEC_FWD = 0, SPEC_TURN = 1, SPEC_REV = 2 };
 // weights from L2 once per 16 rows (80 KB per workgroup: 164 MB per launch beside ~110 MB of rows).  The LOOP instantiation is
 // launched with a few workgroups per CU; each keeps ALL weight fragments and biases of the chain in registers and walks row
 // tiles blockIdx.x, + gridDim.x, ...: the weights are read once per workgroup and the workgroups of a CU drift out of phase.
-template <int A_, int F_, bool DUAL, int KIND, bool LOOP, bool X3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LOOP ? 2 : ((A_ == 64 && KIND != 2) ? 4 : 1))))
+template <int A_, int F_, bool DUAL, int KIND, bool LOOP, int NP>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(NP == 3 ? ((LOOP || A_ == 64) ? 2 : 1) : (LOOP ? 2 : ((A_ == 64 && KIND != 2) ? 4 : 1)))))
 void chain_spec_kernel(const ChainArgs A) {
     constexpr int H_ = A_ / 2;                                                      // readout hidden width
-    constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + (X3 ? 8 : 4);       // (X3: bf16 elements per plane row)
-    __shared__ __attribute__((aligned(16))) float Xs[(DUAL ? 2 : 1) * RC_ROWS * ldt];
+    constexpr int WMAX = A_ > F_ ? A_ : F_, ldt = WMAX + (NP ? 8 : 4);       // (NP > 0: bf16 elements per plane row)
+    constexpr int XSZ = RC_ROWS * ldt * (NP == 3 ? 3 : 2) / 2;                     // floats of one row set's image
+    __shared__ __attribute__((aligned(16))) float Xs[(DUAL ? 2 : 1) * XSZ];
     float* X0 = Xs;
-    float* X1 = Xs + (DUAL ? RC_ROWS * ldt : 0);
+    float* X1 = Xs + (DUAL ? XSZ : 0);
     const int N = A.N, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int n_tiles = (N + RC_ROWS - 1) / RC_ROWS, t_step = LOOP ? (int)gridDim.x : n_tiles;
     float sgA[spec_tp<A_>()][4], tdA[spec_tp<A_>()][4], zA[spec_tp<A_>()][4], zF[spec_tp<F_>()][4], zH[spec_tp<H_>()][4];
@@ -625,7 +653,7 @@ void chain_spec_kernel(const ChainArgs A) {
     if constexpr (KIND == SPEC_FWD) {
         // ---- first round trip: the weights of the first two stages, the input rows, the residual rows, the biases.  The
         //      weights of the third stage are requested while the first multiplies, each bias before its stage's products.
-        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1; WFrag<X3, A_, F_> w2;
+        WFrag<NP, F_, A_> w0; WFrag<NP, A_, A_> w1; WFrag<NP, A_, F_> w2;
         float b0[spec_tp<A_>()][4], b1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], b2[spec_tp<F_>()][4], lF[spec_tp<F_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
@@ -646,14 +674,14 @@ void chain_spec_kernel(const ChainArgs A) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
             if constexpr (LOOP) {
-                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_put_x<DUAL, F_, NP>(X0, X1, ldt, tid, px0, px1);
                 spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1);
                 const int nrow0 = (tile + t_step) * RC_ROWS;                        // (past the end: nothing is loaded)
                 spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
                 spec_load_rows<A_>(A.s[1].res0, nrow0 + li, N, wid, lk, pq0);
                 spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, nrow0 + li, N, wid, lk, pq1);
             } else {
-                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_x<DUAL, F_, NP>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
                 spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
                 spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
                 spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, b0, lA);
@@ -668,26 +696,26 @@ void chain_spec_kernel(const ChainArgs A) {
                 spec_load_bias<F_, MDG_CHAIN_NONE>(A.s[2], wid, lk, b2, lF);
             }
             __syncthreads();
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, NP>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, b0, zA);
             __syncthreads();
             // stage 1: r' = U2 t + c2 + r
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, NP>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, b1, zA);
             }
             __syncthreads();
             // stage 2: h' = Wn' r' + bn'
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, NP>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, b2, zF);
             if constexpr (LOOP) __syncthreads();                                   // (the next tile's rows overwrite X)
         }
     } else if constexpr (KIND == SPEC_TURN) {
-        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1;
-        WFrag<X3, A_, H_> w2; WFrag<X3, H_, A_> w3; WFrag<X3, A_, A_> w4; WFrag<X3, A_, F_> w5;
+        WFrag<NP, F_, A_> w0; WFrag<NP, A_, A_> w1;
+        WFrag<NP, A_, H_> w2; WFrag<NP, H_, A_> w3; WFrag<NP, A_, A_> w4; WFrag<NP, A_, F_> w5;
         float bA0[spec_tp<A_>()][4], bA1[spec_tp<A_>()][4], lA[spec_tp<A_>()][4], bH[spec_tp<H_>()][4], lH[spec_tp<H_>()][4];
         spec_load_w<F_, A_, false>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, false>(A.s[1].W, wid, li, lk, w1);
@@ -711,14 +739,14 @@ void chain_spec_kernel(const ChainArgs A) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
             if constexpr (LOOP) {
-                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_put_x<DUAL, F_, NP>(X0, X1, ldt, tid, px0, px1);
                 spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1);
                 const int nrow0 = (tile + t_step) * RC_ROWS;
                 spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
                 spec_load_rows<A_>(A.s[1].res0, nrow0 + li, N, wid, lk, pq0);
                 spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, nrow0 + li, N, wid, lk, pq1);
             } else {
-                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_x<DUAL, F_, NP>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
                 spec_load_rows<A_>(A.s[1].res0, row, N, wid, lk, q0);
                 spec_load_rows<A_>(DUAL ? A.s[1].res1 : nullptr, row, N, wid, lk, q1);
             }
@@ -728,7 +756,7 @@ void chain_spec_kernel(const ChainArgs A) {
             spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
             __syncthreads();
             if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[0], wid, lk, bA0, lA);
-            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA0, zA);
+            spec_epilogue<DUAL, A_, 1, MDG_CHAIN_NONE, NP>(A.s[0], a0, a1, zA, zA, zA, zA, sgA, tdA, X0, X1, ldt, row, N, wid, li, lk, bA0, zA);
             __syncthreads();
             // stage 1: r' = U2 t + c2 + r
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
@@ -736,7 +764,7 @@ void chain_spec_kernel(const ChainArgs A) {
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
                 if constexpr (!LOOP) spec_load_bias<A_, MDG_CHAIN_NONE>(A.s[1], wid, lk, bA1, lA);
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA1, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, NP>(A.s[1], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, bA1, zA);
             }
             __syncthreads();
             if constexpr (!LOOP) {
@@ -750,14 +778,14 @@ void chain_spec_kernel(const ChainArgs A) {
             spec_mma<DUAL, A_, H_>(X0, X1, ldt, wid, li, lk, w2, h0, h1);
             __syncthreads();
             if constexpr (!LOOP) spec_load_bias<H_, MDG_CHAIN_HEAD>(A.s[2], wid, lk, bH, lH);
-            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD, X3>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
+            spec_epilogue<DUAL, H_, 1, MDG_CHAIN_HEAD, NP>(A.s[2], h0, h1, zH, zH, zH, zH, dH, dH, X0, X1, ldt, row, N, wid, li, lk, bH, lH);
             __syncthreads();
             // stage 3: (rdb, rb) = (ydb, yb) L1
             spec_mma<DUAL, H_, A_>(X0, X1, ldt, wid, li, lk, w3, a0, a1);
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+                spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, NP>(A.s[3], a0, a1, zA, zA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
             }
             __syncthreads();
             // stage 4: (tdb, tb) = (rdb, rb) U2, then the reverse of the (ssp, tangent) pair with su / td of stage 0 (registers)
@@ -765,7 +793,7 @@ void chain_spec_kernel(const ChainArgs A) {
             __syncthreads();
             {
                 float s_[spec_tp<A_>()][4], t_[spec_tp<A_>()][4];
-                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, X3>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
+                spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, NP>(A.s[4], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row,
                                                                                     N, wid, li, lk, zA, zA);
             }
             __syncthreads();
@@ -773,12 +801,12 @@ void chain_spec_kernel(const ChainArgs A) {
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w5, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, NP>(A.s[5], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
             if constexpr (LOOP) __syncthreads();
         }
     } else {
         // ---- REV: (rdb', rb') = (hdb, hb) Wn + (rdb, rb); (udb, ub) = ssp'((rdb', rb') U2); (mdb, mb) = (udb, ub) U1
-        WFrag<X3, F_, A_> w0; WFrag<X3, A_, A_> w1; WFrag<X3, A_, F_> w2;
+        WFrag<NP, F_, A_> w0; WFrag<NP, A_, A_> w1; WFrag<NP, A_, F_> w2;
         spec_load_w<F_, A_, true>(A.s[0].W, wid, li, lk, w0);
         spec_load_w<A_, A_, true>(A.s[1].W, wid, li, lk, w1);
         spec_load_w<A_, F_, true>(A.s[2].W, wid, li, lk, w2);
@@ -796,7 +824,7 @@ void chain_spec_kernel(const ChainArgs A) {
             const int row0 = tile * RC_ROWS, row = row0 + li;
             float q0[spec_tp<A_>()][4], q1[spec_tp<A_>()][4];
             if constexpr (LOOP) {
-                spec_put_x<DUAL, F_, X3>(X0, X1, ldt, tid, px0, px1);
+                spec_put_x<DUAL, F_, NP>(X0, X1, ldt, tid, px0, px1);
                 spec_copy<A_>(q0, pq0); spec_copy<A_>(q1, pq1); spec_copy<A_>(sgA, psg); spec_copy<A_>(tdA, ptd);
                 const int nrow0 = (tile + t_step) * RC_ROWS, nrow = nrow0 + li;
                 spec_fetch_x<DUAL, F_>(A.s[0].in0, A.s[0].in1, nrow0, N, tid, px0, px1);
@@ -805,7 +833,7 @@ void chain_spec_kernel(const ChainArgs A) {
                 spec_load_rows<A_>(A.s[1].aux0, nrow, N, wid, lk, psg);
                 spec_load_rows<A_>(DUAL ? A.s[1].aux1 : nullptr, nrow, N, wid, lk, ptd);
             } else {
-                spec_load_x<DUAL, F_, X3>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
+                spec_load_x<DUAL, F_, NP>(A.s[0].in0, A.s[0].in1, X0, X1, ldt, row0, N, tid);
                 spec_load_rows<A_>(A.s[0].res0, row, N, wid, lk, q0);
                 spec_load_rows<A_>(DUAL ? A.s[0].res1 : nullptr, row, N, wid, lk, q1);
                 spec_load_rows<A_>(A.s[1].aux0, row, N, wid, lk, sgA);
@@ -816,17 +844,17 @@ void chain_spec_kernel(const ChainArgs A) {
             __syncthreads();
             spec_mma<DUAL, F_, A_>(X0, X1, ldt, wid, li, lk, w0, a0, a1);
             __syncthreads();
-            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, X3>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
+            spec_epilogue<DUAL, A_, 0, MDG_CHAIN_NONE, NP>(A.s[0], a0, a1, zA, zA, q0, q1, s_, t_, X0, X1, ldt, row, N, wid, li, lk, zA, zA);
             __syncthreads();
             spec_mma<DUAL, A_, A_>(X0, X1, ldt, wid, li, lk, w1, a0, a1);
             __syncthreads();
-            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, X3>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
+            spec_epilogue<DUAL, A_, 0, DUAL ? MDG_CHAIN_SSP_BWD : MDG_CHAIN_MUL, NP>(A.s[1], a0, a1, sgA, tdA, zA, zA, s_, t_, X0, X1, ldt, row, N, wid,
                                                                                 li, lk, zA, zA);
             __syncthreads();
             f32x4 f0[spec_tp<F_>()], f1[spec_tp<F_>()];
             spec_mma<DUAL, A_, F_>(X0, X1, ldt, wid, li, lk, w2, f0, f1);
             __syncthreads();
-            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, X3>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
+            spec_epilogue<DUAL, F_, 0, MDG_CHAIN_NONE, NP>(A.s[2], f0, f1, zF, zF, zF, zF, dF, dF, X0, X1, ldt, row, N, wid, li, lk, zF, zF);
             if constexpr (LOOP) __syncthreads();
         }
     }
@@ -881,44 +909,55 @@ int loop_grid(int n_tiles) {
     return (n_tiles + rounds - 1) / rounds;
 }
 
-template <int A_, int F_, bool DUAL, int KIND, bool X3>
+template <int A_, int F_, bool DUAL, int KIND, int NP>
 void spec_launch_kind(const ChainArgs& a, int n_tiles, hipStream_t st) {
     int lg = 0;
-    if constexpr (A_ == 64) lg = loop_grid(n_tiles);   // (A = 128: the weights do not fit)
-    if constexpr (A_ == 64) {
-        if (lg) { hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, true, X3>), dim3(lg), dim3(256), 0, st, a); return; }
+    // (LOOP: n_atom_basis = 64, whose weight fragments fit the registers of two workgroups per CU -- with three planes, X6, the
+    //  turn chain's do not: it runs one round of workgroups)
+    constexpr bool can_loop = A_ == 64 && !(NP == 3 && KIND == SPEC_TURN);
+    if constexpr (can_loop) lg = loop_grid(n_tiles);
+    if constexpr (can_loop) {
+        if (lg) { hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, true, NP>), dim3(lg), dim3(256), 0, st, a); return; }
     }
-    hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, false, X3>), dim3(n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((chain_spec_kernel<A_, F_, DUAL, KIND, false, NP>), dim3(n_tiles), dim3(256), 0, st, a);
 }
 
+// np: planes per operand the caller asked for (0 / 2: MDG_CHAIN_X3 / 3: MDG_CHAIN_X6)
 template <int A_, int F_>
-bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, bool x3, hipStream_t st) {
+bool spec_launch(const ChainArgs& a, const MdgChainStage* s, int n, int n_rows, int dual, int np, hipStream_t st) {
     const int kind = spec_kind(s, n, dual, A_, F_);
     if (kind < 0) return false;
     const int n_tiles = (n_rows + RC_ROWS - 1) / RC_ROWS;
+#define MDG_SPEC_NP(K_, NP_) do { if (dual) spec_launch_kind<A_, F_, true, K_, NP_>(a, n_tiles, st); else spec_launch_kind<A_, F_, false, K_, NP_>(a, n_tiles, st); } while (0)
 #define MDG_SPEC(K_)                                                                                                   \
     do {                                                                                                               \
-        if constexpr (A_ == 64) {                          /* X3 is compiled for the n_atom_basis = 64 chains */        \
-            if (x3) {                                                                                                  \
-                if (dual) spec_launch_kind<A_, F_, true, K_, true>(a, n_tiles, st);                                    \
-                else spec_launch_kind<A_, F_, false, K_, true>(a, n_tiles, st);                                        \
-                break;                                                                                                 \
-            }                                                                                                          \
+        /* X6 is as accurate as the f32 instruction, so it is taken where it is faster (tools/kbench_chain.py --flag 4):  \
+           few tiles (latency-bound: 192 rows, A = 128: 18.3 / 26.1 -> 14.5 / 21.2 us), the looping A = 64 chains (39.7 ->  \
+           33.0 us at 32 768 rows) and the dual A = 128 turn chain (80 -> 67 us at 12 288 rows); elsewhere the extra    \
+           registers cost more than the matrix time saved */                                                           \
+        if (np == 3 && (n_tiles <= 512 || (A_ == 64 && K_ != SPEC_TURN) || (A_ == 128 && dual && K_ == SPEC_TURN))) {     \
+            MDG_SPEC_NP(K_, 3);                                                                                        \
+            break;                                                                                                     \
         }                                                                                                              \
-        if (dual) spec_launch_kind<A_, F_, true, K_, false>(a, n_tiles, st);                                           \
-        else spec_launch_kind<A_, F_, false, K_, false>(a, n_tiles, st);                                               \
+        if constexpr (A_ == 64) {                          /* X3 is compiled for the n_atom_basis = 64 chains */        \
+            if (np == 2) { MDG_SPEC_NP(K_, 2); break; }                                                                \
+        }                                                                                                              \
+        MDG_SPEC_NP(K_, 0);                                                                                            \
     } while (0)
     if (kind == SPEC_FWD) MDG_SPEC(SPEC_FWD); else if (kind == SPEC_TURN) MDG_SPEC(SPEC_TURN); else MDG_SPEC(SPEC_REV);
 #undef MDG_SPEC
+#undef MDG_SPEC_NP
     return true;
 }
 
 }  // namespace
 
 extern "C" int mdg_row_chain(const MdgChainStage* stages, int n_stages, int n_rows, int flags, void* stream) {
-    MDG_CHECK_ARG(flags >= 0 && flags <= (MDG_CHAIN_DUAL | MDG_CHAIN_X3), "row_chain: flags: MDG_CHAIN_DUAL | MDG_CHAIN_X3");
+    MDG_CHECK_ARG(flags >= 0 && flags <= (MDG_CHAIN_DUAL | MDG_CHAIN_X3 | MDG_CHAIN_X6) && (flags & (MDG_CHAIN_X3 | MDG_CHAIN_X6)) != (MDG_CHAIN_X3 | MDG_CHAIN_X6),
+                  "row_chain: flags: MDG_CHAIN_DUAL | one of MDG_CHAIN_X3, MDG_CHAIN_X6");
     const int dual = flags & MDG_CHAIN_DUAL;
-    const bool x3 = (flags & MDG_CHAIN_X3) != 0;       // (honoured by the compiled n_atom_basis = 64 chains; f32 products elsewhere)
+    // (X3: honoured by the compiled n_atom_basis = 64 chains, X6: by every compiled chain; f32 matrix instruction elsewhere)
+    const int x3 = (flags & MDG_CHAIN_X6) ? 3 : ((flags & MDG_CHAIN_X3) ? 2 : 0);
     MDG_CHECK_ARG(stages && n_stages >= 1 && n_stages <= MDG_CHAIN_MAX_STAGES, "row_chain: 1..%d stages", MDG_CHAIN_MAX_STAGES);
     MDG_CHECK_ARG(n_rows >= 0 && (int64_t)n_rows * MDG_CHAIN_MAX_WIDTH < ((int64_t)1 << 31), "row_chain: bad row count");
     if (n_rows == 0) return MDG_OK;

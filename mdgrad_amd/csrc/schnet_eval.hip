@@ -256,7 +256,7 @@ int forward_and_turn(const MdgSchnetPlan& P, Bufs& B, const float* x, const floa
                 s.out0 = B.f0; s.out1 = dual ? B.f1 : nullptr; s.out0_h = B.f016; s.out1_h = dual ? B.f116 : nullptr;
             }
         }
-        MDG_RUN(mdg_row_chain(c.s, c.n, N, (dual ? MDG_CHAIN_DUAL : 0) | (P.chain_x3 ? MDG_CHAIN_X3 : 0), st));
+        MDG_RUN(mdg_row_chain(c.s, c.n, N, (dual ? MDG_CHAIN_DUAL : 0) | (P.chain_x3 & (MDG_CHAIN_X3 | MDG_CHAIN_X6)), st));
         r = L.r; rd = dual ? L.rd : nullptr;
         if (i + 1 < P.n_layers) {
             const bool r16 = P.layer[i + 1].rows16 != 0;
@@ -334,7 +334,7 @@ int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, flo
                 { MdgChainStage& s = c.add(S.Wn, F, A, 1, 0, MDG_CHAIN_NONE); s.in0 = L.hdb; s.in1 = L.hb; s.res0 = rdb; s.res1 = rb; s.out0 = L.g0; s.out1 = L.g1; }
                 { MdgChainStage& s = c.add(Sp.U2, A, A, 1, 0, MDG_CHAIN_SSP_BWD); s.aux0 = Lp.su; s.aux1 = Lp.td; s.out0 = L.e0; s.out1 = L.e1; }
                 { MdgChainStage& s = c.add(Sp.U1, A, Sp.filt.n_filters, 1, 0, MDG_CHAIN_NONE); s.out0 = L.f0; s.out1 = L.f1; s.out0_h = L.f016; s.out1_h = L.f116; }
-                MDG_RUN(mdg_row_chain(c.s, c.n, N, MDG_CHAIN_DUAL | (P.chain_x3 ? MDG_CHAIN_X3 : 0), stream));
+                MDG_RUN(mdg_row_chain(c.s, c.n, N, MDG_CHAIN_DUAL | (P.chain_x3 & (MDG_CHAIN_X3 | MDG_CHAIN_X6)), stream));
                 rdb = L.g0; rb = L.g1; udb = L.e0; ub = L.e1; mdb = L.f0; mb = L.f1;
                 mdg = Sp.rows16 ? (const void*)L.f016 : (const void*)L.f0;
                 mg = Sp.rows16 ? (const void*)L.f116 : (const void*)L.f1;
@@ -342,7 +342,7 @@ int run_vjp(const MdgSchnetPlan& P, Bufs& B, const float* x, const float* w, flo
                 // below the first block only the embedding rows' adjoint in U_dot is left (r_dot^0 = 0)
                 Chain c;
                 { MdgChainStage& s = c.add(S.Wn, F, A, 1, 0, MDG_CHAIN_NONE); s.in0 = L.hb; s.res0 = rb; s.out0 = L.g0; }
-                MDG_RUN(mdg_row_chain(c.s, c.n, N, P.chain_x3 ? MDG_CHAIN_X3 : 0, stream));
+                MDG_RUN(mdg_row_chain(c.s, c.n, N, P.chain_x3 & (MDG_CHAIN_X3 | MDG_CHAIN_X6), stream));
                 rb = L.g0;
             }
         }
@@ -421,7 +421,7 @@ extern "C" int mdg_schnet_force(const MdgSchnetPlan* plan, const float* x, float
             { MdgChainStage& s = c.add(S.Wn, S.filt.n_filters, A, 1, 0, MDG_CHAIN_NONE); s.in0 = L.hb; s.res0 = rb; s.out0 = L.g0; }
             { MdgChainStage& s = c.add(Sp.U2, A, A, 1, 0, MDG_CHAIN_MUL); s.aux0 = Lp.su; }
             { MdgChainStage& s = c.add(Sp.U1, A, Sp.filt.n_filters, 1, 0, MDG_CHAIN_NONE); s.out0 = L.f0; s.out0_h = L.f016; }
-            MDG_TRY(mdg_row_chain(c.s, c.n, N, P.chain_x3 ? MDG_CHAIN_X3 : 0, stream));
+            MDG_TRY(mdg_row_chain(c.s, c.n, N, P.chain_x3 & (MDG_CHAIN_X3 | MDG_CHAIN_X6), stream));
             rb = L.g0;
             mg = Sp.rows16 ? (const void*)L.f016 : (const void*)L.f0;
         }

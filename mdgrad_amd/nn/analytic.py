@@ -416,13 +416,19 @@ def _filter_net(conv, P, bf16, rows16):
 
 
 def _chain_x3(net, fns):
-    """Do the node-level chains of this network run with MDG_CHAIN_X3 -- the Dense products as three bf16 MFMAs on operands
-    split into a bf16 head and remainder (csrc/rowchain.hip; ~1e-5 relative per product, 3/16 of the f32 matrix time)?  It comes
-    with the rows16 precision option (every block gathering bf16 node rows: their rounding is 2^-9), `SchNet.chain_x3 = False`
-    or MDG_CHAIN_X3=0 keeps f32 products."""
+    """The flag the node-level chains of this network hand to mdg_row_chain (csrc/rowchain.hip) for their Dense products:
+    MDG_CHAIN_X3 (2) with the rows16 precision option -- three bf16 MFMAs on head / remainder splits, ~1e-5 per product, the
+    gathered rows being rounded at 2^-9 anyway (`SchNet.chain_x3 = False` / MDG_CHAIN_X3=0: not) --, otherwise MDG_CHAIN_X6 (4):
+    three EXACT bf16 pieces per operand and six piece products, the accuracy of the f32 matrix instruction at 3/8 of its issue
+    time -- an OPT-IN (`SchNet.chain_x6 = True`, or MDG_CHAIN_X6=1): measured 1-4 % slower in the pass than the f32 instruction (three
+    planes of weight fragments per lane cost the occupancy the matrix cycles saved, profiles/r06_chain_x6_ab.txt)."""
     import os
-    return (all(fn.rows16 for fn in fns) and getattr(net, "chain_x3", True) is not False
-            and os.environ.get("MDG_CHAIN_X3", "1") != "0")
+    if (all(fn.rows16 for fn in fns) and getattr(net, "chain_x3", True) is not False
+            and os.environ.get("MDG_CHAIN_X3", "1") != "0"):
+        return 2
+    if getattr(net, "chain_x6", False) or os.environ.get("MDG_CHAIN_X6", "0") == "1":
+        return 4
+    return 0
 
 
 def _rows16(net, conv):

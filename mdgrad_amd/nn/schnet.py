@@ -115,6 +115,10 @@ class SchNet(nn.Module):
     # operands split into a bf16 head and remainder (MDG_CHAIN_X3, csrc/rowchain.hip: ~1e-5 per product, f32 accumulate).
     # False: exact f32 products there.
     chain_x3 = True
+    # True (or MDG_CHAIN_X6=1): with f32 rows the chains use six exact-bf16-piece products per Dense product (MDG_CHAIN_X6: f32
+    # accuracy on the bf16 matrix pipe).  Off by default: 1-4 % slower in the pass than v_mfma_f32_16x16x4_f32
+    # (profiles/r06_chain_x6_ab.txt).
+    chain_x6 = False
     # One C-ABI call per force / force-vjp evaluation (nn/plan.py, csrc/schnet_eval.hip) and, inside it, the per-edge stash of
     # the filter network's first layer for the rows16 sweeps -- same kernels and results as the launch-by-launch path / the
     # recomputing sweeps; False selects those (A/B and debugging).

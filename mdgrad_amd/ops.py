@@ -1704,8 +1704,9 @@ class RowChain:
     [n_rows, M] tensors.  `dual`: primal + tangent rows (or the two adjoints) share the weights.  `x3`: MDG_CHAIN_X3, the
     products as three bf16 MFMAs on split operands (the rows16 precision option's companion, `chain_x3`)."""
 
-    def __init__(self, n_rows, dual, device, x3=False):
-        self.N, self.dual, self.dev, self.x3 = int(n_rows), bool(dual), device, bool(x3)
+    def __init__(self, n_rows, dual, device, x3=0):
+        # x3: 0, or the flag MDG_CHAIN_X3 (2) / MDG_CHAIN_X6 (4) (True: X3)
+        self.N, self.dual, self.dev, self.x3 = int(n_rows), bool(dual), device, (2 if x3 is True else int(x3))
         self.stages, self.keep, self.words = [], [], []
 
     @staticmethod
@@ -1756,7 +1757,7 @@ class RowChain:
         lib = _lib.load()
         buf = _array("Q", self.words)                               # [n_stages] MdgChainStage, 18 x 8 bytes each
         assert len(self.words) == 18 * len(self.stages) and C.sizeof(_lib.MdgChainStage) == 144
-        check(lib.mdg_row_chain(buf.buffer_info()[0], len(self.stages), self.N, int(self.dual) | (2 if self.x3 else 0), stream_ptr(self.dev)),
+        check(lib.mdg_row_chain(buf.buffer_info()[0], len(self.stages), self.N, int(self.dual) | self.x3, stream_ptr(self.dev)),
               "mdg_row_chain")
 
 

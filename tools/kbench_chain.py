@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--rows", type=int, default=4096)
     ap.add_argument("--a", type=int, default=64)
     ap.add_argument("--f", type=int, default=128)
+    ap.add_argument("--flag", type=int, default=0, help="0: f32 matrix instruction, 2: MDG_CHAIN_X3, 4: MDG_CHAIN_X6")
     args = ap.parse_args()
     from mdgrad_amd import ops, _lib
     dev = torch.device("cuda:0")
@@ -44,7 +45,7 @@ def main():
     keep = {}
 
     def chain(kind, dual):
-        ch = ops.RowChain(N, dual, dev)
+        ch = ops.RowChain(N, dual, dev, args.flag)
         a = ch.stage(U1, bias=c1, act=True, in0=m, in1=md if dual else None, want_sig=True)
         if kind >= 2:
             ch.stage(U2, bias=c2, res0=r, res1=rd if dual else None)
