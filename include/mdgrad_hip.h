@@ -308,6 +308,28 @@ int mdg_traj_adj_large(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*
                        const float* g_v, const float* g_q, const float* g_pv,
                        float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
                        float* ws, int32_t* flags, void* stream);
+/* The same two trajectories for integrators with topology_update_freq > 1 (torchmd/md.py:200-204; see mdg_traj_*_small_stale
+ * for the call counting: 2 (n_frames - 1) right-hand-side calls per forward launch, 3 (n_frames - 1) per adjoint launch, a
+ * rebuild at every call whose running count is a multiple of `freq`, stale pair set + frozen image flags and no cutoff re-test
+ * in between, torchmd/interface.py:298-300).  The host loop knows each call's count and launches a searching or a
+ * stored-row force kernel accordingly; a forward step whose NEXT first call rebuilds gets one more force launch at the same
+ * positions (the two right-hand-side calls that share a state then see different lists).  No Verlet reuse here (the lists ARE
+ * the semantics).  Built-in pair forms, any number of terms, masks, any cell, N <= 32 768.
+ *   rows  uint32 [mdg_traj_large_stale_words(n_rep, n_atoms)], persistent across launches like the reference's nbr_list /
+ *         offsets attributes: per replica and atom 256 entries j | image code << 15 | term bits << 20 in ascending j, then
+ *         the int32 counts [n_rep][n_atoms]; flags[0] reports a row overflow as in mdg_traj_fwd_large. */
+int64_t mdg_traj_large_stale_words(int n_rep, int n_atoms);
+int mdg_traj_fwd_large_stale(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/, const MdgTerms* terms /*host*/,
+                             const float* theta, const float* mass, const float* t_grid,
+                             const float* v0, const float* q0, const float* pv0,
+                             float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags,
+                             int freq, int64_t count0, uint32_t* rows, void* stream);
+int mdg_traj_adj_large_stale(const MdgTrajParams* prm /*host*/, const MdgCell* cell /*host*/, const MdgTerms* terms /*host*/,
+                             const float* theta, const float* mass, const float* t_grid,
+                             const float* v_t, const float* q_t, const float* pv_t,
+                             const float* g_v, const float* g_q, const float* g_pv,
+                             float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                             float* ws, int32_t* flags, int freq, int64_t count0, uint32_t* rows, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K8  soft-histogram RDF  (replaces rdf.forward and its autograd backward:

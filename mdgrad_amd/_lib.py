@@ -132,6 +132,11 @@ _SIGNATURES = {
                                      P, P, P, P, P, P, P, P, P, P, P, P]),
     "mdg_traj_adj_large": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
                                      P, P, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "mdg_traj_large_stale_words": (C.c_int64, [C.c_int, C.c_int]),
+    "mdg_traj_fwd_large_stale": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
+                                           P, P, P, P, P, P, P, P, P, P, P, C.c_int, C.c_int64, P, P]),
+    "mdg_traj_adj_large_stale": (C.c_int, [C.POINTER(MdgTrajParams), C.POINTER(MdgCell), C.POINTER(MdgTerms),
+                                           P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, C.c_int, C.c_int64, P, P]),
     "mdg_rdf_partial_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "mdg_rdf_fwd": (C.c_int, [P, C.c_int, C.c_int, C.POINTER(MdgCell), C.c_float, P, P, C.c_float,
                               C.c_int, P, P, P]),

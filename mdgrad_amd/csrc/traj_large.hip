@@ -96,6 +96,14 @@ struct LargeArgs {
     int rep0;                                // first replica of this launch (replica groups on concurrent streams, see lg_streams)
     int tile_cap;                            // staged atoms of a tile at most (0: no tiles)
     int ncol;                                // bin columns nb[0] nb[1]
+    // STALE LISTS (topology_update_freq > 1, round 6; mdg_traj_*_large_stale): the pair set and image flags of the last rebuild,
+    // persistent across launches like the reference's nbr_list / offsets attributes.  A row entry is
+    // j | image code << 15 | term bits << 20 in ascending j; the host loop knows every call's running count and says per
+    // launch whether it rebuilds (search at the exact cutoffs of the terms, generate_nbr_list's tests) or evaluates the stored
+    // rows with their frozen flags and no cutoff re-test (interface.py:298-300).
+    uint32_t* st_row;                        // [R][N][LG_CAP]
+    int32_t* st_cnt;                         // [R][N]
+    int st_rebuild;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -763,9 +771,178 @@ __device__ __forceinline__ float prepare_terms(const LargeArgs& A, TermConst (&t
     return rc2max;
 }
 
+// ------------------------------------------------------------------------------------ stale lists
+// One wave, atom i, topology_update_freq > 1 (torchmd/md.py:200-204).  A.st_rebuild (launch-uniform): the atom's pairs are
+// searched at the current positions with generate_nbr_list's tests (topology.py:59-67: minimum image, un-contracted
+// d^2 < rc^2 per term, != 0, the term's selection mask), written to its stale row in ascending j and evaluated; otherwise the
+// stored row is evaluated with its frozen image flags whatever the distances are now.  The two give the same bits at the same
+// positions (same D arithmetic, same order), which is what lets the forward loop keep a force across the two right-hand-side
+// calls that share a state.  Built-in pair forms; no table kind.
+template <bool DIAG, int LEVEL>
+__device__ __forceinline__ void wave_stale_force(
+    const LargeArgs& A, const float* __restrict__ q, const float* __restrict__ lam, int i, bool valid, float* tile, float4* buf,
+    float& fx, float& fy, float& fz, float& gx, float& gy, float& gz, float (&th)[LG_KMAX],
+    const TermConst (&tc)[MDG_MAX_TERMS], int rep) {
+    const int N = A.prm.n_atoms, lane = threadIdx.x & 63, nt = A.terms.n_terms;
+    const float xi = valid ? q[3 * i] : 0.f, yi = valid ? q[3 * i + 1] : 0.f, zi = valid ? q[3 * i + 2] : 0.f;
+    uint32_t* row = A.st_row + ((size_t)rep * N + (valid ? i : 0)) * LG_CAP;
+    int n = 0;
+    if (A.st_rebuild) {
+        auto test = [&](int j, bool live, float pjx, float pjy, float pjz) {
+            bool ok = false;
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            unsigned code = 0;
+            if (live && j != i) {
+                dx = pjx - xi; dy = pjy - yi; dz = pjz - zi;                       // D = x_j - x_i
+                const int img = min_image<DIAG>(A.cell, dx, dy, dz);
+                const float d2 = norm2_ref(dx, dy, dz);
+                unsigned bits = 0;
+                if (d2 != 0.f) {                                                    // topology.py:67
+#pragma unroll
+                    for (int m = 0; m < MDG_MAX_TERMS; ++m) {
+                        if (m >= nt) break;
+                        const uint8_t* mk = A.terms.t[m].mask;
+                        if (d2 < tc[m].rc2 && (!mk || mk[(size_t)i * N + j])) bits |= 1u << m;
+                    }
+                }
+                ok = bits != 0;
+                code = (unsigned)j | ((unsigned)img << 15) | (bits << 20);
+            }
+            const unsigned long long bal = __ballot(ok);
+            if (ok) {
+                const int k = n + __popcll(bal & ((1ull << lane) - 1ull));
+                if (k < LG_CAP) buf[k] = make_float4(dx, dy, dz, __uint_as_float(code));
+            }
+            n += __popcll(bal);
+        };
+        if (DIAG && A.ncell > 0) {
+            // cell-binned scan (the bins of large_prep: width >= the largest cutoff): the 3 x 3 columns around the atom's bin,
+            // a column's three z-bins being one contiguous range of the sorted positions (two when it wraps)
+            if (valid) {
+                const float4* sp = A.spos + (size_t)rep * N;
+                const int32_t* bs = A.bstart + (size_t)rep * (LG_MAX_CELLS + 1);
+                const int nbx = A.nb[0], nby = A.nb[1], nbz = A.nb[2];
+                const int bx = __builtin_amdgcn_readfirstlane(bin_coord_l(xi, A.cell.inv[0], nbx));
+                const int by = __builtin_amdgcn_readfirstlane(bin_coord_l(yi, A.cell.inv[4], nby));
+                const int bz = __builtin_amdgcn_readfirstlane(bin_coord_l(zi, A.cell.inv[8], nbz));
+                const int zl0 = max(bz - 1, 0), zh0 = min(bz + 1, nbz - 1);
+                const int zw = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);
+                for (int c = 0; c < 9; ++c) {
+                    int cx = bx + c / 3 - 1, cy = by + c % 3 - 1;
+                    cx += cx < 0 ? nbx : 0; cx -= cx >= nbx ? nbx : 0;
+                    cy += cy < 0 ? nby : 0; cy -= cy >= nby ? nby : 0;
+                    const int cb = (cx * nby + cy) * nbz;
+                    for (int part = 0; part < 2; ++part) {
+                        if (part && zw < 0) break;
+                        const int a0 = bs[cb + (part ? zw : zl0)], a1 = bs[cb + (part ? zw : zh0) + 1];
+                        for (int a = a0; a < a1; a += 64) {
+                            const int idx = a + lane;
+                            const float4 pj = idx < a1 ? sp[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            test(__float_as_int(pj.w), idx < a1, pj.x, pj.y, pj.z);
+                        }
+                    }
+                }
+                // ascending neighbour index (entries are distinct): rank sort inside the wave's buffer
+                const int m = n < LG_CAP ? n : LG_CAP;
+                float4 mine[LG_CAP / 64];
+                int rank[LG_CAP / 64];
+#pragma unroll
+                for (int u = 0; u < LG_CAP / 64; ++u) {
+                    const int k = lane + 64 * u;
+                    rank[u] = 0;
+                    mine[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (k < m) {
+                        mine[u] = buf[k];
+                        const unsigned key = __float_as_uint(mine[u].w) & 32767u;
+                        for (int l = 0; l < m; ++l) rank[u] += (__float_as_uint(buf[l].w) & 32767u) < key;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < LG_CAP / 64; ++u)
+                    if (lane + 64 * u < m) buf[rank[u]] = mine[u];
+            }
+        } else {
+            for (int t0 = 0; t0 < N; t0 += LG_TILE) {
+                const int tn = min(LG_TILE, N - t0);
+                __syncthreads();
+                for (int e = threadIdx.x; e < 3 * tn; e += blockDim.x) tile[(e % 3) * LG_TILE + e / 3] = q[3 * t0 + e];
+                __syncthreads();
+                if (valid)
+                    for (int c0 = 0; c0 < tn; c0 += 64) {
+                        const int jl = c0 + lane;
+                        const bool live = jl < tn;
+                        test(t0 + jl, live, live ? tile[jl] : 0.f, live ? tile[LG_TILE + jl] : 0.f, live ? tile[2 * LG_TILE + jl] : 0.f);
+                    }
+            }
+        }
+        if (n > LG_CAP) { if (lane == 0) atomicMax(&A.flags[0], n); n = LG_CAP; }
+        if (valid) {
+            for (int k = lane; k < n; k += 64) row[k] = __float_as_uint(buf[k].w);
+            if (lane == 0) A.st_cnt[(size_t)rep * N + i] = n;
+        }
+    } else if (valid) {
+        n = A.st_cnt[(size_t)rep * N + i];
+        for (int k = lane; k < n; k += 64) {
+            const unsigned code = row[k];
+            const int j = (int)(code & 32767u), img = (int)((code >> 15) & 31u);
+            const float ox = (float)(img % 3 - 1), oy = (float)((img / 3) % 3 - 1), oz = (float)(img / 9 - 1);
+            float dx = q[3 * j] - xi, dy = q[3 * j + 1] - yi, dz = q[3 * j + 2] - zi;
+            if (DIAG) {
+                dx = fmaf(ox, A.cell.h[0], dx); dy = fmaf(oy, A.cell.h[4], dy); dz = fmaf(oz, A.cell.h[8], dz);
+            } else {
+                dx += fmaf(oz, A.cell.h[6], fmaf(oy, A.cell.h[3], ox * A.cell.h[0]));
+                dy += fmaf(oz, A.cell.h[7], fmaf(oy, A.cell.h[4], ox * A.cell.h[1]));
+                dz += fmaf(oz, A.cell.h[8], fmaf(oy, A.cell.h[5], ox * A.cell.h[2]));
+            }
+            buf[k] = make_float4(dx, dy, dz, __uint_as_float(code));
+        }
+    }
+    fx = fy = fz = gx = gy = gz = 0.f;
+    if (!valid) return;
+    float wxi = 0.f, wyi = 0.f, wzi = 0.f;
+    const bool nhc_w = A.prm.ensemble == 0;
+    if (LEVEL >= 2) { const float im = nhc_w ? 1.0f / A.mass[i] : 1.0f; wxi = lam[3 * i] * im; wyi = lam[3 * i + 1] * im; wzi = lam[3 * i + 2] * im; }
+    for (int k = lane; k < n; k += 64) {
+        const float4 e = buf[k];
+        const float dx = e.x, dy = e.y, dz = e.z;
+        const unsigned code = __float_as_uint(e.w);
+        const int j = (int)(code & 32767u);
+        const float d2 = norm2_ref(dx, dy, dz);
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (LEVEL >= 2) {
+            const float jm = nhc_w ? 1.0f / A.mass[j] : 1.0f;
+            ax = wxi - lam[3 * j] * jm; ay = wyi - lam[3 * j + 1] * jm; az = wzi - lam[3 * j + 2] * jm;
+        }
+#pragma unroll
+        for (int m = 0; m < MDG_MAX_TERMS; ++m) {
+            if (m >= nt) break;
+            if (!((code >> (20 + m)) & 1u)) continue;
+            PairOut o;
+            float r, ir;
+            pair_eval<LEVEL, -1>(tc[m], d2, r, ir, o);
+            const float c1 = o.du * ir;
+            fx = fmaf(c1, dx, fx); fy = fmaf(c1, dy, fy); fz = fmaf(c1, dz, fz);
+            if (LEVEL >= 2) {
+                const float rx = -dx * ir, ry = -dy * ir, rz = -dz * ir;
+                const float a = rx * ax + ry * ay + rz * az;
+                const float c2 = o.d2u * a - c1 * a;
+                gx -= c2 * rx + c1 * ax; gy -= c2 * ry + c1 * ay; gz -= c2 * rz + c1 * az;
+#pragma unroll
+                for (int p = 0; p < MDG_MAX_THETA; ++p)
+                    if (p < A.terms.t[m].n_theta) th[m * MDG_MAX_THETA + p] -= 0.5f * o.ddu_dth[p] * a;
+            }
+        }
+    }
+    fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
+    if (LEVEL >= 2) { gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); }
+}
+
 // ------------------------------------------------------------------------------------ forward
 // MODE 0: initial force at q0 + frame 0 + KE(v0) partials.   MODE 1: second half of step k.
-template <bool DIAG, int MODE, int KIND>
+// STALE (stale lists): wave_stale_force instead of the search; MODE 2: the force alone, again, at the positions of the step
+// just finished -- the first right-hand-side call of the next step when that call rebuilds the lists (its force then differs
+// from the one the second half of this step used).
+template <bool DIAG, int MODE, int KIND, bool STALE = false>
 __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) {
     // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
     extern __shared__ __attribute__((aligned(16))) float4 nbuf[];
@@ -815,6 +992,17 @@ __global__ __launch_bounds__(LG_BLOCK) void large_force_step(const LargeArgs A) 
     const bool valid = i < N;
     float fx, fy, fz, gx, gy, gz, th[LG_KMAX];
     const float rs = sqrtf(rc2max) + A.skin;                    // (skin 0 unless the lists are kept for the adjoint)
+    if constexpr (STALE) {
+        wave_stale_force<DIAG, 1>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th, tc, rep);
+        if (MODE == 2) {
+            if (valid && lane < 3) {
+                const float F = lane == 0 ? fx : (lane == 1 ? fy : fz);
+                f[3 * i + lane] = F;
+                if (!isfinite(F)) A.flags[1] = 1;
+            }
+            return;
+        }
+    } else
     wave_neighbours_and_force<DIAG, 1, KIND, 1>(A, q, nullptr, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz,
                                                 th, tc, rs * rs, 0.f, rep, MODE == 0 ? 0 : k + 1);
     float kepart = 0.f;
@@ -1180,7 +1368,7 @@ __global__ __launch_bounds__(256) void large_search_rows(const LargeArgs A) {
 // ------------------------------------------------------------------------------------ adjoint
 // force + HVP + parameter vjp at (qsrc, vsrc ; lam) -> f, dq, per-block partials
 // by a fresh search (large_adj_listed below evaluates the forward pass's stored candidates instead).
-template <bool DIAG, int KIND>
+template <bool DIAG, int KIND, bool STALE = false>
 __global__ __launch_bounds__(LG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void large_adj_force(const LargeArgs A, const int second) {
     // dynamic LDS: [waves][LG_CAP] neighbour buffers, then [3][LG_TILE] position tiles for the all-atom scan (absent in cell mode)
@@ -1204,6 +1392,9 @@ void large_adj_force(const LargeArgs A, const int second) {
     // (NVE: from the first evaluation, sovlers.py:82,101 -- both with total weight h)
     const bool tab_eval = (A.prm.ensemble == 0) == (second != 0);
     const float gw = (tab_eval && A.g64) ? 0.5f * (A.t[i_fr] - A.t[i_fr - 1]) * A.terms.t[0].c : 0.f;
+    if constexpr (STALE)
+        wave_stale_force<DIAG, 2>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th, tc, rep);
+    else
     wave_neighbours_and_force<DIAG, 2, KIND, 0>(A, qs, lam, i, valid, tile, nbuf + wid * LG_CAP, fx, fy, fz, gx, gy, gz, th,
                                                 tc, rc2max, gw, rep);
     float vals[LG_NV];
@@ -1985,15 +2176,40 @@ extern "C" int mdg_traj_large_list_builds(const float* ws, int n_rep, int n_atom
                        terms->t[0].p == 12 && (terms->t[0].q == 6 || terms->t[0].c == 0.f);          \
     (void)0;
 
-extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
-                                  const float* theta, const float* mass, const float* t_grid,
-                                  const float* v0, const float* q0, const float* pv0,
-                                  float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream) {
+// stale lists (topology_update_freq > 1): frequency, the integrator's call count at the launch's first call, the persistent rows
+struct StaleOpt { int freq; long long count0; uint32_t* rows; };
+static inline bool stale_due(const StaleOpt* so, long long e) { return (so->count0 + e) % (long long)so->freq == 0; }
+static int validate_stale(const MdgTrajParams* prm, const MdgTerms* terms, const StaleOpt* so) {
+    MDG_CHECK_ARG(so->freq >= 1 && so->count0 >= 0 && so->rows, "traj_large_stale: bad frequency / counter / list buffer");
+    MDG_CHECK_ARG(prm->n_atoms <= 32768, "traj_large_stale: at most 32 768 atoms (15-bit row entries)");
+    for (int m = 0; m < terms->n_terms; ++m)
+        MDG_CHECK_ARG(terms->t[m].kind != MDG_PAIR_TABLE, "traj_large_stale: a tabulated pair model is not supported");
+    return MDG_OK;
+}
+#define LG_STALE_SETUP()                                                                             \
+    if (so) {                                                                                        \
+        a.st_row = so->rows;                                                                         \
+        a.st_cnt = reinterpret_cast<int32_t*>(so->rows + (size_t)R * N * LG_CAP);                    \
+    }                                                                                                \
+    (void)0
+
+static int traj_fwd_large_run(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                              const float* theta, const float* mass, const float* t_grid,
+                              const float* v0, const float* q0, const float* pv0,
+                              float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream,
+                              const StaleOpt* so) {
     int rc = validate_large(prm, cell, terms);
     if (rc) return rc;
     MDG_CHECK_ARG(mass && t_grid && v0 && q0 && v_t && q_t && ws && flags, "traj_fwd_large: null buffer");
     MDG_CHECK_ARG(prm->ensemble == 1 || (pv0 && pv_t), "traj_fwd_large: NHC needs pv0/pv_t");
+    MdgTrajParams pstale;
+    if (so) {                                   // (stale lists: no candidate lists of the Verlet-reuse kind -- block = -1)
+        rc = validate_stale(prm, terms, so);
+        if (rc) return rc;
+        pstale = *prm; pstale.block = -1; prm = &pstale;
+    }
     LG_SETUP();
+    LG_STALE_SETUP();
     a.v_t = v_t; a.q_t = q_t; a.pv_t = pv_t;
     const int C = prm->n_chains, T = prm->n_frames;
     MDG_HIP(hipMemcpyAsync(a.q, q0, sizeof(float) * (size_t)R * N * 3, hipMemcpyDeviceToDevice, st));
@@ -2014,7 +2230,32 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
         else if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, sg, a);    \
         else hipLaunchKernelGGL((large_force_step<false, MODE_, -1>), gF, dim3(64 * wpb), tile_lds, sg, a);            \
     } while (0)
+    // stale lists: the first right-hand-side call of step k has the running index 2 k, the second 2 k + 1 (sovlers.py:110-127);
+    // calls 2 k + 1 and 2 k + 2 share their positions, so the force of the former serves the latter unless that one rebuilds
+#define LG_STALE_STEP(MODE_, REBUILD_)                                                                          \
+    do {                                                                                                        \
+        const dim3 gF(nbF, Rg);                                                                                 \
+        a.st_rebuild = (REBUILD_) ? 1 : 0;                                                                      \
+        if (diag) hipLaunchKernelGGL((large_force_step<true, MODE_, -1, true>), gF, dim3(64 * wpb), tile_lds, sg, a);  \
+        else hipLaunchKernelGGL((large_force_step<false, MODE_, -1, true>), gF, dim3(64 * wpb), tile_lds, sg, a);      \
+    } while (0)
     LG_GROUPS_BEGIN();
+    if (so) {
+        for (int g = 0; g < G; ++g) {
+            LG_GROUP(g);
+            if (a.ncell) LG_PREP_LAUNCH(0);
+            LG_STALE_STEP(0, stale_due(so, 0));
+        }
+        for (int k = 0; k + 1 < T; ++k) {
+            a.step = k;
+            for (int g = 0; g < G; ++g) {
+                LG_GROUP(g);
+                LG_PREP_LAUNCH(1);
+                LG_STALE_STEP(1, stale_due(so, 2ll * k + 1));
+                if (k + 2 < T && stale_due(so, 2ll * k + 2) && !stale_due(so, 2ll * k + 1)) LG_STALE_STEP(2, true);
+            }
+        }
+    } else {
     for (int g = 0; g < G; ++g) {
         LG_GROUP(g);
         if (a.ncell) LG_PREP_LAUNCH(0);
@@ -2039,23 +2280,53 @@ extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell,
             }
         }
     }
+    }
     LG_GROUPS_END();
 #undef LG_FORCE_STEP
+#undef LG_STALE_STEP
     MDG_CHECK_LAUNCH("traj_fwd_large");
     return MDG_OK;
 }
 
-extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+extern "C" int mdg_traj_fwd_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
                                   const float* theta, const float* mass, const float* t_grid,
-                                  const float* v_t, const float* q_t, const float* pv_t,
-                                  const float* g_v, const float* g_q, const float* g_pv,
-                                  float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
-                                  float* ws, int32_t* flags, void* stream) {
+                                  const float* v0, const float* q0, const float* pv0,
+                                  float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags, void* stream) {
+    return traj_fwd_large_run(prm, cell, terms, theta, mass, t_grid, v0, q0, pv0, v_t, q_t, pv_t, ws, flags, stream, nullptr);
+}
+
+extern "C" int64_t mdg_traj_large_stale_words(int n_rep, int n_atoms) {
+    if (n_rep <= 0 || n_atoms <= 0) return -1;
+    return (int64_t)n_rep * n_atoms * (LG_CAP + 1);
+}
+
+extern "C" int mdg_traj_fwd_large_stale(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                        const float* theta, const float* mass, const float* t_grid,
+                                        const float* v0, const float* q0, const float* pv0,
+                                        float* v_t, float* q_t, float* pv_t, float* ws, int32_t* flags,
+                                        int freq, int64_t count0, uint32_t* rows, void* stream) {
+    const StaleOpt so{freq, (long long)count0, rows};
+    return traj_fwd_large_run(prm, cell, terms, theta, mass, t_grid, v0, q0, pv0, v_t, q_t, pv_t, ws, flags, stream, &so);
+}
+
+static int traj_adj_large_run(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                              const float* theta, const float* mass, const float* t_grid,
+                              const float* v_t, const float* q_t, const float* pv_t,
+                              const float* g_v, const float* g_q, const float* g_pv,
+                              float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                              float* ws, int32_t* flags, void* stream, const StaleOpt* so) {
     int rc = validate_large(prm, cell, terms);
     if (rc) return rc;
     MDG_CHECK_ARG(mass && t_grid && v_t && q_t && adj_v0 && adj_q0 && ws && flags, "traj_adj_large: null buffer");
     MDG_CHECK_ARG(prm->ensemble == 1 || (pv_t && adj_pv0), "traj_adj_large: NHC needs pv_t/adj_pv0");
+    MdgTrajParams pstale;
+    if (so) {
+        rc = validate_stale(prm, terms, so);
+        if (rc) return rc;
+        pstale = *prm; pstale.block = -1; prm = &pstale;
+    }
     LG_SETUP();
+    LG_STALE_SETUP();
     a.v_t = const_cast<float*>(v_t); a.q_t = const_cast<float*>(q_t); a.pv_t = const_cast<float*>(pv_t);
     a.g_v = g_v; a.g_q = g_q; a.g_pv = g_pv;
     const int C = prm->n_chains, T = prm->n_frames, KT = terms->n_theta_total;
@@ -2085,18 +2356,36 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         else if (diag) hipLaunchKernelGGL((large_adj_force<true, -1>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);    \
         else hipLaunchKernelGGL((large_adj_force<false, -1>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);            \
     } while (0)
+#define LG_STALE_ADJ(SECOND_, REBUILD_)                                                                             \
+    do {                                                                                                            \
+        const dim3 gF(nbF, Rg);                                                                                     \
+        a.st_rebuild = (REBUILD_) ? 1 : 0;                                                                          \
+        if (diag) hipLaunchKernelGGL((large_adj_force<true, -1, true>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);  \
+        else hipLaunchKernelGGL((large_adj_force<false, -1, true>), gF, dim3(64 * wpb), tile_lds, sg, a, SECOND_);      \
+    } while (0)
     LG_GROUPS_BEGIN();
     for (int i = T - 1; i >= 1; --i) {
         a.step = i;
         for (int g = 0; g < G; ++g) {
             LG_GROUP(g);
             LG_PREP_LAUNCH(2);                                                      // finish interval i + 1, bin frame i
+            if (so) {
+                // an interval makes three calls (sovlers.py:258-266): the dL/dt evaluation at y_i (its result is not used,
+                // but it advances the counter and may rebuild), the first augmented evaluation at the same positions, the
+                // midpoint evaluation -- running counts c0, c0 + 1, c0 + 2
+                const long long c0 = 3ll * (T - 1 - i);
+                LG_STALE_ADJ(0, stale_due(so, c0) || stale_due(so, c0 + 1));
+                LG_PREP_LAUNCH(3);
+                LG_STALE_ADJ(1, stale_due(so, c0 + 2));
+                continue;
+            }
             LG_ADJ_FORCE(0);
             LG_PREP_LAUNCH(3);                                                      // midpoint state, bin it
             LG_ADJ_FORCE(1);
         }
     }
 #undef LG_ADJ_FORCE
+#undef LG_STALE_ADJ
     a.step = 0;
     for (int g = 0; g < G; ++g) {
         LG_GROUP(g);
@@ -2115,4 +2404,25 @@ extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell,
         MDG_HIP(hipMemcpyAsync(adj_theta, a.gth, sizeof(float) * (size_t)R * KT, hipMemcpyDeviceToDevice, st));
     MDG_CHECK_LAUNCH("traj_adj_large");
     return MDG_OK;
+}
+
+extern "C" int mdg_traj_adj_large(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                  const float* theta, const float* mass, const float* t_grid,
+                                  const float* v_t, const float* q_t, const float* pv_t,
+                                  const float* g_v, const float* g_q, const float* g_pv,
+                                  float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                  float* ws, int32_t* flags, void* stream) {
+    return traj_adj_large_run(prm, cell, terms, theta, mass, t_grid, v_t, q_t, pv_t, g_v, g_q, g_pv, adj_v0, adj_q0, adj_pv0,
+                              adj_theta, ws, flags, stream, nullptr);
+}
+
+extern "C" int mdg_traj_adj_large_stale(const MdgTrajParams* prm, const MdgCell* cell, const MdgTerms* terms,
+                                        const float* theta, const float* mass, const float* t_grid,
+                                        const float* v_t, const float* q_t, const float* pv_t,
+                                        const float* g_v, const float* g_q, const float* g_pv,
+                                        float* adj_v0, float* adj_q0, float* adj_pv0, float* adj_theta,
+                                        float* ws, int32_t* flags, int freq, int64_t count0, uint32_t* rows, void* stream) {
+    const StaleOpt so{freq, (long long)count0, rows};
+    return traj_adj_large_run(prm, cell, terms, theta, mass, t_grid, v_t, q_t, pv_t, g_v, g_q, g_pv, adj_v0, adj_q0, adj_pv0,
+                              adj_theta, ws, flags, stream, &so);
 }

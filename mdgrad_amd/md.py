@@ -235,11 +235,16 @@ class _EOM(torch.nn.Module):
             # stale neighbour lists (md.py:200-204): the one-workgroup-per-replica kernels keep the lists of the last rebuild
             # and follow the reference's call counter (mdg_traj_*_small_stale); built-in pair forms, N <= FUSED_MAX_ATOMS, and
             # only from a call count at which the reference rebuilds too or with the lists of an earlier fused pass at hand
-            if (freq < 1 or mods is None or not self.adjoint or N > FUSED_MAX_ATOMS or self.fused_large
-                    or getattr(self, "fused_stale", True) is False):
+            # (round 6: beyond FUSED_MAX_ATOMS, or with fused_large = True, the launch-per-evaluation kernels with stale rows,
+            #  mdg_traj_*_large_stale)
+            stale_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
+            if (freq < 1 or mods is None or not self.adjoint or getattr(self, "fused_stale", True) is False
+                    or N > (min(FUSED_MAX_ATOMS_LARGE, 32768) if stale_large else FUSED_MAX_ATOMS)):
                 return None
             code = getattr(self, "_stale_code", None)
-            if self.update_count % freq != 0 and (code is None or tuple(code.shape[:2]) != (getattr(self.system, "n_replicas", 1), N)):
+            shape = ((getattr(self.system, "n_replicas", 1) * N * 257,) if stale_large
+                     else (getattr(self.system, "n_replicas", 1), N, N))
+            if self.update_count % freq != 0 and (code is None or tuple(code.shape) != shape):
                 return None                 # (between two rebuilds without the lists of this geometry: the generic path)
         table_large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if (mods is None and self.adjoint and self.fused_table
@@ -259,8 +264,6 @@ class _EOM(torch.nn.Module):
             return None
         large = N > FUSED_MAX_ATOMS if self.fused_large is None else bool(self.fused_large)
         if large and N > FUSED_MAX_ATOMS_LARGE:
-            return None
-        if freq != 1 and large:
             return None
         plist = list(self.parameters())
         offs, pos = {}, 0
@@ -292,18 +295,20 @@ class _EOM(torch.nn.Module):
                          else None)
         return spec
 
-    def stale_lists(self, n_rep, n_atoms, device):
+    def stale_lists(self, n_rep, n_atoms, device, large=False):
         """Persistent neighbour-list buffer of the stale-list kernels ([R][N][N] uint16 words: pair set + image flags of
-        every term as of the last rebuild) -- the fused counterpart of the reference's nbr_list / offsets attributes."""
+        every term as of the last rebuild; `large`: the rows of mdg_traj_*_large_stale, [R][N][256] uint32 entries + counts) --
+        the fused counterpart of the reference's nbr_list / offsets attributes."""
         code = getattr(self, "_stale_code", None)
-        if code is None or code.shape != (n_rep, n_atoms, n_atoms) or code.device != device:
+        shape = (n_rep * n_atoms * 257,) if large else (n_rep, n_atoms, n_atoms)
+        if code is None or tuple(code.shape) != shape or code.device != device:
             if code is not None or self.update_count % int(self.topology_update_freq) != 0:
                 raise RuntimeError("mdgrad_amd: the fused stale-list kernels have no lists for this launch (%s) while the call "
                                    "counter (%d, topology_update_freq %d) is between two rebuilds; set integrator.fused_stale = "
                                    "False" % ("another launch geometry holds them" if code is not None else
                                               "a generic force / odeint call on this integrator dropped them",
                                               self.update_count, int(self.topology_update_freq)))
-            code = self._stale_code = torch.zeros(n_rep, n_atoms, n_atoms, dtype=torch.int16, device=device)
+            code = self._stale_code = torch.zeros(*shape, dtype=torch.int32 if large else torch.int16, device=device)
         return code
 
 

@@ -483,10 +483,24 @@ class FusedTrajFn(torch.autograd.Function):
         elif spec.large:
             ws = torch.empty(int(lib.mdg_traj_large_workspace(R, N, T, spec.n_theta_total)), device=dev)
             flags = torch.zeros(8, dtype=torch.int32, device=dev)
-            check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
-                                         ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
-                                         ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
-                  "mdg_traj_fwd_large")
+            if getattr(spec, "stale_freq", 0):
+                # topology_update_freq > 1 beyond one workgroup per replica (round 6): stale rows, the host loop of the library
+                # decides per call whether it rebuilds (md.py:200-204); 2 (T - 1) calls
+                integ = spec._integrator
+                assert int(lib.mdg_traj_large_stale_words(R, N)) == R * N * 257
+                rows = integ.stale_lists(R, N, dev, large=True)
+                check(lib.mdg_traj_fwd_large_stale(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                                   ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t), ptr(q_t),
+                                                   ptr(pv_t), ptr(ws), ptr(flags), int(spec.stale_freq), int(integ.update_count),
+                                                   ptr(rows), stream_ptr(dev)), "mdg_traj_fwd_large_stale")
+                integ.update_count += 2 * (T - 1)
+                integ._stale_fused_dirty = True
+                ctx.stale_code = rows
+            else:
+                check(lib.mdg_traj_fwd_large(C.byref(prm), C.byref(spec.cell_struct), C.byref(spec.terms), ptr(thc),
+                                             ptr(spec.mass), ptr(tc), ptr(v0c), ptr(q0c), ptr(pv0c), ptr(v_t),
+                                             ptr(q_t), ptr(pv_t), ptr(ws), ptr(flags), stream_ptr(dev)),
+                      "mdg_traj_fwd_large")
             fl = flags.tolist()                    # one sync per trajectory (neighbour buffer / table range check)
             if fl[0]:
                 raise RuntimeError("mdgrad_amd: an atom has %d neighbours within the cutoff; the fused large-N "
@@ -594,6 +608,21 @@ class FusedTrajFn(torch.autograd.Function):
                                                  C.byref(fuse.struct()), ptr(gr), stream_ptr(dev)),
                       "mdg_traj_adj_small_rdf")
                 return None
+            if spec.large and getattr(spec, "stale_freq", 0):
+                # stale rows; 3 calls per interval (the dL/dt evaluation and two augmented ones, sovlers.py:258-266)
+                integ = spec._integrator
+                if getattr(integ, "_stale_code", None) is None and getattr(ctx, "stale_code", None) is not None:
+                    integ._stale_code = ctx.stale_code      # (a generic call in between dropped them: see the small path below)
+                rows = integ.stale_lists(R, N, dev, large=True)
+                flags = torch.zeros(8, dtype=torch.int32, device=dev)
+                check(lib.mdg_traj_adj_large_stale(C.byref(prm), C.byref(spec.cell_struct), C.byref(terms), ptr(thc),
+                                                   ptr(spec.mass), ptr(tc), ptr(v_t), ptr(q_t), ptr(pv_t), ptr(gv), ptr(gq),
+                                                   ptr(gp), ptr(adj_v), ptr(adj_q), ptr(adj_p), ptr(adj_th), ptr(ws), ptr(flags),
+                                                   int(spec.stale_freq), int(integ.update_count), ptr(rows), stream_ptr(dev)),
+                      "mdg_traj_adj_large_stale")
+                integ.update_count += 3 * (T - 1)
+                integ._stale_fused_dirty = True
+                return flags
             if spec.large:
                 # the stored candidate lists of the forward pass serve the adjoint unless one overflowed there (or, flag
                 # 5 below, a midpoint moved past their skin): block = -1 asks for fresh searches

@@ -216,12 +216,14 @@ def test_fused_traj_and_adjoint_golden(kind):
         close(y.grad, ga[k], 5e-3, 2e-3 * np.abs(ga[k]).max(), k)
 
 
-@pytest.mark.parametrize("path", ["fused", "generic"])
+@pytest.mark.parametrize("path", ["fused", "fused_large", "generic"])
 def test_adjoint_stale_topology_golden(path):
     """topology_update_freq = 3 (torchmd/md.py:200-204: the list is rebuilt at every third right-hand-side call, the
     adjoint's calls included, and is stale in between) against the reference: through the fused stale-list kernels
     (mdg_traj_fwd_small_stale / mdg_traj_adj_small_stale: the call counter lives on the device) and, forced, through the
-    generic path (the reference's Python control flow on the HIP pair ops)."""
+    generic path (the reference's Python control flow on the HIP pair ops); "fused_large" (round 6): the
+    launch-per-evaluation kernels of systems beyond 1 024 atoms with stale rows (mdg_traj_fwd_large_stale /
+    mdg_traj_adj_large_stale: the library's host loop decides per call whether it rebuilds), forced onto this golden."""
     from mdgrad_amd import ops
     from mdgrad_amd.sovlers import odeint_adjoint
     g = load_golden("nhc_adj_freq3")
@@ -230,13 +232,15 @@ def test_adjoint_stale_topology_golden(path):
         integ.fused_stale = False
         assert integ.fused_spec("NH_verlet") is None
     else:
+        if path == "fused_large":
+            integ.fused_large = True
         spec = integ.fused_spec("NH_verlet")
-        assert spec is not None and spec.stale_freq == 3 and not spec.large
+        assert spec is not None and spec.stale_freq == 3 and spec.large == (path == "fused_large")
     y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
     t = torch.Tensor([float(g["dt"]) * i for i in range(12)]).to(DEV)
     v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
     assert integ.update_count == 22, "two right-hand-side calls per step"
-    assert (v_t.grad_fn is not None and type(v_t.grad_fn).__name__.startswith("FusedTrajFn")) == (path == "fused")
+    assert (v_t.grad_fn is not None and type(v_t.grad_fn).__name__.startswith("FusedTrajFn")) == (path != "generic")
     for x, k in zip((v_t, q_t, pv_t), ["v_t", "q_t", "pv_t"]):
         close(x, g[k], 1e-4, 1e-4, k)
     (q_t[::3].pow(2).mean() + v_t[-1].pow(2).mean()).backward()
@@ -268,8 +272,9 @@ def test_generic_call_between_a_fused_stale_forward_and_its_backward():
     assert torch.isfinite(mdl.sigma.grad).all() and float(mdl.sigma.grad.abs().max()) > 0
 
 
-@pytest.mark.parametrize("freq,two_terms", [(3, False), (2, True), (5, False)])
-def test_stale_lists_persist_across_passes_fused_equals_generic(freq, two_terms):
+@pytest.mark.parametrize("freq,two_terms,large", [(3, False, False), (2, True, False), (5, False, False),
+                                                  (3, False, True), (2, True, True), (4, True, True)])
+def test_stale_lists_persist_across_passes_fused_equals_generic(freq, two_terms, large):
     """The call counter and the lists survive from one pass to the next (epochs of Simulations): two forward + adjoint
     passes in a row on ONE integrator, the second starting between two rebuilds, through the fused stale-list kernels and
     through the generic path -- same trajectories and gradients in both passes; also with two pair terms of different
@@ -290,6 +295,9 @@ def test_stale_lists_persist_across_passes_fused_equals_generic(freq, two_terms)
                                 topology_update_freq=freq).to(DEV)
         if path == "generic":
             integ.fused_stale = False
+        elif large:
+            integ.fused_large = True                                     # (the stale rows of mdg_traj_*_large_stale)
+            assert integ.fused_spec("NH_verlet").large
         out = []
         t = torch.Tensor([0.006 * i for i in range(9)]).to(DEV)          # 8 steps: 16 + 24 calls per pass
         y0 = [s.clone() for s in integ.get_inital_states(wrap=True)]
@@ -354,6 +362,44 @@ def test_nve_fused_golden():
     close(mdl.epsilon.grad, g["grad_epsilon"], 2e-3, 1e-4 * abs(float(g["grad_sigma"][0])), "depsilon")
     for y, k in zip(y0, ["grad_v0", "grad_q0"]):
         close(y.grad, g[k], 5e-3, 2e-3 * np.abs(g[k]).max(), k)
+
+
+@pytest.mark.parametrize("large", [False, True])
+def test_nve_stale_lists_fused_vs_oracle(large):
+    """NVE with topology_update_freq = 3 (verlet_update makes the same 2 + 3 calls per step / adjoint interval as the
+    Nose-Hoover update, torchmd/sovlers.py:21-104): the fused stale-list kernels -- one workgroup per replica, and (large) the
+    launch-per-evaluation path of systems beyond 1 024 atoms -- against the oracle with the reference's call counter."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NVE
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("nve_adj")
+    system = mk_system(g["pos"], g["cell"], g["vel"], g["mass"])
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NVE(Stack({"pair": PairPotentials(system, mdl, cutoff=2.5)}), system, topology_update_freq=3).to(DEV)
+    if large:
+        integ.fused_large = True
+    spec = integ.fused_spec("verlet")
+    assert spec is not None and spec.stale_freq == 3 and bool(spec.large) == large
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=True)]
+    t = torch.Tensor([float(g["dt"]) * i for i in range(10)])
+    v_t, q_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="verlet")
+    assert type(v_t.grad_fn).__name__.startswith("FusedTrajFn") and integ.update_count == 18
+    loss = lambda L: L[1][::3].pow(2).mean() + L[0][-1].pow(2).mean()
+    loss((v_t, q_t)).backward()
+    assert integ.update_count == 18 + 27
+    term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(g["cell"]), p=12, q=6, c=1)
+    eom = O.NVEOracle(O.ModelOracle([term]), freq=3)
+    traj = O.odeint_oracle(eom, (T(g["vel"]), T(g["pos"])), t)
+    close(v_t, traj[0], 1e-4, 1e-4, "v_t")
+    close(q_t, traj[1], 1e-4, 1e-5, "q_t")
+    leaves = [x.clone().requires_grad_(True) for x in traj]
+    loss(leaves).backward()
+    lam, gth = O.adjoint_oracle(eom, traj, [x.grad for x in leaves], t)
+    got = torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])
+    close(got, gth, 2e-3, 1e-4 * float(gth.abs().max()), "dtheta")
+    for y, l, k in zip(y0, lam, ["grad_v0", "grad_q0"]):
+        close(y.grad, l, 5e-3, 2e-3 * float(l.abs().max()), k)
 
 
 def test_simulations_two_epochs_golden():

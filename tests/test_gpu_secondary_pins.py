@@ -111,6 +111,76 @@ def test_large_path_timed_geometry_16_steps_with_device_side_rebuilds_vs_oracle(
     _stacked_large_vs_oracle(16, 64, 17, 0.005, scales, (63,), seed=38, tol_q=1e-4, expect_reuse="some")
 
 
+@pytest.mark.parametrize("n_side,R,freq,n_frames", [(11, 2, 3, 8), (7, 1, 4, 7), (16, 1, 5, 5)])
+def test_large_path_stale_lists_vs_oracle(n_side, R, freq, n_frames):
+    """VERDICT r5 next #7 (second half): topology_update_freq > 1 beyond 1 024 atoms on the FUSED launch-per-evaluation path
+    (mdg_traj_fwd_large_stale / mdg_traj_adj_large_stale; torchmd/md.py:200-204: rebuild at every freq-th right-hand-side call,
+    the adjoint's three calls per interval included, frozen pair set + image flags and no cutoff re-test in between) --
+    1 331 atoms x 2 stacked replicas in a binned box, 343 atoms in a box too small to bin (all-atom search), and config #4's
+    4 096 atoms: trajectory, adjoint of the initial state and dL/dtheta of every replica against its own oracle run with the
+    same call counter; then a SECOND pass on the same integrator that starts between two rebuilds (the rows persist)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    base, cell = liquid(n_side, seed=70 + n_side, jitter=0.05)
+    N = len(base)
+    rng = np.random.default_rng(170 + n_side)
+    pos = np.stack([np.mod(base + rng.normal(0, 0.02, base.shape), cell) for _ in range(R)]).astype(np.float32)
+    vel = np.stack([rng.normal(0, 0.9 + 0.3 * r, base.shape) for r in range(R)]).astype(np.float32)
+    mass = np.full(N, 1.008, dtype=np.float32)
+    system = mk_system(base, cell, np.zeros_like(base), mass)        # (replicas ride in the launch's leading dimension)
+    mdl = P.LennardJones(1.0, 1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, cutoff=2.5)}), system, T=1.0, num_chains=3, Q=30.0,
+                            topology_update_freq=freq).to(DEV)
+    integ.fused_large = True
+    spec = integ.fused_spec("NH_verlet")
+    assert spec is not None and spec.large and spec.stale_freq == freq
+    from mdgrad_amd import ops
+    dt = 0.005
+    t = torch.Tensor([dt * i for i in range(n_frames)])
+
+    def loss_one(L):
+        return (L[1][::2].pow(2).sum() / L[1][::2].numel() + L[0][-1].pow(2).sum() / (N * 3) + L[2][-1].sum() * 1e-3)
+
+    eoms = []
+    for r in range(R):
+        term = O.PairTerm("lj", torch.tensor([1.0, 1.0]), 2.5, T(cell), p=12, q=6, c=1)
+        eoms.append(O.NHCOracle(O.ModelOracle([term]), T(mass), 1.0, 30.0, 3, freq=freq))
+    y = [(T(vel[r]), T(pos[r]), torch.zeros(3)) for r in range(R)]
+    v_in, q_in, p_in = T(vel, DEV), T(pos, DEV), torch.zeros(R, 3, device=DEV)
+    for pas in range(2):
+        v0, q0, pv0 = v_in.clone().requires_grad_(True), q_in.clone().requires_grad_(True), p_in.clone().requires_grad_(True)
+        c_before = integ.update_count
+        v_t, q_t, pv_t = ops.FusedTrajFn.apply(v0, q0, pv0, t.to(DEV), spec.flat_params(), spec)
+        assert integ.update_count == c_before + 2 * (n_frames - 1)
+        mdl.zero_grad()
+        sum(loss_one((v_t[r], q_t[r], pv_t[r])) for r in range(R)).backward()
+        assert integ.update_count == c_before + 5 * (n_frames - 1)
+        gth_sum = torch.zeros(2)
+        for r in range(R):
+            eom = eoms[r]
+            assert eom.update_count == c_before
+            traj = O.odeint_oracle(eom, y[r], t)
+            leaves = [x.clone().requires_grad_(True) for x in traj]
+            loss_one(leaves).backward()
+            lam, gth = O.adjoint_oracle(eom, traj, [x.grad for x in leaves], t)
+            gth_sum += gth
+            tag = "pass %d replica %d (N=%d, freq %d)" % (pas, r, N, freq)
+            close(q_t[r], traj[1], 0, 5e-5, "q_t " + tag)
+            close(v_t[r], traj[0], 0, 1e-3, "v_t " + tag)
+            close(pv_t[r], traj[2], 2e-3, 5e-4, "pv_t " + tag)
+            for got, l, nm in zip((v0.grad[r], q0.grad[r], pv0.grad[r]), lam, ("adj v0", "adj q0", "adj pv0")):
+                close(got, l, 5e-3, 1e-3 * float(l.abs().max()) + 1e-9, nm + " " + tag)
+            y[r] = tuple(x[-1].clone() for x in traj)
+        got = torch.stack([mdl.sigma.grad.reshape(()), mdl.epsilon.grad.reshape(())])
+        close(got, gth_sum, 5e-3, 5e-4 * float(gth_sum.abs().max()), "dL/dtheta pass %d (N=%d, freq %d)" % (pas, N, freq))
+        # the next pass continues from the ORACLE's last frame (both sides start from identical inputs)
+        v_in = torch.stack([y[r][0] for r in range(R)]).to(DEV)
+        q_in = torch.stack([y[r][1] for r in range(R)]).to(DEV)
+        p_in = torch.stack([y[r][2] for r in range(R)]).to(DEV)
+
+
 # ------------------------------------------------------------------ stacked SchNet replicas vs the oracle
 def _cg_water(size, R, seed):
     from mdgrad_amd import units
