@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--table-nodes", type=int, default=0, help="mlp108: nodes of the tabulated pair energy (0 = default)")
     ap.add_argument("--bf16", action="store_true", help="gnn*: bf16 MFMA operands in the filter network (both sweeps)")
     ap.add_argument("--bf16-rows", action="store_true", help="gnn*: --bf16 and bf16 mirrors of the gathered node rows (SchNet.node_rows_bf16)")
+    ap.add_argument("--freq", type=int, default=1, help="lj4096: topology_update_freq (> 1: stale lists, mdg_traj_*_large_stale)")
+    ap.add_argument("--generic", action="store_true", help="lj4096 with --freq > 1: the generic path (integrator.fused_stale = False)")
     args = ap.parse_args()
     args.bf16 = args.bf16 or args.bf16_rows
     from mdgrad_amd import potentials as P, units
@@ -112,8 +114,14 @@ def main():
             pos = np.mod(g + rng.uniform(-0.05, 0.05, g.shape) * (L / n), L)
             system = System(Atoms(positions=pos, cell=[L, L, L], numbers=np.ones(len(pos))), device=dev)
             system.set_velocities(rng.normal(0, 1.0, pos.shape))
+            if args.replicas > 1:
+                system = system.replicate(args.replicas)
+                system.set_positions(np.mod(system.get_positions() + rng.normal(0, 0.02, (len(system), 3)), L))
+                system.set_velocities(rng.normal(0, 1.0, (len(system), 3)))
             integ = NoseHooverChain(Stack({"pair": PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=2.5)}),
-                                    system, T=1.0, num_chains=5, Q=50.0).to(dev)
+                                    system, T=1.0, num_chains=5, Q=50.0, topology_update_freq=args.freq).to(dev)
+            if args.generic:
+                integ.fused_stale = False
             obs = rdf(system, nbins=100, r_range=(0.75, 2.5))
             tf, tb = run(integ, system, obs, args.steps, 0.005)
         else:
