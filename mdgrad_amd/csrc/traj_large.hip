@@ -104,6 +104,7 @@ struct LargeArgs {
     uint32_t* st_row;                        // [R][N][LG_CAP]
     int32_t* st_cnt;                         // [R][N]
     int st_rebuild;
+    int st_bin;                              // prep launches: the coming force launch rebuilds -- bin its positions (else: skip)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(LG_PREP) void large_prep(const LargeArgs A) {
         }
     }
     if (PHASE == 4 || nc == 0) return;                      // (all-atom scan: nothing to bin)
+    if (A.st_row && !A.st_bin) return;                      // (stale lists: the coming evaluation runs over the stored rows)
 
     // ---- binning of (px, py, pz)
     __syncthreads();
@@ -2243,16 +2245,19 @@ static int traj_fwd_large_run(const MdgTrajParams* prm, const MdgCell* cell, con
     if (so) {
         for (int g = 0; g < G; ++g) {
             LG_GROUP(g);
-            if (a.ncell) LG_PREP_LAUNCH(0);
+            a.st_bin = stale_due(so, 0);
+            if (a.ncell && a.st_bin) LG_PREP_LAUNCH(0);
             LG_STALE_STEP(0, stale_due(so, 0));
         }
         for (int k = 0; k + 1 < T; ++k) {
             a.step = k;
+            const bool again = k + 2 < T && stale_due(so, 2ll * k + 2) && !stale_due(so, 2ll * k + 1);
             for (int g = 0; g < G; ++g) {
                 LG_GROUP(g);
+                a.st_bin = stale_due(so, 2ll * k + 1) || again;     // (the bins serve both calls at these positions)
                 LG_PREP_LAUNCH(1);
                 LG_STALE_STEP(1, stale_due(so, 2ll * k + 1));
-                if (k + 2 < T && stale_due(so, 2ll * k + 2) && !stale_due(so, 2ll * k + 1)) LG_STALE_STEP(2, true);
+                if (again) LG_STALE_STEP(2, true);
             }
         }
     } else {
@@ -2368,6 +2373,7 @@ static int traj_adj_large_run(const MdgTrajParams* prm, const MdgCell* cell, con
         a.step = i;
         for (int g = 0; g < G; ++g) {
             LG_GROUP(g);
+            if (so) a.st_bin = stale_due(so, 3ll * (T - 1 - i)) || stale_due(so, 3ll * (T - 1 - i) + 1);
             LG_PREP_LAUNCH(2);                                                      // finish interval i + 1, bin frame i
             if (so) {
                 // an interval makes three calls (sovlers.py:258-266): the dL/dt evaluation at y_i (its result is not used,
@@ -2375,6 +2381,7 @@ static int traj_adj_large_run(const MdgTrajParams* prm, const MdgCell* cell, con
                 // midpoint evaluation -- running counts c0, c0 + 1, c0 + 2
                 const long long c0 = 3ll * (T - 1 - i);
                 LG_STALE_ADJ(0, stale_due(so, c0) || stale_due(so, c0 + 1));
+                a.st_bin = stale_due(so, c0 + 2);
                 LG_PREP_LAUNCH(3);
                 LG_STALE_ADJ(1, stale_due(so, c0 + 2));
                 continue;
