@@ -556,6 +556,45 @@ def test_triclinic_cell_fused_vs_oracle():
     close(y0[0].grad, lam[0], 5e-3, 1e-3 * float(lam[0].abs().max()), "adj v0")
 
 
+@pytest.mark.parametrize("large", [False, True])
+def test_triclinic_cell_stale_lists_fused_vs_oracle(large):
+    """topology_update_freq = 3 in a triclinic cell (64 atoms, ModifiedMorse, cutoff above half the shortest cell height: the
+    frozen image flags matter): the fused stale-list kernels -- one workgroup per replica / the launch-per-evaluation path with
+    its all-atom search -- against the oracle with the reference's call counter."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    g = load_golden("nbr_tric64")
+    rng = np.random.default_rng(3)
+    vel = rng.normal(0, 0.3, g["xyz"].shape).astype(np.float32)
+    mass = np.full(64, 2.0, dtype=np.float32)
+    system = mk_system(g["xyz"], g["cell"], vel, mass)
+    mdl = P.ModifiedMorse(a=1.5, phi=1.0)
+    integ = NoseHooverChain(Stack({"p": PairPotentials(system, mdl, 2.2)}), system, T=0.5, num_chains=2, Q=5.0,
+                            topology_update_freq=3).to(DEV)
+    if large:
+        integ.fused_large = True
+    spec = integ.fused_spec("NH_verlet")
+    assert spec is not None and spec.stale_freq == 3 and bool(spec.large) == large
+    y0 = [s.clone().requires_grad_(True) for s in integ.get_inital_states(wrap=False)]
+    t = torch.Tensor([0.002 * i for i in range(9)])
+    v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t.to(DEV), method="NH_verlet")
+    assert type(v_t.grad_fn).__name__.startswith("FusedTrajFn")
+    (q_t.pow(2).mean() + v_t[-1].pow(2).mean()).backward()
+    assert integ.update_count == 16 + 24
+    term = O.PairTerm("morse", torch.zeros(0), 2.2, T(g["cell"]), a=1.5, phi=1.0)
+    eom = O.NHCOracle(O.ModelOracle([term]), T(mass), 0.5, 5.0, 2, freq=3)
+    traj = O.odeint_oracle(eom, (T(vel), T(g["xyz"]), torch.zeros(2)), t)
+    leaves = [x.clone().requires_grad_(True) for x in traj]
+    (leaves[1].pow(2).mean() + leaves[0][-1].pow(2).mean()).backward()
+    lam, _ = O.adjoint_oracle(eom, traj, [x.grad for x in leaves], t)
+    close(q_t, traj[1], 1e-4, 2e-5, "q_t")
+    close(v_t, traj[0], 1e-3, 1e-4, "v_t")
+    close(y0[1].grad, lam[1], 5e-3, 1e-3 * float(lam[1].abs().max()), "adj q0")
+    close(y0[0].grad, lam[0], 5e-3, 1e-3 * float(lam[0].abs().max()), "adj v0")
+
+
 def test_product_has_no_cpu_path():
     from mdgrad_amd.topology import generate_nbr_list
     with pytest.raises(RuntimeError):
