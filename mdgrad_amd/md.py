@@ -164,7 +164,9 @@ class _EOM(torch.nn.Module):
     #                            trajectory launches (its histogram is then an output of the launch, not a function of q_t in
     #                            the autograd graph: autograd.grad(loss, q_t) / hooks on q_t do not see the RDF term).  Off by
     #                            default: the reference's callers may rely on q_t carrying that term.
-    table_nodes = 1024      # nodes of the u = r^2 grid on [ (table_rmin * cutoff)^2 , cutoff^2 ]
+    table_nodes = 2048      # nodes of the u = r^2 grid on [ (table_rmin * cutoff)^2 , cutoff^2 ] (round 6: 1 024 -> 2 048, the
+    #                         most the wave-per-replica kernels hold in LDS: ELU-module gradients to 6e-4 of the largest entry
+    #                         instead of 1.1e-3, 1 % of the tabulated ring rate)
     table_rmin = 0.2
 
     def update_topology(self, q):                               # md.py:200-204

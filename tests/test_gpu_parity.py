@@ -1009,9 +1009,9 @@ def test_pair_mlp_trajectory_adjoint_golden(mode):
     assert (integ.fused_spec("NH_verlet") is not None) == mode.startswith("table")
     # The table is an approximation of the module: forces to ~1e-7 (trajectories below match to 5e-7), but
     # ELU has a discontinuous second derivative, so phi'' has kinks the cubic table smooths -- the MLP
-    # gradient is first-order accurate in the node spacing: 1e-3 of its largest entry with the default 1 024
-    # nodes, 4e-4 with 4 096 (smooth activations do not have this limit).
-    gtol = {"table": 1.5e-3, "table4096": 6e-4}.get(mode, 2e-4)
+    # gradient is first-order accurate in the node spacing: 6e-4 of its largest entry with the default 2 048
+    # nodes (1.1e-3 with 1 024), 4e-4 with 4 096 (smooth activations do not have this limit).
+    gtol = {"table": 8e-4, "table4096": 6e-4}.get(mode, 2e-4)
     y0 = [s_.clone().requires_grad_(True) for s_ in integ.get_inital_states(wrap=True)]
     t = torch.Tensor([float(g["dt"]) * i for i in range(9)]).to(DEV)
     v_t, q_t, pv_t = odeint_adjoint(integ, tuple(y0), t, method="NH_verlet")
