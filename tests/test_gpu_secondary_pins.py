@@ -181,6 +181,52 @@ def test_large_path_stale_lists_vs_oracle(n_side, R, freq, n_frames):
         p_in = torch.stack([y[r][2] for r in range(R)]).to(DEV)
 
 
+def test_large_path_stale_lists_two_masked_terms_in_a_binned_box_vs_generic():
+    """Stale rows with TERM BITS in a binned box: 1 331 atoms, LJ(2.5) on all pairs + ExcludedVolume(1.9) between the even and the
+    odd atoms (index_tuple), topology_update_freq = 3 -- the rebuild searches the bins at the larger cutoff and records per pair
+    which terms hold it -- two passes on one integrator (the second starts between two rebuilds) against the generic path (the
+    reference's Python control flow with its two separate lists, torchmd/interface.py:228-260)."""
+    from mdgrad_amd import potentials as P
+    from mdgrad_amd.interface import PairPotentials, Stack
+    from mdgrad_amd.md import NoseHooverChain
+    from mdgrad_amd.sovlers import odeint_adjoint
+    base, cell = liquid(11, seed=91, jitter=0.05)
+    N = len(base)
+    rng = np.random.default_rng(191)
+    vel = rng.normal(0, 1.0, base.shape).astype(np.float32)
+    mass = np.full(N, 1.008, dtype=np.float32)
+    res = {}
+    for path in ("fused", "generic"):
+        system = mk_system(base, cell, vel, mass)
+        idx = (list(range(0, N, 2)), list(range(1, N, 2)))
+        terms = {"a": PairPotentials(system, P.LennardJones(1.0, 1.0), cutoff=2.5),
+                 "b": PairPotentials(system, P.ExcludedVolume(1.1, 0.7, 12), cutoff=1.9, index_tuple=idx)}
+        integ = NoseHooverChain(Stack(terms), system, T=1.0, num_chains=3, Q=30.0, topology_update_freq=3).to(DEV)
+        if path == "generic":
+            integ.fused_stale = False
+        else:
+            spec = integ.fused_spec("NH_verlet")
+            assert spec is not None and spec.large and spec.stale_freq == 3
+        t = torch.Tensor([0.005 * i for i in range(6)]).to(DEV)            # 5 steps: 10 + 15 calls per pass
+        y0 = [s_.clone() for s_ in integ.get_inital_states(wrap=True)]
+        out = []
+        for rep in range(2):
+            for p_ in integ.parameters():
+                p_.grad = None
+            ys = [s_.clone().requires_grad_(True) for s_ in y0]
+            v_t, q_t, pv_t = odeint_adjoint(integ, tuple(ys), t, method="NH_verlet")
+            assert (type(v_t.grad_fn).__name__.startswith("FusedTrajFn")) == (path == "fused"), (path, rep)
+            (q_t[::2].pow(2).mean() + v_t[-1].pow(2).mean() + pv_t[-1].sum() * 1e-2).backward()
+            out.append([v_t.detach(), q_t.detach(), pv_t.detach()] + [y.grad for y in ys]
+                       + [torch.cat([p_.grad.reshape(-1) for p_ in integ.parameters()])])
+            y0 = [v_t[-1].detach(), q_t[-1].detach(), pv_t[-1].detach()]
+        assert integ.update_count == 2 * 25
+        res[path] = out
+    for rep in range(2):
+        for a, b, nm in zip(res["fused"][rep], res["generic"][rep], ("v_t", "q_t", "pv_t", "adj v0", "adj q0", "adj pv0", "dtheta")):
+            close(a, b, 2e-4, 2e-5 * float(b.abs().max()) + 1e-7, "pass %d, fused vs generic: %s" % (rep, nm))
+
+
 # ------------------------------------------------------------------ stacked SchNet replicas vs the oracle
 def _cg_water(size, R, seed):
     from mdgrad_amd import units
