@@ -1178,28 +1178,35 @@ def test_table_gradient_words_hold_a_growing_adjoint():
     pos = np.stack([np.mod(g["pos"] + rng.normal(0, 0.02, g["pos"].shape), g["cell"]) for _ in range(R)]).astype(np.float32)
     vel = np.stack([g["vel"] * 2.0 for _ in range(R)]).astype(np.float32)
     t = torch.Tensor([0.01 * i for i in range(nT)]).to(DEV)
+    # ONE forward pass (ring kernels), then the adjoint of ITS saved frames on both kernel families: the trajectory is chaotic
+    # (two forward passes that differ in the last bit of a table node end 0.4 sigma apart), the adjoint sweep restarts from a
+    # saved frame at every interval and is comparable
+    spec = integ.fused_spec("verlet")
+    assert spec is not None and getattr(spec, "table", False)
+    spec.block = 64
+    v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
+    out = ops.FusedTrajFn.apply(v0, q0, None, t, spec.flat_params(), spec)
+    loss = out[1][:, -1].pow(2).mean()                        # the loss sees the LAST frame only: lam(0) is pure amplification
+    incoming = float((2.0 * out[1][:, -1].detach() / out[1][:, -1].numel()).abs().max())
     res = []
     for block in (64, 256):
-        spec = integ.fused_spec("verlet")
-        assert spec is not None and getattr(spec, "table", False)
         spec.block = block
         for p_ in params:
             p_.grad = None
-        v0, q0 = T(vel, DEV).requires_grad_(True), T(pos, DEV).requires_grad_(True)
-        out = ops.FusedTrajFn.apply(v0, q0, None, t, spec.flat_params(), spec)
-        out[1][:, -1].pow(2).mean().backward()               # the loss sees the LAST frame only: lam(0) is pure amplification
+        v0.grad = q0.grad = None
+        loss.backward(retain_graph=True)
         gth = torch.cat([(p_.grad if p_.grad is not None else torch.zeros_like(p_)).reshape(-1) for p_ in params])
-        incoming = float((2.0 * out[1][:, -1].detach() / out[1][:, -1].numel()).abs().max())
-        res.append((q0.grad.clone(), gth.clone(), incoming, out[1][:, -1].detach().clone()))
-    growth = float(res[0][0].abs().max()) / res[0][2]
+        res.append((q0.grad.clone(), gth.clone()))
+    growth = float(res[0][0].abs().max()) / incoming
     assert growth >= 2.0 ** 9, "the trajectory is not chaotic enough to exercise the range (growth %.1f)" % growth
     assert torch.isfinite(res[0][1]).all() and torch.isfinite(res[1][1]).all()
-    # (forward trajectories of the two kernel families agree to rounding amplified by the same growth; the gradients are
-    #  compared where both started from the same saved frames: relative to the largest entry)
     scale = float(res[1][1].abs().max())
     assert scale > 0
     err = float((res[0][1] - res[1][1]).abs().max()) / scale
-    assert err < 5e-2, "module gradients: ring vs workgroup kernels differ by %.3g of the largest entry (growth %.0f)" % (err, growth)
+    errq = float((res[0][0] - res[1][0]).abs().max()) / float(res[1][0].abs().max())
+    # (measured 1e-6 / 5e-7 at a growth of 1.1e4)
+    assert err < 1e-4 and errq < 1e-4, ("ring vs workgroup adjoint on the same frames: module gradients differ by %.3g, adjoint of "
+                                         "q0 by %.3g of the largest entry (growth %.0f)" % (err, errq, growth))
 
 
 def test_fit_rdf_pairmlp_example_learns():
