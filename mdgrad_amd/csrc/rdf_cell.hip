@@ -14,6 +14,9 @@
 //                           table (MDG_PAIR_TABLE, built by the caller from dL/d raw): dL/dx_i = sum_j phi'(d) D/d,
 //                           every pair from both ends, no atomics
 // Pair geometry as everywhere: reference minimum image (topology.py:59-64) and un-contracted d^2.
+// Round 6: FINE z-bins (make_grid): up to 32 bins along z, a window of +- zw of them per stencil column -- still one contiguous
+// range per column, 31 % fewer candidates at 4 096 atoms: forward 1.40 -> 1.25 ms, backward 2.46 -> 2.13 ms for 704 frames
+// (tools/diag_rdf_zfine.py; counts identical, gradient to 2e-7).
 //
 // Round 5: COLUMN TILES in LDS (rdf_cell_fwd_tile_kernel / rdf_cell_bwd_tile_kernel).  The row sweeps above read every
 // candidate of every atom from L2 (27 bins x ~19 atoms x 16 B per atom: 24 GB per backward call at 704 frames x 4 096 atoms --
@@ -30,13 +33,37 @@ constexpr int RC_MAX_CELLS = 4096;           // bins per frame (LDS scan)
 constexpr int RC_THREADS = 1024;
 constexpr int RC_MAX_ATOMS = RC_THREADS * 32;
 
-struct CellGrid { int nb[3]; int ncell; };
+constexpr int RC_MAX_NBZ = 32;               // bins along z at most (FINE z-bins, round 6)
+struct CellGrid { int nb[3]; int ncell; int zw; };      // zw: half-width of the stencil along z, in bins
 
+// MDG_RDF_CELL_ZFINE=0: z-bins of at least the cutoff like x and y (A/B measurements; round 5's grid)
+bool zfine_enabled() {
+    const char* e = getenv("MDG_RDF_CELL_ZFINE");
+    return !(e && e[0] == '0');
+}
+
+// x, y: bins of at least the cutoff, a 3 x 3 stencil of bin COLUMNS.  z (round 6): as many bins as fit (<= RC_MAX_NBZ, <=
+// RC_MAX_CELLS in all) and a stencil of +- zw of them, zw bins >= the cutoff: a column's window bz - zw .. bz + zw is still ONE
+// contiguous range of the sorted array (plus one through the face), so the bookkeeping per row is unchanged, but the window is
+// (2 zw + 1) / nbz of the column instead of three bins of >= the cutoff -- 5.8 instead of 8.5 length units at 4 096 atoms,
+// cutoff 2.6: 31 % fewer candidates for the same pairs.
 CellGrid make_grid(const MdgCell& c, float cutoff) {
     CellGrid g;
     for (int d = 0; d < 3; ++d) {
         int n = (int)floorf(c.h[4 * d] / cutoff);
         g.nb[d] = n > 16 ? 16 : n;                       // (bins wider than the cutoff are fine; 16^3 = RC_MAX_CELLS)
+    }
+    g.zw = 1;
+    if (zfine_enabled() && g.nb[0] >= 3 && g.nb[1] >= 3 && g.nb[2] >= 3) {
+        int nz = RC_MAX_CELLS / (g.nb[0] * g.nb[1]);
+        if (nz > RC_MAX_NBZ) nz = RC_MAX_NBZ;
+        if (nz > g.nb[2]) {
+            const double bin = (double)c.h[8] / nz;
+            int zw = (int)ceil((double)cutoff / bin);
+            if (zw * bin < (double)cutoff * (1.0 + 1e-6)) ++zw;      // (a window that is the cutoff to the last bit: one more)
+            // (the window and its part through the face must not overlap, and it has to pay: narrower than three coarse bins)
+            if (2 * zw + 1 <= nz && (2 * zw + 1) * bin < 3.0 * (double)c.h[8] / g.nb[2]) { g.nb[2] = nz; g.zw = zw; }
+        }
     }
     g.ncell = g.nb[0] * g.nb[1] * g.nb[2];
     return g;
@@ -136,17 +163,19 @@ __device__ __forceinline__ void row_candidates(const float4* __restrict__ sp, co
     const int bx = bin_coord_c(pi.x, cell.inv[0], g.nb[0]);
     const int by = bin_coord_c(pi.y, cell.inv[4], g.nb[1]);
     const int bz = bin_coord_c(pi.z, cell.inv[8], g.nb[2]);
-    const int nbz = g.nb[2];
-    const int wrapped = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);         // the z bin reached through the face
+    const int nbz = g.nb[2], zw = g.zw;
+    // the z bins reached through a face: [wlo, whi] (none: wlo < 0) -- above the window's bins when it leaves through z = 0
+    const int wlo = bz - zw < 0 ? nbz + bz - zw : (bz + zw > nbz - 1 ? 0 : -1);
+    const int whi = bz - zw < 0 ? nbz - 1 : bz + zw - nbz;
     int col[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c)
         col[c] = (wrap_bin(bx + c / 3 - 1, g.nb[0]) * g.nb[1] + wrap_bin(by + c % 3 - 1, g.nb[1])) * nbz;
 #pragma unroll 1
     for (int part = 0; part < 2; ++part) {
-        const bool on = valid && (part == 0 || wrapped >= 0);                 // (rows without an atom / a face: empty ranges)
+        const bool on = valid && (part == 0 || wlo >= 0);                     // (rows without an atom / a face: empty ranges)
         if (part == 1 && !__any(on)) break;
-        const int zlo = part ? max(wrapped, 0) : max(bz - 1, 0), zhi = part ? max(wrapped, 0) : min(bz + 1, nbz - 1);
+        const int zlo = part ? max(wlo, 0) : max(bz - zw, 0), zhi = part ? max(whi, 0) : min(bz + zw, nbz - 1);
         int a0[9], a1[9];
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
@@ -157,7 +186,7 @@ __device__ __forceinline__ void row_candidates(const float4* __restrict__ sp, co
         for (int c = 0; c < 9; ++c) {
             a0[c] += s;
             bool use = on;
-            if (HALF) use = use && (c == 4 ? (part == 0 || wrapped > bz) : col[c] > col[4]);
+            if (HALF) use = use && (c == 4 ? (part == 0 || wlo > bz) : col[c] > col[4]);
             if (!use) a1[c] = 0;
         }
         float4 P[4], Q[4];
@@ -249,7 +278,7 @@ __global__ __launch_bounds__(256) void rdf_cell_bwd_kernel(const float4* __restr
 
 // ---------------------------------------------------------------------------------------------
 // column tiles (see the header): the staged neighbourhood of one (bx, by) column of one frame
-constexpr int RC_MAX_NB = 16;                // bins per dimension (RC_MAX_CELLS = 16^3)
+constexpr int RC_MAX_NB = RC_MAX_NBZ;         // bins along z at most (x, y: 16; RC_MAX_CELLS in all)
 constexpr int RC_TILE_MAX = 4096;            // staged atoms at most (64 KB of float4)
 
 struct TileMeta {
@@ -309,20 +338,21 @@ __device__ __forceinline__ void tile_stage(const float4* __restrict__ sp, const 
 template <bool HALF, class Fn>
 __device__ __forceinline__ void tile_row_candidates(const float4* tile, const TileMeta& M, const MdgCell& cell, const CellGrid& g,
                                                     const float4 pi, int slot_i, bool valid, int s, Fn&& fn) {
-    const int nbz = g.nb[2];
+    const int nbz = g.nb[2], zw = g.zw;
     const int bz = bin_coord_c(pi.z, cell.inv[8], nbz);
-    const int wrapped = bz == 0 ? nbz - 1 : (bz == nbz - 1 ? 0 : -1);
+    const int wlo = bz - zw < 0 ? nbz + bz - zw : (bz + zw > nbz - 1 ? 0 : -1);      // (see row_candidates)
+    const int whi = bz - zw < 0 ? nbz - 1 : bz + zw - nbz;
 #pragma unroll 1
     for (int part = 0; part < 2; ++part) {
-        const bool on = valid && (part == 0 || wrapped >= 0);
+        const bool on = valid && (part == 0 || wlo >= 0);
         if (part == 1 && !__any(on)) break;
-        const int zlo = part ? max(wrapped, 0) : max(bz - 1, 0), zhi = part ? max(wrapped, 0) : min(bz + 1, nbz - 1);
+        const int zlo = part ? max(wlo, 0) : max(bz - zw, 0), zhi = part ? max(whi, 0) : min(bz + zw, nbz - 1);
 #pragma unroll 1
         for (int c = 0; c < 9; ++c) {
             int a0 = M.zst[c][zlo], a1 = M.zst[c][zhi + 1];
             if (HALF && part == 0 && c == 4) a0 = slot_i + 1;
             bool use = on;
-            if (HALF) use = use && (c == 4 ? (part == 0 || wrapped > bz) : ((M.above >> c) & 1u) != 0u);
+            if (HALF) use = use && (c == 4 ? (part == 0 || wlo > bz) : ((M.above >> c) & 1u) != 0u);
             if (!use) a1 = 0;
             for (int a = a0 + s; a < a1; a += 16) fn(tile[a]);
         }
