@@ -228,7 +228,14 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     tri = _lib.make_cell(torch.tensor([[16.9, 0, 0], [3.0, 16.9, 0], [0, 0, 16.9]]))
     assert lib.mdg_rdf_cell_supported(4096, ctypes.byref(tri), 2.62) == 0                # orthorhombic cells only
     nb = int(16.9 // 2.62)
-    assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(box), 2.62) == 5 * 11 * 4096 + 11 * (nb ** 3 + 1)
+    # (round 6: fine z-bins -- as many as fit, at most 32 and 4 096 cells in all; MDG_RDF_CELL_ZFINE=0: bins of >= the cutoff)
+    nbz = min(32, 4096 // (nb * nb))
+    assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(box), 2.62) == 5 * 11 * 4096 + 11 * (nb * nb * nbz + 1)
+    os.environ["MDG_RDF_CELL_ZFINE"] = "0"
+    try:
+        assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(box), 2.62) == 5 * 11 * 4096 + 11 * (nb ** 3 + 1)
+    finally:
+        del os.environ["MDG_RDF_CELL_ZFINE"]
     assert lib.mdg_rdf_cell_scratch(11, 4096, ctypes.byref(tri), 2.62) == -1
     assert lib.mdg_rdf_fwd_cell(None, 11, 4096, ctypes.byref(box), 2.62, None, 0.0175, -1632.0, 100, None, None, None) == -1
     assert b"rdf_fwd_cell" in lib.mdg_last_error()
