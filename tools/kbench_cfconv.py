@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--bf16", action="store_true")
     ap.add_argument("--rows16", action="store_true", help="--bf16 with bf16 mirrors of the gathered node rows (mdg_cfconv_*_rows16)")
+    ap.add_argument("--cold", action="store_true", help="each timed launch after a 1 GiB fill (L2 and the 256 MB Infinity Cache hold "
+                    "none of its operands): what a sweep costs inside a pass, between kernels that touch other data")
     args = ap.parse_args()
     args.bf16 = args.bf16 or args.rows16
     from mdgrad_amd import ops, units, _lib
@@ -86,15 +88,28 @@ def main():
             ("cfconv_fwd STASHED primal+tangent", lambda: ops.cfconv_fwd_stashed(fn, st_s, st_sd, None, h, hd, topo), 0),
             ("cfconv_fwd STASHED tangent (no hd)", lambda: ops.cfconv_fwd_stashed(fn, st_s, st_sd, None, h, None, topo), 0),
         ]
+    junk = torch.empty(1 << 28, device=dev) if args.cold else None
     for name, fnc, mfma in cases:
         fnc()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.reps):
-            fnc()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.reps
+        if args.cold:
+            tot = 0.0
+            for _ in range(args.reps):
+                junk.fill_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fnc()
+                e1.record()
+                torch.cuda.synchronize()
+                tot += e0.elapsed_time(e1)
+            ms = tot / args.reps
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fnc()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.reps
         extra = ""
         if mfma and not args.bf16:
             tf = mfma * 2048.0 / (ms * 1e-3) / 1e12
