@@ -248,6 +248,37 @@ def test_host_side_of_the_cell_sweep_rdf_and_the_large_path_workspace():
     assert huge < 64 * 16384 * 2000, "beyond the cap the lists are not kept (every evaluation searches)"
 
 
+def test_host_side_of_the_stale_list_entry_points_of_the_large_path():
+    """mdg_traj_*_large_stale without a GPU: the size of the persistent row buffer and the refusals that happen before any
+    launch (frequency, counter, missing rows, a tabulated pair model)."""
+    from mdgrad_amd import _lib, ops
+    lib = _lib.load()
+    assert lib.mdg_traj_large_stale_words(2, 100) == 2 * 100 * 257 and lib.mdg_traj_large_stale_words(0, 5) == -1
+    prm, cell = _lib.MdgTrajParams(), _lib.make_cell([16.9] * 3)
+    prm.n_rep, prm.n_atoms, prm.n_frames, prm.n_chains, prm.ensemble = 1, 4096, 5, 3, 0
+    lj = ops.make_terms([ops.make_term(dict(kind=0,      # MDG_PAIR_LJ
+                                             p=12, q=6, c=1.0), 2.5, 0, 2, None)], 2)
+    fake = ctypes.c_void_p(0x1000)                       # (never dereferenced: every call below is refused during validation)
+    B = ctypes.byref
+
+    def fwd(terms, freq, count0, rows):
+        return lib.mdg_traj_fwd_large_stale(B(prm), B(cell), B(terms), fake, fake, fake, fake, fake, fake, fake, fake, fake, fake,
+                                            fake, freq, count0, rows, None)
+
+    def adj(terms, freq, count0, rows):
+        return lib.mdg_traj_adj_large_stale(B(prm), B(cell), B(terms), fake, fake, fake, fake, fake, fake, fake, fake, fake, fake,
+                                            fake, fake, fake, fake, fake, freq, count0, rows, None)
+
+    for call in (fwd, adj):
+        assert call(lj, 0, 0, fake) == -1 and b"frequency" in lib.mdg_last_error()
+        assert call(lj, 3, -1, fake) == -1 and b"counter" in lib.mdg_last_error()
+        assert call(lj, 3, 0, None) == -1 and b"list buffer" in lib.mdg_last_error()
+    tab = ops.make_terms([ops.make_term(dict(kind=ops.MDG_PAIR_TABLE, p=64, a=0.25, phi=0.1, c=1.0), 2.5, 0, 128, None)], 128)
+    assert fwd(tab, 3, 0, fake) == -1 and b"tabulated" in lib.mdg_last_error()
+    prm.n_atoms = 40000
+    assert fwd(lj, 3, 0, fake) == -1                       # (beyond the large path's 32 768 atoms)
+
+
 def test_host_side_of_the_row_chain_and_the_nh_half_step_scratch():
     """mdg_row_chain / mdg_nhv_scratch_floats without a GPU: struct layout, argument validation (every refusal happens before
     a launch), the empty call, and the size of the cross-workgroup scratch (partials of 1 024-element chunks, a ticket per
